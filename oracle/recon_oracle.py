@@ -1,0 +1,264 @@
+"""CPU ORACLE for the RECON graph-context aggregation hot path.  TEST INFRASTRUCTURE ONLY.
+
+This module restates, in plain torch-on-CPU tensor algebra, what the reference computes on the
+path named by BASELINE.json:north_star.  It is the CHECKER: only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import it.  Nothing under
+`recon_amd/` imports it, and the product path has no CPU fallback.
+
+Parity status: PINNED.  The reference has no golden vectors of its own for this path
+(SURVEY.md section 4), so the oracle is pinned against outputs of the reference itself, run
+in the build container by `tests/golden/gen_golden.py` and committed as `tests/golden/*.npz`;
+`tests/test_oracle_golden.py` checks every function below against them (fp32: 1e-5 abs,
+fp64: 1e-12).
+
+All `file:line` citations are relative to the reference tree (ansonb/RECON).
+Floating point throughout; works for float32 and float64 inputs.
+"""
+import itertools
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# =============================================================================== GAT side
+def spmm_rowsum(edge, edge_w, N):
+    """out[r,:] = sum over edges e with edge[0,e]==r of edge_w[e,:]   (GAT/layers.py:54-64).
+
+    The reference builds a hybrid COO [N,N,out] tensor and sums over dim 1; the column index
+    never enters the result and duplicate (row, col) pairs are summed.
+    """
+    out = torch.zeros(N, edge_w.shape[1], dtype=edge_w.dtype)
+    out.index_add_(0, edge[0], edge_w)
+    return out
+
+
+def spmm_rowsum_backward(edge, grad_out):
+    """grad_edge_w = grad_out[edge[0]]   (GAT/layers.py:67-79)."""
+    return grad_out[edge[0]]
+
+
+def spmm_rowsum_aten_sequence(edge, edge_w, N):
+    """Same result through the op sequence the reference itself issues (sparse_coo_tensor ->
+    torch.sparse.sum(dim=1) -> to_dense, GAT/layers.py:56-64).  Used for the timed CPU baseline
+    so that its cost profile (coalesce + sort + copies) is representative of the reference."""
+    a = torch.sparse_coo_tensor(edge, edge_w, torch.Size([N, N, edge_w.shape[1]]))
+    return torch.sparse.sum(a, dim=1).to_dense()
+
+
+def _cat_edges(edge, edge_embed, edge_list_nhop, edge_embed_nhop):
+    # GAT/layers.py:124-127 : n-hop edges are appended when present; an absent n-hop arrives
+    # as a float tensor of shape [0] (GAT/models.py:57,81).
+    if edge_list_nhop is not None and edge_list_nhop.shape[0] > 0:
+        edge = torch.cat((edge, edge_list_nhop), dim=1)
+        edge_embed = torch.cat((edge_embed, edge_embed_nhop), dim=0)
+    return edge, edge_embed
+
+
+def gat_layer_forward(x, edge, edge_embed, edge_list_nhop, edge_embed_nhop, a, a_2, alpha, concat,
+                      mask=None, aten_sequence=False, return_intermediates=False):
+    """SpGraphAttentionLayer.forward   (GAT/layers.py:111-178).
+
+    m_e = a . [x[dst_e]; x[src_e]; r_e]          (:129-137)
+    w_e = exp(-leakyrelu_alpha(a_2 . m_e))       (:143-146)   no max subtraction
+    Z_i = sum_{e: dst_e = i} w_e ; Z_i == 0 -> 1e-12            (:150-152)
+    w_e <- dropout(w_e)  (AFTER the row sum; `mask` holds the 0 / 1/(1-p) factors)   (:158)
+    h_i = (sum_e w_e m_e) / Z_i                  (:161-169)
+    out = elu(h) if concat else h                (:173-178)
+    """
+    N = x.shape[0]
+    edge, edge_embed = _cat_edges(edge, edge_embed, edge_list_nhop, edge_embed_nhop)
+    dst, src = edge[0], edge[1]
+    edge_h = torch.cat((x[dst], x[src], edge_embed), dim=1)          # [E, 2F+R]
+    m = edge_h @ a.t()                                                # [E, D]
+    sigma = (m @ a_2.t()).squeeze(1)                                  # [E]
+    w = torch.exp(-F.leaky_relu(sigma, alpha))
+    rowsum = spmm_rowsum_aten_sequence if aten_sequence else spmm_rowsum
+    Z = rowsum(edge, w.unsqueeze(1), N)
+    Z = torch.where(Z == 0.0, torch.full_like(Z, 1e-12), Z)
+    wk = w if mask is None else w * mask.to(w.dtype)
+    U = rowsum(edge, wk.unsqueeze(1) * m, N)
+    h = U / Z
+    out = F.elu(h) if concat else h
+    if return_intermediates:
+        return out, dict(m=m, sigma=sigma, w=w, Z=Z.squeeze(1), U=U, h=h, edge=edge, edge_embed=edge_embed)
+    return out
+
+
+def gat_layer_backward(x, edge, edge_embed, edge_list_nhop, edge_embed_nhop, a, a_2, alpha, concat,
+                       grad_out, mask=None):
+    """Closed-form gradients of gat_layer_forward (what autograd derives
+    from GAT/layers.py:111-178 together with the custom backward at :67-79).
+
+    Returns dict with g_x, g_edge_embed (rows of the concatenated 1-hop + n-hop list), g_a, g_a_2
+    and the per-edge / per-node intermediates the HIP kernels are checked against stage by stage.
+    """
+    N, Fdim = x.shape
+    out, im = gat_layer_forward(x, edge, edge_embed, edge_list_nhop, edge_embed_nhop, a, a_2, alpha,
+                                concat, mask=mask, return_intermediates=True)
+    edge, ee = im["edge"], im["edge_embed"]
+    dst, src = edge[0], edge[1]
+    m, sigma, w, Z, h = im["m"], im["sigma"], im["w"], im["Z"], im["h"]
+    k = torch.ones_like(w) if mask is None else mask.to(w.dtype)
+    g_h = grad_out * torch.where(h > 0, torch.ones_like(h), torch.exp(h)) if concat else grad_out
+    gU = g_h / Z[:, None]
+    gZ = -(g_h * h).sum(1) / Z
+    t = (gU[dst] * m).sum(1)
+    gw = k * t + gZ[dst]
+    gsig = -gw * w * torch.where(sigma > 0, torch.ones_like(sigma), torch.full_like(sigma, alpha))
+    gm = (k * w)[:, None] * gU[dst] + gsig[:, None] * a_2[0][None, :]
+    g_a2 = (gsig[:, None] * m).sum(0, keepdim=True)
+    gP_dst = torch.zeros(N, m.shape[1], dtype=m.dtype).index_add_(0, dst, gm)
+    gP_src = torch.zeros(N, m.shape[1], dtype=m.dtype).index_add_(0, src, gm)
+    A_dst, A_src, A_rel = a[:, :Fdim], a[:, Fdim:2 * Fdim], a[:, 2 * Fdim:]
+    g_x = gP_dst @ A_dst + gP_src @ A_src
+    g_ee = gm @ A_rel
+    g_a = torch.cat((gP_dst.t() @ x, gP_src.t() @ x, gm.t() @ ee), dim=1)
+    return dict(out=out, g_x=g_x, g_edge_embed=g_ee, g_a=g_a, g_a_2=g_a2, gm=gm, gP_dst=gP_dst,
+                gP_src=gP_src, sigma=sigma, w=w, Z=Z, m=m)
+
+
+def spgat_forward(x, relation_embed, edge_list, edge_type, edge_embed, edge_list_nhop, edge_type_nhop,
+                  head_a, head_a2, W, out_a, out_a2, alpha, masks=None, aten_sequence=False):
+    """SpGAT.forward in eval mode / dropout 0   (GAT/models.py:47-88).
+
+    head_a / head_a2: lists of per-head parameters (attention_i.a, attention_i.a_2).
+    Returns (x_out [N, H*D], out_relation_1 [n_rel, H*D]).
+    """
+    has_nhop = edge_type_nhop is not None and edge_type_nhop.shape[0] > 0
+    ee_nhop = (relation_embed[edge_type_nhop[:, 0]] + relation_embed[edge_type_nhop[:, 1]]) if has_nhop else None
+    nhop = edge_list_nhop if has_nhop else None
+    heads = [gat_layer_forward(x, edge_list, edge_embed, nhop, ee_nhop, a, a2, alpha, True,
+                               mask=None if masks is None else masks[i], aten_sequence=aten_sequence)
+             for i, (a, a2) in enumerate(zip(head_a, head_a2))]
+    xc = torch.cat(heads, dim=1)                                       # :71-72
+    out_rel = relation_embed @ W                                       # :77
+    ee = out_rel[edge_type]                                            # :79
+    ee_nhop = (out_rel[edge_type_nhop[:, 0]] + out_rel[edge_type_nhop[:, 1]]) if has_nhop else None
+    y = F.elu(gat_layer_forward(xc, edge_list, ee, nhop, ee_nhop, out_a, out_a2, alpha, False,
+                                aten_sequence=aten_sequence))          # :86-87
+    return y, out_rel
+
+
+# =============================================================================== GP-GNN side
+def make_start_embedding(n, d):
+    """utils/embedding_utils.py:170-182.  Channel c = ordered pair (i, j), i != j, row-major;
+    ones in node i's first half-slot and node j's second half-slot.  Shape [n(n-1), 2dn, 1]."""
+    C, S = n * (n - 1), 2 * d * n
+    v = np.zeros((C, S, 1), dtype=np.float64)
+    for c, (i, j) in enumerate((i, j) for i in range(n) for j in range(n) if i != j):
+        v[c, 2 * d * i: 2 * d * i + d, 0] = 1.0
+        v[c, 2 * d * j + d: 2 * d * (j + 1), 0] = 1.0
+    return v
+
+
+def get_head_indices(n, d, bs=50):
+    """utils/embedding_utils.py:184-192 -> int64 [bs, C, 2d]: the 2d state slots of node i of pair (i, j)."""
+    rows = [list(range(2 * d * i, 2 * d * (i + 1))) for i in range(n) for j in range(n) if i != j]
+    return np.tile(np.asarray(rows, dtype=np.int64)[None], (bs, 1, 1))
+
+
+def get_tail_indices(n, d, bs=50):
+    """utils/embedding_utils.py:194-202 -> the 2d state slots of node j of pair (i, j)."""
+    rows = [list(range(2 * d * j, 2 * d * (j + 1))) for i in range(n) for j in range(n) if i != j]
+    return np.tile(np.asarray(rows, dtype=np.int64)[None], (bs, 1, 1))
+
+
+def make_start_entity_embeddings(entity_embeddings, entity_pos_indices, embedding_dim, template, max_num_nodes=9):
+    """utils/context_utils.py:387-426.  h0[b, c=(i,j)]: node i's first half-slot <- embedding of the
+    pair's first entity, node j's second half-slot <- embedding of its second entity, zero elsewhere.
+    (The reference pre-fills with the most frequent entity and masks with the template at the end;
+    the result is this scatter.)"""
+    n, d = max_num_nodes, embedding_dim
+    B, C = entity_pos_indices.shape[:2]
+    out = torch.zeros(B, C, 2 * d * n, 1, dtype=entity_embeddings.dtype)
+    for c, (i, j) in enumerate((i, j) for i in range(n) for j in range(n) if i != j):
+        out[:, c, 2 * d * i: 2 * d * i + d, 0] = entity_embeddings[entity_pos_indices[:, c, 0]]
+        out[:, c, 2 * d * j + d: 2 * d * (j + 1), 0] = entity_embeddings[entity_pos_indices[:, c, 1]]
+    return out * template
+
+
+def build_block_adjacency(T, identity, n):
+    """models/models.py:240-259 (copies :450-469, :660-679, :898-917).
+
+    T: [B, n(n-1), (2d)^2] per-ordered-pair transition matrices (already through the non-linearity),
+    identity: [2d, 2d].  Returns A [B, S, S] with A[b, i*2d+r, j*2d+c] = T[b, e(i,j)].view(2d,2d)[r, c]
+    for i != j and identity[r, c] on the diagonal blocks.
+    """
+    B = T.shape[0]
+    dd = identity.shape[0]
+    blocks = torch.empty(B, n, n, dd, dd, dtype=T.dtype)
+    e = 0
+    for i in range(n):
+        for j in range(n):
+            if i == j:
+                blocks[:, i, j] = identity
+            else:
+                blocks[:, i, j] = T[:, e].reshape(B, dd, dd)
+                e += 1
+    return blocks.permute(0, 1, 3, 2, 4).reshape(B, n * dd, n * dd)
+
+
+def propagate(adj_list, h0, nonlinearity, head_indices, tail_indices):
+    """models/models.py:260-274 (copies :470-485, :680-694, :918-932).
+
+    adj_list: L tensors [B, S, S]; h0: [C, S, 1] (shared, GPGNN) or [B, C, S, 1] (per batch, RECON*);
+    per hop h <- nonlinearity(A_l h); relation_l = gather(h, heads) * gather(h, tails);
+    returns cat(relation_1..L, -1): [B, C, 2d*L].  head/tail_indices: [C, 2d] (or [B, C, 2d]).
+    """
+    B = adj_list[0].shape[0]
+    h = h0
+    rels = []
+    hi = head_indices if head_indices.dim() == 3 else head_indices[None].expand(B, -1, -1)
+    ti = tail_indices if tail_indices.dim() == 3 else tail_indices[None].expand(B, -1, -1)
+    for A in adj_list:
+        h = torch.matmul(A[:, None], h)                     # [B, C, S, 1]
+        if nonlinearity != "linear":
+            h = getattr(F, nonlinearity)(h) if nonlinearity != "tanh" else torch.tanh(h)
+        flat = h.reshape(B, h.shape[1], h.shape[2])
+        rels.append(torch.gather(flat, 2, hi) * torch.gather(flat, 2, ti))
+    return torch.cat(rels, dim=-1)
+
+
+def graph_convolution(x, adj, weight, bias=None):
+    """GraphConvolution.forward   (models/layers.py:57-63): relu(adj @ (x @ W) + b).
+    Accepts [n, in] / [n, n] (reference form) or batched [B, n, in] / [B, n, n]."""
+    out = torch.matmul(adj, torch.matmul(x, weight))
+    if bias is not None:
+        out = out + bias
+    return F.relu(out)
+
+
+def build_adjecent_matrix(n, size=72):
+    """utils/build_adjecent_matrix.py:6-17: line graph over ordered pairs of n entities, padded to
+    72x72; A[x, y] = 1 if x[0]==y[1] or x[1]==y[0] or x==y; used rows divided by their sum."""
+    A = np.zeros((size, size), dtype=np.float32)
+    V = list(itertools.permutations(range(n), 2))
+    for i, x in enumerate(V):
+        for j, y in enumerate(V):
+            A[i, j] = 1.0 if (x[0] == y[1] or x[1] == y[0] or i == j) else 0.0
+        s = A[i].sum()
+        if s != 0:
+            A[i] /= s
+    return A
+
+
+# =============================================================================== synthetic workloads
+def synthetic_batched_graph(B, n, e, F_, R, seed=0, n_rel=0):
+    """SURVEY.md 8(d) synthetic generator: disjoint union of B graphs, n nodes / e edges each,
+    dst/src uniform within a graph (duplicates and self loops allowed).  Returns CPU tensors."""
+    g = torch.Generator().manual_seed(seed)
+    base = (torch.arange(B) * n).repeat_interleave(e)
+    dst = torch.randint(0, n, (B * e,), generator=g) + base
+    src = torch.randint(0, n, (B * e,), generator=g) + base
+    edge = torch.stack([dst, src])
+    x = torch.randn(B * n, F_, generator=g)
+    edge_embed = torch.randn(B * e, R, generator=g)
+    return x, edge, edge_embed
+
+
+def xavier_normal(shape, gain, generator):
+    """nn.init.xavier_normal_ as used at GAT/layers.py:102-105 (std = gain*sqrt(2/(fan_in+fan_out)))."""
+    fan_out, fan_in = shape
+    std = gain * (2.0 / (fan_in + fan_out)) ** 0.5
+    return torch.randn(shape, generator=generator) * std

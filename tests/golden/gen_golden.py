@@ -1,0 +1,357 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE (CPU).
+
+This is the only file in the repo that imports /root/reference.  It runs in the
+build container only (the reference never travels to the GPU box); its outputs
+(*.npz: inputs, parameters, expected outputs, expected gradients) are committed.
+
+Reference entry points executed (unmodified, imported from where they lie):
+  GAT/layers.py:51-84    SpecialSpmmFunctionFinal / SpecialSpmmFinal
+  GAT/layers.py:87-181   SpGraphAttentionLayer
+  GAT/models.py:11-88    SpGAT (heads + out_att)
+  models/models.py:85-277  GPGNN.forward (untied branch :238-277 = block adjacency
+                           + 3-hop propagation + head*tail gather)
+  models/layers.py:35-68 GraphConvolution
+  utils/build_adjecent_matrix.py:6-22
+  utils/embedding_utils.py:170-202  make_start_embedding / get_head_indices / get_tail_indices
+  utils/context_utils.py:387-426    make_start_entity_embeddings
+
+Shims (live in a temp dir, never in the repo): a directory with `RECON ->
+/root/reference` (models/models.py:6 imports `RECON.parsing...`), a stub `nltk`
+and `tqdm` package, and the removed numpy aliases np.float / np.long.
+
+Usage:  python tests/golden/gen_golden.py          (rewrites tests/golden/*.npz)
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------- shims
+def _install_shims():
+    shim = tempfile.mkdtemp(prefix="recon_shim_")
+    os.symlink(REF, os.path.join(shim, "RECON"))
+    nltk = types.ModuleType("nltk")
+    nltk.word_tokenize = lambda s: s.split()
+    nltk.sent_tokenize = lambda s: [s]
+
+    class _RP:  # RegexpParser stub
+        def __init__(self, *a, **k):
+            pass
+
+        def parse(self, x):
+            return x
+    nltk.RegexpParser = _RP
+    tok = types.ModuleType("nltk.tokenize")
+    tok.word_tokenize = nltk.word_tokenize
+    tok.sent_tokenize = nltk.sent_tokenize
+    nltk.tokenize = tok
+    sys.modules["nltk"] = nltk
+    sys.modules["nltk.tokenize"] = tok
+    if "tqdm" not in sys.modules:
+        try:
+            import tqdm  # noqa: F401
+        except Exception:
+            tq = types.ModuleType("tqdm")
+            tq.tqdm = lambda x, *a, **k: x
+            sys.modules["tqdm"] = tq
+    if not hasattr(np, "float"):
+        np.float = float
+    if not hasattr(np, "long"):
+        np.long = np.int64
+    sys.path.insert(0, shim)
+    return shim
+
+
+def hashed_uniform(shape, salt, lo=-1.0, hi=1.0):
+    """Exactly reproducible pseudo-random floats (integer hash, no libm)."""
+    n = int(np.prod(shape))
+    i = np.arange(n, dtype=np.uint64) + np.uint64(salt) * np.uint64(0x9E3779B1)
+    i = (i * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+    i ^= i >> np.uint64(15)
+    i = (i * np.uint64(2246822519)) & np.uint64(0xFFFFFFFF)
+    i ^= i >> np.uint64(13)
+    u = (i >> np.uint64(8)).astype(np.float64) / float(1 << 24)   # 24-bit mantissa: exact in fp32
+    return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %-28s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+# --------------------------------------------------------------------------- GAT cases
+def gat_case(name, gat_layers, N, F, R, D, edge, nhop=None, concat=True, dtype=torch.float32,
+             train_p=0.0, alpha=0.2, seed=0):
+    g = torch.Generator().manual_seed(seed + 100)
+    E1 = edge.shape[1]
+    x = torch.randn(N, F, generator=g, dtype=dtype)
+    ee = torch.randn(E1, R, generator=g, dtype=dtype)
+    if nhop is not None:
+        E2 = nhop.shape[1]
+        ee2 = torch.randn(E2, R, generator=g, dtype=dtype)
+    else:
+        E2 = 0
+        nhop_t = torch.tensor([])
+        ee2 = torch.tensor([])
+    torch.manual_seed(seed)
+    layer = gat_layers.SpGraphAttentionLayer(N, F, D, R, dropout=train_p, alpha=alpha, concat=concat)
+    if dtype == torch.float64:
+        layer = layer.double()
+    G = torch.randn(N, D, generator=g, dtype=dtype)
+    x.requires_grad_(True)
+    ee.requires_grad_(True)
+    if nhop is not None:
+        ee2.requires_grad_(True)
+    mask = np.ones(E1 + E2, dtype=np.float32)
+    if train_p > 0:
+        layer.train()
+        torch.manual_seed(seed + 7)
+        m = torch.nn.Dropout(train_p)(torch.ones(E1 + E2, dtype=dtype))
+        mask = t2n(m).astype(np.float32)
+        torch.manual_seed(seed + 7)     # same stream state as the mask draw above
+    else:
+        layer.eval()
+    out = layer(x, edge, ee, nhop if nhop is not None else nhop_t, ee2)
+    (out * G).sum().backward()
+    arrays = dict(x=t2n(x), edge=t2n(edge), edge_embed=t2n(ee), a=t2n(layer.a), a_2=t2n(layer.a_2),
+                  G=t2n(G), out=t2n(out), g_x=t2n(x.grad), g_edge_embed=t2n(ee.grad),
+                  g_a=t2n(layer.a.grad), g_a_2=t2n(layer.a_2.grad), mask=mask,
+                  alpha=np.float64(alpha), concat=np.int32(concat), train_p=np.float32(train_p))
+    if nhop is not None:
+        arrays.update(edge_nhop=t2n(nhop), edge_embed_nhop=t2n(ee2), g_edge_embed_nhop=t2n(ee2.grad))
+    save(name, **arrays)
+
+
+def batched_edges(B, n, e, seed=0):
+    """SURVEY appendix synthetic generator (disjoint union of B graphs)."""
+    g = torch.Generator().manual_seed(seed)
+    base = (torch.arange(B) * n).repeat_interleave(e)
+    dst = torch.randint(0, n, (B * e,), generator=g) + base
+    src = torch.randint(0, n, (B * e,), generator=g) + base
+    return torch.stack([dst, src])
+
+
+def gen_gat():
+    sys.path.insert(0, os.path.join(REF, "GAT"))
+    import layers as gat_layers
+    import models as gat_models
+    assert gat_layers.__file__.startswith(REF)
+
+    # GAT-1: cfg-1 shape (BASELINE.json configs[0])
+    gat_case("gat1_cfg1", gat_layers, 256, 50, 50, 50, batched_edges(32, 8, 56))
+    # GAT-2: duplicates, isolated nodes (9, 10, 11 never a destination), unsorted, self loops; odd dims
+    g = torch.Generator().manual_seed(5)
+    dst = torch.randint(0, 9, (40,), generator=g)
+    src = torch.randint(0, 12, (40,), generator=g)
+    dst[3], src[3] = dst[2], src[2]          # exact duplicate edge
+    dst[10], src[10] = 4, 4                  # self loop
+    e2 = torch.stack([dst, src])
+    gat_case("gat2_dups", gat_layers, 12, 6, 5, 7, e2)
+    # GAT-3: n-hop edges present
+    g = torch.Generator().manual_seed(6)
+    e1 = torch.randint(0, 20, (2, 30), generator=g)
+    eh = torch.randint(0, 20, (2, 20), generator=g)
+    gat_case("gat3_nhop", gat_layers, 20, 8, 8, 12, e1, nhop=eh)
+    # GAT-4: concat=False (last layer form)
+    gat_case("gat4_noconcat", gat_layers, 20, 8, 8, 12, e1, nhop=eh, concat=False)
+    # GAT-5: train mode with dropout p=0.3 (mask recorded)
+    gat_case("gat5_train", gat_layers, 20, 8, 8, 12, e1, nhop=eh, train_p=0.3)
+    # GAT-6: fp64 twin of GAT-2
+    gat_case("gat6_dups_f64", gat_layers, 12, 6, 5, 7, e2, dtype=torch.float64)
+    # GAT-7: D=200 / F=R=200 slice of cfg 2 (8 graphs), vector-width-4 kernel path
+    gat_case("gat7_cfg2_slice", gat_layers, 128, 200, 200, 200, batched_edges(8, 16, 64, seed=3))
+
+    # SPMM-1
+    g = torch.Generator().manual_seed(11)
+    edge = torch.randint(0, 15, (2, 50), generator=g)
+    for tag, od in (("o1", 1), ("oD", 9)):
+        w = torch.randn(50, od, generator=g, requires_grad=True)
+        G = torch.randn(15, od, generator=g)
+        out = gat_layers.SpecialSpmmFinal()(edge, w, 15, 50, od)
+        (out * G).sum().backward()
+        save("spmm1_" + tag, edge=t2n(edge), edge_w=t2n(w), G=t2n(G), out=t2n(out), g_edge_w=t2n(w.grad),
+             N=np.int32(15))
+
+    # SpGAT-1/2: 2 heads + out_att, with / without n-hop
+    for name, with_nhop in (("spgat1_nhop", True), ("spgat2_1hop", False)):
+        N, nfeat, nhid, rdim, nheads, nrel = 40, 12, 8, 12, 2, 6
+        g = torch.Generator().manual_seed(21)
+        x = torch.randn(N, nfeat, generator=g, requires_grad=True)
+        rel = torch.randn(nrel, rdim, generator=g, requires_grad=True)
+        edge = torch.randint(0, N, (2, 90), generator=g)
+        etype = torch.randint(0, nrel, (90,), generator=g)
+        if with_nhop:
+            nhop = torch.randint(0, N, (2, 35), generator=g)
+            ntype = torch.randint(0, nrel, (35, 2), generator=g)
+        else:
+            nhop = torch.tensor([])
+            ntype = torch.tensor([])
+        torch.manual_seed(3)
+        m = gat_models.SpGAT(N, nfeat, nhid, rdim, dropout=0.0, alpha=0.2, nheads=nheads)
+        m.eval()
+        ee = rel[etype]
+        out, out_rel = m(None, x, rel, edge, etype, ee, nhop, ntype)
+        G = torch.randn(out.shape, generator=g)
+        G2 = torch.randn(out_rel.shape, generator=g)
+        ((out * G).sum() + (out_rel * G2).sum()).backward()
+        arrays = dict(x=t2n(x), rel=t2n(rel), edge=t2n(edge), edge_type=t2n(etype), G=t2n(G), G2=t2n(G2),
+                      out=t2n(out), out_rel=t2n(out_rel), g_x=t2n(x.grad), g_rel=t2n(rel.grad),
+                      nheads=np.int32(nheads), nhid=np.int32(nhid), alpha=np.float64(0.2))
+        if with_nhop:
+            arrays.update(edge_nhop=t2n(nhop), edge_type_nhop=t2n(ntype))
+        for k, v in m.state_dict().items():
+            arrays["p." + k] = t2n(v)
+        for k, v in m.named_parameters():
+            arrays["g." + k] = t2n(v.grad)
+        save(name, **arrays)
+
+
+# --------------------------------------------------------------------------- GP-GNN cases
+class _Fixed(torch.nn.Module):
+    """Stands in for representation_to_adj[i]: returns a fixed, differentiable tensor."""
+
+    def __init__(self, value):
+        super().__init__()
+        self.value = torch.nn.Parameter(value)
+
+    def forward(self, _):
+        return self.value
+
+
+def gpgnn_case(name, ref_models, n, d, per_batch_h0, L=3, B=50, salt=1):
+    p = {"max_num_nodes": n, "embedding_dim": d, "layer_number": L, "projection_style": "untie",
+         "non-linear1": "relu", "non-linear": "tanh", "dropout1": 0.0, "position_emb": 3, "units1": 4,
+         "rnn1_layers": 1, "bidirectional": 1, "batch_size": B}
+    C, S, dd = n * (n - 1), 2 * d * n, (2 * d) ** 2
+    emb = np.zeros((5, 3), dtype=np.float32)
+    torch.manual_seed(0)
+    m = ref_models.GPGNN(p, emb, max_sent_len=3, n_out=4)
+    m.eval()
+    Ts = [torch.from_numpy(hashed_uniform((B, C, dd), salt * 10 + i, -0.6, 1.0)) for i in range(L)]
+    for i in range(L):
+        m.representation_to_adj[i] = _Fixed(Ts[i].clone())
+    ident = torch.from_numpy(np.eye(2 * d, dtype=np.float32) + hashed_uniform((2 * d, 2 * d), salt * 10 + 7, -0.1, 0.1))
+    m.identity_transformation.data.copy_(ident)
+    h0_shared = m.start_embedding.data.clone()                  # [C, S, 1]
+    if per_batch_h0:                                            # RECON form, models/models.py:470
+        h0 = torch.from_numpy(hashed_uniform((B, C, S, 1), salt * 10 + 8)) * h0_shared
+        m.start_embedding = torch.nn.Parameter(h0.clone(), requires_grad=True)
+    captured = {}
+    m.linear3.register_forward_pre_hook(lambda mod, inp: captured.__setitem__("rel", inp[0]))
+    real_matmul = torch.matmul
+    adjs = []
+
+    def spy_matmul(a, b):
+        adjs.append(a)
+        return real_matmul(a, b)
+    torch.matmul = spy_matmul
+    try:
+        sent = torch.zeros(B, 3, dtype=torch.long)
+        mark = torch.zeros(B, C, 3, dtype=torch.long)
+        m(sent, mark, None)
+    finally:
+        torch.matmul = real_matmul
+    rel = captured["rel"]                                        # [B, C, 2d*L]
+    G = torch.from_numpy(hashed_uniform(tuple(rel.shape), salt * 10 + 9))
+    (rel * G).sum().backward()
+    arrays = dict(n=np.int32(n), d=np.int32(d), L=np.int32(L), B=np.int32(B), salt=np.int32(salt),
+                  identity=t2n(ident), out=t2n(rel), G_salt=np.int32(salt * 10 + 9),
+                  g_identity=t2n(m.identity_transformation.grad),
+                  head_indices=t2n(m.head_indices[0]), tail_indices=t2n(m.tail_indices[0]),
+                  h0_shared=t2n(h0_shared),
+                  # one graph of each hop's block adjacency pins P1 without storing B*S*S floats
+                  adj_b0=np.stack([t2n(a[0, 0]) for a in adjs]), adj_bl=np.stack([t2n(a[B - 1, 0]) for a in adjs]),
+                  g_T_b0=np.stack([t2n(m.representation_to_adj[i].value.grad[0]) for i in range(L)]),
+                  g_T_sum=np.stack([t2n(m.representation_to_adj[i].value.grad.sum(0)) for i in range(L)]))
+    if per_batch_h0:
+        arrays["g_h0_b0"] = t2n(m.start_embedding.grad[0])
+        arrays["g_h0_sum"] = t2n(m.start_embedding.grad.sum(0))
+    if B * C * dd * L * 4 < 600_000:                              # small case: store T and full grads too
+        arrays["T"] = np.stack([t2n(t) for t in Ts])
+        arrays["g_T"] = np.stack([t2n(m.representation_to_adj[i].value.grad) for i in range(L)])
+        if per_batch_h0:
+            arrays["h0"] = t2n(h0)
+            arrays["g_h0"] = t2n(m.start_embedding.grad)
+    save(name, **arrays)
+
+
+def gen_gpgnn():
+    cwd = os.getcwd()
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    try:
+        from models import models as ref_models
+        from models import layers as ref_layers
+        from utils import build_adjecent_matrix as bam
+        from utils import embedding_utils, context_utils
+    finally:
+        os.chdir(cwd)
+    assert ref_models.__file__.startswith(REF)
+
+    # PROP-1/2: block adjacency + 3-hop propagation, shared h0 (GPGNN form) and per-batch h0 (RECON form)
+    gpgnn_case("prop_n4d2_shared", ref_models, 4, 2, per_batch_h0=False, salt=1)
+    gpgnn_case("prop_n4d2_perbatch", ref_models, 4, 2, per_batch_h0=True, salt=2)
+    gpgnn_case("prop_n9d8_shared", ref_models, 9, 8, per_batch_h0=False, salt=3)      # model_params.json sizes
+    gpgnn_case("prop_n9d8_perbatch", ref_models, 9, 8, per_batch_h0=True, salt=4)
+
+    # PROP-3: make_start_entity_embeddings + the index builders
+    n, d, B, U = 9, 8, 3, 11
+    C = n * (n - 1)
+    tmpl = torch.from_numpy(embedding_utils.make_start_embedding(n, d)).float()
+    ent = torch.from_numpy(hashed_uniform((U, d), 77))
+    rs = np.random.RandomState(4)
+    pos = torch.from_numpy(rs.randint(0, U, size=(B, C, 2)).astype(np.int64))
+    vec = context_utils.make_start_entity_embeddings(ent, pos, None, d, 5, tmpl, max_num_nodes=n)
+    save("prop3_start_entity", n=np.int32(n), d=np.int32(d), entity_embeddings=t2n(ent), pos=t2n(pos),
+         template=t2n(tmpl), out=t2n(vec), max_occ=np.int32(5),
+         head_indices=np.array(embedding_utils.get_head_indices(n, d, bs=2)[0], dtype=np.int64),
+         tail_indices=np.array(embedding_utils.get_tail_indices(n, d, bs=2)[0], dtype=np.int64))
+    for nn_, dd_ in ((3, 2), (5, 3)):
+        save("start_embedding_n%dd%d" % (nn_, dd_),
+             start=embedding_utils.make_start_embedding(nn_, dd_).astype(np.float32),
+             head=np.array([list(r) for r in embedding_utils.get_head_indices(nn_, dd_, bs=1)[0]], dtype=np.int64),
+             tail=np.array([list(r) for r in embedding_utils.get_tail_indices(nn_, dd_, bs=1)[0]], dtype=np.int64))
+
+    # ADJ-1: the eight fixed 72x72 line-graph adjacencies
+    save("adj1_linegraph", adj=np.stack([t2n(a) for a in bam.adjecent_matrix]))
+
+    # GCN-1: GraphConvolution with build_adjecent_matrix(5), with and without bias
+    for tag, bias in (("bias", True), ("nobias", False)):
+        torch.manual_seed(9)
+        layer = ref_layers.GraphConvolution(10, 6, bias=bias)
+        x = torch.from_numpy(hashed_uniform((72, 10), 31)).requires_grad_(True)
+        adj = bam.build_adjecent_matrix(5)
+        out = layer(x, adj)
+        G = torch.from_numpy(hashed_uniform((72, 6), 32))
+        (out * G).sum().backward()
+        arrays = dict(x=t2n(x), adj=t2n(adj), weight=t2n(layer.weight), G=t2n(G), out=t2n(out),
+                      g_x=t2n(x.grad), g_weight=t2n(layer.weight.grad))
+        if bias:
+            arrays.update(bias=t2n(layer.bias), g_bias=t2n(layer.bias.grad))
+        save("gcn1_" + tag, **arrays)
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("the reference is not mounted here; golden vectors can only be regenerated in the build container")
+    torch.set_num_threads(4)
+    _install_shims()
+    gen_gat()
+    # GAT's `layers` / `models` module names collide with the GP-GNN package names: drop them first
+    for k in ("layers", "models"):
+        sys.modules.pop(k, None)
+    sys.path.remove(os.path.join(REF, "GAT"))
+    gen_gpgnn()

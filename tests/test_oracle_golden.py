@@ -1,0 +1,165 @@
+"""Pins oracle/recon_oracle.py against the golden vectors produced by running the reference
+(tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, hashed_uniform
+from oracle import recon_oracle as O
+
+T = torch.from_numpy
+
+
+def _tol(dtype):
+    return dict(atol=1e-12, rtol=1e-10) if dtype == np.float64 else dict(atol=2e-5, rtol=1e-5)
+
+
+GAT_CASES = ["gat1_cfg1", "gat2_dups", "gat3_nhop", "gat4_noconcat", "gat5_train", "gat6_dups_f64",
+             "gat7_cfg2_slice"]
+
+
+@pytest.mark.parametrize("name", GAT_CASES)
+@pytest.mark.parametrize("aten", [False, True])
+def test_gat_layer_forward_backward(name, aten):
+    g = load_golden(name)
+    x, ee, a, a2 = (T(g[k]).requires_grad_(True) for k in ("x", "edge_embed", "a", "a_2"))
+    edge = T(g["edge"])
+    nhop = T(g["edge_nhop"]) if "edge_nhop" in g else None
+    ee2 = T(g["edge_embed_nhop"]).requires_grad_(True) if nhop is not None else None
+    mask = T(g["mask"]) if float(g["train_p"]) > 0 else None
+    out = O.gat_layer_forward(x, edge, ee, nhop, ee2, a, a2, float(g["alpha"]), bool(g["concat"]),
+                              mask=mask, aten_sequence=aten)
+    tol = _tol(g["x"].dtype)
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], **tol)
+    (out * T(g["G"])).sum().backward()
+    for k, t in (("g_x", x), ("g_edge_embed", ee), ("g_a", a), ("g_a_2", a2)):
+        np.testing.assert_allclose(t.grad.numpy(), g[k], atol=tol["atol"] * 20, rtol=tol["rtol"] * 50)
+    if nhop is not None:
+        np.testing.assert_allclose(ee2.grad.numpy(), g["g_edge_embed_nhop"], atol=tol["atol"] * 20, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", GAT_CASES)
+def test_gat_closed_form_backward(name):
+    """The explicit gradient formulas the HIP backward kernels implement == reference autograd."""
+    g = load_golden(name)
+    edge = T(g["edge"])
+    nhop = T(g["edge_nhop"]) if "edge_nhop" in g else None
+    ee2 = T(g["edge_embed_nhop"]) if nhop is not None else None
+    mask = T(g["mask"]) if float(g["train_p"]) > 0 else None
+    r = O.gat_layer_backward(T(g["x"]), edge, T(g["edge_embed"]), nhop, ee2, T(g["a"]), T(g["a_2"]),
+                             float(g["alpha"]), bool(g["concat"]), T(g["G"]), mask=mask)
+    f64 = g["x"].dtype == np.float64
+    atol = 1e-11 if f64 else 4e-4
+    E1 = g["edge"].shape[1]
+    np.testing.assert_allclose(r["g_x"].numpy(), g["g_x"], atol=atol, rtol=1e-4)
+    np.testing.assert_allclose(r["g_edge_embed"][:E1].numpy(), g["g_edge_embed"], atol=atol, rtol=1e-4)
+    np.testing.assert_allclose(r["g_a"].numpy(), g["g_a"], atol=atol, rtol=1e-4)
+    np.testing.assert_allclose(r["g_a_2"].numpy(), g["g_a_2"], atol=atol, rtol=1e-4)
+    if nhop is not None:
+        np.testing.assert_allclose(r["g_edge_embed"][E1:].numpy(), g["g_edge_embed_nhop"], atol=atol, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["spmm1_o1", "spmm1_oD"])
+def test_spmm(name):
+    g = load_golden(name)
+    edge, w = T(g["edge"]), T(g["edge_w"])
+    for fn in (O.spmm_rowsum, O.spmm_rowsum_aten_sequence):
+        np.testing.assert_allclose(fn(edge, w, int(g["N"])).numpy(), g["out"], atol=1e-6)
+    np.testing.assert_array_equal(O.spmm_rowsum_backward(edge, T(g["G"])).numpy(), g["g_edge_w"])
+
+
+@pytest.mark.parametrize("name", ["spgat1_nhop", "spgat2_1hop"])
+def test_spgat(name):
+    g = load_golden(name)
+    H = int(g["nheads"])
+    leaves = {k: T(g[k]).requires_grad_(True) for k in g if k.startswith("p.")}
+    x, rel = T(g["x"]).requires_grad_(True), T(g["rel"]).requires_grad_(True)
+    has = "edge_nhop" in g
+    y, out_rel = O.spgat_forward(
+        x, rel, T(g["edge"]), T(g["edge_type"]), rel[T(g["edge_type"])],
+        T(g["edge_nhop"]) if has else None, T(g["edge_type_nhop"]) if has else None,
+        [leaves["p.attention_%d.a" % i] for i in range(H)], [leaves["p.attention_%d.a_2" % i] for i in range(H)],
+        leaves["p.W"], leaves["p.out_att.a"], leaves["p.out_att.a_2"], float(g["alpha"]))
+    np.testing.assert_allclose(y.detach().numpy(), g["out"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(out_rel.detach().numpy(), g["out_rel"], atol=2e-5, rtol=1e-5)
+    ((y * T(g["G"])).sum() + (out_rel * T(g["G2"])).sum()).backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["g_x"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(rel.grad.numpy(), g["g_rel"], atol=2e-4, rtol=1e-4)
+    for k, t in leaves.items():
+        np.testing.assert_allclose(t.grad.numpy(), g["g." + k[2:]], atol=2e-4, rtol=1e-4, err_msg=k)
+
+
+def _prop_inputs(g):
+    n, d, L, B, salt = (int(g[k]) for k in ("n", "d", "L", "B", "salt"))
+    C, S, dd = n * (n - 1), 2 * d * n, (2 * d) ** 2
+    Ts = [T(hashed_uniform((B, C, dd), salt * 10 + i, -0.6, 1.0)) for i in range(L)]
+    per_batch = "g_h0_sum" in g
+    h0 = T(g["h0_shared"])
+    if per_batch:
+        h0 = T(hashed_uniform((B, C, S, 1), salt * 10 + 8)) * h0
+    Gr = T(hashed_uniform(g["out"].shape, int(g["G_salt"])))
+    return n, d, L, B, Ts, h0, Gr, per_batch
+
+
+@pytest.mark.parametrize("name", ["prop_n4d2_shared", "prop_n4d2_perbatch", "prop_n9d8_shared", "prop_n9d8_perbatch"])
+def test_block_adjacency_and_propagation(name):
+    g = load_golden(name)
+    n, d, L, B, Ts, h0, Gr, per_batch = _prop_inputs(g)
+    if "T" in g:   # the small cases store T itself: the hash generator must reproduce it exactly
+        np.testing.assert_array_equal(np.stack([t.numpy() for t in Ts]), g["T"])
+    Ts = [t.requires_grad_(True) for t in Ts]
+    ident = T(g["identity"]).requires_grad_(True)
+    h0 = h0.requires_grad_(per_batch)
+    adjs = [O.build_block_adjacency(torch.relu(t), ident, n) for t in Ts]     # models/models.py:244-259
+    for l in range(L):
+        np.testing.assert_array_equal(adjs[l][0].detach().numpy(), g["adj_b0"][l])
+        np.testing.assert_array_equal(adjs[l][B - 1].detach().numpy(), g["adj_bl"][l])
+    out = O.propagate(adjs, h0, "relu", T(g["head_indices"]), T(g["tail_indices"]))
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], atol=1e-5, rtol=1e-5)
+    (out * Gr).sum().backward()
+    np.testing.assert_allclose(ident.grad.numpy(), g["g_identity"], atol=2e-3, rtol=2e-4)
+    for l in range(L):
+        np.testing.assert_allclose(Ts[l].grad[0].numpy(), g["g_T_b0"][l], atol=1e-4, rtol=1e-4)
+        np.testing.assert_allclose(Ts[l].grad.sum(0).numpy(), g["g_T_sum"][l], atol=1e-3, rtol=1e-4)
+    if per_batch:
+        np.testing.assert_allclose(h0.grad[0].numpy(), g["g_h0_b0"], atol=1e-4, rtol=1e-4)
+    np.testing.assert_array_equal(O.get_head_indices(n, d, bs=1)[0], g["head_indices"])
+    np.testing.assert_array_equal(O.get_tail_indices(n, d, bs=1)[0], g["tail_indices"])
+    np.testing.assert_array_equal(O.make_start_embedding(n, d).astype(np.float32), g["h0_shared"])
+
+
+def test_start_entity_embeddings():
+    g = load_golden("prop3_start_entity")
+    out = O.make_start_entity_embeddings(T(g["entity_embeddings"]), T(g["pos"]), int(g["d"]), T(g["template"]),
+                                         max_num_nodes=int(g["n"]))
+    np.testing.assert_array_equal(out.numpy(), g["out"])
+    np.testing.assert_array_equal(O.get_head_indices(9, 8, bs=1)[0], g["head_indices"])
+    np.testing.assert_array_equal(O.get_tail_indices(9, 8, bs=1)[0], g["tail_indices"])
+
+
+@pytest.mark.parametrize("n,d", [(3, 2), (5, 3)])
+def test_start_embedding_and_indices(n, d):
+    g = load_golden("start_embedding_n%dd%d" % (n, d))
+    np.testing.assert_array_equal(O.make_start_embedding(n, d).astype(np.float32), g["start"])
+    np.testing.assert_array_equal(O.get_head_indices(n, d, bs=1)[0], g["head"])
+    np.testing.assert_array_equal(O.get_tail_indices(n, d, bs=1)[0], g["tail"])
+
+
+def test_linegraph_adjacency():
+    g = load_golden("adj1_linegraph")
+    for i, n in enumerate(range(2, 10)):
+        np.testing.assert_array_equal(O.build_adjecent_matrix(n), g["adj"][i])
+
+
+@pytest.mark.parametrize("name", ["gcn1_bias", "gcn1_nobias"])
+def test_graph_convolution(name):
+    g = load_golden(name)
+    x, w = T(g["x"]).requires_grad_(True), T(g["weight"]).requires_grad_(True)
+    b = T(g["bias"]).requires_grad_(True) if "bias" in g else None
+    out = O.graph_convolution(x, T(g["adj"]), w, b)
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], atol=1e-6)
+    (out * T(g["G"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["g_x"], atol=1e-6)
+    np.testing.assert_allclose(w.grad.numpy(), g["g_weight"], atol=1e-5)
+    if b is not None:
+        np.testing.assert_allclose(b.grad.numpy(), g["g_bias"], atol=1e-5)
