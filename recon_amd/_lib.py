@@ -1,0 +1,92 @@
+"""ctypes binding of librecon_hip.so (the C ABI declared in include/recon_hip.h).
+
+The library is built in-tree by `make -C recon_amd/csrc` (or `__graft_entry__.build()`).  There is
+NO fallback: if the shared object is missing or an entry point returns an error, a RuntimeError is
+raised.  The product path never computes on the CPU.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librecon_hip.so")
+
+ERRORS = {0: "ok", -1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failed",
+          -4: "workspace too small"}
+
+c_f32p = C.c_void_p
+c_i32p = C.c_void_p
+c_i64p = C.c_void_p
+
+
+class ReconGraph(C.Structure):
+    _fields_ = [("N", C.c_int32), ("E", C.c_int32),
+                ("rowptr_dst", c_i32p), ("eid", c_i32p), ("src", c_i32p), ("dst", c_i32p),
+                ("rowptr_src", c_i32p), ("slot_by_src", c_i32p)]
+
+
+class GatFwdArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("E", C.c_int32), ("F", C.c_int32), ("R", C.c_int32), ("D", C.c_int32),
+                ("H", C.c_int32), ("concat", C.c_int32), ("alpha", C.c_float),
+                ("x", c_f32p), ("edge_embed", c_f32p), ("a", c_f32p), ("a_2", c_f32p), ("keep", c_f32p),
+                ("P", c_f32p), ("Q", c_f32p), ("sigma", c_f32p), ("Z", c_f32p), ("out", c_f32p),
+                ("ld_out", C.c_int32)]
+
+
+class GatBwdArgs(C.Structure):
+    _fields_ = [("fwd", GatFwdArgs), ("grad_out", c_f32p), ("ld_gout", C.c_int32),
+                ("Gm", c_f32p), ("gP", c_f32p), ("partial", c_f32p),
+                ("g_x", c_f32p), ("g_edge_embed", c_f32p), ("g_a", c_f32p), ("g_a_2", c_f32p)]
+
+
+# every symbol include/recon_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("recon_version", C.c_int, []),
+    ("recon_error_string", C.c_char_p, [C.c_int]),
+    ("recon_graph_workspace_bytes", C.c_size_t, [C.c_int32, C.c_int32]),
+    ("recon_graph_build", C.c_int, [c_i64p, c_i64p, C.POINTER(ReconGraph), C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("recon_spmm_rowsum_fwd", C.c_int, [C.POINTER(ReconGraph), c_f32p, C.c_int32, c_f32p, C.c_void_p]),
+    ("recon_spmm_rowsum_bwd", C.c_int, [c_i64p, C.c_int64, c_f32p, C.c_int32, c_f32p, C.c_void_p]),
+    ("recon_gat_fwd", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatFwdArgs), C.c_void_p]),
+    ("recon_gat_project", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatFwdArgs), C.c_void_p]),
+    ("recon_gat_edge_fwd", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatFwdArgs), C.c_void_p]),
+    ("recon_gat_bwd_partial_floats", C.c_size_t, [C.c_int32] * 6),
+    ("recon_gat_bwd", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatBwdArgs), C.c_void_p]),
+    ("recon_sgemm", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32,
+                              c_f32p, C.c_int32, C.c_void_p]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises RuntimeError if the .so is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "librecon_hip.so not found at %s: build it with `make -C recon_amd/csrc` "
+                "(recon_amd has no CPU fallback)" % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        if h.recon_version() != 1:
+            raise RuntimeError("librecon_hip.so ABI version mismatch")
+        _lib = h
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError("%s failed: %s (%d)" % (what, ERRORS.get(code, "unknown"), code))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,94 @@
+// Internal helpers shared by the HIP translation units of librecon_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "recon_hip.h"
+
+#define RECON_CHECK_LAUNCH()                                   \
+    do {                                                       \
+        if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH; \
+    } while (0)
+
+static inline hipStream_t as_stream(recon_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+namespace recon {
+
+constexpr int kWave = 64;
+
+// ---- DPP cross-lane adds (VALU, no LDS traffic) -------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// Sum over aligned groups of G consecutive lanes (G = 4..64, power of two); every lane of the
+// group receives the total.  Quad and row steps are DPP; the 32- and 64-lane steps go through
+// ds_bpermute (__shfl_xor).  Summation order is fixed => deterministic.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+    static_assert(G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "group width");
+    v += dpp_mov<0xB1>(v);                      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);                      // quad_perm [2,3,0,1]
+    if constexpr (G >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror
+    if constexpr (G >= 16) v += dpp_mov<0x140>(v);  // row_mirror
+    if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<4> { using type = float4; };
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(float (&r)[VEC], const float* p) {
+    if constexpr (VEC == 4) { float4 t = *reinterpret_cast<const float4*>(p); r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
+    else if constexpr (VEC == 2) { float2 t = *reinterpret_cast<const float2*>(p); r[0] = t.x; r[1] = t.y; }
+    else { r[0] = *p; }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&r)[VEC]) {
+    if constexpr (VEC == 4) { *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]); }
+    else if constexpr (VEC == 2) { *reinterpret_cast<float2*>(p) = make_float2(r[0], r[1]); }
+    else { *p = r[0]; }
+}
+
+}  // namespace recon
+
+// ---- generic fp32 MFMA GEMM with strided / gathered / head-major operand addressing -------
+namespace recon {
+
+// element (major i, minor j) of an operand lives at
+//   base + major_off(i) + minor_off(j)
+//   major_off(i) = gather ? gather[i]*S1 : (i % P)*S1 + (i / P)*S2
+//   minor_off(j) = (j % Dseg) + (j / Dseg)*Sseg          (contiguous inside segments of Dseg)
+struct OperandDesc {
+    const float* base;
+    const int32_t* gather;
+    int64_t S1, S2, Sseg;
+    int32_t P, Dseg;
+};
+inline OperandDesc plain_operand(const float* base, int64_t ld) {
+    OperandDesc d; d.base = base; d.gather = nullptr; d.S1 = ld; d.S2 = 0; d.Sseg = 0; d.P = 0x7fffffff; d.Dseg = 0x7fffffff; return d;
+}
+struct OutputDesc {
+    float* base;
+    const int32_t* scatter;   // row index map (permutation) or null
+    int64_t S1, S2, Sseg;
+    int32_t P, Dseg;
+};
+inline OutputDesc plain_output(float* base, int64_t ld) {
+    OutputDesc d; d.base = base; d.scatter = nullptr; d.S1 = ld; d.S2 = 0; d.Sseg = 0; d.P = 0x7fffffff; d.Dseg = 0x7fffffff; return d;
+}
+
+// C[M,N] = A[M,K] * B[K,N].  a_k_minor: A's contiguous index is k (else m); b_k_minor: B's contiguous
+// index is k (else n).  split_k > 1 needs `partial` (split_k*M*N floats) and runs a deterministic
+// second-pass reduction.
+int gemm_f32(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool a_k_minor, const OperandDesc& B,
+             bool b_k_minor, const OutputDesc& C, int32_t split_k, float* partial, hipStream_t stream);
+int gemm_pick_split_k(int32_t M, int32_t N, int32_t K);
+
+}  // namespace recon

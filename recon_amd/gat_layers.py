@@ -1,0 +1,217 @@
+"""Drop-in replacement for the reference module `GAT/layers.py` (and its byte-identical twin
+`GAT_sep_space/layers.py`): same module-level names, same constructor / forward signatures, same
+`state_dict` keys (`a`, `a_2`), but the arithmetic runs in hand-written gfx950 kernels behind the
+C ABI of include/recon_hip.h.
+
+    from recon_amd.gat_layers import SpGraphAttentionLayer, ConvKB      # GAT/models.py:6
+
+Exports (GAT/layers.py): CUDA, ConvKB, SpecialSpmmFunctionFinal, SpecialSpmmFinal,
+SpGraphAttentionLayer.  Extra: `gat_heads(...)`, the fused H-head entry used by recon_amd.models.SpGAT.
+
+No CPU path: tensors must be on an MI355X; a missing librecon_hip.so raises RuntimeError.
+"""
+import ctypes as C
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .graph import prepare_graph, _has_nhop
+
+CUDA = torch.cuda.is_available()          # GAT/layers.py:9
+_DEBUG_NAN = os.environ.get("RECON_DEBUG_NAN", "0") == "1"
+
+
+def _require_gpu_f32(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("recon_amd: expected a GPU tensor (this package has no CPU path)")
+        if t.dtype != torch.float32:
+            raise TypeError("recon_amd: the HIP kernels compute in float32, got %s" % t.dtype)
+
+
+class ConvKB(nn.Module):
+    """Scorer exported by GAT/layers.py:12-48 (not on the hot path; re-exported so that
+    `from layers import SpGraphAttentionLayer, ConvKB` keeps working).  Live path: fc1 -> LeakyReLU ->
+    fc2; conv_layer / fc_layer / dropout exist only for state_dict compatibility."""
+
+    def __init__(self, input_dim, input_seq_len, in_channels, out_channels, drop_prob, alpha_leaky):
+        super().__init__()
+        self.conv_layer = nn.Conv2d(in_channels, out_channels, (1, input_seq_len))
+        self.dropout = nn.Dropout(drop_prob)
+        self.non_linearity = nn.LeakyReLU()
+        self.fc_layer = nn.Linear(input_dim * out_channels, 1)
+        self.fc1 = nn.Linear(input_dim * 3, input_dim)
+        self.nl1 = nn.LeakyReLU()
+        self.fc2 = nn.Linear(input_dim, 1)
+        nn.init.xavier_uniform_(self.fc_layer.weight, gain=1.414)
+        nn.init.xavier_uniform_(self.conv_layer.weight, gain=1.414)
+
+    def forward(self, conv_input):
+        return self.fc2(self.nl1(self.fc1(conv_input)))
+
+
+# ------------------------------------------------------------------------------- G1-G3
+class SpecialSpmmFunctionFinal(torch.autograd.Function):
+    """out[r] = sum_{e: edge[0,e]==r} edge_w[e]   (GAT/layers.py:51-79).  Backward is the row gather
+    grad_out[edge[0]]; no gradient for the indices."""
+
+    @staticmethod
+    def forward(ctx, edge, edge_w, N, E, out_features):
+        _require_gpu_f32(edge_w)
+        L = _lib.lib()
+        g = prepare_graph(edge, None, N)
+        w = edge_w.contiguous().view(g.E, -1)
+        out = torch.empty(N, w.shape[1], dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(L.recon_spmm_rowsum_fwd(C.byref(g.c), w.data_ptr(), w.shape[1], out.data_ptr(),
+                                               _lib.current_stream()), "recon_spmm_rowsum_fwd")
+        ctx.graph = g
+        ctx.N, ctx.outfeat, ctx.E = N, w.shape[1], E
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        grad_values = None
+        if ctx.needs_input_grad[1]:
+            g = ctx.graph
+            L = _lib.lib()
+            go = grad_output.contiguous()
+            grad_values = torch.empty(g.E, ctx.outfeat, dtype=torch.float32, device=go.device)
+            with torch.cuda.device(go.device):
+                _lib.check(L.recon_spmm_rowsum_bwd(g.edge[0].data_ptr(), g.E, go.data_ptr(), ctx.outfeat,
+                                                   grad_values.data_ptr(), _lib.current_stream()),
+                           "recon_spmm_rowsum_bwd")
+        return None, grad_values, None, None, None
+
+
+class SpecialSpmmFinal(nn.Module):
+    def forward(self, edge, edge_w, N, E, out_features):        # GAT/layers.py:82-84
+        return SpecialSpmmFunctionFinal.apply(edge, edge_w, N, E, out_features)
+
+
+# ------------------------------------------------------------------------------- G4 (+ H heads)
+def _fwd_args(graph, x, ee, a, a2, keep, P, Q, sigma, Z, out, alpha, concat):
+    H, D = a2.shape
+    return _lib.GatFwdArgs(graph.N, graph.E, x.shape[1], ee.shape[1], D, H, int(bool(concat)), float(alpha),
+                           x.data_ptr(), ee.data_ptr(), a.data_ptr(), a2.data_ptr(), _lib.ptr(keep),
+                           P.data_ptr(), Q.data_ptr(), _lib.ptr(sigma), _lib.ptr(Z), out.data_ptr(), out.shape[1])
+
+
+class _GATHeadsFunction(torch.autograd.Function):
+    """H attention heads sharing (x, edges, edge_embed): out[:, h*D:(h+1)*D] = head h.
+    One C call for the forward (projection GEMMs + fused edge kernel), one for the backward."""
+
+    @staticmethod
+    def forward(ctx, x, ee, a, a2, graph, keep, alpha, concat):
+        _require_gpu_f32(x, ee, a, a2, keep)
+        L = _lib.lib()
+        x, ee, a, a2 = x.contiguous(), ee.contiguous(), a.contiguous(), a2.contiguous()
+        H, D = a2.shape
+        N, E = graph.N, graph.E
+        if x.shape[0] != N or ee.shape[0] != E or a.shape != (H, D, 2 * x.shape[1] + ee.shape[1]):
+            raise ValueError("recon_amd.gat_heads: inconsistent shapes")
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        need_grad = any(ctx.needs_input_grad[:4])
+        P = torch.empty(2, H, N, D, **f32)
+        Q = torch.empty(H, E, D, **f32)
+        out = torch.empty(N, H * D, **f32)
+        sigma = torch.empty(H, E, **f32) if need_grad else None
+        Z = torch.empty(H, N, **f32) if need_grad else None
+        if keep is not None:
+            if not need_grad:
+                sigma, Z = torch.empty(H, E, **f32), torch.empty(H, N, **f32)
+            keep = keep.view(H, E)[:, graph.eid_long].contiguous()       # original order -> CSR-slot order
+        args = _fwd_args(graph, x, ee, a, a2, keep, P, Q, sigma, Z, out, alpha, concat)
+        with torch.cuda.device(dev):
+            _lib.check(L.recon_gat_fwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_fwd")
+        if need_grad:
+            ctx.save_for_backward(x, ee, a, a2, keep, P, Q, sigma, Z, out)
+            ctx.graph, ctx.alpha, ctx.concat = graph, alpha, concat
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, ee, a, a2, keep, P, Q, sigma, Z, out = ctx.saved_tensors
+        graph = ctx.graph
+        L = _lib.lib()
+        H, D = a2.shape
+        N, E, F_, R = graph.N, graph.E, x.shape[1], ee.shape[1]
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        grad_out = grad_out.contiguous()
+        nx, ne, na, na2 = ctx.needs_input_grad[:4]
+        Gm = torch.empty(H, E, D, **f32)
+        gP = torch.empty(2, H, N, D, **f32)
+        partial = torch.empty(L.recon_gat_bwd_partial_floats(N, E, F_, R, D, H), **f32)
+        g_x = torch.empty(N, F_, **f32) if nx else None
+        g_ee = torch.empty(E, R, **f32) if ne else None
+        g_a = torch.empty(H, D, 2 * F_ + R, **f32) if na else None
+        g_a2 = torch.empty(H, D, **f32) if na2 else None
+        args = _lib.GatBwdArgs(_fwd_args(graph, x, ee, a, a2, keep, P, Q, sigma, Z, out, ctx.alpha, ctx.concat),
+                               grad_out.data_ptr(), grad_out.shape[1], Gm.data_ptr(), gP.data_ptr(),
+                               partial.data_ptr(), _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2))
+        with torch.cuda.device(dev):
+            _lib.check(L.recon_gat_bwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_bwd")
+        return g_x, g_ee, g_a, g_a2, None, None, None, None
+
+
+def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=True):
+    """Fused forward of H `SpGraphAttentionLayer`s that share their inputs (GAT/models.py:71-72).
+
+    x [N,F]; edge_embed_all [E,R] (1-hop rows then n-hop rows, original order); a [H,D,2F+R];
+    a_2 [H,D]; graph = prepare_graph(edge, edge_list_nhop, N); keep [H,E] dropout factors in
+    original edge order or None.  Returns [N, H*D] (heads concatenated along dim 1)."""
+    return _GATHeadsFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat)
+
+
+def cat_edge_embed(edge_embed, edge_list_nhop, edge_embed_nhop):
+    """GAT/layers.py:126-127."""
+    if _has_nhop(edge_list_nhop):
+        return torch.cat((edge_embed, edge_embed_nhop), dim=0)
+    return edge_embed
+
+
+class SpGraphAttentionLayer(nn.Module):
+    """Sparse KB-GAT attention layer, GAT/layers.py:87-181 — same constructor, forward signature,
+    attributes and parameters (`a` [D, 2F+R], `a_2` [1, D], xavier_normal gain 1.414)."""
+
+    def __init__(self, num_nodes, in_features, out_features, nrela_dim, dropout, alpha, concat=True):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.num_nodes = num_nodes
+        self.alpha = alpha
+        self.concat = concat
+        self.nrela_dim = nrela_dim
+        self.a = nn.Parameter(torch.zeros(size=(out_features, 2 * in_features + nrela_dim)))
+        nn.init.xavier_normal_(self.a.data, gain=1.414)
+        self.a_2 = nn.Parameter(torch.zeros(size=(1, out_features)))
+        nn.init.xavier_normal_(self.a_2.data, gain=1.414)
+        self.dropout = nn.Dropout(dropout)
+        self.leakyrelu = nn.LeakyReLU(self.alpha)
+        self.special_spmm_final = SpecialSpmmFinal()
+
+    def draw_keep(self, E, device):
+        """Dropout factors for the E un-normalised attention weights, drawn exactly as the reference
+        draws them (one nn.Dropout call on an E-vector, GAT/layers.py:158); None in eval mode."""
+        if self.training and self.dropout.p > 0:
+            return self.dropout(torch.ones(E, dtype=torch.float32, device=device)).view(1, E)
+        return None
+
+    def forward(self, input, edge, edge_embed, edge_list_nhop, edge_embed_nhop):
+        N = input.size()[0]                                  # not self.num_nodes (GAT/layers.py:112)
+        graph = prepare_graph(edge, edge_list_nhop, N)
+        ee = cat_edge_embed(edge_embed, edge_list_nhop, edge_embed_nhop)
+        keep = self.draw_keep(graph.E, input.device)
+        out = gat_heads(input, ee, self.a.unsqueeze(0), self.a_2, graph, keep, self.alpha, self.concat)
+        if _DEBUG_NAN:                                       # the reference's asserts (:147,:167,:172)
+            assert not torch.isnan(out).any()
+        return out
+
+    def __repr__(self):
+        return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'

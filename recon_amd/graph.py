@@ -1,0 +1,85 @@
+"""Graph preparation for the GAT hot path: the reference's int64 [2,E] COO edge tensors ->
+destination-CSR / source-CSC index arrays on the device (K3, csrc/csr.hip).
+
+The reference re-concatenates and re-coalesces the same edges in every one of the H+1 layer calls of
+one SpGAT.forward (GAT/layers.py:124-127, :56-58); here the prepared graph is cached per
+(edge tensor, n-hop tensor, N) so it is built once per batch.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+
+_CACHE = OrderedDict()
+_CACHE_MAX = 8
+
+
+class GraphCSR:
+    """Device-resident CSR/CSC view of a COO edge list.  Attributes mirror `recon_graph`."""
+
+    def __init__(self, edge, N):
+        if not edge.is_cuda:
+            raise RuntimeError("recon_amd: edge tensors must live on the GPU (no CPU path)")
+        if edge.dtype != torch.int64 or edge.dim() != 2 or edge.shape[0] != 2:
+            raise ValueError("edge must be an int64 [2,E] tensor")
+        edge = edge.contiguous()
+        E = edge.shape[1]
+        if N >= 2 ** 31 or E >= 2 ** 31:
+            raise ValueError("graph too large for int32 indices")
+        dev = edge.device
+        self.N, self.E, self.device = int(N), int(E), dev
+        self.edge = edge
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.rowptr_dst = torch.empty(N + 1, **i32)
+        self.rowptr_src = torch.empty(N + 1, **i32)
+        self.eid = torch.empty(E, **i32)
+        self.src = torch.empty(E, **i32)
+        self.dst = torch.empty(E, **i32)
+        self.slot_by_src = torch.empty(E, **i32)
+        L = _lib.lib()
+        ws_bytes = L.recon_graph_workspace_bytes(self.N, self.E)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        self.c = _lib.ReconGraph(self.N, self.E, self.rowptr_dst.data_ptr(), self.eid.data_ptr(),
+                                 self.src.data_ptr(), self.dst.data_ptr(), self.rowptr_src.data_ptr(),
+                                 self.slot_by_src.data_ptr())
+        with torch.cuda.device(dev):
+            rc = L.recon_graph_build(edge[0].data_ptr(), edge[1].data_ptr(), C.byref(self.c), ws.data_ptr(),
+                                     ws_bytes, _lib.current_stream())
+        _lib.check(rc, "recon_graph_build")
+        self._eid_long = None
+
+    @property
+    def eid_long(self):
+        if self._eid_long is None:
+            self._eid_long = self.eid.long()
+        return self._eid_long
+
+
+def _has_nhop(edge_list_nhop):
+    # an absent n-hop arrives as a float tensor of shape [0] (GAT/models.py:57,81): test shape[0]
+    return edge_list_nhop is not None and edge_list_nhop.shape[0] > 0
+
+
+def prepare_graph(edge, edge_list_nhop, N):
+    """Concatenate 1-hop and n-hop edges (GAT/layers.py:124-127) and build / fetch the cached CSR."""
+    nh = _has_nhop(edge_list_nhop)
+    key = (edge.data_ptr(), edge._version, tuple(edge.shape),
+           edge_list_nhop.data_ptr() if nh else 0, edge_list_nhop._version if nh else 0,
+           tuple(edge_list_nhop.shape) if nh else (), int(N), str(edge.device))
+    g = _CACHE.get(key)
+    if g is not None:
+        _CACHE.move_to_end(key)
+        return g
+    full = torch.cat((edge, edge_list_nhop), dim=1) if nh else edge
+    g = GraphCSR(full, N)
+    g._keepalive = (edge, edge_list_nhop if nh else None)   # pins data_ptr identity while cached
+    _CACHE[key] = g
+    while len(_CACHE) > _CACHE_MAX:
+        _CACHE.popitem(last=False)
+    return g
+
+
+def clear_graph_cache():
+    _CACHE.clear()
