@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py — edges aggregated / second, GAT forward + backward, on synthetic KG-context graphs
+(BASELINE.json metric).  One step = one pass of the H-head attention stage (GAT/models.py:71-72
+equivalent: H SpGraphAttentionLayers sharing inputs, outputs concatenated) forward + backward over
+one batch of synthetic graphs, inputs resident in HBM.  Default workload = BASELINE.json configs[1]:
+512 graphs x 16 nodes x 64 edges, F = R = 200, 8 heads x D = 200, fp32.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, every rank owns its own `--graphs` graphs (weak scaling), parameter
+gradients are averaged with one flat RCCL all-reduce per step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK = 157.3e12   # FLOP/s, fp32-input MFMA
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--graphs", type=int, default=512, help="graphs per GPU")
+    ap.add_argument("--nodes", type=int, default=16)
+    ap.add_argument("--edges", type=int, default=64, help="edges per graph")
+    ap.add_argument("--feat", type=int, default=200, help="F = R")
+    ap.add_argument("--dim", type=int, default=200, help="D per head")
+    ap.add_argument("--heads", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def algorithmic_bytes_fwd(N, E, H, D):
+    """bytes the fused forward edge-aggregation must move (fp32 values, int32 CSR):
+    Q [E,HD] once, P_dst and P_src [N,HD] once each, out [N,HD] once, CSR, a_2."""
+    HD = H * D
+    return 4 * HD * (E + 3 * N) + 4 * (E + N + 1) + 4 * HD
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from recon_amd import _lib
+    from recon_amd.models import SpGAT
+    from recon_amd.graph import prepare_graph
+    from recon_amd.gat_layers import _fwd_args
+    from recon_amd.dist import FlatGradBucket
+    from oracle import recon_oracle as O          # synthetic generator + cpu_baseline leg only
+
+    B, n, e, F_, D, H = args.graphs, args.nodes, args.edges, args.feat, args.dim, args.heads
+    R = F_
+    N, E = B * n, B * e
+    x, edge, ee = O.synthetic_batched_graph(B, n, e, F_, R, seed=rank)       # this rank's own graphs
+    torch.manual_seed(0)                                                      # identical parameters on every rank
+    model = SpGAT(N, F_, D, R, dropout=0.0, alpha=0.2, nheads=H)
+    head_params = [p for att in model.attentions for p in (att.a, att.a_2)]
+    cpu_state = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    eed = ee.to(dev).requires_grad_(True)
+    edged = edge.to(dev)
+    nohop = torch.tensor([])
+    Gd = torch.randn(N, H * D, generator=torch.Generator().manual_seed(1)).to(dev)
+    head_params = [p for att in model.attentions for p in (att.a, att.a_2)]
+    bucket = FlatGradBucket(head_params)
+    graph = prepare_graph(edged, nohop, N)                                    # CSR built once per batch (cached)
+
+    def step():
+        bucket.zero()
+        xd.grad = None
+        eed.grad = None
+        out = model.heads_forward(xd, edged, eed, nohop, nohop)
+        out.backward(Gd)
+        bucket.allreduce_mean()
+
+    def barrier_sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier_sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    edges_per_s = world * E * args.steps / dt
+
+    result = {
+        "metric": "edges aggregated/sec (GAT fwd+bwd) on synthetic KG-context graphs",
+        "value": edges_per_s, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cfg2: H-head KB-GAT attention stage fwd+bwd (heads only, dropout 0)",
+                   "graphs_per_gpu": B, "nodes_per_graph": n, "edges_per_graph": e, "F": F_, "R": R,
+                   "D_per_head": D, "heads": H, "N_per_gpu": N, "E_per_gpu": E,
+                   "parallelism": "dp%d (whole graphs sharded, flat grad all-reduce)" % world},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant HBM-bound kernel: fused forward edge aggregation (K1), timed in
+        # situ with HIP events on the launch stream, between the projection GEMMs and the backward.
+        L = _lib.lib()
+        f32 = dict(dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            a = torch.stack([att.a for att in model.attentions]).contiguous()
+            a2 = torch.cat([att.a_2 for att in model.attentions], dim=0).contiguous()
+        P = torch.empty(2, H, N, D, **f32)
+        Q = torch.empty(H, E, D, **f32)
+        sigma = torch.empty(H, E, **f32)
+        Z = torch.empty(H, N, **f32)
+        out = torch.empty(N, H * D, **f32)
+        fa = _fwd_args(graph, xd.detach(), eed.detach(), a, a2, None, P, Q, sigma, Z, out, 0.2, True)
+        st = _lib.current_stream()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        for i in range(args.warmup + args.steps):
+            k = i - args.warmup
+            if k >= 0:
+                ev[k][0].record()
+            _lib.check(L.recon_gat_project(C.byref(graph.c), C.byref(fa), st), "project")
+            if k >= 0:
+                ev[k][1].record()
+            _lib.check(L.recon_gat_edge_fwd(C.byref(graph.c), C.byref(fa), st), "edge_fwd")
+            if k >= 0:
+                ev[k][2].record()
+        torch.cuda.synchronize()
+        t_proj = sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)) / args.steps * 1e-3
+        t_edge = sum(ev[k][1].elapsed_time(ev[k][2]) for k in range(args.steps)) / args.steps * 1e-3
+        bytes_alg = algorithmic_bytes_fwd(N, E, H, D)
+        result["roofline"] = {"kernel": "k_gat_edge_fwd", "bound": "hbm", "achieved": bytes_alg / t_edge / 1e9,
+                              "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_alg / t_edge / HBM_PEAK,
+                              "traffic": None, "algorithmic_bytes": bytes_alg, "avg_us": t_edge * 1e6}
+        flops_proj = 2.0 * H * D * (2.0 * N * F_ + 1.0 * E * R)
+        result["roofline_gemm"] = {"kernel": "k_gemm_f32 (projections P, Q)", "bound": "mfma",
+                                   "achieved": flops_proj / t_proj / 1e12, "peak": MFMA_F32_PEAK / 1e12,
+                                   "unit": "TFLOP/s", "frac": flops_proj / t_proj / MFMA_F32_PEAK,
+                                   "avg_us": t_proj * 1e6}
+
+        # ---- CPU baseline: the oracle issuing the reference's own ATen op sequence (sparse_coo_tensor ->
+        # sparse.sum -> to_dense), all host cores, same workload, bounded to ~args.cpu_seconds.
+        if world == 1 and not args.no_cpu_baseline:
+            heads_a = [cpu_state["attention_%d.a" % h].clone().requires_grad_(True) for h in range(H)]
+            heads_a2 = [cpu_state["attention_%d.a_2" % h].clone().requires_grad_(True) for h in range(H)]
+            xc, eec, Gc = x.clone().requires_grad_(True), ee.clone().requires_grad_(True), Gd.cpu()
+
+            def cpu_step(nh=H):
+                outs = [O.gat_layer_forward(xc, edge, eec, None, None, heads_a[h], heads_a2[h], 0.2, True,
+                                            aten_sequence=True) for h in range(nh)]
+                torch.cat(outs, dim=1).backward(Gc[:, :nh * D])
+            # pick the thread count that runs this op sequence fastest on this host (one-head probe);
+            # all-core runs of these small sparse ops are far slower than 8-32 threads
+            ncpu = os.cpu_count() or 1
+            best = None
+            for th in sorted({t for t in (4, 8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8)}):
+                torch.set_num_threads(th)
+                cpu_step(1)
+                tq = time.perf_counter()
+                cpu_step(1)
+                tq = time.perf_counter() - tq
+                if best is None or tq < best[0]:
+                    best = (tq, th)
+            cores = best[1]
+            torch.set_num_threads(cores)
+            cpu_step()
+            n_cpu, t_cpu0 = 0, time.perf_counter()
+            while n_cpu < 10 and (time.perf_counter() - t_cpu0) < args.cpu_seconds:
+                cpu_step()
+                n_cpu += 1
+            t_cpu = (time.perf_counter() - t_cpu0) / n_cpu
+            result["cpu_baseline"] = {"value": E / t_cpu, "unit": "edges/s", "cores": cores, "kind": "port",
+                                      "sample": "%d full cfg2 steps (same batch, %d heads, fwd+bwd) after 1 warm-up, "
+                                                "oracle with the reference's ATen op sequence, torch %d threads "
+                                                "(fastest of 4..64 on a %d-cpu host)" % (n_cpu, H, cores, ncpu),
+                                      "ms_per_step": 1e3 * t_cpu}
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,8 +102,8 @@ typedef struct {
     const float* keep;          /* [H,E] dropout factors in CSR-slot order, or NULL (eval)   */
     float* P;                   /* [2,H,N,D] workspace / saved                               */
     float* Q;                   /* [H,E,D]   workspace / saved                               */
-    float* sigma;               /* [H,E] saved scores s_e (CSR-slot order), or NULL          */
-    float* Z;                   /* [H,N] saved clamped row sums, or NULL                     */
+    float* sigma;               /* [H,E] saved scores s_e (CSR-slot order); NULL iff Z NULL  */
+    float* Z;                   /* [H,N] saved clamped row sums; NULL = inference call       */
     float* out;                 /* [N, ld_out] ; head h writes columns [h*D, (h+1)*D)        */
     int32_t ld_out;             /* >= H*D                                                    */
 } recon_gat_fwd_args;

@@ -21,6 +21,14 @@ namespace recon {
 namespace {
 
 constexpr int kBlock = 256;
+
+// XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, each
+// with a private L2); neighbouring node blocks share P_src rows (same graph) and cache lines, so give
+// every XCD one CONTIGUOUS chunk of node blocks.  Bijective for any grid size; speed only.
+__device__ __forceinline__ int xcd_block(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
 template <int KR> constexpr int unroll_for() { return KR >= 8 ? 1 : (KR >= 4 ? 2 : 4); }
 
 struct EdgeFwdArgs {
@@ -36,7 +44,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_edge_fwd(const EdgeFwdArgs p) {
     constexpr int GPB = kBlock / G;
     constexpr int kUnroll = unroll_for<KR>();
     const int lig = threadIdx.x % G;
-    const int node = blockIdx.x * GPB + threadIdx.x / G;
+    const int node = xcd_block(blockIdx.x, gridDim.x) * GPB + threadIdx.x / G;
     const int h = blockIdx.y;
     if (node >= p.N) return;            // whole groups exit together; group_sum only crosses a group
     const int D = p.D;
@@ -155,7 +163,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_edge_bwd(const EdgeBwdArgs p) {
     }
     const int n_iter = (p.N + gridDim.x * GPB - 1) / (gridDim.x * GPB);
     for (int it = 0; it < n_iter; ++it) {
-        const int node = (it * gridDim.x + blockIdx.x) * GPB + grp;
+        const int node = (it * gridDim.x + xcd_block(blockIdx.x, gridDim.x)) * GPB + grp;
         const bool nv = node < p.N;                      // keep every lane in the loop: group_sum is wave-wide code
         float pd[KR][VEC], gU[KR][VEC], gd[KR][VEC];
         float dot = 0.f, Zi = 1.f;
@@ -271,7 +279,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_src_gather(const SrcGatherArgs p
     constexpr int GPB = kBlock / G;
     constexpr int kUnroll = 4;
     const int lig = threadIdx.x % G;
-    const int node = blockIdx.x * GPB + threadIdx.x / G;
+    const int node = xcd_block(blockIdx.x, gridDim.x) * GPB + threadIdx.x / G;
     const int h = blockIdx.y;
     if (node >= p.N) return;
     const int D = p.D;
@@ -314,12 +322,24 @@ __global__ void __launch_bounds__(kBlock) k_gat_src_gather(const SrcGatherArgs p
     }
 }
 
-__global__ void k_reduce_partials(const float* __restrict__ partial, int32_t nblk, int32_t HD, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= HD) return;
+// out[i] = sum_b partial[b][i], fixed order: 64 columns x 16 row groups per block, LDS combine
+__global__ void __launch_bounds__(1024) k_reduce_partials(const float* __restrict__ partial, int32_t nblk, int32_t HD,
+                                                          float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    const int per = (nblk + 15) / 16;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[static_cast<int64_t>(b) * HD + i];
-    out[i] = s;
+    if (col < HD)
+        for (int b = grp * per; b < min(nblk, (grp + 1) * per); ++b) s += partial[static_cast<int64_t>(b) * HD + col];
+    red[grp][c] = s;
+    __syncthreads();
+    if (grp == 0 && col < HD) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][c];
+        out[col] = t;
+    }
 }
 
 // ---- dispatch over (VEC, G, KR) --------------------------------------------------------------
@@ -370,7 +390,7 @@ int check_fwd(const recon_graph* g, const recon_gat_fwd_args* a) {
 
 int bwd_blocks(int N, int gpb) {
     int64_t nb = ceil_div64(N, gpb);
-    if (nb > 512) nb = 512;
+    if (nb > 256) nb = 256;
     if (nb < 1) nb = 1;
     return static_cast<int>(nb);
 }
@@ -414,7 +434,8 @@ extern "C" int recon_gat_edge_fwd(const recon_graph* g, const recon_gat_fwd_args
     int rc = check_fwd(g, a);
     if (rc != RECON_OK) return rc;
     if (a->N == 0) return RECON_OK;
-    const bool train = a->sigma != nullptr && a->Z != nullptr;
+    const bool train = a->Z != nullptr;                   // training call: save sigma / Z for the backward
+    if (train && a->E > 0 && !a->sigma) return RECON_ERR_INVALID;
     if (a->keep && !train) return RECON_ERR_INVALID;
     EdgeFwdArgs p;
     p.rowptr = g->rowptr_dst; p.src = g->src; p.P = a->P; p.Q = a->Q; p.a2 = a->a_2; p.keep = a->keep;
@@ -461,8 +482,8 @@ extern "C" int recon_gat_bwd(const recon_graph* g, const recon_gat_bwd_args* b, 
     const recon_gat_fwd_args* a = &b->fwd;
     int rc = check_fwd(g, a);
     if (rc != RECON_OK) return rc;
-    if (!a->sigma || !a->Z || !b->grad_out || !b->gP || !b->partial) return RECON_ERR_INVALID;
-    if (a->E > 0 && !b->Gm) return RECON_ERR_INVALID;
+    if (!a->Z || !b->grad_out || !b->gP || !b->partial) return RECON_ERR_INVALID;
+    if (a->E > 0 && (!a->sigma || !b->Gm)) return RECON_ERR_INVALID;
     if (b->ld_gout < a->H * a->D) return RECON_ERR_INVALID;
     hipStream_t st = as_stream(stream);
     const int32_t N = a->N, E = a->E, F = a->F, R = a->R, D = a->D, H = a->H;
@@ -493,7 +514,7 @@ extern "C" int recon_gat_bwd(const recon_graph* g, const recon_gat_bwd_args* b, 
 #undef CALL_BWD
         RECON_CHECK_LAUNCH();
         if (b->g_a_2) {
-            hipLaunchKernelGGL(k_reduce_partials, dim3(static_cast<unsigned>(ceil_div64(HD, 256))), dim3(256), 0, st,
+            hipLaunchKernelGGL(k_reduce_partials, dim3(static_cast<unsigned>(ceil_div64(HD, 64))), dim3(1024), 0, st,
                                b->partial, nblk, static_cast<int32_t>(HD), b->g_a_2);
             RECON_CHECK_LAUNCH();
         }

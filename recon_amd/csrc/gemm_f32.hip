@@ -4,15 +4,17 @@
 // `self.a.mm(edge_h)` GEMM of GAT/layers.py:129-137 (split algebraically into node and edge parts,
 // SURVEY.md 8a/G4) and the autograd GEMMs derived from it.
 //
-// Block tile 128x128x16, 256 threads = 4 waves (2x2), each wave 2x2 MFMA tiles of 32x32.
+// Block tile 128x128x16 (4 waves as 2x2, each 2x2 MFMA tiles of 32x32) or, for outputs 129..224
+// columns wide, 128x224x16 (4 waves stacked along M, each 1x7 tiles).
 // Global -> registers -> LDS staging with register prefetch of the next K tile; LDS tiles are
 // k-major ([16][128+4]) so both MFMA operand reads are conflict-free ds_read_b32.
+#include <stdlib.h>
 #include "recon_common.h"
 
 namespace recon {
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 132, NT = 256;
+constexpr int BK = 16, NT = 256;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 struct GemmArgs {
@@ -33,147 +35,148 @@ __device__ __forceinline__ int64_t minor_off(int32_t Dseg, int64_t Sseg, int32_t
     return static_cast<int64_t>(j % Dseg) + static_cast<int64_t>(j / Dseg) * Sseg;
 }
 
-// ---- tile loaders: fill r[2][4] (two passes of four floats per thread) ---------------------
-// k-minor operand: tile is 128 (mn) x 16 (k); thread -> row t>>2 (+64), k quad (t&3)*4
-template <int VEC>
-__device__ __forceinline__ void load_kminor(const OperandDesc& d, int32_t mn0, int32_t mn_ext, int32_t k0, int32_t k_end,
-                                            const int64_t* rowoff, float (&r)[2][4]) {
-    const int t = threadIdx.x;
-    const int kq = k0 + (t & 3) * 4;
+// One operand tile: W (m or n extent, 128 or 224) x BK, staged global -> registers -> LDS [BK][W+4].
+//   K_MINOR : memory is contiguous along k   -> thread item = (row, k quad): 4 floats along k
+//   !K_MINOR: memory is contiguous along m/n -> thread item = (k row, mn quad): 4 floats along mn
+template <int W, bool K_MINOR, int VEC>
+struct TileLoader {
+    static constexpr int LD = W + 4;
+    static constexpr int QPR = K_MINOR ? BK / 4 : W / 4;          // quads per tile row
+    static constexpr int ITEMS = K_MINOR ? W * (BK / 4) : BK * (W / 4);
+    static constexpr int NP = (ITEMS + NT - 1) / NT;
+    float r[NP][4];
+    int64_t fix[NP][K_MINOR || VEC == 4 ? 1 : 4];                 // K-invariant address part per item
+
+    __device__ __forceinline__ void init(const OperandDesc& d, int32_t mn0, int32_t mn_ext) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int mn = mn0 + (t >> 2) + 64 * p;
-        const bool rv = mn < mn_ext;
-        if constexpr (VEC == 4) {
-            if (rv && kq < k_end) {
-                const float4 v = *reinterpret_cast<const float4*>(d.base + rowoff[p] + minor_off(d.Dseg, d.Sseg, kq));
-                r[p][0] = v.x; r[p][1] = v.y; r[p][2] = v.z; r[p][3] = v.w;
+        for (int p = 0; p < NP; ++p) {
+            const int idx = threadIdx.x + NT * p;
+            if constexpr (K_MINOR) {
+                const int mn = mn0 + idx / QPR;
+                fix[p][0] = (idx < ITEMS && mn < mn_ext) ? major_off(d, mn) : -1;
             } else {
-                r[p][0] = r[p][1] = r[p][2] = r[p][3] = 0.f;
-            }
-        } else {
+                const int mn = mn0 + (idx % QPR) * 4;
+                if constexpr (VEC == 4) fix[p][0] = (idx < ITEMS && mn < mn_ext) ? minor_off(d.Dseg, d.Sseg, mn) : -1;
+                else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                r[p][j] = (rv && kq + j < k_end) ? d.base[rowoff[p] + minor_off(d.Dseg, d.Sseg, kq + j)] : 0.f;
+                    for (int j = 0; j < 4; ++j) fix[p][j] = (idx < ITEMS && mn + j < mn_ext) ? minor_off(d.Dseg, d.Sseg, mn + j) : -1;
+                }
+            }
         }
     }
-}
-__device__ __forceinline__ void store_kminor(float (*T)[LDT], const float (&r)[2][4]) {
-    const int t = threadIdx.x;
+    __device__ __forceinline__ void load(const OperandDesc& d, int32_t k0, int32_t k_end) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < NP; ++p) {
+            const int idx = threadIdx.x + NT * p;
+            r[p][0] = r[p][1] = r[p][2] = r[p][3] = 0.f;
+            if constexpr (K_MINOR) {
+                const int kq = k0 + (idx % QPR) * 4;
+                if (fix[p][0] >= 0) {
+                    if constexpr (VEC == 4) {
+                        if (kq < k_end) {
+                            const float4 v = *reinterpret_cast<const float4*>(d.base + fix[p][0] + minor_off(d.Dseg, d.Sseg, kq));
+                            r[p][0] = v.x; r[p][1] = v.y; r[p][2] = v.z; r[p][3] = v.w;
+                        }
+                    } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) T[(t & 3) * 4 + j][(t >> 2) + 64 * p] = r[p][j];
-}
-// mn-minor operand: tile is 16 (k) x 128 (mn); thread -> k row t>>5 (+8), mn quad (t&31)*4
-template <int VEC>
-__device__ __forceinline__ void load_mnminor(const OperandDesc& d, int32_t mn0, int32_t mn_ext, int32_t k0, int32_t k_end,
-                                             const int64_t* coloff, float (&r)[2][4]) {
-    const int t = threadIdx.x;
-    const int mn = mn0 + (t & 31) * 4;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int k = k0 + (t >> 5) + 8 * p;
-        if (k < k_end) {
-            const int64_t ro = major_off(d, k);
-            if constexpr (VEC == 4) {
-                if (mn < mn_ext) {
-                    const float4 v = *reinterpret_cast<const float4*>(d.base + ro + coloff[0]);
-                    r[p][0] = v.x; r[p][1] = v.y; r[p][2] = v.z; r[p][3] = v.w;
-                } else {
-                    r[p][0] = r[p][1] = r[p][2] = r[p][3] = 0.f;
+                        for (int j = 0; j < 4; ++j)
+                            if (kq + j < k_end) r[p][j] = d.base[fix[p][0] + minor_off(d.Dseg, d.Sseg, kq + j)];
+                    }
                 }
             } else {
+                const int k = k0 + idx / QPR;
+                if (idx < ITEMS && k < k_end) {
+                    const int64_t ro = major_off(d, k);
+                    if constexpr (VEC == 4) {
+                        if (fix[p][0] >= 0) {
+                            const float4 v = *reinterpret_cast<const float4*>(d.base + ro + fix[p][0]);
+                            r[p][0] = v.x; r[p][1] = v.y; r[p][2] = v.z; r[p][3] = v.w;
+                        }
+                    } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) r[p][j] = (mn + j < mn_ext) ? d.base[ro + coloff[j]] : 0.f;
+                        for (int j = 0; j < 4; ++j)
+                            if (fix[p][j] >= 0) r[p][j] = d.base[ro + fix[p][j]];
+                    }
+                }
             }
-        } else {
-            r[p][0] = r[p][1] = r[p][2] = r[p][3] = 0.f;
         }
     }
-}
-__device__ __forceinline__ void store_mnminor(float (*T)[LDT], const float (&r)[2][4]) {
-    const int t = threadIdx.x;
+    __device__ __forceinline__ void store(float (*T)[LD]) const {
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
-        *reinterpret_cast<float4*>(&T[(t >> 5) + 8 * p][(t & 31) * 4]) = make_float4(r[p][0], r[p][1], r[p][2], r[p][3]);
-}
+        for (int p = 0; p < NP; ++p) {
+            const int idx = threadIdx.x + NT * p;
+            if (idx < ITEMS) {
+                if constexpr (K_MINOR) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) T[(idx % QPR) * 4 + j][idx / QPR] = r[p][j];
+                } else {
+                    *reinterpret_cast<float4*>(&T[idx / QPR][(idx % QPR) * 4]) = make_float4(r[p][0], r[p][1], r[p][2], r[p][3]);
+                }
+            }
+        }
+    }
+};
 
-template <bool A_KMINOR, bool B_KMINOR, int VEC>
+// Block tile (WM*TM*32) x (WN*TN*32) x 16; 4 waves arranged WM x WN, each wave TM x TN MFMA tiles.
+template <bool A_KMINOR, bool B_KMINOR, int VEC, int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(NT) k_gemm_f32(const GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float As[BK][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
+    static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    using LA = TileLoader<BM, A_KMINOR, VEC>;
+    using LB = TileLoader<BN, B_KMINOR, VEC>;
+    __shared__ __attribute__((aligned(16))) float As[BK][LA::LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][LB::LD];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int k_begin = blockIdx.z * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
 
-    // per-thread address pieces that do not change along K
-    int64_t a_fix[4], b_fix[4];
-    if constexpr (A_KMINOR) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) { const int m = m0 + (t >> 2) + 64 * q; a_fix[q] = (m < p.M) ? major_off(p.A, m) : 0; }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int m = m0 + (t & 31) * 4 + j; a_fix[j] = (m < p.M) ? minor_off(p.A.Dseg, p.A.Sseg, m) : 0; }
-    }
-    if constexpr (B_KMINOR) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) { const int n = n0 + (t >> 2) + 64 * q; b_fix[q] = (n < p.N) ? major_off(p.B, n) : 0; }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int n = n0 + (t & 31) * 4 + j; b_fix[j] = (n < p.N) ? minor_off(p.B.Dseg, p.B.Sseg, n) : 0; }
-    }
+    LA la; LB lb;
+    la.init(p.A, m0, p.M);
+    lb.init(p.B, n0, p.N);
 
-    float ra[2][4], rb[2][4];
-    auto load_tiles = [&](int k0) {
-        if constexpr (A_KMINOR) load_kminor<VEC>(p.A, m0, p.M, k0, k_end, a_fix, ra);
-        else load_mnminor<VEC>(p.A, m0, p.M, k0, k_end, a_fix, ra);
-        if constexpr (B_KMINOR) load_kminor<VEC>(p.B, n0, p.N, k0, k_end, b_fix, rb);
-        else load_mnminor<VEC>(p.B, n0, p.N, k0, k_end, b_fix, rb);
-    };
-    auto store_tiles = [&]() {
-        if constexpr (A_KMINOR) store_kminor(As, ra); else store_mnminor(As, ra);
-        if constexpr (B_KMINOR) store_kminor(Bs, rb); else store_mnminor(Bs, rb);
-    };
-
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int mb = (wid >> 1) * 64, nb = (wid & 1) * 64;
+    const int mb = (wid / WN) * TM * 32, nb = (wid % WN) * TN * 32;
     const int lr = lane & 31, lk = lane >> 5;
 
     if (k_begin < k_end) {
-        load_tiles(k_begin);
-        store_tiles();
+        la.load(p.A, k_begin, k_end);
+        lb.load(p.B, k_begin, k_end);
+        la.store(As);
+        lb.store(Bs);
     }
     __syncthreads();
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         const bool more = k0 + BK < k_end;
-        if (more) load_tiles(k0 + BK);
+        if (more) { la.load(p.A, k0 + BK, k_end); lb.load(p.B, k0 + BK, k_end); }
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             const int kk = 2 * ks + lk;
-            const float a0 = As[kk][mb + lr], a1 = As[kk][mb + 32 + lr];
-            const float b0 = Bs[kk][nb + lr], b1 = Bs[kk][nb + 32 + lr];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[kk][mb + i * 32 + lr];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[kk][nb + j * 32 + lr];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
-        if (more) { store_tiles(); }
+        if (more) { la.store(As); lb.store(Bs); }
         __syncthreads();
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TN; ++j) {
         const int col = n0 + nb + j * 32 + lr;
         if (col >= p.N) continue;
         int64_t coff;
@@ -181,7 +184,7 @@ __global__ void __launch_bounds__(NT) k_gemm_f32(const GemmArgs p) {
         if (p.partial) { base = p.partial + static_cast<int64_t>(blockIdx.z) * p.M * p.N; coff = col; }
         else { base = p.C.base; coff = minor_off(p.C.Dseg, p.C.Sseg, col); }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + mb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -222,16 +225,28 @@ bool operand_vec4(const OperandDesc& d, int32_t minor_extent) {
 }
 
 template <bool AK, bool BK_, int VEC>
-void launch(const GemmArgs& a, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC>), grid, dim3(NT), 0, st, a);
+void launch(const GemmArgs& a, bool wide_n, dim3 grid, hipStream_t st) {
+    if (wide_n) hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 4, 1, 1, 7>), grid, dim3(NT), 0, st, a);   // 128 x 224
+    else hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 2, 2>), grid, dim3(NT), 0, st, a);          // 128 x 128
+}
+
+// 128x224 tiles when the output is 129..224 columns wide (N = 200 in every backward GEMM of cfg 2):
+// one column tile at 89 % MFMA efficiency instead of two 128-wide tiles at 78 %.
+bool use_wide_n(int32_t N) {
+    static const int force = getenv("RECON_GEMM_CFG") ? atoi(getenv("RECON_GEMM_CFG")) : 0;   // tuning knob: 1 = 128x128, 2 = 128x224
+    (void)N;
+    return force == 2;        // measured in situ on cfg 2 (profiles/): 128x128 tiles win for every projection today
 }
 
 }  // namespace
 
 int gemm_pick_split_k(int32_t M, int32_t N, int32_t K) {
-    const int64_t tiles = ceil_div64(M, BM) * ceil_div64(N, BN);
+    static const int force = getenv("RECON_GEMM_SPLITK") ? atoi(getenv("RECON_GEMM_SPLITK")) : 0;   // tuning knob
+    if (force > 0) return force;
+    const int bn = use_wide_n(N) ? 224 : 128;
+    const int64_t tiles = ceil_div64(M, 128) * ceil_div64(N, bn);
     if (tiles >= 192) return 1;
-    int64_t s = ceil_div64(512, tiles);
+    int64_t s = ceil_div64(512, tiles);                            // aim at ~2 blocks per CU
     const int64_t max_s = (K / (8 * BK)) > 0 ? K / (8 * BK) : 1;   // at least 8 K tiles per split
     if (s > max_s) s = max_s;
     if (s > 64) s = 64;
@@ -253,10 +268,12 @@ int gemm_f32(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool a_k_min
     split_k = static_cast<int32_t>(ceil_div64(K > 0 ? K : 1, kps));
     a.partial = split_k > 1 ? partial : nullptr;
     const bool v4 = operand_vec4(A, a_k_minor ? K : M) && operand_vec4(B, b_k_minor ? K : N);
-    dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, BM)), static_cast<unsigned>(split_k));
-    if (a_k_minor && b_k_minor) { if (v4) launch<true, true, 4>(a, grid, st); else launch<true, true, 1>(a, grid, st); }
-    else if (a_k_minor && !b_k_minor) { if (v4) launch<true, false, 4>(a, grid, st); else launch<true, false, 1>(a, grid, st); }
-    else if (!a_k_minor && !b_k_minor) { if (v4) launch<false, false, 4>(a, grid, st); else launch<false, false, 1>(a, grid, st); }
+    const bool wide = use_wide_n(N);
+    dim3 grid(static_cast<unsigned>(ceil_div64(N, wide ? 224 : 128)), static_cast<unsigned>(ceil_div64(M, 128)),
+              static_cast<unsigned>(split_k));
+    if (a_k_minor && b_k_minor) { if (v4) launch<true, true, 4>(a, wide, grid, st); else launch<true, true, 1>(a, wide, grid, st); }
+    else if (a_k_minor && !b_k_minor) { if (v4) launch<true, false, 4>(a, wide, grid, st); else launch<true, false, 1>(a, wide, grid, st); }
+    else if (!a_k_minor && !b_k_minor) { if (v4) launch<false, false, 4>(a, wide, grid, st); else launch<false, false, 1>(a, wide, grid, st); }
     else return RECON_ERR_UNSUPPORTED;
     if (split_k > 1) {
         const int64_t MN = static_cast<int64_t>(M) * N;

@@ -1,0 +1,60 @@
+"""Data parallelism for the hot path: one process per GPU, whole graphs sharded
+across ranks (no edge crosses graphs, so any partition of whole graphs is exact and needs no
+data-path collective), parameter gradients summed with ONE all-reduce over a flat fp32 bucket
+(torch.distributed backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(num_graphs, rank, world):
+    """Contiguous block of graphs owned by `rank` (first `num_graphs % world` ranks get one extra)."""
+    base, rem = divmod(num_graphs, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_by_edges(edges_per_graph, world):
+    """Greedy longest-processing-time bin packing of graphs by edge count (for power-law batches,
+    SURVEY.md 8e).  Returns a list of graph-id lists, one per rank; deterministic."""
+    order = sorted(range(len(edges_per_graph)), key=lambda i: (-int(edges_per_graph[i]), i))
+    loads = [0] * world
+    bins = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        bins[r].append(i)
+        loads[r] += int(edges_per_graph[i])
+    return [sorted(b) for b in bins]
+
+
+def take_graph_shard(x, edge, edge_embed, node_ptr, edge_ptr, lo, hi):
+    """Slice a batched disjoint-union graph to graphs [lo, hi): node rows and edge columns are
+    contiguous slices; edge indices are rebased to the shard's first node."""
+    n0, n1 = int(node_ptr[lo]), int(node_ptr[hi])
+    e0, e1 = int(edge_ptr[lo]), int(edge_ptr[hi])
+    return x[n0:n1], (edge[:, e0:e1] - n0), edge_embed[e0:e1]
+
+
+class FlatGradBucket:
+    """All parameter gradients live in ONE flat fp32 buffer (p.grad are views into it), so the
+    per-step reduction is a single all-reduce with no pack/unpack copies."""
+
+    def __init__(self, params, process_group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = process_group
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def allreduce_mean(self, async_op=False):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return None
+        w = dist.get_world_size(self.group)
+        self.flat.div_(w)
+        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
