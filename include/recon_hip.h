@@ -135,6 +135,89 @@ size_t recon_gat_bwd_partial_floats(int32_t N, int32_t E, int32_t F, int32_t R, 
 int recon_gat_bwd(const recon_graph* g, const recon_gat_bwd_args* args, recon_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * P1  block adjacency of the GP-GNN step (models/models.py:240-259; copies :450-469, :660-679,
+ *     :898-917):  A[b, i*dd+r, j*dd+c] = T[b, e(i,j), r*dd+c] for i != j (e = row-major over ordered
+ *     pairs, diagonal skipped) and identity[r,c] for i == j;  dd = 2*embedding_dim, S = n*dd.
+ *     T is the per-pair transition tensor AFTER the non-linearity, [B, n(n-1), dd*dd].
+ * ------------------------------------------------------------------------------------------*/
+int recon_block_adjacency_fwd(const float* T, const float* identity, int32_t B, int32_t n, int32_t dd,
+                              float* A /*[B,S,S]*/, recon_stream_t stream);
+/* gT [B,n(n-1),dd*dd] and g_identity [dd,dd] (either may be NULL) from gA [B,S,S] */
+int recon_block_adjacency_bwd(const float* gA, int32_t B, int32_t n, int32_t dd, float* gT, float* g_identity,
+                              recon_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * P2 / K5  L-hop gated propagation + head*tail gather (models/models.py:260-274; copies :470-485,
+ *     :680-694, :918-932):  h^0 = h0;  h^l = act(A_l h^l-1)  per channel c;
+ *     out[b, c, l*dd + x] = h^l[b, c, head[c,x]] * h^l[b, c, tail[c,x]].
+ *     One launch runs all L hops with the channel states resident in LDS (MFMA 16x16x4 fp32).
+ * ------------------------------------------------------------------------------------------*/
+enum { RECON_ACT_LINEAR = 0, RECON_ACT_RELU = 1, RECON_ACT_TANH = 2 };
+typedef struct {
+    int32_t B, C, S, L, dd;         /* graphs, channels n(n-1), state size n*dd, hops, gather width      */
+    int32_t act;                    /* RECON_ACT_*  (model_params.json "non-linear1")                    */
+    const float* const* adj;        /* HOST array of L device pointers, each [B,S,S]                     */
+    const float* h0;                /* [C,S] shared (h0_batch_stride = 0) or [B,C,S] (stride = C*S)       */
+    int64_t h0_batch_stride;
+    const int64_t* head_idx;        /* [C,dd] (idx_batch_stride = 0) or [B,C,dd]; values in [0,S)         */
+    const int64_t* tail_idx;
+    int64_t idx_batch_stride;
+    float* out;                     /* [B,C,L*dd]                                                         */
+    float* h_saved;                 /* [L,B,C,S] states after each hop (for the backward) or NULL         */
+} recon_prop_args;
+
+int recon_propagate_fwd(const recon_prop_args* args, recon_stream_t stream);
+
+typedef struct {
+    recon_prop_args fwd;            /* h_saved filled by the forward call                                 */
+    const float* grad_out;          /* [B,C,L*dd]                                                         */
+    float* const* g_adj;            /* HOST array of L device pointers [B,S,S] (entries may be NULL)      */
+    float* g_h;                     /* [B,C,S] workspace; on return holds d loss / d h0 per batch element */
+} recon_prop_bwd_args;
+
+int recon_propagate_bwd(const recon_prop_bwd_args* args, recon_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * P4  make_start_entity_embeddings (utils/context_utils.py:387-426): h0[b,c=(i,j),:] has the first
+ *     entity's embedding in node i's first half-slot and the second entity's in node j's second
+ *     half-slot, zero elsewhere, times the start-embedding template.
+ * ------------------------------------------------------------------------------------------*/
+int recon_start_entity_embeddings(const float* entity_embeddings /*[U,d]*/, const int64_t* pos /*[B,C,2]*/,
+                                  const float* templ /*[C,S]*/, int32_t B, int32_t n, int32_t d,
+                                  float* out /*[B,C,S]*/, recon_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * P5 / K6  GraphConvolution (models/layers.py:57-63), batched over B graphs (B = 1 is the
+ *     reference's 2-D call):  out = relu(adj @ (x @ W) + bias).
+ *     support [B*n,out] is caller-allocated scratch / saved for the backward.
+ * ------------------------------------------------------------------------------------------*/
+typedef struct {
+    int32_t B, n, in_features, out_features;
+    const float* x;                 /* [B,n,in]   */
+    const float* adj;               /* [B,n,n]    */
+    const float* weight;            /* [in,out]   */
+    const float* bias;              /* [out] or NULL */
+    float* support;                 /* [B,n,out]  x @ W */
+    float* out;                     /* [B,n,out]  */
+} recon_gcn_args;
+
+int recon_gcn_fwd(const recon_gcn_args* args, recon_stream_t stream);
+
+typedef struct {
+    recon_gcn_args fwd;
+    const float* grad_out;          /* [B,n,out] */
+    float* g_support;               /* [B,n,out] workspace */
+    float* partial;                 /* workspace: recon_gcn_bwd_partial_floats() floats */
+    float* g_x;                     /* [B,n,in]  or NULL */
+    float* g_adj;                   /* [B,n,n]   or NULL */
+    float* g_weight;                /* [in,out]  or NULL */
+    float* g_bias;                  /* [out]     or NULL */
+} recon_gcn_bwd_args;
+
+size_t recon_gcn_bwd_partial_floats(int32_t B, int32_t n, int32_t in_features, int32_t out_features);
+int recon_gcn_bwd(const recon_gcn_bwd_args* args, recon_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * K4  fp32 MFMA GEMM used by the projections, exported for tests:
  *     C[M,N] = A[M,K] * B (B given as [N,K] when b_is_nk != 0, else [K,N]); plain row-major.
  * ------------------------------------------------------------------------------------------*/

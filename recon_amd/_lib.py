@@ -38,6 +38,30 @@ class GatBwdArgs(C.Structure):
                 ("g_x", c_f32p), ("g_edge_embed", c_f32p), ("g_a", c_f32p), ("g_a_2", c_f32p)]
 
 
+class PropArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("C", C.c_int32), ("S", C.c_int32), ("L", C.c_int32), ("dd", C.c_int32),
+                ("act", C.c_int32), ("adj", C.POINTER(C.c_void_p)), ("h0", c_f32p), ("h0_batch_stride", C.c_int64),
+                ("head_idx", c_i64p), ("tail_idx", c_i64p), ("idx_batch_stride", C.c_int64),
+                ("out", c_f32p), ("h_saved", c_f32p)]
+
+
+class PropBwdArgs(C.Structure):
+    _fields_ = [("fwd", PropArgs), ("grad_out", c_f32p), ("g_adj", C.POINTER(C.c_void_p)), ("g_h", c_f32p)]
+
+
+class GcnArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("n", C.c_int32), ("in_features", C.c_int32), ("out_features", C.c_int32),
+                ("x", c_f32p), ("adj", c_f32p), ("weight", c_f32p), ("bias", c_f32p), ("support", c_f32p),
+                ("out", c_f32p)]
+
+
+class GcnBwdArgs(C.Structure):
+    _fields_ = [("fwd", GcnArgs), ("grad_out", c_f32p), ("g_support", c_f32p), ("partial", c_f32p),
+                ("g_x", c_f32p), ("g_adj", c_f32p), ("g_weight", c_f32p), ("g_bias", c_f32p)]
+
+
+ACT = {"linear": 0, "relu": 1, "tanh": 2}
+
 # every symbol include/recon_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("recon_version", C.c_int, []),
@@ -51,6 +75,15 @@ SYMBOLS = [
     ("recon_gat_edge_fwd", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatFwdArgs), C.c_void_p]),
     ("recon_gat_bwd_partial_floats", C.c_size_t, [C.c_int32] * 6),
     ("recon_gat_bwd", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatBwdArgs), C.c_void_p]),
+    ("recon_block_adjacency_fwd", C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_void_p]),
+    ("recon_block_adjacency_bwd", C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_void_p]),
+    ("recon_propagate_fwd", C.c_int, [C.POINTER(PropArgs), C.c_void_p]),
+    ("recon_propagate_bwd", C.c_int, [C.POINTER(PropBwdArgs), C.c_void_p]),
+    ("recon_start_entity_embeddings", C.c_int, [c_f32p, c_i64p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
+                                                C.c_void_p]),
+    ("recon_gcn_fwd", C.c_int, [C.POINTER(GcnArgs), C.c_void_p]),
+    ("recon_gcn_bwd_partial_floats", C.c_size_t, [C.c_int32] * 4),
+    ("recon_gcn_bwd", C.c_int, [C.POINTER(GcnBwdArgs), C.c_void_p]),
     ("recon_sgemm", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32,
                               c_f32p, C.c_int32, C.c_void_p]),
 ]

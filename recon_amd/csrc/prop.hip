@@ -1,0 +1,619 @@
+// K5 / K6 — GP-GNN gated propagation (block adjacency, L-hop propagation with fused head*tail
+// gather, start-entity embeddings) and batched GraphConvolution.
+//
+// Replaces models/models.py:240-274 (and its copies :450-485, :660-694, :898-932),
+// utils/context_utils.py:387-426 and models/layers.py:57-63.
+//
+// Propagation maths per graph b and channel c (a channel = one ordered entity pair):
+//     h^l[c] = act(A_l h^l-1[c])         A_l [S,S], h [S]
+// Channels never mix, so a workgroup owns (graph, chunk of <= 80 channels), keeps the channel
+// states H^T [channels][S] resident in LDS for all L hops and streams each A_l exactly once from
+// HBM straight into MFMA B-operand registers (v_mfma_f32_16x16x4_f32, exact fp32):
+//     out^T[c][s] = sum_t H^T[c][t] * A[s][t]      M = channels, N = S, K = S
+// Both operands are contiguous along the contraction index, so every lane fetches float4s and the
+// K index is permuted consistently (k = 4*(lane>>4) + step) between the A- and B-fragments.
+#include <math.h>
+#include "recon_common.h"
+
+namespace recon {
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kMaxHops = 8;
+constexpr int kPT = 256;
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == RECON_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == RECON_ACT_TANH) return tanhf(v);
+    return v;
+}
+// derivative expressed through the activation OUTPUT y
+__device__ __forceinline__ float act_bwd(float y, int act) {
+    if (act == RECON_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == RECON_ACT_TANH) return 1.f - y * y;
+    return 1.f;
+}
+
+// ------------------------------------------------------------------------------- P1
+__global__ void k_block_adj_fwd(const float* __restrict__ T, const float* __restrict__ I, int32_t B, int32_t n, int32_t dd,
+                                float* __restrict__ A) {
+    const int64_t S = 1LL * n * dd;
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= B * S * S) return;
+    const int col = static_cast<int>(idx % S), row = static_cast<int>((idx / S) % S);
+    const int64_t b = idx / (S * S);
+    const int i = row / dd, r = row % dd, j = col / dd, c = col % dd;
+    float v;
+    if (i == j) v = I[r * dd + c];
+    else {
+        const int e = i * (n - 1) + (j < i ? j : j - 1);
+        v = T[(b * n * (n - 1) + e) * dd * dd + r * dd + c];
+    }
+    A[idx] = v;
+}
+__global__ void k_block_adj_bwd_T(const float* __restrict__ gA, int32_t B, int32_t n, int32_t dd, float* __restrict__ gT) {
+    const int64_t S = 1LL * n * dd, Cn = 1LL * n * (n - 1), d2 = 1LL * dd * dd;
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= B * Cn * d2) return;
+    const int c = static_cast<int>(idx % dd), r = static_cast<int>((idx / dd) % dd);
+    const int e = static_cast<int>((idx / d2) % Cn);
+    const int64_t b = idx / (d2 * Cn);
+    const int i = e / (n - 1);
+    int j = e % (n - 1);
+    if (j >= i) ++j;
+    gT[idx] = gA[(b * S + i * dd + r) * S + j * dd + c];
+}
+// g_identity[r,c] = sum_{b,i} gA[b, i*dd+r, i*dd+c]; one block per (r,c), fixed-order tree
+__global__ void __launch_bounds__(256) k_block_adj_bwd_I(const float* __restrict__ gA, int32_t B, int32_t n, int32_t dd,
+                                                         float* __restrict__ gI) {
+    __shared__ float red[256];
+    const int r = blockIdx.x / dd, c = blockIdx.x % dd;
+    const int64_t S = 1LL * n * dd;
+    float s = 0.f;
+    for (int64_t t = threadIdx.x; t < 1LL * B * n; t += 256) {
+        const int64_t b = t / n;
+        const int i = static_cast<int>(t % n);
+        s += gA[(b * S + i * dd + r) * S + i * dd + c];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) gI[r * dd + c] = red[0];
+}
+
+// ------------------------------------------------------------------------------- P4
+__global__ void k_start_entity(const float* __restrict__ ent, const int64_t* __restrict__ pos, const float* __restrict__ templ,
+                               int32_t B, int32_t n, int32_t d, float* __restrict__ out) {
+    const int64_t S = 2LL * d * n, C = 1LL * n * (n - 1);
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= B * C * S) return;
+    const int s = static_cast<int>(idx % S), c = static_cast<int>((idx / S) % C);
+    const int64_t b = idx / (S * C);
+    const int i = c / (n - 1);
+    int j = c % (n - 1);
+    if (j >= i) ++j;
+    float v = 0.f;
+    if (s >= 2 * d * i && s < 2 * d * i + d) v = ent[pos[(b * C + c) * 2 + 0] * d + (s - 2 * d * i)];
+    else if (s >= 2 * d * j + d && s < 2 * d * (j + 1)) v = ent[pos[(b * C + c) * 2 + 1] * d + (s - 2 * d * j - d)];
+    out[idx] = v * templ[c * S + s];
+}
+
+// ------------------------------------------------------------------------------- P2 forward
+struct PropK {
+    const float* adj[kMaxHops];
+    const float* h0; int64_t h0_bs;
+    const int64_t* head; const int64_t* tail; int64_t idx_bs;
+    float* out; float* hsave;
+    int32_t B, C, S, L, dd, act, CC, Sp, pitch;
+};
+
+template <bool VEC4>
+__device__ __forceinline__ void load_a_row4(float (&v)[4], const float* A, int S, int row, int col, bool row_ok) {
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (!row_ok) return;
+    const float* p = A + static_cast<int64_t>(row) * S + col;
+    if constexpr (VEC4) {
+        if (col < S) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (col + j < S) v[j] = p[j];
+    }
+}
+
+template <int MT, bool VEC4>
+__global__ void __launch_bounds__(kPT) k_propagate_fwd(const PropK p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int c0 = chunk * p.CC;
+    const int pitch = p.pitch, S = p.S, CC = p.CC;
+    float* buf0 = lds;
+    float* buf1 = lds + static_cast<int64_t>(CC) * pitch;
+    // h^0 chunk (zero padded)
+    for (int idx = tid; idx < CC * pitch; idx += kPT) {
+        const int cl = idx / pitch, s = idx % pitch;
+        const int c = c0 + cl;
+        buf0[idx] = (c < p.C && s < S) ? p.h0[b * p.h0_bs + static_cast<int64_t>(c) * S + s] : 0.f;
+    }
+    __syncthreads();
+    const int li = lane & 15, lq = lane >> 4;
+    const int NT = p.Sp >> 4;
+    for (int l = 0; l < p.L; ++l) {
+        const float* cur = (l & 1) ? buf1 : buf0;
+        float* nxt = (l & 1) ? buf0 : buf1;
+        const float* A = p.adj[l] + static_cast<int64_t>(b) * S * S;
+        for (int nt = wave; nt < NT; nt += kPT / 64) {
+            f32x4 acc[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int row = 16 * nt + li;
+            const bool row_ok = row < S;
+            float bq[4], bn[4];
+            load_a_row4<VEC4>(bq, A, S, row, 4 * lq, row_ok);
+            for (int slab = 0; slab < NT; ++slab) {
+                const int kc = 16 * slab + 4 * lq;
+                if (slab + 1 < NT) load_a_row4<VEC4>(bn, A, S, row, kc + 16, row_ok);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float4 aq = *reinterpret_cast<const float4*>(cur + (16 * m + li) * pitch + kc);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, bq[0], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, bq[1], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, bq[2], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, bq[3], acc[m], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bq[j] = bn[j];
+            }
+            // C layout: col (s) = lane&15, row (channel) = (lane>>4)*4 + r
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nxt[(16 * m + 4 * lq + r) * pitch + 16 * nt + li] = act_fwd(acc[m][r], p.act);
+        }
+        __syncthreads();
+        // relation_l = gather(h, heads) * gather(h, tails)   (models/models.py:270-273)
+        for (int idx = tid; idx < CC * p.dd; idx += kPT) {
+            const int cl = idx / p.dd, x = idx % p.dd;
+            const int c = c0 + cl;
+            if (c < p.C) {
+                const int64_t io = b * p.idx_bs + static_cast<int64_t>(c) * p.dd + x;
+                const int hi = static_cast<int>(p.head[io]), ti = static_cast<int>(p.tail[io]);
+                p.out[(static_cast<int64_t>(b) * p.C + c) * (p.L * p.dd) + l * p.dd + x] = nxt[cl * pitch + hi] * nxt[cl * pitch + ti];
+            }
+        }
+        if (p.hsave) {
+            float* hs = p.hsave + ((static_cast<int64_t>(l) * p.B + b) * p.C) * S;
+            for (int idx = tid; idx < CC * S; idx += kPT) {
+                const int cl = idx / S, s = idx % S;
+                if (c0 + cl < p.C) hs[static_cast<int64_t>(c0 + cl) * S + s] = nxt[cl * pitch + s];
+            }
+        }
+        // no second barrier needed: the next hop only writes the buffer nobody reads any more
+    }
+}
+
+// ------------------------------------------------------------------------------- P2 backward (one hop per launch)
+struct PropBwdK {
+    const float* A;           // adj of this hop [B,S,S]
+    const float* Hl;          // state after this hop  [B,C,S]
+    const float* Hprev;       // state before this hop [B,C,S] or h0
+    int64_t hprev_bs;         // batch stride of Hprev (0 for a shared h0)
+    const int64_t* head; const int64_t* tail; int64_t idx_bs;
+    const float* gout;        // [B,C,L*dd]
+    float* gH;                // [B,C,S] in: grad wrt H^l (ignored when first), out: grad wrt H^l-1
+    float* gA;                // [B,S,S] or null
+    int32_t B, C, S, L, dd, act, CC, Sp, pitch, hop, first, chunks;
+};
+
+template <int MT, bool VEC4>
+__global__ void __launch_bounds__(kPT) k_propagate_bwd_hop(const PropBwdK p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int c0 = chunk * p.CC;
+    const int pitch = p.pitch, S = p.S, CC = p.CC;
+    float* X = lds;                                       // H^l, later H^l-1
+    float* Y = lds + static_cast<int64_t>(CC) * pitch;    // grad wrt H^l -> grad wrt pre-activation
+    for (int idx = tid; idx < CC * pitch; idx += kPT) {
+        const int cl = idx / pitch, s = idx % pitch;
+        const int c = c0 + cl;
+        const bool ok = c < p.C && s < S;
+        const int64_t g = (static_cast<int64_t>(b) * p.C + c) * S + s;
+        X[idx] = ok ? p.Hl[g] : 0.f;
+        Y[idx] = (ok && !p.first) ? p.gH[g] : 0.f;
+    }
+    __syncthreads();
+    // relation gradient: d(h[head]*h[tail])
+    for (int idx = tid; idx < CC * p.dd; idx += kPT) {
+        const int cl = idx / p.dd, x = idx % p.dd;
+        const int c = c0 + cl;
+        if (c < p.C) {
+            const int64_t io = b * p.idx_bs + static_cast<int64_t>(c) * p.dd + x;
+            const int hi = static_cast<int>(p.head[io]), ti = static_cast<int>(p.tail[io]);
+            const float g = p.gout[(static_cast<int64_t>(b) * p.C + c) * (p.L * p.dd) + p.hop * p.dd + x];
+            atomicAdd(&Y[cl * pitch + hi], g * X[cl * pitch + ti]);
+            atomicAdd(&Y[cl * pitch + ti], g * X[cl * pitch + hi]);
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < CC * pitch; idx += kPT) Y[idx] *= act_bwd(X[idx], p.act);
+    __syncthreads();
+    for (int idx = tid; idx < CC * pitch; idx += kPT) {
+        const int cl = idx / pitch, s = idx % pitch;
+        const int c = c0 + cl;
+        X[idx] = (c < p.C && s < S) ? p.Hprev[b * p.hprev_bs + static_cast<int64_t>(c) * S + s] : 0.f;
+    }
+    __syncthreads();
+    const int li = lane & 15, lq = lane >> 4;
+    const int NT = p.Sp >> 4;
+    // (i) gA[s][t] = sum_c Y[c][s] * X[c][t]       (M = s, N = t, K = channel)
+    if (p.gA) {
+        float* gA = p.gA + static_cast<int64_t>(b) * S * S;
+        for (int tile = wave; tile < NT * NT; tile += kPT / 64) {
+            const int ms = tile / NT, nt = tile % NT;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kc = 0; kc < CC; kc += 16) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int k = kc + 4 * lq + st;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Y[k * pitch + 16 * ms + li], X[k * pitch + 16 * nt + li], acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = 16 * ms + 4 * lq + r, t = 16 * nt + li;
+                if (s < S && t < S) {
+                    if (p.chunks == 1) gA[static_cast<int64_t>(s) * S + t] = acc[r];
+                    else atomicAdd(&gA[static_cast<int64_t>(s) * S + t], acc[r]);
+                }
+            }
+        }
+    }
+    // (ii) gHprev[c][t] = sum_s Y[c][s] * A[s][t]    (M = channel, N = t, K = s)
+    {
+        const float* A = p.A + static_cast<int64_t>(b) * S * S;
+        for (int nt = wave; nt < NT; nt += kPT / 64) {
+            f32x4 acc[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int col = 16 * nt + li;
+            for (int slab = 0; slab < NT; ++slab) {
+                const int kc = 16 * slab + 4 * lq;
+                float bq[4];
+#pragma unroll
+                for (int st = 0; st < 4; ++st) bq[st] = (kc + st < S && col < S) ? A[static_cast<int64_t>(kc + st) * S + col] : 0.f;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float4 aq = *reinterpret_cast<const float4*>(Y + (16 * m + li) * pitch + kc);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, bq[0], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, bq[1], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, bq[2], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, bq[3], acc[m], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = c0 + 16 * m + 4 * lq + r;
+                    if (c < p.C && col < S) p.gH[(static_cast<int64_t>(b) * p.C + c) * S + col] = acc[m][r];
+                }
+        }
+    }
+}
+
+struct PropGeom { int CC, Sp, pitch, chunks, MT; size_t lds; };
+bool prop_geometry(int C, int S, PropGeom* g) {
+    g->Sp = (S + 15) / 16 * 16;
+    g->pitch = g->Sp + 4;
+    const int Cp = (C + 15) / 16 * 16;
+    int cc = Cp < 80 ? Cp : 80;                                     // <= 5 MFMA row tiles per block
+    while (cc > 16 && 2ull * cc * g->pitch * sizeof(float) > 120 * 1024) cc -= 16;
+    if (2ull * cc * g->pitch * sizeof(float) > 160 * 1024) return false;
+    g->CC = cc;
+    g->MT = cc / 16;
+    g->chunks = (C + cc - 1) / cc;
+    g->lds = 2ull * cc * g->pitch * sizeof(float);
+    return true;
+}
+
+int check_prop(const recon_prop_args* a) {
+    if (!a) return RECON_ERR_INVALID;
+    if (a->B < 0 || a->C <= 0 || a->S <= 0 || a->L <= 0 || a->dd <= 0) return RECON_ERR_INVALID;
+    if (a->L > kMaxHops) return RECON_ERR_UNSUPPORTED;
+    if (a->B > 65535) return RECON_ERR_UNSUPPORTED;
+    if (a->act < 0 || a->act > 2) return RECON_ERR_INVALID;
+    if (!a->adj || !a->h0 || !a->head_idx || !a->tail_idx || !a->out) return RECON_ERR_INVALID;
+    for (int l = 0; l < a->L; ++l) if (!a->adj[l]) return RECON_ERR_INVALID;
+    return RECON_OK;
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+}  // namespace recon
+
+using namespace recon;
+
+extern "C" int recon_block_adjacency_fwd(const float* T, const float* identity, int32_t B, int32_t n, int32_t dd, float* A,
+                                         recon_stream_t stream) {
+    if (B < 0 || n < 1 || dd < 1 || !identity || !A || (n > 1 && B > 0 && !T)) return RECON_ERR_INVALID;
+    const int64_t total = 1LL * B * n * dd * n * dd;
+    if (total == 0) return RECON_OK;
+    hipLaunchKernelGGL(k_block_adj_fwd, dim3(static_cast<unsigned>(ceil_div64(total, 256))), dim3(256), 0, as_stream(stream), T,
+                       identity, B, n, dd, A);
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+extern "C" int recon_block_adjacency_bwd(const float* gA, int32_t B, int32_t n, int32_t dd, float* gT, float* g_identity,
+                                         recon_stream_t stream) {
+    if (B < 0 || n < 1 || dd < 1 || !gA) return RECON_ERR_INVALID;
+    hipStream_t st = as_stream(stream);
+    const int64_t total = 1LL * B * n * (n - 1) * dd * dd;
+    if (gT && total > 0)
+        hipLaunchKernelGGL(k_block_adj_bwd_T, dim3(static_cast<unsigned>(ceil_div64(total, 256))), dim3(256), 0, st, gA, B, n, dd, gT);
+    if (g_identity) hipLaunchKernelGGL(k_block_adj_bwd_I, dim3(dd * dd), dim3(256), 0, st, gA, B, n, dd, g_identity);
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+extern "C" int recon_start_entity_embeddings(const float* ent, const int64_t* pos, const float* templ, int32_t B, int32_t n,
+                                             int32_t d, float* out, recon_stream_t stream) {
+    if (B < 0 || n < 2 || d < 1 || !ent || !pos || !templ || !out) return RECON_ERR_INVALID;
+    const int64_t total = 1LL * B * n * (n - 1) * 2 * d * n;
+    if (total == 0) return RECON_OK;
+    hipLaunchKernelGGL(k_start_entity, dim3(static_cast<unsigned>(ceil_div64(total, 256))), dim3(256), 0, as_stream(stream), ent, pos,
+                       templ, B, n, d, out);
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+#define RECON_DISPATCH_MT(MTV, V4, KERNEL, ...)                                                                        \
+    do {                                                                                                                \
+        switch (MTV) {                                                                                                  \
+            case 1: if (V4) hipLaunchKernelGGL((KERNEL<1, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<1, false>), __VA_ARGS__); break; \
+            case 2: if (V4) hipLaunchKernelGGL((KERNEL<2, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<2, false>), __VA_ARGS__); break; \
+            case 3: if (V4) hipLaunchKernelGGL((KERNEL<3, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<3, false>), __VA_ARGS__); break; \
+            case 4: if (V4) hipLaunchKernelGGL((KERNEL<4, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<4, false>), __VA_ARGS__); break; \
+            default: if (V4) hipLaunchKernelGGL((KERNEL<5, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<5, false>), __VA_ARGS__); break; \
+        }                                                                                                               \
+    } while (0)
+
+extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stream) {
+    int rc = check_prop(a);
+    if (rc != RECON_OK) return rc;
+    if (a->B == 0) return RECON_OK;
+    PropGeom g;
+    if (!prop_geometry(a->C, a->S, &g)) return RECON_ERR_UNSUPPORTED;
+    PropK p;
+    bool v4 = (a->S % 4) == 0;
+    for (int l = 0; l < kMaxHops; ++l) { p.adj[l] = l < a->L ? a->adj[l] : nullptr; if (l < a->L && !al16(a->adj[l])) v4 = false; }
+    p.h0 = a->h0; p.h0_bs = a->h0_batch_stride; p.head = a->head_idx; p.tail = a->tail_idx; p.idx_bs = a->idx_batch_stride;
+    p.out = a->out; p.hsave = a->h_saved;
+    p.B = a->B; p.C = a->C; p.S = a->S; p.L = a->L; p.dd = a->dd; p.act = a->act;
+    p.CC = g.CC; p.Sp = g.Sp; p.pitch = g.pitch;
+    dim3 grid(static_cast<unsigned>(g.chunks), static_cast<unsigned>(a->B));
+    hipStream_t st = as_stream(stream);
+    if (g.lds > 64 * 1024) {
+#define SET_ATTR(MTV, V)                                                                                             \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_fwd<MTV, V>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                        static_cast<int>(g.lds))
+        switch (g.MT) { case 1: SET_ATTR(1, true); SET_ATTR(1, false); break; case 2: SET_ATTR(2, true); SET_ATTR(2, false); break;
+                        case 3: SET_ATTR(3, true); SET_ATTR(3, false); break; case 4: SET_ATTR(4, true); SET_ATTR(4, false); break;
+                        default: SET_ATTR(5, true); SET_ATTR(5, false); break; }
+#undef SET_ATTR
+    }
+    RECON_DISPATCH_MT(g.MT, v4, k_propagate_fwd, grid, dim3(kPT), g.lds, st, p);
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t stream) {
+    if (!ba) return RECON_ERR_INVALID;
+    const recon_prop_args* a = &ba->fwd;
+    int rc = check_prop(a);
+    if (rc != RECON_OK) return rc;
+    if (!a->h_saved || !ba->grad_out || !ba->g_h) return RECON_ERR_INVALID;
+    if (a->B == 0) return RECON_OK;
+    PropGeom g;
+    if (!prop_geometry(a->C, a->S, &g)) return RECON_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const int64_t BCS = 1LL * a->B * a->C * a->S;
+    dim3 grid(static_cast<unsigned>(g.chunks), static_cast<unsigned>(a->B));
+    if (g.lds > 64 * 1024) {
+#define SET_ATTR(MTV, V)                                                                                                 \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_bwd_hop<MTV, V>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                        static_cast<int>(g.lds))
+        switch (g.MT) { case 1: SET_ATTR(1, true); SET_ATTR(1, false); break; case 2: SET_ATTR(2, true); SET_ATTR(2, false); break;
+                        case 3: SET_ATTR(3, true); SET_ATTR(3, false); break; case 4: SET_ATTR(4, true); SET_ATTR(4, false); break;
+                        default: SET_ATTR(5, true); SET_ATTR(5, false); break; }
+#undef SET_ATTR
+    }
+    for (int l = a->L; l >= 1; --l) {
+        PropBwdK p;
+        p.A = a->adj[l - 1];
+        p.Hl = a->h_saved + static_cast<int64_t>(l - 1) * BCS;
+        if (l == 1) { p.Hprev = a->h0; p.hprev_bs = a->h0_batch_stride; }
+        else { p.Hprev = a->h_saved + static_cast<int64_t>(l - 2) * BCS; p.hprev_bs = 1LL * a->C * a->S; }
+        p.head = a->head_idx; p.tail = a->tail_idx; p.idx_bs = a->idx_batch_stride;
+        p.gout = ba->grad_out; p.gH = ba->g_h;
+        p.gA = ba->g_adj ? ba->g_adj[l - 1] : nullptr;
+        p.B = a->B; p.C = a->C; p.S = a->S; p.L = a->L; p.dd = a->dd; p.act = a->act;
+        p.CC = g.CC; p.Sp = g.Sp; p.pitch = g.pitch; p.hop = l - 1; p.first = (l == a->L) ? 1 : 0; p.chunks = g.chunks;
+        if (p.gA && g.chunks > 1) hipMemsetAsync(p.gA, 0, sizeof(float) * a->B * a->S * a->S, st);
+        RECON_DISPATCH_MT(g.MT, false, k_propagate_bwd_hop, grid, dim3(kPT), g.lds, st, p);
+        RECON_CHECK_LAUNCH();
+    }
+    return RECON_OK;
+}
+
+// ------------------------------------------------------------------------------- P5 / K6 GraphConvolution
+namespace {
+
+// Y[b][i][o] = epilogue( sum_j M[i][j] * Xin[b][j][o] ),  M = adj[b] (TRANS = false) or adj[b]^T (TRANS = true).
+// Block = (graph, 64-column tile); thread = one column x 4 consecutive rows per pass.
+// MASK: Xin = gout * (fwd_out > 0)   (ReLU backward folded into the load)
+// EPI : + bias, ReLU
+template <bool TRANS, bool MASK, bool EPI>
+__global__ void __launch_bounds__(256) k_gcn_aggregate(const float* __restrict__ adj, const float* __restrict__ Xin,
+                                                       const float* __restrict__ fwd_out, const float* __restrict__ bias,
+                                                       int32_t n, int32_t O, float* __restrict__ Y) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int np = (n + 3) / 4 * 4;
+    float* MT_ = lds;                       // [n][np]  MT_[j][i] = M[i][j]
+    float* Xs = lds + n * np;               // [n][64]
+    const int b = blockIdx.y, o0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const float* A = adj + static_cast<int64_t>(b) * n * n;
+    for (int idx = threadIdx.x; idx < n * np; idx += 256) {
+        const int j = idx / np, i = idx % np;
+        MT_[idx] = (i < n) ? (TRANS ? A[j * n + i] : A[i * n + j]) : 0.f;
+    }
+    for (int idx = threadIdx.x; idx < n * 64; idx += 256) {
+        const int j = idx / 64, o = o0 + (idx & 63);
+        float v = 0.f;
+        if (o < O) {
+            const int64_t g = (static_cast<int64_t>(b) * n + j) * O + o;
+            v = Xin[g];
+            if constexpr (MASK) v = fwd_out[g] > 0.f ? v : 0.f;
+        }
+        Xs[idx] = v;
+    }
+    __syncthreads();
+    const int o = o0 + tx;
+    for (int i0 = ty * 4; i0 < n; i0 += 16) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < n; ++j) {
+            const float x = Xs[j * 64 + tx];
+            const float4 m = *reinterpret_cast<const float4*>(MT_ + j * np + i0);
+            acc[0] = fmaf(m.x, x, acc[0]); acc[1] = fmaf(m.y, x, acc[1]);
+            acc[2] = fmaf(m.z, x, acc[2]); acc[3] = fmaf(m.w, x, acc[3]);
+        }
+        if (o < O) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (i0 + r < n) {
+                    float v = acc[r];
+                    if constexpr (EPI) { if (bias) v += bias[o]; v = v > 0.f ? v : 0.f; }
+                    Y[(static_cast<int64_t>(b) * n + i0 + r) * O + o] = v;
+                }
+            }
+        }
+    }
+}
+
+// g_adj[b][i][j] = sum_o gpre[b][i][o] * support[b][j][o]
+__global__ void __launch_bounds__(256) k_gcn_grad_adj(const float* __restrict__ gout, const float* __restrict__ fwd_out,
+                                                      const float* __restrict__ sup, int32_t n, int32_t O,
+                                                      float* __restrict__ gadj) {
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    const int i = idx / n, j = idx % n;
+    const int64_t ri = (static_cast<int64_t>(b) * n + i) * O, rj = (static_cast<int64_t>(b) * n + j) * O;
+    float s = 0.f;
+    for (int o = 0; o < O; ++o) s = fmaf(fwd_out[ri + o] > 0.f ? gout[ri + o] : 0.f, sup[rj + o], s);
+    gadj[static_cast<int64_t>(b) * n * n + idx] = s;
+}
+
+// g_bias[o] = sum_rows gpre[row][o]: per-block partial rows, then a fixed-order second pass
+__global__ void __launch_bounds__(256) k_gcn_bias_partial(const float* __restrict__ gout, const float* __restrict__ fwd_out,
+                                                          int64_t rows, int32_t O, int32_t rows_per_block,
+                                                          float* __restrict__ partial) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= O) return;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += fwd_out[r * O + o] > 0.f ? gout[r * O + o] : 0.f;
+    partial[static_cast<int64_t>(blockIdx.y) * O + o] = s;
+}
+__global__ void k_sum_rows(const float* __restrict__ partial, int32_t nrows, int32_t O, float* __restrict__ out) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= O) return;
+    float s = 0.f;
+    for (int r = 0; r < nrows; ++r) s += partial[static_cast<int64_t>(r) * O + o];
+    out[o] = s;
+}
+
+int check_gcn(const recon_gcn_args* a) {
+    if (!a || a->B < 0 || a->n <= 0 || a->in_features <= 0 || a->out_features <= 0) return RECON_ERR_INVALID;
+    if (!a->x || !a->adj || !a->weight || !a->support || !a->out) return RECON_ERR_INVALID;
+    if (a->B > 65535) return RECON_ERR_UNSUPPORTED;
+    const size_t lds = (static_cast<size_t>(a->n) * ((a->n + 3) / 4 * 4) + static_cast<size_t>(a->n) * 64) * sizeof(float);
+    if (lds > 64 * 1024) return RECON_ERR_UNSUPPORTED;
+    return RECON_OK;
+}
+size_t gcn_lds(int n) { return (static_cast<size_t>(n) * ((n + 3) / 4 * 4) + static_cast<size_t>(n) * 64) * sizeof(float); }
+constexpr int kBiasBlocks = 256;
+
+}  // namespace
+
+extern "C" int recon_gcn_fwd(const recon_gcn_args* a, recon_stream_t stream) {
+    int rc = check_gcn(a);
+    if (rc != RECON_OK) return rc;
+    if (a->B == 0) return RECON_OK;
+    hipStream_t st = as_stream(stream);
+    const int32_t rows = a->B * a->n, I = a->in_features, O = a->out_features;
+    // support = x @ W      (models/layers.py:58)
+    rc = gemm_f32(rows, O, I, plain_operand(a->x, I), true, plain_operand(a->weight, O), false, plain_output(a->support, O), 1,
+                  nullptr, st);
+    if (rc != RECON_OK) return rc;
+    // out = relu(adj @ support + bias)     (models/layers.py:59-63)
+    dim3 grid(static_cast<unsigned>(ceil_div64(O, 64)), static_cast<unsigned>(a->B));
+    hipLaunchKernelGGL((k_gcn_aggregate<false, false, true>), grid, dim3(256), gcn_lds(a->n), st, a->adj, a->support, nullptr, a->bias,
+                       a->n, O, a->out);
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+extern "C" size_t recon_gcn_bwd_partial_floats(int32_t B, int32_t n, int32_t in_features, int32_t out_features) {
+    size_t need = static_cast<size_t>(kBiasBlocks) * out_features;
+    const int sk = gemm_pick_split_k(in_features, out_features, B * n);
+    const size_t g = static_cast<size_t>(sk > 1 ? sk : 0) * in_features * out_features;
+    return g > need ? g : need;
+}
+
+extern "C" int recon_gcn_bwd(const recon_gcn_bwd_args* b, recon_stream_t stream) {
+    if (!b) return RECON_ERR_INVALID;
+    const recon_gcn_args* a = &b->fwd;
+    int rc = check_gcn(a);
+    if (rc != RECON_OK) return rc;
+    if (!b->grad_out || !b->g_support || !b->partial) return RECON_ERR_INVALID;
+    if (a->B == 0) return RECON_OK;
+    hipStream_t st = as_stream(stream);
+    const int32_t rows = a->B * a->n, I = a->in_features, O = a->out_features, n = a->n;
+    dim3 grid(static_cast<unsigned>(ceil_div64(O, 64)), static_cast<unsigned>(a->B));
+    // g_support = adj^T @ (grad_out * (out > 0))
+    hipLaunchKernelGGL((k_gcn_aggregate<true, true, false>), grid, dim3(256), gcn_lds(n), st, a->adj, b->grad_out, a->out, nullptr, n, O,
+                       b->g_support);
+    if (b->g_adj)
+        hipLaunchKernelGGL(k_gcn_grad_adj, dim3(static_cast<unsigned>(ceil_div64(n * n, 256)), static_cast<unsigned>(a->B)), dim3(256), 0,
+                           st, b->grad_out, a->out, a->support, n, O, b->g_adj);
+    if (b->g_bias) {
+        const int rpb = static_cast<int>(ceil_div64(rows, kBiasBlocks));
+        const int nb = static_cast<int>(ceil_div64(rows, rpb));
+        hipLaunchKernelGGL(k_gcn_bias_partial, dim3(static_cast<unsigned>(ceil_div64(O, 256)), static_cast<unsigned>(nb)), dim3(256), 0, st,
+                           b->grad_out, a->out, static_cast<int64_t>(rows), O, rpb, b->partial);
+        hipLaunchKernelGGL(k_sum_rows, dim3(static_cast<unsigned>(ceil_div64(O, 256))), dim3(256), 0, st, b->partial, nb, O, b->g_bias);
+    }
+    RECON_CHECK_LAUNCH();
+    // g_x = g_support @ W^T
+    if (b->g_x) {
+        rc = gemm_f32(rows, I, O, plain_operand(b->g_support, O), true, plain_operand(a->weight, O), true, plain_output(b->g_x, I), 1,
+                      nullptr, st);
+        if (rc != RECON_OK) return rc;
+    }
+    // g_W = x^T @ g_support   (split-K over the B*n rows, deterministic second pass)
+    if (b->g_weight) {
+        const int sk = gemm_pick_split_k(I, O, rows);
+        rc = gemm_f32(I, O, rows, plain_operand(a->x, I), false, plain_operand(b->g_support, O), false, plain_output(b->g_weight, O), sk,
+                      b->partial, st);
+        if (rc != RECON_OK) return rc;
+    }
+    return RECON_OK;
+}

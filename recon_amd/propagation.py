@@ -1,0 +1,224 @@
+"""GP-GNN propagation step.  The reference has no module for it: the block is inlined four times in
+models/models.py (GPGNN :238-277, RECON_EAC :447-487, RECON_EAC_KGGAT :657-701, RECON :895-968).
+This module offers the same arithmetic as functions with the reference's tensor conventions, running
+in the gfx950 kernels of csrc/prop.hip:
+
+    build_block_adjacency(T, identity, n)            models/models.py:240-259
+    propagate(adj_list, h0, nonlinearity, head_indices, tail_indices)     :260-274
+    make_start_embedding / get_head_indices / get_tail_indices            utils/embedding_utils.py:170-202
+    make_start_entity_embeddings                     utils/context_utils.py:387-426
+    build_adjecent_matrix                            utils/build_adjecent_matrix.py:6-17
+
+No CPU path: the tensor functions require GPU tensors.
+"""
+import ctypes as C
+import itertools
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _req(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("recon_amd: expected a GPU tensor (this package has no CPU path)")
+        if t.is_floating_point() and t.dtype != torch.float32:
+            raise TypeError("recon_amd: the HIP kernels compute in float32, got %s" % t.dtype)
+
+
+# ------------------------------------------------------------------------------- host-side index builders
+def _pairs(n):
+    return [(i, j) for i in range(n) for j in range(n) if i != j]     # channel order, conversion_util.py:6-20
+
+
+def make_start_embedding(n, d):
+    """[n(n-1), 2dn, 1] float64 numpy array, as utils/embedding_utils.py:170-182 returns it."""
+    v = np.zeros((n * (n - 1), 2 * d * n, 1), dtype=np.float64)
+    for c, (i, j) in enumerate(_pairs(n)):
+        v[c, 2 * d * i: 2 * d * i + d, 0] = 1.0
+        v[c, 2 * d * j + d: 2 * d * (j + 1), 0] = 1.0
+    return v
+
+
+def get_head_indices(n, d, bs=50):
+    """utils/embedding_utils.py:184-192 (nested lists of ranges there; an int64 array here)."""
+    rows = np.asarray([list(range(2 * d * i, 2 * d * (i + 1))) for i, _ in _pairs(n)], dtype=np.int64)
+    return np.tile(rows[None], (bs, 1, 1))
+
+
+def get_tail_indices(n, d, bs=50):
+    """utils/embedding_utils.py:194-202."""
+    rows = np.asarray([list(range(2 * d * j, 2 * d * (j + 1))) for _, j in _pairs(n)], dtype=np.int64)
+    return np.tile(rows[None], (bs, 1, 1))
+
+
+def build_adjecent_matrix(n, size=72):
+    """utils/build_adjecent_matrix.py:6-17 -> torch.FloatTensor [72,72] (row-normalised line graph)."""
+    A = np.zeros((size, size), dtype=np.float32)
+    V = list(itertools.permutations(range(n), 2))
+    for i, x in enumerate(V):
+        for j, y in enumerate(V):
+            A[i, j] = 1.0 if (x[0] == y[1] or x[1] == y[0] or i == j) else 0.0
+        s = A[i].sum()
+        if s != 0:
+            A[i] /= s
+    return torch.from_numpy(A)
+
+
+# ------------------------------------------------------------------------------- P1
+class _BlockAdjacency(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, T, identity, n):
+        _req(T, identity)
+        T, identity = T.contiguous(), identity.contiguous()
+        B = T.shape[0]
+        dd = identity.shape[0]
+        if T.numel() != B * n * (n - 1) * dd * dd:
+            raise ValueError("T must hold B x n(n-1) transition matrices of %dx%d" % (dd, dd))
+        A = torch.empty(B, n * dd, n * dd, dtype=torch.float32, device=T.device)
+        with torch.cuda.device(T.device):
+            _lib.check(_lib.lib().recon_block_adjacency_fwd(T.data_ptr(), identity.data_ptr(), B, n, dd, A.data_ptr(),
+                                                            _lib.current_stream()), "recon_block_adjacency_fwd")
+        ctx.dims = (B, n, dd, tuple(T.shape))
+        return A
+
+    @staticmethod
+    def backward(ctx, gA):
+        B, n, dd, tshape = ctx.dims
+        gA = gA.contiguous()
+        gT = torch.empty(tshape, dtype=torch.float32, device=gA.device) if ctx.needs_input_grad[0] else None
+        gI = torch.empty(dd, dd, dtype=torch.float32, device=gA.device) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(gA.device):
+            _lib.check(_lib.lib().recon_block_adjacency_bwd(gA.data_ptr(), B, n, dd, _lib.ptr(gT), _lib.ptr(gI),
+                                                            _lib.current_stream()), "recon_block_adjacency_bwd")
+        return gT, gI, None
+
+
+def build_block_adjacency(T, identity, n):
+    """models/models.py:240-259: T [B, n-1, n, (2d)^2] or [B, n(n-1), (2d)^2] (AFTER the non-linearity),
+    identity [2d,2d] -> A [B, S, S], A[b, i*2d+r, j*2d+c] = T[b, e(i,j)].view(2d,2d)[r,c], identity on the
+    diagonal blocks."""
+    return _BlockAdjacency.apply(T, identity, n)
+
+
+# ------------------------------------------------------------------------------- P2
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+class _Propagate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h0, act, head, tail, *adjs):
+        _req(h0, head, tail, *adjs)
+        L = len(adjs)
+        adj_shapes = [tuple(a.shape) for a in adjs]
+        adjs = [a.contiguous().view(a.shape[0], a.shape[-2], a.shape[-1]) for a in adjs]   # accepts [B,1,S,S]
+        B, S = adjs[0].shape[0], adjs[0].shape[-1]
+        h0c = h0.contiguous()
+        if h0c.dim() == 4:            # [B, C, S, 1]   (RECON*: models/models.py:470)
+            Cn = h0c.shape[1]
+            h0_bs = Cn * S
+        else:                         # [C, S, 1]      (GPGNN: models/models.py:260)
+            Cn = h0c.shape[0]
+            h0_bs = 0
+        head, tail = head.contiguous(), tail.contiguous()
+        dd = head.shape[-1]
+        idx_bs = Cn * dd if head.dim() == 3 and head.shape[0] > 1 else 0
+        if head.dim() == 3 and head.shape[0] < B and head.shape[0] > 1:
+            raise ValueError("head/tail indices hold %d batch rows but the batch has %d" % (head.shape[0], B))
+        dev = h0.device
+        out = torch.empty(B, Cn, L * dd, dtype=torch.float32, device=dev)
+        need = any(ctx.needs_input_grad)
+        hs = torch.empty(L, B, Cn, S, dtype=torch.float32, device=dev) if need else None
+        parr = _ptr_array(adjs)
+        args = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], parr, h0c.data_ptr(), h0_bs, head.data_ptr(),
+                             tail.data_ptr(), idx_bs, out.data_ptr(), _lib.ptr(hs))
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().recon_propagate_fwd(C.byref(args), _lib.current_stream()), "recon_propagate_fwd")
+        if need:
+            ctx.save_for_backward(h0c, head, tail, hs, *adjs)
+            ctx.meta = (B, Cn, S, L, dd, act, h0_bs, idx_bs, tuple(h0.shape), adj_shapes)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        h0c, head, tail, hs, *adjs = ctx.saved_tensors
+        B, Cn, S, L, dd, act, h0_bs, idx_bs, h0_shape, adj_shapes = ctx.meta
+        dev = gout.device
+        gout = gout.contiguous()
+        g_adjs = [torch.empty(B, S, S, dtype=torch.float32, device=dev) if ctx.needs_input_grad[4 + l] else None
+                  for l in range(L)]
+        g_h = torch.empty(B, Cn, S, dtype=torch.float32, device=dev)
+        parr, garr = _ptr_array(adjs), _ptr_array(g_adjs)
+        fwd = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], parr, h0c.data_ptr(), h0_bs, head.data_ptr(), tail.data_ptr(),
+                            idx_bs, None, hs.data_ptr())
+        fwd.out = gout.data_ptr()      # unused by the backward; must be non-null for the argument check
+        args = _lib.PropBwdArgs(fwd, gout.data_ptr(), garr, g_h.data_ptr())
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().recon_propagate_bwd(C.byref(args), _lib.current_stream()), "recon_propagate_bwd")
+        g_h0 = None
+        if ctx.needs_input_grad[0]:
+            g_h0 = (g_h if h0_bs else g_h.sum(0)).view(h0_shape)
+        return (g_h0, None, None, None) + tuple(g.view(sh) if g is not None else None for g, sh in zip(g_adjs, adj_shapes))
+
+
+def propagate(adj_list, h0, nonlinearity, head_indices, tail_indices):
+    """models/models.py:260-274.  adj_list: L tensors [B,S,S] (or [B,1,S,S] as the reference views them);
+    h0 [C,S,1] shared (GPGNN) or [B,C,S,1] per batch (RECON*); nonlinearity 'relu' | 'tanh' | 'linear'
+    (model_params.json "non-linear1"); head/tail_indices int64 [C,2d] or [bs,C,2d] as the reference
+    stores them.  Returns cat(relation_1..L, -1): [B, C, 2d*L]."""
+    if nonlinearity not in _lib.ACT:
+        raise NotImplementedError(nonlinearity)
+    return _Propagate.apply(h0, nonlinearity, head_indices, tail_indices, *adj_list)
+
+
+# ------------------------------------------------------------------------------- P4
+def make_start_entity_embeddings(entity_embeddings, entity_pos_indices, unique_entities, embedding_dim,
+                                 max_occurred_entity_in_batch_pos, start_embedding_template, max_num_nodes=9):
+    """utils/context_utils.py:387-426, same argument list (unique_entities and the most-frequent-entity
+    hint only steer a speed trick there and do not change the result).  Returns [B, C, 2dn, 1].
+    Forward only on the GPU kernel; gradients to `entity_embeddings` flow through an index_add."""
+    _req(entity_embeddings, start_embedding_template)
+    n, d = max_num_nodes, embedding_dim
+    B, Cn = entity_pos_indices.shape[:2]
+    S = 2 * d * n
+    pos = entity_pos_indices.to(device=entity_embeddings.device, dtype=torch.int64).contiguous()
+    return _StartEntity.apply(entity_embeddings, pos, start_embedding_template.contiguous().view(Cn, S), B, n, d)
+
+
+class _StartEntity(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ent, pos, templ, B, n, d):
+        ent = ent.contiguous()
+        Cn, S = n * (n - 1), 2 * d * n
+        out = torch.empty(B, Cn, S, 1, dtype=torch.float32, device=ent.device)
+        with torch.cuda.device(ent.device):
+            _lib.check(_lib.lib().recon_start_entity_embeddings(ent.data_ptr(), pos.data_ptr(), templ.data_ptr(), B, n, d,
+                                                                out.data_ptr(), _lib.current_stream()),
+                       "recon_start_entity_embeddings")
+        ctx.save_for_backward(pos, templ)
+        ctx.dims = (B, n, d, ent.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, templ = ctx.saved_tensors
+        B, n, d, U = ctx.dims
+        Cn, S = n * (n - 1), 2 * d * n
+        g = (g.view(B, Cn, S) * templ).view(B, Cn, n, 2, d)
+        pi = torch.tensor([i for i in range(n) for j in range(n) if i != j], device=g.device)
+        pj = torch.tensor([j for i in range(n) for j in range(n) if i != j], device=g.device)
+        ar = torch.arange(Cn, device=g.device)
+        g_first = g[:, ar, pi, 0]          # [B,C,d]  node i, first half-slot
+        g_second = g[:, ar, pj, 1]         # [B,C,d]  node j, second half-slot
+        ge = torch.zeros(U, d, dtype=torch.float32, device=g.device)
+        ge.index_add_(0, pos[..., 0].reshape(-1), g_first.reshape(-1, d))
+        ge.index_add_(0, pos[..., 1].reshape(-1), g_second.reshape(-1, d))
+        return ge, None, None, None, None, None

@@ -1,0 +1,186 @@
+"""GPU parity tests for the GP-GNN side: block adjacency, L-hop propagation (+ head*tail gather),
+start-entity embeddings and GraphConvolution — HIP kernels vs golden vectors from the reference and
+vs the CPU oracle.  fp32 tolerance 1e-4 abs on outputs (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, hashed_uniform
+from oracle import recon_oracle as O
+from test_gat_gpu import close, dev
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _prop_inputs(g):
+    n, d, L, B, salt = (int(g[k]) for k in ("n", "d", "L", "B", "salt"))
+    C, S, dd = n * (n - 1), 2 * d * n, (2 * d) ** 2
+    Ts = [T(hashed_uniform((B, C, dd), salt * 10 + i, -0.6, 1.0)) for i in range(L)]
+    per_batch = "g_h0_sum" in g
+    h0 = T(g["h0_shared"])
+    if per_batch:
+        h0 = T(hashed_uniform((B, C, S, 1), salt * 10 + 8)) * h0
+    Gr = T(hashed_uniform(g["out"].shape, int(g["G_salt"])))
+    return n, d, L, B, Ts, h0, Gr, per_batch
+
+
+@pytest.mark.parametrize("name", ["prop_n4d2_shared", "prop_n4d2_perbatch", "prop_n9d8_shared", "prop_n9d8_perbatch"])
+def test_propagation_golden(name):
+    """The reference's GPGNN untied branch (models/models.py:238-277), replayed through the drop-in
+    functions: relu -> build_block_adjacency -> propagate, outputs and all gradients."""
+    from recon_amd.propagation import build_block_adjacency, propagate
+    g = load_golden(name)
+    d_ = dev()
+    n, d, L, B, Ts, h0, Gr, per_batch = _prop_inputs(g)
+    Ts = [t.to(d_).requires_grad_(True) for t in Ts]
+    ident = T(g["identity"]).to(d_).requires_grad_(True)
+    h0 = h0.to(d_).requires_grad_(per_batch)
+    adjs = [build_block_adjacency(torch.relu(t), ident, n) for t in Ts]
+    for l in range(L):
+        np.testing.assert_array_equal(adjs[l][0].detach().cpu().numpy(), g["adj_b0"][l])
+        np.testing.assert_array_equal(adjs[l][B - 1].detach().cpu().numpy(), g["adj_bl"][l])
+    head = T(np.tile(g["head_indices"][None], (B, 1, 1))).to(d_)       # the reference stores [bs, C, 2d]
+    tail = T(np.tile(g["tail_indices"][None], (B, 1, 1))).to(d_)
+    out = propagate([a.view(B, 1, a.shape[1], a.shape[2]) for a in adjs], h0, "relu", head, tail)
+    close(out, g["out"], what=name + " out")
+    (out * Gr.to(d_)).sum().backward()
+    close(ident.grad, g["g_identity"], atol=1e-4, what="g_identity")
+    for l in range(L):
+        close(Ts[l].grad[0], g["g_T_b0"][l], atol=1e-5, what="g_T[%d][0]" % l)
+        close(Ts[l].grad.sum(0), g["g_T_sum"][l], atol=1e-4, what="sum_b g_T[%d]" % l)
+        if "g_T" in g:
+            close(Ts[l].grad, g["g_T"][l], atol=1e-5, what="g_T[%d]" % l)
+    if per_batch:
+        close(h0.grad[0], g["g_h0_b0"], atol=1e-5, what="g_h0[0]")
+        close(h0.grad.sum(0), g["g_h0_sum"], atol=1e-4, what="sum_b g_h0")
+
+
+@pytest.mark.parametrize("n,d,L,B,act,per_batch", [
+    (3, 2, 1, 2, "relu", False),       # S = 12: padded to one 16-wide MFMA tile
+    (5, 3, 3, 3, "tanh", True),        # S = 30: not a multiple of 4 -> scalar loads
+    (9, 8, 3, 5, "linear", True),      # model_params.json sizes
+    (6, 4, 4, 1, "relu", True),        # B = 1, 4 hops
+    (12, 4, 2, 2, "relu", False),      # C = 132 > 80: two channel chunks per graph
+])
+def test_propagation_vs_oracle(n, d, L, B, act, per_batch):
+    from recon_amd.propagation import build_block_adjacency, propagate, make_start_embedding, get_head_indices, get_tail_indices
+    d_ = dev()
+    C, S, dd = n * (n - 1), 2 * d * n, 2 * d
+    g = torch.Generator().manual_seed(n * 100 + d)
+    Ts = [(torch.rand(B, C, dd * dd, generator=g) - 0.4) * 0.5 for _ in range(L)]
+    ident = torch.eye(dd) + 0.05 * torch.randn(dd, dd, generator=g)
+    tmpl = torch.from_numpy(make_start_embedding(n, d)).float()
+    h0 = (torch.randn(B, C, S, 1, generator=g) * tmpl) if per_batch else tmpl
+    head = torch.from_numpy(get_head_indices(n, d, bs=1)[0])
+    tail = torch.from_numpy(get_tail_indices(n, d, bs=1)[0])
+    Gr = torch.randn(B, C, dd * L, generator=g)
+
+    def run(device, build, prop):
+        Tl = [t.clone().to(device).requires_grad_(True) for t in Ts]
+        I = ident.clone().to(device).requires_grad_(True)
+        h = h0.clone().to(device).requires_grad_(per_batch)
+        adjs = [build(torch.relu(t), I, n) for t in Tl]
+        out = prop(adjs, h, act, head.to(device), tail.to(device))
+        (out * Gr.to(device)).sum().backward()
+        return out, [t.grad for t in Tl], I.grad, h.grad
+    out_r, gT_r, gI_r, gh_r = run("cpu", O.build_block_adjacency, O.propagate)
+    out_h, gT_h, gI_h, gh_h = run(d_, build_block_adjacency, propagate)
+    close(out_h, out_r, what="out")
+    close(gI_h, gI_r, atol=1e-5, what="g_identity")
+    for l in range(L):
+        close(gT_h[l], gT_r[l], atol=1e-5, what="g_T[%d]" % l)
+    if per_batch:
+        close(gh_h, gh_r, atol=1e-5, what="g_h0")
+
+
+def test_start_entity_embeddings_golden():
+    from recon_amd.propagation import make_start_entity_embeddings
+    g = load_golden("prop3_start_entity")
+    d_ = dev()
+    ent = T(g["entity_embeddings"]).to(d_).requires_grad_(True)
+    out = make_start_entity_embeddings(ent, T(g["pos"]).to(d_), None, int(g["d"]), int(g["max_occ"]), T(g["template"]).to(d_),
+                                       max_num_nodes=int(g["n"]))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), g["out"])
+    Gr = torch.randn(out.shape, generator=torch.Generator().manual_seed(3))
+    (out * Gr.to(d_)).sum().backward()
+    ent_c = T(g["entity_embeddings"]).requires_grad_(True)
+    ref = O.make_start_entity_embeddings(ent_c, T(g["pos"]), int(g["d"]), T(g["template"]), max_num_nodes=int(g["n"]))
+    (ref * Gr).sum().backward()
+    close(ent.grad, ent_c.grad, atol=1e-5, what="g_entity_embeddings")
+
+
+@pytest.mark.parametrize("name", ["gcn1_bias", "gcn1_nobias"])
+def test_gcn_golden(name):
+    """GraphConvolution drop-in (2-D reference form, 72x72 line-graph adjacency) vs the reference."""
+    from recon_amd.gcn_layers import GraphConvolution
+    g = load_golden(name)
+    d_ = dev()
+    has_bias = "bias" in g
+    layer = GraphConvolution(g["weight"].shape[0], g["weight"].shape[1], bias=has_bias).to(d_)
+    sd = {"weight": T(g["weight"])}
+    if has_bias:
+        sd["bias"] = T(g["bias"])
+    layer.load_state_dict(sd, strict=True)
+    x = T(g["x"]).to(d_).requires_grad_(True)
+    out = layer(x, T(g["adj"]).to(d_))
+    close(out, g["out"], atol=1e-5, what="gcn out")
+    (out * T(g["G"]).to(d_)).sum().backward()
+    close(x.grad, g["g_x"], atol=1e-5, what="g_x")
+    close(layer.weight.grad, g["g_weight"], atol=1e-5, what="g_weight")
+    if has_bias:
+        close(layer.bias.grad, g["g_bias"], atol=1e-5, what="g_bias")
+
+
+@pytest.mark.parametrize("B,n,I,O_", [(1, 9, 7, 5), (6, 32, 300, 300), (3, 17, 40, 130)])
+def test_gcn_batched_vs_oracle(B, n, I, O_):
+    from recon_amd.gcn_layers import GraphConvolution
+    d_ = dev()
+    g = torch.Generator().manual_seed(B * n)
+    x = torch.randn(B, n, I, generator=g)
+    adj = (torch.rand(B, n, n, generator=g) < 0.15).float() + torch.eye(n)
+    adj = adj / adj.sum(-1, keepdim=True)
+    torch.manual_seed(1)
+    layer = GraphConvolution(I, O_)
+    w, b = layer.weight.detach().clone(), layer.bias.detach().clone()
+    Gr = torch.randn(B, n, O_, generator=g)
+    xr, adjr, wr, br = (t.clone().requires_grad_(True) for t in (x, adj, w, b))
+    ref = O.graph_convolution(xr, adjr, wr, br)
+    (ref * Gr).sum().backward()
+    layer = layer.to(d_)
+    xd, adjd = x.to(d_).requires_grad_(True), adj.to(d_).requires_grad_(True)
+    out = layer(xd, adjd)
+    close(out, ref, what="gcn batched out")
+    (out * Gr.to(d_)).sum().backward()
+    close(xd.grad, xr.grad, atol=1e-5, what="g_x")
+    close(adjd.grad, adjr.grad, atol=1e-5, what="g_adj")
+    close(layer.weight.grad, wr.grad, atol=1e-5, what="g_weight")
+    close(layer.bias.grad, br.grad, atol=1e-5, what="g_bias")
+
+
+def test_propagation_full_size_properties():
+    """cfg 3b (B=1024, n=9, 2d=16, L=3): (i) a slice of graphs vs the oracle, (ii) graphs are independent,
+    (iii) zero transition matrices + identity diagonal leave h unchanged: relation = head*tail of h0."""
+    from recon_amd.propagation import build_block_adjacency, propagate, make_start_embedding, get_head_indices, get_tail_indices
+    d_ = dev()
+    n, d, L, B = 9, 8, 3, 1024
+    C, S, dd = n * (n - 1), 2 * d * n, 2 * d
+    g = torch.Generator().manual_seed(0)
+    Ts = [torch.relu(torch.randn(B, C, dd * dd, generator=g)) * 0.1 for _ in range(L)]
+    ident = torch.eye(dd)
+    tmpl = torch.from_numpy(make_start_embedding(n, d)).float()
+    h0 = torch.randn(B, C, S, 1, generator=g) * tmpl
+    head = torch.from_numpy(get_head_indices(n, d, bs=1)[0])
+    tail = torch.from_numpy(get_tail_indices(n, d, bs=1)[0])
+    adjs = [build_block_adjacency(t.to(d_), ident.to(d_), n) for t in Ts]
+    out = propagate(adjs, h0.to(d_), "relu", head.to(d_), tail.to(d_))
+    ref = O.propagate([O.build_block_adjacency(t[:3], ident, n) for t in Ts], h0[:3], "relu", head, tail)
+    close(out[:3], ref, what="cfg3b slice")
+    out2 = propagate([a[5:9].contiguous() for a in adjs], h0[5:9].to(d_), "relu", head.to(d_), tail.to(d_))
+    assert torch.equal(out2, out[5:9])
+    zero = [build_block_adjacency(torch.zeros(4, C, dd * dd, device=d_), ident.to(d_), n) for _ in range(L)]
+    h0p = h0[:4].abs().to(d_)
+    o3 = propagate(zero, h0p, "relu", head.to(d_), tail.to(d_))
+    flat = h0p.view(4, C, S)
+    expect = torch.gather(flat, 2, head.to(d_)[None].expand(4, -1, -1)) * torch.gather(flat, 2, tail.to(d_)[None].expand(4, -1, -1))
+    close(o3, expect.repeat(1, 1, L), atol=1e-6, what="identity propagation")
