@@ -1,0 +1,37 @@
+// Shared by the GEMM translation units: argument block and operand address maps.
+#pragma once
+#include "recon_common.h"
+
+namespace recon {
+
+struct GemmArgs {
+    OperandDesc A, B;
+    OutputDesc C;
+    int32_t M, N, K;
+    int32_t k_per_split;     // multiple of the kernel's K tile
+    float* partial;          // non-null => write plain [z][M][N]
+};
+
+__device__ __forceinline__ int64_t major_off(const OperandDesc& d, int32_t i) {
+    if (d.gather) return static_cast<int64_t>(d.gather[i]) * d.S1;
+    if (i < d.P) return static_cast<int64_t>(i) * d.S1;
+    return static_cast<int64_t>(i % d.P) * d.S1 + static_cast<int64_t>(i / d.P) * d.S2;
+}
+__device__ __forceinline__ int64_t minor_off(int32_t Dseg, int64_t Sseg, int32_t j) {
+    if (j < Dseg) return j;
+    return static_cast<int64_t>(j % Dseg) + static_cast<int64_t>(j / Dseg) * Sseg;
+}
+
+// row offset of output row `row` / epilogue store shared by both GEMM kernels
+__device__ __forceinline__ int64_t out_row_off(const OutputDesc& C, int32_t row) {
+    if (C.scatter) return static_cast<int64_t>(C.scatter[row]) * C.S1;
+    if (row < C.P) return static_cast<int64_t>(row) * C.S1;
+    return static_cast<int64_t>(row % C.P) * C.S1 + static_cast<int64_t>(row / C.P) * C.S2;
+}
+
+// split-precision (bf16 x 3) MFMA GEMM, gemm_bf16x3.hip.  Same contract as gemm_f32 but requires the
+// float4-aligned operand layouts (returns RECON_ERR_UNSUPPORTED otherwise; callers fall back).
+int gemm_bf16x3_launch(const GemmArgs& a, bool a_k_minor, bool b_k_minor, int32_t split_k, hipStream_t st);
+bool gemm_bf16x3_enabled();
+
+}  // namespace recon

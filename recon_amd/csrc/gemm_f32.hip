@@ -9,31 +9,13 @@
 // Global -> registers -> LDS staging with register prefetch of the next K tile; LDS tiles are
 // k-major ([16][128+4]) so both MFMA operand reads are conflict-free ds_read_b32.
 #include <stdlib.h>
-#include "recon_common.h"
+#include "gemm_common.h"
 
 namespace recon {
 namespace {
 
 constexpr int BK = 16, NT = 256;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-struct GemmArgs {
-    OperandDesc A, B;
-    OutputDesc C;
-    int32_t M, N, K;
-    int32_t k_per_split;     // multiple of BK
-    float* partial;          // non-null => write plain [z][M][N]
-};
-
-__device__ __forceinline__ int64_t major_off(const OperandDesc& d, int32_t i) {
-    if (d.gather) return static_cast<int64_t>(d.gather[i]) * d.S1;
-    if (i < d.P) return static_cast<int64_t>(i) * d.S1;
-    return static_cast<int64_t>(i % d.P) * d.S1 + static_cast<int64_t>(i / d.P) * d.S2;
-}
-__device__ __forceinline__ int64_t minor_off(int32_t Dseg, int64_t Sseg, int32_t j) {
-    if (j < Dseg) return j;
-    return static_cast<int64_t>(j % Dseg) + static_cast<int64_t>(j / Dseg) * Sseg;
-}
 
 // One operand tile: W (m or n extent, 128 or 224) x BK, staged global -> registers -> LDS [BK][W+4].
 //   K_MINOR : memory is contiguous along k   -> thread item = (row, k quad): 4 floats along k
@@ -262,19 +244,26 @@ int gemm_f32(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool a_k_min
     if (split_k > 1 && !partial) return RECON_ERR_INVALID;
     GemmArgs a;
     a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K;
+    const bool v4 = operand_vec4(A, a_k_minor ? K : M) && operand_vec4(B, b_k_minor ? K : N);
+    const bool use3 = v4 && gemm_bf16x3_enabled();                 // split-precision bf16 MFMA kernel (K tile 32)
+    const int bk = use3 ? 32 : BK;
     int64_t kps = ceil_div64(K > 0 ? K : 1, split_k);
-    kps = ceil_div64(kps, BK) * BK;
+    kps = ceil_div64(kps, bk) * bk;
     a.k_per_split = static_cast<int32_t>(kps);
     split_k = static_cast<int32_t>(ceil_div64(K > 0 ? K : 1, kps));
     a.partial = split_k > 1 ? partial : nullptr;
-    const bool v4 = operand_vec4(A, a_k_minor ? K : M) && operand_vec4(B, b_k_minor ? K : N);
-    const bool wide = use_wide_n(N);
-    dim3 grid(static_cast<unsigned>(ceil_div64(N, wide ? 224 : 128)), static_cast<unsigned>(ceil_div64(M, 128)),
-              static_cast<unsigned>(split_k));
-    if (a_k_minor && b_k_minor) { if (v4) launch<true, true, 4>(a, wide, grid, st); else launch<true, true, 1>(a, wide, grid, st); }
-    else if (a_k_minor && !b_k_minor) { if (v4) launch<true, false, 4>(a, wide, grid, st); else launch<true, false, 1>(a, wide, grid, st); }
-    else if (!a_k_minor && !b_k_minor) { if (v4) launch<false, false, 4>(a, wide, grid, st); else launch<false, false, 1>(a, wide, grid, st); }
-    else return RECON_ERR_UNSUPPORTED;
+    if (use3) {
+        const int rc = gemm_bf16x3_launch(a, a_k_minor, b_k_minor, split_k, st);
+        if (rc != RECON_OK) return rc;
+    } else {
+        const bool wide = use_wide_n(N);
+        dim3 grid(static_cast<unsigned>(ceil_div64(N, wide ? 224 : 128)), static_cast<unsigned>(ceil_div64(M, 128)),
+                  static_cast<unsigned>(split_k));
+        if (a_k_minor && b_k_minor) { if (v4) launch<true, true, 4>(a, wide, grid, st); else launch<true, true, 1>(a, wide, grid, st); }
+        else if (a_k_minor && !b_k_minor) { if (v4) launch<true, false, 4>(a, wide, grid, st); else launch<true, false, 1>(a, wide, grid, st); }
+        else if (!a_k_minor && !b_k_minor) { if (v4) launch<false, false, 4>(a, wide, grid, st); else launch<false, false, 1>(a, wide, grid, st); }
+        else return RECON_ERR_UNSUPPORTED;
+    }
     if (split_k > 1) {
         const int64_t MN = static_cast<int64_t>(M) * N;
         hipLaunchKernelGGL(k_splitk_reduce, dim3(static_cast<unsigned>(ceil_div64(MN, 256))), dim3(256), 0, st, partial, split_k,

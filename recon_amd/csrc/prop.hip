@@ -123,75 +123,97 @@ __device__ __forceinline__ void load_a_row4(float (&v)[4], const float* A, int S
     }
 }
 
+// One wave per 16-wide column tile of H^T (up to 16 waves per block), ONE LDS buffer: every wave
+// keeps its output tile in MFMA accumulators across the barrier that ends the hop's reads, then
+// overwrites its own columns.  A rows are prefetched three 16-float slabs ahead.
 template <int MT, bool VEC4>
-__global__ void __launch_bounds__(kPT) k_propagate_fwd(const PropK p) {
+__global__ void __launch_bounds__(1024) k_propagate_fwd(const PropK p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = blockDim.x >> 6;
     const int chunk = blockIdx.x, b = blockIdx.y;
     const int c0 = chunk * p.CC;
     const int pitch = p.pitch, S = p.S, CC = p.CC;
-    float* buf0 = lds;
-    float* buf1 = lds + static_cast<int64_t>(CC) * pitch;
-    // h^0 chunk (zero padded)
-    for (int idx = tid; idx < CC * pitch; idx += kPT) {
+    const int NT = p.Sp >> 4;
+    const bool dbl = NT > nwaves;                                  // S > 256: several passes, two buffers
+    float* H = lds;                                                // state read by this hop
+    float* Hn = dbl ? lds + static_cast<int64_t>(CC) * pitch : lds; // state written by this hop
+    for (int idx = tid; idx < CC * pitch; idx += nthreads) {       // h^0 chunk, zero padded
         const int cl = idx / pitch, s = idx % pitch;
         const int c = c0 + cl;
-        buf0[idx] = (c < p.C && s < S) ? p.h0[b * p.h0_bs + static_cast<int64_t>(c) * S + s] : 0.f;
+        H[idx] = (c < p.C && s < S) ? p.h0[b * p.h0_bs + static_cast<int64_t>(c) * S + s] : 0.f;
     }
     __syncthreads();
     const int li = lane & 15, lq = lane >> 4;
-    const int NT = p.Sp >> 4;
+    constexpr int G = 3;                                            // slabs per prefetch group
+    const int ngroups = (NT + G - 1) / G;
     for (int l = 0; l < p.L; ++l) {
-        const float* cur = (l & 1) ? buf1 : buf0;
-        float* nxt = (l & 1) ? buf0 : buf1;
         const float* A = p.adj[l] + static_cast<int64_t>(b) * S * S;
-        for (int nt = wave; nt < NT; nt += kPT / 64) {
+        for (int nt0 = 0; nt0 < NT; nt0 += nwaves) {                // one pass when NT <= nwaves
+            const int nt = nt0 + wave;
+            const bool tile_ok = nt < NT;                           // wave-uniform
             f32x4 acc[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int row = 16 * nt + li;
-            const bool row_ok = row < S;
-            float bq[4], bn[4];
-            load_a_row4<VEC4>(bq, A, S, row, 4 * lq, row_ok);
-            for (int slab = 0; slab < NT; ++slab) {
-                const int kc = 16 * slab + 4 * lq;
-                if (slab + 1 < NT) load_a_row4<VEC4>(bn, A, S, row, kc + 16, row_ok);
+            if (tile_ok) {
+                const int row = 16 * nt + li;
+                const bool row_ok = row < S;
+                float bq[G][4], bn[G][4];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const float4 aq = *reinterpret_cast<const float4*>(cur + (16 * m + li) * pitch + kc);
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, bq[0], acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, bq[1], acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, bq[2], acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, bq[3], acc[m], 0, 0, 0);
+                for (int g = 0; g < G; ++g) load_a_row4<VEC4>(bq[g], A, S, row, 16 * g + 4 * lq, row_ok && g < NT);
+                for (int grp = 0; grp < ngroups; ++grp) {
+                    const int s0 = grp * G;
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        load_a_row4<VEC4>(bn[g], A, S, row, 16 * (s0 + G + g) + 4 * lq, row_ok && (s0 + G + g) < NT);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        if (s0 + g < NT) {
+                            const int kc = 16 * (s0 + g) + 4 * lq;
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+                                const float4 aq = *reinterpret_cast<const float4*>(H + (16 * m + li) * pitch + kc);
+                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, bq[g][0], acc[m], 0, 0, 0);
+                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, bq[g][1], acc[m], 0, 0, 0);
+                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, bq[g][2], acc[m], 0, 0, 0);
+                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, bq[g][3], acc[m], 0, 0, 0);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bq[g][j] = bn[g][j];
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bq[j] = bn[j];
             }
+            if (!dbl) __syncthreads();                              // single buffer: all reads of H^{l-1} done
             // C layout: col (s) = lane&15, row (channel) = (lane>>4)*4 + r
+            if (tile_ok) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) nxt[(16 * m + 4 * lq + r) * pitch + 16 * nt + li] = act_fwd(acc[m][r], p.act);
+                    for (int r = 0; r < 4; ++r) Hn[(16 * m + 4 * lq + r) * pitch + 16 * nt + li] = act_fwd(acc[m][r], p.act);
+            }
         }
         __syncthreads();
+        if (dbl) { float* t = H; H = Hn; Hn = t; }                  // H now holds h^l
         // relation_l = gather(h, heads) * gather(h, tails)   (models/models.py:270-273)
-        for (int idx = tid; idx < CC * p.dd; idx += kPT) {
+        for (int idx = tid; idx < CC * p.dd; idx += nthreads) {
             const int cl = idx / p.dd, x = idx % p.dd;
             const int c = c0 + cl;
             if (c < p.C) {
                 const int64_t io = b * p.idx_bs + static_cast<int64_t>(c) * p.dd + x;
                 const int hi = static_cast<int>(p.head[io]), ti = static_cast<int>(p.tail[io]);
-                p.out[(static_cast<int64_t>(b) * p.C + c) * (p.L * p.dd) + l * p.dd + x] = nxt[cl * pitch + hi] * nxt[cl * pitch + ti];
+                p.out[(static_cast<int64_t>(b) * p.C + c) * (p.L * p.dd) + l * p.dd + x] = H[cl * pitch + hi] * H[cl * pitch + ti];
             }
         }
         if (p.hsave) {
             float* hs = p.hsave + ((static_cast<int64_t>(l) * p.B + b) * p.C) * S;
-            for (int idx = tid; idx < CC * S; idx += kPT) {
+            for (int idx = tid; idx < CC * S; idx += nthreads) {
                 const int cl = idx / S, s = idx % S;
-                if (c0 + cl < p.C) hs[static_cast<int64_t>(c0 + cl) * S + s] = nxt[cl * pitch + s];
+                if (c0 + cl < p.C) hs[static_cast<int64_t>(c0 + cl) * S + s] = H[cl * pitch + s];
             }
         }
-        // no second barrier needed: the next hop only writes the buffer nobody reads any more
+        // the next hop's post-compute barrier orders these reads before its writes
     }
 }
 
@@ -305,7 +327,7 @@ __global__ void __launch_bounds__(kPT) k_propagate_bwd_hop(const PropBwdK p) {
     }
 }
 
-struct PropGeom { int CC, Sp, pitch, chunks, MT; size_t lds; };
+struct PropGeom { int CC, Sp, pitch, chunks, MT, fwd_waves; size_t lds, fwd_lds; };
 bool prop_geometry(int C, int S, PropGeom* g) {
     g->Sp = (S + 15) / 16 * 16;
     g->pitch = g->Sp + 4;
@@ -316,7 +338,10 @@ bool prop_geometry(int C, int S, PropGeom* g) {
     g->CC = cc;
     g->MT = cc / 16;
     g->chunks = (C + cc - 1) / cc;
-    g->lds = 2ull * cc * g->pitch * sizeof(float);
+    g->lds = 2ull * cc * g->pitch * sizeof(float);                  // backward: two state buffers
+    const int NT = g->Sp / 16;
+    g->fwd_waves = NT < 16 ? NT : 16;                               // forward: one wave per column tile
+    g->fwd_lds = (NT > 16 ? 2ull : 1ull) * cc * g->pitch * sizeof(float);
     return true;
 }
 
@@ -398,16 +423,16 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
     p.CC = g.CC; p.Sp = g.Sp; p.pitch = g.pitch;
     dim3 grid(static_cast<unsigned>(g.chunks), static_cast<unsigned>(a->B));
     hipStream_t st = as_stream(stream);
-    if (g.lds > 64 * 1024) {
+    if (g.fwd_lds > 64 * 1024) {
 #define SET_ATTR(MTV, V)                                                                                             \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_fwd<MTV, V>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                        static_cast<int>(g.lds))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_fwd<MTV, V>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              static_cast<int>(g.fwd_lds))
         switch (g.MT) { case 1: SET_ATTR(1, true); SET_ATTR(1, false); break; case 2: SET_ATTR(2, true); SET_ATTR(2, false); break;
                         case 3: SET_ATTR(3, true); SET_ATTR(3, false); break; case 4: SET_ATTR(4, true); SET_ATTR(4, false); break;
                         default: SET_ATTR(5, true); SET_ATTR(5, false); break; }
 #undef SET_ATTR
     }
-    RECON_DISPATCH_MT(g.MT, v4, k_propagate_fwd, grid, dim3(kPT), g.lds, st, p);
+    RECON_DISPATCH_MT(g.MT, v4, k_propagate_fwd, grid, dim3(64 * g.fwd_waves), g.fwd_lds, st, p);
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }
@@ -426,8 +451,8 @@ extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t
     dim3 grid(static_cast<unsigned>(g.chunks), static_cast<unsigned>(a->B));
     if (g.lds > 64 * 1024) {
 #define SET_ATTR(MTV, V)                                                                                                 \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_bwd_hop<MTV, V>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                        static_cast<int>(g.lds))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_bwd_hop<MTV, V>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              static_cast<int>(g.lds))
         switch (g.MT) { case 1: SET_ATTR(1, true); SET_ATTR(1, false); break; case 2: SET_ATTR(2, true); SET_ATTR(2, false); break;
                         case 3: SET_ATTR(3, true); SET_ATTR(3, false); break; case 4: SET_ATTR(4, true); SET_ATTR(4, false); break;
                         default: SET_ATTR(5, true); SET_ATTR(5, false); break; }
