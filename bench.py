@@ -129,42 +129,70 @@ def main():
     }
 
     if rank == 0:
-        # ---- roofline of the dominant HBM-bound kernel: fused forward edge aggregation (K1), timed in
-        # situ with HIP events on the launch stream, between the projection GEMMs and the backward.
+        # ---- roofline of the HBM-bound forward edge aggregation (K1', k_gat_atp_fwd: the kernel SURVEY 8d names),
+        # timed in situ with HIP events on the launch stream between the score stage and the projection GEMM;
+        # the MFMA-bound projection GEMM (the largest single kernel by time) is reported beside it.
+        from recon_amd.gat_layers import _atp_args, gat_path_for
         L = _lib.lib()
         f32 = dict(dtype=torch.float32, device=dev)
         with torch.no_grad():
             a = torch.stack([att.a for att in model.attentions]).contiguous()
             a2 = torch.cat([att.a_2 for att in model.attentions], dim=0).contiguous()
-        P = torch.empty(2, H, N, D, **f32)
-        Q = torch.empty(H, E, D, **f32)
-        sigma = torch.empty(H, E, **f32)
-        Z = torch.empty(H, N, **f32)
-        out = torch.empty(N, H * D, **f32)
-        fa = _fwd_args(graph, xd.detach(), eed.detach(), a, a2, None, P, Q, sigma, Z, out, 0.2, True)
+        W = 2 * F_ + R
+        path = gat_path_for(N, E, F_, R, D, H)
+        result["config"]["formulation"] = "aggregate-then-project" if path == "atp" else "project-then-aggregate"
         st = _lib.current_stream()
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+        if path == "atp":
+            out = torch.empty(N, H * D, **f32)
+            u = torch.empty(H, W, **f32)
+            c_node = torch.empty(N, 2 * H, **f32)
+            c_rel = torch.empty(E, H, **f32)
+            V = torch.empty(N, H, W, **f32)
+            sigma = torch.empty(E, H, **f32)
+            Z = torch.empty(N, H, **f32)
+            Zk = torch.empty(N, H, **f32)
+            fa = _atp_args(graph, xd.detach(), eed.detach(), a, a2, None, u, c_node, c_rel, V, sigma, Z, Zk, out, 0.2, True)
+            stages = (L.recon_gat_atp_scores, L.recon_gat_atp_aggregate, L.recon_gat_atp_project)
+            # compulsory traffic of the aggregation kernel: x and edge_embed rows once, score terms, CSR, V out,
+            # saved sigma / Z / Zk  (fp32 values, int32 indices)
+            bytes_alg = 4 * (N * F_ + E * R + 2 * N * H + E * H + (N + 1) + 2 * E + N * H * W + E * H + 2 * N * H)
+            flops_proj = 2.0 * N * W * H * D
+            kname, gname = "k_gat_atp_fwd", "k_gemm_f32 (batched projection out = act(V a^T))"
+        else:
+            P = torch.empty(2, H, N, D, **f32)
+            Q = torch.empty(H, E, D, **f32)
+            sigma = torch.empty(H, E, **f32)
+            Z = torch.empty(H, N, **f32)
+            out = torch.empty(N, H * D, **f32)
+            fa = _fwd_args(graph, xd.detach(), eed.detach(), a, a2, None, P, Q, sigma, Z, out, 0.2, True)
+            stages = (None, L.recon_gat_edge_fwd, L.recon_gat_project)
+            bytes_alg = algorithmic_bytes_fwd(N, E, H, D)
+            flops_proj = 2.0 * H * D * (2.0 * N * F_ + 1.0 * E * R)
+            kname, gname = "k_gat_edge_fwd", "k_gemm_f32 (projections P, Q)"
+        order = (0, 1, 2) if path == "atp" else (2, 1)                 # proj: GEMMs first, then the edge kernel
         for i in range(args.warmup + args.steps):
             k = i - args.warmup
+            for pos, si in enumerate(order):
+                if stages[si] is None:
+                    continue
+                if k >= 0:
+                    ev[k][pos].record()
+                _lib.check(stages[si](C.byref(graph.c), C.byref(fa), st), "stage")
             if k >= 0:
-                ev[k][0].record()
-            _lib.check(L.recon_gat_project(C.byref(graph.c), C.byref(fa), st), "project")
-            if k >= 0:
-                ev[k][1].record()
-            _lib.check(L.recon_gat_edge_fwd(C.byref(graph.c), C.byref(fa), st), "edge_fwd")
-            if k >= 0:
-                ev[k][2].record()
+                ev[k][len(order)].record()
         torch.cuda.synchronize()
-        t_proj = sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)) / args.steps * 1e-3
-        t_edge = sum(ev[k][1].elapsed_time(ev[k][2]) for k in range(args.steps)) / args.steps * 1e-3
-        bytes_alg = algorithmic_bytes_fwd(N, E, H, D)
-        result["roofline"] = {"kernel": "k_gat_edge_fwd", "bound": "hbm", "achieved": bytes_alg / t_edge / 1e9,
+        ie, ig = order.index(1), order.index(2)
+        t_edge = sum(ev[k][ie].elapsed_time(ev[k][ie + 1]) for k in range(args.steps)) / args.steps * 1e-3
+        t_proj = sum(ev[k][ig].elapsed_time(ev[k][ig + 1]) for k in range(args.steps)) / args.steps * 1e-3
+        result["roofline"] = {"kernel": kname, "bound": "hbm", "achieved": bytes_alg / t_edge / 1e9,
                               "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_alg / t_edge / HBM_PEAK,
-                              "traffic": None, "algorithmic_bytes": bytes_alg, "avg_us": t_edge * 1e6}
-        flops_proj = 2.0 * H * D * (2.0 * N * F_ + 1.0 * E * R)
-        result["roofline_gemm"] = {"kernel": "k_gemm_f32 (projections P, Q)", "bound": "mfma",
-                                   "achieved": flops_proj / t_proj / 1e12, "peak": MFMA_F32_PEAK / 1e12,
-                                   "unit": "TFLOP/s", "frac": flops_proj / t_proj / MFMA_F32_PEAK,
+                              "traffic": None, "algorithmic_bytes": bytes_alg, "avg_us": t_edge * 1e6,
+                              "survey_model_bytes": algorithmic_bytes_fwd(N, E, H, D),
+                              "note": "algorithmic_bytes = compulsory traffic of this kernel; survey_model_bytes = SURVEY 8d's "
+                                      "B_G for the project-then-aggregate layout this kernel no longer needs"}
+        result["roofline_gemm"] = {"kernel": gname, "bound": "mfma", "achieved": flops_proj / t_proj / 1e12,
+                                   "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": flops_proj / t_proj / MFMA_F32_PEAK,
                                    "avg_us": t_proj * 1e6}
 
         # ---- CPU baseline: the oracle issuing the reference's own ATen op sequence (sparse_coo_tensor ->

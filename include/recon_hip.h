@@ -135,6 +135,64 @@ size_t recon_gat_bwd_partial_floats(int32_t N, int32_t E, int32_t F, int32_t R, 
 int recon_gat_bwd(const recon_graph* g, const recon_gat_bwd_args* args, recon_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * G4'  the same layer in "aggregate, then project" order (csrc/gat_atp.hip).  Aggregation and
+ *      projection are both linear, so  h_i = a . V_i  with
+ *        V_i = [ x_i Zk_i/Z_i ; sum_e k_e w_e x[src_e] / Z_i ; sum_e k_e w_e r_e / Z_i ]   (2F+R per head)
+ *      and the scores need only u = a_2^T a:  s_e = u_dst.x[dst_e] + u_src.x[src_e] + u_rel.r_e.
+ *      Half the MFMA work of recon_gat_fwd when E = 4N and no [E, H*D] intermediate; results differ
+ *      from recon_gat_fwd / the reference in fp32 summation order only.  recon_gat_atp_supported()
+ *      tells whether the shape is instantiated (F, R even; 2F+R-wide rows fit the register budget).
+ * ------------------------------------------------------------------------------------------*/
+typedef struct {
+    int32_t N, E;               /* must equal graph->N, graph->E                             */
+    int32_t F, R, D, H;
+    int32_t concat;
+    float alpha;
+    const float* x;             /* [N,F]                                                     */
+    const float* edge_embed;    /* [E,R] original edge order                                 */
+    const float* a;             /* [H,D,2F+R]                                                */
+    const float* a_2;           /* [H,D]                                                     */
+    const float* keep;          /* [E,H] dropout factors, CSR-slot order, or NULL            */
+    float* u;                   /* [H,2F+R]  workspace / saved: a_2^T a                      */
+    float* c_node;              /* [N,2H]    workspace / saved: x.u_dst | x.u_src            */
+    float* c_rel;               /* [E,H]     workspace / saved: r_e.u_rel, CSR-slot order    */
+    float* V;                   /* [N,H,2F+R] workspace / saved                              */
+    float* sigma;               /* [E,H] saved scores (CSR-slot order); NULL iff Z NULL      */
+    float* Z;                   /* [N,H] saved clamped row sums; NULL = inference call       */
+    float* Zk;                  /* [N,H] saved sum_e k_e w_e                                 */
+    float* out;                 /* [N, ld_out]                                               */
+    int32_t ld_out;
+} recon_gat_atp_args;
+
+int recon_gat_atp_supported(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H);
+int recon_gat_atp_fwd(const recon_graph* g, const recon_gat_atp_args* args, recon_stream_t stream);
+/* the three stages of recon_gat_atp_fwd, exported for profiling / tests */
+int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_args* args, recon_stream_t stream);    /* u, c_node, c_rel */
+int recon_gat_atp_aggregate(const recon_graph* g, const recon_gat_atp_args* args, recon_stream_t stream); /* K1': HBM       */
+int recon_gat_atp_project(const recon_graph* g, const recon_gat_atp_args* args, recon_stream_t stream);   /* K4: MFMA       */
+
+typedef struct {
+    recon_gat_atp_args fwd;     /* same tensors as the forward call (u, V, sigma, Z, Zk, out filled)  */
+    const float* grad_out;      /* [N, ld_gout]                                                      */
+    int32_t ld_gout;
+    float* g_h;                 /* [N,H*D]    workspace (only read when concat != 0)                  */
+    float* g_V;                 /* [N,H,2F+R] workspace: d loss / d V                                 */
+    float* g_sigma;             /* [E,H]      workspace: d loss / d s_e                               */
+    float* Gxs;                 /* [E,F]      workspace: per-edge gradient rows bound for x[src_e]    */
+    float* gxd;                 /* [N,F]      workspace: destination-side part of d loss / d x        */
+    float* Gs;                  /* [2,N,H]    workspace: per-node sums of g_sigma (dst view, src view) */
+    float* g_u;                 /* [H,2F+R]   workspace: d loss / d (a_2^T a)                          */
+    float* partial;             /* workspace, recon_gat_atp_bwd_partial_floats() floats               */
+    float* g_x;                 /* [N,F]      or NULL                                                 */
+    float* g_edge_embed;        /* [E,R] original edge order, or NULL                                 */
+    float* g_a;                 /* [H,D,2F+R] or NULL (then g_a_2 must be NULL too)                    */
+    float* g_a_2;               /* [H,D]      or NULL                                                 */
+} recon_gat_atp_bwd_args;
+
+size_t recon_gat_atp_bwd_partial_floats(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H);
+int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_args* args, recon_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * P1  block adjacency of the GP-GNN step (models/models.py:240-259; copies :450-469, :660-679,
  *     :898-917):  A[b, i*dd+r, j*dd+c] = T[b, e(i,j), r*dd+c] for i != j (e = row-major over ordered
  *     pairs, diagonal skipped) and identity[r,c] for i == j;  dd = 2*embedding_dim, S = n*dd.

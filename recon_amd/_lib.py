@@ -38,6 +38,20 @@ class GatBwdArgs(C.Structure):
                 ("g_x", c_f32p), ("g_edge_embed", c_f32p), ("g_a", c_f32p), ("g_a_2", c_f32p)]
 
 
+class GatAtpArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("E", C.c_int32), ("F", C.c_int32), ("R", C.c_int32), ("D", C.c_int32),
+                ("H", C.c_int32), ("concat", C.c_int32), ("alpha", C.c_float),
+                ("x", c_f32p), ("edge_embed", c_f32p), ("a", c_f32p), ("a_2", c_f32p), ("keep", c_f32p),
+                ("u", c_f32p), ("c_node", c_f32p), ("c_rel", c_f32p), ("V", c_f32p), ("sigma", c_f32p),
+                ("Z", c_f32p), ("Zk", c_f32p), ("out", c_f32p), ("ld_out", C.c_int32)]
+
+
+class GatAtpBwdArgs(C.Structure):
+    _fields_ = [("fwd", GatAtpArgs), ("grad_out", c_f32p), ("ld_gout", C.c_int32), ("g_h", c_f32p), ("g_V", c_f32p),
+                ("g_sigma", c_f32p), ("Gxs", c_f32p), ("gxd", c_f32p), ("Gs", c_f32p), ("g_u", c_f32p),
+                ("partial", c_f32p), ("g_x", c_f32p), ("g_edge_embed", c_f32p), ("g_a", c_f32p), ("g_a_2", c_f32p)]
+
+
 class PropArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("C", C.c_int32), ("S", C.c_int32), ("L", C.c_int32), ("dd", C.c_int32),
                 ("act", C.c_int32), ("adj", C.POINTER(C.c_void_p)), ("h0", c_f32p), ("h0_batch_stride", C.c_int64),
@@ -75,6 +89,13 @@ SYMBOLS = [
     ("recon_gat_edge_fwd", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatFwdArgs), C.c_void_p]),
     ("recon_gat_bwd_partial_floats", C.c_size_t, [C.c_int32] * 6),
     ("recon_gat_bwd", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatBwdArgs), C.c_void_p]),
+    ("recon_gat_atp_supported", C.c_int, [C.c_int32] * 6),
+    ("recon_gat_atp_fwd", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatAtpArgs), C.c_void_p]),
+    ("recon_gat_atp_scores", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatAtpArgs), C.c_void_p]),
+    ("recon_gat_atp_aggregate", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatAtpArgs), C.c_void_p]),
+    ("recon_gat_atp_project", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatAtpArgs), C.c_void_p]),
+    ("recon_gat_atp_bwd_partial_floats", C.c_size_t, [C.c_int32] * 6),
+    ("recon_gat_atp_bwd", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatAtpBwdArgs), C.c_void_p]),
     ("recon_block_adjacency_fwd", C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_void_p]),
     ("recon_block_adjacency_bwd", C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_void_p]),
     ("recon_propagate_fwd", C.c_int, [C.POINTER(PropArgs), C.c_void_p]),

@@ -1,0 +1,734 @@
+// K1' — "aggregate, then project" formulation of the KB-GAT layer (all H heads per wave).
+//
+// GAT/layers.py:129-178 projects every edge (m_e = a.[x_dst; x_src; r_e], an E x (2F+R) x D GEMM per
+// head) and then aggregates.  Both steps are linear, so they commute:
+//     s_e   = a_2.m_e = u_dst.x_dst + u_src.x_src + u_rel.r_e            u = a_2^T a   (2F+R per head)
+//     h_i   = sum_e k_e w_e m_e / Z_i = a . V_i,
+//     V_i   = [ x_i Zk_i/Z_i ;  sum_e k_e w_e x_src(e) / Z_i ;  sum_e k_e w_e r_e / Z_i ]
+// i.e. the scores need only three skinny dot products per node / edge, the edge stage aggregates RAW
+// feature rows (read once for all heads), and the only large GEMM left is N x (2F+R) x D per head:
+// half the MFMA work of project-then-aggregate when E = 4N, and no E x H*D intermediate in HBM.
+// Results differ from the reference only in fp32 summation order.
+//
+// Layouts (fp32): u [H][W], c_node [N][2H] (dst half | src half), c_rel / sigma / keep [E][H] in
+// CSR-slot order, Z / Zk [N][H], V [N][H][W], W = 2F+R.
+#include <math.h>
+#include "recon_common.h"
+
+namespace recon {
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ int xcd_block(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// u[h][w] = sum_d a_2[h][d] * a[h][d][w]      block = (64 columns w) x (4 row groups over d), fixed-order combine
+__global__ void __launch_bounds__(256) k_score_vec(const float* __restrict__ a, const float* __restrict__ a2, int32_t D, int32_t W,
+                                                   float* __restrict__ u) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int w = blockIdx.x * 64 + c, h = blockIdx.y;
+    const float* ah = a + static_cast<int64_t>(h) * D * W;
+    const int per = (D + 3) / 4;
+    float s = 0.f;
+    if (w < W)
+        for (int d = grp * per; d < min(D, (grp + 1) * per); ++d) s = fmaf(a2[h * D + d], ah[static_cast<int64_t>(d) * W + w], s);
+    red[grp][c] = s;
+    __syncthreads();
+    if (grp == 0 && w < W) u[static_cast<int64_t>(h) * W + w] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// backward of u = a_2^T a:   g_a[h][d][:] += a_2[h][d] * g_u[h][:] ;  g_a_2[h][d] = a[h][d][:] . g_u[h][:]
+__global__ void __launch_bounds__(256) k_score_vec_bwd(const float* __restrict__ a, const float* __restrict__ a2,
+                                                       const float* __restrict__ gu, int32_t D, int32_t W, float* __restrict__ ga,
+                                                       float* __restrict__ ga2) {
+    __shared__ float red[256];
+    const int d = blockIdx.x, h = blockIdx.y;
+    const int64_t row = (static_cast<int64_t>(h) * D + d) * W;
+    const float a2v = a2[h * D + d];
+    float s = 0.f;
+    for (int w = threadIdx.x; w < W; w += 256) {
+        const float g = gu[static_cast<int64_t>(h) * W + w];
+        s = fmaf(a[row + w], g, s);
+        if (ga) ga[row + w] += a2v * g;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && ga2) ga2[h * D + d] = red[0];
+}
+
+// g_h = g_y * elu'(h) expressed through y = elu(h):  y > 0 ? 1 : y + 1
+__global__ void __launch_bounds__(256) k_elu_grad(const float* __restrict__ gy, int32_t ld_gy, const float* __restrict__ y,
+                                                  int32_t ld_y, int32_t N, int32_t HD, float* __restrict__ gh) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= static_cast<int64_t>(N) * HD) return;
+    const int64_t r = idx / HD, c = idx % HD;
+    const float yv = y[r * ld_y + c];
+    gh[idx] = gy[r * ld_gy + c] * (yv > 0.f ? 1.f : yv + 1.f);
+}
+
+// out[row][j] = X[row'] . U_j,  U_j = u + (j % H)*W + (j / H)*F + off,  row' = gather ? gather[row] : row.
+// One wave per row; U staged in LDS.
+template <int VEC>
+__global__ void __launch_bounds__(kBlock) k_row_dots(const float* __restrict__ X, const int32_t* __restrict__ gather, int32_t rows,
+                                                     int32_t K, const float* __restrict__ u, int32_t H, int32_t W, int32_t F,
+                                                     int32_t off, int32_t NJ, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float U[];     // [NJ][K]
+    for (int idx = threadIdx.x; idx < NJ * K; idx += kBlock) {
+        const int j = idx / K, k = idx % K;
+        U[idx] = u[static_cast<int64_t>(j % H) * W + (j / H) * F + off + k];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (kBlock / 64);
+    for (int row = wave; row < rows; row += nwaves) {
+        const int64_t r = gather ? gather[row] : row;
+        const float* xr = X + r * K;
+        float mine = 0.f;
+        for (int j = 0; j < NJ; ++j) {
+            float part = 0.f;
+            for (int c = lane * VEC; c < K; c += 64 * VEC) {
+                float xv[VEC], uv[VEC];
+                load_vec<VEC>(xv, xr + c);
+                load_vec<VEC>(uv, U + j * K + c);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) part = fmaf(xv[v], uv[v], part);
+            }
+            const float tot = group_sum<64>(part);
+            if (lane == j) mine = tot;
+        }
+        if (lane < NJ) out[static_cast<int64_t>(row) * NJ + lane] = mine;
+    }
+}
+
+struct AtpFwdK {
+    const int32_t* rowptr; const int32_t* src; const int32_t* eid;
+    const float* x; const float* ee; const float* c_node; const float* c_rel; const float* keep;
+    float* V; float* sigma; float* Z; float* Zk;
+    int32_t N, E, F, R, H;
+    float alpha;
+};
+
+// wave = one destination node, HT heads (blockIdx.y selects the head group); lanes span the feature
+// dimension: lane l owns columns (r*64 + l)*VEC .. +VEC of both the x row (F) and the relation row (R).
+template <int VEC, int KR, int HT, bool TRAIN>
+__global__ void __launch_bounds__(kBlock) k_gat_atp_fwd(const AtpFwdK p) {
+    constexpr int UNR = (KR * HT >= 16) ? 1 : 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int node = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + wave;
+    if (node >= p.N) return;
+    const int F = p.F, R = p.R, H = p.H, W = 2 * F + R;
+    const int h0 = blockIdx.y * HT;
+    const int myh = h0 + (lane % HT);
+    const bool hv = myh < H;
+    int cf[KR]; bool aF[KR], aR[KR];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) { cf[r] = (r * 64 + lane) * VEC; aF[r] = cf[r] < F; aR[r] = cf[r] < R; }
+    const float cd = hv ? p.c_node[static_cast<int64_t>(node) * 2 * H + myh] : 0.f;
+    const int beg = p.rowptr[node], end = p.rowptr[node + 1];
+    float accS[HT][KR][VEC], accR[HT][KR][VEC];
+#pragma unroll
+    for (int h = 0; h < HT; ++h)
+#pragma unroll
+        for (int r = 0; r < KR; ++r)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { accS[h][r][v] = 0.f; accR[h][r][v] = 0.f; }
+    float Zl = 0.f, Zkl = 0.f;
+    for (int k0 = beg; k0 < end; k0 += UNR) {
+        float xs[UNR][KR][VEC], re[UNR][KR][VEC], sc[UNR], kf[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int k = k0 + u;
+            sc[u] = 0.f; kf[u] = 1.f;
+#pragma unroll
+            for (int r = 0; r < KR; ++r)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { xs[u][r][v] = 0.f; re[u][r][v] = 0.f; }
+            if (k < end) {
+                const int s = p.src[k], e = p.eid[k];
+                const float* xr = p.x + static_cast<int64_t>(s) * F;
+                const float* rr = p.ee + static_cast<int64_t>(e) * R;
+#pragma unroll
+                for (int r = 0; r < KR; ++r) {
+                    if (aF[r]) load_vec<VEC>(xs[u][r], xr + cf[r]);
+                    if (aR[r]) load_vec<VEC>(re[u][r], rr + cf[r]);
+                }
+                if (hv) {
+                    sc[u] = cd + p.c_node[static_cast<int64_t>(s) * 2 * H + H + myh] + p.c_rel[static_cast<int64_t>(k) * H + myh];
+                    if (p.keep) kf[u] = p.keep[static_cast<int64_t>(k) * H + myh];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int k = k0 + u;
+            if (k < end) {                                              // wave-uniform
+                const float sg = sc[u];
+                const float w = hv ? expf(-(sg > 0.f ? sg : p.alpha * sg)) : 0.f;
+                const float kw = kf[u] * w;
+                Zl += w;
+                Zkl += kw;
+                if constexpr (TRAIN) { if (hv && lane < HT) p.sigma[static_cast<int64_t>(k) * H + myh] = sg; }
+#pragma unroll
+                for (int h = 0; h < HT; ++h) {
+                    const float kwh = lane_bcast(kw, h);
+#pragma unroll
+                    for (int r = 0; r < KR; ++r)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            accS[h][r][v] = fmaf(kwh, xs[u][r][v], accS[h][r][v]);
+                            accR[h][r][v] = fmaf(kwh, re[u][r][v], accR[h][r][v]);
+                        }
+                }
+            }
+        }
+    }
+    const float Zc = (Zl == 0.f) ? 1e-12f : Zl;                         // GAT/layers.py:152
+    const float inv = 1.f / Zc;
+    if constexpr (TRAIN) {
+        if (hv && lane < HT) { p.Z[static_cast<int64_t>(node) * H + myh] = Zc; p.Zk[static_cast<int64_t>(node) * H + myh] = Zkl; }
+    }
+    float xi[KR][VEC];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) xi[r][v] = 0.f;
+        if (aF[r]) load_vec<VEC>(xi[r], p.x + static_cast<int64_t>(node) * F + cf[r]);
+    }
+#pragma unroll
+    for (int h = 0; h < HT; ++h) {
+        if (h0 + h < H) {
+            const float invh = lane_bcast(inv, h);
+            const float zk = lane_bcast(Zkl, h) * invh;
+            float* Vr = p.V + (static_cast<int64_t>(node) * H + h0 + h) * W;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                float o[VEC];
+                if (aF[r]) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) o[v] = xi[r][v] * zk;
+                    store_vec<VEC>(Vr + cf[r], o);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) o[v] = accS[h][r][v] * invh;
+                    store_vec<VEC>(Vr + F + cf[r], o);
+                }
+                if (aR[r]) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) o[v] = accR[h][r][v] * invh;
+                    store_vec<VEC>(Vr + 2 * F + cf[r], o);
+                }
+            }
+        }
+    }
+}
+
+
+struct AtpBwdK {
+    const int32_t* rowptr; const int32_t* src; const int32_t* eid;
+    const float* x; const float* ee; const float* keep; const float* sigma; const float* Z; const float* Zk;
+    const float* V; const float* gV; const float* u;
+    float* gsigma; float* Gs_dst; float* Gxs; float* gxd; float* g_ee;
+    int32_t N, E, F, R, H;
+    float alpha;
+};
+
+// wave = one destination node; head groups of HT are walked one after the other by the SAME wave so the
+// per-edge outputs (g_edge_embed row, Gxs row) can be accumulated across groups without atomics.
+template <int VEC, int KR, int HT>
+__global__ void __launch_bounds__(kBlock) k_gat_atp_bwd(const AtpBwdK p) {
+    extern __shared__ __attribute__((aligned(16))) float U[];          // [H][W]: u_dst | u_src | u_rel per head
+    const int F = p.F, R = p.R, H = p.H, W = 2 * F + R;
+    for (int idx = threadIdx.x; idx < H * W; idx += kBlock) U[idx] = p.u[idx];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int node = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + wave;
+    if (node >= p.N) return;
+    int cf[KR]; bool aF[KR], aR[KR];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) { cf[r] = (r * 64 + lane) * VEC; aF[r] = cf[r] < F; aR[r] = cf[r] < R; }
+    const int beg = p.rowptr[node], end = p.rowptr[node + 1];
+    float xi[KR][VEC], gxd[KR][VEC];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { xi[r][v] = 0.f; gxd[r][v] = 0.f; }
+        if (aF[r]) load_vec<VEC>(xi[r], p.x + static_cast<int64_t>(node) * F + cf[r]);
+    }
+    const int ngroups = (H + HT - 1) / HT;
+    for (int hg = 0; hg < ngroups; ++hg) {
+        const int h0 = hg * HT;
+        const int myh = h0 + (lane % HT);
+        const bool hv = myh < H;
+        const float Zl = hv ? p.Z[static_cast<int64_t>(node) * H + myh] : 1.f;
+        const float Zkl = hv ? p.Zk[static_cast<int64_t>(node) * H + myh] : 0.f;
+        const float invl = 1.f / Zl;
+        float gVs[HT][KR][VEC], gVr[HT][KR][VEC];
+        float tdl = 0.f, ql = 0.f;
+#pragma unroll
+        for (int h = 0; h < HT; ++h) {
+            float pd = 0.f, pq = 0.f;
+            const bool hok = h0 + h < H;                                  // wave-uniform
+            const float zr = lane_bcast(Zkl * invl, h);
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { gVs[h][r][v] = 0.f; gVr[h][r][v] = 0.f; }
+                if (hok) {
+                    const int64_t base = (static_cast<int64_t>(node) * H + h0 + h) * W;
+                    float gd[VEC], vv[VEC];
+                    if (aF[r]) {
+                        load_vec<VEC>(gd, p.gV + base + cf[r]);
+                        load_vec<VEC>(vv, p.V + base + cf[r]);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            pd = fmaf(gd[v], xi[r][v], pd);
+                            pq = fmaf(gd[v], vv[v], pq);
+                            gxd[r][v] = fmaf(zr, gd[v], gxd[r][v]);       // direct path: V_dst = x_i Zk/Z
+                        }
+                        load_vec<VEC>(gVs[h][r], p.gV + base + F + cf[r]);
+                        load_vec<VEC>(vv, p.V + base + F + cf[r]);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) pq = fmaf(gVs[h][r][v], vv[v], pq);
+                    }
+                    if (aR[r]) {
+                        load_vec<VEC>(gVr[h][r], p.gV + base + 2 * F + cf[r]);
+                        load_vec<VEC>(vv, p.V + base + 2 * F + cf[r]);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) pq = fmaf(gVr[h][r][v], vv[v], pq);
+                    }
+                }
+            }
+            const float td = group_sum<64>(pd), tq = group_sum<64>(pq);
+            if ((lane % HT) == h) { tdl = td; ql = tq; }
+        }
+        const float gZl = -ql * invl;                                     // d loss / d Z   (every part of V is ~ 1/Z)
+        float sum_gs = 0.f;
+        for (int k = beg; k < end; ++k) {
+            const int s = p.src[k], e = p.eid[k];
+            float xs[KR][VEC], re[KR][VEC];
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { xs[r][v] = 0.f; re[r][v] = 0.f; }
+                if (aF[r]) load_vec<VEC>(xs[r], p.x + static_cast<int64_t>(s) * F + cf[r]);
+                if (aR[r]) load_vec<VEC>(re[r], p.ee + static_cast<int64_t>(e) * R + cf[r]);
+            }
+            const float sg = hv ? p.sigma[static_cast<int64_t>(k) * H + myh] : 0.f;
+            const float kf = (hv && p.keep) ? p.keep[static_cast<int64_t>(k) * H + myh] : 1.f;
+            float tl = 0.f;
+#pragma unroll
+            for (int h = 0; h < HT; ++h) {
+                float part = 0.f;
+#pragma unroll
+                for (int r = 0; r < KR; ++r)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) part = fmaf(gVs[h][r][v], xs[r][v], fmaf(gVr[h][r][v], re[r][v], part));
+                const float t = group_sum<64>(part);
+                if ((lane % HT) == h) tl = t;
+            }
+            const float w = hv ? expf(-(sg > 0.f ? sg : p.alpha * sg)) : 0.f;
+            const float gw = fmaf(kf * (tl + tdl), invl, gZl);
+            const float gs = hv ? -gw * w * (sg > 0.f ? 1.f : p.alpha) : 0.f;
+            const float al_ = kf * w * invl;
+            sum_gs += gs;
+            if (hv && lane < HT) p.gsigma[static_cast<int64_t>(k) * H + myh] = gs;
+            float gxs[KR][VEC], gr[KR][VEC];
+#pragma unroll
+            for (int r = 0; r < KR; ++r)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { gxs[r][v] = 0.f; gr[r][v] = 0.f; }
+#pragma unroll
+            for (int h = 0; h < HT; ++h) {
+                if (h0 + h < H) {
+                    const float ah = lane_bcast(al_, h), bh = lane_bcast(gs, h);
+                    const float* uh = U + (h0 + h) * W;
+#pragma unroll
+                    for (int r = 0; r < KR; ++r) {
+                        float us[VEC], ur[VEC];
+                        if (aF[r]) {
+                            load_vec<VEC>(us, uh + F + cf[r]);
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) gxs[r][v] = fmaf(ah, gVs[h][r][v], fmaf(bh, us[v], gxs[r][v]));
+                        }
+                        if (aR[r]) {
+                            load_vec<VEC>(ur, uh + 2 * F + cf[r]);
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) gr[r][v] = fmaf(ah, gVr[h][r][v], fmaf(bh, ur[v], gr[r][v]));
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                if (aF[r]) {
+                    float* dst = p.Gxs + static_cast<int64_t>(k) * F + cf[r];
+                    if (hg > 0) { float o[VEC]; load_vec<VEC>(o, dst);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) gxs[r][v] += o[v]; }
+                    store_vec<VEC>(dst, gxs[r]);
+                }
+                if (aR[r] && p.g_ee) {
+                    float* dst = p.g_ee + static_cast<int64_t>(e) * R + cf[r];
+                    if (hg > 0) { float o[VEC]; load_vec<VEC>(o, dst);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) gr[r][v] += o[v]; }
+                    store_vec<VEC>(dst, gr[r]);
+                }
+            }
+        }
+        if (hv && lane < HT) p.Gs_dst[static_cast<int64_t>(node) * H + myh] = sum_gs;
+#pragma unroll
+        for (int h = 0; h < HT; ++h) {
+            if (h0 + h < H) {
+                const float sh = lane_bcast(sum_gs, h);
+                const float* uh = U + (h0 + h) * W;
+#pragma unroll
+                for (int r = 0; r < KR; ++r)
+                    if (aF[r]) {
+                        float ud[VEC];
+                        load_vec<VEC>(ud, uh + cf[r]);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) gxd[r][v] = fmaf(sh, ud[v], gxd[r][v]);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < KR; ++r)
+        if (aF[r]) store_vec<VEC>(p.gxd + static_cast<int64_t>(node) * F + cf[r], gxd[r]);
+}
+
+// CSC walk: g_x[j] = gxd[j] + sum_{e: src_e = j} Gxs[slot];  Gs_src[j][h] = sum gsigma[slot][h]
+struct AtpSrcK {
+    const int32_t* rowptr_src; const int32_t* slot_by_src; const float* Gxs; const float* gxd; const float* gsigma;
+    float* g_x; float* Gs_src;
+    int32_t N, F, H;
+};
+template <int VEC, int KR>
+__global__ void __launch_bounds__(kBlock) k_gat_atp_src(const AtpSrcK p) {
+    const int lane = threadIdx.x & 63;
+    const int node = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+    if (node >= p.N) return;
+    const int F = p.F, H = p.H;
+    float acc[KR][VEC];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[r][v] = 0.f;
+        const int c = (r * 64 + lane) * VEC;
+        if (c < F && p.g_x) load_vec<VEC>(acc[r], p.gxd + static_cast<int64_t>(node) * F + c);
+    }
+    float gs = 0.f;
+    const int beg = p.rowptr_src[node], end = p.rowptr_src[node + 1];
+    for (int k = beg; k < end; ++k) {
+        const int slot = p.slot_by_src[k];
+        if (lane < H) gs += p.gsigma[static_cast<int64_t>(slot) * H + lane];
+        if (p.g_x) {
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                const int c = (r * 64 + lane) * VEC;
+                if (c < F) {
+                    float t[VEC];
+                    load_vec<VEC>(t, p.Gxs + static_cast<int64_t>(slot) * F + c);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[r][v] += t[v];
+                }
+            }
+        }
+    }
+    if (lane < H) p.Gs_src[static_cast<int64_t>(node) * H + lane] = gs;
+    if (p.g_x) {
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const int c = (r * 64 + lane) * VEC;
+            if (c < F) store_vec<VEC>(p.g_x + static_cast<int64_t>(node) * F + c, acc[r]);
+        }
+    }
+}
+
+struct AtpShape { int vec, kr, ht; };
+bool atp_shape(int F, int R, int H, AtpShape* s) {
+    const int mx = F > R ? F : R;
+    int vec;
+    if (F % 4 == 0 && R % 4 == 0) vec = 4;
+    else if (F % 2 == 0 && R % 2 == 0) vec = 2;
+    else return false;
+    int kr = (mx + 64 * vec - 1) / (64 * vec);
+    if (kr > 2 && kr <= 4) kr = 4; else if (kr > 4 && kr <= 8) kr = 8; else if (kr > 8) return false;
+    int ht = 1;
+    while (ht < H && ht < 8) ht <<= 1;
+    while (ht > 1 && 2 * ht * kr * vec > 96) ht >>= 1;           // accumulator budget (VGPRs per lane)
+    if (2 * ht * kr * vec > 96) return false;
+    s->vec = vec; s->kr = kr; s->ht = ht;
+    return true;
+}
+bool al(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+#define ATP_DISPATCH(S, CALL)                                                                              \
+    do {                                                                                                   \
+        const int key_ = (S).vec * 1000 + (S).kr * 10 + ((S).ht == 8 ? 3 : (S).ht == 4 ? 2 : (S).ht == 2 ? 1 : 0); \
+        switch (key_) {                                                                                    \
+            case 4010: CALL(4, 1, 1); break; case 4011: CALL(4, 1, 2); break; case 4012: CALL(4, 1, 4); break; case 4013: CALL(4, 1, 8); break; \
+            case 4020: CALL(4, 2, 1); break; case 4021: CALL(4, 2, 2); break; case 4022: CALL(4, 2, 4); break;   \
+            case 4040: CALL(4, 4, 1); break; case 4041: CALL(4, 4, 2); break; case 4080: CALL(4, 8, 1); break;   \
+            case 2010: CALL(2, 1, 1); break; case 2011: CALL(2, 1, 2); break; case 2012: CALL(2, 1, 4); break; case 2013: CALL(2, 1, 8); break; \
+            case 2020: CALL(2, 2, 1); break; case 2021: CALL(2, 2, 2); break; case 2022: CALL(2, 2, 4); break; case 2023: CALL(2, 2, 8); break; \
+            case 2040: CALL(2, 4, 1); break; case 2041: CALL(2, 4, 2); break; case 2042: CALL(2, 4, 4); break;   \
+            case 2080: CALL(2, 8, 1); break; case 2081: CALL(2, 8, 2); break;                                   \
+            default: return RECON_ERR_UNSUPPORTED;                                                         \
+        }                                                                                                  \
+    } while (0)
+
+int check_atp(const recon_graph* g, const recon_gat_atp_args* a) {
+    if (!g || !a) return RECON_ERR_INVALID;
+    if (a->N != g->N || a->E != g->E) return RECON_ERR_INVALID;
+    if (a->N < 0 || a->E < 0 || a->F <= 0 || a->R <= 0 || a->D <= 0 || a->H <= 0) return RECON_ERR_INVALID;
+    if (a->ld_out < a->H * a->D) return RECON_ERR_INVALID;
+    if (!a->x || !a->a || !a->a_2 || !a->u || !a->c_node || !a->V || !a->out) return RECON_ERR_INVALID;
+    if (a->E > 0 && (!a->edge_embed || !a->c_rel)) return RECON_ERR_INVALID;
+    if (a->H > 4096) return RECON_ERR_UNSUPPORTED;
+    return RECON_OK;
+}
+
+}  // namespace
+}  // namespace recon
+
+using namespace recon;
+
+extern "C" int recon_gat_atp_supported(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H) {
+    (void)N; (void)E; (void)D;
+    AtpShape s;
+    if (F <= 0 || R <= 0 || H <= 0 || H > 32) return 0;
+    if (!atp_shape(F, R, H, &s)) return 0;
+    if (2 * H > 64) return 0;                                       // k_row_dots keeps one result per lane
+    return 1;
+}
+
+static int atp_fwd_common(const recon_graph* g, const recon_gat_atp_args* a, AtpShape* s) {
+    int rc = check_atp(g, a);
+    if (rc != RECON_OK) return rc;
+    if (!recon_gat_atp_supported(a->N, a->E, a->F, a->R, a->D, a->H)) return RECON_ERR_UNSUPPORTED;
+    const bool train = a->Z != nullptr;
+    if (train && (!a->Zk || (a->E > 0 && !a->sigma))) return RECON_ERR_INVALID;
+    if (a->keep && !train) return RECON_ERR_INVALID;
+    atp_shape(a->F, a->R, a->H, s);
+    if (!al(a->x, 4 * s->vec) || !al(a->edge_embed, 4 * s->vec) || !al(a->V, 16) || !al(a->u, 16)) return RECON_ERR_UNSUPPORTED;
+    return RECON_OK;
+}
+
+// stage 1: score vectors u = a_2^T a, then c_node = x.[u_dst | u_src], c_rel = edge_embed[eid].u_rel
+extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_args* a, recon_stream_t stream) {
+    AtpShape s;
+    int rc = atp_fwd_common(g, a, &s);
+    if (rc != RECON_OK) return rc;
+    if (a->N == 0) return RECON_OK;
+    hipStream_t st = as_stream(stream);
+    const int32_t N = a->N, E = a->E, F = a->F, R = a->R, D = a->D, H = a->H, W = 2 * F + R;
+    hipLaunchKernelGGL(k_score_vec, dim3(static_cast<unsigned>(ceil_div64(W, 64)), static_cast<unsigned>(H)), dim3(256), 0, st, a->a,
+                       a->a_2, D, W, a->u);
+    {
+        const int nb = static_cast<int>(ceil_div64(N, 4) < 2048 ? ceil_div64(N, 4) : 2048);
+        const size_t lds = static_cast<size_t>(2) * H * F * sizeof(float);
+        if (lds > 64 * 1024) return RECON_ERR_UNSUPPORTED;
+        if (s.vec == 4) hipLaunchKernelGGL((k_row_dots<4>), dim3(nb), dim3(kBlock), lds, st, a->x, nullptr, N, F, a->u, H, W, F, 0, 2 * H, a->c_node);
+        else hipLaunchKernelGGL((k_row_dots<2>), dim3(nb), dim3(kBlock), lds, st, a->x, nullptr, N, F, a->u, H, W, F, 0, 2 * H, a->c_node);
+    }
+    if (E > 0) {
+        const int nb = static_cast<int>(ceil_div64(E, 4) < 4096 ? ceil_div64(E, 4) : 4096);
+        const size_t lds = static_cast<size_t>(H) * R * sizeof(float);
+        if (lds > 64 * 1024) return RECON_ERR_UNSUPPORTED;
+        if (s.vec == 4) hipLaunchKernelGGL((k_row_dots<4>), dim3(nb), dim3(kBlock), lds, st, a->edge_embed, g->eid, E, R, a->u, H, W, 0, 2 * F, H, a->c_rel);
+        else hipLaunchKernelGGL((k_row_dots<2>), dim3(nb), dim3(kBlock), lds, st, a->edge_embed, g->eid, E, R, a->u, H, W, 0, 2 * F, H, a->c_rel);
+    }
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+// stage 2 (K1'): edge stage, V = normalised aggregated raw features.  HBM bound.
+extern "C" int recon_gat_atp_aggregate(const recon_graph* g, const recon_gat_atp_args* a, recon_stream_t stream) {
+    AtpShape s;
+    int rc = atp_fwd_common(g, a, &s);
+    if (rc != RECON_OK) return rc;
+    if (a->N == 0) return RECON_OK;
+    const bool train = a->Z != nullptr;
+    hipStream_t st = as_stream(stream);
+    AtpFwdK p;
+    p.rowptr = g->rowptr_dst; p.src = g->src; p.eid = g->eid;
+    p.x = a->x; p.ee = a->edge_embed; p.c_node = a->c_node; p.c_rel = a->c_rel; p.keep = a->keep;
+    p.V = a->V; p.sigma = a->sigma; p.Z = a->Z; p.Zk = a->Zk;
+    p.N = a->N; p.E = a->E; p.F = a->F; p.R = a->R; p.H = a->H; p.alpha = a->alpha;
+    dim3 grid(static_cast<unsigned>(ceil_div64(a->N, kBlock / 64)), static_cast<unsigned>(ceil_div64(a->H, s.ht)));
+#define CALL_FWD(V_, K_, H_)                                                                                   \
+    do {                                                                                                       \
+        if (train) hipLaunchKernelGGL((k_gat_atp_fwd<V_, K_, H_, true>), grid, dim3(kBlock), 0, st, p);        \
+        else hipLaunchKernelGGL((k_gat_atp_fwd<V_, K_, H_, false>), grid, dim3(kBlock), 0, st, p);             \
+    } while (0)
+    ATP_DISPATCH(s, CALL_FWD);
+#undef CALL_FWD
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+// stage 3: out[:, h*D:(h+1)*D] = act(V[:, h, :] . a[h]^T)      one batched MFMA GEMM over the heads
+extern "C" int recon_gat_atp_project(const recon_graph* g, const recon_gat_atp_args* a, recon_stream_t stream) {
+    AtpShape s;
+    int rc = atp_fwd_common(g, a, &s);
+    if (rc != RECON_OK) return rc;
+    if (a->N == 0) return RECON_OK;
+    const int32_t W = 2 * a->F + a->R;
+    OperandDesc A = plain_operand(a->V, static_cast<int64_t>(a->H) * W);
+    OperandDesc B = plain_operand(a->a, W);
+    OutputDesc C = plain_output(a->out, a->ld_out);
+    GemmBatch bt;
+    bt.batch = a->H; bt.a_bs = W; bt.b_bs = static_cast<int64_t>(a->D) * W; bt.c_bs = a->D;
+    bt.epilogue = a->concat ? 1 : 0;
+    return gemm_f32_batched(a->N, a->D, W, A, true, B, true, C, bt, 1, nullptr, as_stream(stream));
+}
+
+extern "C" int recon_gat_atp_fwd(const recon_graph* g, const recon_gat_atp_args* a, recon_stream_t stream) {
+    int rc = recon_gat_atp_scores(g, a, stream);
+    if (rc != RECON_OK) return rc;
+    rc = recon_gat_atp_aggregate(g, a, stream);
+    if (rc != RECON_OK) return rc;
+    return recon_gat_atp_project(g, a, stream);
+}
+
+extern "C" size_t recon_gat_atp_bwd_partial_floats(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H) {
+    const int64_t W = 2LL * F + R;
+    const int s1 = gemm_pick_split_k(D, static_cast<int32_t>(W), N);
+    size_t need = static_cast<size_t>(s1 > 1 ? s1 : 0) * H * D * W;            // g_a = g_h^T V, batched over heads
+    const int s2 = gemm_pick_split_k(2 * H, F, N);
+    const size_t n2 = static_cast<size_t>(s2 > 1 ? s2 : 0) * 2 * H * F;
+    const int s3 = gemm_pick_split_k(H, R, E);
+    const size_t n3 = static_cast<size_t>(s3 > 1 ? s3 : 0) * H * R;
+    if (n2 > need) need = n2;
+    if (n3 > need) need = n3;
+    return need > 0 ? need : 1;
+}
+
+extern "C" int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_args* b, recon_stream_t stream) {
+    if (!b) return RECON_ERR_INVALID;
+    const recon_gat_atp_args* a = &b->fwd;
+    int rc = check_atp(g, a);
+    if (rc != RECON_OK) return rc;
+    if (!recon_gat_atp_supported(a->N, a->E, a->F, a->R, a->D, a->H)) return RECON_ERR_UNSUPPORTED;
+    if (!a->Z || !a->Zk || !b->grad_out || !b->g_V || !b->gxd || !b->Gs || !b->g_u || !b->partial) return RECON_ERR_INVALID;
+    if (a->E > 0 && (!a->sigma || !b->g_sigma || !b->Gxs)) return RECON_ERR_INVALID;
+    if (a->concat && !b->g_h) return RECON_ERR_INVALID;
+    if (b->ld_gout < a->H * a->D) return RECON_ERR_INVALID;
+    if (a->N == 0) return RECON_OK;
+    hipStream_t st = as_stream(stream);
+    const int32_t N = a->N, E = a->E, F = a->F, R = a->R, D = a->D, H = a->H, W = 2 * F + R;
+    const int64_t HD = 1LL * H * D;
+    AtpShape s;
+    atp_shape(F, R, H, &s);
+    const size_t lds_u = static_cast<size_t>(H) * W * sizeof(float);
+    if (lds_u > 64 * 1024) return RECON_ERR_UNSUPPORTED;
+
+    // (0) through the ELU
+    const float* gh = b->grad_out;
+    int32_t ld_gh = b->ld_gout;
+    if (a->concat) {
+        hipLaunchKernelGGL(k_elu_grad, dim3(static_cast<unsigned>(ceil_div64(N * HD, 256))), dim3(256), 0, st, b->grad_out, b->ld_gout,
+                           a->out, a->ld_out, N, static_cast<int32_t>(HD), b->g_h);
+        gh = b->g_h; ld_gh = static_cast<int32_t>(HD);
+    }
+    GemmBatch bt;
+    bt.batch = H; bt.epilogue = 0;
+    // (1) g_V[:, h, :] = g_h[:, h, :] . a[h]
+    {
+        OperandDesc A = plain_operand(gh, ld_gh);
+        OperandDesc B = plain_operand(a->a, W);
+        OutputDesc C = plain_output(b->g_V, static_cast<int64_t>(H) * W);
+        bt.a_bs = D; bt.b_bs = static_cast<int64_t>(D) * W; bt.c_bs = W;
+        rc = gemm_f32_batched(N, W, D, A, true, B, false, C, bt, 1, nullptr, st);
+        if (rc != RECON_OK) return rc;
+    }
+    // (2) edge pass over the destination CSR
+    {
+        AtpBwdK p;
+        p.rowptr = g->rowptr_dst; p.src = g->src; p.eid = g->eid;
+        p.x = a->x; p.ee = a->edge_embed; p.keep = a->keep; p.sigma = a->sigma; p.Z = a->Z; p.Zk = a->Zk;
+        p.V = a->V; p.gV = b->g_V; p.u = a->u;
+        p.gsigma = b->g_sigma; p.Gs_dst = b->Gs; p.Gxs = b->Gxs; p.gxd = b->gxd; p.g_ee = b->g_edge_embed;
+        p.N = N; p.E = E; p.F = F; p.R = R; p.H = H; p.alpha = a->alpha;
+        dim3 grid(static_cast<unsigned>(ceil_div64(N, kBlock / 64)));
+#define CALL_BWD(V_, K_, H_) hipLaunchKernelGGL((k_gat_atp_bwd<V_, K_, H_>), grid, dim3(kBlock), lds_u, st, p)
+        ATP_DISPATCH(s, CALL_BWD);
+#undef CALL_BWD
+        RECON_CHECK_LAUNCH();
+    }
+    // (3) source-side sums over the CSC view
+    {
+        AtpSrcK p;
+        p.rowptr_src = g->rowptr_src; p.slot_by_src = g->slot_by_src; p.Gxs = b->Gxs; p.gxd = b->gxd; p.gsigma = b->g_sigma;
+        p.g_x = b->g_x; p.Gs_src = b->Gs + static_cast<int64_t>(N) * H;
+        p.N = N; p.F = F; p.H = H;
+        dim3 grid(static_cast<unsigned>(ceil_div64(N, kBlock / 64)));
+        const int key = s.vec * 10 + s.kr;
+        switch (key) {
+            case 41: hipLaunchKernelGGL((k_gat_atp_src<4, 1>), grid, dim3(kBlock), 0, st, p); break;
+            case 42: hipLaunchKernelGGL((k_gat_atp_src<4, 2>), grid, dim3(kBlock), 0, st, p); break;
+            case 44: hipLaunchKernelGGL((k_gat_atp_src<4, 4>), grid, dim3(kBlock), 0, st, p); break;
+            case 48: hipLaunchKernelGGL((k_gat_atp_src<4, 8>), grid, dim3(kBlock), 0, st, p); break;
+            case 21: hipLaunchKernelGGL((k_gat_atp_src<2, 1>), grid, dim3(kBlock), 0, st, p); break;
+            case 22: hipLaunchKernelGGL((k_gat_atp_src<2, 2>), grid, dim3(kBlock), 0, st, p); break;
+            case 24: hipLaunchKernelGGL((k_gat_atp_src<2, 4>), grid, dim3(kBlock), 0, st, p); break;
+            default: hipLaunchKernelGGL((k_gat_atp_src<2, 8>), grid, dim3(kBlock), 0, st, p); break;
+        }
+        RECON_CHECK_LAUNCH();
+    }
+    if (b->g_a || b->g_a_2) {
+        if (!b->g_a) return RECON_ERR_INVALID;                          // g_a_2 is produced together with g_a
+        // (4) g_a[h] = g_h[:, h, :]^T . V[:, h, :]
+        {
+            OperandDesc A = plain_operand(gh, ld_gh);                   // major = k (node), minor = m (d)
+            OperandDesc B = plain_operand(a->V, static_cast<int64_t>(H) * W);
+            OutputDesc C = plain_output(b->g_a, W);
+            bt.a_bs = D; bt.b_bs = W; bt.c_bs = static_cast<int64_t>(D) * W;
+            const int sk = gemm_pick_split_k(D, W, N);
+            rc = gemm_f32_batched(D, W, N, A, false, B, false, C, bt, sk, b->partial, st);
+            if (rc != RECON_OK) return rc;
+        }
+        // (5) g_u = [Gs_dst | Gs_src]^T x   and   gsigma^T edge_embed[eid]
+        {
+            OperandDesc A = plain_operand(b->Gs, H);                    // A(m = (s,h), k = node) = Gs[s][node][h]
+            A.Dseg = H; A.Sseg = static_cast<int64_t>(N) * H;
+            OperandDesc B = plain_operand(a->x, F);
+            OutputDesc C = plain_output(b->g_u, W);
+            C.P = H; C.S2 = F;
+            const int sk = gemm_pick_split_k(2 * H, F, N);
+            rc = gemm_f32(2 * H, F, N, A, false, B, false, C, sk, b->partial, st);
+            if (rc != RECON_OK) return rc;
+            if (E > 0) {
+                OperandDesc A2 = plain_operand(b->g_sigma, H);
+                OperandDesc B2 = plain_operand(a->edge_embed, R);
+                B2.gather = g->eid;
+                OutputDesc C2 = plain_output(b->g_u + 2 * F, W);
+                const int sk2 = gemm_pick_split_k(H, R, E);
+                rc = gemm_f32(H, R, E, A2, false, B2, false, C2, sk2, b->partial, st);
+                if (rc != RECON_OK) return rc;
+            } else {
+                for (int h = 0; h < H; ++h) (void)hipMemsetAsync(b->g_u + static_cast<int64_t>(h) * W + 2 * F, 0, sizeof(float) * R, st);
+            }
+        }
+        // (6) through u = a_2^T a
+        hipLaunchKernelGGL(k_score_vec_bwd, dim3(static_cast<unsigned>(D), static_cast<unsigned>(H)), dim3(256), 0, st, a->a, a->a_2, b->g_u,
+                           D, W, b->g_a, b->g_a_2);
+        RECON_CHECK_LAUNCH();
+    }
+    return RECON_OK;
+}

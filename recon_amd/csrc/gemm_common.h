@@ -9,8 +9,17 @@ struct GemmArgs {
     OutputDesc C;
     int32_t M, N, K;
     int32_t k_per_split;     // multiple of the kernel's K tile
-    float* partial;          // non-null => write plain [z][M][N]
+    float* partial;          // non-null => write plain [batch][z][M][N]
+    int32_t nsplit;          // blockIdx.z = batch_index * nsplit + split_index
+    int32_t epilogue;        // GEMM_EPI_*
+    int64_t a_bs, b_bs, c_bs;   // per-batch element offsets of A, B, C
 };
+enum { GEMM_EPI_NONE = 0, GEMM_EPI_ELU = 1 };
+
+__device__ __forceinline__ float gemm_epilogue(float v, int epi) {
+    if (epi == GEMM_EPI_ELU) return v > 0.f ? v : expm1f(v);
+    return v;
+}
 
 __device__ __forceinline__ int64_t major_off(const OperandDesc& d, int32_t i) {
     if (d.gather) return static_cast<int64_t>(d.gather[i]) * d.S1;

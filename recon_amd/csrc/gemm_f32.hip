@@ -110,12 +110,16 @@ __global__ void __launch_bounds__(NT) k_gemm_f32(const GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float Bs[BK][LB::LD];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int k_begin = blockIdx.z * p.k_per_split;
+    const int bz = blockIdx.z / p.nsplit, zs = blockIdx.z % p.nsplit;
+    const int k_begin = zs * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
+    OperandDesc dA = p.A, dB = p.B;
+    dA.base += bz * p.a_bs;
+    dB.base += bz * p.b_bs;
 
     LA la; LB lb;
-    la.init(p.A, m0, p.M);
-    lb.init(p.B, n0, p.N);
+    la.init(dA, m0, p.M);
+    lb.init(dB, n0, p.N);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -129,15 +133,15 @@ __global__ void __launch_bounds__(NT) k_gemm_f32(const GemmArgs p) {
     const int lr = lane & 31, lk = lane >> 5;
 
     if (k_begin < k_end) {
-        la.load(p.A, k_begin, k_end);
-        lb.load(p.B, k_begin, k_end);
+        la.load(dA, k_begin, k_end);
+        lb.load(dB, k_begin, k_end);
         la.store(As);
         lb.store(Bs);
     }
     __syncthreads();
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         const bool more = k0 + BK < k_end;
-        if (more) { la.load(p.A, k0 + BK, k_end); lb.load(p.B, k0 + BK, k_end); }
+        if (more) { la.load(dA, k0 + BK, k_end); lb.load(dB, k0 + BK, k_end); }
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             const int kk = 2 * ks + lk;
@@ -164,7 +168,7 @@ __global__ void __launch_bounds__(NT) k_gemm_f32(const GemmArgs p) {
         int64_t coff;
         float* base;
         if (p.partial) { base = p.partial + static_cast<int64_t>(blockIdx.z) * p.M * p.N; coff = col; }
-        else { base = p.C.base; coff = minor_off(p.C.Dseg, p.C.Sseg, col); }
+        else { base = p.C.base + bz * p.c_bs; coff = minor_off(p.C.Dseg, p.C.Sseg, col); }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -172,30 +176,25 @@ __global__ void __launch_bounds__(NT) k_gemm_f32(const GemmArgs p) {
                 const int row = m0 + mb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (row >= p.M) continue;
                 int64_t roff;
-                if (p.partial) roff = static_cast<int64_t>(row) * p.N;
-                else if (p.C.scatter) roff = static_cast<int64_t>(p.C.scatter[row]) * p.C.S1;
-                else if (row < p.C.P) roff = static_cast<int64_t>(row) * p.C.S1;
-                else roff = static_cast<int64_t>(row % p.C.P) * p.C.S1 + static_cast<int64_t>(row / p.C.P) * p.C.S2;
-                base[roff + coff] = acc[i][j][r];
+                if (p.partial) base[static_cast<int64_t>(row) * p.N + coff] = acc[i][j][r];
+                else base[out_row_off(p.C, row) + coff] = gemm_epilogue(acc[i][j][r], p.epilogue);
             }
         }
     }
 }
 
-// deterministic second pass of split-K: C = sum_z partial[z] (fixed order), written through C's addressing
+// deterministic second pass of split-K: C = epilogue(sum_z partial[batch][z]) (fixed order), written through C's addressing
 __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__ partial, int32_t splits, int32_t M,
-                                                       int32_t N, const OutputDesc C) {
+                                                       int32_t N, const OutputDesc C, int64_t c_bs, int32_t epilogue) {
     const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     const int64_t MN = static_cast<int64_t>(M) * N;
     if (idx >= MN) return;
+    const int bz = blockIdx.y;
     const int row = static_cast<int>(idx / N), col = static_cast<int>(idx % N);
+    const float* pz = partial + static_cast<int64_t>(bz) * splits * MN;
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += partial[z * MN + idx];
-    int64_t roff;
-    if (C.scatter) roff = static_cast<int64_t>(C.scatter[row]) * C.S1;
-    else if (row < C.P) roff = static_cast<int64_t>(row) * C.S1;
-    else roff = static_cast<int64_t>(row % C.P) * C.S1 + static_cast<int64_t>(row / C.P) * C.S2;
-    C.base[roff + minor_off(C.Dseg, C.Sseg, col)] = s;
+    for (int z = 0; z < splits; ++z) s += pz[z * MN + idx];
+    C.base[bz * c_bs + out_row_off(C, row) + minor_off(C.Dseg, C.Sseg, col)] = gemm_epilogue(s, epilogue);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -235,30 +234,33 @@ int gemm_pick_split_k(int32_t M, int32_t N, int32_t K) {
     return static_cast<int>(s < 1 ? 1 : s);
 }
 
-int gemm_f32(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool a_k_minor, const OperandDesc& B, bool b_k_minor,
-             const OutputDesc& C, int32_t split_k, float* partial, hipStream_t st) {
-    if (M < 0 || N < 0 || K < 0) return RECON_ERR_INVALID;
-    if (M == 0 || N == 0) return RECON_OK;
+int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool a_k_minor, const OperandDesc& B,
+                     bool b_k_minor, const OutputDesc& C, const GemmBatch& bt, int32_t split_k, float* partial, hipStream_t st) {
+    if (M < 0 || N < 0 || K < 0 || bt.batch < 0) return RECON_ERR_INVALID;
+    if (M == 0 || N == 0 || bt.batch == 0) return RECON_OK;
     if (!A.base || !B.base || !C.base) return RECON_ERR_INVALID;
     if (split_k < 1) split_k = 1;
     if (split_k > 1 && !partial) return RECON_ERR_INVALID;
     GemmArgs a;
     a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K;
-    const bool v4 = operand_vec4(A, a_k_minor ? K : M) && operand_vec4(B, b_k_minor ? K : N);
-    const bool use3 = v4 && gemm_bf16x3_enabled();                 // split-precision bf16 MFMA kernel (K tile 32)
+    a.a_bs = bt.a_bs; a.b_bs = bt.b_bs; a.c_bs = bt.c_bs; a.epilogue = bt.epilogue;
+    const bool v4 = operand_vec4(A, a_k_minor ? K : M) && operand_vec4(B, b_k_minor ? K : N) && (bt.batch == 1 || (!(bt.a_bs & 3) && !(bt.b_bs & 3)));
+    const bool use3 = v4 && bt.batch == 1 && bt.epilogue == GEMM_EPI_NONE && gemm_bf16x3_enabled();   // experimental kernel (K tile 32)
     const int bk = use3 ? 32 : BK;
     int64_t kps = ceil_div64(K > 0 ? K : 1, split_k);
     kps = ceil_div64(kps, bk) * bk;
     a.k_per_split = static_cast<int32_t>(kps);
     split_k = static_cast<int32_t>(ceil_div64(K > 0 ? K : 1, kps));
+    a.nsplit = split_k;
     a.partial = split_k > 1 ? partial : nullptr;
+    if (static_cast<int64_t>(bt.batch) * split_k > 65535) return RECON_ERR_UNSUPPORTED;
     if (use3) {
         const int rc = gemm_bf16x3_launch(a, a_k_minor, b_k_minor, split_k, st);
         if (rc != RECON_OK) return rc;
     } else {
         const bool wide = use_wide_n(N);
         dim3 grid(static_cast<unsigned>(ceil_div64(N, wide ? 224 : 128)), static_cast<unsigned>(ceil_div64(M, 128)),
-                  static_cast<unsigned>(split_k));
+                  static_cast<unsigned>(split_k * bt.batch));
         if (a_k_minor && b_k_minor) { if (v4) launch<true, true, 4>(a, wide, grid, st); else launch<true, true, 1>(a, wide, grid, st); }
         else if (a_k_minor && !b_k_minor) { if (v4) launch<true, false, 4>(a, wide, grid, st); else launch<true, false, 1>(a, wide, grid, st); }
         else if (!a_k_minor && !b_k_minor) { if (v4) launch<false, false, 4>(a, wide, grid, st); else launch<false, false, 1>(a, wide, grid, st); }
@@ -266,11 +268,18 @@ int gemm_f32(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool a_k_min
     }
     if (split_k > 1) {
         const int64_t MN = static_cast<int64_t>(M) * N;
-        hipLaunchKernelGGL(k_splitk_reduce, dim3(static_cast<unsigned>(ceil_div64(MN, 256))), dim3(256), 0, st, partial, split_k,
-                           M, N, C);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(static_cast<unsigned>(ceil_div64(MN, 256)), static_cast<unsigned>(bt.batch)), dim3(256), 0,
+                           st, partial, split_k, M, N, C, bt.c_bs, bt.epilogue);
     }
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
+}
+
+int gemm_f32(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool a_k_minor, const OperandDesc& B, bool b_k_minor,
+             const OutputDesc& C, int32_t split_k, float* partial, hipStream_t st) {
+    GemmBatch bt;
+    bt.batch = 1; bt.a_bs = bt.b_bs = bt.c_bs = 0; bt.epilogue = GEMM_EPI_NONE;
+    return gemm_f32_batched(M, N, K, A, a_k_minor, B, b_k_minor, C, bt, split_k, partial, st);
 }
 
 }  // namespace recon

@@ -91,4 +91,12 @@ int gemm_f32(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool a_k_min
              bool b_k_minor, const OutputDesc& C, int32_t split_k, float* partial, hipStream_t stream);
 int gemm_pick_split_k(int32_t M, int32_t N, int32_t K);
 
+// batched variant: `batch` independent problems, operand/output bases advanced by *_bs elements per batch;
+// epilogue 0 = none, 1 = ELU (applied after the split-K reduction when split_k > 1).
+// `partial` must hold batch*split_k*M*N floats when split_k > 1.
+struct GemmBatch { int32_t batch; int64_t a_bs, b_bs, c_bs; int32_t epilogue; };
+int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool a_k_minor, const OperandDesc& B,
+                     bool b_k_minor, const OutputDesc& C, const GemmBatch& bt, int32_t split_k, float* partial,
+                     hipStream_t stream);
+
 }  // namespace recon

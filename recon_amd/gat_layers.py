@@ -21,6 +21,8 @@ from .graph import prepare_graph, _has_nhop
 
 CUDA = torch.cuda.is_available()          # GAT/layers.py:9
 _DEBUG_NAN = os.environ.get("RECON_DEBUG_NAN", "0") == "1"
+# "auto": aggregate-then-project kernels (csrc/gat_atp.hip) where instantiated, else project-then-aggregate
+_GAT_PATH = os.environ.get("RECON_GAT_PATH", "auto")
 
 
 def _require_gpu_f32(*tensors):
@@ -160,12 +162,104 @@ class _GATHeadsFunction(torch.autograd.Function):
         return g_x, g_ee, g_a, g_a2, None, None, None, None
 
 
+def _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat):
+    H, D = a2.shape
+    return _lib.GatAtpArgs(graph.N, graph.E, x.shape[1], ee.shape[1], D, H, int(bool(concat)), float(alpha),
+                           x.data_ptr(), ee.data_ptr(), a.data_ptr(), a2.data_ptr(), _lib.ptr(keep), u.data_ptr(),
+                           c_node.data_ptr(), _lib.ptr(c_rel), V.data_ptr(), _lib.ptr(sigma), _lib.ptr(Z), _lib.ptr(Zk),
+                           out.data_ptr(), out.shape[1])
+
+
+class _GATHeadsATPFunction(torch.autograd.Function):
+    """Same contract as _GATHeadsFunction, through the aggregate-then-project kernels (csrc/gat_atp.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, ee, a, a2, graph, keep, alpha, concat):
+        _require_gpu_f32(x, ee, a, a2, keep)
+        L = _lib.lib()
+        x, ee, a, a2 = x.contiguous(), ee.contiguous(), a.contiguous(), a2.contiguous()
+        H, D = a2.shape
+        N, E = graph.N, graph.E
+        F_, R = x.shape[1], ee.shape[1]
+        W = 2 * F_ + R
+        if x.shape[0] != N or ee.shape[0] != E or a.shape != (H, D, W):
+            raise ValueError("recon_amd.gat_heads: inconsistent shapes")
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        need_grad = any(ctx.needs_input_grad[:4])
+        train = need_grad or keep is not None
+        out = torch.empty(N, H * D, **f32)
+        u = torch.empty(H, W, **f32)
+        c_node = torch.empty(N, 2 * H, **f32)
+        c_rel = torch.empty(E, H, **f32)
+        V = torch.empty(N, H, W, **f32)
+        sigma = torch.empty(E, H, **f32) if train else None
+        Z = torch.empty(N, H, **f32) if train else None
+        Zk = torch.empty(N, H, **f32) if train else None
+        if keep is not None:
+            keep = keep.view(H, E)[:, graph.eid_long].t().contiguous()        # [H,E] original order -> [E,H] slot order
+        args = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat)
+        with torch.cuda.device(dev):
+            _lib.check(L.recon_gat_atp_fwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_atp_fwd")
+        if need_grad:
+            ctx.save_for_backward(x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out)
+            ctx.graph, ctx.alpha, ctx.concat = graph, alpha, concat
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out = ctx.saved_tensors
+        graph = ctx.graph
+        L = _lib.lib()
+        H, D = a2.shape
+        N, E, F_, R = graph.N, graph.E, x.shape[1], ee.shape[1]
+        W = 2 * F_ + R
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        grad_out = grad_out.contiguous()
+        nx, ne, na, na2 = ctx.needs_input_grad[:4]
+        g_h = torch.empty(N, H * D, **f32) if ctx.concat else None
+        g_V = torch.empty(N, H, W, **f32)
+        g_sigma = torch.empty(E, H, **f32)
+        Gxs = torch.empty(E, F_, **f32)
+        gxd = torch.empty(N, F_, **f32)
+        Gs = torch.empty(2, N, H, **f32)
+        g_u = torch.empty(H, W, **f32)
+        partial = torch.empty(L.recon_gat_atp_bwd_partial_floats(N, E, F_, R, D, H), **f32)
+        g_x = torch.empty(N, F_, **f32) if nx else None
+        g_ee = torch.empty(E, R, **f32) if ne else None
+        g_a = torch.empty(H, D, W, **f32) if (na or na2) else None
+        g_a2 = torch.empty(H, D, **f32) if (na or na2) else None
+        fwd = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, ctx.alpha, ctx.concat)
+        args = _lib.GatAtpBwdArgs(fwd, grad_out.data_ptr(), grad_out.shape[1], _lib.ptr(g_h), g_V.data_ptr(),
+                                  _lib.ptr(g_sigma), _lib.ptr(Gxs), gxd.data_ptr(), Gs.data_ptr(), g_u.data_ptr(),
+                                  partial.data_ptr(), _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2))
+        with torch.cuda.device(dev):
+            _lib.check(L.recon_gat_atp_bwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_atp_bwd")
+        return g_x, g_ee, (g_a if na else None), (g_a2 if na2 else None), None, None, None, None
+
+
+def gat_path_for(N, E, F_, R, D, H):
+    """Which formulation gat_heads uses: 'atp' (aggregate, then project) when instantiated for the shape and
+    the graph is not much sparser than its node set, else 'proj' (project, then aggregate).  RECON_GAT_PATH /
+    `gat_layers._GAT_PATH` = 'atp' | 'proj' forces one."""
+    if _GAT_PATH == "proj":
+        return "proj"
+    ok = _lib.lib().recon_gat_atp_supported(N, E, F_, R, D, H) == 1
+    if _GAT_PATH == "atp":
+        return "atp" if ok else "proj"
+    return "atp" if (ok and 2 * E >= N) else "proj"
+
+
 def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=True):
     """Fused forward of H `SpGraphAttentionLayer`s that share their inputs (GAT/models.py:71-72).
 
     x [N,F]; edge_embed_all [E,R] (1-hop rows then n-hop rows, original order); a [H,D,2F+R];
     a_2 [H,D]; graph = prepare_graph(edge, edge_list_nhop, N); keep [H,E] dropout factors in
     original edge order or None.  Returns [N, H*D] (heads concatenated along dim 1)."""
+    H, D = a_2.shape
+    if gat_path_for(graph.N, graph.E, x.shape[1], edge_embed_all.shape[1], D, H) == "atp":
+        return _GATHeadsATPFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat)
     return _GATHeadsFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat)
 
 

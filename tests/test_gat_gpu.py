@@ -85,10 +85,14 @@ def test_spmm_golden(name):
 GAT_CASES = ["gat1_cfg1", "gat2_dups", "gat3_nhop", "gat4_noconcat", "gat5_train", "gat7_cfg2_slice"]
 
 
+@pytest.mark.parametrize("path", ["auto", "proj"])
 @pytest.mark.parametrize("name", GAT_CASES)
-def test_gat_layer_golden(name):
-    """Drop-in SpGraphAttentionLayer vs the reference's own outputs / gradients."""
+def test_gat_layer_golden(name, path, monkeypatch):
+    """Drop-in SpGraphAttentionLayer vs the reference's own outputs / gradients, through both kernel
+    formulations ('auto' picks aggregate-then-project where instantiated)."""
+    from recon_amd import gat_layers
     from recon_amd.gat_layers import SpGraphAttentionLayer
+    monkeypatch.setattr(gat_layers, "_GAT_PATH", path)
     g = load_golden(name)
     d = dev()
     N, F_ = g["x"].shape
@@ -127,11 +131,17 @@ def test_gat_layer_golden(name):
     (30, 120, 24, 16, 400, 2, True),      # KR=2
     (20, 90, 48, 48, 1600, 1, False),     # out_att-sized head: KR=8
     (16, 0, 8, 8, 16, 2, True),           # no edges at all
+    (24, 100, 1600, 1600, 40, 1, False),  # out_att-sized inputs (F = R = 1600)
+    (36, 140, 12, 8, 20, 11, True),       # 11 heads: two head groups walked by one wave
+    (30, 120, 264, 300, 24, 2, True),     # F, R > 256: two register rows per lane
 ])
-def test_gat_heads_vs_oracle(N, E, F_, R, D, H, concat):
-    """Fused H-head call: every stage (P, Q, sigma, Z, out, all gradients) vs the oracle."""
+@pytest.mark.parametrize("path", ["atp", "proj"])
+def test_gat_heads_vs_oracle(N, E, F_, R, D, H, concat, path, monkeypatch):
+    """Fused H-head call (with dropout factors): outputs and all gradients vs the oracle, both formulations."""
+    from recon_amd import gat_layers
     from recon_amd.gat_layers import gat_heads
     from recon_amd.graph import prepare_graph
+    monkeypatch.setattr(gat_layers, "_GAT_PATH", path)
     d = dev()
     g = torch.Generator().manual_seed(N * 7 + D)
     edge = torch.randint(0, N, (2, E), generator=g)
@@ -234,3 +244,34 @@ def test_full_size_cfg2_properties():
     graph2 = prepare_graph(edged[:, perm].contiguous(), None, B * n)
     out2 = gat_heads(xd.detach(), eed[perm].contiguous(), ad, a2d, graph2, None, 0.2, True)
     close(out2, out, atol=2e-5, what="edge permutation invariance")
+
+
+@pytest.mark.parametrize("path", ["atp", "proj"])
+@pytest.mark.parametrize("N,E,F_,R,D,H,concat", [
+    (64, 300, 16, 8, 32, 3, True),        # H = 3 -> head tile 4 with one masked head
+    (50, 200, 10, 6, 50, 2, True),        # vector width 2
+    (100, 450, 12, 12, 100, 8, True),     # 8 heads per wave
+    (30, 120, 264, 300, 40, 2, False),    # two register rows per lane (F, R > 256)
+    (20, 90, 1600, 1600, 64, 1, False),   # out_att-sized inputs
+    (40, 150, 8, 8, 16, 11, True),        # 11 heads -> two head groups
+    (16, 0, 8, 8, 16, 2, True),           # no edges
+])
+def test_gat_inference_both_formulations(path, N, E, F_, R, D, H, concat, monkeypatch):
+    """No-grad forward through the aggregate-then-project kernels and through the project-then-aggregate
+    kernels: both must match the oracle (they differ in fp32 summation order only)."""
+    from recon_amd import gat_layers
+    from recon_amd.graph import prepare_graph
+    monkeypatch.setattr(gat_layers, "_GAT_PATH", path)
+    d = dev()
+    g = torch.Generator().manual_seed(N * 3 + H)
+    edge = torch.randint(0, N, (2, E), generator=g)
+    x = torch.randn(N, F_, generator=g)
+    ee = torch.randn(E, R, generator=g)
+    a = torch.stack([O.xavier_normal((D, 2 * F_ + R), 1.414, g) for _ in range(H)])
+    a2 = torch.cat([O.xavier_normal((1, D), 1.414, g) for _ in range(H)])
+    graph = prepare_graph(edge.to(d), None, N)
+    with torch.no_grad():
+        out = gat_layers.gat_heads(x.to(d), ee.to(d), a.to(d), a2.to(d), graph, None, 0.2, concat)
+    for h in range(H):
+        ref = O.gat_layer_forward(x.double(), edge, ee.double(), None, None, a[h].double(), a2[h:h + 1].double(), 0.2, concat)
+        close(out[:, h * D:(h + 1) * D], ref.float(), what="%s head %d" % (path, h))
