@@ -459,6 +459,90 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_src(const AtpSrcK p) {
     }
 }
 
+
+// Tall-skinny transposed product with fixed-order reduction (replaces 128x128-tile GEMMs whose M is 8..32):
+//   out[j][c] = sum_r G[r*ldg + j] * X[row(r)*K + c],   j < NJ (<= 16), c < K,  row(r) = gather ? gather[r] : r
+// pass 1: block b sums its slice of rows into partial[b][j][c]; pass 2 adds the slices in order.
+template <int NJ>
+__global__ void __launch_bounds__(256) k_skinny_tn_partial(const float* __restrict__ G, int32_t ldg, int32_t nj,
+                                                           const float* __restrict__ X, const int32_t* __restrict__ gather,
+                                                           int32_t rows, int32_t K, int32_t rows_per_block,
+                                                           float* __restrict__ partial) {
+    // 4 waves split the block's rows; lane l owns columns 4l..4l+3 of a 256-column stripe; fixed-order LDS combine
+    __shared__ float red[3][NJ][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(rows, r0 + rows_per_block);
+    for (int c0 = 0; c0 < K; c0 += 256) {
+        const int c = c0 + 4 * lane;
+        float acc[NJ][4];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f;
+        for (int rb = r0 + wave * 4; rb < r1; rb += 16) {
+            float xv[4][4], gv[4][NJ];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rb + q;
+                xv[q][0] = xv[q][1] = xv[q][2] = xv[q][3] = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) gv[q][j] = 0.f;
+                if (r < r1) {
+                    const int64_t row = gather ? gather[r] : r;
+                    if (c + 3 < K) { const float4 t = *reinterpret_cast<const float4*>(X + row * K + c); xv[q][0] = t.x; xv[q][1] = t.y; xv[q][2] = t.z; xv[q][3] = t.w; }
+                    else { for (int v = 0; v < 4; ++v) if (c + v < K) xv[q][v] = X[row * K + c + v]; }
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) if (j < nj) gv[q][j] = G[static_cast<int64_t>(r) * ldg + j];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[j][v] = fmaf(gv[q][j], xv[q][v], acc[j][v]);
+        }
+        __syncthreads();
+        if (wave > 0) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) red[wave - 1][j][4 * lane + v] = acc[j][v];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (j < nj)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (c + v < K)
+                            partial[(static_cast<int64_t>(blockIdx.x) * nj + j) * K + c + v] =
+                                ((acc[j][v] + red[0][j][4 * lane + v]) + red[1][j][4 * lane + v]) + red[2][j][4 * lane + v];
+        }
+    }
+}
+// out[(j % P)*S1 + (j / P)*S2 + c] = sum_b partial[b][j][c]   (64 elements x 16 slice groups per block, fixed order)
+__global__ void __launch_bounds__(1024) k_skinny_reduce(const float* __restrict__ partial, int32_t nb, int32_t nj, int32_t K,
+                                                        int32_t P, int64_t S1, int64_t S2, float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + e;
+    const int tot = nj * K;
+    const int per = (nb + 15) / 16;
+    float s = 0.f;
+    if (idx < tot)
+        for (int b = grp * per; b < min(nb, (grp + 1) * per); ++b) s += partial[static_cast<int64_t>(b) * tot + idx];
+    red[grp][e] = s;
+    __syncthreads();
+    if (grp == 0 && idx < tot) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][e];
+        const int j = idx / K, c = idx % K;
+        out[(j % P) * S1 + (j / P) * S2 + c] = t;
+    }
+}
+
 struct AtpShape { int vec, kr, ht; };
 bool atp_shape(int F, int R, int H, AtpShape* s) {
     const int mx = F > R ? F : R;
@@ -608,12 +692,10 @@ extern "C" int recon_gat_atp_fwd(const recon_graph* g, const recon_gat_atp_args*
 
 extern "C" size_t recon_gat_atp_bwd_partial_floats(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H) {
     const int64_t W = 2LL * F + R;
-    const int s1 = gemm_pick_split_k(D, static_cast<int32_t>(W), N);
+    const int s1 = gemm_pick_split_k(D, static_cast<int32_t>(W), N, H);
     size_t need = static_cast<size_t>(s1 > 1 ? s1 : 0) * H * D * W;            // g_a = g_h^T V, batched over heads
-    const int s2 = gemm_pick_split_k(2 * H, F, N);
-    const size_t n2 = static_cast<size_t>(s2 > 1 ? s2 : 0) * 2 * H * F;
-    const int s3 = gemm_pick_split_k(H, R, E);
-    const size_t n3 = static_cast<size_t>(s3 > 1 ? s3 : 0) * H * R;
+    const size_t n2 = static_cast<size_t>(512) * 16 * F;                      // skinny-product slices (<= 512 blocks x 16 columns)
+    const size_t n3 = static_cast<size_t>(512) * 16 * R;
     if (n2 > need) need = n2;
     if (n3 > need) need = n3;
     return need > 0 ? need : 1;
@@ -699,31 +781,33 @@ extern "C" int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_a
             OperandDesc B = plain_operand(a->V, static_cast<int64_t>(H) * W);
             OutputDesc C = plain_output(b->g_a, W);
             bt.a_bs = D; bt.b_bs = W; bt.c_bs = static_cast<int64_t>(D) * W;
-            const int sk = gemm_pick_split_k(D, W, N);
+            const int sk = gemm_pick_split_k(D, W, N, H);
             rc = gemm_f32_batched(D, W, N, A, false, B, false, C, bt, sk, b->partial, st);
             if (rc != RECON_OK) return rc;
         }
-        // (5) g_u = [Gs_dst | Gs_src]^T x   and   gsigma^T edge_embed[eid]
+        // (5) g_u = [Gs_dst | Gs_src]^T x   and   gsigma^T edge_embed[eid]   (skinny products, fixed-order reduce)
         {
-            OperandDesc A = plain_operand(b->Gs, H);                    // A(m = (s,h), k = node) = Gs[s][node][h]
-            A.Dseg = H; A.Sseg = static_cast<int64_t>(N) * H;
-            OperandDesc B = plain_operand(a->x, F);
-            OutputDesc C = plain_output(b->g_u, W);
-            C.P = H; C.S2 = F;
-            const int sk = gemm_pick_split_k(2 * H, F, N);
-            rc = gemm_f32(2 * H, F, N, A, false, B, false, C, sk, b->partial, st);
-            if (rc != RECON_OK) return rc;
-            if (E > 0) {
-                OperandDesc A2 = plain_operand(b->g_sigma, H);
-                OperandDesc B2 = plain_operand(a->edge_embed, R);
-                B2.gather = g->eid;
-                OutputDesc C2 = plain_output(b->g_u + 2 * F, W);
-                const int sk2 = gemm_pick_split_k(H, R, E);
-                rc = gemm_f32(H, R, E, A2, false, B2, false, C2, sk2, b->partial, st);
-                if (rc != RECON_OK) return rc;
-            } else {
-                for (int h = 0; h < H; ++h) (void)hipMemsetAsync(b->g_u + static_cast<int64_t>(h) * W + 2 * F, 0, sizeof(float) * R, st);
+            constexpr int kNB = 512;
+            auto skinny = [&](const float* G, int ldg, int nj, const float* X, const int32_t* gather, int rows, int K, int P,
+                              int64_t S1, int64_t S2, float* out) {
+                if (rows <= 0) {
+                    for (int j = 0; j < nj; ++j) (void)hipMemsetAsync(out + (j % P) * S1 + (j / P) * S2, 0, sizeof(float) * K, st);
+                    return;
+                }
+                const int rpb = static_cast<int>(ceil_div64(rows, kNB));
+                const int nb = static_cast<int>(ceil_div64(rows, rpb));
+                if (nj <= 8) hipLaunchKernelGGL((k_skinny_tn_partial<8>), dim3(nb), dim3(256), 0, st, G, ldg, nj, X, gather, rows, K, rpb, b->partial);
+                else hipLaunchKernelGGL((k_skinny_tn_partial<16>), dim3(nb), dim3(256), 0, st, G, ldg, nj, X, gather, rows, K, rpb, b->partial);
+                hipLaunchKernelGGL(k_skinny_reduce, dim3(static_cast<unsigned>(ceil_div64(1LL * nj * K, 64))), dim3(1024), 0, st, b->partial, nb,
+                                   nj, K, P, S1, S2, out);
+            };
+            for (int h0 = 0; h0 < H; h0 += 16) {                       // <= 16 score columns per pass
+                const int nh = H - h0 < 16 ? H - h0 : 16;
+                skinny(b->Gs + h0, H, nh, a->x, nullptr, N, F, nh, W, 0, b->g_u + static_cast<int64_t>(h0) * W);                       // dst
+                skinny(b->Gs + static_cast<int64_t>(N) * H + h0, H, nh, a->x, nullptr, N, F, nh, W, 0, b->g_u + static_cast<int64_t>(h0) * W + F);   // src
+                skinny(b->g_sigma + h0, H, nh, a->edge_embed, g->eid, E, R, nh, W, 0, b->g_u + static_cast<int64_t>(h0) * W + 2 * F);    // rel
             }
+            RECON_CHECK_LAUNCH();
         }
         // (6) through u = a_2^T a
         hipLaunchKernelGGL(k_score_vec_bwd, dim3(static_cast<unsigned>(D), static_cast<unsigned>(H)), dim3(256), 0, st, a->a, a->a_2, b->g_u,

@@ -14,13 +14,13 @@
 namespace recon {
 namespace {
 
-constexpr int BK = 16, NT = 256;
+constexpr int NT = 256;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // One operand tile: W (m or n extent, 128 or 224) x BK, staged global -> registers -> LDS [BK][W+4].
 //   K_MINOR : memory is contiguous along k   -> thread item = (row, k quad): 4 floats along k
 //   !K_MINOR: memory is contiguous along m/n -> thread item = (k row, mn quad): 4 floats along mn
-template <int W, bool K_MINOR, int VEC>
+template <int W, bool K_MINOR, int VEC, int BK>
 struct TileLoader {
     static constexpr int LD = W + 4;
     static constexpr int QPR = K_MINOR ? BK / 4 : W / 4;          // quads per tile row
@@ -100,12 +100,12 @@ struct TileLoader {
 };
 
 // Block tile (WM*TM*32) x (WN*TN*32) x 16; 4 waves arranged WM x WN, each wave TM x TN MFMA tiles.
-template <bool A_KMINOR, bool B_KMINOR, int VEC, int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(NT) k_gemm_f32(const GemmArgs p) {
+template <bool A_KMINOR, bool B_KMINOR, int VEC, int WM, int WN, int TM, int TN, int BK>
+__global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const GemmArgs p) {
     static_assert(WM * WN == 4, "4 waves per block");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    using LA = TileLoader<BM, A_KMINOR, VEC>;
-    using LB = TileLoader<BN, B_KMINOR, VEC>;
+    using LA = TileLoader<BM, A_KMINOR, VEC, BK>;
+    using LB = TileLoader<BN, B_KMINOR, VEC, BK>;
     __shared__ __attribute__((aligned(16))) float As[BK][LA::LD];
     __shared__ __attribute__((aligned(16))) float Bs[BK][LB::LD];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -205,30 +205,48 @@ bool operand_vec4(const OperandDesc& d, int32_t minor_extent) {
     return (minor_extent & 3) == 0;
 }
 
+int gemm_bk() {
+    static const int bk = (getenv("RECON_GEMM_BK") && atoi(getenv("RECON_GEMM_BK")) == 32) ? 32 : 16;   // tuning knob
+    return bk;
+}
+
 template <bool AK, bool BK_, int VEC>
 void launch(const GemmArgs& a, bool wide_n, dim3 grid, hipStream_t st) {
-    if (wide_n) hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 4, 1, 1, 7>), grid, dim3(NT), 0, st, a);   // 128 x 224
-    else hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 2, 2>), grid, dim3(NT), 0, st, a);          // 128 x 128
+    const int cfg = getenv("RECON_GEMM_CFG") ? atoi(getenv("RECON_GEMM_CFG")) : 0;   // read per call: in-process A/B
+    if (cfg == 3) {                                                                                          // 256 x 128 (tuning)
+        grid.y = static_cast<unsigned>(ceil_div64(a.M, 256));
+        hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 4, 2, 16>), grid, dim3(NT), 0, st, a);
+        return;
+    }
+    if (cfg == 4) {                                                                                          // 256 x 256 (tuning)
+        grid.y = static_cast<unsigned>(ceil_div64(a.M, 256));
+        grid.x = static_cast<unsigned>(ceil_div64(a.N, 256));
+        hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 4, 4, 16>), grid, dim3(NT), 0, st, a);
+        return;
+    }
+    if (wide_n) hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 4, 1, 1, 7, 16>), grid, dim3(NT), 0, st, a);   // 128 x 224
+    else if (gemm_bk() == 32) hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 2, 2, 32>), grid, dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 2, 2, 16>), grid, dim3(NT), 0, st, a);          // 128 x 128
 }
 
 // 128x224 tiles when the output is 129..224 columns wide (N = 200 in every backward GEMM of cfg 2):
 // one column tile at 89 % MFMA efficiency instead of two 128-wide tiles at 78 %.
 bool use_wide_n(int32_t N) {
-    static const int force = getenv("RECON_GEMM_CFG") ? atoi(getenv("RECON_GEMM_CFG")) : 0;   // tuning knob: 1 = 128x128, 2 = 128x224
+    const int force = getenv("RECON_GEMM_CFG") ? atoi(getenv("RECON_GEMM_CFG")) : 0;   // tuning knob: 1 = 128x128, 2 = 128x224
     (void)N;
     return force == 2;        // measured in situ on cfg 2 (profiles/): 128x128 tiles win for every projection today
 }
 
 }  // namespace
 
-int gemm_pick_split_k(int32_t M, int32_t N, int32_t K) {
+int gemm_pick_split_k(int32_t M, int32_t N, int32_t K, int32_t batch) {
     static const int force = getenv("RECON_GEMM_SPLITK") ? atoi(getenv("RECON_GEMM_SPLITK")) : 0;   // tuning knob
     if (force > 0) return force;
     const int bn = use_wide_n(N) ? 224 : 128;
-    const int64_t tiles = ceil_div64(M, 128) * ceil_div64(N, bn);
+    const int64_t tiles = ceil_div64(M, 128) * ceil_div64(N, bn) * (batch > 0 ? batch : 1);
     if (tiles >= 192) return 1;
     int64_t s = ceil_div64(512, tiles);                            // aim at ~2 blocks per CU
-    const int64_t max_s = (K / (8 * BK)) > 0 ? K / (8 * BK) : 1;   // at least 8 K tiles per split
+    const int64_t max_s = (K / 128) > 0 ? K / 128 : 1;              // at least 128 of K per split
     if (s > max_s) s = max_s;
     if (s > 64) s = 64;
     return static_cast<int>(s < 1 ? 1 : s);
@@ -246,7 +264,7 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
     a.a_bs = bt.a_bs; a.b_bs = bt.b_bs; a.c_bs = bt.c_bs; a.epilogue = bt.epilogue;
     const bool v4 = operand_vec4(A, a_k_minor ? K : M) && operand_vec4(B, b_k_minor ? K : N) && (bt.batch == 1 || (!(bt.a_bs & 3) && !(bt.b_bs & 3)));
     const bool use3 = v4 && bt.batch == 1 && bt.epilogue == GEMM_EPI_NONE && gemm_bf16x3_enabled();   // experimental kernel (K tile 32)
-    const int bk = use3 ? 32 : BK;
+    const int bk = use3 ? 32 : gemm_bk();
     int64_t kps = ceil_div64(K > 0 ? K : 1, split_k);
     kps = ceil_div64(kps, bk) * bk;
     a.k_per_split = static_cast<int32_t>(kps);

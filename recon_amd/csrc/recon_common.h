@@ -89,7 +89,7 @@ inline OutputDesc plain_output(float* base, int64_t ld) {
 // second-pass reduction.
 int gemm_f32(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool a_k_minor, const OperandDesc& B,
              bool b_k_minor, const OutputDesc& C, int32_t split_k, float* partial, hipStream_t stream);
-int gemm_pick_split_k(int32_t M, int32_t N, int32_t K);
+int gemm_pick_split_k(int32_t M, int32_t N, int32_t K, int32_t batch = 1);
 
 // batched variant: `batch` independent problems, operand/output bases advanced by *_bs elements per batch;
 // epilogue 0 = none, 1 = ELU (applied after the split-K reduction when split_k > 1).
