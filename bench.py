@@ -191,6 +191,13 @@ def main():
                               "survey_model_bytes": algorithmic_bytes_fwd(N, E, H, D),
                               "note": "algorithmic_bytes = compulsory traffic of this kernel; survey_model_bytes = SURVEY 8d's "
                                       "B_G for the project-then-aggregate layout this kernel no longer needs"}
+        try:            # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot collect PMC itself)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
+            if (B, n, e, F_, D, H) == (512, 16, 64, 200, 200, 8) and kname in pmc:
+                result["roofline"]["traffic"] = pmc[kname]["total_bytes"]
+                result["roofline"]["traffic_source"] = "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+        except Exception:
+            pass
         result["roofline_gemm"] = {"kernel": gname, "bound": "mfma", "achieved": flops_proj / t_proj / 1e12,
                                    "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": flops_proj / t_proj / MFMA_F32_PEAK,
                                    "avg_us": t_proj * 1e6}
