@@ -47,16 +47,19 @@ struct TileLoader {
         }
     }
     __device__ __forceinline__ void load(const OperandDesc& d, int32_t k0, int32_t k_end) {
+        // K_MINOR: NT is a multiple of QPR, so every pass of this thread has the same k quad
+        const int kq_t = k0 + (threadIdx.x % QPR) * 4;
+        const int64_t koff_t = (K_MINOR && VEC == 4) ? minor_off(d.Dseg, d.Sseg, kq_t) : 0;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int idx = threadIdx.x + NT * p;
             r[p][0] = r[p][1] = r[p][2] = r[p][3] = 0.f;
             if constexpr (K_MINOR) {
-                const int kq = k0 + (idx % QPR) * 4;
+                const int kq = kq_t;
                 if (fix[p][0] >= 0) {
                     if constexpr (VEC == 4) {
                         if (kq < k_end) {
-                            const float4 v = *reinterpret_cast<const float4*>(d.base + fix[p][0] + minor_off(d.Dseg, d.Sseg, kq));
+                            const float4 v = *reinterpret_cast<const float4*>(d.base + fix[p][0] + koff_t);
                             r[p][0] = v.x; r[p][1] = v.y; r[p][2] = v.z; r[p][3] = v.w;
                         }
                     } else {
@@ -100,14 +103,14 @@ struct TileLoader {
 };
 
 // Block tile (WM*TM*32) x (WN*TN*32) x 16; 4 waves arranged WM x WN, each wave TM x TN MFMA tiles.
-template <bool A_KMINOR, bool B_KMINOR, int VEC, int WM, int WN, int TM, int TN, int BK>
+template <bool A_KMINOR, bool B_KMINOR, int VEC, int WM, int WN, int TM, int TN, int BK, int ABL = 0>
 __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const GemmArgs p) {
     static_assert(WM * WN == 4, "4 waves per block");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     using LA = TileLoader<BM, A_KMINOR, VEC, BK>;
     using LB = TileLoader<BN, B_KMINOR, VEC, BK>;
-    __shared__ __attribute__((aligned(16))) float As[BK][LA::LD];
-    __shared__ __attribute__((aligned(16))) float Bs[BK][LB::LD];
+    __shared__ __attribute__((aligned(16))) float As2[2][BK][LA::LD];      // double buffered: one barrier per K tile
+    __shared__ __attribute__((aligned(16))) float Bs2[2][BK][LB::LD];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int bz = blockIdx.z / p.nsplit, zs = blockIdx.z % p.nsplit;
@@ -135,13 +138,16 @@ __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const G
     if (k_begin < k_end) {
         la.load(dA, k_begin, k_end);
         lb.load(dB, k_begin, k_end);
-        la.store(As);
-        lb.store(Bs);
+        la.store(As2[0]);
+        lb.store(Bs2[0]);
     }
     __syncthreads();
+    int cur = 0;
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         const bool more = k0 + BK < k_end;
-        if (more) { la.load(dA, k0 + BK, k_end); lb.load(dB, k0 + BK, k_end); }
+        float (*As)[LA::LD] = As2[cur];
+        float (*Bs)[LB::LD] = Bs2[cur];
+        if (more && ABL < 1) { la.load(dA, k0 + BK, k_end); lb.load(dB, k0 + BK, k_end); }
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             const int kk = 2 * ks + lk;
@@ -155,12 +161,33 @@ __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const G
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
-        if (more) { la.store(As); lb.store(Bs); }
-        __syncthreads();
+        if constexpr (ABL < 2) {
+            if (more) { la.store(As2[cur ^ 1]); lb.store(Bs2[cur ^ 1]); }
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (!p.partial && !p.C.scatter && p.M <= p.C.P && p.N <= p.C.Dseg) {          // plain row-major C: no index maps
+        float* cb = p.C.base + bz * p.c_bs;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + nb + j * 32 + lr;
+            if (col < p.N) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int rbase = m0 + mb + i * 32 + 4 * lk;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (row < p.M) cb[static_cast<int64_t>(row) * p.C.S1 + col] = gemm_epilogue(acc[i][j][r], p.epilogue);
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + nb + j * 32 + lr;
@@ -213,6 +240,8 @@ int gemm_bk() {
 template <bool AK, bool BK_, int VEC>
 void launch(const GemmArgs& a, bool wide_n, dim3 grid, hipStream_t st) {
     const int cfg = getenv("RECON_GEMM_CFG") ? atoi(getenv("RECON_GEMM_CFG")) : 0;   // read per call: in-process A/B
+    if (cfg == 11) { hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 2, 2, 16, 1>), grid, dim3(NT), 0, st, a); return; }   // ablation: no global loads
+    if (cfg == 12) { hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 2, 2, 16, 2>), grid, dim3(NT), 0, st, a); return; }   // ablation: + no LDS refill / barriers
     if (cfg == 3) {                                                                                          // 256 x 128 (tuning)
         grid.y = static_cast<unsigned>(ceil_div64(a.M, 256));
         hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 4, 2, 16>), grid, dim3(NT), 0, st, a);
@@ -244,9 +273,11 @@ int gemm_pick_split_k(int32_t M, int32_t N, int32_t K, int32_t batch) {
     if (force > 0) return force;
     const int bn = use_wide_n(N) ? 224 : 128;
     const int64_t tiles = ceil_div64(M, 128) * ceil_div64(N, bn) * (batch > 0 ? batch : 1);
-    if (tiles >= 192) return 1;
-    int64_t s = ceil_div64(512, tiles);                            // aim at ~2 blocks per CU
-    const int64_t max_s = (K / 128) > 0 ? K / 128 : 1;              // at least 128 of K per split
+    constexpr int64_t kResident = 256 * 4;                         // CUs x workgroups per CU at 4 waves/SIMD
+    if (tiles >= kResident / 2) return 1;
+    // largest split that keeps every workgroup resident in one round and >= 128 of K per split
+    int64_t s = kResident / tiles;
+    const int64_t max_s = (K / 128) > 0 ? K / 128 : 1;
     if (s > max_s) s = max_s;
     if (s > 64) s = 64;
     return static_cast<int>(s < 1 ? 1 : s);
