@@ -35,8 +35,11 @@ def take_graph_shard(x, edge, edge_embed, node_ptr, edge_ptr, lo, hi):
 
 
 class FlatGradBucket:
-    """All parameter gradients live in ONE flat fp32 buffer (p.grad are views into it), so the
-    per-step reduction is a single all-reduce with no pack/unpack copies."""
+    """One flat fp32 buffer for all parameter gradients, reduced with a single all-reduce per step.
+
+    zero() drops the gradients (so autograd ASSIGNS the freshly produced gradient tensors instead of
+    launching one accumulate kernel per parameter); allreduce_mean() packs them into the flat buffer with
+    one concatenation, averages across ranks, and leaves every p.grad as a view into the buffer."""
 
     def __init__(self, params, process_group=None):
         self.params = [p for p in params if p.requires_grad]
@@ -44,17 +47,27 @@ class FlatGradBucket:
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.views = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
     def zero(self):
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
+
+    def pack(self):
+        grads = [p.grad.reshape(-1) if p.grad is not None else v.reshape(-1).zero_()
+                 for p, v in zip(self.params, self.views)]
+        torch.cat(grads, out=self.flat)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def allreduce_mean(self, async_op=False):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
             return None
         w = dist.get_world_size(self.group)
+        self.pack()
         self.flat.div_(w)
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)

@@ -55,8 +55,8 @@ def _worker(rank, world, port, ret):
     Gs = G[int(node_ptr[lo]):int(node_ptr[hi])]
     # loss = sum over ALL graphs; allreduce_mean divides by world, so pre-scale by world
     pa, pa2, bucket = _local_grads(xs, es, ees, a, a2, Gs, float(world))
-    assert pa.grad.data_ptr() == bucket.flat.data_ptr()          # grads are views into the flat bucket
     bucket.allreduce_mean()
+    assert pa.grad.data_ptr() == bucket.flat.data_ptr()          # after the reduction grads are views into the bucket
     ret[rank] = (pa.grad.clone().numpy(), pa2.grad.clone().numpy())
     dist.barrier()
     dist.destroy_process_group()
@@ -92,7 +92,9 @@ def test_shard_helpers():
 def test_bucket_without_process_group_is_a_noop():
     p = torch.nn.Parameter(torch.ones(3))
     b = FlatGradBucket([p])
-    p.grad.add_(2.0)
-    assert b.allreduce_mean() is None and b.flat.tolist() == [2.0, 2.0, 2.0]
+    (p * 2.0).sum().backward()
+    assert b.allreduce_mean() is None and p.grad.tolist() == [2.0, 2.0, 2.0]
+    b.pack()
+    assert b.flat.tolist() == [2.0, 2.0, 2.0] and p.grad.data_ptr() == b.flat.data_ptr()
     b.zero()
-    assert p.grad.tolist() == [0.0, 0.0, 0.0]
+    assert p.grad is None

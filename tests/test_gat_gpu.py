@@ -275,3 +275,50 @@ def test_gat_inference_both_formulations(path, N, E, F_, R, D, H, concat, monkey
     for h in range(H):
         ref = O.gat_layer_forward(x.double(), edge, ee.double(), None, None, a[h].double(), a2[h:h + 1].double(), 0.2, concat)
         close(out[:, h * D:(h + 1) * D], ref.float(), what="%s head %d" % (path, h))
+
+
+def _power_law_batch(n_graphs, seed=0, max_n=256):
+    """SURVEY 8d cfg-5 generator: n ~ U{16..256}, e = min(4096, 16 n), dst ~ Zipf(1) over the graph's nodes."""
+    rs = np.random.RandomState(seed)
+    dsts, srcs, base = [], [], 0
+    for _ in range(n_graphs):
+        n = int(rs.randint(16, max_n + 1))
+        e = min(4096, 16 * n)
+        p = 1.0 / np.arange(1, n + 1)
+        p /= p.sum()
+        dsts.append(rs.choice(n, size=e, p=p) + base)
+        srcs.append(rs.randint(0, n, size=e) + base)
+        base += n
+    edge = torch.from_numpy(np.stack([np.concatenate(dsts), np.concatenate(srcs)])).long()
+    return edge, base
+
+
+@pytest.mark.parametrize("path", ["atp", "proj"])
+def test_power_law_graphs(path, monkeypatch):
+    """cfg-5-like skewed degree distribution (hub destinations with > 1000 edges, many isolated nodes)."""
+    from recon_amd import gat_layers
+    from recon_amd.graph import prepare_graph
+    monkeypatch.setattr(gat_layers, "_GAT_PATH", path)
+    d = dev()
+    edge, N = _power_law_batch(6, seed=1)
+    E = edge.shape[1]
+    F_, R, D, H = 24, 16, 32, 4
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(N, F_, generator=g)
+    ee = torch.randn(E, R, generator=g) * 0.5
+    a = torch.stack([O.xavier_normal((D, 2 * F_ + R), 1.414, g) for _ in range(H)]) * 0.5
+    a2 = torch.cat([O.xavier_normal((1, D), 1.414, g) for _ in range(H)])
+    G = torch.randn(N, H * D, generator=g)
+    deg = torch.bincount(edge[0], minlength=N)
+    assert deg.max() > 500 and (deg == 0).sum() > 0
+    xd, eed, ad, a2d = (t.to(d).requires_grad_(True) for t in (x, ee, a, a2))
+    out = gat_layers.gat_heads(xd, eed, ad, a2d, prepare_graph(edge.to(d), None, N), None, 0.2, True)
+    (out * G.to(d)).sum().backward()
+    gx = torch.zeros_like(x)
+    for h in range(H):
+        r = O.gat_layer_backward(x.double(), edge, ee.double(), None, None, a[h].double(), a2[h:h + 1].double(), 0.2, True,
+                                 G[:, h * D:(h + 1) * D].double())
+        close(out[:, h * D:(h + 1) * D], r["out"].float(), what="power-law out h%d" % h)
+        close(ad.grad[h], r["g_a"].float(), atol=1e-4, what="g_a h%d" % h)
+        gx += r["g_x"].float()
+    close(xd.grad, gx, atol=1e-4, what="g_x")
