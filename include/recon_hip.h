@@ -182,6 +182,7 @@ typedef struct {
     float* gxd;                 /* [N,F]      workspace: destination-side part of d loss / d x        */
     float* Gs;                  /* [2,N,H]    workspace: per-node sums of g_sigma (dst view, src view) */
     float* g_u;                 /* [H,2F+R]   workspace: d loss / d (a_2^T a)                          */
+    float* q;                   /* [N,H]      workspace: g_h . h per (node, head)                      */
     float* partial;             /* workspace, recon_gat_atp_bwd_partial_floats() floats               */
     float* g_x;                 /* [N,F]      or NULL                                                 */
     float* g_edge_embed;        /* [E,R] original edge order, or NULL                                 */

@@ -48,7 +48,7 @@ class GatAtpArgs(C.Structure):
 
 class GatAtpBwdArgs(C.Structure):
     _fields_ = [("fwd", GatAtpArgs), ("grad_out", c_f32p), ("ld_gout", C.c_int32), ("g_h", c_f32p), ("g_V", c_f32p),
-                ("g_sigma", c_f32p), ("Gxs", c_f32p), ("gxd", c_f32p), ("Gs", c_f32p), ("g_u", c_f32p),
+                ("g_sigma", c_f32p), ("Gxs", c_f32p), ("gxd", c_f32p), ("Gs", c_f32p), ("g_u", c_f32p), ("q", c_f32p),
                 ("partial", c_f32p), ("g_x", c_f32p), ("g_edge_embed", c_f32p), ("g_a", c_f32p), ("g_a_2", c_f32p)]
 
 

@@ -67,14 +67,68 @@ __global__ void __launch_bounds__(256) k_score_vec_bwd(const float* __restrict__
     if (threadIdx.x == 0 && ga2) ga2[h * D + d] = red[0];
 }
 
-// g_h = g_y * elu'(h) expressed through y = elu(h):  y > 0 ? 1 : y + 1
-__global__ void __launch_bounds__(256) k_elu_grad(const float* __restrict__ gy, int32_t ld_gy, const float* __restrict__ y,
-                                                  int32_t ld_y, int32_t N, int32_t HD, float* __restrict__ gh) {
-    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    if (idx >= static_cast<int64_t>(N) * HD) return;
-    const int64_t r = idx / HD, c = idx % HD;
-    const float yv = y[r * ld_y + c];
-    gh[idx] = gy[r * ld_gy + c] * (yv > 0.f ? 1.f : yv + 1.f);
+// One wave per node: g_h = g_y * elu'(h) (written when concat) and q[node][h] = g_h[h,:] . h[h,:], the
+// (g_V . V) term of d loss / d Z  (g_V = g_h a and a V = h, so the 2F+R-wide dot collapses to a D-wide one).
+// h is recovered from y = elu(h): y > 0 ? y : log1p(y).
+__global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy, int32_t ld_gy, const float* __restrict__ y,
+                                                    int32_t ld_y, int32_t N, int32_t H, int32_t D, int32_t concat,
+                                                    float* __restrict__ gh, float* __restrict__ q) {
+    constexpr int IPW = 4;                                               // (node, head) rows per wave, loads batched
+    const int lane = threadIdx.x & 63;
+    const int item0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * IPW;      // N*H < 2^31 (checked by the host)
+    const int total = N * H;
+    if (item0 >= total) return;
+    const bool v4 = ((D | ld_gy | ld_y) & 3) == 0;
+    if (v4 && D <= 256) {
+        const int c = 4 * lane;
+        float4 g4[IPW], y4[IPW];
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) {
+            const int it = item0 + j;
+            g4[j] = make_float4(0.f, 0.f, 0.f, 0.f); y4[j] = g4[j];
+            if (it < total && c < D) {
+                const int node = it / H, h = it % H;
+                g4[j] = *reinterpret_cast<const float4*>(gy + static_cast<int64_t>(node) * ld_gy + h * D + c);
+                y4[j] = *reinterpret_cast<const float4*>(y + static_cast<int64_t>(node) * ld_y + h * D + c);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) {
+            const int it = item0 + j;
+            const float gv[4] = {g4[j].x, g4[j].y, g4[j].z, g4[j].w}, yv[4] = {y4[j].x, y4[j].y, y4[j].z, y4[j].w};
+            float o[4], part = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float g = gv[v], hv = yv[v];
+                if (concat && yv[v] <= 0.f) { const float e = yv[v] + 1.f; g = gv[v] * e; hv = e > 0.f ? __logf(e) : 0.f; }   // h = log(y+1); its error is multiplied by exp(h) <= 1
+                o[v] = g;
+                part = fmaf(g, hv, part);
+            }
+            const float tot = group_sum<64>(part);
+            if (it < total) {
+                if (gh && c < D) *reinterpret_cast<float4*>(gh + static_cast<int64_t>(it) * D + c) = make_float4(o[0], o[1], o[2], o[3]);
+                if (lane == 0) q[it] = tot;
+            }
+        }
+        return;
+    }
+    for (int j = 0; j < IPW; ++j) {
+        const int it = item0 + j;
+        if (it >= total) break;
+        const int node = it / H, h = it % H;
+        const float* gr = gy + static_cast<int64_t>(node) * ld_gy + h * D;
+        const float* yr = y + static_cast<int64_t>(node) * ld_y + h * D;
+        float* go = gh ? gh + static_cast<int64_t>(it) * D : nullptr;
+        float part = 0.f;
+        for (int c = lane; c < D; c += 64) {
+            float g = gr[c], hv = yr[c];
+            if (concat && hv <= 0.f) { const float e = hv + 1.f; g = g * e; hv = e > 0.f ? __logf(e) : 0.f; }
+            if (go) go[c] = g;
+            part = fmaf(g, hv, part);
+        }
+        const float tot = group_sum<64>(part);
+        if (lane == 0) q[it] = tot;
+    }
 }
 
 // out[row][j] = X[row'] . U_j,  U_j = u + (j % H)*W + (j / H)*F + off,  row' = gather ? gather[row] : row.
@@ -238,7 +292,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_fwd(const AtpFwdK p) {
 struct AtpBwdK {
     const int32_t* rowptr; const int32_t* src; const int32_t* eid;
     const float* x; const float* ee; const float* keep; const float* sigma; const float* Z; const float* Zk;
-    const float* V; const float* gV; const float* u;
+    const float* q; const float* gV; const float* u;
     float* gsigma; float* Gs_dst; float* Gxs; float* gxd; float* g_ee;
     int32_t N, E, F, R, H;
     float alpha;
@@ -276,10 +330,11 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_bwd(const AtpBwdK p) {
         const float Zkl = hv ? p.Zk[static_cast<int64_t>(node) * H + myh] : 0.f;
         const float invl = 1.f / Zl;
         float gVs[HT][KR][VEC], gVr[HT][KR][VEC];
-        float tdl = 0.f, ql = 0.f;
+        float tdl = 0.f;
+        const float ql = hv ? p.q[static_cast<int64_t>(node) * H + myh] : 0.f;
 #pragma unroll
         for (int h = 0; h < HT; ++h) {
-            float pd = 0.f, pq = 0.f;
+            float pd = 0.f;
             const bool hok = h0 + h < H;                                  // wave-uniform
             const float zr = lane_bcast(Zkl * invl, h);
 #pragma unroll
@@ -288,31 +343,21 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_bwd(const AtpBwdK p) {
                 for (int v = 0; v < VEC; ++v) { gVs[h][r][v] = 0.f; gVr[h][r][v] = 0.f; }
                 if (hok) {
                     const int64_t base = (static_cast<int64_t>(node) * H + h0 + h) * W;
-                    float gd[VEC], vv[VEC];
+                    float gd[VEC];
                     if (aF[r]) {
                         load_vec<VEC>(gd, p.gV + base + cf[r]);
-                        load_vec<VEC>(vv, p.V + base + cf[r]);
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
                             pd = fmaf(gd[v], xi[r][v], pd);
-                            pq = fmaf(gd[v], vv[v], pq);
                             gxd[r][v] = fmaf(zr, gd[v], gxd[r][v]);       // direct path: V_dst = x_i Zk/Z
                         }
                         load_vec<VEC>(gVs[h][r], p.gV + base + F + cf[r]);
-                        load_vec<VEC>(vv, p.V + base + F + cf[r]);
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) pq = fmaf(gVs[h][r][v], vv[v], pq);
                     }
-                    if (aR[r]) {
-                        load_vec<VEC>(gVr[h][r], p.gV + base + 2 * F + cf[r]);
-                        load_vec<VEC>(vv, p.V + base + 2 * F + cf[r]);
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) pq = fmaf(gVr[h][r][v], vv[v], pq);
-                    }
+                    if (aR[r]) load_vec<VEC>(gVr[h][r], p.gV + base + 2 * F + cf[r]);
                 }
             }
-            const float td = group_sum<64>(pd), tq = group_sum<64>(pq);
-            if ((lane % HT) == h) { tdl = td; ql = tq; }
+            const float td = group_sum<64>(pd);
+            if ((lane % HT) == h) tdl = td;
         }
         const float gZl = -ql * invl;                                     // d loss / d Z   (every part of V is ~ 1/Z)
         float sum_gs = 0.f;
@@ -707,7 +752,7 @@ extern "C" int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_a
     int rc = check_atp(g, a);
     if (rc != RECON_OK) return rc;
     if (!recon_gat_atp_supported(a->N, a->E, a->F, a->R, a->D, a->H)) return RECON_ERR_UNSUPPORTED;
-    if (!a->Z || !a->Zk || !b->grad_out || !b->g_V || !b->gxd || !b->Gs || !b->g_u || !b->partial) return RECON_ERR_INVALID;
+    if (!a->Z || !a->Zk || !b->grad_out || !b->g_V || !b->gxd || !b->Gs || !b->g_u || !b->partial || !b->q) return RECON_ERR_INVALID;
     if (a->E > 0 && (!a->sigma || !b->g_sigma || !b->Gxs)) return RECON_ERR_INVALID;
     if (a->concat && !b->g_h) return RECON_ERR_INVALID;
     if (b->ld_gout < a->H * a->D) return RECON_ERR_INVALID;
@@ -720,14 +765,12 @@ extern "C" int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_a
     const size_t lds_u = static_cast<size_t>(H) * W * sizeof(float);
     if (lds_u > 64 * 1024) return RECON_ERR_UNSUPPORTED;
 
-    // (0) through the ELU
+    // (0) through the ELU, and q = g_h . h per (node, head)
     const float* gh = b->grad_out;
     int32_t ld_gh = b->ld_gout;
-    if (a->concat) {
-        hipLaunchKernelGGL(k_elu_grad, dim3(static_cast<unsigned>(ceil_div64(N * HD, 256))), dim3(256), 0, st, b->grad_out, b->ld_gout,
-                           a->out, a->ld_out, N, static_cast<int32_t>(HD), b->g_h);
-        gh = b->g_h; ld_gh = static_cast<int32_t>(HD);
-    }
+    hipLaunchKernelGGL(k_elu_grad_q, dim3(static_cast<unsigned>(ceil_div64(1LL * N * H, 16))), dim3(256), 0, st, b->grad_out, b->ld_gout, a->out,
+                       a->ld_out, N, H, D, a->concat, a->concat ? b->g_h : nullptr, b->q);
+    if (a->concat) { gh = b->g_h; ld_gh = static_cast<int32_t>(HD); }
     GemmBatch bt;
     bt.batch = H; bt.epilogue = 0;
     // (1) g_V[:, h, :] = g_h[:, h, :] . a[h]
@@ -744,7 +787,7 @@ extern "C" int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_a
         AtpBwdK p;
         p.rowptr = g->rowptr_dst; p.src = g->src; p.eid = g->eid;
         p.x = a->x; p.ee = a->edge_embed; p.keep = a->keep; p.sigma = a->sigma; p.Z = a->Z; p.Zk = a->Zk;
-        p.V = a->V; p.gV = b->g_V; p.u = a->u;
+        p.q = b->q; p.gV = b->g_V; p.u = a->u;
         p.gsigma = b->g_sigma; p.Gs_dst = b->Gs; p.Gxs = b->Gxs; p.gxd = b->gxd; p.g_ee = b->g_edge_embed;
         p.N = N; p.E = E; p.F = F; p.R = R; p.H = H; p.alpha = a->alpha;
         dim3 grid(static_cast<unsigned>(ceil_div64(N, kBlock / 64)));

@@ -225,6 +225,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         gxd = torch.empty(N, F_, **f32)
         Gs = torch.empty(2, N, H, **f32)
         g_u = torch.empty(H, W, **f32)
+        q = torch.empty(N, H, **f32)
         partial = torch.empty(L.recon_gat_atp_bwd_partial_floats(N, E, F_, R, D, H), **f32)
         g_x = torch.empty(N, F_, **f32) if nx else None
         g_ee = torch.empty(E, R, **f32) if ne else None
@@ -233,7 +234,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         fwd = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, ctx.alpha, ctx.concat)
         args = _lib.GatAtpBwdArgs(fwd, grad_out.data_ptr(), grad_out.shape[1], _lib.ptr(g_h), g_V.data_ptr(),
                                   _lib.ptr(g_sigma), _lib.ptr(Gxs), gxd.data_ptr(), Gs.data_ptr(), g_u.data_ptr(),
-                                  partial.data_ptr(), _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2))
+                                  q.data_ptr(), partial.data_ptr(), _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2))
         with torch.cuda.device(dev):
             _lib.check(L.recon_gat_atp_bwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_atp_bwd")
         return g_x, g_ee, (g_a if na else None), (g_a2 if na2 else None), None, None, None, None
