@@ -4,8 +4,8 @@
 // `self.a.mm(edge_h)` GEMM of GAT/layers.py:129-137 (split algebraically into node and edge parts,
 // SURVEY.md 8a/G4) and the autograd GEMMs derived from it.
 //
-// Block tile 128x128x16 (4 waves as 2x2, each 2x2 MFMA tiles of 32x32) or, for outputs 129..224
-// columns wide, 128x224x16 (4 waves stacked along M, each 1x7 tiles).
+// Block tile 128x128x16 (4 waves as 2x2, each 2x2 MFMA tiles of 32x32) or, for outputs 129..208
+// columns wide, 128x208x16 on the 16x16x4 MFMA (4 waves stacked along M, each 2x13 tiles).
 // Global -> registers -> LDS staging with register prefetch of the next K tile; LDS tiles are
 // k-major ([16][128+4]) so both MFMA operand reads are conflict-free ds_read_b32.
 #include <stdlib.h>
@@ -14,7 +14,7 @@
 namespace recon {
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 256, BK16 = 16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // One operand tile: W (m or n extent, 128 or 224) x BK, staged global -> registers -> LDS [BK][W+4].
@@ -103,7 +103,7 @@ struct TileLoader {
 };
 
 // Block tile (WM*TM*32) x (WN*TN*32) x 16; 4 waves arranged WM x WN, each wave TM x TN MFMA tiles.
-template <bool A_KMINOR, bool B_KMINOR, int VEC, int WM, int WN, int TM, int TN, int BK, int ABL = 0>
+template <bool A_KMINOR, bool B_KMINOR, int VEC, int WM, int WN, int TM, int TN, int BK>
 __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const GemmArgs p) {
     static_assert(WM * WN == 4, "4 waves per block");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const G
         const bool more = k0 + BK < k_end;
         float (*As)[LA::LD] = As2[cur];
         float (*Bs)[LB::LD] = Bs2[cur];
-        if (more && ABL < 1) { la.load(dA, k0 + BK, k_end); lb.load(dB, k0 + BK, k_end); }
+        if (more) { la.load(dA, k0 + BK, k_end); lb.load(dB, k0 + BK, k_end); }
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             const int kk = 2 * ks + lk;
@@ -161,11 +161,9 @@ __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const G
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if constexpr (ABL < 2) {
-            if (more) { la.store(As2[cur ^ 1]); lb.store(Bs2[cur ^ 1]); }
-            __syncthreads();
-            cur ^= 1;
-        }
+        if (more) { la.store(As2[cur ^ 1]); lb.store(Bs2[cur ^ 1]); }
+        __syncthreads();
+        cur ^= 1;
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -210,6 +208,84 @@ __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const G
     }
 }
 
+
+// 128 x 208 x 16 block tile on v_mfma_f32_16x16x4_f32: 4 waves stacked along M, each 2 x 13 tiles of 16x16
+// (104 accumulator registers).  Same staging as k_gemm_f32.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+template <bool A_KMINOR, bool B_KMINOR, int VEC>
+__global__ void __launch_bounds__(NT, 3) k_gemm_f32_n208(const GemmArgs p) {
+    constexpr int BM = 128, BN = 208, BK = 16, TN = 13;
+    using LA = TileLoader<BM, A_KMINOR, VEC, BK>;
+    using LB = TileLoader<BN, B_KMINOR, VEC, BK>;
+    __shared__ __attribute__((aligned(16))) float As2[2][BK][LA::LD];
+    __shared__ __attribute__((aligned(16))) float Bs2[2][BK][LB::LD];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int bz = blockIdx.z / p.nsplit, zs = blockIdx.z % p.nsplit;
+    const int k_begin = zs * p.k_per_split;
+    const int k_end = min(p.K, k_begin + p.k_per_split);
+    OperandDesc dA = p.A, dB = p.B;
+    dA.base += bz * p.a_bs;
+    dB.base += bz * p.b_bs;
+    LA la; LB lb;
+    la.init(dA, m0, p.M);
+    lb.init(dB, n0, p.N);
+    f32x4 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int mb = wid * 32;
+    const int li = lane & 15, lq = lane >> 4;
+    if (k_begin < k_end) {
+        la.load(dA, k_begin, k_end);
+        lb.load(dB, k_begin, k_end);
+        la.store(As2[0]);
+        lb.store(Bs2[0]);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        const bool more = k0 + BK < k_end;
+        float (*As)[LA::LD] = As2[cur];
+        float (*Bs)[LB::LD] = Bs2[cur];
+        if (more) { la.load(dA, k0 + BK, k_end); lb.load(dB, k0 + BK, k_end); }
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            const int kk = 4 * ks + lq;
+            const float a0 = As[kk][mb + li], a1 = As[kk][mb + 16 + li];
+            float b[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[kk][16 * j + li];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[j], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[j], acc[1][j], 0, 0, 0);
+            }
+        }
+        if (more) { la.store(As2[cur ^ 1]); lb.store(Bs2[cur ^ 1]); }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // epilogue: C/D layout of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + r
+    float* base = p.partial ? p.partial + static_cast<int64_t>(blockIdx.z) * p.M * p.N : p.C.base + bz * p.c_bs;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + 16 * j + li;
+        if (col >= p.N) continue;
+        const int64_t coff = p.partial ? col : minor_off(p.C.Dseg, p.C.Sseg, col);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + mb + 16 * i + 4 * lq + r;
+                if (row >= p.M) continue;
+                if (p.partial) base[static_cast<int64_t>(row) * p.N + coff] = acc[i][j][r];
+                else base[out_row_off(p.C, row) + coff] = gemm_epilogue(acc[i][j][r], p.epilogue);
+            }
+    }
+}
+
 // deterministic second pass of split-K: C = epilogue(sum_z partial[batch][z]) (fixed order), written through C's addressing
 __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__ partial, int32_t splits, int32_t M,
                                                        int32_t N, const OutputDesc C, int64_t c_bs, int32_t epilogue) {
@@ -232,38 +308,21 @@ bool operand_vec4(const OperandDesc& d, int32_t minor_extent) {
     return (minor_extent & 3) == 0;
 }
 
-int gemm_bk() {
-    static const int bk = (getenv("RECON_GEMM_BK") && atoi(getenv("RECON_GEMM_BK")) == 32) ? 32 : 16;   // tuning knob
-    return bk;
-}
-
 template <bool AK, bool BK_, int VEC>
-void launch(const GemmArgs& a, bool wide_n, dim3 grid, hipStream_t st) {
-    const int cfg = getenv("RECON_GEMM_CFG") ? atoi(getenv("RECON_GEMM_CFG")) : 0;   // read per call: in-process A/B
-    if (cfg == 11) { hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 2, 2, 16, 1>), grid, dim3(NT), 0, st, a); return; }   // ablation: no global loads
-    if (cfg == 12) { hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 2, 2, 16, 2>), grid, dim3(NT), 0, st, a); return; }   // ablation: + no LDS refill / barriers
-    if (cfg == 3) {                                                                                          // 256 x 128 (tuning)
-        grid.y = static_cast<unsigned>(ceil_div64(a.M, 256));
-        hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 4, 2, 16>), grid, dim3(NT), 0, st, a);
-        return;
+void launch(const GemmArgs& a, bool narrow, dim3 grid, hipStream_t st) {
+    if constexpr (AK && BK_) {
+        if (narrow) { hipLaunchKernelGGL((k_gemm_f32_n208<AK, BK_, VEC>), grid, dim3(NT), 0, st, a); return; }   // 128 x 208
     }
-    if (cfg == 4) {                                                                                          // 256 x 256 (tuning)
-        grid.y = static_cast<unsigned>(ceil_div64(a.M, 256));
-        grid.x = static_cast<unsigned>(ceil_div64(a.N, 256));
-        hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 4, 4, 16>), grid, dim3(NT), 0, st, a);
-        return;
-    }
-    if (wide_n) hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 4, 1, 1, 7, 16>), grid, dim3(NT), 0, st, a);   // 128 x 224
-    else if (gemm_bk() == 32) hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 2, 2, 32>), grid, dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 2, 2, 16>), grid, dim3(NT), 0, st, a);          // 128 x 128
+    hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 2, 2, 16>), grid, dim3(NT), 0, st, a);      // 128 x 128
 }
 
-// 128x224 tiles when the output is 129..224 columns wide (N = 200 in every backward GEMM of cfg 2):
-// one column tile at 89 % MFMA efficiency instead of two 128-wide tiles at 78 %.
-bool use_wide_n(int32_t N) {
-    const int force = getenv("RECON_GEMM_CFG") ? atoi(getenv("RECON_GEMM_CFG")) : 0;   // tuning knob: 1 = 128x128, 2 = 128x224
-    (void)N;
-    return force == 2;        // measured in situ on cfg 2 (profiles/): 128x128 tiles win for every projection today
+// Outputs 129..208 columns wide (N = D = 200 per head at cfg 2) take ONE 208-wide column tile of 13 16x16
+// MFMA tiles (4 % padding) instead of two 128-wide tiles (28 % padding).  RECON_GEMM_CFG=1 forces 128x128.
+bool use_narrow(int32_t N, bool a_k_minor = true, bool b_k_minor = true) {
+    const int force = getenv("RECON_GEMM_CFG") ? atoi(getenv("RECON_GEMM_CFG")) : 0;   // read per call: in-process A/B
+    if (force == 1) return false;
+    // measured (tools/gemm_bench.py): +9 % for K-contiguous operands; the other layouts spill at 3 waves/SIMD and lose
+    return a_k_minor && b_k_minor && N > 128 && N <= 208;
 }
 
 }  // namespace
@@ -271,7 +330,7 @@ bool use_wide_n(int32_t N) {
 int gemm_pick_split_k(int32_t M, int32_t N, int32_t K, int32_t batch) {
     static const int force = getenv("RECON_GEMM_SPLITK") ? atoi(getenv("RECON_GEMM_SPLITK")) : 0;   // tuning knob
     if (force > 0) return force;
-    const int bn = use_wide_n(N) ? 224 : 128;
+    const int bn = 128;
     const int64_t tiles = ceil_div64(M, 128) * ceil_div64(N, bn) * (batch > 0 ? batch : 1);
     constexpr int64_t kResident = 256 * 4;                         // CUs x workgroups per CU at 4 waves/SIMD
     if (tiles >= kResident / 2) return 1;
@@ -295,7 +354,7 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
     a.a_bs = bt.a_bs; a.b_bs = bt.b_bs; a.c_bs = bt.c_bs; a.epilogue = bt.epilogue;
     const bool v4 = operand_vec4(A, a_k_minor ? K : M) && operand_vec4(B, b_k_minor ? K : N) && (bt.batch == 1 || (!(bt.a_bs & 3) && !(bt.b_bs & 3)));
     const bool use3 = v4 && bt.batch == 1 && bt.epilogue == GEMM_EPI_NONE && gemm_bf16x3_enabled();   // experimental kernel (K tile 32)
-    const int bk = use3 ? 32 : gemm_bk();
+    const int bk = use3 ? 32 : BK16;
     int64_t kps = ceil_div64(K > 0 ? K : 1, split_k);
     kps = ceil_div64(kps, bk) * bk;
     a.k_per_split = static_cast<int32_t>(kps);
@@ -307,8 +366,8 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
         const int rc = gemm_bf16x3_launch(a, a_k_minor, b_k_minor, split_k, st);
         if (rc != RECON_OK) return rc;
     } else {
-        const bool wide = use_wide_n(N);
-        dim3 grid(static_cast<unsigned>(ceil_div64(N, wide ? 224 : 128)), static_cast<unsigned>(ceil_div64(M, 128)),
+        const bool wide = use_narrow(N, a_k_minor, b_k_minor);
+        dim3 grid(static_cast<unsigned>(ceil_div64(N, wide ? 208 : 128)), static_cast<unsigned>(ceil_div64(M, 128)),
                   static_cast<unsigned>(split_k * bt.batch));
         if (a_k_minor && b_k_minor) { if (v4) launch<true, true, 4>(a, wide, grid, st); else launch<true, true, 1>(a, wide, grid, st); }
         else if (a_k_minor && !b_k_minor) { if (v4) launch<true, false, 4>(a, wide, grid, st); else launch<true, false, 1>(a, wide, grid, st); }
