@@ -183,7 +183,8 @@ typedef struct {
     float* Gs;                  /* [2,N,H]    workspace: per-node sums of g_sigma (dst view, src view) */
     float* g_u;                 /* [H,2F+R]   workspace: d loss / d (a_2^T a)                          */
     float* q;                   /* [N,H]      workspace: g_h . h per (node, head)                      */
-    float* partial;             /* workspace, recon_gat_atp_bwd_partial_floats() floats               */
+    float* partial;             /* workspace, recon_gat_atp_bwd_partial_floats() floats (split-K)     */
+    float* partial2;            /* workspace, recon_gat_atp_bwd_partial2_floats() floats (skinny)     */
     float* g_x;                 /* [N,F]      or NULL                                                 */
     float* g_edge_embed;        /* [E,R] original edge order, or NULL                                 */
     float* g_a;                 /* [H,D,2F+R] or NULL (then g_a_2 must be NULL too)                    */
@@ -191,7 +192,15 @@ typedef struct {
 } recon_gat_atp_bwd_args;
 
 size_t recon_gat_atp_bwd_partial_floats(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H);
+size_t recon_gat_atp_bwd_partial2_floats(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H);
 int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_args* args, recon_stream_t stream);
+/* the same backward as independently launchable phases (bit mask): PREPARE -> { INPUTS, WEIGHTS } -> FINISH.
+ * INPUTS (g_V GEMM, edge pass, source pass, score-vector gradient: HBM bound) and WEIGHTS (g_a = g_h^T V:
+ * MFMA bound) only read what PREPARE wrote and touch disjoint workspaces, so they may run on two streams. */
+enum { RECON_ATP_BWD_PREPARE = 1, RECON_ATP_BWD_INPUTS = 2, RECON_ATP_BWD_WEIGHTS = 4, RECON_ATP_BWD_FINISH = 8,
+       RECON_ATP_BWD_ALL = 15 };
+int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp_bwd_args* args, int32_t phases,
+                            recon_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * P1  block adjacency of the GP-GNN step (models/models.py:240-259; copies :450-469, :660-679,

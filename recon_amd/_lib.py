@@ -49,7 +49,7 @@ class GatAtpArgs(C.Structure):
 class GatAtpBwdArgs(C.Structure):
     _fields_ = [("fwd", GatAtpArgs), ("grad_out", c_f32p), ("ld_gout", C.c_int32), ("g_h", c_f32p), ("g_V", c_f32p),
                 ("g_sigma", c_f32p), ("Gxs", c_f32p), ("gxd", c_f32p), ("Gs", c_f32p), ("g_u", c_f32p), ("q", c_f32p),
-                ("partial", c_f32p), ("g_x", c_f32p), ("g_edge_embed", c_f32p), ("g_a", c_f32p), ("g_a_2", c_f32p)]
+                ("partial", c_f32p), ("partial2", c_f32p), ("g_x", c_f32p), ("g_edge_embed", c_f32p), ("g_a", c_f32p), ("g_a_2", c_f32p)]
 
 
 class PropArgs(C.Structure):
@@ -95,7 +95,9 @@ SYMBOLS = [
     ("recon_gat_atp_aggregate", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatAtpArgs), C.c_void_p]),
     ("recon_gat_atp_project", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatAtpArgs), C.c_void_p]),
     ("recon_gat_atp_bwd_partial_floats", C.c_size_t, [C.c_int32] * 6),
+    ("recon_gat_atp_bwd_partial2_floats", C.c_size_t, [C.c_int32] * 6),
     ("recon_gat_atp_bwd", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatAtpBwdArgs), C.c_void_p]),
+    ("recon_gat_atp_bwd_phase", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatAtpBwdArgs), C.c_int32, C.c_void_p]),
     ("recon_block_adjacency_fwd", C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_void_p]),
     ("recon_block_adjacency_bwd", C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_void_p]),
     ("recon_propagate_fwd", C.c_int, [C.POINTER(PropArgs), C.c_void_p]),

@@ -739,20 +739,32 @@ extern "C" size_t recon_gat_atp_bwd_partial_floats(int32_t N, int32_t E, int32_t
     const int64_t W = 2LL * F + R;
     const int s1 = gemm_pick_split_k(D, static_cast<int32_t>(W), N, H);
     size_t need = static_cast<size_t>(s1 > 1 ? s1 : 0) * H * D * W;            // g_a = g_h^T V, batched over heads
-    const size_t n2 = static_cast<size_t>(512) * 16 * F;                      // skinny-product slices (<= 512 blocks x 16 columns)
-    const size_t n3 = static_cast<size_t>(512) * 16 * R;
-    if (n2 > need) need = n2;
-    if (n3 > need) need = n3;
+    (void)E; (void)F; (void)R;
     return need > 0 ? need : 1;
 }
 
+// scratch of the skinny score-gradient products (<= 512 row slices x 16 columns); separate from `partial` so that
+// the weight-gradient GEMM may run concurrently on another stream
+extern "C" size_t recon_gat_atp_bwd_partial2_floats(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H) {
+    (void)N; (void)E; (void)D; (void)H;
+    const size_t mx = static_cast<size_t>(F > R ? F : R);
+    return static_cast<size_t>(512) * 16 * mx;
+}
+
 extern "C" int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_args* b, recon_stream_t stream) {
+    return recon_gat_atp_bwd_phase(g, b, RECON_ATP_BWD_ALL, stream);
+}
+
+// The backward in four independently launchable phases (bit mask), so that a caller can overlap the
+// MFMA-bound weight-gradient GEMM (WEIGHTS) with the HBM-bound edge chain (INPUTS) on two streams:
+//   PREPARE -> { INPUTS , WEIGHTS } -> FINISH      (INPUTS and WEIGHTS only read what PREPARE wrote)
+extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp_bwd_args* b, int32_t phases, recon_stream_t stream) {
     if (!b) return RECON_ERR_INVALID;
     const recon_gat_atp_args* a = &b->fwd;
     int rc = check_atp(g, a);
     if (rc != RECON_OK) return rc;
     if (!recon_gat_atp_supported(a->N, a->E, a->F, a->R, a->D, a->H)) return RECON_ERR_UNSUPPORTED;
-    if (!a->Z || !a->Zk || !b->grad_out || !b->g_V || !b->gxd || !b->Gs || !b->g_u || !b->partial || !b->q) return RECON_ERR_INVALID;
+    if (!a->Z || !a->Zk || !b->grad_out || !b->g_V || !b->gxd || !b->Gs || !b->g_u || !b->partial || !b->partial2 || !b->q) return RECON_ERR_INVALID;
     if (a->E > 0 && (!a->sigma || !b->g_sigma || !b->Gxs)) return RECON_ERR_INVALID;
     if (a->concat && !b->g_h) return RECON_ERR_INVALID;
     if (b->ld_gout < a->H * a->D) return RECON_ERR_INVALID;
@@ -768,11 +780,13 @@ extern "C" int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_a
     // (0) through the ELU, and q = g_h . h per (node, head)
     const float* gh = b->grad_out;
     int32_t ld_gh = b->ld_gout;
+    if (phases & RECON_ATP_BWD_PREPARE)
     hipLaunchKernelGGL(k_elu_grad_q, dim3(static_cast<unsigned>(ceil_div64(1LL * N * H, 16))), dim3(256), 0, st, b->grad_out, b->ld_gout, a->out,
                        a->ld_out, N, H, D, a->concat, a->concat ? b->g_h : nullptr, b->q);
     if (a->concat) { gh = b->g_h; ld_gh = static_cast<int32_t>(HD); }
     GemmBatch bt;
     bt.batch = H; bt.epilogue = 0;
+    if (phases & RECON_ATP_BWD_INPUTS) {
     // (1) g_V[:, h, :] = g_h[:, h, :] . a[h]
     {
         OperandDesc A = plain_operand(gh, ld_gh);
@@ -816,10 +830,11 @@ extern "C" int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_a
         }
         RECON_CHECK_LAUNCH();
     }
+    }   // INPUTS (its score-gradient products follow below)
     if (b->g_a || b->g_a_2) {
         if (!b->g_a) return RECON_ERR_INVALID;                          // g_a_2 is produced together with g_a
         // (4) g_a[h] = g_h[:, h, :]^T . V[:, h, :]
-        {
+        if (phases & RECON_ATP_BWD_WEIGHTS) {
             OperandDesc A = plain_operand(gh, ld_gh);                   // major = k (node), minor = m (d)
             OperandDesc B = plain_operand(a->V, static_cast<int64_t>(H) * W);
             OutputDesc C = plain_output(b->g_a, W);
@@ -829,7 +844,7 @@ extern "C" int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_a
             if (rc != RECON_OK) return rc;
         }
         // (5) g_u = [Gs_dst | Gs_src]^T x   and   gsigma^T edge_embed[eid]   (skinny products, fixed-order reduce)
-        {
+        if (phases & RECON_ATP_BWD_INPUTS) {
             constexpr int kNB = 512;
             auto skinny = [&](const float* G, int ldg, int nj, const float* X, const int32_t* gather, int rows, int K, int P,
                               int64_t S1, int64_t S2, float* out) {
@@ -839,9 +854,9 @@ extern "C" int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_a
                 }
                 const int rpb = static_cast<int>(ceil_div64(rows, kNB));
                 const int nb = static_cast<int>(ceil_div64(rows, rpb));
-                if (nj <= 8) hipLaunchKernelGGL((k_skinny_tn_partial<8>), dim3(nb), dim3(256), 0, st, G, ldg, nj, X, gather, rows, K, rpb, b->partial);
-                else hipLaunchKernelGGL((k_skinny_tn_partial<16>), dim3(nb), dim3(256), 0, st, G, ldg, nj, X, gather, rows, K, rpb, b->partial);
-                hipLaunchKernelGGL(k_skinny_reduce, dim3(static_cast<unsigned>(ceil_div64(1LL * nj * K, 64))), dim3(1024), 0, st, b->partial, nb,
+                if (nj <= 8) hipLaunchKernelGGL((k_skinny_tn_partial<8>), dim3(nb), dim3(256), 0, st, G, ldg, nj, X, gather, rows, K, rpb, b->partial2);
+                else hipLaunchKernelGGL((k_skinny_tn_partial<16>), dim3(nb), dim3(256), 0, st, G, ldg, nj, X, gather, rows, K, rpb, b->partial2);
+                hipLaunchKernelGGL(k_skinny_reduce, dim3(static_cast<unsigned>(ceil_div64(1LL * nj * K, 64))), dim3(1024), 0, st, b->partial2, nb,
                                    nj, K, P, S1, S2, out);
             };
             for (int h0 = 0; h0 < H; h0 += 16) {                       // <= 16 score columns per pass
@@ -853,6 +868,7 @@ extern "C" int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_a
             RECON_CHECK_LAUNCH();
         }
         // (6) through u = a_2^T a
+        if (phases & RECON_ATP_BWD_FINISH)
         hipLaunchKernelGGL(k_score_vec_bwd, dim3(static_cast<unsigned>(D), static_cast<unsigned>(H)), dim3(256), 0, st, a->a, a->a_2, b->g_u,
                            D, W, b->g_a, b->g_a_2);
         RECON_CHECK_LAUNCH();

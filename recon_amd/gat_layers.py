@@ -23,6 +23,18 @@ CUDA = torch.cuda.is_available()          # GAT/layers.py:9
 _DEBUG_NAN = os.environ.get("RECON_DEBUG_NAN", "0") == "1"
 # "auto": aggregate-then-project kernels (csrc/gat_atp.hip) where instantiated, else project-then-aggregate
 _GAT_PATH = os.environ.get("RECON_GAT_PATH", "auto")
+# RECON_OVERLAP=1 runs the MFMA-bound weight-gradient GEMM of the backward on a side stream next to the HBM-bound
+# edge chain.  Off by default: measured neutral on MI355X (0.927 vs 0.922 ms/step at cfg 2) because the GEMM's
+# 4 waves/SIMD x 128 registers leave no register file for co-resident edge-kernel waves.
+_OVERLAP = os.environ.get("RECON_OVERLAP", "0") == "1"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    s = _SIDE_STREAMS.get(dev)
+    if s is None:
+        s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return s
 
 
 def _require_gpu_f32(*tensors):
@@ -227,6 +239,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         g_u = torch.empty(H, W, **f32)
         q = torch.empty(N, H, **f32)
         partial = torch.empty(L.recon_gat_atp_bwd_partial_floats(N, E, F_, R, D, H), **f32)
+        partial2 = torch.empty(L.recon_gat_atp_bwd_partial2_floats(N, E, F_, R, D, H), **f32)
         g_x = torch.empty(N, F_, **f32) if nx else None
         g_ee = torch.empty(E, R, **f32) if ne else None
         g_a = torch.empty(H, D, W, **f32) if (na or na2) else None
@@ -234,9 +247,24 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         fwd = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, ctx.alpha, ctx.concat)
         args = _lib.GatAtpBwdArgs(fwd, grad_out.data_ptr(), grad_out.shape[1], _lib.ptr(g_h), g_V.data_ptr(),
                                   _lib.ptr(g_sigma), _lib.ptr(Gxs), gxd.data_ptr(), Gs.data_ptr(), g_u.data_ptr(),
-                                  q.data_ptr(), partial.data_ptr(), _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2))
+                                  q.data_ptr(), partial.data_ptr(), partial2.data_ptr(), _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2))
         with torch.cuda.device(dev):
-            _lib.check(L.recon_gat_atp_bwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_atp_bwd")
+            if _OVERLAP and g_a is not None:
+                # PREPARE -> { INPUTS on this stream , WEIGHTS (MFMA-bound GEMM) on a side stream } -> FINISH
+                main = torch.cuda.current_stream()
+                side = _side_stream(dev)
+                gc, ac = C.byref(graph.c), C.byref(args)
+                _lib.check(L.recon_gat_atp_bwd_phase(gc, ac, 1, main.cuda_stream), "recon_gat_atp_bwd_phase")
+                side.wait_stream(main)
+                _lib.check(L.recon_gat_atp_bwd_phase(gc, ac, 4, side.cuda_stream), "recon_gat_atp_bwd_phase")
+                _lib.check(L.recon_gat_atp_bwd_phase(gc, ac, 2, main.cuda_stream), "recon_gat_atp_bwd_phase")
+                main.wait_stream(side)
+                _lib.check(L.recon_gat_atp_bwd_phase(gc, ac, 8, main.cuda_stream), "recon_gat_atp_bwd_phase")
+                for t in (grad_out, g_h, V, g_a, partial, a2, a):      # used on the side stream: keep the allocator honest
+                    if t is not None:
+                        t.record_stream(side)
+            else:
+                _lib.check(L.recon_gat_atp_bwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_atp_bwd")
         return g_x, g_ee, (g_a if na else None), (g_a2 if na2 else None), None, None, None, None
 
 
