@@ -125,7 +125,7 @@ __device__ __forceinline__ void load_a_row4(float (&v)[4], const float* A, int S
 
 // One wave per 16-wide column tile of H^T (up to 16 waves per block), ONE LDS buffer: every wave
 // keeps its output tile in MFMA accumulators across the barrier that ends the hop's reads, then
-// overwrites its own columns.  A rows are prefetched three 16-float slabs ahead.
+// overwrites its own columns.  A rows are prefetched three 16-float slabs ahead, across hop boundaries.
 template <int MT, bool VEC4>
 __global__ void __launch_bounds__(1024) k_propagate_fwd(const PropK p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -146,44 +146,55 @@ __global__ void __launch_bounds__(1024) k_propagate_fwd(const PropK p) {
     const int li = lane & 15, lq = lane >> 4;
     constexpr int G = 3;                                            // slabs per prefetch group
     const int ngroups = (NT + G - 1) / G;
+    const int npass = (NT + nwaves - 1) / nwaves;
+    // A rows are fetched one group of G slabs ahead of the MFMAs, ACROSS pass and hop boundaries (the rows of
+    // the next hop's adjacency do not depend on the state), so HBM latency is never exposed at a barrier.
+    auto fetch = [&](float (&dst)[G][4], int l, int pass, int grp) {
+        const int nt = pass * nwaves + wave;
+        const int row = 16 * nt + li;
+        const bool ok = l < p.L && nt < NT && row < S;
+        const float* A = p.adj[l < p.L ? l : 0] + static_cast<int64_t>(b) * S * S;
+#pragma unroll
+        for (int g = 0; g < G; ++g) load_a_row4<VEC4>(dst[g], A, S, row, 16 * (grp * G + g) + 4 * lq, ok && (grp * G + g) < NT);
+    };
+    float bq[G][4], bn[G][4];
+    fetch(bq, 0, 0, 0);
     for (int l = 0; l < p.L; ++l) {
-        const float* A = p.adj[l] + static_cast<int64_t>(b) * S * S;
-        for (int nt0 = 0; nt0 < NT; nt0 += nwaves) {                // one pass when NT <= nwaves
-            const int nt = nt0 + wave;
+        for (int pass = 0; pass < npass; ++pass) {
+            const int nt = pass * nwaves + wave;
             const bool tile_ok = nt < NT;                           // wave-uniform
             f32x4 acc[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (tile_ok) {
-                const int row = 16 * nt + li;
-                const bool row_ok = row < S;
-                float bq[G][4], bn[G][4];
-#pragma unroll
-                for (int g = 0; g < G; ++g) load_a_row4<VEC4>(bq[g], A, S, row, 16 * g + 4 * lq, row_ok && g < NT);
-                for (int grp = 0; grp < ngroups; ++grp) {
-                    const int s0 = grp * G;
-#pragma unroll
-                    for (int g = 0; g < G; ++g)
-                        load_a_row4<VEC4>(bn[g], A, S, row, 16 * (s0 + G + g) + 4 * lq, row_ok && (s0 + G + g) < NT);
+            for (int grp = 0; grp < ngroups; ++grp) {
+                int nl = l, np = pass, ng = grp + 1;                // the step after this one
+                if (ng == ngroups) { ng = 0; if (++np == npass) { np = 0; ++nl; } }
+                fetch(bn, nl, np, ng);
+                const int s0 = grp * G;
+                if (tile_ok) {
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         if (s0 + g < NT) {
                             const int kc = 16 * (s0 + g) + 4 * lq;
+                            float4 aq[MT];
 #pragma unroll
-                            for (int m = 0; m < MT; ++m) {
-                                const float4 aq = *reinterpret_cast<const float4*>(H + (16 * m + li) * pitch + kc);
-                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, bq[g][0], acc[m], 0, 0, 0);
-                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, bq[g][1], acc[m], 0, 0, 0);
-                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, bq[g][2], acc[m], 0, 0, 0);
-                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, bq[g][3], acc[m], 0, 0, 0);
-                            }
+                            for (int m = 0; m < MT; ++m) aq[m] = *reinterpret_cast<const float4*>(H + (16 * m + li) * pitch + kc);
+                            // consecutive MFMAs hit DIFFERENT accumulators (dependent-accumulator latency is 40 cycles, issue 32)
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[m].x, bq[g][0], acc[m], 0, 0, 0);
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[m].y, bq[g][1], acc[m], 0, 0, 0);
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[m].z, bq[g][2], acc[m], 0, 0, 0);
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[m].w, bq[g][3], acc[m], 0, 0, 0);
                         }
                     }
-#pragma unroll
-                    for (int g = 0; g < G; ++g)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) bq[g][j] = bn[g][j];
                 }
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bq[g][j] = bn[g][j];
             }
             if (!dbl) __syncthreads();                              // single buffer: all reads of H^{l-1} done
             // C layout: col (s) = lane&15, row (channel) = (lane>>4)*4 + r
