@@ -13,6 +13,7 @@
 // Both operands are contiguous along the contraction index, so every lane fetches float4s and the
 // K index is permuted consistently (k = 4*(lane>>4) + step) between the A- and B-fragments.
 #include <math.h>
+#include <stdlib.h>
 #include "recon_common.h"
 
 namespace recon {
@@ -228,6 +229,96 @@ __global__ void __launch_bounds__(1024) k_propagate_fwd(const PropK p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------- P2 forward, wave-independent form
+// Channels never mix, so ONE WAVE owns 16 channels of one graph for all L hops and needs no workgroup barrier:
+// its state H^T [16][S] lives in REGISTERS as MFMA A-fragments (NT float4 per lane), every hop streams the whole
+// A_l through B-fragment registers (the 4-5 waves of a graph re-read it from L2), and the hop's outputs go
+// through a private LDS scratch [16][S+4] only to be re-laid out as next hop's A-fragments and for the
+// head*tail gather.  Used when S <= 144 (NT <= 9 register fragments); larger S falls back to k_propagate_fwd.
+template <int NT, bool VEC4>
+__global__ void __launch_bounds__(256) k_propagate_fwd_w(const PropK p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NB = (NT >= 3) ? 3 : NT;                          // column tiles in flight (independent accumulators)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int MTn = (p.C + 15) >> 4;
+    const int unit = blockIdx.x * 4 + wave;
+    if (unit >= p.B * MTn) return;
+    const int b = unit / MTn, m = unit % MTn;
+    const int S = p.S, pitch = p.pitch;
+    float* scr = lds + static_cast<int64_t>(wave) * 16 * pitch;
+    const int li = lane & 15, lq = lane >> 4;
+    const int cmine = 16 * m + li;                                  // channel whose row this lane holds as A-fragment
+    float af[NT][4];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) {
+        const int k = 16 * s + 4 * lq;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            af[s][t] = (cmine < p.C && k + t < S) ? p.h0[b * p.h0_bs + static_cast<int64_t>(cmine) * S + k + t] : 0.f;
+    }
+    for (int l = 0; l < p.L; ++l) {
+        const float* A = p.adj[l] + static_cast<int64_t>(b) * S * S;
+#pragma unroll 1
+        for (int nt0 = 0; nt0 < NT; nt0 += NB) {
+            f32x4 acc[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float bq[NB][4], bn[NB][4];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) load_a_row4<VEC4>(bq[j], A, S, 16 * (nt0 + j) + li, 4 * lq, nt0 + j < NT && 16 * (nt0 + j) + li < S);
+#pragma unroll
+            for (int s = 0; s < NT; ++s) {
+                if (s + 1 < NT) {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        load_a_row4<VEC4>(bn[j], A, S, 16 * (nt0 + j) + li, 16 * (s + 1) + 4 * lq, nt0 + j < NT && 16 * (nt0 + j) + li < S);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][t], bq[j][t], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) bq[j][t] = bn[j][t];
+            }
+            // C layout: col (s) = lane&15, row (channel) = (lane>>4)*4 + r
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (nt0 + j < NT)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) scr[(4 * lq + r) * pitch + 16 * (nt0 + j) + li] = act_fwd(acc[j][r], p.act);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): this wave's scratch writes have landed
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(scr + li * pitch + 16 * s + 4 * lq);
+            af[s][0] = v.x; af[s][1] = v.y; af[s][2] = v.z; af[s][3] = v.w;
+        }
+        // relation_l = gather(h, heads) * gather(h, tails)   (models/models.py:270-273)
+        for (int idx = lane; idx < 16 * p.dd; idx += 64) {
+            const int cl = idx / p.dd, x = idx % p.dd;
+            const int c = 16 * m + cl;
+            if (c < p.C) {
+                const int64_t io = b * p.idx_bs + static_cast<int64_t>(c) * p.dd + x;
+                const int hi = static_cast<int>(p.head[io]), ti = static_cast<int>(p.tail[io]);
+                p.out[(static_cast<int64_t>(b) * p.C + c) * (p.L * p.dd) + l * p.dd + x] = scr[cl * pitch + hi] * scr[cl * pitch + ti];
+            }
+        }
+        if (p.hsave) {
+            float* hs = p.hsave + ((static_cast<int64_t>(l) * p.B + b) * p.C) * S;
+            for (int idx = lane; idx < 16 * S; idx += 64) {
+                const int cl = idx / S, sidx = idx % S;
+                if (16 * m + cl < p.C) hs[static_cast<int64_t>(16 * m + cl) * S + sidx] = scr[cl * pitch + sidx];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                          // scratch reads done before the next hop overwrites it
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ------------------------------------------------------------------------------- P2 backward (one hop per launch)
 struct PropBwdK {
     const float* A;           // adj of this hop [B,S,S]
@@ -432,8 +523,22 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
     p.out = a->out; p.hsave = a->h_saved;
     p.B = a->B; p.C = a->C; p.S = a->S; p.L = a->L; p.dd = a->dd; p.act = a->act;
     p.CC = g.CC; p.Sp = g.Sp; p.pitch = g.pitch;
-    dim3 grid(static_cast<unsigned>(g.chunks), static_cast<unsigned>(a->B));
     hipStream_t st = as_stream(stream);
+    const int NTn = g.Sp / 16;
+    if (NTn <= 9 && !(getenv("RECON_PROP_FWD") && getenv("RECON_PROP_FWD")[0] == 'b')) {      // wave-independent form
+        const int64_t units = 1LL * a->B * ((a->C + 15) / 16);
+        dim3 wgrid(static_cast<unsigned>(ceil_div64(units, 4)));
+        const size_t wlds = 4ull * 16 * g.pitch * sizeof(float);
+#define CALL_W(N_) do { if (v4) hipLaunchKernelGGL((k_propagate_fwd_w<N_, true>), wgrid, dim3(256), wlds, st, p); \
+                        else hipLaunchKernelGGL((k_propagate_fwd_w<N_, false>), wgrid, dim3(256), wlds, st, p); } while (0)
+        switch (NTn) { case 1: CALL_W(1); break; case 2: CALL_W(2); break; case 3: CALL_W(3); break; case 4: CALL_W(4); break;
+                       case 5: CALL_W(5); break; case 6: CALL_W(6); break; case 7: CALL_W(7); break; case 8: CALL_W(8); break;
+                       default: CALL_W(9); break; }
+#undef CALL_W
+        RECON_CHECK_LAUNCH();
+        return RECON_OK;
+    }
+    dim3 grid(static_cast<unsigned>(g.chunks), static_cast<unsigned>(a->B));
     if (g.fwd_lds > 64 * 1024) {
 #define SET_ATTR(MTV, V)                                                                                             \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_fwd<MTV, V>), hipFuncAttributeMaxDynamicSharedMemorySize, \

@@ -63,7 +63,10 @@ def test_propagation_golden(name):
     (6, 4, 4, 1, "relu", True),        # B = 1, 4 hops
     (12, 4, 2, 2, "relu", False),      # C = 132 > 80: two channel chunks per graph
 ])
-def test_propagation_vs_oracle(n, d, L, B, act, per_batch):
+@pytest.mark.parametrize("form", ["wave", "block"])
+def test_propagation_vs_oracle(n, d, L, B, act, per_batch, form, monkeypatch):
+    """`form`: the forward kernel keeps the channel states in registers per wave (S <= 144) or in LDS per workgroup."""
+    monkeypatch.setenv("RECON_PROP_FWD", "b" if form == "block" else "w")
     from recon_amd.propagation import build_block_adjacency, propagate, make_start_embedding, get_head_indices, get_tail_indices
     d_ = dev()
     C, S, dd = n * (n - 1), 2 * d * n, 2 * d
