@@ -102,6 +102,49 @@ class SpecialSpmmFunctionFinal(torch.autograd.Function):
         return None, grad_values, None, None, None
 
 
+class _GatherRows(torch.autograd.Function):
+    """rows = table[index]; the backward is the same segment sum as SpecialSpmmFinal (rows grouped by index,
+    fixed order) instead of torch's sort-based index backward."""
+
+    @staticmethod
+    def forward(ctx, table, index):
+        _require_gpu_f32(table)
+        ctx.n_rows = table.shape[0]
+        ctx.index = index
+        return table.index_select(0, index)
+
+    @staticmethod
+    def backward(ctx, grad):
+        index = ctx.index
+        key = torch.stack((index, index))                       # row 0 = segment id; row 1 is ignored by the row sum
+        g = prepare_graph(_pin_key(index, key), None, ctx.n_rows)
+        grad = grad.contiguous()
+        out = torch.empty(ctx.n_rows, grad.shape[1], dtype=torch.float32, device=grad.device)
+        with torch.cuda.device(grad.device):
+            _lib.check(_lib.lib().recon_spmm_rowsum_fwd(C.byref(g.c), grad.data_ptr(), grad.shape[1], out.data_ptr(),
+                                                        _lib.current_stream()), "recon_spmm_rowsum_fwd")
+        return out, None
+
+
+_KEY_CACHE = {}
+
+
+def _pin_key(index, key):
+    """One [2,E] key tensor per index tensor (identity + version), so that prepare_graph's cache hits across steps."""
+    k = (index.data_ptr(), index._version, tuple(index.shape))
+    hit = _KEY_CACHE.get(k)
+    if hit is None:
+        if len(_KEY_CACHE) > 16:
+            _KEY_CACHE.clear()
+        hit = _KEY_CACHE[k] = (key, index)
+    return hit[0]
+
+
+def gather_rows(table, index):
+    """table[index] with a deterministic, sort-free backward (used for `relation_embed[edge_type]`, GAT/models.py:79)."""
+    return _GatherRows.apply(table, index)
+
+
 class SpecialSpmmFinal(nn.Module):
     def forward(self, edge, edge_w, N, E, out_features):        # GAT/layers.py:82-84
         return SpecialSpmmFunctionFinal.apply(edge, edge_w, N, E, out_features)

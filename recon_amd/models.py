@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed
+from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed, gather_rows
 from .graph import prepare_graph
 
 
@@ -40,15 +40,15 @@ class SpGAT(nn.Module):
         x = entity_embeddings
         has_nhop = edge_type_nhop.shape[0] != 0
         if has_nhop:
-            edge_embed_nhop = relation_embed[edge_type_nhop[:, 0]] + relation_embed[edge_type_nhop[:, 1]]
+            edge_embed_nhop = gather_rows(relation_embed, edge_type_nhop[:, 0]) + gather_rows(relation_embed, edge_type_nhop[:, 1])
         else:
             edge_embed_nhop = torch.tensor([])
         x = self.heads_forward(x, edge_list, edge_embed, edge_list_nhop, edge_embed_nhop)
         x = self.dropout_layer(x)
         out_relation_1 = relation_embed.mm(self.W)
-        edge_embed = out_relation_1[edge_type]
+        edge_embed = gather_rows(out_relation_1, edge_type)
         if has_nhop:
-            edge_embed_nhop = out_relation_1[edge_type_nhop[:, 0]] + out_relation_1[edge_type_nhop[:, 1]]
+            edge_embed_nhop = gather_rows(out_relation_1, edge_type_nhop[:, 0]) + gather_rows(out_relation_1, edge_type_nhop[:, 1])
         else:
             edge_embed_nhop = torch.tensor([])
         x = F.elu(self.out_att(x, edge_list, edge_embed, edge_list_nhop, edge_embed_nhop))
