@@ -140,6 +140,28 @@ def spgat_forward(x, relation_embed, edge_list, edge_type, edge_embed, edge_list
     return y, out_rel
 
 
+def nhop_edges(train_indices_nhop):
+    """GAT/models.py:145-148: 2-hop quadruples [E2,4] = (source, rel_1, rel_2, target) ->
+    edge_list_nhop [2,E2] = (target, source), edge_type_nhop [E2,2] = (rel_1, rel_2)."""
+    if train_indices_nhop is None or train_indices_nhop.shape[0] == 0:
+        return None, None
+    return torch.stack((train_indices_nhop[:, 3], train_indices_nhop[:, 0])), train_indices_nhop[:, 1:3]
+
+
+def spkbgat_forward(entity_embeddings, relation_embeddings, batch_entities, edge_list, edge_type, train_indices_nhop,
+                    head_a, head_a2, W, out_a, out_a2, W_entities, alpha):
+    """SpKBGATModified.forward / batch_test in eval mode (GAT/models.py:136-185, 188-239).
+    `entity_embeddings` is the table AFTER the in-place L2 normalisation of :160 (the reference normalises
+    `.data`, so no gradient flows through that normalisation).  Returns (out_entity, out_relation, mask)."""
+    nhop_list, nhop_type = nhop_edges(train_indices_nhop)
+    x, out_rel = spgat_forward(entity_embeddings, relation_embeddings, edge_list, edge_type, relation_embeddings[edge_type],
+                               nhop_list, nhop_type, head_a, head_a2, W, out_a, out_a2, alpha)
+    mask = torch.zeros(entity_embeddings.shape[0], dtype=entity_embeddings.dtype)
+    mask[torch.unique(batch_entities)] = 1.0                                    # :167-177
+    out = entity_embeddings @ W_entities + mask[:, None] * x                    # :179-181
+    return F.normalize(out, p=2, dim=1), out_rel, mask                          # :183
+
+
 # =============================================================================== GP-GNN side
 def make_start_embedding(n, d):
     """utils/embedding_utils.py:170-182.  Channel c = ordered pair (i, j), i != j, row-major;

@@ -53,3 +53,64 @@ class SpGAT(nn.Module):
             edge_embed_nhop = torch.tensor([])
         x = F.elu(self.out_att(x, edge_list, edge_embed, edge_list_nhop, edge_embed_nhop))
         return x, out_relation_1
+
+
+class SpKBGATModified(nn.Module):
+    """Stage-A KB-GAT model, shaped like GAT/models.py:91-239 (same constructor, `forward` / `batch_test`
+    signatures and state_dict keys: final_entity_embeddings, final_relation_embeddings, entity_embeddings,
+    relation_embeddings, sparse_gat_1.*, W_entities).  The whole entity table goes through the fused SpGAT
+    above with one entity batch's 1-hop + 2-hop edges; rows outside the batch keep only the W_entities skip
+    connection; outputs are L2-normalised.  Inputs must already live on the GPU."""
+
+    def __init__(self, initial_entity_emb, initial_relation_emb, entity_out_dim, relation_out_dim, drop_GAT, alpha,
+                 nheads_GAT, initial_entity_emb_params=None):
+        super().__init__()
+        self.num_nodes, self.entity_in_dim = initial_entity_emb.shape
+        self.entity_out_dim_1, self.entity_out_dim_2 = entity_out_dim[0], entity_out_dim[1]
+        self.nheads_GAT_1, self.nheads_GAT_2 = nheads_GAT[0], nheads_GAT[1]
+        self.num_relation, self.relation_dim = initial_relation_emb.shape
+        self.relation_out_dim_1 = relation_out_dim[0]
+        self.drop_GAT = drop_GAT
+        self.alpha = alpha
+        wide = self.entity_out_dim_1 * self.nheads_GAT_1
+        self.final_entity_embeddings = nn.Parameter(torch.randn(self.num_nodes, wide))
+        self.final_relation_embeddings = nn.Parameter(torch.randn(self.num_relation, wide))
+        self.entity_embeddings = nn.Parameter(initial_entity_emb)
+        self.relation_embeddings = nn.Parameter(initial_relation_emb)
+        self.sparse_gat_1 = SpGAT(self.num_nodes, self.entity_in_dim, self.entity_out_dim_1, self.relation_dim,
+                                  self.drop_GAT, self.alpha, self.nheads_GAT_1)
+        self.W_entities = nn.Parameter(torch.zeros(size=(self.entity_in_dim, wide)))
+        nn.init.xavier_uniform_(self.W_entities.data, gain=1.414)
+
+    @staticmethod
+    def _nhop(train_indices_nhop):
+        # 2-hop quadruples (source, rel_1, rel_2, target) -> edges target <- source typed (rel_1, rel_2), :145-148
+        if train_indices_nhop.shape[0] == 0:
+            return torch.tensor([]), torch.tensor([])
+        return (torch.stack((train_indices_nhop[:, 3], train_indices_nhop[:, 0])).contiguous(),
+                train_indices_nhop[:, 1:3].contiguous())
+
+    def _encode(self, Corpus_, entity_embeddings, relation_embeddings, batch_entities, adj, train_indices_nhop):
+        edge_list, edge_type = adj[0], adj[1]
+        dev = entity_embeddings.device
+        edge_list, edge_type = edge_list.to(dev), edge_type.to(dev)
+        edge_list_nhop, edge_type_nhop = (t.to(dev) if t.numel() else t for t in self._nhop(train_indices_nhop))
+        edge_embed = gather_rows(relation_embeddings, edge_type)
+        out_entity, out_relation = self.sparse_gat_1(Corpus_, entity_embeddings, relation_embeddings, edge_list, edge_type,
+                                                     edge_embed, edge_list_nhop, edge_type_nhop)
+        mask = torch.zeros(entity_embeddings.shape[0], device=dev)
+        mask[torch.unique(batch_entities.to(dev))] = 1.0
+        out_entity = entity_embeddings.mm(self.W_entities) + mask.unsqueeze(-1) * out_entity
+        return F.normalize(out_entity, p=2, dim=1), out_relation, mask
+
+    def forward(self, Corpus_, batch_entities, adj, train_indices_nhop):
+        self.entity_embeddings.data = F.normalize(self.entity_embeddings.data, p=2, dim=1).detach()     # :160, in place
+        out_entity, out_relation, mask = self._encode(Corpus_, self.entity_embeddings, self.relation_embeddings,
+                                                      batch_entities, adj, train_indices_nhop)
+        self.final_entity_embeddings.data = out_entity.data
+        self.final_relation_embeddings.data = out_relation.data
+        return out_entity, out_relation, mask
+
+    def batch_test(self, Corpus_, batch_entities, adj, train_indices_nhop, entity_embeddings):
+        ent = F.normalize(entity_embeddings.data, p=2, dim=1).detach()
+        return self._encode(Corpus_, ent, self.relation_embeddings.detach(), batch_entities, adj, train_indices_nhop)

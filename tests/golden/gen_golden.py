@@ -217,6 +217,45 @@ def gen_gat():
         for k, v in m.named_parameters():
             arrays["g." + k] = t2n(v.grad)
         save(name, **arrays)
+    gen_kbgat(gat_models)
+
+
+def gen_kbgat(gat_models):
+    """G7: SpKBGATModified.forward / batch_test (GAT/models.py:91-239) on a small KG: whole entity table,
+    one entity batch's 1-hop + 2-hop edges, masking, W_entities skip connection, L2 normalisation."""
+    N, nrel, dim, nhid, nheads = 50, 7, 10, 6, 2
+    g = torch.Generator().manual_seed(31)
+    ent0 = torch.randn(N, dim, generator=g)
+    rel0 = torch.randn(nrel, dim, generator=g)
+    edge = torch.randint(0, N, (2, 70), generator=g)
+    etype = torch.randint(0, nrel, (70,), generator=g)
+    nhop = torch.stack([torch.randint(0, N, (25,), generator=g), torch.randint(0, nrel, (25,), generator=g),
+                        torch.randint(0, nrel, (25,), generator=g), torch.randint(0, N, (25,), generator=g)], dim=1)
+    batch_entities = torch.randint(0, N, (30,), generator=g)
+    for name, nh in (("spkbgat1_nhop", nhop), ("spkbgat2_1hop", torch.zeros(0, 4, dtype=torch.long))):
+        torch.manual_seed(5)
+        m = gat_models.SpKBGATModified(ent0.clone(), rel0.clone(), [nhid, nhid * nheads], [nhid * nheads, nhid * nheads],
+                                       0.0, 0.2, [nheads, nheads], None)
+        m.eval()
+        sd0 = {k: t2n(v).copy() for k, v in m.state_dict().items()}
+        out_e, out_r, mask = m(None, batch_entities, (edge, etype), nh)
+        G = torch.randn(out_e.shape, generator=torch.Generator().manual_seed(1))
+        G2 = torch.randn(out_r.shape, generator=torch.Generator().manual_seed(2))
+        ((out_e * G).sum() + (out_r * G2).sum()).backward()
+        with torch.no_grad():
+            te, tr, tm = m.batch_test(None, batch_entities, (edge, etype), nh, ent0 * 1.7)
+        arrays = dict(edge=t2n(edge), edge_type=t2n(etype), nhop=t2n(nh), batch_entities=t2n(batch_entities),
+                      out_entity=t2n(out_e), out_relation=t2n(out_r), mask=t2n(mask), G=t2n(G), G2=t2n(G2),
+                      test_entity=t2n(te), test_relation=t2n(tr), test_input=t2n(ent0 * 1.7),
+                      nheads=np.int32(nheads), nhid=np.int32(nhid), alpha=np.float64(0.2))
+        for k, v in sd0.items():
+            arrays["p0." + k] = v
+        for k, v in m.state_dict().items():
+            arrays["p1." + k] = t2n(v)              # after forward: normalised table, stashed final_* embeddings
+        for k, v in m.named_parameters():
+            if v.grad is not None:
+                arrays["g." + k] = t2n(v.grad)
+        save(name, **arrays)
 
 
 # --------------------------------------------------------------------------- GP-GNN cases

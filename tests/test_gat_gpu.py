@@ -322,3 +322,36 @@ def test_power_law_graphs(path, monkeypatch):
         close(ad.grad[h], r["g_a"].float(), atol=1e-4, what="g_a h%d" % h)
         gx += r["g_x"].float()
     close(xd.grad, gx, atol=1e-4, what="g_x")
+
+
+@pytest.mark.parametrize("name", ["spkbgat1_nhop", "spkbgat2_1hop"])
+def test_spkbgat_golden(name):
+    """G7: the stage-A model (whole entity table, one entity batch of edges) vs the reference SpKBGATModified:
+    strict state_dict load, forward, in-place side effects, all gradients, batch_test."""
+    from recon_amd.models import SpKBGATModified
+    g = load_golden(name)
+    d = dev()
+    H, nhid = int(g["nheads"]), int(g["nhid"])
+    sd0 = {k[3:]: T(g[k]) for k in g if k.startswith("p0.")}
+    m = SpKBGATModified(sd0["entity_embeddings"].clone(), sd0["relation_embeddings"].clone(), [nhid, nhid * H],
+                        [nhid * H, nhid * H], 0.0, float(g["alpha"]), [H, H], None)
+    m.load_state_dict(sd0, strict=True)
+    m = m.to(d).eval()
+    adj = (T(g["edge"]).to(d), T(g["edge_type"]).to(d))
+    nhop = T(g["nhop"]).to(d)
+    be = T(g["batch_entities"]).to(d)
+    out_e, out_r, mask = m(None, be, adj, nhop)
+    close(out_e, g["out_entity"], what="out_entity")
+    close(out_r, g["out_relation"], what="out_relation")
+    np.testing.assert_array_equal(mask.cpu().numpy(), g["mask"])
+    ((out_e * T(g["G"]).to(d)).sum() + (out_r * T(g["G2"]).to(d)).sum()).backward()
+    for k, p in m.named_parameters():
+        if "g." + k in g:
+            close(p.grad, g["g." + k], atol=1e-5, what="g." + k)
+    sd1 = m.state_dict()
+    for k in ("entity_embeddings", "final_entity_embeddings", "final_relation_embeddings"):
+        close(sd1[k], g["p1." + k], atol=2e-5, what="side effect " + k)
+    with torch.no_grad():
+        te, tr, _ = m.batch_test(None, be, adj, nhop, T(g["test_input"]).to(d))
+    close(te, g["test_entity"], what="batch_test entity")
+    close(tr, g["test_relation"], what="batch_test relation")

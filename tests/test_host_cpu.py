@@ -80,6 +80,9 @@ def test_class_surface_matches_reference():
     ref = load_golden("spgat1_nhop")
     sd = {k[2:]: torch.from_numpy(v) for k, v in ref.items() if k.startswith("p.")}
     models.SpGAT(40, 12, 8, 12, 0.0, 0.2, 2).load_state_dict(sd, strict=True)      # the reference's own checkpoint keys
+    kb = models.SpKBGATModified(torch.randn(20, 6), torch.randn(4, 6), [3, 6], [6, 6], 0.0, 0.2, [2, 2], None)
+    ref_kb = load_golden("spkbgat1_nhop")
+    assert sorted(kb.state_dict().keys()) == sorted(k[3:] for k in ref_kb if k.startswith("p0."))   # reference checkpoint keys
     c = gat_layers.ConvKB(8, 3, 1, 4, 0.1, 0.2)
     assert c(torch.randn(5, 24)).shape == (5, 1)
     assert set(c.state_dict().keys()) == {"conv_layer.weight", "conv_layer.bias", "fc_layer.weight", "fc_layer.bias",

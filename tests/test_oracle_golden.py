@@ -89,6 +89,37 @@ def test_spgat(name):
         np.testing.assert_allclose(t.grad.numpy(), g["g." + k[2:]], atol=2e-4, rtol=1e-4, err_msg=k)
 
 
+@pytest.mark.parametrize("name", ["spkbgat1_nhop", "spkbgat2_1hop"])
+def test_spkbgat(name):
+    g = load_golden(name)
+    H = int(g["nheads"])
+    P = {k[3:]: T(g[k]) for k in g if k.startswith("p0.")}
+    ent = torch.nn.functional.normalize(P["entity_embeddings"], p=2, dim=1).requires_grad_(True)
+    np.testing.assert_allclose(ent.detach().numpy(), g["p1.entity_embeddings"], atol=1e-7)     # the in-place normalisation
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items() if k not in ("entity_embeddings", "final_entity_embeddings", "final_relation_embeddings")}
+    out_e, out_r, mask = O.spkbgat_forward(
+        ent, leaves["relation_embeddings"], T(g["batch_entities"]), T(g["edge"]), T(g["edge_type"]), T(g["nhop"]),
+        [leaves["sparse_gat_1.attention_%d.a" % i] for i in range(H)], [leaves["sparse_gat_1.attention_%d.a_2" % i] for i in range(H)],
+        leaves["sparse_gat_1.W"], leaves["sparse_gat_1.out_att.a"], leaves["sparse_gat_1.out_att.a_2"], leaves["W_entities"], float(g["alpha"]))
+    np.testing.assert_allclose(out_e.detach().numpy(), g["out_entity"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(out_r.detach().numpy(), g["out_relation"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_array_equal(mask.numpy(), g["mask"])
+    np.testing.assert_allclose(g["p1.final_entity_embeddings"], g["out_entity"], atol=0)      # stashed by the reference forward
+    ((out_e * T(g["G"])).sum() + (out_r * T(g["G2"])).sum()).backward()
+    np.testing.assert_allclose(ent.grad.numpy(), g["g.entity_embeddings"], atol=2e-4, rtol=1e-4)
+    for k, t in leaves.items():
+        np.testing.assert_allclose(t.grad.numpy(), g["g." + k], atol=2e-4, rtol=1e-4, err_msg=k)
+    # batch_test: a foreign entity table, normalised on the fly, relation table detached
+    tin = torch.nn.functional.normalize(T(g["test_input"]), p=2, dim=1)
+    with torch.no_grad():
+        te, tr, _ = O.spkbgat_forward(
+            tin, leaves["relation_embeddings"], T(g["batch_entities"]), T(g["edge"]), T(g["edge_type"]), T(g["nhop"]),
+            [leaves["sparse_gat_1.attention_%d.a" % i] for i in range(H)], [leaves["sparse_gat_1.attention_%d.a_2" % i] for i in range(H)],
+            leaves["sparse_gat_1.W"], leaves["sparse_gat_1.out_att.a"], leaves["sparse_gat_1.out_att.a_2"], leaves["W_entities"], float(g["alpha"]))
+    np.testing.assert_allclose(te.numpy(), g["test_entity"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(tr.numpy(), g["test_relation"], atol=2e-5, rtol=1e-5)
+
+
 def _prop_inputs(g):
     n, d, L, B, salt = (int(g[k]) for k in ("n", "d", "L", "B", "salt"))
     C, S, dd = n * (n - 1), 2 * d * n, (2 * d) ** 2
