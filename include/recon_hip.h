@@ -180,7 +180,7 @@ typedef struct {
     float* g_sigma;             /* [E,H]      workspace: d loss / d s_e                               */
     float* Gxs;                 /* [E,F]      workspace: per-edge gradient rows bound for x[src_e]    */
     float* gxd;                 /* [N,F]      workspace: destination-side part of d loss / d x        */
-    float* Gs;                  /* [2,N,H]    workspace: per-node sums of g_sigma (dst view, src view) */
+    float* Gs;                  /* [N,2H]     workspace: per-node sums of g_sigma (dst view | src view) */
     float* g_u;                 /* [H,2F+R]   workspace: d loss / d (a_2^T a)                          */
     float* q;                   /* [N,H]      workspace: g_h . h per (node, head)                      */
     float* partial;             /* workspace, recon_gat_atp_bwd_partial_floats() floats (split-K)     */

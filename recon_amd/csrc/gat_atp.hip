@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_bwd(const AtpBwdK p) {
                 }
             }
         }
-        if (hv && lane < HT) p.Gs_dst[static_cast<int64_t>(node) * H + myh] = sum_gs;
+        if (hv && lane < HT) p.Gs_dst[static_cast<int64_t>(node) * 2 * H + myh] = sum_gs;
 #pragma unroll
         for (int h = 0; h < HT; ++h) {
             if (h0 + h < H) {
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_src(const AtpSrcK p) {
             }
         }
     }
-    if (lane < H) p.Gs_src[static_cast<int64_t>(node) * H + lane] = gs;
+    if (lane < H) p.Gs_src[static_cast<int64_t>(node) * 2 * H + H + lane] = gs;
     if (p.g_x) {
 #pragma unroll
         for (int r = 0; r < KR; ++r) {
@@ -814,7 +814,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
     {
         AtpSrcK p;
         p.rowptr_src = g->rowptr_src; p.slot_by_src = g->slot_by_src; p.Gxs = b->Gxs; p.gxd = b->gxd; p.gsigma = b->g_sigma;
-        p.g_x = b->g_x; p.Gs_src = b->Gs + static_cast<int64_t>(N) * H;
+        p.g_x = b->g_x; p.Gs_src = b->Gs;
         p.N = N; p.F = F; p.H = H;
         dim3 grid(static_cast<unsigned>(ceil_div64(N, kBlock / 64)));
         const int key = s.vec * 10 + s.kr;
@@ -852,18 +852,25 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
                     for (int j = 0; j < nj; ++j) (void)hipMemsetAsync(out + (j % P) * S1 + (j / P) * S2, 0, sizeof(float) * K, st);
                     return;
                 }
-                const int rpb = static_cast<int>(ceil_div64(rows, kNB));
+                int rpb = static_cast<int>(ceil_div64(rows, kNB));
+                if (rpb < 64) rpb = 64;                                 // >= 16 rows per wave
                 const int nb = static_cast<int>(ceil_div64(rows, rpb));
                 if (nj <= 8) hipLaunchKernelGGL((k_skinny_tn_partial<8>), dim3(nb), dim3(256), 0, st, G, ldg, nj, X, gather, rows, K, rpb, b->partial2);
                 else hipLaunchKernelGGL((k_skinny_tn_partial<16>), dim3(nb), dim3(256), 0, st, G, ldg, nj, X, gather, rows, K, rpb, b->partial2);
                 hipLaunchKernelGGL(k_skinny_reduce, dim3(static_cast<unsigned>(ceil_div64(1LL * nj * K, 64))), dim3(1024), 0, st, b->partial2, nb,
                                    nj, K, P, S1, S2, out);
             };
-            for (int h0 = 0; h0 < H; h0 += 16) {                       // <= 16 score columns per pass
+            // Gs is [N][2H] (dst sums | src sums): column j = (s, h) lands in g_u[h][s*F ...]
+            for (int j0 = 0; j0 < 2 * H; j0 += 16) {                  // <= 16 score columns per pass
+                const int nj = 2 * H - j0 < 16 ? 2 * H - j0 : 16;
+                if (j0 == 0 && nj == 2 * H) skinny(b->Gs, 2 * H, nj, a->x, nullptr, N, F, H, W, F, b->g_u);
+                else                                                    // more than 8 heads: one column at a time keeps the map simple
+                    for (int j = j0; j < j0 + nj; ++j)
+                        skinny(b->Gs + j, 2 * H, 1, a->x, nullptr, N, F, 1, W, 0, b->g_u + static_cast<int64_t>(j % H) * W + (j / H) * F);
+            }
+            for (int h0 = 0; h0 < H; h0 += 16) {
                 const int nh = H - h0 < 16 ? H - h0 : 16;
-                skinny(b->Gs + h0, H, nh, a->x, nullptr, N, F, nh, W, 0, b->g_u + static_cast<int64_t>(h0) * W);                       // dst
-                skinny(b->Gs + static_cast<int64_t>(N) * H + h0, H, nh, a->x, nullptr, N, F, nh, W, 0, b->g_u + static_cast<int64_t>(h0) * W + F);   // src
-                skinny(b->g_sigma + h0, H, nh, a->edge_embed, g->eid, E, R, nh, W, 0, b->g_u + static_cast<int64_t>(h0) * W + 2 * F);    // rel
+                skinny(b->g_sigma + h0, H, nh, a->edge_embed, g->eid, E, R, nh, W, 0, b->g_u + static_cast<int64_t>(h0) * W + 2 * F);
             }
             RECON_CHECK_LAUNCH();
         }

@@ -278,7 +278,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         g_sigma = torch.empty(E, H, **f32)
         Gxs = torch.empty(E, F_, **f32)
         gxd = torch.empty(N, F_, **f32)
-        Gs = torch.empty(2, N, H, **f32)
+        Gs = torch.empty(N, 2 * H, **f32)
         g_u = torch.empty(H, W, **f32)
         q = torch.empty(N, H, **f32)
         partial = torch.empty(L.recon_gat_atp_bwd_partial_floats(N, E, F_, R, D, H), **f32)
