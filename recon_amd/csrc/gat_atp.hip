@@ -150,17 +150,24 @@ __global__ void __launch_bounds__(kBlock) k_row_dots(const float* __restrict__ X
         const int64_t r = gather ? gather[row] : row;
         const float* xr = X + r * K;
         float mine = 0.f;
-        for (int j = 0; j < NJ; ++j) {
-            float part = 0.f;
-            for (int c = lane * VEC; c < K; c += 64 * VEC) {
-                float xv[VEC], uv[VEC];
-                load_vec<VEC>(xv, xr + c);
-                load_vec<VEC>(uv, U + j * K + c);
+        for (int j0 = 0; j0 < NJ; j0 += 8) {                            // eight dot products share one multi-value reduction
+            float part[8];
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) part = fmaf(xv[v], uv[v], part);
+            for (int jj = 0; jj < 8; ++jj) {
+                part[jj] = 0.f;
+                if (j0 + jj < NJ) {
+                    for (int c = lane * VEC; c < K; c += 64 * VEC) {
+                        float xv[VEC], uv[VEC];
+                        load_vec<VEC>(xv, xr + c);
+                        load_vec<VEC>(uv, U + (j0 + jj) * K + c);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) part[jj] = fmaf(xv[v], uv[v], part[jj]);
+                    }
+                }
             }
-            const float tot = group_sum<64>(part);
-            if (lane == j) mine = tot;
+            const float tot = multi_sum<8>(part, lane);                 // lane l holds column j0 + (l >> 3)
+            const float t = __shfl(tot, (lane & 7) << 3, 64);           // every lane l now holds column j0 + (l & 7)
+            if (lane >= j0 && lane < j0 + 8) mine = t;                  // lane j keeps column j
         }
         if (lane < NJ) out[static_cast<int64_t>(row) * NJ + lane] = mine;
     }
@@ -321,22 +328,26 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_bwd(const AtpBwdK p) {
         for (int v = 0; v < VEC; ++v) { xi[r][v] = 0.f; gxd[r][v] = 0.f; }
         if (aF[r]) load_vec<VEC>(xi[r], p.x + static_cast<int64_t>(node) * F + cf[r]);
     }
+    // lane l works for head h0 + (l >> SH) (the layout multi_sum leaves its totals in); lane h << SH speaks for head h
+    constexpr int SH = HT == 8 ? 3 : HT == 4 ? 4 : HT == 2 ? 5 : 6;
+    const int hl = lane >> SH;
+    const bool writer = (lane & ((1 << SH) - 1)) == 0;
     const int ngroups = (H + HT - 1) / HT;
     for (int hg = 0; hg < ngroups; ++hg) {
         const int h0 = hg * HT;
-        const int myh = h0 + (lane % HT);
+        const int myh = h0 + hl;
         const bool hv = myh < H;
         const float Zl = hv ? p.Z[static_cast<int64_t>(node) * H + myh] : 1.f;
         const float Zkl = hv ? p.Zk[static_cast<int64_t>(node) * H + myh] : 0.f;
         const float invl = 1.f / Zl;
         float gVs[HT][KR][VEC], gVr[HT][KR][VEC];
-        float tdl = 0.f;
+        float pdv[HT];
         const float ql = hv ? p.q[static_cast<int64_t>(node) * H + myh] : 0.f;
 #pragma unroll
         for (int h = 0; h < HT; ++h) {
             float pd = 0.f;
             const bool hok = h0 + h < H;                                  // wave-uniform
-            const float zr = lane_bcast(Zkl * invl, h);
+            const float zr = lane_bcast(Zkl * invl, h << SH);
 #pragma unroll
             for (int r = 0; r < KR; ++r) {
 #pragma unroll
@@ -356,40 +367,53 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_bwd(const AtpBwdK p) {
                     if (aR[r]) load_vec<VEC>(gVr[h][r], p.gV + base + 2 * F + cf[r]);
                 }
             }
-            const float td = group_sum<64>(pd);
-            if ((lane % HT) == h) tdl = td;
+            pdv[h] = pd;
         }
+        const float tdl = multi_sum<HT>(pdv, lane);
         const float gZl = -ql * invl;                                     // d loss / d Z   (every part of V is ~ 1/Z)
         float sum_gs = 0.f;
-        for (int k = beg; k < end; ++k) {
-            const int s = p.src[k], e = p.eid[k];
-            float xs[KR][VEC], re[KR][VEC];
+        // software pipeline: the rows / score of edge k+1 are in flight while edge k is processed
+        float xs_n[KR][VEC], re_n[KR][VEC], sg_n = 0.f, kf_n = 1.f;
+        int e_n = 0;
+        auto fetch_edge = [&](int k) {
+            const int s = p.src[k];
+            e_n = p.eid[k];
 #pragma unroll
             for (int r = 0; r < KR; ++r) {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) { xs[r][v] = 0.f; re[r][v] = 0.f; }
-                if (aF[r]) load_vec<VEC>(xs[r], p.x + static_cast<int64_t>(s) * F + cf[r]);
-                if (aR[r]) load_vec<VEC>(re[r], p.ee + static_cast<int64_t>(e) * R + cf[r]);
+                for (int v = 0; v < VEC; ++v) { xs_n[r][v] = 0.f; re_n[r][v] = 0.f; }
+                if (aF[r]) load_vec<VEC>(xs_n[r], p.x + static_cast<int64_t>(s) * F + cf[r]);
+                if (aR[r]) load_vec<VEC>(re_n[r], p.ee + static_cast<int64_t>(e_n) * R + cf[r]);
             }
-            const float sg = hv ? p.sigma[static_cast<int64_t>(k) * H + myh] : 0.f;
-            const float kf = (hv && p.keep) ? p.keep[static_cast<int64_t>(k) * H + myh] : 1.f;
-            float tl = 0.f;
+            sg_n = hv ? p.sigma[static_cast<int64_t>(k) * H + myh] : 0.f;
+            kf_n = (hv && p.keep) ? p.keep[static_cast<int64_t>(k) * H + myh] : 1.f;
+        };
+        if (beg < end) fetch_edge(beg);
+        for (int k = beg; k < end; ++k) {
+            float xs[KR][VEC], re[KR][VEC];
+#pragma unroll
+            for (int r = 0; r < KR; ++r)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { xs[r][v] = xs_n[r][v]; re[r][v] = re_n[r][v]; }
+            const float sg = sg_n, kf = kf_n;
+            const int e = e_n;
+            if (k + 1 < end) fetch_edge(k + 1);
+            float part[HT];
 #pragma unroll
             for (int h = 0; h < HT; ++h) {
-                float part = 0.f;
+                part[h] = 0.f;
 #pragma unroll
                 for (int r = 0; r < KR; ++r)
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) part = fmaf(gVs[h][r][v], xs[r][v], fmaf(gVr[h][r][v], re[r][v], part));
-                const float t = group_sum<64>(part);
-                if ((lane % HT) == h) tl = t;
+                    for (int v = 0; v < VEC; ++v) part[h] = fmaf(gVs[h][r][v], xs[r][v], fmaf(gVr[h][r][v], re[r][v], part[h]));
             }
+            const float tl = multi_sum<HT>(part, lane);
             const float w = hv ? expf(-(sg > 0.f ? sg : p.alpha * sg)) : 0.f;
             const float gw = fmaf(kf * (tl + tdl), invl, gZl);
             const float gs = hv ? -gw * w * (sg > 0.f ? 1.f : p.alpha) : 0.f;
             const float al_ = kf * w * invl;
             sum_gs += gs;
-            if (hv && lane < HT) p.gsigma[static_cast<int64_t>(k) * H + myh] = gs;
+            if (hv && writer) p.gsigma[static_cast<int64_t>(k) * H + myh] = gs;
             float gxs[KR][VEC], gr[KR][VEC];
 #pragma unroll
             for (int r = 0; r < KR; ++r)
@@ -398,7 +422,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_bwd(const AtpBwdK p) {
 #pragma unroll
             for (int h = 0; h < HT; ++h) {
                 if (h0 + h < H) {
-                    const float ah = lane_bcast(al_, h), bh = lane_bcast(gs, h);
+                    const float ah = lane_bcast(al_, h << SH), bh = lane_bcast(gs, h << SH);
                     const float* uh = U + (h0 + h) * W;
 #pragma unroll
                     for (int r = 0; r < KR; ++r) {
@@ -434,11 +458,11 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_bwd(const AtpBwdK p) {
                 }
             }
         }
-        if (hv && lane < HT) p.Gs_dst[static_cast<int64_t>(node) * 2 * H + myh] = sum_gs;
+        if (hv && writer) p.Gs_dst[static_cast<int64_t>(node) * 2 * H + myh] = sum_gs;
 #pragma unroll
         for (int h = 0; h < HT; ++h) {
             if (h0 + h < H) {
-                const float sh = lane_bcast(sum_gs, h);
+                const float sh = lane_bcast(sum_gs, h << SH);
                 const float* uh = U + (h0 + h) * W;
 #pragma unroll
                 for (int r = 0; r < KR; ++r)

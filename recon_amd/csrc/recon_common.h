@@ -38,6 +38,39 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// Reduce NV per-lane values over the 64 lanes of a wave at once: each halving step exchanges HALF of the
+// remaining values with the lane whose bit (32, 16, 8) differs, so NV values cost NV-1 exchanges + log2(64/NV)
+// DPP steps instead of NV full reductions.  Lane l ends up with the total of value index l >> (6 - log2 NV).
+template <int NV>
+__device__ __forceinline__ float multi_sum(float (&v)[NV], int lane) {
+    static_assert(NV == 1 || NV == 2 || NV == 4 || NV == 8, "values per wave");
+    if constexpr (NV == 1) {
+        return group_sum<64>(v[0]);
+    } else {
+        float w[NV / 2];
+        const bool up = lane & 32;
+#pragma unroll
+        for (int j = 0; j < NV / 2; ++j) w[j] = (up ? v[j + NV / 2] : v[j]) + __shfl_xor(up ? v[j] : v[j + NV / 2], 32, 64);
+        if constexpr (NV == 2) {
+            float r = w[0];
+            r += __shfl_xor(r, 16, 64);
+            return group_sum<16>(r);
+        } else {
+            float x[NV / 4];
+            const bool up2 = lane & 16;
+#pragma unroll
+            for (int j = 0; j < NV / 4; ++j) x[j] = (up2 ? w[j + NV / 4] : w[j]) + __shfl_xor(up2 ? w[j] : w[j + NV / 4], 16, 64);
+            if constexpr (NV == 4) {
+                return group_sum<16>(x[0]);
+            } else {
+                const bool up3 = lane & 8;
+                const float r = (up3 ? x[1] : x[0]) + __shfl_xor(up3 ? x[0] : x[1], 8, 64);
+                return group_sum<8>(r);
+            }
+        }
+    }
+}
+
 template <int VEC> struct VecT;
 template <> struct VecT<1> { using type = float; };
 template <> struct VecT<2> { using type = float2; };
