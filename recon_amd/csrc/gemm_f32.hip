@@ -148,18 +148,31 @@ __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const G
         float (*As)[LA::LD] = As2[cur];
         float (*Bs)[LB::LD] = Bs2[cur];
         if (more) { la.load(dA, k0 + BK, k_end); lb.load(dB, k0 + BK, k_end); }
+        // fragments of k-step ks+1 are read from LDS before the MFMAs of k-step ks are issued
+        float a[TM], b[TN], an[TM], bn[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = As[lk][mb + i * 32 + lr];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Bs[lk][nb + j * 32 + lr];
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
-            const int kk = 2 * ks + lk;
-            float a[TM], b[TN];
+            if (ks + 1 < BK / 2) {
+                const int kk = 2 * (ks + 1) + lk;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[kk][mb + i * 32 + lr];
+                for (int i = 0; i < TM; ++i) an[i] = As[kk][mb + i * 32 + lr];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[kk][nb + j * 32 + lr];
+                for (int j = 0; j < TN; ++j) bn[j] = Bs[kk][nb + j * 32 + lr];
+            }
+            __builtin_amdgcn_sched_barrier(0);          // keep the next fragments' ds_reads ahead of this step's MFMAs
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = an[i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bn[j];
         }
         if (more) { la.store(As2[cur ^ 1]); lb.store(Bs2[cur ^ 1]); }
         __syncthreads();
