@@ -60,10 +60,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank % ndev)                 # one GPU per rank on a real node (ndev >= world)
+    dev = torch.device("cuda", local_rank % ndev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        # "nccl" = RCCL over xGMI.  RECON_DIST_BACKEND=gloo exists only to exercise this path on a 1-GPU box.
+        backend = os.environ.get("RECON_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from recon_amd import _lib
     from recon_amd.models import SpGAT
