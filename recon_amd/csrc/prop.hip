@@ -64,6 +64,37 @@ __global__ void k_block_adj_bwd_T(const float* __restrict__ gA, int32_t B, int32
     if (j >= i) ++j;
     gT[idx] = gA[(b * S + i * dd + r) * S + j * dd + c];
 }
+
+// float4 variants for dd % 4 == 0 (every 4-float chunk lies inside one dd x dd block): grid = (chunks of one graph, B)
+__global__ void __launch_bounds__(256) k_block_adj_fwd4(const float* __restrict__ T, const float* __restrict__ I, int32_t n, int32_t dd,
+                                                        float* __restrict__ A) {
+    const int S = n * dd, S4 = S >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= S * S4) return;
+    const int b = blockIdx.y;
+    const int row = t / S4, col = (t - row * S4) << 2;
+    const int i = row / dd, r = row - i * dd, j = col / dd, c = col - j * dd;
+    float4 v;
+    if (i == j) v = *reinterpret_cast<const float4*>(I + r * dd + c);
+    else {
+        const int e = i * (n - 1) + (j < i ? j : j - 1);
+        v = *reinterpret_cast<const float4*>(T + (static_cast<int64_t>(b) * n * (n - 1) + e) * dd * dd + r * dd + c);
+    }
+    *reinterpret_cast<float4*>(A + static_cast<int64_t>(b) * S * S + static_cast<int64_t>(row) * S + col) = v;
+}
+__global__ void __launch_bounds__(256) k_block_adj_bwd_T4(const float* __restrict__ gA, int32_t n, int32_t dd, float* __restrict__ gT) {
+    const int S = n * dd, d2 = dd * dd, Cn = n * (n - 1);
+    const int t = blockIdx.x * 256 + threadIdx.x;               // float4 index inside one graph's gT [Cn][dd][dd]
+    if (t >= Cn * (d2 >> 2)) return;
+    const int b = blockIdx.y;
+    const int e = t / (d2 >> 2), rc = (t - e * (d2 >> 2)) << 2;
+    const int r = rc / dd, c = rc - r * dd;
+    const int i = e / (n - 1);
+    int j = e - i * (n - 1);
+    if (j >= i) ++j;
+    const float4 v = *reinterpret_cast<const float4*>(gA + static_cast<int64_t>(b) * S * S + static_cast<int64_t>(i * dd + r) * S + j * dd + c);
+    *reinterpret_cast<float4*>(gT + (static_cast<int64_t>(b) * Cn + e) * d2 + rc) = v;
+}
 // g_identity[r,c] = sum_{b,i} gA[b, i*dd+r, i*dd+c]; one block per (r,c), fixed-order tree
 __global__ void __launch_bounds__(256) k_block_adj_bwd_I(const float* __restrict__ gA, int32_t B, int32_t n, int32_t dd,
                                                          float* __restrict__ gI) {
@@ -333,15 +364,15 @@ struct PropBwdK {
 };
 
 template <int MT, bool VEC4>
-__global__ void __launch_bounds__(kPT) k_propagate_bwd_hop(const PropBwdK p) {
+__global__ void __launch_bounds__(1024) k_propagate_bwd_hop(const PropBwdK p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = blockDim.x >> 6;
     const int chunk = blockIdx.x, b = blockIdx.y;
     const int c0 = chunk * p.CC;
     const int pitch = p.pitch, S = p.S, CC = p.CC;
     float* X = lds;                                       // H^l, later H^l-1
     float* Y = lds + static_cast<int64_t>(CC) * pitch;    // grad wrt H^l -> grad wrt pre-activation
-    for (int idx = tid; idx < CC * pitch; idx += kPT) {
+    for (int idx = tid; idx < CC * pitch; idx += nthreads) {
         const int cl = idx / pitch, s = idx % pitch;
         const int c = c0 + cl;
         const bool ok = c < p.C && s < S;
@@ -351,7 +382,7 @@ __global__ void __launch_bounds__(kPT) k_propagate_bwd_hop(const PropBwdK p) {
     }
     __syncthreads();
     // relation gradient: d(h[head]*h[tail])
-    for (int idx = tid; idx < CC * p.dd; idx += kPT) {
+    for (int idx = tid; idx < CC * p.dd; idx += nthreads) {
         const int cl = idx / p.dd, x = idx % p.dd;
         const int c = c0 + cl;
         if (c < p.C) {
@@ -363,9 +394,9 @@ __global__ void __launch_bounds__(kPT) k_propagate_bwd_hop(const PropBwdK p) {
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < CC * pitch; idx += kPT) Y[idx] *= act_bwd(X[idx], p.act);
+    for (int idx = tid; idx < CC * pitch; idx += nthreads) Y[idx] *= act_bwd(X[idx], p.act);
     __syncthreads();
-    for (int idx = tid; idx < CC * pitch; idx += kPT) {
+    for (int idx = tid; idx < CC * pitch; idx += nthreads) {
         const int cl = idx / pitch, s = idx % pitch;
         const int c = c0 + cl;
         X[idx] = (c < p.C && s < S) ? p.Hprev[b * p.hprev_bs + static_cast<int64_t>(c) * S + s] : 0.f;
@@ -376,7 +407,7 @@ __global__ void __launch_bounds__(kPT) k_propagate_bwd_hop(const PropBwdK p) {
     // (i) gA[s][t] = sum_c Y[c][s] * X[c][t]       (M = s, N = t, K = channel)
     if (p.gA) {
         float* gA = p.gA + static_cast<int64_t>(b) * S * S;
-        for (int tile = wave; tile < NT * NT; tile += kPT / 64) {
+        for (int tile = wave; tile < NT * NT; tile += nwaves) {
             const int ms = tile / NT, nt = tile % NT;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int kc = 0; kc < CC; kc += 16) {
@@ -399,24 +430,32 @@ __global__ void __launch_bounds__(kPT) k_propagate_bwd_hop(const PropBwdK p) {
     // (ii) gHprev[c][t] = sum_s Y[c][s] * A[s][t]    (M = channel, N = t, K = s)
     {
         const float* A = p.A + static_cast<int64_t>(b) * S * S;
-        for (int nt = wave; nt < NT; nt += kPT / 64) {
+        for (int nt = wave; nt < NT; nt += nwaves) {
             f32x4 acc[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int col = 16 * nt + li;
+            float bq[4], bn[4];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) bq[st] = (4 * lq + st < S && col < S) ? A[static_cast<int64_t>(4 * lq + st) * S + col] : 0.f;
             for (int slab = 0; slab < NT; ++slab) {
                 const int kc = 16 * slab + 4 * lq;
-                float bq[4];
 #pragma unroll
-                for (int st = 0; st < 4; ++st) bq[st] = (kc + st < S && col < S) ? A[static_cast<int64_t>(kc + st) * S + col] : 0.f;
+                for (int st = 0; st < 4; ++st)          // rows of the next slab are in flight during this slab's MFMAs
+                    bn[st] = (slab + 1 < NT && kc + 16 + st < S && col < S) ? A[static_cast<int64_t>(kc + 16 + st) * S + col] : 0.f;
+                float4 aq[MT];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const float4 aq = *reinterpret_cast<const float4*>(Y + (16 * m + li) * pitch + kc);
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, bq[0], acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, bq[1], acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, bq[2], acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, bq[3], acc[m], 0, 0, 0);
-                }
+                for (int m = 0; m < MT; ++m) aq[m] = *reinterpret_cast<const float4*>(Y + (16 * m + li) * pitch + kc);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[m].x, bq[0], acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[m].y, bq[1], acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[m].z, bq[2], acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[m].w, bq[3], acc[m], 0, 0, 0);
+#pragma unroll
+                for (int st = 0; st < 4; ++st) bq[st] = bn[st];
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -470,8 +509,11 @@ extern "C" int recon_block_adjacency_fwd(const float* T, const float* identity, 
     if (B < 0 || n < 1 || dd < 1 || !identity || !A || (n > 1 && B > 0 && !T)) return RECON_ERR_INVALID;
     const int64_t total = 1LL * B * n * dd * n * dd;
     if (total == 0) return RECON_OK;
-    hipLaunchKernelGGL(k_block_adj_fwd, dim3(static_cast<unsigned>(ceil_div64(total, 256))), dim3(256), 0, as_stream(stream), T,
-                       identity, B, n, dd, A);
+    const bool v4 = dd % 4 == 0 && B <= 65535 && !((reinterpret_cast<uintptr_t>(T) | reinterpret_cast<uintptr_t>(identity) | reinterpret_cast<uintptr_t>(A)) & 15);
+    if (v4) hipLaunchKernelGGL(k_block_adj_fwd4, dim3(static_cast<unsigned>(ceil_div64(1LL * n * dd * n * dd / 4, 256)), static_cast<unsigned>(B)), dim3(256), 0,
+                               as_stream(stream), T, identity, n, dd, A);
+    else hipLaunchKernelGGL(k_block_adj_fwd, dim3(static_cast<unsigned>(ceil_div64(total, 256))), dim3(256), 0, as_stream(stream), T,
+                            identity, B, n, dd, A);
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }
@@ -481,8 +523,12 @@ extern "C" int recon_block_adjacency_bwd(const float* gA, int32_t B, int32_t n, 
     if (B < 0 || n < 1 || dd < 1 || !gA) return RECON_ERR_INVALID;
     hipStream_t st = as_stream(stream);
     const int64_t total = 1LL * B * n * (n - 1) * dd * dd;
-    if (gT && total > 0)
-        hipLaunchKernelGGL(k_block_adj_bwd_T, dim3(static_cast<unsigned>(ceil_div64(total, 256))), dim3(256), 0, st, gA, B, n, dd, gT);
+    const bool v4 = dd % 4 == 0 && B <= 65535 && !((reinterpret_cast<uintptr_t>(gA) | reinterpret_cast<uintptr_t>(gT)) & 15);
+    if (gT && total > 0) {
+        if (v4) hipLaunchKernelGGL(k_block_adj_bwd_T4, dim3(static_cast<unsigned>(ceil_div64(1LL * n * (n - 1) * dd * dd / 4, 256)), static_cast<unsigned>(B)),
+                                   dim3(256), 0, st, gA, n, dd, gT);
+        else hipLaunchKernelGGL(k_block_adj_bwd_T, dim3(static_cast<unsigned>(ceil_div64(total, 256))), dim3(256), 0, st, gA, B, n, dd, gT);
+    }
     if (g_identity) hipLaunchKernelGGL(k_block_adj_bwd_I, dim3(dd * dd), dim3(256), 0, st, gA, B, n, dd, g_identity);
     RECON_CHECK_LAUNCH();
     return RECON_OK;
@@ -586,7 +632,7 @@ extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t
         p.B = a->B; p.C = a->C; p.S = a->S; p.L = a->L; p.dd = a->dd; p.act = a->act;
         p.CC = g.CC; p.Sp = g.Sp; p.pitch = g.pitch; p.hop = l - 1; p.first = (l == a->L) ? 1 : 0; p.chunks = g.chunks;
         if (p.gA && g.chunks > 1) hipMemsetAsync(p.gA, 0, sizeof(float) * a->B * a->S * a->S, st);
-        RECON_DISPATCH_MT(g.MT, false, k_propagate_bwd_hop, grid, dim3(kPT), g.lds, st, p);
+        RECON_DISPATCH_MT(g.MT, false, k_propagate_bwd_hop, grid, dim3(64 * g.fwd_waves), g.lds, st, p);
         RECON_CHECK_LAUNCH();
     }
     return RECON_OK;
@@ -673,12 +719,23 @@ __global__ void __launch_bounds__(256) k_gcn_bias_partial(const float* __restric
     for (int64_t r = r0; r < r1; ++r) s += fwd_out[r * O + o] > 0.f ? gout[r * O + o] : 0.f;
     partial[static_cast<int64_t>(blockIdx.y) * O + o] = s;
 }
-__global__ void k_sum_rows(const float* __restrict__ partial, int32_t nrows, int32_t O, float* __restrict__ out) {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= O) return;
+// out[o] = sum_r partial[r][o]: 64 columns x 16 row groups per block, fixed-order LDS combine
+__global__ void __launch_bounds__(1024) k_sum_rows(const float* __restrict__ partial, int32_t nrows, int32_t O, float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + c;
+    const int per = (nrows + 15) / 16;
     float s = 0.f;
-    for (int r = 0; r < nrows; ++r) s += partial[static_cast<int64_t>(r) * O + o];
-    out[o] = s;
+    if (o < O)
+        for (int r = grp * per; r < min(nrows, (grp + 1) * per); ++r) s += partial[static_cast<int64_t>(r) * O + o];
+    red[grp][c] = s;
+    __syncthreads();
+    if (grp == 0 && o < O) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][c];
+        out[o] = t;
+    }
 }
 
 int check_gcn(const recon_gcn_args* a) {
@@ -690,7 +747,7 @@ int check_gcn(const recon_gcn_args* a) {
     return RECON_OK;
 }
 size_t gcn_lds(int n) { return (static_cast<size_t>(n) * ((n + 3) / 4 * 4) + static_cast<size_t>(n) * 64) * sizeof(float); }
-constexpr int kBiasBlocks = 256;
+constexpr int kBiasBlocks = 1024;
 
 }  // namespace
 
@@ -740,7 +797,7 @@ extern "C" int recon_gcn_bwd(const recon_gcn_bwd_args* b, recon_stream_t stream)
         const int nb = static_cast<int>(ceil_div64(rows, rpb));
         hipLaunchKernelGGL(k_gcn_bias_partial, dim3(static_cast<unsigned>(ceil_div64(O, 256)), static_cast<unsigned>(nb)), dim3(256), 0, st,
                            b->grad_out, a->out, static_cast<int64_t>(rows), O, rpb, b->partial);
-        hipLaunchKernelGGL(k_sum_rows, dim3(static_cast<unsigned>(ceil_div64(O, 256))), dim3(256), 0, st, b->partial, nb, O, b->g_bias);
+        hipLaunchKernelGGL(k_sum_rows, dim3(static_cast<unsigned>(ceil_div64(O, 64))), dim3(1024), 0, st, b->partial, nb, O, b->g_bias);
     }
     RECON_CHECK_LAUNCH();
     // g_x = g_support @ W^T
