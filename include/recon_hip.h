@@ -72,8 +72,10 @@ int recon_graph_build(const int64_t* edge_dst, const int64_t* edge_src, recon_gr
  * G1-G3  SpecialSpmmFinal: out[r,:] = sum_{e: edge[0,e]==r} edge_w[e,:]   (GAT/layers.py:54-64)
  *        backward: grad_edge_w[e,:] = grad_out[edge[0,e],:]               (GAT/layers.py:67-79)
  * ------------------------------------------------------------------------------------------*/
+size_t recon_spmm_rowsum_workspace_floats(int32_t E, int32_t out_features);
 int recon_spmm_rowsum_fwd(const recon_graph* g, const float* edge_w /*[E,out_features]*/,
-                          int32_t out_features, float* out /*[N,out_features]*/, recon_stream_t stream);
+                          int32_t out_features, float* out /*[N,out_features]*/,
+                          float* workspace /* recon_spmm_rowsum_workspace_floats() floats */, recon_stream_t stream);
 int recon_spmm_rowsum_bwd(const int64_t* edge_dst /*[E]*/, int64_t E, const float* grad_out /*[N,out]*/,
                           int32_t out_features, float* grad_edge_w /*[E,out]*/, recon_stream_t stream);
 

@@ -584,14 +584,82 @@ extern "C" int recon_gat_bwd(const recon_graph* g, const recon_gat_bwd_args* b, 
 
 // ---- G1-G3: SpecialSpmmFinal as a stand-alone op -------------------------------------------
 namespace {
-__global__ void k_spmm_rowsum_fwd(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ eid,
-                                  const float* __restrict__ w, int32_t N, int32_t C, float* __restrict__ out) {
-    const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (idx >= static_cast<int64_t>(N) * C) return;
-    const int node = static_cast<int>(idx / C), c = static_cast<int>(idx % C);
-    float s = 0.f;
-    for (int k = rowptr[node]; k < rowptr[node + 1]; ++k) s += w[static_cast<int64_t>(eid[k]) * C + c];
-    out[idx] = s;
+// Segmented row sum, robust to very long segments (a relation type owning 10^4 edges) and to tiny ones:
+// pass 1: one wave walks kSL consecutive CSR slots in order (lanes span the columns), sums runs of equal
+//         destination in registers, writes segments that lie entirely inside its slot range straight to `out`
+//         and the (at most two) segments that cross its range boundary to carry[wave][0 = continues from the
+//         left | 1 = continues to the right];
+// pass 2: one wave per destination that spans several ranges adds its carries in slot order.  Fixed order,
+//         no atomics.  `out` must be zeroed first (rows without edges).
+constexpr int kSL = 256;
+template <int VEC>
+__global__ void __launch_bounds__(256) k_rowsum_walk(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ dst,
+                                                     const int32_t* __restrict__ eid, const float* __restrict__ w, int32_t E,
+                                                     int32_t C, float* __restrict__ out, float* __restrict__ carry) {
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int k0 = wv * kSL;
+    if (k0 >= E) return;
+    const int k1 = min(E, k0 + kSL);
+    const int c = blockIdx.y * 64 * VEC + lane * VEC;
+    const bool ca = c < C;
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    int cur = dst[k0];
+    auto flush = [&](int node) {
+        const int b = rowptr[node], e = rowptr[node + 1];
+        float* target;
+        if (b >= k0 && e <= k1) target = out + static_cast<int64_t>(node) * C;                        // complete here
+        else target = carry + (static_cast<int64_t>(wv) * 2 + ((b < k0) ? 0 : 1)) * C;               // crosses the range
+        if (ca) store_vec<VEC>(target + c, acc);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    };
+    for (int k = k0; k < k1; k += 4) {
+        float t[4][VEC];
+        int d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            d[u] = cur;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) t[u][v] = 0.f;
+            if (k + u < k1) {
+                d[u] = dst[k + u];
+                if (ca) load_vec<VEC>(t[u], w + static_cast<int64_t>(eid[k + u]) * C + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k + u < k1) {
+                if (d[u] != cur) { flush(cur); cur = d[u]; }        // wave-uniform
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] += t[u][v];
+            }
+        }
+    }
+    flush(cur);
+}
+template <int VEC>
+__global__ void __launch_bounds__(256) k_rowsum_fix(const int32_t* __restrict__ rowptr, int32_t N, int32_t C,
+                                                    const float* __restrict__ carry, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= N) return;
+    const int b = rowptr[node], e = rowptr[node + 1];
+    if (e <= b) return;
+    const int wa = b / kSL, wb = (e - 1) / kSL;
+    if (wa == wb) return;                                           // lay inside one range: already written
+    for (int c = lane * VEC; c < C; c += 64 * VEC) {
+        float s[VEC], t[VEC];
+        load_vec<VEC>(s, carry + (static_cast<int64_t>(wa) * 2 + 1) * C + c);
+        for (int wv = wa + 1; wv <= wb; ++wv) {
+            load_vec<VEC>(t, carry + (static_cast<int64_t>(wv) * 2 + 0) * C + c);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) s[v] += t[v];
+        }
+        store_vec<VEC>(out + static_cast<int64_t>(node) * C + c, s);
+    }
 }
 __global__ void k_spmm_rowsum_bwd(const int64_t* __restrict__ dst, int64_t E, int32_t C, const float* __restrict__ gout,
                                   float* __restrict__ gw) {
@@ -601,13 +669,30 @@ __global__ void k_spmm_rowsum_bwd(const int64_t* __restrict__ dst, int64_t E, in
 }
 }  // namespace
 
+extern "C" size_t recon_spmm_rowsum_workspace_floats(int32_t E, int32_t out_features) {
+    return static_cast<size_t>(ceil_div64(E > 0 ? E : 1, kSL)) * 2 * static_cast<size_t>(out_features > 0 ? out_features : 1);
+}
+
 extern "C" int recon_spmm_rowsum_fwd(const recon_graph* g, const float* edge_w, int32_t out_features, float* out,
-                                     recon_stream_t stream) {
-    if (!g || !out || out_features <= 0 || (g->E > 0 && !edge_w)) return RECON_ERR_INVALID;
+                                     float* workspace, recon_stream_t stream) {
+    if (!g || !out || out_features <= 0 || (g->E > 0 && (!edge_w || !workspace))) return RECON_ERR_INVALID;
     const int64_t total = static_cast<int64_t>(g->N) * out_features;
     if (total == 0) return RECON_OK;
-    hipLaunchKernelGGL(k_spmm_rowsum_fwd, dim3(static_cast<unsigned>(ceil_div64(total, 256))), dim3(256), 0, as_stream(stream),
-                       g->rowptr_dst, g->eid, edge_w, g->N, out_features, out);
+    hipStream_t st = as_stream(stream);
+    (void)hipMemsetAsync(out, 0, sizeof(float) * total, st);
+    if (g->E == 0) return RECON_OK;
+    const int C = out_features;
+    const int vec = (C % 4 == 0 && al(edge_w, 16) && al(out, 16) && al(workspace, 16)) ? 4 : 1;
+    const int nw = static_cast<int>(ceil_div64(g->E, kSL));
+    dim3 grid(static_cast<unsigned>(ceil_div64(nw, 4)), static_cast<unsigned>(ceil_div64(C, 64 * vec)));
+    dim3 fgrid(static_cast<unsigned>(ceil_div64(g->N, 4)));
+    if (vec == 4) {
+        hipLaunchKernelGGL((k_rowsum_walk<4>), grid, dim3(256), 0, st, g->rowptr_dst, g->dst, g->eid, edge_w, g->E, C, out, workspace);
+        hipLaunchKernelGGL((k_rowsum_fix<4>), fgrid, dim3(256), 0, st, g->rowptr_dst, g->N, C, workspace, out);
+    } else {
+        hipLaunchKernelGGL((k_rowsum_walk<1>), grid, dim3(256), 0, st, g->rowptr_dst, g->dst, g->eid, edge_w, g->E, C, out, workspace);
+        hipLaunchKernelGGL((k_rowsum_fix<1>), fgrid, dim3(256), 0, st, g->rowptr_dst, g->N, C, workspace, out);
+    }
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }

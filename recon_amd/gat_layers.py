@@ -80,8 +80,9 @@ class SpecialSpmmFunctionFinal(torch.autograd.Function):
         g = prepare_graph(edge, None, N)
         w = edge_w.contiguous().view(g.E, -1)
         out = torch.empty(N, w.shape[1], dtype=torch.float32, device=w.device)
+        ws = torch.empty(L.recon_spmm_rowsum_workspace_floats(g.E, w.shape[1]), dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
-            _lib.check(L.recon_spmm_rowsum_fwd(C.byref(g.c), w.data_ptr(), w.shape[1], out.data_ptr(),
+            _lib.check(L.recon_spmm_rowsum_fwd(C.byref(g.c), w.data_ptr(), w.shape[1], out.data_ptr(), ws.data_ptr(),
                                                _lib.current_stream()), "recon_spmm_rowsum_fwd")
         ctx.graph = g
         ctx.N, ctx.outfeat, ctx.E = N, w.shape[1], E
@@ -120,9 +121,11 @@ class _GatherRows(torch.autograd.Function):
         g = prepare_graph(_pin_key(index, key), None, ctx.n_rows)
         grad = grad.contiguous()
         out = torch.empty(ctx.n_rows, grad.shape[1], dtype=torch.float32, device=grad.device)
+        L = _lib.lib()
+        ws = torch.empty(L.recon_spmm_rowsum_workspace_floats(g.E, grad.shape[1]), dtype=torch.float32, device=grad.device)
         with torch.cuda.device(grad.device):
-            _lib.check(_lib.lib().recon_spmm_rowsum_fwd(C.byref(g.c), grad.data_ptr(), grad.shape[1], out.data_ptr(),
-                                                        _lib.current_stream()), "recon_spmm_rowsum_fwd")
+            _lib.check(L.recon_spmm_rowsum_fwd(C.byref(g.c), grad.data_ptr(), grad.shape[1], out.data_ptr(), ws.data_ptr(),
+                                               _lib.current_stream()), "recon_spmm_rowsum_fwd")
         return out, None
 
 

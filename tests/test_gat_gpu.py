@@ -355,3 +355,19 @@ def test_spkbgat_golden(name):
         te, tr, _ = m.batch_test(None, be, adj, nhop, T(g["test_input"]).to(d))
     close(te, g["test_entity"], what="batch_test entity")
     close(tr, g["test_relation"], what="batch_test relation")
+
+
+@pytest.mark.parametrize("N,E,C_,skew", [(5, 4000, 24, True), (300, 1000, 7, False), (64, 70000, 200, True), (1000, 3, 4, False)])
+def test_spmm_rowsum_long_and_short_segments(N, E, C_, skew):
+    """SpecialSpmmFinal on segments from empty to tens of thousands of edges (a relation type owning most edges)."""
+    from recon_amd.gat_layers import SpecialSpmmFinal
+    g = torch.Generator().manual_seed(E + N)
+    dst = torch.randint(0, N, (E,), generator=g)
+    if skew:
+        dst[: E * 3 // 4] = 1 % N                                   # one destination owns 3/4 of all edges
+        dst = dst[torch.randperm(E, generator=g)]
+    edge = torch.stack([dst, torch.randint(0, N, (E,), generator=g)])
+    w = torch.randn(E, C_, generator=g)
+    out = SpecialSpmmFinal()(edge.to(dev()), w.to(dev()), N, E, C_)
+    ref = O.spmm_rowsum(edge, w.double(), N)
+    close(out, ref.float(), atol=1e-5, rel_to_max=2e-6, what="rowsum")
