@@ -123,6 +123,11 @@ def lib():
             raise RuntimeError(
                 "librecon_hip.so not found at %s: build it with `make -C recon_amd/csrc` "
                 "(recon_amd has no CPU fallback)" % LIB_PATH)
+        # torch ships its own HIP runtime (torch/lib/libamdhip64.so).  Device pointers and streams handed to the
+        # C ABI come from torch, so the library must bind to THAT runtime: load torch first, otherwise the
+        # dynamic loader resolves librecon_hip.so's libamdhip64 to /opt/rocm and the process ends up with two
+        # HIP runtimes (every launch then fails with RECON_ERR_LAUNCH).
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(h, name)

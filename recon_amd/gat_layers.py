@@ -117,8 +117,7 @@ class _GatherRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         index = ctx.index
-        key = torch.stack((index, index))                       # row 0 = segment id; row 1 is ignored by the row sum
-        g = prepare_graph(_pin_key(index, key), None, ctx.n_rows)
+        g = prepare_graph(_segment_key(index), None, ctx.n_rows)
         grad = grad.contiguous()
         out = torch.empty(ctx.n_rows, grad.shape[1], dtype=torch.float32, device=grad.device)
         L = _lib.lib()
@@ -132,14 +131,15 @@ class _GatherRows(torch.autograd.Function):
 _KEY_CACHE = {}
 
 
-def _pin_key(index, key):
-    """One [2,E] key tensor per index tensor (identity + version), so that prepare_graph's cache hits across steps."""
+def _segment_key(index):
+    """[2,E] edge-style key (row 0 = segment id; row 1 is ignored by the row sum) for an index tensor; one key
+    tensor per index tensor (identity + version) so that prepare_graph's CSR cache hits across steps."""
     k = (index.data_ptr(), index._version, tuple(index.shape))
     hit = _KEY_CACHE.get(k)
     if hit is None:
         if len(_KEY_CACHE) > 16:
             _KEY_CACHE.clear()
-        hit = _KEY_CACHE[k] = (key, index)
+        hit = _KEY_CACHE[k] = (torch.stack((index, index)), index)      # keeps `index` alive: its data_ptr is the key
     return hit[0]
 
 
