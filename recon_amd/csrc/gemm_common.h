@@ -12,6 +12,8 @@ struct GemmArgs {
     float* partial;          // non-null => write plain [batch][z][M][N]
     int32_t nsplit;          // blockIdx.z = batch_index * nsplit + split_index
     int32_t epilogue;        // GEMM_EPI_*
+    int32_t c_vec4;          // 1 => float4 stores of 4 consecutive output columns are legal (alignment, segments)
+    int32_t xcd_remap;       // 1 => XCD-aware tile order (xcd_tile in gemm_f32.hip)
     int64_t a_bs, b_bs, c_bs;   // per-batch element offsets of A, B, C
 };
 enum { GEMM_EPI_NONE = 0, GEMM_EPI_ELU = 1 };

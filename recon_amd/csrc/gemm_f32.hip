@@ -20,9 +20,11 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // One operand tile: W (m or n extent, 128 or 224) x BK, staged global -> registers -> LDS [BK][W+4].
 //   K_MINOR : memory is contiguous along k   -> thread item = (row, k quad): 4 floats along k
 //   !K_MINOR: memory is contiguous along m/n -> thread item = (k row, mn quad): 4 floats along mn
-template <int W, bool K_MINOR, int VEC, int BK>
+// SWZ: column index XORed with ((k >> 2) & 3) << 3 (see k_gemm_f32_n208) — makes the transposed K_MINOR stores
+// conflict-free and keeps 2/4-float alignment for the wide fragment reads.
+template <int W, bool K_MINOR, int VEC, int BK, int LD_ = W + 4, bool SWZ = false>
 struct TileLoader {
-    static constexpr int LD = W + 4;
+    static constexpr int LD = LD_;
     static constexpr int QPR = K_MINOR ? BK / 4 : W / 4;          // quads per tile row
     static constexpr int ITEMS = K_MINOR ? W * (BK / 4) : BK * (W / 4);
     static constexpr int NP = (ITEMS + NT - 1) / NT;
@@ -92,15 +94,37 @@ struct TileLoader {
             const int idx = threadIdx.x + NT * p;
             if (idx < ITEMS) {
                 if constexpr (K_MINOR) {
+                    const int col = SWZ ? (idx / QPR) ^ (((idx % QPR) & 3) << 3) : idx / QPR;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) T[(idx % QPR) * 4 + j][idx / QPR] = r[p][j];
+                    for (int j = 0; j < 4; ++j) T[(idx % QPR) * 4 + j][col] = r[p][j];
                 } else {
-                    *reinterpret_cast<float4*>(&T[idx / QPR][(idx % QPR) * 4]) = make_float4(r[p][0], r[p][1], r[p][2], r[p][3]);
+                    const int k = idx / QPR;
+                    const int col = SWZ ? ((idx % QPR) * 4) ^ (((k >> 2) & 3) << 3) : (idx % QPR) * 4;
+                    *reinterpret_cast<float4*>(&T[k][col]) = make_float4(r[p][0], r[p][1], r[p][2], r[p][3]);
                 }
             }
         }
     }
 };
+
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs by linear id, and each XCD has its own L2:
+// with the natural order the N tiles that share one A tile (and the M tiles that share one B slab) land on 8
+// different L2s and each re-fetches the operand from HBM (PMC: 349 MB for the g_V GEMM whose operands are 56 MB).
+// Give XCD c the c-th CONTIGUOUS chunk of the (n fastest, m, batch*split) tile order instead.
+struct TileId { int x, y, z; };
+__device__ __forceinline__ TileId xcd_tile(int remap) {
+    if (!remap) return {static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), static_cast<int>(blockIdx.z)};
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned c = L & 7u, pos = L >> 3, q = total >> 3, r = total & 7u;
+    const unsigned logical = c * q + min(c, r) + pos;
+    TileId id;
+    id.x = static_cast<int>(logical % gx);
+    const unsigned rest = logical / gx;
+    id.y = static_cast<int>(rest % gy);
+    id.z = static_cast<int>(rest / gy);
+    return id;
+}
 
 // Block tile (WM*TM*32) x (WN*TN*32) x 16; 4 waves arranged WM x WN, each wave TM x TN MFMA tiles.
 template <bool A_KMINOR, bool B_KMINOR, int VEC, int WM, int WN, int TM, int TN, int BK>
@@ -112,8 +136,9 @@ __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const G
     __shared__ __attribute__((aligned(16))) float As2[2][BK][LA::LD];      // double buffered: one barrier per K tile
     __shared__ __attribute__((aligned(16))) float Bs2[2][BK][LB::LD];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int bz = blockIdx.z / p.nsplit, zs = blockIdx.z % p.nsplit;
+    const TileId tile = xcd_tile(p.xcd_remap);
+    const int m0 = tile.y * BM, n0 = tile.x * BN;
+    const int bz = tile.z / p.nsplit, zs = tile.z % p.nsplit;
     const int k_begin = zs * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
     OperandDesc dA = p.A, dB = p.B;
@@ -205,7 +230,7 @@ __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const G
         if (col >= p.N) continue;
         int64_t coff;
         float* base;
-        if (p.partial) { base = p.partial + static_cast<int64_t>(blockIdx.z) * p.M * p.N; coff = col; }
+        if (p.partial) { base = p.partial + static_cast<int64_t>(tile.z) * p.M * p.N; coff = col; }
         else { base = p.C.base + bz * p.c_bs; coff = minor_off(p.C.Dseg, p.C.Sseg, col); }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -213,7 +238,6 @@ __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const G
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + mb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (row >= p.M) continue;
-                int64_t roff;
                 if (p.partial) base[static_cast<int64_t>(row) * p.N + coff] = acc[i][j][r];
                 else base[out_row_off(p.C, row) + coff] = gemm_epilogue(acc[i][j][r], p.epilogue);
             }
@@ -222,19 +246,31 @@ __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const G
 }
 
 
-// 128 x 208 x 16 block tile on v_mfma_f32_16x16x4_f32: 4 waves stacked along M, each 2 x 13 tiles of 16x16
-// (104 accumulator registers).  Same staging as k_gemm_f32.
+// 128 x 208 x 16 block tile on v_mfma_f32_16x16x4_f32 for outputs 129..208 columns wide (N = D = 200 per head at
+// cfg 2): 4 waves stacked along M, each 32 rows x 208 columns = 2 x 13 tiles (104 accumulator registers, three
+// waves per SIMD).  The LDS images are k-major like k_gemm_f32's, but one lane reads the operands of SEVERAL tiles
+// with one wide LDS instruction: lane (i = lane&15, g = lane>>4) reads rows mb + 2i, mb + 2i + 1 of k row 4s+g as
+// one ds_read_b64 — M tile t therefore owns rows {mb + 2i + t} — and float4s of columns 64q + 4i .. (N tiles
+// 4q..4q+3 own columns {64q + 4i + t}); tile 12 = columns 192..207 is a b32 read.  5 LDS reads feed 26 MFMAs per
+// k step (15 with one b32 read per fragment), and the accumulators of 4 neighbouring N tiles are 4 consecutive
+// output columns, so the epilogue stores float4s.  Row lengths 160 (A) and 256 (B) put the lane groups of each
+// wide read on disjoint banks; the XOR swizzle of TileLoader keeps that and removes the 4-way conflict of the
+// transposed k-minor stores (PMC before: half of all LDS cycles were bank-conflict cycles).
+// Measured (tools/gemm_bench.py, M=65536 N=200 K=600): 105 TF vs 97 TF for the b32-read form; a 256 x 208
+// variant with 208 AGPR accumulators at one wave per SIMD reached 97 TF (its epilogue and barriers have no
+// second workgroup to hide behind) and the (T,F)/(F,F) operand layouts spill at 168 VGPRs, so only (T,T) runs here.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 template <bool A_KMINOR, bool B_KMINOR, int VEC>
 __global__ void __launch_bounds__(NT, 3) k_gemm_f32_n208(const GemmArgs p) {
-    constexpr int BM = 128, BN = 208, BK = 16, TN = 13;
-    using LA = TileLoader<BM, A_KMINOR, VEC, BK>;
-    using LB = TileLoader<BN, B_KMINOR, VEC, BK>;
-    __shared__ __attribute__((aligned(16))) float As2[2][BK][LA::LD];
-    __shared__ __attribute__((aligned(16))) float Bs2[2][BK][LB::LD];
+    constexpr int BM = 128, BN = 208, BK = 16, TN = 13, LDA = 160, LDB = 256;
+    using LA = TileLoader<BM, A_KMINOR, VEC, BK, LDA, true>;
+    using LB = TileLoader<BN, B_KMINOR, VEC, BK, LDB, true>;
+    __shared__ __attribute__((aligned(16))) float As2[2][BK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs2[2][BK][LDB];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int bz = blockIdx.z / p.nsplit, zs = blockIdx.z % p.nsplit;
+    const TileId tile = xcd_tile(p.xcd_remap);
+    const int m0 = tile.y * BM, n0 = tile.x * BN;
+    const int bz = tile.z / p.nsplit, zs = tile.z % p.nsplit;
     const int k_begin = zs * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
     OperandDesc dA = p.A, dB = p.B;
@@ -260,43 +296,60 @@ __global__ void __launch_bounds__(NT, 3) k_gemm_f32_n208(const GemmArgs p) {
     int cur = 0;
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         const bool more = k0 + BK < k_end;
-        float (*As)[LA::LD] = As2[cur];
-        float (*Bs)[LB::LD] = Bs2[cur];
+        float (*As)[LDA] = As2[cur];
+        float (*Bs)[LDB] = Bs2[cur];
         if (more) { la.load(dA, k0 + BK, k_end); lb.load(dB, k0 + BK, k_end); }
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
-            const int kk = 4 * ks + lq;
-            const float a0 = As[kk][mb + li], a1 = As[kk][mb + 16 + li];
+            const int kk = 4 * ks + lq, swz = ks << 3;
             float b[TN];
+            const float2 a = *reinterpret_cast<const float2*>(&As[kk][(mb + 2 * li) ^ swz]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[kk][16 * j + li];
+            for (int q = 0; q < 3; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(&Bs[kk][(64 * q + 4 * li) ^ swz]);
+                b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+            }
+            b[12] = Bs[kk][(192 + li) ^ swz];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[j], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[j], acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[j], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[j], acc[1][j], 0, 0, 0);
             }
         }
         if (more) { la.store(As2[cur ^ 1]); lb.store(Bs2[cur ^ 1]); }
         __syncthreads();
         cur ^= 1;
     }
-    // epilogue: C/D layout of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + r
-    float* base = p.partial ? p.partial + static_cast<int64_t>(blockIdx.z) * p.M * p.N : p.C.base + bz * p.c_bs;
+    // epilogue: MFMA C layout col = lane&15, row = (lane>>4)*4 + r, mapped back through the row/column ownership above
+    float* base = p.partial ? p.partial + static_cast<int64_t>(tile.z) * p.M * p.N : p.C.base + bz * p.c_bs;
+    const int epi = p.partial ? GEMM_EPI_NONE : p.epilogue;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + 16 * j + li;
-        if (col >= p.N) continue;
-        const int64_t coff = p.partial ? col : minor_off(p.C.Dseg, p.C.Sseg, col);
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + mb + 2 * (4 * lq + r) + i;
+            if (row >= p.M) continue;
+            float* crow = base + (p.partial ? static_cast<int64_t>(row) * p.N : out_row_off(p.C, row));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + mb + 16 * i + 4 * lq + r;
-                if (row >= p.M) continue;
-                if (p.partial) base[static_cast<int64_t>(row) * p.N + coff] = acc[i][j][r];
-                else base[out_row_off(p.C, row) + coff] = gemm_epilogue(acc[i][j][r], p.epilogue);
+            for (int q = 0; q < 3; ++q) {
+                const int col = n0 + 64 * q + 4 * li;
+                if (p.c_vec4) {
+                    if (col < p.N) {
+                        const int64_t coff = p.partial ? col : minor_off(p.C.Dseg, p.C.Sseg, col);
+                        *reinterpret_cast<float4*>(crow + coff) =
+                            make_float4(gemm_epilogue(acc[i][4 * q][r], epi), gemm_epilogue(acc[i][4 * q + 1][r], epi),
+                                        gemm_epilogue(acc[i][4 * q + 2][r], epi), gemm_epilogue(acc[i][4 * q + 3][r], epi));
+                    }
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        if (col + jj < p.N)
+                            crow[p.partial ? col + jj : minor_off(p.C.Dseg, p.C.Sseg, col + jj)] = gemm_epilogue(acc[i][4 * q + jj][r], epi);
+                }
             }
-    }
+            const int col = n0 + 192 + li;
+            if (col < p.N) crow[p.partial ? col : minor_off(p.C.Dseg, p.C.Sseg, col)] = gemm_epilogue(acc[i][12][r], epi);
+        }
 }
 
 // deterministic second pass of split-K: C = epilogue(sum_z partial[batch][z]) (fixed order), written through C's addressing
@@ -323,19 +376,25 @@ bool operand_vec4(const OperandDesc& d, int32_t minor_extent) {
 
 template <bool AK, bool BK_, int VEC>
 void launch(const GemmArgs& a, bool narrow, dim3 grid, hipStream_t st) {
-    if constexpr (AK && BK_) {
+    if constexpr (AK && BK_ && VEC == 4) {
         if (narrow) { hipLaunchKernelGGL((k_gemm_f32_n208<AK, BK_, VEC>), grid, dim3(NT), 0, st, a); return; }   // 128 x 208
     }
     hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 2, 2, 16>), grid, dim3(NT), 0, st, a);      // 128 x 128
 }
 
-// Outputs 129..208 columns wide (N = D = 200 per head at cfg 2) take ONE 208-wide column tile of 13 16x16
-// MFMA tiles (4 % padding) instead of two 128-wide tiles (28 % padding).  RECON_GEMM_CFG=1 forces 128x128.
-bool use_narrow(int32_t N, bool a_k_minor = true, bool b_k_minor = true) {
-    const int force = getenv("RECON_GEMM_CFG") ? atoi(getenv("RECON_GEMM_CFG")) : 0;   // read per call: in-process A/B
+// Outputs 129..208 columns wide take ONE 208-wide column tile of 13 16x16 MFMA tiles (4 % padding at N = 200)
+// instead of two 128-wide tiles (28 % padding).  RECON_GEMM_CFG=1 forces 128x128 (read per call: in-process A/B).
+bool use_narrow(int32_t N, bool a_k_minor, bool b_k_minor, bool v4) {
+    const int force = getenv("RECON_GEMM_CFG") ? atoi(getenv("RECON_GEMM_CFG")) : 0;
     if (force == 1) return false;
-    // measured (tools/gemm_bench.py): +9 % for K-contiguous operands; the other layouts spill at 3 waves/SIMD and lose
-    return a_k_minor && b_k_minor && N > 128 && N <= 208;
+    return a_k_minor && b_k_minor && v4 && N > 128 && N <= 208;
+}
+
+bool output_vec4(const OutputDesc& C, int32_t N, int64_t c_bs, const float* partial) {
+    if ((N & 3) || (c_bs & 3)) return false;
+    if (partial) return (reinterpret_cast<uintptr_t>(partial) & 15) == 0;
+    if ((reinterpret_cast<uintptr_t>(C.base) & 15) || (C.S1 & 3) || (C.S2 & 3) || (C.Sseg & 3)) return false;
+    return C.Dseg >= N || (C.Dseg & 3) == 0;
 }
 
 }  // namespace
@@ -365,6 +424,7 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
     GemmArgs a;
     a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K;
     a.a_bs = bt.a_bs; a.b_bs = bt.b_bs; a.c_bs = bt.c_bs; a.epilogue = bt.epilogue;
+    a.xcd_remap = (getenv("RECON_GEMM_XCD") && atoi(getenv("RECON_GEMM_XCD")) == 0) ? 0 : 1;   // read per call: in-process A/B
     const bool v4 = operand_vec4(A, a_k_minor ? K : M) && operand_vec4(B, b_k_minor ? K : N) && (bt.batch == 1 || (!(bt.a_bs & 3) && !(bt.b_bs & 3)));
     const bool use3 = v4 && bt.batch == 1 && bt.epilogue == GEMM_EPI_NONE && gemm_bf16x3_enabled();   // experimental kernel (K tile 32)
     const int bk = use3 ? 32 : BK16;
@@ -379,12 +439,13 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
         const int rc = gemm_bf16x3_launch(a, a_k_minor, b_k_minor, split_k, st);
         if (rc != RECON_OK) return rc;
     } else {
-        const bool wide = use_narrow(N, a_k_minor, b_k_minor);
-        dim3 grid(static_cast<unsigned>(ceil_div64(N, wide ? 208 : 128)), static_cast<unsigned>(ceil_div64(M, 128)),
+        const bool narrow = use_narrow(N, a_k_minor, b_k_minor, v4);
+        a.c_vec4 = output_vec4(C, N, bt.c_bs, a.partial) ? 1 : 0;
+        dim3 grid(static_cast<unsigned>(ceil_div64(N, narrow ? 208 : 128)), static_cast<unsigned>(ceil_div64(M, 128)),
                   static_cast<unsigned>(split_k * bt.batch));
-        if (a_k_minor && b_k_minor) { if (v4) launch<true, true, 4>(a, wide, grid, st); else launch<true, true, 1>(a, wide, grid, st); }
-        else if (a_k_minor && !b_k_minor) { if (v4) launch<true, false, 4>(a, wide, grid, st); else launch<true, false, 1>(a, wide, grid, st); }
-        else if (!a_k_minor && !b_k_minor) { if (v4) launch<false, false, 4>(a, wide, grid, st); else launch<false, false, 1>(a, wide, grid, st); }
+        if (a_k_minor && b_k_minor) { if (v4) launch<true, true, 4>(a, narrow, grid, st); else launch<true, true, 1>(a, narrow, grid, st); }
+        else if (a_k_minor && !b_k_minor) { if (v4) launch<true, false, 4>(a, narrow, grid, st); else launch<true, false, 1>(a, narrow, grid, st); }
+        else if (!a_k_minor && !b_k_minor) { if (v4) launch<false, false, 4>(a, narrow, grid, st); else launch<false, false, 1>(a, narrow, grid, st); }
         else return RECON_ERR_UNSUPPORTED;
     }
     if (split_k > 1) {

@@ -21,7 +21,6 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kMaxHops = 8;
-constexpr int kPT = 256;
 
 __device__ __forceinline__ float act_fwd(float v, int act) {
     if (act == RECON_ACT_RELU) return v > 0.f ? v : 0.f;
