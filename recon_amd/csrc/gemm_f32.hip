@@ -22,16 +22,38 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 //   !K_MINOR: memory is contiguous along m/n -> thread item = (k row, mn quad): 4 floats along mn
 // SWZ: column index XORed with ((k >> 2) & 3) << 3 (see k_gemm_f32_n208) — makes the transposed K_MINOR stores
 // conflict-free and keeps 2/4-float alignment for the wide fragment reads.
-template <int W, bool K_MINOR, int VEC, int BK, int LD_ = W + 4, bool SWZ = false>
+// LIN (VEC == 4 only; the host checks that the operand is linear along k: K_MINOR with one k segment, or k-major
+// without gather / row wrap): the loader keeps ONE pointer per item and advances it by a constant per K tile, so a
+// full tile costs NP unpredicated global_load_dwordx4 + NP 64-bit adds instead of the general address arithmetic
+// (~270 non-MFMA instructions per 32 MFMAs in the general form).  Rows beyond the operand's extent read a clamped
+// (valid) row: they only reach output rows/columns that are never stored.  The K tail takes the predicated path.
+template <int W, bool K_MINOR, int VEC, int BK, int LD_ = W + 4, bool SWZ = false, bool LIN = false>
 struct TileLoader {
+    static_assert(!LIN || VEC == 4, "linear loader is float4 only");
     static constexpr int LD = LD_;
     static constexpr int QPR = K_MINOR ? BK / 4 : W / 4;          // quads per tile row
     static constexpr int ITEMS = K_MINOR ? W * (BK / 4) : BK * (W / 4);
     static constexpr int NP = (ITEMS + NT - 1) / NT;
     float r[NP][4];
-    int64_t fix[NP][K_MINOR || VEC == 4 ? 1 : 4];                 // K-invariant address part per item
+    int64_t fix[LIN ? 1 : NP][K_MINOR || VEC == 4 ? 1 : 4];       // K-invariant address part per item (general form)
+    const float* ptr[LIN ? NP : 1];                               // LIN: this item's float4 in the current K tile
+    int64_t kstep;
 
-    __device__ __forceinline__ void init(const OperandDesc& d, int32_t mn0, int32_t mn_ext) {
+    __device__ __forceinline__ void init(const OperandDesc& d, int32_t mn0, int32_t mn_ext, int32_t k_begin) {
+        if constexpr (LIN) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int idx = threadIdx.x + NT * p;
+                if constexpr (K_MINOR) {
+                    const int mn = min(mn0 + idx / QPR, mn_ext - 1);
+                    ptr[p] = d.base + major_off(d, mn) + k_begin + (idx % QPR) * 4;
+                } else {
+                    const int mn = min(mn0 + (idx % QPR) * 4, mn_ext - 4);
+                    ptr[p] = d.base + static_cast<int64_t>(k_begin + min(idx / QPR, BK - 1)) * d.S1 + minor_off(d.Dseg, d.Sseg, mn);
+                }
+            }
+            kstep = K_MINOR ? BK : BK * d.S1;
+        } else {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int idx = threadIdx.x + NT * p;
@@ -47,8 +69,31 @@ struct TileLoader {
                 }
             }
         }
+        }
     }
     __device__ __forceinline__ void load(const OperandDesc& d, int32_t k0, int32_t k_end) {
+        if constexpr (LIN) {
+            if (k0 + BK <= k_end) {                                   // uniform: full K tile
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const float4 v = *reinterpret_cast<const float4*>(ptr[p]);
+                    r[p][0] = v.x; r[p][1] = v.y; r[p][2] = v.z; r[p][3] = v.w;
+                    ptr[p] += kstep;
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int idx = threadIdx.x + NT * p;
+                    const int k = K_MINOR ? k0 + (idx % QPR) * 4 : k0 + idx / QPR;
+                    r[p][0] = r[p][1] = r[p][2] = r[p][3] = 0.f;
+                    if (k < k_end) {
+                        const float4 v = *reinterpret_cast<const float4*>(ptr[p]);
+                        r[p][0] = v.x; r[p][1] = v.y; r[p][2] = v.z; r[p][3] = v.w;
+                    }
+                    ptr[p] += kstep;
+                }
+            }
+        } else {
         // K_MINOR: NT is a multiple of QPR, so every pass of this thread has the same k quad
         const int kq_t = k0 + (threadIdx.x % QPR) * 4;
         const int64_t koff_t = (K_MINOR && VEC == 4) ? minor_off(d.Dseg, d.Sseg, kq_t) : 0;
@@ -86,6 +131,7 @@ struct TileLoader {
                     }
                 }
             }
+        }
         }
     }
     __device__ __forceinline__ void store(float (*T)[LD]) const {
@@ -127,12 +173,12 @@ __device__ __forceinline__ TileId xcd_tile(int remap) {
 }
 
 // Block tile (WM*TM*32) x (WN*TN*32) x 16; 4 waves arranged WM x WN, each wave TM x TN MFMA tiles.
-template <bool A_KMINOR, bool B_KMINOR, int VEC, int WM, int WN, int TM, int TN, int BK>
+template <bool A_KMINOR, bool B_KMINOR, int VEC, int WM, int WN, int TM, int TN, int BK, bool LIN>
 __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const GemmArgs p) {
     static_assert(WM * WN == 4, "4 waves per block");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    using LA = TileLoader<BM, A_KMINOR, VEC, BK>;
-    using LB = TileLoader<BN, B_KMINOR, VEC, BK>;
+    using LA = TileLoader<BM, A_KMINOR, VEC, BK, BM + 4, false, LIN>;
+    using LB = TileLoader<BN, B_KMINOR, VEC, BK, BN + 4, false, LIN>;
     __shared__ __attribute__((aligned(16))) float As2[2][BK][LA::LD];      // double buffered: one barrier per K tile
     __shared__ __attribute__((aligned(16))) float Bs2[2][BK][LB::LD];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -146,8 +192,8 @@ __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const G
     dB.base += bz * p.b_bs;
 
     LA la; LB lb;
-    la.init(dA, m0, p.M);
-    lb.init(dB, n0, p.N);
+    la.init(dA, m0, p.M, k_begin);
+    lb.init(dB, n0, p.N, k_begin);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -260,11 +306,11 @@ __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const G
 // variant with 208 AGPR accumulators at one wave per SIMD reached 97 TF (its epilogue and barriers have no
 // second workgroup to hide behind) and the (T,F)/(F,F) operand layouts spill at 168 VGPRs, so only (T,T) runs here.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-template <bool A_KMINOR, bool B_KMINOR, int VEC>
+template <bool A_KMINOR, bool B_KMINOR, int VEC, bool LIN>
 __global__ void __launch_bounds__(NT, 3) k_gemm_f32_n208(const GemmArgs p) {
     constexpr int BM = 128, BN = 208, BK = 16, TN = 13, LDA = 160, LDB = 256;
-    using LA = TileLoader<BM, A_KMINOR, VEC, BK, LDA, true>;
-    using LB = TileLoader<BN, B_KMINOR, VEC, BK, LDB, true>;
+    using LA = TileLoader<BM, A_KMINOR, VEC, BK, LDA, true, LIN>;
+    using LB = TileLoader<BN, B_KMINOR, VEC, BK, LDB, true, LIN>;
     __shared__ __attribute__((aligned(16))) float As2[2][BK][LDA];
     __shared__ __attribute__((aligned(16))) float Bs2[2][BK][LDB];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -277,8 +323,8 @@ __global__ void __launch_bounds__(NT, 3) k_gemm_f32_n208(const GemmArgs p) {
     dA.base += bz * p.a_bs;
     dB.base += bz * p.b_bs;
     LA la; LB lb;
-    la.init(dA, m0, p.M);
-    lb.init(dB, n0, p.N);
+    la.init(dA, m0, p.M, k_begin);
+    lb.init(dB, n0, p.N, k_begin);
     f32x4 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -375,11 +421,20 @@ bool operand_vec4(const OperandDesc& d, int32_t minor_extent) {
 }
 
 template <bool AK, bool BK_, int VEC>
-void launch(const GemmArgs& a, bool narrow, dim3 grid, hipStream_t st) {
-    if constexpr (AK && BK_ && VEC == 4) {
-        if (narrow) { hipLaunchKernelGGL((k_gemm_f32_n208<AK, BK_, VEC>), grid, dim3(NT), 0, st, a); return; }   // 128 x 208
+void launch(const GemmArgs& a, bool narrow, bool lin, dim3 grid, hipStream_t st) {
+    if constexpr (VEC == 4) {
+        if constexpr (AK && BK_) {
+            // 128 x 208; general loader: the per-item pointers of the linear one spill at this kernel's 168 VGPRs (-11 %)
+            if (narrow) { hipLaunchKernelGGL((k_gemm_f32_n208<AK, BK_, 4, false>), grid, dim3(NT), 0, st, a); return; }
+        }
+        if (lin) { hipLaunchKernelGGL((k_gemm_f32<AK, BK_, 4, 2, 2, 2, 2, 16, true>), grid, dim3(NT), 0, st, a); return; }
     }
-    hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 2, 2, 16>), grid, dim3(NT), 0, st, a);      // 128 x 128
+    hipLaunchKernelGGL((k_gemm_f32<AK, BK_, VEC, 2, 2, 2, 2, 16, false>), grid, dim3(NT), 0, st, a);      // 128 x 128
+}
+
+// operand linear along k (TileLoader LIN): one k segment for k-contiguous operands, no gather / row wrap for k-major ones
+bool operand_linear(const OperandDesc& d, bool k_minor, int32_t K) {
+    return k_minor ? d.Dseg >= K : (d.gather == nullptr && K <= d.P);
 }
 
 // Outputs 129..208 columns wide take ONE 208-wide column tile of 13 16x16 MFMA tiles (4 % padding at N = 200)
@@ -440,12 +495,14 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
         if (rc != RECON_OK) return rc;
     } else {
         const bool narrow = use_narrow(N, a_k_minor, b_k_minor, v4);
+        const bool lin = v4 && operand_linear(A, a_k_minor, K) && operand_linear(B, b_k_minor, K) &&
+                         !(getenv("RECON_GEMM_LIN") && atoi(getenv("RECON_GEMM_LIN")) == 0);
         a.c_vec4 = output_vec4(C, N, bt.c_bs, a.partial) ? 1 : 0;
         dim3 grid(static_cast<unsigned>(ceil_div64(N, narrow ? 208 : 128)), static_cast<unsigned>(ceil_div64(M, 128)),
                   static_cast<unsigned>(split_k * bt.batch));
-        if (a_k_minor && b_k_minor) { if (v4) launch<true, true, 4>(a, narrow, grid, st); else launch<true, true, 1>(a, narrow, grid, st); }
-        else if (a_k_minor && !b_k_minor) { if (v4) launch<true, false, 4>(a, narrow, grid, st); else launch<true, false, 1>(a, narrow, grid, st); }
-        else if (!a_k_minor && !b_k_minor) { if (v4) launch<false, false, 4>(a, narrow, grid, st); else launch<false, false, 1>(a, narrow, grid, st); }
+        if (a_k_minor && b_k_minor) { if (v4) launch<true, true, 4>(a, narrow, lin, grid, st); else launch<true, true, 1>(a, narrow, lin, grid, st); }
+        else if (a_k_minor && !b_k_minor) { if (v4) launch<true, false, 4>(a, narrow, lin, grid, st); else launch<true, false, 1>(a, narrow, lin, grid, st); }
+        else if (!a_k_minor && !b_k_minor) { if (v4) launch<false, false, 4>(a, narrow, lin, grid, st); else launch<false, false, 1>(a, narrow, lin, grid, st); }
         else return RECON_ERR_UNSUPPORTED;
     }
     if (split_k > 1) {
