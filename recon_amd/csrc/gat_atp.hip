@@ -761,8 +761,8 @@ extern "C" int recon_gat_atp_fwd(const recon_graph* g, const recon_gat_atp_args*
 
 extern "C" size_t recon_gat_atp_bwd_partial_floats(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H) {
     const int64_t W = 2LL * F + R;
-    const int s1 = gemm_pick_split_k(D, static_cast<int32_t>(W), N, H);
-    size_t need = static_cast<size_t>(s1 > 1 ? s1 : 0) * H * D * W;            // g_a = g_h^T V, batched over heads
+    const int s1 = gemm_pick_split_k(static_cast<int32_t>(W), D, N, H);
+    size_t need = static_cast<size_t>(s1) * H * D * W;                         // g_a^T = V^T g_h, batched over heads
     (void)E; (void)F; (void)R;
     return need > 0 ? need : 1;
 }
@@ -857,14 +857,16 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
     }   // INPUTS (its score-gradient products follow below)
     if (b->g_a || b->g_a_2) {
         if (!b->g_a) return RECON_ERR_INVALID;                          // g_a_2 is produced together with g_a
-        // (4) g_a[h] = g_h[:, h, :]^T . V[:, h, :]
+        // (4) g_a[h] = g_h[:, h, :]^T . V[:, h, :], computed as its transpose V^T g_h so that D (<= 208 at cfg 2) is the
+        //     tile's column dimension; the split-K second pass stores it back transposed
         if (phases & RECON_ATP_BWD_WEIGHTS) {
-            OperandDesc A = plain_operand(gh, ld_gh);                   // major = k (node), minor = m (d)
-            OperandDesc B = plain_operand(a->V, static_cast<int64_t>(H) * W);
+            OperandDesc A = plain_operand(a->V, static_cast<int64_t>(H) * W);      // major = k (node), minor = m (w)
+            OperandDesc B = plain_operand(gh, ld_gh);                              // major = k (node), minor = n (d)
             OutputDesc C = plain_output(b->g_a, W);
-            bt.a_bs = D; bt.b_bs = W; bt.c_bs = static_cast<int64_t>(D) * W;
-            const int sk = gemm_pick_split_k(D, W, N, H);
-            rc = gemm_f32_batched(D, W, N, A, false, B, false, C, bt, sk, b->partial, st);
+            GemmBatch bw = bt;
+            bw.a_bs = W; bw.b_bs = D; bw.c_bs = static_cast<int64_t>(D) * W; bw.c_transpose = 1;
+            const int sk = gemm_pick_split_k(W, D, N, H);
+            rc = gemm_f32_batched(W, D, N, A, false, B, false, C, bw, sk, b->partial, st);
             if (rc != RECON_OK) return rc;
         }
         // (5) g_u = [Gs_dst | Gs_src]^T x   and   gsigma^T edge_embed[eid]   (skinny products, fixed-order reduce)

@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const G
 // second workgroup to hide behind) and the (T,F)/(F,F) operand layouts spill at 168 VGPRs, so only (T,T) runs here.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 template <bool A_KMINOR, bool B_KMINOR, int VEC, bool LIN>
-__global__ void __launch_bounds__(NT, 3) k_gemm_f32_n208(const GemmArgs p) {
+__global__ void __launch_bounds__(NT, 2) k_gemm_f32_n208(const GemmArgs p) {
     constexpr int BM = 128, BN = 208, BK = 16, TN = 13, LDA = 160, LDB = 256;
     using LA = TileLoader<BM, A_KMINOR, VEC, BK, LDA, true, LIN>;
     using LB = TileLoader<BN, B_KMINOR, VEC, BK, LDB, true, LIN>;
@@ -412,6 +412,32 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
     C.base[bz * c_bs + out_row_off(C, row) + minor_off(C.Dseg, C.Sseg, col)] = gemm_epilogue(s, epilogue);
 }
 
+// transposing form: out(row n, col m) = epilogue(sum_z partial[z][m][n]); 32 x 32 tiles through LDS so that both the
+// partial reads (along n) and the output writes (along m) are coalesced
+__global__ void __launch_bounds__(256) k_splitk_reduce_t(const float* __restrict__ partial, int32_t splits, int32_t M,
+                                                         int32_t N, const OutputDesc C, int64_t c_bs, int32_t epilogue) {
+    __shared__ float tile[32][33];
+    const int bz = blockIdx.z, m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t MN = static_cast<int64_t>(M) * N;
+    const float* pz = partial + static_cast<int64_t>(bz) * splits * MN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty + 8 * i, n = n0 + tx;
+        float s = 0.f;
+        if (m < M && n < N)
+            for (int z = 0; z < splits; ++z) s += pz[z * MN + static_cast<int64_t>(m) * N + n];
+        tile[ty + 8 * i][tx] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i, m = m0 + tx;
+        if (m < M && n < N)
+            C.base[bz * c_bs + out_row_off(C, n) + minor_off(C.Dseg, C.Sseg, m)] = gemm_epilogue(tile[tx][ty + 8 * i], epilogue);
+    }
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 bool operand_vec4(const OperandDesc& d, int32_t minor_extent) {
     if (!aligned16(d.base)) return false;
@@ -423,9 +449,10 @@ bool operand_vec4(const OperandDesc& d, int32_t minor_extent) {
 template <bool AK, bool BK_, int VEC>
 void launch(const GemmArgs& a, bool narrow, bool lin, dim3 grid, hipStream_t st) {
     if constexpr (VEC == 4) {
-        if constexpr (AK && BK_) {
-            // 128 x 208; general loader: the per-item pointers of the linear one spill at this kernel's 168 VGPRs (-11 %)
-            if (narrow) { hipLaunchKernelGGL((k_gemm_f32_n208<AK, BK_, 4, false>), grid, dim3(NT), 0, st, a); return; }
+        if (narrow) {                                                                                   // 128 x 208
+            if (lin) hipLaunchKernelGGL((k_gemm_f32_n208<AK, BK_, 4, true>), grid, dim3(NT), 0, st, a);
+            else hipLaunchKernelGGL((k_gemm_f32_n208<AK, BK_, 4, false>), grid, dim3(NT), 0, st, a);
+            return;
         }
         if (lin) { hipLaunchKernelGGL((k_gemm_f32<AK, BK_, 4, 2, 2, 2, 2, 16, true>), grid, dim3(NT), 0, st, a); return; }
     }
@@ -442,7 +469,8 @@ bool operand_linear(const OperandDesc& d, bool k_minor, int32_t K) {
 bool use_narrow(int32_t N, bool a_k_minor, bool b_k_minor, bool v4) {
     const int force = getenv("RECON_GEMM_CFG") ? atoi(getenv("RECON_GEMM_CFG")) : 0;
     if (force == 1) return false;
-    return a_k_minor && b_k_minor && v4 && N > 128 && N <= 208;
+    (void)a_k_minor; (void)b_k_minor;
+    return v4 && N > 128 && N <= 208;
 }
 
 bool output_vec4(const OutputDesc& C, int32_t N, int64_t c_bs, const float* partial) {
@@ -457,9 +485,10 @@ bool output_vec4(const OutputDesc& C, int32_t N, int64_t c_bs, const float* part
 int gemm_pick_split_k(int32_t M, int32_t N, int32_t K, int32_t batch) {
     static const int force = getenv("RECON_GEMM_SPLITK") ? atoi(getenv("RECON_GEMM_SPLITK")) : 0;   // tuning knob
     if (force > 0) return force;
-    const int bn = 128;
+    const bool narrow = N > 128 && N <= 208;                       // 128 x 208 kernel (when the operands are float4-able)
+    const int bn = narrow ? 208 : 128;
     const int64_t tiles = ceil_div64(M, 128) * ceil_div64(N, bn) * (batch > 0 ? batch : 1);
-    constexpr int64_t kResident = 256 * 4;                         // CUs x workgroups per CU at 4 waves/SIMD
+    const int64_t kResident = 256 * (narrow ? 2 : 4);              // CUs x workgroups per CU (2 / 4 waves per SIMD)
     if (tiles >= kResident / 2) return 1;
     // largest split that keeps every workgroup resident in one round and >= 128 of K per split
     int64_t s = kResident / tiles;
@@ -475,7 +504,7 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
     if (M == 0 || N == 0 || bt.batch == 0) return RECON_OK;
     if (!A.base || !B.base || !C.base) return RECON_ERR_INVALID;
     if (split_k < 1) split_k = 1;
-    if (split_k > 1 && !partial) return RECON_ERR_INVALID;
+    if ((split_k > 1 || bt.c_transpose) && !partial) return RECON_ERR_INVALID;
     GemmArgs a;
     a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K;
     a.a_bs = bt.a_bs; a.b_bs = bt.b_bs; a.c_bs = bt.c_bs; a.epilogue = bt.epilogue;
@@ -488,7 +517,7 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
     a.k_per_split = static_cast<int32_t>(kps);
     split_k = static_cast<int32_t>(ceil_div64(K > 0 ? K : 1, kps));
     a.nsplit = split_k;
-    a.partial = split_k > 1 ? partial : nullptr;
+    a.partial = (split_k > 1 || bt.c_transpose) ? partial : nullptr;
     if (static_cast<int64_t>(bt.batch) * split_k > 65535) return RECON_ERR_UNSUPPORTED;
     if (use3) {
         const int rc = gemm_bf16x3_launch(a, a_k_minor, b_k_minor, split_k, st);
@@ -505,7 +534,10 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
         else if (!a_k_minor && !b_k_minor) { if (v4) launch<false, false, 4>(a, narrow, lin, grid, st); else launch<false, false, 1>(a, narrow, lin, grid, st); }
         else return RECON_ERR_UNSUPPORTED;
     }
-    if (split_k > 1) {
+    if (bt.c_transpose) {
+        hipLaunchKernelGGL(k_splitk_reduce_t, dim3(static_cast<unsigned>(ceil_div64(N, 32)), static_cast<unsigned>(ceil_div64(M, 32)),
+                           static_cast<unsigned>(bt.batch)), dim3(256), 0, st, partial, split_k, M, N, C, bt.c_bs, bt.epilogue);
+    } else if (split_k > 1) {
         const int64_t MN = static_cast<int64_t>(M) * N;
         hipLaunchKernelGGL(k_splitk_reduce, dim3(static_cast<unsigned>(ceil_div64(MN, 256)), static_cast<unsigned>(bt.batch)), dim3(256), 0,
                            st, partial, split_k, M, N, C, bt.c_bs, bt.epilogue);

@@ -127,7 +127,10 @@ int gemm_pick_split_k(int32_t M, int32_t N, int32_t K, int32_t batch = 1);
 // batched variant: `batch` independent problems, operand/output bases advanced by *_bs elements per batch;
 // epilogue 0 = none, 1 = ELU (applied after the split-K reduction when split_k > 1).
 // `partial` must hold batch*split_k*M*N floats when split_k > 1.
-struct GemmBatch { int32_t batch; int64_t a_bs, b_bs, c_bs; int32_t epilogue; };
+// c_transpose = 1: C describes the TRANSPOSE of the product (element (m, n) is stored at C row n, column m), so a
+// caller can put the 129..208-wide dimension of a product on N, where the 128 x 208 tile has 4 % padding.  The
+// transposition happens in the split-K second pass: `partial` is then required even for split_k = 1.
+struct GemmBatch { int32_t batch; int64_t a_bs, b_bs, c_bs; int32_t epilogue; int32_t c_transpose = 0; };
 int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool a_k_minor, const OperandDesc& B,
                      bool b_k_minor, const OutputDesc& C, const GemmBatch& bt, int32_t split_k, float* partial,
                      hipStream_t stream);
