@@ -28,20 +28,36 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
-// u[h][w] = sum_d a_2[h][d] * a[h][d][w]      block = (64 columns w) x (4 row groups over d), fixed-order combine
-__global__ void __launch_bounds__(256) k_score_vec(const float* __restrict__ a, const float* __restrict__ a2, int32_t D, int32_t W,
-                                                   float* __restrict__ u) {
-    __shared__ float red[4][64];
+// u[h][w] = sum_d a_2[h][d] * a[h][d][w]      block = (64 columns w) x (16 row groups over d), fixed-order combine.
+// 16 groups with 4 independent partial sums each: with 4 groups and one dependent chain the kernel was latency
+// bound (15 us for 3.8 MB).
+__global__ void __launch_bounds__(1024) k_score_vec(const float* __restrict__ a, const float* __restrict__ a2, int32_t D, int32_t W,
+                                                    float* __restrict__ u) {
+    __shared__ float red[16][64];
     const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int w = blockIdx.x * 64 + c, h = blockIdx.y;
     const float* ah = a + static_cast<int64_t>(h) * D * W;
-    const int per = (D + 3) / 4;
-    float s = 0.f;
-    if (w < W)
-        for (int d = grp * per; d < min(D, (grp + 1) * per); ++d) s = fmaf(a2[h * D + d], ah[static_cast<int64_t>(d) * W + w], s);
-    red[grp][c] = s;
+    const int per = (D + 15) / 16;
+    const int d0 = grp * per, d1 = min(D, (grp + 1) * per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (w < W) {
+        int d = d0;
+        for (; d + 4 <= d1; d += 4) {
+            s0 = fmaf(a2[h * D + d], ah[static_cast<int64_t>(d) * W + w], s0);
+            s1 = fmaf(a2[h * D + d + 1], ah[static_cast<int64_t>(d + 1) * W + w], s1);
+            s2 = fmaf(a2[h * D + d + 2], ah[static_cast<int64_t>(d + 2) * W + w], s2);
+            s3 = fmaf(a2[h * D + d + 3], ah[static_cast<int64_t>(d + 3) * W + w], s3);
+        }
+        for (; d < d1; ++d) s0 = fmaf(a2[h * D + d], ah[static_cast<int64_t>(d) * W + w], s0);
+    }
+    red[grp][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (grp == 0 && w < W) u[static_cast<int64_t>(h) * W + w] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (grp == 0 && w < W) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][c];
+        u[static_cast<int64_t>(h) * W + w] = t;
+    }
 }
 
 // backward of u = a_2^T a:   g_a[h][d][:] += a_2[h][d] * g_u[h][:] ;  g_a_2[h][d] = a[h][d][:] . g_u[h][:]
@@ -132,44 +148,65 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
 }
 
 // out[row][j] = X[row'] . U_j,  U_j = u + (j % H)*W + (j / H)*F + off,  row' = gather ? gather[row] : row.
-// One wave per row; U staged in LDS.
+// One wave per kRowsPerIter consecutive rows (their loads are issued together: the kernel is latency bound, one row
+// at a time it reached 1.3 TB/s); U staged in LDS once per block, so blocks are sized for >= 32 rows.
+constexpr int kRowsPerIter = 4;
 template <int VEC>
 __global__ void __launch_bounds__(kBlock) k_row_dots(const float* __restrict__ X, const int32_t* __restrict__ gather, int32_t rows,
                                                      int32_t K, const float* __restrict__ u, int32_t H, int32_t W, int32_t F,
                                                      int32_t off, int32_t NJ, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float U[];     // [NJ][K]
-    for (int idx = threadIdx.x; idx < NJ * K; idx += kBlock) {
-        const int j = idx / K, k = idx % K;
-        U[idx] = u[static_cast<int64_t>(j % H) * W + (j / H) * F + off + k];
+    for (int j = 0; j < NJ; ++j) {
+        const float* uj = u + static_cast<int64_t>(j % H) * W + (j / H) * F + off;
+        for (int k = threadIdx.x; k < K; k += kBlock) U[j * K + k] = uj[k];
     }
     __syncthreads();
+    constexpr int RB = kRowsPerIter;
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int wave = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (kBlock / 64);
-    for (int row = wave; row < rows; row += nwaves) {
-        const int64_t r = gather ? gather[row] : row;
-        const float* xr = X + r * K;
-        float mine = 0.f;
-        for (int j0 = 0; j0 < NJ; j0 += 8) {                            // eight dot products share one multi-value reduction
-            float part[8];
+    for (int row0 = wave * RB; row0 < rows; row0 += nwaves * RB) {
+        const float* xr[RB];
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                part[jj] = 0.f;
-                if (j0 + jj < NJ) {
-                    for (int c = lane * VEC; c < K; c += 64 * VEC) {
-                        float xv[VEC], uv[VEC];
-                        load_vec<VEC>(xv, xr + c);
+        for (int b = 0; b < RB; ++b) {
+            const int row = min(row0 + b, rows - 1);                      // rows past the end recompute the last row, not stored
+            xr[b] = X + static_cast<int64_t>(gather ? gather[row] : row) * K;
+        }
+        float mine[RB];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) mine[b] = 0.f;
+        for (int j0 = 0; j0 < NJ; j0 += 8) {                            // eight dot products share one multi-value reduction
+            float part[RB][8];
+#pragma unroll
+            for (int b = 0; b < RB; ++b)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) part[b][jj] = 0.f;
+            for (int c = lane * VEC; c < K; c += 64 * VEC) {
+                float xv[RB][VEC];
+#pragma unroll
+                for (int b = 0; b < RB; ++b) load_vec<VEC>(xv[b], xr[b] + c);
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    if (j0 + jj < NJ) {
+                        float uv[VEC];
                         load_vec<VEC>(uv, U + (j0 + jj) * K + c);
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) part[jj] = fmaf(xv[v], uv[v], part[jj]);
+                        for (int b = 0; b < RB; ++b)
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) part[b][jj] = fmaf(xv[b][v], uv[v], part[b][jj]);
                     }
                 }
             }
-            const float tot = multi_sum<8>(part, lane);                 // lane l holds column j0 + (l >> 3)
-            const float t = __shfl(tot, (lane & 7) << 3, 64);           // every lane l now holds column j0 + (l & 7)
-            if (lane >= j0 && lane < j0 + 8) mine = t;                  // lane j keeps column j
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const float tot = multi_sum<8>(part[b], lane);          // lane l holds column j0 + (l >> 3)
+                const float t = __shfl(tot, (lane & 7) << 3, 64);       // every lane l now holds column j0 + (l & 7)
+                if (lane >= j0 && lane < j0 + 8) mine[b] = t;           // lane j keeps column j
+            }
         }
-        if (lane < NJ) out[static_cast<int64_t>(row) * NJ + lane] = mine;
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+            if (lane < NJ && row0 + b < rows) out[static_cast<int64_t>(row0 + b) * NJ + lane] = mine[b];
     }
 }
 
@@ -547,22 +584,37 @@ __global__ void __launch_bounds__(256) k_skinny_tn_partial(const float* __restri
         float acc[NJ][4];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f;
+        // gathered row ids are fetched one iteration ahead (lane q holds the id of row rb+q), so the row loads do not
+        // wait behind an index load
+        int gi = 0;
+        if (gather && lane < 4 && r0 + wave * 4 + lane < r1) gi = gather[r0 + wave * 4 + lane];
         for (int rb = r0 + wave * 4; rb < r1; rb += 16) {
-            float xv[4][4], gv[4][NJ];
+            int gnext = 0;
+            if (gather && lane < 4 && rb + 16 + lane < r1) gnext = gather[rb + 16 + lane];
+            float xv[4][4];
+            // the 4 x NJ coefficients of this iteration arrive with ONE load (lane q*NJ + j holds G[rb+q][j]) and are
+            // broadcast per use; one scalar-address load per coefficient made the kernel issue bound
+            float gl = 0.f;
+            {
+                const int q = lane / NJ, j = lane % NJ;
+                if (q < 4 && rb + q < r1 && j < nj) gl = G[static_cast<int64_t>(rb + q) * ldg + j];
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = rb + q;
                 xv[q][0] = xv[q][1] = xv[q][2] = xv[q][3] = 0.f;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) gv[q][j] = 0.f;
                 if (r < r1) {
-                    const int64_t row = gather ? gather[r] : r;
+                    const int64_t row = gather ? __builtin_amdgcn_readlane(gi, q) : r;
                     if (c + 3 < K) { const float4 t = *reinterpret_cast<const float4*>(X + row * K + c); xv[q][0] = t.x; xv[q][1] = t.y; xv[q][2] = t.z; xv[q][3] = t.w; }
                     else { for (int v = 0; v < 4; ++v) if (c + v < K) xv[q][v] = X[row * K + c + v]; }
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) if (j < nj) gv[q][j] = G[static_cast<int64_t>(r) * ldg + j];
                 }
             }
+            gi = gnext;
+            float gv[4][NJ];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) gv[q][j] = (q * NJ + j < 64) ? lane_bcast(gl, (q * NJ + j) & 63) : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -590,23 +642,32 @@ __global__ void __launch_bounds__(256) k_skinny_tn_partial(const float* __restri
         }
     }
 }
-// out[(j % P)*S1 + (j / P)*S2 + c] = sum_b partial[b][j][c]   (64 elements x 16 slice groups per block, fixed order)
+// out[(j % P)*S1 + (j / P)*S2 + c] = sum_b partial[b][j][c]   (16 elements x 64 slice groups per block, fixed order)
 __global__ void __launch_bounds__(1024) k_skinny_reduce(const float* __restrict__ partial, int32_t nb, int32_t nj, int32_t K,
                                                         int32_t P, int64_t S1, int64_t S2, float* __restrict__ out) {
-    __shared__ float red[16][64];
-    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + e;
+    __shared__ float red[64][17];
+    const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + e;
     const int tot = nj * K;
-    const int per = (nb + 15) / 16;
-    float s = 0.f;
-    if (idx < tot)
-        for (int b = grp * per; b < min(nb, (grp + 1) * per); ++b) s += partial[static_cast<int64_t>(b) * tot + idx];
-    red[grp][e] = s;
+    const int per = (nb + 63) / 64;
+    const int b0 = grp * per, b1 = min(nb, (grp + 1) * per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (idx < tot) {
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {
+            s0 += partial[static_cast<int64_t>(b) * tot + idx];
+            s1 += partial[static_cast<int64_t>(b + 1) * tot + idx];
+            s2 += partial[static_cast<int64_t>(b + 2) * tot + idx];
+            s3 += partial[static_cast<int64_t>(b + 3) * tot + idx];
+        }
+        for (; b < b1; ++b) s0 += partial[static_cast<int64_t>(b) * tot + idx];
+    }
+    red[grp][e] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp == 0 && idx < tot) {
         float t = 0.f;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) t += red[g][e];
+        for (int g = 0; g < 64; ++g) t += red[g][e];
         const int j = idx / K, c = idx % K;
         out[(j % P) * S1 + (j / P) * S2 + c] = t;
     }
@@ -690,17 +751,17 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
     if (a->N == 0) return RECON_OK;
     hipStream_t st = as_stream(stream);
     const int32_t N = a->N, E = a->E, F = a->F, R = a->R, D = a->D, H = a->H, W = 2 * F + R;
-    hipLaunchKernelGGL(k_score_vec, dim3(static_cast<unsigned>(ceil_div64(W, 64)), static_cast<unsigned>(H)), dim3(256), 0, st, a->a,
+    hipLaunchKernelGGL(k_score_vec, dim3(static_cast<unsigned>(ceil_div64(W, 64)), static_cast<unsigned>(H)), dim3(1024), 0, st, a->a,
                        a->a_2, D, W, a->u);
     {
-        const int nb = static_cast<int>(ceil_div64(N, 4) < 2048 ? ceil_div64(N, 4) : 2048);
+        const int nb = static_cast<int>(ceil_div64(N, 32) < 2048 ? ceil_div64(N, 32) : 2048);
         const size_t lds = static_cast<size_t>(2) * H * F * sizeof(float);
         if (lds > 64 * 1024) return RECON_ERR_UNSUPPORTED;
         if (s.vec == 4) hipLaunchKernelGGL((k_row_dots<4>), dim3(nb), dim3(kBlock), lds, st, a->x, nullptr, N, F, a->u, H, W, F, 0, 2 * H, a->c_node);
         else hipLaunchKernelGGL((k_row_dots<2>), dim3(nb), dim3(kBlock), lds, st, a->x, nullptr, N, F, a->u, H, W, F, 0, 2 * H, a->c_node);
     }
     if (E > 0) {
-        const int nb = static_cast<int>(ceil_div64(E, 4) < 4096 ? ceil_div64(E, 4) : 4096);
+        const int nb = static_cast<int>(ceil_div64(E, 32) < 2048 ? ceil_div64(E, 32) : 2048);
         const size_t lds = static_cast<size_t>(H) * R * sizeof(float);
         if (lds > 64 * 1024) return RECON_ERR_UNSUPPORTED;
         if (s.vec == 4) hipLaunchKernelGGL((k_row_dots<4>), dim3(nb), dim3(kBlock), lds, st, a->edge_embed, g->eid, E, R, a->u, H, W, 0, 2 * F, H, a->c_rel);
@@ -767,12 +828,13 @@ extern "C" size_t recon_gat_atp_bwd_partial_floats(int32_t N, int32_t E, int32_t
     return need > 0 ? need : 1;
 }
 
-// scratch of the skinny score-gradient products (<= 512 row slices x 16 columns); separate from `partial` so that
+// scratch of the skinny score-gradient products (<= kSkinnySlices row slices x 16 columns); separate from `partial` so that
 // the weight-gradient GEMM may run concurrently on another stream
+constexpr int kSkinnySlices = 1024;                              // row slices of the skinny products (first pass blocks)
 extern "C" size_t recon_gat_atp_bwd_partial2_floats(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H) {
     (void)N; (void)E; (void)D; (void)H;
     const size_t mx = static_cast<size_t>(F > R ? F : R);
-    return static_cast<size_t>(512) * 16 * mx;
+    return static_cast<size_t>(kSkinnySlices) * 16 * mx;
 }
 
 extern "C" int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_args* b, recon_stream_t stream) {
@@ -871,7 +933,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         }
         // (5) g_u = [Gs_dst | Gs_src]^T x   and   gsigma^T edge_embed[eid]   (skinny products, fixed-order reduce)
         if (phases & RECON_ATP_BWD_INPUTS) {
-            constexpr int kNB = 512;
+            constexpr int kNB = kSkinnySlices;
             auto skinny = [&](const float* G, int ldg, int nj, const float* X, const int32_t* gather, int rows, int K, int P,
                               int64_t S1, int64_t S2, float* out) {
                 if (rows <= 0) {
@@ -879,11 +941,11 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
                     return;
                 }
                 int rpb = static_cast<int>(ceil_div64(rows, kNB));
-                if (rpb < 64) rpb = 64;                                 // >= 16 rows per wave
+                if (rpb < 32) rpb = 32;                                 // >= 8 rows per wave
                 const int nb = static_cast<int>(ceil_div64(rows, rpb));
                 if (nj <= 8) hipLaunchKernelGGL((k_skinny_tn_partial<8>), dim3(nb), dim3(256), 0, st, G, ldg, nj, X, gather, rows, K, rpb, b->partial2);
                 else hipLaunchKernelGGL((k_skinny_tn_partial<16>), dim3(nb), dim3(256), 0, st, G, ldg, nj, X, gather, rows, K, rpb, b->partial2);
-                hipLaunchKernelGGL(k_skinny_reduce, dim3(static_cast<unsigned>(ceil_div64(1LL * nj * K, 64))), dim3(1024), 0, st, b->partial2, nb,
+                hipLaunchKernelGGL(k_skinny_reduce, dim3(static_cast<unsigned>(ceil_div64(1LL * nj * K, 16))), dim3(1024), 0, st, b->partial2, nb,
                                    nj, K, P, S1, S2, out);
             };
             // Gs is [N][2H] (dst sums | src sums): column j = (s, h) lands in g_u[h][s*F ...]
