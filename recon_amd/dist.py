@@ -69,5 +69,7 @@ class FlatGradBucket:
             return None
         w = dist.get_world_size(self.group)
         self.pack()
+        if dist.get_backend(self.group) == "nccl":                     # RCCL averages inside the collective: no extra pass
+            return dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
         self.flat.div_(w)
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)

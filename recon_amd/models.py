@@ -10,6 +10,21 @@ from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed, gather
 from .graph import prepare_graph
 
 
+class _AliasHeadParams(torch.autograd.Function):
+    """[H,D,W] / [H,D] tensors that ALIAS the per-head parameters (which SpGAT keeps as views of two fused
+    buffers): no copy in forward, and backward hands each head its slice of the fused gradient."""
+
+    @staticmethod
+    def forward(ctx, A, A2, *params):
+        ctx.nheads = len(params) // 2
+        return A.detach(), A2.detach()
+
+    @staticmethod
+    def backward(ctx, gA, gA2):
+        H = ctx.nheads
+        return (None, None) + tuple(gA[i] for i in range(H)) + tuple(gA2[i:i + 1] for i in range(H))
+
+
 class SpGAT(nn.Module):
     def __init__(self, num_nodes, nfeat, nhid, relation_dim, dropout, alpha, nheads):
         super().__init__()
@@ -25,12 +40,33 @@ class SpGAT(nn.Module):
                                              dropout=dropout, alpha=alpha, concat=False)
         self.alpha = alpha
 
+    def fused_head_params(self):
+        """The H heads' `a` / `a_2` as one [H,D,2F+R] / [H,D] pair for the fused launch.  The per-head
+        nn.Parameters (state_dict keys attention_i.a / attention_i.a_2, as in the reference) are kept as views of
+        two fused buffers, so this is an alias, not a per-step torch.stack; whenever something replaced a
+        parameter's storage (.to(), a fresh load) the buffers are rebuilt and the parameters re-pointed."""
+        atts = self.attentions
+        fused = getattr(self, "_fused_heads", None)
+        ok = fused is not None and fused[0].device == atts[0].a.device
+        if ok:
+            A, A2 = fused
+            ok = all(att.a.data_ptr() == A[i].data_ptr() and att.a_2.data_ptr() == A2[i].data_ptr()
+                     for i, att in enumerate(atts))
+        if not ok:
+            with torch.no_grad():
+                A = torch.stack([att.a.data for att in atts]).contiguous()
+                A2 = torch.cat([att.a_2.data for att in atts], dim=0).contiguous()
+                for i, att in enumerate(atts):
+                    att.a.data = A[i]
+                    att.a_2.data = A2[i:i + 1]
+            self._fused_heads = (A, A2)
+        return _AliasHeadParams.apply(A, A2, *[att.a for att in atts], *[att.a_2 for att in atts])
+
     def heads_forward(self, x, edge_list, edge_embed, edge_list_nhop, edge_embed_nhop):
         """The H-head attention stage (GAT/models.py:71-72) as one fused call."""
         graph = prepare_graph(edge_list, edge_list_nhop, x.shape[0])
         ee = cat_edge_embed(edge_embed, edge_list_nhop, edge_embed_nhop)
-        a = torch.stack([att.a for att in self.attentions])               # [H, D, 2F+R]
-        a2 = torch.cat([att.a_2 for att in self.attentions], dim=0)       # [H, D]
+        a, a2 = self.fused_head_params()                                  # [H, D, 2F+R], [H, D]
         keeps = [att.draw_keep(graph.E, x.device) for att in self.attentions]   # reference draw order
         keep = torch.cat(keeps, dim=0) if keeps[0] is not None else None
         return gat_heads(x, ee, a, a2, graph, keep, self.alpha, True)

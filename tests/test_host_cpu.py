@@ -119,3 +119,37 @@ def test_graph_cache_key_and_nhop_flag():
     assert not _has_nhop(torch.tensor([]))            # the reference's "no n-hop" marker: float tensor, shape [0]
     assert not _has_nhop(None)
     assert _has_nhop(torch.zeros(2, 3, dtype=torch.long))
+
+
+def test_fused_head_params_alias_the_per_head_parameters():
+    """SpGAT keeps attention_i.a / attention_i.a_2 (the reference's state_dict keys) as views of two fused
+    buffers: the fused pair is an alias (no per-step stack), gradients reach the per-head parameters, and a
+    replaced parameter storage (load / .to()) is picked up again."""
+    from recon_amd.models import SpGAT
+    torch.manual_seed(0)
+    m = SpGAT(10, 8, 6, 4, dropout=0.0, alpha=0.2, nheads=3)
+    keys = set(m.state_dict().keys())
+    assert {"attention_0.a", "attention_0.a_2", "attention_2.a", "W", "out_att.a", "out_att.a_2"} <= keys
+    ref_a = torch.stack([att.a.detach().clone() for att in m.attentions])
+    ref_a2 = torch.cat([att.a_2.detach().clone() for att in m.attentions], dim=0)
+    a, a2 = m.fused_head_params()
+    assert a.shape == (3, 6, 2 * 8 + 4) and a2.shape == (3, 6)
+    assert torch.equal(a, ref_a) and torch.equal(a2, ref_a2)
+    assert all(att.a.data_ptr() == a[i].data_ptr() for i, att in enumerate(m.attentions))        # aliases
+    (a * 2.0).sum().backward(retain_graph=True)
+    (a2 * 3.0).sum().backward()
+    for att in m.attentions:
+        assert torch.equal(att.a.grad, torch.full_like(att.a, 2.0))
+        assert torch.equal(att.a_2.grad, torch.full_like(att.a_2, 3.0))
+    with torch.no_grad():
+        m.attentions[1].a.add_(1.0)                                    # an optimizer's in-place update is seen
+    assert torch.equal(m.fused_head_params()[0][1], ref_a[1] + 1.0)
+    m.attentions[2].a.data = torch.zeros_like(m.attentions[2].a)       # storage replaced behind our back
+    a_new, _ = m.fused_head_params()
+    assert torch.equal(a_new[2], torch.zeros_like(ref_a[2])) and torch.equal(a_new[0], ref_a[0])
+    assert m.attentions[2].a.data_ptr() == a_new[2].data_ptr()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m2 = SpGAT(10, 8, 6, 4, dropout=0.0, alpha=0.2, nheads=3)
+    m2.fused_head_params()
+    m2.load_state_dict(sd)
+    assert torch.equal(m2.fused_head_params()[0], a_new)
