@@ -48,6 +48,7 @@ class FlatGradBucket:
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.views = []
+        self._avg_ok = True
         off = 0
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
@@ -69,7 +70,10 @@ class FlatGradBucket:
             return None
         w = dist.get_world_size(self.group)
         self.pack()
-        if dist.get_backend(self.group) == "nccl":                     # RCCL averages inside the collective: no extra pass
-            return dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+        if dist.get_backend(self.group) == "nccl" and self._avg_ok:    # RCCL averages inside the collective: no extra pass
+            try:
+                return dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+            except (RuntimeError, ValueError):                          # a build without ncclAvg: same on every rank
+                self._avg_ok = False
         self.flat.div_(w)
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
