@@ -158,7 +158,9 @@ def main():
             sigma = torch.empty(E, H, **f32)
             Z = torch.empty(N, H, **f32)
             Zk = torch.empty(N, H, **f32)
-            fa = _atp_args(graph, xd.detach(), eed.detach(), a, a2, None, u, c_node, c_rel, V, sigma, Z, Zk, out, 0.2, True)
+            from recon_amd.gat_layers import _atp_split_buffer
+            a_split = _atp_split_buffer(F_, R, D, H, dev)
+            fa = _atp_args(graph, xd.detach(), eed.detach(), a, a2, None, u, c_node, c_rel, V, sigma, Z, Zk, out, 0.2, True, a_split)
             stages = (L.recon_gat_atp_scores, L.recon_gat_atp_aggregate, L.recon_gat_atp_project)
             # compulsory traffic of the aggregation kernel: x and edge_embed rows once, score terms, CSR, V out,
             # saved sigma / Z / Zk  (fp32 values, int32 indices)

@@ -164,8 +164,14 @@ typedef struct {
     float* Zk;                  /* [N,H] saved sum_e k_e w_e                                 */
     float* out;                 /* [N, ld_out]                                               */
     int32_t ld_out;
+    void* a_split;              /* recon_gat_atp_split_bytes() bytes, workspace / saved: the three   *
+                                 * bfloat16 term planes of a and a^T for the split-precision GEMMs   *
+                                 * (csrc/gemm_bx3.hip; filled by the scores stage, read by the       *
+                                 * projection and by the backward's g_V product).  NULL = use the    *
+                                 * fp32-MFMA GEMM for those products.                                */
 } recon_gat_atp_args;
 
+size_t recon_gat_atp_split_bytes(int32_t F, int32_t R, int32_t D, int32_t H);
 int recon_gat_atp_supported(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H);
 int recon_gat_atp_fwd(const recon_graph* g, const recon_gat_atp_args* args, recon_stream_t stream);
 /* the three stages of recon_gat_atp_fwd, exported for profiling / tests */
@@ -293,6 +299,15 @@ int recon_gcn_bwd(const recon_gcn_bwd_args* args, recon_stream_t stream);
  * ------------------------------------------------------------------------------------------*/
 int recon_sgemm(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                 int32_t b_is_nk, float* C, int32_t ldc, recon_stream_t stream);
+
+/* K4'  the same product C[M,N] = A[M,K] * B[N,K]^T at fp32 accuracy on the bf16 matrix cores: every fp32
+ * operand is split into three bfloat16 terms and six term products are accumulated in fp32
+ * (csrc/gemm_bx3.hip).  B is split into `workspace` (recon_sgemm_bx3_workspace_bytes) first; A on the fly.
+ * Requires K % 4 == 0 and 16-byte aligned A rows (RECON_ERR_UNSUPPORTED otherwise).  Exported for tests;
+ * the GAT layer uses it for the projection `self.a.mm(...)` (GAT/layers.py:129-137) and its input gradient. */
+size_t recon_sgemm_bx3_workspace_bytes(int32_t N, int32_t K);
+int recon_sgemm_bx3(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
+                    float* C, int32_t ldc, void* workspace, recon_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -43,7 +43,7 @@ class GatAtpArgs(C.Structure):
                 ("H", C.c_int32), ("concat", C.c_int32), ("alpha", C.c_float),
                 ("x", c_f32p), ("edge_embed", c_f32p), ("a", c_f32p), ("a_2", c_f32p), ("keep", c_f32p),
                 ("u", c_f32p), ("c_node", c_f32p), ("c_rel", c_f32p), ("V", c_f32p), ("sigma", c_f32p),
-                ("Z", c_f32p), ("Zk", c_f32p), ("out", c_f32p), ("ld_out", C.c_int32)]
+                ("Z", c_f32p), ("Zk", c_f32p), ("out", c_f32p), ("ld_out", C.c_int32), ("a_split", C.c_void_p)]
 
 
 class GatAtpBwdArgs(C.Structure):
@@ -110,6 +110,10 @@ SYMBOLS = [
     ("recon_gcn_bwd", C.c_int, [C.POINTER(GcnBwdArgs), C.c_void_p]),
     ("recon_sgemm", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32,
                               c_f32p, C.c_int32, C.c_void_p]),
+    ("recon_gat_atp_split_bytes", C.c_size_t, [C.c_int32] * 4),
+    ("recon_sgemm_bx3_workspace_bytes", C.c_size_t, [C.c_int32, C.c_int32]),
+    ("recon_sgemm_bx3", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32,
+                                  C.c_void_p, C.c_void_p]),
 ]
 
 _lib = None

@@ -731,6 +731,14 @@ extern "C" int recon_gat_atp_supported(int32_t N, int32_t E, int32_t F, int32_t 
     return 1;
 }
 
+// a_split layout: planes of a  [3][H][D][kp(W)]  then planes of a^T [3][H][W][kp(D)]  (bf16), each part 16-byte aligned
+static size_t split_part_bytes(int64_t rows, int32_t K, int32_t H) { return align_up(static_cast<size_t>(3) * H * rows * bx3_kp(K) * 2, 256); }
+extern "C" size_t recon_gat_atp_split_bytes(int32_t F, int32_t R, int32_t D, int32_t H) {
+    if (F <= 0 || R <= 0 || D <= 0 || H <= 0) return 256;
+    const int32_t W = 2 * F + R;
+    return split_part_bytes(D, W, H) + split_part_bytes(W, D, H);
+}
+
 static int atp_fwd_common(const recon_graph* g, const recon_gat_atp_args* a, AtpShape* s) {
     int rc = check_atp(g, a);
     if (rc != RECON_OK) return rc;
@@ -753,6 +761,14 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
     const int32_t N = a->N, E = a->E, F = a->F, R = a->R, D = a->D, H = a->H, W = 2 * F + R;
     hipLaunchKernelGGL(k_score_vec, dim3(static_cast<unsigned>(ceil_div64(W, 64)), static_cast<unsigned>(H)), dim3(1024), 0, st, a->a,
                        a->a_2, D, W, a->u);
+    if (a->a_split) {                                             // bf16 term planes of a and a^T for the split-precision GEMMs
+        if (reinterpret_cast<uintptr_t>(a->a_split) & 15) return RECON_ERR_INVALID;
+        char* ws = static_cast<char*>(a->a_split);
+        rc = bx3_split_planes(a->a, W, static_cast<int64_t>(D) * W, false, D, W, H, ws, st);
+        if (rc != RECON_OK) return rc;
+        rc = bx3_split_planes(a->a, W, static_cast<int64_t>(D) * W, true, W, D, H, ws + split_part_bytes(D, W, H), st);
+        if (rc != RECON_OK) return rc;
+    }
     {
         const int nb = static_cast<int>(ceil_div64(N, 32) < 2048 ? ceil_div64(N, 32) : 2048);
         const size_t lds = static_cast<size_t>(2) * H * F * sizeof(float);
@@ -809,6 +825,7 @@ extern "C" int recon_gat_atp_project(const recon_graph* g, const recon_gat_atp_a
     GemmBatch bt;
     bt.batch = a->H; bt.a_bs = W; bt.b_bs = static_cast<int64_t>(a->D) * W; bt.c_bs = a->D;
     bt.epilogue = a->concat ? 1 : 0;
+    if (a->a_split && bx3_supported(A, W, bt)) return gemm_bx3_batched(a->N, a->D, W, A, a->a_split, C, bt, as_stream(stream));
     return gemm_f32_batched(a->N, a->D, W, A, true, B, true, C, bt, 1, nullptr, as_stream(stream));
 }
 
@@ -879,7 +896,10 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         OperandDesc B = plain_operand(a->a, W);
         OutputDesc C = plain_output(b->g_V, static_cast<int64_t>(H) * W);
         bt.a_bs = D; bt.b_bs = static_cast<int64_t>(D) * W; bt.c_bs = W;
-        rc = gemm_f32_batched(N, W, D, A, true, B, false, C, bt, 1, nullptr, st);
+        if (a->a_split && bx3_supported(A, D, bt))
+            rc = gemm_bx3_batched(N, W, D, A, static_cast<const char*>(a->a_split) + split_part_bytes(D, W, H), C, bt, st);
+        else
+            rc = gemm_f32_batched(N, W, D, A, true, B, false, C, bt, 1, nullptr, st);
         if (rc != RECON_OK) return rc;
     }
     // (2) edge pass over the destination CSR

@@ -40,9 +40,25 @@ __device__ __forceinline__ int64_t out_row_off(const OutputDesc& C, int32_t row)
     return static_cast<int64_t>(row % C.P) * C.S1 + static_cast<int64_t>(row / C.P) * C.S2;
 }
 
-// split-precision (bf16 x 3) MFMA GEMM, gemm_bf16x3.hip.  Same contract as gemm_f32 but requires the
-// float4-aligned operand layouts (returns RECON_ERR_UNSUPPORTED otherwise; callers fall back).
-int gemm_bf16x3_launch(const GemmArgs& a, bool a_k_minor, bool b_k_minor, int32_t split_k, hipStream_t st);
-bool gemm_bf16x3_enabled();
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs by linear id, and each XCD has its own L2:
+// with the natural order the N tiles that share one A tile (and the M tiles that share one B slab) land on 8
+// different L2s and each re-fetches the operand from HBM (PMC: 349 MB for the g_V GEMM whose operands are 56 MB).
+// Give XCD c the c-th CONTIGUOUS chunk of the (n fastest, m, batch*split) tile order instead.
+struct TileId { int x, y, z; };
+__device__ __forceinline__ TileId xcd_tile(int remap) {
+    if (!remap) return {static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), static_cast<int>(blockIdx.z)};
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned c = L & 7u, pos = L >> 3, q = total >> 3, r = total & 7u;
+    const unsigned logical = c * q + min(c, r) + pos;
+    TileId id;
+    id.x = static_cast<int>(logical % gx);
+    const unsigned rest = logical / gx;
+    id.y = static_cast<int>(rest % gy);
+    id.z = static_cast<int>(rest / gy);
+    return id;
+}
+
+
 
 }  // namespace recon

@@ -153,25 +153,6 @@ struct TileLoader {
     }
 };
 
-// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs by linear id, and each XCD has its own L2:
-// with the natural order the N tiles that share one A tile (and the M tiles that share one B slab) land on 8
-// different L2s and each re-fetches the operand from HBM (PMC: 349 MB for the g_V GEMM whose operands are 56 MB).
-// Give XCD c the c-th CONTIGUOUS chunk of the (n fastest, m, batch*split) tile order instead.
-struct TileId { int x, y, z; };
-__device__ __forceinline__ TileId xcd_tile(int remap) {
-    if (!remap) return {static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), static_cast<int>(blockIdx.z)};
-    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
-    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-    const unsigned c = L & 7u, pos = L >> 3, q = total >> 3, r = total & 7u;
-    const unsigned logical = c * q + min(c, r) + pos;
-    TileId id;
-    id.x = static_cast<int>(logical % gx);
-    const unsigned rest = logical / gx;
-    id.y = static_cast<int>(rest % gy);
-    id.z = static_cast<int>(rest / gy);
-    return id;
-}
-
 // Block tile (WM*TM*32) x (WN*TN*32) x 16; 4 waves arranged WM x WN, each wave TM x TN MFMA tiles.
 template <bool A_KMINOR, bool B_KMINOR, int VEC, int WM, int WN, int TM, int TN, int BK, bool LIN>
 __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const GemmArgs p) {
@@ -510,8 +491,7 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
     a.a_bs = bt.a_bs; a.b_bs = bt.b_bs; a.c_bs = bt.c_bs; a.epilogue = bt.epilogue;
     a.xcd_remap = (getenv("RECON_GEMM_XCD") && atoi(getenv("RECON_GEMM_XCD")) == 0) ? 0 : 1;   // read per call: in-process A/B
     const bool v4 = operand_vec4(A, a_k_minor ? K : M) && operand_vec4(B, b_k_minor ? K : N) && (bt.batch == 1 || (!(bt.a_bs & 3) && !(bt.b_bs & 3)));
-    const bool use3 = v4 && bt.batch == 1 && bt.epilogue == GEMM_EPI_NONE && gemm_bf16x3_enabled();   // experimental kernel (K tile 32)
-    const int bk = use3 ? 32 : BK16;
+    const int bk = BK16;
     int64_t kps = ceil_div64(K > 0 ? K : 1, split_k);
     kps = ceil_div64(kps, bk) * bk;
     a.k_per_split = static_cast<int32_t>(kps);
@@ -519,10 +499,7 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
     a.nsplit = split_k;
     a.partial = (split_k > 1 || bt.c_transpose) ? partial : nullptr;
     if (static_cast<int64_t>(bt.batch) * split_k > 65535) return RECON_ERR_UNSUPPORTED;
-    if (use3) {
-        const int rc = gemm_bf16x3_launch(a, a_k_minor, b_k_minor, split_k, st);
-        if (rc != RECON_OK) return rc;
-    } else {
+    {
         const bool narrow = use_narrow(N, a_k_minor, b_k_minor, v4);
         const bool lin = v4 && operand_linear(A, a_k_minor, K) && operand_linear(B, b_k_minor, K) &&
                          !(getenv("RECON_GEMM_LIN") && atoi(getenv("RECON_GEMM_LIN")) == 0);

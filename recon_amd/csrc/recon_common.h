@@ -135,4 +135,13 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
                      bool b_k_minor, const OutputDesc& C, const GemmBatch& bt, int32_t split_k, float* partial,
                      hipStream_t stream);
 
+// split-precision (bf16 x 3) MFMA GEMM, gemm_bx3.hip: C = act(A . B^T), A fp32 k-contiguous, B pre-split bf16 planes
+// [3][batch][N][bx3_kp(K)] written by bx3_split_planes (transposed = true reads src as [K][rows]).
+int32_t bx3_kp(int32_t K);
+int bx3_split_planes(const float* src, int64_t ld, int64_t src_bs, bool transposed, int32_t rows, int32_t K, int32_t batch, void* dst,
+                     hipStream_t st);
+bool bx3_supported(const OperandDesc& A, int32_t K, const GemmBatch& bt);
+int gemm_bx3_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, const void* planes, const OutputDesc& C,
+                     const GemmBatch& bt, hipStream_t st);
+
 }  // namespace recon

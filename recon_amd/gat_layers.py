@@ -27,6 +27,9 @@ _GAT_PATH = os.environ.get("RECON_GAT_PATH", "auto")
 # edge chain.  Off by default: measured neutral on MI355X (0.927 vs 0.922 ms/step at cfg 2) because the GEMM's
 # 4 waves/SIMD x 128 registers leave no register file for co-resident edge-kernel waves.
 _OVERLAP = os.environ.get("RECON_OVERLAP", "0") == "1"
+# RECON_GEMM_BX3=0: run the projection and its input-gradient product on the fp32 MFMA GEMM instead of the
+# split-precision (3 x bf16 terms, fp32-accurate) one of csrc/gemm_bx3.hip
+_GEMM_BX3 = os.environ.get("RECON_GEMM_BX3", "1")
 _SIDE_STREAMS = {}
 
 
@@ -220,12 +223,19 @@ class _GATHeadsFunction(torch.autograd.Function):
         return g_x, g_ee, g_a, g_a2, None, None, None, None
 
 
-def _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat):
+def _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split=None):
     H, D = a2.shape
     return _lib.GatAtpArgs(graph.N, graph.E, x.shape[1], ee.shape[1], D, H, int(bool(concat)), float(alpha),
                            x.data_ptr(), ee.data_ptr(), a.data_ptr(), a2.data_ptr(), _lib.ptr(keep), u.data_ptr(),
                            c_node.data_ptr(), _lib.ptr(c_rel), V.data_ptr(), _lib.ptr(sigma), _lib.ptr(Z), _lib.ptr(Zk),
-                           out.data_ptr(), out.shape[1])
+                           out.data_ptr(), out.shape[1], _lib.ptr(a_split))
+
+
+def _atp_split_buffer(F_, R, D, H, dev):
+    """Workspace of the split-precision GEMMs (bf16 term planes of a and a^T); RECON_GEMM_BX3=0 keeps fp32 MFMA."""
+    if _GEMM_BX3 == "0":
+        return None
+    return torch.empty(_lib.lib().recon_gat_atp_split_bytes(F_, R, D, H), dtype=torch.uint8, device=dev)
 
 
 class _GATHeadsATPFunction(torch.autograd.Function):
@@ -256,17 +266,18 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         Zk = torch.empty(N, H, **f32) if train else None
         if keep is not None:
             keep = keep.view(H, E)[:, graph.eid_long].t().contiguous()        # [H,E] original order -> [E,H] slot order
-        args = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat)
+        a_split = _atp_split_buffer(F_, R, D, H, dev)
+        args = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split)
         with torch.cuda.device(dev):
             _lib.check(L.recon_gat_atp_fwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_atp_fwd")
         if need_grad:
-            ctx.save_for_backward(x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out)
+            ctx.save_for_backward(x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, a_split)
             ctx.graph, ctx.alpha, ctx.concat = graph, alpha, concat
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out = ctx.saved_tensors
+        x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, a_split = ctx.saved_tensors
         graph = ctx.graph
         L = _lib.lib()
         H, D = a2.shape
@@ -290,7 +301,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         g_ee = torch.empty(E, R, **f32) if ne else None
         g_a = torch.empty(H, D, W, **f32) if (na or na2) else None
         g_a2 = torch.empty(H, D, **f32) if (na or na2) else None
-        fwd = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, ctx.alpha, ctx.concat)
+        fwd = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, ctx.alpha, ctx.concat, a_split)
         args = _lib.GatAtpBwdArgs(fwd, grad_out.data_ptr(), grad_out.shape[1], _lib.ptr(g_h), g_V.data_ptr(),
                                   _lib.ptr(g_sigma), _lib.ptr(Gxs), gxd.data_ptr(), Gs.data_ptr(), g_u.data_ptr(),
                                   q.data_ptr(), partial.data_ptr(), partial2.data_ptr(), _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2))

@@ -71,6 +71,31 @@ def test_sgemm(M, N, K, nk, cfg, monkeypatch):
     close(Cd, ref, atol=1e-5, rel_to_max=2e-6, what="sgemm")
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 208, 32), (200, 72, 52), (33, 257, 20), (700, 200, 600), (513, 600, 200),
+                                   (300, 204, 36), (1000, 25, 8)])
+def test_sgemm_bx3(M, N, K):
+    """Split-precision (3 x bf16) MFMA GEMM: fp32-class accuracy against an fp64 product."""
+    from recon_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * torch.exp(2.0 * torch.randn(M, 1, generator=g))     # rows of very different scale
+    B = torch.randn(N, K, generator=g)
+    Ad, Bd = A.to(dev()), B.to(dev())
+    Cd = torch.full((M, N), float("nan"), device=dev())
+    L = _lib.lib()
+    ws = torch.empty(L.recon_sgemm_bx3_workspace_bytes(N, K), dtype=torch.uint8, device=dev())
+    rc = L.recon_sgemm_bx3(M, N, K, Ad.data_ptr(), K, Bd.data_ptr(), K, Cd.data_ptr(), N, ws.data_ptr(), _lib.current_stream())
+    assert rc == 0
+    ref = A.double() @ B.double().t()
+    # elementwise bound of an fp32 dot product: |err| <= c * eps * sum_k |a_k b_k| with c = 16, eps = 2^-24
+    # (the fp32 library GEMM reaches c = 6 on these inputs; a two-term bf16 split would need c = 256)
+    bound = (A.double().abs() @ B.double().abs().t()) * (2.0 ** -20) + 1e-30
+    err = (Cd.cpu().double() - ref).abs()
+    assert torch.isfinite(Cd).all()
+    assert (err <= bound).all(), float((err / bound).max())
+    f32 = (A.to(dev()) @ B.to(dev()).t()).cpu().double()                 # the fp32 library product is no closer
+    assert err.max() <= 4.0 * (f32 - ref).abs().max() + 1e-12
+
+
 # ------------------------------------------------------------------------------- G1-G3
 @pytest.mark.parametrize("name", ["spmm1_o1", "spmm1_oD"])
 def test_spmm_golden(name):

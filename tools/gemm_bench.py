@@ -24,7 +24,11 @@ def run(M, N, K, nk, cfgs, rounds=5, iters=10):
         L.recon_sgemm(M, N, K, A.data_ptr(), K, B.data_ptr(), B.shape[1], nk, Cc.data_ptr(), N, st)
     def ref():
         torch.mm(A, B.t() if nk else B)
+    ws = torch.empty(L.recon_sgemm_bx3_workspace_bytes(N, K), dtype=torch.uint8, device=d) if nk else None
+    def bx3():
+        L.recon_sgemm_bx3(M, N, K, A.data_ptr(), K, B.data_ptr(), K, Cc.data_ptr(), N, ws.data_ptr(), st)
     res = {c: [] for c in cfgs}; res["torch"] = []
+    if nk: res["bx3"] = []
     for r in range(rounds + 1):
         for c in cfgs:
             os.environ["RECON_GEMM_CFG"] = str(c)
@@ -32,9 +36,12 @@ def run(M, N, K, nk, cfgs, rounds=5, iters=10):
             if r: res[c].append(t)
         t = time_once(ref, iters)
         if r: res["torch"].append(t)
+        if nk:
+            t = time_once(bx3, iters)
+            if r: res["bx3"].append(t)
     fl = 2.0 * M * N * K
     line = "M=%6d N=%5d K=%6d nk=%d :" % (M, N, K, nk)
-    for c in list(cfgs) + ["torch"]:
+    for c in list(cfgs) + ["torch"] + (["bx3"] if nk else []):
         med = sorted(res[c])[len(res[c]) // 2]
         line += "  [%s] %7.1f us %6.1f TF" % (c, med, fl / med / 1e6)
     print(line)
