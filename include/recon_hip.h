@@ -308,6 +308,11 @@ int recon_sgemm(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, co
 size_t recon_sgemm_bx3_workspace_bytes(int32_t N, int32_t K);
 int recon_sgemm_bx3(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                     float* C, int32_t ldc, void* workspace, recon_stream_t stream);
+/* C[M,N] = A^T * B for k-major operands A[K,M], B[K,N] (the weight-gradient form g_a^T = V^T g_h; split-K with a
+ * fixed-order second pass; both operands split on the fly).  Requires M, N, lda, ldb multiples of 4. */
+size_t recon_sgemm_bx3_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int recon_sgemm_bx3_tn(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
+                       float* C, int32_t ldc, void* workspace, recon_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -114,6 +114,9 @@ SYMBOLS = [
     ("recon_sgemm_bx3_workspace_bytes", C.c_size_t, [C.c_int32, C.c_int32]),
     ("recon_sgemm_bx3", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32,
                                   C.c_void_p, C.c_void_p]),
+    ("recon_sgemm_bx3_tn_workspace_bytes", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    ("recon_sgemm_bx3_tn", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32,
+                                     C.c_void_p, C.c_void_p]),
 ]
 
 _lib = None

@@ -839,7 +839,9 @@ extern "C" int recon_gat_atp_fwd(const recon_graph* g, const recon_gat_atp_args*
 
 extern "C" size_t recon_gat_atp_bwd_partial_floats(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H) {
     const int64_t W = 2LL * F + R;
-    const int s1 = gemm_pick_split_k(static_cast<int32_t>(W), D, N, H);
+    int s1 = gemm_pick_split_k(static_cast<int32_t>(W), D, N, H);
+    const int s2 = bx3_kmajor_splits(N, bx3_kmajor_split_k(static_cast<int32_t>(W), D, N, H));   // split-precision form
+    if (s2 > s1) s1 = s2;
     size_t need = static_cast<size_t>(s1) * H * D * W;                         // g_a^T = V^T g_h, batched over heads
     (void)E; (void)F; (void)R;
     return need > 0 ? need : 1;
@@ -947,8 +949,15 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
             OutputDesc C = plain_output(b->g_a, W);
             GemmBatch bw = bt;
             bw.a_bs = W; bw.b_bs = D; bw.c_bs = static_cast<int64_t>(D) * W; bw.c_transpose = 1;
-            const int sk = gemm_pick_split_k(W, D, N, H);
-            rc = gemm_f32_batched(W, D, N, A, false, B, false, C, bw, sk, b->partial, st);
+            const int64_t ldv = static_cast<int64_t>(H) * W;
+            if (a->a_split && bx3_kmajor_supported(a->V, ldv, W, gh, ld_gh, D, W, D)) {       // split-precision MFMA, both operands k-major
+                const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));
+                rc = gemm_bx3_kmajor_batched(W, D, N, a->V, ldv, W, gh, ld_gh, D, H, sk, b->partial, st);
+                if (rc == RECON_OK) rc = splitk_reduce(b->partial, sk, W, D, C, bw.c_bs, H, 0, true, st);
+            } else {
+                const int sk = gemm_pick_split_k(W, D, N, H);
+                rc = gemm_f32_batched(W, D, N, A, false, B, false, C, bw, sk, b->partial, st);
+            }
             if (rc != RECON_OK) return rc;
         }
         // (5) g_u = [Gs_dst | Gs_src]^T x   and   gsigma^T edge_embed[eid]   (skinny products, fixed-order reduce)

@@ -65,35 +65,126 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[3]) {
     }
 }
 
+// the six term products of one accumulator, issued for a GROUP of independent accumulators term by term: six
+// back-to-back MFMAs into the same accumulator would each wait for the previous result (dependent-issue latency
+// of the 4-pass MFMA), a group of 4 (2 row tiles x 2 column tiles) keeps 3 independent MFMAs between dependent ones
+template <int NJ>
+__device__ __forceinline__ void bx3_products(f32x4 (&acc)[2][TN], const bf16x8 (&a)[2][3], const bf16x8 (&b)[2][3], int j0) {
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};      // small terms first
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][TA[t]], b[jj][TB[t]], acc[i][j0 + jj], 0, 0, 0);
+}
+
+__device__ __forceinline__ void bx3_mma_reg(f32x4 (&acc)[2][TN], const bf16x8 (&a)[2][3], const unsigned char* Bs, int b_rd) {
+    // column tiles in pairs; the fragments of the next pair are read while the 24 MFMAs of this one run (two register
+    // sets pinned with sched_barrier: left alone the scheduler reads into one set and waits for every read)
+    bf16x8 b[2][2][3];
+    auto read_pair = [&](int j0, bf16x8 (&dst)[2][3]) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            if (j0 + jj < TN) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) dst[jj][q] = *reinterpret_cast<const bf16x8*>(Bs + q * (BN * 64) + b_rd + (j0 + jj) * 1024);
+            }
+    };
+    read_pair(0, b[0]);
+#pragma unroll
+    for (int g = 0; g < (TN + 1) / 2; ++g) {
+        if (2 * g + 2 < TN) read_pair(2 * g + 2, b[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (2 * g + 1 < TN) bx3_products<2>(acc, a, b[g & 1], 2 * g);
+        else bx3_products<1>(acc, a, b[g & 1], 2 * g);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// one K tile (32) of the wave's 32 x 208 block with both operands in LDS (k-major kernel): 6 + 39 ds_read_b128, 156 MFMAs
+__device__ __forceinline__ void bx3_mma(f32x4 (&acc)[2][TN], const unsigned char (*As)[BM * 64], const unsigned char (*Bs)[BN * 64],
+                                        const int (&a_rd)[2], int b_rd) {
+    bf16x8 a[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(&As[q][a_rd[i]]);
+    bx3_mma_reg(acc, a, &Bs[0][0], b_rd);
+}
+
+// MFMA C layout col = lane&15, row = (lane>>4)*4 + r; columns through the B row permutation (tile 4q+t <-> columns 64q+4i+t)
+__device__ __forceinline__ void bx3_store(const f32x4 (&acc)[2][TN], const OutputDesc& C, float* base, int M, int N, int m0, int n0,
+                                          int mb, int li, int lq, int epi, int c_vec4) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + mb + 16 * i + 4 * lq + r;
+            if (row >= M) continue;
+            float* crow = base + out_row_off(C, row);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int col = n0 + 64 * q + 4 * li;
+                if (c_vec4) {
+                    if (col < N)
+                        *reinterpret_cast<float4*>(crow + minor_off(C.Dseg, C.Sseg, col)) =
+                            make_float4(gemm_epilogue(acc[i][4 * q][r], epi), gemm_epilogue(acc[i][4 * q + 1][r], epi),
+                                        gemm_epilogue(acc[i][4 * q + 2][r], epi), gemm_epilogue(acc[i][4 * q + 3][r], epi));
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        if (col + jj < N) crow[minor_off(C.Dseg, C.Sseg, col + jj)] = gemm_epilogue(acc[i][4 * q + jj][r], epi);
+                }
+            }
+            const int col = n0 + 192 + li;
+            if (col < N) crow[minor_off(C.Dseg, C.Sseg, col)] = gemm_epilogue(acc[i][12][r], epi);
+        }
+}
+
+// A never touches LDS: the rows of a wave's 32 x 208 block are private to that wave, so every lane loads its own MFMA
+// fragment (row lane&15, 8 consecutive k) straight from global memory, splits it in registers and keeps the three
+// bf16x8 terms as MFMA operands.  B (pre-split planes) is copied global -> LDS by the LDS-DMA path
+// (global_load_lds_dwordx4: no staging registers, no ds_write) into a DOUBLE-buffered image, so a K tile costs one
+// barrier and both operands of tile t+1 are in flight during the MFMAs of tile t.  The DMA writes lane-linear
+// (wave base + 16 B x lane), so the bank rotation of the image is applied on the SOURCE address: lane -> (plane, row,
+// physical slot) -> the k group that lives there.
+constexpr int B_TILE_BYTES = 3 * BN * 64;                        // 39936: one buffer of the B image
+constexpr int B_DMA = (B_TILE_BYTES / 16 + NT - 1) / NT;         // 10 DMA instructions per thread and tile
+
 __global__ void __launch_bounds__(NT, 2) k_gemm_bx3(const Bx3Args p) {
-    __shared__ __attribute__((aligned(16))) unsigned char As[3][BM * 64];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[3][BN * 64];
-    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][B_TILE_BYTES];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const TileId tile = xcd_tile(p.xcd_remap);
     const int m0 = tile.y * BM, n0 = tile.x * BN, bz = tile.z;
+    const int mb = wid * 32;
+    const int li = lane & 15, lq = lane >> 4;
 
-    // ---- A items: item i (0, 1) = row t/4 + 64 i, 8 floats at k0 + 8 (t & 3)
-    const int a_kq = t & 3;
+    // ---- A: fragment-shaped loads, M tile i = rows mb + 16 i + li, this lane's 8 k values start at 8 lq
     const float* aptr[2];
-    int a_lds[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (t >> 2) + 64 * i;
-        aptr[i] = p.A.base + bz * p.a_bs + major_off(p.A, min(m0 + row, p.M - 1)) + 8 * a_kq;
-        a_lds[i] = lds_off(row, a_kq);
-    }
-    // ---- B items: slot index idx = t + 256 i over (plane, LDS row, k group); LDS row <-> output column permutation
-    int b_goff[B_NP], b_lds[B_NP];
+    for (int i = 0; i < 2; ++i) aptr[i] = p.A.base + bz * p.a_bs + major_off(p.A, min(m0 + mb + 16 * i + li, p.M - 1)) + 8 * lq;
+    // ---- B: DMA i of wave w fills the 1 KiB piece (4 i + w) of the image; slot s = 64 (4 i + w) + lane
+    int b_goff[B_DMA];
     const __bf16* bbase = p.Bp + bz * p.b_bs;
 #pragma unroll
-    for (int i = 0; i < B_NP; ++i) {
-        const int idx = min(t + NT * i, B_ITEMS - 1);
-        const int plane = idx / (BN * 4), rem = idx % (BN * 4), rowL = rem >> 2, kq = rem & 3;
+    for (int i = 0; i < B_DMA; ++i) {
+        const int s = min(64 * (4 * i + wid) + lane, B_TILE_BYTES / 16 - 1);
+        const int plane = s / (BN * 4), rem = s % (BN * 4), rowL = rem >> 2, pslot = rem & 3;
+        const int kq = (pslot - 2 * (rowL >> 3)) & 3;                 // inverse of lds_off's rotation
         const int j = rowL >> 4, rho = rowL & 15;
         const int col = j < 12 ? 64 * (j >> 2) + 4 * rho + (j & 3) : 192 + rho;
         b_goff[i] = static_cast<int>(plane * p.b_plane + static_cast<int64_t>(min(n0 + col, p.N - 1)) * p.b_row + 8 * kq);
-        b_lds[i] = plane * (BN * 64) + lds_off(rowL, kq);
     }
+    auto dma_b = [&](int k0, int buf) {
+#pragma unroll
+        for (int i = 0; i < B_DMA; ++i)
+            if (64 * (4 * i + wid) < B_TILE_BYTES / 16)                // wave-uniform: the last round is 3 waves wide
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(bbase + b_goff[i] + k0),
+                                                 (__attribute__((address_space(3))) void*)(&Bs[buf][1024 * (4 * i + wid)]), 16, 0, 0);
+    };
 
     f32x4 acc[2][TN];
 #pragma unroll
@@ -102,31 +193,148 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_bx3(const Bx3Args p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     float av[2][8];
-    u32x4 bv[B_NP];
-    auto load_tile = [&](int k0) {
+    bf16x8 af[2][3];
+    // The A loads are inline asm with one hand-placed s_waitcnt: as ordinary loads next to an LDS-DMA in flight the
+    // compiler waits vmcnt(0) at their first use AND turns the guarded addresses into branches, which serialises
+    // the tile.  Lanes past K read the start of their row instead and are zeroed when the tile is split.
+    bool a_ok[2];
+    f32x4 araw[2][2];
+    auto load_a = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) a_ok[h] = k0 + 8 * lq + 4 * h < p.K;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int k = k0 + 8 * a_kq + 4 * h;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < p.K) v = *reinterpret_cast<const float4*>(aptr[i] + k0 + 4 * h);
-                av[i][4 * h] = v.x; av[i][4 * h + 1] = v.y; av[i][4 * h + 2] = v.z; av[i][4 * h + 3] = v.w;
+                const int off = -8 * lq + ((k0 + 4 * h + 8 * lq) & -static_cast<int>(a_ok[h]));
+                const float* q = aptr[i] + off;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(araw[i][h]) : "v"(q));
             }
-#pragma unroll
-        for (int i = 0; i < B_NP; ++i) bv[i] = *reinterpret_cast<const u32x4*>(bbase + b_goff[i] + k0);   // planes are zero padded to Kp
     };
-    auto store_tile = [&]() {
+    auto wait_a = [&]() {                                             // also drains the DMA of the same tile (needed before the barrier anyway)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(araw[0][0]), "+v"(araw[0][1]), "+v"(araw[1][0]), "+v"(araw[1][1]));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[i][e] = a_ok[e >> 2] ? araw[i][e >> 2][e & 3] : 0.f;
+    };
+    auto split_a = [&]() {
+        wait_a();
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             u32x4 s[3];
             split8(av[i], s);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(&As[q][a_lds[i]]) = s[q];
+            for (int q = 0; q < 3; ++q) af[i][q] = __builtin_bit_cast(bf16x8, s[q]);
         }
+    };
+    const int b_rd = lds_off(li, lq);                                 // + j * 16 rows * 64 B (the rotation depends on row & 8 only)
+
+    dma_b(0, 0);
+    load_a(0);
+    split_a();
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+        if (k0 + BK < p.K) dma_b(k0 + BK, buf ^ 1);
+        load_a(k0 + BK);                                              // unconditional (past K every lane re-reads its row start): no
+        bx3_mma_reg(acc, af, Bs[buf], b_rd);                          // control-flow join may sit between a load and its use
+        split_a();
+        __syncthreads();
+        buf ^= 1;
+    }
+    bx3_store(acc, p.C, p.C.base + bz * p.c_bs, p.M, p.N, m0, n0, mb, li, lq, p.epilogue, p.c_vec4);
+}
+
+// The same product for k-MAJOR operands: A is [K][M] and B is [K][N] in memory (m / n contiguous), both fp32 and both
+// split on the fly — the weight gradient g_a^T = V^T g_h, whose K is the node dimension.  A thread loads a 4(k) x 4(m)
+// block (four float4), transposes it in registers and writes, per m, the four consecutive k values of each term plane
+// as one ds_write_b64 into the same k-contiguous LDS image as above, so the MFMA loop is identical.  Split-K: every
+// (batch, split) writes its tile to partial[z][M][N]; the caller reduces (and here transposes) in a second pass.
+struct Bx3KmArgs {
+    const float* A; const float* B;
+    int64_t lda, ldb, a_bs, b_bs;
+    float* partial;
+    int32_t M, N, K, k_per_split, nsplit, c_vec4;
+};
+
+__global__ void __launch_bounds__(NT, 2) k_gemm_bx3_kmajor(const Bx3KmArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[3][BM * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[3][BN * 64];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const TileId tile = xcd_tile(1);
+    const int m0 = tile.y * BM, n0 = tile.x * BN;
+    const int bz = tile.z / p.nsplit, zs = tile.z % p.nsplit;
+    const int k_begin = zs * p.k_per_split, k_end = min(p.K, k_begin + p.k_per_split);
+
+    // block (k quad kqd, m/n quad): A has 32 x 8 blocks = one per thread, B 52 x 8 = 416 blocks (threads < 160 take two)
+    const int kqd = t & 7;
+    const int a_mq = t >> 3;
+    const float* aptr = p.A + bz * p.a_bs + min(m0 + 4 * a_mq, p.M - 4);
+    int b_nq[2];
+    const float* bptr[2];
+    bool b_on[2];
 #pragma unroll
-        for (int i = 0; i < B_NP; ++i)
-            if (t + NT * i < B_ITEMS) *reinterpret_cast<u32x4*>(&Bs[0][0] + b_lds[i]) = bv[i];
+    for (int i = 0; i < 2; ++i) {
+        b_nq[i] = (t >> 3) + 32 * i;
+        b_on[i] = b_nq[i] < BN / 4;
+        bptr[i] = p.B + bz * p.b_bs + min(n0 + 4 * b_nq[i], p.N - 4);
+    }
+
+    f32x4 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float av[4][4], bv[2][4][4];                                     // [k][m]
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = k0 + 4 * kqd + r;
+            const bool ok = k < k_end;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) v = *reinterpret_cast<const float4*>(aptr + static_cast<int64_t>(k) * p.lda);
+            av[r][0] = v.x; av[r][1] = v.y; av[r][2] = v.z; av[r][3] = v.w;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok && b_on[i]) w = *reinterpret_cast<const float4*>(bptr[i] + static_cast<int64_t>(k) * p.ldb);
+                bv[i][r][0] = w.x; bv[i][r][1] = w.y; bv[i][r][2] = w.z; bv[i][r][3] = w.w;
+            }
+        }
+    };
+    // write the four k values of column j of a block as 3 x 8 bytes at LDS row `row`
+    auto put = [&](unsigned char* T, int plane_bytes, const float (&blk)[4][4], int j, int row) {
+        float x[4] = {blk[0][j], blk[1][j], blk[2][j], blk[3][j]};
+        const int off = lds_off(row, kqd >> 1) + ((kqd & 1) << 3);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            uint32_t w[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const __bf16 h0 = static_cast<__bf16>(x[2 * h]), h1 = static_cast<__bf16>(x[2 * h + 1]);
+                const uint32_t b0 = __builtin_bit_cast(uint16_t, h0), b1 = __builtin_bit_cast(uint16_t, h1);
+                w[h] = b0 | (b1 << 16);
+                if (q < 2) {
+                    x[2 * h] -= __builtin_bit_cast(float, b0 << 16);
+                    x[2 * h + 1] -= __builtin_bit_cast(float, b1 << 16);
+                }
+            }
+            *reinterpret_cast<uint2*>(T + q * plane_bytes + off) = make_uint2(w[0], w[1]);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) put(&As[0][0], BM * 64, av, j, 4 * a_mq + j);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (b_on[i]) {
+                const int nq = b_nq[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)                              // column 4nq+j -> LDS row of the tile that owns it
+                    put(&Bs[0][0], BN * 64, bv[i], j, nq < 48 ? 16 * (4 * (nq >> 4) + j) + (nq & 15) : 4 * nq + j);
+            }
     };
 
     const int mb = wid * 32;
@@ -134,62 +342,19 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_bx3(const Bx3Args p) {
     int a_rd[2], b_rd;
 #pragma unroll
     for (int i = 0; i < 2; ++i) a_rd[i] = lds_off(mb + 16 * i + li, lq);
-    b_rd = lds_off(li, lq);                                           // + j * 16 rows * 64 B (the rotation depends on row & 8 only)
+    b_rd = lds_off(li, lq);
 
-    load_tile(0);
-    for (int k0 = 0; k0 < p.K; k0 += BK) {
+    if (k_begin < k_end) load_tile(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         store_tile();
         __syncthreads();
-        if (k0 + BK < p.K) load_tile(k0 + BK);
-        bf16x8 a[2][3];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(&As[q][a_rd[i]]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            bf16x8 b[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) b[q] = *reinterpret_cast<const bf16x8*>(&Bs[q][b_rd + j * 1024]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[2], acc[i][j], 0, 0, 0);      // small terms first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[0], acc[i][j], 0, 0, 0);
-            }
-        }
+        if (k0 + BK < k_end) load_tile(k0 + BK);
+        bx3_mma(acc, As, Bs, a_rd, b_rd);
         __syncthreads();
     }
-
-    // epilogue: MFMA C layout col = lane&15, row = (lane>>4)*4 + r; columns through the B row permutation
-    float* base = p.C.base + bz * p.c_bs;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + mb + 16 * i + 4 * lq + r;
-            if (row >= p.M) continue;
-            float* crow = base + out_row_off(p.C, row);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int col = n0 + 64 * q + 4 * li;
-                if (p.c_vec4) {
-                    if (col < p.N)
-                        *reinterpret_cast<float4*>(crow + minor_off(p.C.Dseg, p.C.Sseg, col)) =
-                            make_float4(gemm_epilogue(acc[i][4 * q][r], p.epilogue), gemm_epilogue(acc[i][4 * q + 1][r], p.epilogue),
-                                        gemm_epilogue(acc[i][4 * q + 2][r], p.epilogue), gemm_epilogue(acc[i][4 * q + 3][r], p.epilogue));
-                } else {
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        if (col + jj < p.N) crow[minor_off(p.C.Dseg, p.C.Sseg, col + jj)] = gemm_epilogue(acc[i][4 * q + jj][r], p.epilogue);
-                }
-            }
-            const int col = n0 + 192 + li;
-            if (col < p.N) crow[minor_off(p.C.Dseg, p.C.Sseg, col)] = gemm_epilogue(acc[i][12][r], p.epilogue);
-        }
+    OutputDesc C;
+    C.base = nullptr; C.scatter = nullptr; C.S1 = p.N; C.S2 = 0; C.Sseg = 0; C.P = 0x7fffffff; C.Dseg = 0x7fffffff;
+    bx3_store(acc, C, p.partial + static_cast<int64_t>(tile.z) * p.M * p.N, p.M, p.N, m0, n0, mb, li, lq, GEMM_EPI_NONE, p.c_vec4);
 }
 
 // planes[q][r][k] = q-th bf16 term of src[r][k] (row stride ld), k < Kp zero padded; one thread per 8 k values.
@@ -264,6 +429,52 @@ int gemm_bx3_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, cons
     return RECON_OK;
 }
 
+bool bx3_kmajor_supported(const float* A, int64_t lda, int64_t a_bs, const float* B, int64_t ldb, int64_t b_bs, int32_t M, int32_t N) {
+    if ((M & 3) || (N & 3) || M < 4 || N < 4 || (lda & 3) || (ldb & 3) || (a_bs & 3) || (b_bs & 3)) return false;
+    return !(reinterpret_cast<uintptr_t>(A) & 15) && !(reinterpret_cast<uintptr_t>(B) & 15);
+}
+
+// split-K choice of the k-major product: fill the 512 resident workgroups once, >= 4 K tiles per split
+int bx3_kmajor_split_k(int32_t M, int32_t N, int32_t K, int32_t batch) {
+    const int64_t tiles = ceil_div64(M, BM) * ceil_div64(N, BN) * (batch > 0 ? batch : 1);
+    int64_t s = 512 / (tiles > 0 ? tiles : 1);
+    const int64_t max_s = K / (4 * BK) > 0 ? K / (4 * BK) : 1;
+    if (s > max_s) s = max_s;
+    if (s > 64) s = 64;
+    return static_cast<int>(s < 1 ? 1 : s);
+}
+
+// partial[batch][split][M][N] = A_slice^T . B_slice  with A = [K][M] (row stride lda), B = [K][N] (row stride ldb)
+int gemm_bx3_kmajor_batched(int32_t M, int32_t N, int32_t K, const float* A, int64_t lda, int64_t a_bs, const float* B, int64_t ldb,
+                            int64_t b_bs, int32_t batch, int32_t split_k, float* partial, hipStream_t st) {
+    if (M < 0 || N < 0 || K < 0 || batch < 0 || split_k < 1) return RECON_ERR_INVALID;
+    if (M == 0 || N == 0 || batch == 0) return RECON_OK;
+    if (!A || !B || !partial) return RECON_ERR_INVALID;
+    if (!bx3_kmajor_supported(A, lda, a_bs, B, ldb, b_bs, M, N) || (reinterpret_cast<uintptr_t>(partial) & 15)) return RECON_ERR_UNSUPPORTED;
+    Bx3KmArgs a;
+    a.A = A; a.B = B; a.lda = lda; a.ldb = ldb; a.a_bs = a_bs; a.b_bs = b_bs; a.partial = partial;
+    a.M = M; a.N = N; a.K = K;
+    int64_t kps = ceil_div64(K > 0 ? K : 1, split_k);
+    kps = ceil_div64(kps, BK) * BK;
+    a.k_per_split = static_cast<int32_t>(kps);
+    a.nsplit = static_cast<int32_t>(ceil_div64(K > 0 ? K : 1, kps));
+    if (a.nsplit != split_k) return RECON_ERR_INVALID;                // callers size `partial` with the same rounding (bx3_kmajor_splits)
+    a.c_vec4 = 1;
+    if (static_cast<int64_t>(batch) * split_k > 65535) return RECON_ERR_UNSUPPORTED;
+    const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, BM)), static_cast<unsigned>(batch * split_k));
+    hipLaunchKernelGGL(k_gemm_bx3_kmajor, grid, dim3(NT), 0, st, a);
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+
+// number of splits actually used for a requested split count (K tiles of 32 per split, rounded up)
+int bx3_kmajor_splits(int32_t K, int32_t split_k) {
+    if (split_k < 1) split_k = 1;
+    int64_t kps = ceil_div64(K > 0 ? K : 1, split_k);
+    kps = ceil_div64(kps, BK) * BK;
+    return static_cast<int>(ceil_div64(K > 0 ? K : 1, kps));
+}
+
 }  // namespace recon
 
 // Stand-alone entry (tests, tools/gemm_bench.py): C[M,N] = A[M,K] . B[N,K]^T with B split into `workspace`.
@@ -285,4 +496,26 @@ extern "C" int recon_sgemm_bx3(int32_t M, int32_t N, int32_t K, const float* A, 
     int rc = bx3_split_planes(B, ldb, 0, false, N, K, 1, workspace, st);
     if (rc != RECON_OK) return rc;
     return gemm_bx3_batched(M, N, K, Ad, workspace, plain_output(C_, ldc), bt, st);
+}
+
+// C[M,N] = A^T . B for k-major operands A = [K][M], B = [K][N] (the weight-gradient form), same accuracy.
+extern "C" size_t recon_sgemm_bx3_tn_workspace_bytes(int32_t M, int32_t N, int32_t K) {
+    using namespace recon;
+    if (M <= 0 || N <= 0 || K <= 0) return 16;
+    const int sk = bx3_kmajor_splits(K, bx3_kmajor_split_k(M, N, K, 1));
+    return static_cast<size_t>(sk) * M * N * sizeof(float) + 16;
+}
+
+extern "C" int recon_sgemm_bx3_tn(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb, float* C_,
+                                  int32_t ldc, void* workspace, recon_stream_t stream) {
+    using namespace recon;
+    if (M < 0 || N < 0 || K < 0) return RECON_ERR_INVALID;
+    if (M == 0 || N == 0) return RECON_OK;
+    if (!A || !B || !C_ || !workspace) return RECON_ERR_INVALID;
+    hipStream_t st = as_stream(stream);
+    if (!bx3_kmajor_supported(A, lda, 0, B, ldb, 0, M, N)) return RECON_ERR_UNSUPPORTED;
+    const int sk = bx3_kmajor_splits(K, bx3_kmajor_split_k(M, N, K, 1));
+    int rc = gemm_bx3_kmajor_batched(M, N, K, A, lda, 0, B, ldb, 0, 1, sk, static_cast<float*>(workspace), st);
+    if (rc != RECON_OK) return rc;
+    return splitk_reduce(static_cast<const float*>(workspace), sk, M, N, plain_output(C_, ldc), 0, 1, GEMM_EPI_NONE, false, st);
 }

@@ -523,6 +523,22 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
     return RECON_OK;
 }
 
+int splitk_reduce(const float* partial, int32_t splits, int32_t M, int32_t N, const OutputDesc& C, int64_t c_bs, int32_t batch,
+                  int32_t epilogue, bool transpose, hipStream_t st) {
+    if (!partial || !C.base || splits < 1 || M < 0 || N < 0 || batch < 0) return RECON_ERR_INVALID;
+    if (M == 0 || N == 0 || batch == 0) return RECON_OK;
+    if (transpose) {
+        hipLaunchKernelGGL(k_splitk_reduce_t, dim3(static_cast<unsigned>(ceil_div64(N, 32)), static_cast<unsigned>(ceil_div64(M, 32)),
+                           static_cast<unsigned>(batch)), dim3(256), 0, st, partial, splits, M, N, C, c_bs, epilogue);
+    } else {
+        const int64_t MN = static_cast<int64_t>(M) * N;
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(static_cast<unsigned>(ceil_div64(MN, 256)), static_cast<unsigned>(batch)), dim3(256), 0,
+                           st, partial, splits, M, N, C, c_bs, epilogue);
+    }
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+
 int gemm_f32(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool a_k_minor, const OperandDesc& B, bool b_k_minor,
              const OutputDesc& C, int32_t split_k, float* partial, hipStream_t st) {
     GemmBatch bt;

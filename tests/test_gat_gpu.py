@@ -96,6 +96,26 @@ def test_sgemm_bx3(M, N, K):
     assert err.max() <= 4.0 * (f32 - ref).abs().max() + 1e-12
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 208, 64), (600, 200, 8192), (36, 204, 1000), (260, 24, 77), (4, 420, 33)])
+def test_sgemm_bx3_tn(M, N, K):
+    """The k-major (weight-gradient) form of the split-precision GEMM: C = A^T B, A [K,M], B [K,N]."""
+    from recon_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(K, M, generator=g) * torch.exp(2.0 * torch.randn(1, M, generator=g))
+    B = torch.randn(K, N, generator=g)
+    Ad, Bd = A.to(dev()), B.to(dev())
+    Cd = torch.full((M, N), float("nan"), device=dev())
+    L = _lib.lib()
+    ws = torch.empty(L.recon_sgemm_bx3_tn_workspace_bytes(M, N, K), dtype=torch.uint8, device=dev())
+    rc = L.recon_sgemm_bx3_tn(M, N, K, Ad.data_ptr(), M, Bd.data_ptr(), N, Cd.data_ptr(), N, ws.data_ptr(), _lib.current_stream())
+    assert rc == 0
+    ref = A.double().t() @ B.double()
+    bound = (A.double().abs().t() @ B.double().abs()) * (2.0 ** -20) + 1e-30
+    err = (Cd.cpu().double() - ref).abs()
+    assert torch.isfinite(Cd).all()
+    assert (err <= bound).all(), float((err / bound).max())
+
+
 # ------------------------------------------------------------------------------- G1-G3
 @pytest.mark.parametrize("name", ["spmm1_o1", "spmm1_oD"])
 def test_spmm_golden(name):
