@@ -197,7 +197,11 @@ typedef struct {
     float* g_edge_embed;        /* [E,R] original edge order, or NULL                                 */
     float* g_a;                 /* [H,D,2F+R] or NULL (then g_a_2 must be NULL too)                    */
     float* g_a_2;               /* [H,D]      or NULL                                                 */
+    void* gh_split;             /* recon_gat_atp_bwd_split_bytes() bytes, workspace: bfloat16 term planes of g_h for  *
+                                 * the split-precision weight-gradient GEMM; NULL (or fwd.a_split NULL) = fp32 MFMA  */
 } recon_gat_atp_bwd_args;
+
+size_t recon_gat_atp_bwd_split_bytes(int32_t N, int32_t D, int32_t H);
 
 size_t recon_gat_atp_bwd_partial_floats(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H);
 size_t recon_gat_atp_bwd_partial2_floats(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H);
@@ -309,7 +313,8 @@ size_t recon_sgemm_bx3_workspace_bytes(int32_t N, int32_t K);
 int recon_sgemm_bx3(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                     float* C, int32_t ldc, void* workspace, recon_stream_t stream);
 /* C[M,N] = A^T * B for k-major operands A[K,M], B[K,N] (the weight-gradient form g_a^T = V^T g_h; split-K with a
- * fixed-order second pass; both operands split on the fly).  Requires M, N, lda, ldb multiples of 4. */
+ * fixed-order second pass; A is split on the fly, B into `workspace` first).  Requires M, lda multiples of 4 and
+ * N a multiple of 8 (RECON_ERR_UNSUPPORTED otherwise). */
 size_t recon_sgemm_bx3_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
 int recon_sgemm_bx3_tn(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                        float* C, int32_t ldc, void* workspace, recon_stream_t stream);

@@ -49,7 +49,8 @@ class GatAtpArgs(C.Structure):
 class GatAtpBwdArgs(C.Structure):
     _fields_ = [("fwd", GatAtpArgs), ("grad_out", c_f32p), ("ld_gout", C.c_int32), ("g_h", c_f32p), ("g_V", c_f32p),
                 ("g_sigma", c_f32p), ("Gxs", c_f32p), ("gxd", c_f32p), ("Gs", c_f32p), ("g_u", c_f32p), ("q", c_f32p),
-                ("partial", c_f32p), ("partial2", c_f32p), ("g_x", c_f32p), ("g_edge_embed", c_f32p), ("g_a", c_f32p), ("g_a_2", c_f32p)]
+                ("partial", c_f32p), ("partial2", c_f32p), ("g_x", c_f32p), ("g_edge_embed", c_f32p), ("g_a", c_f32p), ("g_a_2", c_f32p),
+                ("gh_split", C.c_void_p)]
 
 
 class PropArgs(C.Structure):
@@ -111,6 +112,7 @@ SYMBOLS = [
     ("recon_sgemm", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32,
                               c_f32p, C.c_int32, C.c_void_p]),
     ("recon_gat_atp_split_bytes", C.c_size_t, [C.c_int32] * 4),
+    ("recon_gat_atp_bwd_split_bytes", C.c_size_t, [C.c_int32] * 3),
     ("recon_sgemm_bx3_workspace_bytes", C.c_size_t, [C.c_int32, C.c_int32]),
     ("recon_sgemm_bx3", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32,
                                   C.c_void_p, C.c_void_p]),

@@ -88,7 +88,9 @@ __global__ void __launch_bounds__(256) k_score_vec_bwd(const float* __restrict__
 // h is recovered from y = elu(h): y > 0 ? y : log1p(y).
 __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy, int32_t ld_gy, const float* __restrict__ y,
                                                     int32_t ld_y, int32_t N, int32_t H, int32_t D, int32_t concat,
-                                                    float* __restrict__ gh, float* __restrict__ q) {
+                                                    float* __restrict__ gh, float* __restrict__ q, uint16_t* __restrict__ ghp,
+                                                    int64_t ld_p, int64_t plane_p) {
+    // ghp (optional): the three bfloat16 term planes [3][N][ld_p] of g_h for the split-precision weight-gradient GEMM
     constexpr int IPW = 4;                                               // (node, head) rows per wave, loads batched
     const int lane = threadIdx.x & 63;
     const int item0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * IPW;      // N*H < 2^31 (checked by the host)
@@ -123,6 +125,24 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
             const float tot = group_sum<64>(part);
             if (it < total) {
                 if (gh && c < D) *reinterpret_cast<float4*>(gh + static_cast<int64_t>(it) * D + c) = make_float4(o[0], o[1], o[2], o[3]);
+                if (ghp && c < D) {
+                    const int node = it / H, h = it % H;
+                    uint16_t* dst = ghp + static_cast<int64_t>(node) * ld_p + h * D + c;
+                    float x[4] = {o[0], o[1], o[2], o[3]};
+#pragma unroll
+                    for (int pq = 0; pq < 3; ++pq) {
+                        uint32_t w[2];
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const __bf16 b0 = static_cast<__bf16>(x[2 * hh]), b1 = static_cast<__bf16>(x[2 * hh + 1]);
+                            const uint32_t u0 = __builtin_bit_cast(uint16_t, b0), u1 = __builtin_bit_cast(uint16_t, b1);
+                            w[hh] = u0 | (u1 << 16);
+                            x[2 * hh] -= __builtin_bit_cast(float, u0 << 16);
+                            x[2 * hh + 1] -= __builtin_bit_cast(float, u1 << 16);
+                        }
+                        *reinterpret_cast<uint2*>(dst + pq * plane_p) = make_uint2(w[0], w[1]);
+                    }
+                }
                 if (lane == 0) q[it] = tot;
             }
         }
@@ -837,6 +857,11 @@ extern "C" int recon_gat_atp_fwd(const recon_graph* g, const recon_gat_atp_args*
     return recon_gat_atp_project(g, a, stream);
 }
 
+extern "C" size_t recon_gat_atp_bwd_split_bytes(int32_t N, int32_t D, int32_t H) {
+    if (N <= 0 || D <= 0 || H <= 0) return 256;
+    return align_up(static_cast<size_t>(3) * N * bx3_kp(H * D) * 2, 256);
+}
+
 extern "C" size_t recon_gat_atp_bwd_partial_floats(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H) {
     const int64_t W = 2LL * F + R;
     int s1 = gemm_pick_split_k(static_cast<int32_t>(W), D, N, H);
@@ -885,9 +910,14 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
     // (0) through the ELU, and q = g_h . h per (node, head)
     const float* gh = b->grad_out;
     int32_t ld_gh = b->ld_gout;
+    // bf16 term planes of g_h [3][N][kp(HD)] for the split-precision weight-gradient GEMM (written by the same pass)
+    const int64_t ld_ghp = bx3_kp(static_cast<int32_t>(HD));
+    const bool gh_planes = b->gh_split && a->a_split && !(reinterpret_cast<uintptr_t>(b->gh_split) & 15) && (D % 8) == 0 && D <= 256 &&
+                           ((b->ld_gout | a->ld_out) & 3) == 0;
+    uint16_t* ghp = gh_planes ? static_cast<uint16_t*>(b->gh_split) : nullptr;
     if (phases & RECON_ATP_BWD_PREPARE)
     hipLaunchKernelGGL(k_elu_grad_q, dim3(static_cast<unsigned>(ceil_div64(1LL * N * H, 16))), dim3(256), 0, st, b->grad_out, b->ld_gout, a->out,
-                       a->ld_out, N, H, D, a->concat, a->concat ? b->g_h : nullptr, b->q);
+                       a->ld_out, N, H, D, a->concat, a->concat ? b->g_h : nullptr, b->q, ghp, ld_ghp, static_cast<int64_t>(N) * ld_ghp);
     if (a->concat) { gh = b->g_h; ld_gh = static_cast<int32_t>(HD); }
     GemmBatch bt;
     bt.batch = H; bt.epilogue = 0;
@@ -950,9 +980,9 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
             GemmBatch bw = bt;
             bw.a_bs = W; bw.b_bs = D; bw.c_bs = static_cast<int64_t>(D) * W; bw.c_transpose = 1;
             const int64_t ldv = static_cast<int64_t>(H) * W;
-            if (a->a_split && bx3_kmajor_supported(a->V, ldv, W, gh, ld_gh, D, W, D)) {       // split-precision MFMA, both operands k-major
+            if (gh_planes && bx3_kmajor_supported(a->V, ldv, W, ld_ghp, D, W, D)) {           // split-precision MFMA, both operands k-major
                 const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));
-                rc = gemm_bx3_kmajor_batched(W, D, N, a->V, ldv, W, gh, ld_gh, D, H, sk, b->partial, st);
+                rc = gemm_bx3_kmajor_batched(W, D, N, a->V, ldv, W, b->gh_split, ld_ghp, static_cast<int64_t>(N) * ld_ghp, D, H, sk, b->partial, st);
                 if (rc == RECON_OK) rc = splitk_reduce(b->partial, sk, W, D, C, bw.c_bs, H, 0, true, st);
             } else {
                 const int sk = gemm_pick_split_k(W, D, N, H);

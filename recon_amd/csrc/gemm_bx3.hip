@@ -194,9 +194,9 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_bx3(const Bx3Args p) {
 
     float av[2][8];
     bf16x8 af[2][3];
-    // The A loads are inline asm with one hand-placed s_waitcnt: as ordinary loads next to an LDS-DMA in flight the
-    // compiler waits vmcnt(0) at their first use AND turns the guarded addresses into branches, which serialises
-    // the tile.  Lanes past K read the start of their row instead and are zeroed when the tile is split.
+    // The A loads are branch free (a guarded load gets its own basic block and the join serialises the tile): lanes
+    // past K read the start of their row instead and are zeroed when the tile is split.  They are ordinary loads —
+    // inline-asm loads would let the register allocator reuse the destination registers while the data is in flight.
     bool a_ok[2];
     f32x4 araw[2][2];
     auto load_a = [&](int k0) {
@@ -207,12 +207,11 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_bx3(const Bx3Args p) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int off = -8 * lq + ((k0 + 4 * h + 8 * lq) & -static_cast<int>(a_ok[h]));
-                const float* q = aptr[i] + off;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(araw[i][h]) : "v"(q));
+                const float4 v = *reinterpret_cast<const float4*>(aptr[i] + off);
+                araw[i][h] = f32x4{v.x, v.y, v.z, v.w};
             }
     };
-    auto wait_a = [&]() {                                             // also drains the DMA of the same tile (needed before the barrier anyway)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(araw[0][0]), "+v"(araw[0][1]), "+v"(araw[1][0]), "+v"(araw[1][1]));
+    auto wait_a = [&]() {                                             // first use: the compiler's wait also drains the DMA of the same tile
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -238,7 +237,9 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_bx3(const Bx3Args p) {
     for (int k0 = 0; k0 < p.K; k0 += BK) {
         if (k0 + BK < p.K) dma_b(k0 + BK, buf ^ 1);
         load_a(k0 + BK);                                              // unconditional (past K every lane re-reads its row start): no
-        bx3_mma_reg(acc, af, Bs[buf], b_rd);                          // control-flow join may sit between a load and its use
+        __builtin_amdgcn_sched_barrier(0);                            // control-flow join may sit between a load and its use, and
+        bx3_mma_reg(acc, af, Bs[buf], b_rd);                          // the first use (with its s_waitcnt) stays behind the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
         split_a();
         __syncthreads();
         buf ^= 1;
@@ -246,40 +247,79 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_bx3(const Bx3Args p) {
     bx3_store(acc, p.C, p.C.base + bz * p.c_bs, p.M, p.N, m0, n0, mb, li, lq, p.epilogue, p.c_vec4);
 }
 
-// The same product for k-MAJOR operands: A is [K][M] and B is [K][N] in memory (m / n contiguous), both fp32 and both
-// split on the fly — the weight gradient g_a^T = V^T g_h, whose K is the node dimension.  A thread loads a 4(k) x 4(m)
-// block (four float4), transposes it in registers and writes, per m, the four consecutive k values of each term plane
-// as one ds_write_b64 into the same k-contiguous LDS image as above, so the MFMA loop is identical.  Split-K: every
-// (batch, split) writes its tile to partial[z][M][N]; the caller reduces (and here transposes) in a second pass.
+// The same product for k-MAJOR operands — the weight gradient g_a^T = V^T g_h, whose K is the node dimension:
+//   A  fp32 [K][M] (m contiguous), split on the fly;   B  pre-split bf16 planes [3][K][ldb] (n contiguous).
+// Both tiles are staged through registers into ROW-MAJOR LDS images [k][m] / [k][n] exactly as they lie in memory
+// (A: four float4 -> 3 x ds_write_b64 each; B: ten 16-byte copies), and the MFMA fragments — 8 consecutive k for one
+// m — come out of LDS through the transposing read ds_read_b64_tr_b16 (16 lanes read a [4 k][16 m] block, lane i
+// receives column i), two reads per fragment.  Bank layout: A rows are 256 B = 8 chunks of 32 B, chunk index XORed
+// with (k&3 | (k>>3&1)<<2); B rows are 416 B = 26 slots of 16 B, rotated by 8 slots when k & 8 — in both images the
+// 8 rows one transposing read touches per 32 lanes land on disjoint bank groups.
+// Split-K: every (batch, split) writes its tile to partial[z][M][N]; the caller reduces (and here transposes).
 struct Bx3KmArgs {
-    const float* A; const float* B;
-    int64_t lda, ldb, a_bs, b_bs;
+    const float* A; const __bf16* Bp;
+    int64_t lda, ldb, b_plane, a_bs, b_bs;
     float* partial;
-    int32_t M, N, K, k_per_split, nsplit, c_vec4;
+    int32_t M, N, K, k_per_split, nsplit;
 };
 
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using i16x4 = __attribute__((ext_vector_type(4))) short;
+constexpr int KA_PLANE = BK * 256, KB_PLANE = BK * 416;            // bytes per plane of the A / B image
+
+__device__ __forceinline__ int ka_h(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int off_lo, int off_hi) {
+    const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(base + off_lo));
+    const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(base + off_hi));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 __global__ void __launch_bounds__(NT, 2) k_gemm_bx3_kmajor(const Bx3KmArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char As[3][BM * 64];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[3][BN * 64];
-    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    __shared__ __attribute__((aligned(16))) unsigned char S[3 * KA_PLANE + 3 * KB_PLANE];      // A image | B image
+    unsigned char* const As = S;
+    unsigned char* const Bs = S + 3 * KA_PLANE;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const TileId tile = xcd_tile(1);
     const int m0 = tile.y * BM, n0 = tile.x * BN;
     const int bz = tile.z / p.nsplit, zs = tile.z % p.nsplit;
     const int k_begin = zs * p.k_per_split, k_end = min(p.K, k_begin + p.k_per_split);
 
-    // block (k quad kqd, m/n quad): A has 32 x 8 blocks = one per thread, B 52 x 8 = 416 blocks (threads < 160 take two)
-    const int kqd = t & 7;
-    const int a_mq = t >> 3;
-    const float* aptr = p.A + bz * p.a_bs + min(m0 + 4 * a_mq, p.M - 4);
-    int b_nq[2];
-    const float* bptr[2];
-    bool b_on[2];
+    // ---- A items: idx = t + 256 i -> (k = idx >> 5, m quad = idx & 31); one float4 each
+    const float* aptr[4];
+    int a_lds[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        b_nq[i] = (t >> 3) + 32 * i;
-        b_on[i] = b_nq[i] < BN / 4;
-        bptr[i] = p.B + bz * p.b_bs + min(n0 + 4 * b_nq[i], p.N - 4);
+    for (int i = 0; i < 4; ++i) {
+        const int idx = t + NT * i, k = idx >> 5, mq = idx & 31;
+        aptr[i] = p.A + bz * p.a_bs + min(m0 + 4 * mq, p.M - 4);
+        a_lds[i] = k * 256 + (((mq >> 2) ^ ka_h(k)) << 5) + ((mq & 3) << 3);
     }
+    // ---- B: LDS-DMA, no staging registers.  Piece pc = 4 i + wave (39 pieces of 64 slots: 13 per plane) lands lane-linear
+    //      at slot s = 64 (pc % 13) + lane of its plane = (k = s / 26, physical slot s % 26); the rotation of the image is
+    //      applied on the source side: the physical slot holds logical slot (phys - 8 [k & 8]) mod 26.
+    constexpr int KB_DMA = 10;
+    int b_goff[KB_DMA], b_k[KB_DMA];
+#pragma unroll
+    for (int i = 0; i < KB_DMA; ++i) {
+        const int pc = min(4 * i + wid, 38);
+        const int s = 64 * (pc % 13) + lane, k = s / 26, phys = s % 26;
+        int slot = phys - ((k & 8) ? 8 : 0);
+        if (slot < 0) slot += 26;
+        b_k[i] = k;
+        b_goff[i] = min(n0 + 8 * slot, p.N - 8);
+    }
+    const __bf16* bbase = p.Bp + bz * p.b_bs;
+    auto dma_b = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < KB_DMA; ++i)
+            if (4 * i + wid < 39) {                                       // wave-uniform
+                const int pc = 4 * i + wid;
+                const __bf16* q = bbase + (pc / 13) * p.b_plane + static_cast<int64_t>(min(k0 + b_k[i], k_end - 1)) * p.ldb + b_goff[i];
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(q),
+                                                 (__attribute__((address_space(3))) void*)(Bs + (pc / 13) * KB_PLANE + 1024 * (pc % 13)), 16, 0, 0);
+            }
+    };
 
     f32x4 acc[2][TN];
 #pragma unroll
@@ -287,74 +327,110 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_bx3_kmajor(const Bx3KmArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float av[4][4], bv[2][4][4];                                     // [k][m]
+    f32x4 araw[4];
+    bool a_ok[4];
+    // loads are branch free: rows past the split's K range re-read its last row (finite values); A's are zeroed at the split
     auto load_tile = [&](int k0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = k0 + 4 * kqd + r;
-            const bool ok = k < k_end;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) v = *reinterpret_cast<const float4*>(aptr + static_cast<int64_t>(k) * p.lda);
-            av[r][0] = v.x; av[r][1] = v.y; av[r][2] = v.z; av[r][3] = v.w;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok && b_on[i]) w = *reinterpret_cast<const float4*>(bptr[i] + static_cast<int64_t>(k) * p.ldb);
-                bv[i][r][0] = w.x; bv[i][r][1] = w.y; bv[i][r][2] = w.z; bv[i][r][3] = w.w;
-            }
-        }
-    };
-    // write the four k values of column j of a block as 3 x 8 bytes at LDS row `row`
-    auto put = [&](unsigned char* T, int plane_bytes, const float (&blk)[4][4], int j, int row) {
-        float x[4] = {blk[0][j], blk[1][j], blk[2][j], blk[3][j]};
-        const int off = lds_off(row, kqd >> 1) + ((kqd & 1) << 3);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            uint32_t w[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const __bf16 h0 = static_cast<__bf16>(x[2 * h]), h1 = static_cast<__bf16>(x[2 * h + 1]);
-                const uint32_t b0 = __builtin_bit_cast(uint16_t, h0), b1 = __builtin_bit_cast(uint16_t, h1);
-                w[h] = b0 | (b1 << 16);
-                if (q < 2) {
-                    x[2 * h] -= __builtin_bit_cast(float, b0 << 16);
-                    x[2 * h + 1] -= __builtin_bit_cast(float, b1 << 16);
-                }
-            }
-            *reinterpret_cast<uint2*>(T + q * plane_bytes + off) = make_uint2(w[0], w[1]);
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + ((t + NT * i) >> 5);
+            a_ok[i] = k < k_end;
+            const float4 v = *reinterpret_cast<const float4*>(aptr[i] + static_cast<int64_t>(min(k, k_end - 1)) * p.lda);
+            araw[i] = f32x4{v.x, v.y, v.z, v.w};
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) put(&As[0][0], BM * 64, av, j, 4 * a_mq + j);
+        for (int i = 0; i < 4; ++i) {
+            float x[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            if (b_on[i]) {
-                const int nq = b_nq[i];
+            for (int e = 0; e < 4; ++e) x[e] = a_ok[i] ? araw[i][e] : 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)                              // column 4nq+j -> LDS row of the tile that owns it
-                    put(&Bs[0][0], BN * 64, bv[i], j, nq < 48 ? 16 * (4 * (nq >> 4) + j) + (nq & 15) : 4 * nq + j);
+            for (int q = 0; q < 3; ++q) {
+                uint32_t w[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const __bf16 h0 = static_cast<__bf16>(x[2 * h]), h1 = static_cast<__bf16>(x[2 * h + 1]);
+                    const uint32_t b0 = __builtin_bit_cast(uint16_t, h0), b1 = __builtin_bit_cast(uint16_t, h1);
+                    w[h] = b0 | (b1 << 16);
+                    if (q < 2) {
+                        x[2 * h] -= __builtin_bit_cast(float, b0 << 16);
+                        x[2 * h + 1] -= __builtin_bit_cast(float, b1 << 16);
+                    }
+                }
+                *reinterpret_cast<uint2*>(As + q * KA_PLANE + a_lds[i]) = make_uint2(w[0], w[1]);
             }
+        }
     };
 
+    // ---- fragment addresses: lane (ip = lane & 15, g = lane >> 4); half hh covers k = 8 g + 4 hh + (ip >> 2)
     const int mb = wid * 32;
-    const int li = lane & 15, lq = lane >> 4;
-    int a_rd[2], b_rd;
+    const int ip = lane & 15, g = lane >> 4;
+    int a_off[2][2], b_row[2];
+    bool b_rot[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a_rd[i] = lds_off(mb + 16 * i + li, lq);
-    b_rd = lds_off(li, lq);
-
-    if (k_begin < k_end) load_tile(k_begin);
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        store_tile();
-        __syncthreads();
-        if (k0 + BK < k_end) load_tile(k0 + BK);
-        bx3_mma(acc, As, Bs, a_rd, b_rd);
-        __syncthreads();
+    for (int hh = 0; hh < 2; ++hh) {
+        const int k = 8 * g + 4 * hh + (ip >> 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a_off[i][hh] = k * 256 + (((2 * wid + i) ^ ka_h(k)) << 5) + ((ip & 3) << 3);
+        b_row[hh] = k * 416 + (((ip & 3) & 1) << 3);
+        b_rot[hh] = (k & 8) != 0;
     }
-    OutputDesc C;
-    C.base = nullptr; C.scatter = nullptr; C.S1 = p.N; C.S2 = 0; C.Sseg = 0; C.P = 0x7fffffff; C.Dseg = 0x7fffffff;
-    bx3_store(acc, C, p.partial + static_cast<int64_t>(tile.z) * p.M * p.N, p.M, p.N, m0, n0, mb, li, lq, GEMM_EPI_NONE, p.c_vec4);
+    auto b_off = [&](int j, int hh) {                                 // column tile j: slot 2 j + ((ip & 3) >> 1), rotated by 8 (mod 26) when k & 8
+        const int slot = 2 * j + ((ip & 3) >> 1);
+        int phys = slot + (b_rot[hh] ? 8 : 0);
+        if (phys >= 26) phys -= 26;
+        return b_row[hh] + phys * 16;
+    };
+    auto mma_tile = [&]() {
+        bf16x8 a[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[i][q] = tr_frag(As + q * KA_PLANE, a_off[i][0], a_off[i][1]);
+        bf16x8 b[2][2][3];                                                // column tile j+1 is read while the 12 MFMAs of tile j run ([.][0] only)
+        auto read_one = [&](int j, bf16x8 (&dst)[2][3]) {
+            const int o0 = b_off(j, 0), o1 = b_off(j, 1);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) dst[0][q] = tr_frag(Bs + q * KB_PLANE, o0, o1);
+        };
+        read_one(0, b[0]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (j + 1 < TN) read_one(j + 1, b[(j + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            bx3_products<1>(acc, a, b[j & 1], j);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // B has ONE LDS buffer: its DMA for tile t+1 can only start once every wave is done with tile t (second barrier);
+    // it then runs under the split/store of A, and the co-resident workgroup's MFMA phase covers what is left.
+    if (k_begin < k_end) { load_tile(k_begin); dma_b(k_begin); }
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        store_tile();                                                 // s_waitcnt vmcnt(0): A registers and the B DMA
+        __syncthreads();
+        load_tile(k0 + BK);                                           // past the range: clamped re-reads, never stored
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (k0 + BK < k_end) dma_b(k0 + BK);
+    }
+    // epilogue: MFMA C layout col = lane & 15, row = (lane >> 4) * 4 + r; plain column order in this kernel
+    float* base = p.partial + static_cast<int64_t>(tile.z) * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + mb + 16 * i + 4 * g + r;
+            if (row >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + 16 * j + ip;
+                if (col < p.N) base[static_cast<int64_t>(row) * p.N + col] = acc[i][j][r];
+            }
+        }
 }
 
 // planes[q][r][k] = q-th bf16 term of src[r][k] (row stride ld), k < Kp zero padded; one thread per 8 k values.
@@ -429,9 +505,9 @@ int gemm_bx3_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, cons
     return RECON_OK;
 }
 
-bool bx3_kmajor_supported(const float* A, int64_t lda, int64_t a_bs, const float* B, int64_t ldb, int64_t b_bs, int32_t M, int32_t N) {
-    if ((M & 3) || (N & 3) || M < 4 || N < 4 || (lda & 3) || (ldb & 3) || (a_bs & 3) || (b_bs & 3)) return false;
-    return !(reinterpret_cast<uintptr_t>(A) & 15) && !(reinterpret_cast<uintptr_t>(B) & 15);
+bool bx3_kmajor_supported(const float* A, int64_t lda, int64_t a_bs, int64_t ldb, int64_t b_bs, int32_t M, int32_t N) {
+    if ((M & 3) || (N & 7) || M < 4 || N < 8 || (lda & 3) || (a_bs & 3) || (ldb & 7) || (b_bs & 7)) return false;
+    return !(reinterpret_cast<uintptr_t>(A) & 15);
 }
 
 // split-K choice of the k-major product: fill the 512 resident workgroups once, >= 4 K tiles per split
@@ -444,22 +520,23 @@ int bx3_kmajor_split_k(int32_t M, int32_t N, int32_t K, int32_t batch) {
     return static_cast<int>(s < 1 ? 1 : s);
 }
 
-// partial[batch][split][M][N] = A_slice^T . B_slice  with A = [K][M] (row stride lda), B = [K][N] (row stride ldb)
-int gemm_bx3_kmajor_batched(int32_t M, int32_t N, int32_t K, const float* A, int64_t lda, int64_t a_bs, const float* B, int64_t ldb,
-                            int64_t b_bs, int32_t batch, int32_t split_k, float* partial, hipStream_t st) {
+// partial[batch][split][M][N] = A_slice^T . B_slice  with A = fp32 [K][M] (row stride lda), B = bf16 planes [3][K][ldb]
+// (plane stride b_plane elements); a_bs / b_bs = per-batch column offsets
+int gemm_bx3_kmajor_batched(int32_t M, int32_t N, int32_t K, const float* A, int64_t lda, int64_t a_bs, const void* Bplanes, int64_t ldb,
+                            int64_t b_plane, int64_t b_bs, int32_t batch, int32_t split_k, float* partial, hipStream_t st) {
     if (M < 0 || N < 0 || K < 0 || batch < 0 || split_k < 1) return RECON_ERR_INVALID;
     if (M == 0 || N == 0 || batch == 0) return RECON_OK;
-    if (!A || !B || !partial) return RECON_ERR_INVALID;
-    if (!bx3_kmajor_supported(A, lda, a_bs, B, ldb, b_bs, M, N) || (reinterpret_cast<uintptr_t>(partial) & 15)) return RECON_ERR_UNSUPPORTED;
+    if (!A || !Bplanes || !partial) return RECON_ERR_INVALID;
+    if (!bx3_kmajor_supported(A, lda, a_bs, ldb, b_bs, M, N) || (reinterpret_cast<uintptr_t>(Bplanes) & 15) || (b_plane & 7))
+        return RECON_ERR_UNSUPPORTED;
     Bx3KmArgs a;
-    a.A = A; a.B = B; a.lda = lda; a.ldb = ldb; a.a_bs = a_bs; a.b_bs = b_bs; a.partial = partial;
-    a.M = M; a.N = N; a.K = K;
+    a.A = A; a.Bp = static_cast<const __bf16*>(Bplanes); a.lda = lda; a.ldb = ldb; a.b_plane = b_plane; a.a_bs = a_bs; a.b_bs = b_bs;
+    a.partial = partial; a.M = M; a.N = N; a.K = K;
     int64_t kps = ceil_div64(K > 0 ? K : 1, split_k);
     kps = ceil_div64(kps, BK) * BK;
     a.k_per_split = static_cast<int32_t>(kps);
     a.nsplit = static_cast<int32_t>(ceil_div64(K > 0 ? K : 1, kps));
     if (a.nsplit != split_k) return RECON_ERR_INVALID;                // callers size `partial` with the same rounding (bx3_kmajor_splits)
-    a.c_vec4 = 1;
     if (static_cast<int64_t>(batch) * split_k > 65535) return RECON_ERR_UNSUPPORTED;
     const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, BM)), static_cast<unsigned>(batch * split_k));
     hipLaunchKernelGGL(k_gemm_bx3_kmajor, grid, dim3(NT), 0, st, a);
@@ -499,11 +576,13 @@ extern "C" int recon_sgemm_bx3(int32_t M, int32_t N, int32_t K, const float* A, 
 }
 
 // C[M,N] = A^T . B for k-major operands A = [K][M], B = [K][N] (the weight-gradient form), same accuracy.
+// workspace = bf16 planes of B ([3][K][kp(N)]) followed by the split-K partials.
+static size_t tn_planes_bytes(int32_t N, int32_t K) { return align_up(static_cast<size_t>(3) * K * recon::bx3_kp(N) * 2, 256); }
 extern "C" size_t recon_sgemm_bx3_tn_workspace_bytes(int32_t M, int32_t N, int32_t K) {
     using namespace recon;
-    if (M <= 0 || N <= 0 || K <= 0) return 16;
+    if (M <= 0 || N <= 0 || K <= 0) return 256;
     const int sk = bx3_kmajor_splits(K, bx3_kmajor_split_k(M, N, K, 1));
-    return static_cast<size_t>(sk) * M * N * sizeof(float) + 16;
+    return tn_planes_bytes(N, K) + static_cast<size_t>(sk) * M * N * sizeof(float) + 256;
 }
 
 extern "C" int recon_sgemm_bx3_tn(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb, float* C_,
@@ -511,11 +590,15 @@ extern "C" int recon_sgemm_bx3_tn(int32_t M, int32_t N, int32_t K, const float* 
     using namespace recon;
     if (M < 0 || N < 0 || K < 0) return RECON_ERR_INVALID;
     if (M == 0 || N == 0) return RECON_OK;
-    if (!A || !B || !C_ || !workspace) return RECON_ERR_INVALID;
+    if (!A || !B || !C_ || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 15)) return RECON_ERR_INVALID;
     hipStream_t st = as_stream(stream);
-    if (!bx3_kmajor_supported(A, lda, 0, B, ldb, 0, M, N)) return RECON_ERR_UNSUPPORTED;
-    const int sk = bx3_kmajor_splits(K, bx3_kmajor_split_k(M, N, K, 1));
-    int rc = gemm_bx3_kmajor_batched(M, N, K, A, lda, 0, B, ldb, 0, 1, sk, static_cast<float*>(workspace), st);
+    const int32_t Np = bx3_kp(N);
+    if (!bx3_kmajor_supported(A, lda, 0, Np, 0, M, N)) return RECON_ERR_UNSUPPORTED;
+    int rc = bx3_split_planes(B, ldb, 0, false, K, N, 1, workspace, st);             // rows = k, minor = n (zero padded to Np)
     if (rc != RECON_OK) return rc;
-    return splitk_reduce(static_cast<const float*>(workspace), sk, M, N, plain_output(C_, ldc), 0, 1, GEMM_EPI_NONE, false, st);
+    float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + tn_planes_bytes(N, K));
+    const int sk = bx3_kmajor_splits(K, bx3_kmajor_split_k(M, N, K, 1));
+    rc = gemm_bx3_kmajor_batched(M, N, K, A, lda, 0, workspace, Np, static_cast<int64_t>(K) * Np, 0, 1, sk, partial, st);
+    if (rc != RECON_OK) return rc;
+    return splitk_reduce(partial, sk, M, N, plain_output(C_, ldc), 0, 1, GEMM_EPI_NONE, false, st);
 }

@@ -143,13 +143,13 @@ int bx3_split_planes(const float* src, int64_t ld, int64_t src_bs, bool transpos
 bool bx3_supported(const OperandDesc& A, int32_t K, const GemmBatch& bt);
 int gemm_bx3_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, const void* planes, const OutputDesc& C,
                      const GemmBatch& bt, hipStream_t st);
-// k-major form (A = [K][M], B = [K][N], both fp32, both split on the fly): partial[batch][split][M][N]; reduce with
-// splitk_reduce (gemm_f32.hip).  split_k must be bx3_kmajor_splits(K, requested) (K tiles of 32 per split).
-bool bx3_kmajor_supported(const float* A, int64_t lda, int64_t a_bs, const float* B, int64_t ldb, int64_t b_bs, int32_t M, int32_t N);
+// k-major form (A = fp32 [K][M] split on the fly, B = bf16 planes [3][K][ldb], n contiguous): partial[batch][split][M][N];
+// reduce with splitk_reduce (gemm_f32.hip).  split_k must be bx3_kmajor_splits(K, requested) (K tiles of 32 per split).
+bool bx3_kmajor_supported(const float* A, int64_t lda, int64_t a_bs, int64_t ldb, int64_t b_bs, int32_t M, int32_t N);
 int bx3_kmajor_split_k(int32_t M, int32_t N, int32_t K, int32_t batch);
 int bx3_kmajor_splits(int32_t K, int32_t split_k);
-int gemm_bx3_kmajor_batched(int32_t M, int32_t N, int32_t K, const float* A, int64_t lda, int64_t a_bs, const float* B, int64_t ldb,
-                            int64_t b_bs, int32_t batch, int32_t split_k, float* partial, hipStream_t st);
+int gemm_bx3_kmajor_batched(int32_t M, int32_t N, int32_t K, const float* A, int64_t lda, int64_t a_bs, const void* Bplanes, int64_t ldb,
+                            int64_t b_plane, int64_t b_bs, int32_t batch, int32_t split_k, float* partial, hipStream_t st);
 // C = epilogue(sum over splits of partial[batch][split][M][N]) through C's addressing; transpose: element (m, n) -> C(n, m)
 int splitk_reduce(const float* partial, int32_t splits, int32_t M, int32_t N, const OutputDesc& C, int64_t c_bs, int32_t batch,
                   int32_t epilogue, bool transpose, hipStream_t st);

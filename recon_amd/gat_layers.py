@@ -301,10 +301,13 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         g_ee = torch.empty(E, R, **f32) if ne else None
         g_a = torch.empty(H, D, W, **f32) if (na or na2) else None
         g_a2 = torch.empty(H, D, **f32) if (na or na2) else None
+        gh_split = (torch.empty(L.recon_gat_atp_bwd_split_bytes(N, D, H), dtype=torch.uint8, device=dev)
+                    if (a_split is not None and g_a is not None and os.environ.get("RECON_GEMM_BX3_KM", "1") != "0") else None)
         fwd = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, ctx.alpha, ctx.concat, a_split)
         args = _lib.GatAtpBwdArgs(fwd, grad_out.data_ptr(), grad_out.shape[1], _lib.ptr(g_h), g_V.data_ptr(),
                                   _lib.ptr(g_sigma), _lib.ptr(Gxs), gxd.data_ptr(), Gs.data_ptr(), g_u.data_ptr(),
-                                  q.data_ptr(), partial.data_ptr(), partial2.data_ptr(), _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2))
+                                  q.data_ptr(), partial.data_ptr(), partial2.data_ptr(), _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2),
+                                  _lib.ptr(gh_split))
         with torch.cuda.device(dev):
             if _OVERLAP and g_a is not None:
                 # PREPARE -> { INPUTS on this stream , WEIGHTS (MFMA-bound GEMM) on a side stream } -> FINISH
