@@ -77,12 +77,12 @@ def main():
     from recon_amd.graph import prepare_graph
     from recon_amd.gat_layers import _fwd_args
     from recon_amd.dist import FlatGradBucket
-    from oracle import recon_oracle as O          # synthetic generator + cpu_baseline leg only
+    from recon_amd import synth
 
     B, n, e, F_, D, H = args.graphs, args.nodes, args.edges, args.feat, args.dim, args.heads
     R = F_
     N, E = B * n, B * e
-    x, edge, ee = O.synthetic_batched_graph(B, n, e, F_, R, seed=rank)       # this rank's own graphs
+    x, edge, ee = synth.synthetic_batched_graph(B, n, e, F_, R, seed=rank)   # this rank's own graphs
     torch.manual_seed(0)                                                      # identical parameters on every rank
     model = SpGAT(N, F_, D, R, dropout=0.0, alpha=0.2, nheads=H)
     head_params = [p for att in model.attentions for p in (att.a, att.a_2)]
@@ -222,6 +222,7 @@ def main():
         # ---- CPU baseline: the oracle issuing the reference's own ATen op sequence (sparse_coo_tensor ->
         # sparse.sum -> to_dense), all host cores, same workload, bounded to ~args.cpu_seconds.
         if world == 1 and not args.no_cpu_baseline:
+            from oracle import recon_oracle as O          # the checker, timed here as the baseline only
             heads_a = [cpu_state["attention_%d.a" % h].clone().requires_grad_(True) for h in range(H)]
             heads_a2 = [cpu_state["attention_%d.a_2" % h].clone().requires_grad_(True) for h in range(H)]
             xc, eec, Gc = x.clone().requires_grad_(True), ee.clone().requires_grad_(True), Gd.cpu()
@@ -255,6 +256,30 @@ def main():
                                                 "oracle with the reference's ATen op sequence, torch %d threads "
                                                 "(fastest of 4..64 on a %d-cpu host)" % (n_cpu, H, cores, ncpu),
                                       "ms_per_step": 1e3 * t_cpu}
+            # ---- stock PyTorch-ROCm eager on the SAME GPU: the same ATen op sequence with device tensors,
+            # i.e. what the unmodified reference would run as on this machine.  Reported, never the target.
+            try:
+                ga = [t.detach().to(dev).requires_grad_(True) for t in heads_a]
+                ga2 = [t.detach().to(dev).requires_grad_(True) for t in heads_a2]
+                xg, eeg = xd.detach().clone().requires_grad_(True), eed.detach().clone().requires_grad_(True)
+
+                def eager_step():
+                    outs = [O.gat_layer_forward(xg, edged, eeg, None, None, ga[h], ga2[h], 0.2, True, aten_sequence=True)
+                            for h in range(H)]
+                    torch.cat(outs, dim=1).backward(Gd)
+                eager_step()
+                torch.cuda.synchronize(dev)
+                t_e0 = time.perf_counter()
+                for _ in range(3):
+                    eager_step()
+                torch.cuda.synchronize(dev)
+                t_e = (time.perf_counter() - t_e0) / 3
+                result["eager_rocm_baseline"] = {"value": E / t_e, "unit": "edges/s", "ms_per_step": 1e3 * t_e, "kind": "port",
+                                                 "sample": "3 full cfg2 steps after 1 warm-up, the oracle's ATen op sequence "
+                                                           "(sparse_coo_tensor -> sparse.sum -> to_dense, %d heads in a Python "
+                                                           "loop) executed by PyTorch-ROCm eager on cuda:0" % H}
+            except Exception as exc:                                   # an op of the sequence unsupported by this build
+                result["eager_rocm_baseline"] = {"value": None, "error": repr(exc)[:200]}
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

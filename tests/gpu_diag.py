@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stage-by-stage diagnosis of the GAT HIP path on the GPU box (prints max errors per stage; never
-asserts).  Usage on the box:  python tools/gpu_diag.py"""
+asserts).  Usage on the box:  python tests/gpu_diag.py   (a checker script, not collected by pytest)"""
 import ctypes as C
 import os
 import sys

@@ -153,3 +153,28 @@ def test_fused_head_params_alias_the_per_head_parameters():
     m2.fused_head_params()
     m2.load_state_dict(sd)
     assert torch.equal(m2.fused_head_params()[0], a_new)
+
+
+def test_synthetic_generators_match_the_oracles():
+    """bench.py / tools use recon_amd.synth; the oracle keeps its own copy — same seeds, same tensors."""
+    from recon_amd import synth
+    from oracle import recon_oracle as O
+    a = synth.synthetic_batched_graph(5, 7, 11, 6, 4, seed=3)
+    b = O.synthetic_batched_graph(5, 7, 11, 6, 4, seed=3)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    assert torch.equal(synth.xavier_normal((6, 10), 1.414, g1), O.xavier_normal((6, 10), 1.414, g2))
+
+
+def test_only_the_allowed_places_touch_the_oracle():
+    """oracle/ is test infrastructure: outside tests/ only __graft_entry__.smoke() and bench.py's baseline leg use it."""
+    offenders = []
+    for sub in ("recon_amd", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(dirpath, f)).read(), re.M):
+                    offenders.append(os.path.join(sub, f))
+    assert offenders == []
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert len(re.findall(r"from oracle import", bench)) == 1 and "not args.no_cpu_baseline" in bench

@@ -3,7 +3,7 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import recon_oracle as O
+from recon_amd import synth as O
 from recon_amd import gat_layers
 from recon_amd.graph import prepare_graph
 

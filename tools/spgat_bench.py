@@ -3,7 +3,7 @@
 import json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import recon_oracle as O
+from recon_amd import synth as O
 from recon_amd.models import SpGAT
 from recon_amd.gat_layers import gather_rows
 
