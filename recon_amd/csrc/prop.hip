@@ -371,13 +371,15 @@ __global__ void __launch_bounds__(1024) k_propagate_bwd_hop(const PropBwdK p) {
     const int pitch = p.pitch, S = p.S, CC = p.CC;
     float* X = lds;                                       // H^l, later H^l-1
     float* Y = lds + static_cast<int64_t>(CC) * pitch;    // grad wrt H^l -> grad wrt pre-activation
-    for (int idx = tid; idx < CC * pitch; idx += nthreads) {
-        const int cl = idx / pitch, s = idx % pitch;
+    // one wave per channel row, lanes along s: coalesced, no per-element division
+    for (int cl = wave; cl < CC; cl += nwaves) {
         const int c = c0 + cl;
-        const bool ok = c < p.C && s < S;
-        const int64_t g = (static_cast<int64_t>(b) * p.C + c) * S + s;
-        X[idx] = ok ? p.Hl[g] : 0.f;
-        Y[idx] = (ok && !p.first) ? p.gH[g] : 0.f;
+        const int64_t g0 = (static_cast<int64_t>(b) * p.C + c) * S;
+        for (int s = lane; s < pitch; s += 64) {
+            const bool ok = c < p.C && s < S;
+            X[cl * pitch + s] = ok ? p.Hl[g0 + s] : 0.f;
+            Y[cl * pitch + s] = (ok && !p.first) ? p.gH[g0 + s] : 0.f;
+        }
     }
     __syncthreads();
     // relation gradient: d(h[head]*h[tail])
@@ -395,18 +397,25 @@ __global__ void __launch_bounds__(1024) k_propagate_bwd_hop(const PropBwdK p) {
     __syncthreads();
     for (int idx = tid; idx < CC * pitch; idx += nthreads) Y[idx] *= act_bwd(X[idx], p.act);
     __syncthreads();
-    for (int idx = tid; idx < CC * pitch; idx += nthreads) {
-        const int cl = idx / pitch, s = idx % pitch;
+    for (int cl = wave; cl < CC; cl += nwaves) {
         const int c = c0 + cl;
-        X[idx] = (c < p.C && s < S) ? p.Hprev[b * p.hprev_bs + static_cast<int64_t>(c) * S + s] : 0.f;
+        const float* src = p.Hprev + b * p.hprev_bs + static_cast<int64_t>(c) * S;
+        for (int s = lane; s < pitch; s += 64) X[cl * pitch + s] = (c < p.C && s < S) ? src[s] : 0.f;
     }
     __syncthreads();
     const int li = lane & 15, lq = lane >> 4;
     const int NT = p.Sp >> 4;
     // (i) gA[s][t] = sum_c Y[c][s] * X[c][t]       (M = s, N = t, K = channel)
-    if (p.gA) {
+    // Work split.  (ii) gives column tile nt to wave nt (NT slabs x 4 x MT MFMAs); a tile of (i) costs CC/4 MFMAs, so NT
+    // tiles of (i) weigh exactly one column of (ii): the waves beyond NT take NT tiles of (i) each while the first NT
+    // waves run (ii), and whatever is left of (i) is dealt round-robin to everybody afterwards.  No barrier in between:
+    // both products only read X, Y and A.
+    const int wii = NT < nwaves ? NT : nwaves;                      // waves busy with (ii)
+    const int nfree = nwaves - wii;
+    const int tiles_a = p.gA ? min(NT * NT, nfree * NT) : 0;        // pass A: free waves only
+    auto ga_tile = [&](int tile) {
         float* gA = p.gA + static_cast<int64_t>(b) * S * S;
-        for (int tile = wave; tile < NT * NT; tile += nwaves) {
+        {
             const int ms = tile / NT, nt = tile % NT;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int kc = 0; kc < CC; kc += 16) {
@@ -425,7 +434,9 @@ __global__ void __launch_bounds__(1024) k_propagate_bwd_hop(const PropBwdK p) {
                 }
             }
         }
-    }
+    };
+    if (p.gA && wave >= wii)
+        for (int tile = wave - wii; tile < tiles_a; tile += nfree) ga_tile(tile);
     // (ii) gHprev[c][t] = sum_s Y[c][s] * A[s][t]    (M = channel, N = t, K = s)
     {
         const float* A = p.A + static_cast<int64_t>(b) * S * S;
@@ -465,6 +476,8 @@ __global__ void __launch_bounds__(1024) k_propagate_bwd_hop(const PropBwdK p) {
                 }
         }
     }
+    if (p.gA)
+        for (int tile = tiles_a + wave; tile < NT * NT; tile += nwaves) ga_tile(tile);      // pass B: the rest of (i), all waves
 }
 
 struct PropGeom { int CC, Sp, pitch, chunks, MT, fwd_waves; size_t lds, fwd_lds; };
@@ -631,7 +644,7 @@ extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t
         p.B = a->B; p.C = a->C; p.S = a->S; p.L = a->L; p.dd = a->dd; p.act = a->act;
         p.CC = g.CC; p.Sp = g.Sp; p.pitch = g.pitch; p.hop = l - 1; p.first = (l == a->L) ? 1 : 0; p.chunks = g.chunks;
         if (p.gA && g.chunks > 1) hipMemsetAsync(p.gA, 0, sizeof(float) * a->B * a->S * a->S, st);
-        RECON_DISPATCH_MT(g.MT, false, k_propagate_bwd_hop, grid, dim3(64 * g.fwd_waves), g.lds, st, p);
+        RECON_DISPATCH_MT(g.MT, false, k_propagate_bwd_hop, grid, dim3(1024), g.lds, st, p);
         RECON_CHECK_LAUNCH();
     }
     return RECON_OK;

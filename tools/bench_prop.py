@@ -47,6 +47,8 @@ def prop(B=1024, n=9, d=8, L=3):
             propagate([a.detach() for a in adjs], h0.detach(), "relu", head, tail)
 
     def fwd_bwd():
+        for t in Ts + [ident, h0]:
+            t.grad = None                                  # no accumulate kernels in the timed region
         a2 = [build_block_adjacency(t, ident, n) for t in Ts]
         out = propagate(a2, h0, "relu", head, tail)
         out.backward(G)
