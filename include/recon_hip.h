@@ -279,8 +279,12 @@ typedef struct {
     const float* bias;              /* [out] or NULL */
     float* support;                 /* [B,n,out]  x @ W */
     float* out;                     /* [B,n,out]  */
+    void* w_split;                  /* recon_gcn_split_bytes() bytes or NULL: bfloat16 term planes of W^T and W *
+                                     * (filled by recon_gcn_fwd, read again by recon_gcn_bwd); with it x @ W and *
+                                     * g_support @ W^T run on the split-precision GEMM (csrc/gemm_bx3.hip)       */
 } recon_gcn_args;
 
+size_t recon_gcn_split_bytes(int32_t in_features, int32_t out_features);
 int recon_gcn_fwd(const recon_gcn_args* args, recon_stream_t stream);
 
 typedef struct {

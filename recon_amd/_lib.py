@@ -67,7 +67,7 @@ class PropBwdArgs(C.Structure):
 class GcnArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("n", C.c_int32), ("in_features", C.c_int32), ("out_features", C.c_int32),
                 ("x", c_f32p), ("adj", c_f32p), ("weight", c_f32p), ("bias", c_f32p), ("support", c_f32p),
-                ("out", c_f32p)]
+                ("out", c_f32p), ("w_split", C.c_void_p)]
 
 
 class GcnBwdArgs(C.Structure):
@@ -106,6 +106,7 @@ SYMBOLS = [
     ("recon_propagate_bwd", C.c_int, [C.POINTER(PropBwdArgs), C.c_void_p]),
     ("recon_start_entity_embeddings", C.c_int, [c_f32p, c_i64p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
                                                 C.c_void_p]),
+    ("recon_gcn_split_bytes", C.c_size_t, [C.c_int32, C.c_int32]),
     ("recon_gcn_fwd", C.c_int, [C.POINTER(GcnArgs), C.c_void_p]),
     ("recon_gcn_bwd_partial_floats", C.c_size_t, [C.c_int32] * 4),
     ("recon_gcn_bwd", C.c_int, [C.POINTER(GcnBwdArgs), C.c_void_p]),

@@ -763,6 +763,12 @@ constexpr int kBiasBlocks = 1024;
 
 }  // namespace
 
+static size_t gcn_split_part(int32_t rows, int32_t K) { return align_up(static_cast<size_t>(3) * rows * bx3_kp(K) * 2, 256); }
+extern "C" size_t recon_gcn_split_bytes(int32_t in_features, int32_t out_features) {
+    if (in_features <= 0 || out_features <= 0) return 256;
+    return gcn_split_part(out_features, in_features) + gcn_split_part(in_features, out_features);
+}
+
 extern "C" int recon_gcn_fwd(const recon_gcn_args* a, recon_stream_t stream) {
     int rc = check_gcn(a);
     if (rc != RECON_OK) return rc;
@@ -770,8 +776,18 @@ extern "C" int recon_gcn_fwd(const recon_gcn_args* a, recon_stream_t stream) {
     hipStream_t st = as_stream(stream);
     const int32_t rows = a->B * a->n, I = a->in_features, O = a->out_features;
     // support = x @ W      (models/layers.py:58)
-    rc = gemm_f32(rows, O, I, plain_operand(a->x, I), true, plain_operand(a->weight, O), false, plain_output(a->support, O), 1,
-                  nullptr, st);
+    GemmBatch one;
+    one.batch = 1; one.a_bs = one.b_bs = one.c_bs = 0; one.epilogue = 0;
+    const OperandDesc X = plain_operand(a->x, I);
+    if (a->w_split && !(reinterpret_cast<uintptr_t>(a->w_split) & 15) && bx3_supported(X, I, one)) {
+        // bf16 term planes of W^T [3][O][kp(I)] (this product) and of W [3][I][kp(O)] (g_x in the backward)
+        char* ws = static_cast<char*>(a->w_split);
+        rc = bx3_split_planes(a->weight, O, 0, true, O, I, 1, ws, st);
+        if (rc == RECON_OK) rc = bx3_split_planes(a->weight, O, 0, false, I, O, 1, ws + gcn_split_part(O, I), st);
+        if (rc == RECON_OK) rc = gemm_bx3_batched(rows, O, I, X, ws, plain_output(a->support, O), one, st);
+    } else {
+        rc = gemm_f32(rows, O, I, X, true, plain_operand(a->weight, O), false, plain_output(a->support, O), 1, nullptr, st);
+    }
     if (rc != RECON_OK) return rc;
     // out = relu(adj @ support + bias)     (models/layers.py:59-63)
     dim3 grid(static_cast<unsigned>(ceil_div64(O, 64)), static_cast<unsigned>(a->B));
@@ -814,8 +830,14 @@ extern "C" int recon_gcn_bwd(const recon_gcn_bwd_args* b, recon_stream_t stream)
     RECON_CHECK_LAUNCH();
     // g_x = g_support @ W^T
     if (b->g_x) {
-        rc = gemm_f32(rows, I, O, plain_operand(b->g_support, O), true, plain_operand(a->weight, O), true, plain_output(b->g_x, I), 1,
-                      nullptr, st);
+        GemmBatch one;
+        one.batch = 1; one.a_bs = one.b_bs = one.c_bs = 0; one.epilogue = 0;
+        const OperandDesc G = plain_operand(b->g_support, O);
+        if (a->w_split && !(reinterpret_cast<uintptr_t>(a->w_split) & 15) && bx3_supported(plain_operand(a->x, I), I, one) &&
+            bx3_supported(G, O, one))                                  // same condition as the forward, which filled the planes
+            rc = gemm_bx3_batched(rows, I, O, G, static_cast<const char*>(a->w_split) + gcn_split_part(O, I), plain_output(b->g_x, I), one, st);
+        else
+            rc = gemm_f32(rows, I, O, G, true, plain_operand(a->weight, O), true, plain_output(b->g_x, I), 1, nullptr, st);
         if (rc != RECON_OK) return rc;
     }
     // g_W = x^T @ g_support   (split-K over the B*n rows, deterministic second pass)

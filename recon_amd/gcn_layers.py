@@ -8,6 +8,7 @@ Extension over the reference: `forward` also accepts a batch, input [B,n,in] wit
 (the reference's torch.mm only takes the 2-D single-graph form)."""
 import ctypes as C
 import math
+import os
 
 import torch
 from torch.nn.parameter import Parameter
@@ -40,17 +41,20 @@ class _GcnFunction(torch.autograd.Function):
         dev = x.device
         sup = torch.empty(B, n, O, dtype=torch.float32, device=dev)
         out = torch.empty(B, n, O, dtype=torch.float32, device=dev)
+        w_split = None
+        if os.environ.get("RECON_GEMM_BX3", "1") != "0":      # split-precision GEMMs (fp32-accurate, csrc/gemm_bx3.hip)
+            w_split = torch.empty(_lib.lib().recon_gcn_split_bytes(I, O), dtype=torch.uint8, device=dev)
         args = _lib.GcnArgs(B, n, I, O, x3.data_ptr(), adj3.data_ptr(), weight.data_ptr(), _lib.ptr(bias),
-                            sup.data_ptr(), out.data_ptr())
+                            sup.data_ptr(), out.data_ptr(), _lib.ptr(w_split))
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().recon_gcn_fwd(C.byref(args), _lib.current_stream()), "recon_gcn_fwd")
-        ctx.save_for_backward(x3, adj3, weight, bias, sup, out)
+        ctx.save_for_backward(x3, adj3, weight, bias, sup, out, w_split)
         ctx.shapes = (tuple(x.shape), tuple(adj.shape))
         return out.view(x.shape[:-1] + (O,))
 
     @staticmethod
     def backward(ctx, gout):
-        x3, adj3, weight, bias, sup, out = ctx.saved_tensors
+        x3, adj3, weight, bias, sup, out, w_split = ctx.saved_tensors
         B, n, I = x3.shape
         O = weight.shape[1]
         dev = gout.device
@@ -65,7 +69,7 @@ class _GcnFunction(torch.autograd.Function):
         g_w = torch.empty(I, O, **f32) if nw else None
         g_b = torch.empty(O, **f32) if (nb and bias is not None) else None
         fwd = _lib.GcnArgs(B, n, I, O, x3.data_ptr(), adj3.data_ptr(), weight.data_ptr(), _lib.ptr(bias), sup.data_ptr(),
-                           out.data_ptr())
+                           out.data_ptr(), _lib.ptr(w_split))
         args = _lib.GcnBwdArgs(fwd, gout.data_ptr(), g_sup.data_ptr(), partial.data_ptr(), _lib.ptr(g_x), _lib.ptr(g_adj),
                                _lib.ptr(g_w), _lib.ptr(g_b))
         with torch.cuda.device(dev):
