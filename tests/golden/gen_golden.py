@@ -327,6 +327,37 @@ def gpgnn_case(name, ref_models, n, d, per_batch_h0, L=3, B=50, salt=1):
     save(name, **arrays)
 
 
+def gpgnn_full_case(name, ref_models, style, n=3, d=2, L=3, B=50):
+    """N3: the whole reference GPGNN (real embeddings, LSTM, Linear layers): state_dict, inputs, logits and the
+    gradient of every trainable parameter for a fixed scalar."""
+    p = {"max_num_nodes": n, "embedding_dim": d, "layer_number": L, "projection_style": style,
+         "non-linear1": "relu", "non-linear": "tanh", "dropout1": 0.0, "position_emb": 3, "units1": 4,
+         "rnn1_layers": 1, "bidirectional": 1, "batch_size": B}
+    C = n * (n - 1)
+    emb = hashed_uniform((7, 5), 301, -0.5, 0.5).astype(np.float32)
+    emb[0] = 0.0
+    torch.manual_seed(11)
+    if style == "tie" and n != 9:
+        return                                                       # the reference's tied branch hard-codes 8 x 9 (models.py:188)
+    m = ref_models.GPGNN(p, emb, max_sent_len=4, n_out=3)
+    m.eval()
+    gs = torch.Generator().manual_seed(5)
+    sent = torch.randint(1, 7, (B, 4), generator=gs)
+    mark = torch.randint(0, 4, (B, C, 4), generator=gs)
+    out = m(sent, mark, None)
+    G = torch.from_numpy(hashed_uniform(tuple(out.shape), 302))
+    (out * G).sum().backward()
+    arrays = dict(n=np.int32(n), d=np.int32(d), L=np.int32(L), B=np.int32(B), style=np.array(style), emb=emb,
+                  sent=t2n(sent), mark=t2n(mark), out=t2n(out), G=t2n(G))
+    for k, v in m.state_dict().items():
+        if k not in ("head_indices", "tail_indices", "start_embedding"):      # regenerated by the constructor; [50,C,2d] int64 is bulky
+            arrays["sd." + k] = t2n(v)
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            arrays["g." + k] = t2n(v.grad)
+    save(name, **arrays)
+
+
 def gen_gpgnn():
     cwd = os.getcwd()
     os.chdir(REF)
@@ -341,6 +372,8 @@ def gen_gpgnn():
     assert ref_models.__file__.startswith(REF)
 
     # PROP-1/2: block adjacency + 3-hop propagation, shared h0 (GPGNN form) and per-batch h0 (RECON form)
+    gpgnn_full_case("gpgnn1_untied", ref_models, "untie")
+    gpgnn_full_case("gpgnn2_tied_n9", ref_models, "tie", n=9, d=1, L=2)
     gpgnn_case("prop_n4d2_shared", ref_models, 4, 2, per_batch_h0=False, salt=1)
     gpgnn_case("prop_n4d2_perbatch", ref_models, 4, 2, per_batch_h0=True, salt=2)
     gpgnn_case("prop_n9d8_shared", ref_models, 9, 8, per_batch_h0=False, salt=3)      # model_params.json sizes

@@ -178,3 +178,24 @@ def test_only_the_allowed_places_touch_the_oracle():
     assert offenders == []
     bench = open(os.path.join(ROOT, "bench.py")).read()
     assert len(re.findall(r"from oracle import", bench)) == 1 and "not args.no_cpu_baseline" in bench
+
+
+@pytest.mark.parametrize("name", ["gpgnn1_untied", "gpgnn2_tied_n9"])
+def test_gpgnn_state_dict_matches_reference(name):
+    """the reference GPGNN's checkpoint keys and shapes, so its state_dict loads unchanged."""
+    from recon_amd.gpgnn import GPGNN
+    g = load_golden(name)
+    p = {"max_num_nodes": int(g["n"]), "embedding_dim": int(g["d"]), "layer_number": int(g["L"]), "projection_style": str(g["style"]),
+         "non-linear1": "relu", "non-linear": "tanh", "dropout1": 0.0, "position_emb": 3, "units1": 4, "rnn1_layers": 1,
+         "bidirectional": 1, "batch_size": int(g["B"])}
+    m = GPGNN(p, g["emb"], max_sent_len=4, n_out=3)
+    ref = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    sd = m.state_dict()
+    regenerated = {"head_indices", "tail_indices", "start_embedding"}
+    assert set(sd.keys()) - regenerated == set(ref.keys())
+    for k, v in ref.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    n, d = int(g["n"]), int(g["d"])
+    assert tuple(sd["head_indices"].shape) == (50, n * (n - 1), 2 * d)          # bs = 50 baked in, models/models.py:138-142
+    missing, unexpected = m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ref.items()}, strict=False)
+    assert set(missing) == regenerated and not unexpected

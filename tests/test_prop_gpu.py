@@ -187,3 +187,23 @@ def test_propagation_full_size_properties():
     flat = h0p.view(4, C, S)
     expect = torch.gather(flat, 2, head.to(d_)[None].expand(4, -1, -1)) * torch.gather(flat, 2, tail.to(d_)[None].expand(4, -1, -1))
     close(o3, expect.repeat(1, 1, L), atol=1e-6, what="identity propagation")
+
+
+@pytest.mark.parametrize("name", ["gpgnn1_untied", "gpgnn2_tied_n9"])
+def test_gpgnn_model_golden(name):
+    """the reference GPGNN end to end (stock encoder + HIP block adjacency / propagation): logits and the
+    gradient of every trainable parameter against the reference's own outputs."""
+    from recon_amd.gpgnn import GPGNN
+    g = load_golden(name)
+    p = {"max_num_nodes": int(g["n"]), "embedding_dim": int(g["d"]), "layer_number": int(g["L"]), "projection_style": str(g["style"]),
+         "non-linear1": "relu", "non-linear": "tanh", "dropout1": 0.0, "position_emb": 3, "units1": 4, "rnn1_layers": 1,
+         "bidirectional": 1, "batch_size": int(g["B"])}
+    m = GPGNN(p, g["emb"], max_sent_len=4, n_out=3)
+    m.load_state_dict({k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("sd.")}, strict=False)
+    m.train().to(dev())                     # dropout is 0 in the fixture; MIOpen's LSTM backward needs training mode
+    out = m(torch.from_numpy(g["sent"]).to(dev()), torch.from_numpy(g["mark"]).to(dev()), None)
+    close(out, g["out"], atol=1e-4, what="gpgnn logits")
+    (out * torch.from_numpy(g["G"]).to(dev())).sum().backward()
+    for k, v in m.named_parameters():
+        if "g." + k in g:
+            close(v.grad, g["g." + k], atol=1e-4, rel_to_max=1e-4, what="grad " + k)
