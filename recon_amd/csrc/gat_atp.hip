@@ -171,11 +171,20 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
 // One wave per kRowsPerIter consecutive rows (their loads are issued together: the kernel is latency bound, one row
 // at a time it reached 1.3 TB/s); U staged in LDS once per block, so blocks are sized for >= 32 rows.
 constexpr int kRowsPerIter = 4;
+// Two independent jobs (node scores and edge scores) share ONE launch: blocks [0, nb0) run job 0, the rest job 1, so
+// the small node job does not leave the chip three quarters empty for its whole latency-bound duration.
+struct RowDotsJob { const float* X; const int32_t* gather; int32_t rows, K, F, off, NJ, nb; float* out; };
 template <int VEC>
-__global__ void __launch_bounds__(kBlock) k_row_dots(const float* __restrict__ X, const int32_t* __restrict__ gather, int32_t rows,
-                                                     int32_t K, const float* __restrict__ u, int32_t H, int32_t W, int32_t F,
-                                                     int32_t off, int32_t NJ, float* __restrict__ out) {
+__global__ void __launch_bounds__(kBlock) k_row_dots(const RowDotsJob j0, const RowDotsJob j1, const float* __restrict__ u, int32_t H,
+                                                     int32_t W) {
     extern __shared__ __attribute__((aligned(16))) float U[];     // [NJ][K]
+    const bool second = static_cast<int>(blockIdx.x) >= j0.nb;
+    const RowDotsJob& jb = second ? j1 : j0;
+    const float* __restrict__ X = jb.X;
+    const int32_t* __restrict__ gather = jb.gather;
+    float* __restrict__ out = jb.out;
+    const int rows = jb.rows, K = jb.K, F = jb.F, off = jb.off, NJ = jb.NJ;
+    const int bid = second ? blockIdx.x - j0.nb : blockIdx.x, nblocks = jb.nb;
     for (int j = 0; j < NJ; ++j) {
         const float* uj = u + static_cast<int64_t>(j % H) * W + (j / H) * F + off;
         for (int k = threadIdx.x; k < K; k += kBlock) U[j * K + k] = uj[k];
@@ -183,8 +192,8 @@ __global__ void __launch_bounds__(kBlock) k_row_dots(const float* __restrict__ X
     __syncthreads();
     constexpr int RB = kRowsPerIter;
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nwaves = gridDim.x * (kBlock / 64);
+    const int wave = bid * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = nblocks * (kBlock / 64);
     for (int row0 = wave * RB; row0 < rows; row0 += nwaves * RB) {
         const float* xr[RB];
 #pragma unroll
@@ -790,18 +799,17 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
         if (rc != RECON_OK) return rc;
     }
     {
-        const int nb = static_cast<int>(ceil_div64(N, 32) < 2048 ? ceil_div64(N, 32) : 2048);
-        const size_t lds = static_cast<size_t>(2) * H * F * sizeof(float);
+        RowDotsJob jn, je;
+        jn.X = a->x; jn.gather = nullptr; jn.rows = N; jn.K = F; jn.F = F; jn.off = 0; jn.NJ = 2 * H; jn.out = a->c_node;
+        jn.nb = static_cast<int>(ceil_div64(N, 16) < 2048 ? ceil_div64(N, 16) : 2048);
+        je.X = a->edge_embed; je.gather = g->eid; je.rows = E; je.K = R; je.F = 0; je.off = 2 * F; je.NJ = H; je.out = a->c_rel;
+        je.nb = E > 0 ? static_cast<int>(ceil_div64(E, 32) < 2048 ? ceil_div64(E, 32) : 2048) : 0;
+        const size_t lds_n = static_cast<size_t>(2) * H * F * sizeof(float), lds_e = static_cast<size_t>(H) * R * sizeof(float);
+        const size_t lds = lds_n > lds_e ? lds_n : lds_e;
         if (lds > 64 * 1024) return RECON_ERR_UNSUPPORTED;
-        if (s.vec == 4) hipLaunchKernelGGL((k_row_dots<4>), dim3(nb), dim3(kBlock), lds, st, a->x, nullptr, N, F, a->u, H, W, F, 0, 2 * H, a->c_node);
-        else hipLaunchKernelGGL((k_row_dots<2>), dim3(nb), dim3(kBlock), lds, st, a->x, nullptr, N, F, a->u, H, W, F, 0, 2 * H, a->c_node);
-    }
-    if (E > 0) {
-        const int nb = static_cast<int>(ceil_div64(E, 32) < 2048 ? ceil_div64(E, 32) : 2048);
-        const size_t lds = static_cast<size_t>(H) * R * sizeof(float);
-        if (lds > 64 * 1024) return RECON_ERR_UNSUPPORTED;
-        if (s.vec == 4) hipLaunchKernelGGL((k_row_dots<4>), dim3(nb), dim3(kBlock), lds, st, a->edge_embed, g->eid, E, R, a->u, H, W, 0, 2 * F, H, a->c_rel);
-        else hipLaunchKernelGGL((k_row_dots<2>), dim3(nb), dim3(kBlock), lds, st, a->edge_embed, g->eid, E, R, a->u, H, W, 0, 2 * F, H, a->c_rel);
+        const dim3 grid(static_cast<unsigned>(jn.nb + je.nb));
+        if (s.vec == 4) hipLaunchKernelGGL((k_row_dots<4>), grid, dim3(kBlock), lds, st, jn, je, a->u, H, W);
+        else hipLaunchKernelGGL((k_row_dots<2>), grid, dim3(kBlock), lds, st, jn, je, a->u, H, W);
     }
     RECON_CHECK_LAUNCH();
     return RECON_OK;
