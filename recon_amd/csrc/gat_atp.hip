@@ -598,15 +598,22 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_src(const AtpSrcK p) {
 // Tall-skinny transposed product with fixed-order reduction (replaces 128x128-tile GEMMs whose M is 8..32):
 //   out[j][c] = sum_r G[r*ldg + j] * X[row(r)*K + c],   j < NJ (<= 16), c < K,  row(r) = gather ? gather[r] : r
 // pass 1: block b sums its slice of rows into partial[b][j][c]; pass 2 adds the slices in order.
+// Up to two independent products per launch (blocks [0, j0.nb) run job 0, the rest job 1), like k_row_dots.
+struct SkinnyJob { const float* G; const float* X; const int32_t* gather; float* partial; int32_t ldg, nj, rows, K, rpb, nb; };
 template <int NJ>
-__global__ void __launch_bounds__(256) k_skinny_tn_partial(const float* __restrict__ G, int32_t ldg, int32_t nj,
-                                                           const float* __restrict__ X, const int32_t* __restrict__ gather,
-                                                           int32_t rows, int32_t K, int32_t rows_per_block,
-                                                           float* __restrict__ partial) {
+__global__ void __launch_bounds__(256) k_skinny_tn_partial(const SkinnyJob j0, const SkinnyJob j1) {
     // 4 waves split the block's rows; lane l owns columns 4l..4l+3 of a 256-column stripe; fixed-order LDS combine
     __shared__ float red[3][NJ][256];
+    const bool second = static_cast<int>(blockIdx.x) >= j0.nb;
+    const SkinnyJob& jb = second ? j1 : j0;
+    const float* __restrict__ G = jb.G;
+    const float* __restrict__ X = jb.X;
+    const int32_t* __restrict__ gather = jb.gather;
+    float* __restrict__ partial = jb.partial;
+    const int ldg = jb.ldg, nj = jb.nj, rows = jb.rows, K = jb.K, rows_per_block = jb.rpb;
+    const int bid = second ? blockIdx.x - j0.nb : blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = blockIdx.x * rows_per_block;
+    const int r0 = bid * rows_per_block;
     const int r1 = min(rows, r0 + rows_per_block);
     for (int c0 = 0; c0 < K; c0 += 256) {
         const int c = c0 + 4 * lane;
@@ -666,17 +673,24 @@ __global__ void __launch_bounds__(256) k_skinny_tn_partial(const float* __restri
 #pragma unroll
                     for (int v = 0; v < 4; ++v)
                         if (c + v < K)
-                            partial[(static_cast<int64_t>(blockIdx.x) * nj + j) * K + c + v] =
+                            partial[(static_cast<int64_t>(bid) * nj + j) * K + c + v] =
                                 ((acc[j][v] + red[0][j][4 * lane + v]) + red[1][j][4 * lane + v]) + red[2][j][4 * lane + v];
         }
     }
 }
 // out[(j % P)*S1 + (j / P)*S2 + c] = sum_b partial[b][j][c]   (16 elements x 64 slice groups per block, fixed order)
-__global__ void __launch_bounds__(1024) k_skinny_reduce(const float* __restrict__ partial, int32_t nb, int32_t nj, int32_t K,
-                                                        int32_t P, int64_t S1, int64_t S2, float* __restrict__ out) {
+struct SkinnyRedJob { const float* partial; float* out; int64_t S1, S2; int32_t nb, nj, K, P, nblocks; };
+__global__ void __launch_bounds__(1024) k_skinny_reduce(const SkinnyRedJob j0, const SkinnyRedJob j1) {
     __shared__ float red[64][17];
+    const bool second = static_cast<int>(blockIdx.x) >= j0.nblocks;
+    const SkinnyRedJob& jb = second ? j1 : j0;
+    const float* __restrict__ partial = jb.partial;
+    float* __restrict__ out = jb.out;
+    const int nb = jb.nb, nj = jb.nj, K = jb.K, P = jb.P;
+    const int64_t S1 = jb.S1, S2 = jb.S2;
+    const int bid = second ? blockIdx.x - j0.nblocks : blockIdx.x;
     const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int idx = blockIdx.x * 16 + e;
+    const int idx = bid * 16 + e;
     const int tot = nj * K;
     const int per = (nb + 63) / 64;
     const int b0 = grp * per, b1 = min(nb, (grp + 1) * per);
@@ -886,7 +900,7 @@ constexpr int kSkinnySlices = 1024;                              // row slices o
 extern "C" size_t recon_gat_atp_bwd_partial2_floats(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H) {
     (void)N; (void)E; (void)D; (void)H;
     const size_t mx = static_cast<size_t>(F > R ? F : R);
-    return static_cast<size_t>(kSkinnySlices) * 16 * mx;
+    return static_cast<size_t>(2) * kSkinnySlices * 16 * mx;       // two products in flight
 }
 
 extern "C" int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_args* b, recon_stream_t stream) {
@@ -1001,31 +1015,67 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         // (5) g_u = [Gs_dst | Gs_src]^T x   and   gsigma^T edge_embed[eid]   (skinny products, fixed-order reduce)
         if (phases & RECON_ATP_BWD_INPUTS) {
             constexpr int kNB = kSkinnySlices;
-            auto skinny = [&](const float* G, int ldg, int nj, const float* X, const int32_t* gather, int rows, int K, int P,
-                              int64_t S1, int64_t S2, float* out) {
-                if (rows <= 0) {
-                    for (int j = 0; j < nj; ++j) (void)hipMemsetAsync(out + (j % P) * S1 + (j / P) * S2, 0, sizeof(float) * K, st);
-                    return;
+            // Each product: out[(j % P)*S1 + (j / P)*S2 + :] = sum_r G[r][j] * X[row(r)][:].  Products are launched in PAIRS (one
+            // launch for the partial sums, one for the fixed-order reduce); each half of `partial2` serves one product of a pair.
+            struct Prod { const float* G; int ldg, nj; const float* X; const int32_t* gather; int rows, K, P; int64_t S1, S2; float* out; };
+            const size_t half = recon_gat_atp_bwd_partial2_floats(N, E, F, R, D, H) / 2;
+            auto run_pair = [&](const Prod* pr, int count) {
+                SkinnyJob sj[2];
+                SkinnyRedJob rj[2];
+                int nj_max = 0;
+                for (int i = 0; i < 2; ++i) {
+                    sj[i] = SkinnyJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 1, 0};
+                    rj[i] = SkinnyRedJob{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0};
+                    if (i >= count) continue;
+                    const Prod& q = pr[i];
+                    if (q.rows <= 0) {
+                        for (int j = 0; j < q.nj; ++j) (void)hipMemsetAsync(q.out + (j % q.P) * q.S1 + (j / q.P) * q.S2, 0, sizeof(float) * q.K, st);
+                        continue;
+                    }
+                    int rpb = static_cast<int>(ceil_div64(q.rows, kSkinnySlices));
+                    if (rpb < 32) rpb = 32;                             // >= 8 rows per wave
+                    const int nb = static_cast<int>(ceil_div64(q.rows, rpb));
+                    float* part = b->partial2 + i * half;
+                    sj[i] = SkinnyJob{q.G, q.X, q.gather, part, q.ldg, q.nj, q.rows, q.K, rpb, nb};
+                    rj[i] = SkinnyRedJob{part, q.out, q.S1, q.S2, nb, q.nj, q.K, q.P, static_cast<int32_t>(ceil_div64(1LL * q.nj * q.K, 16))};
+                    if (q.nj > nj_max) nj_max = q.nj;
                 }
-                int rpb = static_cast<int>(ceil_div64(rows, kNB));
-                if (rpb < 32) rpb = 32;                                 // >= 8 rows per wave
-                const int nb = static_cast<int>(ceil_div64(rows, rpb));
-                if (nj <= 8) hipLaunchKernelGGL((k_skinny_tn_partial<8>), dim3(nb), dim3(256), 0, st, G, ldg, nj, X, gather, rows, K, rpb, b->partial2);
-                else hipLaunchKernelGGL((k_skinny_tn_partial<16>), dim3(nb), dim3(256), 0, st, G, ldg, nj, X, gather, rows, K, rpb, b->partial2);
-                hipLaunchKernelGGL(k_skinny_reduce, dim3(static_cast<unsigned>(ceil_div64(1LL * nj * K, 16))), dim3(1024), 0, st, b->partial2, nb,
-                                   nj, K, P, S1, S2, out);
+                if (sj[0].nb + sj[1].nb == 0) return;
+                (void)nj_max;
+                // partial sums: one launch per product when their column counts need different instantiations (measured: a
+                // shared <16> launch makes the 8-column product pay for 16), one launch for both otherwise; ONE reduce
+                const SkinnyJob none = SkinnyJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 1, 0};
+                const bool same = (sj[0].nj <= 8) == (sj[1].nj <= 8) && sj[0].nb > 0 && sj[1].nb > 0;
+                auto launch = [&](const SkinnyJob& x, const SkinnyJob& y) {
+                    const dim3 gp(static_cast<unsigned>(x.nb + y.nb));
+                    const int m = x.nj > y.nj ? x.nj : y.nj;
+                    if (m <= 8) hipLaunchKernelGGL((k_skinny_tn_partial<8>), gp, dim3(256), 0, st, x, y);
+                    else hipLaunchKernelGGL((k_skinny_tn_partial<16>), gp, dim3(256), 0, st, x, y);
+                };
+                if (same) launch(sj[0], sj[1]);
+                else {
+                    if (sj[0].nb > 0) launch(sj[0], none);
+                    if (sj[1].nb > 0) launch(sj[1], none);
+                }
+                const dim3 gr(static_cast<unsigned>(rj[0].nblocks + rj[1].nblocks));
+                hipLaunchKernelGGL(k_skinny_reduce, gr, dim3(1024), 0, st, rj[0], rj[1]);
             };
-            // Gs is [N][2H] (dst sums | src sums): column j = (s, h) lands in g_u[h][s*F ...]
-            for (int j0 = 0; j0 < 2 * H; j0 += 16) {                  // <= 16 score columns per pass
-                const int nj = 2 * H - j0 < 16 ? 2 * H - j0 : 16;
-                if (j0 == 0 && nj == 2 * H) skinny(b->Gs, 2 * H, nj, a->x, nullptr, N, F, H, W, F, b->g_u);
-                else                                                    // more than 8 heads: one column at a time keeps the map simple
-                    for (int j = j0; j < j0 + nj; ++j)
-                        skinny(b->Gs + j, 2 * H, 1, a->x, nullptr, N, F, 1, W, 0, b->g_u + static_cast<int64_t>(j % H) * W + (j / H) * F);
-            }
-            for (int h0 = 0; h0 < H; h0 += 16) {
-                const int nh = H - h0 < 16 ? H - h0 : 16;
-                skinny(b->g_sigma + h0, H, nh, a->edge_embed, g->eid, E, R, nh, W, 0, b->g_u + static_cast<int64_t>(h0) * W + 2 * F);
+            if (2 * H <= 16) {
+                // the common case: node-side product (Gs is [N][2H], dst sums | src sums: column (s, h) lands in g_u[h][s*F ...])
+                // and edge-side product (g_sigma^T edge_embed[eid]) side by side
+                const Prod pr[2] = {{b->Gs, 2 * H, 2 * H, a->x, nullptr, N, F, H, W, F, b->g_u},
+                                    {b->g_sigma, H, H, a->edge_embed, g->eid, E, R, H, W, 0, b->g_u + 2 * F}};
+                run_pair(pr, 2);
+            } else {
+                for (int j = 0; j < 2 * H; ++j) {                        // more than 8 heads: one column at a time keeps the map simple
+                    const Prod one = {b->Gs + j, 2 * H, 1, a->x, nullptr, N, F, 1, W, 0, b->g_u + static_cast<int64_t>(j % H) * W + (j / H) * F};
+                    run_pair(&one, 1);
+                }
+                for (int h0 = 0; h0 < H; h0 += 16) {
+                    const int nh = H - h0 < 16 ? H - h0 : 16;
+                    const Prod one = {b->g_sigma + h0, H, nh, a->edge_embed, g->eid, E, R, nh, W, 0, b->g_u + static_cast<int64_t>(h0) * W + 2 * F};
+                    run_pair(&one, 1);
+                }
             }
             RECON_CHECK_LAUNCH();
         }
