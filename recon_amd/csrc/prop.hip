@@ -705,6 +705,63 @@ __global__ void __launch_bounds__(256) k_gcn_aggregate(const float* __restrict__
     }
 }
 
+// The same product for n <= 32 on the matrix cores: Y[b] (32 x 64 tile) = M (32 x 32, zero padded) . X (32 x 64) with
+// v_mfma_f32_16x16x4_f32; wave w owns 16 columns and both 16-row tiles.  The VALU form above spends two LDS reads per
+// four FMAs and is LDS-issue bound (37 us at cfg 3a for 80 MB of traffic).  LDS images are k-major with pitches
+// = 16 (mod 32) floats, so the two k groups a 32-lane read touches fall on disjoint banks.
+template <bool TRANS, bool MASK, bool EPI>
+__global__ void __launch_bounds__(256) k_gcn_aggregate_mfma(const float* __restrict__ adj, const float* __restrict__ Xin,
+                                                            const float* __restrict__ fwd_out, const float* __restrict__ bias,
+                                                            int32_t n, int32_t O, float* __restrict__ Y) {
+    constexpr int PM = 48, PX = 80;
+    __shared__ float Mk[32 * PM];           // Mk[k][i] = M[i][k]
+    __shared__ float Xs[32 * PX];           // Xs[k][o]
+    const int b = blockIdx.y, o0 = blockIdx.x * 64;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const float* A = adj + static_cast<int64_t>(b) * n * n;
+    for (int idx = t; idx < 32 * 32; idx += 256) {
+        const int k = idx >> 5, i = idx & 31;
+        float v = 0.f;
+        if (k < n && i < n) v = TRANS ? A[k * n + i] : A[i * n + k];       // M = adj (forward) or adj^T (backward)
+        Mk[k * PM + i] = v;
+    }
+    for (int idx = t; idx < 32 * 64; idx += 256) {
+        const int k = idx >> 6, o = o0 + (idx & 63);
+        float v = 0.f;
+        if (k < n && o < O) {
+            const int64_t g = (static_cast<int64_t>(b) * n + k) * O + o;
+            v = Xin[g];
+            if constexpr (MASK) v = fwd_out[g] > 0.f ? v : 0.f;
+        }
+        Xs[k * PX + (idx & 63)] = v;
+    }
+    __syncthreads();
+    const int li = lane & 15, lq = lane >> 4;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int k = 4 * s + lq;
+        const float bx = Xs[k * PX + 16 * w + li];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Mk[k * PM + li], bx, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Mk[k * PM + 16 + li], bx, acc[1], 0, 0, 0);
+    }
+    const int o = o0 + 16 * w + li;                                 // C layout: col = lane & 15, row = (lane >> 4) * 4 + r
+    if (o < O) {
+        const float bv = (EPI && bias) ? bias[o] : 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * tt + 4 * lq + r;
+                if (i < n) {
+                    float v = acc[tt][r];
+                    if constexpr (EPI) { v += bv; v = v > 0.f ? v : 0.f; }
+                    Y[(static_cast<int64_t>(b) * n + i) * O + o] = v;
+                }
+            }
+    }
+}
+
 // g_adj[b][i][j] = sum_o gpre[b][i][o] * support[b][j][o]
 __global__ void __launch_bounds__(256) k_gcn_grad_adj(const float* __restrict__ gout, const float* __restrict__ fwd_out,
                                                       const float* __restrict__ sup, int32_t n, int32_t O,
@@ -727,25 +784,41 @@ __global__ void __launch_bounds__(256) k_gcn_bias_partial(const float* __restric
     if (o >= O) return;
     const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += fwd_out[r * O + o] > 0.f ? gout[r * O + o] : 0.f;
-    partial[static_cast<int64_t>(blockIdx.y) * O + o] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                     // four independent chains: the loop is latency bound
+    int64_t r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        s0 += fwd_out[r * O + o] > 0.f ? gout[r * O + o] : 0.f;
+        s1 += fwd_out[(r + 1) * O + o] > 0.f ? gout[(r + 1) * O + o] : 0.f;
+        s2 += fwd_out[(r + 2) * O + o] > 0.f ? gout[(r + 2) * O + o] : 0.f;
+        s3 += fwd_out[(r + 3) * O + o] > 0.f ? gout[(r + 3) * O + o] : 0.f;
+    }
+    for (; r < r1; ++r) s0 += fwd_out[r * O + o] > 0.f ? gout[r * O + o] : 0.f;
+    partial[static_cast<int64_t>(blockIdx.y) * O + o] = (s0 + s1) + (s2 + s3);
 }
-// out[o] = sum_r partial[r][o]: 64 columns x 16 row groups per block, fixed-order LDS combine
+// out[o] = sum_r partial[r][o]: 16 columns x 64 row groups per block, fixed-order LDS combine
 __global__ void __launch_bounds__(1024) k_sum_rows(const float* __restrict__ partial, int32_t nrows, int32_t O, float* __restrict__ out) {
-    __shared__ float red[16][64];
-    const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int o = blockIdx.x * 64 + c;
-    const int per = (nrows + 15) / 16;
-    float s = 0.f;
-    if (o < O)
-        for (int r = grp * per; r < min(nrows, (grp + 1) * per); ++r) s += partial[static_cast<int64_t>(r) * O + o];
-    red[grp][c] = s;
+    __shared__ float red[64][17];
+    const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int o = blockIdx.x * 16 + c;
+    const int per = (nrows + 63) / 64;
+    const int r0 = grp * per, r1 = min(nrows, (grp + 1) * per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (o < O) {
+        int r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            s0 += partial[static_cast<int64_t>(r) * O + o];
+            s1 += partial[static_cast<int64_t>(r + 1) * O + o];
+            s2 += partial[static_cast<int64_t>(r + 2) * O + o];
+            s3 += partial[static_cast<int64_t>(r + 3) * O + o];
+        }
+        for (; r < r1; ++r) s0 += partial[static_cast<int64_t>(r) * O + o];
+    }
+    red[grp][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp == 0 && o < O) {
         float t = 0.f;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) t += red[g][c];
+        for (int g = 0; g < 64; ++g) t += red[g][c];
         out[o] = t;
     }
 }
@@ -791,8 +864,12 @@ extern "C" int recon_gcn_fwd(const recon_gcn_args* a, recon_stream_t stream) {
     if (rc != RECON_OK) return rc;
     // out = relu(adj @ support + bias)     (models/layers.py:59-63)
     dim3 grid(static_cast<unsigned>(ceil_div64(O, 64)), static_cast<unsigned>(a->B));
-    hipLaunchKernelGGL((k_gcn_aggregate<false, false, true>), grid, dim3(256), gcn_lds(a->n), st, a->adj, a->support, nullptr, a->bias,
-                       a->n, O, a->out);
+    if (a->n <= 32)
+        hipLaunchKernelGGL((k_gcn_aggregate_mfma<false, false, true>), grid, dim3(256), 0, st, a->adj, a->support, nullptr, a->bias, a->n, O,
+                           a->out);
+    else
+        hipLaunchKernelGGL((k_gcn_aggregate<false, false, true>), grid, dim3(256), gcn_lds(a->n), st, a->adj, a->support, nullptr, a->bias,
+                           a->n, O, a->out);
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }
@@ -815,8 +892,12 @@ extern "C" int recon_gcn_bwd(const recon_gcn_bwd_args* b, recon_stream_t stream)
     const int32_t rows = a->B * a->n, I = a->in_features, O = a->out_features, n = a->n;
     dim3 grid(static_cast<unsigned>(ceil_div64(O, 64)), static_cast<unsigned>(a->B));
     // g_support = adj^T @ (grad_out * (out > 0))
-    hipLaunchKernelGGL((k_gcn_aggregate<true, true, false>), grid, dim3(256), gcn_lds(n), st, a->adj, b->grad_out, a->out, nullptr, n, O,
-                       b->g_support);
+    if (n <= 32)
+        hipLaunchKernelGGL((k_gcn_aggregate_mfma<true, true, false>), grid, dim3(256), 0, st, a->adj, b->grad_out, a->out, nullptr, n, O,
+                           b->g_support);
+    else
+        hipLaunchKernelGGL((k_gcn_aggregate<true, true, false>), grid, dim3(256), gcn_lds(n), st, a->adj, b->grad_out, a->out, nullptr, n, O,
+                           b->g_support);
     if (b->g_adj)
         hipLaunchKernelGGL(k_gcn_grad_adj, dim3(static_cast<unsigned>(ceil_div64(n * n, 256)), static_cast<unsigned>(a->B)), dim3(256), 0,
                            st, b->grad_out, a->out, a->support, n, O, b->g_adj);
@@ -825,7 +906,7 @@ extern "C" int recon_gcn_bwd(const recon_gcn_bwd_args* b, recon_stream_t stream)
         const int nb = static_cast<int>(ceil_div64(rows, rpb));
         hipLaunchKernelGGL(k_gcn_bias_partial, dim3(static_cast<unsigned>(ceil_div64(O, 256)), static_cast<unsigned>(nb)), dim3(256), 0, st,
                            b->grad_out, a->out, static_cast<int64_t>(rows), O, rpb, b->partial);
-        hipLaunchKernelGGL(k_sum_rows, dim3(static_cast<unsigned>(ceil_div64(O, 64))), dim3(1024), 0, st, b->partial, nb, O, b->g_bias);
+        hipLaunchKernelGGL(k_sum_rows, dim3(static_cast<unsigned>(ceil_div64(O, 16))), dim3(1024), 0, st, b->partial, nb, O, b->g_bias);
     }
     RECON_CHECK_LAUNCH();
     // g_x = g_support @ W^T

@@ -49,5 +49,5 @@ def run(M, N, K, nk, cfgs, rounds=5, iters=10):
 if __name__ == "__main__":
     cfgs = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "3", "4"])]
     for shp in [(4096, 4096, 4096, 1), (8192, 3200, 200, 1), (65536, 200, 600, 1), (65536, 200, 600, 0), (8192, 600, 200, 0),
-                (32768, 200, 1600, 0), (32768, 208, 1600, 0)]:
+                (32768, 200, 1600, 0), (32768, 208, 1600, 0), (65536, 600, 200, 1), (65536, 624, 224, 1)]:
         run(*shp, cfgs=cfgs)
