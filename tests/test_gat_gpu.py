@@ -293,6 +293,30 @@ def test_full_size_cfg2_properties():
     close(out2, out, atol=2e-5, what="edge permutation invariance")
 
 
+def test_full_size_cfg2_split_precision_vs_fp32_gemm(monkeypatch):
+    """BASELINE.json configs[1] at full size: the layer on the split-precision GEMMs (3 bf16 terms per fp32 operand)
+    and on the exact-fp32 MFMA GEMMs must agree in outputs and in every gradient to fp32 round-off."""
+    from recon_amd import gat_layers
+    from recon_amd.graph import prepare_graph
+    d = dev()
+    B, n, e, F_, R, D, H = 512, 16, 64, 200, 200, 200, 8
+    x, edge, ee = O.synthetic_batched_graph(B, n, e, F_, R, seed=0)
+    g = torch.Generator().manual_seed(0)
+    a = torch.stack([O.xavier_normal((D, 2 * F_ + R), 1.414, g) for _ in range(H)])
+    a2 = torch.cat([O.xavier_normal((1, D), 1.414, g) for _ in range(H)])
+    G = torch.randn(B * n, H * D, generator=g).to(d)
+    graph = prepare_graph(edge.to(d), None, B * n)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setattr(gat_layers, "_GEMM_BX3", mode)
+        leaves = [t.to(d).requires_grad_(True) for t in (x, ee, a, a2)]
+        out = gat_layers.gat_heads(*leaves, graph, None, 0.2, True)
+        grads = torch.autograd.grad(out, leaves, G)
+        res[mode] = [out.detach()] + [t.detach() for t in grads]
+    for name, u, v in zip(("out", "g_x", "g_edge_embed", "g_a", "g_a_2"), res["1"], res["0"]):
+        close(u, v, atol=2e-5, rel_to_max=2e-6, what="bx3 vs fp32 GEMM: " + name)
+
+
 @pytest.mark.parametrize("path", ["atp", "proj"])
 @pytest.mark.parametrize("N,E,F_,R,D,H,concat", [
     (64, 300, 16, 8, 32, 3, True),        # H = 3 -> head tile 4 with one masked head
