@@ -5,9 +5,11 @@
 // SURVEY.md 8a/G4) and the autograd GEMMs derived from it.
 //
 // Block tile 128x128x16 (4 waves as 2x2, each 2x2 MFMA tiles of 32x32) or, for outputs 129..208
-// columns wide, 128x208x16 on the 16x16x4 MFMA (4 waves stacked along M, each 2x13 tiles).
-// Global -> registers -> LDS staging with register prefetch of the next K tile; LDS tiles are
-// k-major ([16][128+4]) so both MFMA operand reads are conflict-free ds_read_b32.
+// columns wide, 128x208x16 on the 16x16x4 MFMA (4 waves stacked along M, each 2x13 tiles, wide LDS
+// fragment reads).  Global -> registers -> LDS staging with register prefetch of the next K tile;
+// LDS tiles are k-major.  The layer's three large products normally run on the split-precision
+// kernels of gemm_bx3.hip; this file serves layout (B), GraphConvolution's weight gradient, operand
+// layouts those kernels do not take, and RECON_GEMM_BX3=0.
 #include <stdlib.h>
 #include "gemm_common.h"
 
