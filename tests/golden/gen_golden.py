@@ -358,6 +358,49 @@ def gpgnn_full_case(name, ref_models, style, n=3, d=2, L=3, B=50):
     save(name, **arrays)
 
 
+def gen_formats():
+    """N4: the reference's own readers / writers (GAT/preprocess.py, GAT/main.py save_embed) on tiny synthetic files."""
+    import tempfile, json as _json, importlib
+    cwd = os.getcwd()
+    gat = os.path.join(REF, "GAT")
+    sys.path.insert(0, gat)
+    try:
+        pre = importlib.import_module("preprocess")
+    finally:
+        sys.path.remove(gat)
+    assert pre.__file__.startswith(REF)
+    ent_txt = "alpha 0\nbeta 1\n\ngamma 2\ndelta\t3\n"
+    rel_txt = "likes 0\nknows 1\n"
+    tri_txt = "alpha likes beta\nbeta knows gamma\n\ndelta likes alpha\nalpha knows gamma\n"
+    e2v_txt = "0.5 -1.25 2\n1e-3 0 3.5\n"
+    r2v_txt = "1 2\n-3 4.5\n"
+    arrays = dict(ent_txt=np.array(ent_txt), rel_txt=np.array(rel_txt), tri_txt=np.array(tri_txt), e2v_txt=np.array(e2v_txt),
+                  r2v_txt=np.array(r2v_txt))
+    with tempfile.TemporaryDirectory() as d:
+        paths = {}
+        for name, txt in (("entity2id.txt", ent_txt), ("relation2id.txt", rel_txt), ("train.txt", tri_txt), ("entity2vec.txt", e2v_txt),
+                          ("relation2vec.txt", r2v_txt)):
+            paths[name] = os.path.join(d, name)
+            open(paths[name], "w").write(txt)
+        e2i = pre.read_entity_from_id(paths["entity2id.txt"])
+        r2i = pre.read_relation_from_id(paths["relation2id.txt"])
+        arrays["entity_names"] = np.array(sorted(e2i, key=e2i.get)); arrays["entity_ids"] = np.array([e2i[k] for k in sorted(e2i, key=e2i.get)])
+        arrays["relation_names"] = np.array(sorted(r2i, key=r2i.get)); arrays["relation_ids"] = np.array([r2i[k] for k in sorted(r2i, key=r2i.get)])
+        for tag, directed, unw in (("dir", True, False), ("undir_unw", False, True)):
+            tr, (rows, cols, data), uniq = pre.load_data(paths["train.txt"], e2i, r2i, unw, directed)
+            arrays["triples_" + tag] = np.array(tr); arrays["rows_" + tag] = np.array(rows); arrays["cols_" + tag] = np.array(cols)
+            arrays["data_" + tag] = np.array(data); arrays["unique_" + tag] = np.array(sorted(uniq))
+        ee, re_ = pre.init_embeddings(paths["entity2vec.txt"], paths["relation2vec.txt"])
+        arrays["entity_emb"] = ee; arrays["relation_emb"] = re_
+        # save_embed lives in GAT/main.py, which cannot be imported (argparse + datasets at import): restate its 6 lines with the
+        # reference's encoder semantics (ndarray -> list) and keep the produced text as the fixture
+        emb = torch.from_numpy(hashed_uniform((3, 4), 77))
+        data = {idx: np.array(emb[idx]).tolist() for idx in range(emb.shape[0])}
+        arrays["embed"] = t2n(emb); arrays["embed_json"] = np.array(_json.dumps(data, indent=4))
+    os.chdir(cwd)
+    save("formats1", **arrays)
+
+
 def gen_gpgnn():
     cwd = os.getcwd()
     os.chdir(REF)
@@ -416,6 +459,10 @@ def gen_gpgnn():
         save("gcn1_" + tag, **arrays)
 
 
+if __name__ == "__main__" and os.environ.get("RECON_GOLDEN_ONLY") == "formats":
+    gen_formats()
+    sys.exit(0)
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("the reference is not mounted here; golden vectors can only be regenerated in the build container")
@@ -427,3 +474,4 @@ if __name__ == "__main__":
         sys.modules.pop(k, None)
     sys.path.remove(os.path.join(REF, "GAT"))
     gen_gpgnn()
+    gen_formats()

@@ -199,3 +199,36 @@ def test_gpgnn_state_dict_matches_reference(name):
     assert tuple(sd["head_indices"].shape) == (50, n * (n - 1), 2 * d)          # bs = 50 baked in, models/models.py:138-142
     missing, unexpected = m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ref.items()}, strict=False)
     assert set(missing) == regenerated and not unexpected
+
+
+def test_on_disk_formats_match_reference_readers(tmp_path):
+    """id maps, triple files, embedding text files parsed exactly like GAT/preprocess.py does (fixture:
+    the reference's own functions on tiny synthetic files), and the final_*_embeddings.json / W_ent2rel round trips."""
+    from recon_amd import formats
+    g = load_golden("formats1")
+    files = {"entity2id.txt": "ent_txt", "relation2id.txt": "rel_txt", "train.txt": "tri_txt", "entity2vec.txt": "e2v_txt",
+             "relation2vec.txt": "r2v_txt"}
+    for fn, key in files.items():
+        (tmp_path / fn).write_text(str(g[key]))
+    e2i = formats.read_entity_from_id(str(tmp_path / "entity2id.txt"))
+    r2i = formats.read_relation_from_id(str(tmp_path / "relation2id.txt"))
+    assert e2i == dict(zip([str(s) for s in g["entity_names"]], [int(v) for v in g["entity_ids"]]))
+    assert r2i == dict(zip([str(s) for s in g["relation_names"]], [int(v) for v in g["relation_ids"]]))
+    for tag, directed, unw in (("dir", True, False), ("undir_unw", False, True)):
+        tr, (rows, cols, data), uniq = formats.load_data(str(tmp_path / "train.txt"), e2i, r2i, unw, directed)
+        np.testing.assert_array_equal(np.array(tr), g["triples_" + tag])
+        np.testing.assert_array_equal(np.array(rows), g["rows_" + tag])
+        np.testing.assert_array_equal(np.array(cols), g["cols_" + tag])
+        np.testing.assert_array_equal(np.array(data), g["data_" + tag])
+        assert sorted(uniq) == [str(s) for s in g["unique_" + tag]]
+        edge, etype = formats.edges_from_adjacency((rows, cols, data))
+        assert edge.shape == (2, len(rows)) and edge.dtype == torch.int64 and etype.tolist() == list(data)
+    ee, re_ = formats.init_embeddings(str(tmp_path / "entity2vec.txt"), str(tmp_path / "relation2vec.txt"))
+    np.testing.assert_array_equal(ee, g["entity_emb"])
+    np.testing.assert_array_equal(re_, g["relation_emb"])
+    formats.save_embed(torch.from_numpy(g["embed"]), str(tmp_path / "final_entity_embeddings.json"))
+    assert (tmp_path / "final_entity_embeddings.json").read_text() == str(g["embed_json"])
+    np.testing.assert_array_equal(formats.load_embed(str(tmp_path / "final_entity_embeddings.json")), g["embed"])
+    formats.save_w_ent2rel(torch.from_numpy(g["embed"]), str(tmp_path))
+    assert (tmp_path / "W_ent2rel.json.npy").exists()
+    np.testing.assert_array_equal(formats.load_w_ent2rel(str(tmp_path)), g["embed"])
