@@ -22,6 +22,12 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kMaxHops = 8;
 
+// logical block index such that XCD x (blocks b with b % 8 == x) owns a contiguous chunk of the logical range
+__device__ __forceinline__ int xcd_block(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
 __device__ __forceinline__ float act_fwd(float v, int act) {
     if (act == RECON_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == RECON_ACT_TANH) return tanhf(v);
@@ -272,7 +278,9 @@ __global__ void __launch_bounds__(256) k_propagate_fwd_w(const PropK p) {
     constexpr int NB = (NT >= 3) ? 3 : NT;                          // column tiles in flight (independent accumulators)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int MTn = (p.C + 15) >> 4;
-    const int unit = blockIdx.x * 4 + wave;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); give every XCD a contiguous
+    // chunk of units so that the waves of one graph, which stream the same A_l, hit the same L2 (PMC: 49 % L2 hits before)
+    const int unit = xcd_block(blockIdx.x, gridDim.x) * 4 + wave;
     if (unit >= p.B * MTn) return;
     const int b = unit / MTn, m = unit % MTn;
     const int S = p.S, pitch = p.pitch;
