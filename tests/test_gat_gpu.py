@@ -442,3 +442,34 @@ def test_spmm_rowsum_long_and_short_segments(N, E, C_, skew):
     out = SpecialSpmmFinal()(edge.to(dev()), w.to(dev()), N, E, C_)
     ref = O.spmm_rowsum(edge, w.double(), N)
     close(out, ref.float(), atol=1e-5, rel_to_max=2e-6, what="rowsum")
+
+
+@pytest.mark.parametrize("N,E,F_,R,D,H", [
+    (16, 0, 8, 8, 16, 2),             # no edges at all
+    (40, 7, 200, 200, 200, 8),        # nearly empty graph at cfg-2 widths (most rows isolated: Z clamp path)
+    (300, 1200, 200, 200, 200, 8),    # cfg-2 widths, ragged sizes (row / column tails of every GEMM tile)
+    (33, 100, 12, 20, 24, 3),         # odd head count, D % 8 == 0 but tiny
+    (64, 256, 16, 16, 8, 8),          # D = 8: one 16-byte plane slot per head
+    (129, 500, 40, 36, 208, 2),       # D = 208: exactly one full column tile
+    (500, 100, 200, 200, 200, 8),     # N >> E: the project-then-aggregate kernels take over
+])
+def test_training_edge_shapes(N, E, F_, R, D, H):
+    """Forward + all four gradients of the fused H-head stage against the oracle on shapes that hit the tile tails, the
+    empty-input paths and the formulation switch."""
+    from recon_amd.gat_layers import gat_heads
+    from recon_amd.graph import prepare_graph
+    g = torch.Generator().manual_seed(N + E)
+    x, ee = torch.randn(N, F_, generator=g), torch.randn(E, R, generator=g)
+    edge = torch.randint(0, N, (2, E), generator=g)
+    a, a2 = torch.randn(H, D, 2 * F_ + R, generator=g) * 0.1, torch.randn(H, D, generator=g) * 0.1
+    G = torch.randn(N, H * D, generator=g)
+    leaves = [t.to(dev()).requires_grad_(True) for t in (x, ee, a, a2)]
+    out = gat_heads(*leaves, prepare_graph(edge.to(dev()), None, N), None, 0.2, True)
+    grads = torch.autograd.grad(out, leaves, G.to(dev()))
+    cl = [t.clone().requires_grad_(True) for t in (x, ee, a, a2)]
+    ref = torch.cat([O.gat_layer_forward(cl[0], edge, cl[1], None, None, cl[2][h], cl[3][h:h + 1], 0.2, True) for h in range(H)], 1)
+    rg = torch.autograd.grad(ref, cl, G)
+    close(out, ref, what="out")
+    for name, u, v in zip(("g_x", "g_edge_embed", "g_a", "g_a_2"), grads, rg):
+        if v.numel():
+            close(u, v, atol=1e-4, rel_to_max=1e-4, what=name)
