@@ -296,7 +296,11 @@ typedef struct {
     float* g_adj;                   /* [B,n,n]   or NULL */
     float* g_weight;                /* [in,out]  or NULL */
     float* g_bias;                  /* [out]     or NULL */
+    void* gs_split;                 /* recon_gcn_bwd_split_bytes() bytes or NULL: bfloat16 term planes of g_support for *
+                                     * the split-precision weight-gradient product (needs fwd.w_split as well)         */
 } recon_gcn_bwd_args;
+
+size_t recon_gcn_bwd_split_bytes(int32_t B, int32_t n, int32_t out_features);
 
 size_t recon_gcn_bwd_partial_floats(int32_t B, int32_t n, int32_t in_features, int32_t out_features);
 int recon_gcn_bwd(const recon_gcn_bwd_args* args, recon_stream_t stream);
@@ -317,8 +321,8 @@ size_t recon_sgemm_bx3_workspace_bytes(int32_t N, int32_t K);
 int recon_sgemm_bx3(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                     float* C, int32_t ldc, void* workspace, recon_stream_t stream);
 /* C[M,N] = A^T * B for k-major operands A[K,M], B[K,N] (the weight-gradient form g_a^T = V^T g_h; split-K with a
- * fixed-order second pass; A is split on the fly, B into `workspace` first).  Requires M, lda multiples of 4 and
- * N a multiple of 8 (RECON_ERR_UNSUPPORTED otherwise). */
+ * fixed-order second pass; A is split on the fly, B into `workspace` first).  Requires M and lda to be multiples
+ * of 4 (RECON_ERR_UNSUPPORTED otherwise). */
 size_t recon_sgemm_bx3_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
 int recon_sgemm_bx3_tn(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                        float* C, int32_t ldc, void* workspace, recon_stream_t stream);

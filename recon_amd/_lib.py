@@ -72,7 +72,7 @@ class GcnArgs(C.Structure):
 
 class GcnBwdArgs(C.Structure):
     _fields_ = [("fwd", GcnArgs), ("grad_out", c_f32p), ("g_support", c_f32p), ("partial", c_f32p),
-                ("g_x", c_f32p), ("g_adj", c_f32p), ("g_weight", c_f32p), ("g_bias", c_f32p)]
+                ("g_x", c_f32p), ("g_adj", c_f32p), ("g_weight", c_f32p), ("g_bias", c_f32p), ("gs_split", C.c_void_p)]
 
 
 ACT = {"linear": 0, "relu": 1, "tanh": 2}
@@ -109,6 +109,7 @@ SYMBOLS = [
     ("recon_gcn_split_bytes", C.c_size_t, [C.c_int32, C.c_int32]),
     ("recon_gcn_fwd", C.c_int, [C.POINTER(GcnArgs), C.c_void_p]),
     ("recon_gcn_bwd_partial_floats", C.c_size_t, [C.c_int32] * 4),
+    ("recon_gcn_bwd_split_bytes", C.c_size_t, [C.c_int32] * 3),
     ("recon_gcn_bwd", C.c_int, [C.POINTER(GcnBwdArgs), C.c_void_p]),
     ("recon_sgemm", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32,
                               c_f32p, C.c_int32, C.c_void_p]),

@@ -261,6 +261,7 @@ struct Bx3KmArgs {
     int64_t lda, ldb, b_plane, a_bs, b_bs;
     float* partial;
     int32_t M, N, K, k_per_split, nsplit;
+    int32_t n_ld;                  // columns present in the planes (multiple of 8, >= N; the excess is zero padding)
 };
 
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
@@ -307,7 +308,7 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_bx3_kmajor(const Bx3KmArgs p) {
         int slot = phys - ((k & 8) ? 8 : 0);
         if (slot < 0) slot += 26;
         b_k[i] = k;
-        b_goff[i] = min(n0 + 8 * slot, p.N - 8);
+        b_goff[i] = min(n0 + 8 * slot, p.n_ld - 8);
     }
     const __bf16* bbase = p.Bp + bz * p.b_bs;
     auto dma_b = [&](int k0) {
@@ -505,8 +506,11 @@ int gemm_bx3_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, cons
     return RECON_OK;
 }
 
+// N itself may be any size as long as every plane row holds (N rounded up to 8) columns, zero padded: b_bs + that <= ldb
 bool bx3_kmajor_supported(const float* A, int64_t lda, int64_t a_bs, int64_t ldb, int64_t b_bs, int32_t M, int32_t N) {
-    if ((M & 3) || (N & 7) || M < 4 || N < 8 || (lda & 3) || (a_bs & 3) || (ldb & 7) || (b_bs & 7)) return false;
+    const int64_t n_ld = (static_cast<int64_t>(N) + 7) / 8 * 8;
+    if ((M & 3) || M < 4 || N < 1 || (lda & 3) || (a_bs & 3) || (ldb & 7) || (b_bs & 7) || n_ld > ldb) return false;
+    if ((N & 7) && b_bs != 0) return false;                          // batched heads sit side by side in a row: no room for padding
     return !(reinterpret_cast<uintptr_t>(A) & 15);
 }
 
@@ -532,6 +536,7 @@ int gemm_bx3_kmajor_batched(int32_t M, int32_t N, int32_t K, const float* A, int
     Bx3KmArgs a;
     a.A = A; a.Bp = static_cast<const __bf16*>(Bplanes); a.lda = lda; a.ldb = ldb; a.b_plane = b_plane; a.a_bs = a_bs; a.b_bs = b_bs;
     a.partial = partial; a.M = M; a.N = N; a.K = K;
+    a.n_ld = (N + 7) / 8 * 8;
     int64_t kps = ceil_div64(K > 0 ? K : 1, split_k);
     kps = ceil_div64(kps, BK) * BK;
     a.k_per_split = static_cast<int32_t>(kps);

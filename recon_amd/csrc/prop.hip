@@ -884,9 +884,16 @@ extern "C" int recon_gcn_fwd(const recon_gcn_args* a, recon_stream_t stream) {
 
 extern "C" size_t recon_gcn_bwd_partial_floats(int32_t B, int32_t n, int32_t in_features, int32_t out_features) {
     size_t need = static_cast<size_t>(kBiasBlocks) * out_features;
-    const int sk = gemm_pick_split_k(in_features, out_features, B * n);
-    const size_t g = static_cast<size_t>(sk > 1 ? sk : 0) * in_features * out_features;
+    int sk = gemm_pick_split_k(in_features, out_features, B * n);
+    const int sk3 = bx3_kmajor_splits(B * n, bx3_kmajor_split_k(in_features, out_features, B * n, 1));      // split-precision form
+    if (sk3 > sk) sk = sk3;
+    const size_t g = static_cast<size_t>(sk) * in_features * out_features;
     return g > need ? g : need;
+}
+
+extern "C" size_t recon_gcn_bwd_split_bytes(int32_t B, int32_t n, int32_t out_features) {
+    if (B <= 0 || n <= 0 || out_features <= 0) return 256;
+    return align_up(static_cast<size_t>(3) * B * n * bx3_kp(out_features) * 2, 256);
 }
 
 extern "C" int recon_gcn_bwd(const recon_gcn_bwd_args* b, recon_stream_t stream) {
@@ -931,9 +938,18 @@ extern "C" int recon_gcn_bwd(const recon_gcn_bwd_args* b, recon_stream_t stream)
     }
     // g_W = x^T @ g_support   (split-K over the B*n rows, deterministic second pass)
     if (b->g_weight) {
-        const int sk = gemm_pick_split_k(I, O, rows);
-        rc = gemm_f32(I, O, rows, plain_operand(a->x, I), false, plain_operand(b->g_support, O), false, plain_output(b->g_weight, O), sk,
-                      b->partial, st);
+        const int64_t ldp = bx3_kp(O);
+        if (b->gs_split && a->w_split && !(reinterpret_cast<uintptr_t>(b->gs_split) & 15) && bx3_kmajor_supported(a->x, I, 0, ldp, 0, I, O)) {
+            // split-precision, both operands k-major: x split on the fly, g_support from its bf16 term planes
+            rc = bx3_split_planes(b->g_support, O, 0, false, rows, O, 1, b->gs_split, st);
+            const int sk = bx3_kmajor_splits(rows, bx3_kmajor_split_k(I, O, rows, 1));
+            if (rc == RECON_OK) rc = gemm_bx3_kmajor_batched(I, O, rows, a->x, I, 0, b->gs_split, ldp, static_cast<int64_t>(rows) * ldp, 0, 1, sk, b->partial, st);
+            if (rc == RECON_OK) rc = splitk_reduce(b->partial, sk, I, O, plain_output(b->g_weight, O), 0, 1, 0, false, st);
+        } else {
+            const int sk = gemm_pick_split_k(I, O, rows);
+            rc = gemm_f32(I, O, rows, plain_operand(a->x, I), false, plain_operand(b->g_support, O), false, plain_output(b->g_weight, O), sk,
+                          b->partial, st);
+        }
         if (rc != RECON_OK) return rc;
     }
     return RECON_OK;

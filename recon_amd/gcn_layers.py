@@ -70,8 +70,10 @@ class _GcnFunction(torch.autograd.Function):
         g_b = torch.empty(O, **f32) if (nb and bias is not None) else None
         fwd = _lib.GcnArgs(B, n, I, O, x3.data_ptr(), adj3.data_ptr(), weight.data_ptr(), _lib.ptr(bias), sup.data_ptr(),
                            out.data_ptr(), _lib.ptr(w_split))
+        gs_split = (torch.empty(L.recon_gcn_bwd_split_bytes(B, n, O), dtype=torch.uint8, device=dev)
+                    if (w_split is not None and g_w is not None) else None)
         args = _lib.GcnBwdArgs(fwd, gout.data_ptr(), g_sup.data_ptr(), partial.data_ptr(), _lib.ptr(g_x), _lib.ptr(g_adj),
-                               _lib.ptr(g_w), _lib.ptr(g_b))
+                               _lib.ptr(g_w), _lib.ptr(g_b), _lib.ptr(gs_split))
         with torch.cuda.device(dev):
             _lib.check(L.recon_gcn_bwd(C.byref(args), _lib.current_stream()), "recon_gcn_bwd")
         xs, adjs = ctx.shapes

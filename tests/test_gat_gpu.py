@@ -96,7 +96,8 @@ def test_sgemm_bx3(M, N, K):
     assert err.max() <= 4.0 * (f32 - ref).abs().max() + 1e-12
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 208, 64), (600, 200, 8192), (36, 216, 1000), (260, 24, 77), (4, 424, 33)])
+@pytest.mark.parametrize("M,N,K", [(128, 208, 64), (600, 200, 8192), (36, 216, 1000), (260, 24, 77), (4, 424, 33), (300, 300, 4096),
+                                   (12, 5, 50)])
 def test_sgemm_bx3_tn(M, N, K):
     """The k-major (weight-gradient) form of the split-precision GEMM: C = A^T B, A [K,M], B [K,N]."""
     from recon_amd import _lib
