@@ -163,8 +163,8 @@ extern "C" int recon_graph_build(const int64_t* edge_dst, const int64_t* edge_sr
     const int32_t N = g->N, E = g->E;
     hipStream_t st = as_stream(stream);
     if (E == 0) {
-        hipMemsetAsync(g->rowptr_dst, 0, sizeof(int32_t) * (N + 1), st);
-        hipMemsetAsync(g->rowptr_src, 0, sizeof(int32_t) * (N + 1), st);
+        if (hipMemsetAsync(g->rowptr_dst, 0, sizeof(int32_t) * (N + 1), st) != hipSuccess ||
+            hipMemsetAsync(g->rowptr_src, 0, sizeof(int32_t) * (N + 1), st) != hipSuccess) return RECON_ERR_LAUNCH;
         return RECON_OK;
     }
     if (!edge_dst || !edge_src || !g->eid || !g->src || !g->dst || !g->slot_by_src || !workspace) return RECON_ERR_INVALID;

@@ -575,7 +575,7 @@ extern "C" int recon_gat_bwd(const recon_graph* g, const recon_gat_bwd_args* b, 
         } else {
             // no edges: the relation block of g_a is zero
             for (int64_t row = 0; row < HD; ++row)
-                hipMemsetAsync(b->g_a + row * W + 2 * F, 0, sizeof(float) * R, st);
+                if (hipMemsetAsync(b->g_a + row * W + 2 * F, 0, sizeof(float) * R, st) != hipSuccess) return RECON_ERR_LAUNCH;
         }
     }
     return RECON_OK;

@@ -1014,7 +1014,6 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         }
         // (5) g_u = [Gs_dst | Gs_src]^T x   and   gsigma^T edge_embed[eid]   (skinny products, fixed-order reduce)
         if (phases & RECON_ATP_BWD_INPUTS) {
-            constexpr int kNB = kSkinnySlices;
             // Each product: out[(j % P)*S1 + (j / P)*S2 + :] = sum_r G[r][j] * X[row(r)][:].  Products are launched in PAIRS (one
             // launch for the partial sums, one for the fixed-order reduce); each half of `partial2` serves one product of a pair.
             struct Prod { const float* G; int ldg, nj; const float* X; const int32_t* gather; int rows, K, P; int64_t S1, S2; float* out; };

@@ -27,8 +27,6 @@ namespace recon {
 namespace {
 
 constexpr int BM = 128, BN = 208, BK = 32, NT = 256, TN = 13;
-constexpr int B_ITEMS = 3 * BN * 4;                              // 16-byte slots of one B tile (3 planes x 208 rows x 4)
-constexpr int B_NP = (B_ITEMS + NT - 1) / NT;                    // 10
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;

@@ -651,7 +651,7 @@ extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t
         p.gA = ba->g_adj ? ba->g_adj[l - 1] : nullptr;
         p.B = a->B; p.C = a->C; p.S = a->S; p.L = a->L; p.dd = a->dd; p.act = a->act;
         p.CC = g.CC; p.Sp = g.Sp; p.pitch = g.pitch; p.hop = l - 1; p.first = (l == a->L) ? 1 : 0; p.chunks = g.chunks;
-        if (p.gA && g.chunks > 1) hipMemsetAsync(p.gA, 0, sizeof(float) * a->B * a->S * a->S, st);
+        if (p.gA && g.chunks > 1 && hipMemsetAsync(p.gA, 0, sizeof(float) * a->B * a->S * a->S, st) != hipSuccess) return RECON_ERR_LAUNCH;
         RECON_DISPATCH_MT(g.MT, false, k_propagate_bwd_hop, grid, dim3(1024), g.lds, st, p);
         RECON_CHECK_LAUNCH();
     }
