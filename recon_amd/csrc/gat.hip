@@ -616,21 +616,23 @@ __global__ void __launch_bounds__(256) k_rowsum_walk(const int32_t* __restrict__
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
     };
-    for (int k = k0; k < k1; k += 4) {
-        float t[4][VEC];
-        int d[4];
+    // eight rows in flight, branch-free loads (a guarded load gets its own basic block and is then waited for on its own):
+    // slots past the range re-read its last slot and are skipped at the accumulate; lanes past C read a clamped column
+    const int cc = ca ? c : 0;
+    constexpr int U = 8;
+    for (int k = k0; k < k1; k += U) {
+        float t[U][VEC];
+        int d[U], e[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            d[u] = cur;
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) t[u][v] = 0.f;
-            if (k + u < k1) {
-                d[u] = dst[k + u];
-                if (ca) load_vec<VEC>(t[u], w + static_cast<int64_t>(eid[k + u]) * C + c);
-            }
+        for (int u = 0; u < U; ++u) {
+            const int kk = min(k + u, k1 - 1);
+            d[u] = dst[kk];
+            e[u] = eid[kk];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) load_vec<VEC>(t[u], w + static_cast<int64_t>(e[u]) * C + cc);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
             if (k + u < k1) {
                 if (d[u] != cur) { flush(cur); cur = d[u]; }        // wave-uniform
 #pragma unroll

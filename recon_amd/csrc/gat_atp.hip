@@ -148,6 +148,48 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
         }
         return;
     }
+    if (v4) {                                                            // wide heads (out_att: D = H*D of the heads): 256 columns per pass
+        for (int j = 0; j < IPW; ++j) {
+            const int it = item0 + j;
+            if (it >= total) break;
+            const int node = it / H, h = it % H;
+            const float* gr = gy + static_cast<int64_t>(node) * ld_gy + h * D;
+            const float* yr = y + static_cast<int64_t>(node) * ld_y + h * D;
+            float part = 0.f;
+            for (int c = 4 * lane; c < D; c += 256) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gr + c), y4 = *reinterpret_cast<const float4*>(yr + c);
+                const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};
+                float x[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    float g = gv[v], hv = yv[v];
+                    if (concat && yv[v] <= 0.f) { const float e = yv[v] + 1.f; g = gv[v] * e; hv = e > 0.f ? __logf(e) : 0.f; }
+                    x[v] = g;
+                    part = fmaf(g, hv, part);
+                }
+                if (gh) *reinterpret_cast<float4*>(gh + static_cast<int64_t>(it) * D + c) = make_float4(x[0], x[1], x[2], x[3]);
+                if (ghp) {
+                    uint16_t* dst = ghp + static_cast<int64_t>(node) * ld_p + h * D + c;
+#pragma unroll
+                    for (int pq = 0; pq < 3; ++pq) {
+                        uint32_t w[2];
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const __bf16 b0 = static_cast<__bf16>(x[2 * hh]), b1 = static_cast<__bf16>(x[2 * hh + 1]);
+                            const uint32_t u0 = __builtin_bit_cast(uint16_t, b0), u1 = __builtin_bit_cast(uint16_t, b1);
+                            w[hh] = u0 | (u1 << 16);
+                            x[2 * hh] -= __builtin_bit_cast(float, u0 << 16);
+                            x[2 * hh + 1] -= __builtin_bit_cast(float, u1 << 16);
+                        }
+                        *reinterpret_cast<uint2*>(dst + pq * plane_p) = make_uint2(w[0], w[1]);
+                    }
+                }
+            }
+            const float tot = group_sum<64>(part);
+            if (lane == 0) q[it] = tot;
+        }
+        return;
+    }
     for (int j = 0; j < IPW; ++j) {
         const int it = item0 + j;
         if (it >= total) break;
@@ -934,7 +976,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
     int32_t ld_gh = b->ld_gout;
     // bf16 term planes of g_h [3][N][kp(HD)] for the split-precision weight-gradient GEMM (written by the same pass)
     const int64_t ld_ghp = bx3_kp(static_cast<int32_t>(HD));
-    const bool gh_planes = b->gh_split && a->a_split && !(reinterpret_cast<uintptr_t>(b->gh_split) & 15) && (D % 8) == 0 && D <= 256 &&
+    const bool gh_planes = b->gh_split && a->a_split && !(reinterpret_cast<uintptr_t>(b->gh_split) & 15) && (D % 8) == 0 &&
                            ((b->ld_gout | a->ld_out) & 3) == 0;
     uint16_t* ghp = gh_planes ? static_cast<uint16_t*>(b->gh_split) : nullptr;
     if (phases & RECON_ATP_BWD_PREPARE)
