@@ -315,30 +315,29 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_fwd(const AtpFwdK p) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) { accS[h][r][v] = 0.f; accR[h][r][v] = 0.f; }
     float Zl = 0.f, Zkl = 0.f;
+    // Loads are branch free: a guarded load gets its own basic block and the value join makes the compiler wait for each
+    // load on its own, so the row of x[src] and the row of r_e (and the score terms) would arrive one round trip after
+    // the other.  Slots past the row re-read its last slot (weight forced to 0), lanes past F / R read column 0 (their
+    // accumulators are never stored), lanes past H read head h0.
+    int cfF[KR], cfR[KR];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) { cfF[r] = aF[r] ? cf[r] : 0; cfR[r] = aR[r] ? cf[r] : 0; }
+    const int myhc = hv ? myh : h0;
     for (int k0 = beg; k0 < end; k0 += UNR) {
         float xs[UNR][KR][VEC], re[UNR][KR][VEC], sc[UNR], kf[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int k = k0 + u;
-            sc[u] = 0.f; kf[u] = 1.f;
+            const int k = min(k0 + u, end - 1);
+            const int s = p.src[k], e = p.eid[k];
+            const float* xr = p.x + static_cast<int64_t>(s) * F;
+            const float* rr = p.ee + static_cast<int64_t>(e) * R;
 #pragma unroll
-            for (int r = 0; r < KR; ++r)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) { xs[u][r][v] = 0.f; re[u][r][v] = 0.f; }
-            if (k < end) {
-                const int s = p.src[k], e = p.eid[k];
-                const float* xr = p.x + static_cast<int64_t>(s) * F;
-                const float* rr = p.ee + static_cast<int64_t>(e) * R;
-#pragma unroll
-                for (int r = 0; r < KR; ++r) {
-                    if (aF[r]) load_vec<VEC>(xs[u][r], xr + cf[r]);
-                    if (aR[r]) load_vec<VEC>(re[u][r], rr + cf[r]);
-                }
-                if (hv) {
-                    sc[u] = cd + p.c_node[static_cast<int64_t>(s) * 2 * H + H + myh] + p.c_rel[static_cast<int64_t>(k) * H + myh];
-                    if (p.keep) kf[u] = p.keep[static_cast<int64_t>(k) * H + myh];
-                }
+            for (int r = 0; r < KR; ++r) {
+                load_vec<VEC>(xs[u][r], xr + cfF[r]);
+                load_vec<VEC>(re[u][r], rr + cfR[r]);
             }
+            sc[u] = cd + p.c_node[static_cast<int64_t>(s) * 2 * H + H + myhc] + p.c_rel[static_cast<int64_t>(k) * H + myhc];
+            kf[u] = p.keep ? p.keep[static_cast<int64_t>(k) * H + myhc] : 1.f;
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -428,13 +427,20 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_bwd(const AtpBwdK p) {
     int cf[KR]; bool aF[KR], aR[KR];
 #pragma unroll
     for (int r = 0; r < KR; ++r) { cf[r] = (r * 64 + lane) * VEC; aF[r] = cf[r] < F; aR[r] = cf[r] < R; }
+    // branch-free loads throughout (see k_gat_atp_fwd): lanes past F / R read column 0 and are masked by a select or by
+    // never being stored
+    int cfF[KR], cfR[KR];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) { cfF[r] = aF[r] ? cf[r] : 0; cfR[r] = aR[r] ? cf[r] : 0; }
     const int beg = p.rowptr[node], end = p.rowptr[node + 1];
     float xi[KR][VEC], gxd[KR][VEC];
 #pragma unroll
     for (int r = 0; r < KR; ++r) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) { xi[r][v] = 0.f; gxd[r][v] = 0.f; }
-        if (aF[r]) load_vec<VEC>(xi[r], p.x + static_cast<int64_t>(node) * F + cf[r]);
+        for (int v = 0; v < VEC; ++v) gxd[r][v] = 0.f;
+        load_vec<VEC>(xi[r], p.x + static_cast<int64_t>(node) * F + cfF[r]);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) xi[r][v] = aF[r] ? xi[r][v] : 0.f;
     }
     // lane l works for head h0 + (l >> SH) (the layout multi_sum leaves its totals in); lane h << SH speaks for head h
     constexpr int SH = HT == 8 ? 3 : HT == 4 ? 4 : HT == 2 ? 5 : 6;
@@ -460,19 +466,20 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_bwd(const AtpBwdK p) {
             for (int r = 0; r < KR; ++r) {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) { gVs[h][r][v] = 0.f; gVr[h][r][v] = 0.f; }
-                if (hok) {
+                if (hok) {                                                // wave-uniform
                     const int64_t base = (static_cast<int64_t>(node) * H + h0 + h) * W;
                     float gd[VEC];
-                    if (aF[r]) {
-                        load_vec<VEC>(gd, p.gV + base + cf[r]);
+                    load_vec<VEC>(gd, p.gV + base + cfF[r]);
+                    load_vec<VEC>(gVs[h][r], p.gV + base + F + cfF[r]);
+                    load_vec<VEC>(gVr[h][r], p.gV + base + 2 * F + cfR[r]);
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) {
-                            pd = fmaf(gd[v], xi[r][v], pd);
-                            gxd[r][v] = fmaf(zr, gd[v], gxd[r][v]);       // direct path: V_dst = x_i Zk/Z
-                        }
-                        load_vec<VEC>(gVs[h][r], p.gV + base + F + cf[r]);
+                    for (int v = 0; v < VEC; ++v) {
+                        gd[v] = aF[r] ? gd[v] : 0.f;
+                        gVs[h][r][v] = aF[r] ? gVs[h][r][v] : 0.f;
+                        gVr[h][r][v] = aR[r] ? gVr[h][r][v] : 0.f;
+                        pd = fmaf(gd[v], xi[r][v], pd);
+                        gxd[r][v] = fmaf(zr, gd[v], gxd[r][v]);           // direct path: V_dst = x_i Zk/Z
                     }
-                    if (aR[r]) load_vec<VEC>(gVr[h][r], p.gV + base + 2 * F + cf[r]);
                 }
             }
             pdv[h] = pd;
@@ -487,14 +494,13 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_bwd(const AtpBwdK p) {
             const int s = p.src[k];
             e_n = p.eid[k];
 #pragma unroll
-            for (int r = 0; r < KR; ++r) {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) { xs_n[r][v] = 0.f; re_n[r][v] = 0.f; }
-                if (aF[r]) load_vec<VEC>(xs_n[r], p.x + static_cast<int64_t>(s) * F + cf[r]);
-                if (aR[r]) load_vec<VEC>(re_n[r], p.ee + static_cast<int64_t>(e_n) * R + cf[r]);
+            for (int r = 0; r < KR; ++r) {                              // lanes past F / R: garbage x 0 (their g_V terms are zeroed)
+                load_vec<VEC>(xs_n[r], p.x + static_cast<int64_t>(s) * F + cfF[r]);
+                load_vec<VEC>(re_n[r], p.ee + static_cast<int64_t>(e_n) * R + cfR[r]);
             }
-            sg_n = hv ? p.sigma[static_cast<int64_t>(k) * H + myh] : 0.f;
-            kf_n = (hv && p.keep) ? p.keep[static_cast<int64_t>(k) * H + myh] : 1.f;
+            const int mh = hv ? myh : h0;
+            sg_n = p.sigma[static_cast<int64_t>(k) * H + mh];
+            kf_n = p.keep ? p.keep[static_cast<int64_t>(k) * H + mh] : 1.f;
         };
         if (beg < end) fetch_edge(beg);
         for (int k = beg; k < end; ++k) {
