@@ -616,18 +616,35 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_src(const AtpSrcK p) {
     }
     float gs = 0.f;
     const int beg = p.rowptr_src[node], end = p.rowptr_src[node + 1];
-    for (int k = beg; k < end; ++k) {
-        const int slot = p.slot_by_src[k];
-        if (lane < H) gs += p.gsigma[static_cast<int64_t>(slot) * H + lane];
-        if (p.g_x) {
+    // four edges per iteration, every load issued before the first use and branch free (slots past the row re-read its
+    // last slot and are skipped at the accumulate; lanes past F / H read column 0 / head 0 and are never stored)
+    constexpr int U = 4;
+    const int hl = lane < H ? lane : 0;
+    for (int k0 = beg; k0 < end; k0 += U) {
+        int slot[U];
 #pragma unroll
-            for (int r = 0; r < KR; ++r) {
-                const int c = (r * 64 + lane) * VEC;
-                if (c < F) {
-                    float t[VEC];
-                    load_vec<VEC>(t, p.Gxs + static_cast<int64_t>(slot) * F + c);
+        for (int u = 0; u < U; ++u) slot[u] = p.slot_by_src[min(k0 + u, end - 1)];
+        float g4[U], t[U][KR][VEC];
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc[r][v] += t[v];
+        for (int u = 0; u < U; ++u) {
+            g4[u] = p.gsigma[static_cast<int64_t>(slot[u]) * H + hl];
+            if (p.g_x) {                                                    // uniform
+#pragma unroll
+                for (int r = 0; r < KR; ++r) {
+                    const int c = (r * 64 + lane) * VEC;
+                    load_vec<VEC>(t[u][r], p.Gxs + static_cast<int64_t>(slot[u]) * F + (c < F ? c : 0));
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (k0 + u < end) {                                              // uniform; fixed summation order
+                gs += g4[u];
+                if (p.g_x) {
+#pragma unroll
+                    for (int r = 0; r < KR; ++r)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[r][v] += t[u][r][v];
                 }
             }
         }
