@@ -357,6 +357,121 @@ __global__ void __launch_bounds__(256) k_propagate_fwd_w(const PropK p) {
     }
 }
 
+// ------------------------------------------------------------------------------- P2 forward, staged form
+// One workgroup = ONE graph, one wave per 16 channels (state in registers as MFMA A-fragments, as in the wave form), but
+// A_l is no longer fetched fragment by fragment (16 rows x 64 bytes per instruction, once per wave: PMC showed the texture
+// path 59 % busy and 49 % L2 hits).  It is streamed ONCE per graph through a ring of three LDS slabs of 16 rows (= one
+// column tile of the output) by the LDS-DMA path in full 1 KiB pieces; all waves read their B fragments from the slab.
+// Raw s_barrier + counted vmcnt keep two slabs in flight across each barrier.  Slab rows are 16 bytes longer than S
+// floats, which puts the 16 rows of a ds_read_b128 on distinct bank groups and keeps the image lane-linear (37 slots of
+// 16 bytes per row at S = 144; the extra slot is filled with a don't-care load).  Needs S % 16 == 0.
+template <int NT>
+__global__ void __launch_bounds__(1024) k_propagate_fwd_s(const PropK p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int S = p.S, pitch = p.pitch;                              // pitch = S + 4 floats
+    const int rowb = (S + 4) * 4, slots_per_row = (S + 4) / 4;       // slab row in bytes / in 16-byte slots
+    const int slab_bytes = 16 * rowb, slab_slots = 16 * slots_per_row;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;                                  // = channel groups of the graph
+    const int b = blockIdx.x, m = wave;
+    unsigned char* ring = smem;                                      // [3][16][rowb]
+    float* scr = reinterpret_cast<float*>(smem + 3 * slab_bytes) + static_cast<int64_t>(wave) * 16 * pitch;
+    const int li = lane & 15, lq = lane >> 4;
+    const int cmine = 16 * m + li;
+    const int ndma = (slab_slots + 63) / 64;                         // DMA instructions per slab (10 at S = 144)
+    const int my_dma = (ndma - wave + nw - 1) / nw;                  // this wave's share: instructions wave, wave + nw, ...
+    const int steps = p.L * NT;
+
+    float af[NT][4];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) {
+        const int k = 16 * s + 4 * lq;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[s][t] = (cmine < p.C) ? p.h0[b * p.h0_bs + static_cast<int64_t>(cmine) * S + k + t] : 0.f;
+    }
+    // slab g = rows 16 (g % NT) .. +15 of A_{g / NT}
+    auto dma_slab = [&](int g) {
+        const float* A = p.adj[g / NT] + static_cast<int64_t>(b) * S * S + static_cast<int64_t>(16 * (g % NT)) * S;
+        unsigned char* dst = ring + (g % 3) * slab_bytes;
+        for (int i = wave; i < ndma; i += nw) {
+            const int slot = 64 * i + lane;
+            if (slot < slab_slots) {
+                const int row = slot / slots_per_row, sl = slot % slots_per_row;
+                const float* src = A + static_cast<int64_t>(row) * S + 4 * (sl < S / 4 ? sl : 0);      // last slot of a row: padding
+                // issued as inline asm: through the builtin the compiler knows an LDS-DMA is in flight and waits vmcnt(0) before
+                // the next ds_read of the ring (it cannot tell the slots apart), which would serialise the whole pipeline.
+                // Hidden from its counters the DMA only makes the compiler's own vmcnt waits more conservative (in-order
+                // completion); the waits that matter for the ring are the explicit ones below.
+                const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(
+                    static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void*)(dst + 1024 * i))));
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "m0", "memory");
+            }
+        }
+    };
+    // the h0 loads must be complete BEFORE the loop: otherwise their s_waitcnt vmcnt(0) sits at the first MFMA inside the loop
+    // body, where it would drain the DMA pipeline in every iteration
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    dma_slab(0);
+    if (steps > 1) dma_slab(1);
+    f32x4 acc0, acc1;
+    for (int g = 0; g < steps; ++g) {
+        const int nt = g % NT, l = g / NT;
+        // this wave's pieces of slab g have landed (the pieces of slab g+1 may still fly), then everybody's have
+        if (g + 1 < steps) {
+            if (my_dma >= 3) __builtin_amdgcn_s_waitcnt(0x0f70 | 0);            // conservative for unusual shapes: vmcnt(0)
+            else if (my_dma == 2) __builtin_amdgcn_s_waitcnt(0x0f70 | 2);       // vmcnt(2)
+            else if (my_dma == 1) __builtin_amdgcn_s_waitcnt(0x0f70 | 1);
+            else __builtin_amdgcn_s_waitcnt(0x0f70 | 0);
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0f70 | 0);
+        }
+        __builtin_amdgcn_s_barrier();
+        if (g + 2 < steps) dma_slab(g + 2);                          // its ring slot was last read in step g-1: everyone is past that
+        const unsigned char* slab = ring + (g % 3) * slab_bytes + li * rowb + lq * 16;
+        acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc0;
+        float4 bq[NT];
+#pragma unroll
+        for (int s = 0; s < NT; ++s) bq[s] = *reinterpret_cast<const float4*>(slab + 64 * s);
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            f32x4& a = (s & 1) ? acc1 : acc0;
+            a = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][0], bq[s].x, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][1], bq[s].y, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][2], bq[s].z, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][3], bq[s].w, a, 0, 0, 0);
+        }
+        // C layout: col (s) = lane&15, row (channel) = (lane>>4)*4 + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) scr[(4 * lq + r) * pitch + 16 * nt + li] = act_fwd(acc0[r] + acc1[r], p.act);
+        if (nt == NT - 1) {                                          // hop finished: wave-private epilogue, as in the wave form
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < NT; ++s) {
+                const float4 v = *reinterpret_cast<const float4*>(scr + li * pitch + 16 * s + 4 * lq);
+                af[s][0] = v.x; af[s][1] = v.y; af[s][2] = v.z; af[s][3] = v.w;
+            }
+            for (int idx = lane; idx < 16 * p.dd; idx += 64) {       // relation_l = gather(h, heads) * gather(h, tails)
+                const int cl = idx / p.dd, x = idx % p.dd;
+                const int c = 16 * m + cl;
+                if (c < p.C) {
+                    const int64_t io = b * p.idx_bs + static_cast<int64_t>(c) * p.dd + x;
+                    const int hi = static_cast<int>(p.head[io]), ti = static_cast<int>(p.tail[io]);
+                    p.out[(static_cast<int64_t>(b) * p.C + c) * (p.L * p.dd) + l * p.dd + x] = scr[cl * pitch + hi] * scr[cl * pitch + ti];
+                }
+            }
+            if (p.hsave) {
+                float* hs = p.hsave + ((static_cast<int64_t>(l) * p.B + b) * p.C) * S;
+                for (int cl = 0; cl < 16 && 16 * m + cl < p.C; ++cl)
+                    for (int sidx = lane; sidx < S; sidx += 64) hs[static_cast<int64_t>(16 * m + cl) * S + sidx] = scr[cl * pitch + sidx];
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- P2 backward (one hop per launch)
 struct PropBwdK {
     const float* A;           // adj of this hop [B,S,S]
@@ -591,6 +706,18 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
     p.CC = g.CC; p.Sp = g.Sp; p.pitch = g.pitch;
     hipStream_t st = as_stream(stream);
     const int NTn = g.Sp / 16;
+    const int mtn_s = (a->C + 15) / 16;
+    if (NTn <= 9 && (a->S % 16) == 0 && v4 && mtn_s <= 16 && g.pitch == a->S + 4 && getenv("RECON_PROP_FWD") && getenv("RECON_PROP_FWD")[0] == 's') {   // staged form
+        const size_t slds = 3ull * 16 * (a->S + 4) * sizeof(float) + static_cast<size_t>(mtn_s) * 16 * g.pitch * sizeof(float);
+#define CALL_S(N_) do { if (slds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_fwd_s<N_>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(slds)); \
+                        hipLaunchKernelGGL((k_propagate_fwd_s<N_>), dim3(static_cast<unsigned>(a->B)), dim3(64 * mtn_s), slds, st, p); } while (0)
+        switch (NTn) { case 1: CALL_S(1); break; case 2: CALL_S(2); break; case 3: CALL_S(3); break; case 4: CALL_S(4); break;
+                       case 5: CALL_S(5); break; case 6: CALL_S(6); break; case 7: CALL_S(7); break; case 8: CALL_S(8); break;
+                       default: CALL_S(9); break; }
+#undef CALL_S
+        RECON_CHECK_LAUNCH();
+        return RECON_OK;
+    }
     if (NTn <= 9 && !(getenv("RECON_PROP_FWD") && getenv("RECON_PROP_FWD")[0] == 'b')) {      // wave-independent form
         const int64_t units = 1LL * a->B * ((a->C + 15) / 16);
         dim3 wgrid(static_cast<unsigned>(ceil_div64(units, 4)));
