@@ -390,9 +390,13 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
     const int bz = blockIdx.y;
     const int row = static_cast<int>(idx / N), col = static_cast<int>(idx % N);
     const float* pz = partial + static_cast<int64_t>(bz) * splits * MN;
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += pz[z * MN + idx];
-    C.base[bz * c_bs + out_row_off(C, row) + minor_off(C.Dseg, C.Sseg, col)] = gemm_epilogue(s, epilogue);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                      // four interleaved chains, combined in a fixed order
+    int z = 0;
+    for (; z + 4 <= splits; z += 4) {
+        s0 += pz[z * MN + idx]; s1 += pz[(z + 1) * MN + idx]; s2 += pz[(z + 2) * MN + idx]; s3 += pz[(z + 3) * MN + idx];
+    }
+    for (; z < splits; ++z) s0 += pz[z * MN + idx];
+    C.base[bz * c_bs + out_row_off(C, row) + minor_off(C.Dseg, C.Sseg, col)] = gemm_epilogue((s0 + s1) + (s2 + s3), epilogue);
 }
 
 // transposing form: out(row n, col m) = epilogue(sum_z partial[z][m][n]); 32 x 32 tiles through LDS so that both the
@@ -404,14 +408,22 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_t(const float* __restrict
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int64_t MN = static_cast<int64_t>(M) * N;
     const float* pz = partial + static_cast<int64_t>(bz) * splits * MN;
+    // split index outermost: the four rows of a thread are four independent load / add chains (fixed order per element)
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int64_t off[4];
+    bool ok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + ty + 8 * i, n = n0 + tx;
-        float s = 0.f;
-        if (m < M && n < N)
-            for (int z = 0; z < splits; ++z) s += pz[z * MN + static_cast<int64_t>(m) * N + n];
-        tile[ty + 8 * i][tx] = s;
+        ok[i] = m < M && n < N;
+        off[i] = ok[i] ? static_cast<int64_t>(m) * N + n : 0;
     }
+    for (int z = 0; z < splits; ++z) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += pz[z * MN + off[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = ok[i] ? acc[i] : 0.f;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
