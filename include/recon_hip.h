@@ -222,9 +222,12 @@ int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp_bwd_args* 
  * ------------------------------------------------------------------------------------------*/
 int recon_block_adjacency_fwd(const float* T, const float* identity, int32_t B, int32_t n, int32_t dd,
                               float* A /*[B,S,S]*/, recon_stream_t stream);
-/* gT [B,n(n-1),dd*dd] and g_identity [dd,dd] (either may be NULL) from gA [B,S,S] */
+/* gT [B,n(n-1),dd*dd] and g_identity [dd,dd] (either may be NULL) from gA [B,S,S]; `workspace`
+ * (recon_block_adjacency_bwd_workspace_floats() floats) holds the per-slice partial sums of g_identity, which
+ * is reduced in a fixed order (required when g_identity is not NULL). */
+size_t recon_block_adjacency_bwd_workspace_floats(int32_t B, int32_t n, int32_t dd);
 int recon_block_adjacency_bwd(const float* gA, int32_t B, int32_t n, int32_t dd, float* gT, float* g_identity,
-                              recon_stream_t stream);
+                              float* workspace, recon_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * P2 / K5  L-hop gated propagation + head*tail gather (models/models.py:260-274; copies :470-485,

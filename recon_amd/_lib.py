@@ -101,7 +101,8 @@ SYMBOLS = [
     ("recon_gat_atp_bwd", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatAtpBwdArgs), C.c_void_p]),
     ("recon_gat_atp_bwd_phase", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatAtpBwdArgs), C.c_int32, C.c_void_p]),
     ("recon_block_adjacency_fwd", C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_void_p]),
-    ("recon_block_adjacency_bwd", C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_void_p]),
+    ("recon_block_adjacency_bwd_workspace_floats", C.c_size_t, [C.c_int32] * 3),
+    ("recon_block_adjacency_bwd", C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     ("recon_propagate_fwd", C.c_int, [C.POINTER(PropArgs), C.c_void_p]),
     ("recon_propagate_bwd", C.c_int, [C.POINTER(PropBwdArgs), C.c_void_p]),
     ("recon_start_entity_embeddings", C.c_int, [c_f32p, c_i64p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,

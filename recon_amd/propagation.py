@@ -92,9 +92,12 @@ class _BlockAdjacency(torch.autograd.Function):
         gA = gA.contiguous()
         gT = torch.empty(tshape, dtype=torch.float32, device=gA.device) if ctx.needs_input_grad[0] else None
         gI = torch.empty(dd, dd, dtype=torch.float32, device=gA.device) if ctx.needs_input_grad[1] else None
+        L = _lib.lib()
+        ws = (torch.empty(L.recon_block_adjacency_bwd_workspace_floats(B, n, dd), dtype=torch.float32, device=gA.device)
+              if gI is not None else None)
         with torch.cuda.device(gA.device):
-            _lib.check(_lib.lib().recon_block_adjacency_bwd(gA.data_ptr(), B, n, dd, _lib.ptr(gT), _lib.ptr(gI),
-                                                            _lib.current_stream()), "recon_block_adjacency_bwd")
+            _lib.check(L.recon_block_adjacency_bwd(gA.data_ptr(), B, n, dd, _lib.ptr(gT), _lib.ptr(gI), _lib.ptr(ws),
+                                                   _lib.current_stream()), "recon_block_adjacency_bwd")
         return gT, gI, None
 
 
