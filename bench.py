@@ -160,7 +160,7 @@ def main():
             Z = torch.empty(N, H, **f32)
             Zk = torch.empty(N, H, **f32)
             from recon_amd.gat_layers import _atp_split_buffer
-            a_split = _atp_split_buffer(F_, R, D, H, dev)
+            a_split = _atp_split_buffer(F_, R, D, H, dev, N)
             fa = _atp_args(graph, xd.detach(), eed.detach(), a, a2, None, u, c_node, c_rel, V, sigma, Z, Zk, out, 0.2, True, a_split)
             stages = (L.recon_gat_atp_scores, L.recon_gat_atp_aggregate, L.recon_gat_atp_project)
             # compulsory traffic of the aggregation kernel: x and edge_embed rows once, score terms, CSR, V out,

@@ -27,9 +27,12 @@ _GAT_PATH = os.environ.get("RECON_GAT_PATH", "auto")
 # edge chain.  Off by default: measured neutral on MI355X (0.927 vs 0.922 ms/step at cfg 2) because the GEMM's
 # 4 waves/SIMD x 128 registers leave no register file for co-resident edge-kernel waves.
 _OVERLAP = os.environ.get("RECON_OVERLAP", "0") == "1"
-# RECON_GEMM_BX3=0: run the projection and its input-gradient product on the fp32 MFMA GEMM instead of the
-# split-precision (3 x bf16 terms, fp32-accurate) one of csrc/gemm_bx3.hip
-_GEMM_BX3 = os.environ.get("RECON_GEMM_BX3", "1")
+# The layer's three large products run on the split-precision GEMMs of csrc/gemm_bx3.hip (3 bf16 terms per fp32 operand,
+# fp32-accurate) when they are large enough to pay for the extra launches (term planes of a, a^T, g_h): measured cross-over
+# on MI355X at cfg-2 widths is 192..256 graphs, i.e. ~6 GFLOP per product.  RECON_GEMM_BX3 = auto (default) | 1 (always) |
+# 0 (never: exact-fp32 MFMA GEMMs).
+_GEMM_BX3 = os.environ.get("RECON_GEMM_BX3", "auto")
+_BX3_MIN_FLOP = 6.0e9
 _SIDE_STREAMS = {}
 
 
@@ -231,9 +234,12 @@ def _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out,
                            out.data_ptr(), out.shape[1], _lib.ptr(a_split))
 
 
-def _atp_split_buffer(F_, R, D, H, dev):
-    """Workspace of the split-precision GEMMs (bf16 term planes of a and a^T); RECON_GEMM_BX3=0 keeps fp32 MFMA."""
+def _atp_split_buffer(F_, R, D, H, dev, N=None):
+    """Workspace of the split-precision GEMMs (bf16 term planes of a and a^T), or None to stay on the fp32-MFMA GEMMs
+    (RECON_GEMM_BX3=0, or a product too small to pay for the extra launches)."""
     if _GEMM_BX3 == "0":
+        return None
+    if _GEMM_BX3 != "1" and N is not None and 2.0 * N * (2 * F_ + R) * H * D < _BX3_MIN_FLOP:
         return None
     return torch.empty(_lib.lib().recon_gat_atp_split_bytes(F_, R, D, H), dtype=torch.uint8, device=dev)
 
@@ -266,7 +272,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         Zk = torch.empty(N, H, **f32) if train else None
         if keep is not None:
             keep = keep.view(H, E)[:, graph.eid_long].t().contiguous()        # [H,E] original order -> [E,H] slot order
-        a_split = _atp_split_buffer(F_, R, D, H, dev)
+        a_split = _atp_split_buffer(F_, R, D, H, dev, N)
         args = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split)
         with torch.cuda.device(dev):
             _lib.check(L.recon_gat_atp_fwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_atp_fwd")

@@ -33,3 +33,14 @@ def hashed_uniform(shape, salt, lo=-1.0, hi=1.0):
     i ^= i >> np.uint64(13)
     u = (i >> np.uint64(8)).astype(np.float64) / float(1 << 24)
     return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
+
+
+@pytest.fixture(autouse=True)
+def _gpu_tests_force_split_precision_gemms(request, monkeypatch):
+    """The layer picks its GEMM family by problem size (split-precision bf16 x 3 above ~6 GFLOP per product, exact-fp32 MFMA
+    below).  The golden cases are small, so GPU tests force the split-precision family on — it is the one the benchmark
+    runs — and individual tests switch it off where they compare the two (RECON_GEMM_BX3 semantics, gat_layers.py)."""
+    if request.node.get_closest_marker("gpu") is not None:
+        from recon_amd import gat_layers
+        monkeypatch.setattr(gat_layers, "_GEMM_BX3", "1")
+    yield
