@@ -42,7 +42,8 @@ class _GcnFunction(torch.autograd.Function):
         sup = torch.empty(B, n, O, dtype=torch.float32, device=dev)
         out = torch.empty(B, n, O, dtype=torch.float32, device=dev)
         w_split = None
-        if os.environ.get("RECON_GEMM_BX3", "1") != "0":      # split-precision GEMMs (fp32-accurate, csrc/gemm_bx3.hip)
+        mode = os.environ.get("RECON_GEMM_BX3", "auto")       # split-precision GEMMs (fp32-accurate, csrc/gemm_bx3.hip): auto | 1 | 0
+        if mode == "1" or (mode != "0" and 2.0 * B * n * I * O >= 2.0e9):    # small products do not pay for the term-plane launches
             w_split = torch.empty(_lib.lib().recon_gcn_split_bytes(I, O), dtype=torch.uint8, device=dev)
         args = _lib.GcnArgs(B, n, I, O, x3.data_ptr(), adj3.data_ptr(), weight.data_ptr(), _lib.ptr(bias),
                             sup.data_ptr(), out.data_ptr(), _lib.ptr(w_split))
