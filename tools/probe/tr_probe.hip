@@ -1,4 +1,4 @@
-// Probe of ds_read_b64_tr_b16 semantics: every lane passes the address of 4 contiguous 16-bit elements
+// Probe of ds_read_b64_tr_b16 semantics (build: hipcc --offload-arch=gfx950 -O2 tr_probe.hip -o tr_probe; run on the GPU box): every lane passes the address of 4 contiguous 16-bit elements
 // (row i'>>2, column quad i'&3 of a [4][16] block with row stride S); prints what each lane receives.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
