@@ -474,3 +474,26 @@ def test_training_edge_shapes(N, E, F_, R, D, H):
     for name, u, v in zip(("g_x", "g_edge_embed", "g_a", "g_a_2"), grads, rg):
         if v.numel():
             close(u, v, atol=1e-4, rel_to_max=1e-4, what=name)
+
+
+def test_phased_backward_on_two_streams_matches(monkeypatch):
+    """recon_gat_atp_bwd_phase (PREPARE -> {INPUTS | WEIGHTS on a side stream} -> FINISH) produces exactly what the
+    single-call backward does."""
+    from recon_amd import gat_layers
+    from recon_amd.graph import prepare_graph
+    N, E, F_, R, D, H = 300, 1200, 40, 24, 48, 4
+    g = torch.Generator().manual_seed(3)
+    x, ee = torch.randn(N, F_, generator=g), torch.randn(E, R, generator=g)
+    edge = torch.randint(0, N, (2, E), generator=g)
+    a, a2 = torch.randn(H, D, 2 * F_ + R, generator=g) * 0.1, torch.randn(H, D, generator=g) * 0.1
+    G = torch.randn(N, H * D, generator=g).to(dev())
+    graph = prepare_graph(edge.to(dev()), None, N)
+    res = []
+    for overlap in (False, True):
+        monkeypatch.setattr(gat_layers, "_OVERLAP", overlap)
+        leaves = [t.to(dev()).requires_grad_(True) for t in (x, ee, a, a2)]
+        out = gat_layers.gat_heads(*leaves, graph, None, 0.2, True)
+        res.append([t.detach().clone() for t in torch.autograd.grad(out, leaves, G)])
+        torch.cuda.synchronize()
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
