@@ -247,12 +247,14 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_bx3(const Bx3Args p) {
 
 // The same product for k-MAJOR operands — the weight gradient g_a^T = V^T g_h, whose K is the node dimension:
 //   A  fp32 [K][M] (m contiguous), split on the fly;   B  pre-split bf16 planes [3][K][ldb] (n contiguous).
-// Both tiles are staged through registers into ROW-MAJOR LDS images [k][m] / [k][n] exactly as they lie in memory
+// Both tiles are staged (A through registers, B by LDS-DMA) into ROW-MAJOR LDS images [k][m] / [k][n] as they lie in memory
 // (A: four float4 -> 3 x ds_write_b64 each; B: ten 16-byte copies), and the MFMA fragments — 8 consecutive k for one
 // m — come out of LDS through the transposing read ds_read_b64_tr_b16 (16 lanes read a [4 k][16 m] block, lane i
 // receives column i), two reads per fragment.  Bank layout: A rows are 256 B = 8 chunks of 32 B, chunk index XORed
-// with (k&3 | (k>>3&1)<<2); B rows are 416 B = 26 slots of 16 B, rotated by 8 slots when k & 8 — in both images the
-// 8 rows one transposing read touches per 32 lanes land on disjoint bank groups.
+// with (k&3 | (k>>3&1)<<2); B rows are 28 slots of 16 B, shifted by 2 slots when k & 8 — in both images the
+// 8 rows one transposing read touches per 32 lanes land on disjoint bank groups (B: 28 slots per row — two of them
+// padding — rotated by 2 slots when k & 8: found conflict-free for every column tile by exhaustive check; the unpadded
+// 26-slot row with a wrapping rotation left 17 % of the LDS cycles as conflicts).
 // Split-K: every (batch, split) writes its tile to partial[z][M][N]; the caller reduces (and here transposes).
 struct Bx3KmArgs {
     const float* A; const __bf16* Bp;
@@ -264,7 +266,8 @@ struct Bx3KmArgs {
 
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using i16x4 = __attribute__((ext_vector_type(4))) short;
-constexpr int KA_PLANE = BK * 256, KB_PLANE = BK * 416;            // bytes per plane of the A / B image
+constexpr int KB_SLOTS = 28;                                       // 16-byte slots per B image row: 26 of data + 2 of padding
+constexpr int KA_PLANE = BK * 256, KB_PLANE = BK * KB_SLOTS * 16;  // bytes per plane of the A / B image
 
 __device__ __forceinline__ int ka_h(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
@@ -294,17 +297,17 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_bx3_kmajor(const Bx3KmArgs p) {
         aptr[i] = p.A + bz * p.a_bs + min(m0 + 4 * mq, p.M - 4);
         a_lds[i] = k * 256 + (((mq >> 2) ^ ka_h(k)) << 5) + ((mq & 3) << 3);
     }
-    // ---- B: LDS-DMA, no staging registers.  Piece pc = 4 i + wave (39 pieces of 64 slots: 13 per plane) lands lane-linear
-    //      at slot s = 64 (pc % 13) + lane of its plane = (k = s / 26, physical slot s % 26); the rotation of the image is
-    //      applied on the source side: the physical slot holds logical slot (phys - 8 [k & 8]) mod 26.
-    constexpr int KB_DMA = 10;
+    // ---- B: LDS-DMA, no staging registers.  Piece pc = 4 i + wave (42 pieces of 64 slots: 14 per plane) lands lane-linear
+    //      at slot s = 64 (pc % 14) + lane of its plane = (k = s / 28, physical slot s % 28); the rotation of the image is
+    //      applied on the source side: the physical slot holds logical slot phys - 2 [k & 8] (padding slots read slot 0).
+    constexpr int KB_PIECES = 3 * (BK * KB_SLOTS / 64), KB_DMA = (KB_PIECES + 3) / 4;     // 42, 11
     int b_goff[KB_DMA], b_k[KB_DMA];
 #pragma unroll
     for (int i = 0; i < KB_DMA; ++i) {
-        const int pc = min(4 * i + wid, 38);
-        const int s = 64 * (pc % 13) + lane, k = s / 26, phys = s % 26;
-        int slot = phys - ((k & 8) ? 8 : 0);
-        if (slot < 0) slot += 26;
+        const int pc = min(4 * i + wid, KB_PIECES - 1);
+        const int s = 64 * (pc % (KB_PIECES / 3)) + lane, k = s / KB_SLOTS, phys = s % KB_SLOTS;
+        int slot = phys - ((k & 8) ? 2 : 0);
+        if (slot < 0 || slot >= 26) slot = 0;
         b_k[i] = k;
         b_goff[i] = min(n0 + 8 * slot, p.n_ld - 8);
     }
@@ -312,11 +315,11 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_bx3_kmajor(const Bx3KmArgs p) {
     auto dma_b = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < KB_DMA; ++i)
-            if (4 * i + wid < 39) {                                       // wave-uniform
+            if (4 * i + wid < KB_PIECES) {                                // wave-uniform
                 const int pc = 4 * i + wid;
-                const __bf16* q = bbase + (pc / 13) * p.b_plane + static_cast<int64_t>(min(k0 + b_k[i], k_end - 1)) * p.ldb + b_goff[i];
+                const __bf16* q = bbase + (pc / (KB_PIECES / 3)) * p.b_plane + static_cast<int64_t>(min(k0 + b_k[i], k_end - 1)) * p.ldb + b_goff[i];
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(q),
-                                                 (__attribute__((address_space(3))) void*)(Bs + (pc / 13) * KB_PLANE + 1024 * (pc % 13)), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(Bs + (pc / (KB_PIECES / 3)) * KB_PLANE + 1024 * (pc % (KB_PIECES / 3))), 16, 0, 0);
             }
     };
 
@@ -372,14 +375,11 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_bx3_kmajor(const Bx3KmArgs p) {
         const int k = 8 * g + 4 * hh + (ip >> 2);
 #pragma unroll
         for (int i = 0; i < 2; ++i) a_off[i][hh] = k * 256 + (((2 * wid + i) ^ ka_h(k)) << 5) + ((ip & 3) << 3);
-        b_row[hh] = k * 416 + (((ip & 3) & 1) << 3);
+        b_row[hh] = k * (KB_SLOTS * 16) + (((ip & 3) & 1) << 3);
         b_rot[hh] = (k & 8) != 0;
     }
-    auto b_off = [&](int j, int hh) {                                 // column tile j: slot 2 j + ((ip & 3) >> 1), rotated by 8 (mod 26) when k & 8
-        const int slot = 2 * j + ((ip & 3) >> 1);
-        int phys = slot + (b_rot[hh] ? 8 : 0);
-        if (phys >= 26) phys -= 26;
-        return b_row[hh] + phys * 16;
+    auto b_off = [&](int j, int hh) {                                 // column tile j: slot 2 j + ((ip & 3) >> 1), shifted by 2 when k & 8
+        return b_row[hh] + (2 * j + ((ip & 3) >> 1) + (b_rot[hh] ? 2 : 0)) * 16;
     };
     auto mma_tile = [&]() {
         bf16x8 a[2][3];
