@@ -497,3 +497,4 @@ def test_phased_backward_on_two_streams_matches(monkeypatch):
         torch.cuda.synchronize()
     for u, v in zip(*res):
         assert torch.equal(u, v)
+
