@@ -828,97 +828,53 @@ extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t
 // ------------------------------------------------------------------------------- P5 / K6 GraphConvolution
 namespace {
 
-// Y[b][i][o] = epilogue( sum_j M[i][j] * Xin[b][j][o] ),  M = adj[b] (TRANS = false) or adj[b]^T (TRANS = true).
-// Block = (graph, 64-column tile); thread = one column x 4 consecutive rows per pass.
+// Y[b][i][o] = epilogue( sum_j M[i][j] * Xin[b][j][o] ),  M = adj[b] (TRANS = false) or adj[b]^T (TRANS = true), on the
+// matrix cores (v_mfma_f32_16x16x4_f32).  Block = (64-column tile, graph, 32-row tile); wave w owns 16 columns and both
+// 16-row tiles; the contraction index is walked in chunks of 32 through LDS, so any n is accepted (n <= 32, the
+// reference's regime, is one chunk and one row tile).
 // MASK: Xin = gout * (fwd_out > 0)   (ReLU backward folded into the load)
 // EPI : + bias, ReLU
-template <bool TRANS, bool MASK, bool EPI>
-__global__ void __launch_bounds__(256) k_gcn_aggregate(const float* __restrict__ adj, const float* __restrict__ Xin,
-                                                       const float* __restrict__ fwd_out, const float* __restrict__ bias,
-                                                       int32_t n, int32_t O, float* __restrict__ Y) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int np = (n + 3) / 4 * 4;
-    float* MT_ = lds;                       // [n][np]  MT_[j][i] = M[i][j]
-    float* Xs = lds + n * np;               // [n][64]
-    const int b = blockIdx.y, o0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const float* A = adj + static_cast<int64_t>(b) * n * n;
-    for (int idx = threadIdx.x; idx < n * np; idx += 256) {
-        const int j = idx / np, i = idx % np;
-        MT_[idx] = (i < n) ? (TRANS ? A[j * n + i] : A[i * n + j]) : 0.f;
-    }
-    for (int idx = threadIdx.x; idx < n * 64; idx += 256) {
-        const int j = idx / 64, o = o0 + (idx & 63);
-        float v = 0.f;
-        if (o < O) {
-            const int64_t g = (static_cast<int64_t>(b) * n + j) * O + o;
-            v = Xin[g];
-            if constexpr (MASK) v = fwd_out[g] > 0.f ? v : 0.f;
-        }
-        Xs[idx] = v;
-    }
-    __syncthreads();
-    const int o = o0 + tx;
-    for (int i0 = ty * 4; i0 < n; i0 += 16) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < n; ++j) {
-            const float x = Xs[j * 64 + tx];
-            const float4 m = *reinterpret_cast<const float4*>(MT_ + j * np + i0);
-            acc[0] = fmaf(m.x, x, acc[0]); acc[1] = fmaf(m.y, x, acc[1]);
-            acc[2] = fmaf(m.z, x, acc[2]); acc[3] = fmaf(m.w, x, acc[3]);
-        }
-        if (o < O) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (i0 + r < n) {
-                    float v = acc[r];
-                    if constexpr (EPI) { if (bias) v += bias[o]; v = v > 0.f ? v : 0.f; }
-                    Y[(static_cast<int64_t>(b) * n + i0 + r) * O + o] = v;
-                }
-            }
-        }
-    }
-}
-
-// The same product for n <= 32 on the matrix cores: Y[b] (32 x 64 tile) = M (32 x 32, zero padded) . X (32 x 64) with
-// v_mfma_f32_16x16x4_f32; wave w owns 16 columns and both 16-row tiles.  The VALU form above spends two LDS reads per
-// four FMAs and is LDS-issue bound (37 us at cfg 3a for 80 MB of traffic).  LDS images are k-major with pitches
-// = 16 (mod 32) floats, so the two k groups a 32-lane read touches fall on disjoint banks.
+// LDS images are k-major with pitches = 16 (mod 32) floats, so the two k groups a 32-lane read touches fall on disjoint
+// banks.  (A VALU form with two LDS reads per four FMAs was LDS-issue bound: 37 us at cfg 3a for 80 MB of traffic.)
 template <bool TRANS, bool MASK, bool EPI>
 __global__ void __launch_bounds__(256) k_gcn_aggregate_mfma(const float* __restrict__ adj, const float* __restrict__ Xin,
                                                             const float* __restrict__ fwd_out, const float* __restrict__ bias,
                                                             int32_t n, int32_t O, float* __restrict__ Y) {
     constexpr int PM = 48, PX = 80;
-    __shared__ float Mk[32 * PM];           // Mk[k][i] = M[i][k]
+    __shared__ float Mk[32 * PM];           // Mk[k][i] = M[i0 + i][k0 + k]
     __shared__ float Xs[32 * PX];           // Xs[k][o]
-    const int b = blockIdx.y, o0 = blockIdx.x * 64;
+    const int b = blockIdx.y, o0 = blockIdx.x * 64, i0 = blockIdx.z * 32;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const float* A = adj + static_cast<int64_t>(b) * n * n;
-    for (int idx = t; idx < 32 * 32; idx += 256) {
-        const int k = idx >> 5, i = idx & 31;
-        float v = 0.f;
-        if (k < n && i < n) v = TRANS ? A[k * n + i] : A[i * n + k];       // M = adj (forward) or adj^T (backward)
-        Mk[k * PM + i] = v;
-    }
-    for (int idx = t; idx < 32 * 64; idx += 256) {
-        const int k = idx >> 6, o = o0 + (idx & 63);
-        float v = 0.f;
-        if (k < n && o < O) {
-            const int64_t g = (static_cast<int64_t>(b) * n + k) * O + o;
-            v = Xin[g];
-            if constexpr (MASK) v = fwd_out[g] > 0.f ? v : 0.f;
-        }
-        Xs[k * PX + (idx & 63)] = v;
-    }
-    __syncthreads();
     const int li = lane & 15, lq = lane >> 4;
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int k0 = 0; k0 < n; k0 += 32) {
+        if (k0) __syncthreads();
+        for (int idx = t; idx < 32 * 32; idx += 256) {
+            const int k = idx >> 5, i = idx & 31;
+            float v = 0.f;
+            if (k0 + k < n && i0 + i < n)
+                v = TRANS ? A[static_cast<int64_t>(k0 + k) * n + i0 + i] : A[static_cast<int64_t>(i0 + i) * n + k0 + k];
+            Mk[k * PM + i] = v;
+        }
+        for (int idx = t; idx < 32 * 64; idx += 256) {
+            const int k = idx >> 6, o = o0 + (idx & 63);
+            float v = 0.f;
+            if (k0 + k < n && o < O) {
+                const int64_t g = (static_cast<int64_t>(b) * n + k0 + k) * O + o;
+                v = Xin[g];
+                if constexpr (MASK) v = fwd_out[g] > 0.f ? v : 0.f;
+            }
+            Xs[k * PX + (idx & 63)] = v;
+        }
+        __syncthreads();
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int k = 4 * s + lq;
-        const float bx = Xs[k * PX + 16 * w + li];
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Mk[k * PM + li], bx, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Mk[k * PM + 16 + li], bx, acc[1], 0, 0, 0);
+        for (int s = 0; s < 8; ++s) {
+            const int k = 4 * s + lq;
+            const float bx = Xs[k * PX + 16 * w + li];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Mk[k * PM + li], bx, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Mk[k * PM + 16 + li], bx, acc[1], 0, 0, 0);
+        }
     }
     const int o = o0 + 16 * w + li;                                 // C layout: col = lane & 15, row = (lane >> 4) * 4 + r
     if (o < O) {
@@ -927,7 +883,7 @@ __global__ void __launch_bounds__(256) k_gcn_aggregate_mfma(const float* __restr
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = 16 * tt + 4 * lq + r;
+                const int i = i0 + 16 * tt + 4 * lq + r;
                 if (i < n) {
                     float v = acc[tt][r];
                     if constexpr (EPI) { v += bv; v = v > 0.f ? v : 0.f; }
@@ -973,12 +929,9 @@ __global__ void __launch_bounds__(256) k_gcn_bias_partial(const float* __restric
 int check_gcn(const recon_gcn_args* a) {
     if (!a || a->B < 0 || a->n <= 0 || a->in_features <= 0 || a->out_features <= 0) return RECON_ERR_INVALID;
     if (!a->x || !a->adj || !a->weight || !a->support || !a->out) return RECON_ERR_INVALID;
-    if (a->B > 65535) return RECON_ERR_UNSUPPORTED;
-    const size_t lds = (static_cast<size_t>(a->n) * ((a->n + 3) / 4 * 4) + static_cast<size_t>(a->n) * 64) * sizeof(float);
-    if (lds > 64 * 1024) return RECON_ERR_UNSUPPORTED;
+    if (a->B > 65535 || a->n > 65535 * 32) return RECON_ERR_UNSUPPORTED;      // grid.y = graphs, grid.z = 32-row tiles
     return RECON_OK;
 }
-size_t gcn_lds(int n) { return (static_cast<size_t>(n) * ((n + 3) / 4 * 4) + static_cast<size_t>(n) * 64) * sizeof(float); }
 constexpr int kBiasBlocks = 1024;
 
 }  // namespace
@@ -1010,13 +963,9 @@ extern "C" int recon_gcn_fwd(const recon_gcn_args* a, recon_stream_t stream) {
     }
     if (rc != RECON_OK) return rc;
     // out = relu(adj @ support + bias)     (models/layers.py:59-63)
-    dim3 grid(static_cast<unsigned>(ceil_div64(O, 64)), static_cast<unsigned>(a->B));
-    if (a->n <= 32)
-        hipLaunchKernelGGL((k_gcn_aggregate_mfma<false, false, true>), grid, dim3(256), 0, st, a->adj, a->support, nullptr, a->bias, a->n, O,
-                           a->out);
-    else
-        hipLaunchKernelGGL((k_gcn_aggregate<false, false, true>), grid, dim3(256), gcn_lds(a->n), st, a->adj, a->support, nullptr, a->bias,
-                           a->n, O, a->out);
+    dim3 grid(static_cast<unsigned>(ceil_div64(O, 64)), static_cast<unsigned>(a->B), static_cast<unsigned>(ceil_div64(a->n, 32)));
+    hipLaunchKernelGGL((k_gcn_aggregate_mfma<false, false, true>), grid, dim3(256), 0, st, a->adj, a->support, nullptr, a->bias, a->n, O,
+                       a->out);
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }
@@ -1044,14 +993,10 @@ extern "C" int recon_gcn_bwd(const recon_gcn_bwd_args* b, recon_stream_t stream)
     if (a->B == 0) return RECON_OK;
     hipStream_t st = as_stream(stream);
     const int32_t rows = a->B * a->n, I = a->in_features, O = a->out_features, n = a->n;
-    dim3 grid(static_cast<unsigned>(ceil_div64(O, 64)), static_cast<unsigned>(a->B));
+    dim3 grid(static_cast<unsigned>(ceil_div64(O, 64)), static_cast<unsigned>(a->B), static_cast<unsigned>(ceil_div64(n, 32)));
     // g_support = adj^T @ (grad_out * (out > 0))
-    if (n <= 32)
-        hipLaunchKernelGGL((k_gcn_aggregate_mfma<true, true, false>), grid, dim3(256), 0, st, a->adj, b->grad_out, a->out, nullptr, n, O,
-                           b->g_support);
-    else
-        hipLaunchKernelGGL((k_gcn_aggregate<true, true, false>), grid, dim3(256), gcn_lds(n), st, a->adj, b->grad_out, a->out, nullptr, n, O,
-                           b->g_support);
+    hipLaunchKernelGGL((k_gcn_aggregate_mfma<true, true, false>), grid, dim3(256), 0, st, a->adj, b->grad_out, a->out, nullptr, n, O,
+                       b->g_support);
     if (b->g_adj)
         hipLaunchKernelGGL(k_gcn_grad_adj, dim3(static_cast<unsigned>(ceil_div64(n * n, 256)), static_cast<unsigned>(a->B)), dim3(256), 0,
                            st, b->grad_out, a->out, a->support, n, O, b->g_adj);

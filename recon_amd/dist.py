@@ -59,9 +59,24 @@ class FlatGradBucket:
             p.grad = None
 
     def pack(self):
-        grads = [p.grad.reshape(-1) if p.grad is not None else v.reshape(-1).zero_()
-                 for p, v in zip(self.params, self.views)]
-        torch.cat(grads, out=self.flat)
+        """Bring every gradient into the flat buffer.  A gradient that already IS its view of the buffer (a second step
+        without zero(), optimizer.zero_grad(set_to_none=False)) stays where it is; a missing one (unused parameter, empty
+        shard) becomes zeros; the rest are copied with one multi-tensor copy.  Never writes through an aliased source, so
+        no rank can fail here while the others wait in the collective."""
+        dst, src = [], []
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() == v.data_ptr() and g.stride() == v.stride() and g.shape == v.shape:
+                continue
+            else:
+                if g.dtype != v.dtype or g.device != v.device or g.shape != v.shape:
+                    g = g.to(device=v.device, dtype=v.dtype).view_as(v)
+                dst.append(v)
+                src.append(g)
+        if dst:
+            torch._foreach_copy_(dst, src)
         for p, v in zip(self.params, self.views):
             p.grad = v
 

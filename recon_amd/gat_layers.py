@@ -140,7 +140,7 @@ _KEY_CACHE = {}
 def _segment_key(index):
     """[2,E] edge-style key (row 0 = segment id; row 1 is ignored by the row sum) for an index tensor; one key
     tensor per index tensor (identity + version) so that prepare_graph's CSR cache hits across steps."""
-    k = (index.data_ptr(), index._version, tuple(index.shape))
+    k = (index.data_ptr(), index._version, tuple(index.shape), tuple(index.stride()))
     hit = _KEY_CACHE.get(k)
     if hit is None:
         if len(_KEY_CACHE) > 16:

@@ -5,16 +5,17 @@ uniform(-1/sqrt(out), 1/sqrt(out)) init) and `SparseMM`, running in csrc/prop.hi
     from recon_amd.gcn_layers import GraphConvolution          # models/models.py:8
 
 Extension over the reference: `forward` also accepts a batch, input [B,n,in] with adj [B,n,n]
-(the reference's torch.mm only takes the 2-D single-graph form)."""
+(the reference's torch.mm only takes the 2-D single-graph form).  Any n is accepted (the aggregate kernel tiles
+the adjacency in 32 x 32 blocks); B <= 65 535 graphs per call."""
 import ctypes as C
 import math
-import os
 
 import torch
 from torch.nn.parameter import Parameter
 from torch.nn.modules.module import Module
 
 from . import _lib
+from . import gat_layers as _gl        # the GEMM-family switch (_GEMM_BX3) is ONE module-level setting for GAT and GCN
 
 
 def _req(*ts):
@@ -40,9 +41,11 @@ class _GcnFunction(torch.autograd.Function):
             raise ValueError("GraphConvolution: inconsistent shapes")
         dev = x.device
         sup = torch.empty(B, n, O, dtype=torch.float32, device=dev)
-        out = torch.empty(B, n, O, dtype=torch.float32, device=dev)
+        # allocated in the caller's shape and returned AS IS: the tensor saved for the backward (its sign is the ReLU mask)
+        # is the tensor the caller holds, so an in-place edit of the result is caught by autograd's version check
+        out = torch.empty(x.shape[:-1] + (O,), dtype=torch.float32, device=dev)
         w_split = None
-        mode = os.environ.get("RECON_GEMM_BX3", "auto")       # split-precision GEMMs (fp32-accurate, csrc/gemm_bx3.hip): auto | 1 | 0
+        mode = _gl._GEMM_BX3                                  # split-precision GEMMs (fp32-accurate, csrc/gemm_bx3.hip): auto | 1 | 0
         if mode == "1" or (mode != "0" and 2.0 * B * n * I * O >= 2.0e9):    # small products do not pay for the term-plane launches
             w_split = torch.empty(_lib.lib().recon_gcn_split_bytes(I, O), dtype=torch.uint8, device=dev)
         args = _lib.GcnArgs(B, n, I, O, x3.data_ptr(), adj3.data_ptr(), weight.data_ptr(), _lib.ptr(bias),
@@ -51,7 +54,7 @@ class _GcnFunction(torch.autograd.Function):
             _lib.check(_lib.lib().recon_gcn_fwd(C.byref(args), _lib.current_stream()), "recon_gcn_fwd")
         ctx.save_for_backward(x3, adj3, weight, bias, sup, out, w_split)
         ctx.shapes = (tuple(x.shape), tuple(adj.shape))
-        return out.view(x.shape[:-1] + (O,))
+        return out
 
     @staticmethod
     def backward(ctx, gout):

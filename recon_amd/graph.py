@@ -6,6 +6,7 @@ one SpGAT.forward (GAT/layers.py:124-127, :56-58); here the prepared graph is ca
 (edge tensor, n-hop tensor, N) so it is built once per batch.
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import torch
@@ -14,6 +15,7 @@ from . import _lib
 
 _CACHE = OrderedDict()
 _CACHE_MAX = 8
+_VALIDATE = os.environ.get("RECON_VALIDATE_EDGES", "1") != "0"
 
 
 class GraphCSR:
@@ -29,6 +31,13 @@ class GraphCSR:
         if N >= 2 ** 31 or E >= 2 ** 31:
             raise ValueError("graph too large for int32 indices")
         dev = edge.device
+        if E > 0 and _VALIDATE:
+            # once per cached graph (one host sync): ids outside [0, N) would be truncated to int32, sorted on too few bits
+            # and make the edge kernels read out of bounds; the reference fails on the same input (index out of range)
+            lo, hi = torch.aminmax(edge)
+            lo, hi = int(lo), int(hi)
+            if lo < 0 or hi >= N:
+                raise IndexError("recon_amd: edge index out of range: ids span [%d, %d] but input has %d rows" % (lo, hi, N))
         self.N, self.E, self.device = int(N), int(E), dev
         self.edge = edge
         i32 = dict(dtype=torch.int32, device=dev)
@@ -65,9 +74,11 @@ def _has_nhop(edge_list_nhop):
 def prepare_graph(edge, edge_list_nhop, N):
     """Concatenate 1-hop and n-hop edges (GAT/layers.py:124-127) and build / fetch the cached CSR."""
     nh = _has_nhop(edge_list_nhop)
-    key = (edge.data_ptr(), edge._version, tuple(edge.shape),
+    # identity + version + shape + strides: two views of one storage with equal shapes but different strides are different
+    # edge lists.  (Writes through .data do not bump _version: do not mutate a cached edge tensor that way.)
+    key = (edge.data_ptr(), edge._version, tuple(edge.shape), tuple(edge.stride()),
            edge_list_nhop.data_ptr() if nh else 0, edge_list_nhop._version if nh else 0,
-           tuple(edge_list_nhop.shape) if nh else (), int(N), str(edge.device))
+           tuple(edge_list_nhop.shape) if nh else (), tuple(edge_list_nhop.stride()) if nh else (), int(N), str(edge.device))
     g = _CACHE.get(key)
     if g is not None:
         _CACHE.move_to_end(key)

@@ -35,12 +35,29 @@ def hashed_uniform(shape, salt, lo=-1.0, hi=1.0):
     return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
 
 
+# GPU tests that run the layers (GAT heads / SpGAT / SpKBGAT / GraphConvolution) are run once per GEMM family: the layer
+# picks its family by problem size ("auto": exact-fp32 MFMA GEMMs below ~6 GFLOP per product, split-precision above), so on
+# the small golden / oracle shapes each family has to be forced to get odd-shape and tile-tail coverage of its own.
+GEMM_FAMILIES = ("1", "0")          # values of recon_amd.gat_layers._GEMM_BX3 (shared by gcn_layers)
+_NO_FAMILY = ("test_graph_build", "test_sgemm", "test_spmm", "test_full_size_cfg2_split_precision_vs_fp32_gemm",
+              "test_block_adjacency", "test_propagation", "test_start_entity", "test_gpgnn", "test_phased_backward")
+
+
+def pytest_generate_tests(metafunc):
+    if "gemm_family" not in metafunc.fixturenames:
+        return
+    is_gpu = metafunc.definition.get_closest_marker("gpu") is not None
+    name = metafunc.definition.originalname
+    if is_gpu and not name.startswith(_NO_FAMILY):
+        metafunc.parametrize("gemm_family", GEMM_FAMILIES, indirect=True, ids=["gemm_bx3", "gemm_f32"])
+
+
 @pytest.fixture(autouse=True)
-def _gpu_tests_force_split_precision_gemms(request, monkeypatch):
-    """The layer picks its GEMM family by problem size (split-precision bf16 x 3 above ~6 GFLOP per product, exact-fp32 MFMA
-    below).  The golden cases are small, so GPU tests force the split-precision family on — it is the one the benchmark
-    runs — and individual tests switch it off where they compare the two (RECON_GEMM_BX3 semantics, gat_layers.py)."""
-    if request.node.get_closest_marker("gpu") is not None:
+def gemm_family(request, monkeypatch):
+    fam = getattr(request, "param", None)
+    if fam is None and request.node.get_closest_marker("gpu") is not None:
+        fam = "1"                    # un-parametrized GPU tests: the benchmark's family
+    if fam is not None:
         from recon_amd import gat_layers
-        monkeypatch.setattr(gat_layers, "_GEMM_BX3", "1")
-    yield
+        monkeypatch.setattr(gat_layers, "_GEMM_BX3", fam)
+    yield fam

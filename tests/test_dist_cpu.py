@@ -98,3 +98,61 @@ def test_bucket_without_process_group_is_a_noop():
     assert b.flat.tolist() == [2.0, 2.0, 2.0] and p.grad.data_ptr() == b.flat.data_ptr()
     b.zero()
     assert p.grad is None
+
+
+def test_bucket_pack_none_grad_and_repeated_steps():
+    """pack() must not write through an aliased source: an unused parameter (grad None) and a second step whose p.grad is
+    already the bucket view (no zero() in between) both used to raise inside torch.cat(out=flat)."""
+    used = torch.nn.Parameter(torch.ones(3))
+    unused = torch.nn.Parameter(torch.ones(2, 2))
+    b = FlatGradBucket([used, unused])
+    (used * 2.0).sum().backward()
+    b.pack()
+    assert b.flat.tolist() == [2.0, 2.0, 2.0, 0.0, 0.0, 0.0, 0.0]
+    assert unused.grad is not None and unused.grad.data_ptr() == b.views[1].data_ptr()
+    # second step without zero(): autograd accumulates INTO the views, pack() must keep them
+    (used * 3.0).sum().backward()
+    b.pack()
+    assert b.flat.tolist() == [5.0, 5.0, 5.0, 0.0, 0.0, 0.0, 0.0]
+    # optimizer.zero_grad(set_to_none=False) keeps the views and zeroes them in place
+    torch.optim.SGD([used, unused], lr=0.1).zero_grad(set_to_none=False)
+    (used * 1.5).sum().backward()
+    b.pack()
+    assert b.flat.tolist() == [1.5, 1.5, 1.5, 0.0, 0.0, 0.0, 0.0]
+    # a fresh (non-aliased) gradient after zero() is copied, stale content of the buffer is overwritten
+    b.zero()
+    (used * 4.0 + 0.0 * unused.sum()).sum().backward()
+    b.pack()
+    assert b.flat.tolist() == [4.0, 4.0, 4.0, 0.0, 0.0, 0.0, 0.0]
+
+
+def _worker_empty_shard(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    p = torch.nn.Parameter(torch.arange(4.0))
+    q = torch.nn.Parameter(torch.ones(2))
+    bucket = FlatGradBucket([p, q])
+    for step in range(2):                                      # two steps; rank 1 owns an empty shard (no backward at all)
+        if rank == 0:
+            ((p * p).sum() * float(world)).backward()           # q unused on every rank
+        bucket.allreduce_mean()
+        if step == 0:
+            first = p.grad.clone()
+            bucket.zero()
+    ret[rank] = (first.numpy(), p.grad.clone().numpy(), q.grad.clone().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_empty_shard_does_not_hang():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_empty_shard, args=(world, _free_port(), ret), nprocs=world, join=True)
+    want = 2.0 * np.arange(4.0, dtype=np.float32)
+    for r in range(world):
+        np.testing.assert_allclose(ret[r][0], want)
+        np.testing.assert_allclose(ret[r][1], want)
+        np.testing.assert_array_equal(ret[r][2], np.zeros(2, np.float32))

@@ -52,6 +52,30 @@ def test_graph_build(N, E, seed):
     np.testing.assert_array_equal(G.rowptr_src.cpu().numpy(), rowptr.numpy())
 
 
+def test_graph_build_rejects_out_of_range_ids():
+    """The reference fails on an edge id outside [0, N) (index out of range); so does the drop-in, once per cached graph."""
+    from recon_amd.graph import GraphCSR, prepare_graph
+    edge = torch.tensor([[0, 1, 5], [1, 2, 0]], device=dev())
+    with pytest.raises(IndexError):
+        GraphCSR(edge, 5)
+    with pytest.raises(IndexError):
+        prepare_graph(torch.tensor([[0, 1], [1, -1]], device=dev()), None, 4)
+    GraphCSR(edge, 6)
+
+
+def test_graph_cache_distinguishes_strided_views():
+    """Two views of one storage with equal data_ptr and shape but different strides are different edge lists."""
+    from recon_amd.graph import prepare_graph
+    base = torch.tensor([[0, 3, 1, 2, 2, 0, 3, 1], [1, 1, 0, 0, 3, 3, 2, 2]], device=dev())       # [2, 8]
+    a = base[:, :4]                       # columns 0..3, stride (8, 1)
+    b = base.view(-1)[:8].view(2, 4)      # same data_ptr and shape, stride (4, 1): rows are base[0,:4], base[0,4:]
+    assert a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() != b.stride()
+    ga, gb = prepare_graph(a, None, 4), prepare_graph(b, None, 4)
+    assert ga is not gb
+    np.testing.assert_array_equal(ga.src.cpu().numpy()[np.argsort(ga.eid.cpu().numpy())], a[1].cpu().numpy())
+    np.testing.assert_array_equal(gb.src.cpu().numpy()[np.argsort(gb.eid.cpu().numpy())], b[1].cpu().numpy())
+
+
 # ------------------------------------------------------------------------------- K4
 @pytest.mark.parametrize("cfg", ["0", "1"])        # RECON_GEMM_CFG: default tile choice / 128x128 forced
 @pytest.mark.parametrize("M,N,K,nk", [(128, 128, 16, 1), (200, 72, 50, 1), (33, 257, 19, 0), (1000, 400, 200, 0),

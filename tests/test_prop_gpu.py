@@ -135,7 +135,8 @@ def test_gcn_golden(name):
         close(layer.bias.grad, g["g_bias"], atol=1e-5, what="g_bias")
 
 
-@pytest.mark.parametrize("B,n,I,O_", [(1, 9, 7, 5), (6, 32, 300, 300), (3, 17, 40, 130)])
+@pytest.mark.parametrize("B,n,I,O_", [(1, 9, 7, 5), (6, 32, 300, 300), (3, 17, 40, 130),
+                                      (2, 33, 20, 70), (2, 100, 24, 64), (1, 257, 12, 9)])     # n > 32: tiled adjacency (any n)
 def test_gcn_batched_vs_oracle(B, n, I, O_):
     from recon_amd.gcn_layers import GraphConvolution
     d_ = dev()
@@ -159,6 +160,23 @@ def test_gcn_batched_vs_oracle(B, n, I, O_):
     close(adjd.grad, adjr.grad, atol=1e-5, what="g_adj")
     close(layer.weight.grad, wr.grad, atol=1e-5, what="g_weight")
     close(layer.bias.grad, br.grad, atol=1e-5, what="g_bias")
+
+
+def test_gcn_inplace_edit_of_result_is_caught():
+    """The tensor saved for the backward (its sign is the ReLU mask) is the tensor the caller holds: editing it in place
+    must trip autograd's version check instead of silently corrupting the mask."""
+    from recon_amd.gcn_layers import GraphConvolution
+    d_ = dev()
+    layer = GraphConvolution(6, 5).to(d_)
+    x = torch.randn(2, 4, 6, device=d_, requires_grad=True)
+    adj = torch.rand(2, 4, 4, device=d_)
+    out = layer(x, adj)
+    assert out.shape == (2, 4, 5)
+    out.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out.sum().backward()
+    x2 = torch.randn(4, 6, device=d_, requires_grad=True)        # the reference's 2-D form keeps its shape too
+    assert layer(x2, adj[0]).shape == (4, 5)
 
 
 def test_propagation_full_size_properties():
