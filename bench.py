@@ -27,7 +27,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, fp32-input MFMA
-MFMA_BF16_PEAK = 2.5e15    # FLOP/s, dense bf16 MFMA (the split-precision GEMM issues 6 bf16 MFMAs per fp32 product)
+MFMA_BF16_PEAK = 2.5e15    # FLOP/s, dense bf16 / f16 MFMA (the split-precision GEMMs issue 3 f16 or 6 bf16 MFMAs per fp32 product)
 
 
 def parse():
@@ -128,7 +128,7 @@ def main():
         "metric": "edges aggregated/sec (GAT fwd+bwd) on synthetic KG-context graphs",
         "value": edges_per_s, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",      # fp32 in, fp32 out, fp32 accumulation; the GEMMs run fp32 operands as 3 bf16 terms each
+        "dtype": "f32", "data": "synthetic",      # fp32 in, fp32 out, fp32 accumulation; the GEMMs run fp32 operands as 2 f16 (or 3 bf16) terms each
         "config": {"workload": "cfg2: H-head KB-GAT attention stage fwd+bwd (heads only, dropout 0)",
                    "graphs_per_gpu": B, "nodes_per_graph": n, "edges_per_graph": e, "F": F_, "R": R,
                    "D_per_head": D, "heads": H, "N_per_gpu": N, "E_per_gpu": E,
@@ -160,8 +160,8 @@ def main():
             Z = torch.empty(N, H, **f32)
             Zk = torch.empty(N, H, **f32)
             from recon_amd.gat_layers import _atp_split_buffer
-            a_split = _atp_split_buffer(F_, R, D, H, dev, N)
-            fa = _atp_args(graph, xd.detach(), eed.detach(), a, a2, None, u, c_node, c_rel, V, sigma, Z, Zk, out, 0.2, True, a_split)
+            a_split, aux = _atp_split_buffer(F_, R, D, H, dev, N)
+            fa = _atp_args(graph, xd.detach(), eed.detach(), a, a2, None, u, c_node, c_rel, V, sigma, Z, Zk, out, 0.2, True, a_split, aux)
             stages = (L.recon_gat_atp_scores, L.recon_gat_atp_aggregate, L.recon_gat_atp_project)
             # compulsory traffic of the aggregation kernel: x and edge_embed rows once, score terms, CSR, V out,
             # saved sigma / Z / Zk  (fp32 values, int32 indices)
@@ -179,7 +179,7 @@ def main():
             bytes_alg = algorithmic_bytes_fwd(N, E, H, D)
             flops_proj = 2.0 * H * D * (2.0 * N * F_ + 1.0 * E * R)
             kname, gname = "k_gat_edge_fwd", "k_gemm_f32 (projections P, Q)"
-            a_split = None
+            a_split = aux = None
         order = (0, 1, 2) if path == "atp" else (2, 1)                 # proj: GEMMs first, then the edge kernel
         for i in range(args.warmup + args.steps):
             k = i - args.warmup
@@ -202,14 +202,21 @@ def main():
                               "note": "algorithmic_bytes = compulsory traffic of this kernel; survey_model_bytes = SURVEY 8d's "
                                       "B_G for the project-then-aggregate layout this kernel no longer needs"}
         try:            # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot collect PMC itself)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
+            pmc_file = "round2_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "round2_pmc_traffic.json")) else "round1_pmc_traffic.json"
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             if (B, n, e, F_, D, H) == (512, 16, 64, 200, 200, 8) and kname in pmc:
                 result["roofline"]["traffic"] = pmc[kname]["total_bytes"]
-                result["roofline"]["traffic_source"] = "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+                result["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)" % pmc_file
         except Exception:
             pass
-        bx3 = path == "atp" and a_split is not None
-        if bx3:     # priced in bf16 MFMA flops actually issued (6 term products per fp32 product) against the dense bf16 peak
+        bx3 = path == "atp" and a_split is not None and aux is None
+        if path == "atp" and aux is not None:     # f16 x 2: priced in f16 MFMA flops actually issued (3 term products per fp32 product)
+            result["roofline_gemm"] = {"kernel": "k_gemm_hx2 (batched projection out = act(V a^T), 2 x f16 pre-split operands under per-tensor "
+                                                 "power-of-two scales, fp32 accumulate)",
+                                       "bound": "mfma", "achieved": 3.0 * flops_proj / t_proj / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
+                                       "unit": "TFLOP/s", "frac": 3.0 * flops_proj / t_proj / MFMA_BF16_PEAK, "avg_us": t_proj * 1e6,
+                                       "fp32_equivalent_tflops": flops_proj / t_proj / 1e12}
+        elif bx3:     # priced in bf16 MFMA flops actually issued (6 term products per fp32 product) against the dense bf16 peak
             result["roofline_gemm"] = {"kernel": "k_gemm_bx3 (batched projection out = act(V a^T), 3 x bf16 split operands, fp32 accumulate)",
                                        "bound": "mfma", "achieved": 6.0 * flops_proj / t_proj / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
                                        "unit": "TFLOP/s", "frac": 6.0 * flops_proj / t_proj / MFMA_BF16_PEAK, "avg_us": t_proj * 1e6,

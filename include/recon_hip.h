@@ -145,6 +145,8 @@ int recon_gat_bwd(const recon_graph* g, const recon_gat_bwd_args* args, recon_st
  *      from recon_gat_fwd / the reference in fp32 summation order only.  recon_gat_atp_supported()
  *      tells whether the shape is instantiated (F, R even; 2F+R-wide rows fit the register budget).
  * ------------------------------------------------------------------------------------------*/
+enum { RECON_SPLIT_BF16X3 = 0, RECON_SPLIT_F16X2 = 2 };
+
 typedef struct {
     int32_t N, E;               /* must equal graph->N, graph->E                             */
     int32_t F, R, D, H;
@@ -169,6 +171,16 @@ typedef struct {
                                  * (csrc/gemm_bx3.hip; filled by the scores stage, read by the       *
                                  * projection and by the backward's g_V product).  NULL = use the    *
                                  * fp32-MFMA GEMM for those products.                                */
+    int32_t split_mode;         /* RECON_SPLIT_*: which split-precision family a_split is for.  With         *
+                                 * RECON_SPLIT_F16X2 (csrc/gemm_hx2.hip; needs (2F+R) % 8 == 0, D % 8 == 0,  *
+                                 * else the call falls back to BF16X3) the buffers keep their sizes but hold  *
+                                 * HALF planes: a_split the two planes of a and a^T, V the two planes         *
+                                 * [2][N*H][2F+R] of s_V * V instead of fp32 V, gh_split the two planes of g_h */
+    float keep_max;             /* upper bound of the factors in `keep` (1/(1-p)); ignored when keep is NULL  */
+    void* aux;                  /* RECON_SPLIT_F16X2: recon_hx2_aux_bytes() bytes, 256-byte aligned, workspace *
+                                 * / saved: max-magnitude slots of a, x, edge_embed, grad_out (the per-tensor   *
+                                 * power-of-two scales derive from them) and a page of zeros; zeroed by the     *
+                                 * scores stage                                                                */
 } recon_gat_atp_args;
 
 size_t recon_gat_atp_split_bytes(int32_t F, int32_t R, int32_t D, int32_t H);
@@ -183,7 +195,7 @@ typedef struct {
     recon_gat_atp_args fwd;     /* same tensors as the forward call (u, V, sigma, Z, Zk, out filled)  */
     const float* grad_out;      /* [N, ld_gout]                                                      */
     int32_t ld_gout;
-    float* g_h;                 /* [N,H*D]    workspace (only read when concat != 0)                  */
+    float* g_h;                 /* [N,H*D]    workspace (only read when concat != 0; unused, may be NULL, in F16X2 mode) */
     float* g_V;                 /* [N,H,2F+R] workspace: d loss / d V                                 */
     float* g_sigma;             /* [E,H]      workspace: d loss / d s_e                               */
     float* Gxs;                 /* [E,F]      workspace: per-edge gradient rows bound for x[src_e]    */
@@ -329,6 +341,23 @@ int recon_sgemm_bx3(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda
 size_t recon_sgemm_bx3_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
 int recon_sgemm_bx3_tn(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                        float* C, int32_t ldc, void* workspace, recon_stream_t stream);
+
+/* K4''  the same two products on the fp16 matrix cores with TWO half terms per operand and three term products
+ * (csrc/gemm_hx2.hip): every operand is scaled by a per-tensor power of two taken from its max magnitude, so that
+ * half's 5 exponent bits suffice, and pre-split into two half planes; fp32-class accuracy at half the MFMA work of
+ * the bf16 x 3 form.  These stand-alone entries measure (amax) and split both operands into `workspace` (256-byte
+ * aligned) first; the *_presplit forms re-run only the GEMM on the planes a previous call left there (benchmarks).
+ * Requires K % 8 == 0 (k-contiguous form); any M, N for the k-major form.  In the GAT layer the planes are written by
+ * the kernels that produce the operands (edge aggregation: V; ELU-gradient pass: g_h). */
+size_t recon_hx2_aux_bytes(void);      /* size of recon_gat_atp_args.aux */
+size_t recon_sgemm_hx2_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int recon_sgemm_hx2(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
+                    float* C, int32_t ldc, void* workspace, recon_stream_t stream);
+int recon_sgemm_hx2_presplit(int32_t M, int32_t N, int32_t K, float* C, int32_t ldc, void* workspace, recon_stream_t stream);
+size_t recon_sgemm_hx2_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int recon_sgemm_hx2_tn(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
+                       float* C, int32_t ldc, void* workspace, recon_stream_t stream);
+int recon_sgemm_hx2_tn_presplit(int32_t M, int32_t N, int32_t K, float* C, int32_t ldc, void* workspace, recon_stream_t stream);
 
 #ifdef __cplusplus
 }

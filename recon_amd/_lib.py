@@ -43,7 +43,8 @@ class GatAtpArgs(C.Structure):
                 ("H", C.c_int32), ("concat", C.c_int32), ("alpha", C.c_float),
                 ("x", c_f32p), ("edge_embed", c_f32p), ("a", c_f32p), ("a_2", c_f32p), ("keep", c_f32p),
                 ("u", c_f32p), ("c_node", c_f32p), ("c_rel", c_f32p), ("V", c_f32p), ("sigma", c_f32p),
-                ("Z", c_f32p), ("Zk", c_f32p), ("out", c_f32p), ("ld_out", C.c_int32), ("a_split", C.c_void_p)]
+                ("Z", c_f32p), ("Zk", c_f32p), ("out", c_f32p), ("ld_out", C.c_int32), ("a_split", C.c_void_p),
+                ("split_mode", C.c_int32), ("keep_max", C.c_float), ("aux", C.c_void_p)]
 
 
 class GatAtpBwdArgs(C.Structure):
@@ -122,6 +123,15 @@ SYMBOLS = [
     ("recon_sgemm_bx3_tn_workspace_bytes", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     ("recon_sgemm_bx3_tn", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32,
                                      C.c_void_p, C.c_void_p]),
+    ("recon_hx2_aux_bytes", C.c_size_t, []),
+    ("recon_sgemm_hx2_workspace_bytes", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    ("recon_sgemm_hx2", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32,
+                                  C.c_void_p, C.c_void_p]),
+    ("recon_sgemm_hx2_presplit", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("recon_sgemm_hx2_tn_workspace_bytes", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    ("recon_sgemm_hx2_tn", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32,
+                                     C.c_void_p, C.c_void_p]),
+    ("recon_sgemm_hx2_tn_presplit", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_void_p, C.c_void_p]),
 ]
 
 _lib = None

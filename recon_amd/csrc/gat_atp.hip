@@ -32,24 +32,32 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 // 16 groups with 4 independent partial sums each: with 4 groups and one dependent chain the kernel was latency
 // bound (15 us for 3.8 MB).
 __global__ void __launch_bounds__(1024) k_score_vec(const float* __restrict__ a, const float* __restrict__ a2, int32_t D, int32_t W,
-                                                    float* __restrict__ u) {
+                                                    float* __restrict__ u, uint32_t* __restrict__ amax_a) {
     __shared__ float red[16][64];
     const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int w = blockIdx.x * 64 + c, h = blockIdx.y;
     const float* ah = a + static_cast<int64_t>(h) * D * W;
     const int per = (D + 15) / 16;
     const int d0 = grp * per, d1 = min(D, (grp + 1) * per);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, mx = 0.f;             // mx: max |a| seen by this thread (every element is read once)
     if (w < W) {
         int d = d0;
         for (; d + 4 <= d1; d += 4) {
-            s0 = fmaf(a2[h * D + d], ah[static_cast<int64_t>(d) * W + w], s0);
-            s1 = fmaf(a2[h * D + d + 1], ah[static_cast<int64_t>(d + 1) * W + w], s1);
-            s2 = fmaf(a2[h * D + d + 2], ah[static_cast<int64_t>(d + 2) * W + w], s2);
-            s3 = fmaf(a2[h * D + d + 3], ah[static_cast<int64_t>(d + 3) * W + w], s3);
+            const float v0 = ah[static_cast<int64_t>(d) * W + w], v1 = ah[static_cast<int64_t>(d + 1) * W + w];
+            const float v2 = ah[static_cast<int64_t>(d + 2) * W + w], v3 = ah[static_cast<int64_t>(d + 3) * W + w];
+            s0 = fmaf(a2[h * D + d], v0, s0);
+            s1 = fmaf(a2[h * D + d + 1], v1, s1);
+            s2 = fmaf(a2[h * D + d + 2], v2, s2);
+            s3 = fmaf(a2[h * D + d + 3], v3, s3);
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));
         }
-        for (; d < d1; ++d) s0 = fmaf(a2[h * D + d], ah[static_cast<int64_t>(d) * W + w], s0);
+        for (; d < d1; ++d) {
+            const float v0 = ah[static_cast<int64_t>(d) * W + w];
+            s0 = fmaf(a2[h * D + d], v0, s0);
+            mx = fmaxf(mx, fabsf(v0));
+        }
     }
+    if (amax_a) hx2_amax_commit(mx, amax_a);
     red[grp][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp == 0 && w < W) {
@@ -89,8 +97,10 @@ __global__ void __launch_bounds__(256) k_score_vec_bwd(const float* __restrict__
 __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy, int32_t ld_gy, const float* __restrict__ y,
                                                     int32_t ld_y, int32_t N, int32_t H, int32_t D, int32_t concat,
                                                     float* __restrict__ gh, float* __restrict__ q, uint16_t* __restrict__ ghp,
-                                                    int64_t ld_p, int64_t plane_p) {
-    // ghp (optional): the three bfloat16 term planes [3][N][ld_p] of g_h for the split-precision weight-gradient GEMM
+                                                    int64_t ld_p, int64_t plane_p, int32_t f16x2, const Hx2Scale gsc) {
+    // ghp (optional): term planes of g_h for the split-precision GEMMs — three bfloat16 planes [3][N][ld_p], or (f16x2) the
+    // two half planes [2][N][ld_p] of s_g * g_h, s_g from the published max |grad_out| (|elu'| <= 1, so it bounds |g_h|)
+    const float gs = f16x2 ? hx2_scale(gsc) : 1.f;
     constexpr int IPW = 4;                                               // (node, head) rows per wave, loads batched
     const int lane = threadIdx.x & 63;
     const int item0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * IPW;      // N*H < 2^31 (checked by the host)
@@ -129,6 +139,13 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
                     const int node = it / H, h = it % H;
                     uint16_t* dst = ghp + static_cast<int64_t>(node) * ld_p + h * D + c;
                     float x[4] = {o[0], o[1], o[2], o[3]};
+                    if (f16x2) {
+                        uint32_t hi[2], lo[2];
+                        hx2_split2(x[0] * gs, x[1] * gs, hi[0], lo[0]);
+                        hx2_split2(x[2] * gs, x[3] * gs, hi[1], lo[1]);
+                        *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0], hi[1]);
+                        *reinterpret_cast<uint2*>(dst + plane_p) = make_uint2(lo[0], lo[1]);
+                    } else
 #pragma unroll
                     for (int pq = 0; pq < 3; ++pq) {
                         uint32_t w[2];
@@ -170,6 +187,13 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
                 if (gh) *reinterpret_cast<float4*>(gh + static_cast<int64_t>(it) * D + c) = make_float4(x[0], x[1], x[2], x[3]);
                 if (ghp) {
                     uint16_t* dst = ghp + static_cast<int64_t>(node) * ld_p + h * D + c;
+                    if (f16x2) {
+                        uint32_t hi[2], lo[2];
+                        hx2_split2(x[0] * gs, x[1] * gs, hi[0], lo[0]);
+                        hx2_split2(x[2] * gs, x[3] * gs, hi[1], lo[1]);
+                        *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0], hi[1]);
+                        *reinterpret_cast<uint2*>(dst + plane_p) = make_uint2(lo[0], lo[1]);
+                    } else
 #pragma unroll
                     for (int pq = 0; pq < 3; ++pq) {
                         uint32_t w[2];
@@ -215,7 +239,7 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
 constexpr int kRowsPerIter = 4;
 // Two independent jobs (node scores and edge scores) share ONE launch: blocks [0, nb0) run job 0, the rest job 1, so
 // the small node job does not leave the chip three quarters empty for its whole latency-bound duration.
-struct RowDotsJob { const float* X; const int32_t* gather; int32_t rows, K, F, off, NJ, nb; float* out; };
+struct RowDotsJob { const float* X; const int32_t* gather; int32_t rows, K, F, off, NJ, nb; float* out; uint32_t* amax; };
 template <int VEC>
 __global__ void __launch_bounds__(kBlock) k_row_dots(const RowDotsJob j0, const RowDotsJob j1, const float* __restrict__ u, int32_t H,
                                                      int32_t W) {
@@ -236,6 +260,7 @@ __global__ void __launch_bounds__(kBlock) k_row_dots(const RowDotsJob j0, const 
     const int lane = threadIdx.x & 63;
     const int wave = bid * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = nblocks * (kBlock / 64);
+    float mx = 0.f;                                                    // max |X| over the rows this wave reads (every row is read by one wave)
     for (int row0 = wave * RB; row0 < rows; row0 += nwaves * RB) {
         const float* xr[RB];
 #pragma unroll
@@ -256,6 +281,12 @@ __global__ void __launch_bounds__(kBlock) k_row_dots(const RowDotsJob j0, const 
                 float xv[RB][VEC];
 #pragma unroll
                 for (int b = 0; b < RB; ++b) load_vec<VEC>(xv[b], xr[b] + c);
+                if (j0 == 0) {
+#pragma unroll
+                    for (int b = 0; b < RB; ++b)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) mx = fmaxf(mx, fabsf(xv[b][v]));
+                }
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
                     if (j0 + jj < NJ) {
@@ -279,6 +310,7 @@ __global__ void __launch_bounds__(kBlock) k_row_dots(const RowDotsJob j0, const 
         for (int b = 0; b < RB; ++b)
             if (lane < NJ && row0 + b < rows) out[static_cast<int64_t>(row0 + b) * NJ + lane] = mine[b];
     }
+    if (jb.amax) hx2_amax_commit(mx, jb.amax);
 }
 
 struct AtpFwdK {
@@ -287,7 +319,30 @@ struct AtpFwdK {
     float* V; float* sigma; float* Z; float* Zk;
     int32_t N, E, F, R, H;
     float alpha;
+    int32_t planes;             // 1: V is written as two half planes [2][N*H][W] of s_V * V (gemm_hx2.hip) instead of fp32 [N][H][W]
+    Hx2Scale vs;                // s_V from max(|x|, |edge_embed|) * keep_max, an upper bound of |V| (V rows are k-weighted means)
 };
+
+// two half planes of VEC consecutive scaled values: 2 * VEC bytes per plane
+template <int VEC>
+__device__ __forceinline__ void store_planes(_Float16* hi_p, int64_t plane, const float (&o)[VEC], float s) {
+    float c[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) c[v] = fminf(fmaxf(o[v] * s, -65504.f), 65504.f);     // the scale comes from a bound, not from V itself
+    if constexpr (VEC == 4) {
+        uint32_t hi[2], lo[2];
+        hx2_split2(c[0], c[1], hi[0], lo[0]);
+        hx2_split2(c[2], c[3], hi[1], lo[1]);
+        *reinterpret_cast<uint2*>(hi_p) = make_uint2(hi[0], hi[1]);
+        *reinterpret_cast<uint2*>(hi_p + plane) = make_uint2(lo[0], lo[1]);
+    } else {
+        static_assert(VEC == 2, "vector width");
+        uint32_t hi, lo;
+        hx2_split2(c[0], c[1], hi, lo);
+        *reinterpret_cast<uint32_t*>(hi_p) = hi;
+        *reinterpret_cast<uint32_t*>(hi_p + plane) = lo;
+    }
+}
 
 // wave = one destination node, HT heads (blockIdx.y selects the head group); lanes span the feature
 // dimension: lane l owns columns (r*64 + l)*VEC .. +VEC of both the x row (F) and the relation row (R).
@@ -299,6 +354,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_fwd(const AtpFwdK p) {
     const int node = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + wave;
     if (node >= p.N) return;
     const int F = p.F, R = p.R, H = p.H, W = 2 * F + R;
+    const float vscale = p.planes ? hx2_scale(p.vs) : 1.f;             // scalar loads: in flight under the whole edge walk
     const int h0 = blockIdx.y * HT;
     const int myh = h0 + (lane % HT);
     const bool hv = myh < H;
@@ -375,27 +431,30 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_fwd(const AtpFwdK p) {
         for (int v = 0; v < VEC; ++v) xi[r][v] = 0.f;
         if (aF[r]) load_vec<VEC>(xi[r], p.x + static_cast<int64_t>(node) * F + cf[r]);
     }
+    const int64_t vplane = static_cast<int64_t>(p.N) * H * W;
 #pragma unroll
     for (int h = 0; h < HT; ++h) {
         if (h0 + h < H) {
             const float invh = lane_bcast(inv, h);
             const float zk = lane_bcast(Zkl, h) * invh;
-            float* Vr = p.V + (static_cast<int64_t>(node) * H + h0 + h) * W;
+            const int64_t vrow = (static_cast<int64_t>(node) * H + h0 + h) * W;
+            float* Vr = p.V + vrow;
+            _Float16* Vh = reinterpret_cast<_Float16*>(p.V) + vrow;
 #pragma unroll
             for (int r = 0; r < KR; ++r) {
                 float o[VEC];
                 if (aF[r]) {
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) o[v] = xi[r][v] * zk;
-                    store_vec<VEC>(Vr + cf[r], o);
+                    if (p.planes) store_planes<VEC>(Vh + cf[r], vplane, o, vscale); else store_vec<VEC>(Vr + cf[r], o);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) o[v] = accS[h][r][v] * invh;
-                    store_vec<VEC>(Vr + F + cf[r], o);
+                    if (p.planes) store_planes<VEC>(Vh + F + cf[r], vplane, o, vscale); else store_vec<VEC>(Vr + F + cf[r], o);
                 }
                 if (aR[r]) {
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) o[v] = accR[h][r][v] * invh;
-                    store_vec<VEC>(Vr + 2 * F + cf[r], o);
+                    if (p.planes) store_planes<VEC>(Vh + 2 * F + cf[r], vplane, o, vscale); else store_vec<VEC>(Vr + 2 * F + cf[r], o);
                 }
             }
         }
@@ -847,6 +906,28 @@ extern "C" size_t recon_gat_atp_split_bytes(int32_t F, int32_t R, int32_t D, int
     return split_part_bytes(D, W, H) + split_part_bytes(W, D, H);
 }
 
+// f16 x 2 mode (gemm_hx2.hip): V, g_h, a and a^T live as two half planes each and all three large products run on them.
+// All or nothing: the planes replace the fp32 tensors, so the decision must be the same in every stage of a step.
+//   aux (recon_hx2_aux_bytes(), 256-byte aligned): amax quantities [0] a, [1] x, [2] edge_embed, [3] grad_out (kHx2Slots hashed
+//   slots each), then a page of zeros
+//   a_split: planes of a [2][H][D][kp(W)], then (at the bf16 x 3 layout's offset) planes of a^T [2][H][W][kp(D)]
+static bool atp_hx2(const recon_gat_atp_args* a) {
+    if (a->split_mode != RECON_SPLIT_F16X2 || !a->a_split || !a->aux) return false;
+    const int64_t W = 2LL * a->F + a->R;
+    if ((W & 7) || (a->D & 7) || (a->ld_out & 3)) return false;
+    if ((reinterpret_cast<uintptr_t>(a->a_split) & 15) || (reinterpret_cast<uintptr_t>(a->aux) & 255) || (reinterpret_cast<uintptr_t>(a->V) & 15))
+        return false;
+    const int64_t pa = static_cast<int64_t>(a->H) * a->D * hx2_kp(static_cast<int32_t>(W)), pt = static_cast<int64_t>(a->H) * W * hx2_kp(a->D);
+    return 2 * (pa > pt ? pa : pt) < (1LL << 31) && W < (1 << 24);
+}
+static uint32_t* atp_q(const recon_gat_atp_args* a, int q) { return static_cast<uint32_t*>(a->aux) + q * kHx2QuantityWords; }
+static Hx2Scale atp_scale_a(const recon_gat_atp_args* a) { return Hx2Scale{atp_q(a, 0), nullptr, 1.f}; }
+static Hx2Scale atp_scale_v(const recon_gat_atp_args* a) {
+    const float km = (a->keep && a->keep_max > 1.f) ? a->keep_max : 1.f;
+    return Hx2Scale{atp_q(a, 1), atp_q(a, 2), km};
+}
+static Hx2Scale atp_scale_g(const recon_gat_atp_args* a) { return Hx2Scale{atp_q(a, 3), nullptr, 1.f}; }
+
 static int atp_fwd_common(const recon_graph* g, const recon_gat_atp_args* a, AtpShape* s) {
     int rc = check_atp(g, a);
     if (rc != RECON_OK) return rc;
@@ -867,9 +948,17 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
     if (a->N == 0) return RECON_OK;
     hipStream_t st = as_stream(stream);
     const int32_t N = a->N, E = a->E, F = a->F, R = a->R, D = a->D, H = a->H, W = 2 * F + R;
+    const bool hx2 = atp_hx2(a);
+    if (hx2 && hipMemsetAsync(a->aux, 0, kHx2AuxBytes, st) != hipSuccess) return RECON_ERR_LAUNCH;
     hipLaunchKernelGGL(k_score_vec, dim3(static_cast<unsigned>(ceil_div64(W, 64)), static_cast<unsigned>(H)), dim3(1024), 0, st, a->a,
-                       a->a_2, D, W, a->u);
-    if (a->a_split) {                                             // bf16 term planes of a and a^T for the split-precision GEMMs
+                       a->a_2, D, W, a->u, hx2 ? atp_q(a, 0) : nullptr);
+    if (hx2) {                                                    // half planes of s_a a and s_a a^T
+        char* ws = static_cast<char*>(a->a_split);
+        rc = hx2_split_planes(a->a, W, static_cast<int64_t>(D) * W, false, D, W, H, ws, atp_scale_a(a), st);
+        if (rc != RECON_OK) return rc;
+        rc = hx2_split_planes(a->a, W, static_cast<int64_t>(D) * W, true, W, D, H, ws + split_part_bytes(D, W, H), atp_scale_a(a), st);
+        if (rc != RECON_OK) return rc;
+    } else if (a->a_split) {                                      // bf16 term planes of a and a^T for the split-precision GEMMs
         if (reinterpret_cast<uintptr_t>(a->a_split) & 15) return RECON_ERR_INVALID;
         char* ws = static_cast<char*>(a->a_split);
         rc = bx3_split_planes(a->a, W, static_cast<int64_t>(D) * W, false, D, W, H, ws, st);
@@ -880,6 +969,7 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
     {
         RowDotsJob jn, je;
         jn.X = a->x; jn.gather = nullptr; jn.rows = N; jn.K = F; jn.F = F; jn.off = 0; jn.NJ = 2 * H; jn.out = a->c_node;
+        jn.amax = hx2 ? atp_q(a, 1) : nullptr; je.amax = hx2 ? atp_q(a, 2) : nullptr;
         jn.nb = static_cast<int>(ceil_div64(N, 16) < 2048 ? ceil_div64(N, 16) : 2048);
         je.X = a->edge_embed; je.gather = g->eid; je.rows = E; je.K = R; je.F = 0; je.off = 2 * F; je.NJ = H; je.out = a->c_rel;
         je.nb = E > 0 ? static_cast<int>(ceil_div64(E, 32) < 2048 ? ceil_div64(E, 32) : 2048) : 0;
@@ -907,6 +997,8 @@ extern "C" int recon_gat_atp_aggregate(const recon_graph* g, const recon_gat_atp
     p.x = a->x; p.ee = a->edge_embed; p.c_node = a->c_node; p.c_rel = a->c_rel; p.keep = a->keep;
     p.V = a->V; p.sigma = a->sigma; p.Z = a->Z; p.Zk = a->Zk;
     p.N = a->N; p.E = a->E; p.F = a->F; p.R = a->R; p.H = a->H; p.alpha = a->alpha;
+    p.planes = atp_hx2(a) ? 1 : 0;
+    p.vs = p.planes ? atp_scale_v(a) : Hx2Scale{nullptr, nullptr, 1.f};
     dim3 grid(static_cast<unsigned>(ceil_div64(a->N, kBlock / 64)), static_cast<unsigned>(ceil_div64(a->H, s.ht)));
 #define CALL_FWD(V_, K_, H_)                                                                                   \
     do {                                                                                                       \
@@ -932,6 +1024,9 @@ extern "C" int recon_gat_atp_project(const recon_graph* g, const recon_gat_atp_a
     GemmBatch bt;
     bt.batch = a->H; bt.a_bs = W; bt.b_bs = static_cast<int64_t>(a->D) * W; bt.c_bs = a->D;
     bt.epilogue = a->concat ? 1 : 0;
+    if (atp_hx2(a))
+        return gemm_hx2_batched(a->N, a->D, W, a->V, static_cast<int64_t>(a->N) * a->H * W, static_cast<int64_t>(a->H) * W, W, a->a_split, C, bt,
+                                atp_scale_v(a), atp_scale_a(a), as_stream(stream));
     if (a->a_split && bx3_supported(A, W, bt)) return gemm_bx3_batched(a->N, a->D, W, A, a->a_split, C, bt, as_stream(stream));
     return gemm_f32_batched(a->N, a->D, W, A, true, B, true, C, bt, 1, nullptr, as_stream(stream));
 }
@@ -983,7 +1078,9 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
     if (!recon_gat_atp_supported(a->N, a->E, a->F, a->R, a->D, a->H)) return RECON_ERR_UNSUPPORTED;
     if (!a->Z || !a->Zk || !b->grad_out || !b->g_V || !b->gxd || !b->Gs || !b->g_u || !b->partial || !b->partial2 || !b->q) return RECON_ERR_INVALID;
     if (a->E > 0 && (!a->sigma || !b->g_sigma || !b->Gxs)) return RECON_ERR_INVALID;
-    if (a->concat && !b->g_h) return RECON_ERR_INVALID;
+    const bool hx2 = atp_hx2(a);
+    if (a->concat && !b->g_h && !hx2) return RECON_ERR_INVALID;
+    if (hx2 && (!b->gh_split || (reinterpret_cast<uintptr_t>(b->gh_split) & 15) || (b->ld_gout & 3))) return RECON_ERR_INVALID;
     if (b->ld_gout < a->H * a->D) return RECON_ERR_INVALID;
     if (a->N == 0) return RECON_OK;
     hipStream_t st = as_stream(stream);
@@ -999,12 +1096,19 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
     int32_t ld_gh = b->ld_gout;
     // bf16 term planes of g_h [3][N][kp(HD)] for the split-precision weight-gradient GEMM (written by the same pass)
     const int64_t ld_ghp = bx3_kp(static_cast<int32_t>(HD));
-    const bool gh_planes = b->gh_split && a->a_split && !(reinterpret_cast<uintptr_t>(b->gh_split) & 15) && (D % 8) == 0 &&
-                           ((b->ld_gout | a->ld_out) & 3) == 0;
+    const bool gh_planes = hx2 || (b->gh_split && a->a_split && !(reinterpret_cast<uintptr_t>(b->gh_split) & 15) && (D % 8) == 0 &&
+                                   ((b->ld_gout | a->ld_out) & 3) == 0);
     uint16_t* ghp = gh_planes ? static_cast<uint16_t*>(b->gh_split) : nullptr;
-    if (phases & RECON_ATP_BWD_PREPARE)
-    hipLaunchKernelGGL(k_elu_grad_q, dim3(static_cast<unsigned>(ceil_div64(1LL * N * H, 16))), dim3(256), 0, st, b->grad_out, b->ld_gout, a->out,
-                       a->ld_out, N, H, D, a->concat, a->concat ? b->g_h : nullptr, b->q, ghp, ld_ghp, static_cast<int64_t>(N) * ld_ghp);
+    if (phases & RECON_ATP_BWD_PREPARE) {
+        if (hx2) {                                                // max |grad_out| bounds |g_h| (|elu'| <= 1): the scale of the g_h planes
+            if (hipMemsetAsync(atp_q(a, 3), 0, sizeof(uint32_t) * kHx2QuantityWords, st) != hipSuccess) return RECON_ERR_LAUNCH;
+            rc = hx2_amax(b->grad_out, N, static_cast<int32_t>(HD), b->ld_gout, atp_q(a, 3), st);
+            if (rc != RECON_OK) return rc;
+        }
+        hipLaunchKernelGGL(k_elu_grad_q, dim3(static_cast<unsigned>(ceil_div64(1LL * N * H, 16))), dim3(256), 0, st, b->grad_out, b->ld_gout, a->out,
+                           a->ld_out, N, H, D, a->concat, (a->concat && !hx2) ? b->g_h : nullptr, b->q, ghp, ld_ghp, static_cast<int64_t>(N) * ld_ghp,
+                           hx2 ? 1 : 0, hx2 ? atp_scale_g(a) : Hx2Scale{nullptr, nullptr, 1.f});
+    }
     if (a->concat) { gh = b->g_h; ld_gh = static_cast<int32_t>(HD); }
     GemmBatch bt;
     bt.batch = H; bt.epilogue = 0;
@@ -1015,7 +1119,10 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         OperandDesc B = plain_operand(a->a, W);
         OutputDesc C = plain_output(b->g_V, static_cast<int64_t>(H) * W);
         bt.a_bs = D; bt.b_bs = static_cast<int64_t>(D) * W; bt.c_bs = W;
-        if (a->a_split && bx3_supported(A, D, bt))
+        if (hx2)
+            rc = gemm_hx2_batched(N, W, D, b->gh_split, static_cast<int64_t>(N) * ld_ghp, ld_ghp, D,
+                                  static_cast<const char*>(a->a_split) + split_part_bytes(D, W, H), C, bt, atp_scale_g(a), atp_scale_a(a), st);
+        else if (a->a_split && bx3_supported(A, D, bt))
             rc = gemm_bx3_batched(N, W, D, A, static_cast<const char*>(a->a_split) + split_part_bytes(D, W, H), C, bt, st);
         else
             rc = gemm_f32_batched(N, W, D, A, true, B, false, C, bt, 1, nullptr, st);
@@ -1067,7 +1174,12 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
             GemmBatch bw = bt;
             bw.a_bs = W; bw.b_bs = D; bw.c_bs = static_cast<int64_t>(D) * W; bw.c_transpose = 1;
             const int64_t ldv = static_cast<int64_t>(H) * W;
-            if (gh_planes && bx3_kmajor_supported(a->V, ldv, W, ld_ghp, D, W, D)) {           // split-precision MFMA, both operands k-major
+            if (hx2) {                                                                     // f16 x 2: both operands are half planes
+                const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));
+                rc = gemm_hx2_kmajor_batched(W, D, N, a->V, ldv, static_cast<int64_t>(N) * ldv, W, b->gh_split, ld_ghp, static_cast<int64_t>(N) * ld_ghp, D,
+                                             H, sk, b->partial, static_cast<const char*>(a->aux) + kHx2ZeroPageOffset, atp_scale_v(a), atp_scale_g(a), st);
+                if (rc == RECON_OK) rc = splitk_reduce(b->partial, sk, W, D, C, bw.c_bs, H, 0, true, st);
+            } else if (gh_planes && bx3_kmajor_supported(a->V, ldv, W, ld_ghp, D, W, D)) {    // split-precision MFMA, both operands k-major
                 const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));
                 rc = gemm_bx3_kmajor_batched(W, D, N, a->V, ldv, W, b->gh_split, ld_ghp, static_cast<int64_t>(N) * ld_ghp, D, H, sk, b->partial, st);
                 if (rc == RECON_OK) rc = splitk_reduce(b->partial, sk, W, D, C, bw.c_bs, H, 0, true, st);

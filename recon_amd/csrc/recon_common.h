@@ -89,6 +89,65 @@ __device__ __forceinline__ void store_vec(float* p, const float (&r)[VEC]) {
     else { *p = r[0]; }
 }
 
+// ---- f16 x 2 split-precision operands (gemm_hx2.hip): per-tensor power-of-two scale from the tensor's max magnitude ----
+// amax values live in device memory as fp32 BIT PATTERNS (uint32): non-negative floats order like unsigned integers, so
+// producers publish them with atomicMax (exact, order independent).  A scale descriptor names up to two slots and a host
+// multiplier: amax = max(*p0, *p1) * mul  (p0 == nullptr: unscaled, s = 1).
+// Each amax QUANTITY is kHx2Slots words spread 256 bytes apart (device-scope atomics on ONE address execute one after the
+// other at the memory side, ~5-12 ns each: 12 k of them cost 60-90 us; hashed over 32 lines in different channels they
+// overlap); producers hash their wave into a slot, consumers take the max over the slots with 32 scalar loads.
+constexpr int kHx2Slots = 32, kHx2SlotStride = 64;                       // stride in uint32 words
+constexpr int kHx2QuantityWords = kHx2Slots * kHx2SlotStride;            // 2048 words = 8 KiB per quantity
+constexpr size_t kHx2AuxQuantities = 4;
+constexpr size_t kHx2ZeroPageOffset = kHx2AuxQuantities * kHx2QuantityWords * 4;       // byte offset of the 1 KiB page of zeros
+constexpr size_t kHx2AuxBytes = kHx2ZeroPageOffset + 1024;
+struct Hx2Scale { const uint32_t* p0; const uint32_t* p1; float mul; };
+
+// s = 2^(14 - floor(log2 amax)): s * amax in [2^14, 2^15) — half overflows at 65504 = 2^16 - 32
+__device__ __forceinline__ float hx2_scale_of(float amax) {
+    const uint32_t e = (__builtin_bit_cast(uint32_t, amax) >> 23) & 0xffu;
+    if (e == 0u || e == 255u) return 1.f;                              // zero / denormal / inf / nan: leave the data alone
+    int se = 268 - static_cast<int>(e);                                // 127 + 14 - (e - 127)
+    se = se < 1 ? 1 : (se > 253 ? 253 : se);
+    return __builtin_bit_cast(float, static_cast<uint32_t>(se) << 23);
+}
+__device__ __forceinline__ uint32_t hx2_amax_bits(const uint32_t* p) {
+    uint32_t b = 0;
+#pragma unroll
+    for (int i = 0; i < kHx2Slots; ++i) { const uint32_t v = p[i * kHx2SlotStride]; b = v > b ? v : b; }
+    return b;
+}
+__device__ __forceinline__ float hx2_scale(const Hx2Scale& q) {
+    if (!q.p0) return 1.f;
+    uint32_t b = hx2_amax_bits(q.p0);
+    if (q.p1) { const uint32_t b1 = hx2_amax_bits(q.p1); b = b1 > b ? b1 : b; }
+    return hx2_scale_of(__builtin_bit_cast(float, b) * q.mul);
+}
+// exact reciprocal of a power of two with exponent field in [1, 253]
+__device__ __forceinline__ float hx2_inv(float s) { return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(uint32_t, s)); }
+
+// two ALREADY SCALED fp32 values -> packed high terms / packed low terms (round to nearest even; the residual is exact)
+__device__ __forceinline__ void hx2_split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    const _Float16 h0 = static_cast<_Float16>(x0), h1 = static_cast<_Float16>(x1);
+    const _Float16 l0 = static_cast<_Float16>(x0 - static_cast<float>(h0)), l1 = static_cast<_Float16>(x1 - static_cast<float>(h1));
+    hi = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h0)) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h1)) << 16);
+    lo = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, l0)) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, l1)) << 16);
+}
+
+// wave-wide max of a non-negative per-lane value, then at most one atomicMax per wave into the wave's hashed slot of the
+// (zeroed) quantity.  A wave first READS its slot (device scope, relaxed) and only sends the atomic when it would raise the
+// value: the value is monotone, so a stale read can only cause a redundant atomic, never a lost maximum.
+__device__ __forceinline__ void hx2_amax_commit(float m, uint32_t* quantity) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t w = (blockIdx.x + blockIdx.y * gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        uint32_t* slot = quantity + ((w * 2654435761u) >> 27) * kHx2SlotStride;          // top 5 bits of a multiplicative hash
+        const uint32_t bits = __builtin_bit_cast(uint32_t, m);
+        if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+    }
+}
+
 }  // namespace recon
 
 // ---- generic fp32 MFMA GEMM with strided / gathered / head-major operand addressing -------
@@ -150,6 +209,19 @@ int bx3_kmajor_split_k(int32_t M, int32_t N, int32_t K, int32_t batch);
 int bx3_kmajor_splits(int32_t K, int32_t split_k);
 int gemm_bx3_kmajor_batched(int32_t M, int32_t N, int32_t K, const float* A, int64_t lda, int64_t a_bs, const void* Bplanes, int64_t ldb,
                             int64_t b_plane, int64_t b_bs, int32_t batch, int32_t split_k, float* partial, hipStream_t st);
+// split-precision (f16 x 2) MFMA GEMMs on PRE-SPLIT operands, gemm_hx2.hip
+int32_t hx2_kp(int32_t K);
+int hx2_amax(const float* src, int64_t rows, int32_t cols, int64_t ld, uint32_t* slot, hipStream_t st);
+int hx2_split_planes(const float* src, int64_t ld, int64_t src_bs, bool transposed, int32_t rows, int32_t K, int32_t batch, void* dst,
+                     const Hx2Scale& sc, hipStream_t st);
+bool hx2_supported(const void* Ap, int64_t a_plane, int64_t a_row, int64_t a_bs, int32_t K);
+int gemm_hx2_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t a_plane, int64_t a_row, int64_t a_bs, const void* Bplanes,
+                     const OutputDesc& C, const GemmBatch& bt, const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st);
+bool hx2_kmajor_supported(const void* Ap, int64_t lda, int64_t a_plane, int64_t a_bs, const void* Bp, int64_t ldb, int64_t b_plane,
+                          int64_t b_bs, int32_t M, int32_t N);
+int gemm_hx2_kmajor_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t lda, int64_t a_plane, int64_t a_bs, const void* Bp,
+                            int64_t ldb, int64_t b_plane, int64_t b_bs, int32_t batch, int32_t split_k, float* partial, const void* zeros,
+                            const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st);
 // C = epilogue(sum over splits of partial[batch][split][M][N]) through C's addressing; transpose: element (m, n) -> C(n, m)
 int splitk_reduce(const float* partial, int32_t splits, int32_t M, int32_t N, const OutputDesc& C, int64_t c_bs, int32_t batch,
                   int32_t epilogue, bool transpose, hipStream_t st);

@@ -27,12 +27,16 @@ _GAT_PATH = os.environ.get("RECON_GAT_PATH", "auto")
 # edge chain.  Off by default: measured neutral on MI355X (0.927 vs 0.922 ms/step at cfg 2) because the GEMM's
 # 4 waves/SIMD x 128 registers leave no register file for co-resident edge-kernel waves.
 _OVERLAP = os.environ.get("RECON_OVERLAP", "0") == "1"
-# The layer's three large products run on the split-precision GEMMs of csrc/gemm_bx3.hip (3 bf16 terms per fp32 operand,
-# fp32-accurate) when they are large enough to pay for the extra launches (term planes of a, a^T, g_h): measured cross-over
-# on MI355X at cfg-2 widths is 192..256 graphs, i.e. ~6 GFLOP per product.  RECON_GEMM_BX3 = auto (default) | 1 (always) |
-# 0 (never: exact-fp32 MFMA GEMMs).
+# The layer's three large products run on split-precision MFMA GEMMs (fp32-accurate) when they are large enough to pay for
+# the extra launches (term planes of a, a^T, g_h): measured cross-over on MI355X at cfg-2 widths is 192..256 graphs, i.e.
+# ~6 GFLOP per product.  RECON_GEMM_BX3 (one switch for GAT and GraphConvolution) =
+#   auto (default): above the cross-over the f16 x 2 family (csrc/gemm_hx2.hip: 2 half terms per operand under a per-tensor
+#                   power-of-two scale, 3 MFMAs per product, operands pre-split by the kernels that produce them) where the
+#                   shape allows ((2F+R) % 8 == 0, D % 8 == 0), else bf16 x 3; below it the exact-fp32 MFMA GEMMs
+#   2: f16 x 2 always (falls back to bf16 x 3 per shape)   1: bf16 x 3 always (csrc/gemm_bx3.hip)   0: exact fp32 always
 _GEMM_BX3 = os.environ.get("RECON_GEMM_BX3", "auto")
 _BX3_MIN_FLOP = 6.0e9
+SPLIT_BF16X3, SPLIT_F16X2 = 0, 2
 _SIDE_STREAMS = {}
 
 
@@ -226,29 +230,38 @@ class _GATHeadsFunction(torch.autograd.Function):
         return g_x, g_ee, g_a, g_a2, None, None, None, None
 
 
-def _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split=None):
+def _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split=None, aux=None,
+              keep_max=1.0):
     H, D = a2.shape
     return _lib.GatAtpArgs(graph.N, graph.E, x.shape[1], ee.shape[1], D, H, int(bool(concat)), float(alpha),
                            x.data_ptr(), ee.data_ptr(), a.data_ptr(), a2.data_ptr(), _lib.ptr(keep), u.data_ptr(),
                            c_node.data_ptr(), _lib.ptr(c_rel), V.data_ptr(), _lib.ptr(sigma), _lib.ptr(Z), _lib.ptr(Zk),
-                           out.data_ptr(), out.shape[1], _lib.ptr(a_split))
+                           out.data_ptr(), out.shape[1], _lib.ptr(a_split), SPLIT_F16X2 if aux is not None else SPLIT_BF16X3,
+                           float(keep_max), _lib.ptr(aux))
 
 
 def _atp_split_buffer(F_, R, D, H, dev, N=None):
-    """Workspace of the split-precision GEMMs (bf16 term planes of a and a^T), or None to stay on the fp32-MFMA GEMMs
-    (RECON_GEMM_BX3=0, or a product too small to pay for the extra launches)."""
+    """(a_split, aux): workspace of the split-precision GEMMs (term planes of a and a^T) and, for the f16 x 2 family, the
+    2 KiB block of max-magnitude slots + zero page; (None, None) to stay on the fp32-MFMA GEMMs (RECON_GEMM_BX3=0, or a
+    product too small to pay for the extra launches)."""
     if _GEMM_BX3 == "0":
-        return None
-    if _GEMM_BX3 != "1" and N is not None and 2.0 * N * (2 * F_ + R) * H * D < _BX3_MIN_FLOP:
-        return None
-    return torch.empty(_lib.lib().recon_gat_atp_split_bytes(F_, R, D, H), dtype=torch.uint8, device=dev)
+        return None, None
+    if _GEMM_BX3 not in ("1", "2") and N is not None and 2.0 * N * (2 * F_ + R) * H * D < _BX3_MIN_FLOP:
+        return None, None
+    a_split = torch.empty(_lib.lib().recon_gat_atp_split_bytes(F_, R, D, H), dtype=torch.uint8, device=dev)
+    aux = None
+    if _GEMM_BX3 != "1" and (2 * F_ + R) % 8 == 0 and D % 8 == 0:
+        aux = torch.empty(_lib.lib().recon_hx2_aux_bytes(), dtype=torch.uint8, device=dev)     # allocator blocks are 512-byte aligned
+        if aux.data_ptr() % 256:
+            aux = None
+    return a_split, aux
 
 
 class _GATHeadsATPFunction(torch.autograd.Function):
     """Same contract as _GATHeadsFunction, through the aggregate-then-project kernels (csrc/gat_atp.hip)."""
 
     @staticmethod
-    def forward(ctx, x, ee, a, a2, graph, keep, alpha, concat):
+    def forward(ctx, x, ee, a, a2, graph, keep, alpha, concat, keep_max):
         _require_gpu_f32(x, ee, a, a2, keep)
         L = _lib.lib()
         x, ee, a, a2 = x.contiguous(), ee.contiguous(), a.contiguous(), a2.contiguous()
@@ -272,18 +285,22 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         Zk = torch.empty(N, H, **f32) if train else None
         if keep is not None:
             keep = keep.view(H, E)[:, graph.eid_long].t().contiguous()        # [H,E] original order -> [E,H] slot order
-        a_split = _atp_split_buffer(F_, R, D, H, dev, N)
-        args = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split)
+        a_split, aux = _atp_split_buffer(F_, R, D, H, dev, N)
+        if keep is None:
+            keep_max = 1.0
+        elif keep_max is None:                                  # explicit factors without a bound: one host read (tests)
+            keep_max = float(keep.max()) if aux is not None and keep.numel() else 1.0
+        args = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split, aux, keep_max)
         with torch.cuda.device(dev):
             _lib.check(L.recon_gat_atp_fwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_atp_fwd")
         if need_grad:
-            ctx.save_for_backward(x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, a_split)
-            ctx.graph, ctx.alpha, ctx.concat = graph, alpha, concat
+            ctx.save_for_backward(x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, a_split, aux)
+            ctx.graph, ctx.alpha, ctx.concat, ctx.keep_max = graph, alpha, concat, keep_max
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, a_split = ctx.saved_tensors
+        x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, a_split, aux = ctx.saved_tensors
         graph = ctx.graph
         L = _lib.lib()
         H, D = a2.shape
@@ -293,7 +310,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         grad_out = grad_out.contiguous()
         nx, ne, na, na2 = ctx.needs_input_grad[:4]
-        g_h = torch.empty(N, H * D, **f32) if ctx.concat else None
+        g_h = torch.empty(N, H * D, **f32) if (ctx.concat and aux is None) else None     # f16 x 2: g_h exists as half planes only
         g_V = torch.empty(N, H, W, **f32)
         g_sigma = torch.empty(E, H, **f32)
         Gxs = torch.empty(E, F_, **f32)
@@ -308,8 +325,10 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         g_a = torch.empty(H, D, W, **f32) if (na or na2) else None
         g_a2 = torch.empty(H, D, **f32) if (na or na2) else None
         gh_split = (torch.empty(L.recon_gat_atp_bwd_split_bytes(N, D, H), dtype=torch.uint8, device=dev)
-                    if (a_split is not None and g_a is not None and os.environ.get("RECON_GEMM_BX3_KM", "1") != "0") else None)
-        fwd = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, ctx.alpha, ctx.concat, a_split)
+                    if (aux is not None or (a_split is not None and g_a is not None and os.environ.get("RECON_GEMM_BX3_KM", "1") != "0"))
+                    else None)
+        fwd = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, ctx.alpha, ctx.concat, a_split, aux,
+                        ctx.keep_max)
         args = _lib.GatAtpBwdArgs(fwd, grad_out.data_ptr(), grad_out.shape[1], _lib.ptr(g_h), g_V.data_ptr(),
                                   _lib.ptr(g_sigma), _lib.ptr(Gxs), gxd.data_ptr(), Gs.data_ptr(), g_u.data_ptr(),
                                   q.data_ptr(), partial.data_ptr(), partial2.data_ptr(), _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2),
@@ -326,12 +345,12 @@ class _GATHeadsATPFunction(torch.autograd.Function):
                 _lib.check(L.recon_gat_atp_bwd_phase(gc, ac, 2, main.cuda_stream), "recon_gat_atp_bwd_phase")
                 main.wait_stream(side)
                 _lib.check(L.recon_gat_atp_bwd_phase(gc, ac, 8, main.cuda_stream), "recon_gat_atp_bwd_phase")
-                for t in (grad_out, g_h, V, g_a, partial, a2, a):      # used on the side stream: keep the allocator honest
+                for t in (grad_out, g_h, V, g_a, partial, a2, a, gh_split, aux):      # used on the side stream: keep the allocator honest
                     if t is not None:
                         t.record_stream(side)
             else:
                 _lib.check(L.recon_gat_atp_bwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_atp_bwd")
-        return g_x, g_ee, (g_a if na else None), (g_a2 if na2 else None), None, None, None, None
+        return g_x, g_ee, (g_a if na else None), (g_a2 if na2 else None), None, None, None, None, None
 
 
 def gat_path_for(N, E, F_, R, D, H):
@@ -346,15 +365,16 @@ def gat_path_for(N, E, F_, R, D, H):
     return "atp" if (ok and 2 * E >= N) else "proj"
 
 
-def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=True):
+def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=True, keep_max=None):
     """Fused forward of H `SpGraphAttentionLayer`s that share their inputs (GAT/models.py:71-72).
 
     x [N,F]; edge_embed_all [E,R] (1-hop rows then n-hop rows, original order); a [H,D,2F+R];
     a_2 [H,D]; graph = prepare_graph(edge, edge_list_nhop, N); keep [H,E] dropout factors in
-    original edge order or None.  Returns [N, H*D] (heads concatenated along dim 1)."""
+    original edge order or None; keep_max an upper bound of them (1/(1-p); read back from `keep` when omitted).
+    Returns [N, H*D] (heads concatenated along dim 1)."""
     H, D = a_2.shape
     if gat_path_for(graph.N, graph.E, x.shape[1], edge_embed_all.shape[1], D, H) == "atp":
-        return _GATHeadsATPFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat)
+        return _GATHeadsATPFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat, keep_max)
     return _GATHeadsFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat)
 
 
@@ -392,12 +412,18 @@ class SpGraphAttentionLayer(nn.Module):
             return self.dropout(torch.ones(E, dtype=torch.float32, device=device)).view(1, E)
         return None
 
+    def keep_bound(self):
+        """Upper bound of the dropout factors draw_keep produces: 1 / (1 - p)."""
+        p = float(self.dropout.p)
+        return 1.0 / (1.0 - p) if p < 1.0 else 1.0
+
     def forward(self, input, edge, edge_embed, edge_list_nhop, edge_embed_nhop):
         N = input.size()[0]                                  # not self.num_nodes (GAT/layers.py:112)
         graph = prepare_graph(edge, edge_list_nhop, N)
         ee = cat_edge_embed(edge_embed, edge_list_nhop, edge_embed_nhop)
         keep = self.draw_keep(graph.E, input.device)
-        out = gat_heads(input, ee, self.a.unsqueeze(0), self.a_2, graph, keep, self.alpha, self.concat)
+        out = gat_heads(input, ee, self.a.unsqueeze(0), self.a_2, graph, keep, self.alpha, self.concat,
+                        keep_max=self.keep_bound() if keep is not None else None)
         if _DEBUG_NAN:                                       # the reference's asserts (:147,:167,:172)
             assert not torch.isnan(out).any()
         return out

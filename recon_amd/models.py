@@ -69,7 +69,8 @@ class SpGAT(nn.Module):
         a, a2 = self.fused_head_params()                                  # [H, D, 2F+R], [H, D]
         keeps = [att.draw_keep(graph.E, x.device) for att in self.attentions]   # reference draw order
         keep = torch.cat(keeps, dim=0) if keeps[0] is not None else None
-        return gat_heads(x, ee, a, a2, graph, keep, self.alpha, True)
+        return gat_heads(x, ee, a, a2, graph, keep, self.alpha, True,
+                         keep_max=self.attentions[0].keep_bound() if keep is not None else None)
 
     def forward(self, Corpus_, entity_embeddings, relation_embed, edge_list, edge_type, edge_embed,
                 edge_list_nhop, edge_type_nhop):

@@ -38,7 +38,7 @@ def hashed_uniform(shape, salt, lo=-1.0, hi=1.0):
 # GPU tests that run the layers (GAT heads / SpGAT / SpKBGAT / GraphConvolution) are run once per GEMM family: the layer
 # picks its family by problem size ("auto": exact-fp32 MFMA GEMMs below ~6 GFLOP per product, split-precision above), so on
 # the small golden / oracle shapes each family has to be forced to get odd-shape and tile-tail coverage of its own.
-GEMM_FAMILIES = ("1", "0")          # values of recon_amd.gat_layers._GEMM_BX3 (shared by gcn_layers)
+GEMM_FAMILIES = ("2", "1", "0")     # values of recon_amd.gat_layers._GEMM_BX3 (shared by gcn_layers): f16 x 2, bf16 x 3, exact fp32
 _NO_FAMILY = ("test_graph_build", "test_sgemm", "test_spmm", "test_full_size_cfg2_split_precision_vs_fp32_gemm",
               "test_block_adjacency", "test_propagation", "test_start_entity", "test_gpgnn", "test_phased_backward")
 
@@ -49,14 +49,14 @@ def pytest_generate_tests(metafunc):
     is_gpu = metafunc.definition.get_closest_marker("gpu") is not None
     name = metafunc.definition.originalname
     if is_gpu and not name.startswith(_NO_FAMILY):
-        metafunc.parametrize("gemm_family", GEMM_FAMILIES, indirect=True, ids=["gemm_bx3", "gemm_f32"])
+        metafunc.parametrize("gemm_family", GEMM_FAMILIES, indirect=True, ids=["gemm_hx2", "gemm_bx3", "gemm_f32"])
 
 
 @pytest.fixture(autouse=True)
 def gemm_family(request, monkeypatch):
     fam = getattr(request, "param", None)
     if fam is None and request.node.get_closest_marker("gpu") is not None:
-        fam = "1"                    # un-parametrized GPU tests: the benchmark's family
+        fam = "2"                    # un-parametrized GPU tests: the benchmark's family
     if fam is not None:
         from recon_amd import gat_layers
         monkeypatch.setattr(gat_layers, "_GEMM_BX3", fam)

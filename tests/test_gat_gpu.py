@@ -141,6 +141,63 @@ def test_sgemm_bx3_tn(M, N, K):
     assert (err <= bound).all(), float((err / bound).max())
 
 
+def _hx2_ws(nbytes):
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev())
+    off = (-ws.data_ptr()) % 256
+    return ws, ws.data_ptr() + off
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-6, 3e4])
+@pytest.mark.parametrize("M,N,K", [(128, 208, 32), (200, 72, 56), (33, 257, 24), (700, 200, 600), (513, 600, 200),
+                                   (300, 204, 40), (1000, 25, 8)])
+def test_sgemm_hx2(M, N, K, scale):
+    """Split-precision (2 x f16, per-tensor power-of-two scale) MFMA GEMM: fp32-class accuracy against an fp64 product, at
+    magnitudes far outside half's own range."""
+    from recon_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * torch.exp(2.0 * torch.randn(M, 1, generator=g)) * scale     # rows of very different scale
+    B = torch.randn(N, K, generator=g) / scale
+    Ad, Bd = A.to(dev()), B.to(dev())
+    Cd = torch.full((M, N), float("nan"), device=dev())
+    L = _lib.lib()
+    ws, wsp = _hx2_ws(L.recon_sgemm_hx2_workspace_bytes(M, N, K))
+    rc = L.recon_sgemm_hx2(M, N, K, Ad.data_ptr(), K, Bd.data_ptr(), K, Cd.data_ptr(), N, wsp, _lib.current_stream())
+    assert rc == 0
+    ref = A.double() @ B.double().t()
+    # the bound test_sgemm_bx3 holds bf16 x 3 to, plus the floor of a per-TENSOR scale: elements more than 2^18 below their
+    # tensor's maximum keep an absolute error of 2^-39 of that maximum (their low half term is subnormal)
+    Aa, Ba = A.double().abs(), B.double().abs()
+    bound = (Aa @ Ba.t()) * (2.0 ** -20) + (2.0 ** -38) * (Aa.max() * Ba.sum(1)[None, :] + Ba.max() * Aa.sum(1)[:, None]) + 1e-30
+    err = (Cd.cpu().double() - ref).abs()
+    assert torch.isfinite(Cd).all()
+    assert (err <= bound).all(), float((err / bound).max())
+    f32 = (Ad @ Bd.t()).cpu().double()
+    assert err.max() <= 4.0 * (f32 - ref).abs().max() + 1e-12
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 208, 64), (600, 200, 8192), (36, 216, 1000), (260, 24, 77), (4, 424, 33), (300, 300, 4096),
+                                   (12, 5, 50), (8, 8, 1)])
+def test_sgemm_hx2_tn(M, N, K):
+    """The k-major (weight-gradient) form of the 2 x f16 GEMM: C = A^T B, A [K,M], B [K,N]; K tails come from a page of zeros."""
+    from recon_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(K, M, generator=g) * torch.exp(2.0 * torch.randn(1, M, generator=g)) * 1e-3
+    B = torch.randn(K, N, generator=g) * 50.0
+    Ad, Bd = A.to(dev()), B.to(dev())
+    Cd = torch.full((M, N), float("nan"), device=dev())
+    L = _lib.lib()
+    ws, wsp = _hx2_ws(L.recon_sgemm_hx2_tn_workspace_bytes(M, N, K))
+    ws.fill_(0xFF)                                                     # NaN patterns everywhere the kernels must not read
+    rc = L.recon_sgemm_hx2_tn(M, N, K, Ad.data_ptr(), M, Bd.data_ptr(), N, Cd.data_ptr(), N, wsp, _lib.current_stream())
+    assert rc == 0
+    ref = A.double().t() @ B.double()
+    Aa, Ba = A.double().abs(), B.double().abs()
+    bound = (Aa.t() @ Ba) * (2.0 ** -20) + (2.0 ** -38) * (Aa.max() * Ba.sum(0)[None, :] + Ba.max() * Aa.sum(0)[:, None]) + 1e-30
+    err = (Cd.cpu().double() - ref).abs()
+    assert torch.isfinite(Cd).all()
+    assert (err <= bound).all(), float((err / bound).max())
+
+
 # ------------------------------------------------------------------------------- G1-G3
 @pytest.mark.parametrize("name", ["spmm1_o1", "spmm1_oD"])
 def test_spmm_golden(name):
@@ -318,9 +375,11 @@ def test_full_size_cfg2_properties():
     close(out2, out, atol=2e-5, what="edge permutation invariance")
 
 
-def test_full_size_cfg2_split_precision_vs_fp32_gemm(monkeypatch):
-    """BASELINE.json configs[1] at full size: the layer on the split-precision GEMMs (3 bf16 terms per fp32 operand)
-    and on the exact-fp32 MFMA GEMMs must agree in outputs and in every gradient to fp32 round-off."""
+@pytest.mark.parametrize("family", ["2", "1"])
+def test_full_size_cfg2_split_precision_vs_fp32_gemm(family, monkeypatch):
+    """BASELINE.json configs[1] at full size: the layer on the split-precision GEMMs (2 half terms under a per-tensor scale,
+    or 3 bf16 terms per fp32 operand) and on the exact-fp32 MFMA GEMMs must agree in outputs and in every gradient to fp32
+    round-off."""
     from recon_amd import gat_layers
     from recon_amd.graph import prepare_graph
     d = dev()
@@ -332,13 +391,13 @@ def test_full_size_cfg2_split_precision_vs_fp32_gemm(monkeypatch):
     G = torch.randn(B * n, H * D, generator=g).to(d)
     graph = prepare_graph(edge.to(d), None, B * n)
     res = {}
-    for mode in ("1", "0"):
+    for mode in (family, "0"):
         monkeypatch.setattr(gat_layers, "_GEMM_BX3", mode)
         leaves = [t.to(d).requires_grad_(True) for t in (x, ee, a, a2)]
         out = gat_layers.gat_heads(*leaves, graph, None, 0.2, True)
         grads = torch.autograd.grad(out, leaves, G)
         res[mode] = [out.detach()] + [t.detach() for t in grads]
-    for name, u, v in zip(("out", "g_x", "g_edge_embed", "g_a", "g_a_2"), res["1"], res["0"]):
+    for name, u, v in zip(("out", "g_x", "g_edge_embed", "g_a", "g_a_2"), res[family], res["0"]):
         close(u, v, atol=2e-5, rel_to_max=2e-6, what="bx3 vs fp32 GEMM: " + name)
 
 

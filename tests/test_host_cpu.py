@@ -238,7 +238,7 @@ def test_gemm_family_policy(monkeypatch):
     """auto: small products stay on the exact-fp32 MFMA GEMMs (None workspace); 0: always."""
     from recon_amd import gat_layers
     monkeypatch.setattr(gat_layers, "_GEMM_BX3", "auto")
-    assert gat_layers._atp_split_buffer(50, 50, 50, 1, "cpu", N=256) is None           # cfg 1
+    assert gat_layers._atp_split_buffer(50, 50, 50, 1, "cpu", N=256) == (None, None)   # cfg 1
     assert 2.0 * 8192 * 600 * 8 * 200 > gat_layers._BX3_MIN_FLOP                          # cfg 2 takes the split-precision kernels
     monkeypatch.setattr(gat_layers, "_GEMM_BX3", "0")
-    assert gat_layers._atp_split_buffer(200, 200, 200, 8, "cpu", N=8192) is None
+    assert gat_layers._atp_split_buffer(200, 200, 200, 8, "cpu", N=8192) == (None, None)
