@@ -13,6 +13,7 @@
 // Layouts (fp32): u [H][W], c_node [N][2H] (dst half | src half), c_rel / sigma / keep [E][H] in
 // CSR-slot order, Z / Zk [N][H], V [N][H][W], W = 2F+R.
 #include <math.h>
+#include <stdlib.h>
 #include "recon_common.h"
 
 namespace recon {
@@ -473,15 +474,29 @@ struct AtpBwdK {
 
 // wave = one destination node; head groups of HT are walked one after the other by the SAME wave so the
 // per-edge outputs (g_edge_embed row, Gxs row) can be accumulated across groups without atomics.
+#ifndef RECON_K2_PF
+#define RECON_K2_PF 2
+#endif
+#ifndef RECON_K2_OCC
+#define RECON_K2_OCC 3
+#endif
 template <int VEC, int KR, int HT>
-__global__ void __launch_bounds__(kBlock) k_gat_atp_bwd(const AtpBwdK p) {
+__global__ void __launch_bounds__(kBlock, RECON_K2_OCC) k_gat_atp_bwd(const AtpBwdK p) {
     extern __shared__ __attribute__((aligned(16))) float U[];          // [H][W]: u_dst | u_src | u_rel per head
     const int F = p.F, R = p.R, H = p.H, W = 2 * F + R;
-    for (int idx = threadIdx.x; idx < H * W; idx += kBlock) U[idx] = p.u[idx];
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int node = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + wave;
+    // The walk is a chain of dependent round trips (row pointers -> slot indices -> rows); start it before anything else:
+    // the slot -> (source node, edge id) indices of the first 64 slots come with ONE coalesced load per array (lane j holds
+    // slot beg + j) and are handed out with v_readlane instead of an index load in front of every row load.
+    const int nodec = min(node, p.N - 1);
+    const int beg = p.rowptr[nodec], end = p.rowptr[nodec + 1];
+    const int cn0 = min(64, end - beg);
+    int srcv0 = 0, eidv0 = 0;
+    if (beg < end) { const int kk = beg + min(lane, cn0 - 1); srcv0 = p.src[kk]; eidv0 = p.eid[kk]; }
+    for (int idx = threadIdx.x; idx < H * W; idx += kBlock) U[idx] = p.u[idx];
+    __syncthreads();
     if (node >= p.N) return;
     int cf[KR]; bool aF[KR], aR[KR];
 #pragma unroll
@@ -491,7 +506,6 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_bwd(const AtpBwdK p) {
     int cfF[KR], cfR[KR];
 #pragma unroll
     for (int r = 0; r < KR; ++r) { cfF[r] = aF[r] ? cf[r] : 0; cfR[r] = aR[r] ? cf[r] : 0; }
-    const int beg = p.rowptr[node], end = p.rowptr[node + 1];
     float xi[KR][VEC], gxd[KR][VEC];
 #pragma unroll
     for (int r = 0; r < KR; ++r) {
@@ -510,12 +524,37 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_bwd(const AtpBwdK p) {
         const int h0 = hg * HT;
         const int myh = h0 + hl;
         const bool hv = myh < H;
+        // ring of PF register slots (static indices: the loop body is unrolled PF times) holding the rows / score of the next
+        // PF edges; filled for the first edges BEFORE the g_V rows are requested, so both are in flight together
+        constexpr int PF = KR == 1 ? RECON_K2_PF : (KR == 2 ? 2 : 1);
+        const int mh = hv ? myh : h0;
+        int c0 = beg, cn = cn0, srcv = srcv0, eidv = eidv0;
+        const float* keepp = p.keep ? p.keep : p.sigma;
+        float xs_r[PF][KR][VEC], re_r[PF][KR][VEC], sg_r[PF], kf_r[PF];
+        auto fetch_edge = [&](int slot, int j) {                         // j: position inside the chunk (uniform), clamped by the caller
+            const int s_ = __builtin_amdgcn_readlane(srcv, j), e_ = __builtin_amdgcn_readlane(eidv, j);
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {                               // lanes past F / R: garbage x 0 (their g_V terms are zeroed)
+                load_vec<VEC>(xs_r[slot][r], p.x + static_cast<int64_t>(s_) * F + cfF[r]);
+                load_vec<VEC>(re_r[slot][r], p.ee + static_cast<int64_t>(e_) * R + cfR[r]);
+            }
+            sg_r[slot] = p.sigma[static_cast<int64_t>(c0 + j) * H + mh];
+            kf_r[slot] = keepp[static_cast<int64_t>(c0 + j) * H + mh];  // eval: re-reads sigma, replaced by 1 at the use (no branch)
+        };
+        if (beg < end) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) fetch_edge(u, min(u, cn - 1));
+        }
         const float Zl = hv ? p.Z[static_cast<int64_t>(node) * H + myh] : 1.f;
         const float Zkl = hv ? p.Zk[static_cast<int64_t>(node) * H + myh] : 0.f;
         const float invl = 1.f / Zl;
         float gVs[HT][KR][VEC], gVr[HT][KR][VEC];
         float pdv[HT];
         const float ql = hv ? p.q[static_cast<int64_t>(node) * H + myh] : 0.f;
+        // (Requesting all 3 HT rows at once — branch free, the destination part staged through LDS-DMA — was measured: the
+        // extra live registers spill at 3 waves per SIMD and the kernel gets slower, 80 -> 91 us at cfg 2; so was a persistent
+        // node-pipelined form with the next node's rows in flight: 107 us at the one wave per SIMD its 346 registers allow.
+        // PMC: 1 580 VALU instructions per node keep a SIMD's issue port busy for 42 us of the kernel's 80 as it is.)
 #pragma unroll
         for (int h = 0; h < HT; ++h) {
             float pd = 0.f;
@@ -546,89 +585,89 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_bwd(const AtpBwdK p) {
         const float tdl = multi_sum<HT>(pdv, lane);
         const float gZl = -ql * invl;                                     // d loss / d Z   (every part of V is ~ 1/Z)
         float sum_gs = 0.f;
-        // software pipeline: the rows / score of edge k+1 are in flight while edge k is processed
-        float xs_n[KR][VEC], re_n[KR][VEC], sg_n = 0.f, kf_n = 1.f;
-        int e_n = 0;
-        auto fetch_edge = [&](int k) {
-            const int s = p.src[k];
-            e_n = p.eid[k];
+        while (c0 < end) {
+            for (int j0 = 0; j0 < cn; j0 += PF) {
 #pragma unroll
-            for (int r = 0; r < KR; ++r) {                              // lanes past F / R: garbage x 0 (their g_V terms are zeroed)
-                load_vec<VEC>(xs_n[r], p.x + static_cast<int64_t>(s) * F + cfF[r]);
-                load_vec<VEC>(re_n[r], p.ee + static_cast<int64_t>(e_n) * R + cfR[r]);
-            }
-            const int mh = hv ? myh : h0;
-            sg_n = p.sigma[static_cast<int64_t>(k) * H + mh];
-            kf_n = p.keep ? p.keep[static_cast<int64_t>(k) * H + mh] : 1.f;
-        };
-        if (beg < end) fetch_edge(beg);
-        for (int k = beg; k < end; ++k) {
-            float xs[KR][VEC], re[KR][VEC];
+                for (int u = 0; u < PF; ++u) {
+                    const int j = j0 + u;
+                    if (j >= cn) break;                                  // wave-uniform
+                    const int k = c0 + j;
+                    const int e = __builtin_amdgcn_readlane(eidv, j);
+                    float xs[KR][VEC], re[KR][VEC];
 #pragma unroll
-            for (int r = 0; r < KR; ++r)
+                    for (int r = 0; r < KR; ++r)
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) { xs[r][v] = xs_n[r][v]; re[r][v] = re_n[r][v]; }
-            const float sg = sg_n, kf = kf_n;
-            const int e = e_n;
-            if (k + 1 < end) fetch_edge(k + 1);
-            float part[HT];
+                        for (int v = 0; v < VEC; ++v) { xs[r][v] = xs_r[u][r][v]; re[r][v] = re_r[u][r][v]; }
+                    const float sg = sg_r[u], kf = p.keep ? kf_r[u] : 1.f;
+                    if (j + PF < cn) fetch_edge(u, j + PF);              // wave-uniform; refills the slot just consumed
+                    float part[HT];
 #pragma unroll
-            for (int h = 0; h < HT; ++h) {
-                part[h] = 0.f;
+                    for (int h = 0; h < HT; ++h) {
+                        part[h] = 0.f;
 #pragma unroll
-                for (int r = 0; r < KR; ++r)
+                        for (int r = 0; r < KR; ++r)
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) part[h] = fmaf(gVs[h][r][v], xs[r][v], fmaf(gVr[h][r][v], re[r][v], part[h]));
-            }
-            const float tl = multi_sum<HT>(part, lane);
-            const float w = hv ? expf(-(sg > 0.f ? sg : p.alpha * sg)) : 0.f;
-            const float gw = fmaf(kf * (tl + tdl), invl, gZl);
-            const float gs = hv ? -gw * w * (sg > 0.f ? 1.f : p.alpha) : 0.f;
-            const float al_ = kf * w * invl;
-            sum_gs += gs;
-            if (hv && writer) p.gsigma[static_cast<int64_t>(k) * H + myh] = gs;
-            float gxs[KR][VEC], gr[KR][VEC];
+                            for (int v = 0; v < VEC; ++v) part[h] = fmaf(gVs[h][r][v], xs[r][v], fmaf(gVr[h][r][v], re[r][v], part[h]));
+                    }
+                    const float tl = multi_sum<HT>(part, lane);
+                    const float w = hv ? expf(-(sg > 0.f ? sg : p.alpha * sg)) : 0.f;
+                    const float gw = fmaf(kf * (tl + tdl), invl, gZl);
+                    const float gs = hv ? -gw * w * (sg > 0.f ? 1.f : p.alpha) : 0.f;
+                    const float al_ = kf * w * invl;
+                    sum_gs += gs;
+                    if (hv && writer) p.gsigma[static_cast<int64_t>(k) * H + myh] = gs;
+                    float gxs[KR][VEC], gr[KR][VEC];
 #pragma unroll
-            for (int r = 0; r < KR; ++r)
+                    for (int r = 0; r < KR; ++r)
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) { gxs[r][v] = 0.f; gr[r][v] = 0.f; }
+                        for (int v = 0; v < VEC; ++v) { gxs[r][v] = 0.f; gr[r][v] = 0.f; }
 #pragma unroll
-            for (int h = 0; h < HT; ++h) {
-                if (h0 + h < H) {
-                    const float ah = lane_bcast(al_, h << SH), bh = lane_bcast(gs, h << SH);
-                    const float* uh = U + (h0 + h) * W;
+                    for (int h = 0; h < HT; ++h) {
+                        if (h0 + h < H) {
+                            const float ah = lane_bcast(al_, h << SH), bh = lane_bcast(gs, h << SH);
+                            const float* uh = U + (h0 + h) * W;
+#pragma unroll
+                            for (int r = 0; r < KR; ++r) {
+                                float us[VEC], ur[VEC];
+                                if (aF[r]) {
+                                    load_vec<VEC>(us, uh + F + cf[r]);
+#pragma unroll
+                                    for (int v = 0; v < VEC; ++v) gxs[r][v] = fmaf(ah, gVs[h][r][v], fmaf(bh, us[v], gxs[r][v]));
+                                }
+                                if (aR[r]) {
+                                    load_vec<VEC>(ur, uh + 2 * F + cf[r]);
+#pragma unroll
+                                    for (int v = 0; v < VEC; ++v) gr[r][v] = fmaf(ah, gVr[h][r][v], fmaf(bh, ur[v], gr[r][v]));
+                                }
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < KR; ++r) {
-                        float us[VEC], ur[VEC];
                         if (aF[r]) {
-                            load_vec<VEC>(us, uh + F + cf[r]);
+                            float* dst = p.Gxs + static_cast<int64_t>(k) * F + cf[r];
+                            if (hg > 0) { float o[VEC]; load_vec<VEC>(o, dst);
 #pragma unroll
-                            for (int v = 0; v < VEC; ++v) gxs[r][v] = fmaf(ah, gVs[h][r][v], fmaf(bh, us[v], gxs[r][v]));
+                                for (int v = 0; v < VEC; ++v) gxs[r][v] += o[v]; }
+                            store_vec<VEC>(dst, gxs[r]);
                         }
-                        if (aR[r]) {
-                            load_vec<VEC>(ur, uh + 2 * F + cf[r]);
+                        if (aR[r] && p.g_ee) {
+                            float* dst = p.g_ee + static_cast<int64_t>(e) * R + cf[r];
+                            if (hg > 0) { float o[VEC]; load_vec<VEC>(o, dst);
 #pragma unroll
-                            for (int v = 0; v < VEC; ++v) gr[r][v] = fmaf(ah, gVr[h][r][v], fmaf(bh, ur[v], gr[r][v]));
+                                for (int v = 0; v < VEC; ++v) gr[r][v] += o[v]; }
+                            store_vec<VEC>(dst, gr[r]);
                         }
                     }
                 }
             }
+            c0 += 64;
+            if (c0 < end) {                                              // next chunk of a long row: new index vectors, refill the ring
+                cn = min(64, end - c0);
+                const int kk = c0 + min(lane, cn - 1);
+                srcv = p.src[kk]; eidv = p.eid[kk];
 #pragma unroll
-            for (int r = 0; r < KR; ++r) {
-                if (aF[r]) {
-                    float* dst = p.Gxs + static_cast<int64_t>(k) * F + cf[r];
-                    if (hg > 0) { float o[VEC]; load_vec<VEC>(o, dst);
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) gxs[r][v] += o[v]; }
-                    store_vec<VEC>(dst, gxs[r]);
-                }
-                if (aR[r] && p.g_ee) {
-                    float* dst = p.g_ee + static_cast<int64_t>(e) * R + cf[r];
-                    if (hg > 0) { float o[VEC]; load_vec<VEC>(o, dst);
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) gr[r][v] += o[v]; }
-                    store_vec<VEC>(dst, gr[r]);
-                }
+                for (int u = 0; u < PF; ++u) fetch_edge(u, min(u, cn - 1));
             }
         }
         if (hv && writer) p.Gs_dst[static_cast<int64_t>(node) * 2 * H + myh] = sum_gs;
@@ -1090,6 +1129,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
     atp_shape(F, R, H, &s);
     const size_t lds_u = static_cast<size_t>(H) * W * sizeof(float);
     if (lds_u > 64 * 1024) return RECON_ERR_UNSUPPORTED;
+    const size_t lds_k2 = lds_u;
 
     // (0) through the ELU, and q = g_h . h per (node, head)
     const float* gh = b->grad_out;
@@ -1137,7 +1177,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         p.gsigma = b->g_sigma; p.Gs_dst = b->Gs; p.Gxs = b->Gxs; p.gxd = b->gxd; p.g_ee = b->g_edge_embed;
         p.N = N; p.E = E; p.F = F; p.R = R; p.H = H; p.alpha = a->alpha;
         dim3 grid(static_cast<unsigned>(ceil_div64(N, kBlock / 64)));
-#define CALL_BWD(V_, K_, H_) hipLaunchKernelGGL((k_gat_atp_bwd<V_, K_, H_>), grid, dim3(kBlock), lds_u, st, p)
+#define CALL_BWD(V_, K_, H_) hipLaunchKernelGGL((k_gat_atp_bwd<V_, K_, H_>), grid, dim3(kBlock), lds_k2, st, p)
         ATP_DISPATCH(s, CALL_BWD);
 #undef CALL_BWD
         RECON_CHECK_LAUNCH();
