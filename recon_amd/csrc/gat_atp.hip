@@ -320,7 +320,7 @@ struct AtpFwdK {
     float* V; float* sigma; float* Z; float* Zk;
     int32_t N, E, F, R, H;
     float alpha;
-    int32_t planes;             // 1: V is written as two half planes [2][N*H][W] of s_V * V (gemm_hx2.hip) instead of fp32 [N][H][W]
+    int32_t planes;             // 1: V is written as half terms [N*H][2][W] of s_V * V (gemm_hx2.hip: high row | low row) instead of fp32 [N][H][W]
     Hx2Scale vs;                // s_V from max(|x|, |edge_embed|) * keep_max, an upper bound of |V| (V rows are k-weighted means)
 };
 
@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_fwd(const AtpFwdK p) {
         for (int v = 0; v < VEC; ++v) xi[r][v] = 0.f;
         if (aF[r]) load_vec<VEC>(xi[r], p.x + static_cast<int64_t>(node) * F + cf[r]);
     }
-    const int64_t vplane = static_cast<int64_t>(p.N) * H * W;
+    const int64_t vplane = W;
 #pragma unroll
     for (int h = 0; h < HT; ++h) {
         if (h0 + h < H) {
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_fwd(const AtpFwdK p) {
             const float zk = lane_bcast(Zkl, h) * invh;
             const int64_t vrow = (static_cast<int64_t>(node) * H + h0 + h) * W;
             float* Vr = p.V + vrow;
-            _Float16* Vh = reinterpret_cast<_Float16*>(p.V) + vrow;
+            _Float16* Vh = reinterpret_cast<_Float16*>(p.V) + 2 * vrow;       // the two term rows of a (node, head) lie side by side: 4 W bytes, as in fp32
 #pragma unroll
             for (int r = 0; r < KR; ++r) {
                 float o[VEC];
@@ -945,7 +945,9 @@ extern "C" size_t recon_gat_atp_split_bytes(int32_t F, int32_t R, int32_t D, int
     return split_part_bytes(D, W, H) + split_part_bytes(W, D, H);
 }
 
-// f16 x 2 mode (gemm_hx2.hip): V, g_h, a and a^T live as two half planes each and all three large products run on them.
+// f16 x 2 mode (gemm_hx2.hip): V, g_h, a and a^T live as two half terms each and all three large products run on them
+// (V as [N][H][2][W], g_h as [N][2][kp(HD)]: a row's high and low terms side by side, so that the producers write one
+// contiguous piece per row as they did in fp32).
 // All or nothing: the planes replace the fp32 tensors, so the decision must be the same in every stage of a step.
 //   aux (recon_hx2_aux_bytes(), 256-byte aligned): amax quantities [0] a, [1] x, [2] edge_embed, [3] grad_out (kHx2Slots hashed
 //   slots each), then a page of zeros
@@ -1064,8 +1066,8 @@ extern "C" int recon_gat_atp_project(const recon_graph* g, const recon_gat_atp_a
     bt.batch = a->H; bt.a_bs = W; bt.b_bs = static_cast<int64_t>(a->D) * W; bt.c_bs = a->D;
     bt.epilogue = a->concat ? 1 : 0;
     if (atp_hx2(a))
-        return gemm_hx2_batched(a->N, a->D, W, a->V, static_cast<int64_t>(a->N) * a->H * W, static_cast<int64_t>(a->H) * W, W, a->a_split, C, bt,
-                                atp_scale_v(a), atp_scale_a(a), as_stream(stream));
+        return gemm_hx2_batched(a->N, a->D, W, a->V, W, 2LL * a->H * W, 2LL * W, a->a_split, C, bt, atp_scale_v(a), atp_scale_a(a),
+                                as_stream(stream));                   // V terms [N][H][2][W]: plane stride W, row stride 2 H W, head stride 2 W
     if (a->a_split && bx3_supported(A, W, bt)) return gemm_bx3_batched(a->N, a->D, W, A, a->a_split, C, bt, as_stream(stream));
     return gemm_f32_batched(a->N, a->D, W, A, true, B, true, C, bt, 1, nullptr, as_stream(stream));
 }
@@ -1146,8 +1148,8 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
             if (rc != RECON_OK) return rc;
         }
         hipLaunchKernelGGL(k_elu_grad_q, dim3(static_cast<unsigned>(ceil_div64(1LL * N * H, 16))), dim3(256), 0, st, b->grad_out, b->ld_gout, a->out,
-                           a->ld_out, N, H, D, a->concat, (a->concat && !hx2) ? b->g_h : nullptr, b->q, ghp, ld_ghp, static_cast<int64_t>(N) * ld_ghp,
-                           hx2 ? 1 : 0, hx2 ? atp_scale_g(a) : Hx2Scale{nullptr, nullptr, 1.f});
+                           a->ld_out, N, H, D, a->concat, (a->concat && !hx2) ? b->g_h : nullptr, b->q, ghp, hx2 ? 2 * ld_ghp : ld_ghp,
+                           hx2 ? ld_ghp : static_cast<int64_t>(N) * ld_ghp, hx2 ? 1 : 0, hx2 ? atp_scale_g(a) : Hx2Scale{nullptr, nullptr, 1.f});
     }
     if (a->concat) { gh = b->g_h; ld_gh = static_cast<int32_t>(HD); }
     GemmBatch bt;
@@ -1160,7 +1162,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         OutputDesc C = plain_output(b->g_V, static_cast<int64_t>(H) * W);
         bt.a_bs = D; bt.b_bs = static_cast<int64_t>(D) * W; bt.c_bs = W;
         if (hx2)
-            rc = gemm_hx2_batched(N, W, D, b->gh_split, static_cast<int64_t>(N) * ld_ghp, ld_ghp, D,
+            rc = gemm_hx2_batched(N, W, D, b->gh_split, ld_ghp, 2 * ld_ghp, D,              // g_h terms [N][2][ld_ghp]
                                   static_cast<const char*>(a->a_split) + split_part_bytes(D, W, H), C, bt, atp_scale_g(a), atp_scale_a(a), st);
         else if (a->a_split && bx3_supported(A, D, bt))
             rc = gemm_bx3_batched(N, W, D, A, static_cast<const char*>(a->a_split) + split_part_bytes(D, W, H), C, bt, st);
@@ -1216,7 +1218,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
             const int64_t ldv = static_cast<int64_t>(H) * W;
             if (hx2) {                                                                     // f16 x 2: both operands are half planes
                 const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));
-                rc = gemm_hx2_kmajor_batched(W, D, N, a->V, ldv, static_cast<int64_t>(N) * ldv, W, b->gh_split, ld_ghp, static_cast<int64_t>(N) * ld_ghp, D,
+                rc = gemm_hx2_kmajor_batched(W, D, N, a->V, 2 * ldv, W, 2LL * W, b->gh_split, 2 * ld_ghp, ld_ghp, D,
                                              H, sk, b->partial, static_cast<const char*>(a->aux) + kHx2ZeroPageOffset, atp_scale_v(a), atp_scale_g(a), st);
                 if (rc == RECON_OK) rc = splitk_reduce(b->partial, sk, W, D, C, bw.c_bs, H, 0, true, st);
             } else if (gh_planes && bx3_kmajor_supported(a->V, ldv, W, ld_ghp, D, W, D)) {    // split-precision MFMA, both operands k-major
