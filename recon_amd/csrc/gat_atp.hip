@@ -100,7 +100,8 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
                                                     float* __restrict__ gh, float* __restrict__ q, uint16_t* __restrict__ ghp,
                                                     int64_t ld_p, int64_t plane_p, int32_t f16x2, const Hx2Scale gsc) {
     // ghp (optional): term planes of g_h for the split-precision GEMMs — three bfloat16 planes [3][N][ld_p], or (f16x2) the
-    // two half planes [2][N][ld_p] of s_g * g_h, s_g from the published max |grad_out| (|elu'| <= 1, so it bounds |g_h|)
+    // half terms of s_g * g_h, head-major [H][N][2][D] (ld_p = 2 D, plane_p = D), s_g from the published max |grad_out|
+    // (|elu'| <= 1, so it bounds |g_h|)
     const float gs = f16x2 ? hx2_scale(gsc) : 1.f;
     constexpr int IPW = 4;                                               // (node, head) rows per wave, loads batched
     const int lane = threadIdx.x & 63;
@@ -138,7 +139,7 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
                 if (gh && c < D) *reinterpret_cast<float4*>(gh + static_cast<int64_t>(it) * D + c) = make_float4(o[0], o[1], o[2], o[3]);
                 if (ghp && c < D) {
                     const int node = it / H, h = it % H;
-                    uint16_t* dst = ghp + static_cast<int64_t>(node) * ld_p + h * D + c;
+                    uint16_t* dst = f16x2 ? ghp + (static_cast<int64_t>(h) * N + node) * ld_p + c : ghp + static_cast<int64_t>(node) * ld_p + h * D + c;
                     float x[4] = {o[0], o[1], o[2], o[3]};
                     if (f16x2) {
                         uint32_t hi[2], lo[2];
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
                 }
                 if (gh) *reinterpret_cast<float4*>(gh + static_cast<int64_t>(it) * D + c) = make_float4(x[0], x[1], x[2], x[3]);
                 if (ghp) {
-                    uint16_t* dst = ghp + static_cast<int64_t>(node) * ld_p + h * D + c;
+                    uint16_t* dst = f16x2 ? ghp + (static_cast<int64_t>(h) * N + node) * ld_p + c : ghp + static_cast<int64_t>(node) * ld_p + h * D + c;
                     if (f16x2) {
                         uint32_t hi[2], lo[2];
                         hx2_split2(x[0] * gs, x[1] * gs, hi[0], lo[0]);
@@ -320,7 +321,7 @@ struct AtpFwdK {
     float* V; float* sigma; float* Z; float* Zk;
     int32_t N, E, F, R, H;
     float alpha;
-    int32_t planes;             // 1: V is written as half terms [N*H][2][W] of s_V * V (gemm_hx2.hip: high row | low row) instead of fp32 [N][H][W]
+    int32_t planes;             // 1: V is written as half terms [H][N][2][W] of s_V * V (gemm_hx2.hip: high row | low row) instead of fp32 [N][H][W]
     Hx2Scale vs;                // s_V from max(|x|, |edge_embed|) * keep_max, an upper bound of |V| (V rows are k-weighted means)
 };
 
@@ -440,7 +441,10 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_fwd(const AtpFwdK p) {
             const float zk = lane_bcast(Zkl, h) * invh;
             const int64_t vrow = (static_cast<int64_t>(node) * H + h0 + h) * W;
             float* Vr = p.V + vrow;
-            _Float16* Vh = reinterpret_cast<_Float16*>(p.V) + 2 * vrow;       // the two term rows of a (node, head) lie side by side: 4 W bytes, as in fp32
+            // half terms: HEAD-major [H][N][2][W] — a (node, head) still writes one contiguous 4 W-byte piece (high row | low
+            // row), and the 128 rows a GEMM workgroup reads for one head are one compact 128 x 4 W-byte region instead of
+            // 64-byte pieces strewn over H x 4 W-byte strides
+            _Float16* Vh = reinterpret_cast<_Float16*>(p.V) + 2 * (static_cast<int64_t>(h0 + h) * p.N + node) * W;
 #pragma unroll
             for (int r = 0; r < KR; ++r) {
                 float o[VEC];
@@ -946,8 +950,8 @@ extern "C" size_t recon_gat_atp_split_bytes(int32_t F, int32_t R, int32_t D, int
 }
 
 // f16 x 2 mode (gemm_hx2.hip): V, g_h, a and a^T live as two half terms each and all three large products run on them
-// (V as [N][H][2][W], g_h as [N][2][kp(HD)]: a row's high and low terms side by side, so that the producers write one
-// contiguous piece per row as they did in fp32).
+// (V as [H][N][2][W], g_h as [H][N][2][D]: head-major, a row's high and low terms side by side — the producers write one
+// contiguous piece per (node, head) and a GEMM workgroup's 128 rows of one head are one compact region).
 // All or nothing: the planes replace the fp32 tensors, so the decision must be the same in every stage of a step.
 //   aux (recon_hx2_aux_bytes(), 256-byte aligned): amax quantities [0] a, [1] x, [2] edge_embed, [3] grad_out (kHx2Slots hashed
 //   slots each), then a page of zeros
@@ -1066,8 +1070,8 @@ extern "C" int recon_gat_atp_project(const recon_graph* g, const recon_gat_atp_a
     bt.batch = a->H; bt.a_bs = W; bt.b_bs = static_cast<int64_t>(a->D) * W; bt.c_bs = a->D;
     bt.epilogue = a->concat ? 1 : 0;
     if (atp_hx2(a))
-        return gemm_hx2_batched(a->N, a->D, W, a->V, W, 2LL * a->H * W, 2LL * W, a->a_split, C, bt, atp_scale_v(a), atp_scale_a(a),
-                                as_stream(stream));                   // V terms [N][H][2][W]: plane stride W, row stride 2 H W, head stride 2 W
+        return gemm_hx2_batched(a->N, a->D, W, a->V, W, 2LL * W, 2LL * a->N * W, a->a_split, C, bt, atp_scale_v(a), atp_scale_a(a),
+                                as_stream(stream));                   // V terms [H][N][2][W]: plane stride W, row stride 2 W, head stride 2 N W
     if (a->a_split && bx3_supported(A, W, bt)) return gemm_bx3_batched(a->N, a->D, W, A, a->a_split, C, bt, as_stream(stream));
     return gemm_f32_batched(a->N, a->D, W, A, true, B, true, C, bt, 1, nullptr, as_stream(stream));
 }
@@ -1148,8 +1152,9 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
             if (rc != RECON_OK) return rc;
         }
         hipLaunchKernelGGL(k_elu_grad_q, dim3(static_cast<unsigned>(ceil_div64(1LL * N * H, 16))), dim3(256), 0, st, b->grad_out, b->ld_gout, a->out,
-                           a->ld_out, N, H, D, a->concat, (a->concat && !hx2) ? b->g_h : nullptr, b->q, ghp, hx2 ? 2 * ld_ghp : ld_ghp,
-                           hx2 ? ld_ghp : static_cast<int64_t>(N) * ld_ghp, hx2 ? 1 : 0, hx2 ? atp_scale_g(a) : Hx2Scale{nullptr, nullptr, 1.f});
+                           a->ld_out, N, H, D, a->concat, (a->concat && !hx2) ? b->g_h : nullptr, b->q, ghp, hx2 ? 2LL * D : ld_ghp,
+                           hx2 ? static_cast<int64_t>(D) : static_cast<int64_t>(N) * ld_ghp, hx2 ? 1 : 0,
+                           hx2 ? atp_scale_g(a) : Hx2Scale{nullptr, nullptr, 1.f});
     }
     if (a->concat) { gh = b->g_h; ld_gh = static_cast<int32_t>(HD); }
     GemmBatch bt;
@@ -1162,7 +1167,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         OutputDesc C = plain_output(b->g_V, static_cast<int64_t>(H) * W);
         bt.a_bs = D; bt.b_bs = static_cast<int64_t>(D) * W; bt.c_bs = W;
         if (hx2)
-            rc = gemm_hx2_batched(N, W, D, b->gh_split, ld_ghp, 2 * ld_ghp, D,              // g_h terms [N][2][ld_ghp]
+            rc = gemm_hx2_batched(N, W, D, b->gh_split, D, 2LL * D, 2LL * N * D,             // g_h terms [H][N][2][D]
                                   static_cast<const char*>(a->a_split) + split_part_bytes(D, W, H), C, bt, atp_scale_g(a), atp_scale_a(a), st);
         else if (a->a_split && bx3_supported(A, D, bt))
             rc = gemm_bx3_batched(N, W, D, A, static_cast<const char*>(a->a_split) + split_part_bytes(D, W, H), C, bt, st);
@@ -1218,7 +1223,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
             const int64_t ldv = static_cast<int64_t>(H) * W;
             if (hx2) {                                                                     // f16 x 2: both operands are half planes
                 const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));
-                rc = gemm_hx2_kmajor_batched(W, D, N, a->V, 2 * ldv, W, 2LL * W, b->gh_split, 2 * ld_ghp, ld_ghp, D,
+                rc = gemm_hx2_kmajor_batched(W, D, N, a->V, 2LL * W, W, 2LL * N * W, b->gh_split, 2LL * D, D, 2LL * N * D,
                                              H, sk, b->partial, static_cast<const char*>(a->aux) + kHx2ZeroPageOffset, atp_scale_v(a), atp_scale_g(a), st);
                 if (rc == RECON_OK) rc = splitk_reduce(b->partial, sk, W, D, C, bw.c_bs, H, 0, true, st);
             } else if (gh_planes && bx3_kmajor_supported(a->V, ldv, W, ld_ghp, D, W, D)) {    // split-precision MFMA, both operands k-major
