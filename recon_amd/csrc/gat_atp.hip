@@ -768,17 +768,17 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_src(const AtpSrcK p) {
 // Up to two independent products per launch (blocks [0, j0.nb) run job 0, the rest job 1), like k_row_dots.
 struct SkinnyJob { const float* G; const float* X; const int32_t* gather; float* partial; int32_t ldg, nj, rows, K, rpb, nb; };
 template <int NJ>
-__global__ void __launch_bounds__(256) k_skinny_tn_partial(const SkinnyJob j0, const SkinnyJob j1) {
+__global__ void __launch_bounds__(256) k_skinny_tn_partial(const SkinnyJob j0, const SkinnyJob j1, const SkinnyJob j2) {
     // 4 waves split the block's rows; lane l owns columns 4l..4l+3 of a 256-column stripe; fixed-order LDS combine
     __shared__ float red[3][NJ][256];
-    const bool second = static_cast<int>(blockIdx.x) >= j0.nb;
-    const SkinnyJob& jb = second ? j1 : j0;
+    const int which = static_cast<int>(blockIdx.x) < j0.nb ? 0 : (static_cast<int>(blockIdx.x) < j0.nb + j1.nb ? 1 : 2);
+    const SkinnyJob& jb = which == 0 ? j0 : (which == 1 ? j1 : j2);
     const float* __restrict__ G = jb.G;
     const float* __restrict__ X = jb.X;
     const int32_t* __restrict__ gather = jb.gather;
     float* __restrict__ partial = jb.partial;
     const int ldg = jb.ldg, nj = jb.nj, rows = jb.rows, K = jb.K, rows_per_block = jb.rpb;
-    const int bid = second ? blockIdx.x - j0.nb : blockIdx.x;
+    const int bid = blockIdx.x - (which == 0 ? 0 : (which == 1 ? j0.nb : j0.nb + j1.nb));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = bid * rows_per_block;
     const int r1 = min(rows, r0 + rows_per_block);
@@ -847,15 +847,15 @@ __global__ void __launch_bounds__(256) k_skinny_tn_partial(const SkinnyJob j0, c
 }
 // out[(j % P)*S1 + (j / P)*S2 + c] = sum_b partial[b][j][c]   (16 elements x 64 slice groups per block, fixed order)
 struct SkinnyRedJob { const float* partial; float* out; int64_t S1, S2; int32_t nb, nj, K, P, nblocks; };
-__global__ void __launch_bounds__(1024) k_skinny_reduce(const SkinnyRedJob j0, const SkinnyRedJob j1) {
+__global__ void __launch_bounds__(1024) k_skinny_reduce(const SkinnyRedJob j0, const SkinnyRedJob j1, const SkinnyRedJob j2) {
     __shared__ float red[64][17];
-    const bool second = static_cast<int>(blockIdx.x) >= j0.nblocks;
-    const SkinnyRedJob& jb = second ? j1 : j0;
+    const int which = static_cast<int>(blockIdx.x) < j0.nblocks ? 0 : (static_cast<int>(blockIdx.x) < j0.nblocks + j1.nblocks ? 1 : 2);
+    const SkinnyRedJob& jb = which == 0 ? j0 : (which == 1 ? j1 : j2);
     const float* __restrict__ partial = jb.partial;
     float* __restrict__ out = jb.out;
     const int nb = jb.nb, nj = jb.nj, K = jb.K, P = jb.P;
     const int64_t S1 = jb.S1, S2 = jb.S2;
-    const int bid = second ? blockIdx.x - j0.nblocks : blockIdx.x;
+    const int bid = blockIdx.x - (which == 0 ? 0 : (which == 1 ? j0.nblocks : j0.nblocks + j1.nblocks));
     const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int idx = bid * 16 + e;
     const int tot = nj * K;
@@ -1015,9 +1015,11 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
         RowDotsJob jn, je;
         jn.X = a->x; jn.gather = nullptr; jn.rows = N; jn.K = F; jn.F = F; jn.off = 0; jn.NJ = 2 * H; jn.out = a->c_node;
         jn.amax = hx2 ? atp_q(a, 1) : nullptr; je.amax = hx2 ? atp_q(a, 2) : nullptr;
-        jn.nb = static_cast<int>(ceil_div64(N, 16) < 2048 ? ceil_div64(N, 16) : 2048);
+        static const int rd_n = getenv("RECON_TUNE_RD_N") ? atoi(getenv("RECON_TUNE_RD_N")) : 32;
+        static const int rd_e = getenv("RECON_TUNE_RD_E") ? atoi(getenv("RECON_TUNE_RD_E")) : 64;
+        jn.nb = static_cast<int>(ceil_div64(N, rd_n) < 2048 ? ceil_div64(N, rd_n) : 2048);
         je.X = a->edge_embed; je.gather = g->eid; je.rows = E; je.K = R; je.F = 0; je.off = 2 * F; je.NJ = H; je.out = a->c_rel;
-        je.nb = E > 0 ? static_cast<int>(ceil_div64(E, 32) < 2048 ? ceil_div64(E, 32) : 2048) : 0;
+        je.nb = E > 0 ? static_cast<int>(ceil_div64(E, rd_e) < 2048 ? ceil_div64(E, rd_e) : 2048) : 0;
         const size_t lds_n = static_cast<size_t>(2) * H * F * sizeof(float), lds_e = static_cast<size_t>(H) * R * sizeof(float);
         const size_t lds = lds_n > lds_e ? lds_n : lds_e;
         if (lds > 64 * 1024) return RECON_ERR_UNSUPPORTED;
@@ -1105,7 +1107,7 @@ constexpr int kSkinnySlices = 1024;                              // row slices o
 extern "C" size_t recon_gat_atp_bwd_partial2_floats(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H) {
     (void)N; (void)E; (void)D; (void)H;
     const size_t mx = static_cast<size_t>(F > R ? F : R);
-    return static_cast<size_t>(2) * kSkinnySlices * 16 * mx;       // two products in flight
+    return static_cast<size_t>(3) * kSkinnySlices * 16 * mx;       // three products in flight
 }
 
 extern "C" int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_args* b, recon_stream_t stream) {
@@ -1238,15 +1240,16 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         }
         // (5) g_u = [Gs_dst | Gs_src]^T x   and   gsigma^T edge_embed[eid]   (skinny products, fixed-order reduce)
         if (phases & RECON_ATP_BWD_INPUTS) {
-            // Each product: out[(j % P)*S1 + (j / P)*S2 + :] = sum_r G[r][j] * X[row(r)][:].  Products are launched in PAIRS (one
-            // launch for the partial sums, one for the fixed-order reduce); each half of `partial2` serves one product of a pair.
+            // Each product: out[(j % P)*S1 + (j / P)*S2 + :] = sum_r G[r][j] * X[row(r)][:].  Up to THREE products share one
+            // launch for the partial sums and one for the fixed-order reduce (these kernels are a few MB each and latency
+            // bound: every launch saved is ~10 us); each third of `partial2` serves one product.
             struct Prod { const float* G; int ldg, nj; const float* X; const int32_t* gather; int rows, K, P; int64_t S1, S2; float* out; };
-            const size_t half = recon_gat_atp_bwd_partial2_floats(N, E, F, R, D, H) / 2;
-            auto run_pair = [&](const Prod* pr, int count) {
-                SkinnyJob sj[2];
-                SkinnyRedJob rj[2];
-                int nj_max = 0;
-                for (int i = 0; i < 2; ++i) {
+            const size_t third = recon_gat_atp_bwd_partial2_floats(N, E, F, R, D, H) / 3;
+            auto run_jobs = [&](const Prod* pr, int count) {
+                SkinnyJob sj[3];
+                SkinnyRedJob rj[3];
+                int nj_max = 0, nb_total = 0, nr_total = 0;
+                for (int i = 0; i < 3; ++i) {
                     sj[i] = SkinnyJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 1, 0};
                     rj[i] = SkinnyRedJob{nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0};
                     if (i >= count) continue;
@@ -1258,46 +1261,34 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
                     int rpb = static_cast<int>(ceil_div64(q.rows, kSkinnySlices));
                     if (rpb < 32) rpb = 32;                             // >= 8 rows per wave
                     const int nb = static_cast<int>(ceil_div64(q.rows, rpb));
-                    float* part = b->partial2 + i * half;
+                    float* part = b->partial2 + i * third;
                     sj[i] = SkinnyJob{q.G, q.X, q.gather, part, q.ldg, q.nj, q.rows, q.K, rpb, nb};
                     rj[i] = SkinnyRedJob{part, q.out, q.S1, q.S2, nb, q.nj, q.K, q.P, static_cast<int32_t>(ceil_div64(1LL * q.nj * q.K, 16))};
                     if (q.nj > nj_max) nj_max = q.nj;
+                    nb_total += nb; nr_total += rj[i].nblocks;
                 }
-                if (sj[0].nb + sj[1].nb == 0) return;
-                (void)nj_max;
-                // partial sums: one launch per product when their column counts need different instantiations (measured: a
-                // shared <16> launch makes the 8-column product pay for 16), one launch for both otherwise; ONE reduce
-                const SkinnyJob none = SkinnyJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 1, 0};
-                const bool same = (sj[0].nj <= 8) == (sj[1].nj <= 8) && sj[0].nb > 0 && sj[1].nb > 0;
-                auto launch = [&](const SkinnyJob& x, const SkinnyJob& y) {
-                    const dim3 gp(static_cast<unsigned>(x.nb + y.nb));
-                    const int m = x.nj > y.nj ? x.nj : y.nj;
-                    if (m <= 8) hipLaunchKernelGGL((k_skinny_tn_partial<8>), gp, dim3(256), 0, st, x, y);
-                    else hipLaunchKernelGGL((k_skinny_tn_partial<16>), gp, dim3(256), 0, st, x, y);
-                };
-                if (same) launch(sj[0], sj[1]);
-                else {
-                    if (sj[0].nb > 0) launch(sj[0], none);
-                    if (sj[1].nb > 0) launch(sj[1], none);
-                }
-                const dim3 gr(static_cast<unsigned>(rj[0].nblocks + rj[1].nblocks));
-                hipLaunchKernelGGL(k_skinny_reduce, gr, dim3(1024), 0, st, rj[0], rj[1]);
+                if (nb_total == 0) return;
+                const dim3 gp(static_cast<unsigned>(nb_total));
+                if (nj_max <= 8) hipLaunchKernelGGL((k_skinny_tn_partial<8>), gp, dim3(256), 0, st, sj[0], sj[1], sj[2]);
+                else hipLaunchKernelGGL((k_skinny_tn_partial<16>), gp, dim3(256), 0, st, sj[0], sj[1], sj[2]);
+                hipLaunchKernelGGL(k_skinny_reduce, dim3(static_cast<unsigned>(nr_total)), dim3(1024), 0, st, rj[0], rj[1], rj[2]);
             };
-            if (2 * H <= 16) {
-                // the common case: node-side product (Gs is [N][2H], dst sums | src sums: column (s, h) lands in g_u[h][s*F ...])
-                // and edge-side product (g_sigma^T edge_embed[eid]) side by side
-                const Prod pr[2] = {{b->Gs, 2 * H, 2 * H, a->x, nullptr, N, F, H, W, F, b->g_u},
+            if (H <= 8) {
+                // the common case, all three in one <8> launch: node-side products (Gs is [N][2H], dst sums | src sums: column
+                // (s, h) lands in g_u[h][s*F ...]) as two H-column jobs, and the edge-side product g_sigma^T edge_embed[eid]
+                const Prod pr[3] = {{b->Gs, 2 * H, H, a->x, nullptr, N, F, H, W, 0, b->g_u},
+                                    {b->Gs + H, 2 * H, H, a->x, nullptr, N, F, H, W, 0, b->g_u + F},
                                     {b->g_sigma, H, H, a->edge_embed, g->eid, E, R, H, W, 0, b->g_u + 2 * F}};
-                run_pair(pr, 2);
+                run_jobs(pr, 3);
             } else {
                 for (int j = 0; j < 2 * H; ++j) {                        // more than 8 heads: one column at a time keeps the map simple
                     const Prod one = {b->Gs + j, 2 * H, 1, a->x, nullptr, N, F, 1, W, 0, b->g_u + static_cast<int64_t>(j % H) * W + (j / H) * F};
-                    run_pair(&one, 1);
+                    run_jobs(&one, 1);
                 }
                 for (int h0 = 0; h0 < H; h0 += 16) {
                     const int nh = H - h0 < 16 ? H - h0 : 16;
                     const Prod one = {b->g_sigma + h0, H, nh, a->edge_embed, g->eid, E, R, nh, W, 0, b->g_u + static_cast<int64_t>(h0) * W + 2 * F};
-                    run_pair(&one, 1);
+                    run_jobs(&one, 1);
                 }
             }
             RECON_CHECK_LAUNCH();

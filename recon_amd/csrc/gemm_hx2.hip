@@ -19,7 +19,6 @@
 //
 // Tiling is the one of gemm_bx3.hip: block 128 x 208 x 32, 4 waves x (2 x 13) MFMA tiles, two workgroups per CU.
 #include <stdlib.h>
-#include <type_traits>
 #include "gemm_common.h"
 
 namespace recon {
@@ -90,23 +89,23 @@ __device__ __forceinline__ void hx2_store(const f32x4 (&acc)[2][TN], const Outpu
 
 constexpr int B_TILE_BYTES = T * BN * 64;                        // 26624: one buffer of the B image
 constexpr int B_PIECES = B_TILE_BYTES / 1024;                    // 26 pieces of 1 KiB (one LDS-DMA instruction of one wave each)
-constexpr int NSTAGE = 3;                                        // K tiles in flight: 3 x 26 KiB of B image, two workgroups per CU = 156 KiB of LDS
+constexpr int B_DMA = (B_PIECES + 3) / 4;                        // 7 rounds over the 4 waves
 
 // C = act(A . B^T / (s_a s_b)), both operands k-contiguous half planes.  A never touches LDS: the rows of a wave's
 // 32 x 208 block are private to that wave, so every lane loads its own MFMA fragments (row lane & 15, 8 consecutive k,
 // one 16-byte load per term).  B is copied global -> LDS by the LDS-DMA path into a double-buffered image whose bank
 // rotation is applied on the source address; one barrier per K tile.
-// NW waves per workgroup, each 32 rows x 208 columns: NW = 4 (128 rows, two workgroups per CU) or NW = 8 (256 rows, one per
-// CU): the B image is shared by twice the rows, which halves the LDS-DMA pieces every wave has to issue per K tile (an
-// issue costs 100-185 cycles inside a loaded phase — seven of them per 78 MFMAs were as expensive as the MFMAs).
-template <int NW>
-__global__ void __launch_bounds__(64 * NW, 2) k_gemm_hx2(const Hx2Args p) {
-    constexpr int B_DMA = (B_PIECES + NW - 1) / NW;                  // rounds over the waves: 7 (NW = 4) or 4 (NW = 8)
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[NSTAGE][B_TILE_BYTES];
+// (Measured and not kept: three K tiles in flight behind a counted vmcnt and a raw barrier, with the B copies issued from
+// inline asm so that the compiler does not drain them before every ds_read, and 256-row workgroups of 8 waves — 5-10 % faster
+// on out_att-sized products in isolation, 3-8 % slower inside the layer's step at K = 200 / 600.  By elimination on the
+// projection shape: 59.5 us in full, 49.6 without the epilogue stores, 48.1 without A loads, 50.4 without B copies, 33.0 for
+// MFMAs + fragment reads + barriers alone.)
+__global__ void __launch_bounds__(NT, 2) k_gemm_hx2(const Hx2Args p) {
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][B_TILE_BYTES];
     const int t = threadIdx.x, lane = t & 63;
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const TileId tile = xcd_tile(p.xcd_remap);
-    const int m0 = tile.y * (32 * NW), n0 = tile.x * BN, bz = tile.z;
+    const int m0 = tile.y * BM, n0 = tile.x * BN, bz = tile.z;
     const int mb = wid * 32;
     const int li = lane & 15, lq = lane >> 4;
 
@@ -116,38 +115,24 @@ __global__ void __launch_bounds__(64 * NW, 2) k_gemm_hx2(const Hx2Args p) {
 #pragma unroll
         for (int q = 0; q < T; ++q)
             aptr[i][q] = p.Ap + bz * p.a_bs + q * p.a_plane + static_cast<int64_t>(min(m0 + mb + 16 * i + li, p.M - 1)) * p.a_row + 8 * lq;
-    // every wave issues exactly B_DMA pieces per K tile (waves whose last round would fall off the image repeat their
-    // previous piece): the counted s_waitcnt in front of the barrier relies on a fixed number of VMEM operations per tile
-    int b_goff[B_DMA], b_piece[B_DMA];
+    int b_goff[B_DMA];
     const _Float16* bbase = p.Bp + bz * p.b_bs;
 #pragma unroll
     for (int i = 0; i < B_DMA; ++i) {
-        const int pc = NW * i + wid < B_PIECES ? NW * i + wid : NW * i + wid - NW;
-        b_piece[i] = pc;
-        const int s = 64 * pc + lane;
+        const int s = min(64 * (4 * i + wid) + lane, B_TILE_BYTES / 16 - 1);
         const int plane = s / (BN * 4), rem = s % (BN * 4), rowL = rem >> 2, pslot = rem & 3;
         const int kq = (pslot - 2 * (rowL >> 3)) & 3;                 // inverse of lds_off's rotation
         const int j = rowL >> 4, rho = rowL & 15;
         const int col = j < 12 ? 64 * (j >> 2) + 4 * rho + (j & 3) : 192 + rho;
         b_goff[i] = static_cast<int>(plane * p.b_plane + static_cast<int64_t>(min(n0 + col, p.N - 1)) * p.b_row + 8 * kq);
     }
-    // Issued as inline asm: through the builtin the compiler knows an LDS-DMA is in flight and drains vmcnt before the next
-    // ds_read of the image (it cannot tell the buffers apart) — the copy of tile t + 2 would be waited for before the MFMAs
-    // of tile t even start.  Hidden from its counters the DMA only makes the compiler's own vmcnt waits for the A fragments
-    // more conservative; there is no destination register the allocator could reuse while the data is in flight.
-    uint32_t b_lds[B_DMA];
-#pragma unroll
-    for (int i = 0; i < B_DMA; ++i)
-        b_lds[i] = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void*)(&Bs[0][1024 * b_piece[i]])));
     auto dma_b = [&](int k0, int buf) {
 #pragma unroll
-        for (int i = 0; i < B_DMA; ++i) {
-            const _Float16* src = bbase + b_goff[i] + k0;
-            const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(b_lds[i] + buf * B_TILE_BYTES);
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "m0", "memory");
-        }
+        for (int i = 0; i < B_DMA; ++i)
+            if (4 * i + wid < B_PIECES)                                // wave-uniform
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(bbase + b_goff[i] + k0),
+                                                 (__attribute__((address_space(3))) void*)(&Bs[buf][1024 * (4 * i + wid)]), 16, 0, 0);
     };
-    const int k_last = (p.K - 1) / BK * BK;                          // first k of the last K tile
 
     f32x4 acc[2][TN];
 #pragma unroll
@@ -155,30 +140,26 @@ __global__ void __launch_bounds__(64 * NW, 2) k_gemm_hx2(const Hx2Args p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // A loads are branch free: lanes past K re-read the start of their row and are zeroed when the fragment is taken.
-    // NSTAGE K tiles are in flight (PMC on the two-stage form: every wave sat 1.2 us per K tile in s_waitcnt — a K tile's
-    // MFMAs take 0.6-1.2 us, an HBM round trip under load 2 us — and the matrix pipe was busy 34 % of the kernel).
-    u32x4 araw[NSTAGE][2][T];
-    bool a_ok[NSTAGE];
+    // A loads are branch free: lanes past K re-read the start of their row and are zeroed when the fragment is taken
+    u32x4 araw[2][T];
     f16x8 af[2][T];
-    auto load_a = [&](int k0, auto stage) {
-        constexpr int S = decltype(stage)::value;
-        a_ok[S] = k0 + 8 * lq < p.K;
-        const int off = -8 * lq + ((k0 + 8 * lq) & -static_cast<int>(a_ok[S]));
+    bool a_ok = true;
+    auto load_a = [&](int k0) {
+        a_ok = k0 + 8 * lq < p.K;
+        const int off = -8 * lq + ((k0 + 8 * lq) & -static_cast<int>(a_ok));
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int q = 0; q < T; ++q) araw[S][i][q] = *reinterpret_cast<const u32x4*>(aptr[i][q] + off);
+            for (int q = 0; q < T; ++q) araw[i][q] = *reinterpret_cast<const u32x4*>(aptr[i][q] + off);
     };
-    auto take_a = [&](auto stage) {                                  // first use: the wait also covers the DMA of the same tile (issued before it)
-        constexpr int S = decltype(stage)::value;
+    auto take_a = [&]() {                                            // first use: the wait also covers the DMA of the same tile
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int q = 0; q < T; ++q) {
                 u32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = a_ok[S] ? araw[S][i][q][e] : 0u;
+                for (int e = 0; e < 4; ++e) v[e] = a_ok ? araw[i][q][e] : 0u;
                 af[i][q] = __builtin_bit_cast(f16x8, v);
             }
     };
@@ -205,47 +186,20 @@ __global__ void __launch_bounds__(64 * NW, 2) k_gemm_hx2(const Hx2Args p) {
         }
     };
 
-    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
-    // stage s of the ring holds K tile t with t % 3 == s.  Iteration t: request tile t + 2 (its LDS buffer was last read in
-    // iteration t - 1, and every wave passed that iteration's barrier), run the MFMAs of tile t, take tile t + 1.
-    auto step = [&](int k0, auto cur, auto nxt, auto far) {
-        constexpr int C = decltype(cur)::value, F_ = decltype(far)::value;
-        dma_b(min(k0 + 2 * BK, k_last), F_);                         // past the end: the last tile again, into a buffer nobody reads any more
-        load_a(k0 + 2 * BK, far);                                    // past K: clamped re-reads, zeroed at the take
-        __builtin_amdgcn_sched_barrier(0);
-        mma(Bs[C]);
-        __builtin_amdgcn_sched_barrier(0);
-        // Tile t + 1 (requested one iteration ago) must have landed — this wave's A fragments and its pieces of the B image —
-        // while the B_DMA + 2 T operations of tile t + 2 requested above stay in flight.  A raw barrier, not __syncthreads():
-        // that carries a release fence which drains vmcnt altogether.  What the barrier orders: every wave has read buffer
-        // `cur` (the MFMAs waited for its ds_reads) before the next iteration's DMA overwrites it, and every wave's pieces of
-        // tile t + 1 are in LDS before anyone reads them.
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_DMA + 2 * T) : "memory");
-        take_a(nxt);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
     dma_b(0, 0);
-    load_a(0, S0{});
-    dma_b(min(BK, k_last), 1);
-    load_a(BK, S1{});
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_DMA + 2 * T) : "memory");
-    take_a(S0{});
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // whole groups of three K tiles in a branch-free body (with a branch between the steps the compiler's wait-count
-    // analysis merges the paths and falls back to vmcnt(0) after every request), then the 0..2 tiles that are left
-    int k0 = 0;
-    for (; k0 + 3 * BK <= p.K + BK - 1 - (p.K + BK - 1) % BK; k0 += 3 * BK) {
-        step(k0, S0{}, S1{}, S2{});
-        step(k0 + BK, S1{}, S2{}, S0{});
-        step(k0 + 2 * BK, S2{}, S0{}, S1{});
-    }
-    if (k0 < p.K) {
-        step(k0, S0{}, S1{}, S2{});
-        if (k0 + BK < p.K) step(k0 + BK, S1{}, S2{}, S0{});
+    load_a(0);
+    take_a();
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+        if (k0 + BK < p.K) dma_b(k0 + BK, buf ^ 1);
+        load_a(k0 + BK);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(Bs[buf]);
+        __builtin_amdgcn_sched_barrier(0);
+        take_a();
+        __syncthreads();
+        buf ^= 1;
     }
     const float ia = hx2_inv(hx2_scale(p.sa)), ib = hx2_inv(hx2_scale(p.sb));
     hx2_store(acc, p.C, p.C.base + bz * p.c_bs, p.M, p.N, m0, n0, mb, li, lq, p.epilogue, p.c_vec4, ia, ib);
@@ -435,13 +389,14 @@ __global__ void __launch_bounds__(256) k_hx2_split_planes(const float* __restric
 
 // *slot = max(*slot, max |src[r][c]|) as fp32 bit pattern (non-negative floats order like unsigned integers); the slot
 // must have been zeroed.  max is exact and order independent, so the atomics do not cost determinism.
-__global__ void __launch_bounds__(1024) k_hx2_amax(const float* __restrict__ src, int64_t rows, int32_t cols, int64_t ld, uint32_t* __restrict__ slot) {
+template <int NTHREADS>
+__global__ void __launch_bounds__(NTHREADS) k_hx2_amax(const float* __restrict__ src, int64_t rows, int32_t cols, int64_t ld, uint32_t* __restrict__ slot) {
     float m = 0.f;
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * 1024;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * NTHREADS;
     if (ld == cols && !(reinterpret_cast<uintptr_t>(src) & 15)) {
         const int64_t n = rows * cols, n4 = n >> 2;
         const float4* s4 = reinterpret_cast<const float4*>(src);
-        int64_t i = static_cast<int64_t>(blockIdx.x) * 1024 + threadIdx.x;
+        int64_t i = static_cast<int64_t>(blockIdx.x) * NTHREADS + threadIdx.x;
         for (; i + 3 * stride < n4; i += 4 * stride) {                  // four independent 16-byte loads in flight per lane
             const float4 v0 = s4[i], v1 = s4[i + stride], v2 = s4[i + 2 * stride], v3 = s4[i + 3 * stride];
             const float a = fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w)));
@@ -457,10 +412,19 @@ __global__ void __launch_bounds__(1024) k_hx2_amax(const float* __restrict__ src
         if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(src[(n4 << 2) + threadIdx.x]));
     } else {
         const int64_t n = rows * cols;
-        for (int64_t i = static_cast<int64_t>(blockIdx.x) * 1024 + threadIdx.x; i < n; i += stride)
+        for (int64_t i = static_cast<int64_t>(blockIdx.x) * NTHREADS + threadIdx.x; i < n; i += stride)
             m = fmaxf(m, fabsf(src[(i / cols) * ld + (i % cols)]));
     }
-    hx2_amax_commit(m, slot);
+    // one commit per workgroup: wave maxima through LDS first
+    __shared__ float wm[NTHREADS / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float v = threadIdx.x < NTHREADS / 64 ? wm[threadIdx.x] : 0.f;
+        hx2_amax_commit(v, slot);
+    }
 }
 
 }  // namespace
@@ -471,9 +435,14 @@ int hx2_amax(const float* src, int64_t rows, int32_t cols, int64_t ld, uint32_t*
     if (rows <= 0 || cols <= 0) return RECON_OK;
     if (!src || !slot) return RECON_ERR_INVALID;
     const int64_t n = rows * cols;
-    int64_t blocks = ceil_div64(n, 1024 * 16);
-    if (blocks > 512) blocks = 512;                                  // 2 x 16 waves per CU
-    hipLaunchKernelGGL(k_hx2_amax, dim3(static_cast<unsigned>(blocks)), dim3(1024), 0, st, src, rows, cols, ld, slot);
+    static const int cfg = getenv("RECON_TUNE_AMAX") ? atoi(getenv("RECON_TUNE_AMAX")) : 1;
+    const int threads = cfg == 2 ? 256 : (cfg == 1 ? 512 : 1024);
+    const int64_t cap = cfg == 2 ? 2048 : (cfg == 1 ? 1024 : 512);   // 32 waves per CU in every case
+    int64_t blocks = ceil_div64(n, static_cast<int64_t>(threads) * 16);
+    if (blocks > cap) blocks = cap;
+    if (threads == 256) hipLaunchKernelGGL((k_hx2_amax<256>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, src, rows, cols, ld, slot);
+    else if (threads == 512) hipLaunchKernelGGL((k_hx2_amax<512>), dim3(static_cast<unsigned>(blocks)), dim3(512), 0, st, src, rows, cols, ld, slot);
+    else hipLaunchKernelGGL((k_hx2_amax<1024>), dim3(static_cast<unsigned>(blocks)), dim3(1024), 0, st, src, rows, cols, ld, slot);
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
 }
@@ -518,18 +487,8 @@ int gemm_hx2_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t a_
                 (C.Dseg >= N || !(C.Dseg & 3))) ? 1 : 0;
     a.xcd_remap = 1;
     a.sa = sa; a.sb = sb;
-    static const int force_nw = getenv("RECON_HX2_NW") ? atoi(getenv("RECON_HX2_NW")) : 0;
-    // 256-row workgroups (one per CU) where they fill the chip as well as 128-row ones (two per CU) and the K loop is long
-    // enough to pay for the coarser tail: measured on MI355X 60.3 -> 56.8 us (65536 x 200 x 600), 347 -> 311 us
-    // (8192 x 1600 x 4800), but 78.0 -> 79.4 us at K = 200 (65536 x 600 x 200)
-    auto fill = [&](int rows, int slots) {
-        const int64_t wg = ceil_div64(N, BN) * ceil_div64(M, rows) * bt.batch;
-        return static_cast<double>(wg) / static_cast<double>(ceil_div64(wg, slots) * slots);
-    };
-    const int nw = force_nw ? force_nw : (M >= 2048 && K >= 512 && fill(256, 256) >= fill(128, 512) ? 8 : 4);
-    const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, 32 * nw)), static_cast<unsigned>(bt.batch));
-    if (nw == 8) hipLaunchKernelGGL((k_gemm_hx2<8>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((k_gemm_hx2<4>), grid, dim3(256), 0, st, a);
+    const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, BM)), static_cast<unsigned>(bt.batch));
+    hipLaunchKernelGGL(k_gemm_hx2, grid, dim3(NT), 0, st, a);
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
 }
