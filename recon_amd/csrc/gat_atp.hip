@@ -614,7 +614,7 @@ __global__ void __launch_bounds__(kBlock, RECON_K2_OCC) k_gat_atp_bwd(const AtpB
                             for (int v = 0; v < VEC; ++v) part[h] = fmaf(gVs[h][r][v], xs[r][v], fmaf(gVr[h][r][v], re[r][v], part[h]));
                     }
                     const float tl = multi_sum<HT>(part, lane);
-                    const float w = hv ? expf(-(sg > 0.f ? sg : p.alpha * sg)) : 0.f;
+                    const float w = hv ? __expf(-(sg > 0.f ? sg : p.alpha * sg)) : 0.f;      // v_exp_f32: 2 ulp, enough for a gradient factor
                     const float gw = fmaf(kf * (tl + tdl), invl, gZl);
                     const float gs = hv ? -gw * w * (sg > 0.f ? 1.f : p.alpha) : 0.f;
                     const float al_ = kf * w * invl;

@@ -230,31 +230,96 @@ class _GATHeadsFunction(torch.autograd.Function):
         return g_x, g_ee, g_a, g_a2, None, None, None, None
 
 
+def _p(t):
+    """Device pointer of a tensor, an int that already is one, or None."""
+    return t if (t is None or isinstance(t, int)) else t.data_ptr()
+
+
 def _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split=None, aux=None,
               keep_max=1.0):
+    """recon_gat_atp_args from tensors or raw device pointers (workspace slices)."""
     H, D = a2.shape
     return _lib.GatAtpArgs(graph.N, graph.E, x.shape[1], ee.shape[1], D, H, int(bool(concat)), float(alpha),
-                           x.data_ptr(), ee.data_ptr(), a.data_ptr(), a2.data_ptr(), _lib.ptr(keep), u.data_ptr(),
-                           c_node.data_ptr(), _lib.ptr(c_rel), V.data_ptr(), _lib.ptr(sigma), _lib.ptr(Z), _lib.ptr(Zk),
-                           out.data_ptr(), out.shape[1], _lib.ptr(a_split), SPLIT_F16X2 if aux is not None else SPLIT_BF16X3,
-                           float(keep_max), _lib.ptr(aux))
+                           x.data_ptr(), ee.data_ptr(), a.data_ptr(), a2.data_ptr(), _p(keep), _p(u),
+                           _p(c_node), _p(c_rel), _p(V), _p(sigma), _p(Z), _p(Zk),
+                           out.data_ptr(), out.shape[1], _p(a_split), SPLIT_F16X2 if aux is not None else SPLIT_BF16X3,
+                           float(keep_max), _p(aux))
+
+
+def _atp_split_mode(F_, R, D, H, N=None):
+    """0: exact-fp32 MFMA GEMMs, 1: bf16 x 3, 2: f16 x 2 (see _GEMM_BX3 above)."""
+    if _GEMM_BX3 == "0":
+        return 0
+    if _GEMM_BX3 not in ("1", "2") and N is not None and 2.0 * N * (2 * F_ + R) * H * D < _BX3_MIN_FLOP:
+        return 0
+    if _GEMM_BX3 != "1" and (2 * F_ + R) % 8 == 0 and D % 8 == 0:
+        return 2
+    return 1
 
 
 def _atp_split_buffer(F_, R, D, H, dev, N=None):
     """(a_split, aux): workspace of the split-precision GEMMs (term planes of a and a^T) and, for the f16 x 2 family, the
-    2 KiB block of max-magnitude slots + zero page; (None, None) to stay on the fp32-MFMA GEMMs (RECON_GEMM_BX3=0, or a
+    block of max-magnitude slots + zero page; (None, None) to stay on the fp32-MFMA GEMMs (RECON_GEMM_BX3=0, or a
     product too small to pay for the extra launches)."""
-    if _GEMM_BX3 == "0":
-        return None, None
-    if _GEMM_BX3 not in ("1", "2") and N is not None and 2.0 * N * (2 * F_ + R) * H * D < _BX3_MIN_FLOP:
+    mode = _atp_split_mode(F_, R, D, H, N)
+    if mode == 0:
         return None, None
     a_split = torch.empty(_lib.lib().recon_gat_atp_split_bytes(F_, R, D, H), dtype=torch.uint8, device=dev)
     aux = None
-    if _GEMM_BX3 != "1" and (2 * F_ + R) % 8 == 0 and D % 8 == 0:
+    if mode == 2:
         aux = torch.empty(_lib.lib().recon_hx2_aux_bytes(), dtype=torch.uint8, device=dev)     # allocator blocks are 512-byte aligned
         if aux.data_ptr() % 256:
             aux = None
     return a_split, aux
+
+
+def _carve(dev, sizes):
+    """ONE allocation for a list of byte sizes (a torch.empty costs 3-4 us of host time, a layer call needs a dozen scratch
+    arrays, and at cfg 2 the host side of a step is as long as its GPU side): returns the tensor and the 256-byte aligned
+    device pointers of the slices (None for size None)."""
+    offs, tot = [], 0
+    for sz in sizes:
+        if sz is None:
+            offs.append(None)
+        else:
+            offs.append(tot)
+            tot += (int(sz) + 255) & ~255
+    buf = torch.empty(tot + 256, dtype=torch.uint8, device=dev)
+    base = (buf.data_ptr() + 255) & ~255
+    return buf, [None if o is None else base + o for o in offs]
+
+
+_SIZE_CACHE = {}
+
+
+def _lib_sizes(N, E, F_, R, D, H):
+    """Workspace sizes of the C ABI for one shape (ctypes calls are not free either: cached per shape)."""
+    key = (N, E, F_, R, D, H)
+    v = _SIZE_CACHE.get(key)
+    if v is None:
+        L = _lib.lib()
+        if len(_SIZE_CACHE) > 64:
+            _SIZE_CACHE.clear()
+        v = _SIZE_CACHE[key] = (L.recon_gat_atp_split_bytes(F_, R, D, H), L.recon_hx2_aux_bytes(),
+                                4 * L.recon_gat_atp_bwd_partial_floats(N, E, F_, R, D, H),
+                                4 * L.recon_gat_atp_bwd_partial2_floats(N, E, F_, R, D, H), L.recon_gat_atp_bwd_split_bytes(N, D, H))
+    return v
+
+
+def _on_device(dev):
+    """Context that makes `dev` current — only entered when it is not already (the context manager costs ~10 us)."""
+    return torch.cuda.device(dev) if torch.cuda.current_device() != dev.index else _NULL_CTX
+
+
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_CTX = _NullCtx()
 
 
 class _GATHeadsATPFunction(torch.autograd.Function):
@@ -272,35 +337,34 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         if x.shape[0] != N or ee.shape[0] != E or a.shape != (H, D, W):
             raise ValueError("recon_amd.gat_heads: inconsistent shapes")
         dev = x.device
-        f32 = dict(dtype=torch.float32, device=dev)
         need_grad = any(ctx.needs_input_grad[:4])
         train = need_grad or keep is not None
-        out = torch.empty(N, H * D, **f32)
-        u = torch.empty(H, W, **f32)
-        c_node = torch.empty(N, 2 * H, **f32)
-        c_rel = torch.empty(E, H, **f32)
-        V = torch.empty(N, H, W, **f32)
-        sigma = torch.empty(E, H, **f32) if train else None
-        Z = torch.empty(N, H, **f32) if train else None
-        Zk = torch.empty(N, H, **f32) if train else None
+        out = torch.empty(N, H * D, dtype=torch.float32, device=dev)
+        mode = _atp_split_mode(F_, R, D, H, N)
+        split_bytes, aux_bytes = _lib_sizes(N, E, F_, R, D, H)[:2]
+        # u [H,W], c_node [N,2H], c_rel [E,H], V [N,H,W], sigma [E,H], Z [N,H], Zk [N,H], a_split, aux: one allocation
+        ws, (u, c_node, c_rel, V, sigma, Z, Zk, a_split, aux) = _carve(dev, (
+            4 * H * W, 4 * N * 2 * H, 4 * E * H, 4 * N * H * W, 4 * E * H if train else None, 4 * N * H if train else None,
+            4 * N * H if train else None, split_bytes if mode else None, aux_bytes if mode == 2 else None))
         if keep is not None:
             keep = keep.view(H, E)[:, graph.eid_long].t().contiguous()        # [H,E] original order -> [E,H] slot order
-        a_split, aux = _atp_split_buffer(F_, R, D, H, dev, N)
         if keep is None:
             keep_max = 1.0
         elif keep_max is None:                                  # explicit factors without a bound: one host read (tests)
             keep_max = float(keep.max()) if aux is not None and keep.numel() else 1.0
         args = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split, aux, keep_max)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _lib.check(L.recon_gat_atp_fwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_atp_fwd")
         if need_grad:
-            ctx.save_for_backward(x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, a_split, aux)
+            ctx.save_for_backward(x, ee, a, a2, keep, out, ws)
+            ctx.ptrs = (u, c_node, c_rel, V, sigma, Z, Zk, a_split, aux)
             ctx.graph, ctx.alpha, ctx.concat, ctx.keep_max = graph, alpha, concat, keep_max
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, a_split, aux = ctx.saved_tensors
+        x, ee, a, a2, keep, out, ws = ctx.saved_tensors
+        u, c_node, c_rel, V, sigma, Z, Zk, a_split, aux = ctx.ptrs
         graph = ctx.graph
         L = _lib.lib()
         H, D = a2.shape
@@ -310,30 +374,24 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         grad_out = grad_out.contiguous()
         nx, ne, na, na2 = ctx.needs_input_grad[:4]
-        g_h = torch.empty(N, H * D, **f32) if (ctx.concat and aux is None) else None     # f16 x 2: g_h exists as half planes only
-        g_V = torch.empty(N, H, W, **f32)
-        g_sigma = torch.empty(E, H, **f32)
-        Gxs = torch.empty(E, F_, **f32)
-        gxd = torch.empty(N, F_, **f32)
-        Gs = torch.empty(N, 2 * H, **f32)
-        g_u = torch.empty(H, W, **f32)
-        q = torch.empty(N, H, **f32)
-        partial = torch.empty(L.recon_gat_atp_bwd_partial_floats(N, E, F_, R, D, H), **f32)
-        partial2 = torch.empty(L.recon_gat_atp_bwd_partial2_floats(N, E, F_, R, D, H), **f32)
+        want_a = na or na2
+        _, _, partial_b, partial2_b, ghs_b = _lib_sizes(N, E, F_, R, D, H)
+        use_gh_planes = aux is not None or (a_split is not None and want_a and os.environ.get("RECON_GEMM_BX3_KM", "1") != "0")
+        # scratch of the backward in one allocation: g_h [N,HD] (not in f16 x 2 mode: g_h exists as half planes only), g_V
+        # [N,H,W], g_sigma [E,H], Gxs [E,F], gxd [N,F], Gs [N,2H], g_u [H,W], q [N,H], split-K partials, skinny partials,
+        # g_h term planes
+        ws2, (g_h, g_V, g_sigma, Gxs, gxd, Gs, g_u, q, partial, partial2, gh_split) = _carve(dev, (
+            4 * N * H * D if (ctx.concat and aux is None) else None, 4 * N * H * W, 4 * E * H, 4 * E * F_, 4 * N * F_, 4 * N * 2 * H,
+            4 * H * W, 4 * N * H, partial_b, partial2_b, ghs_b if use_gh_planes else None))
         g_x = torch.empty(N, F_, **f32) if nx else None
         g_ee = torch.empty(E, R, **f32) if ne else None
-        g_a = torch.empty(H, D, W, **f32) if (na or na2) else None
-        g_a2 = torch.empty(H, D, **f32) if (na or na2) else None
-        gh_split = (torch.empty(L.recon_gat_atp_bwd_split_bytes(N, D, H), dtype=torch.uint8, device=dev)
-                    if (aux is not None or (a_split is not None and g_a is not None and os.environ.get("RECON_GEMM_BX3_KM", "1") != "0"))
-                    else None)
+        g_a = torch.empty(H, D, W, **f32) if want_a else None
+        g_a2 = torch.empty(H, D, **f32) if want_a else None
         fwd = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, ctx.alpha, ctx.concat, a_split, aux,
                         ctx.keep_max)
-        args = _lib.GatAtpBwdArgs(fwd, grad_out.data_ptr(), grad_out.shape[1], _lib.ptr(g_h), g_V.data_ptr(),
-                                  _lib.ptr(g_sigma), _lib.ptr(Gxs), gxd.data_ptr(), Gs.data_ptr(), g_u.data_ptr(),
-                                  q.data_ptr(), partial.data_ptr(), partial2.data_ptr(), _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2),
-                                  _lib.ptr(gh_split))
-        with torch.cuda.device(dev):
+        args = _lib.GatAtpBwdArgs(fwd, grad_out.data_ptr(), grad_out.shape[1], g_h, g_V, g_sigma, Gxs, gxd, Gs, g_u, q, partial, partial2,
+                                  _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2), gh_split)
+        with _on_device(dev):
             if _OVERLAP and g_a is not None:
                 # PREPARE -> { INPUTS on this stream , WEIGHTS (MFMA-bound GEMM) on a side stream } -> FINISH
                 main = torch.cuda.current_stream()
@@ -345,7 +403,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
                 _lib.check(L.recon_gat_atp_bwd_phase(gc, ac, 2, main.cuda_stream), "recon_gat_atp_bwd_phase")
                 main.wait_stream(side)
                 _lib.check(L.recon_gat_atp_bwd_phase(gc, ac, 8, main.cuda_stream), "recon_gat_atp_bwd_phase")
-                for t in (grad_out, g_h, V, g_a, partial, a2, a, gh_split, aux):      # used on the side stream: keep the allocator honest
+                for t in (grad_out, ws, ws2, g_a, a2, a):                # used on the side stream: keep the allocator honest
                     if t is not None:
                         t.record_stream(side)
             else:
