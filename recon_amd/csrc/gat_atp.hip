@@ -999,9 +999,7 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
                        a->a_2, D, W, a->u, hx2 ? atp_q(a, 0) : nullptr);
     if (hx2) {                                                    // half planes of s_a a and s_a a^T
         char* ws = static_cast<char*>(a->a_split);
-        rc = hx2_split_planes(a->a, W, static_cast<int64_t>(D) * W, false, D, W, H, ws, atp_scale_a(a), st);
-        if (rc != RECON_OK) return rc;
-        rc = hx2_split_planes(a->a, W, static_cast<int64_t>(D) * W, true, W, D, H, ws + split_part_bytes(D, W, H), atp_scale_a(a), st);
+        rc = hx2_split_planes_both(a->a, static_cast<int64_t>(D) * W, D, W, H, ws, ws + split_part_bytes(D, W, H), atp_scale_a(a), st);
         if (rc != RECON_OK) return rc;
     } else if (a->a_split) {                                      // bf16 term planes of a and a^T for the split-precision GEMMs
         if (reinterpret_cast<uintptr_t>(a->a_split) & 15) return RECON_ERR_INVALID;
