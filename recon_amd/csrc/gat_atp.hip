@@ -327,10 +327,14 @@ struct AtpFwdK {
 
 // two half planes of VEC consecutive scaled values: 2 * VEC bytes per plane
 template <int VEC>
-__device__ __forceinline__ void store_planes(_Float16* hi_p, int64_t plane, const float (&o)[VEC], float s) {
+__device__ __forceinline__ void store_planes(_Float16* hi_p, int64_t plane, const float (&o)[VEC], float s, bool clamp) {
     float c[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) c[v] = fminf(fmaxf(o[v] * s, -65504.f), 65504.f);     // the scale comes from a bound, not from V itself
+    for (int v = 0; v < VEC; ++v) c[v] = o[v] * s;
+    if (clamp) {                // uniform.  The scale comes from a bound, not from V itself: max(|x|, |edge_embed|) bounds V exactly without
+#pragma unroll                  // dropout (rows of V are means), with dropout the caller's keep_max enters — guard against a wrong one
+        for (int v = 0; v < VEC; ++v) c[v] = fminf(fmaxf(c[v], -65504.f), 65504.f);
+    }
     if constexpr (VEC == 4) {
         uint32_t hi[2], lo[2];
         hx2_split2(c[0], c[1], hi[0], lo[0]);
@@ -356,7 +360,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_fwd(const AtpFwdK p) {
     const int node = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + wave;
     if (node >= p.N) return;
     const int F = p.F, R = p.R, H = p.H, W = 2 * F + R;
-    const float vscale = p.planes ? hx2_scale(p.vs) : 1.f;             // scalar loads: in flight under the whole edge walk
+    const float vscale = p.planes ? hx2_scale_wave(p.vs) : 1.f;       // one vector load + butterfly, in flight under the edge walk
     const int h0 = blockIdx.y * HT;
     const int myh = h0 + (lane % HT);
     const bool hv = myh < H;
@@ -451,15 +455,15 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_fwd(const AtpFwdK p) {
                 if (aF[r]) {
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) o[v] = xi[r][v] * zk;
-                    if (p.planes) store_planes<VEC>(Vh + cf[r], vplane, o, vscale); else store_vec<VEC>(Vr + cf[r], o);
+                    if (p.planes) store_planes<VEC>(Vh + cf[r], vplane, o, vscale, p.keep != nullptr); else store_vec<VEC>(Vr + cf[r], o);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) o[v] = accS[h][r][v] * invh;
-                    if (p.planes) store_planes<VEC>(Vh + F + cf[r], vplane, o, vscale); else store_vec<VEC>(Vr + F + cf[r], o);
+                    if (p.planes) store_planes<VEC>(Vh + F + cf[r], vplane, o, vscale, p.keep != nullptr); else store_vec<VEC>(Vr + F + cf[r], o);
                 }
                 if (aR[r]) {
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) o[v] = accR[h][r][v] * invh;
-                    if (p.planes) store_planes<VEC>(Vh + 2 * F + cf[r], vplane, o, vscale); else store_vec<VEC>(Vr + 2 * F + cf[r], o);
+                    if (p.planes) store_planes<VEC>(Vh + 2 * F + cf[r], vplane, o, vscale, p.keep != nullptr); else store_vec<VEC>(Vr + 2 * F + cf[r], o);
                 }
             }
         }
