@@ -162,6 +162,79 @@ def spkbgat_forward(entity_embeddings, relation_embeddings, batch_entities, edge
     return F.normalize(out, p=2, dim=1), out_rel, mask                          # :183
 
 
+# ------------------------------------------------------------------------------- stage-A batch builders
+def kg_graph(adj_indices, adj_values):
+    """Corpus.get_graph (GAT/create_batch.py:708-732): graph[source][target] = [relations...] in insertion order;
+    adj_indices [2,T] has the TARGET in row 0 and the SOURCE in row 1 (GAT/preprocess.py: rows = e2, cols = e1)."""
+    graph = {}
+    for t, s, r in zip(adj_indices[0].tolist(), adj_indices[1].tolist(), adj_values.tolist()):
+        graph.setdefault(s, {}).setdefault(t, []).append(r)
+    return graph
+
+
+def kg_bfs(graph, source, nbd_size):
+    """Corpus.bfs (:788-842): first-visit-wins breadth-first search; returns the nodes at EXACTLY `nbd_size` hops in
+    discovery order as (relation lists along the path, target first ... source side last; entities target ... )."""
+    visit, distance, parent = {source: 1}, {source: 0}, {source: (-1, -1)}
+    queue = [source]
+    while queue:
+        top = queue.pop(0)
+        for target in graph.get(top, {}):
+            if target in visit:
+                continue
+            distance[target] = distance[top] + 1
+            if distance[target] > nbd_size:
+                continue                                                # :811-812 (not marked visited)
+            queue.append(target)
+            visit[target] = 1
+            parent[target] = (top, graph[top][target])
+    out = []
+    for target in visit:
+        if distance[target] != nbd_size:
+            continue
+        relations, entities, temp = [], [target], target
+        while parent[temp] != (-1, -1):
+            relations.append(parent[temp][1])
+            entities.append(parent[temp][0])
+            temp = parent[temp][0]
+        out.append((tuple(tuple(r) for r in relations), tuple(entities[:-1])))
+    return out
+
+
+def kg_further_neighbors(graph, nbd_size):
+    """Corpus.get_further_neighbors (:844-869): {source: [entries at nbd_size hops]} for every source that has out-edges."""
+    res = {}
+    for source in graph:
+        n = kg_bfs(graph, source, nbd_size)
+        if n:
+            res[source] = n
+    return res
+
+
+def kg_batch_adj_data(neighbors_1hop, entities):
+    """Corpus.get_batch_adj_data (:391-436): for every batch entity, in order, one edge (target, entity) per relation of every
+    1-hop neighbour.  Returns (edge [2,E] int64 = (targets; sources), edge_type [E], source set, target set)."""
+    trgts, srcs, vals, tset = [], [], [], set()
+    for e in entities:
+        for rel_tuple, target_tuple in neighbors_1hop.get(e, []):
+            tset.add(target_tuple[0])
+            for rel in rel_tuple[0]:
+                trgts.append(target_tuple[0]); srcs.append(e); vals.append(rel)
+    return (torch.tensor([trgts, srcs], dtype=torch.long).reshape(2, -1), torch.tensor(vals, dtype=torch.long), set(entities), tset)
+
+
+def kg_batch_nhop_neighbors(neighbors_2hop, batch_sources, partial_2hop=False):
+    """Corpus.get_batch_nhop_neighbors_all (:871-895): quadruples (source, first relation source->parent, first relation
+    parent->target, target) for every 2-hop neighbour of every batch source, in the given source order."""
+    quads = []
+    for s in batch_sources:
+        for i, (rels, ents) in enumerate(neighbors_2hop.get(s, [])):
+            if partial_2hop and i >= 1:
+                break
+            quads.append([s, rels[-1][0], rels[0][0], ents[0]])
+    return np.array(quads, dtype=np.int32).reshape(-1, 4)
+
+
 # =============================================================================== GP-GNN side
 def make_start_embedding(n, d):
     """utils/embedding_utils.py:170-182.  Channel c = ordered pair (i, j), i != j, row-major;

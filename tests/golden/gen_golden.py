@@ -15,6 +15,8 @@ Reference entry points executed (unmodified, imported from where they lie):
   utils/build_adjecent_matrix.py:6-22
   utils/embedding_utils.py:170-202  make_start_embedding / get_head_indices / get_tail_indices
   utils/context_utils.py:387-426    make_start_entity_embeddings
+  GAT/create_batch.py:391-436, 708-732, 788-895  Corpus.get_graph / bfs / get_further_neighbors /
+                           get_batch_adj_data / get_batch_nhop_neighbors_all
 
 Shims (live in a temp dir, never in the repo): a directory with `RECON ->
 /root/reference` (models/models.py:6 imports `RECON.parsing...`), a stub `nltk`
@@ -401,6 +403,58 @@ def gen_formats():
     save("formats1", **arrays)
 
 
+def synthetic_kg(n_ent, n_rel, n_tri, seed):
+    """Small random knowledge graph with the awkward cases on purpose: several relations on one (head, tail) pair, self
+    loops, 2-cycles, entities without out-edges, targets reachable over several parents."""
+    rs = np.random.RandomState(seed)
+    heads = rs.randint(0, max(2, n_ent * 2 // 3), n_tri)             # the top third of the ids never appear as heads
+    tails = rs.randint(0, n_ent, n_tri)
+    rels = rs.randint(0, n_rel, n_tri)
+    dup = rs.randint(0, n_tri, n_tri // 6)                           # repeat some (head, tail) pairs with another relation
+    heads = np.concatenate([heads, heads[dup], [0, 1, 1, 2]]); tails = np.concatenate([tails, tails[dup], [0, 2, 1, 1]])
+    rels = np.concatenate([rels, rs.randint(0, n_rel, dup.size), [0, 1, 2, 0]])
+    return heads.astype(np.int64), rels.astype(np.int64), tails.astype(np.int64)
+
+
+def gen_sampler():
+    """N1: the reference's own batch builders (GAT/create_batch.py Corpus.get_graph / bfs / get_further_neighbors /
+    get_batch_adj_data / get_batch_nhop_neighbors_all) on small synthetic knowledge graphs."""
+    import importlib
+    gat = os.path.join(REF, "GAT")
+    sys.path.insert(0, gat)
+    try:
+        cb = importlib.import_module("create_batch")
+    finally:
+        sys.path.remove(gat)
+    assert cb.__file__.startswith(REF)
+    for name, (n_ent, n_rel, n_tri, seed) in (("sampler1_small", (12, 3, 30, 0)), ("sampler2_medium", (60, 7, 400, 1))):
+        h, r, t = synthetic_kg(n_ent, n_rel, n_tri, seed)
+        triples = list(zip(h.tolist(), r.tolist(), t.tolist()))
+        adj = (t.tolist(), h.tolist(), r.tolist())                   # GAT/preprocess.py:73-81: rows = e2 (tail), cols = e1 (head)
+        e2i = {"e%d" % i: i for i in range(n_ent)}
+        r2i = {"r%d" % i: i for i in range(n_rel)}
+        args = types.SimpleNamespace(entities_per_batch=5, partial_2hop=False)
+        uniq = ["e%d" % i for i in range(n_ent)]
+        C = cb.Corpus(args, (triples, adj), (triples[:2], adj), (triples[:2], adj), e2i, r2i, None, 8, 2, uniq, uniq, None, None, None,
+                      get_2hop=True, get_1hop=True)
+        arrays = dict(adj_indices=np.array([adj[0], adj[1]], dtype=np.int64), adj_values=np.array(adj[2], dtype=np.int64),
+                      n_ent=np.array(n_ent))
+        rs = np.random.RandomState(seed + 10)
+        batches = [list(range(n_ent)), rs.permutation(n_ent)[:5].tolist(), rs.permutation(n_ent)[: max(3, n_ent // 4)].tolist(), [n_ent - 1]]
+        for bi, ents in enumerate(batches):
+            (ind, val), sets = C.get_batch_adj_data(None, unique_entities_train=ents, start_idx=0, end_idx=len(ents))
+            arrays["b%d_entities" % bi] = np.array(ents, dtype=np.int64)
+            arrays["b%d_edge" % bi] = t2n(ind).reshape(2, -1); arrays["b%d_edge_type" % bi] = t2n(val)
+            arrays["b%d_sources" % bi] = np.array(sorted(sets["source"]), dtype=np.int64)
+            arrays["b%d_targets" % bi] = np.array(sorted(sets["target"]), dtype=np.int64)
+            arrays["b%d_nhop" % bi] = C.get_batch_nhop_neighbors_all(args, ents, C.node_neighbors_2hop).reshape(-1, 4)
+            args.partial_2hop = True
+            arrays["b%d_nhop_partial" % bi] = C.get_batch_nhop_neighbors_all(args, ents, C.node_neighbors_2hop).reshape(-1, 4)
+            args.partial_2hop = False
+        arrays["n_batches"] = np.array(len(batches))
+        save(name, **arrays)
+
+
 def gen_gpgnn():
     cwd = os.getcwd()
     os.chdir(REF)
@@ -463,6 +517,11 @@ if __name__ == "__main__" and os.environ.get("RECON_GOLDEN_ONLY") == "formats":
     gen_formats()
     sys.exit(0)
 
+if __name__ == "__main__" and os.environ.get("RECON_GOLDEN_ONLY") == "sampler":
+    _install_shims()
+    gen_sampler()
+    sys.exit(0)
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("the reference is not mounted here; golden vectors can only be regenerated in the build container")
@@ -475,3 +534,4 @@ if __name__ == "__main__":
     sys.path.remove(os.path.join(REF, "GAT"))
     gen_gpgnn()
     gen_formats()
+    gen_sampler()

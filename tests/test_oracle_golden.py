@@ -194,3 +194,22 @@ def test_graph_convolution(name):
     np.testing.assert_allclose(w.grad.numpy(), g["g_weight"], atol=1e-5)
     if b is not None:
         np.testing.assert_allclose(b.grad.numpy(), g["g_bias"], atol=1e-5)
+
+
+# ------------------------------------------------------------------------------- N1: stage-A batch builders
+@pytest.mark.parametrize("name", ["sampler1_small", "sampler2_medium"])
+def test_kg_batch_builders_vs_reference(name):
+    """Oracle restatement of Corpus.get_graph / bfs / get_further_neighbors / get_batch_adj_data /
+    get_batch_nhop_neighbors_all (GAT/create_batch.py) against the reference's own outputs: exact integer equality, in order."""
+    g = load_golden(name)
+    graph = O.kg_graph(T(g["adj_indices"]), T(g["adj_values"]))
+    n1, n2 = O.kg_further_neighbors(graph, 1), O.kg_further_neighbors(graph, 2)
+    for b in range(int(g["n_batches"])):
+        ents = g["b%d_entities" % b].tolist()
+        edge, etype, sset, tset = O.kg_batch_adj_data(n1, ents)
+        np.testing.assert_array_equal(edge.numpy(), g["b%d_edge" % b])
+        np.testing.assert_array_equal(etype.numpy(), g["b%d_edge_type" % b])
+        assert sorted(sset) == g["b%d_sources" % b].tolist() and sorted(tset) == g["b%d_targets" % b].tolist()
+        np.testing.assert_array_equal(O.kg_batch_nhop_neighbors(n2, ents), g["b%d_nhop" % b])
+        np.testing.assert_array_equal(O.kg_batch_nhop_neighbors(n2, ents, partial_2hop=True), g["b%d_nhop_partial" % b])
+    assert sum(g["b%d_nhop" % b].shape[0] for b in range(int(g["n_batches"]))) > 20        # the cases are not vacuous

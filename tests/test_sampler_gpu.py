@@ -1,0 +1,94 @@
+"""GPU tests of the stage-A batch builders (recon_amd/sampler.py): exact integer equality, in order, with the
+reference's own outputs (tests/golden/sampler*.npz, produced by running GAT/create_batch.py Corpus) and with the oracle on
+larger random knowledge graphs; and the sampler feeding SpKBGATModified end to end."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import recon_oracle as O
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("name", ["sampler1_small", "sampler2_medium"])
+def test_sampler_golden(name):
+    from recon_amd.sampler import KGNeighbourSampler
+    g = load_golden(name)
+    sm = KGNeighbourSampler(T(g["adj_indices"]).to(dev()), T(g["adj_values"]).to(dev()), int(g["n_ent"]))
+    for b in range(int(g["n_batches"])):
+        ents = T(g["b%d_entities" % b]).to(dev())
+        (edge, et), (ss, ts) = sm.batch_adj_data(ents)
+        np.testing.assert_array_equal(edge.cpu().numpy(), g["b%d_edge" % b])
+        np.testing.assert_array_equal(et.cpu().numpy(), g["b%d_edge_type" % b])
+        assert ss.tolist() == g["b%d_sources" % b].tolist() and ts.tolist() == g["b%d_targets" % b].tolist()
+        np.testing.assert_array_equal(sm.batch_nhop_neighbors(ents).cpu().numpy(), g["b%d_nhop" % b])
+        np.testing.assert_array_equal(sm.batch_nhop_neighbors(ents, partial_2hop=True).cpu().numpy(), g["b%d_nhop_partial" % b])
+
+
+@pytest.mark.parametrize("Ne,Tn,n_rel,B,seed", [(500, 6000, 20, 128, 5), (3000, 9000, 237, 128, 6), (40, 2000, 3, 40, 7), (64, 0, 4, 8, 8)])
+def test_sampler_vs_oracle_random(Ne, Tn, n_rel, B, seed):
+    """Dense, sparse, tiny-and-saturated and empty graphs; batch entities in random order (as the reference iterates a shuffled list)."""
+    from recon_amd.sampler import KGNeighbourSampler
+    rs = np.random.RandomState(seed)
+    adj = T(np.stack([rs.randint(0, Ne, Tn), rs.randint(0, max(1, Ne * 3 // 4), Tn)])).long()
+    val = T(rs.randint(0, n_rel, Tn)).long()
+    sm = KGNeighbourSampler(adj.to(dev()), val.to(dev()), Ne)
+    graph = O.kg_graph(adj, val)
+    n1, n2 = O.kg_further_neighbors(graph, 1), O.kg_further_neighbors(graph, 2)
+    ents = rs.permutation(Ne)[:B].tolist()
+    (edge, et), (ss, ts) = sm.batch_adj_data(torch.tensor(ents, device=dev()))
+    e2, t2, sset, tset = O.kg_batch_adj_data(n1, ents)
+    assert torch.equal(edge.cpu(), e2) and torch.equal(et.cpu(), t2)
+    assert ss.tolist() == sorted(sset) and ts.tolist() == sorted(tset)
+    q = sm.batch_nhop_neighbors(torch.tensor(ents, device=dev()))
+    np.testing.assert_array_equal(q.cpu().numpy(), O.kg_batch_nhop_neighbors(n2, ents))
+    if Tn:
+        assert edge.shape[1] > 0 and q.shape[0] > 0
+
+
+def test_sampler_rejects_bad_input():
+    from recon_amd.sampler import KGNeighbourSampler
+    with pytest.raises(RuntimeError):
+        KGNeighbourSampler(torch.zeros(2, 3, dtype=torch.long), torch.zeros(3, dtype=torch.long), 4)       # CPU tensors
+    with pytest.raises(IndexError):
+        KGNeighbourSampler(torch.tensor([[0, 5], [1, 2]], device=dev()), torch.zeros(2, dtype=torch.long, device=dev()), 4)
+
+
+def test_sampler_feeds_spkbgat():
+    """One stage-A iteration assembled on the device: sampler -> SpKBGATModified (whole entity table, one entity batch) -> the
+    same forward on the edges the ORACLE's builders produce.  Bitwise equal: the edge lists are identical, the kernels deterministic."""
+    from recon_amd.sampler import KGNeighbourSampler
+    from recon_amd.models import SpKBGATModified
+    rs = np.random.RandomState(11)
+    Ne, Tn, n_rel, B = 300, 2500, 11, 32
+    adj = T(np.stack([rs.randint(0, Ne, Tn), rs.randint(0, Ne, Tn)])).long()
+    val = T(rs.randint(0, n_rel, Tn)).long()
+    d = dev()
+    sm = KGNeighbourSampler(adj.to(d), val.to(d), Ne)
+    ents = rs.permutation(Ne)[:B].tolist()
+    g = torch.Generator().manual_seed(0)
+    ent_emb, rel_emb = torch.randn(Ne, 16, generator=g), torch.randn(n_rel, 16, generator=g)
+    torch.manual_seed(0)
+    m = SpKBGATModified(ent_emb.clone(), rel_emb.clone(), [8, 16], [16, 16], 0.0, 0.2, [2, 2], None).to(d).eval()
+    ents_d = torch.tensor(ents, device=d)
+    (edge, et), (ss, ts) = sm.batch_adj_data(ents_d)
+    nhop = sm.batch_nhop_neighbors(ents_d)
+    batch_all = torch.unique(torch.cat((ss, ts)))
+    with torch.no_grad():
+        out_e, out_r, mask = m(None, batch_all, (edge, et), nhop)
+    graph = O.kg_graph(adj, val)
+    e2, t2, sset, tset = O.kg_batch_adj_data(O.kg_further_neighbors(graph, 1), ents)
+    q2 = torch.from_numpy(O.kg_batch_nhop_neighbors(O.kg_further_neighbors(graph, 2), ents).astype(np.int64))
+    torch.manual_seed(0)
+    m2 = SpKBGATModified(ent_emb.clone(), rel_emb.clone(), [8, 16], [16, 16], 0.0, 0.2, [2, 2], None).to(d).eval()
+    with torch.no_grad():
+        out_e2, out_r2, mask2 = m2(None, torch.tensor(sorted(sset | tset), device=d), (e2.to(d), t2.to(d)), q2.to(d))
+    assert torch.equal(out_e, out_e2) and torch.equal(out_r, out_r2) and torch.equal(mask, mask2)
+    assert torch.isfinite(out_e).all() and float(mask.sum()) == len(sset | tset)
