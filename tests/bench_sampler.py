@@ -5,7 +5,7 @@ synthetic knowledge graph of FB15k-237's size (14 541 entities, 237 relations, 2
 import json, os, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # lives under tests/: it times the oracle as the host baseline
 from recon_amd.sampler import KGNeighbourSampler
 from oracle import recon_oracle as O           # the checker, timed here as the host baseline only
 
