@@ -184,6 +184,9 @@ typedef struct {
 } recon_gat_atp_args;
 
 size_t recon_gat_atp_split_bytes(int32_t F, int32_t R, int32_t D, int32_t H);
+/* 1 if the RECON_SPLIT_F16X2 mode takes this shape ((2F+R) % 8 == 0, D % 8 == 0, plane offsets within 32 bits); given that,
+ * 16-byte aligned a_split / V, 256-byte aligned aux and ld_out % 4 == 0 the call uses it, otherwise it falls back to BF16X3 */
+int recon_gat_atp_f16x2_supported(int32_t F, int32_t R, int32_t D, int32_t H);
 int recon_gat_atp_supported(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H);
 int recon_gat_atp_fwd(const recon_graph* g, const recon_gat_atp_args* args, recon_stream_t stream);
 /* the three stages of recon_gat_atp_fwd, exported for profiling / tests */

@@ -93,6 +93,7 @@ SYMBOLS = [
     ("recon_gat_bwd_partial_floats", C.c_size_t, [C.c_int32] * 6),
     ("recon_gat_bwd", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatBwdArgs), C.c_void_p]),
     ("recon_gat_atp_supported", C.c_int, [C.c_int32] * 6),
+    ("recon_gat_atp_f16x2_supported", C.c_int, [C.c_int32] * 4),
     ("recon_gat_atp_fwd", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatAtpArgs), C.c_void_p]),
     ("recon_gat_atp_scores", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatAtpArgs), C.c_void_p]),
     ("recon_gat_atp_aggregate", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatAtpArgs), C.c_void_p]),

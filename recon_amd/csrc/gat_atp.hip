@@ -960,15 +960,18 @@ extern "C" size_t recon_gat_atp_split_bytes(int32_t F, int32_t R, int32_t D, int
 //   aux (recon_hx2_aux_bytes(), 256-byte aligned): amax quantities [0] a, [1] x, [2] edge_embed, [3] grad_out (kHx2Slots hashed
 //   slots each), then a page of zeros
 //   a_split: planes of a [2][H][D][kp(W)], then (at the bf16 x 3 layout's offset) planes of a^T [2][H][W][kp(D)]
-static bool atp_hx2(const recon_gat_atp_args* a) {
-    if (a->split_mode != RECON_SPLIT_F16X2 || !a->a_split || !a->aux) return false;
-    const int64_t W = 2LL * a->F + a->R;
-    if ((W & 7) || (a->D & 7) || (a->ld_out & 3)) return false;
-    if ((reinterpret_cast<uintptr_t>(a->a_split) & 15) || (reinterpret_cast<uintptr_t>(a->aux) & 255) || (reinterpret_cast<uintptr_t>(a->V) & 15))
-        return false;
-    const int64_t pa = static_cast<int64_t>(a->H) * a->D * hx2_kp(static_cast<int32_t>(W)), pt = static_cast<int64_t>(a->H) * W * hx2_kp(a->D);
+static bool atp_hx2_shape(int32_t F, int32_t R, int32_t D, int32_t H) {
+    const int64_t W = 2LL * F + R;
+    if (F <= 0 || R <= 0 || D <= 0 || H <= 0 || (W & 7) || (D & 7)) return false;
+    const int64_t pa = static_cast<int64_t>(H) * D * hx2_kp(static_cast<int32_t>(W)), pt = static_cast<int64_t>(H) * W * hx2_kp(D);
     return 2 * (pa > pt ? pa : pt) < (1LL << 31) && W < (1 << 24);
 }
+static bool atp_hx2(const recon_gat_atp_args* a) {
+    if (a->split_mode != RECON_SPLIT_F16X2 || !a->a_split || !a->aux) return false;
+    if (!atp_hx2_shape(a->F, a->R, a->D, a->H) || (a->ld_out & 3)) return false;
+    return !((reinterpret_cast<uintptr_t>(a->a_split) & 15) || (reinterpret_cast<uintptr_t>(a->aux) & 255) || (reinterpret_cast<uintptr_t>(a->V) & 15));
+}
+extern "C" int recon_gat_atp_f16x2_supported(int32_t F, int32_t R, int32_t D, int32_t H) { return atp_hx2_shape(F, R, D, H) ? 1 : 0; }
 static uint32_t* atp_q(const recon_gat_atp_args* a, int q) { return static_cast<uint32_t*>(a->aux) + q * kHx2QuantityWords; }
 static Hx2Scale atp_scale_a(const recon_gat_atp_args* a) { return Hx2Scale{atp_q(a, 0), nullptr, 1.f}; }
 static Hx2Scale atp_scale_v(const recon_gat_atp_args* a) {

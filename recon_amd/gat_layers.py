@@ -252,7 +252,7 @@ def _atp_split_mode(F_, R, D, H, N=None):
         return 0
     if _GEMM_BX3 not in ("1", "2") and N is not None and 2.0 * N * (2 * F_ + R) * H * D < _BX3_MIN_FLOP:
         return 0
-    if _GEMM_BX3 != "1" and (2 * F_ + R) % 8 == 0 and D % 8 == 0:
+    if _GEMM_BX3 != "1" and _lib.lib().recon_gat_atp_f16x2_supported(F_, R, D, H) == 1:
         return 2
     return 1
 
