@@ -581,3 +581,32 @@ def test_phased_backward_on_two_streams_matches(monkeypatch):
     for u, v in zip(*res):
         assert torch.equal(u, v)
 
+
+
+@pytest.mark.parametrize("xs,es,gs,p", [(1e3, 1e-3, 1e-8, 0.0), (1e-4, 1e2, 1e6, 0.0), (1.0, 1.0, 1.0, 0.9), (30.0, 1e-2, 1e-3, 0.5)])
+def test_wide_dynamic_range_inputs(xs, es, gs, p):
+    """The f16 x 2 GEMM family lives on per-tensor power-of-two scales (half has 5 exponent bits): inputs, gradients and
+    dropout factors far from unit scale must come out as accurate, relative to each tensor's own magnitude, as at unit scale."""
+    from recon_amd.gat_layers import gat_heads
+    from recon_amd.graph import prepare_graph
+    N, E, F_, R, D, H = 96, 400, 24, 16, 32, 4
+    g = torch.Generator().manual_seed(17)
+    x, ee = torch.randn(N, F_, generator=g) * xs, torch.randn(E, R, generator=g) * es
+    edge = torch.randint(0, N, (2, E), generator=g)
+    a = torch.randn(H, D, 2 * F_ + R, generator=g) * (0.05 / max(xs, es))       # keeps the scores O(1)
+    a2 = torch.randn(H, D, generator=g)
+    G = torch.randn(N, H * D, generator=g) * gs
+    keep = ((torch.rand(H, E, generator=g) >= p).float() / (1.0 - p)) if p > 0 else None
+    leaves = [t.to(dev()).requires_grad_(True) for t in (x, ee, a, a2)]
+    out = gat_heads(*leaves, prepare_graph(edge.to(dev()), None, N), keep.to(dev()) if keep is not None else None, 0.2, True,
+                    keep_max=(1.0 / (1.0 - p)) if p > 0 else None)
+    grads = torch.autograd.grad(out, leaves, G.to(dev()))
+    cl = [t.double().clone().requires_grad_(True) for t in (x, ee, a, a2)]
+    ref = torch.cat([O.gat_layer_forward(cl[0], edge, cl[1], None, None, cl[2][h], cl[3][h:h + 1], 0.2, True,
+                                         mask=keep[h].double() if keep is not None else None) for h in range(H)], 1)
+    rg = torch.autograd.grad(ref, cl, G.double())
+    assert torch.isfinite(out).all()
+    close(out, ref.float(), atol=0.0, rel_to_max=2e-5, what="out")
+    for name, u, v in zip(("g_x", "g_edge_embed", "g_a", "g_a_2"), grads, rg):
+        assert torch.isfinite(u).all(), name
+        close(u, v.float(), atol=0.0, rel_to_max=1e-4, what=name)
