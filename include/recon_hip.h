@@ -324,6 +324,41 @@ size_t recon_gcn_bwd_partial_floats(int32_t B, int32_t n, int32_t in_features, i
 int recon_gcn_bwd(const recon_gcn_bwd_args* args, recon_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * P5 / K6 in bfloat16 (BASELINE.json configs[2]: "bf16 + MFMA on W-projection"): the same layer on bfloat16 tensors — bf16
+ *     storage, fp32 accumulation, x @ W / g_support @ W^T / x^T @ g_support on v_mfma_f32_16x16x32_bf16 (csrc/gemm_b16.hip).
+ *     Activations carry a row stride that is a multiple of 8 elements (16 bytes) and at least the feature count rounded up
+ *     to 8, so that feature counts like 300 need no repacking between layers; columns past the feature count of `support`,
+ *     `out` and `g_support` are written as zeros, those of `x` must be finite.  All pointers are bf16 (uint16_t) data.
+ * ------------------------------------------------------------------------------------------*/
+typedef struct {
+    int32_t B, n, in_features, out_features;
+    const void* x; int64_t ldx;     /* [B*n, ldx] bf16, 16-byte aligned                                          */
+    const void* adj;                /* [B, n, n] bf16                                                            */
+    const void* weight;             /* [in, out] bf16, contiguous                                                */
+    const void* bias;               /* [out] bf16 or NULL                                                        */
+    void* support; int64_t lds;     /* [B*n, lds] bf16: x @ W, scratch / saved                                    */
+    void* out; int64_t ldo;         /* [B*n, ldo] bf16                                                           */
+    void* w_planes;                 /* recon_gcn_b16_planes_bytes() bytes, scratch / saved: W^T and W zero padded along k */
+} recon_gcn_b16_args;
+
+typedef struct {
+    recon_gcn_b16_args fwd;
+    const void* grad_out; int64_t ldg;   /* [B*n, ldg] bf16                                                      */
+    void* g_support;                /* [B*n, fwd.lds] bf16 workspace                                             */
+    float* partial;                 /* recon_gcn_b16_bwd_partial_floats() floats                                 */
+    void* g_x; int64_t ldgx;        /* [B*n, ldgx] bf16 or NULL                                                  */
+    void* g_adj;                    /* [B, n, n] bf16 or NULL                                                    */
+    void* g_weight;                 /* [in, out] bf16 or NULL                                                    */
+    void* g_bias;                   /* [out] bf16 or NULL                                                        */
+    const void* zeros;              /* >= 1 KiB of zero bytes, 16-byte aligned (K tails of the k-major GEMM)     */
+} recon_gcn_b16_bwd_args;
+
+size_t recon_gcn_b16_planes_bytes(int32_t in_features, int32_t out_features);
+int recon_gcn_b16_fwd(const recon_gcn_b16_args* args, recon_stream_t stream);
+size_t recon_gcn_b16_bwd_partial_floats(int32_t B, int32_t n, int32_t in_features, int32_t out_features);
+int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* args, recon_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * K4  fp32 MFMA GEMM used by the projections, exported for tests:
  *     C[M,N] = A[M,K] * B (B given as [N,K] when b_is_nk != 0, else [K,N]); plain row-major.
  * ------------------------------------------------------------------------------------------*/

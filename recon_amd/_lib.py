@@ -76,6 +76,18 @@ class GcnBwdArgs(C.Structure):
                 ("g_x", c_f32p), ("g_adj", c_f32p), ("g_weight", c_f32p), ("g_bias", c_f32p), ("gs_split", C.c_void_p)]
 
 
+class GcnB16Args(C.Structure):
+    _fields_ = [("B", C.c_int32), ("n", C.c_int32), ("in_features", C.c_int32), ("out_features", C.c_int32),
+                ("x", C.c_void_p), ("ldx", C.c_int64), ("adj", C.c_void_p), ("weight", C.c_void_p), ("bias", C.c_void_p),
+                ("support", C.c_void_p), ("lds", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64), ("w_planes", C.c_void_p)]
+
+
+class GcnB16BwdArgs(C.Structure):
+    _fields_ = [("fwd", GcnB16Args), ("grad_out", C.c_void_p), ("ldg", C.c_int64), ("g_support", C.c_void_p), ("partial", c_f32p),
+                ("g_x", C.c_void_p), ("ldgx", C.c_int64), ("g_adj", C.c_void_p), ("g_weight", C.c_void_p), ("g_bias", C.c_void_p),
+                ("zeros", C.c_void_p)]
+
+
 ACT = {"linear": 0, "relu": 1, "tanh": 2}
 
 # every symbol include/recon_hip.h declares: (name, restype, argtypes)
@@ -114,6 +126,10 @@ SYMBOLS = [
     ("recon_gcn_bwd_partial_floats", C.c_size_t, [C.c_int32] * 4),
     ("recon_gcn_bwd_split_bytes", C.c_size_t, [C.c_int32] * 3),
     ("recon_gcn_bwd", C.c_int, [C.POINTER(GcnBwdArgs), C.c_void_p]),
+    ("recon_gcn_b16_planes_bytes", C.c_size_t, [C.c_int32, C.c_int32]),
+    ("recon_gcn_b16_fwd", C.c_int, [C.POINTER(GcnB16Args), C.c_void_p]),
+    ("recon_gcn_b16_bwd_partial_floats", C.c_size_t, [C.c_int32] * 4),
+    ("recon_gcn_b16_bwd", C.c_int, [C.POINTER(GcnB16BwdArgs), C.c_void_p]),
     ("recon_sgemm", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32,
                               c_f32p, C.c_int32, C.c_void_p]),
     ("recon_gat_atp_split_bytes", C.c_size_t, [C.c_int32] * 4),

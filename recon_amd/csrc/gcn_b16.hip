@@ -1,0 +1,236 @@
+// bfloat16 GraphConvolution (models/layers.py:57-63 with bfloat16 tensors; BASELINE.json configs[2], SURVEY 8d cfg 3a):
+//     out = relu(adj @ (x @ W) + bias),   bf16 storage, fp32 accumulation.
+// x @ W, g_support @ W^T and x^T @ g_support run on the bf16 MFMA GEMMs of gemm_b16.hip; the per-graph aggregate adj @ support
+// (n x n x out per graph, n <= 32 in the reference's regime) stays on v_mfma_f32_16x16x4_f32 with bf16 loads / stores — it is
+// bandwidth bound and fp32 products cost nothing there.  Activations carry a row stride (ldx, lds, ldo ... multiples of 8
+// elements = 16 bytes) so that feature counts like 300 need no repacking between layers: columns past the feature count are
+// written as zeros and read as "times zero".
+#include "recon_common.h"
+
+namespace recon {
+int32_t b16_kp(int32_t K);
+int b16_pad_planes(const void* src, int64_t ld, bool transposed, int32_t rows, int32_t K, void* dst, hipStream_t st);
+int gemm_b16(int32_t M, int32_t N, int32_t K, const void* A, int64_t lda, const void* Bp, void* C, int64_t ldc, bool out_bf16, hipStream_t st);
+int b16_kmajor_splits(int32_t M, int32_t N, int32_t K);
+int gemm_b16_kmajor(int32_t M, int32_t N, int32_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* out, int64_t ldo, float* partial,
+                    const void* zeros, hipStream_t st);
+
+namespace {
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ float bf2f(uint16_t v) { return __builtin_bit_cast(float, static_cast<uint32_t>(v) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(uint16_t, static_cast<__bf16>(v)); }
+
+// Y[b][i][o] = epilogue( sum_j M[i][j] * Xin[b][j][o] ),  M = adj[b] (TRANS = false) or adj[b]^T; block = (64 columns, graph,
+// 32-row tile), the contraction walked in chunks of 32 through LDS (any n).  MASK: Xin = gout * (fwd_out > 0); EPI: + bias, ReLU.
+// Columns O <= o < ldy are written as zeros.
+template <bool TRANS, bool MASK, bool EPI>
+__global__ void __launch_bounds__(256) k_gcn_b16_aggregate(const uint16_t* __restrict__ adj, const uint16_t* __restrict__ Xin, int64_t ldx,
+                                                           const uint16_t* __restrict__ fwd_out, int64_t ldf, const uint16_t* __restrict__ bias,
+                                                           int32_t n, int32_t O, uint16_t* __restrict__ Y, int64_t ldy) {
+    constexpr int PM = 48, PX = 80;
+    __shared__ float Mk[32 * PM];           // Mk[k][i] = M[i0 + i][k0 + k]
+    __shared__ float Xs[32 * PX];           // Xs[k][o]
+    const int b = blockIdx.y, o0 = blockIdx.x * 64, i0 = blockIdx.z * 32;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint16_t* A = adj + static_cast<int64_t>(b) * n * n;
+    const int li = lane & 15, lq = lane >> 4;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int k0 = 0; k0 < n; k0 += 32) {
+        if (k0) __syncthreads();
+        for (int idx = t; idx < 32 * 32; idx += 256) {
+            const int k = idx >> 5, i = idx & 31;
+            float v = 0.f;
+            if (k0 + k < n && i0 + i < n)
+                v = bf2f(TRANS ? A[static_cast<int64_t>(k0 + k) * n + i0 + i] : A[static_cast<int64_t>(i0 + i) * n + k0 + k]);
+            Mk[k * PM + i] = v;
+        }
+        for (int idx = t; idx < 32 * 16; idx += 256) {                     // 4 consecutive columns per thread: 8-byte loads (row strides are
+            const int k = idx >> 4, oq = o0 + 4 * (idx & 15);              // multiples of 8 elements, so a quad never straddles a row)
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + k < n && oq < ldx) {                                  // columns in [O, ldx) hold zeros (or are masked below)
+                const int64_t row = static_cast<int64_t>(b) * n + k0 + k;
+                const uint2 raw = *reinterpret_cast<const uint2*>(Xin + row * ldx + oq);
+                v[0] = bf2f(raw.x & 0xffffu); v[1] = bf2f(raw.x >> 16); v[2] = bf2f(raw.y & 0xffffu); v[3] = bf2f(raw.y >> 16);
+                if constexpr (MASK) {
+                    const uint2 m = oq < ldf ? *reinterpret_cast<const uint2*>(fwd_out + row * ldf + oq) : make_uint2(0, 0);
+                    v[0] = bf2f(m.x & 0xffffu) > 0.f ? v[0] : 0.f; v[1] = bf2f(m.x >> 16) > 0.f ? v[1] : 0.f;
+                    v[2] = bf2f(m.y & 0xffffu) > 0.f ? v[2] : 0.f; v[3] = bf2f(m.y >> 16) > 0.f ? v[3] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = oq + q < O ? v[q] : 0.f;
+            }
+            *reinterpret_cast<float4*>(&Xs[k * PX + 4 * (idx & 15)]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int k = 4 * s + lq;
+            const float bx = Xs[k * PX + 16 * w + li];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Mk[k * PM + li], bx, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Mk[k * PM + 16 + li], bx, acc[1], 0, 0, 0);
+        }
+    }
+    const int o = o0 + 16 * w + li;                                 // C layout: col = lane & 15, row = (lane >> 4) * 4 + r
+    if (o < ldy) {
+        const float bv = (EPI && bias && o < O) ? bf2f(bias[o]) : 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 16 * tt + 4 * lq + r;
+                if (i < n) {
+                    float v = acc[tt][r];
+                    if constexpr (EPI) { v += bv; v = v > 0.f ? v : 0.f; }
+                    Y[(static_cast<int64_t>(b) * n + i) * ldy + o] = o < O ? f2bf(v) : static_cast<uint16_t>(0);
+                }
+            }
+    }
+}
+
+// g_adj[b][i][j] = sum_o gpre[b][i][o] * support[b][j][o]
+__global__ void __launch_bounds__(256) k_gcn_b16_grad_adj(const uint16_t* __restrict__ gout, int64_t ldg, const uint16_t* __restrict__ fwd_out, int64_t ldf,
+                                                          const uint16_t* __restrict__ sup, int64_t lds, int32_t n, int32_t O, uint16_t* __restrict__ gadj) {
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    const int i = idx / n, j = idx % n;
+    const int64_t ri = static_cast<int64_t>(b) * n + i, rj = static_cast<int64_t>(b) * n + j;
+    float s = 0.f;
+    for (int o = 0; o < O; ++o) s = fmaf(bf2f(fwd_out[ri * ldf + o]) > 0.f ? bf2f(gout[ri * ldg + o]) : 0.f, bf2f(sup[rj * lds + o]), s);
+    gadj[static_cast<int64_t>(b) * n * n + idx] = f2bf(s);
+}
+
+// g_bias[o] = sum_rows gpre[row][o]: block = 64 columns x 4 row lanes over a slice of rows (fixed-order LDS combine), then a
+// second pass over the slices (16 columns x 64 slice groups per block, fixed order)
+__global__ void __launch_bounds__(256) k_gcn_b16_bias_partial(const uint16_t* __restrict__ gout, int64_t ldg, const uint16_t* __restrict__ fwd_out, int64_t ldf,
+                                                              int64_t rows, int32_t O, int32_t rows_per_block, float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + c;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float s0 = 0.f, s1 = 0.f;
+    if (o < O) {
+        int64_t r = r0 + rl;
+        for (; r + 4 < r1; r += 8) {
+            s0 += bf2f(fwd_out[r * ldf + o]) > 0.f ? bf2f(gout[r * ldg + o]) : 0.f;
+            s1 += bf2f(fwd_out[(r + 4) * ldf + o]) > 0.f ? bf2f(gout[(r + 4) * ldg + o]) : 0.f;
+        }
+        for (; r < r1; r += 4) s0 += bf2f(fwd_out[r * ldf + o]) > 0.f ? bf2f(gout[r * ldg + o]) : 0.f;
+    }
+    red[rl][c] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && o < O) partial[static_cast<int64_t>(blockIdx.y) * O + o] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+__global__ void __launch_bounds__(1024) k_gcn_b16_bias_reduce(const float* __restrict__ partial, int32_t nb, int32_t O, uint16_t* __restrict__ gbias) {
+    __shared__ float red[64][17];
+    const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int o = blockIdx.x * 16 + e;
+    const int per = (nb + 63) / 64;
+    const int b0 = grp * per, b1 = min(nb, (grp + 1) * per);
+    float s = 0.f;
+    if (o < O)
+        for (int b = b0; b < b1; ++b) s += partial[static_cast<int64_t>(b) * O + o];
+    red[grp][e] = s;
+    __syncthreads();
+    if (grp == 0 && o < O) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 64; ++g) t += red[g][e];
+        gbias[o] = f2bf(t);
+    }
+}
+constexpr int kBiasBlocks = 1024;
+
+int check(const recon_gcn_b16_args* a) {
+    if (!a || a->B < 0 || a->n <= 0 || a->in_features <= 0 || a->out_features <= 0) return RECON_ERR_INVALID;
+    if (!a->x || !a->adj || !a->weight || !a->support || !a->out || !a->w_planes) return RECON_ERR_INVALID;
+    const int64_t i8 = (a->in_features + 7) / 8 * 8, o8 = (a->out_features + 7) / 8 * 8;
+    if ((a->ldx & 7) || (a->lds & 7) || (a->ldo & 7) || a->ldx < i8 || a->lds < o8 || a->ldo < o8) return RECON_ERR_INVALID;
+    if ((reinterpret_cast<uintptr_t>(a->x) | reinterpret_cast<uintptr_t>(a->support) | reinterpret_cast<uintptr_t>(a->out) |
+         reinterpret_cast<uintptr_t>(a->w_planes)) & 15) return RECON_ERR_INVALID;
+    if (a->B > 65535 || a->n > 65535 * 32) return RECON_ERR_UNSUPPORTED;
+    return RECON_OK;
+}
+size_t planes_part(int32_t rows, int32_t K) { return align_up(static_cast<size_t>(rows) * b16_kp(K) * 2, 256); }
+
+}  // namespace
+}  // namespace recon
+
+using namespace recon;
+
+extern "C" size_t recon_gcn_b16_planes_bytes(int32_t in_features, int32_t out_features) {
+    if (in_features <= 0 || out_features <= 0) return 256;
+    return planes_part(out_features, in_features) + planes_part(in_features, out_features);
+}
+
+extern "C" int recon_gcn_b16_fwd(const recon_gcn_b16_args* a, recon_stream_t stream) {
+    int rc = check(a);
+    if (rc != RECON_OK) return rc;
+    if (a->B == 0) return RECON_OK;
+    hipStream_t st = as_stream(stream);
+    const int32_t rows = a->B * a->n, I = a->in_features, O = a->out_features;
+    char* wp = static_cast<char*>(a->w_planes);
+    // W^T [O][kp(I)] for this product, W [I][kp(O)] for g_x in the backward (both zero padded along k)
+    rc = b16_pad_planes(a->weight, O, true, O, I, wp, st);
+    if (rc == RECON_OK) rc = b16_pad_planes(a->weight, O, false, I, O, wp + planes_part(O, I), st);
+    // support = x @ W      (models/layers.py:58)
+    if (rc == RECON_OK) rc = gemm_b16(rows, O, I, a->x, a->ldx, wp, a->support, a->lds, true, st);
+    if (rc != RECON_OK) return rc;
+    // out = relu(adj @ support + bias)     (:59-63)
+    dim3 grid(static_cast<unsigned>(ceil_div64(a->ldo, 64)), static_cast<unsigned>(a->B), static_cast<unsigned>(ceil_div64(a->n, 32)));
+    hipLaunchKernelGGL((k_gcn_b16_aggregate<false, false, true>), grid, dim3(256), 0, st, static_cast<const uint16_t*>(a->adj),
+                       static_cast<const uint16_t*>(a->support), a->lds, nullptr, 0, static_cast<const uint16_t*>(a->bias), a->n, O,
+                       static_cast<uint16_t*>(a->out), a->ldo);
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+extern "C" size_t recon_gcn_b16_bwd_partial_floats(int32_t B, int32_t n, int32_t in_features, int32_t out_features) {
+    const size_t need = static_cast<size_t>(kBiasBlocks) * (out_features > 0 ? out_features : 0);
+    const size_t g = static_cast<size_t>(b16_kmajor_splits(in_features, out_features, B * n)) * in_features * out_features;
+    return (g > need ? g : need) + 1;
+}
+
+extern "C" int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* b, recon_stream_t stream) {
+    if (!b) return RECON_ERR_INVALID;
+    const recon_gcn_b16_args* a = &b->fwd;
+    int rc = check(a);
+    if (rc != RECON_OK) return rc;
+    if (!b->grad_out || !b->g_support || !b->partial || !b->zeros || (b->ldg & 7) || (b->ldgx & 7)) return RECON_ERR_INVALID;
+    if (a->B == 0) return RECON_OK;
+    hipStream_t st = as_stream(stream);
+    const int32_t rows = a->B * a->n, I = a->in_features, O = a->out_features, n = a->n;
+    const uint16_t* gout = static_cast<const uint16_t*>(b->grad_out);
+    const uint16_t* fout = static_cast<const uint16_t*>(a->out);
+    // g_support = adj^T @ (grad_out * (out > 0)); pad columns zeroed (it is the A operand of the next product)
+    dim3 grid(static_cast<unsigned>(ceil_div64(a->lds, 64)), static_cast<unsigned>(a->B), static_cast<unsigned>(ceil_div64(n, 32)));
+    hipLaunchKernelGGL((k_gcn_b16_aggregate<true, true, false>), grid, dim3(256), 0, st, static_cast<const uint16_t*>(a->adj), gout, b->ldg, fout, a->ldo,
+                       nullptr, n, O, static_cast<uint16_t*>(b->g_support), a->lds);
+    if (b->g_adj)
+        hipLaunchKernelGGL(k_gcn_b16_grad_adj, dim3(static_cast<unsigned>(ceil_div64(n * n, 256)), static_cast<unsigned>(a->B)), dim3(256), 0, st, gout,
+                           b->ldg, fout, a->ldo, static_cast<const uint16_t*>(a->support), a->lds, n, O, static_cast<uint16_t*>(b->g_adj));
+    if (b->g_bias) {
+        int rpb = static_cast<int>(ceil_div64(rows, kBiasBlocks));
+        if (rpb < 16) rpb = 16;
+        const int nb = static_cast<int>(ceil_div64(rows, rpb));
+        hipLaunchKernelGGL(k_gcn_b16_bias_partial, dim3(static_cast<unsigned>(ceil_div64(O, 64)), static_cast<unsigned>(nb)), dim3(256), 0, st, gout, b->ldg,
+                           fout, a->ldo, static_cast<int64_t>(rows), O, rpb, b->partial);
+        hipLaunchKernelGGL(k_gcn_b16_bias_reduce, dim3(static_cast<unsigned>(ceil_div64(O, 16))), dim3(1024), 0, st, b->partial, nb, O,
+                           static_cast<uint16_t*>(b->g_bias));
+    }
+    RECON_CHECK_LAUNCH();
+    // g_x = g_support @ W^T : B operand = W [I][kp(O)] (k = out contiguous)
+    if (b->g_x) {
+        const int64_t i8 = (I + 7) / 8 * 8;
+        if (b->ldgx < i8 || (reinterpret_cast<uintptr_t>(b->g_x) & 15)) return RECON_ERR_INVALID;
+        rc = gemm_b16(rows, I, O, b->g_support, a->lds, static_cast<const char*>(a->w_planes) + planes_part(O, I), b->g_x, b->ldgx, true, st);
+        if (rc != RECON_OK) return rc;                                // (pad columns of g_x stay unwritten: every reader of a gradient stops at the feature count)
+    }
+    // g_W = x^T @ g_support   (k-major, split-K over the B*n rows, fixed-order second pass)
+    if (b->g_weight) {
+        rc = gemm_b16_kmajor(I, O, rows, a->x, a->ldx, b->g_support, a->lds, b->g_weight, O, b->partial, b->zeros, st);
+        if (rc != RECON_OK) return rc;
+    }
+    return RECON_OK;
+}

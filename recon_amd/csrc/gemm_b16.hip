@@ -1,0 +1,365 @@
+// bf16 GEMMs of the bfloat16 GraphConvolution path (BASELINE.json configs[2]: "bf16 + MFMA on W-projection").
+//
+// Plain bf16 operands, fp32 accumulation on v_mfma_f32_16x16x32_bf16, bf16 (or fp32) results: what torch.mm does for bf16
+// tensors, i.e. what the reference's layer (models/layers.py:57-63) computes when its tensors are bfloat16.  With ONE MFMA per
+// 16x16x32 block these products are memory bound (x @ W at cfg 3a: 6.5 GFLOP = 2.6 us of matrix pipe against 40 MB of
+// traffic), so the kernels are the f16 x 2 kernels of gemm_hx2.hip with the second term and its products removed: same
+// 128 x 208 x 32 tiles, A fragments loaded straight from global memory, B through LDS-DMA into a double-buffered image.
+//
+//   k-contiguous form   C[M,N] = A[M,K] . Bp[N,Kp]^T      A rows 16-byte aligned (lda % 8 == 0), Bp zero padded to Kp = 32 k
+//   k-major form        C[M,N] = A[K,M]^T . B[K,N]        the weight gradient x^T g_support; split-K partials in fp32
+#include <stdlib.h>
+#include "gemm_common.h"
+
+namespace recon {
+namespace {
+
+constexpr int BM = 128, BN = 208, BK = 32, NT = 256, TN = 13;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using i16x4 = __attribute__((ext_vector_type(4))) short;
+
+struct B16Args {
+    const uint16_t* A; const uint16_t* Bp;
+    int64_t lda, ldb;              // elements; ldb = Kp
+    void* C; int64_t ldc;          // bf16 or fp32 rows of ldc elements
+    int32_t M, N, K;
+};
+
+__device__ __forceinline__ int lds_off(int row, int kq) { return row * 64 + (((kq + 2 * (row >> 3)) & 3) << 4); }
+__device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(uint16_t, static_cast<__bf16>(v)); }
+
+constexpr int B_TILE_BYTES = BN * 64;                            // 13312
+constexpr int B_PIECES = B_TILE_BYTES / 1024;                    // 13
+constexpr int B_DMA = (B_PIECES + 3) / 4;                        // 4
+
+template <bool OUT_BF16>
+__global__ void __launch_bounds__(NT, 2) k_gemm_b16(const B16Args p) {
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][B_TILE_BYTES];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const TileId tile = xcd_tile(1);
+    const int m0 = tile.y * BM, n0 = tile.x * BN;
+    const int mb = wid * 32;
+    const int li = lane & 15, lq = lane >> 4;
+
+    const uint16_t* aptr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) aptr[i] = p.A + static_cast<int64_t>(min(m0 + mb + 16 * i + li, p.M - 1)) * p.lda + 8 * lq;
+    int b_goff[B_DMA];
+#pragma unroll
+    for (int i = 0; i < B_DMA; ++i) {
+        const int s = min(64 * (4 * i + wid) + lane, B_TILE_BYTES / 16 - 1);
+        const int rowL = s >> 2, pslot = s & 3;
+        const int kq = (pslot - 2 * (rowL >> 3)) & 3;                 // inverse of lds_off's rotation
+        const int j = rowL >> 4, rho = rowL & 15;
+        const int col = j < 12 ? 64 * (j >> 2) + 4 * rho + (j & 3) : 192 + rho;      // tile 4q+t <-> columns 64q + 4i + t
+        b_goff[i] = static_cast<int>(static_cast<int64_t>(min(n0 + col, p.N - 1)) * p.ldb + 8 * kq);
+    }
+    auto dma_b = [&](int k0, int buf) {
+#pragma unroll
+        for (int i = 0; i < B_DMA; ++i)
+            if (4 * i + wid < B_PIECES)                                // wave-uniform
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(p.Bp + b_goff[i] + k0),
+                                                 (__attribute__((address_space(3))) void*)(&Bs[buf][1024 * (4 * i + wid)]), 16, 0, 0);
+    };
+    f32x4 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 araw[2];
+    bf16x8 af[2];
+    bool a_ok = true;
+    auto load_a = [&](int k0) {                                      // branch free: lanes past K re-read the start of their row
+        a_ok = k0 + 8 * lq < p.K;
+        const int off = -8 * lq + ((k0 + 8 * lq) & -static_cast<int>(a_ok));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) araw[i] = *reinterpret_cast<const u32x4*>(aptr[i] + off);
+    };
+    auto take_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = a_ok ? araw[i][e] : 0u;
+            af[i] = __builtin_bit_cast(bf16x8, v);
+        }
+    };
+    const int b_rd = lds_off(li, lq);
+    auto mma = [&](const unsigned char* Bt) {
+        bf16x8 b[2][2];
+        auto read_pair = [&](int j0, bf16x8 (&dst)[2]) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+                if (j0 + jj < TN) dst[jj] = *reinterpret_cast<const bf16x8*>(Bt + b_rd + (j0 + jj) * 1024);
+        };
+        read_pair(0, b[0]);
+#pragma unroll
+        for (int g = 0; g < (TN + 1) / 2; ++g) {
+            if (2 * g + 2 < TN) read_pair(2 * g + 2, b[(g + 1) & 1]);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+                if (2 * g + jj < TN)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[i][2 * g + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], b[g & 1][jj], acc[i][2 * g + jj], 0, 0, 0);
+        }
+    };
+
+    dma_b(0, 0);
+    load_a(0);
+    take_a();
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+        if (k0 + BK < p.K) dma_b(k0 + BK, buf ^ 1);
+        load_a(k0 + BK);
+        mma(Bs[buf]);
+        take_a();
+        __syncthreads();
+        buf ^= 1;
+    }
+    // MFMA C layout col = lane&15, row = (lane>>4)*4 + r; four neighbouring tiles = four consecutive columns
+    const bool v4 = !(p.ldc & 3) && !(reinterpret_cast<uintptr_t>(p.C) & 15);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + mb + 16 * i + 4 * lq + r;
+            if (row >= p.M) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int col = n0 + 64 * q + 4 * li;
+                const float v0 = acc[i][4 * q][r], v1 = acc[i][4 * q + 1][r], v2 = acc[i][4 * q + 2][r], v3 = acc[i][4 * q + 3][r];
+                if constexpr (OUT_BF16) {
+                    uint16_t* crow = static_cast<uint16_t*>(p.C) + static_cast<int64_t>(row) * p.ldc;
+                    if (v4 && col + 3 < p.N) {
+                        *reinterpret_cast<uint2*>(crow + col) = make_uint2(f2bf(v0) | (static_cast<uint32_t>(f2bf(v1)) << 16),
+                                                                           f2bf(v2) | (static_cast<uint32_t>(f2bf(v3)) << 16));
+                    } else {
+                        const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) if (col + jj < p.N) crow[col + jj] = f2bf(vv[jj]);
+                    }
+                } else {
+                    float* crow = static_cast<float*>(p.C) + static_cast<int64_t>(row) * p.ldc;
+                    if (v4 && col + 3 < p.N) *reinterpret_cast<float4*>(crow + col) = make_float4(v0, v1, v2, v3);
+                    else {
+                        const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) if (col + jj < p.N) crow[col + jj] = vv[jj];
+                    }
+                }
+            }
+            const int col = n0 + 192 + li;
+            if (col < p.N) {
+                if constexpr (OUT_BF16) static_cast<uint16_t*>(p.C)[static_cast<int64_t>(row) * p.ldc + col] = f2bf(acc[i][12][r]);
+                else static_cast<float*>(p.C)[static_cast<int64_t>(row) * p.ldc + col] = acc[i][12][r];
+            }
+        }
+}
+
+// ---- k-major form: partial[z][M][N] = A[ks..ke, :M]^T . B[ks..ke, :N]; both tiles by LDS-DMA into row-major images, fragments
+//      through the transposing read (layouts of gemm_hx2.hip / gemm_bx3.hip); rows past the K range come from a page of zeros
+struct B16KmArgs {
+    const uint16_t* A; const uint16_t* B; const uint16_t* zeros;
+    int64_t lda, ldb;
+    float* partial;
+    int32_t M, N, K, k_per_split, nsplit, m_ld, n_ld;
+};
+constexpr int KB_SLOTS = 28;
+constexpr int KA_BYTES = BK * 256, KB_BYTES = BK * KB_SLOTS * 16;                      // 8192, 14336
+constexpr int KA_PIECES = KA_BYTES / 1024, KB_PIECES = KB_BYTES / 1024;               // 8, 14
+__device__ __forceinline__ int ka_h(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int off_lo, int off_hi) {
+    const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(base + off_lo));
+    const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(base + off_hi));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ void __launch_bounds__(NT, 2) k_gemm_b16_kmajor(const B16KmArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char S[2][KA_BYTES + KB_BYTES];      // double buffered: 2 x 22 KiB
+    const int t = threadIdx.x, lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const TileId tile = xcd_tile(1);
+    const int m0 = tile.y * BM, n0 = tile.x * BN, zs = tile.z;
+    const int k_begin = zs * p.k_per_split, k_end = min(p.K, k_begin + p.k_per_split);
+    // pieces 0..7: A image (piece = 4 k rows of 16 slots), pieces 8..21: B image (64 slots each, 28 per k row): 22 pieces over 4 waves
+    constexpr int NP = KA_PIECES + KB_PIECES, ND = (NP + 3) / 4;
+    int d_k[ND], d_col[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int pc = min(4 * i + wid, NP - 1);
+        if (pc < KA_PIECES) {
+            const int s = 64 * pc + lane, k = s >> 4, phys = s & 15;
+            d_k[i] = k;
+            d_col[i] = min(m0 + 16 * ((phys >> 1) ^ ka_h(k)) + 8 * (phys & 1), p.m_ld - 8);
+        } else {
+            const int s = 64 * (pc - KA_PIECES) + lane, k = s / KB_SLOTS, phys = s % KB_SLOTS;
+            int slot = phys - ((k & 8) ? 2 : 0);
+            if (slot < 0 || slot >= 26) slot = 0;
+            d_k[i] = k;
+            d_col[i] = min(n0 + 8 * slot, p.n_ld - 8);
+        }
+    }
+    const uint16_t* zlane = p.zeros + 8 * lane;
+    auto dma = [&](int k0, int buf) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+            if (4 * i + wid < NP) {                                       // wave-uniform
+                const int pc = 4 * i + wid, k = k0 + d_k[i];
+                const bool isa = pc < KA_PIECES;
+                const uint16_t* q = k < k_end ? (isa ? p.A + static_cast<int64_t>(k) * p.lda : p.B + static_cast<int64_t>(k) * p.ldb) + d_col[i] : zlane;
+                unsigned char* dst = S[buf] + (isa ? 1024 * pc : KA_BYTES + 1024 * (pc - KA_PIECES));
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(q), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+    };
+    f32x4 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int mb = wid * 32;
+    const int ip = lane & 15, g = lane >> 4;
+    int a_off[2][2], b_row[2];
+    bool b_rot[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int k = 8 * g + 4 * hh + (ip >> 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a_off[i][hh] = k * 256 + (((2 * wid + i) ^ ka_h(k)) << 5) + ((ip & 3) << 3);
+        b_row[hh] = k * (KB_SLOTS * 16) + (((ip & 3) & 1) << 3);
+        b_rot[hh] = (k & 8) != 0;
+    }
+    auto b_off = [&](int j, int hh) { return b_row[hh] + (2 * j + ((ip & 3) >> 1) + (b_rot[hh] ? 2 : 0)) * 16; };
+    if (k_begin < k_end) dma(k_begin, 0);
+    int buf = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this tile's copies have landed ...
+        __syncthreads();                                              // ... everyone's, and nobody still reads the other buffer
+        if (k0 + BK < k_end) dma(k0 + BK, buf ^ 1);
+        const unsigned char* As = S[buf];
+        const unsigned char* Bs = S[buf] + KA_BYTES;
+        bf16x8 a[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = tr_frag(As, a_off[i][0], a_off[i][1]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const bf16x8 b = tr_frag(Bs, b_off(j, 0), b_off(j, 1));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    float* base = p.partial + static_cast<int64_t>(tile.z) * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + mb + 16 * i + 4 * g + r;
+            if (row >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + 16 * j + ip;
+                if (col < p.N) base[static_cast<int64_t>(row) * p.N + col] = acc[i][j][r];
+            }
+        }
+}
+
+// dst[r][k] = bf16 src element, zero padded to Kp columns: TRANS reads src as [K][rows] (dst = src^T)
+template <bool TRANS>
+__global__ void __launch_bounds__(256) k_b16_pad_planes(const uint16_t* __restrict__ src, int64_t ld, int32_t rows, int32_t K, int32_t Kp,
+                                                        uint16_t* __restrict__ dst) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= static_cast<int64_t>(rows) * Kp) return;
+    const int r = static_cast<int>(TRANS ? idx % rows : idx / Kp), k = static_cast<int>(TRANS ? idx / rows : idx % Kp);
+    dst[static_cast<int64_t>(r) * Kp + k] = k < K ? (TRANS ? src[static_cast<int64_t>(k) * ld + r] : src[static_cast<int64_t>(r) * ld + k]) : 0;
+}
+
+// out (bf16 [M][N], row stride ldo) = sum of `splits` fp32 partials [z][M][N]: 16 elements x 16 split groups per block, fixed order
+__global__ void __launch_bounds__(256) k_b16_reduce(const float* __restrict__ partial, int32_t splits, int32_t M, int32_t N, uint16_t* __restrict__ out,
+                                                    int64_t ldo) {
+    __shared__ float red[16][17];
+    const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 16 + e, MN = static_cast<int64_t>(M) * N;
+    const int per = (splits + 15) / 16;
+    const int z0 = grp * per, z1 = min(splits, (grp + 1) * per);
+    float s = 0.f;
+    if (idx < MN)
+        for (int z = z0; z < z1; ++z) s += partial[z * MN + idx];
+    red[grp][e] = s;
+    __syncthreads();
+    if (grp == 0 && idx < MN) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][e];
+        out[(idx / N) * ldo + idx % N] = f2bf(t);
+    }
+}
+
+}  // namespace
+
+int32_t b16_kp(int32_t K) { return (K + BK - 1) / BK * BK; }
+
+int b16_pad_planes(const void* src, int64_t ld, bool transposed, int32_t rows, int32_t K, void* dst, hipStream_t st) {
+    if (rows <= 0 || K <= 0) return RECON_OK;
+    if (!src || !dst) return RECON_ERR_INVALID;
+    const int32_t Kp = b16_kp(K);
+    const dim3 grid(static_cast<unsigned>(ceil_div64(static_cast<int64_t>(rows) * Kp, 256)));
+    if (transposed) hipLaunchKernelGGL((k_b16_pad_planes<true>), grid, dim3(256), 0, st, static_cast<const uint16_t*>(src), ld, rows, K, Kp, static_cast<uint16_t*>(dst));
+    else hipLaunchKernelGGL((k_b16_pad_planes<false>), grid, dim3(256), 0, st, static_cast<const uint16_t*>(src), ld, rows, K, Kp, static_cast<uint16_t*>(dst));
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+
+// C[M,N] = A[M,K] . Bp[N,kp(K)]^T; A bf16 with lda % 8 == 0 and a 16-byte aligned base; C bf16 (out_bf16) or fp32
+int gemm_b16(int32_t M, int32_t N, int32_t K, const void* A, int64_t lda, const void* Bp, void* C, int64_t ldc, bool out_bf16, hipStream_t st) {
+    if (M < 0 || N < 0 || K < 0) return RECON_ERR_INVALID;
+    if (M == 0 || N == 0) return RECON_OK;
+    if (!A || !Bp || !C) return RECON_ERR_INVALID;
+    if (K <= 0 || (lda & 7) || lda < ((K + 7) & ~7) || ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bp)) & 15)) return RECON_ERR_UNSUPPORTED;
+    B16Args a;
+    a.A = static_cast<const uint16_t*>(A); a.Bp = static_cast<const uint16_t*>(Bp); a.lda = lda; a.ldb = b16_kp(K);
+    if (static_cast<int64_t>(N) * a.ldb >= (1LL << 31)) return RECON_ERR_UNSUPPORTED;
+    a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, BM)), 1);
+    if (out_bf16) hipLaunchKernelGGL((k_gemm_b16<true>), grid, dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((k_gemm_b16<false>), grid, dim3(NT), 0, st, a);
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+
+int b16_kmajor_splits(int32_t M, int32_t N, int32_t K) { return bx3_kmajor_splits(K, bx3_kmajor_split_k(M, N, K, 1)); }
+
+// out (bf16 [M][N], row stride ldo) = A[K,M]^T . B[K,N]; lda, ldb % 8 == 0, every row holds (M resp. N rounded up to 8) readable
+// columns; `partial` = b16_kmajor_splits(M, N, K) * M * N floats; `zeros` = 1 KiB of zero bytes
+int gemm_b16_kmajor(int32_t M, int32_t N, int32_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* out, int64_t ldo, float* partial,
+                    const void* zeros, hipStream_t st) {
+    if (M < 0 || N < 0 || K < 0) return RECON_ERR_INVALID;
+    if (M == 0 || N == 0) return RECON_OK;
+    if (!A || !B || !out || !partial || !zeros) return RECON_ERR_INVALID;
+    const int32_t m_ld = (M + 7) / 8 * 8, n_ld = (N + 7) / 8 * 8;
+    if ((lda & 7) || (ldb & 7) || m_ld > lda || n_ld > ldb ||
+        ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(zeros)) & 15))
+        return RECON_ERR_UNSUPPORTED;
+    B16KmArgs a;
+    a.A = static_cast<const uint16_t*>(A); a.B = static_cast<const uint16_t*>(B); a.zeros = static_cast<const uint16_t*>(zeros);
+    a.lda = lda; a.ldb = ldb; a.partial = partial; a.M = M; a.N = N; a.K = K; a.m_ld = m_ld; a.n_ld = n_ld;
+    const int sk = b16_kmajor_splits(M, N, K);
+    int64_t kps = ceil_div64(K > 0 ? K : 1, sk);
+    kps = ceil_div64(kps, BK) * BK;
+    a.k_per_split = static_cast<int32_t>(kps);
+    a.nsplit = static_cast<int32_t>(ceil_div64(K > 0 ? K : 1, kps));
+    if (a.nsplit != sk || sk > 65535) return RECON_ERR_INVALID;
+    const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, BM)), static_cast<unsigned>(sk));
+    hipLaunchKernelGGL(k_gemm_b16_kmajor, grid, dim3(NT), 0, st, a);
+    hipLaunchKernelGGL(k_b16_reduce, dim3(static_cast<unsigned>(ceil_div64(static_cast<int64_t>(M) * N, 16))), dim3(256), 0, st, partial, sk, M, N,
+                       static_cast<uint16_t*>(out), ldo);
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+
+}  // namespace recon

@@ -4,6 +4,9 @@ uniform(-1/sqrt(out), 1/sqrt(out)) init) and `SparseMM`, running in csrc/prop.hi
 
     from recon_amd.gcn_layers import GraphConvolution          # models/models.py:8
 
+bfloat16 tensors (`layer.to(torch.bfloat16)`, bf16 input / adj) take the bf16 MFMA path of csrc/gemm_b16.hip / gcn_b16.hip:
+bf16 storage, fp32 accumulation, what torch.mm does for bf16 operands.
+
 Extension over the reference: `forward` also accepts a batch, input [B,n,in] with adj [B,n,n]
 (the reference's torch.mm only takes the 2-D single-graph form).  Any n is accepted (the aggregate kernel tiles
 the adjacency in 32 x 32 blocks); B <= 65 535 graphs per call."""
@@ -84,6 +87,121 @@ class _GcnFunction(torch.autograd.Function):
         return (g_x.view(xs) if g_x is not None else None, g_adj.view(adjs) if g_adj is not None else None, g_w, g_b)
 
 
+def _rows_view(t, feat):
+    """(data_ptr-compatible 2-D view info) of a [..., n, feat] bf16 tensor whose rows are feat contiguous elements at a regular
+    row stride ld with ld % 8 == 0 and ld >= feat rounded up to 8 — the layout the bf16 kernels read in place (a contiguous tensor
+    with feat % 8 == 0, or the padded views this module hands out).  Returns ld, or None if the tensor has to be repacked."""
+    if t.dim() < 2 or t.stride(-1) != 1:
+        return None
+    ld = t.stride(-2)
+    if ld % 8 or ld < (feat + 7) // 8 * 8 or t.data_ptr() % 16:
+        return None
+    rows = t.shape[-2]
+    for d in range(t.dim() - 3, -1, -1):                       # leading dims must continue the same row sequence
+        if t.shape[d] != 1 and t.stride(d) != rows * ld:
+            return None
+        rows *= t.shape[d]
+    return ld
+
+
+def _packed_rows(t, feat, zero_pad):
+    """[rows, ld] bf16 buffer holding t's rows (ld = feat rounded up to 8); pad columns zeroed when the kernels multiply them."""
+    ld = (feat + 7) // 8 * 8
+    t2 = t.reshape(-1, feat)
+    if ld == feat:
+        return t2.contiguous(), ld
+    buf = (torch.zeros if zero_pad else torch.empty)(t2.shape[0], ld, dtype=torch.bfloat16, device=t.device)
+    buf[:, :feat] = t2
+    return buf, ld
+
+
+_ZEROS = {}
+
+
+def _zero_page(dev):
+    z = _ZEROS.get(dev)
+    if z is None:
+        z = _ZEROS[dev] = torch.zeros(1024, dtype=torch.uint8, device=dev)
+    return z
+
+
+class _GcnB16Function(torch.autograd.Function):
+    """The layer on bfloat16 tensors (BASELINE.json configs[2]): bf16 storage, fp32 accumulation, the three feature products on
+    the bf16 matrix cores (csrc/gemm_b16.hip, gcn_b16.hip).  Feature counts that are not multiples of 8 live in row-padded
+    buffers; the result is returned as a [..., :out] view of one, which the next layer reads in place."""
+
+    @staticmethod
+    def forward(ctx, x, adj, weight, bias):
+        for t in (x, adj, weight, bias):
+            if t is not None and (not t.is_cuda or t.dtype != torch.bfloat16):
+                raise TypeError("recon_amd: the bfloat16 GraphConvolution path needs bfloat16 GPU tensors for input, adj, weight and bias")
+        n, I = x.shape[-2], x.shape[-1]
+        O = weight.shape[1]
+        B = x.numel() // (n * I) if x.numel() else 0
+        adj3 = adj.contiguous().view(-1, n, n) if adj.numel() else adj.reshape(0, n, n)
+        if adj3.shape[0] != B or weight.shape[0] != I:
+            raise ValueError("GraphConvolution: inconsistent shapes")
+        dev = x.device
+        L = _lib.lib()
+        ldx = _rows_view(x, I)
+        xr = x
+        if ldx is None:
+            xr, ldx = _packed_rows(x, I, zero_pad=True)
+        o8 = (O + 7) // 8 * 8
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        sup = torch.empty(B * n, o8, **bf)
+        out_p = torch.empty(B * n, o8, **bf)
+        weight = weight.contiguous()
+        planes = torch.empty(L.recon_gcn_b16_planes_bytes(I, O), dtype=torch.uint8, device=dev)
+        args = _lib.GcnB16Args(B, n, I, O, xr.data_ptr(), ldx, adj3.data_ptr(), weight.data_ptr(), _lib.ptr(bias), sup.data_ptr(), o8,
+                               out_p.data_ptr(), o8, planes.data_ptr())
+        with torch.cuda.device(dev):
+            _lib.check(L.recon_gcn_b16_fwd(C.byref(args), _lib.current_stream()), "recon_gcn_b16_fwd")
+        ctx.save_for_backward(xr, adj3, weight, bias, sup, out_p, planes)
+        ctx.meta = (B, n, I, O, ldx, o8, tuple(x.shape), tuple(adj.shape))
+        return out_p[:, :O].view(x.shape[:-1] + (O,)) if o8 == O else out_p.as_strided(x.shape[:-1] + (O,), _strides(x.shape[:-1], o8))
+
+    @staticmethod
+    def backward(ctx, gout):
+        xr, adj3, weight, bias, sup, out_p, planes = ctx.saved_tensors
+        B, n, I, O, ldx, o8, xs, adjs = ctx.meta
+        dev = gout.device
+        L = _lib.lib()
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        nx, nadj, nw, nb = ctx.needs_input_grad
+        if gout.dtype != torch.bfloat16:
+            gout = gout.to(torch.bfloat16)
+        ldg = _rows_view(gout, O)
+        gr = gout
+        if ldg is None:
+            gr, ldg = _packed_rows(gout, O, zero_pad=False)     # pad columns of a gradient are never read
+        i8 = (I + 7) // 8 * 8
+        g_sup = torch.empty(B * n, o8, **bf)
+        partial = torch.empty(L.recon_gcn_b16_bwd_partial_floats(B, n, I, O), dtype=torch.float32, device=dev)
+        g_x = torch.empty(B * n, i8, **bf) if nx else None
+        g_adj = torch.empty(B, n, n, **bf) if nadj else None
+        g_w = torch.empty(I, O, **bf) if nw else None
+        g_b = torch.empty(O, **bf) if (nb and bias is not None) else None
+        fwd = _lib.GcnB16Args(B, n, I, O, xr.data_ptr(), ldx, adj3.data_ptr(), weight.data_ptr(), _lib.ptr(bias), sup.data_ptr(), o8,
+                              out_p.data_ptr(), o8, planes.data_ptr())
+        args = _lib.GcnB16BwdArgs(fwd, gr.data_ptr(), ldg, g_sup.data_ptr(), partial.data_ptr(), _lib.ptr(g_x), i8, _lib.ptr(g_adj),
+                                  _lib.ptr(g_w), _lib.ptr(g_b), _zero_page(dev).data_ptr())
+        with torch.cuda.device(dev):
+            _lib.check(L.recon_gcn_b16_bwd(C.byref(args), _lib.current_stream()), "recon_gcn_b16_bwd")
+        if g_x is not None:
+            g_x = g_x.view(xs) if i8 == I else g_x.as_strided(xs, _strides(xs[:-1], i8))
+        return g_x, (g_adj.view(adjs) if g_adj is not None else None), g_w, g_b
+
+
+def _strides(lead, ld):
+    """Strides of a [*lead, feat] view over rows of stride ld (lead = leading dims ending with the row dim)."""
+    st, acc = [], ld
+    for d in reversed(lead):
+        st.append(acc)
+        acc *= d
+    return tuple(reversed(st)) + (1,)
+
+
 class SparseMM(torch.autograd.Function):
     """models/layers.py:9-32 is a legacy (non-static) autograd Function for `mm` that current torch can no
     longer run; this static equivalent keeps the name and the gradients dA = g B^T, dB = A^T g."""
@@ -122,6 +240,8 @@ class GraphConvolution(Module):
             self.bias.data.uniform_(-stdv, stdv)
 
     def forward(self, input, adj):
+        if input.dtype == torch.bfloat16:                      # bf16 storage / fp32 accumulate path (module.to(torch.bfloat16))
+            return _GcnB16Function.apply(input, adj, self.weight, self.bias)
         return _GcnFunction.apply(input, adj, self.weight, self.bias)
 
     def __repr__(self):

@@ -225,3 +225,82 @@ def test_gpgnn_model_golden(name):
     for k, v in m.named_parameters():
         if "g." + k in g:
             close(v.grad, g["g." + k], atol=1e-4, rel_to_max=1e-4, what="grad " + k)
+
+
+# ------------------------------------------------------------------------------- GraphConvolution in bfloat16 (configs[2])
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("B,n,I,O_", [(1, 9, 7, 5), (6, 32, 300, 300), (3, 17, 40, 136), (2, 100, 24, 64), (4, 32, 304, 208)])
+def test_gcn_bf16_vs_oracle(B, n, I, O_):
+    """bf16 storage / fp32 accumulation.  Forward: against the fp32 oracle on the SAME bf16-rounded inputs (what remains is the
+    rounding of `support` and of the result to bf16, 2^-8 relative each).  Backward: against the oracle's gradient formulas
+    evaluated with the ReLU mask of the bf16 forward — a pre-activation within bf16 rounding of zero may land on the other side
+    of the ReLU than in fp32, which changes that element's gradient by O(1) and says nothing about the kernels."""
+    from recon_amd.gcn_layers import GraphConvolution
+    d_ = dev()
+    g = torch.Generator().manual_seed(B * n + I)
+    x = _bf(torch.randn(B, n, I, generator=g))
+    adj = (torch.rand(B, n, n, generator=g) < 0.15).float() + torch.eye(n)
+    adj = _bf(adj / adj.sum(-1, keepdim=True))
+    torch.manual_seed(1)
+    layer = GraphConvolution(I, O_).to(torch.bfloat16)
+    w, b = layer.weight.detach().clone().float(), layer.bias.detach().clone().float()
+    Gr = _bf(torch.randn(B, n, O_, generator=g))
+    ref = O.graph_convolution(x.float(), adj.float(), w, b)
+    layer = layer.to(d_)
+    xd, adjd = x.to(d_).requires_grad_(True), adj.to(d_).requires_grad_(True)
+    out = layer(xd, adjd)
+    assert out.dtype == torch.bfloat16 and out.shape == (B, n, O_)
+    close(out.float(), ref, atol=1e-3, rel_to_max=1.5e-2, what="gcn bf16 out")
+    flipped = ((out.float().cpu() > 0) != (ref > 0)).float().mean().item()
+    assert flipped < 0.02, flipped                                     # the masks agree except next to zero
+    (out * Gr.to(d_)).sum().backward()
+    # models/layers.py:57-63 differentiated by hand (as oracle.graph_convolution's autograd does), mask from the bf16 forward
+    sup = (x.float() @ w).to(torch.bfloat16).float()                   # torch.mm in bf16 rounds its result: so does the kernel
+    gpre = Gr.float() * (out.float().cpu() > 0)
+    g_sup = (adj.float().transpose(1, 2) @ gpre).to(torch.bfloat16).float()
+    close(xd.grad.float(), g_sup @ w.t(), atol=1e-3, rel_to_max=1e-2, what="g_x")
+    close(adjd.grad.float(), gpre @ sup.transpose(1, 2), atol=1e-3, rel_to_max=1e-2, what="g_adj")
+    close(layer.weight.grad.float(), x.float().reshape(-1, I).t() @ g_sup.reshape(-1, O_), atol=1e-3, rel_to_max=1e-2, what="g_weight")
+    close(layer.bias.grad.float(), gpre.reshape(-1, O_).sum(0), atol=1e-3, rel_to_max=1e-2, what="g_bias")
+
+
+def test_gcn_bf16_stack_reads_padded_rows_in_place():
+    """Three bf16 layers at D = 300 (cfg 3a): a layer's result is a [..., :300] view of 304-wide rows that the next layer (and, on
+    the way back, the previous one) reads in place; the 2-D reference form and a repacked (contiguous) input agree with it."""
+    from recon_amd.gcn_layers import GraphConvolution, _rows_view
+    d_ = dev()
+    B, n, D = 8, 32, 300
+    g = torch.Generator().manual_seed(5)
+    x = _bf(torch.randn(B, n, D, generator=g)).to(d_).requires_grad_(True)
+    adj = (torch.rand(B, n, n, generator=g) < 0.15).float() + torch.eye(n)
+    adj = _bf(adj / adj.sum(-1, keepdim=True)).to(d_)
+    torch.manual_seed(2)
+    layers = [GraphConvolution(D, D).to(torch.bfloat16).to(d_) for _ in range(3)]
+    h = x
+    for layer in layers:
+        h = layer(h, adj)
+        assert _rows_view(h, D) == 304 and not h.is_contiguous()
+    G = _bf(torch.randn(B, n, D, generator=g)).to(d_)
+    (h * G).sum().backward()
+    # the same stack with every intermediate repacked to a contiguous tensor
+    x2 = x.detach().clone().requires_grad_(True)
+    h2 = x2
+    for layer in layers:
+        h2 = layer(h2, adj).contiguous()
+    grads = [layer.weight.grad.clone() for layer in layers]
+    for layer in layers:
+        layer.weight.grad = None
+    (h2 * G).sum().backward()
+    assert torch.equal(h, h2) and torch.equal(x.grad, x2.grad)
+    for layer, gw in zip(layers, grads):
+        assert torch.equal(layer.weight.grad, gw)
+    # fp32 oracle on the bf16-rounded parameters
+    hr = x.detach().cpu().float()
+    for layer in layers:
+        hr = O.graph_convolution(hr, adj.cpu().float(), layer.weight.detach().cpu().float(), layer.bias.detach().cpu().float())
+    close(h.float(), hr, atol=1e-3, rel_to_max=3e-2, what="3-layer bf16 stack")
+    y2d = layers[0](x.detach()[0], adj[0])
+    assert torch.equal(y2d, layers[0](x.detach(), adj)[0])

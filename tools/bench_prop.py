@@ -61,15 +61,15 @@ def prop(B=1024, n=9, d=8, L=3):
                       "fwd_GBps_algorithmic": bytes_alg / tf / 1e9}))
 
 
-def gcn(B=1024, n=32, D=300, hops=3):
+def gcn(B=1024, n=32, D=300, hops=3, dtype=torch.float32):
     dv = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(B, n, D, generator=g).to(dv).requires_grad_(True)
+    x = torch.randn(B, n, D, generator=g).to(dtype).to(dv).requires_grad_(True)
     adj = (torch.rand(B, n, n, generator=g) < 0.15).float() + torch.eye(n)
-    adj = (adj / adj.sum(-1, keepdim=True)).to(dv)
+    adj = (adj / adj.sum(-1, keepdim=True)).to(dtype).to(dv)
     torch.manual_seed(0)
-    layers = [GraphConvolution(D, D).to(dv) for _ in range(hops)]
-    G = torch.randn(B, n, D, generator=g).to(dv)
+    layers = [GraphConvolution(D, D).to(dtype).to(dv) for _ in range(hops)]
+    G = torch.randn(B, n, D, generator=g).to(dtype).to(dv)
 
     def fwd():
         with torch.no_grad():
@@ -84,11 +84,17 @@ def gcn(B=1024, n=32, D=300, hops=3):
         h.backward(G)
     tf, tb = timeit(fwd), timeit(fwd_bwd)
     flops = hops * 2.0 * B * n * D * (D + n)
-    print(json.dumps({"workload": "cfg3a GraphConvolution x%d fwd" % hops, "B": B, "n": n, "D": D,
+    for l in layers:
+        l.weight.grad = None
+        l.bias.grad = None
+    print(json.dumps({"workload": "cfg3a GraphConvolution x%d fwd" % hops, "dtype": str(dtype).replace("torch.", ""), "B": B, "n": n, "D": D,
                       "fwd_us": tf * 1e6, "fwd_bwd_us": tb * 1e6, "dense_edges_per_s_fwd": B * n * n * hops / tf,
                       "fwd_TFLOPs": flops / tf / 1e12}))
 
 
 if __name__ == "__main__":
+    torch.autograd.set_multithreading_enabled(False)
     prop()
     gcn()
+    gcn(dtype=torch.bfloat16)
+    gcn(D=304, dtype=torch.bfloat16)
