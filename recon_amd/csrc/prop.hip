@@ -294,6 +294,192 @@ __global__ void __launch_bounds__(1024) k_propagate_fwd(const PropK p) {
 }
 
 
+// ------------------------------------------------------------------------------- P2 forward on the bf16 matrix cores
+// k_propagate_fwd_x: the same L-hop propagation with every fp32 operand split into three bfloat16 terms ON THE FLY and six term
+// products accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (the scheme of gemm_bx3.hip: fp32-class accuracy, no scaling — bfloat16
+// keeps fp32's exponent range — at 2.67x the fp32-MFMA ceiling).  One workgroup = one graph; wave w owns the 16 state rows
+// s = 16 w .. 16 w + 15 of every hop:  Hnew^T [S x C] = A_l [S x S] . H^T [S x C],  M = s, N = channel, K = t.
+//   * A_l is read exactly ONCE from HBM: each lane fetches its own MFMA A-fragment (row s = lane & 15, 8 consecutive t) as two
+//     float4 and splits it in registers; a hop's rows are requested while the previous hop computes;
+//   * the state lives in LDS as three bf16 planes [3][channel][t] (k-contiguous: B fragments are ds_read_b128), split once per
+//     hop when it is written, reconstructed exactly (8 + 8 + 8 mantissa bits) for the head (.) tail gather;
+//   * two barriers per hop (all reads of H^l-1 done -> write H^l -> visible).
+// Opt-in (RECON_PROP_FWD=x), parity-tested like the other forms.  Measured at cfg 3b: 207 us against 167 us for the fp32-MFMA wave
+// form below, although its matrix-pipe time is 31 us against 58: one graph = one workgroup of 9 waves (3/2/2/2 over the SIMDs)
+// with 77 KB of LDS image and 168 registers, so a CU holds a single workgroup, and the waves spend 62 % of their life parked at
+// the two barriers per hop and behind the A loads (PMC: SQ_WAIT_ANY 165 M of 267 M wave cycles, MFMA busy 31 us of 207).  Forcing
+// two workgroups per CU (96 registers) spills 420 bytes per lane: 341 us.
+using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4_t = __attribute__((ext_vector_type(4))) uint32_t;
+
+__device__ __forceinline__ void px_split8(const float (&v)[8], bf16x8_t (&out)[3]) {
+    float r[8];
+    u32x4_t w[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x0 = q == 0 ? v[2 * j] : r[2 * j], x1 = q == 0 ? v[2 * j + 1] : r[2 * j + 1];
+            const uint32_t b0 = __builtin_bit_cast(uint16_t, static_cast<__bf16>(x0)), b1 = __builtin_bit_cast(uint16_t, static_cast<__bf16>(x1));
+            w[q][j] = b0 | (b1 << 16);
+            if (q < 2) { r[2 * j] = x0 - __builtin_bit_cast(float, b0 << 16); r[2 * j + 1] = x1 - __builtin_bit_cast(float, b1 << 16); }
+        }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) out[q] = __builtin_bit_cast(bf16x8_t, w[q]);
+}
+
+// NTC = channel tiles of 16 (C <= 16 NTC), KS = K steps of 32 (S <= 32 KS); blockDim.x = 64 * ceil(S / 16).
+// LDS image of the state: [plane 3][K step KS][channel 16 NTC][64 bytes = 32 t], the 16-byte slot of t group kq rotated by
+// 2 (channel >> 3) — the B image of gemm_bx3.hip, conflict free for the ds_read_b128 fragment reads.
+#ifndef RECON_PX_OCC
+#define RECON_PX_OCC 2
+#endif
+template <int NTC, int KS>
+__global__ void __launch_bounds__(128 * KS, RECON_PX_OCC) k_propagate_fwd_x(const PropK p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xl[];
+    constexpr int STEP = NTC * 16 * 64;                               // bytes of one K step of one plane
+    constexpr int PLANE = KS * STEP;
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x, S = p.S, C = p.C;
+    const int li = lane & 15, lq = lane >> 4;
+    auto state_off = [](int c, int t) { return (t >> 5) * STEP + c * 64 + ((((t >> 3) + 2 * (c >> 3)) & 3) << 4) + 2 * (t & 7); };
+    auto store_state = [&](int c, int t0, const float (&v)[4]) {      // 4 consecutive t (t0 % 4 == 0) of channel c -> the three planes
+        float r[4] = {v[0], v[1], v[2], v[3]};
+        const int off = state_off(c, t0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            uint32_t w[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t b0 = __builtin_bit_cast(uint16_t, static_cast<__bf16>(r[2 * h])), b1 = __builtin_bit_cast(uint16_t, static_cast<__bf16>(r[2 * h + 1]));
+                w[h] = b0 | (b1 << 16);
+                r[2 * h] -= __builtin_bit_cast(float, b0 << 16); r[2 * h + 1] -= __builtin_bit_cast(float, b1 << 16);
+            }
+            *reinterpret_cast<uint2*>(xl + q * PLANE + off) = make_uint2(w[0], w[1]);
+        }
+    };
+    auto state_at = [&](int c, int t) {                               // exact fp32 value of H[c][t]: 8 + 8 + 8 mantissa bits
+        const int off = state_off(c, t);
+        float v = 0.f;
+#pragma unroll
+        for (int q = 2; q >= 0; --q) v += __builtin_bit_cast(float, static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(xl + q * PLANE + off)) << 16);
+        return v;
+    };
+    // ---- h^0 -> planes (zero padded to 16 NTC channels x 32 KS columns)
+    for (int idx = tid; idx < NTC * 16 * KS * 8; idx += nthreads) {
+        const int c = idx / (KS * 8), t0 = 4 * (idx % (KS * 8));
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (c < C && t0 + e < S) ? p.h0[b * p.h0_bs + static_cast<int64_t>(c) * S + t0 + e] : 0.f;
+        store_state(c, t0, v);
+    }
+    // ---- this wave's rows of A_l: fragment (row 16 w + li, columns 32 ks + 8 lq .. + 7) as two float4, two K steps ahead of the MFMAs
+    const int row = 16 * wave + li;
+    const bool row_ok = row < S;
+    const bool vec = (S & 3) == 0;
+    const int64_t arow = (static_cast<int64_t>(b) * S + (row_ok ? row : 0)) * S;
+    auto load_a = [&](float (&dst)[8], int l, int ks) {
+        const float* A = p.adj[l] + arow;
+        const int t0 = 32 * ks + 8 * lq;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = t0 + 4 * h;
+            if (vec) {                                                // S % 4 == 0: a quad is inside the row or outside it
+                const float4 q4 = *reinterpret_cast<const float4*>(A + (t < S ? t : 0));
+                dst[4 * h] = q4.x; dst[4 * h + 1] = q4.y; dst[4 * h + 2] = q4.z; dst[4 * h + 3] = q4.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[4 * h + e] = A[t + e < S ? t + e : 0];
+            }
+        }
+    };
+    // gather indices of this thread's first GI output items: the same in every hop, so their (dependent, int64) loads leave the loop
+    constexpr int GI = 3;
+    int g_hi[GI], g_ti[GI];
+#pragma unroll
+    for (int i = 0; i < GI; ++i) {
+        const int idx = min(tid + i * nthreads, C * p.dd - 1);
+        const int64_t io = b * p.idx_bs + idx;
+        g_hi[i] = static_cast<int>(p.head[io]); g_ti[i] = static_cast<int>(p.tail[io]);
+    }
+    constexpr int PFD = KS >= 2 ? 2 : 1;                               // K steps in flight
+    float araw[PFD][8];
+#pragma unroll
+    for (int i = 0; i < PFD; ++i) load_a(araw[i], 0, i);
+    __syncthreads();
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};      // small terms first
+    const int b_rd = li * 64 + (((lq + 2 * (li >> 3)) & 3) << 4);     // + 1024 j (the rotation depends on channel & 8 only) + STEP ks
+    for (int l = 0; l < p.L; ++l) {
+        f32x4 acc[NTC];
+#pragma unroll
+        for (int j = 0; j < NTC; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float av[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[e] = (row_ok && 32 * ks + 8 * lq + e < S) ? araw[ks % PFD][e] : 0.f;      // rows / columns past S: zero
+            // refill the slot just consumed with the step PFD ahead (the next hop's first steps at the end of this one)
+            if (ks + PFD < KS) load_a(araw[ks % PFD], l, ks + PFD);
+            else if (l + 1 < p.L) load_a(araw[ks % PFD], l + 1, ks % PFD);        // step n of a hop always lives in slot n % PFD
+            bf16x8_t a[3];
+            px_split8(av, a);
+            // channel tiles in pairs: two independent accumulator chains of six products each
+#pragma unroll
+            for (int j = 0; j < NTC; j += 2) {
+                bf16x8_t bfr[2][3];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    if (j + jj < NTC)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            bfr[jj][q] = *reinterpret_cast<const bf16x8_t*>(xl + q * PLANE + ks * STEP + 1024 * (j + jj) + b_rd);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+                        if (j + jj < NTC) acc[j + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[TA[t]], bfr[jj][TB[t]], acc[j + jj], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                              // every wave has read H^l-1
+        // C layout: column (lane & 15) = channel 16 j + li, rows 4 lq + r = state index s = 16 w + 4 lq + r
+        float* hs = p.hsave ? p.hsave + ((static_cast<int64_t>(l) * p.B + b) * C) * S : nullptr;
+        const int s0 = 16 * wave + 4 * lq;
+#pragma unroll
+        for (int j = 0; j < NTC; ++j) {
+            const int c = 16 * j + li;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (s0 + r < S) ? act_fwd(acc[j][r], p.act) : 0.f;
+            store_state(c, s0, v);                                    // s0 < 16 ceil(S/16) <= 32 KS: inside the padded image
+            if (hs && c < C) {
+                if (vec && s0 + 3 < S) *reinterpret_cast<float4*>(hs + static_cast<int64_t>(c) * S + s0) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (s0 + r < S) hs[static_cast<int64_t>(c) * S + s0 + r] = v[r];
+                }
+            }
+        }
+        __syncthreads();                                              // H^l complete
+        // relation_l = heads * tails   (models/models.py:270-273); the first GI items of a thread use the indices fetched before the hop loop
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            const int idx = tid + i * nthreads;
+            if (idx < C * p.dd) {
+                const int c = idx / p.dd, x = idx % p.dd;
+                p.out[(static_cast<int64_t>(b) * C + c) * (p.L * p.dd) + l * p.dd + x] = state_at(c, g_hi[i]) * state_at(c, g_ti[i]);
+            }
+        }
+        for (int idx = tid + GI * nthreads; idx < C * p.dd; idx += nthreads) {
+            const int c = idx / p.dd, x = idx % p.dd;
+            const int64_t io = b * p.idx_bs + static_cast<int64_t>(c) * p.dd + x;
+            const int hi = static_cast<int>(p.head[io]), ti = static_cast<int>(p.tail[io]);
+            p.out[(static_cast<int64_t>(b) * C + c) * (p.L * p.dd) + l * p.dd + x] = state_at(c, hi) * state_at(c, ti);
+        }
+        // the next hop's first barrier orders these reads before its writes
+    }
+}
+
 // ------------------------------------------------------------------------------- P2 forward, wave-independent form
 // Channels never mix, so ONE WAVE owns 16 channels of one graph for all L hops and needs no workgroup barrier:
 // its state H^T [16][S] lives in REGISTERS as MFMA A-fragments (NT float4 per lane), every hop streams the whole
@@ -747,6 +933,23 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
     hipStream_t st = as_stream(stream);
     const int NTn = g.Sp / 16;
     const int mtn_s = (a->C + 15) / 16;
+    {
+        const char* form = getenv("RECON_PROP_FWD");
+        const int ntc = (a->C + 15) / 16, ks = (a->S + 31) / 32, mw = (a->S + 15) / 16;
+        if (form && form[0] == 'x' && ntc <= 8 && ks <= 8 && mw <= 16) {             // bf16 x 3 on the bf16 matrix cores: opt-in (see the kernel's header)
+            const size_t xlds = 3ull * ks * ntc * 16 * 64;
+            bool launched = true;
+#define CALL_X(N_, K_) do { if (xlds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_fwd_x<N_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(xlds)); \
+                            hipLaunchKernelGGL((k_propagate_fwd_x<N_, K_>), dim3(static_cast<unsigned>(a->B)), dim3(64 * mw), xlds, st, p); } while (0)
+#define CALL_XK(N_) switch (ks) { case 1: CALL_X(N_, 1); break; case 2: CALL_X(N_, 2); break; case 3: CALL_X(N_, 3); break; case 4: CALL_X(N_, 4); break; \
+                                  case 5: CALL_X(N_, 5); break; case 6: CALL_X(N_, 6); break; case 7: CALL_X(N_, 7); break; default: CALL_X(N_, 8); break; }
+            switch (ntc) { case 1: CALL_XK(1); break; case 2: CALL_XK(2); break; case 3: CALL_XK(3); break; case 4: CALL_XK(4); break; case 5: CALL_XK(5); break;
+                           case 6: CALL_XK(6); break; case 7: CALL_XK(7); break; case 8: CALL_XK(8); break; default: launched = false; break; }
+#undef CALL_XK
+#undef CALL_X
+            if (launched) { RECON_CHECK_LAUNCH(); return RECON_OK; }
+        }
+    }
     if (NTn <= 9 && (a->S % 16) == 0 && v4 && mtn_s <= 16 && g.pitch == a->S + 4 && getenv("RECON_PROP_FWD") && getenv("RECON_PROP_FWD")[0] == 's') {   // staged form
         const size_t slds = 3ull * 16 * (a->S + 4) * sizeof(float) + static_cast<size_t>(mtn_s) * 16 * g.pitch * sizeof(float);
 #define CALL_S(N_) do { if (slds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_fwd_s<N_>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(slds)); \
@@ -758,7 +961,7 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
         RECON_CHECK_LAUNCH();
         return RECON_OK;
     }
-    if (NTn <= 9 && !(getenv("RECON_PROP_FWD") && getenv("RECON_PROP_FWD")[0] == 'b')) {      // wave-independent form
+    if (NTn <= 9 && !(getenv("RECON_PROP_FWD") && getenv("RECON_PROP_FWD")[0] == 'b')) {      // wave-independent form (RECON_PROP_FWD=w, or shapes the bf16 form does not take)
         const int64_t units = 1LL * a->B * ((a->C + 15) / 16);
         dim3 wgrid(static_cast<unsigned>(ceil_div64(units, 4)));
         const size_t wlds = 4ull * 16 * g.pitch * sizeof(float);
