@@ -482,14 +482,11 @@ struct AtpBwdK {
 
 // wave = one destination node; head groups of HT are walked one after the other by the SAME wave so the
 // per-edge outputs (g_edge_embed row, Gxs row) can be accumulated across groups without atomics.
-#ifndef RECON_K2_PF
-#define RECON_K2_PF 2
-#endif
-#ifndef RECON_K2_OCC
-#define RECON_K2_OCC 3
-#endif
+// Two rows in flight per wave at three waves per SIMD (<= 168 registers) is the measured optimum at cfg 2: a four-deep ring needs
+// 197 registers (two waves per SIMD: 101 us against 80), four deep at three waves spills (130 us).
+constexpr int kK2Ring = 2, kK2WavesPerSimd = 3;
 template <int VEC, int KR, int HT>
-__global__ void __launch_bounds__(kBlock, RECON_K2_OCC) k_gat_atp_bwd(const AtpBwdK p) {
+__global__ void __launch_bounds__(kBlock, kK2WavesPerSimd) k_gat_atp_bwd(const AtpBwdK p) {
     extern __shared__ __attribute__((aligned(16))) float U[];          // [H][W]: u_dst | u_src | u_rel per head
     const int F = p.F, R = p.R, H = p.H, W = 2 * F + R;
     const int lane = threadIdx.x & 63;
@@ -534,7 +531,7 @@ __global__ void __launch_bounds__(kBlock, RECON_K2_OCC) k_gat_atp_bwd(const AtpB
         const bool hv = myh < H;
         // ring of PF register slots (static indices: the loop body is unrolled PF times) holding the rows / score of the next
         // PF edges; filled for the first edges BEFORE the g_V rows are requested, so both are in flight together
-        constexpr int PF = KR == 1 ? RECON_K2_PF : (KR == 2 ? 2 : 1);
+        constexpr int PF = KR == 1 ? kK2Ring : (KR == 2 ? 2 : 1);
         const int mh = hv ? myh : h0;
         int c0 = beg, cn = cn0, srcv = srcv0, eidv = eidv0;
         const float* keepp = p.keep ? p.keep : p.sigma;
@@ -1020,8 +1017,9 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
         RowDotsJob jn, je;
         jn.X = a->x; jn.gather = nullptr; jn.rows = N; jn.K = F; jn.F = F; jn.off = 0; jn.NJ = 2 * H; jn.out = a->c_node;
         jn.amax = hx2 ? atp_q(a, 1) : nullptr; je.amax = hx2 ? atp_q(a, 2) : nullptr;
-        static const int rd_n = getenv("RECON_TUNE_RD_N") ? atoi(getenv("RECON_TUNE_RD_N")) : 32;
-        static const int rd_e = getenv("RECON_TUNE_RD_E") ? atoi(getenv("RECON_TUNE_RD_E")) : 64;
+        // rows per block, measured at cfg 2 (every block first stages its score vectors in LDS): 16 / 32 rows 24.7 us, 32 / 64 rows
+        // 18.7 us, 64 / 128 rows 25.4 us
+        constexpr int rd_n = 32, rd_e = 64;
         jn.nb = static_cast<int>(ceil_div64(N, rd_n) < 2048 ? ceil_div64(N, rd_n) : 2048);
         je.X = a->edge_embed; je.gather = g->eid; je.rows = E; je.K = R; je.F = 0; je.off = 2 * F; je.NJ = H; je.out = a->c_rel;
         je.nb = E > 0 ? static_cast<int>(ceil_div64(E, rd_e) < 2048 ? ceil_div64(E, rd_e) : 2048) : 0;

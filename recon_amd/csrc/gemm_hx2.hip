@@ -469,14 +469,11 @@ int hx2_amax(const float* src, int64_t rows, int32_t cols, int64_t ld, uint32_t*
     if (rows <= 0 || cols <= 0) return RECON_OK;
     if (!src || !slot) return RECON_ERR_INVALID;
     const int64_t n = rows * cols;
-    static const int cfg = getenv("RECON_TUNE_AMAX") ? atoi(getenv("RECON_TUNE_AMAX")) : 1;
-    const int threads = cfg == 2 ? 256 : (cfg == 1 ? 512 : 1024);
-    const int64_t cap = cfg == 2 ? 2048 : (cfg == 1 ? 1024 : 512);   // 32 waves per CU in every case
-    int64_t blocks = ceil_div64(n, static_cast<int64_t>(threads) * 16);
-    if (blocks > cap) blocks = cap;
-    if (threads == 256) hipLaunchKernelGGL((k_hx2_amax<256>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, src, rows, cols, ld, slot);
-    else if (threads == 512) hipLaunchKernelGGL((k_hx2_amax<512>), dim3(static_cast<unsigned>(blocks)), dim3(512), 0, st, src, rows, cols, ld, slot);
-    else hipLaunchKernelGGL((k_hx2_amax<1024>), dim3(static_cast<unsigned>(blocks)), dim3(1024), 0, st, src, rows, cols, ld, slot);
+    // 512 threads x <= 1024 blocks (32 waves per CU), one commit per block: 13.5 us for 52 MB at cfg 2 (1024 x 512: 14.1, 256 x 2048: 14.8;
+    // one commit per WAVE: 17.7)
+    int64_t blocks = ceil_div64(n, 512 * 16);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL((k_hx2_amax<512>), dim3(static_cast<unsigned>(blocks)), dim3(512), 0, st, src, rows, cols, ld, slot);
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
 }
@@ -572,9 +569,7 @@ int gemm_hx2_kmajor_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int
     if (static_cast<int64_t>(batch) * split_k > 65535) return RECON_ERR_UNSUPPORTED;
     a.sa = sa; a.sb = sb;
     const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, BM)), static_cast<unsigned>(batch * split_k));
-    static const int occ = getenv("RECON_HX2_KM_OCC") ? atoi(getenv("RECON_HX2_KM_OCC")) : 2;
-    if (occ == 3) hipLaunchKernelGGL((k_gemm_hx2_kmajor<3>), grid, dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL((k_gemm_hx2_kmajor<2>), grid, dim3(NT), 0, st, a);
+    hipLaunchKernelGGL((k_gemm_hx2_kmajor<2>), grid, dim3(NT), 0, st, a);      // three workgroups per CU (<= 168 registers) spill: 241 us against 70
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
 }

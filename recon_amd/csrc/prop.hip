@@ -331,11 +331,8 @@ __device__ __forceinline__ void px_split8(const float (&v)[8], bf16x8_t (&out)[3
 // NTC = channel tiles of 16 (C <= 16 NTC), KS = K steps of 32 (S <= 32 KS); blockDim.x = 64 * ceil(S / 16).
 // LDS image of the state: [plane 3][K step KS][channel 16 NTC][64 bytes = 32 t], the 16-byte slot of t group kq rotated by
 // 2 (channel >> 3) — the B image of gemm_bx3.hip, conflict free for the ds_read_b128 fragment reads.
-#ifndef RECON_PX_OCC
-#define RECON_PX_OCC 2
-#endif
 template <int NTC, int KS>
-__global__ void __launch_bounds__(128 * KS, RECON_PX_OCC) k_propagate_fwd_x(const PropK p) {
+__global__ void __launch_bounds__(128 * KS, 2) k_propagate_fwd_x(const PropK p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xl[];
     constexpr int STEP = NTC * 16 * 64;                               // bytes of one K step of one plane
     constexpr int PLANE = KS * STEP;
