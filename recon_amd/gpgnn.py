@@ -8,7 +8,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .propagation import (build_block_adjacency, propagate, make_start_embedding, get_head_indices, get_tail_indices)
+from .propagation import (build_block_adjacency, propagate, make_start_embedding, make_start_entity_embeddings, get_head_indices,
+                          get_tail_indices)
 
 
 class GPGNN(nn.Module):
@@ -80,4 +81,93 @@ class GPGNN(nn.Module):
                     T = getattr(F, p['non-linear1'])(T)
                 adjs.append(build_block_adjacency(T, self.identity_transformation, n))
         relation = propagate(adjs, self.start_embedding, p['non-linear1'], self.head_indices[0], self.tail_indices[0])   # :260-274
+        return self.linear3(relation).view(B * self.MAX_EDGES_PER_GRAPH, -1)
+
+
+class CharEmbeddings(nn.Module):
+    """models/models.py:15-24 (state_dict key `embeddings.weight`)."""
+
+    def __init__(self, vocab_size, embed_dim, drop_out_rate):
+        super().__init__()
+        self.embeddings = nn.Embedding(vocab_size, embed_dim, padding_idx=0)
+        self.dropout = nn.Dropout(drop_out_rate)
+
+    def forward(self, chars):
+        return self.dropout(self.embeddings(chars))
+
+
+class EntityEmbedding(nn.Module):
+    """Entity attribute context encoder, models/models.py:26-83: every context line of an entity is a word sequence (word
+    vectors + char-CNN features) run through an LSTM; the final states of all lines of one entity are convolved and max-pooled
+    over the unmasked lines into one vector per entity.  Stock PyTorch-ROCm ops (MIOpen LSTM / convolution): this is the
+    encoder in front of the propagation path, not the path.  Keys: word_embeddings.weight (the caller's table, shared),
+    char_embeddings.embeddings.weight, lstm.*, conv1d.*, conv1d_entity.*."""
+
+    def __init__(self, input_dim, hidden_dim, layers, is_bidirectional, drop_out_rate, entity_embed_dim, conv_filter_size,
+                 entity_conv_filter_size, word_embeddings, char_embed_dim, max_word_len_entity, char_vocab, char_feature_size):
+        super().__init__()
+        self.input_dim, self.hidden_dim, self.layers = input_dim, hidden_dim, layers
+        self.is_bidirectional, self.drop_rate = is_bidirectional, drop_out_rate
+        self.word_embeddings = word_embeddings
+        self.char_embeddings = CharEmbeddings(len(char_vocab), char_embed_dim, drop_out_rate)
+        self.lstm = nn.LSTM(input_dim, hidden_dim, layers, batch_first=True, bidirectional=bool(is_bidirectional))
+        self.conv1d = nn.Conv1d(char_embed_dim, char_feature_size, conv_filter_size)
+        self.word_span = max_word_len_entity + conv_filter_size - 1      # chars one word occupies in the padded char sequence
+        self.conv1d_entity = nn.Conv1d(2 * hidden_dim, entity_embed_dim, entity_conv_filter_size)
+
+    def forward(self, words, chars, conv_mask):
+        """words [U, lines, len], chars [U, lines, cfs-1 + len*(max_char+cfs-1)], conv_mask bool [U, lines-ecfs+1] (True = padding
+        line) -> [U, entity_embed_dim]."""
+        U, lines = words.shape[0], words.shape[1]
+        words = words.reshape(U * lines, words.shape[2])
+        chars = chars.reshape(U * lines, chars.shape[2])
+        word_vec = self.word_embeddings(words)
+        char_vec = self.char_embeddings(chars).permute(0, 2, 1)
+        char_feat = torch.tanh(F.max_pool1d(self.conv1d(char_vec), self.word_span, self.word_span)).permute(0, 2, 1)
+        _, (h_n, _) = self.lstm(torch.cat((word_vec, char_feat), -1))
+        # last layer, both directions side by side (the reference reshapes to (layers, 2, batch, hidden): bidirectional only)
+        h_n = h_n.view(self.layers, 2, U * lines, self.hidden_dim)[-1].permute(1, 0, 2).reshape(U, lines, 2 * self.hidden_dim)
+        conv = self.conv1d_entity(h_n.permute(0, 2, 1))
+        conv = conv.masked_fill(conv_mask.unsqueeze(1), -float('inf'))
+        return conv.max(dim=2).values
+
+
+class RECON_EAC(GPGNN):
+    """The reference's `RECON_EAC` (models/models.py:279-487): GPGNN whose start embedding is built PER BATCH from the entity
+    attribute context (`EntityEmbedding` -> `make_start_entity_embeddings`, utils/context_utils.py:387-426) instead of the
+    fixed one-hot template.  Same constructor, forward signature and state_dict keys (GPGNN's plus entity_embedding_module.*).
+    The per-batch start vectors, the block adjacency and the L-hop propagation run on the HIP kernels of csrc/prop.hip.
+
+    Two places where the reference's code cannot be followed literally: its tied-projection branch (:401-445) hard-codes
+    9 nodes AND ignores the context embeddings (it propagates the fixed template) — kept as is, through GPGNN.forward; and its
+    head / tail index tensors bake in `batch_size` — the kernels take the [C,2d] pattern, so any batch size runs."""
+
+    def __init__(self, p, embeddings, max_sent_len, n_out, char_vocab, MAX_EDGES_PER_GRAPH=72):
+        super().__init__(p, embeddings, max_sent_len, n_out, MAX_EDGES_PER_GRAPH)
+        n, d = p['max_num_nodes'], p['embedding_dim']
+        self.head_indices = nn.Parameter(torch.LongTensor(get_head_indices(n, d, bs=p['batch_size'])), requires_grad=False)   # :338-342
+        self.tail_indices = nn.Parameter(torch.LongTensor(get_tail_indices(n, d, bs=p['batch_size'])), requires_grad=False)
+        self.entity_embedding_module = EntityEmbedding(
+            p['char_embed_dim'] + embeddings.shape[1], p['hidden_dim_ent'], p['num_entEmb_layers'], p['is_bidirectional_ent'],
+            p['drop_out_rate_ent'], p['entity_embed_dim'], p['conv_filter_size'], p['entity_conv_filter_size'], self.word_embedding,
+            p['char_embed_dim'], p['max_char_len'], char_vocab, p['char_feature_size'])
+
+    def forward(self, sentence_input, entity_markers, num_entities, unique_entites, entity_indices, context_words, context_chars,
+                context_mask, entities_position, max_occurred_entity_in_batch_pos):
+        p = self.p
+        if self.tied:
+            return super().forward(sentence_input, entity_markers, num_entities)
+        n, L = p['max_num_nodes'], p['layer_number']
+        entity_embeddings = self.entity_embedding_module(context_words, context_chars, context_mask)
+        h0 = make_start_entity_embeddings(entity_embeddings, entities_position, unique_entites, p['embedding_dim'],
+                                          max_occurred_entity_in_batch_pos, self.start_embedding, max_num_nodes=n)     # :365
+        rnn_result = self.encode(sentence_input, entity_markers)
+        B = rnn_result.size(0)
+        adjs = []
+        for i in range(L):                                               # :447-466
+            T = self.representation_to_adj[i](rnn_result)
+            if p['non-linear1'] != "linear":
+                T = getattr(F, p['non-linear1'])(T)
+            adjs.append(build_block_adjacency(T, self.identity_transformation, n))
+        relation = propagate(adjs, h0, p['non-linear1'], self.head_indices[0], self.tail_indices[0])                   # :467-484
         return self.linear3(relation).view(B * self.MAX_EDGES_PER_GRAPH, -1)

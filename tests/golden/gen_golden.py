@@ -360,6 +360,49 @@ def gpgnn_full_case(name, ref_models, style, n=3, d=2, L=3, B=50):
     save(name, **arrays)
 
 
+EAC_P = {"max_num_nodes": 3, "embedding_dim": 2, "layer_number": 3, "projection_style": "untie", "non-linear1": "relu",
+         "non-linear": "tanh", "dropout1": 0.0, "position_emb": 3, "units1": 4, "rnn1_layers": 1, "bidirectional": 1, "batch_size": 4,
+         "char_embed_dim": 3, "hidden_dim_ent": 3, "num_entEmb_layers": 1, "is_bidirectional_ent": 1, "drop_out_rate_ent": 0.0,
+         "entity_embed_dim": 2, "conv_filter_size": 2, "entity_conv_filter_size": 2, "max_char_len": 4, "char_feature_size": 3}
+
+
+def recon_eac_case(name, ref_models):
+    """N3: the whole reference RECON_EAC (models/models.py:279-487) — entity attribute context encoder, per-batch start
+    embeddings, untied block adjacency, 3-hop propagation, classifier: state_dict, inputs, logits, parameter gradients."""
+    p = dict(EAC_P)
+    n, B, U, lines, wl = p["max_num_nodes"], p["batch_size"], 5, 4, 3
+    C = n * (n - 1)
+    emb = hashed_uniform((7, 5), 311, -0.5, 0.5).astype(np.float32)
+    emb[0] = 0.0
+    char_vocab = {c: i for i, c in enumerate("_abcdefg")}
+    torch.manual_seed(13)
+    m = ref_models.RECON_EAC(p, emb, max_sent_len=4, n_out=3, char_vocab=char_vocab)
+    m.eval()
+    gs = torch.Generator().manual_seed(6)
+    sent = torch.randint(1, 7, (B, 4), generator=gs)
+    mark = torch.randint(0, 4, (B, C, 4), generator=gs)
+    ctx_words = torch.randint(0, 7, (U, lines, wl), generator=gs)
+    span = p["max_char_len"] + p["conv_filter_size"] - 1
+    ctx_chars = torch.randint(0, len(char_vocab), (U, lines, p["conv_filter_size"] - 1 + wl * span), generator=gs)
+    mask = torch.rand(U, lines - p["entity_conv_filter_size"] + 1, generator=gs) < 0.4      # True = padding line
+    mask[:, 0] = False
+    pos = torch.randint(0, U, (B, C, 2), generator=gs)
+    max_occ = 2
+    ent = m.entity_embedding_module(ctx_words, ctx_chars, mask).detach().clone()
+    out = m(sent, mark, None, None, None, ctx_words, ctx_chars, mask, pos, max_occ)
+    G = torch.from_numpy(hashed_uniform(tuple(out.shape), 312))
+    (out * G).sum().backward()
+    arrays = dict(emb=emb, sent=t2n(sent), mark=t2n(mark), ctx_words=t2n(ctx_words), ctx_chars=t2n(ctx_chars), ctx_mask=t2n(mask),
+                  pos=t2n(pos), max_occ=np.int32(max_occ), ent=t2n(ent), out=t2n(out), G=t2n(G), n_chars=np.int32(len(char_vocab)))
+    for k, v in m.state_dict().items():
+        if k not in ("head_indices", "tail_indices", "start_embedding"):
+            arrays["sd." + k] = t2n(v)
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            arrays["g." + k] = t2n(v.grad)
+    save(name, **arrays)
+
+
 def gen_formats():
     """N4: the reference's own readers / writers (GAT/preprocess.py, GAT/main.py save_embed) on tiny synthetic files."""
     import tempfile, json as _json, importlib
@@ -471,6 +514,9 @@ def gen_gpgnn():
     # PROP-1/2: block adjacency + 3-hop propagation, shared h0 (GPGNN form) and per-batch h0 (RECON form)
     gpgnn_full_case("gpgnn1_untied", ref_models, "untie")
     gpgnn_full_case("gpgnn2_tied_n9", ref_models, "tie", n=9, d=1, L=2)
+    recon_eac_case("eac1_untied", ref_models)
+    if os.environ.get("RECON_GOLDEN_ONLY") == "eac":
+        return
     gpgnn_case("prop_n4d2_shared", ref_models, 4, 2, per_batch_h0=False, salt=1)
     gpgnn_case("prop_n4d2_perbatch", ref_models, 4, 2, per_batch_h0=True, salt=2)
     gpgnn_case("prop_n9d8_shared", ref_models, 9, 8, per_batch_h0=False, salt=3)      # model_params.json sizes
@@ -515,6 +561,11 @@ def gen_gpgnn():
 
 if __name__ == "__main__" and os.environ.get("RECON_GOLDEN_ONLY") == "formats":
     gen_formats()
+    sys.exit(0)
+
+if __name__ == "__main__" and os.environ.get("RECON_GOLDEN_ONLY") == "eac":
+    _install_shims()
+    gen_gpgnn()
     sys.exit(0)
 
 if __name__ == "__main__" and os.environ.get("RECON_GOLDEN_ONLY") == "sampler":

@@ -201,6 +201,33 @@ def test_gpgnn_state_dict_matches_reference(name):
     assert set(missing) == regenerated and not unexpected
 
 
+EAC_P = {"max_num_nodes": 3, "embedding_dim": 2, "layer_number": 3, "projection_style": "untie", "non-linear1": "relu",
+         "non-linear": "tanh", "dropout1": 0.0, "position_emb": 3, "units1": 4, "rnn1_layers": 1, "bidirectional": 1, "batch_size": 4,
+         "char_embed_dim": 3, "hidden_dim_ent": 3, "num_entEmb_layers": 1, "is_bidirectional_ent": 1, "drop_out_rate_ent": 0.0,
+         "entity_embed_dim": 2, "conv_filter_size": 2, "entity_conv_filter_size": 2, "max_char_len": 4, "char_feature_size": 3}
+
+
+def test_recon_eac_state_dict_matches_reference():
+    """the reference RECON_EAC's checkpoint keys and shapes (fixture written by running its constructor), and
+    its entity-context encoder — stock ops, so it runs here — against the reference's entity vectors (the numerical check of
+    the whole model is the GPU test)."""
+    from recon_amd.gpgnn import RECON_EAC
+    g = load_golden("eac1_untied")
+    m = RECON_EAC(dict(EAC_P), g["emb"], max_sent_len=4, n_out=3, char_vocab=list(range(int(g["n_chars"]))))
+    ref = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    sd = m.state_dict()
+    regenerated = {"head_indices", "tail_indices", "start_embedding"}
+    assert set(sd.keys()) - regenerated == set(ref.keys())
+    for k, v in ref.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    assert tuple(sd["head_indices"].shape) == (EAC_P["batch_size"], 6, 4)          # bs = p['batch_size'], models/models.py:338-342
+    missing, unexpected = m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ref.items()}, strict=False)
+    assert set(missing) == regenerated and not unexpected
+    assert m.entity_embedding_module.word_embeddings is m.word_embedding           # one table, two keys
+    ent = m.eval().entity_embedding_module(torch.from_numpy(g["ctx_words"]), torch.from_numpy(g["ctx_chars"]), torch.from_numpy(g["ctx_mask"]))
+    np.testing.assert_allclose(ent.detach().numpy(), g["ent"], atol=1e-6)
+
+
 def test_on_disk_formats_match_reference_readers(tmp_path):
     """id maps, triple files, embedding text files parsed exactly like GAT/preprocess.py does (fixture:
     the reference's own functions on tiny synthetic files), and the final_*_embeddings.json / W_ent2rel round trips."""

@@ -228,6 +228,28 @@ def test_gpgnn_model_golden(name):
             close(v.grad, g["g." + k], atol=1e-4, rel_to_max=1e-4, what="grad " + k)
 
 
+def test_recon_eac_model_golden():
+    """SURVEY 8f N3, second model: the reference RECON_EAC end to end — entity-context encoder (stock ops), per-batch start
+    embeddings, block adjacency and propagation (HIP) — logits and every parameter gradient, including those that reach the
+    context encoder only through the start-embedding kernel's backward."""
+    from recon_amd.gpgnn import RECON_EAC
+    from tests.test_host_cpu import EAC_P
+    g = load_golden("eac1_untied")
+    m = RECON_EAC(dict(EAC_P), g["emb"], max_sent_len=4, n_out=3, char_vocab=list(range(int(g["n_chars"]))))
+    m.load_state_dict({k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("sd.")}, strict=False)
+    m.train().to(dev())
+    t = lambda k: torch.from_numpy(g[k]).to(dev())
+    out = m(t("sent"), t("mark"), None, None, None, t("ctx_words"), t("ctx_chars"), t("ctx_mask"), t("pos"), int(g["max_occ"]))
+    close(out, g["out"], atol=1e-4, what="recon_eac logits")
+    (out * t("G")).sum().backward()
+    seen = 0
+    for k, v in m.named_parameters():
+        if "g." + k in g:
+            close(v.grad, g["g." + k], atol=1e-4, rel_to_max=1e-4, what="grad " + k)
+            seen += 1
+    assert seen == sum(k.startswith("g.") for k in g)
+
+
 # ------------------------------------------------------------------------------- GraphConvolution in bfloat16 (configs[2])
 def _bf(t):
     return t.to(torch.bfloat16)
