@@ -33,8 +33,8 @@ MFMA_BF16_PEAK = 2.5e15    # FLOP/s, dense bf16 / f16 MFMA (the split-precision 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--graphs", type=int, default=512, help="graphs per GPU")
     ap.add_argument("--nodes", type=int, default=16)
     ap.add_argument("--edges", type=int, default=64, help="edges per graph")

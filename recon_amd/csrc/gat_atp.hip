@@ -321,62 +321,81 @@ struct AtpFwdK {
     float* V; float* sigma; float* Z; float* Zk;
     int32_t N, E, F, R, H;
     float alpha;
-    int32_t planes;             // 1: V is written as half terms [H][N][2][W] of s_V * V (gemm_hx2.hip: high row | low row) instead of fp32 [N][H][W]
+    int32_t planes;             // 1 (2: with paired 16-byte stores, F % 8 == 0 and R % 8 == 0): V is written as half terms [H][N][2][W] of s_V * V (gemm_hx2.hip: high row | low row) instead of fp32 [N][H][W]
     Hx2Scale vs;                // s_V from max(|x|, |edge_embed|) * keep_max, an upper bound of |V| (V rows are k-weighted means)
 };
 
-// two half planes of VEC consecutive scaled values: 2 * VEC bytes per plane
+// two half planes of VEC consecutive ALREADY SCALED values: 2 * VEC bytes per plane.  Values are clamped to half's range: the
+// scale comes from a bound, not from V itself — max(|x|, |edge_embed|) bounds V exactly without dropout (rows of V are means),
+// with dropout the caller's keep_max enters; one v_med3 per value guards against a wrong one.
+__device__ __forceinline__ float hx2_clamp(float c) { return __builtin_amdgcn_fmed3f(c, -65504.f, 65504.f); }
 template <int VEC>
-__device__ __forceinline__ void store_planes(_Float16* hi_p, int64_t plane, const float (&o)[VEC], float s, bool clamp) {
-    float c[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) c[v] = o[v] * s;
-    if (clamp) {                // uniform.  The scale comes from a bound, not from V itself: max(|x|, |edge_embed|) bounds V exactly without
-#pragma unroll                  // dropout (rows of V are means), with dropout the caller's keep_max enters — guard against a wrong one
-        for (int v = 0; v < VEC; ++v) c[v] = fminf(fmaxf(c[v], -65504.f), 65504.f);
-    }
+__device__ __forceinline__ void store_planes(_Float16* hi_p, int64_t plane, const float (&c)[VEC]) {
     if constexpr (VEC == 4) {
         uint32_t hi[2], lo[2];
-        hx2_split2(c[0], c[1], hi[0], lo[0]);
-        hx2_split2(c[2], c[3], hi[1], lo[1]);
+        hx2_split2(hx2_clamp(c[0]), hx2_clamp(c[1]), hi[0], lo[0]);
+        hx2_split2(hx2_clamp(c[2]), hx2_clamp(c[3]), hi[1], lo[1]);
         *reinterpret_cast<uint2*>(hi_p) = make_uint2(hi[0], hi[1]);
         *reinterpret_cast<uint2*>(hi_p + plane) = make_uint2(lo[0], lo[1]);
     } else {
         static_assert(VEC == 2, "vector width");
         uint32_t hi, lo;
-        hx2_split2(c[0], c[1], hi, lo);
+        hx2_split2(hx2_clamp(c[0]), hx2_clamp(c[1]), hi, lo);
         *reinterpret_cast<uint32_t*>(hi_p) = hi;
         *reinterpret_cast<uint32_t*>(hi_p + plane) = lo;
     }
 }
 
+// The same for VEC = 4 with 16-byte stores: lanes 2i and 2i+1 hold columns 8i .. 8i+7 between them; they swap halves (DPP
+// quad_perm [1,0,3,2]) so that the even lane writes the 8 high terms into the high row and the odd lane the 8 low terms into
+// the low row — one dwordx4 store instruction where store_planes issues two dwordx2.  Requires both lanes of a pair active
+// together and 16-byte aligned parts: F % 8 == 0, R % 8 == 0.
+__device__ __forceinline__ void store_planes_paired(_Float16* hi_p, int64_t plane, const float (&c)[4], bool odd) {
+    uint32_t hi[2], lo[2];
+    hx2_split2(hx2_clamp(c[0]), hx2_clamp(c[1]), hi[0], lo[0]);
+    hx2_split2(hx2_clamp(c[2]), hx2_clamp(c[3]), hi[1], lo[1]);
+    constexpr int kSwapPairs = 0xB1;                                  // quad_perm [1,0,3,2]
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t phi = __builtin_amdgcn_mov_dpp(hi[j], kSwapPairs, 0xf, 0xf, true);      // the partner's terms
+        const uint32_t plo = __builtin_amdgcn_mov_dpp(lo[j], kSwapPairs, 0xf, 0xf, true);
+        w[j] = odd ? plo : hi[j];                                     // even: own high terms (columns 8i..8i+3) | odd: partner's low terms
+        w[2 + j] = odd ? lo[j] : phi;                                 // even: partner's high terms (8i+4..8i+7) | odd: own low terms
+    }
+    _Float16* dst = odd ? hi_p + plane - 4 : hi_p;                    // odd lane's own columns start at 8i+4
+    *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // wave = one destination node, HT heads (blockIdx.y selects the head group); lanes span the feature
 // dimension: lane l owns columns (r*64 + l)*VEC .. +VEC of both the x row (F) and the relation row (R).
-template <int VEC, int KR, int HT, bool TRAIN>
+// PL: 0 = V as fp32 [N][H][W]; 1 = half-term rows [H][N][2][W] (gemm_hx2.hip), 8-byte stores; 2 = the same through paired 16-byte stores
+// A wave can walk kK1NodesPerWave nodes (4 i + wave of its block's 4 * kK1NodesPerWave consecutive ones) with everything of node
+// i+1 that does not depend on its edges — row pointers, the index vectors of its first 64 slots, its own row, its score term —
+// requested while node i is being worked on.  Measured at cfg 2 with s_memtime stamps in the kernel (1.9 GHz under load): a wave
+// lives 23.4 k cycles per node = 5.1 k until its index vectors are there (two dependent round trips), 9.2 k in the edge walk,
+// 7.6 k converting and issuing its 24 stores, 0.9 k until they are acknowledged.  Taking the first 5.1 k off the chain (2 nodes per
+// wave, one round of 4 096 waves) did NOT shorten the kernel: 38 us against 36 — what the kernel waits for is the memory system
+// under 160 MB of writes, not its own chain (same for 4 rows in flight instead of 2, for 4 or 2 heads per wave, for 8- or 16-byte
+// stores: 35.5 - 41 us).  Kept at 1.
+constexpr int kK1NodesPerWave = 1;
+template <int VEC, int KR, int HT, bool TRAIN, int PL>
 __global__ void __launch_bounds__(kBlock) k_gat_atp_fwd(const AtpFwdK p) {
+    // edges in flight per wave: their rows are requested together, so a node of degree <= UNR costs ONE row round trip
     constexpr int UNR = (KR * HT >= 16) ? 1 : 2;
+    constexpr int NPW = kK1NodesPerWave;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int node = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + wave;
-    if (node >= p.N) return;
+    const int first = xcd_block(blockIdx.x, gridDim.x) * ((kBlock / 64) * NPW) + wave;
+    if (first >= p.N) return;
     const int F = p.F, R = p.R, H = p.H, W = 2 * F + R;
-    const float vscale = p.planes ? hx2_scale_wave(p.vs) : 1.f;       // one vector load + butterfly, in flight under the edge walk
     const int h0 = blockIdx.y * HT;
     const int myh = h0 + (lane % HT);
     const bool hv = myh < H;
+    const int myhc = hv ? myh : h0;
     int cf[KR]; bool aF[KR], aR[KR];
 #pragma unroll
     for (int r = 0; r < KR; ++r) { cf[r] = (r * 64 + lane) * VEC; aF[r] = cf[r] < F; aR[r] = cf[r] < R; }
-    const float cd = hv ? p.c_node[static_cast<int64_t>(node) * 2 * H + myh] : 0.f;
-    const int beg = p.rowptr[node], end = p.rowptr[node + 1];
-    float accS[HT][KR][VEC], accR[HT][KR][VEC];
-#pragma unroll
-    for (int h = 0; h < HT; ++h)
-#pragma unroll
-        for (int r = 0; r < KR; ++r)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) { accS[h][r][v] = 0.f; accR[h][r][v] = 0.f; }
-    float Zl = 0.f, Zkl = 0.f;
     // Loads are branch free: a guarded load gets its own basic block and the value join makes the compiler wait for each
     // load on its own, so the row of x[src] and the row of r_e (and the score terms) would arrive one round trip after
     // the other.  Slots past the row re-read its last slot (weight forced to 0), lanes past F / R read column 0 (their
@@ -384,89 +403,137 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_fwd(const AtpFwdK p) {
     int cfF[KR], cfR[KR];
 #pragma unroll
     for (int r = 0; r < KR; ++r) { cfF[r] = aF[r] ? cf[r] : 0; cfR[r] = aR[r] ? cf[r] : 0; }
-    const int myhc = hv ? myh : h0;
-    for (int k0 = beg; k0 < end; k0 += UNR) {
-        float xs[UNR][KR][VEC], re[UNR][KR][VEC], sc[UNR], kf[UNR];
+    // The walk is a chain of dependent round trips (row pointers -> slot indices -> rows): the slot -> (source node, edge id)
+    // indices of up to 64 slots come with ONE coalesced load per array (lane j holds slot beg + j) and are handed out with
+    // v_readlane.
+    int begs[NPW], ends[NPW];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int k = min(k0 + u, end - 1);
-            const int s = p.src[k], e = p.eid[k];
-            const float* xr = p.x + static_cast<int64_t>(s) * F;
-            const float* rr = p.ee + static_cast<int64_t>(e) * R;
-#pragma unroll
-            for (int r = 0; r < KR; ++r) {
-                load_vec<VEC>(xs[u][r], xr + cfF[r]);
-                load_vec<VEC>(re[u][r], rr + cfR[r]);
-            }
-            sc[u] = cd + p.c_node[static_cast<int64_t>(s) * 2 * H + H + myhc] + p.c_rel[static_cast<int64_t>(k) * H + myhc];
-            kf[u] = p.keep ? p.keep[static_cast<int64_t>(k) * H + myhc] : 1.f;
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int k = k0 + u;
-            if (k < end) {                                              // wave-uniform
-                const float sg = sc[u];
-                const float w = hv ? expf(-(sg > 0.f ? sg : p.alpha * sg)) : 0.f;
-                const float kw = kf[u] * w;
-                Zl += w;
-                Zkl += kw;
-                if constexpr (TRAIN) { if (hv && lane < HT) p.sigma[static_cast<int64_t>(k) * H + myh] = sg; }
-#pragma unroll
-                for (int h = 0; h < HT; ++h) {
-                    const float kwh = lane_bcast(kw, h);
-#pragma unroll
-                    for (int r = 0; r < KR; ++r)
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) {
-                            accS[h][r][v] = fmaf(kwh, xs[u][r][v], accS[h][r][v]);
-                            accR[h][r][v] = fmaf(kwh, re[u][r][v], accR[h][r][v]);
-                        }
-                }
-            }
-        }
+    for (int i = 0; i < NPW; ++i) {
+        const int nd = min(first + (kBlock / 64) * i, p.N - 1);
+        begs[i] = p.rowptr[nd]; ends[i] = p.rowptr[nd + 1];
     }
-    const float Zc = (Zl == 0.f) ? 1e-12f : Zl;                         // GAT/layers.py:152
-    const float inv = 1.f / Zc;
-    if constexpr (TRAIN) {
-        if (hv && lane < HT) { p.Z[static_cast<int64_t>(node) * H + myh] = Zc; p.Zk[static_cast<int64_t>(node) * H + myh] = Zkl; }
-    }
-    float xi[KR][VEC];
+    struct NodeIn { int srcv, eidv; float cd; float xi[KR][VEC]; };
+    auto request = [&](NodeIn& q, int node, int beg, int end) {         // node < N
+        q.srcv = 0; q.eidv = 0;
+        if (beg < end) { const int kk = beg + min(lane, min(64, end - beg) - 1); q.srcv = p.src[kk]; q.eidv = p.eid[kk]; }
+        q.cd = p.c_node[static_cast<int64_t>(node) * 2 * H + myhc];
 #pragma unroll
-    for (int r = 0; r < KR; ++r) {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) xi[r][v] = 0.f;
-        if (aF[r]) load_vec<VEC>(xi[r], p.x + static_cast<int64_t>(node) * F + cf[r]);
-    }
+        for (int r = 0; r < KR; ++r) load_vec<VEC>(q.xi[r], p.x + static_cast<int64_t>(node) * F + cfF[r]);
+    };
+    NodeIn cur, nxt;
+    request(cur, first, begs[0], ends[0]);
+    const float vscale = PL ? hx2_scale_wave(p.vs) : 1.f;             // one vector load + butterfly, in flight under the edge walk
+    const bool odd = lane & 1;
     const int64_t vplane = W;
 #pragma unroll
-    for (int h = 0; h < HT; ++h) {
-        if (h0 + h < H) {
-            const float invh = lane_bcast(inv, h);
-            const float zk = lane_bcast(Zkl, h) * invh;
-            const int64_t vrow = (static_cast<int64_t>(node) * H + h0 + h) * W;
-            float* Vr = p.V + vrow;
-            // half terms: HEAD-major [H][N][2][W] — a (node, head) still writes one contiguous 4 W-byte piece (high row | low
-            // row), and the 128 rows a GEMM workgroup reads for one head are one compact 128 x 4 W-byte region instead of
-            // 64-byte pieces strewn over H x 4 W-byte strides
-            _Float16* Vh = reinterpret_cast<_Float16*>(p.V) + 2 * (static_cast<int64_t>(h0 + h) * p.N + node) * W;
+    for (int i = 0; i < NPW; ++i) {
+        const int node = first + (kBlock / 64) * i;
+        if (node >= p.N) break;                                          // wave-uniform
+        const int beg = begs[i], end = ends[i];
+        if (i + 1 < NPW && node + (kBlock / 64) < p.N) request(nxt, node + (kBlock / 64), begs[i + 1 < NPW ? i + 1 : i], ends[i + 1 < NPW ? i + 1 : i]);
+        int cn = min(64, end - beg);
+        int srcv = cur.srcv, eidv = cur.eidv;
+        const float cd = hv ? cur.cd : 0.f;
+        float accS[HT][KR][VEC], accR[HT][KR][VEC];
 #pragma unroll
-            for (int r = 0; r < KR; ++r) {
-                float o[VEC];
-                if (aF[r]) {
+        for (int h = 0; h < HT; ++h)
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) o[v] = xi[r][v] * zk;
-                    if (p.planes) store_planes<VEC>(Vh + cf[r], vplane, o, vscale, p.keep != nullptr); else store_vec<VEC>(Vr + cf[r], o);
+            for (int r = 0; r < KR; ++r)
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) o[v] = accS[h][r][v] * invh;
-                    if (p.planes) store_planes<VEC>(Vh + F + cf[r], vplane, o, vscale, p.keep != nullptr); else store_vec<VEC>(Vr + F + cf[r], o);
+                for (int v = 0; v < VEC; ++v) { accS[h][r][v] = 0.f; accR[h][r][v] = 0.f; }
+        float Zl = 0.f, Zkl = 0.f;
+        for (int c0 = beg; c0 < end; c0 += 64) {
+            if (c0 > beg) {                                              // next chunk of a long row: new index vectors
+                cn = min(64, end - c0);
+                const int kk = c0 + min(lane, cn - 1);
+                srcv = p.src[kk]; eidv = p.eid[kk];
+            }
+            for (int j0 = 0; j0 < cn; j0 += UNR) {
+                float xs[UNR][KR][VEC], re[UNR][KR][VEC], sc[UNR], kf[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int j = min(j0 + u, cn - 1);
+                    const int64_t k = c0 + j;
+                    const int s = __builtin_amdgcn_readlane(srcv, j), e = __builtin_amdgcn_readlane(eidv, j);
+                    const float* xr = p.x + static_cast<int64_t>(s) * F;
+                    const float* rr = p.ee + static_cast<int64_t>(e) * R;
+#pragma unroll
+                    for (int r = 0; r < KR; ++r) {
+                        load_vec<VEC>(xs[u][r], xr + cfF[r]);
+                        load_vec<VEC>(re[u][r], rr + cfR[r]);
+                    }
+                    sc[u] = cd + p.c_node[static_cast<int64_t>(s) * 2 * H + H + myhc] + p.c_rel[k * H + myhc];
+                    kf[u] = p.keep ? p.keep[k * H + myhc] : 1.f;
                 }
-                if (aR[r]) {
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) o[v] = accR[h][r][v] * invh;
-                    if (p.planes) store_planes<VEC>(Vh + 2 * F + cf[r], vplane, o, vscale, p.keep != nullptr); else store_vec<VEC>(Vr + 2 * F + cf[r], o);
+                for (int u = 0; u < UNR; ++u) {
+                    if (j0 + u < cn) {                                      // wave-uniform
+                        const int64_t k = c0 + j0 + u;
+                        const float sg = sc[u];
+                        const float w = hv ? expf(-(sg > 0.f ? sg : p.alpha * sg)) : 0.f;
+                        const float kw = kf[u] * w;
+                        Zl += w;
+                        Zkl += kw;
+                        if constexpr (TRAIN) { if (hv && lane < HT) p.sigma[k * H + myh] = sg; }
+#pragma unroll
+                        for (int h = 0; h < HT; ++h) {
+                            const float kwh = lane_bcast(kw, h);
+#pragma unroll
+                            for (int r = 0; r < KR; ++r)
+#pragma unroll
+                                for (int v = 0; v < VEC; ++v) {
+                                    accS[h][r][v] = fmaf(kwh, xs[u][r][v], accS[h][r][v]);
+                                    accR[h][r][v] = fmaf(kwh, re[u][r][v], accR[h][r][v]);
+                                }
+                        }
+                    }
                 }
             }
         }
+        const float Zc = (Zl == 0.f) ? 1e-12f : Zl;                     // GAT/layers.py:152
+        const float inv = 1.f / Zc;
+        if constexpr (TRAIN) {
+            if (hv && lane < HT) { p.Z[static_cast<int64_t>(node) * H + myh] = Zc; p.Zk[static_cast<int64_t>(node) * H + myh] = Zkl; }
+        }
+        // Every load has landed by now on every path; say so.  Without it the compiler meets "a load may still be in flight" at the
+        // join behind each head's (uniform) guard below and drains the counter there — vmcnt counts stores too, so every head would
+        // wait for the previous head's stores to COMPLETE.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0), nothing else
+        auto put = [&](float* Vr, _Float16* Vh, int col, const float (&o)[VEC]) {
+            if constexpr (PL == 0) store_vec<VEC>(Vr + col, o);
+            else if constexpr (PL == 2 && VEC == 4) store_planes_paired(Vh + col, vplane, o, odd);
+            else store_planes<VEC>(Vh + col, vplane, o);
+        };
+#pragma unroll
+        for (int h = 0; h < HT; ++h) {
+            if (h0 + h < H) {
+                const float invh = lane_bcast(inv, h) * vscale;           // the operand scale rides on the normalisation
+                const float zk = lane_bcast(Zkl, h) * invh;
+                float* Vr = p.V + (static_cast<int64_t>(node) * H + h0 + h) * W;
+                // half terms: HEAD-major [H][N][2][W] — a (node, head) still writes one contiguous 4 W-byte piece (high row | low
+                // row), and the 128 rows a GEMM workgroup reads for one head are one compact 128 x 4 W-byte region instead of
+                // 64-byte pieces strewn over H x 4 W-byte strides
+                _Float16* Vh = reinterpret_cast<_Float16*>(p.V) + 2 * (static_cast<int64_t>(h0 + h) * p.N + node) * W;
+#pragma unroll
+                for (int r = 0; r < KR; ++r) {
+                    float o[VEC];
+                    if (aF[r]) {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) o[v] = cur.xi[r][v] * zk;
+                        put(Vr, Vh, cf[r], o);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) o[v] = accS[h][r][v] * invh;
+                        put(Vr, Vh, F + cf[r], o);
+                    }
+                    if (aR[r]) {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) o[v] = accR[h][r][v] * invh;
+                        put(Vr, Vh, 2 * F + cf[r], o);
+                    }
+                }
+            }
+        }
+        cur = nxt;
     }
 }
 
@@ -1047,13 +1114,17 @@ extern "C" int recon_gat_atp_aggregate(const recon_graph* g, const recon_gat_atp
     p.x = a->x; p.ee = a->edge_embed; p.c_node = a->c_node; p.c_rel = a->c_rel; p.keep = a->keep;
     p.V = a->V; p.sigma = a->sigma; p.Z = a->Z; p.Zk = a->Zk;
     p.N = a->N; p.E = a->E; p.F = a->F; p.R = a->R; p.H = a->H; p.alpha = a->alpha;
-    p.planes = atp_hx2(a) ? 1 : 0;
+    p.planes = atp_hx2(a) ? ((a->F % 8 == 0 && a->R % 8 == 0) ? 2 : 1) : 0;
     p.vs = p.planes ? atp_scale_v(a) : Hx2Scale{nullptr, nullptr, 1.f};
-    dim3 grid(static_cast<unsigned>(ceil_div64(a->N, kBlock / 64)), static_cast<unsigned>(ceil_div64(a->H, s.ht)));
+    dim3 grid(static_cast<unsigned>(ceil_div64(a->N, (kBlock / 64) * kK1NodesPerWave)), static_cast<unsigned>(ceil_div64(a->H, s.ht)));
 #define CALL_FWD(V_, K_, H_)                                                                                   \
     do {                                                                                                       \
-        if (train) hipLaunchKernelGGL((k_gat_atp_fwd<V_, K_, H_, true>), grid, dim3(kBlock), 0, st, p);        \
-        else hipLaunchKernelGGL((k_gat_atp_fwd<V_, K_, H_, false>), grid, dim3(kBlock), 0, st, p);             \
+        if (p.planes == 2 && V_ == 4) { if (train) hipLaunchKernelGGL((k_gat_atp_fwd<V_, K_, H_, true, 2>), grid, dim3(kBlock), 0, st, p);  \
+                            else hipLaunchKernelGGL((k_gat_atp_fwd<V_, K_, H_, false, 2>), grid, dim3(kBlock), 0, st, p); }     \
+        else if (p.planes) { if (train) hipLaunchKernelGGL((k_gat_atp_fwd<V_, K_, H_, true, 1>), grid, dim3(kBlock), 0, st, p);  \
+                            else hipLaunchKernelGGL((k_gat_atp_fwd<V_, K_, H_, false, 1>), grid, dim3(kBlock), 0, st, p); }     \
+        else { if (train) hipLaunchKernelGGL((k_gat_atp_fwd<V_, K_, H_, true, 0>), grid, dim3(kBlock), 0, st, p);               \
+               else hipLaunchKernelGGL((k_gat_atp_fwd<V_, K_, H_, false, 0>), grid, dim3(kBlock), 0, st, p); }                  \
     } while (0)
     ATP_DISPATCH(s, CALL_FWD);
 #undef CALL_FWD

@@ -188,6 +188,8 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_hx2(const Hx2Args p) {
 
     dma_b(0, 0);
     load_a(0);
+    // the operands' scales (32 amax slots each): read here, under the first tile's round trip, not in front of the stores
+    const float ia = hx2_inv(hx2_scale_wave(p.sa)), ib = hx2_inv(hx2_scale_wave(p.sb));
     take_a();
     __syncthreads();
     int buf = 0;
@@ -201,7 +203,6 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_hx2(const Hx2Args p) {
         __syncthreads();
         buf ^= 1;
     }
-    const float ia = hx2_inv(hx2_scale(p.sa)), ib = hx2_inv(hx2_scale(p.sb));
     hx2_store(acc, p.C, p.C.base + bz * p.c_bs, p.M, p.N, m0, n0, mb, li, lq, p.epilogue, p.c_vec4, ia, ib);
 }
 
@@ -339,6 +340,7 @@ __global__ void __launch_bounds__(NT, OCC) k_gemm_hx2_kmajor(const Hx2KmArgs p) 
     // ONE buffer per operand: the DMA of tile t+1 starts once every wave is done with tile t; the co-resident workgroups'
     // MFMA phases cover its flight
     if (k_begin < k_end) dma(k_begin);
+    const float ia = hx2_inv(hx2_scale_wave(p.sa)), ib = hx2_inv(hx2_scale_wave(p.sb));      // under the first tile's round trip
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -346,7 +348,6 @@ __global__ void __launch_bounds__(NT, OCC) k_gemm_hx2_kmajor(const Hx2KmArgs p) 
         __syncthreads();
         if (k0 + BK < k_end) dma(k0 + BK);
     }
-    const float ia = hx2_inv(hx2_scale(p.sa)), ib = hx2_inv(hx2_scale(p.sb));
     float* base = p.partial + static_cast<int64_t>(tile.z) * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
