@@ -431,6 +431,12 @@ def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=Tru
     original edge order or None; keep_max an upper bound of them (1/(1-p); read back from `keep` when omitted).
     Returns [N, H*D] (heads concatenated along dim 1)."""
     H, D = a_2.shape
+    if x.dtype in (torch.bfloat16, torch.float16):
+        # Reduced-precision STORAGE at the layer boundary (BASELINE.json configs[4]: "mixed GAT+Propagation stack, bf16"): features
+        # and edge embeddings arrive and leave in x.dtype; scores, softmax, aggregation and projections run the fp32 kernels (the
+        # reference's own arithmetic is fp32; its exp(-leakyrelu(.)) has no max subtraction and would overflow half precision).
+        out = gat_heads(x.float(), edge_embed_all.float(), a.float(), a_2.float(), graph, keep, alpha, concat, keep_max)
+        return out.to(x.dtype)
     if gat_path_for(graph.N, graph.E, x.shape[1], edge_embed_all.shape[1], D, H) == "atp":
         return _GATHeadsATPFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat, keep_max)
     return _GATHeadsFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat)

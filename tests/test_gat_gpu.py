@@ -479,6 +479,49 @@ def test_power_law_graphs(path, monkeypatch):
     close(xd.grad, gx, atol=1e-4, what="g_x")
 
 
+def test_cfg5_bf16_gat_then_gcn_stack():
+    """BASELINE.json configs[4] in its stated dtype: power-law graphs, an H-head GAT layer with bf16 features in and out (fp32
+    kernels inside), followed by a 3-layer bf16 GraphConvolution stack on the same node features, forward and backward.  Against
+    the fp32 oracle on the SAME bf16-rounded inputs: what remains is the rounding of each layer's result to bf16 (2^-8 relative)."""
+    from recon_amd import gat_layers
+    from recon_amd.graph import prepare_graph
+    from recon_amd.gcn_layers import GraphConvolution
+    d = dev()
+    edge, N = _power_law_batch(4, seed=3, max_n=128)
+    E = edge.shape[1]
+    F_, R, D, H = 32, 16, 16, 4
+    g = torch.Generator().manual_seed(0)
+    bf = lambda t: t.to(torch.bfloat16)
+    x = bf(torch.randn(N, F_, generator=g))
+    ee = bf(torch.randn(E, R, generator=g) * 0.5)
+    a = torch.stack([O.xavier_normal((D, 2 * F_ + R), 1.414, g) for _ in range(H)]) * 0.5
+    a2 = torch.cat([O.xavier_normal((1, D), 1.414, g) for _ in range(H)])
+    xd, eed = x.to(d).requires_grad_(True), ee.to(d).requires_grad_(True)
+    ad, a2d = a.to(d).requires_grad_(True), a2.to(d).requires_grad_(True)
+    h = gat_layers.gat_heads(xd, eed, ad, a2d, prepare_graph(edge.to(d), None, N), None, 0.2, True)
+    assert h.dtype == torch.bfloat16 and h.shape == (N, H * D)
+    refs = [O.gat_layer_forward(x.double(), edge, ee.double(), None, None, a[i].double(), a2[i:i + 1].double(), 0.2, True) for i in range(H)]
+    ref_h = torch.cat(refs, dim=1).float()
+    close(h.float(), ref_h, atol=2e-3, rel_to_max=1e-2, what="bf16 GAT heads")
+    # the same node features through three bf16 graph convolutions over a dense row-normalised adjacency of the batch
+    torch.manual_seed(2)
+    adj = torch.zeros(N, N)
+    adj[edge[0], edge[1]] = 1.0
+    adj += torch.eye(N)
+    adj = bf(adj / adj.sum(-1, keepdim=True))
+    layers = [GraphConvolution(H * D, H * D).to(torch.bfloat16).to(d) for _ in range(3)]
+    cur, ref = h, bf(ref_h).float()
+    for l in layers:
+        cur = l(cur, adj.to(d))
+        ref = bf(O.graph_convolution(ref, adj.float(), l.weight.detach().float().cpu(), l.bias.detach().float().cpu())).float()
+    assert cur.dtype == torch.bfloat16
+    close(cur.float(), ref, atol=5e-3, rel_to_max=5e-2, what="bf16 GAT + 3 x GCN")
+    cur.float().sum().backward()                                  # gradients reach every input of the mixed stack, in its dtype
+    assert xd.grad.dtype == torch.bfloat16 and eed.grad.dtype == torch.bfloat16 and ad.grad.dtype == torch.float32
+    for t in (xd.grad, eed.grad, ad.grad, a2d.grad, layers[0].weight.grad):
+        assert bool(torch.isfinite(t.float()).all()) and float(t.float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("name", ["spkbgat1_nhop", "spkbgat2_1hop"])
 def test_spkbgat_golden(name):
     """G7: the stage-A model (whole entity table, one entity batch of edges) vs the reference SpKBGATModified:
