@@ -180,7 +180,8 @@ typedef struct {
     void* aux;                  /* RECON_SPLIT_F16X2: recon_hx2_aux_bytes() bytes, 256-byte aligned, workspace *
                                  * / saved: max-magnitude slots of a, x, edge_embed, grad_out (the per-tensor   *
                                  * power-of-two scales derive from them) and a page of zeros; zeroed by the     *
-                                 * scores stage                                                                */
+                                 * scores stage; the backward publishes grad_out's slots and re-zeroes them     *
+                                 * in its last kernel, so it must be given the aux of the matching forward      */
 } recon_gat_atp_args;
 
 size_t recon_gat_atp_split_bytes(int32_t F, int32_t R, int32_t D, int32_t H);

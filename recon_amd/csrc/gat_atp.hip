@@ -33,7 +33,7 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 // 16 groups with 4 independent partial sums each: with 4 groups and one dependent chain the kernel was latency
 // bound (15 us for 3.8 MB).
 __global__ void __launch_bounds__(1024) k_score_vec(const float* __restrict__ a, const float* __restrict__ a2, int32_t D, int32_t W,
-                                                    float* __restrict__ u, uint32_t* __restrict__ amax_a) {
+                                                    float* __restrict__ u, uint32_t* __restrict__ aux) {
     __shared__ float red[16][64];
     const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int w = blockIdx.x * 64 + c, h = blockIdx.y;
@@ -58,7 +58,6 @@ __global__ void __launch_bounds__(1024) k_score_vec(const float* __restrict__ a,
             mx = fmaxf(mx, fabsf(v0));
         }
     }
-    if (amax_a) hx2_amax_commit(mx, amax_a);
     red[grp][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp == 0 && w < W) {
@@ -67,14 +66,41 @@ __global__ void __launch_bounds__(1024) k_score_vec(const float* __restrict__ a,
         for (int g = 0; g < 16; ++g) t += red[g][c];
         u[static_cast<int64_t>(h) * W + w] = t;
     }
+    if (aux) {
+        // First kernel of a forward pass in f16 x 2 mode.  (1) Its share of max |a| goes out as ONE plain store per block into
+        // a word of quantity 0 that no slot uses (hx2_blkmax_word) — k_hx2_split_both, which needs the scale first, gathers the
+        // words and writes the 32 slots the GEMMs read: nothing of quantity 0 has to be zero beforehand.  (2) Quantities 1..3 and
+        // the page of zeros, which later kernels fill by atomicMax / read as zeros, are cleared here: the fill launch this
+        // replaces cost 4.5 us per step.
+        __syncthreads();
+        red[grp][c] = mx;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float m = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) m = fmaxf(m, red[g][threadIdx.x]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            const int b = blockIdx.y * gridDim.x + blockIdx.x;
+            if (threadIdx.x == 0) aux[hx2_blkmax_word(b)] = __builtin_bit_cast(uint32_t, m);
+        }
+        const int nblk = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+        const int total = static_cast<int>(kHx2AuxBytes / 4) - kHx2QuantityWords;      // everything behind quantity 0
+        const int per_b = (total + nblk - 1) / nblk;
+        for (int i = b * per_b + threadIdx.x; i < min(total, (b + 1) * per_b); i += 1024) aux[kHx2QuantityWords + i] = 0u;
+    }
 }
 
 // backward of u = a_2^T a:   g_a[h][d][:] += a_2[h][d] * g_u[h][:] ;  g_a_2[h][d] = a[h][d][:] . g_u[h][:]
 __global__ void __launch_bounds__(256) k_score_vec_bwd(const float* __restrict__ a, const float* __restrict__ a2,
                                                        const float* __restrict__ gu, int32_t D, int32_t W, float* __restrict__ ga,
-                                                       float* __restrict__ ga2) {
+                                                       float* __restrict__ ga2, uint32_t* __restrict__ rezero, int32_t rezero_words) {
     __shared__ float red[256];
     const int d = blockIdx.x, h = blockIdx.y;
+    // last kernel of a backward pass: hand the max-magnitude slots of grad_out back zeroed, so that a second backward over the
+    // same saved state (retain_graph) publishes into clean slots
+    if (rezero && d == 0 && h == 0)
+        for (int i = threadIdx.x; i < rezero_words; i += 256) rezero[i] = 0u;
     const int64_t row = (static_cast<int64_t>(h) * D + d) * W;
     const float a2v = a2[h * D + d];
     float s = 0.f;
@@ -311,6 +337,75 @@ __global__ void __launch_bounds__(kBlock) k_row_dots(const RowDotsJob j0, const 
 #pragma unroll
         for (int b = 0; b < RB; ++b)
             if (lane < NJ && row0 + b < rows) out[static_cast<int64_t>(row0 + b) * NJ + lane] = mine[b];
+    }
+    if (jb.amax) hx2_amax_commit(mx, jb.amax);
+}
+
+// The same products on the fp32 matrix cores — out[16 rows][NJ <= 16] = X[16 x K] . U^T with v_mfma_f32_16x16x4_f32 (exact fp32
+// products, fp32 accumulation): the VALU form above spends a multi-value wave reduction per 8 dot products and runs at 2.5x its
+// traffic bound.  One wave per 16 rows; lane (i = lane & 15, q = lane >> 4) loads 16 bytes of row i per 16-k group (k = 16 g + 4 q ..
+// + 3: the MFMA's k slot q carries these four k in four steps — any assignment works as long as A and B agree), eight groups in
+// flight; U sits in LDS as [16][Kp], Kp = 4 mod 8 so that the 16 columns' 16-byte reads fall on disjoint banks.  K % 4 == 0.
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+__device__ __host__ inline int row_dots_kp(int K) { return (K % 8 == 0) ? K + 4 : K; }
+__global__ void __launch_bounds__(kBlock) k_row_dots_x(const RowDotsJob j0, const RowDotsJob j1, const float* __restrict__ u, int32_t H,
+                                                       int32_t W) {
+    extern __shared__ __attribute__((aligned(16))) float U[];     // [16][Kp], zero beyond NJ
+    const bool second = static_cast<int>(blockIdx.x) >= j0.nb;
+    const RowDotsJob& jb = second ? j1 : j0;
+    const float* __restrict__ X = jb.X;
+    const int32_t* __restrict__ gather = jb.gather;
+    float* __restrict__ out = jb.out;
+    const int rows = jb.rows, K = jb.K, F = jb.F, off = jb.off, NJ = jb.NJ, Kp = row_dots_kp(jb.K);
+    const int bid = second ? blockIdx.x - j0.nb : blockIdx.x, nblocks = jb.nb;
+    constexpr int GU = 16;                                               // K <= 256: the whole row in one batch of loads
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntiles = (rows + 15) / 16, G = (K + 15) / 16;
+    const float* Ui = U + i * Kp;
+    float mx = 0.f;
+    bool staged = false;
+    for (int tile = bid * (kBlock / 64) + wave; tile < ntiles || !staged; tile += nblocks * (kBlock / 64)) {
+        const bool live = tile < ntiles;                                  // a wave without a tile still takes part in the staging
+        const int row = min(tile * 16 + i, rows - 1);                    // rows past the end recompute the last row, not stored
+        const float* xr = X + static_cast<int64_t>(gather ? gather[row] : row) * K;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        for (int g0 = 0; g0 < G; g0 += GU) {
+            f32x4_t xv[GU];
+            int cc[GU];
+#pragma unroll
+            for (int t = 0; t < GU; ++t) {                                // branch free: groups past K re-read column 0 and are zeroed
+                const int c = 16 * (g0 + t) + 4 * q;
+                const bool ok = c < K;
+                cc[t] = ok ? c : 0;
+                xv[t] = *reinterpret_cast<const f32x4_t*>(xr + cc[t]);
+                if (!ok) xv[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+            if (!staged) {                                                // the score vectors arrive while the first rows are in flight
+                for (int idx = threadIdx.x; idx < 16 * Kp; idx += kBlock) {
+                    const int j = idx / Kp, k = idx - j * Kp;
+                    U[idx] = (j < NJ && k < K) ? u[static_cast<int64_t>(j % H) * W + (j / H) * F + off + k] : 0.f;
+                }
+                __syncthreads();
+                staged = true;
+            }
+#pragma unroll
+            for (int t = 0; t < GU; ++t) {
+                const f32x4_t uv = *reinterpret_cast<const f32x4_t*>(Ui + cc[t]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    mx = fmaxf(mx, fabsf(xv[t][e]));
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t][e], uv[e], acc, 0, 0, 0);
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                 // C layout: row 4 q + r, column i
+                const int ro = tile * 16 + 4 * q + r;
+                if (ro < rows && i < NJ) out[static_cast<int64_t>(ro) * NJ + i] = acc[r];
+            }
+        }
     }
     if (jb.amax) hx2_amax_commit(mx, jb.amax);
 }
@@ -913,6 +1008,9 @@ __global__ void __launch_bounds__(256) k_skinny_tn_partial(const SkinnyJob j0, c
         }
     }
 }
+// (A matrix-core form of these partial products — v_mfma_f32_16x16x4_f32 with the contraction over the rows, both H-column halves
+// of the node-side product in one pass over x — was measured at cfg 2: 17.7 - 18.9 us against 16.7 for this kernel.  Like the
+// score dots it is a few tens of MB behind a ~5 us kernel turn-around: the arithmetic is not what it waits for.)
 // out[(j % P)*S1 + (j / P)*S2 + c] = sum_b partial[b][j][c]   (16 elements x 64 slice groups per block, fixed order)
 struct SkinnyRedJob { const float* partial; float* out; int64_t S1, S2; int32_t nb, nj, K, P, nblocks; };
 __global__ void __launch_bounds__(1024) k_skinny_reduce(const SkinnyRedJob j0, const SkinnyRedJob j1, const SkinnyRedJob j2) {
@@ -1065,12 +1163,14 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
     hipStream_t st = as_stream(stream);
     const int32_t N = a->N, E = a->E, F = a->F, R = a->R, D = a->D, H = a->H, W = 2 * F + R;
     const bool hx2 = atp_hx2(a);
-    if (hx2 && hipMemsetAsync(a->aux, 0, kHx2AuxBytes, st) != hipSuccess) return RECON_ERR_LAUNCH;
+    const int nblk_a = static_cast<int>(ceil_div64(W, 64)) * H;
+    if (hx2 && nblk_a > kHx2BlkMaxWords) return RECON_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_score_vec, dim3(static_cast<unsigned>(ceil_div64(W, 64)), static_cast<unsigned>(H)), dim3(1024), 0, st, a->a,
                        a->a_2, D, W, a->u, hx2 ? atp_q(a, 0) : nullptr);
     if (hx2) {                                                    // half planes of s_a a and s_a a^T
         char* ws = static_cast<char*>(a->a_split);
-        rc = hx2_split_planes_both(a->a, static_cast<int64_t>(D) * W, D, W, H, ws, ws + split_part_bytes(D, W, H), atp_scale_a(a), st);
+        rc = hx2_split_planes_both(a->a, static_cast<int64_t>(D) * W, D, W, H, ws, ws + split_part_bytes(D, W, H), atp_scale_a(a), st,
+                                   atp_q(a, 0), nblk_a);
         if (rc != RECON_OK) return rc;
     } else if (a->a_split) {                                      // bf16 term planes of a and a^T for the split-precision GEMMs
         if (reinterpret_cast<uintptr_t>(a->a_split) & 15) return RECON_ERR_INVALID;
@@ -1094,7 +1194,14 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
         const size_t lds = lds_n > lds_e ? lds_n : lds_e;
         if (lds > 64 * 1024) return RECON_ERR_UNSUPPORTED;
         const dim3 grid(static_cast<unsigned>(jn.nb + je.nb));
-        if (s.vec == 4) hipLaunchKernelGGL((k_row_dots<4>), grid, dim3(kBlock), lds, st, jn, je, a->u, H, W);
+        const bool mfma = s.vec == 4 && 2 * H <= 16;
+        if (mfma) {                                                   // 16 rows per wave, 64 per block
+            jn.nb = static_cast<int>(ceil_div64(N, 64) < 4096 ? ceil_div64(N, 64) : 4096);
+            je.nb = E > 0 ? static_cast<int>(ceil_div64(E, 64) < 8192 ? ceil_div64(E, 64) : 8192) : 0;
+            const int kpm = row_dots_kp(F) > row_dots_kp(R) ? row_dots_kp(F) : row_dots_kp(R);
+            hipLaunchKernelGGL(k_row_dots_x, dim3(static_cast<unsigned>(jn.nb + je.nb)), dim3(kBlock), sizeof(float) * 16 * kpm, st, jn, je,
+                               a->u, H, W);
+        } else if (s.vec == 4) hipLaunchKernelGGL((k_row_dots<4>), grid, dim3(kBlock), lds, st, jn, je, a->u, H, W);
         else hipLaunchKernelGGL((k_row_dots<2>), grid, dim3(kBlock), lds, st, jn, je, a->u, H, W);
     }
     RECON_CHECK_LAUNCH();
@@ -1223,7 +1330,8 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
     uint16_t* ghp = gh_planes ? static_cast<uint16_t*>(b->gh_split) : nullptr;
     if (phases & RECON_ATP_BWD_PREPARE) {
         if (hx2) {                                                // max |grad_out| bounds |g_h| (|elu'| <= 1): the scale of the g_h planes
-            if (hipMemsetAsync(atp_q(a, 3), 0, sizeof(uint32_t) * kHx2QuantityWords, st) != hipSuccess) return RECON_ERR_LAUNCH;
+            // quantity 3 is zero here: the scores stage cleared all of aux, and a backward pass clears it again when it is done with it
+            // (k_score_vec_bwd) — a fill of its own cost 5 us per step
             rc = hx2_amax(b->grad_out, N, static_cast<int32_t>(HD), b->ld_gout, atp_q(a, 3), st);
             if (rc != RECON_OK) return rc;
         }
@@ -1370,8 +1478,10 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         // (6) through u = a_2^T a
         if (phases & RECON_ATP_BWD_FINISH)
         hipLaunchKernelGGL(k_score_vec_bwd, dim3(static_cast<unsigned>(D), static_cast<unsigned>(H)), dim3(256), 0, st, a->a, a->a_2, b->g_u,
-                           D, W, b->g_a, b->g_a_2);
+                           D, W, b->g_a, b->g_a_2, atp_hx2(a) ? atp_q(a, 3) : nullptr, kHx2QuantityWords);
         RECON_CHECK_LAUNCH();
+    } else if ((phases & RECON_ATP_BWD_FINISH) && atp_hx2(a)) {        // input gradients only: no last kernel to clear the slots in
+        if (hipMemsetAsync(atp_q(a, 3), 0, sizeof(uint32_t) * kHx2QuantityWords, st) != hipSuccess) return RECON_ERR_LAUNCH;
     }
     return RECON_OK;
 }

@@ -393,8 +393,18 @@ __global__ void __launch_bounds__(256) k_hx2_split_planes(const float* __restric
 // the transposed planes[q][b][c][r] (rows C, k = R).  The transposed half walks the source row-wise (consecutive threads =
 // consecutive c) so that its reads are coalesced; each thread gathers 8 rows of one column.
 __global__ void __launch_bounds__(256) k_hx2_split_both(const float* __restrict__ src, int64_t src_bs, int32_t R, int32_t C_, int32_t Cp, int32_t Rp,
-                                                        _Float16* __restrict__ dst_n, _Float16* __restrict__ dst_t, int32_t batch, const Hx2Scale sc) {
-    const float s = hx2_scale(sc);
+                                                        _Float16* __restrict__ dst_n, _Float16* __restrict__ dst_t, int32_t batch, const Hx2Scale sc,
+                                                        uint32_t* __restrict__ blkmax_quantity, int32_t nblk) {
+    // blkmax_quantity: the source's max magnitude arrives as nblk per-block words of that quantity (plain stores of the kernel in
+    // front) instead of in its 32 slots; this kernel gathers them, and its first block fills the slots for the readers behind it
+    float s;
+    if (blkmax_quantity) {
+        const uint32_t bits = hx2_blkmax_wave(blkmax_quantity, nblk);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < kHx2Slots) blkmax_quantity[threadIdx.x * kHx2SlotStride] = bits;
+        s = hx2_scale_of(__builtin_bit_cast(float, bits) * sc.mul);
+    } else {
+        s = hx2_scale(sc);
+    }
     const float* sp = src + blockIdx.y * src_bs;
     const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     float v[8];
@@ -495,14 +505,14 @@ int hx2_split_planes(const float* src, int64_t ld, int64_t src_bs, bool transpos
 
 // planes of src[b][R][C] (contiguous rows) and of its transpose in one launch: dst_n [2][batch][R][kp(C)], dst_t [2][batch][C][kp(R)]
 int hx2_split_planes_both(const float* src, int64_t src_bs, int32_t R, int32_t C_, int32_t batch, void* dst_n, void* dst_t, const Hx2Scale& sc,
-                          hipStream_t st) {
+                          hipStream_t st, uint32_t* blkmax_quantity, int32_t nblk) {
     if (R <= 0 || C_ <= 0 || batch <= 0) return RECON_OK;
     if (!src || !dst_n || !dst_t || ((reinterpret_cast<uintptr_t>(dst_n) | reinterpret_cast<uintptr_t>(dst_t)) & 15)) return RECON_ERR_INVALID;
     const int32_t Cp = hx2_kp(C_), Rp = hx2_kp(R);
     const int64_t n0 = static_cast<int64_t>(R) * (Cp / 8), n1 = static_cast<int64_t>(C_) * (Rp / 8);
     const dim3 grid(static_cast<unsigned>(ceil_div64(n0 > n1 ? n0 : n1, 256)), static_cast<unsigned>(batch), 2);
     hipLaunchKernelGGL(k_hx2_split_both, grid, dim3(256), 0, st, src, src_bs, R, C_, Cp, Rp, static_cast<_Float16*>(dst_n), static_cast<_Float16*>(dst_t),
-                       batch, sc);
+                       batch, sc, blkmax_quantity, nblk);
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
 }

@@ -101,6 +101,11 @@ constexpr int kHx2QuantityWords = kHx2Slots * kHx2SlotStride;            // 2048
 constexpr size_t kHx2AuxQuantities = 4;
 constexpr size_t kHx2ZeroPageOffset = kHx2AuxQuantities * kHx2QuantityWords * 4;       // byte offset of the 1 KiB page of zeros
 constexpr size_t kHx2AuxBytes = kHx2ZeroPageOffset + 1024;
+// Per-block maxima published by PLAIN stores (no zeroing needed): block b of the producer owns one word of its quantity that no
+// slot uses — word 1 + b / 32 behind slot b % 32; the consumer that needs the scale first gathers the words (hx2_blkmax_wave) and
+// one of its blocks writes all 32 slots for the kernels that read the quantity the usual way.
+constexpr int kHx2BlkMaxWords = kHx2Slots * (kHx2SlotStride - 1);
+__host__ __device__ inline int hx2_blkmax_word(int b) { return (b % kHx2Slots) * kHx2SlotStride + 1 + b / kHx2Slots; }
 struct Hx2Scale { const uint32_t* p0; const uint32_t* p1; float mul; };
 
 // s = 2^(14 - floor(log2 amax)): s * amax in [2^14, 2^15) — half overflows at 65504 = 2^16 - 32
@@ -133,6 +138,15 @@ __device__ __forceinline__ float hx2_scale_wave(const Hx2Scale& q) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(b, off, 64); b = o > b ? o : b; }
     return hx2_scale_of(__builtin_bit_cast(float, b) * q.mul);
+}
+// max over nblk block words of a quantity (all 64 lanes must call); returns the fp32 bit pattern
+__device__ __forceinline__ uint32_t hx2_blkmax_wave(const uint32_t* quantity, int nblk) {
+    const int lane = threadIdx.x & 63;
+    uint32_t b = 0;
+    for (int k = lane; k < nblk; k += 64) { const uint32_t v = quantity[hx2_blkmax_word(k)]; b = v > b ? v : b; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(b, off, 64); b = o > b ? o : b; }
+    return b;
 }
 // exact reciprocal of a power of two with exponent field in [1, 253]
 __device__ __forceinline__ float hx2_inv(float s) { return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(uint32_t, s)); }
@@ -232,7 +246,7 @@ int hx2_amax(const float* src, int64_t rows, int32_t cols, int64_t ld, uint32_t*
 int hx2_split_planes(const float* src, int64_t ld, int64_t src_bs, bool transposed, int32_t rows, int32_t K, int32_t batch, void* dst,
                      const Hx2Scale& sc, hipStream_t st);
 int hx2_split_planes_both(const float* src, int64_t src_bs, int32_t R, int32_t C_, int32_t batch, void* dst_n, void* dst_t, const Hx2Scale& sc,
-                          hipStream_t st);
+                          hipStream_t st, uint32_t* blkmax_quantity = nullptr, int32_t nblk = 0);
 bool hx2_supported(const void* Ap, int64_t a_plane, int64_t a_row, int64_t a_bs, int32_t K);
 int gemm_hx2_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t a_plane, int64_t a_row, int64_t a_bs, const void* Bplanes,
                      const OutputDesc& C, const GemmBatch& bt, const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st);
