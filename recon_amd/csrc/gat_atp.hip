@@ -348,16 +348,24 @@ __global__ void __launch_bounds__(kBlock) k_row_dots(const RowDotsJob j0, const 
 // flight; U sits in LDS as [16][Kp], Kp = 4 mod 8 so that the 16 columns' 16-byte reads fall on disjoint banks.  K % 4 == 0.
 using f32x4_t = __attribute__((ext_vector_type(4))) float;
 __device__ __host__ inline int row_dots_kp(int K) { return (K % 8 == 0) ? K + 4 : K; }
+// The last nsplit blocks write the half planes of a and a^T (hx2_split_both_block): that pass needs only what
+// the kernel in front of this one published, and as a launch of its own it cost 10 us of which 5 are kernel turn-around.
 __global__ void __launch_bounds__(kBlock) k_row_dots_x(const RowDotsJob j0, const RowDotsJob j1, const float* __restrict__ u, int32_t H,
-                                                       int32_t W) {
+                                                       int32_t W, const Hx2SplitBoth sp, int32_t nsplit) {
     extern __shared__ __attribute__((aligned(16))) float U[];     // [16][Kp], zero beyond NJ
-    const bool second = static_cast<int>(blockIdx.x) >= j0.nb;
+    if (static_cast<int>(blockIdx.x) >= j0.nb + j1.nb) {           // last in the grid (first: 24.6 us for the launch against 21.2)
+        const int lin = blockIdx.x - (j0.nb + j1.nb);
+        hx2_split_both_block(sp, lin % sp.gx, (lin / sp.gx) % sp.batch, lin / (sp.gx * sp.batch));
+        return;
+    }
+    const int bx = blockIdx.x;
+    const bool second = bx >= j0.nb;
     const RowDotsJob& jb = second ? j1 : j0;
     const float* __restrict__ X = jb.X;
     const int32_t* __restrict__ gather = jb.gather;
     float* __restrict__ out = jb.out;
     const int rows = jb.rows, K = jb.K, F = jb.F, off = jb.off, NJ = jb.NJ, Kp = row_dots_kp(jb.K);
-    const int bid = second ? blockIdx.x - j0.nb : blockIdx.x, nblocks = jb.nb;
+    const int bid = second ? bx - j0.nb : bx, nblocks = jb.nb;
     constexpr int GU = 16;                                               // K <= 256: the whole row in one batch of loads
     const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1167,11 +1175,19 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
     if (hx2 && nblk_a > kHx2BlkMaxWords) return RECON_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_score_vec, dim3(static_cast<unsigned>(ceil_div64(W, 64)), static_cast<unsigned>(H)), dim3(1024), 0, st, a->a,
                        a->a_2, D, W, a->u, hx2 ? atp_q(a, 0) : nullptr);
+    const bool dots_x = s.vec == 4 && 2 * H <= 16;                // score dots on the matrix cores (k_row_dots_x)
+    Hx2SplitBoth sp{};
+    int nsplit = 0;
     if (hx2) {                                                    // half planes of s_a a and s_a a^T
         char* ws = static_cast<char*>(a->a_split);
-        rc = hx2_split_planes_both(a->a, static_cast<int64_t>(D) * W, D, W, H, ws, ws + split_part_bytes(D, W, H), atp_scale_a(a), st,
-                                   atp_q(a, 0), nblk_a);
-        if (rc != RECON_OK) return rc;
+        if (!hx2_split_both_args(a->a, static_cast<int64_t>(D) * W, D, W, H, ws, ws + split_part_bytes(D, W, H), &sp)) return RECON_ERR_INVALID;
+        sp.sc = atp_scale_a(a); sp.blkmax_quantity = atp_q(a, 0); sp.nblk = nblk_a;
+        if (dots_x) nsplit = sp.gx * H * 2;                       // rides in the score dots' launch
+        else {
+            rc = hx2_split_planes_both(a->a, static_cast<int64_t>(D) * W, D, W, H, ws, ws + split_part_bytes(D, W, H), atp_scale_a(a), st,
+                                       atp_q(a, 0), nblk_a);
+            if (rc != RECON_OK) return rc;
+        }
     } else if (a->a_split) {                                      // bf16 term planes of a and a^T for the split-precision GEMMs
         if (reinterpret_cast<uintptr_t>(a->a_split) & 15) return RECON_ERR_INVALID;
         char* ws = static_cast<char*>(a->a_split);
@@ -1194,13 +1210,12 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
         const size_t lds = lds_n > lds_e ? lds_n : lds_e;
         if (lds > 64 * 1024) return RECON_ERR_UNSUPPORTED;
         const dim3 grid(static_cast<unsigned>(jn.nb + je.nb));
-        const bool mfma = s.vec == 4 && 2 * H <= 16;
-        if (mfma) {                                                   // 16 rows per wave, 64 per block
+        if (dots_x) {                                                 // 16 rows per wave, 64 per block
             jn.nb = static_cast<int>(ceil_div64(N, 64) < 4096 ? ceil_div64(N, 64) : 4096);
             je.nb = E > 0 ? static_cast<int>(ceil_div64(E, 64) < 8192 ? ceil_div64(E, 64) : 8192) : 0;
             const int kpm = row_dots_kp(F) > row_dots_kp(R) ? row_dots_kp(F) : row_dots_kp(R);
-            hipLaunchKernelGGL(k_row_dots_x, dim3(static_cast<unsigned>(jn.nb + je.nb)), dim3(kBlock), sizeof(float) * 16 * kpm, st, jn, je,
-                               a->u, H, W);
+            hipLaunchKernelGGL(k_row_dots_x, dim3(static_cast<unsigned>(jn.nb + je.nb + nsplit)), dim3(kBlock), sizeof(float) * 16 * kpm, st,
+                               jn, je, a->u, H, W, sp, nsplit);
         } else if (s.vec == 4) hipLaunchKernelGGL((k_row_dots<4>), grid, dim3(kBlock), lds, st, jn, je, a->u, H, W);
         else hipLaunchKernelGGL((k_row_dots<2>), grid, dim3(kBlock), lds, st, jn, je, a->u, H, W);
     }

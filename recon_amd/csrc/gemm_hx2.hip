@@ -388,49 +388,8 @@ __global__ void __launch_bounds__(256) k_hx2_split_planes(const float* __restric
     *reinterpret_cast<u32x4*>(d + plane) = u32x4{hi[0], hi[1], hi[2], hi[3]};
 }
 
-// Both orientations of ONE batched matrix src[b][R][C] in a single launch (the layer needs the planes of a AND of a^T, and
-// each launch of these few-MB kernels costs ~6 us): blockIdx.z = 0 writes planes[q][b][r][c] (rows R, k = C), blockIdx.z = 1
-// the transposed planes[q][b][c][r] (rows C, k = R).  The transposed half walks the source row-wise (consecutive threads =
-// consecutive c) so that its reads are coalesced; each thread gathers 8 rows of one column.
-__global__ void __launch_bounds__(256) k_hx2_split_both(const float* __restrict__ src, int64_t src_bs, int32_t R, int32_t C_, int32_t Cp, int32_t Rp,
-                                                        _Float16* __restrict__ dst_n, _Float16* __restrict__ dst_t, int32_t batch, const Hx2Scale sc,
-                                                        uint32_t* __restrict__ blkmax_quantity, int32_t nblk) {
-    // blkmax_quantity: the source's max magnitude arrives as nblk per-block words of that quantity (plain stores of the kernel in
-    // front) instead of in its 32 slots; this kernel gathers them, and its first block fills the slots for the readers behind it
-    float s;
-    if (blkmax_quantity) {
-        const uint32_t bits = hx2_blkmax_wave(blkmax_quantity, nblk);
-        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < kHx2Slots) blkmax_quantity[threadIdx.x * kHx2SlotStride] = bits;
-        s = hx2_scale_of(__builtin_bit_cast(float, bits) * sc.mul);
-    } else {
-        s = hx2_scale(sc);
-    }
-    const float* sp = src + blockIdx.y * src_bs;
-    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    float v[8];
-    _Float16* d;
-    int64_t plane;
-    if (blockIdx.z == 0) {
-        const int kq = static_cast<int>(idx % (Cp / 8)), r = static_cast<int>(idx / (Cp / 8));
-        if (r >= R) return;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const int k = 8 * kq + j; v[j] = k < C_ ? sp[static_cast<int64_t>(r) * C_ + k] : 0.f; }
-        plane = static_cast<int64_t>(batch) * R * Cp;
-        d = dst_n + (static_cast<int64_t>(blockIdx.y) * R + r) * Cp + 8 * kq;
-    } else {
-        const int c = static_cast<int>(idx % C_), kq = static_cast<int>(idx / C_);      // consecutive threads: consecutive source columns
-        if (kq >= Rp / 8) return;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const int k = 8 * kq + j; v[j] = k < R ? sp[static_cast<int64_t>(k) * C_ + c] : 0.f; }
-        plane = static_cast<int64_t>(batch) * C_ * Rp;
-        d = dst_t + (static_cast<int64_t>(blockIdx.y) * C_ + c) * Rp + 8 * kq;
-    }
-    uint32_t hi[4], lo[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) hx2_split2(v[2 * j] * s, v[2 * j + 1] * s, hi[j], lo[j]);
-    *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
-    *reinterpret_cast<u32x4*>(d + plane) = u32x4{lo[0], lo[1], lo[2], lo[3]};
-}
+// Both orientations of ONE batched matrix in a single launch: hx2_split_both_block (recon_common.h) per block
+__global__ void __launch_bounds__(256) k_hx2_split_both(const Hx2SplitBoth p) { hx2_split_both_block(p, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // *slot = max(*slot, max |src[r][c]|) as fp32 bit pattern (non-negative floats order like unsigned integers); the slot
 // must have been zeroed.  max is exact and order independent, so the atomics do not cost determinism.
@@ -504,15 +463,22 @@ int hx2_split_planes(const float* src, int64_t ld, int64_t src_bs, bool transpos
 }
 
 // planes of src[b][R][C] (contiguous rows) and of its transpose in one launch: dst_n [2][batch][R][kp(C)], dst_t [2][batch][C][kp(R)]
+bool hx2_split_both_args(const float* src, int64_t src_bs, int32_t R, int32_t C_, int32_t batch, void* dst_n, void* dst_t, Hx2SplitBoth* p) {
+    if (!src || !dst_n || !dst_t || ((reinterpret_cast<uintptr_t>(dst_n) | reinterpret_cast<uintptr_t>(dst_t)) & 15)) return false;
+    p->src = src; p->src_bs = src_bs; p->R = R; p->C = C_; p->Cp = hx2_kp(C_); p->Rp = hx2_kp(R); p->batch = batch;
+    const int64_t n0 = static_cast<int64_t>(R) * (p->Cp / 8), n1 = static_cast<int64_t>(C_) * (p->Rp / 8);
+    p->gx = static_cast<int32_t>(ceil_div64(n0 > n1 ? n0 : n1, 256));
+    p->dst_n = static_cast<_Float16*>(dst_n); p->dst_t = static_cast<_Float16*>(dst_t);
+    p->sc = Hx2Scale{nullptr, nullptr, 1.f}; p->blkmax_quantity = nullptr; p->nblk = 0;
+    return true;
+}
 int hx2_split_planes_both(const float* src, int64_t src_bs, int32_t R, int32_t C_, int32_t batch, void* dst_n, void* dst_t, const Hx2Scale& sc,
                           hipStream_t st, uint32_t* blkmax_quantity, int32_t nblk) {
     if (R <= 0 || C_ <= 0 || batch <= 0) return RECON_OK;
-    if (!src || !dst_n || !dst_t || ((reinterpret_cast<uintptr_t>(dst_n) | reinterpret_cast<uintptr_t>(dst_t)) & 15)) return RECON_ERR_INVALID;
-    const int32_t Cp = hx2_kp(C_), Rp = hx2_kp(R);
-    const int64_t n0 = static_cast<int64_t>(R) * (Cp / 8), n1 = static_cast<int64_t>(C_) * (Rp / 8);
-    const dim3 grid(static_cast<unsigned>(ceil_div64(n0 > n1 ? n0 : n1, 256)), static_cast<unsigned>(batch), 2);
-    hipLaunchKernelGGL(k_hx2_split_both, grid, dim3(256), 0, st, src, src_bs, R, C_, Cp, Rp, static_cast<_Float16*>(dst_n), static_cast<_Float16*>(dst_t),
-                       batch, sc, blkmax_quantity, nblk);
+    Hx2SplitBoth p;
+    if (!hx2_split_both_args(src, src_bs, R, C_, batch, dst_n, dst_t, &p)) return RECON_ERR_INVALID;
+    p.sc = sc; p.blkmax_quantity = blkmax_quantity; p.nblk = nblk;
+    hipLaunchKernelGGL(k_hx2_split_both, dim3(static_cast<unsigned>(p.gx), static_cast<unsigned>(batch), 2), dim3(256), 0, st, p);
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
 }

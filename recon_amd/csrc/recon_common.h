@@ -245,6 +245,56 @@ int32_t hx2_kp(int32_t K);
 int hx2_amax(const float* src, int64_t rows, int32_t cols, int64_t ld, uint32_t* slot, hipStream_t st);
 int hx2_split_planes(const float* src, int64_t ld, int64_t src_bs, bool transposed, int32_t rows, int32_t K, int32_t batch, void* dst,
                      const Hx2Scale& sc, hipStream_t st);
+// Both orientations of ONE batched matrix src[b][R][C] as half planes — planes[q][b][r][c] (rows R, k = C, zero padded to Cp) and the
+// transposed planes[q][b][c][r] (rows C, k = R, padded to Rp) — as the work of block (bx, by = batch entry, bz = orientation) of a
+// gx x batch x 2 grid of 256 threads.  A device function so that it can ride in another kernel's launch (k_row_dots_x): these
+// few-MB passes cost a kernel turn-around (~5 us) more than their traffic.  The transposed half walks the source row-wise
+// (consecutive threads = consecutive c) so that its reads are coalesced; each thread gathers 8 rows of one column.
+// blkmax_quantity: the source's max magnitude arrives as nblk per-block words of that quantity (plain stores of the kernel in
+// front, hx2_blkmax_word) instead of in its 32 slots; every wave gathers them, and block (0,0,0) fills the slots for later readers.
+struct Hx2SplitBoth {
+    const float* src; int64_t src_bs; int32_t R, C, Cp, Rp, batch, gx;
+    _Float16* dst_n; _Float16* dst_t; Hx2Scale sc; uint32_t* blkmax_quantity; int32_t nblk;
+};
+__device__ __forceinline__ void hx2_split_both_block(const Hx2SplitBoth& p, int bx, int by, int bz) {
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    float s;
+    if (p.blkmax_quantity) {
+        const uint32_t bits = hx2_blkmax_wave(p.blkmax_quantity, p.nblk);
+        if (bx == 0 && by == 0 && bz == 0 && threadIdx.x < kHx2Slots) p.blkmax_quantity[threadIdx.x * kHx2SlotStride] = bits;
+        s = hx2_scale_of(__builtin_bit_cast(float, bits) * p.sc.mul);
+    } else {
+        s = hx2_scale(p.sc);
+    }
+    const float* sp = p.src + by * p.src_bs;
+    const int64_t idx = static_cast<int64_t>(bx) * 256 + threadIdx.x;
+    const int R = p.R, C_ = p.C, Cp = p.Cp, Rp = p.Rp;
+    float v[8];
+    _Float16* d;
+    int64_t plane;
+    if (bz == 0) {
+        const int kq = static_cast<int>(idx % (Cp / 8)), r = static_cast<int>(idx / (Cp / 8));
+        if (r >= R) return;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int k = 8 * kq + j; v[j] = k < C_ ? sp[static_cast<int64_t>(r) * C_ + k] : 0.f; }
+        plane = static_cast<int64_t>(p.batch) * R * Cp;
+        d = p.dst_n + (static_cast<int64_t>(by) * R + r) * Cp + 8 * kq;
+    } else {
+        const int c = static_cast<int>(idx % C_), kq = static_cast<int>(idx / C_);      // consecutive threads: consecutive source columns
+        if (kq >= Rp / 8) return;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int k = 8 * kq + j; v[j] = k < R ? sp[static_cast<int64_t>(k) * C_ + c] : 0.f; }
+        plane = static_cast<int64_t>(p.batch) * C_ * Rp;
+        d = p.dst_t + (static_cast<int64_t>(by) * C_ + c) * Rp + 8 * kq;
+    }
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hx2_split2(v[2 * j] * s, v[2 * j + 1] * s, hi[j], lo[j]);
+    *reinterpret_cast<u32x4_t*>(d) = u32x4_t{hi[0], hi[1], hi[2], hi[3]};
+    *reinterpret_cast<u32x4_t*>(d + plane) = u32x4_t{lo[0], lo[1], lo[2], lo[3]};
+}
+// fills everything of `p` but the scale source; false when the arguments do not fit (alignment)
+bool hx2_split_both_args(const float* src, int64_t src_bs, int32_t R, int32_t C_, int32_t batch, void* dst_n, void* dst_t, Hx2SplitBoth* p);
 int hx2_split_planes_both(const float* src, int64_t src_bs, int32_t R, int32_t C_, int32_t batch, void* dst_n, void* dst_t, const Hx2Scale& sc,
                           hipStream_t st, uint32_t* blkmax_quantity = nullptr, int32_t nblk = 0);
 bool hx2_supported(const void* Ap, int64_t a_plane, int64_t a_row, int64_t a_bs, int32_t K);
