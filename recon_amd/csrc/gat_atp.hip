@@ -118,6 +118,66 @@ __global__ void __launch_bounds__(256) k_score_vec_bwd(const float* __restrict__
     if (threadIdx.x == 0 && ga2) ga2[h * D + d] = red[0];
 }
 
+// Last kernel of a backward pass in f16 x 2 mode: the fixed-order second pass of the split-K weight gradient
+// (partial[h][z][w][d] -> g_a[h][d][w], transposed through LDS) with the score path's a_2[h][d] * g_u[h][w] added on the way, and —
+// in the blocks behind the tiles — g_a_2[h][d] = a[h][d][:] . g_u[h][:], 8 rows per block.  As k_splitk_reduce_t + k_score_vec_bwd
+// this was two launches and a second read-modify-write pass over g_a.  W % 4 == 0.
+__global__ void __launch_bounds__(256) k_atp_weights_finish(const float* __restrict__ partial, int32_t splits, int32_t W, int32_t D, int32_t H,
+                                                            const float* __restrict__ a, const float* __restrict__ a2,
+                                                            const float* __restrict__ gu, float* __restrict__ ga, float* __restrict__ ga2,
+                                                            uint32_t* __restrict__ rezero, int32_t rezero_words) {
+    __shared__ float tile[32][33];
+    if (rezero && blockIdx.x == 0)                                       // see k_score_vec_bwd
+        for (int i = threadIdx.x; i < rezero_words; i += 256) rezero[i] = 0u;
+    const int tw = (W + 31) / 32, td = (D + 31) / 32, ntile = tw * td * H;
+    if (static_cast<int>(blockIdx.x) < ntile) {
+        const int b = blockIdx.x, h = b / (td * tw), m0 = ((b / td) % tw) * 32, n0 = (b % td) * 32;      // m = w, n = d
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        const int64_t MN = static_cast<int64_t>(W) * D;
+        const float* pz = partial + static_cast<int64_t>(h) * splits * MN;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int64_t off[4];
+        bool ok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + ty + 8 * i, n = n0 + tx;
+            ok[i] = m < W && n < D;
+            off[i] = ok[i] ? static_cast<int64_t>(m) * D + n : 0;
+        }
+        for (int z = 0; z < splits; ++z) {                              // split index outermost: four independent chains, fixed order
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] += pz[z * MN + off[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = ok[i] ? acc[i] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + ty + 8 * i, m = m0 + tx;
+            if (m < W && n < D)
+                ga[(static_cast<int64_t>(h) * D + n) * W + m] = fmaf(a2[h * D + n], gu[static_cast<int64_t>(h) * W + m], tile[tx][ty + 8 * i]);
+        }
+    } else if (ga2) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int r0 = (static_cast<int>(blockIdx.x) - ntile) * 8 + wave * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = r0 + i;                                        // r = h * D + d
+            if (r >= H * D) break;                                       // wave-uniform
+            const int h = r / D;
+            float sum = 0.f;
+            for (int w = 4 * lane; w < W; w += 256) {
+                const float4 av = *reinterpret_cast<const float4*>(a + static_cast<int64_t>(r) * W + w);
+                const float4 gv = *reinterpret_cast<const float4*>(gu + static_cast<int64_t>(h) * W + w);
+                sum = fmaf(av.x, gv.x, fmaf(av.y, gv.y, fmaf(av.z, gv.z, fmaf(av.w, gv.w, sum))));
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+            if (lane == 0) ga2[r] = sum;
+        }
+    }
+}
+
 // One wave per node: g_h = g_y * elu'(h) (written when concat) and q[node][h] = g_h[h,:] . h[h,:], the
 // (g_V . V) term of d loss / d Z  (g_V = g_h a and a V = h, so the 2F+R-wide dot collapses to a D-wide one).
 // h is recovered from y = elu(h): y > 0 ? y : log1p(y).
@@ -1424,7 +1484,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
                 const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));
                 rc = gemm_hx2_kmajor_batched(W, D, N, a->V, 2LL * W, W, 2LL * N * W, b->gh_split, 2LL * D, D, 2LL * N * D,
                                              H, sk, b->partial, static_cast<const char*>(a->aux) + kHx2ZeroPageOffset, atp_scale_v(a), atp_scale_g(a), st);
-                if (rc == RECON_OK) rc = splitk_reduce(b->partial, sk, W, D, C, bw.c_bs, H, 0, true, st);
+                // its second pass runs in FINISH, fused with the score path's terms (k_atp_weights_finish)
             } else if (gh_planes && bx3_kmajor_supported(a->V, ldv, W, ld_ghp, D, W, D)) {    // split-precision MFMA, both operands k-major
                 const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));
                 rc = gemm_bx3_kmajor_batched(W, D, N, a->V, ldv, W, b->gh_split, ld_ghp, static_cast<int64_t>(N) * ld_ghp, D, H, sk, b->partial, st);
@@ -1491,7 +1551,12 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
             RECON_CHECK_LAUNCH();
         }
         // (6) through u = a_2^T a
-        if (phases & RECON_ATP_BWD_FINISH)
+        if ((phases & RECON_ATP_BWD_FINISH) && hx2) {
+            const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));
+            const int ntile = static_cast<int>(ceil_div64(W, 32) * ceil_div64(D, 32)) * H;
+            hipLaunchKernelGGL(k_atp_weights_finish, dim3(static_cast<unsigned>(ntile + ceil_div64(1LL * H * D, 8))), dim3(256), 0, st, b->partial, sk, W,
+                               D, H, a->a, a->a_2, b->g_u, b->g_a, b->g_a_2, atp_q(a, 3), kHx2QuantityWords);
+        } else if (phases & RECON_ATP_BWD_FINISH)
         hipLaunchKernelGGL(k_score_vec_bwd, dim3(static_cast<unsigned>(D), static_cast<unsigned>(H)), dim3(256), 0, st, a->a, a->a_2, b->g_u,
                            D, W, b->g_a, b->g_a_2, atp_hx2(a) ? atp_q(a, 3) : nullptr, kHx2QuantityWords);
         RECON_CHECK_LAUNCH();
