@@ -786,6 +786,49 @@ __global__ void __launch_bounds__(kBlock, kK2WavesPerSimd) k_gat_atp_bwd(const A
         float gVs[HT][KR][VEC], gVr[HT][KR][VEC];
         float pdv[HT];
         const float ql = hv ? p.q[static_cast<int64_t>(node) * H + myh] : 0.f;
+        if (h0 + HT <= H) {
+            // Every head of the group exists (the common case): no guard per head, all 3 HT rows requested together.  A guard around
+            // one head's loads is a basic block of its own, and at the join behind it the compiler drains the load counter: eight
+            // dependent round trips per node, 20 k of a wave's 45 k cycles (s_memtime stamps at cfg 2: 5.8 k until the score vectors
+            // are staged, 20.2 k for these rows, 17.1 k in the edge loop, 2.2 k to the end).  Straight-line, the compiler interleaves
+            // requests and arithmetic within 165 registers; 85 -> 76.6 us (two batches of four heads: 77.2).  The asm keeps the
+            // batch's arithmetic in front of what follows.
+            // (Measured on top and not kept: the edge loop without its `break` / guarded refill, so that no vmcnt(0) is left at the top
+            // of an edge — 80 us, 2 spills; touching every line of the node's rows up front so that the guarded form hits L2 — 90 us.)
+            constexpr int HB = HT >= 8 ? 8 : HT;
+            const float* gvn = p.gV + (static_cast<int64_t>(node) * H + h0) * W;
+#pragma unroll
+            for (int hb = 0; hb < HT; hb += HB) {
+                float gd[HB][KR][VEC];
+#pragma unroll
+                for (int t = 0; t < HB; ++t)
+#pragma unroll
+                    for (int r = 0; r < KR; ++r) {
+                        const float* row = gvn + static_cast<int64_t>(hb + t) * W;
+                        load_vec<VEC>(gd[t][r], row + cfF[r]);
+                        load_vec<VEC>(gVs[hb + t][r], row + F + cfF[r]);
+                        load_vec<VEC>(gVr[hb + t][r], row + 2 * F + cfR[r]);
+                    }
+#pragma unroll
+                for (int t = 0; t < HB; ++t) {
+                    const int h = hb + t;
+                    const float zr = lane_bcast(Zkl * invl, h << SH);
+                    float pd = 0.f;
+#pragma unroll
+                    for (int r = 0; r < KR; ++r)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            const float g = aF[r] ? gd[t][r][v] : 0.f;
+                            gVs[h][r][v] = aF[r] ? gVs[h][r][v] : 0.f;
+                            gVr[h][r][v] = aR[r] ? gVr[h][r][v] : 0.f;
+                            pd = fmaf(g, xi[r][v], pd);
+                            gxd[r][v] = fmaf(zr, g, gxd[r][v]);
+                        }
+                    pdv[h] = pd;
+                }
+                asm volatile("" : "+v"(pdv[hb + HB - 1]) : : "memory");
+            }
+        } else {
         // (Requesting all 3 HT rows at once — branch free, the destination part staged through LDS-DMA — was measured: the
         // extra live registers spill at 3 waves per SIMD and the kernel gets slower, 80 -> 91 us at cfg 2; so was a persistent
         // node-pipelined form with the next node's rows in flight: 107 us at the one wave per SIMD its 346 registers allow.
@@ -817,6 +860,7 @@ __global__ void __launch_bounds__(kBlock, kK2WavesPerSimd) k_gat_atp_bwd(const A
             }
             pdv[h] = pd;
         }
+        }
         const float tdl = multi_sum<HT>(pdv, lane);
         const float gZl = -ql * invl;                                     // d loss / d Z   (every part of V is ~ 1/Z)
         float sum_gs = 0.f;
@@ -826,8 +870,7 @@ __global__ void __launch_bounds__(kBlock, kK2WavesPerSimd) k_gat_atp_bwd(const A
                 for (int u = 0; u < PF; ++u) {
                     const int j = j0 + u;
                     if (j >= cn) break;                                  // wave-uniform
-                    const int k = c0 + j;
-                    const int e = __builtin_amdgcn_readlane(eidv, j);
+                    const int k = c0 + j;                    const int e = __builtin_amdgcn_readlane(eidv, j);
                     float xs[KR][VEC], re[KR][VEC];
 #pragma unroll
                     for (int r = 0; r < KR; ++r)
