@@ -37,7 +37,7 @@ struct Hx2Args {
     OutputDesc C;
     int64_t c_bs;
     int32_t M, N, K;               // K: multiple of 8; B planes are zero padded to hx2_kp(K), A is masked here
-    int32_t epilogue, c_vec4, xcd_remap;
+    int32_t epilogue, c_vec4, xcd_remap, c_plain;
     Hx2Scale sa, sb;
 };
 
@@ -84,6 +84,34 @@ __device__ __forceinline__ void hx2_store(const f32x4 (&acc)[2][TN], const Outpu
             }
             const int col = n0 + 192 + li;
             if (col < N) crow[minor_off(C.Dseg, C.Sseg, col)] = fin(acc[i][12][r]);
+        }
+}
+
+// The same for the layer's own outputs — plain rows (no scatter, no segments), float4-aligned, the region below 2 GiB — without any
+// branch: rows past M and columns past N become out-of-range buffer offsets.  The general form above decides scatter / segments / vector width / column bounds per
+// store, a few branches each; a wave spends several hundred cycles per store instruction in it.
+template <int EPI>
+__device__ __forceinline__ void hx2_store_plain(const f32x4 (&acc)[2][TN], float* base, int64_t ld, int M, int N, int m0, int n0, int mb,
+                                                int li, int lq, float scale) {
+    auto fin = [&](float v) { return __builtin_bit_cast(uint32_t, gemm_epilogue(v * scale, EPI)); };
+    // buffer stores: a lane whose offset lies outside the region is dropped by the hardware — no exec mask, no branch per store
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, static_cast<int>((static_cast<int64_t>(M - 1) * ld + N) * 4), 0x00020000);
+    constexpr int kOut = 0x7ffffff0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + mb + 16 * i + 4 * lq + r;
+            const int rowoff = static_cast<int>(row * ld) + n0;          // < 2^29 (checked on the host)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int col = 64 * q + 4 * li;
+                const int off = (row < M && n0 + col < N) ? (rowoff + col) * 4 : kOut;     // N % 4 == 0: a float4 is in or out as a whole
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{fin(acc[i][4 * q][r]), fin(acc[i][4 * q + 1][r]), fin(acc[i][4 * q + 2][r]),
+                                                             fin(acc[i][4 * q + 3][r])}, rsrc, off, 0, 0);
+            }
+            const int off = (row < M && n0 + 192 + li < N) ? (rowoff + 192 + li) * 4 : kOut;
+            __builtin_amdgcn_raw_buffer_store_b32(fin(acc[i][12][r]), rsrc, off, 0, 0);
         }
 }
 
@@ -203,7 +231,12 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_hx2(const Hx2Args p) {
         __syncthreads();
         buf ^= 1;
     }
-    hx2_store(acc, p.C, p.C.base + bz * p.c_bs, p.M, p.N, m0, n0, mb, li, lq, p.epilogue, p.c_vec4, ia, ib);
+    if (p.c_plain) {                                                 // uniform
+        if (p.epilogue == GEMM_EPI_ELU) hx2_store_plain<GEMM_EPI_ELU>(acc, p.C.base + bz * p.c_bs, p.C.S1, p.M, p.N, m0, n0, mb, li, lq, ia * ib);
+        else hx2_store_plain<GEMM_EPI_NONE>(acc, p.C.base + bz * p.c_bs, p.C.S1, p.M, p.N, m0, n0, mb, li, lq, ia * ib);
+    } else {
+        hx2_store(acc, p.C, p.C.base + bz * p.c_bs, p.M, p.N, m0, n0, mb, li, lq, p.epilogue, p.c_vec4, ia, ib);
+    }
 }
 
 // The same product for k-MAJOR operands — the weight gradient g_a^T = V^T g_h, whose K is the node dimension:
@@ -348,17 +381,22 @@ __global__ void __launch_bounds__(NT, OCC) k_gemm_hx2_kmajor(const Hx2KmArgs p) 
         __syncthreads();
         if (k0 + BK < k_end) dma(k0 + BK);
     }
+    // 104 four-byte stores per wave, rows past M and columns past N masked out: as buffer stores whose offset lies outside the tile's
+    // M x N region for a masked lane (the hardware drops those), i.e. without an exec mask and a branch around every one of them
     float* base = p.partial + static_cast<int64_t>(tile.z) * p.M * p.N;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, p.M * p.N * 4, 0x00020000);
+    const float sc = ia * ib;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + mb + 16 * i + 4 * g + r;
-            if (row >= p.M) continue;
+            const int rowoff = row < p.M ? row * p.N : 0x1ffffff0;        // (rowoff + col) * 4 stays below 2^32 and outside the region
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + 16 * j + ip;
-                if (col < p.N) base[static_cast<int64_t>(row) * p.N + col] = acc[i][j][r] * ia * ib;
+                const int off = col < p.N ? (rowoff + col) * 4 : 0x7ffffff0;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[i][j][r] * sc), rsrc, off, 0, 0);
             }
         }
 }
@@ -508,6 +546,7 @@ int gemm_hx2_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t a_
     a.c_vec4 = (!(N & 3) && !(bt.c_bs & 3) && !(reinterpret_cast<uintptr_t>(C.base) & 15) && !(C.S1 & 3) && !(C.S2 & 3) && !(C.Sseg & 3) &&
                 (C.Dseg >= N || !(C.Dseg & 3))) ? 1 : 0;
     a.xcd_remap = 1;
+    a.c_plain = (a.c_vec4 && !C.scatter && C.P >= M && C.Dseg >= N && (static_cast<int64_t>(M) * C.S1 + N) * 4 < (1LL << 31)) ? 1 : 0;   // plain rows: the straight-line store
     a.sa = sa; a.sb = sb;
     const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, BM)), static_cast<unsigned>(bt.batch));
     hipLaunchKernelGGL(k_gemm_hx2, grid, dim3(NT), 0, st, a);
