@@ -188,7 +188,6 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
     // ghp (optional): term planes of g_h for the split-precision GEMMs — three bfloat16 planes [3][N][ld_p], or (f16x2) the
     // half terms of s_g * g_h, head-major [H][N][2][D] (ld_p = 2 D, plane_p = D), s_g from the published max |grad_out|
     // (|elu'| <= 1, so it bounds |g_h|)
-    const float gs = f16x2 ? hx2_scale(gsc) : 1.f;
     constexpr int IPW = 4;                                               // (node, head) rows per wave, loads batched
     const int lane = threadIdx.x & 63;
     const int item0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * IPW;      // N*H < 2^31 (checked by the host)
@@ -196,18 +195,21 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
     if (item0 >= total) return;
     const bool v4 = ((D | ld_gy | ld_y) & 3) == 0;
     if (v4 && D <= 256) {
+        // All 2 IPW row loads and the scale's slot load go out together, branch free (rows past the end re-read the last row,
+        // lanes past D column 0; both are masked afterwards): behind a guard each load pair is a basic block of its own and the
+        // compiler drains the counter at every join — IPW dependent round trips, plus one for a scale read in front of them.
         const int c = 4 * lane;
+        const bool cok = c < D;
+        const int cc = cok ? c : 0;
         float4 g4[IPW], y4[IPW];
 #pragma unroll
         for (int j = 0; j < IPW; ++j) {
-            const int it = item0 + j;
-            g4[j] = make_float4(0.f, 0.f, 0.f, 0.f); y4[j] = g4[j];
-            if (it < total && c < D) {
-                const int node = it / H, h = it % H;
-                g4[j] = *reinterpret_cast<const float4*>(gy + static_cast<int64_t>(node) * ld_gy + h * D + c);
-                y4[j] = *reinterpret_cast<const float4*>(y + static_cast<int64_t>(node) * ld_y + h * D + c);
-            }
+            const int it = min(item0 + j, total - 1);
+            const int node = it / H, h = it % H;
+            g4[j] = *reinterpret_cast<const float4*>(gy + static_cast<int64_t>(node) * ld_gy + h * D + cc);
+            y4[j] = *reinterpret_cast<const float4*>(y + static_cast<int64_t>(node) * ld_y + h * D + cc);
         }
+        const float gs = f16x2 ? hx2_scale_wave(gsc) : 1.f;
 #pragma unroll
         for (int j = 0; j < IPW; ++j) {
             const int it = item0 + j;
@@ -220,7 +222,7 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
                 o[v] = g;
                 part = fmaf(g, hv, part);
             }
-            const float tot = group_sum<64>(part);
+            const float tot = group_sum<64>(cok ? part : 0.f);
             if (it < total) {
                 if (gh && c < D) *reinterpret_cast<float4*>(gh + static_cast<int64_t>(it) * D + c) = make_float4(o[0], o[1], o[2], o[3]);
                 if (ghp && c < D) {
@@ -253,6 +255,7 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
         }
         return;
     }
+    const float gs = f16x2 ? hx2_scale_wave(gsc) : 1.f;
     if (v4) {                                                            // wide heads (out_att: D = H*D of the heads): 256 columns per pass
         for (int j = 0; j < IPW; ++j) {
             const int it = item0 + j;
