@@ -1,3 +1,10 @@
-timeout 900 python -m pytest tests/test_gat_gpu.py -m gpu -x -q 2>&1 | tail -1
-for r in 1 2 3; do python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['avg_us'], d['roofline']['frac'], d['roofline_gemm']['avg_us'])"; done
-bash tools/step_breakdown.sh 2>/dev/null | grep -i "elu\|amax\|src\|skinny" | head
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/bd_spgat -o t -- python3 tools/spgat_bench.py 200 > gpurun_out/bd_spgat.log 2>&1
+python3 - <<PY
+import csv,glob
+f=glob.glob("gpurun_out/bd_spgat/**/*kernel_stats.csv",recursive=True)[0]
+tot=0
+for r in list(csv.DictReader(open(f)))[:40]:
+    n=r["Name"].replace("void recon::(anonymous namespace)::","").replace("recon::(anonymous namespace)::","")[:70]
+    print("%-72s %5s %9.1f %8.1f"%(n,r["Calls"],float(r["TotalDurationNs"])/13e3,float(r["AverageNs"])/1e3))
+PY

@@ -35,4 +35,5 @@ def run(D, B=512, n=16, e=64, F_=200, H=8, nrel=64, iters=10):
     print(json.dumps({"workload": "SpGAT (8 heads + out_att) fwd+bwd, cfg 2", "D_per_head": D, "ms_per_step": ms, "edges_per_s": E / ms * 1e3}))
 
 if __name__ == "__main__":
-    run(200); run(25)
+    for D in ([int(v) for v in sys.argv[1:]] or [200, 25]):
+        run(D)
