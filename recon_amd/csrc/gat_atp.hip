@@ -408,14 +408,14 @@ __global__ void __launch_bounds__(kBlock) k_row_dots(const RowDotsJob j0, const 
 // products, fp32 accumulation): the VALU form above spends a multi-value wave reduction per 8 dot products and runs at 2.5x its
 // traffic bound.  One wave per 16 rows; lane (i = lane & 15, q = lane >> 4) loads 16 bytes of row i per 16-k group (k = 16 g + 4 q ..
 // + 3: the MFMA's k slot q carries these four k in four steps — any assignment works as long as A and B agree), eight groups in
-// flight; U sits in LDS as [16][Kp], Kp = 4 mod 8 so that the 16 columns' 16-byte reads fall on disjoint banks.  K % 4 == 0.
+// flight (two register batches); U sits in LDS as [NJ][Kp], Kp = 4 mod 8 so that the 16 columns' 16-byte reads fall on disjoint banks.  K % 4 == 0.
 using f32x4_t = __attribute__((ext_vector_type(4))) float;
 __device__ __host__ inline int row_dots_kp(int K) { return (K % 8 == 0) ? K + 4 : K; }
 // The last nsplit blocks write the half planes of a and a^T (hx2_split_both_block): that pass needs only what
 // the kernel in front of this one published, and as a launch of its own it cost 10 us of which 5 are kernel turn-around.
 __global__ void __launch_bounds__(kBlock) k_row_dots_x(const RowDotsJob j0, const RowDotsJob j1, const float* __restrict__ u, int32_t H,
                                                        int32_t W, const Hx2SplitBoth sp, int32_t nsplit) {
-    extern __shared__ __attribute__((aligned(16))) float U[];     // [16][Kp], zero beyond NJ
+    extern __shared__ __attribute__((aligned(16))) float U[];     // [NJ][Kp] (the launch reserves max NJ = 2 H rows)
     if (static_cast<int>(blockIdx.x) >= j0.nb + j1.nb) {           // last in the grid (first: 24.6 us for the launch against 21.2)
         const int lin = blockIdx.x - (j0.nb + j1.nb);
         hx2_split_both_block(sp, lin % sp.gx, (lin / sp.gx) % sp.batch, lin / (sp.gx * sp.batch));
@@ -429,11 +429,12 @@ __global__ void __launch_bounds__(kBlock) k_row_dots_x(const RowDotsJob j0, cons
     float* __restrict__ out = jb.out;
     const int rows = jb.rows, K = jb.K, F = jb.F, off = jb.off, NJ = jb.NJ, Kp = row_dots_kp(jb.K);
     const int bid = second ? bx - j0.nb : bx, nblocks = jb.nb;
-    constexpr int GU = 16;                                               // K <= 256: the whole row in one batch of loads
+    constexpr int GU = 8;                                                // groups per register batch, two batches in flight
     const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ntiles = (rows + 15) / 16, G = (K + 15) / 16;
-    const float* Ui = U + i * Kp;
+    const bool iu = i < NJ;                                              // columns past NJ multiply by zero: U holds NJ rows only
+    const float* Ui = U + (iu ? i : 0) * Kp;
     float mx = 0.f;
     bool staged = false;
     for (int tile = bid * (kBlock / 64) + wave; tile < ntiles || !staged; tile += nblocks * (kBlock / 64)) {
@@ -441,32 +442,44 @@ __global__ void __launch_bounds__(kBlock) k_row_dots_x(const RowDotsJob j0, cons
         const int row = min(tile * 16 + i, rows - 1);                    // rows past the end recompute the last row, not stored
         const float* xr = X + static_cast<int64_t>(gather ? gather[row] : row) * K;
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-        for (int g0 = 0; g0 < G; g0 += GU) {
-            f32x4_t xv[GU];
-            int cc[GU];
+        // two register batches of GU groups: batch b+1 is requested in front of batch b's MFMAs (rows wider than 256 columns —
+        // out_att-sized inputs — were one dependent round trip per batch: 150 us for 262 MB)
+        f32x4_t xv[2][GU];
+        int cc[2][GU];
+        auto request = [&](int g0, int buf) {
 #pragma unroll
             for (int t = 0; t < GU; ++t) {                                // branch free: groups past K re-read column 0 and are zeroed
                 const int c = 16 * (g0 + t) + 4 * q;
                 const bool ok = c < K;
-                cc[t] = ok ? c : 0;
-                xv[t] = *reinterpret_cast<const f32x4_t*>(xr + cc[t]);
-                if (!ok) xv[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                cc[buf][t] = ok ? c : 0;
+                xv[buf][t] = *reinterpret_cast<const f32x4_t*>(xr + cc[buf][t]);
+                if (!ok) xv[buf][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
-            if (!staged) {                                                // the score vectors arrive while the first rows are in flight
-                for (int idx = threadIdx.x; idx < 16 * Kp; idx += kBlock) {
-                    const int j = idx / Kp, k = idx - j * Kp;
-                    U[idx] = (j < NJ && k < K) ? u[static_cast<int64_t>(j % H) * W + (j / H) * F + off + k] : 0.f;
-                }
-                __syncthreads();
-                staged = true;
+        };
+        request(0, 0);
+        if (!staged) {                                                    // the score vectors arrive while the first rows are in flight
+            for (int idx = threadIdx.x; idx < NJ * Kp; idx += kBlock) {
+                const int j = idx / Kp, k = idx - j * Kp;
+                U[idx] = k < K ? u[static_cast<int64_t>(j % H) * W + (j / H) * F + off + k] : 0.f;
             }
+            __syncthreads();
+            staged = true;
+        }
+        for (int g0 = 0; g0 < G; g0 += 2 * GU) {
 #pragma unroll
-            for (int t = 0; t < GU; ++t) {
-                const f32x4_t uv = *reinterpret_cast<const f32x4_t*>(Ui + cc[t]);
+            for (int half = 0; half < 2; ++half) {
+                const int gb = g0 + half * GU;
+                if (gb >= G) break;                                       // wave-uniform
+                if (gb + GU < G) request(gb + GU, half ^ 1);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    mx = fmaxf(mx, fabsf(xv[t][e]));
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t][e], uv[e], acc, 0, 0, 0);
+                for (int t = 0; t < GU; ++t) {
+                    f32x4_t uv = *reinterpret_cast<const f32x4_t*>(Ui + cc[half][t]);
+                    if (!iu) uv = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        mx = fmaxf(mx, fabsf(xv[half][t][e]));
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[half][t][e], uv[e], acc, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1322,7 +1335,7 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
             jn.nb = static_cast<int>(ceil_div64(N, 64) < 4096 ? ceil_div64(N, 64) : 4096);
             je.nb = E > 0 ? static_cast<int>(ceil_div64(E, 64) < 8192 ? ceil_div64(E, 64) : 8192) : 0;
             const int kpm = row_dots_kp(F) > row_dots_kp(R) ? row_dots_kp(F) : row_dots_kp(R);
-            hipLaunchKernelGGL(k_row_dots_x, dim3(static_cast<unsigned>(jn.nb + je.nb + nsplit)), dim3(kBlock), sizeof(float) * 16 * kpm, st,
+            hipLaunchKernelGGL(k_row_dots_x, dim3(static_cast<unsigned>(jn.nb + je.nb + nsplit)), dim3(kBlock), sizeof(float) * (2 * H) * kpm, st,
                                jn, je, a->u, H, W, sp, nsplit);
         } else if (s.vec == 4) hipLaunchKernelGGL((k_row_dots<4>), grid, dim3(kBlock), lds, st, jn, je, a->u, H, W);
         else hipLaunchKernelGGL((k_row_dots<2>), grid, dim3(kBlock), lds, st, jn, je, a->u, H, W);
