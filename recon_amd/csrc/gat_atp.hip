@@ -734,7 +734,7 @@ constexpr int kK2Ring = 2, kK2WavesPerSimd = 3;
 // Wide rows (KR >= 4 register rows per lane: out_att-sized inputs) get the register budget of two waves per SIMD, KR = 8 of one: at
 // three the KR = 8 form spilled 259 registers (0.73 ms per call at N = 8 192, F = R = 1 600).
 template <int VEC, int KR, int HT>
-__global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : (KR >= 4 ? 2 : kK2WavesPerSimd)) k_gat_atp_bwd(const AtpBwdK p) {
+__global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >= 4 || KR * HT >= 8 && KR >= 2) ? 2 : kK2WavesPerSimd)) k_gat_atp_bwd(const AtpBwdK p) {
     extern __shared__ __attribute__((aligned(16))) float U[];          // [H][W]: u_dst | u_src | u_rel per head
     const int F = p.F, R = p.R, H = p.H, W = 2 * F + R;
     const int lane = threadIdx.x & 63;

@@ -157,7 +157,7 @@ struct TileLoader {
 
 // Block tile (WM*TM*32) x (WN*TN*32) x 16; 4 waves arranged WM x WN, each wave TM x TN MFMA tiles.
 template <bool A_KMINOR, bool B_KMINOR, int VEC, int WM, int WN, int TM, int TN, int BK, bool LIN>
-__global__ void __launch_bounds__(NT, (TM * TN <= 4) ? 4 : 1) k_gemm_f32(const GemmArgs p) {
+__global__ void __launch_bounds__(NT, (TM * TN <= 4) ? (VEC == 1 ? 3 : 4) : 1) k_gemm_f32(const GemmArgs p) {      // the scalar-load form spills at 4
     static_assert(WM * WN == 4, "4 waves per block");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     using LA = TileLoader<BM, A_KMINOR, VEC, BK, BM + 4, false, LIN>;
