@@ -1,9 +1,3 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/bd_prop -o t -- python3 tools/bench_prop.py > gpurun_out/bd_prop.log 2>&1
-python3 - <<PY
-import csv,glob
-f=glob.glob("gpurun_out/bd_prop/**/*kernel_stats.csv",recursive=True)[0]
-for r in list(csv.DictReader(open(f)))[:22]:
-    n=r["Name"].replace("void recon::(anonymous namespace)::","").replace("recon::(anonymous namespace)::","")[:80]
-    print("%-82s %5s %9.1f %8.1f"%(n,r["Calls"],float(r["TotalDurationNs"])/1e3,float(r["AverageNs"])/1e3))
-PY
+timeout 900 python -m pytest tests/test_gat_gpu.py -m gpu -x -q 2>&1 | tail -1
+timeout 300 python tools/gemm_hx2_bench.py 2>&1 | grep "^tn" | cut -c1-30,95-125
+for r in 1 2 3; do python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['avg_us'], d['roofline']['frac'], d['roofline_gemm']['avg_us'])"; done
