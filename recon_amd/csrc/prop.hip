@@ -705,14 +705,48 @@ __global__ void __launch_bounds__(1024) k_propagate_bwd_hop(const PropBwdK p) {
     const int pitch = p.pitch, S = p.S, CC = p.CC;
     float* X = lds;                                       // H^l, later H^l-1
     float* Y = lds + static_cast<int64_t>(CC) * pitch;    // grad wrt H^l -> grad wrt pre-activation
-    // one wave per channel row, lanes along s: coalesced, no per-element division
-    for (int cl = wave; cl < CC; cl += nwaves) {
-        const int c = c0 + cl;
-        const int64_t g0 = (static_cast<int64_t>(b) * p.C + c) * S;
-        for (int s = lane; s < pitch; s += 64) {
-            const bool ok = c < p.C && s < S;
-            X[cl * pitch + s] = ok ? p.Hl[g0 + s] : 0.f;
-            Y[cl * pitch + s] = (ok && !p.first) ? p.gH[g0 + s] : 0.f;
+    // VEC4 (S % 4 == 0, 16-byte aligned states, <= kStage 16-byte pieces per thread): every thread requests all its pieces of a
+    // state at once, branch free (rows past C re-read row C - 1 and are zeroed on the way into LDS), so a phase is ONE round trip.
+    // s_memtime stamps at cfg 3b with the row-by-row form below: of a workgroup's 92.6 k cycles 25.4 k went into this phase and
+    // 14.2 k into the H^l-1 one — guarded 4-byte loads, one dependent round trip per row and 64-column step.
+    constexpr int kStage = 4;
+    const int nf4 = S >> 2, npieces = CC * nf4;
+    const bool staged = VEC4 && npieces <= kStage * nthreads;
+    auto stage = [&](const float* src0, int64_t row_stride, bool zero_all, float* dst) {      // dst[cl][0 .. pitch) = row c0 + cl of src0
+        float4 v[kStage];
+#pragma unroll
+        for (int i = 0; i < kStage; ++i) {
+            const int idx = min(tid + i * nthreads, npieces - 1);
+            const int cl = idx / nf4, j = idx - cl * nf4;
+            v[i] = *reinterpret_cast<const float4*>(src0 + static_cast<int64_t>(min(c0 + cl, p.C - 1)) * row_stride + 4 * j);
+        }
+#pragma unroll
+        for (int i = 0; i < kStage; ++i) {
+            const int idx = tid + i * nthreads;
+            if (idx < npieces) {
+                const int cl = idx / nf4, j = idx - cl * nf4;
+                const bool ok = c0 + cl < p.C && !zero_all;
+                *reinterpret_cast<float4*>(dst + cl * pitch + 4 * j) = ok ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        for (int idx = tid; idx < CC * (pitch - S); idx += nthreads) {    // the pad columns S .. pitch
+            const int cl = idx / (pitch - S), s = S + idx % (pitch - S);
+            dst[cl * pitch + s] = 0.f;
+        }
+    };
+    if (staged) {
+        stage(p.Hl + static_cast<int64_t>(b) * p.C * S, S, false, X);
+        stage(p.gH + static_cast<int64_t>(b) * p.C * S, S, p.first != 0, Y);
+    } else {
+        // one wave per channel row, lanes along s: coalesced, no per-element division
+        for (int cl = wave; cl < CC; cl += nwaves) {
+            const int c = c0 + cl;
+            const int64_t g0 = (static_cast<int64_t>(b) * p.C + c) * S;
+            for (int s = lane; s < pitch; s += 64) {
+                const bool ok = c < p.C && s < S;
+                X[cl * pitch + s] = ok ? p.Hl[g0 + s] : 0.f;
+                Y[cl * pitch + s] = (ok && !p.first) ? p.gH[g0 + s] : 0.f;
+            }
         }
     }
     __syncthreads();
@@ -731,10 +765,14 @@ __global__ void __launch_bounds__(1024) k_propagate_bwd_hop(const PropBwdK p) {
     __syncthreads();
     for (int idx = tid; idx < CC * pitch; idx += nthreads) Y[idx] *= act_bwd(X[idx], p.act);
     __syncthreads();
-    for (int cl = wave; cl < CC; cl += nwaves) {
-        const int c = c0 + cl;
-        const float* src = p.Hprev + b * p.hprev_bs + static_cast<int64_t>(c) * S;
-        for (int s = lane; s < pitch; s += 64) X[cl * pitch + s] = (c < p.C && s < S) ? src[s] : 0.f;
+    if (staged) {
+        stage(p.Hprev + b * p.hprev_bs, S, false, X);
+    } else {
+        for (int cl = wave; cl < CC; cl += nwaves) {
+            const int c = c0 + cl;
+            const float* src = p.Hprev + b * p.hprev_bs + static_cast<int64_t>(c) * S;
+            for (int s = lane; s < pitch; s += 64) X[cl * pitch + s] = (c < p.C && s < S) ? src[s] : 0.f;
+        }
     }
     __syncthreads();
     const int li = lane & 15, lq = lane >> 4;
@@ -1018,7 +1056,8 @@ extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t
         p.B = a->B; p.C = a->C; p.S = a->S; p.L = a->L; p.dd = a->dd; p.act = a->act;
         p.CC = g.CC; p.Sp = g.Sp; p.pitch = g.pitch; p.hop = l - 1; p.first = (l == a->L) ? 1 : 0; p.chunks = g.chunks;
         if (p.gA && g.chunks > 1 && hipMemsetAsync(p.gA, 0, sizeof(float) * a->B * a->S * a->S, st) != hipSuccess) return RECON_ERR_LAUNCH;
-        RECON_DISPATCH_MT(g.MT, false, k_propagate_bwd_hop, grid, dim3(1024), g.lds, st, p);
+        const bool v4b = (a->S % 4) == 0 && al16(p.Hl) && al16(p.Hprev) && al16(p.gH) && (p.hprev_bs % 4) == 0;
+        RECON_DISPATCH_MT(g.MT, v4b, k_propagate_bwd_hop, grid, dim3(1024), g.lds, st, p);
         RECON_CHECK_LAUNCH();
     }
     return RECON_OK;
