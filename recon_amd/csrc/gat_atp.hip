@@ -559,9 +559,9 @@ __device__ __forceinline__ void store_planes_paired(_Float16* hi_p, int64_t plan
 // stores: 35.5 - 41 us).  Kept at 1.
 constexpr int kK1NodesPerWave = 1;
 template <int VEC, int KR, int HT, bool TRAIN, int PL>
-__global__ void __launch_bounds__(kBlock) k_gat_atp_fwd(const AtpFwdK p) {
+__global__ void __launch_bounds__(kBlock, KR >= 8 ? 2 : 1) k_gat_atp_fwd(const AtpFwdK p) {      // KR = 8: 260 registers unbounded, one short of two waves per SIMD
     // edges in flight per wave: their rows are requested together, so a node of degree <= UNR costs ONE row round trip
-    constexpr int UNR = (KR * HT >= 16) ? 1 : 2;
+    constexpr int UNR = (KR * HT >= 16 || KR >= 8) ? 1 : 2;       // KR = 8: two edges in flight are 128 registers of rows
     constexpr int NPW = kK1NodesPerWave;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
