@@ -169,7 +169,11 @@ def main():
             stages = (L.recon_gat_atp_scores, L.recon_gat_atp_aggregate, L.recon_gat_atp_project)
             # compulsory traffic of the aggregation kernel: x and edge_embed rows once, score terms, CSR, V out,
             # saved sigma / Z / Zk  (fp32 values, int32 indices)
-            bytes_alg = 4 * (N * F_ + E * R + 2 * N * H + E * H + (N + 1) + 2 * E + N * H * W + E * H + 2 * N * H)
+            # V: without attention dropout (this workload) and in f16 x 2 mode the destination part x_i Zk/Z is one row for all heads and is
+            # written once (for head 0; the GEMMs read that copy): N * (H * (F + R) + F) elements instead of N * H * W
+            dst_shared = aux is not None and H > 1 and F_ % 8 == 0
+            v_elems = N * (H * (F_ + R) + F_) if dst_shared else N * H * W
+            bytes_alg = 4 * (N * F_ + E * R + 2 * N * H + E * H + (N + 1) + 2 * E + v_elems + E * H + 2 * N * H)
             flops_proj = 2.0 * N * W * H * D
             kname, gname = "k_gat_atp_fwd", "k_gemm_f32 (batched projection out = act(V a^T))"
         else:
@@ -203,8 +207,15 @@ def main():
                               "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_alg / t_edge / HBM_PEAK,
                               "traffic": None, "algorithmic_bytes": bytes_alg, "avg_us": t_edge * 1e6,
                               "survey_model_bytes": algorithmic_bytes_fwd(N, E, H, D),
-                              "note": "algorithmic_bytes = compulsory traffic of this kernel; survey_model_bytes = SURVEY 8d's "
+                              "note": "algorithmic_bytes = compulsory traffic of this kernel as it runs (without attention dropout the "
+                                      "destination part of V is written once, not once per head); survey_model_bytes = SURVEY 8d's "
                                       "B_G for the project-then-aggregate layout this kernel no longer needs"}
+        if path == "atp":
+            # SURVEY 8d's own definition, for reference: B_G over the time of everything in the layer forward except the projection GEMM
+            # (here: the score stage and the aggregation kernel), against the same 8 TB/s
+            t_scores = sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)) / args.steps * 1e-3
+            result["roofline"]["survey_definition"] = {"bytes": algorithmic_bytes_fwd(N, E, H, D), "time_us": (t_scores + t_edge) * 1e6,
+                                                       "frac": algorithmic_bytes_fwd(N, E, H, D) / (t_scores + t_edge) / HBM_PEAK}
         try:            # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot collect PMC itself)
             pmc_file = "round2_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "round2_pmc_traffic.json")) else "round1_pmc_traffic.json"
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))

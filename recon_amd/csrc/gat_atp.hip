@@ -500,6 +500,8 @@ struct AtpFwdK {
     float* V; float* sigma; float* Z; float* Zk;
     int32_t N, E, F, R, H;
     float alpha;
+    int32_t dst_shared;         // 1: the destination part of V (x_i Zk/Z) is written for head 0 only — without attention dropout Zk = Z and
+                                // every head's copy is the same row; the GEMMs read head 0's (a_shared_k / a_shared_m)
     int32_t planes;             // 1 (2: with paired 16-byte stores, F % 8 == 0 and R % 8 == 0): V is written as half terms [H][N][2][W] of s_V * V (gemm_hx2.hip: high row | low row) instead of fp32 [N][H][W]
     Hx2Scale vs;                // s_V from max(|x|, |edge_embed|) * keep_max, an upper bound of |V| (V rows are k-weighted means)
 };
@@ -697,9 +699,11 @@ __global__ void __launch_bounds__(kBlock, KR >= 8 ? 2 : 1) k_gat_atp_fwd(const A
                 for (int r = 0; r < KR; ++r) {
                     float o[VEC];
                     if (aF[r]) {
+                        if (!(p.dst_shared && h0 + h > 0)) {                  // uniform
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) o[v] = cur.xi[r][v] * zk;
-                        put(Vr, Vh, cf[r], o);
+                            for (int v = 0; v < VEC; ++v) o[v] = cur.xi[r][v] * zk;
+                            put(Vr, Vh, cf[r], o);
+                        }
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) o[v] = accS[h][r][v] * invh;
                         put(Vr, Vh, F + cf[r], o);
@@ -1263,6 +1267,13 @@ static bool atp_hx2(const recon_gat_atp_args* a) {
     return !((reinterpret_cast<uintptr_t>(a->a_split) & 15) || (reinterpret_cast<uintptr_t>(a->aux) & 255) || (reinterpret_cast<uintptr_t>(a->V) & 15));
 }
 extern "C" int recon_gat_atp_f16x2_supported(int32_t F, int32_t R, int32_t D, int32_t H) { return atp_hx2_shape(F, R, D, H) ? 1 : 0; }
+// The destination part of V is one row for all heads when there is no attention dropout (Zk = Z): K1' writes it for head 0 only and
+// the projection / weight-gradient GEMMs read head 0's copy for every head (52 MB less written and, twice, less read at cfg 2).
+// F % 8 == 0 so that the shared columns are whole 16-byte groups; the heads' planes lie within 2^31 elements.
+static int32_t atp_dst_shared(const recon_gat_atp_args* a) {
+    const int64_t W = 2LL * a->F + a->R;
+    return (atp_hx2(a) && !a->keep && a->H > 1 && (a->F % 8) == 0 && 2 * W * a->N * a->H < (1LL << 31)) ? a->F : 0;
+}
 static uint32_t* atp_q(const recon_gat_atp_args* a, int q) { return static_cast<uint32_t*>(a->aux) + q * kHx2QuantityWords; }
 static Hx2Scale atp_scale_a(const recon_gat_atp_args* a) { return Hx2Scale{atp_q(a, 0), nullptr, 1.f}; }
 static Hx2Scale atp_scale_v(const recon_gat_atp_args* a) {
@@ -1358,6 +1369,7 @@ extern "C" int recon_gat_atp_aggregate(const recon_graph* g, const recon_gat_atp
     p.V = a->V; p.sigma = a->sigma; p.Z = a->Z; p.Zk = a->Zk;
     p.N = a->N; p.E = a->E; p.F = a->F; p.R = a->R; p.H = a->H; p.alpha = a->alpha;
     p.planes = atp_hx2(a) ? ((a->F % 8 == 0 && a->R % 8 == 0) ? 2 : 1) : 0;
+    p.dst_shared = atp_dst_shared(a) ? 1 : 0;
     p.vs = p.planes ? atp_scale_v(a) : Hx2Scale{nullptr, nullptr, 1.f};
     dim3 grid(static_cast<unsigned>(ceil_div64(a->N, (kBlock / 64) * kK1NodesPerWave)), static_cast<unsigned>(ceil_div64(a->H, s.ht)));
 #define CALL_FWD(V_, K_, H_)                                                                                   \
@@ -1390,7 +1402,7 @@ extern "C" int recon_gat_atp_project(const recon_graph* g, const recon_gat_atp_a
     bt.epilogue = a->concat ? 1 : 0;
     if (atp_hx2(a))
         return gemm_hx2_batched(a->N, a->D, W, a->V, W, 2LL * W, 2LL * a->N * W, a->a_split, C, bt, atp_scale_v(a), atp_scale_a(a),
-                                as_stream(stream));                   // V terms [H][N][2][W]: plane stride W, row stride 2 W, head stride 2 N W
+                                as_stream(stream), atp_dst_shared(a));  // V terms [H][N][2][W]: plane stride W, row stride 2 W, head stride 2 N W
     if (a->a_split && bx3_supported(A, W, bt)) return gemm_bx3_batched(a->N, a->D, W, A, a->a_split, C, bt, as_stream(stream));
     return gemm_f32_batched(a->N, a->D, W, A, true, B, true, C, bt, 1, nullptr, as_stream(stream));
 }
@@ -1544,7 +1556,8 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
             if (hx2) {                                                                     // f16 x 2: both operands are half planes
                 const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));
                 rc = gemm_hx2_kmajor_batched(W, D, N, a->V, 2LL * W, W, 2LL * N * W, b->gh_split, 2LL * D, D, 2LL * N * D,
-                                             H, sk, b->partial, static_cast<const char*>(a->aux) + kHx2ZeroPageOffset, atp_scale_v(a), atp_scale_g(a), st);
+                                             H, sk, b->partial, static_cast<const char*>(a->aux) + kHx2ZeroPageOffset, atp_scale_v(a), atp_scale_g(a), st,
+                                             atp_dst_shared(a));
                 // its second pass runs in FINISH, fused with the score path's terms (k_atp_weights_finish)
             } else if (gh_planes && bx3_kmajor_supported(a->V, ldv, W, ld_ghp, D, W, D)) {    // split-precision MFMA, both operands k-major
                 const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));

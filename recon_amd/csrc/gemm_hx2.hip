@@ -38,6 +38,7 @@ struct Hx2Args {
     int64_t c_bs;
     int32_t M, N, K;               // K: multiple of 8; B planes are zero padded to hx2_kp(K), A is masked here
     int32_t epilogue, c_vec4, xcd_remap, c_plain;
+    int32_t a_shared_k;            // A's columns k < a_shared_k are the same for every batch entry and are read from entry 0 (0: none)
     Hx2Scale sa, sb;
 };
 
@@ -172,9 +173,11 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_hx2(const Hx2Args p) {
     u32x4 araw[2][T];
     f16x8 af[2][T];
     bool a_ok = true;
+    const int a_back = static_cast<int>(bz * p.a_bs);                 // < 2^31 (checked on the host when a_shared_k is set)
     auto load_a = [&](int k0) {
         a_ok = k0 + 8 * lq < p.K;
-        const int off = -8 * lq + ((k0 + 8 * lq) & -static_cast<int>(a_ok));
+        int off = -8 * lq + ((k0 + 8 * lq) & -static_cast<int>(a_ok));
+        if (k0 + 8 * lq < p.a_shared_k) off -= a_back;                 // shared columns: batch entry 0's copy (lane predicate, no branch)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -253,6 +256,7 @@ struct Hx2KmArgs {
     float* partial;
     int32_t M, N, K, k_per_split, nsplit;
     int32_t m_ld, n_ld;            // columns present in the planes (multiples of 8, >= M / N; the excess is zero padding)
+    int32_t a_shared_m;            // A's columns m < a_shared_m are the same for every batch entry and are read from entry 0 (0: none)
     Hx2Scale sa, sb;
 };
 
@@ -289,6 +293,7 @@ __global__ void __launch_bounds__(NT, OCC) k_gemm_hx2_kmajor(const Hx2KmArgs p) 
         const int pc = 4 * i + wid, s = 64 * (pc & 7) + lane, k = s >> 4, phys = s & 15;
         a_k[i] = k;
         a_col[i] = min(m0 + 16 * ((phys >> 1) ^ ka_h(k)) + 8 * (phys & 1), p.m_ld - 8);
+        if (a_col[i] >= p.a_shared_m) a_col[i] += static_cast<int>(bz * p.a_bs);        // its batch entry's columns; shared ones stay at entry 0
     }
     // ---- B: piece pc = 4 i + wave (14 per plane), slot s = 64 (pc % 14) + lane = (k = s / 28, physical slot s % 28);
     //      the physical slot holds logical slot phys - 2 [k & 8] (the two padding slots re-read slot 0)
@@ -302,7 +307,7 @@ __global__ void __launch_bounds__(NT, OCC) k_gemm_hx2_kmajor(const Hx2KmArgs p) 
         b_k[i] = k;
         b_col[i] = min(n0 + 8 * slot, p.n_ld - 8);
     }
-    const _Float16* abase = p.Ap + bz * p.a_bs;
+    const _Float16* abase = p.Ap;                                    // the batch entry's offset rides in a_col (see a_shared_m)
     const _Float16* bbase = p.Bp + bz * p.b_bs;
     const _Float16* zlane = p.zeros + 8 * lane;
     auto dma = [&](int k0) {
@@ -528,7 +533,7 @@ bool hx2_supported(const void* Ap, int64_t a_plane, int64_t a_row, int64_t a_bs,
 
 // A: half planes, element (plane q, batch z, row m, k) at Ap[q*a_plane + z*a_bs + m*a_row + k]; B planes [2][batch][N][hx2_kp(K)]
 int gemm_hx2_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t a_plane, int64_t a_row, int64_t a_bs, const void* Bplanes,
-                     const OutputDesc& C, const GemmBatch& bt, const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st) {
+                     const OutputDesc& C, const GemmBatch& bt, const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st, int32_t a_shared_k) {
     if (M < 0 || N < 0 || K < 0 || bt.batch < 0) return RECON_ERR_INVALID;
     if (M == 0 || N == 0 || bt.batch == 0) return RECON_OK;
     if (!Ap || !Bplanes || !C.base) return RECON_ERR_INVALID;
@@ -546,6 +551,8 @@ int gemm_hx2_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t a_
     a.c_vec4 = (!(N & 3) && !(bt.c_bs & 3) && !(reinterpret_cast<uintptr_t>(C.base) & 15) && !(C.S1 & 3) && !(C.S2 & 3) && !(C.Sseg & 3) &&
                 (C.Dseg >= N || !(C.Dseg & 3))) ? 1 : 0;
     a.xcd_remap = 1;
+    if (a_shared_k < 0 || (a_shared_k & 7) || (a_shared_k && a_bs * bt.batch >= (1LL << 31))) return RECON_ERR_INVALID;
+    a.a_shared_k = a_shared_k;
     a.c_plain = (a.c_vec4 && !C.scatter && C.P >= M && C.Dseg >= N && (static_cast<int64_t>(M) * C.S1 + N) * 4 < (1LL << 31)) ? 1 : 0;   // plain rows: the straight-line store
     a.sa = sa; a.sb = sb;
     const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, BM)), static_cast<unsigned>(bt.batch));
@@ -567,7 +574,7 @@ bool hx2_kmajor_supported(const void* Ap, int64_t lda, int64_t a_plane, int64_t 
 // split_k must be bx3_kmajor_splits(K, requested) (same K-tile rounding as the bf16 x 3 kernel)
 int gemm_hx2_kmajor_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t lda, int64_t a_plane, int64_t a_bs, const void* Bp,
                             int64_t ldb, int64_t b_plane, int64_t b_bs, int32_t batch, int32_t split_k, float* partial, const void* zeros,
-                            const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st) {
+                            const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st, int32_t a_shared_m) {
     if (M < 0 || N < 0 || K < 0 || batch < 0 || split_k < 1) return RECON_ERR_INVALID;
     if (M == 0 || N == 0 || batch == 0) return RECON_OK;
     if (!Ap || !Bp || !partial || !zeros || (reinterpret_cast<uintptr_t>(zeros) & 15)) return RECON_ERR_INVALID;
@@ -584,6 +591,8 @@ int gemm_hx2_kmajor_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int
     if (a.nsplit != split_k) return RECON_ERR_INVALID;
     if (static_cast<int64_t>(batch) * split_k > 65535) return RECON_ERR_UNSUPPORTED;
     a.sa = sa; a.sb = sb;
+    if (a_shared_m < 0 || (a_shared_m & 7) || a_bs * batch + lda >= (1LL << 31)) return RECON_ERR_UNSUPPORTED;      // a_col carries the batch offset as int
+    a.a_shared_m = a_shared_m;
     const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, BM)), static_cast<unsigned>(batch * split_k));
     hipLaunchKernelGGL((k_gemm_hx2_kmajor<2>), grid, dim3(NT), 0, st, a);      // three workgroups per CU (<= 168 registers) spill: 241 us against 70
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;

@@ -299,12 +299,12 @@ int hx2_split_planes_both(const float* src, int64_t src_bs, int32_t R, int32_t C
                           hipStream_t st, uint32_t* blkmax_quantity = nullptr, int32_t nblk = 0);
 bool hx2_supported(const void* Ap, int64_t a_plane, int64_t a_row, int64_t a_bs, int32_t K);
 int gemm_hx2_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t a_plane, int64_t a_row, int64_t a_bs, const void* Bplanes,
-                     const OutputDesc& C, const GemmBatch& bt, const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st);
+                     const OutputDesc& C, const GemmBatch& bt, const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st, int32_t a_shared_k = 0);
 bool hx2_kmajor_supported(const void* Ap, int64_t lda, int64_t a_plane, int64_t a_bs, const void* Bp, int64_t ldb, int64_t b_plane,
                           int64_t b_bs, int32_t M, int32_t N);
 int gemm_hx2_kmajor_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t lda, int64_t a_plane, int64_t a_bs, const void* Bp,
                             int64_t ldb, int64_t b_plane, int64_t b_bs, int32_t batch, int32_t split_k, float* partial, const void* zeros,
-                            const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st);
+                            const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st, int32_t a_shared_m = 0);
 // C = epilogue(sum over splits of partial[batch][split][M][N]) through C's addressing; transpose: element (m, n) -> C(n, m)
 int splitk_reduce(const float* partial, int32_t splits, int32_t M, int32_t N, const OutputDesc& C, int64_t c_bs, int32_t batch,
                   int32_t epilogue, bool transpose, hipStream_t st);
