@@ -175,7 +175,9 @@ typedef struct {
                                  * RECON_SPLIT_F16X2 (csrc/gemm_hx2.hip; needs (2F+R) % 8 == 0, D % 8 == 0,  *
                                  * else the call falls back to BF16X3) the buffers keep their sizes but hold  *
                                  * HALF planes: a_split the two planes of a and a^T, V the two planes         *
-                                 * [2][N*H][2F+R] of s_V * V instead of fp32 V, gh_split the two planes of g_h */
+                                 * [2][N*H][2F+R] of s_V * V instead of fp32 V (head-major rows; when keep is  *
+                                 * NULL the first F columns exist for head 0 only — they are the same for all  *
+                                 * heads — and V is an opaque workspace), gh_split the two planes of g_h        */
     float keep_max;             /* upper bound of the factors in `keep` (1/(1-p)); ignored when keep is NULL  */
     void* aux;                  /* RECON_SPLIT_F16X2: recon_hx2_aux_bytes() bytes, 256-byte aligned, workspace *
                                  * / saved: max-magnitude slots of a, x, edge_embed, grad_out (the per-tensor   *
