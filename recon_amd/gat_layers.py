@@ -36,6 +36,7 @@ _OVERLAP = os.environ.get("RECON_OVERLAP", "0") == "1"
 #   2: f16 x 2 always (falls back to bf16 x 3 per shape)   1: bf16 x 3 always (csrc/gemm_bx3.hip)   0: exact fp32 always
 _GEMM_BX3 = os.environ.get("RECON_GEMM_BX3", "auto")
 _BX3_MIN_FLOP = 6.0e9
+_HX2_MIN_FLOP = 1.0e9     # f16 x 2: operands arrive pre-split from their producers, so it pays from smaller products on (cfg 2 at D = 25 -> 32: 2.5 GFLOP, 1.00 -> 0.94 ms per SpGAT step)
 SPLIT_BF16X3, SPLIT_F16X2 = 0, 2
 _SIDE_STREAMS = {}
 
@@ -246,15 +247,18 @@ def _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out,
                            float(keep_max), _p(aux))
 
 
+_PAD_MIN_OUT = 1 << 18            # below this many output elements the padding's extra launches cost more than the aligned GEMMs win
+
+
 def _atp_split_mode(F_, R, D, H, N=None):
     """0: exact-fp32 MFMA GEMMs, 1: bf16 x 3, 2: f16 x 2 (see _GEMM_BX3 above)."""
     if _GEMM_BX3 == "0":
         return 0
-    if _GEMM_BX3 not in ("1", "2") and N is not None and 2.0 * N * (2 * F_ + R) * H * D < _BX3_MIN_FLOP:
+    flop = 2.0 * N * (2 * F_ + R) * H * D if N is not None else float("inf")
+    hx2 = _GEMM_BX3 != "1" and _lib.lib().recon_gat_atp_f16x2_supported(F_, R, D, H) == 1
+    if _GEMM_BX3 not in ("1", "2") and flop < (_HX2_MIN_FLOP if hx2 else _BX3_MIN_FLOP):
         return 0
-    if _GEMM_BX3 != "1" and _lib.lib().recon_gat_atp_f16x2_supported(F_, R, D, H) == 1:
-        return 2
-    return 1
+    return 2 if hx2 else 1
 
 
 def _atp_split_buffer(F_, R, D, H, dev, N=None):
@@ -438,6 +442,17 @@ def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=Tru
         out = gat_heads(x.float(), edge_embed_all.float(), a.float(), a_2.float(), graph, keep, alpha, concat, keep_max)
         return out.to(x.dtype)
     if gat_path_for(graph.N, graph.E, x.shape[1], edge_embed_all.shape[1], D, H) == "atp":
+        Dp = (D + 7) // 8 * 8
+        if Dp != D and graph.N * H * D >= _PAD_MIN_OUT:
+            # Heads whose width is not a multiple of 8 (the reference's D = 25 per head) run as Dp-wide heads with zero rows appended to
+            # `a` and `a_2`: the extra output columns are act(0) = 0 and are dropped, the extra gradient rows are dropped by autograd.
+            # Unpadded, the head offsets h * D are not 16-byte aligned and the three products fall back to scalar-load GEMMs (the
+            # weight gradient alone: 188 us at cfg 2 with D = 25).
+            N = x.shape[0]
+            a_p = torch.nn.functional.pad(a, (0, 0, 0, Dp - D))
+            a2_p = torch.nn.functional.pad(a_2, (0, Dp - D))
+            out_p = _GATHeadsATPFunction.apply(x, edge_embed_all, a_p, a2_p, graph, keep, alpha, concat, keep_max)
+            return out_p.view(N, H, Dp)[:, :, :D].reshape(N, H * D)
         return _GATHeadsATPFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat, keep_max)
     return _GATHeadsFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat)
 
