@@ -479,6 +479,36 @@ def test_power_law_graphs(path, monkeypatch):
     close(xd.grad, gx, atol=1e-4, what="g_x")
 
 
+def test_heads_of_width_25_run_padded():
+    """The reference's D = 25 per head (H * D = 200): above `_PAD_MIN_OUT` output elements `gat_heads` runs the heads 32 wide with
+    zero rows appended to `a` / `a_2` and drops the extra columns; outputs and every gradient against the oracle, unpadded."""
+    from recon_amd import gat_layers
+    from recon_amd.graph import prepare_graph
+    d = dev()
+    B, n, e, F_, R, D, H = 160, 16, 64, 200, 200, 25, 8
+    N = B * n
+    assert N * H * D >= gat_layers._PAD_MIN_OUT
+    x, edge, ee = O.synthetic_batched_graph(B, n, e, F_, R, seed=2)
+    g = torch.Generator().manual_seed(3)
+    a = torch.stack([O.xavier_normal((D, 2 * F_ + R), 1.414, g) for _ in range(H)])
+    a2 = torch.cat([O.xavier_normal((1, D), 1.414, g) for _ in range(H)])
+    G = torch.randn(N, H * D, generator=g)
+    leaves = [t.to(d).requires_grad_(True) for t in (x, ee, a, a2)]
+    out = gat_layers.gat_heads(*leaves, prepare_graph(edge.to(d), None, N), None, 0.2, True)
+    assert out.shape == (N, H * D)
+    (out * G.to(d)).sum().backward()
+    gx, gee = torch.zeros_like(x), torch.zeros_like(ee)
+    for h in range(H):
+        r = O.gat_layer_backward(x.double(), edge, ee.double(), None, None, a[h].double(), a2[h:h + 1].double(), 0.2, True,
+                                 G[:, h * D:(h + 1) * D].double())
+        close(out[:, h * D:(h + 1) * D], r["out"].float(), what="D=25 out h%d" % h)
+        close(leaves[2].grad[h], r["g_a"].float(), atol=1e-4, what="g_a h%d" % h)
+        close(leaves[3].grad[h], r["g_a_2"].float().view(-1), atol=1e-4, what="g_a_2 h%d" % h)
+        gx += r["g_x"].float(); gee += r["g_edge_embed"].float()
+    close(leaves[0].grad, gx, atol=1e-4, what="g_x")
+    close(leaves[1].grad, gee, atol=1e-4, what="g_edge_embed")
+
+
 def test_cfg5_bf16_gat_then_gcn_stack():
     """BASELINE.json configs[4] in its stated dtype: power-law graphs, an H-head GAT layer with bf16 features in and out (fp32
     kernels inside), followed by a 3-layer bf16 GraphConvolution stack on the same node features, forward and backward.  Against
