@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RECON_ABI_VERSION 1
+#define RECON_ABI_VERSION 2
 
 enum {
     RECON_OK = 0,
@@ -58,9 +58,33 @@ typedef struct {
     int32_t* dst;               /* [E]   destination node of each CSR slot                   */
     int32_t* rowptr_src;        /* [N+1] CSC over sources                                    */
     int32_t* slot_by_src;       /* [E]   CSC position -> CSR slot                            */
+    /* Hub rows (optional; all zero = every destination row is walked by one wave, whatever its length).  The aggregate-then-
+     * project edge kernels give one wavefront to one destination node; a node with hundreds of in-edges (power-law graphs)
+     * is then one long serial chain.  With these tables a row of more than hub_chunk slots is cut into pieces of at most
+     * hub_chunk slots, each walked by its own wavefront, and summed in table order by a second small launch: results do not
+     * depend on scheduling.  Filled by recon_graph_hubs_count() + recon_graph_hubs_fill().                              */
+    int32_t hub_chunk;          /* slots per piece (RECON_HUB_CHUNK), 0: no splitting                                    */
+    int32_t n_hub;              /* destination nodes with more than hub_chunk slots                                      */
+    int32_t n_piece;            /* their pieces                                                                          */
+    int32_t* hub_node;          /* [n_hub]     node id, ascending                                                        */
+    int32_t* hub_ptr;           /* [n_hub + 1] first piece of each hub                                                   */
+    int32_t* piece;             /* [n_piece][4] (node, first slot, end slot, hub ordinal), 16-byte aligned               */
+    float* hub_ws;              /* scratch of the piece partial sums, reused by every call on this graph (calls on one graph
+                                   are stream ordered): at least recon_graph_hub_ws_floats() floats for the widest layer   */
+    int64_t hub_ws_floats;
 } recon_graph;
 
+#define RECON_HUB_CHUNK 64
+
 size_t recon_graph_workspace_bytes(int32_t N, int32_t E);
+/* Hub tables of a built graph.  count: one pass over rowptr_dst, synchronises the stream and returns the table sizes (0, 0: nothing
+ * to do).  fill: the caller has set hub_chunk / n_hub / n_piece to what count returned and hub_node, hub_ptr, piece to device
+ * arrays of those sizes.  hub_ws may be set (or grown) at any time before a layer call. */
+int recon_graph_hubs_count(const recon_graph* g, int32_t chunk, void* workspace /* device, 8 bytes */, int32_t* n_hub, int32_t* n_piece,
+                           recon_stream_t stream);
+int recon_graph_hubs_fill(const recon_graph* g, recon_stream_t stream);
+/* floats of hub_ws one KB-GAT layer call (forward or backward) on this graph needs */
+size_t recon_graph_hub_ws_floats(const recon_graph* g, int32_t F, int32_t R, int32_t H);
 
 /* edge_dst / edge_src: the two rows of the reference's int64 [2,E] edge tensor (row 0 =
  * aggregation target, row 1 = neighbour; GAT/create_batch.py:429-433).  Returns RECON_ERR_INVALID

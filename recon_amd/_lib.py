@@ -21,7 +21,9 @@ c_i64p = C.c_void_p
 class ReconGraph(C.Structure):
     _fields_ = [("N", C.c_int32), ("E", C.c_int32),
                 ("rowptr_dst", c_i32p), ("eid", c_i32p), ("src", c_i32p), ("dst", c_i32p),
-                ("rowptr_src", c_i32p), ("slot_by_src", c_i32p)]
+                ("rowptr_src", c_i32p), ("slot_by_src", c_i32p),
+                ("hub_chunk", C.c_int32), ("n_hub", C.c_int32), ("n_piece", C.c_int32),
+                ("hub_node", c_i32p), ("hub_ptr", c_i32p), ("piece", c_i32p), ("hub_ws", c_f32p), ("hub_ws_floats", C.c_int64)]
 
 
 class GatFwdArgs(C.Structure):
@@ -96,6 +98,9 @@ SYMBOLS = [
     ("recon_error_string", C.c_char_p, [C.c_int]),
     ("recon_graph_workspace_bytes", C.c_size_t, [C.c_int32, C.c_int32]),
     ("recon_graph_build", C.c_int, [c_i64p, c_i64p, C.POINTER(ReconGraph), C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("recon_graph_hubs_count", C.c_int, [C.POINTER(ReconGraph), C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]),
+    ("recon_graph_hubs_fill", C.c_int, [C.POINTER(ReconGraph), C.c_void_p]),
+    ("recon_graph_hub_ws_floats", C.c_size_t, [C.POINTER(ReconGraph), C.c_int32, C.c_int32, C.c_int32]),
     ("recon_spmm_rowsum_workspace_floats", C.c_size_t, [C.c_int32, C.c_int32]),
     ("recon_spmm_rowsum_fwd", C.c_int, [C.POINTER(ReconGraph), c_f32p, C.c_int32, c_f32p, c_f32p, C.c_void_p]),
     ("recon_spmm_rowsum_bwd", C.c_int, [c_i64p, C.c_int64, c_f32p, C.c_int32, c_f32p, C.c_void_p]),
@@ -172,7 +177,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.recon_version() != 1:
+        if h.recon_version() != 2:
             raise RuntimeError("librecon_hip.so ABI version mismatch")
         _lib = h
     return _lib

@@ -147,7 +147,83 @@ int radix_sort_pairs(SortWs& ws, int32_t n, int32_t key_range, int32_t** kout, i
     return RECON_OK;
 }
 
+// Hub tables (recon_hip.h): destination rows longer than `chunk` slots, in node order, cut into pieces of <= chunk slots.
+// ONE workgroup walks rowptr 1024 nodes at a time and hands out table positions with a block-wide exclusive scan, so that the
+// tables are ordered and the same on every run; hubs are rare and the graph is cached (1 M nodes: ~1 ms, once).
+template <bool FILL>
+__global__ void __launch_bounds__(1024) k_hub_scan(const int32_t* __restrict__ rowptr, int32_t N, int32_t chunk, int32_t* __restrict__ counts,
+                                                   int32_t* __restrict__ hub_node, int32_t* __restrict__ hub_ptr, int4* __restrict__ piece) {
+    __shared__ int wave_h[16], wave_p[16];
+    __shared__ int base[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { base[0] = 0; base[1] = 0; }
+    __syncthreads();
+    for (int i0 = 0; i0 < N; i0 += 1024) {
+        const int i = i0 + tid;
+        int beg = 0, deg = 0;
+        if (i < N) { beg = rowptr[i]; deg = rowptr[i + 1] - beg; }
+        const int hub = deg > chunk ? 1 : 0;
+        const int np = hub ? (deg + chunk - 1) / chunk : 0;
+        int sh = hub, sp = np;                                            // inclusive scans inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int th = __shfl_up(sh, d), tp = __shfl_up(sp, d);
+            if (lane >= d) { sh += th; sp += tp; }
+        }
+        if (lane == 63) { wave_h[wave] = sh; wave_p[wave] = sp; }
+        __syncthreads();
+        int oh = base[0], op = base[1];
+        for (int w = 0; w < wave; ++w) { oh += wave_h[w]; op += wave_p[w]; }
+        if (FILL && hub) {
+            const int t = oh + sh - 1, p0 = op + sp - np;
+            hub_node[t] = i; hub_ptr[t] = p0;
+            for (int q = 0; q < np; ++q) {
+                const int b = beg + q * chunk;
+                piece[p0 + q] = make_int4(i, b, min(b + chunk, beg + deg), t);
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) { base[0] = oh + sh; base[1] = op + sp; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (FILL) hub_ptr[base[0]] = base[1];
+        else { counts[0] = base[0]; counts[1] = base[1]; }
+    }
+}
+
 }  // namespace
+
+extern "C" int recon_graph_hubs_count(const recon_graph* g, int32_t chunk, void* workspace, int32_t* n_hub, int32_t* n_piece, recon_stream_t stream) {
+    if (!g || !n_hub || !n_piece || chunk <= 0 || g->N < 0 || !g->rowptr_dst) return RECON_ERR_INVALID;
+    *n_hub = 0; *n_piece = 0;
+    if (g->N == 0 || g->E <= chunk) return RECON_OK;
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 3)) return RECON_ERR_INVALID;
+    hipStream_t st = as_stream(stream);
+    int32_t* d = static_cast<int32_t*>(workspace);
+    hipLaunchKernelGGL((k_hub_scan<false>), dim3(1), dim3(1024), 0, st, g->rowptr_dst, g->N, chunk, d, nullptr, nullptr, nullptr);
+    RECON_CHECK_LAUNCH();
+    int32_t h[2] = {0, 0};
+    if (hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return RECON_ERR_LAUNCH;
+    *n_hub = h[0]; *n_piece = h[1];
+    return RECON_OK;
+}
+
+extern "C" int recon_graph_hubs_fill(const recon_graph* g, recon_stream_t stream) {
+    if (!g || g->N < 0 || !g->rowptr_dst || g->hub_chunk <= 0 || g->n_hub < 0 || g->n_piece < 0) return RECON_ERR_INVALID;
+    if (g->n_hub == 0) return RECON_OK;
+    if (!g->hub_node || !g->hub_ptr || !g->piece || (reinterpret_cast<uintptr_t>(g->piece) & 15)) return RECON_ERR_INVALID;
+    hipLaunchKernelGGL((k_hub_scan<true>), dim3(1), dim3(1024), 0, as_stream(stream), g->rowptr_dst, g->N, g->hub_chunk, nullptr, g->hub_node,
+                       g->hub_ptr, reinterpret_cast<int4*>(g->piece));
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+// per piece and head: the partial sums of the source and relation parts (F + R) and of Z, Zk (forward); the backward needs H
+extern "C" size_t recon_graph_hub_ws_floats(const recon_graph* g, int32_t F, int32_t R, int32_t H) {
+    if (!g || g->n_piece <= 0 || F <= 0 || R <= 0 || H <= 0) return 0;
+    return static_cast<size_t>(g->n_piece) * H * (static_cast<size_t>(F) + R + 2);
+}
 
 extern "C" size_t recon_graph_workspace_bytes(int32_t N, int32_t E) {
     (void)N;

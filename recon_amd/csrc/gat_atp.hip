@@ -504,6 +504,12 @@ struct AtpFwdK {
                                 // every head's copy is the same row; the GEMMs read head 0's (a_shared_k / a_shared_m)
     int32_t planes;             // 1 (2: with paired 16-byte stores, F % 8 == 0 and R % 8 == 0): V is written as half terms [H][N][2][W] of s_V * V (gemm_hx2.hip: high row | low row) instead of fp32 [N][H][W]
     Hx2Scale vs;                // s_V from max(|x|, |edge_embed|) * keep_max, an upper bound of |V| (V rows are k-weighted means)
+    // hub rows (recon_graph): the first n_piece waves of the grid walk one piece each and leave UNNORMALISED partial sums in hubS
+    // [n_piece][H][F + R] and hubZ [n_piece][2][H]; the wave of a node with more than hub_chunk slots does nothing, and
+    // k_gat_atp_hub_fwd sums the pieces in table order, normalises and writes the node's V / Z / Zk.  hub_chunk = 0: off.
+    int32_t hub_chunk, n_piece;
+    const int4* piece;
+    float* hubS; float* hubZ;
 };
 
 // two half planes of VEC consecutive ALREADY SCALED values: 2 * VEC bytes per plane.  Values are clamped to half's range: the
@@ -567,8 +573,17 @@ __global__ void __launch_bounds__(kBlock, KR >= 8 ? 2 : 1) k_gat_atp_fwd(const A
     constexpr int NPW = kK1NodesPerWave;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int first = xcd_block(blockIdx.x, gridDim.x) * ((kBlock / 64) * NPW) + wave;
-    if (first >= p.N) return;
+    static_assert(NPW == 1, "hub pieces are handed out one per wave");
+    // pieces first (they are the longest rows of the launch), in blockIdx order so that they are dealt round over the XCDs; the
+    // nodes behind them in XCD-contiguous ranges
+    const int npb = (p.n_piece + kBlock / 64 - 1) / (kBlock / 64);
+    const bool is_piece = static_cast<int>(blockIdx.x) < npb;
+    const int widx = blockIdx.x * (kBlock / 64) + wave;                  // piece id when is_piece
+    int first = xcd_block(blockIdx.x - npb, gridDim.x - npb) * ((kBlock / 64) * NPW) + wave, pbeg = 0, pend = 0;
+    if (is_piece) {
+        if (widx >= p.n_piece) return;
+        const int4 pc = p.piece[widx]; first = pc.x; pbeg = pc.y; pend = pc.z;
+    } else if (first >= p.N) return;
     const int F = p.F, R = p.R, H = p.H, W = 2 * F + R;
     const int h0 = blockIdx.y * HT;
     const int myh = h0 + (lane % HT);
@@ -593,6 +608,8 @@ __global__ void __launch_bounds__(kBlock, KR >= 8 ? 2 : 1) k_gat_atp_fwd(const A
         const int nd = min(first + (kBlock / 64) * i, p.N - 1);
         begs[i] = p.rowptr[nd]; ends[i] = p.rowptr[nd + 1];
     }
+    if (is_piece) { begs[0] = pbeg; ends[0] = pend; }
+    else if (p.hub_chunk && ends[0] - begs[0] > p.hub_chunk) return;    // a hub: its pieces and k_gat_atp_hub_fwd write this node
     struct NodeIn { int srcv, eidv; float cd; float xi[KR][VEC]; };
     auto request = [&](NodeIn& q, int node, int beg, int end) {         // node < N
         q.srcv = 0; q.eidv = 0;
@@ -671,6 +688,21 @@ __global__ void __launch_bounds__(kBlock, KR >= 8 ? 2 : 1) k_gat_atp_fwd(const A
                 }
             }
         }
+        if (is_piece) {                                                  // wave-uniform: partial sums, nothing normalised
+            if (hv && lane < HT) { p.hubZ[(static_cast<int64_t>(widx) * 2) * H + myh] = Zl; p.hubZ[(static_cast<int64_t>(widx) * 2 + 1) * H + myh] = Zkl; }
+#pragma unroll
+            for (int h = 0; h < HT; ++h) {
+                if (h0 + h < H) {
+                    float* dst = p.hubS + (static_cast<int64_t>(widx) * H + h0 + h) * (F + R);
+#pragma unroll
+                    for (int r = 0; r < KR; ++r) {
+                        if (aF[r]) store_vec<VEC>(dst + cf[r], accS[h][r]);
+                        if (aR[r]) store_vec<VEC>(dst + F + cf[r], accR[h][r]);
+                    }
+                }
+            }
+            return;
+        }
         const float Zc = (Zl == 0.f) ? 1e-12f : Zl;                     // GAT/layers.py:152
         const float inv = 1.f / Zc;
         if constexpr (TRAIN) {
@@ -720,6 +752,54 @@ __global__ void __launch_bounds__(kBlock, KR >= 8 ? 2 : 1) k_gat_atp_fwd(const A
     }
 }
 
+// The second half of a hub's forward: wave = one (hub, head).  Sums the pieces' partial sums in table order (fixed: results do not
+// depend on scheduling), normalises as the epilogue above does and writes the node's V rows, Z and Zk.  8-byte plane stores: hubs are few.
+template <int VEC, int PL>
+__global__ void __launch_bounds__(kBlock) k_gat_atp_hub_fwd(const AtpFwdK p, const int32_t* __restrict__ hub_node, const int32_t* __restrict__ hub_ptr,
+                                                            int32_t n_hub) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int idx = blockIdx.x * (kBlock / 64) + wave;
+    const int F = p.F, R = p.R, H = p.H, W = 2 * F + R;
+    if (idx >= n_hub * H) return;
+    const int t = idx / H, h = idx - t * H;
+    const int node = hub_node[t], p0 = hub_ptr[t], p1 = hub_ptr[t + 1];
+    const float vscale = PL ? hx2_scale_wave(p.vs) : 1.f;
+    float Zl = 0.f, Zkl = 0.f;
+    for (int q = p0; q < p1; ++q) { Zl += p.hubZ[(static_cast<int64_t>(q) * 2) * H + h]; Zkl += p.hubZ[(static_cast<int64_t>(q) * 2 + 1) * H + h]; }
+    const float Zc = (Zl == 0.f) ? 1e-12f : Zl;                         // GAT/layers.py:152
+    if (p.Z && lane == 0) { p.Z[static_cast<int64_t>(node) * H + h] = Zc; p.Zk[static_cast<int64_t>(node) * H + h] = Zkl; }
+    const float invh = (1.f / Zc) * vscale, zk = Zkl * invh;
+    float* Vr = p.V + (static_cast<int64_t>(node) * H + h) * W;
+    _Float16* Vh = reinterpret_cast<_Float16*>(p.V) + 2 * (static_cast<int64_t>(h) * p.N + node) * W;
+    auto put = [&](int col, const float (&o)[VEC]) {
+        if constexpr (PL == 0) store_vec<VEC>(Vr + col, o);
+        else store_planes<VEC>(Vh + col, W, o);
+    };
+    for (int c = lane * VEC; c < F + R; c += 64 * VEC) {                // partial sums [F | R] are columns F .. of V
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        for (int q = p0; q < p1; ++q) {
+            float tv[VEC];
+            load_vec<VEC>(tv, p.hubS + (static_cast<int64_t>(q) * H + h) * (F + R) + c);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] += tv[v];
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] *= invh;
+        put(F + c, acc);
+    }
+    if (!(p.dst_shared && h > 0)) {
+        for (int c = lane * VEC; c < F; c += 64 * VEC) {
+            float xv[VEC];
+            load_vec<VEC>(xv, p.x + static_cast<int64_t>(node) * F + c);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) xv[v] *= zk;
+            put(c, xv);
+        }
+    }
+}
 
 struct AtpBwdK {
     const int32_t* rowptr; const int32_t* src; const int32_t* eid;
@@ -728,6 +808,12 @@ struct AtpBwdK {
     float* gsigma; float* Gs_dst; float* Gxs; float* gxd; float* g_ee;
     int32_t N, E, F, R, H;
     float alpha;
+    // hub rows (recon_graph): the first n_piece waves walk one piece each and leave their sum of g_sigma in hubG [n_piece][H] (and
+    // store no g_x row); the wave of a node with more than hub_chunk slots walks none of them (it still writes the direct part of
+    // g_x and zero sums), and k_gat_atp_hub_bwd adds the pieces' sums in table order.  hub_chunk = 0: off.
+    int32_t hub_chunk, n_piece;
+    const int4* piece;
+    float* hubG;
 };
 
 // wave = one destination node; head groups of HT are walked one after the other by the SAME wave so the
@@ -743,12 +829,22 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
     const int F = p.F, R = p.R, H = p.H, W = 2 * F + R;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int node = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + wave;
+    // pieces first (they are the longest rows of the launch), in blockIdx order so that they are dealt round over the XCDs; the
+    // nodes behind them in XCD-contiguous ranges
+    const int npb = (p.n_piece + kBlock / 64 - 1) / (kBlock / 64);
+    const int widx = blockIdx.x * (kBlock / 64) + wave;                  // piece id in a piece block
+    const bool is_piece = static_cast<int>(blockIdx.x) < npb && widx < p.n_piece;
+    int node = static_cast<int>(blockIdx.x) < npb ? p.N : xcd_block(blockIdx.x - npb, gridDim.x - npb) * (kBlock / 64) + wave;
     // The walk is a chain of dependent round trips (row pointers -> slot indices -> rows); start it before anything else:
     // the slot -> (source node, edge id) indices of the first 64 slots come with ONE coalesced load per array (lane j holds
     // slot beg + j) and are handed out with v_readlane instead of an index load in front of every row load.
-    const int nodec = min(node, p.N - 1);
-    const int beg = p.rowptr[nodec], end = p.rowptr[nodec + 1];
+    int beg, end;
+    if (is_piece) { const int4 pc = p.piece[widx]; node = pc.x; beg = pc.y; end = pc.z; }
+    else {
+        const int nodec = min(node, p.N - 1);
+        beg = p.rowptr[nodec]; end = p.rowptr[nodec + 1];
+        if (p.hub_chunk && end - beg > p.hub_chunk) end = beg;           // a hub: its pieces walk the row
+    }
     const int cn0 = min(64, end - beg);
     int srcv0 = 0, eidv0 = 0;
     if (beg < end) { const int kk = beg + min(lane, cn0 - 1); srcv0 = p.src[kk]; eidv0 = p.eid[kk]; }
@@ -970,7 +1066,10 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                 for (int u = 0; u < PF; ++u) fetch_edge(u, min(u, cn - 1));
             }
         }
-        if (hv && writer) p.Gs_dst[static_cast<int64_t>(node) * 2 * H + myh] = sum_gs;
+        if (hv && writer) {
+            if (is_piece) p.hubG[static_cast<int64_t>(widx) * H + myh] = sum_gs;
+            else p.Gs_dst[static_cast<int64_t>(node) * 2 * H + myh] = sum_gs;
+        }
 #pragma unroll
         for (int h = 0; h < HT; ++h) {
             if (h0 + h < H) {
@@ -987,9 +1086,40 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
             }
         }
     }
+    if (is_piece) return;                                                // k_gat_atp_hub_bwd adds the pieces' share to the node's row
 #pragma unroll
     for (int r = 0; r < KR; ++r)
         if (aF[r]) store_vec<VEC>(p.gxd + static_cast<int64_t>(node) * F + cf[r], gxd[r]);
+}
+
+// The second half of a hub's backward: wave = one hub.  Adds the pieces' sums of g_sigma in table order to Gs_dst (the node's own
+// wave wrote zeros) and their share sum_h S_h u_dst[h] to the node's g_x row.  H <= 64 (one head per lane).
+template <int VEC>
+__global__ void __launch_bounds__(kBlock) k_gat_atp_hub_bwd(const AtpBwdK p, const int32_t* __restrict__ hub_node, const int32_t* __restrict__ hub_ptr,
+                                                            int32_t n_hub) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = blockIdx.x * (kBlock / 64) + wave;
+    const int F = p.F, R = p.R, H = p.H, W = 2 * F + R;
+    if (t >= n_hub) return;
+    const int node = hub_node[t], p0 = hub_ptr[t], p1 = hub_ptr[t + 1];
+    float tot = 0.f;
+    if (lane < H) {
+        for (int q = p0; q < p1; ++q) tot += p.hubG[static_cast<int64_t>(q) * H + lane];
+        p.Gs_dst[static_cast<int64_t>(node) * 2 * H + lane] += tot;
+    }
+    for (int c = lane * VEC; c < F; c += 64 * VEC) {
+        float o[VEC];
+        load_vec<VEC>(o, p.gxd + static_cast<int64_t>(node) * F + c);
+        for (int h = 0; h < H; ++h) {
+            const float sh = lane_bcast(tot, h);
+            float ud[VEC];
+            load_vec<VEC>(ud, p.u + static_cast<int64_t>(h) * W + c);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o[v] = fmaf(sh, ud[v], o[v]);
+        }
+        store_vec<VEC>(p.gxd + static_cast<int64_t>(node) * F + c, o);
+    }
 }
 
 // CSC walk: g_x[j] = gxd[j] + sum_{e: src_e = j} Gxs[slot];  Gs_src[j][h] = sum gsigma[slot][h]
@@ -1274,6 +1404,10 @@ static int32_t atp_dst_shared(const recon_gat_atp_args* a) {
     const int64_t W = 2LL * a->F + a->R;
     return (atp_hx2(a) && !a->keep && a->H > 1 && (a->F % 8) == 0 && 2 * W * a->N * a->H < (1LL << 31)) ? a->F : 0;
 }
+// hub tables present and complete (recon_graph_hubs_fill)
+static bool atp_hubs(const recon_graph* g) {
+    return g->hub_chunk > 0 && g->n_hub > 0 && g->n_piece > 0 && g->hub_node && g->hub_ptr && g->piece && g->hub_ws;
+}
 static uint32_t* atp_q(const recon_gat_atp_args* a, int q) { return static_cast<uint32_t*>(a->aux) + q * kHx2QuantityWords; }
 static Hx2Scale atp_scale_a(const recon_gat_atp_args* a) { return Hx2Scale{atp_q(a, 0), nullptr, 1.f}; }
 static Hx2Scale atp_scale_v(const recon_gat_atp_args* a) {
@@ -1371,7 +1505,13 @@ extern "C" int recon_gat_atp_aggregate(const recon_graph* g, const recon_gat_atp
     p.planes = atp_hx2(a) ? ((a->F % 8 == 0 && a->R % 8 == 0) ? 2 : 1) : 0;
     p.dst_shared = atp_dst_shared(a) ? 1 : 0;
     p.vs = p.planes ? atp_scale_v(a) : Hx2Scale{nullptr, nullptr, 1.f};
-    dim3 grid(static_cast<unsigned>(ceil_div64(a->N, (kBlock / 64) * kK1NodesPerWave)), static_cast<unsigned>(ceil_div64(a->H, s.ht)));
+    const bool hubs = atp_hubs(g);
+    if (hubs && static_cast<size_t>(g->hub_ws_floats) < recon_graph_hub_ws_floats(g, a->F, a->R, a->H)) return RECON_ERR_WORKSPACE;
+    p.hub_chunk = hubs ? g->hub_chunk : 0; p.n_piece = hubs ? g->n_piece : 0;
+    p.piece = reinterpret_cast<const int4*>(g->piece);
+    p.hubS = g->hub_ws; p.hubZ = hubs ? g->hub_ws + static_cast<size_t>(g->n_piece) * a->H * (a->F + a->R) : nullptr;
+    dim3 grid(static_cast<unsigned>(ceil_div64(a->N, (kBlock / 64) * kK1NodesPerWave) + ceil_div64(p.n_piece, kBlock / 64)),
+              static_cast<unsigned>(ceil_div64(a->H, s.ht)));
 #define CALL_FWD(V_, K_, H_)                                                                                   \
     do {                                                                                                       \
         if (p.planes == 2 && V_ == 4) { if (train) hipLaunchKernelGGL((k_gat_atp_fwd<V_, K_, H_, true, 2>), grid, dim3(kBlock), 0, st, p);  \
@@ -1383,6 +1523,13 @@ extern "C" int recon_gat_atp_aggregate(const recon_graph* g, const recon_gat_atp
     } while (0)
     ATP_DISPATCH(s, CALL_FWD);
 #undef CALL_FWD
+    if (hubs) {
+        const dim3 gh(static_cast<unsigned>(ceil_div64(1LL * g->n_hub * a->H, kBlock / 64)));
+        if (s.vec == 4) { if (p.planes) hipLaunchKernelGGL((k_gat_atp_hub_fwd<4, 1>), gh, dim3(kBlock), 0, st, p, g->hub_node, g->hub_ptr, g->n_hub);
+                          else hipLaunchKernelGGL((k_gat_atp_hub_fwd<4, 0>), gh, dim3(kBlock), 0, st, p, g->hub_node, g->hub_ptr, g->n_hub); }
+        else { if (p.planes) hipLaunchKernelGGL((k_gat_atp_hub_fwd<2, 1>), gh, dim3(kBlock), 0, st, p, g->hub_node, g->hub_ptr, g->n_hub);
+               else hipLaunchKernelGGL((k_gat_atp_hub_fwd<2, 0>), gh, dim3(kBlock), 0, st, p, g->hub_node, g->hub_ptr, g->n_hub); }
+    }
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }
@@ -1515,10 +1662,19 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         p.q = b->q; p.gV = b->g_V; p.u = a->u;
         p.gsigma = b->g_sigma; p.Gs_dst = b->Gs; p.Gxs = b->Gxs; p.gxd = b->gxd; p.g_ee = b->g_edge_embed;
         p.N = N; p.E = E; p.F = F; p.R = R; p.H = H; p.alpha = a->alpha;
-        dim3 grid(static_cast<unsigned>(ceil_div64(N, kBlock / 64)));
+        const bool hubs = atp_hubs(g);
+        if (hubs && static_cast<size_t>(g->hub_ws_floats) < recon_graph_hub_ws_floats(g, F, R, H)) return RECON_ERR_WORKSPACE;
+        p.hub_chunk = hubs ? g->hub_chunk : 0; p.n_piece = hubs ? g->n_piece : 0;
+        p.piece = reinterpret_cast<const int4*>(g->piece); p.hubG = g->hub_ws;
+        dim3 grid(static_cast<unsigned>(ceil_div64(N, kBlock / 64) + ceil_div64(p.n_piece, kBlock / 64)));
 #define CALL_BWD(V_, K_, H_) hipLaunchKernelGGL((k_gat_atp_bwd<V_, K_, H_>), grid, dim3(kBlock), lds_k2, st, p)
         ATP_DISPATCH(s, CALL_BWD);
 #undef CALL_BWD
+        if (hubs) {
+            const dim3 gh(static_cast<unsigned>(ceil_div64(g->n_hub, kBlock / 64)));
+            if (s.vec == 4) hipLaunchKernelGGL((k_gat_atp_hub_bwd<4>), gh, dim3(kBlock), 0, st, p, g->hub_node, g->hub_ptr, g->n_hub);
+            else hipLaunchKernelGGL((k_gat_atp_hub_bwd<2>), gh, dim3(kBlock), 0, st, p, g->hub_node, g->hub_ptr, g->n_hub);
+        }
         RECON_CHECK_LAUNCH();
     }
     // (3) source-side sums over the CSC view

@@ -357,6 +357,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         elif keep_max is None:                                  # explicit factors without a bound: one host read (tests)
             keep_max = float(keep.max()) if aux is not None and keep.numel() else 1.0
         args = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split, aux, keep_max)
+        graph.reserve_hub_ws(F_, R, H)
         with _on_device(dev):
             _lib.check(L.recon_gat_atp_fwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_atp_fwd")
         if need_grad:
@@ -395,6 +396,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
                         ctx.keep_max)
         args = _lib.GatAtpBwdArgs(fwd, grad_out.data_ptr(), grad_out.shape[1], g_h, g_V, g_sigma, Gxs, gxd, Gs, g_u, q, partial, partial2,
                                   _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2), gh_split)
+        graph.reserve_hub_ws(F_, R, H)
         with _on_device(dev):
             if _OVERLAP and g_a is not None:
                 # PREPARE -> { INPUTS on this stream , WEIGHTS (MFMA-bound GEMM) on a side stream } -> FINISH

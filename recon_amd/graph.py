@@ -16,6 +16,7 @@ from . import _lib
 _CACHE = OrderedDict()
 _CACHE_MAX = 8
 _VALIDATE = os.environ.get("RECON_VALIDATE_EDGES", "1") != "0"
+HUB_CHUNK = 64          # RECON_HUB_CHUNK (include/recon_hip.h); 0 switches the splitting of long destination rows off (tests compare both)
 
 
 class GraphCSR:
@@ -58,6 +59,33 @@ class GraphCSR:
                                      ws_bytes, _lib.current_stream())
         _lib.check(rc, "recon_graph_build")
         self._eid_long = None
+        # hub rows (include/recon_hip.h): destinations with more than HUB_CHUNK in-edges are cut into pieces, one wavefront each
+        self.n_hub = self.n_piece = 0
+        self._hub_ws = None
+        if HUB_CHUNK > 0 and E > HUB_CHUNK:
+            nh, npc = C.c_int32(0), C.c_int32(0)
+            with torch.cuda.device(dev):
+                _lib.check(L.recon_graph_hubs_count(C.byref(self.c), HUB_CHUNK, ws.data_ptr(), C.byref(nh), C.byref(npc),
+                                                    _lib.current_stream()), "recon_graph_hubs_count")
+            if nh.value > 0:
+                self.n_hub, self.n_piece = nh.value, npc.value
+                self.hub_node = torch.empty(self.n_hub, **i32)
+                self.hub_ptr = torch.empty(self.n_hub + 1, **i32)
+                self.piece = torch.empty(self.n_piece, 4, **i32)
+                self.c.hub_chunk, self.c.n_hub, self.c.n_piece = HUB_CHUNK, self.n_hub, self.n_piece
+                self.c.hub_node, self.c.hub_ptr, self.c.piece = self.hub_node.data_ptr(), self.hub_ptr.data_ptr(), self.piece.data_ptr()
+                with torch.cuda.device(dev):
+                    _lib.check(L.recon_graph_hubs_fill(C.byref(self.c), _lib.current_stream()), "recon_graph_hubs_fill")
+
+    def reserve_hub_ws(self, F, R, H):
+        """Scratch of the hub pieces' partial sums for one KB-GAT layer call of these sizes; grows, never shrinks (the calls on one graph
+        are stream ordered and nothing in it outlives a call)."""
+        if self.n_piece == 0:
+            return
+        need = _lib.lib().recon_graph_hub_ws_floats(C.byref(self.c), F, R, H)
+        if self._hub_ws is None or self._hub_ws.numel() < need:
+            self._hub_ws = torch.empty(need, dtype=torch.float32, device=self.device)
+            self.c.hub_ws, self.c.hub_ws_floats = self._hub_ws.data_ptr(), need
 
     @property
     def eid_long(self):

@@ -479,6 +479,103 @@ def test_power_law_graphs(path, monkeypatch):
     close(xd.grad, gx, atol=1e-4, what="g_x")
 
 
+def _hub_graph(N, degs, seed):
+    """Destination i gets degs[i] in-edges (0 for i >= len(degs)), sources uniform, columns shuffled."""
+    rs = np.random.RandomState(seed)
+    dst = np.repeat(np.arange(len(degs)), degs)
+    src = rs.randint(0, N, size=dst.size)
+    perm = rs.permutation(dst.size)
+    return torch.from_numpy(np.stack([dst[perm], src[perm]])).long()
+
+
+def test_hub_tables():
+    """recon_graph_hubs_count / _fill against numpy: rows longer than 64 slots, in node order, in pieces of <= 64 slots."""
+    from recon_amd.graph import GraphCSR, HUB_CHUNK
+    d = dev()
+    rs = np.random.RandomState(5)
+    N = 5000
+    degs = rs.randint(0, 40, size=N)
+    hubs = rs.choice(N, size=37, replace=False)
+    degs[hubs] = rs.randint(65, 900, size=37)
+    degs[hubs[0]] = 65; degs[hubs[1]] = 128; degs[hubs[2]] = 129; degs[N - 1] = 300; degs[0] = 64
+    g = GraphCSR(_hub_graph(N, degs, 1).to(d), N)
+    want = np.nonzero(degs > HUB_CHUNK)[0]
+    assert g.n_hub == want.size
+    assert np.array_equal(g.hub_node.cpu().numpy(), want)
+    rowptr = np.concatenate([[0], np.cumsum(degs)])
+    pieces, ptr = [], [0]
+    for t, i in enumerate(want):
+        for b in range(rowptr[i], rowptr[i + 1], HUB_CHUNK):
+            pieces.append((i, b, min(b + HUB_CHUNK, rowptr[i + 1]), t))
+        ptr.append(len(pieces))
+    assert g.n_piece == len(pieces)
+    assert np.array_equal(g.hub_ptr.cpu().numpy(), np.array(ptr))
+    assert np.array_equal(g.piece.cpu().numpy(), np.array(pieces))
+    assert GraphCSR(_hub_graph(100, np.full(100, 64), 2).to(d), 100).n_hub == 0
+
+
+@pytest.mark.parametrize("N,F_,R,D,H,concat,drop,train", [
+    (90, 24, 16, 32, 4, True, False, True),       # f16 x 2 capable: half-term V rows, destination part shared
+    (90, 24, 16, 32, 4, True, True, True),        # attention dropout: Zk != Z, destination part per head
+    (60, 10, 6, 50, 2, True, False, True),        # VEC 2
+    (70, 12, 8, 20, 11, True, True, True),        # 11 heads: two head groups by one wave, per piece
+    (40, 264, 300, 24, 2, True, False, True),     # two register rows per lane
+    (50, 200, 200, 40, 1, False, False, True),    # out_att-like single head
+    (90, 24, 16, 32, 4, True, False, False),      # inference: no Z / sigma
+])
+def test_hub_rows_split_vs_oracle_and_unsplit(N, F_, R, D, H, concat, drop, train, monkeypatch):
+    """Destination rows of 65 ... 700 slots walked in pieces by several wavefronts: outputs and all gradients against the oracle
+    and against the one-wave-per-row walk of the same kernels (HUB_CHUNK = 0)."""
+    from recon_amd import gat_layers, graph as graph_mod
+    monkeypatch.setattr(gat_layers, "_GAT_PATH", "atp")
+    d = dev()
+    degs = np.zeros(N, dtype=np.int64)
+    degs[:12] = [700, 65, 64, 128, 129, 3, 0, 191, 66, 1, 320, 5]
+    degs[12:N - 3] = np.random.RandomState(N).randint(0, 9, size=N - 15)
+    degs[N - 1] = 100                                              # the last node a hub
+    edge = _hub_graph(N, degs, 3)
+    E = edge.shape[1]
+    g = torch.Generator().manual_seed(N + D)
+    x = torch.randn(N, F_, generator=g)
+    ee = torch.randn(E, R, generator=g) * 0.5
+    a = torch.stack([O.xavier_normal((D, 2 * F_ + R), 1.414, g) for _ in range(H)]) * 0.5
+    a2 = torch.cat([O.xavier_normal((1, D), 1.414, g) for _ in range(H)])
+    keep = (torch.rand(H, E, generator=g) > 0.3).float() / 0.7 if drop else None
+    G = torch.randn(N, (H * D) if concat else D * H, generator=g)
+    res = {}
+    for chunk in (graph_mod.HUB_CHUNK, 0):
+        monkeypatch.setattr(graph_mod, "HUB_CHUNK", chunk)
+        graph_mod.clear_graph_cache()
+        gr = graph_mod.prepare_graph(edge.to(d), None, N)
+        assert (gr.n_hub == 8) if chunk else (gr.n_hub == 0)
+        xd, eed, ad, a2d = (t.to(d).requires_grad_(train) for t in (x, ee, a, a2))
+        kd = keep.to(d) if drop else None
+        if train:
+            out = gat_layers.gat_heads(xd, eed, ad, a2d, gr, kd, 0.2, concat)
+            (out * G.to(d)).sum().backward()
+            res[chunk] = [t.detach().cpu() for t in (out, xd.grad, eed.grad, ad.grad, a2d.grad)]
+        else:
+            with torch.no_grad():
+                res[chunk] = [gat_layers.gat_heads(xd, eed, ad, a2d, gr, None, 0.2, concat).cpu()]
+    graph_mod.clear_graph_cache()
+    names = ("out", "g_x", "g_edge_embed", "g_a", "g_a_2")
+    for nm, s_, u_ in zip(names, res[graph_mod.HUB_CHUNK], res[0]):
+        close(s_, u_, atol=2e-5, rel_to_max=2e-5, what="split vs unsplit " + nm)
+    out, rest = res[graph_mod.HUB_CHUNK][0], res[graph_mod.HUB_CHUNK][1:]
+    g_x = torch.zeros_like(x); g_ee = torch.zeros_like(ee)
+    for h in range(H):
+        r = O.gat_layer_backward(x.double(), edge, ee.double(), None, None, a[h].double(), a2[h:h + 1].double(), 0.2, concat,
+                                 G[:, h * D:(h + 1) * D].double(), mask=keep[h].double() if drop else None)
+        close(out[:, h * D:(h + 1) * D], r["out"].float(), what="out h%d" % h)
+        if train:
+            close(rest[2][h], r["g_a"].float(), atol=1e-4, what="g_a h%d" % h)
+            close(rest[3][h:h + 1], r["g_a_2"].float(), atol=1e-4, what="g_a_2 h%d" % h)
+            g_x += r["g_x"].float(); g_ee += r["g_edge_embed"].float()
+    if train:
+        close(rest[0], g_x, atol=1e-4, what="g_x")
+        close(rest[1], g_ee, atol=1e-4, what="g_edge_embed")
+
+
 def test_heads_of_width_25_run_padded():
     """The reference's D = 25 per head (H * D = 200): above `_PAD_MIN_OUT` output elements `gat_heads` runs the heads 32 wide with
     zero rows appended to `a` / `a_2` and drops the extra columns; outputs and every gradient against the oracle, unpadded."""

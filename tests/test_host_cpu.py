@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     bound = {s[0] for s in _lib.SYMBOLS}
     assert bound == set(declared), (bound ^ set(declared))
     L = _lib.lib()
-    assert L.recon_version() == 1
+    assert L.recon_version() == 2
     assert L.recon_error_string(-2) == b"unsupported shape"
     # size queries are pure host functions
     assert L.recon_graph_workspace_bytes(100, 1000) >= 4 * 1000 * 4

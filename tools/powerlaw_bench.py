@@ -49,4 +49,5 @@ def run(B=64, D=25, F_=200, H=8, nrel=64, iters=10):
                       **res, "edges_per_s_fwd_bwd": E / res["fwd_bwd_ms"] * 1e3}))
 
 if __name__ == "__main__":
-    run(64); run(512)
+    for B in ([int(v) for v in sys.argv[1:]] or [64, 512]):
+        run(B)
