@@ -69,6 +69,11 @@ typedef struct {
     int32_t* hub_node;          /* [n_hub]     node id, ascending                                                        */
     int32_t* hub_ptr;           /* [n_hub + 1] first piece of each hub                                                   */
     int32_t* piece;             /* [n_piece][4] (node, first slot, end slot, hub ordinal), 16-byte aligned               */
+    /* the same for the source-side walk of the backward (CSC rows: a node that is the neighbour in many edges) */
+    int32_t n_hub_src, n_piece_src;
+    int32_t* hub_node_src;      /* [n_hub_src]                                                                           */
+    int32_t* hub_ptr_src;       /* [n_hub_src + 1]                                                                       */
+    int32_t* piece_src;         /* [n_piece_src][4] (node, first CSC position, end position, hub ordinal)                */
     float* hub_ws;              /* scratch of the piece partial sums, reused by every call on this graph (calls on one graph
                                    are stream ordered): at least recon_graph_hub_ws_floats() floats for the widest layer   */
     int64_t hub_ws_floats;
@@ -77,10 +82,11 @@ typedef struct {
 #define RECON_HUB_CHUNK 64
 
 size_t recon_graph_workspace_bytes(int32_t N, int32_t E);
-/* Hub tables of a built graph.  count: one pass over rowptr_dst, synchronises the stream and returns the table sizes (0, 0: nothing
- * to do).  fill: the caller has set hub_chunk / n_hub / n_piece to what count returned and hub_node, hub_ptr, piece to device
- * arrays of those sizes.  hub_ws may be set (or grown) at any time before a layer call. */
-int recon_graph_hubs_count(const recon_graph* g, int32_t chunk, void* workspace /* device, 8 bytes */, int32_t* n_hub, int32_t* n_piece,
+/* Hub tables of a built graph.  count: one pass over rowptr_dst and one over rowptr_src, synchronises the stream and returns the
+ * table sizes counts[4] = (n_hub, n_piece, n_hub_src, n_piece_src); all zero: nothing to do.  fill: the caller has set hub_chunk
+ * and the four sizes to what count returned and the six table pointers to device arrays of those sizes (a side without hubs may
+ * stay NULL).  hub_ws may be set (or grown) at any time before a layer call. */
+int recon_graph_hubs_count(const recon_graph* g, int32_t chunk, void* workspace /* device, 16 bytes */, int32_t* counts /* host [4] */,
                            recon_stream_t stream);
 int recon_graph_hubs_fill(const recon_graph* g, recon_stream_t stream);
 /* floats of hub_ws one KB-GAT layer call (forward or backward) on this graph needs */

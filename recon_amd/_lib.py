@@ -23,7 +23,9 @@ class ReconGraph(C.Structure):
                 ("rowptr_dst", c_i32p), ("eid", c_i32p), ("src", c_i32p), ("dst", c_i32p),
                 ("rowptr_src", c_i32p), ("slot_by_src", c_i32p),
                 ("hub_chunk", C.c_int32), ("n_hub", C.c_int32), ("n_piece", C.c_int32),
-                ("hub_node", c_i32p), ("hub_ptr", c_i32p), ("piece", c_i32p), ("hub_ws", c_f32p), ("hub_ws_floats", C.c_int64)]
+                ("hub_node", c_i32p), ("hub_ptr", c_i32p), ("piece", c_i32p),
+                ("n_hub_src", C.c_int32), ("n_piece_src", C.c_int32), ("hub_node_src", c_i32p), ("hub_ptr_src", c_i32p), ("piece_src", c_i32p),
+                ("hub_ws", c_f32p), ("hub_ws_floats", C.c_int64)]
 
 
 class GatFwdArgs(C.Structure):
@@ -98,7 +100,7 @@ SYMBOLS = [
     ("recon_error_string", C.c_char_p, [C.c_int]),
     ("recon_graph_workspace_bytes", C.c_size_t, [C.c_int32, C.c_int32]),
     ("recon_graph_build", C.c_int, [c_i64p, c_i64p, C.POINTER(ReconGraph), C.c_void_p, C.c_size_t, C.c_void_p]),
-    ("recon_graph_hubs_count", C.c_int, [C.POINTER(ReconGraph), C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]),
+    ("recon_graph_hubs_count", C.c_int, [C.POINTER(ReconGraph), C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     ("recon_graph_hubs_fill", C.c_int, [C.POINTER(ReconGraph), C.c_void_p]),
     ("recon_graph_hub_ws_floats", C.c_size_t, [C.POINTER(ReconGraph), C.c_int32, C.c_int32, C.c_int32]),
     ("recon_spmm_rowsum_workspace_floats", C.c_size_t, [C.c_int32, C.c_int32]),

@@ -194,35 +194,45 @@ __global__ void __launch_bounds__(1024) k_hub_scan(const int32_t* __restrict__ r
 
 }  // namespace
 
-extern "C" int recon_graph_hubs_count(const recon_graph* g, int32_t chunk, void* workspace, int32_t* n_hub, int32_t* n_piece, recon_stream_t stream) {
-    if (!g || !n_hub || !n_piece || chunk <= 0 || g->N < 0 || !g->rowptr_dst) return RECON_ERR_INVALID;
-    *n_hub = 0; *n_piece = 0;
+extern "C" int recon_graph_hubs_count(const recon_graph* g, int32_t chunk, void* workspace, int32_t* counts, recon_stream_t stream) {
+    if (!g || !counts || chunk <= 0 || g->N < 0 || !g->rowptr_dst || !g->rowptr_src) return RECON_ERR_INVALID;
+    counts[0] = counts[1] = counts[2] = counts[3] = 0;
     if (g->N == 0 || g->E <= chunk) return RECON_OK;
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 3)) return RECON_ERR_INVALID;
     hipStream_t st = as_stream(stream);
     int32_t* d = static_cast<int32_t*>(workspace);
     hipLaunchKernelGGL((k_hub_scan<false>), dim3(1), dim3(1024), 0, st, g->rowptr_dst, g->N, chunk, d, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL((k_hub_scan<false>), dim3(1), dim3(1024), 0, st, g->rowptr_src, g->N, chunk, d + 2, nullptr, nullptr, nullptr);
     RECON_CHECK_LAUNCH();
-    int32_t h[2] = {0, 0};
-    if (hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return RECON_ERR_LAUNCH;
-    *n_hub = h[0]; *n_piece = h[1];
+    if (hipMemcpyAsync(counts, d, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return RECON_ERR_LAUNCH;
     return RECON_OK;
 }
 
 extern "C" int recon_graph_hubs_fill(const recon_graph* g, recon_stream_t stream) {
-    if (!g || g->N < 0 || !g->rowptr_dst || g->hub_chunk <= 0 || g->n_hub < 0 || g->n_piece < 0) return RECON_ERR_INVALID;
-    if (g->n_hub == 0) return RECON_OK;
-    if (!g->hub_node || !g->hub_ptr || !g->piece || (reinterpret_cast<uintptr_t>(g->piece) & 15)) return RECON_ERR_INVALID;
-    hipLaunchKernelGGL((k_hub_scan<true>), dim3(1), dim3(1024), 0, as_stream(stream), g->rowptr_dst, g->N, g->hub_chunk, nullptr, g->hub_node,
-                       g->hub_ptr, reinterpret_cast<int4*>(g->piece));
+    if (!g || g->N < 0 || !g->rowptr_dst || !g->rowptr_src || g->hub_chunk <= 0 || g->n_hub < 0 || g->n_piece < 0 || g->n_hub_src < 0 ||
+        g->n_piece_src < 0) return RECON_ERR_INVALID;
+    if (g->n_hub > 0) {
+        if (!g->hub_node || !g->hub_ptr || !g->piece || (reinterpret_cast<uintptr_t>(g->piece) & 15)) return RECON_ERR_INVALID;
+        hipLaunchKernelGGL((k_hub_scan<true>), dim3(1), dim3(1024), 0, as_stream(stream), g->rowptr_dst, g->N, g->hub_chunk, nullptr, g->hub_node,
+                           g->hub_ptr, reinterpret_cast<int4*>(g->piece));
+    }
+    if (g->n_hub_src > 0) {
+        if (!g->hub_node_src || !g->hub_ptr_src || !g->piece_src || (reinterpret_cast<uintptr_t>(g->piece_src) & 15)) return RECON_ERR_INVALID;
+        hipLaunchKernelGGL((k_hub_scan<true>), dim3(1), dim3(1024), 0, as_stream(stream), g->rowptr_src, g->N, g->hub_chunk, nullptr,
+                           g->hub_node_src, g->hub_ptr_src, reinterpret_cast<int4*>(g->piece_src));
+    }
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }
 
-// per piece and head: the partial sums of the source and relation parts (F + R) and of Z, Zk (forward); the backward needs H
+// destination side, per piece and head: the partial sums of the source and relation parts (F + R) and of Z, Zk (forward; the backward
+// needs H per piece); source side, per piece: a g_x row and H sums of g_sigma.  One scratch serves both: the walks are stream ordered.
 extern "C" size_t recon_graph_hub_ws_floats(const recon_graph* g, int32_t F, int32_t R, int32_t H) {
-    if (!g || g->n_piece <= 0 || F <= 0 || R <= 0 || H <= 0) return 0;
-    return static_cast<size_t>(g->n_piece) * H * (static_cast<size_t>(F) + R + 2);
+    if (!g || F <= 0 || R <= 0 || H <= 0) return 0;
+    const size_t d = g->n_piece > 0 ? static_cast<size_t>(g->n_piece) * H * (static_cast<size_t>(F) + R + 2) : 0;
+    const size_t s = g->n_piece_src > 0 ? static_cast<size_t>(g->n_piece_src) * (static_cast<size_t>(F) + H) : 0;
+    return d > s ? d : s;
 }
 
 extern "C" size_t recon_graph_workspace_bytes(int32_t N, int32_t E) {

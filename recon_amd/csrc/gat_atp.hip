@@ -1127,12 +1127,29 @@ struct AtpSrcK {
     const int32_t* rowptr_src; const int32_t* slot_by_src; const float* Gxs; const float* gxd; const float* gsigma;
     float* g_x; float* Gs_src;
     int32_t N, F, H;
+    // hub rows of the CSC view (recon_graph): the first n_piece waves sum one piece each into hubP [n_piece][F + H] (g_x part | sums of
+    // g_sigma); the wave of a node with more than hub_chunk positions leaves its row to k_gat_atp_hub_src.  hub_chunk = 0: off.
+    int32_t hub_chunk, n_piece;
+    const int4* piece;
+    float* hubP;
 };
 template <int VEC, int KR>
 __global__ void __launch_bounds__(kBlock) k_gat_atp_src(const AtpSrcK p) {
     const int lane = threadIdx.x & 63;
-    const int node = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
-    if (node >= p.N) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int npb = (p.n_piece + kBlock / 64 - 1) / (kBlock / 64);       // piece blocks first, dealt round the XCDs (see k_gat_atp_fwd)
+    const int widx = blockIdx.x * (kBlock / 64) + wave;
+    const bool is_piece = static_cast<int>(blockIdx.x) < npb;
+    int node = xcd_block(blockIdx.x - npb, gridDim.x - npb) * (kBlock / 64) + wave;
+    int beg, end;
+    if (is_piece) {
+        if (widx >= p.n_piece) return;
+        const int4 pc = p.piece[widx]; node = pc.x; beg = pc.y; end = pc.z;
+    } else {
+        if (node >= p.N) return;
+        beg = p.rowptr_src[node]; end = p.rowptr_src[node + 1];
+        if (p.hub_chunk && end - beg > p.hub_chunk) return;
+    }
     const int F = p.F, H = p.H;
     float acc[KR][VEC];
 #pragma unroll
@@ -1140,50 +1157,82 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_src(const AtpSrcK p) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[r][v] = 0.f;
         const int c = (r * 64 + lane) * VEC;
-        if (c < F && p.g_x) load_vec<VEC>(acc[r], p.gxd + static_cast<int64_t>(node) * F + c);
+        if (!is_piece && c < F && p.g_x) load_vec<VEC>(acc[r], p.gxd + static_cast<int64_t>(node) * F + c);
     }
     float gs = 0.f;
-    const int beg = p.rowptr_src[node], end = p.rowptr_src[node + 1];
-    // four edges per iteration, every load issued before the first use and branch free (slots past the row re-read its
-    // last slot and are skipped at the accumulate; lanes past F / H read column 0 / head 0 and are never stored)
+    // The CSC position -> slot indices of up to 64 positions come with one coalesced load and are handed out with v_readlane; four
+    // edges per iteration, every load issued before the first use and branch free (positions past the row re-read its last one
+    // and are skipped at the accumulate; lanes past F / H read column 0 / head 0 and are never stored)
     constexpr int U = 4;
     const int hl = lane < H ? lane : 0;
-    for (int k0 = beg; k0 < end; k0 += U) {
-        int slot[U];
+    for (int c0 = beg; c0 < end; c0 += 64) {
+        const int cn = min(64, end - c0);
+        const int slotv = p.slot_by_src[c0 + min(lane, cn - 1)];
+        for (int j0 = 0; j0 < cn; j0 += U) {
+            int slot[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) slot[u] = p.slot_by_src[min(k0 + u, end - 1)];
-        float g4[U], t[U][KR][VEC];
+            for (int u = 0; u < U; ++u) slot[u] = __builtin_amdgcn_readlane(slotv, min(j0 + u, cn - 1));
+            float g4[U], t[U][KR][VEC];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            g4[u] = p.gsigma[static_cast<int64_t>(slot[u]) * H + hl];
-            if (p.g_x) {                                                    // uniform
+            for (int u = 0; u < U; ++u) {
+                g4[u] = p.gsigma[static_cast<int64_t>(slot[u]) * H + hl];
+                if (p.g_x) {                                                // uniform
 #pragma unroll
-                for (int r = 0; r < KR; ++r) {
-                    const int c = (r * 64 + lane) * VEC;
-                    load_vec<VEC>(t[u][r], p.Gxs + static_cast<int64_t>(slot[u]) * F + (c < F ? c : 0));
+                    for (int r = 0; r < KR; ++r) {
+                        const int c = (r * 64 + lane) * VEC;
+                        load_vec<VEC>(t[u][r], p.Gxs + static_cast<int64_t>(slot[u]) * F + (c < F ? c : 0));
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (k0 + u < end) {                                              // uniform; fixed summation order
-                gs += g4[u];
-                if (p.g_x) {
+            for (int u = 0; u < U; ++u) {
+                if (j0 + u < cn) {                                           // uniform; fixed summation order
+                    gs += g4[u];
+                    if (p.g_x) {
 #pragma unroll
-                    for (int r = 0; r < KR; ++r)
+                        for (int r = 0; r < KR; ++r)
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) acc[r][v] += t[u][r][v];
+                            for (int v = 0; v < VEC; ++v) acc[r][v] += t[u][r][v];
+                    }
                 }
             }
         }
     }
-    if (lane < H) p.Gs_src[static_cast<int64_t>(node) * 2 * H + H + lane] = gs;
+    float* gs_out = is_piece ? p.hubP + static_cast<int64_t>(widx) * (F + H) + F : p.Gs_src + static_cast<int64_t>(node) * 2 * H + H;
+    float* row_out = is_piece ? p.hubP + static_cast<int64_t>(widx) * (F + H) : p.g_x + static_cast<int64_t>(node) * F;
+    if (lane < H) gs_out[lane] = gs;
     if (p.g_x) {
 #pragma unroll
         for (int r = 0; r < KR; ++r) {
             const int c = (r * 64 + lane) * VEC;
-            if (c < F) store_vec<VEC>(p.g_x + static_cast<int64_t>(node) * F + c, acc[r]);
+            if (c < F) {
+                if (is_piece && ((F + H) % VEC)) {                            // uniform: a piece's row starts at a multiple of F + H floats
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) row_out[c + v] = acc[r][v];
+                } else store_vec<VEC>(row_out + c, acc[r]);
+            }
         }
+    }
+}
+
+// The second half of a source hub: wave = one hub, g_x row = its direct part + the pieces' rows in table order, Gs_src likewise.
+__global__ void __launch_bounds__(kBlock) k_gat_atp_hub_src(const AtpSrcK p, const int32_t* __restrict__ hub_node, const int32_t* __restrict__ hub_ptr,
+                                                            int32_t n_hub) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int F = p.F, H = p.H;
+    if (t >= n_hub) return;
+    const int node = hub_node[t], p0 = hub_ptr[t], p1 = hub_ptr[t + 1];
+    if (lane < H) {
+        float gs = 0.f;
+        for (int q = p0; q < p1; ++q) gs += p.hubP[static_cast<int64_t>(q) * (F + H) + F + lane];
+        p.Gs_src[static_cast<int64_t>(node) * 2 * H + H + lane] = gs;
+    }
+    if (!p.g_x) return;
+    for (int c = lane; c < F; c += 64) {
+        float a = p.gxd[static_cast<int64_t>(node) * F + c];
+        for (int q = p0; q < p1; ++q) a += p.hubP[static_cast<int64_t>(q) * (F + H) + c];
+        p.g_x[static_cast<int64_t>(node) * F + c] = a;
     }
 }
 
@@ -1683,7 +1732,11 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         p.rowptr_src = g->rowptr_src; p.slot_by_src = g->slot_by_src; p.Gxs = b->Gxs; p.gxd = b->gxd; p.gsigma = b->g_sigma;
         p.g_x = b->g_x; p.Gs_src = b->Gs;
         p.N = N; p.F = F; p.H = H;
-        dim3 grid(static_cast<unsigned>(ceil_div64(N, kBlock / 64)));
+        const bool hubs = g->hub_chunk > 0 && g->n_hub_src > 0 && g->n_piece_src > 0 && g->hub_node_src && g->hub_ptr_src && g->piece_src && g->hub_ws;
+        if (hubs && static_cast<size_t>(g->hub_ws_floats) < recon_graph_hub_ws_floats(g, F, R, H)) return RECON_ERR_WORKSPACE;
+        p.hub_chunk = hubs ? g->hub_chunk : 0; p.n_piece = hubs ? g->n_piece_src : 0;
+        p.piece = reinterpret_cast<const int4*>(g->piece_src); p.hubP = g->hub_ws;
+        dim3 grid(static_cast<unsigned>(ceil_div64(N, kBlock / 64) + ceil_div64(p.n_piece, kBlock / 64)));
         const int key = s.vec * 10 + s.kr;
         switch (key) {
             case 41: hipLaunchKernelGGL((k_gat_atp_src<4, 1>), grid, dim3(kBlock), 0, st, p); break;
@@ -1695,6 +1748,8 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
             case 24: hipLaunchKernelGGL((k_gat_atp_src<2, 4>), grid, dim3(kBlock), 0, st, p); break;
             default: hipLaunchKernelGGL((k_gat_atp_src<2, 8>), grid, dim3(kBlock), 0, st, p); break;
         }
+        if (hubs) hipLaunchKernelGGL(k_gat_atp_hub_src, dim3(static_cast<unsigned>(ceil_div64(g->n_hub_src, kBlock / 64))), dim3(kBlock), 0, st, p,
+                                     g->hub_node_src, g->hub_ptr_src, g->n_hub_src);
         RECON_CHECK_LAUNCH();
     }
     }   // INPUTS (its score-gradient products follow below)

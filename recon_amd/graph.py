@@ -60,27 +60,35 @@ class GraphCSR:
         _lib.check(rc, "recon_graph_build")
         self._eid_long = None
         # hub rows (include/recon_hip.h): destinations with more than HUB_CHUNK in-edges are cut into pieces, one wavefront each
-        self.n_hub = self.n_piece = 0
+        self.n_hub = self.n_piece = self.n_hub_src = self.n_piece_src = 0
         self._hub_ws = None
         if HUB_CHUNK > 0 and E > HUB_CHUNK:
-            nh, npc = C.c_int32(0), C.c_int32(0)
+            cnt = (C.c_int32 * 4)()
             with torch.cuda.device(dev):
-                _lib.check(L.recon_graph_hubs_count(C.byref(self.c), HUB_CHUNK, ws.data_ptr(), C.byref(nh), C.byref(npc),
-                                                    _lib.current_stream()), "recon_graph_hubs_count")
-            if nh.value > 0:
-                self.n_hub, self.n_piece = nh.value, npc.value
-                self.hub_node = torch.empty(self.n_hub, **i32)
-                self.hub_ptr = torch.empty(self.n_hub + 1, **i32)
-                self.piece = torch.empty(self.n_piece, 4, **i32)
-                self.c.hub_chunk, self.c.n_hub, self.c.n_piece = HUB_CHUNK, self.n_hub, self.n_piece
-                self.c.hub_node, self.c.hub_ptr, self.c.piece = self.hub_node.data_ptr(), self.hub_ptr.data_ptr(), self.piece.data_ptr()
+                _lib.check(L.recon_graph_hubs_count(C.byref(self.c), HUB_CHUNK, ws.data_ptr(), cnt, _lib.current_stream()), "recon_graph_hubs_count")
+            if cnt[0] > 0 or cnt[2] > 0:
+                self.n_hub, self.n_piece, self.n_hub_src, self.n_piece_src = (int(v) for v in cnt)
+                self.c.hub_chunk = HUB_CHUNK
+                if self.n_hub:
+                    self.hub_node = torch.empty(self.n_hub, **i32)
+                    self.hub_ptr = torch.empty(self.n_hub + 1, **i32)
+                    self.piece = torch.empty(self.n_piece, 4, **i32)
+                    self.c.n_hub, self.c.n_piece = self.n_hub, self.n_piece
+                    self.c.hub_node, self.c.hub_ptr, self.c.piece = self.hub_node.data_ptr(), self.hub_ptr.data_ptr(), self.piece.data_ptr()
+                if self.n_hub_src:
+                    self.hub_node_src = torch.empty(self.n_hub_src, **i32)
+                    self.hub_ptr_src = torch.empty(self.n_hub_src + 1, **i32)
+                    self.piece_src = torch.empty(self.n_piece_src, 4, **i32)
+                    self.c.n_hub_src, self.c.n_piece_src = self.n_hub_src, self.n_piece_src
+                    self.c.hub_node_src, self.c.hub_ptr_src, self.c.piece_src = (self.hub_node_src.data_ptr(), self.hub_ptr_src.data_ptr(),
+                                                                                 self.piece_src.data_ptr())
                 with torch.cuda.device(dev):
                     _lib.check(L.recon_graph_hubs_fill(C.byref(self.c), _lib.current_stream()), "recon_graph_hubs_fill")
 
     def reserve_hub_ws(self, F, R, H):
         """Scratch of the hub pieces' partial sums for one KB-GAT layer call of these sizes; grows, never shrinks (the calls on one graph
         are stream ordered and nothing in it outlives a call)."""
-        if self.n_piece == 0:
+        if self.n_piece == 0 and self.n_piece_src == 0:
             return
         need = _lib.lib().recon_graph_hub_ws_floats(C.byref(self.c), F, R, H)
         if self._hub_ws is None or self._hub_ws.numel() < need:

@@ -479,11 +479,18 @@ def test_power_law_graphs(path, monkeypatch):
     close(xd.grad, gx, atol=1e-4, what="g_x")
 
 
-def _hub_graph(N, degs, seed):
-    """Destination i gets degs[i] in-edges (0 for i >= len(degs)), sources uniform, columns shuffled."""
+def _hub_graph(N, degs, seed, src_hubs=()):
+    """Destination i gets degs[i] in-edges (0 for i >= len(degs)), sources uniform except that node j is the source of exactly c
+    edges for every (j, c) in src_hubs; columns shuffled."""
     rs = np.random.RandomState(seed)
     dst = np.repeat(np.arange(len(degs)), degs)
-    src = rs.randint(0, N, size=dst.size)
+    others = np.setdiff1d(np.arange(N), [j for j, _ in src_hubs])
+    src = others[rs.randint(0, others.size, size=dst.size)]
+    at = 0
+    order = rs.permutation(dst.size)
+    for j, c in src_hubs:
+        src[order[at:at + c]] = j
+        at += c
     perm = rs.permutation(dst.size)
     return torch.from_numpy(np.stack([dst[perm], src[perm]])).long()
 
@@ -498,20 +505,32 @@ def test_hub_tables():
     hubs = rs.choice(N, size=37, replace=False)
     degs[hubs] = rs.randint(65, 900, size=37)
     degs[hubs[0]] = 65; degs[hubs[1]] = 128; degs[hubs[2]] = 129; degs[N - 1] = 300; degs[0] = 64
-    g = GraphCSR(_hub_graph(N, degs, 1).to(d), N)
-    want = np.nonzero(degs > HUB_CHUNK)[0]
-    assert g.n_hub == want.size
+    edge = _hub_graph(N, degs, 1, src_hubs=((17, 65), (4000, 1000), (N - 1, 64), (3, 129)))
+    g = GraphCSR(edge.to(d), N)
+
+    def tables(deg):
+        want = np.nonzero(deg > HUB_CHUNK)[0]
+        rowptr = np.concatenate([[0], np.cumsum(deg)])
+        pieces, ptr = [], [0]
+        for t, i in enumerate(want):
+            for b in range(rowptr[i], rowptr[i + 1], HUB_CHUNK):
+                pieces.append((i, b, min(b + HUB_CHUNK, rowptr[i + 1]), t))
+            ptr.append(len(pieces))
+        return want, np.array(ptr), np.array(pieces)
+
+    want, ptr, pieces = tables(degs)
+    assert g.n_hub == want.size and g.n_piece == len(pieces)
     assert np.array_equal(g.hub_node.cpu().numpy(), want)
-    rowptr = np.concatenate([[0], np.cumsum(degs)])
-    pieces, ptr = [], [0]
-    for t, i in enumerate(want):
-        for b in range(rowptr[i], rowptr[i + 1], HUB_CHUNK):
-            pieces.append((i, b, min(b + HUB_CHUNK, rowptr[i + 1]), t))
-        ptr.append(len(pieces))
-    assert g.n_piece == len(pieces)
-    assert np.array_equal(g.hub_ptr.cpu().numpy(), np.array(ptr))
-    assert np.array_equal(g.piece.cpu().numpy(), np.array(pieces))
-    assert GraphCSR(_hub_graph(100, np.full(100, 64), 2).to(d), 100).n_hub == 0
+    assert np.array_equal(g.hub_ptr.cpu().numpy(), ptr)
+    assert np.array_equal(g.piece.cpu().numpy(), pieces)
+    want, ptr, pieces = tables(np.bincount(edge[1].numpy(), minlength=N))
+    assert list(want) == [3, 17, 4000] and g.n_hub_src == 3 and g.n_piece_src == len(pieces)
+    assert np.array_equal(g.hub_node_src.cpu().numpy(), want)
+    assert np.array_equal(g.hub_ptr_src.cpu().numpy(), ptr)
+    assert np.array_equal(g.piece_src.cpu().numpy(), pieces)
+    dst = np.repeat(np.arange(100), 64)                                  # every row of both views exactly 64 long: no hub
+    g0 = GraphCSR(torch.from_numpy(np.stack([dst, (dst + 1 + np.arange(6400) % 64) % 100])).long().to(d), 100)
+    assert g0.n_hub == 0 and g0.n_hub_src == 0
 
 
 @pytest.mark.parametrize("N,F_,R,D,H,concat,drop,train", [
@@ -533,7 +552,7 @@ def test_hub_rows_split_vs_oracle_and_unsplit(N, F_, R, D, H, concat, drop, trai
     degs[:12] = [700, 65, 64, 128, 129, 3, 0, 191, 66, 1, 320, 5]
     degs[12:N - 3] = np.random.RandomState(N).randint(0, 9, size=N - 15)
     degs[N - 1] = 100                                              # the last node a hub
-    edge = _hub_graph(N, degs, 3)
+    edge = _hub_graph(N, degs, 3, src_hubs=((N - 2, 300), (7, 65), (0, 130)))        # and three source-side hubs (CSC walk of the backward)
     E = edge.shape[1]
     g = torch.Generator().manual_seed(N + D)
     x = torch.randn(N, F_, generator=g)
@@ -547,7 +566,7 @@ def test_hub_rows_split_vs_oracle_and_unsplit(N, F_, R, D, H, concat, drop, trai
         monkeypatch.setattr(graph_mod, "HUB_CHUNK", chunk)
         graph_mod.clear_graph_cache()
         gr = graph_mod.prepare_graph(edge.to(d), None, N)
-        assert (gr.n_hub == 8) if chunk else (gr.n_hub == 0)
+        assert (gr.n_hub == 8 and gr.n_hub_src >= 3) if chunk else (gr.n_hub == 0 and gr.n_hub_src == 0)
         xd, eed, ad, a2d = (t.to(d).requires_grad_(train) for t in (x, ee, a, a2))
         kd = keep.to(d) if drop else None
         if train:
