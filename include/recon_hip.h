@@ -398,6 +398,12 @@ int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* args, recon_stream_t stream)
 int recon_sgemm(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                 int32_t b_is_nk, float* C, int32_t ldc, recon_stream_t stream);
 
+/* Small dense products (tens of MFLOP), plain fp32 FMAs with K split 16 ways inside a workgroup and a fixed-order combine:
+ *     C[M,N] = op(A) * op(B);  A is [M,K] (a_is_km == 0) or [K,M]; B is [K,N] (b_is_nk == 0) or [N,K].
+ * Replaces `relation_embed.mm(self.W)` (GAT/models.py:75) and its two gradient products, which are launch / latency bound on tile GEMMs. */
+int recon_sgemm_small(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, int32_t a_is_km, const float* B, int32_t ldb,
+                      int32_t b_is_nk, float* C, int32_t ldc, recon_stream_t stream);
+
 /* K4'  the same product C[M,N] = A[M,K] * B[N,K]^T at fp32 accuracy on the bf16 matrix cores: every fp32
  * operand is split into three bfloat16 terms and six term products are accumulated in fp32
  * (csrc/gemm_bx3.hip).  B is split into `workspace` (recon_sgemm_bx3_workspace_bytes) first; A on the fly.

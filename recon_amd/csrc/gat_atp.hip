@@ -752,6 +752,30 @@ __global__ void __launch_bounds__(kBlock, KR >= 8 ? 2 : 1) k_gat_atp_fwd(const A
     }
 }
 
+// acc += sum over pieces q in [p0, p1) of the VEC floats at base + q * stride, in table order.  A hub of 9 000 edges has 142 pieces:
+// one load at a time is 142 dependent round trips (measured on a 272 k-edge graph with such hubs: 78 us for the forward combine,
+// 109 us for the source-side one), so eight pieces' loads are issued before the first add.
+template <int VEC>
+__device__ __forceinline__ void sum_pieces(float (&acc)[VEC], const float* __restrict__ base, int64_t stride, int p0, int p1) {
+    constexpr int U = 8;
+    int q = p0;
+    for (; q + U <= p1; q += U) {
+        float tv[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_vec<VEC>(tv[u], base + static_cast<int64_t>(q + u) * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] += tv[u][v];
+    }
+    for (; q < p1; ++q) {
+        float tv[VEC];
+        load_vec<VEC>(tv, base + static_cast<int64_t>(q) * stride);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += tv[v];
+    }
+}
+
 // The second half of a hub's forward: wave = one (hub, head).  Sums the pieces' partial sums in table order (fixed: results do not
 // depend on scheduling), normalises as the epilogue above does and writes the node's V rows, Z and Zk.  8-byte plane stores: hubs are few.
 template <int VEC, int PL>
@@ -765,8 +789,10 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_hub_fwd(const AtpFwdK p, con
     const int t = idx / H, h = idx - t * H;
     const int node = hub_node[t], p0 = hub_ptr[t], p1 = hub_ptr[t + 1];
     const float vscale = PL ? hx2_scale_wave(p.vs) : 1.f;
-    float Zl = 0.f, Zkl = 0.f;
-    for (int q = p0; q < p1; ++q) { Zl += p.hubZ[(static_cast<int64_t>(q) * 2) * H + h]; Zkl += p.hubZ[(static_cast<int64_t>(q) * 2 + 1) * H + h]; }
+    float zz[1] = {0.f}, zzk[1] = {0.f};
+    sum_pieces<1>(zz, p.hubZ + h, 2 * H, p0, p1);
+    sum_pieces<1>(zzk, p.hubZ + H + h, 2 * H, p0, p1);
+    const float Zl = zz[0], Zkl = zzk[0];
     const float Zc = (Zl == 0.f) ? 1e-12f : Zl;                         // GAT/layers.py:152
     if (p.Z && lane == 0) { p.Z[static_cast<int64_t>(node) * H + h] = Zc; p.Zk[static_cast<int64_t>(node) * H + h] = Zkl; }
     const float invh = (1.f / Zc) * vscale, zk = Zkl * invh;
@@ -780,12 +806,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_hub_fwd(const AtpFwdK p, con
         float acc[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-        for (int q = p0; q < p1; ++q) {
-            float tv[VEC];
-            load_vec<VEC>(tv, p.hubS + (static_cast<int64_t>(q) * H + h) * (F + R) + c);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[v] += tv[v];
-        }
+        sum_pieces<VEC>(acc, p.hubS + static_cast<int64_t>(h) * (F + R) + c, static_cast<int64_t>(H) * (F + R), p0, p1);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] *= invh;
         put(F + c, acc);
@@ -1105,7 +1126,9 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_hub_bwd(const AtpBwdK p, con
     const int node = hub_node[t], p0 = hub_ptr[t], p1 = hub_ptr[t + 1];
     float tot = 0.f;
     if (lane < H) {
-        for (int q = p0; q < p1; ++q) tot += p.hubG[static_cast<int64_t>(q) * H + lane];
+        float tt[1] = {0.f};
+        sum_pieces<1>(tt, p.hubG + lane, H, p0, p1);
+        tot = tt[0];
         p.Gs_dst[static_cast<int64_t>(node) * 2 * H + lane] += tot;
     }
     for (int c = lane * VEC; c < F; c += 64 * VEC) {
@@ -1215,25 +1238,26 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_src(const AtpSrcK p) {
     }
 }
 
-// The second half of a source hub: wave = one hub, g_x row = its direct part + the pieces' rows in table order, Gs_src likewise.
+// The second half of a source hub: wave = one (hub, 64-column stripe); g_x row = its direct part + the pieces' rows in table order,
+// Gs_src likewise (by the wave of stripe 0).
 __global__ void __launch_bounds__(kBlock) k_gat_atp_hub_src(const AtpSrcK p, const int32_t* __restrict__ hub_node, const int32_t* __restrict__ hub_ptr,
                                                             int32_t n_hub) {
     const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int F = p.F, H = p.H;
-    if (t >= n_hub) return;
+    const int stripes = (F + 63) / 64;
+    const int idx = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (idx >= n_hub * stripes) return;
+    const int t = idx / stripes, c = (idx - t * stripes) * 64 + lane;
     const int node = hub_node[t], p0 = hub_ptr[t], p1 = hub_ptr[t + 1];
-    if (lane < H) {
-        float gs = 0.f;
-        for (int q = p0; q < p1; ++q) gs += p.hubP[static_cast<int64_t>(q) * (F + H) + F + lane];
-        p.Gs_src[static_cast<int64_t>(node) * 2 * H + H + lane] = gs;
+    if (c < H) {                                                         // stripe 0 (H <= 64)
+        float gs[1] = {0.f};
+        sum_pieces<1>(gs, p.hubP + F + c, F + H, p0, p1);
+        p.Gs_src[static_cast<int64_t>(node) * 2 * H + H + c] = gs[0];
     }
-    if (!p.g_x) return;
-    for (int c = lane; c < F; c += 64) {
-        float a = p.gxd[static_cast<int64_t>(node) * F + c];
-        for (int q = p0; q < p1; ++q) a += p.hubP[static_cast<int64_t>(q) * (F + H) + c];
-        p.g_x[static_cast<int64_t>(node) * F + c] = a;
-    }
+    if (!p.g_x || c >= F) return;
+    float a[1] = {p.gxd[static_cast<int64_t>(node) * F + c]};
+    sum_pieces<1>(a, p.hubP + c, F + H, p0, p1);
+    p.g_x[static_cast<int64_t>(node) * F + c] = a[0];
 }
 
 
@@ -1748,7 +1772,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
             case 24: hipLaunchKernelGGL((k_gat_atp_src<2, 4>), grid, dim3(kBlock), 0, st, p); break;
             default: hipLaunchKernelGGL((k_gat_atp_src<2, 8>), grid, dim3(kBlock), 0, st, p); break;
         }
-        if (hubs) hipLaunchKernelGGL(k_gat_atp_hub_src, dim3(static_cast<unsigned>(ceil_div64(g->n_hub_src, kBlock / 64))), dim3(kBlock), 0, st, p,
+        if (hubs) hipLaunchKernelGGL(k_gat_atp_hub_src, dim3(static_cast<unsigned>(ceil_div64(1LL * g->n_hub_src * ceil_div64(F, 64), kBlock / 64))), dim3(kBlock), 0, st, p,
                                      g->hub_node_src, g->hub_ptr_src, g->n_hub_src);
         RECON_CHECK_LAUNCH();
     }

@@ -560,7 +560,133 @@ int gemm_f32(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool a_k_min
     return gemm_f32_batched(M, N, K, A, a_k_minor, B, b_k_minor, C, bt, split_k, partial, st);
 }
 
+// Small dense products (tens of MFLOP: relation_embed.mm(W) and its two gradients, GAT/models.py:75).  Tile GEMMs — this file's and the
+// library's behind torch.mm — take 18 - 36 us for them on MI355X (one or two workgroups walking K step by step, every step a
+// dependent round trip; 200 us here at K = 1 600): the arithmetic is nothing, the serial K walk is everything.  Here a workgroup owns a
+// 16 x 16 output tile and its 16 groups of 16 threads each take 1/16 of K (4 x 4 outputs per thread, plain FMAs), then the slices are
+// added in fixed order through LDS: hundreds of workgroups, 1/16 of the walk each.
+template <bool A_KM, bool B_NK, bool VEC4>
+__global__ void __launch_bounds__(256) k_gemm_small(const float* __restrict__ A, int32_t lda, const float* __restrict__ B, int32_t ldb,
+                                                    float* __restrict__ C, int32_t ldc, int32_t M, int32_t N, int32_t K) {
+    __shared__ float red[16][16][17];
+    const int tid = threadIdx.x, slice = tid >> 4, tm = (tid >> 2) & 3, tn = tid & 3;
+    const int m0 = blockIdx.y * 16 + tm * 4, n0 = blockIdx.x * 16 + tn * 4;
+    const int ks = ((K + 15) / 16 + 3) & ~3;                             // K per slice, a multiple of the 4-deep step
+    const int k_begin = slice * ks, k_end = min(K, k_begin + ks);
+    int64_t arow[4], bcol[4];
+    float am[4], bm[4];                                                   // 0 for rows / columns past the edge (their loads are clamped)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = min(m0 + i, M - 1), n = min(n0 + i, N - 1);
+        arow[i] = A_KM ? m : static_cast<int64_t>(m) * lda;
+        bcol[i] = B_NK ? static_cast<int64_t>(n) * ldb : n;
+        am[i] = m0 + i < M ? 1.f : 0.f;
+        bm[i] = n0 + i < N ? 1.f : 0.f;
+    }
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k = k_begin; k < k_end; k += 4) {
+        float a[4][4], b[4][4];
+        if constexpr (VEC4) {
+            // 16-byte loads along whichever index is contiguous (the host checked the divisibility and alignment this needs): a
+            // group of four rows / columns is inside or outside as a whole and is clamped as a whole
+            const int m4 = min(m0, M - 4), n4 = min(n0, N - 4);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int kc = min(k + kk, k_end - 1);
+                const float km = k + kk < k_end ? 1.f : 0.f;
+                if constexpr (A_KM) {
+                    const float4 t = *reinterpret_cast<const float4*>(A + static_cast<int64_t>(kc) * lda + m4);
+                    a[0][kk] = t.x * km; a[1][kk] = t.y * km; a[2][kk] = t.z * km; a[3][kk] = t.w * km;
+                }
+                if constexpr (!B_NK) {
+                    const float4 t = *reinterpret_cast<const float4*>(B + static_cast<int64_t>(kc) * ldb + n4);
+                    b[kk][0] = t.x; b[kk][1] = t.y; b[kk][2] = t.z; b[kk][3] = t.w;
+                    if constexpr (!A_KM) { (void)km; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (!A_KM) {                                        // K % 4 == 0: k .. k + 3 < k_end
+                    const float4 t = *reinterpret_cast<const float4*>(A + arow[i] + k);
+                    a[i][0] = t.x; a[i][1] = t.y; a[i][2] = t.z; a[i][3] = t.w;
+                }
+                if constexpr (B_NK) {
+                    const float4 t = *reinterpret_cast<const float4*>(B + bcol[i] + k);
+                    b[0][i] = t.x; b[1][i] = t.y; b[2][i] = t.z; b[3][i] = t.w;
+                }
+            }
+            if constexpr (!A_KM && !B_NK) {                                   // the k mask rides on a in the other forms
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i][kk] *= (k + kk < k_end ? 1.f : 0.f);
+            }
+        } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int kc = min(k + kk, k_end - 1);
+            const float km = k + kk < k_end ? 1.f : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i][kk] = A[arow[i] + (A_KM ? static_cast<int64_t>(kc) * lda : kc)] * km;
+                b[kk][i] = B[bcol[i] + (B_NK ? kc : static_cast<int64_t>(kc) * ldb)];
+            }
+        }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i][kk], b[kk][j], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[slice][tm * 4 + i][tn * 4 + j] = acc[i][j] * am[i] * bm[j];
+    __syncthreads();
+    const int om = tid >> 4, on = tid & 15;
+    float sum = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) sum += red[sl][om][on];
+    const int m = blockIdx.y * 16 + om, n = blockIdx.x * 16 + on;
+    if (m < M && n < N) C[static_cast<int64_t>(m) * ldc + n] = sum;
+}
+
 }  // namespace recon
+
+extern "C" int recon_sgemm_small(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, int32_t a_is_km, const float* B, int32_t ldb,
+                                 int32_t b_is_nk, float* C, int32_t ldc, recon_stream_t stream) {
+    using namespace recon;
+    if (M < 0 || N < 0 || K < 0) return RECON_ERR_INVALID;
+    if (M == 0 || N == 0) return RECON_OK;
+    if (!C || (K > 0 && (!A || !B))) return RECON_ERR_INVALID;
+    if (lda < (a_is_km ? M : K) || ldb < (b_is_nk ? K : N) || ldc < N) return RECON_ERR_INVALID;
+    if ((N + 15) / 16 > 65535 * 16 || (M + 15) / 16 > 65535) return RECON_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    if (K == 0) {
+        if (hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, st) != hipSuccess) return RECON_ERR_LAUNCH;
+        return RECON_OK;
+    }
+    const dim3 grid(static_cast<unsigned>((N + 15) / 16), static_cast<unsigned>((M + 15) / 16));
+    const bool k4 = !a_is_km || b_is_nk;                                  // some operand is read 4 k at a time
+    const bool vec4 = !((lda | ldb) & 3) && !((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) && (!k4 || !(K & 3)) &&
+                      (!a_is_km || !(M & 3)) && (b_is_nk || !(N & 3));
+#define SMALL_CALL(AK, BN)                                                                                                      \
+    do {                                                                                                                        \
+        if (vec4) hipLaunchKernelGGL((k_gemm_small<AK, BN, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);   \
+        else hipLaunchKernelGGL((k_gemm_small<AK, BN, false>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);       \
+    } while (0)
+    if (a_is_km) { if (b_is_nk) SMALL_CALL(true, true); else SMALL_CALL(true, false); }
+    else { if (b_is_nk) SMALL_CALL(false, true); else SMALL_CALL(false, false); }
+#undef SMALL_CALL
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
 
 extern "C" int recon_sgemm(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                            int32_t b_is_nk, float* C, int32_t ldc, recon_stream_t stream) {

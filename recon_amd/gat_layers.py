@@ -139,6 +139,50 @@ class _GatherRows(torch.autograd.Function):
         return out, None
 
 
+class _SmallMM(torch.autograd.Function):
+    """A @ B for the models' small dense products (relation_embed.mm(W), GAT/models.py:75: 64..237 rows) on a kernel made for them
+    (csrc/gemm_f32.hip k_gemm_small): the library GEMM behind torch.mm takes ~40 us for these 10-MFLOP products on MI355X (rocprofv3, full SpGAT step: 4 calls =
+    7 % of a 2 ms step), this one a launch."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        _require_gpu_f32(A, B)
+        A, B = A.contiguous(), B.contiguous()
+        ctx.save_for_backward(A, B)
+        return _sgemm_small(A, False, B, False)
+
+    @staticmethod
+    def backward(ctx, g):
+        A, B = ctx.saved_tensors
+        g = g.contiguous()
+        gA = _sgemm_small(g, False, B, True) if ctx.needs_input_grad[0] else None      # g B^T: B [K,N] read as the [N',K'] form
+        gB = _sgemm_small(A, True, g, False) if ctx.needs_input_grad[1] else None      # A^T g: A [M,K] read as the k-major form
+        return gA, gB
+
+
+def _sgemm_small(A, a_is_km, B, b_is_nk):
+    """op(A) op(B) on recon_sgemm_small; A, B contiguous 2-d fp32."""
+    M, K = (A.shape[1], A.shape[0]) if a_is_km else A.shape
+    N = B.shape[0] if b_is_nk else B.shape[1]
+    out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    if M and N:
+        with _on_device(A.device):
+            _lib.check(_lib.lib().recon_sgemm_small(M, N, K, A.data_ptr(), A.shape[1], 1 if a_is_km else 0, B.data_ptr(), B.shape[1],
+                                                    1 if b_is_nk else 0, out.data_ptr(), N, _lib.current_stream()), "recon_sgemm_small")
+    return out
+
+
+_SMALL_MM_FLOP = 2.0e8
+
+
+def small_mm(A, B):
+    """torch.mm semantics; fp32 GPU products below ~0.2 GFLOP run on recon_sgemm (see _SmallMM), the rest on torch.mm."""
+    if (A.is_cuda and A.dtype == torch.float32 and B.dtype == torch.float32 and A.dim() == 2 and B.dim() == 2
+            and 0 < A.shape[1] == B.shape[0] and 2.0 * A.shape[0] * A.shape[1] * B.shape[1] < _SMALL_MM_FLOP):
+        return _SmallMM.apply(A, B)
+    return torch.mm(A, B)
+
+
 _KEY_CACHE = {}
 
 

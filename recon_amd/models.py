@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed, gather_rows
+from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed, gather_rows, small_mm
 from .graph import prepare_graph
 
 
@@ -82,7 +82,7 @@ class SpGAT(nn.Module):
             edge_embed_nhop = torch.tensor([])
         x = self.heads_forward(x, edge_list, edge_embed, edge_list_nhop, edge_embed_nhop)
         x = self.dropout_layer(x)
-        out_relation_1 = relation_embed.mm(self.W)
+        out_relation_1 = small_mm(relation_embed, self.W)
         edge_embed = gather_rows(out_relation_1, edge_type)
         if has_nhop:
             edge_embed_nhop = gather_rows(out_relation_1, edge_type_nhop[:, 0]) + gather_rows(out_relation_1, edge_type_nhop[:, 1])

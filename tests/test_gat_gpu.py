@@ -479,6 +479,24 @@ def test_power_law_graphs(path, monkeypatch):
     close(xd.grad, gx, atol=1e-4, what="g_x")
 
 
+@pytest.mark.parametrize("M,K,N", [(237, 100, 200), (64, 200, 1600), (3, 5, 7), (1, 1, 1), (500, 33, 129), (4, 8, 4), (20, 36, 52), (237, 1600, 200)])
+def test_small_mm(M, K, N):
+    """The models' small dense products (relation_embed.mm(W)) on recon_sgemm: values and both gradients against float64."""
+    from recon_amd.gat_layers import small_mm, _SmallMM
+    d = dev()
+    g = torch.Generator().manual_seed(M + N)
+    A, B, G = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g), torch.randn(M, N, generator=g)
+    Ad, Bd = A.to(d).requires_grad_(True), B.to(d).requires_grad_(True)
+    out = small_mm(Ad, Bd)
+    assert isinstance(out.grad_fn, _SmallMM._backward_cls) or out.grad_fn.name().startswith("_SmallMM")
+    (out * G.to(d)).sum().backward()
+    close(out, (A.double() @ B.double()).float(), atol=1e-5, rel_to_max=1e-5, what="A B")
+    close(Ad.grad, (G.double() @ B.double().t()).float(), atol=1e-5, rel_to_max=1e-5, what="g_A")
+    close(Bd.grad, (A.double().t() @ G.double()).float(), atol=1e-5, rel_to_max=1e-5, what="g_B")
+    big = small_mm(torch.randn(4096, 256, device=d), torch.randn(256, 512, device=d, requires_grad=True))      # above the threshold: torch.mm
+    assert not big.grad_fn.name().startswith("_SmallMM")
+
+
 def _hub_graph(N, degs, seed, src_hubs=()):
     """Destination i gets degs[i] in-edges (0 for i >= len(degs)), sources uniform except that node j is the source of exactly c
     edges for every (j, c) in src_hubs; columns shuffled."""
