@@ -287,13 +287,14 @@ __global__ void __launch_bounds__(NT, OCC) k_gemm_hx2_kmajor(const Hx2KmArgs p) 
 
     // ---- A: piece pc = 4 i + wave (8 per plane) lands lane-linear at slot s = 64 (pc & 7) + lane of its plane
     //      = (k = s >> 4, physical 16-byte slot s & 15); that slot holds logical chunk ((phys >> 1) ^ ka_h(k)), half phys & 1
-    int a_k[KA_DMA], a_col[KA_DMA];
+    int a_k[KA_DMA];
+    int64_t a_col[KA_DMA];                                           // with the batch entry's offset: 2 N W halves per head pass 2^31 at a few million nodes
 #pragma unroll
     for (int i = 0; i < KA_DMA; ++i) {
         const int pc = 4 * i + wid, s = 64 * (pc & 7) + lane, k = s >> 4, phys = s & 15;
         a_k[i] = k;
         a_col[i] = min(m0 + 16 * ((phys >> 1) ^ ka_h(k)) + 8 * (phys & 1), p.m_ld - 8);
-        if (a_col[i] >= p.a_shared_m) a_col[i] += static_cast<int>(bz * p.a_bs);        // its batch entry's columns; shared ones stay at entry 0
+        if (a_col[i] >= p.a_shared_m) a_col[i] += bz * p.a_bs;        // its batch entry's columns; shared ones stay at entry 0
     }
     // ---- B: piece pc = 4 i + wave (14 per plane), slot s = 64 (pc % 14) + lane = (k = s / 28, physical slot s % 28);
     //      the physical slot holds logical slot phys - 2 [k & 8] (the two padding slots re-read slot 0)
@@ -591,7 +592,7 @@ int gemm_hx2_kmajor_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int
     if (a.nsplit != split_k) return RECON_ERR_INVALID;
     if (static_cast<int64_t>(batch) * split_k > 65535) return RECON_ERR_UNSUPPORTED;
     a.sa = sa; a.sb = sb;
-    if (a_shared_m < 0 || (a_shared_m & 7) || a_bs * batch + lda >= (1LL << 31)) return RECON_ERR_UNSUPPORTED;      // a_col carries the batch offset as int
+    if (a_shared_m < 0 || (a_shared_m & 7)) return RECON_ERR_UNSUPPORTED;
     a.a_shared_m = a_shared_m;
     const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, BM)), static_cast<unsigned>(batch * split_k));
     hipLaunchKernelGGL((k_gemm_hx2_kmajor<2>), grid, dim3(NT), 0, st, a);      // three workgroups per CU (<= 168 registers) spill: 241 us against 70

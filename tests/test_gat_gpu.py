@@ -375,6 +375,64 @@ def test_full_size_cfg2_properties():
     close(out2, out, atol=2e-5, what="edge permutation invariance")
 
 
+@pytest.mark.parametrize("family", ["2", "1", "0"])
+def test_index_range_beyond_2_31_elements(family, monkeypatch):
+    """Maximum sizes: N = 3.2 M nodes x 4 heads x (2F + R = 192) is 2.46 G elements of V / g_V (9.8 GB each) — every row offset past
+    node 2.8 M needs 64-bit arithmetic.  The graph is TWO copies of one half (same features, node ids shifted by N/2), so the second
+    copy's outputs and input gradients must repeat the first's (same per-node work, only the addresses differ), the weight gradients
+    are sums over both, and a sample of the first copy's nodes is checked against the oracle on their induced sub-problem."""
+    from recon_amd import gat_layers
+    from recon_amd.gat_layers import gat_heads
+    from recon_amd.graph import prepare_graph, clear_graph_cache
+    monkeypatch.setattr(gat_layers, "_GEMM_BX3", family)                 # every GEMM family has its own offset arithmetic
+    d = dev()
+    if torch.cuda.get_device_properties(0).total_memory < 100 * 2 ** 30:
+        pytest.skip("needs ~60 GB of device memory")
+    Nh, Eh, F_, R, D, H = 1600000, 2400000, 64, 64, 32, 4
+    g = torch.Generator().manual_seed(11)
+    dst = torch.randint(0, Nh, (Eh,), generator=g); src = torch.randint(0, Nh, (Eh,), generator=g)
+    dst[:3000] = 7                                                    # one hub row (pieces) in each copy
+    xh = torch.randn(Nh, F_, generator=g); eeh = torch.randn(Eh, R, generator=g) * 0.5
+    a = torch.stack([O.xavier_normal((D, 2 * F_ + R), 1.414, g) for _ in range(H)]) * 0.5
+    a2 = torch.cat([O.xavier_normal((1, D), 1.414, g) for _ in range(H)])
+    Gh = torch.randn(Nh, H * D, generator=g)
+    edge = torch.stack([torch.cat([dst, dst + Nh]), torch.cat([src, src + Nh])])
+    N = 2 * Nh
+    assert N * H * (2 * F_ + R) > 2 ** 31
+    xd = torch.cat([xh, xh]).to(d).requires_grad_(True)
+    eed = torch.cat([eeh, eeh]).to(d).requires_grad_(True)
+    ad, a2d = a.to(d).requires_grad_(True), a2.to(d).requires_grad_(True)
+    clear_graph_cache()
+    graph = prepare_graph(edge.to(d), None, N)
+    assert graph.n_hub == 2
+    out = gat_heads(xd, eed, ad, a2d, graph, None, 0.2, True)
+    Gd = torch.cat([Gh, Gh]).to(d)
+    out.backward(Gd)
+    assert torch.equal(out[:Nh], out[Nh:]), "second copy of the graph (offsets beyond 2^31 elements) differs from the first"
+    close(xd.grad[Nh:], xd.grad[:Nh], atol=1e-6, rel_to_max=1e-6, what="g_x of the second copy")
+    close(eed.grad[Eh:], eed.grad[:Eh], atol=1e-6, rel_to_max=1e-6, what="g_edge_embed of the second copy")
+    # a sample of destination nodes of the first copy against the oracle on their in-edges (forward) ...
+    sample = torch.cat([torch.tensor([7]), torch.randint(0, Nh, (300,), generator=g)]).unique()
+    emask = torch.isin(dst, sample)
+    nodes = torch.cat([sample, src[emask]]).unique()
+    relabel = torch.full((Nh,), -1, dtype=torch.long); relabel[nodes] = torch.arange(nodes.numel())
+    sub_edge = torch.stack([relabel[dst[emask]], relabel[src[emask]]])
+    outc = out[:Nh].detach().cpu()
+    for h in range(H):
+        ref = O.gat_layer_forward(xh[nodes], sub_edge, eeh[emask], None, None, a[h], a2[h:h + 1], 0.2, True)
+        close(outc[sample][:, h * D:(h + 1) * D], ref[relabel[sample]], what="sampled rows, head %d" % h)
+    # ... and the weight gradient against a second run on ONE copy: sums over both copies = 2 x
+    del out, Gd, graph
+    clear_graph_cache()
+    x1 = xh.to(d); e1 = eeh.to(d)
+    a1, a21 = a.to(d).requires_grad_(True), a2.to(d).requires_grad_(True)
+    out1 = gat_heads(x1, e1, a1, a21, prepare_graph(torch.stack([dst, src]).to(d), None, Nh), None, 0.2, True)
+    out1.backward(Gh.to(d))
+    close(ad.grad, 2 * a1.grad, atol=1e-3, rel_to_max=2e-5, what="g_a over both copies")
+    close(a2d.grad, 2 * a21.grad, atol=1e-3, rel_to_max=2e-5, what="g_a_2 over both copies")
+    clear_graph_cache()
+
+
 @pytest.mark.parametrize("family", ["2", "1"])
 def test_full_size_cfg2_split_precision_vs_fp32_gemm(family, monkeypatch):
     """BASELINE.json configs[1] at full size: the layer on the split-precision GEMMs (2 half terms under a per-tensor scale,
