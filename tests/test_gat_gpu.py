@@ -793,6 +793,32 @@ def test_spmm_rowsum_long_and_short_segments(N, E, C_, skew):
     close(out, ref.float(), atol=1e-5, rel_to_max=2e-6, what="rowsum")
 
 
+def test_spmm_rowsum_beyond_2_31_elements():
+    """SpecialSpmmFinal with E x out_features = 2.4 G elements of edge values (9.8 GB): row offsets need 64-bit arithmetic.  Two copies
+    of one edge list with the same values: both halves of the output must agree, and a sample of rows with float64 sums."""
+    from recon_amd.gat_layers import SpecialSpmmFinal
+    d = dev()
+    if torch.cuda.get_device_properties(0).total_memory < 100 * 2 ** 30:
+        pytest.skip("needs ~40 GB of device memory")
+    Nh, Eh, C_ = 300000, 2400000, 512
+    assert 2 * Eh * C_ > 2 ** 31
+    g = torch.Generator().manual_seed(3)
+    dst = torch.randint(0, Nh, (Eh,), generator=g)
+    dst[:5000] = 11
+    w = torch.randn(Eh, C_, generator=g)
+    edge = torch.stack([torch.cat([dst, dst + Nh]), torch.zeros(2 * Eh, dtype=torch.long)])
+    wd = torch.cat([w, w]).to(d).requires_grad_(True)
+    out = SpecialSpmmFinal()(edge.to(d), wd, 2 * Nh, 2 * Eh, C_)
+    assert torch.equal(out[:Nh], out[Nh:])
+    rows = torch.cat([torch.tensor([11]), torch.randint(0, Nh, (200,), generator=g)]).unique()
+    ref = torch.stack([w[dst == r].double().sum(0) for r in rows])
+    close(out[rows.to(d)], ref.float(), atol=1e-4, rel_to_max=2e-6, what="sampled rows")
+    G = torch.randn(2 * Nh, C_, generator=g).to(d)
+    out.backward(G)
+    pick = torch.randint(0, 2 * Eh, (1000,), generator=g)
+    assert torch.equal(wd.grad[pick.to(d)], G[edge[0][pick].to(d)])      # GAT/layers.py:67-79: grad_edge_w[e] = grad_out[edge[0, e]]
+
+
 @pytest.mark.parametrize("N,E,F_,R,D,H", [
     (16, 0, 8, 8, 16, 2),             # no edges at all
     (40, 7, 200, 200, 200, 8),        # nearly empty graph at cfg-2 widths (most rows isolated: Z clamp path)
