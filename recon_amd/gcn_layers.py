@@ -202,6 +202,9 @@ def _strides(lead, ld):
     return tuple(reversed(st)) + (1,)
 
 
+_MAX_BATCH = 65535          # graphs per launch (recon_gcn_fwd/bwd return RECON_ERR_UNSUPPORTED above)
+
+
 class SparseMM(torch.autograd.Function):
     """models/layers.py:9-32 is a legacy (non-static) autograd Function for `mm` that current torch can no
     longer run; this static equivalent keeps the name and the gradients dA = g B^T, dB = A^T g."""
@@ -240,9 +243,12 @@ class GraphConvolution(Module):
             self.bias.data.uniform_(-stdv, stdv)
 
     def forward(self, input, adj):
-        if input.dtype == torch.bfloat16:                      # bf16 storage / fp32 accumulate path (module.to(torch.bfloat16))
-            return _GcnB16Function.apply(input, adj, self.weight, self.bias)
-        return _GcnFunction.apply(input, adj, self.weight, self.bias)
+        fn = _GcnB16Function if input.dtype == torch.bfloat16 else _GcnFunction     # bf16 storage / fp32 accumulate (module.to(torch.bfloat16))
+        if input.dim() == 3 and input.shape[0] > _MAX_BATCH:   # 16-bit grid dimension over the graphs; graphs are independent: run slices
+            B = input.shape[0]
+            return torch.cat([fn.apply(input[b0:b0 + _MAX_BATCH], adj[b0:b0 + _MAX_BATCH] if adj.dim() == 3 else adj, self.weight, self.bias)
+                              for b0 in range(0, B, _MAX_BATCH)], dim=0)
+        return fn.apply(input, adj, self.weight, self.bias)
 
     def __repr__(self):
         return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'

@@ -109,6 +109,9 @@ def build_block_adjacency(T, identity, n):
 
 
 # ------------------------------------------------------------------------------- P2
+_MAX_BATCH = 65535          # graphs per launch (recon_propagate_* / recon_gcn_*: RECON_ERR_UNSUPPORTED above)
+
+
 def _ptr_array(tensors):
     arr = (C.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
@@ -179,6 +182,16 @@ def propagate(adj_list, h0, nonlinearity, head_indices, tail_indices):
     stores them.  Returns cat(relation_1..L, -1): [B, C, 2d*L]."""
     if nonlinearity not in _lib.ACT:
         raise NotImplementedError(nonlinearity)
+    B = adj_list[0].shape[0] if adj_list else 0
+    if B > _MAX_BATCH:                    # the kernels index graphs with a 16-bit grid dimension; graphs are independent: run slices
+        outs = []
+        for b0 in range(0, B, _MAX_BATCH):
+            sl = slice(b0, min(B, b0 + _MAX_BATCH))
+            hs = h0[sl] if h0.dim() == 4 else h0
+            hi = head_indices[sl] if head_indices.dim() == 3 and head_indices.shape[0] == B else head_indices
+            ti = tail_indices[sl] if tail_indices.dim() == 3 and tail_indices.shape[0] == B else tail_indices
+            outs.append(_Propagate.apply(hs, nonlinearity, hi, ti, *[a[sl] for a in adj_list]))
+        return torch.cat(outs, dim=0)
     return _Propagate.apply(h0, nonlinearity, head_indices, tail_indices, *adj_list)
 
 

@@ -241,6 +241,46 @@ def test_gcn_beyond_4_gib_activations(dtype):
         close(xd.grad[:k].float(), xr.grad, what="g_x", **tol)
 
 
+def test_batches_above_the_grid_limit_run_in_slices(monkeypatch):
+    """More than 65 535 graphs per call (the kernels' 16-bit grid dimension) are run in slices by the host side; here the limit is
+    lowered to 3 / 2 graphs: outputs and gradients of a 7-graph batch must equal the one-launch results."""
+    from recon_amd import propagation, gcn_layers
+    from recon_amd.propagation import build_block_adjacency, propagate, make_start_embedding, get_head_indices, get_tail_indices
+    d_ = dev()
+    n, d, L, B = 4, 2, 2, 7
+    C, S, dd = n * (n - 1), 2 * d * n, 2 * d
+    g = torch.Generator().manual_seed(2)
+    Ts = [(torch.rand(B, C, dd * dd, generator=g) - 0.4) * 0.5 for _ in range(L)]
+    ident0 = torch.eye(dd) + 0.05 * torch.randn(dd, dd, generator=g)
+    h00 = torch.randn(B, C, S, 1, generator=g) * torch.from_numpy(make_start_embedding(n, d)).float()
+    head = torch.from_numpy(get_head_indices(n, d, bs=B)).to(d_)          # [B, C, 2d] as the reference stores them
+    tail = torch.from_numpy(get_tail_indices(n, d, bs=B)).to(d_)
+    Gr = torch.randn(B, C, dd * L, generator=g).to(d_)
+    x0 = torch.randn(B, 5, 6, generator=g); adj0 = torch.rand(B, 5, 5, generator=g); Gg = torch.randn(B, 5, 4, generator=g).to(d_)
+    torch.manual_seed(0)
+    layer = gcn_layers.GraphConvolution(6, 4).to(d_)
+    res = []
+    for lim_p, lim_g in ((65535, 65535), (3, 2)):
+        monkeypatch.setattr(propagation, "_MAX_BATCH", lim_p)
+        monkeypatch.setattr(gcn_layers, "_MAX_BATCH", lim_g)
+        Tl = [t.clone().to(d_).requires_grad_(True) for t in Ts]
+        I = ident0.clone().to(d_).requires_grad_(True)
+        h = h00.clone().to(d_).requires_grad_(True)
+        out = propagate([build_block_adjacency(torch.relu(t), I, n) for t in Tl], h, "tanh", head, tail)
+        (out * Gr).sum().backward()
+        x = x0.clone().to(d_).requires_grad_(True); adj = adj0.clone().to(d_).requires_grad_(True)
+        layer.zero_grad()
+        og = layer(x, adj)
+        (og * Gg).sum().backward()
+        res.append([out, h.grad, I.grad] + [t.grad for t in Tl] + [og, x.grad, adj.grad, layer.weight.grad.clone(), layer.bias.grad.clone()])
+    names = ["out", "g_h0", "g_identity", "g_T0", "g_T1", "gcn out", "gcn g_x", "gcn g_adj", "gcn g_weight", "gcn g_bias"]
+    for nm, a_, b_ in zip(names, res[0], res[1]):
+        if nm in ("g_identity", "gcn g_weight", "gcn g_bias"):            # sums over the batch: slices add in a different order
+            close(b_, a_, atol=1e-5, rel_to_max=1e-5, what=nm)
+        else:
+            assert torch.equal(a_, b_), nm
+
+
 def test_gcn_inplace_edit_of_result_is_caught():
     """The tensor saved for the backward (its sign is the ReLU mask) is the tensor the caller holds: editing it in place
     must trip autograd's version check instead of silently corrupting the mask."""
