@@ -214,6 +214,11 @@ typedef struct {
                                  * power-of-two scales derive from them) and a page of zeros; zeroed by the     *
                                  * scores stage; the backward publishes grad_out's slots and re-zeroes them     *
                                  * in its last kernel, so it must be given the aux of the matching forward      */
+    const int32_t* ee_index;    /* NULL: edge_embed holds one row per edge.  Else [E], CSR-slot order: edge_embed is a TABLE and the *
+                                 * edge in slot k uses row ee_index[k] of it — `relation_embed[edge_type]` (GAT/models.py:156, :79)  *
+                                 * read in place instead of materialised as E x R; n-hop edges index rows appended to the table.      *
+                                 * The backward then writes g_edge_embed [E,R] in CSR-SLOT order (row k = gradient of the row slot k    *
+                                 * used); summing those rows by ee_index gives the table's gradient (recon_spmm_rowsum_fwd).            */
 } recon_gat_atp_args;
 
 size_t recon_gat_atp_split_bytes(int32_t F, int32_t R, int32_t D, int32_t H);

@@ -835,6 +835,7 @@ struct AtpBwdK {
     int32_t hub_chunk, n_piece;
     const int4* piece;
     float* hubG;
+    int32_t gee_by_slot;        // edge_embed is a table read through `eid` (recon_gat_atp_args.ee_index): g_ee rows go by CSR slot
 };
 
 // wave = one destination node; head groups of HT are walked one after the other by the SAME wave so the
@@ -1069,7 +1070,7 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                             store_vec<VEC>(dst, gxs[r]);
                         }
                         if (aR[r] && p.g_ee) {
-                            float* dst = p.g_ee + static_cast<int64_t>(e) * R + cf[r];
+                            float* dst = p.g_ee + static_cast<int64_t>(p.gee_by_slot ? k : e) * R + cf[r];
                             if (hg > 0) { float o[VEC]; load_vec<VEC>(o, dst);
 #pragma unroll
                                 for (int v = 0; v < VEC; ++v) gr[r][v] += o[v]; }
@@ -1543,7 +1544,7 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
         // 18.7 us, 64 / 128 rows 25.4 us
         constexpr int rd_n = 32, rd_e = 64;
         jn.nb = static_cast<int>(ceil_div64(N, rd_n) < 2048 ? ceil_div64(N, rd_n) : 2048);
-        je.X = a->edge_embed; je.gather = g->eid; je.rows = E; je.K = R; je.F = 0; je.off = 2 * F; je.NJ = H; je.out = a->c_rel;
+        je.X = a->edge_embed; je.gather = a->ee_index ? a->ee_index : g->eid; je.rows = E; je.K = R; je.F = 0; je.off = 2 * F; je.NJ = H; je.out = a->c_rel;
         je.nb = E > 0 ? static_cast<int>(ceil_div64(E, rd_e) < 2048 ? ceil_div64(E, rd_e) : 2048) : 0;
         const size_t lds_n = static_cast<size_t>(2) * H * F * sizeof(float), lds_e = static_cast<size_t>(H) * R * sizeof(float);
         const size_t lds = lds_n > lds_e ? lds_n : lds_e;
@@ -1571,7 +1572,7 @@ extern "C" int recon_gat_atp_aggregate(const recon_graph* g, const recon_gat_atp
     const bool train = a->Z != nullptr;
     hipStream_t st = as_stream(stream);
     AtpFwdK p;
-    p.rowptr = g->rowptr_dst; p.src = g->src; p.eid = g->eid;
+    p.rowptr = g->rowptr_dst; p.src = g->src; p.eid = a->ee_index ? a->ee_index : g->eid;       // the row of edge_embed a slot reads
     p.x = a->x; p.ee = a->edge_embed; p.c_node = a->c_node; p.c_rel = a->c_rel; p.keep = a->keep;
     p.V = a->V; p.sigma = a->sigma; p.Z = a->Z; p.Zk = a->Zk;
     p.N = a->N; p.E = a->E; p.F = a->F; p.R = a->R; p.H = a->H; p.alpha = a->alpha;
@@ -1730,7 +1731,8 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
     // (2) edge pass over the destination CSR
     {
         AtpBwdK p;
-        p.rowptr = g->rowptr_dst; p.src = g->src; p.eid = g->eid;
+        p.rowptr = g->rowptr_dst; p.src = g->src; p.eid = a->ee_index ? a->ee_index : g->eid;
+        p.gee_by_slot = a->ee_index ? 1 : 0;
         p.x = a->x; p.ee = a->edge_embed; p.keep = a->keep; p.sigma = a->sigma; p.Z = a->Z; p.Zk = a->Zk;
         p.q = b->q; p.gV = b->g_V; p.u = a->u;
         p.gsigma = b->g_sigma; p.Gs_dst = b->Gs; p.Gxs = b->Gxs; p.gxd = b->gxd; p.g_ee = b->g_edge_embed;
@@ -1810,6 +1812,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
             // launch for the partial sums and one for the fixed-order reduce (these kernels are a few MB each and latency
             // bound: every launch saved is ~10 us); each third of `partial2` serves one product.
             struct Prod { const float* G; int ldg, nj; const float* X; const int32_t* gather; int rows, K, P; int64_t S1, S2; float* out; };
+            const int32_t* ee_gather = a->ee_index ? a->ee_index : g->eid;
             const size_t third = recon_gat_atp_bwd_partial2_floats(N, E, F, R, D, H) / 3;
             auto run_jobs = [&](const Prod* pr, int count) {
                 SkinnyJob sj[3];
@@ -1844,7 +1847,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
                 // (s, h) lands in g_u[h][s*F ...]) as two H-column jobs, and the edge-side product g_sigma^T edge_embed[eid]
                 const Prod pr[3] = {{b->Gs, 2 * H, H, a->x, nullptr, N, F, H, W, 0, b->g_u},
                                     {b->Gs + H, 2 * H, H, a->x, nullptr, N, F, H, W, 0, b->g_u + F},
-                                    {b->g_sigma, H, H, a->edge_embed, g->eid, E, R, H, W, 0, b->g_u + 2 * F}};
+                                    {b->g_sigma, H, H, a->edge_embed, ee_gather, E, R, H, W, 0, b->g_u + 2 * F}};
                 run_jobs(pr, 3);
             } else {
                 for (int j = 0; j < 2 * H; ++j) {                        // more than 8 heads: one column at a time keeps the map simple
@@ -1853,7 +1856,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
                 }
                 for (int h0 = 0; h0 < H; h0 += 16) {
                     const int nh = H - h0 < 16 ? H - h0 : 16;
-                    const Prod one = {b->g_sigma + h0, H, nh, a->edge_embed, g->eid, E, R, nh, W, 0, b->g_u + static_cast<int64_t>(h0) * W + 2 * F};
+                    const Prod one = {b->g_sigma + h0, H, nh, a->edge_embed, ee_gather, E, R, nh, W, 0, b->g_u + static_cast<int64_t>(h0) * W + 2 * F};
                     run_jobs(&one, 1);
                 }
             }

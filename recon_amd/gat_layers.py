@@ -127,16 +127,7 @@ class _GatherRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
-        index = ctx.index
-        g = prepare_graph(_segment_key(index), None, ctx.n_rows)
-        grad = grad.contiguous()
-        out = torch.empty(ctx.n_rows, grad.shape[1], dtype=torch.float32, device=grad.device)
-        L = _lib.lib()
-        ws = torch.empty(L.recon_spmm_rowsum_workspace_floats(g.E, grad.shape[1]), dtype=torch.float32, device=grad.device)
-        with torch.cuda.device(grad.device):
-            _lib.check(L.recon_spmm_rowsum_fwd(C.byref(g.c), grad.data_ptr(), grad.shape[1], out.data_ptr(), ws.data_ptr(),
-                                               _lib.current_stream()), "recon_spmm_rowsum_fwd")
-        return out, None
+        return _rowsum_by_index(grad.contiguous(), ctx.index, ctx.n_rows), None
 
 
 class _SmallMM(torch.autograd.Function):
@@ -281,14 +272,14 @@ def _p(t):
 
 
 def _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split=None, aux=None,
-              keep_max=1.0):
+              keep_max=1.0, ee_index=None):
     """recon_gat_atp_args from tensors or raw device pointers (workspace slices)."""
     H, D = a2.shape
     return _lib.GatAtpArgs(graph.N, graph.E, x.shape[1], ee.shape[1], D, H, int(bool(concat)), float(alpha),
                            x.data_ptr(), ee.data_ptr(), a.data_ptr(), a2.data_ptr(), _p(keep), _p(u),
                            _p(c_node), _p(c_rel), _p(V), _p(sigma), _p(Z), _p(Zk),
                            out.data_ptr(), out.shape[1], _p(a_split), SPLIT_F16X2 if aux is not None else SPLIT_BF16X3,
-                           float(keep_max), _p(aux))
+                           float(keep_max), _p(aux), _p(ee_index))
 
 
 _PAD_MIN_OUT = 1 << 18            # below this many output elements the padding's extra launches cost more than the aligned GEMMs win
@@ -374,7 +365,8 @@ class _GATHeadsATPFunction(torch.autograd.Function):
     """Same contract as _GATHeadsFunction, through the aggregate-then-project kernels (csrc/gat_atp.hip)."""
 
     @staticmethod
-    def forward(ctx, x, ee, a, a2, graph, keep, alpha, concat, keep_max):
+    def forward(ctx, x, ee, a, a2, graph, keep, alpha, concat, keep_max, ee_index=None):
+        """ee_index (int64 [E], original edge order) makes `ee` a table: edge e uses row ee_index[e] (see gat_heads)."""
         _require_gpu_f32(x, ee, a, a2, keep)
         L = _lib.lib()
         x, ee, a, a2 = x.contiguous(), ee.contiguous(), a.contiguous(), a2.contiguous()
@@ -382,8 +374,13 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         N, E = graph.N, graph.E
         F_, R = x.shape[1], ee.shape[1]
         W = 2 * F_ + R
-        if x.shape[0] != N or ee.shape[0] != E or a.shape != (H, D, W):
+        if x.shape[0] != N or (ee.shape[0] != E and ee_index is None) or a.shape != (H, D, W):
             raise ValueError("recon_amd.gat_heads: inconsistent shapes")
+        idx_slot = None
+        if ee_index is not None:
+            if ee_index.shape != (E,) or ee_index.dtype != torch.int64:
+                raise ValueError("recon_amd.gat_heads: ee_index must be an int64 [E] tensor")
+            idx_slot = graph.slot_order_index(ee_index, ee.shape[0])          # int32 [E], the row each CSR slot reads
         dev = x.device
         need_grad = any(ctx.needs_input_grad[:4])
         train = need_grad or keep is not None
@@ -400,7 +397,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
             keep_max = 1.0
         elif keep_max is None:                                  # explicit factors without a bound: one host read (tests)
             keep_max = float(keep.max()) if aux is not None and keep.numel() else 1.0
-        args = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split, aux, keep_max)
+        args = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split, aux, keep_max, idx_slot)
         graph.reserve_hub_ws(F_, R, H)
         with _on_device(dev):
             _lib.check(L.recon_gat_atp_fwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_atp_fwd")
@@ -408,6 +405,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
             ctx.save_for_backward(x, ee, a, a2, keep, out, ws)
             ctx.ptrs = (u, c_node, c_rel, V, sigma, Z, Zk, a_split, aux)
             ctx.graph, ctx.alpha, ctx.concat, ctx.keep_max = graph, alpha, concat, keep_max
+            ctx.idx_slot = idx_slot
         return out
 
     @staticmethod
@@ -437,7 +435,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         g_a = torch.empty(H, D, W, **f32) if want_a else None
         g_a2 = torch.empty(H, D, **f32) if want_a else None
         fwd = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, ctx.alpha, ctx.concat, a_split, aux,
-                        ctx.keep_max)
+                        ctx.keep_max, ctx.idx_slot)
         args = _lib.GatAtpBwdArgs(fwd, grad_out.data_ptr(), grad_out.shape[1], g_h, g_V, g_sigma, Gxs, gxd, Gs, g_u, q, partial, partial2,
                                   _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2), gh_split)
         graph.reserve_hub_ws(F_, R, H)
@@ -458,7 +456,23 @@ class _GATHeadsATPFunction(torch.autograd.Function):
                         t.record_stream(side)
             else:
                 _lib.check(L.recon_gat_atp_bwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_atp_bwd")
-        return g_x, g_ee, (g_a if na else None), (g_a2 if na2 else None), None, None, None, None, None
+        if g_ee is not None and ctx.idx_slot is not None:
+            # table mode: g_ee holds one row per CSR slot; the table's gradient is their sum by row index (fixed order: the same
+            # segment walk as SpecialSpmmFinal)
+            g_ee = _rowsum_by_index(g_ee, graph.slot_index_long(ctx.idx_slot), ee.shape[0])
+        return g_x, g_ee, (g_a if na else None), (g_a2 if na2 else None), None, None, None, None, None, None
+
+
+def _rowsum_by_index(rows, index, n_rows):
+    """out[r] = sum of rows[k] over k with index[k] == r (index int64 [E]), fixed summation order."""
+    g = prepare_graph(_segment_key(index), None, n_rows)
+    out = torch.empty(n_rows, rows.shape[1], dtype=torch.float32, device=rows.device)
+    L = _lib.lib()
+    ws = torch.empty(L.recon_spmm_rowsum_workspace_floats(g.E, rows.shape[1]), dtype=torch.float32, device=rows.device)
+    with torch.cuda.device(rows.device):
+        _lib.check(L.recon_spmm_rowsum_fwd(C.byref(g.c), rows.data_ptr(), rows.shape[1], out.data_ptr(), ws.data_ptr(), _lib.current_stream()),
+                   "recon_spmm_rowsum_fwd")
+    return out
 
 
 def gat_path_for(N, E, F_, R, D, H):
@@ -473,14 +487,21 @@ def gat_path_for(N, E, F_, R, D, H):
     return "atp" if (ok and 2 * E >= N) else "proj"
 
 
-def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=True, keep_max=None):
+def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=True, keep_max=None, ee_index=None):
     """Fused forward of H `SpGraphAttentionLayer`s that share their inputs (GAT/models.py:71-72).
 
     x [N,F]; edge_embed_all [E,R] (1-hop rows then n-hop rows, original order); a [H,D,2F+R];
     a_2 [H,D]; graph = prepare_graph(edge, edge_list_nhop, N); keep [H,E] dropout factors in
     original edge order or None; keep_max an upper bound of them (1/(1-p); read back from `keep` when omitted).
+    ee_index (int64 [E], original edge order) turns edge_embed_all into a TABLE [T,R]: edge e uses row ee_index[e] —
+    `relation_embed[edge_type]` (GAT/models.py:79, :156) read in place by the kernels instead of materialised as E x R by the caller
+    (at 272 k edges x 200 columns that tensor is 218 MB, written once and read four times per step); the table's gradient comes back
+    summed over the edges of each row.
     Returns [N, H*D] (heads concatenated along dim 1)."""
     H, D = a_2.shape
+    if ee_index is not None and (x.dtype != torch.float32 or
+                                 gat_path_for(graph.N, graph.E, x.shape[1], edge_embed_all.shape[1], D, H) != "atp"):
+        return gat_heads(x, gather_rows(edge_embed_all, ee_index), a, a_2, graph, keep, alpha, concat, keep_max)   # only the ATP kernels index
     if x.dtype in (torch.bfloat16, torch.float16):
         # Reduced-precision STORAGE at the layer boundary (BASELINE.json configs[4]: "mixed GAT+Propagation stack, bf16"): features
         # and edge embeddings arrive and leave in x.dtype; scores, softmax, aggregation and projections run the fp32 kernels (the
@@ -497,9 +518,9 @@ def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=Tru
             N = x.shape[0]
             a_p = torch.nn.functional.pad(a, (0, 0, 0, Dp - D))
             a2_p = torch.nn.functional.pad(a_2, (0, Dp - D))
-            out_p = _GATHeadsATPFunction.apply(x, edge_embed_all, a_p, a2_p, graph, keep, alpha, concat, keep_max)
+            out_p = _GATHeadsATPFunction.apply(x, edge_embed_all, a_p, a2_p, graph, keep, alpha, concat, keep_max, ee_index)
             return out_p.view(N, H, Dp)[:, :, :D].reshape(N, H * D)
-        return _GATHeadsATPFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat, keep_max)
+        return _GATHeadsATPFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat, keep_max, ee_index)
     return _GATHeadsFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat)
 
 

@@ -59,6 +59,7 @@ class GraphCSR:
                                      ws_bytes, _lib.current_stream())
         _lib.check(rc, "recon_graph_build")
         self._eid_long = None
+        self._slot_idx = {}
         # hub rows (include/recon_hip.h): destinations with more than HUB_CHUNK in-edges are cut into pieces, one wavefront each
         self.n_hub = self.n_piece = self.n_hub_src = self.n_piece_src = 0
         self._hub_ws = None
@@ -84,6 +85,30 @@ class GraphCSR:
                                                                                  self.piece_src.data_ptr())
                 with torch.cuda.device(dev):
                     _lib.check(L.recon_graph_hubs_fill(C.byref(self.c), _lib.current_stream()), "recon_graph_hubs_fill")
+
+    def slot_order_index(self, index, n_rows):
+        """int32 [E]: index (int64 [E], original edge order) permuted to CSR-slot order — the table row each slot reads
+        (recon_gat_atp_args.ee_index).  Cached per index tensor (identity + version): the two layers of a SpGAT share it."""
+        key = (index.data_ptr(), index._version, tuple(index.stride()))
+        hit = self._slot_idx.get(key)
+        if hit is None:
+            if _VALIDATE and self.E > 0:
+                lo, hi = torch.aminmax(index)
+                if int(lo) < 0 or int(hi) >= n_rows:
+                    raise IndexError("recon_amd: row index out of range: [%d, %d] into a table of %d rows" % (int(lo), int(hi), n_rows))
+            slot_long = index[self.eid_long].contiguous()
+            hit = (slot_long.to(torch.int32), slot_long, index)              # `index` pins data_ptr identity while cached
+            if len(self._slot_idx) >= 4:
+                self._slot_idx.pop(next(iter(self._slot_idx)))
+            self._slot_idx[key] = hit
+        return hit[0]
+
+    def slot_index_long(self, idx_slot):
+        """The int64 twin of a slot_order_index() result (the segment key of the table-gradient row sum)."""
+        for i32, i64, _ in self._slot_idx.values():
+            if i32 is idx_slot:
+                return i64
+        return idx_slot.long()
 
     def reserve_hub_ws(self, F, R, H):
         """Scratch of the hub pieces' partial sums for one KB-GAT layer call of these sizes; grows, never shrinks (the calls on one graph

@@ -671,6 +671,65 @@ def test_hub_rows_split_vs_oracle_and_unsplit(N, F_, R, D, H, concat, drop, trai
         close(rest[1], g_ee, atol=1e-4, what="g_edge_embed")
 
 
+@pytest.mark.parametrize("N,E,F_,R,D,H,concat,drop,nrel,extra", [
+    (200, 3000, 24, 16, 32, 4, True, False, 7, 0),        # relation table only (1-hop edges), f16 x 2 capable
+    (200, 3000, 24, 16, 32, 4, True, True, 7, 500),       # + 500 edges with rows of their own appended to the table (n-hop edges), dropout
+    (60, 900, 10, 6, 50, 2, True, False, 3, 40),          # VEC 2
+    (70, 1200, 12, 8, 20, 11, True, False, 5, 0),         # 11 heads: the per-slot gradient rows are accumulated over two head groups
+    (50, 800, 200, 200, 40, 1, False, False, 9, 100),     # out_att-like
+])
+def test_edge_embed_as_indexed_table(N, E, F_, R, D, H, concat, drop, nrel, extra, monkeypatch):
+    """gat_heads(..., ee_index=...): `relation_embed[edge_type]` read in place from the table.  Outputs must be bit-equal to the call on
+    the materialised E x R tensor (the kernels read the same values), input gradients equal, and the table's gradient the row sum of
+    the materialised call's per-edge gradient; everything against the oracle as well.  Hub rows included."""
+    from recon_amd import gat_layers
+    from recon_amd.graph import prepare_graph
+    monkeypatch.setattr(gat_layers, "_GAT_PATH", "atp")
+    d = dev()
+    g = torch.Generator().manual_seed(N + E)
+    dst = torch.randint(0, N, (E,), generator=g); dst[:E // 3] = 3                   # one hub destination
+    src = torch.randint(0, N, (E,), generator=g); src[E // 2:E // 2 + 100] = 5       # and a hub source
+    edge = torch.stack([dst, src])
+    table = torch.randn(nrel + extra, R, generator=g) * 0.5
+    index = torch.randint(0, nrel, (E,), generator=g)
+    if extra:
+        index[E - extra:] = nrel + torch.arange(extra)                                # the last `extra` edges own a row each
+    x = torch.randn(N, F_, generator=g)
+    a = torch.stack([O.xavier_normal((D, 2 * F_ + R), 1.414, g) for _ in range(H)]) * 0.5
+    a2 = torch.cat([O.xavier_normal((1, D), 1.414, g) for _ in range(H)])
+    keep = (torch.rand(H, E, generator=g) > 0.3).float() / 0.7 if drop else None
+    G = torch.randn(N, H * D, generator=g)
+    graph = prepare_graph(edge.to(d), None, N)
+    assert graph.n_hub >= 1
+    res = []
+    for mode in ("table", "dense"):
+        xd, td, ad, a2d = (t.to(d).requires_grad_(True) for t in (x, table, a, a2))
+        kd = keep.to(d) if drop else None
+        if mode == "table":
+            out = gat_layers.gat_heads(xd, td, ad, a2d, graph, kd, 0.2, concat, ee_index=index.to(d))
+        else:
+            out = gat_layers.gat_heads(xd, gat_layers.gather_rows(td, index.to(d)), ad, a2d, graph, kd, 0.2, concat)
+        (out * G.to(d)).sum().backward()
+        res.append([t.detach().cpu() for t in (out, xd.grad, ad.grad, a2d.grad, td.grad)])
+    assert torch.equal(res[0][0], res[1][0]), "outputs differ between table and materialised edge embeddings"
+    for nm, t_, m_ in zip(("g_x", "g_a", "g_a_2", "g_table"), res[0][1:], res[1][1:]):
+        close(t_, m_, atol=1e-5, rel_to_max=1e-5, what="table vs materialised " + nm)
+    ee = table[index]
+    g_x = torch.zeros_like(x); g_ee = torch.zeros_like(ee)
+    for h in range(H):
+        r = O.gat_layer_backward(x.double(), edge, ee.double(), None, None, a[h].double(), a2[h:h + 1].double(), 0.2, concat,
+                                 G[:, h * D:(h + 1) * D].double(), mask=keep[h].double() if drop else None)
+        close(res[0][0][:, h * D:(h + 1) * D], r["out"].float(), what="out h%d" % h)
+        close(res[0][2][h], r["g_a"].float(), atol=1e-4, what="g_a h%d" % h)
+        g_x += r["g_x"].float(); g_ee += r["g_edge_embed"].float()
+    close(res[0][1], g_x, atol=1e-4, what="g_x")
+    close(res[0][4], torch.zeros_like(table).index_add_(0, index, g_ee), atol=1e-4, what="g_table")
+    with torch.no_grad():                                                            # inference call
+        out_i = gat_layers.gat_heads(x.to(d), table.to(d), a.to(d), a2.to(d), graph, None, 0.2, concat, ee_index=index.to(d))
+    if not drop:
+        close(out_i, res[0][0], atol=1e-6, rel_to_max=1e-6, what="inference")
+
+
 def test_heads_of_width_25_run_padded():
     """The reference's D = 25 per head (H * D = 200): above `_PAD_MIN_OUT` output elements `gat_heads` runs the heads 32 wide with
     zero rows appended to `a` / `a_2` and drops the extra columns; outputs and every gradient against the oracle, unpadded."""
