@@ -13,6 +13,8 @@ No CPU path: tensors must be on an MI355X; a missing librecon_hip.so raises Runt
 import ctypes as C
 import os
 
+from collections import OrderedDict
+
 import torch
 import torch.nn as nn
 
@@ -524,11 +526,46 @@ def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=Tru
     return _GATHeadsFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat)
 
 
+class IndexedRows:
+    """`table[index]` that has not been materialised: what the reference writes as `relation_embed[edge_type]` (GAT/models.py:79,
+    :156), handed to the attention layer as the pair so that the kernels read the table in place (gat_heads' ee_index)."""
+
+    def __init__(self, table, index):
+        self.table, self.index = table, index
+
+    def materialize(self):
+        return gather_rows(self.table, self.index)
+
+
+_INDEX_CACHE = OrderedDict()
+
+
+def _extended_index(index, n_rows, n_extra):
+    """cat(index, n_rows + arange(n_extra)): the n-hop edges' rows are appended to the table.  One tensor per (index tensor, sizes) so
+    that the per-graph caches keyed on it (slot order, row-sum CSR) hit across steps."""
+    key = (index.data_ptr(), index._version, tuple(index.shape), int(n_rows), int(n_extra))
+    hit = _INDEX_CACHE.get(key)
+    if hit is None:
+        hit = (torch.cat((index, torch.arange(n_rows, n_rows + n_extra, dtype=torch.int64, device=index.device))), index)
+        _INDEX_CACHE[key] = hit
+        while len(_INDEX_CACHE) > 8:
+            _INDEX_CACHE.popitem(last=False)
+    else:
+        _INDEX_CACHE.move_to_end(key)
+    return hit[0]
+
+
 def cat_edge_embed(edge_embed, edge_list_nhop, edge_embed_nhop):
-    """GAT/layers.py:126-127."""
+    """GAT/layers.py:126-127.  Returns (rows, ee_index): ee_index is None for a materialised [E,R] tensor; for IndexedRows the rows are
+    the table (with the n-hop edges' rows appended) and ee_index [E] says which row each edge uses."""
+    if isinstance(edge_embed, IndexedRows):
+        table, index = edge_embed.table, edge_embed.index
+        if _has_nhop(edge_list_nhop):
+            return torch.cat((table, edge_embed_nhop), dim=0), _extended_index(index, table.shape[0], edge_embed_nhop.shape[0])
+        return table, index
     if _has_nhop(edge_list_nhop):
-        return torch.cat((edge_embed, edge_embed_nhop), dim=0)
-    return edge_embed
+        return torch.cat((edge_embed, edge_embed_nhop), dim=0), None
+    return edge_embed, None
 
 
 class SpGraphAttentionLayer(nn.Module):
@@ -566,10 +603,10 @@ class SpGraphAttentionLayer(nn.Module):
     def forward(self, input, edge, edge_embed, edge_list_nhop, edge_embed_nhop):
         N = input.size()[0]                                  # not self.num_nodes (GAT/layers.py:112)
         graph = prepare_graph(edge, edge_list_nhop, N)
-        ee = cat_edge_embed(edge_embed, edge_list_nhop, edge_embed_nhop)
+        ee, ee_index = cat_edge_embed(edge_embed, edge_list_nhop, edge_embed_nhop)     # edge_embed: [E,R] as in the reference, or IndexedRows
         keep = self.draw_keep(graph.E, input.device)
         out = gat_heads(input, ee, self.a.unsqueeze(0), self.a_2, graph, keep, self.alpha, self.concat,
-                        keep_max=self.keep_bound() if keep is not None else None)
+                        keep_max=self.keep_bound() if keep is not None else None, ee_index=ee_index)
         if _DEBUG_NAN:                                       # the reference's asserts (:147,:167,:172)
             assert not torch.isnan(out).any()
         return out

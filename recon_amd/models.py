@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed, gather_rows, small_mm
+from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed, gather_rows, small_mm, IndexedRows
 from .graph import prepare_graph
 
 
@@ -65,17 +65,21 @@ class SpGAT(nn.Module):
     def heads_forward(self, x, edge_list, edge_embed, edge_list_nhop, edge_embed_nhop):
         """The H-head attention stage (GAT/models.py:71-72) as one fused call."""
         graph = prepare_graph(edge_list, edge_list_nhop, x.shape[0])
-        ee = cat_edge_embed(edge_embed, edge_list_nhop, edge_embed_nhop)
+        ee, ee_index = cat_edge_embed(edge_embed, edge_list_nhop, edge_embed_nhop)
         a, a2 = self.fused_head_params()                                  # [H, D, 2F+R], [H, D]
         keeps = [att.draw_keep(graph.E, x.device) for att in self.attentions]   # reference draw order
         keep = torch.cat(keeps, dim=0) if keeps[0] is not None else None
         return gat_heads(x, ee, a, a2, graph, keep, self.alpha, True,
-                         keep_max=self.attentions[0].keep_bound() if keep is not None else None)
+                         keep_max=self.attentions[0].keep_bound() if keep is not None else None, ee_index=ee_index)
 
     def forward(self, Corpus_, entity_embeddings, relation_embed, edge_list, edge_type, edge_embed,
                 edge_list_nhop, edge_type_nhop):
         x = entity_embeddings
         has_nhop = edge_type_nhop.shape[0] != 0
+        if edge_embed is None:
+            # what every caller in the reference passes is relation_embed[edge_type] (GAT/models.py:156, :212): with None the layer reads
+            # the relation table in place instead of an E x R copy of it
+            edge_embed = IndexedRows(relation_embed, edge_type)
         if has_nhop:
             edge_embed_nhop = gather_rows(relation_embed, edge_type_nhop[:, 0]) + gather_rows(relation_embed, edge_type_nhop[:, 1])
         else:
@@ -83,7 +87,7 @@ class SpGAT(nn.Module):
         x = self.heads_forward(x, edge_list, edge_embed, edge_list_nhop, edge_embed_nhop)
         x = self.dropout_layer(x)
         out_relation_1 = small_mm(relation_embed, self.W)
-        edge_embed = gather_rows(out_relation_1, edge_type)
+        edge_embed = IndexedRows(out_relation_1, edge_type)               # out_relation_1[edge_type] (:79), read in place by the layer
         if has_nhop:
             edge_embed_nhop = gather_rows(out_relation_1, edge_type_nhop[:, 0]) + gather_rows(out_relation_1, edge_type_nhop[:, 1])
         else:
@@ -132,9 +136,9 @@ class SpKBGATModified(nn.Module):
         dev = entity_embeddings.device
         edge_list, edge_type = edge_list.to(dev), edge_type.to(dev)
         edge_list_nhop, edge_type_nhop = (t.to(dev) if t.numel() else t for t in self._nhop(train_indices_nhop))
-        edge_embed = gather_rows(relation_embeddings, edge_type)
+        # :156 `edge_embed = self.relation_embeddings[edge_type]`: None lets SpGAT read the relation table in place (IndexedRows)
         out_entity, out_relation = self.sparse_gat_1(Corpus_, entity_embeddings, relation_embeddings, edge_list, edge_type,
-                                                     edge_embed, edge_list_nhop, edge_type_nhop)
+                                                     None, edge_list_nhop, edge_type_nhop)
         mask = torch.zeros(entity_embeddings.shape[0], device=dev)
         mask[torch.unique(batch_entities.to(dev))] = 1.0
         out_entity = entity_embeddings.mm(self.W_entities) + mask.unsqueeze(-1) * out_entity

@@ -6,6 +6,7 @@ entities have thousands of edges, as in the real graph.  fp32, forward and forwa
 import json, os, sys
 import numpy as np
 import torch
+DENSE = "--dense" in sys.argv      # pass relation_embed[edge_type] materialised (the reference's call) instead of None (read in place)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recon_amd.models import SpGAT
 from recon_amd.gat_layers import gather_rows
@@ -33,12 +34,12 @@ def run(N=14541, E=272115, nrel=237, F_=100, D=100, H=2, nhop=0, iters=10):
 
     def fwd():
         with torch.no_grad():
-            m(None, x, rel, edge, et, rel[et], edge_nhop, et_nhop)
+            m(None, x, rel, edge, et, rel[et] if DENSE else None, edge_nhop, et_nhop)
 
     def step():
         for q in m.parameters(): q.grad = None
         x.grad = None; rel.grad = None
-        out, _ = m(None, x, rel, edge, et, gather_rows(rel, et), edge_nhop, et_nhop)
+        out, _ = m(None, x, rel, edge, et, gather_rows(rel, et) if DENSE else None, edge_nhop, et_nhop)
         out.backward(G)
     res = {}
     for name, fn in (("fwd", fwd), ("fwd_bwd", step)):

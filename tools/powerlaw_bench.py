@@ -4,6 +4,7 @@ e = min(4096, 16 n) edges, dst ~ Zipf(1), src uniform; SpGAT (8 heads x D=25 + o
 import json, os, sys
 import numpy as np
 import torch
+DENSE = "--dense" in sys.argv      # pass relation_embed[edge_type] materialised (the reference's call) instead of None (read in place)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recon_amd.models import SpGAT
 from recon_amd.gat_layers import gather_rows
@@ -30,11 +31,11 @@ def run(B=64, D=25, F_=200, H=8, nrel=64, iters=10):
     deg = torch.bincount(edge[0], minlength=N)
     def fwd():
         with torch.no_grad():
-            m(None, x, rel, edge, et, rel[et], nohop, nohop)
+            m(None, x, rel, edge, et, rel[et] if DENSE else None, nohop, nohop)
     def step():
         for p in m.parameters(): p.grad = None
         x.grad = None; rel.grad = None
-        out, _ = m(None, x, rel, edge, et, gather_rows(rel, et), nohop, nohop)
+        out, _ = m(None, x, rel, edge, et, gather_rows(rel, et) if DENSE else None, nohop, nohop)
         out.backward(G)
     res = {}
     for name, fn in (("fwd", fwd), ("fwd_bwd", step)):
@@ -49,5 +50,5 @@ def run(B=64, D=25, F_=200, H=8, nrel=64, iters=10):
                       **res, "edges_per_s_fwd_bwd": E / res["fwd_bwd_ms"] * 1e3}))
 
 if __name__ == "__main__":
-    for B in ([int(v) for v in sys.argv[1:]] or [64, 512]):
+    for B in ([int(v) for v in sys.argv[1:] if v.isdigit()] or [64, 512]):
         run(B)

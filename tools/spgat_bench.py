@@ -2,6 +2,7 @@
 """Secondary bench: full SpGAT (H heads + out_att) forward + backward at cfg 2, D = 200 and D = 25."""
 import json, os, sys
 import torch
+DENSE = "--dense" in sys.argv      # pass relation_embed[edge_type] materialised (the reference's call) instead of None (read in place)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recon_amd import synth as O
 from recon_amd.models import SpGAT
@@ -23,7 +24,7 @@ def run(D, B=512, n=16, e=64, F_=200, H=8, nrel=64, iters=10):
     def step():
         for p in m.parameters(): p.grad = None
         x.grad = None; rel.grad = None
-        out, out_rel = m(None, x, rel, edge, et, gather_rows(rel, et), nohop, nohop)
+        out, out_rel = m(None, x, rel, edge, et, gather_rows(rel, et) if DENSE else None, nohop, nohop)
         out.backward(G)
     for _ in range(3): step()
     torch.cuda.synchronize()
@@ -35,5 +36,5 @@ def run(D, B=512, n=16, e=64, F_=200, H=8, nrel=64, iters=10):
     print(json.dumps({"workload": "SpGAT (8 heads + out_att) fwd+bwd, cfg 2", "D_per_head": D, "ms_per_step": ms, "edges_per_s": E / ms * 1e3}))
 
 if __name__ == "__main__":
-    for D in ([int(v) for v in sys.argv[1:]] or [200, 25]):
+    for D in ([int(v) for v in sys.argv[1:] if v.isdigit()] or [200, 25]):
         run(D)
