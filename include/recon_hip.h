@@ -219,6 +219,8 @@ typedef struct {
                                  * read in place instead of materialised as E x R; n-hop edges index rows appended to the table.      *
                                  * The backward then writes g_edge_embed [E,R] in CSR-SLOT order (row k = gradient of the row slot k    *
                                  * used); summing those rows by ee_index gives the table's gradient (recon_spmm_rowsum_fwd).            */
+    int32_t ee_rows;            /* rows of the table when ee_index is set (ignored otherwise).  c_rel then holds max(E, ee_rows) x H    *
+                                 * floats: the score terms r.u_rel are computed once per table ROW and looked up per edge               */
 } recon_gat_atp_args;
 
 size_t recon_gat_atp_split_bytes(int32_t F, int32_t R, int32_t D, int32_t H);

@@ -48,7 +48,7 @@ class GatAtpArgs(C.Structure):
                 ("x", c_f32p), ("edge_embed", c_f32p), ("a", c_f32p), ("a_2", c_f32p), ("keep", c_f32p),
                 ("u", c_f32p), ("c_node", c_f32p), ("c_rel", c_f32p), ("V", c_f32p), ("sigma", c_f32p),
                 ("Z", c_f32p), ("Zk", c_f32p), ("out", c_f32p), ("ld_out", C.c_int32), ("a_split", C.c_void_p),
-                ("split_mode", C.c_int32), ("keep_max", C.c_float), ("aux", C.c_void_p), ("ee_index", c_i32p)]
+                ("split_mode", C.c_int32), ("keep_max", C.c_float), ("aux", C.c_void_p), ("ee_index", c_i32p), ("ee_rows", C.c_int32)]
 
 
 class GatAtpBwdArgs(C.Structure):

@@ -500,6 +500,7 @@ struct AtpFwdK {
     float* V; float* sigma; float* Z; float* Zk;
     int32_t N, E, F, R, H;
     float alpha;
+    int32_t crel_by_row;        // 1: edge_embed is a table (recon_gat_atp_args.ee_index) and c_rel holds one entry per table ROW
     int32_t dst_shared;         // 1: the destination part of V (x_i Zk/Z) is written for head 0 only — without attention dropout Zk = Z and
                                 // every head's copy is the same row; the GEMMs read head 0's (a_shared_k / a_shared_m)
     int32_t planes;             // 1 (2: with paired 16-byte stores, F % 8 == 0 and R % 8 == 0): V is written as half terms [H][N][2][W] of s_V * V (gemm_hx2.hip: high row | low row) instead of fp32 [N][H][W]
@@ -660,7 +661,7 @@ __global__ void __launch_bounds__(kBlock, KR >= 8 ? 2 : 1) k_gat_atp_fwd(const A
                         load_vec<VEC>(xs[u][r], xr + cfF[r]);
                         load_vec<VEC>(re[u][r], rr + cfR[r]);
                     }
-                    sc[u] = cd + p.c_node[static_cast<int64_t>(s) * 2 * H + H + myhc] + p.c_rel[k * H + myhc];
+                    sc[u] = cd + p.c_node[static_cast<int64_t>(s) * 2 * H + H + myhc] + p.c_rel[(p.crel_by_row ? static_cast<int64_t>(e) : k) * H + myhc];
                     kf[u] = p.keep ? p.keep[k * H + myhc] : 1.f;
                 }
 #pragma unroll
@@ -1427,6 +1428,7 @@ int check_atp(const recon_graph* g, const recon_gat_atp_args* a) {
     if (!a->x || !a->a || !a->a_2 || !a->u || !a->c_node || !a->V || !a->out) return RECON_ERR_INVALID;
     if (a->E > 0 && (!a->edge_embed || !a->c_rel)) return RECON_ERR_INVALID;
     if (a->H > 4096) return RECON_ERR_UNSUPPORTED;
+    if (a->ee_index && a->E > 0 && a->ee_rows <= 0) return RECON_ERR_INVALID;
     return RECON_OK;
 }
 
@@ -1544,15 +1546,17 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
         // 18.7 us, 64 / 128 rows 25.4 us
         constexpr int rd_n = 32, rd_e = 64;
         jn.nb = static_cast<int>(ceil_div64(N, rd_n) < 2048 ? ceil_div64(N, rd_n) : 2048);
-        je.X = a->edge_embed; je.gather = a->ee_index ? a->ee_index : g->eid; je.rows = E; je.K = R; je.F = 0; je.off = 2 * F; je.NJ = H; je.out = a->c_rel;
-        je.nb = E > 0 ? static_cast<int>(ceil_div64(E, rd_e) < 2048 ? ceil_div64(E, rd_e) : 2048) : 0;
+        // table mode: one score term per table ROW (looked up by K1' through ee_index), not one per edge
+        const int32_t erows = a->ee_index ? (E > 0 ? a->ee_rows : 0) : E;
+        je.X = a->edge_embed; je.gather = a->ee_index ? nullptr : g->eid; je.rows = erows; je.K = R; je.F = 0; je.off = 2 * F; je.NJ = H; je.out = a->c_rel;
+        je.nb = erows > 0 ? static_cast<int>(ceil_div64(erows, rd_e) < 2048 ? ceil_div64(erows, rd_e) : 2048) : 0;
         const size_t lds_n = static_cast<size_t>(2) * H * F * sizeof(float), lds_e = static_cast<size_t>(H) * R * sizeof(float);
         const size_t lds = lds_n > lds_e ? lds_n : lds_e;
         if (lds > 64 * 1024) return RECON_ERR_UNSUPPORTED;
         const dim3 grid(static_cast<unsigned>(jn.nb + je.nb));
         if (dots_x) {                                                 // 16 rows per wave, 64 per block
             jn.nb = static_cast<int>(ceil_div64(N, 64) < 4096 ? ceil_div64(N, 64) : 4096);
-            je.nb = E > 0 ? static_cast<int>(ceil_div64(E, 64) < 8192 ? ceil_div64(E, 64) : 8192) : 0;
+            je.nb = erows > 0 ? static_cast<int>(ceil_div64(erows, 64) < 8192 ? ceil_div64(erows, 64) : 8192) : 0;
             const int kpm = row_dots_kp(F) > row_dots_kp(R) ? row_dots_kp(F) : row_dots_kp(R);
             hipLaunchKernelGGL(k_row_dots_x, dim3(static_cast<unsigned>(jn.nb + je.nb + nsplit)), dim3(kBlock), sizeof(float) * (2 * H) * kpm, st,
                                jn, je, a->u, H, W, sp, nsplit);
@@ -1576,6 +1580,7 @@ extern "C" int recon_gat_atp_aggregate(const recon_graph* g, const recon_gat_atp
     p.x = a->x; p.ee = a->edge_embed; p.c_node = a->c_node; p.c_rel = a->c_rel; p.keep = a->keep;
     p.V = a->V; p.sigma = a->sigma; p.Z = a->Z; p.Zk = a->Zk;
     p.N = a->N; p.E = a->E; p.F = a->F; p.R = a->R; p.H = a->H; p.alpha = a->alpha;
+    p.crel_by_row = a->ee_index ? 1 : 0;
     p.planes = atp_hx2(a) ? ((a->F % 8 == 0 && a->R % 8 == 0) ? 2 : 1) : 0;
     p.dst_shared = atp_dst_shared(a) ? 1 : 0;
     p.vs = p.planes ? atp_scale_v(a) : Hx2Scale{nullptr, nullptr, 1.f};

@@ -281,7 +281,7 @@ def _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out,
                            x.data_ptr(), ee.data_ptr(), a.data_ptr(), a2.data_ptr(), _p(keep), _p(u),
                            _p(c_node), _p(c_rel), _p(V), _p(sigma), _p(Z), _p(Zk),
                            out.data_ptr(), out.shape[1], _p(a_split), SPLIT_F16X2 if aux is not None else SPLIT_BF16X3,
-                           float(keep_max), _p(aux), _p(ee_index))
+                           float(keep_max), _p(aux), _p(ee_index), ee.shape[0] if ee_index is not None else 0)
 
 
 _PAD_MIN_OUT = 1 << 18            # below this many output elements the padding's extra launches cost more than the aligned GEMMs win
@@ -391,7 +391,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         split_bytes, aux_bytes = _lib_sizes(N, E, F_, R, D, H)[:2]
         # u [H,W], c_node [N,2H], c_rel [E,H], V [N,H,W], sigma [E,H], Z [N,H], Zk [N,H], a_split, aux: one allocation
         ws, (u, c_node, c_rel, V, sigma, Z, Zk, a_split, aux) = _carve(dev, (
-            4 * H * W, 4 * N * 2 * H, 4 * E * H, 4 * N * H * W, 4 * E * H if train else None, 4 * N * H if train else None,
+            4 * H * W, 4 * N * 2 * H, 4 * max(E, ee.shape[0] if ee_index is not None else 0) * H, 4 * N * H * W, 4 * E * H if train else None, 4 * N * H if train else None,
             4 * N * H if train else None, split_bytes if mode else None, aux_bytes if mode == 2 else None))
         if keep is not None:
             keep = keep.view(H, E)[:, graph.eid_long].t().contiguous()        # [H,E] original order -> [E,H] slot order

@@ -677,6 +677,7 @@ def test_hub_rows_split_vs_oracle_and_unsplit(N, F_, R, D, H, concat, drop, trai
     (60, 900, 10, 6, 50, 2, True, False, 3, 40),          # VEC 2
     (70, 1200, 12, 8, 20, 11, True, False, 5, 0),         # 11 heads: the per-slot gradient rows are accumulated over two head groups
     (50, 800, 200, 200, 40, 1, False, False, 9, 100),     # out_att-like
+    (20, 30, 8, 8, 16, 2, True, False, 50, 0),            # more table rows than edges (the per-row score terms outgrow E x H)
 ])
 def test_edge_embed_as_indexed_table(N, E, F_, R, D, H, concat, drop, nrel, extra, monkeypatch):
     """gat_heads(..., ee_index=...): `relation_embed[edge_type]` read in place from the table.  Outputs must be bit-equal to the call on
@@ -700,7 +701,7 @@ def test_edge_embed_as_indexed_table(N, E, F_, R, D, H, concat, drop, nrel, extr
     keep = (torch.rand(H, E, generator=g) > 0.3).float() / 0.7 if drop else None
     G = torch.randn(N, H * D, generator=g)
     graph = prepare_graph(edge.to(d), None, N)
-    assert graph.n_hub >= 1
+    assert graph.n_hub >= 1 or E < 200
     res = []
     for mode in ("table", "dense"):
         xd, td, ad, a2d = (t.to(d).requires_grad_(True) for t in (x, table, a, a2))
