@@ -755,10 +755,10 @@ __global__ void __launch_bounds__(kBlock, KR >= 8 ? 2 : 1) k_gat_atp_fwd(const A
 
 // acc += sum over pieces q in [p0, p1) of the VEC floats at base + q * stride, in table order.  A hub of 9 000 edges has 142 pieces:
 // one load at a time is 142 dependent round trips (measured on a 272 k-edge graph with such hubs: 78 us for the forward combine,
-// 109 us for the source-side one), so eight pieces' loads are issued before the first add.
+// 109 us for the source-side one), so sixteen pieces' loads are issued before the first add.
 template <int VEC>
 __device__ __forceinline__ void sum_pieces(float (&acc)[VEC], const float* __restrict__ base, int64_t stride, int p0, int p1) {
-    constexpr int U = 8;
+    constexpr int U = 16;
     int q = p0;
     for (; q + U <= p1; q += U) {
         float tv[U][VEC];
@@ -790,10 +790,10 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_hub_fwd(const AtpFwdK p, con
     const int t = idx / H, h = idx - t * H;
     const int node = hub_node[t], p0 = hub_ptr[t], p1 = hub_ptr[t + 1];
     const float vscale = PL ? hx2_scale_wave(p.vs) : 1.f;
-    float zz[1] = {0.f}, zzk[1] = {0.f};
-    sum_pieces<1>(zz, p.hubZ + h, 2 * H, p0, p1);
-    sum_pieces<1>(zzk, p.hubZ + H + h, 2 * H, p0, p1);
-    const float Zl = zz[0], Zkl = zzk[0];
+    // Z, Zk: lane q takes pieces p0 + q, p0 + q + 64, ..., then a butterfly — fixed order, and not two more serial walks of the pieces
+    float zl = 0.f, zkl = 0.f;
+    for (int q = p0 + lane; q < p1; q += 64) { zl += p.hubZ[(static_cast<int64_t>(q) * 2) * H + h]; zkl += p.hubZ[(static_cast<int64_t>(q) * 2 + 1) * H + h]; }
+    const float Zl = group_sum<64>(zl), Zkl = group_sum<64>(zkl);
     const float Zc = (Zl == 0.f) ? 1e-12f : Zl;                         // GAT/layers.py:152
     if (p.Z && lane == 0) { p.Z[static_cast<int64_t>(node) * H + h] = Zc; p.Zk[static_cast<int64_t>(node) * H + h] = Zkl; }
     const float invh = (1.f / Zc) * vscale, zk = Zkl * invh;
