@@ -56,7 +56,7 @@ typedef struct {
     int32_t* eid;               /* [E]   CSR slot -> original edge column                    */
     int32_t* src;               /* [E]   source node (edge[1,:]) of each CSR slot            */
     int32_t* dst;               /* [E]   destination node of each CSR slot                   */
-    int32_t* rowptr_src;        /* [N+1] CSC over sources                                    */
+    int32_t* rowptr_src;        /* [N+1] CSC over sources; NULL at build: destination CSR only (src, slot_by_src unused) */
     int32_t* slot_by_src;       /* [E]   CSC position -> CSR slot                            */
     /* Hub rows (optional; all zero = every destination row is walked by one wave, whatever its length).  The aggregate-then-
      * project edge kernels give one wavefront to one destination node; a node with hundreds of in-edges (power-law graphs)

@@ -195,14 +195,15 @@ __global__ void __launch_bounds__(1024) k_hub_scan(const int32_t* __restrict__ r
 }  // namespace
 
 extern "C" int recon_graph_hubs_count(const recon_graph* g, int32_t chunk, void* workspace, int32_t* counts, recon_stream_t stream) {
-    if (!g || !counts || chunk <= 0 || g->N < 0 || !g->rowptr_dst || !g->rowptr_src) return RECON_ERR_INVALID;
+    if (!g || !counts || chunk <= 0 || g->N < 0 || !g->rowptr_dst) return RECON_ERR_INVALID;
     counts[0] = counts[1] = counts[2] = counts[3] = 0;
     if (g->N == 0 || g->E <= chunk) return RECON_OK;
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 3)) return RECON_ERR_INVALID;
     hipStream_t st = as_stream(stream);
     int32_t* d = static_cast<int32_t*>(workspace);
     hipLaunchKernelGGL((k_hub_scan<false>), dim3(1), dim3(1024), 0, st, g->rowptr_dst, g->N, chunk, d, nullptr, nullptr, nullptr);
-    hipLaunchKernelGGL((k_hub_scan<false>), dim3(1), dim3(1024), 0, st, g->rowptr_src, g->N, chunk, d + 2, nullptr, nullptr, nullptr);
+    if (g->rowptr_src) hipLaunchKernelGGL((k_hub_scan<false>), dim3(1), dim3(1024), 0, st, g->rowptr_src, g->N, chunk, d + 2, nullptr, nullptr, nullptr);
+    else if (hipMemsetAsync(d + 2, 0, 2 * sizeof(int32_t), st) != hipSuccess) return RECON_ERR_LAUNCH;
     RECON_CHECK_LAUNCH();
     if (hipMemcpyAsync(counts, d, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
         return RECON_ERR_LAUNCH;
@@ -210,7 +211,7 @@ extern "C" int recon_graph_hubs_count(const recon_graph* g, int32_t chunk, void*
 }
 
 extern "C" int recon_graph_hubs_fill(const recon_graph* g, recon_stream_t stream) {
-    if (!g || g->N < 0 || !g->rowptr_dst || !g->rowptr_src || g->hub_chunk <= 0 || g->n_hub < 0 || g->n_piece < 0 || g->n_hub_src < 0 ||
+    if (!g || g->N < 0 || !g->rowptr_dst || (g->n_hub_src > 0 && !g->rowptr_src) || g->hub_chunk <= 0 || g->n_hub < 0 || g->n_piece < 0 || g->n_hub_src < 0 ||
         g->n_piece_src < 0) return RECON_ERR_INVALID;
     if (g->n_hub > 0) {
         if (!g->hub_node || !g->hub_ptr || !g->piece || (reinterpret_cast<uintptr_t>(g->piece) & 15)) return RECON_ERR_INVALID;
@@ -245,15 +246,17 @@ extern "C" size_t recon_graph_workspace_bytes(int32_t N, int32_t E) {
 extern "C" int recon_graph_build(const int64_t* edge_dst, const int64_t* edge_src, recon_graph* g, void* workspace,
                                  size_t workspace_bytes, recon_stream_t stream) {
     if (!g || g->N < 0 || g->E < 0) return RECON_ERR_INVALID;
-    if (!g->rowptr_dst || !g->rowptr_src) return RECON_ERR_INVALID;
+    if (!g->rowptr_dst) return RECON_ERR_INVALID;
+    const bool with_src = g->rowptr_src != nullptr;                 // NULL: destination CSR only (row sums need no source view)
     const int32_t N = g->N, E = g->E;
     hipStream_t st = as_stream(stream);
     if (E == 0) {
         if (hipMemsetAsync(g->rowptr_dst, 0, sizeof(int32_t) * (N + 1), st) != hipSuccess ||
-            hipMemsetAsync(g->rowptr_src, 0, sizeof(int32_t) * (N + 1), st) != hipSuccess) return RECON_ERR_LAUNCH;
+            (with_src && hipMemsetAsync(g->rowptr_src, 0, sizeof(int32_t) * (N + 1), st) != hipSuccess)) return RECON_ERR_LAUNCH;
         return RECON_OK;
     }
-    if (!edge_dst || !edge_src || !g->eid || !g->src || !g->dst || !g->slot_by_src || !workspace) return RECON_ERR_INVALID;
+    if (!edge_dst || !g->eid || !g->dst || !workspace) return RECON_ERR_INVALID;
+    if (with_src && (!edge_src || !g->src || !g->slot_by_src)) return RECON_ERR_INVALID;
     if (workspace_bytes < recon_graph_workspace_bytes(N, E)) return RECON_ERR_WORKSPACE;
     const size_t e = align_up(static_cast<size_t>(E) * sizeof(int32_t), 256);
     char* w = static_cast<char*>(workspace);
@@ -274,6 +277,7 @@ extern "C" int recon_graph_build(const int64_t* edge_dst, const int64_t* edge_sr
     hipLaunchKernelGGL(k_copy_i32, eb, dim3(256), 0, st, ks, g->dst, E);
     hipLaunchKernelGGL(k_copy_i32, eb, dim3(256), 0, st, vs, g->eid, E);
     hipLaunchKernelGGL(k_rowptr_lower_bound, nb, dim3(256), 0, st, g->dst, E, N, g->rowptr_dst);
+    if (!with_src) { RECON_CHECK_LAUNCH(); return RECON_OK; }
     // source CSC over CSR slots: stable sort of (src of slot, slot)
     hipLaunchKernelGGL(k_gather_src, eb, dim3(256), 0, st, edge_src, g->eid, E, g->src, ws.vA);
     hipLaunchKernelGGL(k_copy_i32, eb, dim3(256), 0, st, g->src, ws.kA, E);

@@ -684,13 +684,17 @@ extern "C" int recon_spmm_rowsum_fwd(const recon_graph* g, const float* edge_w, 
     (void)hipMemsetAsync(out, 0, sizeof(float) * total, st);
     if (g->E == 0) return RECON_OK;
     const int C = out_features;
-    const int vec = (C % 4 == 0 && al(edge_w, 16) && al(out, 16) && al(workspace, 16)) ? 4 : 1;
+    const int vec = (C % 4 == 0 && al(edge_w, 16) && al(out, 16) && al(workspace, 16)) ? 4
+                  : ((C % 2 == 0 && al(edge_w, 8) && al(out, 8) && al(workspace, 8)) ? 2 : 1);       // C = 50: the reference's relation width
     const int nw = static_cast<int>(ceil_div64(g->E, kSL));
     dim3 grid(static_cast<unsigned>(ceil_div64(nw, 4)), static_cast<unsigned>(ceil_div64(C, 64 * vec)));
     dim3 fgrid(static_cast<unsigned>(ceil_div64(g->N, 4)));
     if (vec == 4) {
         hipLaunchKernelGGL((k_rowsum_walk<4>), grid, dim3(256), 0, st, g->rowptr_dst, g->dst, g->eid, edge_w, g->E, C, out, workspace);
         hipLaunchKernelGGL((k_rowsum_fix<4>), fgrid, dim3(256), 0, st, g->rowptr_dst, g->N, C, workspace, out);
+    } else if (vec == 2) {
+        hipLaunchKernelGGL((k_rowsum_walk<2>), grid, dim3(256), 0, st, g->rowptr_dst, g->dst, g->eid, edge_w, g->E, C, out, workspace);
+        hipLaunchKernelGGL((k_rowsum_fix<2>), fgrid, dim3(256), 0, st, g->rowptr_dst, g->N, C, workspace, out);
     } else {
         hipLaunchKernelGGL((k_rowsum_walk<1>), grid, dim3(256), 0, st, g->rowptr_dst, g->dst, g->eid, edge_w, g->E, C, out, workspace);
         hipLaunchKernelGGL((k_rowsum_fix<1>), fgrid, dim3(256), 0, st, g->rowptr_dst, g->N, C, workspace, out);

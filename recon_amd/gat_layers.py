@@ -467,7 +467,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
 
 def _rowsum_by_index(rows, index, n_rows):
     """out[r] = sum of rows[k] over k with index[k] == r (index int64 [E]), fixed summation order."""
-    g = prepare_graph(_segment_key(index), None, n_rows)
+    g = prepare_graph(_segment_key(index), None, n_rows, rows_only=True)
     out = torch.empty(n_rows, rows.shape[1], dtype=torch.float32, device=rows.device)
     L = _lib.lib()
     ws = torch.empty(L.recon_spmm_rowsum_workspace_floats(g.E, rows.shape[1]), dtype=torch.float32, device=rows.device)

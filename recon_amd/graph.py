@@ -22,7 +22,9 @@ HUB_CHUNK = 64          # RECON_HUB_CHUNK (include/recon_hip.h); 0 switches the 
 class GraphCSR:
     """Device-resident CSR/CSC view of a COO edge list.  Attributes mirror `recon_graph`."""
 
-    def __init__(self, edge, N):
+    def __init__(self, edge, N, rows_only=False):
+        """rows_only: destination CSR only — what the row sums need (SpecialSpmmFinal, the backward of gather_rows, the table gradients);
+        no source view, no hub tables: half the sorting of a full build."""
         if not edge.is_cuda:
             raise RuntimeError("recon_amd: edge tensors must live on the GPU (no CPU path)")
         if edge.dtype != torch.int64 or edge.dim() != 2 or edge.shape[0] != 2:
@@ -43,17 +45,17 @@ class GraphCSR:
         self.edge = edge
         i32 = dict(dtype=torch.int32, device=dev)
         self.rowptr_dst = torch.empty(N + 1, **i32)
-        self.rowptr_src = torch.empty(N + 1, **i32)
+        self.rows_only = bool(rows_only)
+        self.rowptr_src = None if rows_only else torch.empty(N + 1, **i32)
         self.eid = torch.empty(E, **i32)
-        self.src = torch.empty(E, **i32)
+        self.src = None if rows_only else torch.empty(E, **i32)
         self.dst = torch.empty(E, **i32)
-        self.slot_by_src = torch.empty(E, **i32)
+        self.slot_by_src = None if rows_only else torch.empty(E, **i32)
         L = _lib.lib()
         ws_bytes = L.recon_graph_workspace_bytes(self.N, self.E)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         self.c = _lib.ReconGraph(self.N, self.E, self.rowptr_dst.data_ptr(), self.eid.data_ptr(),
-                                 self.src.data_ptr(), self.dst.data_ptr(), self.rowptr_src.data_ptr(),
-                                 self.slot_by_src.data_ptr())
+                                 _lib.ptr(self.src), self.dst.data_ptr(), _lib.ptr(self.rowptr_src), _lib.ptr(self.slot_by_src))
         with torch.cuda.device(dev):
             rc = L.recon_graph_build(edge[0].data_ptr(), edge[1].data_ptr(), C.byref(self.c), ws.data_ptr(),
                                      ws_bytes, _lib.current_stream())
@@ -63,7 +65,7 @@ class GraphCSR:
         # hub rows (include/recon_hip.h): destinations with more than HUB_CHUNK in-edges are cut into pieces, one wavefront each
         self.n_hub = self.n_piece = self.n_hub_src = self.n_piece_src = 0
         self._hub_ws = None
-        if HUB_CHUNK > 0 and E > HUB_CHUNK:
+        if HUB_CHUNK > 0 and E > HUB_CHUNK and not rows_only:
             cnt = (C.c_int32 * 4)()
             with torch.cuda.device(dev):
                 _lib.check(L.recon_graph_hubs_count(C.byref(self.c), HUB_CHUNK, ws.data_ptr(), cnt, _lib.current_stream()), "recon_graph_hubs_count")
@@ -132,20 +134,20 @@ def _has_nhop(edge_list_nhop):
     return edge_list_nhop is not None and edge_list_nhop.shape[0] > 0
 
 
-def prepare_graph(edge, edge_list_nhop, N):
+def prepare_graph(edge, edge_list_nhop, N, rows_only=False):
     """Concatenate 1-hop and n-hop edges (GAT/layers.py:124-127) and build / fetch the cached CSR."""
     nh = _has_nhop(edge_list_nhop)
     # identity + version + shape + strides: two views of one storage with equal shapes but different strides are different
     # edge lists.  (Writes through .data do not bump _version: do not mutate a cached edge tensor that way.)
     key = (edge.data_ptr(), edge._version, tuple(edge.shape), tuple(edge.stride()),
            edge_list_nhop.data_ptr() if nh else 0, edge_list_nhop._version if nh else 0,
-           tuple(edge_list_nhop.shape) if nh else (), tuple(edge_list_nhop.stride()) if nh else (), int(N), str(edge.device))
+           tuple(edge_list_nhop.shape) if nh else (), tuple(edge_list_nhop.stride()) if nh else (), int(N), str(edge.device), bool(rows_only))
     g = _CACHE.get(key)
     if g is not None:
         _CACHE.move_to_end(key)
         return g
     full = torch.cat((edge, edge_list_nhop), dim=1) if nh else edge
-    g = GraphCSR(full, N)
+    g = GraphCSR(full, N, rows_only)
     g._keepalive = (edge, edge_list_nhop if nh else None)   # pins data_ptr identity while cached
     _CACHE[key] = g
     while len(_CACHE) > _CACHE_MAX:

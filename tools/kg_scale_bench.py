@@ -55,6 +55,42 @@ def run(N=14541, E=272115, nrel=237, F_=100, D=100, H=2, nhop=0, iters=10):
                       "max_out_degree": int(sdeg.max()), "heads": H, "D_per_head": D, **res, "edges_per_s_fwd_bwd": Et / res["fwd_bwd_ms"] * 1e3}))
 
 
+def run_kbgat(N=14541, E=272115, nrel=237, nhop=100000, iters=10):
+    """The reference's stage-A model as GAT/main.py builds it (embedding_size 50, entity_out_dim [100, 200], nheads_GAT [2, 2], drop 0.3,
+    train mode): SpKBGATModified.forward on the whole graph + `nhop` 2-hop quadruples, and the backward of a scalar of its outputs."""
+    from recon_amd.models import SpKBGATModified
+    dv = torch.device("cuda:0")
+    rs = np.random.RandomState(0)
+    p = 1.0 / np.arange(1, N + 1) ** 0.8; p /= p.sum()
+    perm = rs.permutation(N)
+    edge = torch.from_numpy(np.stack([perm[rs.choice(N, size=E, p=p)], rs.permutation(N)[rs.choice(N, size=E, p=p)]])).long().to(dv)
+    g = torch.Generator().manual_seed(1)
+    et = torch.randint(0, nrel, (E,), generator=g).to(dv)
+    quads = torch.stack([torch.randint(0, N, (nhop,), generator=g), torch.randint(0, nrel, (nhop,), generator=g),
+                         torch.randint(0, nrel, (nhop,), generator=g), torch.from_numpy(rs.choice(N, size=nhop, p=p))], dim=1).long().to(dv)
+    batch_entities = torch.randint(0, N, (20000,), generator=g).to(dv)
+    torch.manual_seed(0)
+    m = SpKBGATModified(torch.randn(N, 50), torch.randn(nrel, 50), [100, 200], [100, 200], 0.3, 0.2, [2, 2]).to(dv)
+    m.train()
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        ent, rel, _ = m(None, batch_entities, (edge, et), quads)
+        (ent.sum() + rel.sum()).backward()
+    for _ in range(3): step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): step()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print(json.dumps({"workload": "SpKBGATModified fwd+bwd (train mode, dropout 0.3), FB15k-237-sized synthetic", "N": N, "E": E + nhop, "nhop": nhop,
+                      "fwd_bwd_ms": ms, "edges_per_s_fwd_bwd": (E + nhop) / ms * 1e3}))
+
+
 if __name__ == "__main__":
-    run()
-    if "--nhop" in sys.argv: run(nhop=100000)
+    if "--kbgat" in sys.argv:
+        run_kbgat()
+    else:
+        run()
+        if "--nhop" in sys.argv: run(nhop=100000)
