@@ -30,14 +30,23 @@ __global__ void __launch_bounds__(kThreads) k_radix_hist(const int32_t* __restri
     blockhist[threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
 }
 
-// single-block exclusive scan (in place); n is at most a few hundred thousand counters
+// single-block exclusive scan (in place); n is at most a few hundred thousand counters.  Every thread owns a contiguous chunk (a multiple
+// of four counters, read and written 16 bytes at a time with all of a chunk's loads in flight together: one counter per dependent
+// load made this kernel 127 us at 372 k edges — most of a graph build).
 __global__ void __launch_bounds__(1024) k_scan_exclusive(int32_t* __restrict__ data, int32_t n) {
     __shared__ int32_t sums[1024];
     const int t = threadIdx.x;
-    const int chunk = (n + 1023) / 1024;
-    const int lo = t * chunk, hi = min(lo + chunk, n);
+    const int chunk = (((n + 1023) / 1024) + 3) & ~3;
+    const int lo = min(t * chunk, n), hi = min(lo + chunk, n);
+    const bool full = hi - lo == chunk && !(reinterpret_cast<uintptr_t>(data) & 15);
     int32_t s = 0;
-    for (int i = lo; i < hi; ++i) s += data[i];
+    if (full) {
+        const int4* d4 = reinterpret_cast<const int4*>(data + lo);
+#pragma unroll 8
+        for (int i = 0; i < chunk / 4; ++i) { const int4 v = d4[i]; s += (v.x + v.y) + (v.z + v.w); }
+    } else {
+        for (int i = lo; i < hi; ++i) s += data[i];
+    }
     sums[t] = s;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {      // Hillis-Steele inclusive scan
@@ -47,7 +56,19 @@ __global__ void __launch_bounds__(1024) k_scan_exclusive(int32_t* __restrict__ d
         __syncthreads();
     }
     int32_t run = sums[t] - s;
-    for (int i = lo; i < hi; ++i) { int32_t v = data[i]; data[i] = run; run += v; }
+    if (full) {
+        int4* d4 = reinterpret_cast<int4*>(data + lo);
+#pragma unroll 8
+        for (int i = 0; i < chunk / 4; ++i) {
+            const int4 v = d4[i];
+            int4 o;
+            o.x = run; o.y = o.x + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
+            run = o.w + v.w;
+            d4[i] = o;
+        }
+    } else {
+        for (int i = lo; i < hi; ++i) { int32_t v = data[i]; data[i] = run; run += v; }
+    }
 }
 
 __global__ void __launch_bounds__(kThreads) k_radix_scatter(const int32_t* __restrict__ keys_in,
@@ -148,48 +169,44 @@ int radix_sort_pairs(SortWs& ws, int32_t n, int32_t key_range, int32_t** kout, i
 }
 
 // Hub tables (recon_hip.h): destination rows longer than `chunk` slots, in node order, cut into pieces of <= chunk slots.
-// ONE workgroup walks rowptr 1024 nodes at a time and hands out table positions with a block-wide exclusive scan, so that the
-// tables are ordered and the same on every run; hubs are rare and the graph is cached (1 M nodes: ~1 ms, once).
+// ONE workgroup: every thread counts the hubs / pieces of its own run of consecutive nodes, a block-wide exclusive scan hands out the
+// table positions, and the thread fills them in node order — ordered tables, the same on every run.
 template <bool FILL>
 __global__ void __launch_bounds__(1024) k_hub_scan(const int32_t* __restrict__ rowptr, int32_t N, int32_t chunk, int32_t* __restrict__ counts,
                                                    int32_t* __restrict__ hub_node, int32_t* __restrict__ hub_ptr, int4* __restrict__ piece) {
-    __shared__ int wave_h[16], wave_p[16];
-    __shared__ int base[2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { base[0] = 0; base[1] = 0; }
+    __shared__ int32_t sh[1024], sp[1024];
+    const int t = threadIdx.x;
+    const int per = (N + 1023) / 1024;                                   // every thread owns `per` consecutive nodes
+    const int lo = min(t * per, N), hi = min(lo + per, N);
+    int h = 0, p = 0;
+    for (int i = lo; i < hi; ++i) {
+        const int deg = rowptr[i + 1] - rowptr[i];
+        if (deg > chunk) { ++h; p += (deg + chunk - 1) / chunk; }
+    }
+    sh[t] = h; sp[t] = p;
     __syncthreads();
-    for (int i0 = 0; i0 < N; i0 += 1024) {
-        const int i = i0 + tid;
-        int beg = 0, deg = 0;
-        if (i < N) { beg = rowptr[i]; deg = rowptr[i + 1] - beg; }
-        const int hub = deg > chunk ? 1 : 0;
-        const int np = hub ? (deg + chunk - 1) / chunk : 0;
-        int sh = hub, sp = np;                                            // inclusive scans inside the wave
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int th = __shfl_up(sh, d), tp = __shfl_up(sp, d);
-            if (lane >= d) { sh += th; sp += tp; }
-        }
-        if (lane == 63) { wave_h[wave] = sh; wave_p[wave] = sp; }
+    for (int off = 1; off < 1024; off <<= 1) {                           // Hillis-Steele inclusive scans
+        const int vh = (t >= off) ? sh[t - off] : 0, vp = (t >= off) ? sp[t - off] : 0;
         __syncthreads();
-        int oh = base[0], op = base[1];
-        for (int w = 0; w < wave; ++w) { oh += wave_h[w]; op += wave_p[w]; }
-        if (FILL && hub) {
-            const int t = oh + sh - 1, p0 = op + sp - np;
-            hub_node[t] = i; hub_ptr[t] = p0;
-            for (int q = 0; q < np; ++q) {
-                const int b = beg + q * chunk;
-                piece[p0 + q] = make_int4(i, b, min(b + chunk, beg + deg), t);
+        sh[t] += vh; sp[t] += vp;
+        __syncthreads();
+    }
+    if (FILL) {
+        int oh = sh[t] - h, op = sp[t] - p;
+        for (int i = lo; i < hi; ++i) {
+            const int beg = rowptr[i], deg = rowptr[i + 1] - beg;
+            if (deg > chunk) {
+                const int np = (deg + chunk - 1) / chunk;
+                hub_node[oh] = i; hub_ptr[oh] = op;
+                for (int q = 0; q < np; ++q) {
+                    const int b = beg + q * chunk;
+                    piece[op + q] = make_int4(i, b, min(b + chunk, beg + deg), oh);
+                }
+                ++oh; op += np;
             }
         }
-        __syncthreads();
-        if (tid == 1023) { base[0] = oh + sh; base[1] = op + sp; }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        if (FILL) hub_ptr[base[0]] = base[1];
-        else { counts[0] = base[0]; counts[1] = base[1]; }
-    }
+        if (t == 1023) hub_ptr[sh[t]] = sp[t];
+    } else if (t == 1023) { counts[0] = sh[t]; counts[1] = sp[t]; }
 }
 
 }  // namespace
