@@ -591,7 +591,9 @@ namespace {
 //         left | 1 = continues to the right];
 // pass 2: one wave per destination that spans several ranges adds its carries in slot order.  Fixed order,
 //         no atomics.  `out` must be zeroed first (rows without edges).
-constexpr int kSL = 256;
+// 128 slots per wave, sixteen rows in flight: a wave's walk is a chain of dependent round trips (8 of them now; 256 slots x 8 rows in
+// flight = 32 took 75 - 105 us per call whatever the width, and 100 k slots filled only 98 workgroups)
+constexpr int kSL = 128;
 template <int VEC>
 __global__ void __launch_bounds__(256) k_rowsum_walk(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ dst,
                                                      const int32_t* __restrict__ eid, const float* __restrict__ w, int32_t E,
@@ -616,10 +618,10 @@ __global__ void __launch_bounds__(256) k_rowsum_walk(const int32_t* __restrict__
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
     };
-    // eight rows in flight, branch-free loads (a guarded load gets its own basic block and is then waited for on its own):
+    // sixteen rows in flight, branch-free loads (a guarded load gets its own basic block and is then waited for on its own):
     // slots past the range re-read its last slot and are skipped at the accumulate; lanes past C read a clamped column
     const int cc = ca ? c : 0;
-    constexpr int U = 8;
+    constexpr int U = 16;
     for (int k = k0; k < k1; k += U) {
         float t[U][VEC];
         int d[U], e[U];
@@ -653,9 +655,22 @@ __global__ void __launch_bounds__(256) k_rowsum_fix(const int32_t* __restrict__ 
     const int wa = b / kSL, wb = (e - 1) / kSL;
     if (wa == wb) return;                                           // lay inside one range: already written
     for (int c = lane * VEC; c < C; c += 64 * VEC) {
-        float s[VEC], t[VEC];
+        float s[VEC];
         load_vec<VEC>(s, carry + (static_cast<int64_t>(wa) * 2 + 1) * C + c);
-        for (int wv = wa + 1; wv <= wb; ++wv) {
+        // a relation owning 10^4 edges spans ~80 ranges: eight carries' loads in flight, added in range order
+        constexpr int UF = 8;
+        int wv = wa + 1;
+        for (; wv + UF <= wb + 1; wv += UF) {
+            float t[UF][VEC];
+#pragma unroll
+            for (int u = 0; u < UF; ++u) load_vec<VEC>(t[u], carry + (static_cast<int64_t>(wv + u) * 2 + 0) * C + c);
+#pragma unroll
+            for (int u = 0; u < UF; ++u)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) s[v] += t[u][v];
+        }
+        for (; wv <= wb; ++wv) {
+            float t[VEC];
             load_vec<VEC>(t, carry + (static_cast<int64_t>(wv) * 2 + 0) * C + c);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) s[v] += t[v];
