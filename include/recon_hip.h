@@ -408,8 +408,11 @@ int recon_sgemm(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, co
 /* Small dense products (tens of MFLOP), plain fp32 FMAs with K split 16 ways inside a workgroup and a fixed-order combine:
  *     C[M,N] = op(A) * op(B);  A is [M,K] (a_is_km == 0) or [K,M]; B is [K,N] (b_is_nk == 0) or [N,K].
  * Replaces `relation_embed.mm(self.W)` (GAT/models.py:75) and its two gradient products, which are launch / latency bound on tile GEMMs. */
+size_t recon_sgemm_small_workspace_floats(int32_t M, int32_t N, int32_t K);  /* 0: no workspace needed */
+/* workspace: recon_sgemm_small_workspace_floats() floats, or NULL.  With it, products with few output tiles and a long K (weight
+ * gradients: 50 x 200 over K = 14 541 rows) also cut K over workgroups and add the parts in fixed order. */
 int recon_sgemm_small(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, int32_t a_is_km, const float* B, int32_t ldb,
-                      int32_t b_is_nk, float* C, int32_t ldc, recon_stream_t stream);
+                      int32_t b_is_nk, float* C, int32_t ldc, float* workspace, recon_stream_t stream);
 
 /* K4'  the same product C[M,N] = A[M,K] * B[N,K]^T at fp32 accuracy on the bf16 matrix cores: every fp32
  * operand is split into three bfloat16 terms and six term products are accumulated in fp32

@@ -137,8 +137,9 @@ SYMBOLS = [
     ("recon_gcn_b16_fwd", C.c_int, [C.POINTER(GcnB16Args), C.c_void_p]),
     ("recon_gcn_b16_bwd_partial_floats", C.c_size_t, [C.c_int32] * 4),
     ("recon_gcn_b16_bwd", C.c_int, [C.POINTER(GcnB16BwdArgs), C.c_void_p]),
+    ("recon_sgemm_small_workspace_floats", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     ("recon_sgemm_small", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32,
-                                    C.c_void_p]),
+                                    c_f32p, C.c_void_p]),
     ("recon_sgemm", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32,
                               c_f32p, C.c_int32, C.c_void_p]),
     ("recon_gat_atp_split_bytes", C.c_size_t, [C.c_int32] * 4),

@@ -565,14 +565,18 @@ int gemm_f32(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool a_k_min
 // dependent round trip; 200 us here at K = 1 600): the arithmetic is nothing, the serial K walk is everything.  Here a workgroup owns a
 // 16 x 16 output tile and its 16 groups of 16 threads each take 1/16 of K (4 x 4 outputs per thread, plain FMAs), then the slices are
 // added in fixed order through LDS: hundreds of workgroups, 1/16 of the walk each.
+// gridDim.z > 1: K is also cut over workgroups (weight-gradient shapes: a 50 x 200 output over K = 14 541 rows is 52 tiles);
+// workgroup z writes its tile of partial[z][M][N] (C = partial, ldc = N) and k_gemm_small_combine adds the z slices in order.
 template <bool A_KM, bool B_NK, bool VEC4>
 __global__ void __launch_bounds__(256) k_gemm_small(const float* __restrict__ A, int32_t lda, const float* __restrict__ B, int32_t ldb,
-                                                    float* __restrict__ C, int32_t ldc, int32_t M, int32_t N, int32_t K) {
+                                                    float* __restrict__ C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t kz) {
     __shared__ float red[16][16][17];
     const int tid = threadIdx.x, slice = tid >> 4, tm = (tid >> 2) & 3, tn = tid & 3;
     const int m0 = blockIdx.y * 16 + tm * 4, n0 = blockIdx.x * 16 + tn * 4;
-    const int ks = ((K + 15) / 16 + 3) & ~3;                             // K per slice, a multiple of the 4-deep step
-    const int k_begin = slice * ks, k_end = min(K, k_begin + ks);
+    const int z0 = blockIdx.z * kz, z1 = min(K, z0 + kz);               // this workgroup's part of K (kz: a multiple of 4; all of K when gridDim.z == 1)
+    C += static_cast<int64_t>(blockIdx.z) * M * ldc;
+    const int ks = ((z1 - z0 + 15) / 16 + 3) & ~3;                       // K per slice, a multiple of the 4-deep step
+    const int k_begin = min(z1, z0 + slice * ks), k_end = min(z1, k_begin + ks);
     int64_t arow[4], bcol[4];
     float am[4], bm[4];                                                   // 0 for rows / columns past the edge (their loads are clamped)
 #pragma unroll
@@ -657,10 +661,41 @@ __global__ void __launch_bounds__(256) k_gemm_small(const float* __restrict__ A,
     if (m < M && n < N) C[static_cast<int64_t>(m) * ldc + n] = sum;
 }
 
+__global__ void __launch_bounds__(256) k_gemm_small_combine(const float* __restrict__ partial, int32_t nz, int64_t MN, int32_t N, float* __restrict__ C,
+                                                            int32_t ldc) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= MN) return;
+    float s = 0.f;
+    for (int z = 0; z < nz; ++z) s += partial[z * MN + i];
+    C[(i / N) * ldc + i % N] = s;
+}
+
 }  // namespace recon
 
+// K cut over workgroups when the output has few tiles and K is long: (splits, K per split)
+static void small_split(int32_t M, int32_t N, int32_t K, int* nz, int* kz) {
+    const int64_t tiles = static_cast<int64_t>((M + 15) / 16) * ((N + 15) / 16);
+    int z = 1;
+    if (tiles < 512 && K >= 2048) {
+        z = static_cast<int>((1024 + tiles - 1) / tiles);
+        const int zmax = K / 512;                                        // at least 32 k per 16-thread slice
+        if (z > zmax) z = zmax;
+        if (z > 64) z = 64;
+        if (z < 1) z = 1;
+    }
+    int per = (K + z - 1) / z;
+    per = (per + 3) & ~3;
+    *kz = per; *nz = (K + per - 1) / per;
+}
+extern "C" size_t recon_sgemm_small_workspace_floats(int32_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    int nz, kz;
+    small_split(M, N, K, &nz, &kz);
+    return nz > 1 ? static_cast<size_t>(nz) * M * N : 0;
+}
+
 extern "C" int recon_sgemm_small(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, int32_t a_is_km, const float* B, int32_t ldb,
-                                 int32_t b_is_nk, float* C, int32_t ldc, recon_stream_t stream) {
+                                 int32_t b_is_nk, float* C, int32_t ldc, float* workspace, recon_stream_t stream) {
     using namespace recon;
     if (M < 0 || N < 0 || K < 0) return RECON_ERR_INVALID;
     if (M == 0 || N == 0) return RECON_OK;
@@ -672,18 +707,28 @@ extern "C" int recon_sgemm_small(int32_t M, int32_t N, int32_t K, const float* A
         if (hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, st) != hipSuccess) return RECON_ERR_LAUNCH;
         return RECON_OK;
     }
-    const dim3 grid(static_cast<unsigned>((N + 15) / 16), static_cast<unsigned>((M + 15) / 16));
+    int nz = 1, kz = K;
+    if (workspace) small_split(M, N, K, &nz, &kz);                       // NULL: one workgroup per tile walks all of K
+    if (nz == 1) kz = (K + 3) & ~3;
+    float* const Cfinal = C;
+    const int32_t ldc_final = ldc;
+    if (nz > 1) { C = workspace; ldc = N; }
+    const dim3 grid(static_cast<unsigned>((N + 15) / 16), static_cast<unsigned>((M + 15) / 16), static_cast<unsigned>(nz));
     const bool k4 = !a_is_km || b_is_nk;                                  // some operand is read 4 k at a time
     const bool vec4 = !((lda | ldb) & 3) && !((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) && (!k4 || !(K & 3)) &&
                       (!a_is_km || !(M & 3)) && (b_is_nk || !(N & 3));
 #define SMALL_CALL(AK, BN)                                                                                                      \
     do {                                                                                                                        \
-        if (vec4) hipLaunchKernelGGL((k_gemm_small<AK, BN, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);   \
-        else hipLaunchKernelGGL((k_gemm_small<AK, BN, false>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);       \
+        if (vec4) hipLaunchKernelGGL((k_gemm_small<AK, BN, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kz);   \
+        else hipLaunchKernelGGL((k_gemm_small<AK, BN, false>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kz);       \
     } while (0)
     if (a_is_km) { if (b_is_nk) SMALL_CALL(true, true); else SMALL_CALL(true, false); }
     else { if (b_is_nk) SMALL_CALL(false, true); else SMALL_CALL(false, false); }
 #undef SMALL_CALL
+    if (nz > 1) {
+        const int64_t MN = static_cast<int64_t>(M) * N;
+        hipLaunchKernelGGL(k_gemm_small_combine, dim3(static_cast<unsigned>((MN + 255) / 256)), dim3(256), 0, st, workspace, nz, MN, N, Cfinal, ldc_final);
+    }
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }

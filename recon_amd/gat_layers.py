@@ -153,19 +153,41 @@ class _SmallMM(torch.autograd.Function):
         return gA, gB
 
 
+class _ThinWeightMM(torch.autograd.Function):
+    """A @ B for a tall A [rows, K] and a small weight B [K, N] (`entity_embeddings.mm(self.W_entities)`, GAT/models.py:177): forward and
+    g_A on torch.mm; the weight gradient A^T g — a K x N output over `rows` terms, for which the library picks a 32 x 32 x 256 tile kernel
+    that takes 98 us at 14 541 x 50 x 200 — on recon_sgemm_small with the long dimension cut over workgroups (fixed-order combine)."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        ctx.save_for_backward(A, B)
+        return torch.mm(A, B)
+
+    @staticmethod
+    def backward(ctx, g):
+        A, B = ctx.saved_tensors
+        gA = torch.mm(g, B.t()) if ctx.needs_input_grad[0] else None
+        gB = _sgemm_small(A.contiguous(), True, g.contiguous(), False) if ctx.needs_input_grad[1] else None
+        return gA, gB
+
+
 def _sgemm_small(A, a_is_km, B, b_is_nk):
     """op(A) op(B) on recon_sgemm_small; A, B contiguous 2-d fp32."""
     M, K = (A.shape[1], A.shape[0]) if a_is_km else A.shape
     N = B.shape[0] if b_is_nk else B.shape[1]
     out = torch.empty(M, N, dtype=torch.float32, device=A.device)
     if M and N:
+        L = _lib.lib()
+        nws = L.recon_sgemm_small_workspace_floats(M, N, K)
+        ws = torch.empty(nws, dtype=torch.float32, device=A.device) if nws else None
         with _on_device(A.device):
-            _lib.check(_lib.lib().recon_sgemm_small(M, N, K, A.data_ptr(), A.shape[1], 1 if a_is_km else 0, B.data_ptr(), B.shape[1],
-                                                    1 if b_is_nk else 0, out.data_ptr(), N, _lib.current_stream()), "recon_sgemm_small")
+            _lib.check(L.recon_sgemm_small(M, N, K, A.data_ptr(), A.shape[1], 1 if a_is_km else 0, B.data_ptr(), B.shape[1],
+                                           1 if b_is_nk else 0, out.data_ptr(), N, _lib.ptr(ws), _lib.current_stream()), "recon_sgemm_small")
     return out
 
 
 _SMALL_MM_FLOP = 2.0e8
+_THIN_WEIGHT_ELEMS = 1 << 16        # weights up to 64 k elements: their gradient has at most 256 output tiles
 
 
 def small_mm(A, B):
@@ -173,6 +195,9 @@ def small_mm(A, B):
     if (A.is_cuda and A.dtype == torch.float32 and B.dtype == torch.float32 and A.dim() == 2 and B.dim() == 2
             and 0 < A.shape[1] == B.shape[0] and 2.0 * A.shape[0] * A.shape[1] * B.shape[1] < _SMALL_MM_FLOP):
         return _SmallMM.apply(A, B)
+    if (A.is_cuda and A.dtype == torch.float32 and B.dtype == torch.float32 and A.dim() == 2 and B.dim() == 2 and A.shape[1] == B.shape[0]
+            and 0 < B.shape[0] * B.shape[1] <= _THIN_WEIGHT_ELEMS and A.shape[0] >= 2048):
+        return _ThinWeightMM.apply(A, B)
     return torch.mm(A, B)
 
 

@@ -148,7 +148,7 @@ class SpKBGATModified(nn.Module):
                                                      None, edge_list_nhop, edge_type_nhop)
         mask = torch.zeros(entity_embeddings.shape[0], device=dev)
         mask[torch.unique(batch_entities.to(dev))] = 1.0
-        out_entity = entity_embeddings.mm(self.W_entities) + mask.unsqueeze(-1) * out_entity
+        out_entity = small_mm(entity_embeddings, self.W_entities) + mask.unsqueeze(-1) * out_entity
         return F.normalize(out_entity, p=2, dim=1), out_relation, mask
 
     def forward(self, Corpus_, batch_entities, adj, train_indices_nhop):

@@ -555,6 +555,23 @@ def test_small_mm(M, K, N):
     assert not big.grad_fn.name().startswith("_SmallMM")
 
 
+@pytest.mark.parametrize("rows,K,N", [(14541, 50, 200), (5000, 33, 70), (2048, 8, 4), (20000, 256, 256)])
+def test_thin_weight_mm(rows, K, N):
+    """`entity_embeddings.mm(W_entities)` (GAT/models.py:177): the weight gradient A^T g on recon_sgemm_small with the long dimension cut
+    over workgroups; values and both gradients against float64."""
+    from recon_amd.gat_layers import small_mm
+    d = dev()
+    g = torch.Generator().manual_seed(rows + N)
+    A, B, G = torch.randn(rows, K, generator=g), torch.randn(K, N, generator=g), torch.randn(rows, N, generator=g)
+    Ad, Bd = A.to(d).requires_grad_(True), B.to(d).requires_grad_(True)
+    out = small_mm(Ad, Bd)
+    assert out.grad_fn.name().startswith(("_ThinWeightMM", "_SmallMM"))          # the smallest shape is a "small" product outright
+    (out * G.to(d)).sum().backward()
+    close(out, (A.double() @ B.double()).float(), atol=1e-4, rel_to_max=1e-5, what="A B")
+    close(Ad.grad, (G.double() @ B.double().t()).float(), atol=1e-4, rel_to_max=1e-5, what="g_A")
+    close(Bd.grad, (A.double().t() @ G.double()).float(), atol=1e-4, rel_to_max=2e-6, what="g_B")
+
+
 def _hub_graph(N, degs, seed, src_hubs=()):
     """Destination i gets degs[i] in-edges (0 for i >= len(degs)), sources uniform except that node j is the source of exactly c
     edges for every (j, c) in src_hubs; columns shuffled."""
