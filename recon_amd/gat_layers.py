@@ -625,12 +625,15 @@ class SpGraphAttentionLayer(nn.Module):
         p = float(self.dropout.p)
         return 1.0 / (1.0 - p) if p < 1.0 else 1.0
 
-    def forward(self, input, edge, edge_embed, edge_list_nhop, edge_embed_nhop):
+    def forward(self, input, edge, edge_embed, edge_list_nhop, edge_embed_nhop, elu=None):
+        """elu (extension, default = self.concat as in GAT/layers.py:174-178): apply the ELU inside the layer.  A caller that writes
+        `F.elu(layer(...))` around a concat=False layer (GAT/models.py:86) passes elu=True instead and gets the activation — and its
+        gradient — from the projection's epilogue rather than from two more passes over the output."""
         N = input.size()[0]                                  # not self.num_nodes (GAT/layers.py:112)
         graph = prepare_graph(edge, edge_list_nhop, N)
         ee, ee_index = cat_edge_embed(edge_embed, edge_list_nhop, edge_embed_nhop)     # edge_embed: [E,R] as in the reference, or IndexedRows
         keep = self.draw_keep(graph.E, input.device)
-        out = gat_heads(input, ee, self.a.unsqueeze(0), self.a_2, graph, keep, self.alpha, self.concat,
+        out = gat_heads(input, ee, self.a.unsqueeze(0), self.a_2, graph, keep, self.alpha, self.concat if elu is None else bool(elu),
                         keep_max=self.keep_bound() if keep is not None else None, ee_index=ee_index)
         if _DEBUG_NAN:                                       # the reference's asserts (:147,:167,:172)
             assert not torch.isnan(out).any()

@@ -92,7 +92,7 @@ class SpGAT(nn.Module):
             edge_embed_nhop = gather_rows(out_relation_1, edge_type_nhop[:, 0]) + gather_rows(out_relation_1, edge_type_nhop[:, 1])
         else:
             edge_embed_nhop = torch.tensor([])
-        x = F.elu(self.out_att(x, edge_list, edge_embed, edge_list_nhop, edge_embed_nhop))
+        x = self.out_att(x, edge_list, edge_embed, edge_list_nhop, edge_embed_nhop, elu=True)        # F.elu(out_att(...)), :86-87, in the epilogue
         return x, out_relation_1
 
 
