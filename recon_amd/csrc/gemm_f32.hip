@@ -676,7 +676,7 @@ __global__ void __launch_bounds__(256) k_gemm_small_combine(const float* __restr
 static void small_split(int32_t M, int32_t N, int32_t K, int* nz, int* kz) {
     const int64_t tiles = static_cast<int64_t>((M + 15) / 16) * ((N + 15) / 16);
     int z = 1;
-    if (tiles < 512 && K >= 2048) {
+    if (tiles < 512 && K >= 1024) {
         z = static_cast<int>((1024 + tiles - 1) / tiles);
         const int zmax = K / 512;                                        // at least 32 k per 16-thread slice
         if (z > zmax) z = zmax;
