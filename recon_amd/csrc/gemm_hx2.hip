@@ -129,12 +129,17 @@ constexpr int B_DMA = (B_PIECES + 3) / 4;                        // 7 rounds ove
 // on out_att-sized products in isolation, 3-8 % slower inside the layer's step at K = 200 / 600.  By elimination on the
 // projection shape: 59.5 us in full, 49.6 without the epilogue stores, 48.1 without A loads, 50.4 without B copies, 33.0 for
 // MFMAs + fragment reads + barriers alone.)
-__global__ void __launch_bounds__(NT, 2) k_gemm_hx2(const Hx2Args p) {
+// NW waves per workgroup: 4 (128 rows, two workgroups per CU: the layer's K = 200 / 600 products) or 8 (256 rows, one workgroup per
+// CU: every B tile copied into LDS serves twice the rows — out_att-sized products, K >= 1024, where the copies of B and the re-reads
+// of A through L2 are what the loop waits for).
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) k_gemm_hx2(const Hx2Args p) {
+    constexpr int BMW = 32 * NW, B_DMAW = (B_PIECES + NW - 1) / NW;
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2][B_TILE_BYTES];
     const int t = threadIdx.x, lane = t & 63;
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const TileId tile = xcd_tile(p.xcd_remap);
-    const int m0 = tile.y * BM, n0 = tile.x * BN, bz = tile.z;
+    const int m0 = tile.y * BMW, n0 = tile.x * BN, bz = tile.z;
     const int mb = wid * 32;
     const int li = lane & 15, lq = lane >> 4;
 
@@ -144,11 +149,11 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_hx2(const Hx2Args p) {
 #pragma unroll
         for (int q = 0; q < T; ++q)
             aptr[i][q] = p.Ap + bz * p.a_bs + q * p.a_plane + static_cast<int64_t>(min(m0 + mb + 16 * i + li, p.M - 1)) * p.a_row + 8 * lq;
-    int b_goff[B_DMA];
+    int b_goff[B_DMAW];
     const _Float16* bbase = p.Bp + bz * p.b_bs;
 #pragma unroll
-    for (int i = 0; i < B_DMA; ++i) {
-        const int s = min(64 * (4 * i + wid) + lane, B_TILE_BYTES / 16 - 1);
+    for (int i = 0; i < B_DMAW; ++i) {
+        const int s = min(64 * (NW * i + wid) + lane, B_TILE_BYTES / 16 - 1);
         const int plane = s / (BN * 4), rem = s % (BN * 4), rowL = rem >> 2, pslot = rem & 3;
         const int kq = (pslot - 2 * (rowL >> 3)) & 3;                 // inverse of lds_off's rotation
         const int j = rowL >> 4, rho = rowL & 15;
@@ -157,10 +162,10 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_hx2(const Hx2Args p) {
     }
     auto dma_b = [&](int k0, int buf) {
 #pragma unroll
-        for (int i = 0; i < B_DMA; ++i)
-            if (4 * i + wid < B_PIECES)                                // wave-uniform
+        for (int i = 0; i < B_DMAW; ++i)
+            if (NW * i + wid < B_PIECES)                               // wave-uniform
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(bbase + b_goff[i] + k0),
-                                                 (__attribute__((address_space(3))) void*)(&Bs[buf][1024 * (4 * i + wid)]), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(&Bs[buf][1024 * (NW * i + wid)]), 16, 0, 0);
     };
 
     f32x4 acc[2][TN];
@@ -556,8 +561,11 @@ int gemm_hx2_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t a_
     a.a_shared_k = a_shared_k;
     a.c_plain = (a.c_vec4 && !C.scatter && C.P >= M && C.Dseg >= N && (static_cast<int64_t>(M) * C.S1 + N) * 4 < (1LL << 31)) ? 1 : 0;   // plain rows: the straight-line store
     a.sa = sa; a.sb = sb;
-    const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, BM)), static_cast<unsigned>(bt.batch));
-    hipLaunchKernelGGL(k_gemm_hx2, grid, dim3(NT), 0, st, a);
+    // 256-row workgroups for long K and enough rows to fill the chip with them (see k_gemm_hx2)
+    const bool wide = K >= 1024 && ceil_div64(M, 256) * ceil_div64(N, BN) * bt.batch >= 256;
+    const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, wide ? 256 : BM)), static_cast<unsigned>(bt.batch));
+    if (wide) hipLaunchKernelGGL((k_gemm_hx2<8>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_gemm_hx2<4>), grid, dim3(NT), 0, st, a);
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
 }

@@ -149,7 +149,7 @@ def _hx2_ws(nbytes):
 
 @pytest.mark.parametrize("scale", [1.0, 1e-6, 3e4])
 @pytest.mark.parametrize("M,N,K", [(128, 208, 32), (200, 72, 56), (33, 257, 24), (700, 200, 600), (513, 600, 200),
-                                   (300, 204, 40), (1000, 25, 8)])
+                                   (300, 204, 40), (1000, 25, 8), (4100, 3300, 1032)])     # the last: the 256-row workgroup form (K >= 1024, >= 256 tiles)
 def test_sgemm_hx2(M, N, K, scale):
     """Split-precision (2 x f16, per-tensor power-of-two scale) MFMA GEMM: fp32-class accuracy against an fp64 product, at
     magnitudes far outside half's own range."""
