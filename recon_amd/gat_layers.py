@@ -31,7 +31,7 @@ _GAT_PATH = os.environ.get("RECON_GAT_PATH", "auto")
 _OVERLAP = os.environ.get("RECON_OVERLAP", "0") == "1"
 # The layer's three large products run on split-precision MFMA GEMMs (fp32-accurate) when they are large enough to pay for
 # the extra launches (term planes of a, a^T, g_h): measured cross-over on MI355X at cfg-2 widths is 192..256 graphs, i.e.
-# ~6 GFLOP per product.  RECON_GEMM_BX3 (one switch for GAT and GraphConvolution) =
+# ~6 GFLOP per product for bf16 x 3 (~1 GFLOP for f16 x 2, whose operands arrive pre-split).  RECON_GEMM_BX3 (one switch for GAT and GraphConvolution) =
 #   auto (default): above the cross-over the f16 x 2 family (csrc/gemm_hx2.hip: 2 half terms per operand under a per-tensor
 #                   power-of-two scale, 3 MFMAs per product, operands pre-split by the kernels that produce them) where the
 #                   shape allows ((2F+R) % 8 == 0, D % 8 == 0), else bf16 x 3; below it the exact-fp32 MFMA GEMMs
