@@ -1443,6 +1443,10 @@ extern "C" int recon_gat_atp_supported(int32_t N, int32_t E, int32_t F, int32_t 
     if (F <= 0 || R <= 0 || H <= 0 || H > 32) return 0;
     if (!atp_shape(F, R, H, &s)) return 0;
     if (2 * H > 64) return 0;                                       // k_row_dots keeps one result per lane
+    // LDS stages (64 KiB per workgroup without opting into more): K2' keeps u [H][2F+R], the score dots their 2H (H) vectors of
+    // F (R) columns, padded by 4.  Callers fall back to the project-then-aggregate kernels (gat_heads: 'proj').
+    const int64_t W = 2LL * F + R, mx = F > R ? F : R;
+    if (4 * H * W > 64 * 1024 || 8LL * H * (mx + 4) > 64 * 1024) return 0;
     return 1;
 }
 

@@ -263,6 +263,7 @@ def test_gat_layer_golden(name, path, monkeypatch):
     (24, 100, 1600, 1600, 40, 1, False),  # out_att-sized inputs (F = R = 1600)
     (36, 140, 12, 8, 20, 11, True),       # 11 heads: two head groups walked by one wave
     (30, 120, 264, 300, 24, 2, True),     # F, R > 256: two register rows per lane
+    (12, 40, 1040, 64, 16, 8, True),      # 8 heads x (2F+R) floats of score vectors exceed the 64 KiB LDS stage: falls back to 'proj'
 ])
 @pytest.mark.parametrize("path", ["atp", "proj"])
 def test_gat_heads_vs_oracle(N, E, F_, R, D, H, concat, path, monkeypatch):
