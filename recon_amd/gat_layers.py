@@ -91,7 +91,7 @@ class SpecialSpmmFunctionFinal(torch.autograd.Function):
         _require_gpu_f32(edge_w)
         L = _lib.lib()
         g = prepare_graph(edge, None, N)
-        w = edge_w.contiguous().view(g.E, -1)
+        w = edge_w.contiguous().view(g.E, -1 if g.E else int(out_features))       # no edges: the width comes from the argument
         out = torch.empty(N, w.shape[1], dtype=torch.float32, device=w.device)
         ws = torch.empty(L.recon_spmm_rowsum_workspace_floats(g.E, w.shape[1]), dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
@@ -99,6 +99,7 @@ class SpecialSpmmFunctionFinal(torch.autograd.Function):
                                                _lib.current_stream()), "recon_spmm_rowsum_fwd")
         ctx.graph = g
         ctx.N, ctx.outfeat, ctx.E = N, w.shape[1], E
+        ctx.w_shape = edge_w.shape
         return out
 
     @staticmethod
@@ -113,7 +114,7 @@ class SpecialSpmmFunctionFinal(torch.autograd.Function):
                 _lib.check(L.recon_spmm_rowsum_bwd(g.edge[0].data_ptr(), g.E, go.data_ptr(), ctx.outfeat,
                                                    grad_values.data_ptr(), _lib.current_stream()),
                            "recon_spmm_rowsum_bwd")
-        return None, grad_values, None, None, None
+        return None, (grad_values.view(ctx.w_shape) if grad_values is not None else None), None, None, None
 
 
 class _GatherRows(torch.autograd.Function):

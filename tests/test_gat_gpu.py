@@ -855,7 +855,7 @@ def test_spkbgat_golden(name):
     close(tr, g["test_relation"], what="batch_test relation")
 
 
-@pytest.mark.parametrize("N,E,C_,skew", [(5, 4000, 24, True), (300, 1000, 7, False), (64, 70000, 200, True), (1000, 3, 4, False), (237, 50000, 50, True),
+@pytest.mark.parametrize("N,E,C_,skew", [(5, 4000, 24, True), (300, 1000, 7, False), (64, 70000, 200, True), (1000, 3, 4, False), (237, 50000, 50, True), (9, 0, 5, False),
                                           (40, 3000, 130, False)])          # C = 50, 130: the two-wide column form
 def test_spmm_rowsum_long_and_short_segments(N, E, C_, skew):
     """SpecialSpmmFinal on segments from empty to tens of thousands of edges (a relation type owning most edges)."""
