@@ -202,3 +202,72 @@ def test_fuzz_propagation_gcn_rowsum_small_mm_vs_oracle():
         chk("mm", cfg, out, A.double() @ Bm.double(), rel=2e-5); chk("mm g_A", cfg, Ad.grad, Gr.double() @ Bm.double().t(), rel=2e-5)
         chk("mm g_B", cfg, Bd.grad, A.double().t() @ Gr.double(), rel=2e-5)
     assert not chk.bad, chk.bad[:5]
+
+
+def test_fuzz_formulations_inference_and_spkbgat_vs_oracle(monkeypatch):
+    """40 random cases each of: the two formulations of the layer against each other (aggregate-then-project vs project-then-aggregate:
+    outputs and all gradients) and the inference call against the training call; SpKBGATModified.forward and .batch_test (whole entity
+    table, 1-hop + 2-hop edges, mask, W_entities skip, L2 norm) against the oracle's restatement of GAT/models.py:136-239."""
+    from recon_amd import gat_layers, graph as graph_mod
+    from recon_amd.models import SpKBGATModified
+    d = dev()
+    rs = np.random.RandomState(0)
+    chk = _Checker()
+    for it in range(40):
+        g = torch.Generator().manual_seed(it)
+        # ---- proj path vs atp path, and eval (no grad) vs train outputs
+        N = int(rs.randint(1, 300)); E = int(rs.choice([0, 3, 200, 3000])); F_ = int(rs.choice([3, 4, 7, 16, 50])); R = int(rs.choice([1, 4, 5, 16, 50]))
+        D = int(rs.choice([1, 8, 25, 40])); H = int(rs.randint(1, 6)); concat = bool(rs.randint(0, 2))
+        cfg = ("paths", it, N, E, F_, R, D, H, concat)
+        try:
+            p = 1.0 / np.arange(1, N + 1); p /= p.sum()
+            edge = torch.from_numpy(np.stack([rs.choice(N, size=E, p=p), rs.randint(0, N, size=E)])).long() if E else torch.zeros(2, 0, dtype=torch.long)
+            x = torch.randn(N, F_, generator=g); ee = torch.randn(E, R, generator=g) * 0.5
+            a = torch.randn(H, D, 2 * F_ + R, generator=g) / np.sqrt(2 * F_ + R); a2 = torch.randn(H, D, generator=g) * 0.3
+            G = torch.randn(N, H * D, generator=g)
+            res = {}
+            for path in ("atp", "proj"):
+                monkeypatch.setattr(gat_layers, "_GAT_PATH", path); monkeypatch.setattr(gat_layers, "_GEMM_BX3", "auto")
+                graph_mod.clear_graph_cache()
+                gr = graph_mod.prepare_graph(edge.to(d), None, N)
+                xd, eed, ad, a2d = (t.to(d).requires_grad_(True) for t in (x, ee, a, a2))
+                out = gat_layers.gat_heads(xd, eed, ad, a2d, gr, None, 0.2, concat)
+                (out * G.to(d)).sum().backward()
+                with torch.no_grad():
+                    oi = gat_layers.gat_heads(x.to(d), ee.to(d), a.to(d), a2.to(d), gr, None, 0.2, concat)
+                chk("eval " + path, cfg, oi, out, atol=1e-6, rel=1e-6)
+                res[path] = [out, xd.grad, eed.grad, ad.grad, a2d.grad]
+            for nm, u, v in zip(("out", "g_x", "g_ee", "g_a", "g_a2"), res["atp"], res["proj"]):
+                chk("atp vs proj " + nm, cfg, u, v)
+            monkeypatch.setattr(gat_layers, "_GAT_PATH", "auto")
+        except Exception as ex:
+            chk.bad.append(("exception", cfg, repr(ex)[:300], 0))
+        # ---- SpKBGATModified forward / batch_test vs oracle
+        Ne = int(rs.choice([20, 200, 1000])); E1 = int(rs.choice([0, 50, 3000])); E2 = int(rs.choice([0, 30, 500])); nrel = int(rs.randint(1, 20)); emb = int(rs.choice([4, 10, 50]))
+        d1 = int(rs.choice([8, 25, 100])); h1 = int(rs.choice([1, 2, 4]))
+        cfg = ("kbgat", it, Ne, E1, E2, nrel, emb, d1, h1)
+        try:
+            graph_mod.clear_graph_cache()
+            edge = torch.from_numpy(np.stack([rs.randint(0, Ne, E1), rs.randint(0, Ne, E1)])).long()
+            et = torch.randint(0, nrel, (E1,), generator=g)
+            quads = torch.stack([torch.randint(0, Ne, (E2,), generator=g), torch.randint(0, nrel, (E2,), generator=g), torch.randint(0, nrel, (E2,), generator=g),
+                                 torch.randint(0, Ne, (E2,), generator=g)], dim=1) if E2 else torch.zeros(0, 4, dtype=torch.long)
+            ents = torch.randint(0, Ne, (max(1, Ne // 3),), generator=g)
+            ent_emb, rel_emb = torch.randn(Ne, emb, generator=g), torch.randn(nrel, emb, generator=g)
+            torch.manual_seed(it)
+            m = SpKBGATModified(ent_emb.clone(), rel_emb.clone(), [d1, d1 * h1], [d1, d1 * h1], 0.0, 0.2, [h1, 1], None).to(d).eval()
+            oe, orr, mask = m(None, ents.to(d), (edge.to(d), et.to(d)), quads.to(d))
+            sg = m.sparse_gat_1
+            nrm = torch.nn.functional.normalize(ent_emb, p=2, dim=1)
+            re_, rr_, mk = O.spkbgat_forward(nrm.double(), rel_emb.double(), ents, edge, et, quads if E2 else None,
+                                             [a.a.detach().cpu().double() for a in sg.attentions], [a.a_2.detach().cpu().double() for a in sg.attentions],
+                                             sg.W.detach().cpu().double(), sg.out_att.a.detach().cpu().double(), sg.out_att.a_2.detach().cpu().double(),
+                                             m.W_entities.detach().cpu().double(), 0.2)
+            chk("kbgat ent", cfg, oe, re_); chk("kbgat rel", cfg, orr, rr_); chk("kbgat mask", cfg, mask, mk, atol=0, rel=0)
+            with torch.no_grad():
+                be, br, _ = m.batch_test(None, ents.to(d), (edge.to(d), et.to(d)), quads.to(d), m.entity_embeddings)
+            chk("kbgat batch_test ent", cfg, be, re_); chk("kbgat batch_test rel", cfg, br, rr_)
+        except Exception as ex:
+            chk.bad.append(("exception", cfg, repr(ex)[:300], 0))
+    graph_mod.clear_graph_cache()
+    assert not chk.bad, chk.bad[:5]
