@@ -294,20 +294,30 @@ def build_block_adjacency(T, identity, n):
     return blocks.permute(0, 1, 3, 2, 4).reshape(B, n * dd, n * dd)
 
 
-def propagate(adj_list, h0, nonlinearity, head_indices, tail_indices):
+def propagate(adj_list, h0, nonlinearity, head_indices, tail_indices, as_gemm=False):
     """models/models.py:260-274 (copies :470-485, :680-694, :918-932).
 
     adj_list: L tensors [B, S, S]; h0: [C, S, 1] (shared, GPGNN) or [B, C, S, 1] (per batch, RECON*);
     per hop h <- nonlinearity(A_l h); relation_l = gather(h, heads) * gather(h, tails);
     returns cat(relation_1..L, -1): [B, C, 2d*L].  head/tail_indices: [C, 2d] (or [B, C, 2d]).
+
+    as_gemm: the same product written as ONE matrix product per graph (h^l[b] = A_l[b] . H[b], H = [S, C]) instead of the
+    reference's broadcast of B*C matrix-vector products — identical maths (only the fp summation order inside the BLAS call may
+    differ), used for sizes where the broadcast form takes minutes and tens of GB (n = 32: S = 512, C = 992);
+    tests/test_oracle_golden.py checks it against the golden vectors like the default form.
     """
     B = adj_list[0].shape[0]
     h = h0
     rels = []
     hi = head_indices if head_indices.dim() == 3 else head_indices[None].expand(B, -1, -1)
     ti = tail_indices if tail_indices.dim() == 3 else tail_indices[None].expand(B, -1, -1)
+    if as_gemm and h.dim() == 3:
+        h = h[None].expand(B, -1, -1, -1)
     for A in adj_list:
-        h = torch.matmul(A[:, None], h)                     # [B, C, S, 1]
+        if as_gemm:
+            h = torch.bmm(A, h.squeeze(-1).transpose(1, 2)).transpose(1, 2).unsqueeze(-1)      # [B, C, S, 1]
+        else:
+            h = torch.matmul(A[:, None], h)                 # [B, C, S, 1]
         if nonlinearity != "linear":
             h = getattr(F, nonlinearity)(h) if nonlinearity != "tanh" else torch.tanh(h)
         flat = h.reshape(B, h.shape[1], h.shape[2])

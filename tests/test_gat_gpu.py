@@ -341,9 +341,10 @@ def test_spgat_golden(name):
 
 
 def test_full_size_cfg2_properties():
-    """BASELINE.json configs[1] at full size (B=512, n=16, 64 e/graph, F=R=D=200, H=8): too slow for the
-    oracle in full, so check (i) a slice of graphs against the oracle, (ii) linearity of the backward in
-    grad_out, (iii) permutation invariance: shuffling the edge columns changes nothing but fp order."""
+    """BASELINE.json configs[1] at full size (B=512, n=16, 64 e/graph, F=R=D=200, H=8), size-independent properties:
+    (i) graphs of a batch are independent (a slice against the oracle), (ii) linearity of the backward in grad_out,
+    (iii) permutation invariance: shuffling the edge columns changes nothing but fp order.  Every output and gradient of
+    this configuration against the float64 oracle: tests/test_full_size_gpu.py."""
     from recon_amd.gat_layers import gat_heads
     from recon_amd.graph import prepare_graph
     d = dev()
