@@ -14,30 +14,17 @@
 // K index is permuted consistently (k = 4*(lane>>4) + step) between the A- and B-fragments.
 #include <math.h>
 #include <stdlib.h>
-#include "recon_common.h"
+#include "prop_common.h"
 
 namespace recon {
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-constexpr int kMaxHops = 8;
 
 // logical block index such that XCD x (blocks b with b % 8 == x) owns a contiguous chunk of the logical range
 __device__ __forceinline__ int xcd_block(int b, int nb) {
     const int q = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-}
-
-__device__ __forceinline__ float act_fwd(float v, int act) {
-    if (act == RECON_ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == RECON_ACT_TANH) return tanhf(v);
-    return v;
-}
-// derivative expressed through the activation OUTPUT y
-__device__ __forceinline__ float act_bwd(float y, int act) {
-    if (act == RECON_ACT_RELU) return y > 0.f ? 1.f : 0.f;
-    if (act == RECON_ACT_TANH) return 1.f - y * y;
-    return 1.f;
 }
 
 // ------------------------------------------------------------------------------- P1
@@ -167,14 +154,6 @@ __global__ void k_start_entity(const float* __restrict__ ent, const int64_t* __r
 }
 
 // ------------------------------------------------------------------------------- P2 forward
-struct PropK {
-    const float* adj[kMaxHops];
-    const float* h0; int64_t h0_bs;
-    const int64_t* head; const int64_t* tail; int64_t idx_bs;
-    float* out; float* hsave;
-    int32_t B, C, S, L, dd, act, CC, Sp, pitch;
-};
-
 template <bool VEC4>
 __device__ __forceinline__ void load_a_row4(float (&v)[4], const float* A, int S, int row, int col, bool row_ok) {
     v[0] = v[1] = v[2] = v[3] = 0.f;
@@ -684,18 +663,6 @@ __global__ void __launch_bounds__(1024) k_propagate_fwd_s(const PropK p) {
 }
 
 // ------------------------------------------------------------------------------- P2 backward (one hop per launch)
-struct PropBwdK {
-    const float* A;           // adj of this hop [B,S,S]
-    const float* Hl;          // state after this hop  [B,C,S]
-    const float* Hprev;       // state before this hop [B,C,S] or h0
-    int64_t hprev_bs;         // batch stride of Hprev (0 for a shared h0)
-    const int64_t* head; const int64_t* tail; int64_t idx_bs;
-    const float* gout;        // [B,C,L*dd]
-    float* gH;                // [B,C,S] in: grad wrt H^l (ignored when first), out: grad wrt H^l-1
-    float* gA;                // [B,S,S] or null
-    int32_t B, C, S, L, dd, act, CC, Sp, pitch, hop, first, chunks;
-};
-
 template <int MT, bool VEC4>
 __global__ void __launch_bounds__(1024) k_propagate_bwd_hop(const PropBwdK p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -969,7 +936,10 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
     const int NTn = g.Sp / 16;
     const int mtn_s = (a->C + 15) / 16;
     {
+        // default: two-term half operands on the f16 matrix cores (prop_h.hip) wherever that form exists; RECON_PROP_FWD = w | b | s | x
+        // selects one of the forms below (fp32 MFMA per wave / per workgroup / staged, bf16 x 3), h forces the default
         const char* form = getenv("RECON_PROP_FWD");
+        if ((!form || form[0] == 'h' || form[0] == '\0') && prop_fwd_h_supported(p)) return prop_fwd_h(p, st);
         const int ntc = (a->C + 15) / 16, ks = (a->S + 31) / 32, mw = (a->S + 15) / 16;
         if (form && form[0] == 'x' && ntc <= 8 && ks <= 4 && mw <= 16) {     // S <= 128: wider states spill in this form             // bf16 x 3 on the bf16 matrix cores: opt-in (see the kernel's header)
             const size_t xlds = 3ull * ks * ntc * 16 * 64;
