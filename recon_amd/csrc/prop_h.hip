@@ -77,12 +77,30 @@ __device__ __forceinline__ float tanh_fast(float x) {
     return ax < 0.1f ? poly : big;
 }
 
+// s_memtime stamps for tools/probe/prop_h_stamps.hip (compiled out of the library)
+#ifdef RECON_PROP_STAMPS
+__device__ unsigned long long* g_stamps;
+#define STAMP(slot)                                                                                                   \
+    do {                                                                                                              \
+        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 77) && (wave == 0 || wave == NW - 1) && gi < 4) {          \
+            g_stamps[((((blockIdx.x ? 1 : 0) * 2 + (wave ? 1 : 0)) * 4 + gi) * 8 + hop_i) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+        }                                                                                                             \
+    } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
 constexpr int kGatherRegs = 2;                    // gather items per thread whose indices stay in registers (cfg 3b: exactly 2)
 constexpr uint32_t kOOB = 0xfffffff0u;            // a buffer offset past every num_records: the load returns zeros
 
 // NKS = K steps of 32 (S = 32 NKS or 32 NKS - 16), NTC = channel tiles of 16 (C <= 16 NTC); blockDim.x = 4 S (one wave per 16 rows of A).
-// Dynamic LDS: half planes [2][NKS][16 NTC][64 B] | fp32 state (under the channel scales) [16 NTC][S + 4] | channel maxima [2][16 NTC] |
-// inverse channel scales [16 NTC] | inverse row scales [waves][16]
+// Dynamic LDS: half planes [2][NKS][16 NTC][64 B] | channel maxima [2][16 NTC] | inverse channel scales [16 NTC] | inverse row scales [waves][16]
+//
+// State image.  Element (channel c, column t) of plane q lives at byte
+//     q PLANE + (t >> 5) STEP + 64 c + 16 (((t >> 2) & 3) ^ ((c >> 1) & 3)) + 8 ((t >> 4) & 1) + 2 (t & 3):
+// one 64-byte row per (K step, channel); its four 16-byte slots are the B fragments of the four lane groups (slot q holds t = 4 q .. 4 q + 3
+// and 16 + 4 q .. + 3 of the K step), XOR-rotated by the channel so that the ds_read_b128 of a fragment is conflict free and the 8-byte
+// writes of the epilogue (16 channels x 4 columns per lane group) meet two to a bank pair instead of four.
 template <int NKS, int NTC>
 __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -91,10 +109,9 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
     constexpr int PLANE = NKS * STEP;
     constexpr int KP = NKS * 32;
     constexpr int NCW = (CH + 2 * NKS - 2) / (2 * NKS - 1);      // channels a wave stages (at least 2 NKS - 1 waves)
-    const int S = p.S, C = p.C, pitch = S + 4;
+    const int S = p.S, C = p.C;
     unsigned char* Hs = sm;
-    unsigned char* Hfb = sm + 2 * PLANE;          // fp32 state, addressed in bytes
-    uint32_t* chmax = reinterpret_cast<uint32_t*>(Hfb + CH * pitch * 4);
+    uint32_t* chmax = reinterpret_cast<uint32_t*>(sm + 2 * PLANE);
     float* isg = reinterpret_cast<float*>(chmax + 2 * CH);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = nthreads >> 6;
@@ -105,19 +122,11 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
     // lane offset for all ten loads (the rest is the instruction's immediate); the half K step past S is requested out of range.
     const uint32_t voff_a = (static_cast<uint32_t>(16 * wave + li) * S + 4 * lq) * 4;
     const uint32_t voff_tail = (S & 16) ? kOOB : voff_a + (KP - 16) * 4;
-    auto load_a = [&](u32x4 (&raw)[NKS][2], int l, int bb) {
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.adj[l]) + static_cast<int64_t>(bb) * SSb), 0,
-                                                          static_cast<int>(SSb), 0x00020000);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                raw[ks][h] = (ks == NKS - 1 && h == 1) ? __builtin_amdgcn_raw_buffer_load_b128(rs, voff_tail, 0, 0)
-                                                       : __builtin_amdgcn_raw_buffer_load_b128(rs, voff_a + (32 * ks + 16 * h) * 4, 0, 0);
+    auto rsrc_a = [&](int l, int bb) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.adj[l]) + static_cast<int64_t>(bb) * SSb), 0,
+                                                 static_cast<int>(SSb), 0x00020000);
     };
-    // four consecutive t of one channel, scaled, into the two planes at byte offset `off` of plane 0.
-    // off(c, t0) = (t0 >> 5) STEP + 64 c + 16 (((t0 >> 2) & 3) ^ (2 ((c >> 3) & 1))) + 8 ((t0 >> 4) & 1): adding 2 (c >> 3) mod 4 is an XOR
-    // with bit 1, so the channel part and the column part separate (one of them is wave-uniform wherever this is called)
+    // two half terms of four consecutive (scaled) columns -> 8 bytes of each plane
     auto store_state4 = [&](int off, float v0, float v1, float v2, float v3) {
         uint32_t h0, l0, h1, l1;
         hx2_split2(v0, v1, h0, l0);
@@ -125,69 +134,97 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
         *reinterpret_cast<uint2*>(Hs + off) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(Hs + PLANE + off) = make_uint2(l0, l1);
     };
-    auto col_off = [](int t0) { return (t0 >> 5) * STEP + (((t0 >> 2) & 3) << 4) + (((t0 >> 4) & 1) << 3); };
-    const int b_rd = li * 64 + (((lq + 2 * (li >> 3)) & 3) << 4);      // B fragment: + 1024 j + STEP ks (+ PLANE for the low terms)
+    auto col_off = [](int t0) { return (t0 >> 5) * STEP + (((t0 >> 2) & 3) << 4) + (((t0 >> 4) & 1) << 3); };      // XOR ((c >> 1) & 3) << 4, + 64 c
+    const int swz = ((li >> 1) & 3) << 4;                               // channel 16 j + li: the same for every j
+    const int b_rd = li * 64 + ((lq << 4) ^ swz);                       // B fragment: + 1024 j + STEP ks (+ PLANE for the low terms)
     const int t0w = 16 * wave + 4 * lq;                                 // this lane's four state columns in the C layout
-    const int so_w = (col_off(t0w) + 64 * li) ^ (((li >> 3) & 1) << 5);  // + 1024 j: (16 j + li) >> 3 has li's parity bit
-    const int hf_w = (li * pitch + t0w) * 4;                            // + 64 j pitch
+    const int so_w = (col_off(t0w) ^ swz) + 64 * li;                    // + 1024 j
     const int nitems = C * p.dd, Ldd = p.L * p.dd;
     const bool homog = p.act != RECON_ACT_TANH;                         // act(k v) = k act(v) for k > 0: the old channel scale stays on
+    const bool relu = p.act == RECON_ACT_RELU;
 
+    // h^0 of graph bb: this wave's NCW channels, one 16-byte piece per lane
+    const uint32_t vo_h = 4 * lane < S ? 16u * lane : kOOB;
+    auto load_h0 = [&](u32x4 (&hv)[NCW], int bb) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.h0 + bb * p.h0_bs), 0, C * S * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NCW; ++i) {
+            const int c = wave + i * NW;
+            hv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, c < C ? vo_h + static_cast<uint32_t>(c * S * 4) : kOOB, 0, 0);
+        }
+    };
     u32x4 raw[NKS][2];
     int b = blockIdx.x;
-    if (b < p.B) load_a(raw, 0, b);
+    if (b < p.B) {
+        const auto rs = rsrc_a(0, b);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            raw[ks][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_a + 128 * ks, 0, 0);
+            raw[ks][1] = ks == NKS - 1 ? __builtin_amdgcn_raw_buffer_load_b128(rs, voff_tail, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs, voff_a + 128 * ks + 64, 0, 0);
+        }
+    }
+    int gi = -1, hop_i = 0;
+    (void)gi; (void)hop_i;
 #pragma unroll 1
     for (; b < p.B; b += gridDim.x) {
-        // ---- gather items of this thread (the same in every hop): byte positions of head / tail in the fp32 state, of the channel's
-        // inverse scale and of the result in `out`
-        uint32_t g_hi[kGatherRegs], g_ti[kGatherRegs], g_o[kGatherRegs], g_c[kGatherRegs];
+        ++gi; hop_i = 7;
+        STAMP(0);
+        // ---- h^0: wave w stages channels w, w + NW, ... (a whole channel per wave: its max magnitude is a wave reduction); columns past S
+        // and channels past C come back as zeros (out-of-range offsets).  (Requesting the next graph's h^0 during the last hop was
+        // measured: 89 -> 95 us — it competes with the adjacency prefetch for the CU's ~12 B/clk share of HBM.)
         {
-            const int64_t* hd = p.head + b * p.idx_bs;
-            const int64_t* tl = p.tail + b * p.idx_bs;
-#pragma unroll
-            for (int i = 0; i < kGatherRegs; ++i) {
-                const uint32_t idx = min(tid + i * nthreads, nitems - 1);
-                const uint32_t c = idx / static_cast<uint32_t>(p.dd);
-                g_hi[i] = 4u * (c * pitch + static_cast<uint32_t>(hd[idx])); g_ti[i] = 4u * (c * pitch + static_cast<uint32_t>(tl[idx]));
-                g_o[i] = 4u * (idx + c * (Ldd - p.dd));                         // c L dd + x
-                g_c[i] = 4u * c;
-            }
-        }
-        // ---- h^0: wave w stages channels w, w + NW, ... (a whole channel per wave: its max magnitude is a wave reduction); columns
-        // past S and channels past C come back as zeros (out-of-range offsets)
-        {
-            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.h0 + b * p.h0_bs), 0, C * S * 4, 0x00020000);
-            const int t0 = 4 * lane;
-            const uint32_t vo = t0 < S ? 16u * lane : kOOB;
-            const int so = col_off(t0);
             u32x4 hv[NCW];
+            load_h0(hv, b);
+            const int t0 = 4 * lane;
+            const int so = col_off(t0);
+            if (wave == 0) {
 #pragma unroll
-            for (int i = 0; i < NCW; ++i) {
-                const int c = wave + i * NW;
-                hv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, c < C ? vo + static_cast<uint32_t>(c * S * 4) : kOOB, 0, 0);
+                for (int k = 0; k < (2 * CH + 63) / 64; ++k)
+                    if (lane + 64 * k < 2 * CH) chmax[lane + 64 * k] = 0u;
             }
-            for (int i = tid; i < 2 * CH; i += nthreads) chmax[i] = 0u;
+            float mx[NCW];
+#pragma unroll
+            for (int i = 0; i < NCW; ++i)                                           // NCW independent reduction chains
+                mx[i] = wave_max(fmaxf(fmaxf(fabsf(as_f(hv[i].x)), fabsf(as_f(hv[i].y))), fmaxf(fabsf(as_f(hv[i].z)), fabsf(as_f(hv[i].w)))));
 #pragma unroll
             for (int i = 0; i < NCW; ++i) {
                 const int c = wave + i * NW;                                        // wave-uniform
                 if (c < CH) {
-                    const float v0 = as_f(hv[i].x), v1 = as_f(hv[i].y);
-                    const float v2 = as_f(hv[i].z), v3 = as_f(hv[i].w);
-                    const float m = wave_max(fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))));
-                    const float sg = hx2_scale_of(m);
-                    if (t0 < KP) store_state4((so + 64 * c) ^ (((c >> 3) & 1) << 5), v0 * sg, v1 * sg, v2 * sg, v3 * sg);
-                    if (t0 < S) *reinterpret_cast<float4*>(Hfb + (c * pitch + t0) * 4) = make_float4(v0 * sg, v1 * sg, v2 * sg, v3 * sg);
+                    const float sg = hx2_scale_of(mx[i]);
+                    if (t0 < KP) store_state4((so ^ (((c >> 1) & 3) << 4)) + 64 * c, as_f(hv[i].x) * sg, as_f(hv[i].y) * sg, as_f(hv[i].z) * sg, as_f(hv[i].w) * sg);
                     if (lane == 0) isg[c] = hx2_inv(sg);
                 }
             }
         }
+        // ---- gather items of this thread (the same in every hop): byte positions of head / tail in plane 0, of the channel's inverse
+        // scale and of the result in `out`
+        uint32_t g_hi[kGatherRegs], g_ti[kGatherRegs], g_o[kGatherRegs], g_c[kGatherRegs];
+        {
+            const int64_t* hd = p.head + b * p.idx_bs;
+            const int64_t* tl = p.tail + b * p.idx_bs;
+            auto pos = [&](uint32_t c, uint32_t t) {
+                return (t >> 5) * STEP + 64 * c + (((((t >> 2) & 3) ^ ((c >> 1) & 3))) << 4) + (((t >> 4) & 1) << 3) + 2 * (t & 3);
+            };
+#pragma unroll
+            for (int i = 0; i < kGatherRegs; ++i) {
+                const uint32_t idx = min(tid + i * nthreads, nitems - 1);
+                const uint32_t c = idx / static_cast<uint32_t>(p.dd);
+                g_hi[i] = pos(c, static_cast<uint32_t>(hd[idx])); g_ti[i] = pos(c, static_cast<uint32_t>(tl[idx]));
+                g_o[i] = 4u * (idx + c * (Ldd - p.dd));                         // c L dd + x
+                g_c[i] = 4u * c;
+            }
+        }
+        STAMP(1);
         lds_barrier();
+        STAMP(2);
         float inv_sig[NTC];
 #pragma unroll
         for (int j = 0; j < NTC; ++j) inv_sig[j] = isg[16 * j + li];
 
 #pragma unroll 1
         for (int l = 0; l < p.L; ++l) {
+            hop_i = l;
+            STAMP(0);
             // ---- this hop's rows: per-row scale, two half terms per element
             float m = 0.f;
 #pragma unroll
@@ -214,16 +251,22 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
                 a_hi[ks] = __builtin_bit_cast(f16x8, u32x4{hi[0], hi[1], hi[2], hi[3]});
                 a_lo[ks] = __builtin_bit_cast(f16x8, u32x4{lo[0], lo[1], lo[2], lo[3]});
             }
-            // ---- the rows of the NEXT step (next hop, or hop 0 of this workgroup's next graph) start their trip now
-            {
-                const bool more_hops = l + 1 < p.L;
-                const int nb = more_hops ? b : b + static_cast<int>(gridDim.x);
-                if (nb < p.B) load_a(raw, more_hops ? l + 1 : 0, nb);
-            }
-            // ---- products
+            STAMP(1);
+            // ---- products, with the rows of the NEXT step (next hop, or hop 0 of this workgroup's next graph) requested between the K
+            // steps: a CU takes ~40 cycles per 1 KiB load instruction, so ten of them in a row block the wave for as long as the
+            // matrix pipe needs for the hop (s_memtime stamps: 3-4 k cycles) — interleaved they ride under the MFMAs
+            const bool more_hops = l + 1 < p.L;
+            const int nb = more_hops ? b : b + static_cast<int>(gridDim.x);
+#ifdef RECON_PROP_NOPREFETCH
+            const bool pre = false;
+#else
+            const bool pre = nb < p.B;
+#endif
+            const auto rs_n = rsrc_a(more_hops ? l + 1 : 0, pre ? nb : b);
             f32x4 acc[NTC];
 #pragma unroll
             for (int j = 0; j < NTC; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            STAMP(2);
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
@@ -243,15 +286,21 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) if (j + jj < NTC) acc[j + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[ks], bh[jj], acc[j + jj], 0, 0, 0);
                 }
+                if (pre) {
+                    raw[ks][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_n, voff_a + 128 * ks, 0, 0);
+                    raw[ks][1] = ks == NKS - 1 ? __builtin_amdgcn_raw_buffer_load_b128(rs_n, voff_tail, 0, 0)
+                                               : __builtin_amdgcn_raw_buffer_load_b128(rs_n, voff_a + 128 * ks + 64, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0x078f);                            // everything but VMEM may move across: the requests stay where they are written
             }
-            // ---- epilogue 1: row scales off, activation, channel maxima (every lane sends its own: the LDS unit orders the four lanes of
-            // a channel).  C layout: column (lane & 15) = channel 16 j + li, rows 4 lq + r.  Values stay under the OLD channel scale
+            STAMP(3);
+            // ---- epilogue 1: row scales off, activation, channel maxima (every lane sends its own ds_max: reducing the four lanes of a channel
+            // on the VALU first measured no faster).  C layout: column (lane & 15) = channel 16 j + li, rows 4 lq + r.  Values stay under the OLD channel scale
             // where the activation commutes with it (relu, linear).
             lds_wait();
             const float4 ia = *reinterpret_cast<const float4*>(atab + 4 * lq);
             uint32_t* cm = chmax + (l & 1) * CH;
             if (homog) {
-                const bool relu = p.act == RECON_ACT_RELU;
 #pragma unroll
                 for (int j = 0; j < NTC; ++j) {
                     acc[j][0] *= ia.x; acc[j][1] *= ia.y; acc[j][2] *= ia.z; acc[j][3] *= ia.w;
@@ -271,56 +320,78 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
                     atomicMax(cm + 16 * j + li, __builtin_bit_cast(uint32_t, mm));
                 }
             }
+                          // unconditional: a conditional definition would keep the old value live through every hop                                 // the next graph's h^0 travels under the rest of this hop
+            STAMP(4);
             lds_barrier();                                                          // everybody has read H^l-1; maxima complete
-            // ---- epilogue 2: H^l under its new channel scales into the planes and the fp32 copy
-            for (int i = tid; i < CH; i += nthreads) chmax[((l + 1) & 1) * CH + i] = 0u;
+            STAMP(5);
+            // ---- epilogue 2: H^l under its new channel scales into the planes
+            if (wave == 0) {
+#pragma unroll
+                for (int k = 0; k < (CH + 63) / 64; ++k)
+                    if (lane + 64 * k < CH) chmax[((l + 1) & 1) * CH + lane + 64 * k] = 0u;
+            }
 #pragma unroll
             for (int j = 0; j < NTC; ++j) {
                 const float inv_u = homog ? inv_sig[j] : 1.f;                       // the unit acc[j] is in now
                 const float sg = hx2_scale_of(__builtin_bit_cast(float, cm[16 * j + li]) * inv_u);
                 const float f = sg * inv_u;
                 inv_sig[j] = hx2_inv(sg);
-                const float w0 = acc[j][0] * f, w1 = acc[j][1] * f, w2 = acc[j][2] * f, w3 = acc[j][3] * f;
-                store_state4(so_w + 1024 * j, w0, w1, w2, w3);
-                *reinterpret_cast<float4*>(Hfb + hf_w + 64 * j * pitch) = make_float4(w0, w1, w2, w3);
+                store_state4(so_w + 1024 * j, acc[j][0] * f, acc[j][1] * f, acc[j][2] * f, acc[j][3] * f);
                 if (tid < 16) isg[16 * j + li] = inv_sig[j];
             }
+            STAMP(6);
             lds_barrier();                                                          // H^l complete
-            // ---- relation_l = gather(h, heads) * gather(h, tails)   (models/models.py:270-273), saved state
+            STAMP(7);
+            // ---- relation_l = gather(h, heads) * gather(h, tails)   (models/models.py:270-273), saved state; values = (hi + lo) / scale
+            auto state_at = [&](uint32_t pos) {
+                return static_cast<float>(*reinterpret_cast<const _Float16*>(Hs + pos)) + static_cast<float>(*reinterpret_cast<const _Float16*>(Hs + PLANE + pos));
+            };
             char* out = reinterpret_cast<char*>(p.out + (static_cast<int64_t>(b) * C * p.L + l) * p.dd);
 #pragma unroll
             for (int i = 0; i < kGatherRegs; ++i)
                 if (tid + i * nthreads < nitems) {
                     const float k = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(isg) + g_c[i]);
-                    *reinterpret_cast<float*>(out + g_o[i]) = (*reinterpret_cast<const float*>(Hfb + g_hi[i]) * k) * (*reinterpret_cast<const float*>(Hfb + g_ti[i]) * k);
+                    *reinterpret_cast<float*>(out + g_o[i]) = (state_at(g_hi[i]) * k) * (state_at(g_ti[i]) * k);
                 }
             if (nitems > kGatherRegs * nthreads) {                                   // more items per thread: their index loads wait for the prefetch
                 for (int idx = tid + kGatherRegs * nthreads; idx < nitems; idx += nthreads) {
-                    const int c = idx / p.dd, x = idx - c * p.dd;
+                    const uint32_t c = idx / p.dd, x = idx - c * p.dd;
                     const int64_t io = b * p.idx_bs + idx;
-                    const float* hf = reinterpret_cast<const float*>(Hfb) + c * pitch;
+                    const uint32_t th = static_cast<uint32_t>(p.head[io]), tt = static_cast<uint32_t>(p.tail[io]);
+                    const uint32_t base = 64 * c, sw = (c >> 1) & 3;
+                    const uint32_t ph = (th >> 5) * STEP + base + ((((th >> 2) & 3) ^ sw) << 4) + (((th >> 4) & 1) << 3) + 2 * (th & 3);
+                    const uint32_t pt = (tt >> 5) * STEP + base + ((((tt >> 2) & 3) ^ sw) << 4) + (((tt >> 4) & 1) << 3) + 2 * (tt & 3);
                     const float k = isg[c];
-                    reinterpret_cast<float*>(out)[c * Ldd + x] = (hf[static_cast<int>(p.head[io])] * k) * (hf[static_cast<int>(p.tail[io])] * k);
+                    reinterpret_cast<float*>(out)[c * Ldd + x] = (state_at(ph) * k) * (state_at(pt) * k);
                 }
             }
-            if (p.hsave) {                                                          // wave w: rows w, w + NW, ...; lanes: 16-byte pieces
+            if (p.hsave) {                                                          // wave w: rows w, w + NW, ...; lane = (K step, half, slot)
                 char* hs = reinterpret_cast<char*>(p.hsave + ((static_cast<int64_t>(l) * p.B + b) * C) * S);
-                if (4 * lane < S)
+                const int ts = 32 * (lane >> 3) + 16 * ((lane >> 2) & 1) + 4 * (lane & 3);       // the four columns behind this lane's 8 bytes
+                const int lo_off = (lane >> 3) * STEP + (((lane >> 2) & 1) << 3);
+                if (ts < S)
                     for (int c = wave; c < C; c += NW) {
                         const float k = isg[c];
-                        float4 v = *reinterpret_cast<const float4*>(Hfb + (c * pitch + 4 * lane) * 4);
-                        v.x *= k; v.y *= k; v.z *= k; v.w *= k;
-                        *reinterpret_cast<float4*>(hs + static_cast<uint32_t>(c * S + 4 * lane) * 4u) = v;
+                        const int off = lo_off + 64 * c + (((lane & 3) ^ ((c >> 1) & 3)) << 4);
+                        const uint2 hi = *reinterpret_cast<const uint2*>(Hs + off), lo = *reinterpret_cast<const uint2*>(Hs + PLANE + off);
+                        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                        const h2 a0 = __builtin_bit_cast(h2, hi.x), a1 = __builtin_bit_cast(h2, hi.y), b0 = __builtin_bit_cast(h2, lo.x), b1 = __builtin_bit_cast(h2, lo.y);
+                        float4 v;
+                        v.x = (static_cast<float>(a0[0]) + static_cast<float>(b0[0])) * k; v.y = (static_cast<float>(a0[1]) + static_cast<float>(b0[1])) * k;
+                        v.z = (static_cast<float>(a1[0]) + static_cast<float>(b1[0])) * k; v.w = (static_cast<float>(a1[1]) + static_cast<float>(b1[1])) * k;
+                        *reinterpret_cast<float4*>(hs + static_cast<uint32_t>(c * S + ts) * 4u) = v;
                     }
             }
+            STAMP(8);
         }
+        hop_i = 6; STAMP(0);
         lds_barrier();                                                              // the gathers are done before the next graph's h^0 lands
     }
 }
 
 size_t fwd_h_lds(int nks, int ntc, int S) {
     const size_t ch = 16ull * ntc;
-    return 2ull * nks * ch * 64 + ch * (S + 4) * sizeof(float) + 3ull * ch * sizeof(uint32_t) + static_cast<size_t>(S / 16) * 16 * sizeof(float);
+    return 2ull * nks * ch * 64 + 3ull * ch * sizeof(uint32_t) + static_cast<size_t>(S / 16) * 16 * sizeof(float);
 }
 
 int num_cus() {
