@@ -135,9 +135,9 @@ __global__ void k_rowptr_lower_bound(const int32_t* __restrict__ sorted_keys, in
 }
 
 __global__ void k_gather_src(const int64_t* __restrict__ edge_src, const int32_t* __restrict__ eid, int32_t E,
-                             int32_t* __restrict__ src_out, int32_t* __restrict__ iota) {
+                             int32_t* __restrict__ src_out, int32_t* __restrict__ keys, int32_t* __restrict__ iota) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < E) { src_out[k] = static_cast<int32_t>(edge_src[eid[k]]); iota[k] = k; }
+    if (k < E) { const int32_t v = static_cast<int32_t>(edge_src[eid[k]]); src_out[k] = v; keys[k] = v; iota[k] = k; }
 }
 
 __global__ void k_copy_i32(const int32_t* __restrict__ in, int32_t* __restrict__ out, int32_t n) {
@@ -149,12 +149,15 @@ int bits_for(int32_t n) { int b = 1; while (b < 31 && (1 << b) < n) ++b; return 
 
 struct SortWs { int32_t *kA, *kB, *vA, *vB, *hist; int32_t nblocks; };
 
-// stable sort of (kA, vA); result ends up in (*kout, *vout) which point into the ping-pong buffers
-int radix_sort_pairs(SortWs& ws, int32_t n, int32_t key_range, int32_t** kout, int32_t** vout, hipStream_t st) {
+// stable sort of (kA, vA); the LAST pass scatters into (kfinal, vfinal) when given (a copy launch each less per sort: a graph build is
+// launch bound at the stage-A batch sizes), else the result ends up in (*kout, *vout), which point into the ping-pong buffers
+int radix_sort_pairs(SortWs& ws, int32_t n, int32_t key_range, int32_t** kout, int32_t** vout, hipStream_t st, int32_t* kfinal = nullptr,
+                     int32_t* vfinal = nullptr) {
     const int passes = (bits_for(key_range) + 7) / 8;
     int32_t *ki = ws.kA, *vi = ws.vA, *ko = ws.kB, *vo = ws.vB;
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
+        if (p == passes - 1) { if (kfinal) ko = kfinal; if (vfinal) vo = vfinal; }
         hipLaunchKernelGGL(k_radix_hist, dim3(ws.nblocks), dim3(kThreads), 0, st, ki, n, shift, ws.hist, ws.nblocks);
         hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, ws.hist, 256 * ws.nblocks);
         hipLaunchKernelGGL(k_radix_scatter, dim3(ws.nblocks), dim3(kThreads), 0, st, ki, vi, ko, vo, n, shift, ws.hist,
@@ -289,18 +292,14 @@ extern "C" int recon_graph_build(const int64_t* edge_dst, const int64_t* edge_sr
     // destination CSR: stable sort of (dst, edge column)
     hipLaunchKernelGGL(k_convert_keys, eb, dim3(256), 0, st, edge_dst, ws.kA, ws.vA, E);
     int32_t *ks, *vs;
-    int rc = radix_sort_pairs(ws, E, N, &ks, &vs, st);
+    int rc = radix_sort_pairs(ws, E, N, &ks, &vs, st, g->dst, g->eid);
     if (rc != RECON_OK) return rc;
-    hipLaunchKernelGGL(k_copy_i32, eb, dim3(256), 0, st, ks, g->dst, E);
-    hipLaunchKernelGGL(k_copy_i32, eb, dim3(256), 0, st, vs, g->eid, E);
     hipLaunchKernelGGL(k_rowptr_lower_bound, nb, dim3(256), 0, st, g->dst, E, N, g->rowptr_dst);
     if (!with_src) { RECON_CHECK_LAUNCH(); return RECON_OK; }
     // source CSC over CSR slots: stable sort of (src of slot, slot)
-    hipLaunchKernelGGL(k_gather_src, eb, dim3(256), 0, st, edge_src, g->eid, E, g->src, ws.vA);
-    hipLaunchKernelGGL(k_copy_i32, eb, dim3(256), 0, st, g->src, ws.kA, E);
-    rc = radix_sort_pairs(ws, E, N, &ks, &vs, st);
+    hipLaunchKernelGGL(k_gather_src, eb, dim3(256), 0, st, edge_src, g->eid, E, g->src, ws.kA, ws.vA);
+    rc = radix_sort_pairs(ws, E, N, &ks, &vs, st, nullptr, g->slot_by_src);
     if (rc != RECON_OK) return rc;
-    hipLaunchKernelGGL(k_copy_i32, eb, dim3(256), 0, st, vs, g->slot_by_src, E);
     hipLaunchKernelGGL(k_rowptr_lower_bound, nb, dim3(256), 0, st, ks, E, N, g->rowptr_src);
     RECON_CHECK_LAUNCH();
     return RECON_OK;

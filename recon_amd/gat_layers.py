@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .graph import prepare_graph, _has_nhop
+from .graph import prepare_graph, _has_nhop, trust, trusted
 
 CUDA = torch.cuda.is_available()          # GAT/layers.py:9
 _DEBUG_NAN = os.environ.get("RECON_DEBUG_NAN", "0") == "1"
@@ -213,7 +213,10 @@ def _segment_key(index):
     if hit is None:
         if len(_KEY_CACHE) > 16:
             _KEY_CACHE.clear()
-        hit = _KEY_CACHE[k] = (torch.stack((index, index)), index)      # keeps `index` alive: its data_ptr is the key
+        key = torch.stack((index, index))
+        if trusted(index):
+            trust(key)
+        hit = _KEY_CACHE[k] = (key, index)      # keeps `index` alive: its data_ptr is the key
     return hit[0]
 
 
@@ -572,7 +575,10 @@ def _extended_index(index, n_rows, n_extra):
     key = (index.data_ptr(), index._version, tuple(index.shape), int(n_rows), int(n_extra))
     hit = _INDEX_CACHE.get(key)
     if hit is None:
-        hit = (torch.cat((index, torch.arange(n_rows, n_rows + n_extra, dtype=torch.int64, device=index.device))), index)
+        ext = torch.cat((index, torch.arange(n_rows, n_rows + n_extra, dtype=torch.int64, device=index.device)))
+        if trusted(index):
+            trust(ext)
+        hit = (ext, index)
         _INDEX_CACHE[key] = hit
         while len(_INDEX_CACHE) > 8:
             _INDEX_CACHE.popitem(last=False)

@@ -16,13 +16,29 @@ from . import _lib
 _CACHE = OrderedDict()
 _CACHE_MAX = 8
 _VALIDATE = os.environ.get("RECON_VALIDATE_EDGES", "1") != "0"
+
+
+def trust(*tensors):
+    """Mark index tensors whose values are in range BY CONSTRUCTION (produced on the device from already validated data: the
+    neighbour sampler's batches, keys derived inside this package).  Validation costs a host synchronisation per fresh tensor
+    (`aminmax` -> int()), and in the stage-A loop every iteration brings fresh tensors (GAT/main.py:478-516).  Returns its argument(s)."""
+    for t in tensors:
+        if torch.is_tensor(t):
+            t._recon_trusted = True
+    return tensors[0] if len(tensors) == 1 else tensors
+
+
+def trusted(t):
+    return getattr(t, "_recon_trusted", False)
+
+
 HUB_CHUNK = 64          # RECON_HUB_CHUNK (include/recon_hip.h); 0 switches the splitting of long destination rows off (tests compare both)
 
 
 class GraphCSR:
     """Device-resident CSR/CSC view of a COO edge list.  Attributes mirror `recon_graph`."""
 
-    def __init__(self, edge, N, rows_only=False):
+    def __init__(self, edge, N, rows_only=False, validate=True):
         """rows_only: destination CSR only — what the row sums need (SpecialSpmmFinal, the backward of gather_rows, the table gradients);
         no source view, no hub tables: half the sorting of a full build."""
         if not edge.is_cuda:
@@ -34,7 +50,7 @@ class GraphCSR:
         if N >= 2 ** 31 or E >= 2 ** 31:
             raise ValueError("graph too large for int32 indices")
         dev = edge.device
-        if E > 0 and _VALIDATE:
+        if E > 0 and _VALIDATE and validate and not trusted(edge):
             # once per cached graph (one host sync): ids outside [0, N) would be truncated to int32, sorted on too few bits
             # and make the edge kernels read out of bounds; the reference fails on the same input (index out of range)
             lo, hi = torch.aminmax(edge)
@@ -94,11 +110,13 @@ class GraphCSR:
         key = (index.data_ptr(), index._version, tuple(index.stride()))
         hit = self._slot_idx.get(key)
         if hit is None:
-            if _VALIDATE and self.E > 0:
+            if _VALIDATE and self.E > 0 and not trusted(index):
                 lo, hi = torch.aminmax(index)
                 if int(lo) < 0 or int(hi) >= n_rows:
                     raise IndexError("recon_amd: row index out of range: [%d, %d] into a table of %d rows" % (int(lo), int(hi), n_rows))
             slot_long = index[self.eid_long].contiguous()
+            if trusted(index):
+                trust(slot_long)                                              # a permutation of trusted values
             hit = (slot_long.to(torch.int32), slot_long, index)              # `index` pins data_ptr identity while cached
             if len(self._slot_idx) >= 4:
                 self._slot_idx.pop(next(iter(self._slot_idx)))
@@ -147,7 +165,7 @@ def prepare_graph(edge, edge_list_nhop, N, rows_only=False):
         _CACHE.move_to_end(key)
         return g
     full = torch.cat((edge, edge_list_nhop), dim=1) if nh else edge
-    g = GraphCSR(full, N, rows_only)
+    g = GraphCSR(full, N, rows_only, validate=not (trusted(edge) and (not nh or trusted(edge_list_nhop))))
     g._keepalive = (edge, edge_list_nhop if nh else None)   # pins data_ptr identity while cached
     _CACHE[key] = g
     while len(_CACHE) > _CACHE_MAX:

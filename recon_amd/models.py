@@ -7,7 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed, gather_rows, small_mm, IndexedRows
-from .graph import prepare_graph
+from .graph import prepare_graph, trust, trusted
 
 
 class _AliasHeadParams(torch.autograd.Function):
@@ -81,7 +81,10 @@ class SpGAT(nn.Module):
             # the relation table in place instead of an E x R copy of it
             edge_embed = IndexedRows(relation_embed, edge_type)
         if has_nhop:
-            edge_embed_nhop = gather_rows(relation_embed, edge_type_nhop[:, 0]) + gather_rows(relation_embed, edge_type_nhop[:, 1])
+            t0, t1 = edge_type_nhop[:, 0], edge_type_nhop[:, 1]
+            if trusted(edge_type_nhop):
+                trust(t0, t1)                                             # views do not inherit the mark
+            edge_embed_nhop = gather_rows(relation_embed, t0) + gather_rows(relation_embed, t1)
         else:
             edge_embed_nhop = torch.tensor([])
         x = self.heads_forward(x, edge_list, edge_embed, edge_list_nhop, edge_embed_nhop)
@@ -89,7 +92,7 @@ class SpGAT(nn.Module):
         out_relation_1 = small_mm(relation_embed, self.W)
         edge_embed = IndexedRows(out_relation_1, edge_type)               # out_relation_1[edge_type] (:79), read in place by the layer
         if has_nhop:
-            edge_embed_nhop = gather_rows(out_relation_1, edge_type_nhop[:, 0]) + gather_rows(out_relation_1, edge_type_nhop[:, 1])
+            edge_embed_nhop = gather_rows(out_relation_1, t0) + gather_rows(out_relation_1, t1)
         else:
             edge_embed_nhop = torch.tensor([])
         x = self.out_att(x, edge_list, edge_embed, edge_list_nhop, edge_embed_nhop, elu=True)        # F.elu(out_att(...)), :86-87, in the epilogue
@@ -124,17 +127,21 @@ class SpKBGATModified(nn.Module):
         nn.init.xavier_uniform_(self.W_entities.data, gain=1.414)
 
     def _nhop(self, train_indices_nhop, dev):
-        """2-hop quadruples (source, rel_1, rel_2, target) -> edges target <- source typed (rel_1, rel_2), :145-148, on `dev`.  The derived
-        tensors are kept per quadruple tensor (identity + version): the training loop passes the same quadruples every iteration
-        (GAT/main.py:226-229), and every cache below this call — the CSR of the batch, the row-sum keys of the relation gathers — is
-        keyed on tensor identity; fresh tensors each step meant ~15 sorts per step (rocprofv3: 45 % of a 6.9 ms step)."""
+        """2-hop quadruples (source, rel_1, rel_2, target) -> edges target <- source typed (rel_1, rel_2), GAT/models.py:145-148, on `dev`.
+        The derived tensors are kept per quadruple tensor (identity + version).  In the reference's training loop every iteration
+        brings a NEW quadruple tensor (GAT/main.py:494-508: `get_batch_nhop_neighbors_all` + `.cuda()`), so this cache only helps
+        callers that re-use a batch (evaluation over a fixed split, benchmarks of the cached regime); what keeps the fresh-tensor
+        regime cheap is that tensors marked by `graph.trust` (the sampler's batches) are never validated with a host round trip."""
         if train_indices_nhop.shape[0] == 0:
             return torch.tensor([]), torch.tensor([])
         key = (train_indices_nhop.data_ptr(), train_indices_nhop._version, tuple(train_indices_nhop.shape), str(dev))
         hit = getattr(self, "_nhop_cache", None)
         if hit is None or hit[0] != key:
             q = train_indices_nhop.to(dev)
-            hit = (key, torch.stack((q[:, 3], q[:, 0])).contiguous(), q[:, 1:3].contiguous(), train_indices_nhop)
+            edge_nhop, type_nhop = torch.stack((q[:, 3], q[:, 0])).contiguous(), q[:, 1:3].contiguous()
+            if trusted(train_indices_nhop):
+                trust(edge_nhop, type_nhop)
+            hit = (key, edge_nhop, type_nhop, train_indices_nhop)
             self._nhop_cache = hit
         return hit[1], hit[2]
 
@@ -147,7 +154,7 @@ class SpKBGATModified(nn.Module):
         out_entity, out_relation = self.sparse_gat_1(Corpus_, entity_embeddings, relation_embeddings, edge_list, edge_type,
                                                      None, edge_list_nhop, edge_type_nhop)
         mask = torch.zeros(entity_embeddings.shape[0], device=dev)
-        mask[torch.unique(batch_entities.to(dev))] = 1.0
+        mask[batch_entities.to(dev)] = 1.0               # the reference takes torch.unique first (:167-170): same mask, but a host round trip
         out_entity = small_mm(entity_embeddings, self.W_entities) + mask.unsqueeze(-1) * out_entity
         return F.normalize(out_entity, p=2, dim=1), out_relation, mask
 

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""One full-graph SpGAT step at the reference's own training scale (GAT/main.py defaults on FB15k-237: 14 541 entities, 237 relations,
-272 115 training triples, 100-d embeddings, 2 heads x 100 + out_att 200; every step runs the WHOLE graph — GAT/main.py:217-251).
+"""One full-graph SpGAT step at the scale of the reference's stage-A data (FB15k-237-sized: 14 541 entities, 237 relations, 272 115
+training triples, 100-d embeddings, 2 heads x 100 + out_att 200) with EVERY edge of the graph in one call and the same tensors every
+step.  This is a size probe of the kernels (hub rows of ~9 000 edges, 272 k edges per launch), NOT the reference's training loop: that
+one builds a fresh 128-entity batch per iteration (GAT/main.py:478-525) and is measured by tools/stage_a_iter_bench.py.
 Synthetic stand-in for the data set (there is no network): head and tail entities drawn Zipf-like (exponent 0.8) so that the largest
 entities have thousands of edges, as in the real graph.  fp32, forward and forward + backward."""
 import json, os, sys

@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""One stage-A (KB-GAT) training iteration as the reference runs it — /root/reference/GAT/main.py:478-525: per iteration a FRESH
+entity batch, its 1-hop adjacency (`Corpus.get_batch_adj_data`) and 2-hop quadruples (`get_batch_nhop_neighbors_all`) as NEW tensors,
+`SpKBGATModified.forward`, the TransE margin loss of `batch_gat_loss` (:344-376, valid_invalid_ratio_gat = 2), backward, SGD step and
+the `loss.item()` read-back — on an FB15k-237-sized synthetic knowledge graph (14 541 entities, 237 relations, 272 115 triples, Zipf-like
+degrees), 128 entities per batch (`--entities_per_batch` of the reference's run scripts).
+
+Nothing keyed on tensor identity survives an iteration in this regime ("fresh").  For comparison the same iteration with ONE batch
+re-used every time ("cached": what tools/kg_scale_bench.py --kbgat measures) and the batch assembly alone.  Prints one JSON line.
+
+  python tools/stage_a_iter_bench.py [--iters 30] [--entities 128] [--no-2hop]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from recon_amd.models import SpKBGATModified  # noqa: E402
+from recon_amd.sampler import KGNeighbourSampler  # noqa: E402
+
+
+def synthetic_kg(N=14541, T=272115, nrel=237, seed=0):
+    rs = np.random.RandomState(seed)
+    p = 1.0 / np.arange(1, N + 1) ** 0.8
+    p /= p.sum()
+    tails = rs.permutation(N)[rs.choice(N, size=T, p=p)]
+    heads = rs.permutation(N)[rs.choice(N, size=T, p=p)]
+    rel = rs.randint(0, nrel, size=T)
+    return torch.from_numpy(np.stack([tails, heads])).long(), torch.from_numpy(rel).long()
+
+
+def batch_gat_loss(loss_fn, train_indices, entity_embed, relation_embed, ratio=2, rows=None):
+    """GAT/main.py:344-376 restated: positives first, 2 * ratio negatives per positive behind them.  `rows(table, index)`: how the
+    embedding rows are fetched — None = `table[index]` as the reference writes it (its backward is torch's sort-based
+    indexing_backward_kernel: 0.33 ms per gather at these sizes, six gathers per iteration), or recon_amd's gather_rows (fixed-order
+    segment sums, the SpecialSpmmFinal walk)."""
+    if rows is None:
+        rows = lambda table, index: table[index]
+    n_pos = train_indices.shape[0] // (2 * ratio + 1)
+    pos = train_indices[:n_pos].repeat(2 * ratio, 1)
+    neg = train_indices[n_pos:]
+    pos_norm = torch.norm(rows(entity_embed, pos[:, 0]) + rows(relation_embed, pos[:, 1]) - rows(entity_embed, pos[:, 2]), p=1, dim=1)
+    neg_norm = torch.norm(rows(entity_embed, neg[:, 0]) + rows(relation_embed, neg[:, 1]) - rows(entity_embed, neg[:, 2]), p=1, dim=1)
+    y = -torch.ones(2 * ratio * n_pos, device=entity_embed.device)
+    return loss_fn(pos_norm, neg_norm, y)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--entities", type=int, default=128)
+    ap.add_argument("--no-2hop", action="store_true")
+    ap.add_argument("--ratio", type=int, default=2)
+    ap.add_argument("--loss-rows", choices=["torch", "recon"], default="torch", help="table[index] (the reference's loss code) or recon_amd.gat_layers.gather_rows")
+    args = ap.parse_args()
+    dv = torch.device("cuda:0")
+    torch.autograd.set_multithreading_enabled(False)
+    N, nrel = 14541, 237
+    adj_idx, adj_val = synthetic_kg(N=N, nrel=nrel)
+    sampler = KGNeighbourSampler(adj_idx.to(dv), adj_val.to(dv), N)
+    torch.manual_seed(0)
+    model = SpKBGATModified(torch.randn(N, 50), torch.randn(nrel, 50), [100, 200], [100, 200], 0.3, 0.2, [2, 2]).to(dv)
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+    loss_fn = torch.nn.MarginRankingLoss(margin=1.0)
+    g = torch.Generator().manual_seed(1)
+    sources_all = torch.unique(adj_idx[1])
+
+    rows = None
+    if args.loss_rows == "recon":
+        from recon_amd.gat_layers import gather_rows
+        from recon_amd.graph import trust
+        rows = lambda table, index: gather_rows(table, trust(index.contiguous()))
+
+    def make_batch():
+        ents = sources_all[torch.randperm(sources_all.numel(), generator=g)[:args.entities]].to(dv)
+        (edge, edge_type), (srcs, _) = sampler.batch_adj_data(ents)
+        quads = torch.tensor([], dtype=torch.long) if args.no_2hop else sampler.batch_nhop_neighbors(srcs)
+        # training triples of the batch (head, relation, tail) + 2 * ratio corrupted copies (Corpus.get_iteration_triples_batch)
+        pos = torch.stack((edge[1], edge_type, edge[0]), dim=1)
+        neg = pos.repeat(2 * args.ratio, 1)
+        half = neg.shape[0] // 2
+        neg[:half, 0] = torch.randint(0, N, (half,), device=dv)
+        neg[half:, 2] = torch.randint(0, N, (neg.shape[0] - half,), device=dv)
+        return ents, (edge, edge_type), quads, torch.cat((pos, neg), dim=0)
+
+    def train_iter(batch):
+        ents, adj, quads, train_indices = batch
+        entity_embed, relation_embed, _ = model(None, ents, adj, quads)
+        opt.zero_grad()
+        loss = batch_gat_loss(loss_fn, train_indices, entity_embed, relation_embed, args.ratio, rows)
+        loss.backward()
+        opt.step()
+        return loss.data.item()                                       # the reference reads the loss back every iteration
+
+    def timed(fn, iters):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+
+    one = make_batch()
+    for _ in range(3):
+        train_iter(one)
+        train_iter(make_batch())
+    t_batch = timed(make_batch, args.iters)
+    t_cached = timed(lambda: train_iter(one), args.iters)
+    t_fresh = timed(lambda: train_iter(make_batch()), args.iters)
+    E1, E2 = one[1][0].shape[1], (0 if args.no_2hop else one[2].shape[0])
+    print(json.dumps({"workload": "stage-A iteration (GAT/main.py:478-525): sampler batch -> SpKBGATModified fwd -> margin loss -> bwd -> SGD, FB15k-237-sized synthetic KG",
+                      "entities_per_batch": args.entities, "loss_rows": args.loss_rows, "edges_1hop": E1, "quads_2hop": E2,
+                      "batch_assembly_ms": t_batch, "iteration_cached_batch_ms": t_cached, "iteration_fresh_batch_ms": t_fresh,
+                      "model_step_fresh_ms": t_fresh - t_batch, "fresh_over_cached": (t_fresh - t_batch) / t_cached,
+                      "edges_per_s_fresh": (E1 + E2) / t_fresh * 1e3}))
+
+
+if __name__ == "__main__":
+    main()
