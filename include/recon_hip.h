@@ -265,7 +265,12 @@ int recon_gat_atp_bwd(const recon_graph* g, const recon_gat_atp_bwd_args* args, 
  * INPUTS (g_V GEMM, edge pass, source pass, score-vector gradient: HBM bound) and WEIGHTS (g_a = g_h^T V:
  * MFMA bound) only read what PREPARE wrote and touch disjoint workspaces, so they may run on two streams. */
 enum { RECON_ATP_BWD_PREPARE = 1, RECON_ATP_BWD_INPUTS = 2, RECON_ATP_BWD_WEIGHTS = 4, RECON_ATP_BWD_FINISH = 8,
-       RECON_ATP_BWD_ALL = 15 };
+       RECON_ATP_BWD_ALL = 15,
+       /* modifier for data-parallel callers that reduce the weight gradient across ranks UNDER the INPUTS phase: with WEIGHTS, the
+        * split-K second pass runs at once and leaves g_a = G = V^T g_h (the part of g_a that does not depend on INPUTS); with FINISH,
+        * g_a is taken to hold G already and only  g_a += a_2 (x) g_u,  g_a_2 = a . g_u  are applied.  Both are linear in (G, g_u), so
+        * mean over ranks of g_a = mean(G) + a_2 (x) mean(g_u): all-reduce G early, g_u (H x (2F+R) floats) after INPUTS, then FINISH. */
+       RECON_ATP_BWD_EARLY_SUM = 16 };
 int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp_bwd_args* args, int32_t phases,
                             recon_stream_t stream);
 

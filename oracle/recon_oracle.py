@@ -115,7 +115,7 @@ def gat_layer_backward(x, edge, edge_embed, edge_list_nhop, edge_embed_nhop, a, 
     g_ee = gm @ A_rel
     g_a = torch.cat((gP_dst.t() @ x, gP_src.t() @ x, gm.t() @ ee), dim=1)
     return dict(out=out, g_x=g_x, g_edge_embed=g_ee, g_a=g_a, g_a_2=g_a2, gm=gm, gP_dst=gP_dst,
-                gP_src=gP_src, sigma=sigma, w=w, Z=Z, m=m)
+                gP_src=gP_src, sigma=sigma, w=w, Z=Z, m=m, g_sigma=gsig)
 
 
 def spgat_forward(x, relation_embed, edge_list, edge_type, edge_embed, edge_list_nhop, edge_type_nhop,

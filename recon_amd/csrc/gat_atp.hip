@@ -1804,7 +1804,8 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
                 rc = gemm_hx2_kmajor_batched(W, D, N, a->V, 2LL * W, W, 2LL * N * W, b->gh_split, 2LL * D, D, 2LL * N * D,
                                              H, sk, b->partial, static_cast<const char*>(a->aux) + kHx2ZeroPageOffset, atp_scale_v(a), atp_scale_g(a), st,
                                              atp_dst_shared(a));
-                // its second pass runs in FINISH, fused with the score path's terms (k_atp_weights_finish)
+                // its second pass runs in FINISH, fused with the score path's terms (k_atp_weights_finish) — unless the caller wants G now
+                if (rc == RECON_OK && (phases & RECON_ATP_BWD_EARLY_SUM)) rc = splitk_reduce(b->partial, sk, W, D, C, bw.c_bs, H, 0, true, st);
             } else if (gh_planes && bx3_kmajor_supported(a->V, ldv, W, ld_ghp, D, W, D)) {    // split-precision MFMA, both operands k-major
                 const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));
                 rc = gemm_bx3_kmajor_batched(W, D, N, a->V, ldv, W, b->gh_split, ld_ghp, static_cast<int64_t>(N) * ld_ghp, D, H, sk, b->partial, st);
@@ -1872,7 +1873,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
             RECON_CHECK_LAUNCH();
         }
         // (6) through u = a_2^T a
-        if ((phases & RECON_ATP_BWD_FINISH) && hx2) {
+        if ((phases & RECON_ATP_BWD_FINISH) && hx2 && !(phases & RECON_ATP_BWD_EARLY_SUM)) {
             const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));
             const int ntile = static_cast<int>(ceil_div64(W, 32) * ceil_div64(D, 32)) * H;
             hipLaunchKernelGGL(k_atp_weights_finish, dim3(static_cast<unsigned>(ntile + ceil_div64(1LL * H * D, 8))), dim3(256), 0, st, b->partial, sk, W,

@@ -92,3 +92,81 @@ class FlatGradBucket:
                 self._avg_ok = False
         self.flat.div_(w)
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+
+class OverlappedWeightGradSync:
+    """Cross-rank averaging of the attention heads' weight gradients UNDER the backward's edge chain ("launch it as soon as
+    the last layer's grads are ready, overlap with the remaining backward").
+
+    g_a = G + a_2 (x) g_u with G = V^T g_h (the MFMA-bound product, 3.85 MB at cfg 2) and g_u = the score path's gradient (H x (2F+R)
+    floats, known only after the edge chain).  Both enter linearly and a_2 is the same on every rank, so
+        mean_ranks(g_a) = mean(G) + a_2 (x) mean(g_u),      mean_ranks(g_a_2) = a . mean(g_u):
+    the backward (gat_layers._GATHeadsATPFunction, RECON_ATP_BWD_EARLY_SUM) sends G off asynchronously as soon as its split-K sum is
+    done, runs the edge chain while it travels, reduces the few KB of g_u, and finishes on the means.  Gradients come back from autograd
+    already averaged; `reduced` lists them so that a FlatGradBucket packs them without a second collective.
+
+        sync = OverlappedWeightGradSync()
+        with sync.installed():
+            out.backward(G)
+        bucket.pack()                        # p.grad views of the flat buffer, already averaged
+
+    world size 1 / no process group: every call is a no-op and the backward runs its usual single pass."""
+
+    def __init__(self, process_group=None, force_sync=False):
+        self.group = process_group
+        self.force_sync = force_sync          # tests: the same arithmetic with blocking collectives (the serial schedule)
+        self.reduced = []
+        self._avg_ok = True
+
+    def active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def all_reduce_mean(self, t, async_op=False):
+        if not self.active():
+            return None
+        w = dist.get_world_size(self.group)
+        async_op = async_op and not self.force_sync
+        if dist.get_backend(self.group) == "nccl" and self._avg_ok:
+            try:
+                return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+            except (RuntimeError, ValueError):
+                self._avg_ok = False
+        t.div_(w)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def mark_reduced(self, *tensors):
+        self.reduced.extend(t for t in tensors if t is not None)
+
+    def installed(self):
+        """Context manager: routes the heads' backward through this reducer while active (a no-op at world size 1)."""
+        return _Installed(self)
+
+
+class _Installed:
+    def __init__(self, sync):
+        self.sync, self.prev = sync, None
+
+    def __enter__(self):
+        from . import gat_layers
+        self.sync.reduced = []
+        self.prev = gat_layers.set_weight_grad_sync(self.sync if self.sync.active() else None)
+        return self.sync
+
+    def __exit__(self, *exc):
+        from . import gat_layers
+        gat_layers.set_weight_grad_sync(self.prev)
+        return False
+
+
+def overlapped_weight_grad_schedule(run_phase, g_big, g_small, sync):
+    """The schedule of the heads' backward under an OverlappedWeightGradSync, with the compute phases as callables — what
+    gat_layers._GATHeadsATPFunction.backward does with recon_gat_atp_bwd_phase; kept here in this form so that the CPU tests
+    (gloo, world size 2) exercise the collectives' ordering and the linearity argument without a GPU."""
+    run_phase("prepare")
+    run_phase("weights_sum")                       # g_big <- G
+    handle = sync.all_reduce_mean(g_big, async_op=True)
+    run_phase("inputs")                            # g_small <- g_u   (must not touch g_big)
+    sync.all_reduce_mean(g_small, async_op=False)
+    if handle is not None:
+        handle.wait()
+    run_phase("finish")                            # g_big <- g_big + a_2 (x) g_small ; g_a_2 <- a . g_small

@@ -29,6 +29,17 @@ _GAT_PATH = os.environ.get("RECON_GAT_PATH", "auto")
 # edge chain.  Off by default: measured neutral on MI355X (0.927 vs 0.922 ms/step at cfg 2) because the GEMM's
 # 4 waves/SIMD x 128 registers leave no register file for co-resident edge-kernel waves.
 _OVERLAP = os.environ.get("RECON_OVERLAP", "0") == "1"
+# Data parallelism (recon_amd/dist.py::OverlappedWeightGradSync): an object with all_reduce_mean(tensor, async_op) -> handle-or-None.  While one
+# is installed, the backward of the aggregate-then-project heads reduces its weight gradients across ranks ITSELF and returns them already
+# averaged: G = V^T g_h is summed over split-K and sent off before the edge chain (INPUTS) runs, so the big collective travels under it.
+_WEIGHT_GRAD_SYNC = None
+
+
+def set_weight_grad_sync(sync):
+    """Install (or, with None, remove) the cross-rank reducer of the heads' weight gradients; returns the previous one."""
+    global _WEIGHT_GRAD_SYNC
+    prev, _WEIGHT_GRAD_SYNC = _WEIGHT_GRAD_SYNC, sync
+    return prev
 # The layer's three large products run on split-precision MFMA GEMMs (fp32-accurate) when they are large enough to pay for
 # the extra launches (term planes of a, a^T, g_h): measured cross-over on MI355X at cfg-2 widths is 192..256 graphs, i.e.
 # ~6 GFLOP per product for bf16 x 3 (~1 GFLOP for f16 x 2, whose operands arrive pre-split).  RECON_GEMM_BX3 (one switch for GAT and GraphConvolution) =
@@ -359,6 +370,12 @@ def _carve(dev, sizes):
     return buf, [None if o is None else base + o for o in offs]
 
 
+def _view_f32(buf, ptr, n):
+    """float32 [n] tensor over the slice of a _carve() buffer that starts at device pointer `ptr` (slices are 256-byte aligned)."""
+    off = int(ptr) - buf.data_ptr()
+    return buf[off:off + 4 * n].view(torch.float32)
+
+
 _SIZE_CACHE = {}
 
 
@@ -470,8 +487,22 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         args = _lib.GatAtpBwdArgs(fwd, grad_out.data_ptr(), grad_out.shape[1], g_h, g_V, g_sigma, Gxs, gxd, Gs, g_u, q, partial, partial2,
                                   _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2), gh_split)
         graph.reserve_hub_ws(F_, R, H)
+        sync = _WEIGHT_GRAD_SYNC if g_a is not None else None
         with _on_device(dev):
-            if _OVERLAP and g_a is not None:
+            if sync is not None:
+                # PREPARE -> WEIGHTS (+ split-K sum: g_a = G) -> [all-reduce G, asynchronous] || INPUTS -> all-reduce g_u -> FINISH on the means
+                st = _lib.current_stream()
+                gc, ac = C.byref(graph.c), C.byref(args)
+                _lib.check(L.recon_gat_atp_bwd_phase(gc, ac, 1 | 4 | 16, st), "recon_gat_atp_bwd_phase")
+                handle = sync.all_reduce_mean(g_a, async_op=True)
+                _lib.check(L.recon_gat_atp_bwd_phase(gc, ac, 2, st), "recon_gat_atp_bwd_phase")
+                g_u_t = _view_f32(ws2, g_u, H * W)                       # g_u lives inside ws2: hand the reducer a tensor view of it
+                sync.all_reduce_mean(g_u_t, async_op=False)
+                if handle is not None:
+                    handle.wait()
+                _lib.check(L.recon_gat_atp_bwd_phase(gc, ac, 8 | 16, st), "recon_gat_atp_bwd_phase")
+                sync.mark_reduced(g_a, g_a2)
+            elif _OVERLAP and g_a is not None:
                 # PREPARE -> { INPUTS on this stream , WEIGHTS (MFMA-bound GEMM) on a side stream } -> FINISH
                 main = torch.cuda.current_stream()
                 side = _side_stream(dev)

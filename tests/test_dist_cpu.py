@@ -156,3 +156,75 @@ def test_two_rank_empty_shard_does_not_hang():
         np.testing.assert_allclose(ret[r][0], want)
         np.testing.assert_allclose(ret[r][1], want)
         np.testing.assert_array_equal(ret[r][2], np.zeros(2, np.float32))
+
+
+# ------------------------------------------------------------------------------- the weight gradient reduced UNDER the edge chain
+def _overlap_worker(rank, world, port, ret, force_sync):
+    """recon_amd.dist.overlapped_weight_grad_schedule on two ranks, the compute phases played by the oracle's closed-form backward
+    (GAT/layers.py:111-178 differentiated: g_a = G + a_2 (x) g_u with G = (k w gU[dst])^T edge_h, g_u = g_sigma^T edge_h,
+    g_a_2 = g_u a^T): G is all-reduced asynchronously while "inputs" runs, g_u after it, "finish" works on the means."""
+    from recon_amd.dist import OverlappedWeightGradSync, overlapped_weight_grad_schedule
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    B, x, edge, ee, a, a2, G, node_ptr, edge_ptr = _problem()
+    lo, hi = shard_range(B, rank, world)
+    xs, es, ees = take_graph_shard(x, edge, ee, node_ptr, edge_ptr, lo, hi)
+    Gs = G[int(node_ptr[lo]):int(node_ptr[hi])] * float(world)              # loss = sum over ALL graphs; the reducer averages
+    r = O.gat_layer_backward(xs, es, ees, None, None, a, a2, 0.2, True, Gs)
+    edge_h = torch.cat((xs[es[0]], xs[es[1]], ees), dim=1)
+    g_big, g_small, g_a2 = torch.empty_like(a), torch.empty(1, a.shape[1]), torch.empty_like(a2)
+    log = []
+
+    def run_phase(name):
+        log.append(name)
+        if name == "weights_sum":
+            g_big.copy_((r["gm"] - r["g_sigma"][:, None] * a2[0][None, :]).t() @ edge_h)
+        elif name == "inputs":
+            g_small.copy_((r["g_sigma"][None, :] @ edge_h))
+        elif name == "finish":
+            g_big.add_(a2.t() @ g_small)
+            g_a2.copy_(g_small @ a.t())
+    sync = OverlappedWeightGradSync(force_sync=force_sync)
+    assert sync.active()
+    overlapped_weight_grad_schedule(run_phase, g_big, g_small, sync)
+    assert log == ["prepare", "weights_sum", "inputs", "finish"]
+    ret[rank] = (g_big.clone().numpy(), g_a2.clone().numpy(), r["g_a"].numpy(), r["g_a_2"].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_overlap(force_sync):
+    world = 2
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_overlap_worker, args=(world, _free_port(), ret, force_sync), nprocs=world, join=True)
+    return ret
+
+
+def test_overlapped_weight_gradient_schedule_world2():
+    """(i) the overlapped schedule (asynchronous all-reduce of G under "inputs") gives BIT-equal gradients to the same arithmetic with
+    blocking collectives; (ii) both ranks end with the same values; (iii) they equal the mean over ranks of the full local
+    gradients (the plain one-bucket all-reduce) and the single-process gradient of the whole batch."""
+    over, serial = _run_overlap(False), _run_overlap(True)
+    for k in range(2):
+        np.testing.assert_array_equal(over[0][k], over[1][k])
+        np.testing.assert_array_equal(over[0][k], serial[0][k])
+        np.testing.assert_array_equal(over[1][k], serial[1][k])
+    plain_a = (over[0][2] + over[1][2]) / 2                                 # mean of the ranks' complete g_a / g_a_2
+    plain_a2 = (over[0][3] + over[1][3]) / 2
+    np.testing.assert_allclose(over[0][0], plain_a, atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(over[0][1], plain_a2, atol=1e-5, rtol=1e-5)
+    B, x, edge, ee, a, a2, G, _, _ = _problem()
+    full = O.gat_layer_backward(x, edge, ee, None, None, a, a2, 0.2, True, G)
+    np.testing.assert_allclose(over[0][0], full["g_a"].numpy(), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(over[0][1], full["g_a_2"].numpy(), atol=1e-5, rtol=1e-5)
+
+
+def test_weight_grad_sync_is_inert_without_a_process_group():
+    from recon_amd.dist import OverlappedWeightGradSync
+    from recon_amd import gat_layers
+    sync = OverlappedWeightGradSync()
+    assert not sync.active() and sync.all_reduce_mean(torch.ones(3)) is None
+    with sync.installed():
+        assert gat_layers._WEIGHT_GRAD_SYNC is None                        # world size 1: the backward keeps its single pass

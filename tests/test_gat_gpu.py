@@ -954,6 +954,46 @@ def test_phased_backward_on_two_streams_matches(monkeypatch):
 
 
 
+def test_weight_gradient_early_sum_schedule_matches(gemm_family):
+    """RECON_ATP_BWD_EARLY_SUM (the data-parallel backward: G = V^T g_h summed over split-K and handed to the collective BEFORE the
+    edge chain, g_a += a_2 (x) g_u afterwards) against the single-pass backward, with a stand-in reducer that records the order of
+    the calls and leaves the tensors alone (one rank's mean is itself).  Same gradients to fp32 round-off (fmaf vs mul + add in
+    the last kernel), input gradients bit-equal."""
+    from recon_amd import gat_layers
+    from recon_amd.graph import prepare_graph
+    N, E, F_, R, D, H = 2048, 8192, 64, 64, 64, 4
+    g = torch.Generator().manual_seed(5)
+    x, ee = torch.randn(N, F_, generator=g), torch.randn(E, R, generator=g)
+    edge = torch.randint(0, N, (2, E), generator=g)
+    a, a2 = torch.randn(H, D, 2 * F_ + R, generator=g) * 0.1, torch.randn(H, D, generator=g) * 0.1
+    G = torch.randn(N, H * D, generator=g).to(dev())
+    graph = prepare_graph(edge.to(dev()), None, N)
+
+    class Recorder:
+        def __init__(self):
+            self.calls, self.reduced = [], []
+
+        def all_reduce_mean(self, t, async_op=False):
+            self.calls.append((tuple(t.shape), async_op))
+            return None
+
+        def mark_reduced(self, *ts):
+            self.reduced.extend(ts)
+    res = []
+    for sync in (None, Recorder()):
+        prev = gat_layers.set_weight_grad_sync(sync)
+        try:
+            leaves = [t.to(dev()).requires_grad_(True) for t in (x, ee, a, a2)]
+            out = gat_layers.gat_heads(*leaves, graph, None, 0.2, True)
+            res.append([t.detach().clone() for t in torch.autograd.grad(out, leaves, G)])
+        finally:
+            gat_layers.set_weight_grad_sync(prev)
+    assert sync.calls == [((H, D, 2 * F_ + R), True), ((H * (2 * F_ + R),), False)] and len(sync.reduced) == 2
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    close(res[1][2], res[0][2], atol=1e-6, rel_to_max=1e-6, what="g_a, early-sum schedule")
+    close(res[1][3], res[0][3], atol=1e-6, rel_to_max=1e-6, what="g_a_2, early-sum schedule")
+
+
 @pytest.mark.parametrize("xs,es,gs,p", [(1e3, 1e-3, 1e-8, 0.0), (1e-4, 1e2, 1e6, 0.0), (1.0, 1.0, 1.0, 0.9), (30.0, 1e-2, 1e-3, 0.5)])
 def test_wide_dynamic_range_inputs(xs, es, gs, p):
     """The f16 x 2 GEMM family lives on per-tensor power-of-two scales (half has 5 exponent bits): inputs, gradients and
