@@ -223,6 +223,7 @@ def main():
                               "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_alg / t_edge / HBM_PEAK,
                               "traffic": None, "algorithmic_bytes": bytes_alg, "avg_us": t_edge * 1e6,
                               "survey_model_bytes": algorithmic_bytes_fwd(N, E, H, D),
+                              "algorithmic_bytes_is": "the builder's byte model of the restructured kernel (inputs, CSR, V as written, saved scores), not SURVEY 8d's B_G",
                               "note": "algorithmic_bytes = compulsory traffic of this kernel as it runs (without attention dropout the "
                                       "destination part of V is written once, not once per head); survey_model_bytes = SURVEY 8d's "
                                       "B_G for the project-then-aggregate layout this kernel no longer needs"}
@@ -233,11 +234,14 @@ def main():
             result["roofline"]["survey_definition"] = {"bytes": algorithmic_bytes_fwd(N, E, H, D), "time_us": (t_scores + t_edge) * 1e6,
                                                        "frac": algorithmic_bytes_fwd(N, E, H, D) / (t_scores + t_edge) / HBM_PEAK}
         try:            # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot collect PMC itself)
-            pmc_file = "round2_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "round2_pmc_traffic.json")) else "round1_pmc_traffic.json"
+            pmc_file = next(f for f in ("round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json")
+                            if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             if (B, n, e, F_, D, H) == (512, 16, 64, 200, 200, 8) and kname in pmc:
                 result["roofline"]["traffic"] = pmc[kname]["total_bytes"]
-                result["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)" % pmc_file
+                result["roofline"]["traffic_is_from_profiles"] = True
+                result["roofline"]["traffic_source"] = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of this command, collected "
+                                                        "by tools/profile_bench.sh and committed — NOT observed by this run (bench.py cannot collect PMC)") % pmc_file
         except Exception:
             pass
         bx3 = path == "atp" and a_split is not None and aux is None
@@ -256,6 +260,60 @@ def main():
             result["roofline_gemm"] = {"kernel": gname, "bound": "mfma", "achieved": flops_proj / t_proj / 1e12,
                                        "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": flops_proj / t_proj / MFMA_F32_PEAK,
                                        "avg_us": t_proj * 1e6}
+
+        # ---- the same step on the exact-fp32 MFMA GEMMs (RECON_GEMM_BX3=0: v_mfma_f32_32x32x2_f32, no split operands): brackets the
+        # "dtype f32" claim of the main line, whose three large products run fp32 operands as two f16 terms each
+        if world == 1:
+            from recon_amd import gat_layers
+            from recon_amd.graph import clear_graph_cache
+            n_x = max(10, args.steps // 4)
+
+            def timed(fn, k):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                tq = time.perf_counter()
+                for _ in range(k):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - tq) / k * 1e3
+            fam = gat_layers._GEMM_BX3
+            gat_layers._GEMM_BX3 = "0"
+            try:
+                ms_x = timed(step, n_x)
+            finally:
+                gat_layers._GEMM_BX3 = fam
+            result["exact_fp32"] = {"ms_per_step": ms_x, "edges_per_s": E / ms_x * 1e3, "steps": n_x,
+                                    "what": "same step, every GEMM on the exact fp32 matrix-core path (gat_layers._GEMM_BX3 = '0')"}
+            # ---- SURVEY 8d's "uncached" figure: a NEW edge tensor every step (as every iteration of the reference's loops brings one), so
+            # the CSR / CSC build (2 radix sorts, row pointers, hub scan, one host sync) is inside the step
+            fresh = [edged.clone() for _ in range(n_x + 3)]
+            it = iter(fresh)
+
+            def step_uncached():
+                ed = next(it)
+                bucket.zero()
+                xd.grad = None
+                eed.grad = None
+                model.heads_forward(xd, ed, eed, nohop, nohop).backward(Gd)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            for _ in range(n_x):
+                step_uncached()
+            torch.cuda.synchronize()
+            ms_u = (time.perf_counter() - tq) / n_x * 1e3
+            clear_graph_cache()
+            result["uncached"] = {"ms_per_step": ms_u, "edges_per_s": E / ms_u * 1e3, "steps": n_x,
+                                  "what": "same step with the graph preparation (COO -> CSR + CSC, hub tables) rebuilt from a fresh edge tensor every step"}
+            # ---- the other BASELINE.json configurations that fit one GPU (SURVEY 8d's cfg 3a / 3b / 5), priced with 8d's own formulas
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import secondary
+                result["secondary"] = secondary.all_secondary(fast=True)
+            except Exception as exc:                                    # never lose the main line to a secondary workload
+                result["secondary"] = {"error": repr(exc)[:300]}
 
         # ---- CPU baseline: the oracle issuing the reference's own ATen op sequence (sparse_coo_tensor ->
         # sparse.sum -> to_dense), all host cores, same workload, bounded to ~args.cpu_seconds.

@@ -1,0 +1,175 @@
+"""Secondary workloads of BASELINE.json (configs[2] read as SURVEY 8d's cfg 3a / 3b, configs[4] as cfg 5), each timed with HIP events
+and priced with SURVEY 8d's own byte / flop formulas.  bench.py puts these figures into its one JSON line (`secondary`); every
+function returns a dict  {"ms": ..., "bytes" | "flops": ..., "bound": "hbm" | "mfma", "frac": ..., ...}  and frees what it allocated.
+
+Peaks: HBM 8.0 TB/s, fp32 MFMA 157.3 TF/s (/opt/skills/guides/MI355X_MICROARCH.md)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+HBM_PEAK = 8.0e12
+MFMA_F32_PEAK = 157.3e12
+
+
+def _time(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def propagation(n, B=1024, d=8, L=3, iters=10, with_backward=True):
+    """cfg 3b: GP-GNN block form (models/models.py:240-274), 2d = 16, L = 3 untied, per-batch h0 from P4's template, relu.
+    Forward (adjacency prebuilt, inference), forward with the states saved, and block adjacency + propagation forward + backward.
+    Bytes: 4 (L B S^2 + B C S + B C 2d L); flops 2 B S^2 C L."""
+    from recon_amd.propagation import build_block_adjacency, propagate, make_start_embedding, get_head_indices, get_tail_indices
+    dv = torch.device("cuda:0")
+    C, S, dd = n * (n - 1), 2 * d * n, 2 * d
+    g = torch.Generator().manual_seed(0)
+    small = 8                                                        # n = 32: 1 GiB per T: build 8 graphs on the host, repeat on the device
+    reps = B // small if n > 16 else 1
+    Bh = small if n > 16 else B
+    Ts = [(torch.relu(torch.randn(Bh, C, dd * dd, generator=g)) * (0.1 if n <= 16 else 0.02)).to(dv).repeat(reps, 1, 1).requires_grad_(True) for _ in range(L)]
+    ident = torch.eye(dd, device=dv, requires_grad=True)
+    tmpl = torch.from_numpy(make_start_embedding(n, d)).float()
+    h0 = (torch.randn(Bh, C, S, 1, generator=g) * tmpl).to(dv).repeat(reps, 1, 1, 1).requires_grad_(True)
+    head = torch.from_numpy(get_head_indices(n, d, bs=1)[0]).to(dv)
+    tail = torch.from_numpy(get_tail_indices(n, d, bs=1)[0]).to(dv)
+    G = torch.randn(B, C, dd * L, generator=g).to(dv) if n <= 16 else torch.randn(Bh, C, dd * L, generator=g).to(dv).repeat(reps, 1, 1)
+    with torch.no_grad():
+        adjs = [build_block_adjacency(t, ident, n) for t in Ts]
+
+    def fwd():
+        with torch.no_grad():
+            propagate(adjs, h0.detach(), "relu", head, tail)
+
+    def fwd_bwd():
+        for t in Ts + [ident, h0]:
+            t.grad = None
+        a2 = [build_block_adjacency(t, ident, n) for t in Ts]
+        propagate(a2, h0, "relu", head, tail).backward(G)
+    nbytes = 4.0 * (L * B * S * S + B * C * S + B * C * dd * L)
+    flops = 2.0 * B * S * S * C * L
+    tf = _time(fwd, iters)
+    res = {"B": B, "n": n, "S": S, "C": C, "L": L, "fwd_ms": tf * 1e3, "bytes": nbytes, "flops": flops,
+           "GBps": nbytes / tf / 1e9, "TFLOPs": flops / tf / 1e12}
+    if n <= 16:      # S <= 160: two-term f16 kernel, 11 us of matrix work against one 39 us pass over the adjacency stack: HBM binds
+        res.update(bound="hbm", frac=nbytes / tf / HBM_PEAK, kernel="k_propagate_fwd_h")
+    else:            # S = 512 does not fit that kernel: fp32 MFMA form, priced against the fp32 matrix peak
+        res.update(bound="mfma", frac=flops / tf / MFMA_F32_PEAK, kernel="k_propagate_fwd")
+    if with_backward:
+        tb = _time(fwd_bwd, max(2, iters // 2))
+        res["fwd_bwd_incl_adjacency_ms"] = tb * 1e3
+    del Ts, adjs, h0, G
+    torch.cuda.empty_cache()
+    return res
+
+
+def gcn_bf16(B=1024, n=32, D=300, hops=3, iters=10):
+    """cfg 3a: GraphConvolution x 3 (models/layers.py:57-63) in bf16 storage / fp32 accumulation.  Bytes (unfused, s = 2):
+    per hop 2 B n D s + B n^2 s + D^2 s; flops per hop 2 B n D (D + n)."""
+    from recon_amd.gcn_layers import GraphConvolution
+    dv = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    dt = torch.bfloat16
+    x = torch.randn(B, n, D, generator=g).to(dt).to(dv).requires_grad_(True)
+    adj = (torch.rand(B, n, n, generator=g) < 0.15).float() + torch.eye(n)
+    adj = (adj / adj.sum(-1, keepdim=True)).to(dt).to(dv)
+    torch.manual_seed(0)
+    layers = [GraphConvolution(D, D).to(dt).to(dv) for _ in range(hops)]
+    G = torch.randn(B, n, D, generator=g).to(dt).to(dv)
+
+    def fwd():
+        with torch.no_grad():
+            h = x
+            for l in layers:
+                h = l(h, adj)
+
+    def fwd_bwd():
+        for l in layers:
+            l.weight.grad = None
+            l.bias.grad = None
+        x.grad = None
+        h = x
+        for l in layers:
+            h = l(h, adj)
+        h.backward(G)
+    s = 2.0
+    nbytes = hops * (2 * B * n * D * s + B * n * n * s + D * D * s)
+    flops = hops * 2.0 * B * n * D * (D + n)
+    tf, tb = _time(fwd, iters), _time(fwd_bwd, max(2, iters // 2))
+    return {"B": B, "n": n, "D": D, "hops": hops, "dtype": "bf16", "fwd_ms": tf * 1e3, "fwd_bwd_ms": tb * 1e3, "bytes": nbytes, "flops": flops,
+            "bound": "hbm", "frac": nbytes / tf / HBM_PEAK, "GBps": nbytes / tf / 1e9, "TFLOPs": flops / tf / 1e12,
+            "dense_edges_per_s_fwd": B * n * n * hops / tf}
+
+
+def powerlaw_spgat(B=64, D=25, F_=200, H=8, nrel=64, iters=10):
+    """cfg 5-like: power-law destination degrees (n ~ U{16..256}, e = min(4096, 16 n), dst ~ Zipf(1)), full SpGAT (H heads + out_att),
+    fp32, relation table read in place.  Bytes: SURVEY 8d's B_G for the two attention layers' forward edge stages
+    (4 HD (E + 3 N) + 4 (E + N + 1) + 4 HD with HD = H D for the heads and for out_att)."""
+    from recon_amd.models import SpGAT
+    dv = torch.device("cuda:0")
+    rs = np.random.RandomState(0)
+    dsts, srcs, base = [], [], 0
+    for _ in range(B):
+        n = int(rs.randint(16, 257))
+        e = min(4096, 16 * n)
+        p = 1.0 / np.arange(1, n + 1)
+        p /= p.sum()
+        dsts.append(rs.choice(n, size=e, p=p) + base)
+        srcs.append(rs.randint(0, n, size=e) + base)
+        base += n
+    edge = torch.from_numpy(np.stack([np.concatenate(dsts), np.concatenate(srcs)])).long().to(dv)
+    N, E = base, edge.shape[1]
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, F_, generator=g).to(dv).requires_grad_(True)
+    rel = torch.randn(nrel, F_, generator=g).to(dv).requires_grad_(True)
+    et = torch.randint(0, nrel, (E,), generator=g).to(dv)
+    torch.manual_seed(0)
+    m = SpGAT(N, F_, D, F_, 0.0, 0.2, H).to(dv)
+    G = torch.randn(N, H * D, generator=g).to(dv)
+    nohop = torch.tensor([])
+
+    def fwd():
+        with torch.no_grad():
+            m(None, x, rel, edge, et, None, nohop, nohop)
+
+    def fwd_bwd():
+        for q in m.parameters():
+            q.grad = None
+        x.grad = None
+        rel.grad = None
+        out, _ = m(None, x, rel, edge, et, None, nohop, nohop)
+        out.backward(G)
+    HD = H * D
+    b_g = 2 * (4.0 * HD * (E + 3 * N) + 4.0 * (E + N + 1) + 4.0 * HD)
+    tf, tb = _time(fwd, iters), _time(fwd_bwd, max(2, iters // 2))
+    deg = torch.bincount(edge[0], minlength=N)
+    return {"graphs": B, "N": N, "E": E, "max_in_degree": int(deg.max()), "D_per_head": D, "heads": H, "fwd_ms": tf * 1e3, "fwd_bwd_ms": tb * 1e3,
+            "edges_per_s_fwd_bwd": E / tb, "bytes": b_g, "bound": "hbm", "frac": b_g / tf / HBM_PEAK,
+            "note": "frac prices SURVEY 8d's B_G of both layers against the WHOLE forward (GEMMs, row sums, hub combines included)"}
+
+
+def all_secondary(fast=True):
+    it = 6 if fast else 20
+    return {"cfg3b_n9_propagation": propagation(9, iters=it),
+            "cfg3b_n32_propagation": propagation(32, iters=2, with_backward=False),
+            "cfg3a_gcn_bf16": gcn_bf16(iters=it),
+            "cfg5_powerlaw_spgat": powerlaw_spgat(iters=it)}
+
+
+if __name__ == "__main__":
+    import json
+    torch.autograd.set_multithreading_enabled(False)
+    for k, v in all_secondary(fast="--long" not in sys.argv).items():
+        print(json.dumps({k: v}))
