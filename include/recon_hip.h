@@ -307,9 +307,17 @@ typedef struct {
     int64_t idx_batch_stride;
     float* out;                     /* [B,C,L*dd]                                                         */
     float* h_saved;                 /* [L,B,C,S] states after each hop (for the backward) or NULL         */
+    float* stats;                   /* [B, 2L+1] or NULL: per graph the max magnitudes of h^0..h^L and of   *
+                                     * A_1..A_L.  Written by the forward when h_saved is given and          *
+                                     * recon_propagate_form() == 1 (the two-term f16 kernels, whose         *
+                                     * per-tensor scales in the backward come from these); the backward     *
+                                     * runs its two-term form only when given the same buffer              */
 } recon_prop_args;
 
 int recon_propagate_fwd(const recon_prop_args* args, recon_stream_t stream);
+/* 1: this problem runs on the two-term f16 matrix-core kernels (csrc/prop_h.hip: S % 16 == 0, S <= 160, C <= 96, aligned pointers,
+ * RECON_PROP_FWD unset or "h"); 0: on the fp32 matrix-core forms.  The adjacency pointers need not be set for this query. */
+int recon_propagate_form(const recon_prop_args* args);
 
 typedef struct {
     recon_prop_args fwd;            /* h_saved filled by the forward call                                 */

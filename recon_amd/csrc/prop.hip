@@ -932,6 +932,7 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
     p.out = a->out; p.hsave = a->h_saved;
     p.B = a->B; p.C = a->C; p.S = a->S; p.L = a->L; p.dd = a->dd; p.act = a->act;
     p.CC = g.CC; p.Sp = g.Sp; p.pitch = g.pitch;
+    p.stats = a->h_saved ? a->stats : nullptr;
     hipStream_t st = as_stream(stream);
     const int NTn = g.Sp / 16;
     const int mtn_s = (a->C + 15) / 16;
@@ -993,6 +994,22 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
     return RECON_OK;
 }
 
+static bool prop_h_form_env() {
+    const char* form = getenv("RECON_PROP_FWD");
+    return !form || form[0] == 'h' || form[0] == '\0';
+}
+
+extern "C" int recon_propagate_form(const recon_prop_args* a) {
+    if (!a || a->B < 0 || a->C <= 0 || a->S <= 0 || a->L <= 0 || a->L > kMaxHops || a->dd <= 0 || !a->h0) return 0;
+    PropGeom g;
+    if (!prop_geometry(a->C, a->S, &g)) return 0;
+    PropK p{};
+    for (int l = 0; l < kMaxHops; ++l) p.adj[l] = nullptr;              // the adjacency pointers' alignment is checked at the call
+    p.h0 = a->h0; p.h0_bs = a->h0_batch_stride; p.hsave = nullptr;
+    p.B = a->B; p.C = a->C; p.S = a->S; p.L = 0; p.dd = a->dd; p.pitch = g.pitch;
+    return (prop_h_form_env() && prop_fwd_h_supported(p)) ? 1 : 0;
+}
+
 extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t stream) {
     if (!ba) return RECON_ERR_INVALID;
     const recon_prop_args* a = &ba->fwd;
@@ -1000,6 +1017,14 @@ extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t
     if (rc != RECON_OK) return rc;
     if (!a->h_saved || !ba->grad_out || !ba->g_h) return RECON_ERR_INVALID;
     if (a->B == 0) return RECON_OK;
+    if (a->stats && prop_h_form_env() && !(getenv("RECON_PROP_BWD") && getenv("RECON_PROP_BWD")[0] == 'f')) {      // two-term f16 form (RECON_PROP_BWD=f: fp32 MFMA form)
+        PropBwdH q{};
+        for (int l = 0; l < kMaxHops; ++l) { q.adj[l] = l < a->L ? a->adj[l] : nullptr; q.gadj[l] = (l < a->L && ba->g_adj) ? ba->g_adj[l] : nullptr; }
+        q.h0 = a->h0; q.h0_bs = a->h0_batch_stride; q.hsave = a->h_saved; q.head = a->head_idx; q.tail = a->tail_idx; q.idx_bs = a->idx_batch_stride;
+        q.gout = ba->grad_out; q.gH = ba->g_h; q.stats = a->stats;
+        q.B = a->B; q.C = a->C; q.S = a->S; q.L = a->L; q.dd = a->dd; q.act = a->act;
+        if (prop_bwd_h_supported(q)) return prop_bwd_h(q, as_stream(stream));
+    }
     PropGeom g;
     if (!prop_geometry(a->C, a->S, &g)) return RECON_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);

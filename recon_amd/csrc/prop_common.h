@@ -12,6 +12,20 @@ struct PropK {
     const int64_t* head; const int64_t* tail; int64_t idx_bs;
     float* out; float* hsave;
     int32_t B, C, S, L, dd, act, CC, Sp, pitch;
+    float* stats;             // [B][2L+1] max magnitudes of h^0..h^L, A_1..A_L per graph (two-term forms, with hsave) or null
+};
+
+// backward of the two-term form (prop_h.hip): all L hops of a graph in one persistent workgroup
+struct PropBwdH {
+    const float* adj[kMaxHops];
+    float* gadj[kMaxHops];    // [B,S,S] per hop or null
+    const float* h0; int64_t h0_bs;
+    const float* hsave;       // [L][B][C][S]
+    const int64_t* head; const int64_t* tail; int64_t idx_bs;
+    const float* gout;        // [B][C][L*dd]
+    float* gH;                // [B][C][S] out: gradient wrt h^0 per batch element
+    const float* stats;       // [B][2L+1] from the forward
+    int32_t B, C, S, L, dd, act;
 };
 
 struct PropBwdK {
@@ -42,5 +56,7 @@ __device__ __forceinline__ float act_bwd(float y, int act) {
 // does not take (the caller then runs a fp32-MFMA form of prop.hip)
 bool prop_fwd_h_supported(const PropK& p);
 int prop_fwd_h(const PropK& p, hipStream_t st);
+bool prop_bwd_h_supported(const PropBwdH& p);
+int prop_bwd_h(const PropBwdH& p, hipStream_t st);
 
 }  // namespace recon

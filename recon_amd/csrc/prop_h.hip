@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = nthreads >> 6;
     float* atab = isg + CH + 16 * wave;           // this wave's 16 inverse row scales
+    uint32_t* gstat = reinterpret_cast<uint32_t*>(isg + CH + 16 * NW);      // [2 kMaxHops + 1] max magnitudes of this graph (for the backward)
     const int li = lane & 15, lq = lane >> 4;
     const uint32_t SSb = static_cast<uint32_t>(S) * S * 4;                      // bytes of one A_l of one graph
     // A fragments: k slots 0..3 = t 32 ks + 4 lq .., slots 4..7 = t 32 ks + 16 + 4 lq ..  One buffer descriptor per (graph, hop), one
@@ -172,6 +173,7 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
         // ---- h^0: wave w stages channels w, w + NW, ... (a whole channel per wave: its max magnitude is a wave reduction); columns past S
         // and channels past C come back as zeros (out-of-range offsets).  (Requesting the next graph's h^0 during the last hop was
         // measured: 89 -> 95 us — it competes with the adjacency prefetch for the CU's ~12 B/clk share of HBM.)
+        float mh0 = 0.f;                                                           // max |h^0| over this wave's channels
         {
             u32x4 hv[NCW];
             load_h0(hv, b);
@@ -181,11 +183,14 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
 #pragma unroll
                 for (int k = 0; k < (2 * CH + 63) / 64; ++k)
                     if (lane + 64 * k < 2 * CH) chmax[lane + 64 * k] = 0u;
+                if (lane < 2 * kMaxHops + 1) gstat[lane] = 0u;
             }
             float mx[NCW];
 #pragma unroll
             for (int i = 0; i < NCW; ++i)                                           // NCW independent reduction chains
                 mx[i] = wave_max(fmaxf(fmaxf(fabsf(as_f(hv[i].x)), fabsf(as_f(hv[i].y))), fmaxf(fabsf(as_f(hv[i].z)), fabsf(as_f(hv[i].w)))));
+#pragma unroll
+            for (int i = 0; i < NCW; ++i) mh0 = fmaxf(mh0, mx[i]);
 #pragma unroll
             for (int i = 0; i < NCW; ++i) {
                 const int c = wave + i * NW;                                        // wave-uniform
@@ -217,6 +222,7 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
         STAMP(1);
         lds_barrier();
         STAMP(2);
+        if (p.stats && lane == 0) atomicMax(gstat, __builtin_bit_cast(uint32_t, mh0));       // gstat was cleared before the barrier
         float inv_sig[NTC];
 #pragma unroll
         for (int j = 0; j < NTC; ++j) inv_sig[j] = isg[16 * j + li];
@@ -236,6 +242,11 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
                     m = fmaxf(fmaxf(fabsf(as_f(q.z)), fabsf(as_f(q.w))), m);
                 }
             m = rows_max(m);                                                        // lanes li, li + 16, li + 32, li + 48 hold one row
+            if (p.stats) {                                                          // max |A_l| of the graph, for the backward's scale
+                float mw = dpp_max<0xB1>(m);
+                mw = dpp_max<0x4E>(mw); mw = dpp_max<0x141>(mw); mw = dpp_max<0x140>(mw);
+                if (lane == 0) atomicMax(gstat + p.L + 1 + l, __builtin_bit_cast(uint32_t, mw));
+            }
             const float alpha = hx2_scale_of(m);
             if (lq == 0) atab[li] = hx2_inv(alpha);
             f16x8 a_hi[NKS], a_lo[NKS];
@@ -329,6 +340,13 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
 #pragma unroll
                 for (int k = 0; k < (CH + 63) / 64; ++k)
                     if (lane + 64 * k < CH) chmax[((l + 1) & 1) * CH + lane + 64 * k] = 0u;
+                if (p.stats) {                                                      // max |H^l| of the graph
+                    float mh = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NTC; ++j) mh = fmaxf(mh, __builtin_bit_cast(float, cm[16 * j + li]) * (homog ? inv_sig[j] : 1.f));
+                    mh = dpp_max<0xB1>(mh); mh = dpp_max<0x4E>(mh); mh = dpp_max<0x141>(mh); mh = dpp_max<0x140>(mh);
+                    if (lane == 0) gstat[l + 1] = __builtin_bit_cast(uint32_t, mh);
+                }
             }
 #pragma unroll
             for (int j = 0; j < NTC; ++j) {
@@ -386,12 +404,340 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
         }
         hop_i = 6; STAMP(0);
         lds_barrier();                                                              // the gathers are done before the next graph's h^0 lands
+        if (p.stats && tid < 2 * p.L + 1) p.stats[static_cast<int64_t>(b) * (2 * p.L + 1) + tid] = __builtin_bit_cast(float, gstat[tid]);
+    }
+}
+
+// ================================================================================================ backward, two-term f16 form
+// All L hops of a graph in one persistent workgroup (one per CU, graphs b = blockIdx.x, + gridDim.x, ...); wave w owns the 16 columns
+// t = 16 w .. 16 w + 15 of both products of a hop (M = t):
+//   (c)  gA_l^T [t][s]     = sum_c  H^l-1[c][t] . Y_l[c][s]          (K = channels)   -> g_adj, 16-byte stores
+//   (d)  gH^l-1^T [t][c]   = sum_s  A_l[s][t]   . Y_l[c][s]          (K = s)          -> next hop's Y after (+ relation gradient) . act'
+// with Y_l = d loss / d (pre-activation of hop l), [C][S], resident in LDS as two half planes under ONE power-of-two scale per graph and
+// hop (the contraction runs over channels in (c) and over columns in (d): only a scalar scale commutes with both).  The other
+// operands stream through a ring of two LDS slabs of 32 rows (A_l: 32 rows s; H^l-1: 32 channels), fp32 -> two half terms on the way in,
+// under per-graph scales known from the forward (`stats`: max |A_l|, max |H^l|); their fragments — 8 consecutive k for one t, where k is
+// the slab's ROW index — come out through the transposing read ds_read_b64_tr_b16, as do Y's in (c).  The relation gradient
+// (d out / d h[head], h[tail]) is scattered into an fp32 image R one hop ahead, with LDS float atomics (indices are arbitrary).
+// One workgroup barrier per slab step and one for the max magnitude of the new Y.
+template <int NKS, int NTC>
+__global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    constexpr int CH = NTC * 16;
+    constexpr int NKC = (CH + 31) / 32;           // K steps of (c)
+    constexpr int YCH = NKC * 32;                 // channel rows of the Y image: rows CH .. YCH stay zero ((c) contracts over them)
+    constexpr int STEP = YCH * 64;                // bytes of one K step (32 columns) of one plane of Y
+    constexpr int PLANE = NKS * STEP;
+    const int S = p.S, C = p.C, L = p.L;
+    const int RS = 2 * S + 16;                    // slab row: S halves + 16 bytes (rows 8 apart land on different banks)
+    const int SLAB = 32 * RS;                     // one plane of one slab
+    const int pitch = S + 4;                      // fp32 image of the relation gradient
+    unsigned char* Ys = sm;                                          // [2][PLANE]
+    unsigned char* ring = sm + 2 * PLANE;                            // [2 slots][2 planes][SLAB]
+    unsigned char* Rb = ring + 4 * SLAB;                             // fp32 [CH][pitch]
+    uint32_t* ymax = reinterpret_cast<uint32_t*>(Rb + CH * pitch * 4);      // [2]
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = nthreads >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const uint32_t SSb = static_cast<uint32_t>(S) * S * 4;
+    const int nstat = 2 * L + 1;
+
+    // ---- slab staging: 32 rows x S floats = 8 S float4 = two per thread (nthreads = 4 S); unit u = tid + i nthreads -> (row, 4 columns)
+    const int nf4 = S >> 2;
+    int s_row[2], s_off[2];
+    uint32_t s_goff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = tid + i * nthreads;
+        const int r = u / nf4, c4 = u - r * nf4;
+        s_row[i] = r;
+        s_off[i] = r * RS + 8 * c4;
+        s_goff[i] = static_cast<uint32_t>(r * S + 4 * c4) * 4u;
+    }
+    // source of slab step (hop l, kind, k): kind 0 = channels 32 k .. of H^l-1 (product (c)), kind 1 = rows 32 k .. of A_l (product (d))
+    auto slab_rsrc = [&](int bb, int l, int kind, int k, int& rows) {
+        if (kind == 0) {
+            const float* P = l >= 2 ? p.hsave + ((static_cast<int64_t>(l) - 2) * p.B + bb) * C * S : p.h0 + bb * p.h0_bs;
+            rows = min(32, C - 32 * k);
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P + static_cast<int64_t>(32 * k) * S), 0, max(rows, 0) * S * 4, 0x00020000);
+        }
+        rows = min(32, S - 32 * k);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.adj[l - 1]) + static_cast<int64_t>(bb) * SSb + static_cast<int64_t>(32 * k) * S * 4),
+                                                 0, rows * S * 4, 0x00020000);
+    };
+    // the flat sequence of slab steps of one graph: hops l = L .. 1, per hop NKC steps of kind 0 (only when g_adj[l-1] is wanted) then NKS of kind 1
+    struct Step { int bb, l, kind, k; };
+    auto next_step = [&](Step st) {
+        ++st.k;
+        if (st.kind == 0 && st.k == NKC) { st.kind = 1; st.k = 0; }
+        else if (st.kind == 1 && st.k == NKS) {
+            st.k = 0; --st.l;
+            if (st.l == 0) { st.l = L; st.bb += static_cast<int>(gridDim.x); }
+            st.kind = p.gadj[st.l - 1] ? 0 : 1;
+        }
+        return st;
+    };
+    auto load_slab = [&](u32x4 (&dst)[2], Step st) {
+        if (st.bb >= p.B) { dst[0] = u32x4{0u, 0u, 0u, 0u}; dst[1] = dst[0]; return; }
+        int rows;
+        const auto rs = slab_rsrc(st.bb, st.l, st.kind, st.k, rows);              // rows past the source come back as zeros (out of range)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, s_goff[i], 0, 0);
+    };
+    auto store_slab = [&](const u32x4 (&src)[2], int slot, float scale) {
+        unsigned char* d = ring + slot * 2 * SLAB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            uint32_t h0, l0, h1, l1;
+            hx2_split2(as_f(src[i].x) * scale, as_f(src[i].y) * scale, h0, l0);
+            hx2_split2(as_f(src[i].z) * scale, as_f(src[i].w) * scale, h1, l1);
+            *reinterpret_cast<uint2*>(d + s_off[i]) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(d + SLAB + s_off[i]) = make_uint2(l0, l1);
+        }
+    };
+    // ---- fragment addresses.  Transposing read: the 16 lanes of group lq address a 4 (k) x 16 (m) block of halves, lane ip at row ip >> 2,
+    // columns 4 (ip & 3) ..; lane ip receives column ip of the four rows.  Two reads (k rows 8 lq .. + 3 and + 4 .. + 7) make a fragment.
+    const int tr_slab = (8 * lq + (li >> 2)) * RS + (16 * wave + 4 * (li & 3)) * 2;        // + 4 RS for the second read; + slot, plane
+    auto tr_frag = [](const unsigned char* lo_p, const unsigned char* hi_p) {
+        typedef short i16x4 __attribute__((ext_vector_type(4)));
+        const i16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(lo_p));
+        const i16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(hi_p));
+        return __builtin_bit_cast(f16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    // Y image (the forward's state image with NATURAL column order inside a K step): element (c, s) of plane q at
+    //   q PLANE + (s >> 5) STEP + 64 c + 16 (((s >> 3) & 3) ^ ((c >> 1) & 3)) + 2 (s & 7)
+    // (c): Y^T fragment of column tile n, K step kc — rows (k) = channels c0 = 32 kc + 8 lq + (li >> 2) (+ 4 for the second read), columns
+    // (m) = s0 = 16 n + 4 (li & 3) ..: with (s0 >> 3) & 3 = 2 (n & 1) | ((li & 3) >> 1) and (c0 >> 1) & 3 = (li >> 3) & 1 (| 2 for the second read)
+    // the address separates into a per-lane base and constants of (n, kc):
+    //   first read : yc_lane + 2048 kc + (n >> 1) STEP + 32 (n & 1);   second: the same + 256 with the 32 (n & 1) term flipped
+    const int yc_lane = 64 * (8 * lq + (li >> 2)) + (((((li & 3) >> 1) ^ ((li >> 3) & 1))) << 4) + 8 * (li & 1);
+    const int swz = ((li >> 1) & 3) << 4;
+    const int yb_rd = li * 64 + ((lq << 4) ^ swz);                     // (d): B fragment of channel 16 j + li, columns 32 ks + 8 lq ..: + 1024 j + STEP ks
+    const int t0w = 16 * wave + 4 * lq;                                 // C layout of (d): channel 16 j + li, columns t0w .. + 3
+    const int yw = (t0w >> 5) * STEP + 64 * li + (((((t0w >> 3) & 3) << 4)) ^ swz) + 2 * (t0w & 7);       // + 1024 j
+    const int rw = (li * pitch + t0w) * 4;                              // R image: + 64 j pitch
+    const int nitems = C * p.dd, Ldd = L * p.dd;
+    const float* statp = p.stats;
+
+    // ---- zero state of the workgroup: R, the maxima, and the Y image (its columns S .. 32 NKS are never written and meet zero rows of A)
+    for (int i = tid; i < CH * pitch; i += nthreads) reinterpret_cast<float*>(Rb)[i] = 0.f;
+    for (int i = tid; i < 2 * PLANE / 16; i += nthreads) reinterpret_cast<uint4*>(Ys)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 2) ymax[tid] = 0u;
+    // ---- slab pipeline.  Step n consumes slab n from ring slot n & 1.  At the start of step n: slot n & 1 holds slab n (written during step
+    // n - 1), register set (n + 1) & 1 holds slab n + 1 and set n & 1 slab n + 2 (both in flight).  Step n: barrier; set (n + 1) & 1 -> slot
+    // (n + 1) & 1; request slab n + 3 into that set; products of slab n.
+    u32x4 stg[2][2];
+    Step nxt{static_cast<int>(blockIdx.x), L, p.gadj[L - 1] ? 0 : 1, 0};      // descriptor of slab n + 1 (kept one ahead of the step counter)
+    Step pre = nxt;                                                     // descriptor of the next slab to request
+    auto scale_of_step = [&](Step st) {
+        if (st.bb >= p.B) return 1.f;
+        const float* sb = statp + static_cast<int64_t>(st.bb) * nstat;
+        return hx2_scale_of(st.kind == 0 ? sb[st.l - 1] : sb[L + st.l]);
+    };
+    load_slab(stg[0], pre); pre = next_step(pre);                       // slab 0
+    load_slab(stg[1], pre); pre = next_step(pre);                       // slab 1
+    store_slab(stg[0], 0, scale_of_step(nxt));                          // slab 0 -> slot 0
+    load_slab(stg[0], pre); pre = next_step(pre);                       // slab 2
+    nxt = next_step(nxt);
+    int stepno = 0;
+    auto step_in = [&]() {
+        lds_barrier();                                                  // slab `stepno` (and a freshly written Y image) visible; the other slot is free
+        const int q = (stepno + 1) & 1;
+        store_slab(stg[q], q, scale_of_step(nxt));
+        load_slab(stg[q], pre);
+        pre = next_step(pre);
+        nxt = next_step(nxt);
+    };
+
+#pragma unroll 1
+    for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+        const float* st_b = statp + static_cast<int64_t>(b) * nstat;
+        // relation-gradient items of this thread (the same positions in every hop)
+        uint32_t it_h[kGatherRegs], it_t[kGatherRegs], it_c[kGatherRegs], it_x[kGatherRegs];
+        {
+            const int64_t* hd = p.head + b * p.idx_bs;
+            const int64_t* tl = p.tail + b * p.idx_bs;
+#pragma unroll
+            for (int i = 0; i < kGatherRegs; ++i) {
+                const uint32_t idx = min(tid + i * nthreads, nitems - 1);
+                const uint32_t c = idx / static_cast<uint32_t>(p.dd);
+                it_c[i] = c; it_x[i] = idx - c * p.dd;
+                it_h[i] = static_cast<uint32_t>(hd[idx]); it_t[i] = static_cast<uint32_t>(tl[idx]);
+            }
+        }
+        // d out_l / d h^l into R: R[c][head] += g X[c][tail], R[c][tail] += g X[c][head]   (X = h^l, g = grad_out[b, c, (l-1) dd + x]);
+        // the loads are issued by scatter_load and committed (LDS float atomics) later, so that their latency is not waited for
+        float sc_g[kGatherRegs], sc_h[kGatherRegs], sc_t[kGatherRegs];
+        auto scatter_load = [&](int l) {
+            const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.hsave + ((static_cast<int64_t>(l) - 1) * p.B + b) * C * S), 0, C * S * 4, 0x00020000);
+            const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gout + static_cast<int64_t>(b) * C * Ldd), 0, C * Ldd * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < kGatherRegs; ++i) {
+                sc_g[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, 4u * (it_c[i] * Ldd + (l - 1) * p.dd + it_x[i]), 0, 0));
+                sc_h[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, 4u * (it_c[i] * S + it_h[i]), 0, 0));
+                sc_t[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, 4u * (it_c[i] * S + it_t[i]), 0, 0));
+            }
+        };
+        auto scatter_commit = [&](int l) {
+            float* R = reinterpret_cast<float*>(Rb);
+#pragma unroll
+            for (int i = 0; i < kGatherRegs; ++i)
+                if (tid + i * nthreads < nitems) {
+                    atomicAdd(R + it_c[i] * pitch + it_h[i], sc_g[i] * sc_t[i]);
+                    atomicAdd(R + it_c[i] * pitch + it_t[i], sc_g[i] * sc_h[i]);
+                }
+            if (nitems > kGatherRegs * nthreads) {
+                const float* X = p.hsave + ((static_cast<int64_t>(l) - 1) * p.B + b) * C * S;
+                const float* go = p.gout + static_cast<int64_t>(b) * C * Ldd + (l - 1) * p.dd;
+                for (int idx = tid + kGatherRegs * nthreads; idx < nitems; idx += nthreads) {
+                    const int c = idx / p.dd, x = idx - c * p.dd;
+                    const int64_t io = b * p.idx_bs + idx;
+                    const int hi = static_cast<int>(p.head[io]), ti = static_cast<int>(p.tail[io]);
+                    const float g = go[c * Ldd + x];
+                    atomicAdd(R + c * pitch + hi, g * X[c * S + ti]);
+                    atomicAdd(R + c * pitch + ti, g * X[c * S + hi]);
+                }
+            }
+        };
+        // h^lx at this lane's positions of the C layout (for act'): requested early, used by make_y
+        u32x4 xq[NTC];
+        auto x_load = [&](int lx) {
+            const float* X = p.hsave + ((static_cast<int64_t>(lx) - 1) * p.B + b) * C * S;
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, C * S * 4, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < NTC; ++j)
+                xq[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, static_cast<uint32_t>((16 * j + li) * S + t0w) * 4u, 0, 0);      // channels past C: zeros
+        };
+        // new Y = (acc / unit + R) . act'(X) from (d)'s result (zero for the first Y of a graph); writes the image under its own scale,
+        // leaves R zeroed, returns 1 / scale
+        auto make_y = [&](f32x4 (&acc)[NTC], float inv_unit, int par) {
+            float mm = 0.f;
+#pragma unroll
+            for (int j = 0; j < NTC; ++j) {
+                const float4 r = *reinterpret_cast<const float4*>(Rb + rw + 64 * j * pitch);
+                *reinterpret_cast<float4*>(Rb + rw + 64 * j * pitch) = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float xv[4] = {as_f(xq[j].x), as_f(xq[j].y), as_f(xq[j].z), as_f(xq[j].w)};
+                const float rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = fmaf(acc[j][q], inv_unit, rv[q]);
+                    const float dact = p.act == RECON_ACT_RELU ? (xv[q] > 0.f ? 1.f : 0.f) : (p.act == RECON_ACT_TANH ? 1.f - xv[q] * xv[q] : 1.f);
+                    acc[j][q] = (16 * j + li < C) ? v * dact : 0.f;
+                    mm = fmaxf(mm, fabsf(acc[j][q]));
+                }
+            }
+            mm = wave_max(mm);
+            if (lane == 0) atomicMax(ymax + par, __builtin_bit_cast(uint32_t, mm));
+            lds_barrier();                                              // every wave is through with the old image; the maximum is complete
+            const float sg = hx2_scale_of(__builtin_bit_cast(float, ymax[par]));
+            if (tid == 0) ymax[par ^ 1] = 0u;
+#pragma unroll
+            for (int j = 0; j < NTC; ++j) {
+                uint32_t h0, l0, h1, l1;
+                hx2_split2(acc[j][0] * sg, acc[j][1] * sg, h0, l0);
+                hx2_split2(acc[j][2] * sg, acc[j][3] * sg, h1, l1);
+                *reinterpret_cast<uint2*>(Ys + yw + 1024 * j) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(Ys + PLANE + yw + 1024 * j) = make_uint2(l0, l1);
+            }
+            return hx2_inv(sg);                                         // the next slab step's barrier publishes the image
+        };
+
+        int par = 0;
+        scatter_load(L);
+        x_load(L);
+        lds_barrier();                                                  // R zeroed (kernel start / previous graph's last make_y) before anyone adds to it
+        scatter_commit(L);
+        lds_barrier();
+        f32x4 accd[NTC];
+#pragma unroll
+        for (int j = 0; j < NTC; ++j) accd[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float inv_sy = make_y(accd, 0.f, par);
+        par ^= 1;
+
+#pragma unroll 1
+        for (int l = L; l >= 1; --l) {
+            const float sA = hx2_scale_of(st_b[L + l]), sP = hx2_scale_of(st_b[l - 1]);
+            const bool want_gA = p.gadj[l - 1] != nullptr;
+            if (l > 1) scatter_load(l - 1);                             // for the next Y
+            bool committed = l == 1;
+            // ---------------- (c): g_adj[l-1]^T tile  [t in wave's tile][all s] = sum_c P^T[t][c] Y^T[s][c]
+            if (want_gA) {
+                constexpr int NTS = NKS * 2;                            // column tiles of s (S = 16 NW <= 16 NTS)
+                f32x4 accc[NTS];
+#pragma unroll
+                for (int n = 0; n < NTS; ++n) accc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                for (int kc = 0; kc < NKC; ++kc) {
+                    step_in();
+                    if (!committed) { scatter_commit(l - 1); committed = true; }      // after a barrier that follows the zeroing of R, before the ones in front of make_y
+                    const unsigned char* sl = ring + (stepno & 1) * 2 * SLAB;
+                    const f16x8 a_hi = tr_frag(sl + tr_slab, sl + tr_slab + 4 * RS), a_lo = tr_frag(sl + SLAB + tr_slab, sl + SLAB + tr_slab + 4 * RS);
+                    const unsigned char* yk = Ys + yc_lane + 2048 * kc;
+#pragma unroll
+                    for (int n = 0; n < NTS; ++n) {
+                        if (n < NW) {                                   // uniform
+                            const unsigned char* q0 = yk + (n >> 1) * STEP + 32 * (n & 1);
+                            const unsigned char* q1 = yk + 256 + (n >> 1) * STEP + 32 * ((n & 1) ^ 1);
+                            const f16x8 b_hi = tr_frag(q0, q1), b_lo = tr_frag(q0 + PLANE, q1 + PLANE);
+                            accc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo, accc[n], 0, 0, 0);
+                            accc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi, accc[n], 0, 0, 0);
+                            accc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, accc[n], 0, 0, 0);
+                        }
+                    }
+                    ++stepno;
+                }
+                // C layout: column (lane & 15) = s = 16 n + li, rows t = 16 w + 4 lq + r: g_adj[s][t .. t + 3] as one 16-byte store
+                const float k = hx2_inv(sP) * inv_sy;
+                const auto rga = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.gadj[l - 1]) + static_cast<int64_t>(b) * SSb, 0, static_cast<int>(SSb), 0x00020000);
+                const uint32_t go_lane = static_cast<uint32_t>(li * S + t0w) * 4u;
+#pragma unroll
+                for (int n = 0; n < NTS; ++n)
+                    if (n < NW) {
+                        const f32x4 v = accc[n] * k;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rga, go_lane + static_cast<uint32_t>(n) * 64u * S, 0, 0);
+                    }
+            }
+            // ---------------- (d): gH^l-1^T tile [t in wave's tile][all c] = sum_s A_l^T[t][s] Y[c][s]
+            if (l > 1) x_load(l - 1);                                   // h^l-1 at this lane's positions, for act' behind (d)
+#pragma unroll
+            for (int j = 0; j < NTC; ++j) accd[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int ks = 0; ks < NKS; ++ks) {
+                step_in();
+                if (!committed) { scatter_commit(l - 1); committed = true; }
+                const unsigned char* sl = ring + (stepno & 1) * 2 * SLAB;
+                const f16x8 a_hi = tr_frag(sl + tr_slab, sl + tr_slab + 4 * RS), a_lo = tr_frag(sl + SLAB + tr_slab, sl + SLAB + tr_slab + 4 * RS);
+#pragma unroll
+                for (int j = 0; j < NTC; ++j) {
+                    const f16x8 b_hi = *reinterpret_cast<const f16x8*>(Ys + ks * STEP + 1024 * j + yb_rd);
+                    const f16x8 b_lo = *reinterpret_cast<const f16x8*>(Ys + PLANE + ks * STEP + 1024 * j + yb_rd);
+                    accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo, accd[j], 0, 0, 0);
+                    accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi, accd[j], 0, 0, 0);
+                    accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, accd[j], 0, 0, 0);
+                }
+                ++stepno;
+            }
+            const float inv_unit = hx2_inv(sA) * inv_sy;
+            if (l > 1) {
+                if ((want_gA ? NKC : 0) + NKS == 1) lds_barrier();      // a one-step hop: the scatter commits behind its only barrier are not yet ordered
+                inv_sy = make_y(accd, inv_unit, par);
+                par ^= 1;
+            } else {                                                    // d loss / d h^0: column (lane & 15) = channel, rows t
+                const auto rgh = __builtin_amdgcn_make_buffer_rsrc(p.gH + static_cast<int64_t>(b) * C * S, 0, C * S * 4, 0x00020000);      // channels past C: dropped (out of range)
+                const uint32_t gh_lane = static_cast<uint32_t>(li * S + t0w) * 4u;
+#pragma unroll
+                for (int j = 0; j < NTC; ++j) {
+                    const f32x4 v = accd[j] * inv_unit;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rgh, gh_lane + static_cast<uint32_t>(j) * 64u * S, 0, 0);
+                }
+            }
+        }
     }
 }
 
 size_t fwd_h_lds(int nks, int ntc, int S) {
     const size_t ch = 16ull * ntc;
-    return 2ull * nks * ch * 64 + 3ull * ch * sizeof(uint32_t) + static_cast<size_t>(S / 16) * 16 * sizeof(float);
+    return 2ull * nks * ch * 64 + 3ull * ch * sizeof(uint32_t) + static_cast<size_t>(S / 16) * 16 * sizeof(float) + (2 * kMaxHops + 1) * sizeof(uint32_t);
 }
 
 int num_cus() {
@@ -405,7 +751,43 @@ int num_cus() {
     return n;
 }
 
+size_t bwd_h_lds(int nks, int ntc, int S) {
+    const size_t ch = 16ull * ntc;
+    const size_t ych = (ch + 31) / 32 * 32;
+    return 2ull * nks * ych * 64 + 4ull * 32 * (2 * S + 16) + ch * (S + 4) * sizeof(float) + 64;
+}
+
 }  // namespace
+
+bool prop_bwd_h_supported(const PropBwdH& p) {
+    if (p.S % 16 != 0 || p.S > 160 || p.C > 96 || p.S < 16 || p.dd < 1 || !p.stats || !p.hsave || !p.gH || !p.gout) return false;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    for (int l = 0; l < p.L; ++l) if (!al16(p.adj[l]) || !al16(p.gadj[l])) return false;
+    if (!al16(p.h0) || (p.h0_bs % 4) != 0 || !al16(p.hsave) || !al16(p.gH)) return false;
+    const int nks = (p.S + 31) / 32, ntc = (p.C + 15) / 16;
+    return bwd_h_lds(nks, ntc, p.S) <= 160 * 1024;
+}
+
+int prop_bwd_h(const PropBwdH& p, hipStream_t st) {
+    if (!prop_bwd_h_supported(p)) return RECON_ERR_UNSUPPORTED;
+    const int nks = (p.S + 31) / 32, ntc = (p.C + 15) / 16, nw = p.S / 16;
+    const size_t lds = bwd_h_lds(nks, ntc, p.S);
+    const int grid = p.B < num_cus() ? p.B : num_cus();
+#define CALL_B(K_, N_)                                                                                                                  \
+    do {                                                                                                                                \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_bwd_h<K_, N_>),                     \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));             \
+        hipLaunchKernelGGL((k_propagate_bwd_h<K_, N_>), dim3(static_cast<unsigned>(grid)), dim3(64 * nw), lds, st, p);                  \
+    } while (0)
+#define CALL_BN(K_)                                                                                                                     \
+    switch (ntc) { case 1: CALL_B(K_, 1); break; case 2: CALL_B(K_, 2); break; case 3: CALL_B(K_, 3); break; case 4: CALL_B(K_, 4); break; \
+                   case 5: CALL_B(K_, 5); break; default: CALL_B(K_, 6); break; }
+    switch (nks) { case 1: CALL_BN(1); break; case 2: CALL_BN(2); break; case 3: CALL_BN(3); break; case 4: CALL_BN(4); break; default: CALL_BN(5); break; }
+#undef CALL_BN
+#undef CALL_B
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
 
 bool prop_fwd_h_supported(const PropK& p) {
     if (p.S % 16 != 0 || p.S > 160 || p.C > 96 || p.S < 16 || p.dd < 1) return false;

@@ -145,11 +145,18 @@ class _Propagate(torch.autograd.Function):
         hs = torch.empty(L, B, Cn, S, dtype=torch.float32, device=dev) if need else None
         parr = _ptr_array(adjs)
         args = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], parr, h0c.data_ptr(), h0_bs, head.data_ptr(),
-                             tail.data_ptr(), idx_bs, out.data_ptr(), _lib.ptr(hs))
+                             tail.data_ptr(), idx_bs, out.data_ptr(), _lib.ptr(hs), None)
+        stats = None
+        if need and _lib.lib().recon_propagate_form(C.byref(args)) == 1:
+            # two-term f16 kernels: the forward records per graph the max magnitudes of the states and adjacencies, the backward takes its
+            # per-tensor scales from them (include/recon_hip.h: recon_prop_args.stats)
+            stats = torch.empty(B, 2 * L + 1, dtype=torch.float32, device=dev)
+            args.stats = C.cast(stats.data_ptr(), _lib.c_f32p)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().recon_propagate_fwd(C.byref(args), _lib.current_stream()), "recon_propagate_fwd")
         if need:
             ctx.save_for_backward(h0c, head, tail, hs, *adjs)
+            ctx.stats = stats
             ctx.meta = (B, Cn, S, L, dd, act, h0_bs, idx_bs, tuple(h0.shape), adj_shapes)
         return out
 
@@ -164,7 +171,7 @@ class _Propagate(torch.autograd.Function):
         g_h = torch.empty(B, Cn, S, dtype=torch.float32, device=dev)
         parr, garr = _ptr_array(adjs), _ptr_array(g_adjs)
         fwd = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], parr, h0c.data_ptr(), h0_bs, head.data_ptr(), tail.data_ptr(),
-                            idx_bs, None, hs.data_ptr())
+                            idx_bs, None, hs.data_ptr(), _lib.ptr(ctx.stats))
         fwd.out = gout.data_ptr()      # unused by the backward; must be non-null for the argument check
         args = _lib.PropBwdArgs(fwd, gout.data_ptr(), garr, g_h.data_ptr())
         with torch.cuda.device(dev):
