@@ -454,35 +454,49 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
         s_off[i] = r * RS + 8 * c4;
         s_goff[i] = static_cast<uint32_t>(r * S + 4 * c4) * 4u;
     }
-    // source of slab step (hop l, kind, k): kind 0 = channels 32 k .. of H^l-1 (product (c)), kind 1 = rows 32 k .. of A_l (product (d))
-    auto slab_rsrc = [&](int bb, int l, int kind, int k, int& rows) {
-        if (kind == 0) {
-            const float* P = l >= 2 ? p.hsave + ((static_cast<int64_t>(l) - 2) * p.B + bb) * C * S : p.h0 + bb * p.h0_bs;
-            rows = min(32, C - 32 * k);
-            return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P + static_cast<int64_t>(32 * k) * S), 0, max(rows, 0) * S * 4, 0x00020000);
+    // ---- slab requests.  The slabs of one graph come in PHASES (hop l = L .. 1; per hop first the NKC slabs of H^l-1 — kind 0, product (c),
+    // only when g_adj[l-1] is wanted — then the NKS slabs of A_l — kind 1, product (d)).  A phase has ONE buffer descriptor (the whole
+    // [C][S] state / [S][S] adjacency of the graph: rows past it come back as zeros) and ONE scale; a request inside a phase costs two loads
+    // and an add, the scalar work (64-bit addresses, the statistics) is paid once per phase.
+    struct Phase { int bb, l, kind, k; };
+    auto phase_len = [&](int kind) { return kind == 0 ? NKC : NKS; };
+    auto first_kind = [&](int l) { return p.gadj[l - 1] ? 0 : 1; };
+    Phase ph{static_cast<int>(blockIdx.x), L, first_kind(L), 0};
+    auto phase_rsrc = [&](const Phase& q) {
+        if (q.kind == 0) {
+            const float* P = q.l >= 2 ? p.hsave + ((static_cast<int64_t>(q.l) - 2) * p.B + q.bb) * C * S : p.h0 + q.bb * p.h0_bs;
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, C * S * 4, 0x00020000);
         }
-        rows = min(32, S - 32 * k);
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.adj[l - 1]) + static_cast<int64_t>(bb) * SSb + static_cast<int64_t>(32 * k) * S * 4),
-                                                 0, rows * S * 4, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.adj[q.l - 1]) + static_cast<int64_t>(q.bb) * SSb), 0,
+                                                 static_cast<int>(SSb), 0x00020000);
     };
-    // the flat sequence of slab steps of one graph: hops l = L .. 1, per hop NKC steps of kind 0 (only when g_adj[l-1] is wanted) then NKS of kind 1
-    struct Step { int bb, l, kind, k; };
-    auto next_step = [&](Step st) {
-        ++st.k;
-        if (st.kind == 0 && st.k == NKC) { st.kind = 1; st.k = 0; }
-        else if (st.kind == 1 && st.k == NKS) {
-            st.k = 0; --st.l;
-            if (st.l == 0) { st.l = L; st.bb += static_cast<int>(gridDim.x); }
-            st.kind = p.gadj[st.l - 1] ? 0 : 1;
-        }
-        return st;
+    auto phase_scale = [&](const Phase& q) {
+        const float* sb = p.stats + static_cast<int64_t>(q.bb) * nstat;
+        return hx2_scale_of(q.kind == 0 ? sb[q.l - 1] : sb[L + q.l]);
     };
-    auto load_slab = [&](u32x4 (&dst)[2], Step st) {
-        if (st.bb >= p.B) { dst[0] = u32x4{0u, 0u, 0u, 0u}; dst[1] = dst[0]; return; }
-        int rows;
-        const auto rs = slab_rsrc(st.bb, st.l, st.kind, st.k, rows);              // rows past the source come back as zeros (out of range)
+    bool ph_live = ph.bb < p.B;
+    auto ph_rs = phase_rsrc(ph_live ? ph : Phase{0, L, 1, 0});
+    float ph_sc = ph_live ? phase_scale(ph) : 1.f;
+    float stg_sc[2] = {1.f, 1.f};                                      // scale of the slab in each register set
+    auto request = [&](u32x4 (&dst)[2], float& sc) {
+        sc = ph_sc;
+        if (ph_live) {
+            const uint32_t koff = static_cast<uint32_t>(ph.k) * 128u * S;          // 32 rows
 #pragma unroll
-        for (int i = 0; i < 2; ++i) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, s_goff[i], 0, 0);
+            for (int i = 0; i < 2; ++i) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(ph_rs, s_goff[i] + koff, 0, 0);
+        } else {
+            dst[0] = u32x4{0u, 0u, 0u, 0u}; dst[1] = dst[0];
+        }
+        if (++ph.k == phase_len(ph.kind)) {                            // next phase
+            ph.k = 0;
+            if (ph.kind == 0) ph.kind = 1;
+            else {
+                if (--ph.l == 0) { ph.l = L; ph.bb += static_cast<int>(gridDim.x); }
+                ph.kind = first_kind(ph.l);
+            }
+            ph_live = ph.bb < p.B;
+            if (ph_live) { ph_rs = phase_rsrc(ph); ph_sc = phase_scale(ph); }
+        }
     };
     auto store_slab = [&](const u32x4 (&src)[2], int slot, float scale) {
         unsigned char* d = ring + slot * 2 * SLAB;
@@ -517,7 +531,6 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
     const int yw = (t0w >> 5) * STEP + 64 * li + (((((t0w >> 3) & 3) << 4)) ^ swz) + 2 * (t0w & 7);       // + 1024 j
     const int rw = (li * pitch + t0w) * 4;                              // R image: + 64 j pitch
     const int nitems = C * p.dd, Ldd = L * p.dd;
-    const float* statp = p.stats;
 
     // ---- zero state of the workgroup: R, the maxima, and the Y image (its columns S .. 32 NKS are never written and meet zero rows of A)
     for (int i = tid; i < CH * pitch; i += nthreads) reinterpret_cast<float*>(Rb)[i] = 0.f;
@@ -527,31 +540,32 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
     // n - 1), register set (n + 1) & 1 holds slab n + 1 and set n & 1 slab n + 2 (both in flight).  Step n: barrier; set (n + 1) & 1 -> slot
     // (n + 1) & 1; request slab n + 3 into that set; products of slab n.
     u32x4 stg[2][2];
-    Step nxt{static_cast<int>(blockIdx.x), L, p.gadj[L - 1] ? 0 : 1, 0};      // descriptor of slab n + 1 (kept one ahead of the step counter)
-    Step pre = nxt;                                                     // descriptor of the next slab to request
-    auto scale_of_step = [&](Step st) {
-        if (st.bb >= p.B) return 1.f;
-        const float* sb = statp + static_cast<int64_t>(st.bb) * nstat;
-        return hx2_scale_of(st.kind == 0 ? sb[st.l - 1] : sb[L + st.l]);
-    };
-    load_slab(stg[0], pre); pre = next_step(pre);                       // slab 0
-    load_slab(stg[1], pre); pre = next_step(pre);                       // slab 1
-    store_slab(stg[0], 0, scale_of_step(nxt));                          // slab 0 -> slot 0
-    load_slab(stg[0], pre); pre = next_step(pre);                       // slab 2
-    nxt = next_step(nxt);
+    request(stg[0], stg_sc[0]);                                         // slab 0
+    request(stg[1], stg_sc[1]);                                         // slab 1
+    store_slab(stg[0], 0, stg_sc[0]);                                   // slab 0 -> slot 0
+    request(stg[0], stg_sc[0]);                                         // slab 2
     int stepno = 0;
-    auto step_in = [&]() {
+    int gi = -1, hop_i = 0;
+    (void)gi; (void)hop_i;
+    auto step_in = [&](bool stamp = false) {
+        if (stamp) STAMP(13);
         lds_barrier();                                                  // slab `stepno` (and a freshly written Y image) visible; the other slot is free
+        if (stamp) STAMP(14);
         const int q = (stepno + 1) & 1;
-        store_slab(stg[q], q, scale_of_step(nxt));
-        load_slab(stg[q], pre);
-        pre = next_step(pre);
-        nxt = next_step(nxt);
+        store_slab(stg[q], q, stg_sc[q]);
+        if (stamp) STAMP(15);
+    };
+    auto step_out = [&]() {                                              // behind the step's products: the request (its issue waits on the CU's memory queue)
+        const int q = (stepno + 1) & 1;
+        request(stg[q], stg_sc[q]);
+        ++stepno;
     };
 
 #pragma unroll 1
     for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
-        const float* st_b = statp + static_cast<int64_t>(b) * nstat;
+        ++gi; hop_i = 7;
+        STAMP(0);
+        const float* st_b = p.stats + static_cast<int64_t>(b) * nstat;
         // relation-gradient items of this thread (the same positions in every hop)
         uint32_t it_h[kGatherRegs], it_t[kGatherRegs], it_c[kGatherRegs], it_x[kGatherRegs];
         {
@@ -610,7 +624,7 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
         };
         // new Y = (acc / unit + R) . act'(X) from (d)'s result (zero for the first Y of a graph); writes the image under its own scale,
         // leaves R zeroed, returns 1 / scale
-        auto make_y = [&](f32x4 (&acc)[NTC], float inv_unit, int par) {
+        auto make_y = [&](f32x4 (&acc)[NTC], float inv_unit, int par, int l_next_scatter) {
             float mm = 0.f;
 #pragma unroll
             for (int j = 0; j < NTC; ++j) {
@@ -631,6 +645,9 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
             lds_barrier();                                              // every wave is through with the old image; the maximum is complete
             const float sg = hx2_scale_of(__builtin_bit_cast(float, ymax[par]));
             if (tid == 0) ymax[par ^ 1] = 0u;
+            // R is zero again and nobody reads it before the next make_y (one hop and several barriers away): the relation gradient of the
+            // hop below goes in now — its operands were requested with this hop's X and arrived under the same wait
+            if (l_next_scatter >= 1) scatter_commit(l_next_scatter);
 #pragma unroll
             for (int j = 0; j < NTC; ++j) {
                 uint32_t h0, l0, h1, l1;
@@ -651,15 +668,18 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
         f32x4 accd[NTC];
 #pragma unroll
         for (int j = 0; j < NTC; ++j) accd[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float inv_sy = make_y(accd, 0.f, par);
+        if (L >= 2) scatter_load(L - 1);
+        float inv_sy = make_y(accd, 0.f, par, L - 1);
         par ^= 1;
+        STAMP(1);
 
 #pragma unroll 1
         for (int l = L; l >= 1; --l) {
             const float sA = hx2_scale_of(st_b[L + l]), sP = hx2_scale_of(st_b[l - 1]);
             const bool want_gA = p.gadj[l - 1] != nullptr;
-            if (l > 1) scatter_load(l - 1);                             // for the next Y
-            bool committed = l == 1;
+            hop_i = L - l;
+            STAMP(0);
+
             // ---------------- (c): g_adj[l-1]^T tile  [t in wave's tile][all s] = sum_c P^T[t][c] Y^T[s][c]
             if (want_gA) {
                 constexpr int NTS = NKS * 2;                            // column tiles of s (S = 16 NW <= 16 NTS)
@@ -669,7 +689,7 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
 #pragma unroll 1
                 for (int kc = 0; kc < NKC; ++kc) {
                     step_in();
-                    if (!committed) { scatter_commit(l - 1); committed = true; }      // after a barrier that follows the zeroing of R, before the ones in front of make_y
+                    STAMP(5 + kc);
                     const unsigned char* sl = ring + (stepno & 1) * 2 * SLAB;
                     const f16x8 a_hi = tr_frag(sl + tr_slab, sl + tr_slab + 4 * RS), a_lo = tr_frag(sl + SLAB + tr_slab, sl + SLAB + tr_slab + 4 * RS);
                     const unsigned char* yk = Ys + yc_lane + 2048 * kc;
@@ -684,8 +704,9 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
                             accc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, accc[n], 0, 0, 0);
                         }
                     }
-                    ++stepno;
+                    step_out();
                 }
+                STAMP(1);
                 // C layout: column (lane & 15) = s = 16 n + li, rows t = 16 w + 4 lq + r: g_adj[s][t .. t + 3] as one 16-byte store
                 const float k = hx2_inv(sP) * inv_sy;
                 const auto rga = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.gadj[l - 1]) + static_cast<int64_t>(b) * SSb, 0, static_cast<int>(SSb), 0x00020000);
@@ -697,14 +718,17 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rga, go_lane + static_cast<uint32_t>(n) * 64u * S, 0, 0);
                     }
             }
+            STAMP(2);
             // ---------------- (d): gH^l-1^T tile [t in wave's tile][all c] = sum_s A_l^T[t][s] Y[c][s]
             if (l > 1) x_load(l - 1);                                   // h^l-1 at this lane's positions, for act' behind (d)
+            if (l > 2) scatter_load(l - 2);                             // operands of the relation gradient one hop further down
 #pragma unroll
             for (int j = 0; j < NTC; ++j) accd[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int ks = 0; ks < NKS; ++ks) {
-                step_in();
-                if (!committed) { scatter_commit(l - 1); committed = true; }
+                step_in(ks == 2);
+                STAMP(8 + ks);
+
                 const unsigned char* sl = ring + (stepno & 1) * 2 * SLAB;
                 const f16x8 a_hi = tr_frag(sl + tr_slab, sl + tr_slab + 4 * RS), a_lo = tr_frag(sl + SLAB + tr_slab, sl + SLAB + tr_slab + 4 * RS);
 #pragma unroll
@@ -715,13 +739,14 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
                     accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi, accd[j], 0, 0, 0);
                     accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, accd[j], 0, 0, 0);
                 }
-                ++stepno;
+                step_out();
             }
+            STAMP(3);
             const float inv_unit = hx2_inv(sA) * inv_sy;
             if (l > 1) {
-                if ((want_gA ? NKC : 0) + NKS == 1) lds_barrier();      // a one-step hop: the scatter commits behind its only barrier are not yet ordered
-                inv_sy = make_y(accd, inv_unit, par);
+                inv_sy = make_y(accd, inv_unit, par, l - 2);
                 par ^= 1;
+                STAMP(4);
             } else {                                                    // d loss / d h^0: column (lane & 15) = channel, rows t
                 const auto rgh = __builtin_amdgcn_make_buffer_rsrc(p.gH + static_cast<int64_t>(b) * C * S, 0, C * S * 4, 0x00020000);      // channels past C: dropped (out of range)
                 const uint32_t gh_lane = static_cast<uint32_t>(li * S + t0w) * 4u;
