@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--heads", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-extras", action="store_true", help="main step and roofline only (profiling runs): no exact_fp32 / uncached / secondary legs")
     return ap.parse_args()
 
 
@@ -263,7 +264,7 @@ def main():
 
         # ---- the same step on the exact-fp32 MFMA GEMMs (RECON_GEMM_BX3=0: v_mfma_f32_32x32x2_f32, no split operands): brackets the
         # "dtype f32" claim of the main line, whose three large products run fp32 operands as two f16 terms each
-        if world == 1:
+        if world == 1 and not args.no_extras:
             from recon_amd import gat_layers
             from recon_amd.graph import clear_graph_cache
             n_x = max(10, args.steps // 4)

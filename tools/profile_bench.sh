@@ -4,7 +4,7 @@
 # Outputs land in gpurun_out/prof_<tag>/ ; tools/prof_summary.py condenses them for profiles/.
 set -u
 TAG=${1:-r1}
-ARGS=${2:---steps 10 --warmup 3 --no-cpu-baseline}
+ARGS=${2:---steps 10 --warmup 3 --no-cpu-baseline --no-extras}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
