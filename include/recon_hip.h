@@ -307,6 +307,12 @@ typedef struct {
     int64_t idx_batch_stride;
     float* out;                     /* [B,C,L*dd]                                                         */
     float* h_saved;                 /* [L,B,C,S] states after each hop (for the backward) or NULL         */
+    const float* const* trans;      /* BLOCK MODE (or NULL): HOST array of L device pointers, each [B, n(n-1), dd*dd] — the  *
+                                     * transition matrices AFTER the non-linearity; A_l is then never materialised: the     *
+                                     * kernels read A_l[b, i*dd+r, j*dd+c] = trans[l][b, e(i,j), r, c] (identity[r,c] on the   *
+                                     * diagonal blocks) in place, recon_block_adjacency_fwd's layout.  `adj` is ignored.    *
+                                     * Only where recon_propagate_form() == 1 and dd == 16 (S = 16 n).                      */
+    const float* identity;          /* [dd,dd], with trans                                                               */
     float* stats;                   /* [B, 2L+1] or NULL: per graph the max magnitudes of h^0..h^L and of   *
                                      * A_1..A_L.  Written by the forward when h_saved is given and          *
                                      * recon_propagate_form() == 1 (the two-term f16 kernels, whose         *
@@ -315,8 +321,9 @@ typedef struct {
 } recon_prop_args;
 
 int recon_propagate_fwd(const recon_prop_args* args, recon_stream_t stream);
-/* 1: this problem runs on the two-term f16 matrix-core kernels (csrc/prop_h.hip: S % 16 == 0, S <= 160, C <= 96, aligned pointers,
- * RECON_PROP_FWD unset or "h"); 0: on the fp32 matrix-core forms.  The adjacency pointers need not be set for this query. */
+/* Bit 0: the forward of this problem runs on the two-term f16 matrix-core kernels (csrc/prop_h.hip: S % 16 == 0, S <= 160, C <= 96,
+ * aligned pointers, RECON_PROP_FWD unset or "h"); bit 1: so does the backward (its LDS image also fits); 0: fp32 matrix-core forms.
+ * Block mode (`trans`) needs both bits when gradients are wanted.  The adjacency pointers need not be set for this query. */
 int recon_propagate_form(const recon_prop_args* args);
 
 typedef struct {
@@ -324,7 +331,13 @@ typedef struct {
     const float* grad_out;          /* [B,C,L*dd]                                                         */
     float* const* g_adj;            /* HOST array of L device pointers [B,S,S] (entries may be NULL)      */
     float* g_h;                     /* [B,C,S] workspace; on return holds d loss / d h0 per batch element */
+    float* const* g_trans;          /* block mode: HOST array of L device pointers [B, n(n-1), dd*dd] (entries may be NULL): *
+                                     * the gradient lands in the transition tensors' own layout, g_adj is ignored           */
+    float* g_identity;              /* block mode: [dd,dd] summed over graphs, nodes and hops (fixed order), or NULL         */
+    float* identity_ws;             /* block mode: recon_propagate_identity_ws_floats() floats when g_identity is wanted    */
 } recon_prop_bwd_args;
+
+size_t recon_propagate_identity_ws_floats(int32_t dd);
 
 int recon_propagate_bwd(const recon_prop_bwd_args* args, recon_stream_t stream);
 

@@ -62,11 +62,12 @@ class PropArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("C", C.c_int32), ("S", C.c_int32), ("L", C.c_int32), ("dd", C.c_int32),
                 ("act", C.c_int32), ("adj", C.POINTER(C.c_void_p)), ("h0", c_f32p), ("h0_batch_stride", C.c_int64),
                 ("head_idx", c_i64p), ("tail_idx", c_i64p), ("idx_batch_stride", C.c_int64),
-                ("out", c_f32p), ("h_saved", c_f32p), ("stats", c_f32p)]
+                ("out", c_f32p), ("h_saved", c_f32p), ("trans", C.POINTER(C.c_void_p)), ("identity", c_f32p), ("stats", c_f32p)]
 
 
 class PropBwdArgs(C.Structure):
-    _fields_ = [("fwd", PropArgs), ("grad_out", c_f32p), ("g_adj", C.POINTER(C.c_void_p)), ("g_h", c_f32p)]
+    _fields_ = [("fwd", PropArgs), ("grad_out", c_f32p), ("g_adj", C.POINTER(C.c_void_p)), ("g_h", c_f32p),
+                ("g_trans", C.POINTER(C.c_void_p)), ("g_identity", c_f32p), ("identity_ws", c_f32p)]
 
 
 class GcnArgs(C.Structure):
@@ -127,6 +128,7 @@ SYMBOLS = [
     ("recon_propagate_fwd", C.c_int, [C.POINTER(PropArgs), C.c_void_p]),
     ("recon_propagate_bwd", C.c_int, [C.POINTER(PropBwdArgs), C.c_void_p]),
     ("recon_propagate_form", C.c_int, [C.POINTER(PropArgs)]),
+    ("recon_propagate_identity_ws_floats", C.c_size_t, [C.c_int32]),
     ("recon_start_entity_embeddings", C.c_int, [c_f32p, c_i64p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
                                                 C.c_void_p]),
     ("recon_gcn_split_bytes", C.c_size_t, [C.c_int32, C.c_int32]),

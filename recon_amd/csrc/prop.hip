@@ -843,7 +843,15 @@ int check_prop(const recon_prop_args* a) {
     if (a->L > kMaxHops) return RECON_ERR_UNSUPPORTED;
     if (a->B > 65535) return RECON_ERR_UNSUPPORTED;
     if (a->act < 0 || a->act > 2) return RECON_ERR_INVALID;
-    if (!a->adj || !a->h0 || !a->head_idx || !a->tail_idx || !a->out) return RECON_ERR_INVALID;
+    if (!a->h0 || !a->head_idx || !a->tail_idx || !a->out) return RECON_ERR_INVALID;
+    if (a->trans) {                                                 // block mode: dd == 16, S = 16 n, C = n (n - 1)
+        if (!a->identity) return RECON_ERR_INVALID;
+        for (int l = 0; l < a->L; ++l) if (!a->trans[l]) return RECON_ERR_INVALID;
+        const int n = a->S / 16;
+        if (a->dd != 16 || a->S != 16 * n || a->C != n * (n - 1)) return RECON_ERR_UNSUPPORTED;
+        return RECON_OK;
+    }
+    if (!a->adj) return RECON_ERR_INVALID;
     for (int l = 0; l < a->L; ++l) if (!a->adj[l]) return RECON_ERR_INVALID;
     return RECON_OK;
 }
@@ -927,7 +935,13 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
     if (!prop_geometry(a->C, a->S, &g)) return RECON_ERR_UNSUPPORTED;
     PropK p;
     bool v4 = (a->S % 4) == 0;
-    for (int l = 0; l < kMaxHops; ++l) { p.adj[l] = l < a->L ? a->adj[l] : nullptr; if (l < a->L && !al16(a->adj[l])) v4 = false; }
+    const bool blk = a->trans != nullptr;
+    for (int l = 0; l < kMaxHops; ++l) {
+        p.adj[l] = (l < a->L && !blk) ? a->adj[l] : nullptr;
+        p.trans[l] = (l < a->L && blk) ? a->trans[l] : nullptr;
+        if (l < a->L && !al16(blk ? a->trans[l] : a->adj[l])) v4 = false;
+    }
+    p.identity = blk ? a->identity : nullptr;
     p.h0 = a->h0; p.h0_bs = a->h0_batch_stride; p.head = a->head_idx; p.tail = a->tail_idx; p.idx_bs = a->idx_batch_stride;
     p.out = a->out; p.hsave = a->h_saved;
     p.B = a->B; p.C = a->C; p.S = a->S; p.L = a->L; p.dd = a->dd; p.act = a->act;
@@ -941,6 +955,7 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
         // selects one of the forms below (fp32 MFMA per wave / per workgroup / staged, bf16 x 3), h forces the default
         const char* form = getenv("RECON_PROP_FWD");
         if ((!form || form[0] == 'h' || form[0] == '\0') && prop_fwd_h_supported(p)) return prop_fwd_h(p, st);
+        if (blk) return RECON_ERR_UNSUPPORTED;                          // the other forms need a materialised adjacency
         const int ntc = (a->C + 15) / 16, ks = (a->S + 31) / 32, mw = (a->S + 15) / 16;
         if (form && form[0] == 'x' && ntc <= 8 && ks <= 4 && mw <= 16) {     // S <= 128: wider states spill in this form             // bf16 x 3 on the bf16 matrix cores: opt-in (see the kernel's header)
             const size_t xlds = 3ull * ks * ntc * 16 * 64;
@@ -999,6 +1014,10 @@ static bool prop_h_form_env() {
     return !form || form[0] == 'h' || form[0] == '\0';
 }
 
+extern "C" size_t recon_propagate_identity_ws_floats(int32_t dd) {
+    return static_cast<size_t>(prop_h_grid(1 << 30)) * (dd > 0 ? dd : 1) * (dd > 0 ? dd : 1);
+}
+
 extern "C" int recon_propagate_form(const recon_prop_args* a) {
     if (!a || a->B < 0 || a->C <= 0 || a->S <= 0 || a->L <= 0 || a->L > kMaxHops || a->dd <= 0 || !a->h0) return 0;
     PropGeom g;
@@ -1007,7 +1026,8 @@ extern "C" int recon_propagate_form(const recon_prop_args* a) {
     for (int l = 0; l < kMaxHops; ++l) p.adj[l] = nullptr;              // the adjacency pointers' alignment is checked at the call
     p.h0 = a->h0; p.h0_bs = a->h0_batch_stride; p.hsave = nullptr;
     p.B = a->B; p.C = a->C; p.S = a->S; p.L = 0; p.dd = a->dd; p.pitch = g.pitch;
-    return (prop_h_form_env() && prop_fwd_h_supported(p)) ? 1 : 0;
+    if (!(prop_h_form_env() && prop_fwd_h_supported(p))) return 0;
+    return prop_bwd_h_shape_ok(a->C, a->S) ? 3 : 1;                     // bit 1: the backward's two-term form exists for this shape too
 }
 
 extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t stream) {
@@ -1019,12 +1039,25 @@ extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t
     if (a->B == 0) return RECON_OK;
     if (a->stats && prop_h_form_env() && !(getenv("RECON_PROP_BWD") && getenv("RECON_PROP_BWD")[0] == 'f')) {      // two-term f16 form (RECON_PROP_BWD=f: fp32 MFMA form)
         PropBwdH q{};
-        for (int l = 0; l < kMaxHops; ++l) { q.adj[l] = l < a->L ? a->adj[l] : nullptr; q.gadj[l] = (l < a->L && ba->g_adj) ? ba->g_adj[l] : nullptr; }
+        const bool blk = a->trans != nullptr;
+        for (int l = 0; l < kMaxHops; ++l) {
+            q.adj[l] = (l < a->L && !blk) ? a->adj[l] : nullptr; q.gadj[l] = (l < a->L && !blk && ba->g_adj) ? ba->g_adj[l] : nullptr;
+            q.trans[l] = (l < a->L && blk) ? a->trans[l] : nullptr; q.gtrans[l] = (l < a->L && blk && ba->g_trans) ? ba->g_trans[l] : nullptr;
+        }
+        q.identity = blk ? a->identity : nullptr;
+        q.gident_ws = (blk && ba->g_identity) ? ba->identity_ws : nullptr;
+        if (blk && ba->g_identity && !ba->identity_ws) return RECON_ERR_INVALID;
         q.h0 = a->h0; q.h0_bs = a->h0_batch_stride; q.hsave = a->h_saved; q.head = a->head_idx; q.tail = a->tail_idx; q.idx_bs = a->idx_batch_stride;
         q.gout = ba->grad_out; q.gH = ba->g_h; q.stats = a->stats;
         q.B = a->B; q.C = a->C; q.S = a->S; q.L = a->L; q.dd = a->dd; q.act = a->act;
-        if (prop_bwd_h_supported(q)) return prop_bwd_h(q, as_stream(stream));
-    }
+        if (prop_bwd_h_supported(q)) {
+            rc = prop_bwd_h(q, as_stream(stream));
+            if (rc == RECON_OK && q.gident_ws)                          // per-workgroup partial sums -> g_identity, fixed order
+                hipLaunchKernelGGL(k_sum_rows, dim3(16), dim3(1024), 0, as_stream(stream), q.gident_ws, prop_h_grid(a->B), 256, ba->g_identity);
+            return rc;
+        }
+        if (blk) return RECON_ERR_UNSUPPORTED;
+    } else if (a->trans) return RECON_ERR_UNSUPPORTED;
     PropGeom g;
     if (!prop_geometry(a->C, a->S, &g)) return RECON_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);

@@ -13,6 +13,8 @@ struct PropK {
     float* out; float* hsave;
     int32_t B, C, S, L, dd, act, CC, Sp, pitch;
     float* stats;             // [B][2L+1] max magnitudes of h^0..h^L, A_1..A_L per graph (two-term forms, with hsave) or null
+    const float* trans[kMaxHops];     // block mode (identity != null): transition tensors [B][C][dd*dd]; adj unused
+    const float* identity;
 };
 
 // backward of the two-term form (prop_h.hip): all L hops of a graph in one persistent workgroup
@@ -26,6 +28,10 @@ struct PropBwdH {
     float* gH;                // [B][C][S] out: gradient wrt h^0 per batch element
     const float* stats;       // [B][2L+1] from the forward
     int32_t B, C, S, L, dd, act;
+    const float* trans[kMaxHops];     // block mode (identity != null)
+    float* gtrans[kMaxHops];
+    const float* identity;
+    float* gident_ws;         // [grid][dd*dd] per-workgroup partial sums of the identity gradient, or null
 };
 
 struct PropBwdK {
@@ -56,6 +62,8 @@ __device__ __forceinline__ float act_bwd(float y, int act) {
 // does not take (the caller then runs a fp32-MFMA form of prop.hip)
 bool prop_fwd_h_supported(const PropK& p);
 int prop_fwd_h(const PropK& p, hipStream_t st);
+bool prop_bwd_h_shape_ok(int C, int S);   // LDS budget of the backward's two-term form
+int prop_h_grid(int B);               // workgroups the two-term kernels launch for B graphs (one per CU, persistent)
 bool prop_bwd_h_supported(const PropBwdH& p);
 int prop_bwd_h(const PropBwdH& p, hipStream_t st);
 

@@ -101,7 +101,7 @@ constexpr uint32_t kOOB = 0xfffffff0u;            // a buffer offset past every 
 // one 64-byte row per (K step, channel); its four 16-byte slots are the B fragments of the four lane groups (slot q holds t = 4 q .. 4 q + 3
 // and 16 + 4 q .. + 3 of the K step), XOR-rotated by the channel so that the ds_read_b128 of a fragment is conflict free and the 8-byte
 // writes of the epilogue (16 channels x 4 columns per lane group) meet two to a bank pair instead of four.
-template <int NKS, int NTC>
+template <int NKS, int NTC, bool BLK>
 __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     constexpr int CH = NTC * 16;
@@ -126,6 +126,33 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
     auto rsrc_a = [&](int l, int bb) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.adj[l]) + static_cast<int64_t>(bb) * SSb), 0,
                                                  static_cast<int>(SSb), 0x00020000);
+    };
+    // BLOCK MODE (p.identity, dd == 16: this wave's 16 rows are node i = wave, a K step covers nodes j = 2 ks and 2 ks + 1): the fragment of
+    // block (i, j) is rows r = li, columns 4 lq .. of trans[l][b, e(i, j)] — one contiguous KiB per load instruction — or of `identity` when
+    // j == i; e(i, j) = i (n - 1) + (j < i ? j : j - 1).  Everything but the lane offset is wave-uniform: descriptor, soffset and the
+    // choice of the identity are scalar selects.
+    constexpr bool blocks = BLK;
+    const int nn = S >> 4;                                               // nodes (block mode)
+    const uint32_t voff_blk = static_cast<uint32_t>(li * 16 + 4 * lq) * 4u;
+    const auto rs_ident = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(blocks ? p.identity : p.h0), 0, 1024, 0x00020000);
+    auto rsrc_t = [&](int l, int bb) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.trans[l] + static_cast<int64_t>(bb) * C * 256), 0, C * 1024, 0x00020000);
+    };
+    auto load_rows = [&](u32x4 (&raw)[NKS][2], int ks, int l, int bb, decltype(rs_ident) rs_adj) {      // the two loads of K step ks
+        if constexpr (!blocks) {
+            raw[ks][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_adj, voff_a + 128 * ks, 0, 0);
+            raw[ks][1] = ks == NKS - 1 ? __builtin_amdgcn_raw_buffer_load_b128(rs_adj, voff_tail, 0, 0)
+                                       : __builtin_amdgcn_raw_buffer_load_b128(rs_adj, voff_a + 128 * ks + 64, 0, 0);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = 2 * ks + h;
+                const bool diag = j == wave;
+                const int e = wave * (nn - 1) + (j < wave ? j : j - 1);
+                const auto rs = diag ? rs_ident : rs_adj;
+                raw[ks][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, j < nn ? voff_blk : kOOB, diag ? 0 : e * 1024, 0);
+            }
+        }
     };
     // two half terms of four consecutive (scaled) columns -> 8 bytes of each plane
     auto store_state4 = [&](int off, float v0, float v1, float v2, float v3) {
@@ -157,12 +184,9 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
     u32x4 raw[NKS][2];
     int b = blockIdx.x;
     if (b < p.B) {
-        const auto rs = rsrc_a(0, b);
+        const auto rs = blocks ? rsrc_t(0, b) : rsrc_a(0, b);
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            raw[ks][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_a + 128 * ks, 0, 0);
-            raw[ks][1] = ks == NKS - 1 ? __builtin_amdgcn_raw_buffer_load_b128(rs, voff_tail, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs, voff_a + 128 * ks + 64, 0, 0);
-        }
+        for (int ks = 0; ks < NKS; ++ks) load_rows(raw, ks, 0, b, rs);
     }
     int gi = -1, hop_i = 0;
     (void)gi; (void)hop_i;
@@ -273,7 +297,7 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
 #else
             const bool pre = nb < p.B;
 #endif
-            const auto rs_n = rsrc_a(more_hops ? l + 1 : 0, pre ? nb : b);
+            const auto rs_n = blocks ? rsrc_t(more_hops ? l + 1 : 0, pre ? nb : b) : rsrc_a(more_hops ? l + 1 : 0, pre ? nb : b);
             f32x4 acc[NTC];
 #pragma unroll
             for (int j = 0; j < NTC; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -297,11 +321,7 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) if (j + jj < NTC) acc[j + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[ks], bh[jj], acc[j + jj], 0, 0, 0);
                 }
-                if (pre) {
-                    raw[ks][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_n, voff_a + 128 * ks, 0, 0);
-                    raw[ks][1] = ks == NKS - 1 ? __builtin_amdgcn_raw_buffer_load_b128(rs_n, voff_tail, 0, 0)
-                                               : __builtin_amdgcn_raw_buffer_load_b128(rs_n, voff_a + 128 * ks + 64, 0, 0);
-                }
+                if (pre) load_rows(raw, ks, 0, 0, rs_n);
                 __builtin_amdgcn_sched_barrier(0x078f);                            // everything but VMEM may move across: the requests stay where they are written
             }
             STAMP(3);
@@ -420,7 +440,7 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
 // the slab's ROW index — come out through the transposing read ds_read_b64_tr_b16, as do Y's in (c).  The relation gradient
 // (d out / d h[head], h[tail]) is scattered into an fp32 image R one hop ahead, with LDS float atomics (indices are arbitrary).
 // One workgroup barrier per slab step and one for the max magnitude of the new Y.
-template <int NKS, int NTC>
+template <int NKS, int NTC, bool BLK>
 __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     constexpr int CH = NTC * 16;
@@ -444,8 +464,8 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
 
     // ---- slab staging: 32 rows x S floats = 8 S float4 = two per thread (nthreads = 4 S); unit u = tid + i nthreads -> (row, 4 columns)
     const int nf4 = S >> 2;
-    int s_row[2], s_off[2];
-    uint32_t s_goff[2];
+    int s_row[2], s_off[2], s_j[2];
+    uint32_t s_goff[2], s_boff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int u = tid + i * nthreads;
@@ -453,20 +473,31 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
         s_row[i] = r;
         s_off[i] = r * RS + 8 * c4;
         s_goff[i] = static_cast<uint32_t>(r * S + 4 * c4) * 4u;
+        s_j[i] = c4 >> 2;                                               // block mode (dd == 16): column block of this unit ...
+        s_boff[i] = static_cast<uint32_t>((r & 15) * 16 + 4 * (c4 & 3)) * 4u;      // ... and its place inside a 16 x 16 block
     }
+    // BLOCK MODE (p.identity): A_l[i dd + r][j dd + c] = trans[l-1][b, e(i, j), r, c] (identity on the diagonal), read in place; the gradient
+    // of product (c) goes straight into the transition tensors' layout and the diagonal blocks into a per-workgroup sum
+    constexpr bool blocks = BLK;
+    const int nn = S >> 4;
+    const auto rs_ident = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(blocks ? p.identity : p.h0), 0, 1024, 0x00020000);
+    const uint32_t voff_blk = static_cast<uint32_t>(li * 16 + 4 * lq) * 4u;
+    f32x4 gI_acc = f32x4{0.f, 0.f, 0.f, 0.f};                          // d loss / d identity [r = li][c = 4 lq ..], this wave's node, all graphs and hops
+    auto want_c = [&](int l) { return blocks ? (p.gtrans[l - 1] != nullptr || p.gident_ws != nullptr) : p.gadj[l - 1] != nullptr; };
     // ---- slab requests.  The slabs of one graph come in PHASES (hop l = L .. 1; per hop first the NKC slabs of H^l-1 — kind 0, product (c),
     // only when g_adj[l-1] is wanted — then the NKS slabs of A_l — kind 1, product (d)).  A phase has ONE buffer descriptor (the whole
     // [C][S] state / [S][S] adjacency of the graph: rows past it come back as zeros) and ONE scale; a request inside a phase costs two loads
     // and an add, the scalar work (64-bit addresses, the statistics) is paid once per phase.
     struct Phase { int bb, l, kind, k; };
     auto phase_len = [&](int kind) { return kind == 0 ? NKC : NKS; };
-    auto first_kind = [&](int l) { return p.gadj[l - 1] ? 0 : 1; };
+    auto first_kind = [&](int l) { return want_c(l) ? 0 : 1; };
     Phase ph{static_cast<int>(blockIdx.x), L, first_kind(L), 0};
     auto phase_rsrc = [&](const Phase& q) {
         if (q.kind == 0) {
             const float* P = q.l >= 2 ? p.hsave + ((static_cast<int64_t>(q.l) - 2) * p.B + q.bb) * C * S : p.h0 + q.bb * p.h0_bs;
             return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, C * S * 4, 0x00020000);
         }
+        if (blocks) return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.trans[q.l - 1] + static_cast<int64_t>(q.bb) * C * 256), 0, C * 1024, 0x00020000);
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.adj[q.l - 1]) + static_cast<int64_t>(q.bb) * SSb), 0,
                                                  static_cast<int>(SSb), 0x00020000);
     };
@@ -480,7 +511,17 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
     float stg_sc[2] = {1.f, 1.f};                                      // scale of the slab in each register set
     auto request = [&](u32x4 (&dst)[2], float& sc) {
         sc = ph_sc;
-        if (ph_live) {
+        if (ph_live && blocks && ph.kind == 1) {                        // rows of nodes 2 k, 2 k + 1 out of the transition blocks / the identity
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ni = 2 * ph.k + (s_row[i] >> 4), j = s_j[i];
+                const bool valid = ni < nn, diag = ni == j;
+                const uint32_t e = static_cast<uint32_t>(ni * (nn - 1) + (j < ni ? j : j - 1));
+                const u32x4 vt = __builtin_amdgcn_raw_buffer_load_b128(ph_rs, (valid && !diag) ? e * 1024u + s_boff[i] : kOOB, 0, 0);
+                const u32x4 vi = __builtin_amdgcn_raw_buffer_load_b128(rs_ident, (valid && diag) ? s_boff[i] : kOOB, 0, 0);
+                dst[i] = vt | vi;                                       // one of the two is zeros (out of range)
+            }
+        } else if (ph_live) {
             const uint32_t koff = static_cast<uint32_t>(ph.k) * 128u * S;          // 32 rows
 #pragma unroll
             for (int i = 0; i < 2; ++i) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(ph_rs, s_goff[i] + koff, 0, 0);
@@ -676,7 +717,7 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
 #pragma unroll 1
         for (int l = L; l >= 1; --l) {
             const float sA = hx2_scale_of(st_b[L + l]), sP = hx2_scale_of(st_b[l - 1]);
-            const bool want_gA = p.gadj[l - 1] != nullptr;
+            const bool want_gA = want_c(l);
             hop_i = L - l;
             STAMP(0);
 
@@ -709,6 +750,19 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
                 STAMP(1);
                 // C layout: column (lane & 15) = s = 16 n + li, rows t = 16 w + 4 lq + r: g_adj[s][t .. t + 3] as one 16-byte store
                 const float k = hx2_inv(sP) * inv_sy;
+                if (blocks) {
+                    // tile (s-tile n, this wave's t-tile) = block (i = n, j = wave) of g_A: rows r = li, columns 4 lq .. of g_trans[l-1][b, e(n, wave)] — one
+                    // contiguous KiB per store instruction; the diagonal block adds to the identity's gradient
+                    const bool st = p.gtrans[l - 1] != nullptr;
+                    const auto rgt = __builtin_amdgcn_make_buffer_rsrc(st ? p.gtrans[l - 1] + static_cast<int64_t>(b) * C * 256 : const_cast<float*>(p.h0), 0, st ? C * 1024 : 0, 0x00020000);
+#pragma unroll
+                    for (int n = 0; n < NTS; ++n)
+                        if (n < NW) {
+                            const f32x4 v = accc[n] * k;
+                            if (n == wave) gI_acc += v;
+                            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rgt, voff_blk, (n * (nn - 1) + (wave < n ? wave : wave - 1)) * 1024, 0);
+                        }
+                } else {
                 const auto rga = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.gadj[l - 1]) + static_cast<int64_t>(b) * SSb, 0, static_cast<int>(SSb), 0x00020000);
                 const uint32_t go_lane = static_cast<uint32_t>(li * S + t0w) * 4u;
 #pragma unroll
@@ -717,6 +771,7 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
                         const f32x4 v = accc[n] * k;
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rga, go_lane + static_cast<uint32_t>(n) * 64u * S, 0, 0);
                     }
+                }
             }
             STAMP(2);
             // ---------------- (d): gH^l-1^T tile [t in wave's tile][all c] = sum_s A_l^T[t][s] Y[c][s]
@@ -758,6 +813,17 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
             }
         }
     }
+    if (blocks && p.gident_ws) {                                        // this workgroup's share of d loss / d identity: the waves' sums added in wave order
+        lds_barrier();
+        float* red = reinterpret_cast<float*>(ring);                    // [NW][16][16]
+        *reinterpret_cast<f32x4*>(red + wave * 256 + li * 16 + 4 * lq) = gI_acc;
+        lds_barrier();
+        if (tid < 256) {
+            float sum = 0.f;
+            for (int w = 0; w < NW; ++w) sum += red[w * 256 + tid];
+            p.gident_ws[static_cast<int64_t>(blockIdx.x) * 256 + tid] = sum;
+        }
+    }
 }
 
 size_t fwd_h_lds(int nks, int ntc, int S) {
@@ -784,10 +850,18 @@ size_t bwd_h_lds(int nks, int ntc, int S) {
 
 }  // namespace
 
+int prop_h_grid(int B) { return B < num_cus() ? B : num_cus(); }
+bool prop_bwd_h_shape_ok(int C, int S) {
+    return S % 16 == 0 && S >= 16 && S <= 160 && C <= 96 && bwd_h_lds((S + 31) / 32, (C + 15) / 16, S) <= 160 * 1024;
+}
+
 bool prop_bwd_h_supported(const PropBwdH& p) {
+    if (p.identity && (p.dd != 16 || p.C != (p.S / 16) * (p.S / 16 - 1))) return false;
     if (p.S % 16 != 0 || p.S > 160 || p.C > 96 || p.S < 16 || p.dd < 1 || !p.stats || !p.hsave || !p.gH || !p.gout) return false;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    for (int l = 0; l < p.L; ++l) if (!al16(p.adj[l]) || !al16(p.gadj[l])) return false;
+    for (int l = 0; l < p.L; ++l)
+        if (p.identity ? (!al16(p.trans[l]) || !al16(p.gtrans[l])) : (!al16(p.adj[l]) || !al16(p.gadj[l]))) return false;
+    if (p.identity && !al16(p.identity)) return false;
     if (!al16(p.h0) || (p.h0_bs % 4) != 0 || !al16(p.hsave) || !al16(p.gH)) return false;
     const int nks = (p.S + 31) / 32, ntc = (p.C + 15) / 16;
     return bwd_h_lds(nks, ntc, p.S) <= 160 * 1024;
@@ -798,26 +872,32 @@ int prop_bwd_h(const PropBwdH& p, hipStream_t st) {
     const int nks = (p.S + 31) / 32, ntc = (p.C + 15) / 16, nw = p.S / 16;
     const size_t lds = bwd_h_lds(nks, ntc, p.S);
     const int grid = p.B < num_cus() ? p.B : num_cus();
-#define CALL_B(K_, N_)                                                                                                                  \
+#define CALL_B(K_, N_, X_)                                                                                                              \
     do {                                                                                                                                \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_bwd_h<K_, N_>),                     \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_bwd_h<K_, N_, X_>),                 \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));             \
-        hipLaunchKernelGGL((k_propagate_bwd_h<K_, N_>), dim3(static_cast<unsigned>(grid)), dim3(64 * nw), lds, st, p);                  \
+        hipLaunchKernelGGL((k_propagate_bwd_h<K_, N_, X_>), dim3(static_cast<unsigned>(grid)), dim3(64 * nw), lds, st, p);              \
     } while (0)
+    if (p.identity) {                                                   // block mode: S = 16 n, C = n (n - 1): one (NKS, NTC) per n
+        switch (nw) { case 2: CALL_B(1, 1, true); break; case 3: case 4: CALL_B(2, 1, true); break; case 5: case 6: CALL_B(3, 2, true); break;
+                      case 7: CALL_B(4, 3, true); break; case 8: CALL_B(4, 4, true); break; case 9: CALL_B(5, 5, true); break; default: return RECON_ERR_UNSUPPORTED; }
+    } else {
 #define CALL_BN(K_)                                                                                                                     \
-    switch (ntc) { case 1: CALL_B(K_, 1); break; case 2: CALL_B(K_, 2); break; case 3: CALL_B(K_, 3); break; case 4: CALL_B(K_, 4); break; \
-                   case 5: CALL_B(K_, 5); break; default: CALL_B(K_, 6); break; }
+    switch (ntc) { case 1: CALL_B(K_, 1, false); break; case 2: CALL_B(K_, 2, false); break; case 3: CALL_B(K_, 3, false); break; case 4: CALL_B(K_, 4, false); break; \
+                   case 5: CALL_B(K_, 5, false); break; default: CALL_B(K_, 6, false); break; }
     switch (nks) { case 1: CALL_BN(1); break; case 2: CALL_BN(2); break; case 3: CALL_BN(3); break; case 4: CALL_BN(4); break; default: CALL_BN(5); break; }
 #undef CALL_BN
+    }
 #undef CALL_B
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
 }
 
 bool prop_fwd_h_supported(const PropK& p) {
+    if (p.identity && (p.dd != 16 || p.C != (p.S / 16) * (p.S / 16 - 1) || (reinterpret_cast<uintptr_t>(p.identity) & 15) != 0)) return false;
     if (p.S % 16 != 0 || p.S > 160 || p.C > 96 || p.S < 16 || p.dd < 1) return false;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    for (int l = 0; l < p.L; ++l) if (!al16(p.adj[l])) return false;
+    for (int l = 0; l < p.L; ++l) if (!al16(p.identity ? p.trans[l] : p.adj[l])) return false;
     if (!al16(p.h0) || (p.h0_bs % 4) != 0 || (p.hsave && !al16(p.hsave))) return false;
     const int nks = (p.S + 31) / 32, ntc = (p.C + 15) / 16;
     return fwd_h_lds(nks, ntc, p.S) <= 160 * 1024;
@@ -828,17 +908,23 @@ int prop_fwd_h(const PropK& p, hipStream_t st) {
     const int nks = (p.S + 31) / 32, ntc = (p.C + 15) / 16, nw = p.S / 16;
     const size_t lds = fwd_h_lds(nks, ntc, p.S);
     const int grid = p.B < num_cus() ? p.B : num_cus();
-#define CALL_H(K_, N_)                                                                                                                  \
+#define CALL_H(K_, N_, X_)                                                                                                              \
     do {                                                                                                                                \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_fwd_h<K_, N_>),                     \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_fwd_h<K_, N_, X_>),                 \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));             \
-        hipLaunchKernelGGL((k_propagate_fwd_h<K_, N_>), dim3(static_cast<unsigned>(grid)), dim3(64 * nw), lds, st, p);                  \
+        hipLaunchKernelGGL((k_propagate_fwd_h<K_, N_, X_>), dim3(static_cast<unsigned>(grid)), dim3(64 * nw), lds, st, p);              \
     } while (0)
+    if (p.identity) {                                                   // block mode: S = 16 n, C = n (n - 1): one (NKS, NTC) per n
+        switch (nw) { case 2: CALL_H(1, 1, true); break; case 3: case 4: CALL_H(2, 1, true); break; case 5: case 6: CALL_H(3, 2, true); break;
+                      case 7: CALL_H(4, 3, true); break; case 8: CALL_H(4, 4, true); break; case 9: CALL_H(5, 5, true); break; case 10: CALL_H(5, 6, true); break;
+                      default: return RECON_ERR_UNSUPPORTED; }
+    } else {
 #define CALL_HN(K_)                                                                                                                     \
-    switch (ntc) { case 1: CALL_H(K_, 1); break; case 2: CALL_H(K_, 2); break; case 3: CALL_H(K_, 3); break; case 4: CALL_H(K_, 4); break; \
-                   case 5: CALL_H(K_, 5); break; default: CALL_H(K_, 6); break; }
+    switch (ntc) { case 1: CALL_H(K_, 1, false); break; case 2: CALL_H(K_, 2, false); break; case 3: CALL_H(K_, 3, false); break; case 4: CALL_H(K_, 4, false); break; \
+                   case 5: CALL_H(K_, 5, false); break; default: CALL_H(K_, 6, false); break; }
     switch (nks) { case 1: CALL_HN(1); break; case 2: CALL_HN(2); break; case 3: CALL_HN(3); break; case 4: CALL_HN(4); break; default: CALL_HN(5); break; }
 #undef CALL_HN
+    }
 #undef CALL_H
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;

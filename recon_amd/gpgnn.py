@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .propagation import (build_block_adjacency, propagate, make_start_embedding, make_start_entity_embeddings, get_head_indices,
+from .propagation import (build_block_adjacency, propagate, propagate_blocks, make_start_embedding, make_start_entity_embeddings, get_head_indices,
                           get_tail_indices)
 
 
@@ -72,15 +72,16 @@ class GPGNN(nn.Module):
             T = self.representation_to_adj(rnn_result)
             if p['non-linear'] != "linear":
                 T = getattr(F, p['non-linear'])(T)
-            adjs = [build_block_adjacency(T, self.identity_transformation, n)] * L
+            Ts = [T] * L
         else:                                                            # :238-259: one per hop, `non-linear1` on it
-            adjs = []
+            Ts = []
             for i in range(L):
                 T = self.representation_to_adj[i](rnn_result)
                 if p['non-linear1'] != "linear":
                     T = getattr(F, p['non-linear1'])(T)
-                adjs.append(build_block_adjacency(T, self.identity_transformation, n))
-        relation = propagate(adjs, self.start_embedding, p['non-linear1'], self.head_indices[0], self.tail_indices[0])   # :260-274
+                Ts.append(T)
+        # :240-274 — block adjacency + propagation; fused (A_l never materialised) where the kernels allow, else build_block_adjacency + propagate
+        relation = propagate_blocks(Ts, self.identity_transformation, n, self.start_embedding, p['non-linear1'], self.head_indices[0], self.tail_indices[0])
         return self.linear3(relation).view(B * self.MAX_EDGES_PER_GRAPH, -1)
 
 
@@ -163,11 +164,11 @@ class RECON_EAC(GPGNN):
                                           max_occurred_entity_in_batch_pos, self.start_embedding, max_num_nodes=n)     # :365
         rnn_result = self.encode(sentence_input, entity_markers)
         B = rnn_result.size(0)
-        adjs = []
+        Ts = []
         for i in range(L):                                               # :447-466
             T = self.representation_to_adj[i](rnn_result)
             if p['non-linear1'] != "linear":
                 T = getattr(F, p['non-linear1'])(T)
-            adjs.append(build_block_adjacency(T, self.identity_transformation, n))
-        relation = propagate(adjs, h0, p['non-linear1'], self.head_indices[0], self.tail_indices[0])                   # :467-484
+            Ts.append(T)
+        relation = propagate_blocks(Ts, self.identity_transformation, n, h0, p['non-linear1'], self.head_indices[0], self.tail_indices[0])     # :447-484
         return self.linear3(relation).view(B * self.MAX_EDGES_PER_GRAPH, -1)

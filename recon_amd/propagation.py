@@ -12,6 +12,7 @@ in the gfx950 kernels of csrc/prop.hip:
 No CPU path: the tensor functions require GPU tensors.
 """
 import ctypes as C
+import os
 import itertools
 
 import numpy as np
@@ -145,9 +146,9 @@ class _Propagate(torch.autograd.Function):
         hs = torch.empty(L, B, Cn, S, dtype=torch.float32, device=dev) if need else None
         parr = _ptr_array(adjs)
         args = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], parr, h0c.data_ptr(), h0_bs, head.data_ptr(),
-                             tail.data_ptr(), idx_bs, out.data_ptr(), _lib.ptr(hs), None)
+                             tail.data_ptr(), idx_bs, out.data_ptr(), _lib.ptr(hs), None, None, None)
         stats = None
-        if need and _lib.lib().recon_propagate_form(C.byref(args)) == 1:
+        if need and _lib.lib().recon_propagate_form(C.byref(args)) & 1:
             # two-term f16 kernels: the forward records per graph the max magnitudes of the states and adjacencies, the backward takes its
             # per-tensor scales from them (include/recon_hip.h: recon_prop_args.stats)
             stats = torch.empty(B, 2 * L + 1, dtype=torch.float32, device=dev)
@@ -171,9 +172,9 @@ class _Propagate(torch.autograd.Function):
         g_h = torch.empty(B, Cn, S, dtype=torch.float32, device=dev)
         parr, garr = _ptr_array(adjs), _ptr_array(g_adjs)
         fwd = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], parr, h0c.data_ptr(), h0_bs, head.data_ptr(), tail.data_ptr(),
-                            idx_bs, None, hs.data_ptr(), _lib.ptr(ctx.stats))
+                            idx_bs, None, hs.data_ptr(), None, None, _lib.ptr(ctx.stats))
         fwd.out = gout.data_ptr()      # unused by the backward; must be non-null for the argument check
-        args = _lib.PropBwdArgs(fwd, gout.data_ptr(), garr, g_h.data_ptr())
+        args = _lib.PropBwdArgs(fwd, gout.data_ptr(), garr, g_h.data_ptr(), None, None, None)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().recon_propagate_bwd(C.byref(args), _lib.current_stream()), "recon_propagate_bwd")
         g_h0 = None
@@ -200,6 +201,88 @@ def propagate(adj_list, h0, nonlinearity, head_indices, tail_indices):
             outs.append(_Propagate.apply(hs, nonlinearity, hi, ti, *[a[sl] for a in adj_list]))
         return torch.cat(outs, dim=0)
     return _Propagate.apply(h0, nonlinearity, head_indices, tail_indices, *adj_list)
+
+
+class _PropagateBlocks(torch.autograd.Function):
+    """Block adjacency + propagation in one pass (models/models.py:240-274 as the reference inlines it): the kernels read
+    A_l[b, i*2d+r, j*2d+c] = T_l[b, e(i,j), r, c] (identity on the diagonal) in place, so A_l is never written or read, and the
+    backward writes d loss / d T_l in T's own layout and sums the diagonal blocks into d loss / d identity."""
+
+    @staticmethod
+    def forward(ctx, h0, identity, act, head, tail, n, *Ts):
+        _req(h0, identity, head, tail, *Ts)
+        L = len(Ts)
+        dd = identity.shape[0]
+        B = Ts[0].shape[0]
+        S, Cn = n * dd, n * (n - 1)
+        t_shapes = [tuple(t.shape) for t in Ts]
+        Ts = [t.contiguous().view(B, Cn, dd * dd) for t in Ts]
+        identity = identity.contiguous()
+        h0c = h0.contiguous()
+        h0_bs = Cn * S if h0c.dim() == 4 else 0
+        head, tail = head.contiguous(), tail.contiguous()
+        idx_bs = Cn * dd if head.dim() == 3 and head.shape[0] > 1 else 0
+        dev = h0.device
+        out = torch.empty(B, Cn, L * dd, dtype=torch.float32, device=dev)
+        need = any(ctx.needs_input_grad)
+        hs = torch.empty(L, B, Cn, S, dtype=torch.float32, device=dev) if need else None
+        stats = torch.empty(B, 2 * L + 1, dtype=torch.float32, device=dev) if need else None
+        tarr = _ptr_array(Ts)
+        args = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], None, h0c.data_ptr(), h0_bs, head.data_ptr(), tail.data_ptr(), idx_bs,
+                             out.data_ptr(), _lib.ptr(hs), tarr, identity.data_ptr(), _lib.ptr(stats))
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().recon_propagate_fwd(C.byref(args), _lib.current_stream()), "recon_propagate_fwd (block mode)")
+        if need:
+            ctx.save_for_backward(h0c, identity, head, tail, hs, stats, *Ts)
+            ctx.meta = (B, Cn, S, L, dd, act, h0_bs, idx_bs, tuple(h0.shape), t_shapes)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        h0c, identity, head, tail, hs, stats, *Ts = ctx.saved_tensors
+        B, Cn, S, L, dd, act, h0_bs, idx_bs, h0_shape, t_shapes = ctx.meta
+        dev = gout.device
+        gout = gout.contiguous()
+        g_Ts = [torch.empty(B, Cn, dd * dd, dtype=torch.float32, device=dev) if ctx.needs_input_grad[6 + l] else None for l in range(L)]
+        g_I = torch.empty(dd, dd, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        g_h = torch.empty(B, Cn, S, dtype=torch.float32, device=dev)
+        Lb = _lib.lib()
+        ws = torch.empty(Lb.recon_propagate_identity_ws_floats(dd), dtype=torch.float32, device=dev) if g_I is not None else None
+        tarr, garr = _ptr_array(Ts), _ptr_array(g_Ts)
+        fwd = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], None, h0c.data_ptr(), h0_bs, head.data_ptr(), tail.data_ptr(), idx_bs,
+                            gout.data_ptr(), hs.data_ptr(), tarr, identity.data_ptr(), stats.data_ptr())
+        args = _lib.PropBwdArgs(fwd, gout.data_ptr(), None, g_h.data_ptr(), garr, _lib.ptr(g_I), _lib.ptr(ws))
+        with torch.cuda.device(dev):
+            _lib.check(Lb.recon_propagate_bwd(C.byref(args), _lib.current_stream()), "recon_propagate_bwd (block mode)")
+        g_h0 = None
+        if ctx.needs_input_grad[0]:
+            g_h0 = (g_h if h0_bs else g_h.sum(0)).view(h0_shape)
+        return (g_h0, g_I, None, None, None, None) + tuple(g.view(sh) if g is not None else None for g, sh in zip(g_Ts, t_shapes))
+
+
+def blocks_mode_available(B, n, dd, h0, need_grad=True):
+    """Whether propagate_blocks() runs fused (two-term f16 kernels for the forward and, when gradients are wanted, for the backward:
+    2d = 16, n <= 9 (n = 10 forward only), B within one launch)."""
+    if dd != 16 or n < 2 or n > 10 or B > _MAX_BATCH or B == 0 or os.environ.get("RECON_PROP_BLOCKS", "1") == "0":
+        return False
+    Cn, S = n * (n - 1), n * dd
+    probe = _lib.PropArgs(B, Cn, S, 1, dd, 1, None, h0.data_ptr(), Cn * S if h0.dim() == 4 else 0, None, None, 0, None, None, None, None, None)
+    form = _lib.lib().recon_propagate_form(C.byref(probe))
+    return form == 3 or (form == 1 and not need_grad)
+
+
+def propagate_blocks(T_list, identity, n, h0, nonlinearity, head_indices, tail_indices):
+    """models/models.py:240-274 in one call: T_list = L transition tensors [B, n(n-1), (2d)^2] (or [B, n-1, n, (2d)^2]) AFTER their
+    non-linearity, identity [2d, 2d]; equivalent to
+        propagate([build_block_adjacency(T, identity, n) for T in T_list], h0, nonlinearity, head_indices, tail_indices)
+    and computed exactly like that wherever the fused kernels do not apply (2d != 16, n > 10, batches above one launch)."""
+    if nonlinearity not in _lib.ACT:
+        raise NotImplementedError(nonlinearity)
+    B, dd = T_list[0].shape[0], identity.shape[0]
+    need_grad = torch.is_grad_enabled() and (identity.requires_grad or h0.requires_grad or any(T.requires_grad for T in T_list))
+    if not blocks_mode_available(B, n, dd, h0, need_grad):
+        return propagate([build_block_adjacency(T, identity, n) for T in T_list], h0, nonlinearity, head_indices, tail_indices)
+    return _PropagateBlocks.apply(h0, identity, nonlinearity, head_indices, tail_indices, n, *T_list)
 
 
 # ------------------------------------------------------------------------------- P4

@@ -140,6 +140,58 @@ def test_propagation_vs_oracle(n, d, L, B, act, per_batch, form, monkeypatch):
         close(gh_h, gh_r, atol=1e-5, what="g_h0")
 
 
+@pytest.mark.parametrize("n,L,B,act,per_batch,tied", [(9, 3, 7, "relu", True, False), (9, 3, 300, "relu", False, False), (4, 2, 5, "tanh", True, False),
+                                                       (10, 1, 3, "linear", True, False), (6, 3, 4, "relu", True, True)])
+def test_propagate_blocks_matches_unfused(n, L, B, act, per_batch, tied):
+    """propagate_blocks (models/models.py:240-274 in one call: the kernels read A_l out of the transition tensors in place and write
+    d loss / d T in T's layout) against build_block_adjacency + propagate: the SAME arithmetic on the same values — forward, d T and
+    d h0 bit-equal; d identity to round-off (per-workgroup partial sums instead of the stand-alone reduction) — and against the oracle."""
+    from recon_amd.propagation import (build_block_adjacency, propagate, propagate_blocks, blocks_mode_available, make_start_embedding,
+                                       get_head_indices, get_tail_indices)
+    d_ = dev()
+    d = 8
+    C, S, dd = n * (n - 1), 2 * d * n, 2 * d
+    g = torch.Generator().manual_seed(n * 10 + L)
+    Ts = [torch.relu(torch.randn(B, C, dd * dd, generator=g)) * 0.1 for _ in range(1 if tied else L)]
+    ident = torch.eye(dd) + 0.05 * torch.randn(dd, dd, generator=g)
+    tmpl = torch.from_numpy(make_start_embedding(n, d)).float()
+    h0 = (torch.randn(B, C, S, 1, generator=g) * tmpl) if per_batch else tmpl
+    head = torch.from_numpy(get_head_indices(n, d, bs=1)[0])
+    tail = torch.from_numpy(get_tail_indices(n, d, bs=1)[0])
+    Gr = torch.randn(B, C, dd * L, generator=g)
+    assert blocks_mode_available(B, n, dd, h0.to(d_)) == (n <= 9)          # n = 10: the backward's LDS image does not fit: unfused path, same answers
+
+    def run(device, fused, dt=torch.float32):
+        Tl = [t.clone().to(device=device, dtype=dt).requires_grad_(True) for t in Ts]
+        tl = Tl * L if tied else Tl
+        I = ident.clone().to(device=device, dtype=dt).requires_grad_(True)
+        h = h0.clone().to(device=device, dtype=dt).requires_grad_(per_batch)
+        if fused:
+            out = propagate_blocks(tl, I, n, h, act, head.to(device), tail.to(device))
+        elif device == "cpu":
+            out = O.propagate([O.build_block_adjacency(t, I, n) for t in tl], h, act, head, tail)
+        else:
+            out = propagate([build_block_adjacency(t, I, n) for t in tl], h, act, head.to(device), tail.to(device))
+        (out * Gr.to(device=device, dtype=dt)).sum().backward()
+        return out.detach(), [t.grad for t in Tl], I.grad, h.grad
+    out_f, gT_f, gI_f, gh_f = run(d_, True)
+    out_u, gT_u, gI_u, gh_u = run(d_, False)
+    assert torch.equal(out_f, out_u)
+    for a, b in zip(gT_f, gT_u):
+        if tied:
+            close(a, b, atol=1e-6, rel_to_max=1e-6, what="g_T (tied: L gradients summed by autograd vs in one buffer)")
+        else:
+            assert torch.equal(a, b)
+    if per_batch:
+        assert torch.equal(gh_f, gh_u)
+    close(gI_f, gI_u, atol=1e-5, rel_to_max=1e-5, what="g_identity fused vs unfused")
+    out_r, gT_r, gI_r, gh_r = run("cpu", False, torch.float64)
+    close(out_f, out_r.float(), what="out vs oracle")
+    close(gI_f, gI_r.float(), atol=1e-5, what="g_identity vs oracle")
+    for a, b in zip(gT_f, gT_r):
+        close(a, b.float(), atol=1e-5, what="g_T vs oracle")
+
+
 def test_start_entity_embeddings_golden():
     from recon_amd.propagation import make_start_entity_embeddings
     g = load_golden("prop3_start_entity")

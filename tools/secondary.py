@@ -32,7 +32,8 @@ def propagation(n, B=1024, d=8, L=3, iters=10, with_backward=True):
     """cfg 3b: GP-GNN block form (models/models.py:240-274), 2d = 16, L = 3 untied, per-batch h0 from P4's template, relu.
     Forward (adjacency prebuilt, inference), forward with the states saved, and block adjacency + propagation forward + backward.
     Bytes: 4 (L B S^2 + B C S + B C 2d L); flops 2 B S^2 C L."""
-    from recon_amd.propagation import build_block_adjacency, propagate, make_start_embedding, get_head_indices, get_tail_indices
+    from recon_amd.propagation import (build_block_adjacency, propagate, propagate_blocks, blocks_mode_available, make_start_embedding,
+                                       get_head_indices, get_tail_indices)
     dv = torch.device("cuda:0")
     C, S, dd = n * (n - 1), 2 * d * n, 2 * d
     g = torch.Generator().manual_seed(0)
@@ -70,6 +71,19 @@ def propagation(n, B=1024, d=8, L=3, iters=10, with_backward=True):
     if with_backward:
         tb = _time(fwd_bwd, max(2, iters // 2))
         res["fwd_bwd_incl_adjacency_ms"] = tb * 1e3
+        if blocks_mode_available(B, n, dd, h0):
+            # models/models.py:240-274 in one call: A_l read out of the transition tensors in place, d T written in T's layout
+
+            def fused():
+                for t in Ts + [ident, h0]:
+                    t.grad = None
+                propagate_blocks(Ts, ident, n, h0, "relu", head, tail).backward(G)
+
+            def fused_fwd():
+                with torch.no_grad():
+                    propagate_blocks(Ts, ident, n, h0, "relu", head, tail)
+            res["fused_blocks_fwd_ms"] = _time(fused_fwd, iters) * 1e3
+            res["fused_blocks_fwd_bwd_ms"] = _time(fused, max(2, iters // 2)) * 1e3
     del Ts, adjs, h0, G
     torch.cuda.empty_cache()
     return res
