@@ -431,6 +431,14 @@ int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* args, recon_stream_t stream)
 int recon_sgemm(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                 int32_t b_is_nk, float* C, int32_t ldc, recon_stream_t stream);
 
+/* The same kernels with either operand in either orientation — A is [M,K] (a_is_km == 0) or [K,M]; B is [K,N] (b_is_nk == 0) or [N,K] —
+ * and split-K (fixed-order second pass) when `workspace` (recon_sgemm_ex_workspace_floats() floats, may be 0) is given: what the
+ * models' dense products outside the attention layer run on (`entity_embeddings.mm(self.W_entities)`, GAT/models.py:177, and the
+ * gradients of it), in place of the library GEMM behind torch.mm. */
+size_t recon_sgemm_ex_workspace_floats(int32_t M, int32_t N, int32_t K);
+int recon_sgemm_ex(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, int32_t a_is_km, const float* B, int32_t ldb,
+                   int32_t b_is_nk, float* C, int32_t ldc, float* workspace, recon_stream_t stream);
+
 /* Small dense products (tens of MFLOP), plain fp32 FMAs with K split 16 ways inside a workgroup and a fixed-order combine:
  *     C[M,N] = op(A) * op(B);  A is [M,K] (a_is_km == 0) or [K,M]; B is [K,N] (b_is_nk == 0) or [N,K].
  * Replaces `relation_embed.mm(self.W)` (GAT/models.py:75) and its two gradient products, which are launch / latency bound on tile GEMMs. */

@@ -141,6 +141,9 @@ SYMBOLS = [
     ("recon_gcn_b16_bwd_partial_floats", C.c_size_t, [C.c_int32] * 4),
     ("recon_gcn_b16_bwd", C.c_int, [C.POINTER(GcnB16BwdArgs), C.c_void_p]),
     ("recon_sgemm_small_workspace_floats", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    ("recon_sgemm_ex_workspace_floats", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    ("recon_sgemm_ex", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32,
+                                 c_f32p, C.c_void_p]),
     ("recon_sgemm_small", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32,
                                     c_f32p, C.c_void_p]),
     ("recon_sgemm", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32,

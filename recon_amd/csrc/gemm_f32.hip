@@ -733,6 +733,22 @@ extern "C" int recon_sgemm_small(int32_t M, int32_t N, int32_t K, const float* A
     return RECON_OK;
 }
 
+extern "C" size_t recon_sgemm_ex_workspace_floats(int32_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int sk = recon::gemm_pick_split_k(M, N, K);
+    return sk > 1 ? static_cast<size_t>(sk) * M * N : 0;
+}
+
+extern "C" int recon_sgemm_ex(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, int32_t a_is_km, const float* B, int32_t ldb,
+                              int32_t b_is_nk, float* C, int32_t ldc, float* workspace, recon_stream_t stream) {
+    using namespace recon;
+    if (M < 0 || N < 0 || K < 0) return RECON_ERR_INVALID;
+    if (M == 0 || N == 0) return RECON_OK;
+    const int sk = workspace ? gemm_pick_split_k(M, N, K) : 1;
+    return gemm_f32(M, N, K, plain_operand(A, lda), a_is_km == 0, plain_operand(B, ldb), b_is_nk != 0, plain_output(C, ldc), sk,
+                    sk > 1 ? workspace : nullptr, as_stream(stream));
+}
+
 extern "C" int recon_sgemm(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                            int32_t b_is_nk, float* C, int32_t ldc, recon_stream_t stream) {
     using namespace recon;

@@ -166,21 +166,62 @@ class _SmallMM(torch.autograd.Function):
 
 
 class _ThinWeightMM(torch.autograd.Function):
-    """A @ B for a tall A [rows, K] and a small weight B [K, N] (`entity_embeddings.mm(self.W_entities)`, GAT/models.py:177): forward and
-    g_A on torch.mm; the weight gradient A^T g — a K x N output over `rows` terms, for which the library picks a 32 x 32 x 256 tile kernel
-    that takes 98 us at 14 541 x 50 x 200 — on recon_sgemm_small with the long dimension cut over workgroups (fixed-order combine)."""
+    """A @ B for a tall A [rows, K] and a small weight B [K, N] (`entity_embeddings.mm(self.W_entities)`, GAT/models.py:177).  Forward and
+    g_A = g B^T on the fp32 matrix-core GEMM of this library (recon_sgemm_ex); the weight gradient A^T g — a K x N output over `rows`
+    terms, for which a library GEMM picks a 32 x 32 x 256 tile kernel that takes 98 us at 14 541 x 50 x 200 — on recon_sgemm_small
+    with the long dimension cut over workgroups (fixed-order combine)."""
 
     @staticmethod
     def forward(ctx, A, B):
+        _require_gpu_f32(A, B)
+        A, B = A.contiguous(), B.contiguous()
         ctx.save_for_backward(A, B)
-        return torch.mm(A, B)
+        return _sgemm_ex(A, False, B, False)
 
     @staticmethod
     def backward(ctx, g):
         A, B = ctx.saved_tensors
-        gA = torch.mm(g, B.t()) if ctx.needs_input_grad[0] else None
-        gB = _sgemm_small(A.contiguous(), True, g.contiguous(), False) if ctx.needs_input_grad[1] else None
+        g = g.contiguous()
+        gA = _sgemm_ex(g, False, B, True) if ctx.needs_input_grad[0] else None
+        gB = _sgemm_small(A, True, g, False) if ctx.needs_input_grad[1] else None
         return gA, gB
+
+
+class _GemmMM(torch.autograd.Function):
+    """torch.mm semantics for fp32 GPU matrices of any size on this library's fp32 matrix-core GEMM (recon_sgemm_ex: exact fp32
+    v_mfma_f32_32x32x2_f32 tiles, split-K with a fixed-order second pass where the output has few tiles), forward and both gradients."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        _require_gpu_f32(A, B)
+        A, B = A.contiguous(), B.contiguous()
+        ctx.save_for_backward(A, B)
+        return _sgemm_ex(A, False, B, False)
+
+    @staticmethod
+    def backward(ctx, g):
+        A, B = ctx.saved_tensors
+        g = g.contiguous()
+        gA = _sgemm_ex(g, False, B, True) if ctx.needs_input_grad[0] else None        # g B^T
+        gB = _sgemm_ex(A, True, g, False) if ctx.needs_input_grad[1] else None        # A^T g
+        return gA, gB
+
+
+def _sgemm_ex(A, a_is_km, B, b_is_nk):
+    """op(A) op(B) on recon_sgemm_ex; A, B contiguous 2-d fp32."""
+    M, K = (A.shape[1], A.shape[0]) if a_is_km else A.shape
+    N = B.shape[0] if b_is_nk else B.shape[1]
+    out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    if M and N:
+        if K == 0:
+            return out.zero_()
+        L = _lib.lib()
+        nws = L.recon_sgemm_ex_workspace_floats(M, N, K)
+        ws = torch.empty(nws, dtype=torch.float32, device=A.device) if nws else None
+        with _on_device(A.device):
+            _lib.check(L.recon_sgemm_ex(M, N, K, A.data_ptr(), A.shape[1], 1 if a_is_km else 0, B.data_ptr(), B.shape[1],
+                                        1 if b_is_nk else 0, out.data_ptr(), N, _lib.ptr(ws), _lib.current_stream()), "recon_sgemm_ex")
+    return out
 
 
 def _sgemm_small(A, a_is_km, B, b_is_nk):
@@ -203,13 +244,17 @@ _THIN_WEIGHT_ELEMS = 1 << 16        # weights up to 64 k elements: their gradien
 
 
 def small_mm(A, B):
-    """torch.mm semantics; fp32 GPU products below ~0.2 GFLOP run on recon_sgemm (see _SmallMM), the rest on torch.mm."""
+    """torch.mm semantics for the models' dense products outside the attention layer; fp32 GPU matrices never reach a library GEMM:
+    products below ~0.2 GFLOP run on recon_sgemm_small (_SmallMM), tall-times-small-weight ones on _ThinWeightMM, everything else on
+    the fp32 matrix-core GEMM (_GemmMM).  Other dtypes / devices: torch.mm."""
     if (A.is_cuda and A.dtype == torch.float32 and B.dtype == torch.float32 and A.dim() == 2 and B.dim() == 2
             and 0 < A.shape[1] == B.shape[0] and 2.0 * A.shape[0] * A.shape[1] * B.shape[1] < _SMALL_MM_FLOP):
         return _SmallMM.apply(A, B)
     if (A.is_cuda and A.dtype == torch.float32 and B.dtype == torch.float32 and A.dim() == 2 and B.dim() == 2 and A.shape[1] == B.shape[0]
             and 0 < B.shape[0] * B.shape[1] <= _THIN_WEIGHT_ELEMS and A.shape[0] >= 2048):
         return _ThinWeightMM.apply(A, B)
+    if A.is_cuda and A.dtype == torch.float32 and B.dtype == torch.float32 and A.dim() == 2 and B.dim() == 2 and A.shape[1] == B.shape[0]:
+        return _GemmMM.apply(A, B)
     return torch.mm(A, B)
 
 

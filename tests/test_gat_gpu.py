@@ -574,6 +574,23 @@ def test_thin_weight_mm(rows, K, N):
     close(Bd.grad, (A.double().t() @ G.double()).float(), atol=1e-4, rel_to_max=2e-6, what="g_B")
 
 
+@pytest.mark.parametrize("M,K,N", [(3000, 700, 900), (14541, 200, 400), (513, 1000, 77), (100, 4096, 2000), (1, 5000, 3000)])
+def test_large_mm_runs_on_the_library_free_path(M, K, N):
+    """small_mm above its small / thin-weight classes: this library's fp32 matrix-core GEMM (recon_sgemm_ex), never torch.mm — values and
+    both gradients against float64 at fp32 round-off of a K-term (gradients: M- / N-term) dot product."""
+    from recon_amd.gat_layers import small_mm
+    d = dev()
+    g = torch.Generator().manual_seed(M + N)
+    A, B, G = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g), torch.randn(M, N, generator=g)
+    Ad, Bd = A.to(d).requires_grad_(True), B.to(d).requires_grad_(True)
+    out = small_mm(Ad, Bd)
+    assert out.grad_fn.name().startswith(("_GemmMM", "_ThinWeightMM", "_SmallMM"))
+    (out * G.to(d)).sum().backward()
+    close(out, (A.double() @ B.double()).float(), atol=1e-4, rel_to_max=1e-5, what="A B")
+    close(Ad.grad, (G.double() @ B.double().t()).float(), atol=1e-4, rel_to_max=1e-5, what="g_A")
+    close(Bd.grad, (A.double().t() @ G.double()).float(), atol=1e-4, rel_to_max=1e-5, what="g_B")
+
+
 def _hub_graph(N, degs, seed, src_hubs=()):
     """Destination i gets degs[i] in-edges (0 for i >= len(degs)), sources uniform except that node j is the source of exactly c
     edges for every (j, c) in src_hubs; columns shuffled."""
