@@ -24,8 +24,15 @@ enum { GEMM_EPI_NONE = 0, GEMM_EPI_ELU = 1 };
 // projection's epilogue — 104 values per lane, two waves per SIMD in lockstep — at 18 k of a wave's 117 k cycles).  expm1f is a
 // ~40-instruction library routine.
 __device__ __forceinline__ float expm1_nonpos(float v) { return __expf(v) - 1.f; }
+// The exact-fp32 family keeps expm1's RELATIVE accuracy near zero as well (F.elu of the reference is expm1): below 1/16 the series
+// v + v^2/2 + v^3/6 + v^4/24 (truncation <= v^4/120 relative = 1.3e-7), the fast form elsewhere (no cancellation there).
+__device__ __forceinline__ float expm1_nonpos_exact(float v) {
+    const float poly = v * fmaf(v, fmaf(v, fmaf(v, 1.f / 24.f, 1.f / 6.f), 0.5f), 1.f);
+    return v > -0.0625f ? poly : __expf(v) - 1.f;
+}
+template <bool EXACT = false>
 __device__ __forceinline__ float gemm_epilogue(float v, int epi) {
-    if (epi == GEMM_EPI_ELU) return v > 0.f ? v : expm1_nonpos(v);
+    if (epi == GEMM_EPI_ELU) return v > 0.f ? v : (EXACT ? expm1_nonpos_exact(v) : expm1_nonpos(v));
     return v;
 }
 

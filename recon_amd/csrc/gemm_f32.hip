@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? (VEC == 1 ? 3 : 4) : 1) k
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = rbase + (r & 3) + 8 * (r >> 2);
-                        if (row < p.M) cb[static_cast<int64_t>(row) * p.C.S1 + col] = gemm_epilogue(acc[i][j][r], p.epilogue);
+                        if (row < p.M) cb[static_cast<int64_t>(row) * p.C.S1 + col] = gemm_epilogue<true>(acc[i][j][r], p.epilogue);
                     }
                 }
             }
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(NT, (TM * TN <= 4) ? (VEC == 1 ? 3 : 4) : 1) k
                 const int row = m0 + mb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (row >= p.M) continue;
                 if (p.partial) base[static_cast<int64_t>(row) * p.N + coff] = acc[i][j][r];
-                else base[out_row_off(p.C, row) + coff] = gemm_epilogue(acc[i][j][r], p.epilogue);
+                else base[out_row_off(p.C, row) + coff] = gemm_epilogue<true>(acc[i][j][r], p.epilogue);
             }
         }
     }
@@ -366,18 +366,18 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_f32_n208(const GemmArgs p) {
                     if (col < p.N) {
                         const int64_t coff = p.partial ? col : minor_off(p.C.Dseg, p.C.Sseg, col);
                         *reinterpret_cast<float4*>(crow + coff) =
-                            make_float4(gemm_epilogue(acc[i][4 * q][r], epi), gemm_epilogue(acc[i][4 * q + 1][r], epi),
-                                        gemm_epilogue(acc[i][4 * q + 2][r], epi), gemm_epilogue(acc[i][4 * q + 3][r], epi));
+                            make_float4(gemm_epilogue<true>(acc[i][4 * q][r], epi), gemm_epilogue<true>(acc[i][4 * q + 1][r], epi),
+                                        gemm_epilogue<true>(acc[i][4 * q + 2][r], epi), gemm_epilogue<true>(acc[i][4 * q + 3][r], epi));
                     }
                 } else {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj)
                         if (col + jj < p.N)
-                            crow[p.partial ? col + jj : minor_off(p.C.Dseg, p.C.Sseg, col + jj)] = gemm_epilogue(acc[i][4 * q + jj][r], epi);
+                            crow[p.partial ? col + jj : minor_off(p.C.Dseg, p.C.Sseg, col + jj)] = gemm_epilogue<true>(acc[i][4 * q + jj][r], epi);
                 }
             }
             const int col = n0 + 192 + li;
-            if (col < p.N) crow[p.partial ? col : minor_off(p.C.Dseg, p.C.Sseg, col)] = gemm_epilogue(acc[i][12][r], epi);
+            if (col < p.N) crow[p.partial ? col : minor_off(p.C.Dseg, p.C.Sseg, col)] = gemm_epilogue<true>(acc[i][12][r], epi);
         }
 }
 
@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
         s0 += pz[z * MN + idx]; s1 += pz[(z + 1) * MN + idx]; s2 += pz[(z + 2) * MN + idx]; s3 += pz[(z + 3) * MN + idx];
     }
     for (; z < splits; ++z) s0 += pz[z * MN + idx];
-    C.base[bz * c_bs + out_row_off(C, row) + minor_off(C.Dseg, C.Sseg, col)] = gemm_epilogue((s0 + s1) + (s2 + s3), epilogue);
+    C.base[bz * c_bs + out_row_off(C, row) + minor_off(C.Dseg, C.Sseg, col)] = gemm_epilogue<true>((s0 + s1) + (s2 + s3), epilogue);
 }
 
 // transposing form: out(row n, col m) = epilogue(sum_z partial[z][m][n]); 32 x 32 tiles through LDS so that both the
@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_t(const float* __restrict
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + ty + 8 * i, m = m0 + tx;
         if (m < M && n < N)
-            C.base[bz * c_bs + out_row_off(C, n) + minor_off(C.Dseg, C.Sseg, m)] = gemm_epilogue(tile[tx][ty + 8 * i], epilogue);
+            C.base[bz * c_bs + out_row_off(C, n) + minor_off(C.Dseg, C.Sseg, m)] = gemm_epilogue<true>(tile[tx][ty + 8 * i], epilogue);
     }
 }
 

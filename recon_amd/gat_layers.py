@@ -491,9 +491,9 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         elif keep_max is None:                                  # explicit factors without a bound: one host read (tests)
             keep_max = float(keep.max()) if aux is not None and keep.numel() else 1.0
         args = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split, aux, keep_max, idx_slot)
-        graph.reserve_hub_ws(F_, R, H)
+        gstruct, _hub_keep = graph.call_struct(F_, R, H)
         with _on_device(dev):
-            _lib.check(L.recon_gat_atp_fwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_atp_fwd")
+            _lib.check(L.recon_gat_atp_fwd(C.byref(gstruct), C.byref(args), _lib.current_stream()), "recon_gat_atp_fwd")
         if need_grad:
             ctx.save_for_backward(x, ee, a, a2, keep, out, ws)
             ctx.ptrs = (u, c_node, c_rel, V, sigma, Z, Zk, a_split, aux)
@@ -531,13 +531,13 @@ class _GATHeadsATPFunction(torch.autograd.Function):
                         ctx.keep_max, ctx.idx_slot)
         args = _lib.GatAtpBwdArgs(fwd, grad_out.data_ptr(), grad_out.shape[1], g_h, g_V, g_sigma, Gxs, gxd, Gs, g_u, q, partial, partial2,
                                   _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2), gh_split)
-        graph.reserve_hub_ws(F_, R, H)
+        gstruct, _hub_keep = graph.call_struct(F_, R, H)
         sync = _WEIGHT_GRAD_SYNC if g_a is not None else None
         with _on_device(dev):
             if sync is not None:
                 # PREPARE -> WEIGHTS (+ split-K sum: g_a = G) -> [all-reduce G, asynchronous] || INPUTS -> all-reduce g_u -> FINISH on the means
                 st = _lib.current_stream()
-                gc, ac = C.byref(graph.c), C.byref(args)
+                gc, ac = C.byref(gstruct), C.byref(args)
                 _lib.check(L.recon_gat_atp_bwd_phase(gc, ac, 1 | 4 | 16, st), "recon_gat_atp_bwd_phase")
                 handle = sync.all_reduce_mean(g_a, async_op=True)
                 _lib.check(L.recon_gat_atp_bwd_phase(gc, ac, 2, st), "recon_gat_atp_bwd_phase")
@@ -551,7 +551,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
                 # PREPARE -> { INPUTS on this stream , WEIGHTS (MFMA-bound GEMM) on a side stream } -> FINISH
                 main = torch.cuda.current_stream()
                 side = _side_stream(dev)
-                gc, ac = C.byref(graph.c), C.byref(args)
+                gc, ac = C.byref(gstruct), C.byref(args)
                 _lib.check(L.recon_gat_atp_bwd_phase(gc, ac, 1, main.cuda_stream), "recon_gat_atp_bwd_phase")
                 side.wait_stream(main)
                 _lib.check(L.recon_gat_atp_bwd_phase(gc, ac, 4, side.cuda_stream), "recon_gat_atp_bwd_phase")
@@ -562,7 +562,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
                     if t is not None:
                         t.record_stream(side)
             else:
-                _lib.check(L.recon_gat_atp_bwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_atp_bwd")
+                _lib.check(L.recon_gat_atp_bwd(C.byref(gstruct), C.byref(args), _lib.current_stream()), "recon_gat_atp_bwd")
         if g_ee is not None and ctx.idx_slot is not None:
             # table mode: g_ee holds one row per CSR slot; the table's gradient is their sum by row index (fixed order: the same
             # segment walk as SpecialSpmmFinal)
@@ -606,9 +606,12 @@ def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=Tru
     summed over the edges of each row.
     Returns [N, H*D] (heads concatenated along dim 1)."""
     H, D = a_2.shape
-    if ee_index is not None and (x.dtype != torch.float32 or
+    if ee_index is not None and (x.dtype != torch.float32 or edge_embed_all.dtype != torch.float32 or
                                  gat_path_for(graph.N, graph.E, x.shape[1], edge_embed_all.shape[1], D, H) != "atp"):
-        return gat_heads(x, gather_rows(edge_embed_all, ee_index), a, a_2, graph, keep, alpha, concat, keep_max)   # only the ATP kernels index
+        # only the fp32 ATP kernels read a table through an index: materialise the rows (gather_rows is an fp32 kernel with a fixed-order
+        # backward; reduced-precision tables go through index_select, whose autograd is native)
+        rows = gather_rows(edge_embed_all, ee_index) if edge_embed_all.dtype == torch.float32 else edge_embed_all.index_select(0, ee_index)
+        return gat_heads(x, rows, a, a_2, graph, keep, alpha, concat, keep_max)
     if x.dtype in (torch.bfloat16, torch.float16):
         # Reduced-precision STORAGE at the layer boundary (BASELINE.json configs[4]: "mixed GAT+Propagation stack, bf16"): features
         # and edge embeddings arrive and leave in x.dtype; scores, softmax, aggregation and projections run the fp32 kernels (the

@@ -87,11 +87,15 @@ class _GcnFunction(torch.autograd.Function):
         return (g_x.view(xs) if g_x is not None else None, g_adj.view(adjs) if g_adj is not None else None, g_w, g_b)
 
 
-def _rows_view(t, feat):
+def _rows_view(t, feat, pads_read=True):
     """(data_ptr-compatible 2-D view info) of a [..., n, feat] bf16 tensor whose rows are feat contiguous elements at a regular
     row stride ld with ld % 8 == 0 and ld >= feat rounded up to 8 — the layout the bf16 kernels read in place (a contiguous tensor
     with feat % 8 == 0, or the padded views this module hands out).  Returns ld, or None if the tensor has to be repacked."""
     if t.dim() < 2 or t.stride(-1) != 1:
+        return None
+    if pads_read and feat % 8 and not getattr(t, "_recon_padded", False):
+        # the kernels read the pad columns feat .. round_up(feat, 8) of every row (times zero weights): only rows THIS module wrote have
+        # zeros there — somebody else's `buf[..., :feat]` may carry inf / NaN in them, and 0 * NaN would poison the result
         return None
     ld = t.stride(-2)
     if ld % 8 or ld < (feat + 7) // 8 * 8 or t.data_ptr() % 16:
@@ -159,7 +163,12 @@ class _GcnB16Function(torch.autograd.Function):
             _lib.check(L.recon_gcn_b16_fwd(C.byref(args), _lib.current_stream()), "recon_gcn_b16_fwd")
         ctx.save_for_backward(xr, adj3, weight, bias, sup, out_p, planes)
         ctx.meta = (B, n, I, O, ldx, o8, tuple(x.shape), tuple(adj.shape))
-        return out_p[:, :O].view(x.shape[:-1] + (O,)) if o8 == O else out_p.as_strided(x.shape[:-1] + (O,), _strides(x.shape[:-1], o8))
+        if o8 == O:
+            return out_p.view(x.shape[:-1] + (O,))
+        out_p[:, O:].zero_()                                              # the next layer (and the backward) read these columns in place
+        out = out_p.as_strided(x.shape[:-1] + (O,), _strides(x.shape[:-1], o8))
+        out._recon_padded = True
+        return out
 
     @staticmethod
     def backward(ctx, gout):
@@ -171,7 +180,7 @@ class _GcnB16Function(torch.autograd.Function):
         nx, nadj, nw, nb = ctx.needs_input_grad
         if gout.dtype != torch.bfloat16:
             gout = gout.to(torch.bfloat16)
-        ldg = _rows_view(gout, O)
+        ldg = _rows_view(gout, O, pads_read=False)                 # pad columns of a gradient are never read
         gr = gout
         if ldg is None:
             gr, ldg = _packed_rows(gout, O, zero_pad=False)     # pad columns of a gradient are never read
@@ -189,7 +198,12 @@ class _GcnB16Function(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(L.recon_gcn_b16_bwd(C.byref(args), _lib.current_stream()), "recon_gcn_b16_bwd")
         if g_x is not None:
-            g_x = g_x.view(xs) if i8 == I else g_x.as_strided(xs, _strides(xs[:-1], i8))
+            if i8 == I:
+                g_x = g_x.view(xs)
+            else:
+                g_x[:, I:].zero_()
+                g_x = g_x.as_strided(xs, _strides(xs[:-1], i8))
+                g_x._recon_padded = True
         return g_x, (g_adj.view(adjs) if g_adj is not None else None), g_w, g_b
 
 
@@ -212,14 +226,23 @@ class SparseMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, matrix1, matrix2):
         ctx.save_for_backward(matrix1, matrix2)
-        return torch.mm(matrix1, matrix2)
+        return _mm(matrix1, matrix2, False, False)
 
     @staticmethod
     def backward(ctx, grad_output):
         matrix1, matrix2 = ctx.saved_tensors
-        g1 = torch.mm(grad_output, matrix2.t()) if ctx.needs_input_grad[0] else None
-        g2 = torch.mm(matrix1.t(), grad_output) if ctx.needs_input_grad[1] else None
+        g1 = _mm(grad_output, matrix2, False, True) if ctx.needs_input_grad[0] else None
+        g2 = _mm(matrix1, grad_output, True, False) if ctx.needs_input_grad[1] else None
         return g1, g2
+
+
+def _mm(a, b, a_t, b_t):
+    """op(a) op(b): fp32 GPU matrices on this library's fp32 matrix-core GEMM (recon_sgemm_ex); anything else (the class is kept for
+    name compatibility and is also importable on a CPU-only host) on torch.mm."""
+    if a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2:
+        from .gat_layers import _sgemm_ex
+        return _sgemm_ex(a.contiguous(), a_t, b.contiguous(), b_t)
+    return torch.mm(a.t() if a_t else a, b.t() if b_t else b)
 
 
 class GraphConvolution(Module):

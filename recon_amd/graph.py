@@ -80,7 +80,6 @@ class GraphCSR:
         self._slot_idx = {}
         # hub rows (include/recon_hip.h): destinations with more than HUB_CHUNK in-edges are cut into pieces, one wavefront each
         self.n_hub = self.n_piece = self.n_hub_src = self.n_piece_src = 0
-        self._hub_ws = None
         if HUB_CHUNK > 0 and E > HUB_CHUNK and not rows_only:
             cnt = (C.c_int32 * 4)()
             with torch.cuda.device(dev):
@@ -130,15 +129,18 @@ class GraphCSR:
                 return i64
         return idx_slot.long()
 
-    def reserve_hub_ws(self, F, R, H):
-        """Scratch of the hub pieces' partial sums for one KB-GAT layer call of these sizes; grows, never shrinks (the calls on one graph
-        are stream ordered and nothing in it outlives a call)."""
+    def call_struct(self, F, R, H):
+        """The `recon_graph` to hand to ONE layer call of these sizes.  Graphs without hub rows: the cached struct itself (read-only).
+        With hub rows the pieces' partial sums need scratch that the call writes: a fresh buffer per call (from the caching allocator,
+        i.e. ordered on the calling stream) in a COPY of the struct — a cached graph stays read-only, so concurrent calls on one graph
+        from different streams or threads do not share mutable state.  Returns (struct, keep-alive)."""
         if self.n_piece == 0 and self.n_piece_src == 0:
-            return
+            return self.c, None
         need = _lib.lib().recon_graph_hub_ws_floats(C.byref(self.c), F, R, H)
-        if self._hub_ws is None or self._hub_ws.numel() < need:
-            self._hub_ws = torch.empty(need, dtype=torch.float32, device=self.device)
-            self.c.hub_ws, self.c.hub_ws_floats = self._hub_ws.data_ptr(), need
+        ws = torch.empty(need, dtype=torch.float32, device=self.device)
+        c = _lib.ReconGraph.from_buffer_copy(self.c)
+        c.hub_ws, c.hub_ws_floats = ws.data_ptr(), need
+        return c, ws
 
     @property
     def eid_long(self):
@@ -159,7 +161,8 @@ def prepare_graph(edge, edge_list_nhop, N, rows_only=False):
     # edge lists.  (Writes through .data do not bump _version: do not mutate a cached edge tensor that way.)
     key = (edge.data_ptr(), edge._version, tuple(edge.shape), tuple(edge.stride()),
            edge_list_nhop.data_ptr() if nh else 0, edge_list_nhop._version if nh else 0,
-           tuple(edge_list_nhop.shape) if nh else (), tuple(edge_list_nhop.stride()) if nh else (), int(N), str(edge.device), bool(rows_only))
+           tuple(edge_list_nhop.shape) if nh else (), tuple(edge_list_nhop.stride()) if nh else (), int(N), str(edge.device), bool(rows_only),
+           int(HUB_CHUNK))
     g = _CACHE.get(key)
     if g is not None:
         _CACHE.move_to_end(key)

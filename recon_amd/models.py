@@ -89,7 +89,7 @@ class SpGAT(nn.Module):
             edge_embed_nhop = torch.tensor([])
         x = self.heads_forward(x, edge_list, edge_embed, edge_list_nhop, edge_embed_nhop)
         x = self.dropout_layer(x)
-        out_relation_1 = small_mm(relation_embed, self.W)
+        out_relation_1 = small_mm(relation_embed.to(self.W.dtype), self.W)    # (a reduced-precision relation table meets the fp32 parameter here)
         edge_embed = IndexedRows(out_relation_1, edge_type)               # out_relation_1[edge_type] (:79), read in place by the layer
         if has_nhop:
             edge_embed_nhop = gather_rows(out_relation_1, t0) + gather_rows(out_relation_1, t1)

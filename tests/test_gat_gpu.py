@@ -971,6 +971,29 @@ def test_phased_backward_on_two_streams_matches(monkeypatch):
 
 
 
+def test_spgat_forward_with_bf16_features_and_relation_table():
+    """SpGAT.forward with bf16 entity features and a bf16 relation table (reduced-precision storage at the layer boundary): the models hand
+    the layers `IndexedRows(table, edge_type)`; with a non-fp32 table the rows are materialised by index_select.  Against the fp32 oracle on
+    the bf16-rounded inputs (each layer's result is rounded to bf16 once)."""
+    from recon_amd.models import SpGAT
+    d = dev()
+    N, E, F_, D, H, nrel = 96, 400, 32, 16, 2, 7
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(N, F_, generator=g).to(torch.bfloat16)
+    rel = torch.randn(nrel, F_, generator=g).to(torch.bfloat16)
+    edge = torch.randint(0, N, (2, E), generator=g)
+    et = torch.randint(0, nrel, (E,), generator=g)
+    torch.manual_seed(0)
+    m = SpGAT(N, F_, D, F_, 0.0, 0.2, H).to(d)
+    out, out_rel = m(None, x.to(d), rel.to(d), edge.to(d), et.to(d), None, torch.tensor([]), torch.tensor([]))
+    assert out.shape == (N, H * D) and torch.isfinite(out.float()).all()
+    sd = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}
+    ref, ref_rel = O.spgat_forward(x.float(), rel.float(), edge, et, rel.float()[et], None, None,
+                                   [sd["attention_%d.a" % h] for h in range(H)], [sd["attention_%d.a_2" % h] for h in range(H)],
+                                   sd["W"], sd["out_att.a"], sd["out_att.a_2"], 0.2)
+    close(out.float(), ref, atol=2e-2, rel_to_max=3e-2, what="bf16 SpGAT out")
+
+
 def test_weight_gradient_early_sum_schedule_matches(gemm_family):
     """RECON_ATP_BWD_EARLY_SUM (the data-parallel backward: G = V^T g_h summed over split-K and handed to the collective BEFORE the
     edge chain, g_a += a_2 (x) g_u afterwards) against the single-pass backward, with a stand-in reducer that records the order of

@@ -498,3 +498,21 @@ def test_gcn_bf16_stack_reads_padded_rows_in_place():
     close(h.float(), hr, atol=1e-3, rel_to_max=3e-2, what="3-layer bf16 stack")
     y2d = layers[0](x.detach()[0], adj[0])
     assert torch.equal(y2d, layers[0](x.detach(), adj)[0])
+
+
+def test_gcn_bf16_foreign_padded_view_is_repacked():
+    """A caller's own `buf[..., :300]` view of wider rows may hold anything in its pad columns (here: NaN); the bf16 kernels read pad
+    columns in place only for rows this module produced, everything else is repacked with zeros — the result must not depend on them."""
+    from recon_amd.gcn_layers import GraphConvolution
+    d_ = dev()
+    B, n, D = 4, 32, 300
+    g = torch.Generator().manual_seed(11)
+    buf = torch.full((B, n, 304), float("nan"), dtype=torch.bfloat16, device=d_)
+    x = _bf(torch.randn(B, n, D, generator=g)).to(d_)
+    buf[..., :D] = x
+    adj = (torch.rand(B, n, n, generator=g) < 0.15).float() + torch.eye(n)
+    adj = _bf(adj / adj.sum(-1, keepdim=True)).to(d_)
+    torch.manual_seed(2)
+    layer = GraphConvolution(D, D).to(torch.bfloat16).to(d_)
+    y_view, y_plain = layer(buf[..., :D], adj), layer(x, adj)
+    assert torch.isfinite(y_view.float()).all() and torch.equal(y_view, y_plain)
