@@ -5,6 +5,7 @@
 // bandwidth bound and fp32 products cost nothing there.  Activations carry a row stride (ldx, lds, ldo ... multiples of 8
 // elements = 16 bytes) so that feature counts like 300 need no repacking between layers: columns past the feature count are
 // written as zeros and read as "times zero".
+#include <stdlib.h>
 #include "recon_common.h"
 
 namespace recon {
@@ -140,13 +141,163 @@ __global__ void __launch_bounds__(1024) k_gcn_b16_bias_reduce(const float* __res
         gbias[o] = f2bf(t);
     }
 }
+// ------------------------------------------------------------------------------------------------ fused forward (n <= 32)
+// out = relu(adj @ (x @ W) + bias) for graphs of at most 32 nodes in ONE kernel: a wave owns one graph (32 rows), a workgroup four.
+//   1. support [32 x O] = x_b [32 x I] . W on v_mfma_f32_16x16x32_bf16: A fragments (row i, 8 consecutive k) are 16-byte global loads
+//      into registers, the W^T planes [O][kp(I)] (k contiguous, zero padded) go through a double-buffered LDS slab per K step, shared by
+//      the four waves; the product stays in the accumulators (2 row tiles x NT column tiles).
+//   2. out^T [O x 32] = support^T . adj^T, again on the matrix cores and WITHOUT moving `support`: in the C layout a lane holds, for
+//      column o, rows j = 4 lq + r of both row tiles — read as an MFMA operand (row o = lane & 15 of tile t, eight k slots = nodes
+//      4 lq .. + 3 and 16 + 4 lq .. + 3, rounded to bf16 as torch.mm would round `support`) that is exactly an A fragment under a
+//      permutation of the contraction index; adj's fragments are fetched under the same permutation (two 8-byte loads per lane).
+//      The result's C layout has four consecutive columns o per node: + bias, ReLU, one 8-byte store.
+// Traffic per layer: x once, out once, adj, W from L2 — 41 MB at cfg 3a (B = 1024, n = 32, D = 300) against 19.7 MB x 4 + the support
+// round trip of the GEMM + aggregate pair.  `support` is not written (the backward recomputes nothing from it unless d adj is wanted,
+// and then the unfused path runs).
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4_g = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2_g = __attribute__((ext_vector_type(2))) uint32_t;
+constexpr int kFusedNT = 20;                      // column tiles of 16: out_features <= 320
+
+struct GcnFusedK {
+    const uint16_t* x; int64_t ldx;
+    const uint16_t* adj; const uint16_t* wt; const uint16_t* bias;      // wt: W^T planes [O][Ip]
+    uint16_t* out; int64_t ldo;
+    int32_t B, n, I, Ip, O, nt;                                          // nt = ceil(ldo / 16) <= kFusedNT
+};
+
+__device__ __forceinline__ int gf_lds_off(int row, int kq) { return row * 64 + (((kq + 2 * (row >> 3)) & 3) << 4); }
+
+__global__ void __launch_bounds__(256, 1) k_gcn_b16_fused_fwd(const GcnFusedK p) {
+    __shared__ __attribute__((aligned(16))) unsigned char Ws[2][kFusedNT * 16 * 64];      // one K step of W^T: [o][32 k], 2 x 20 KiB
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int g = blockIdx.x * 4 + w;                                    // this wave's graph (may be past B: loads come back as zeros)
+    const int n = p.n, nt = p.nt;
+    const int64_t rows_total = static_cast<int64_t>(p.B) * n;
+    // x: rows of graph g, out-of-range rows / columns read as zeros through the descriptor (the tensor's own extent)
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0,
+                                                      static_cast<int>(min<int64_t>(rows_total * p.ldx * 2, 0x7fffffff)), 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wt), 0, p.O * p.Ip * 2, 0x00020000);
+    uint32_t xoff[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int i = 16 * rt + li;
+        xoff[rt] = (g < p.B && i < n) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.ldx + 8 * lq) * 2) : 0xfffffff0u;
+    }
+    // W^T slab staging: piece s = t + 256 q -> (row o = s >> 2, k group s & 3) of the K step; rows past O come back as zeros
+    constexpr int WQ = (kFusedNT * 16 * 4 + 255) / 256;                  // 5 pieces per thread
+    uint32_t woff[WQ]; int wlds[WQ];
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+        const int s = t + 256 * q, o = s >> 2, kq = s & 3;
+        woff[q] = (o < 16 * nt) ? static_cast<uint32_t>((o * p.Ip + 8 * kq) * 2) : 0xfffffff0u;
+        wlds[q] = o < kFusedNT * 16 ? gf_lds_off(o, kq) : -1;
+    }
+    const int nks = p.Ip >> 5;
+    u32x4_g wreg[WQ], areg[2];
+    auto load_w = [&](int ks) {
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) wreg[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[q] + 64u * ks, 0, 0);
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < WQ; ++q)
+            if (wlds[q] >= 0) *reinterpret_cast<u32x4_g*>(&Ws[buf][wlds[q]]) = wreg[q];
+    };
+    auto load_a = [&](int ks) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) areg[rt] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff[rt] + 64u * ks, 0, 0);
+    };
+    f32x4 acc[2][kFusedNT];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int c = 0; c < kFusedNT; ++c) acc[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_w(0);
+    load_a(0);
+    store_w(0);
+    __syncthreads();
+    const int b_rd = gf_lds_off(li, lq);
+    for (int ks = 0; ks < nks; ++ks) {
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, areg[0]), a1 = __builtin_bit_cast(bf16x8, areg[1]);
+        if (ks + 1 < nks) { load_w(ks + 1); load_a(ks + 1); }
+        const unsigned char* slab = Ws[ks & 1];
+#pragma unroll
+        for (int c = 0; c < kFusedNT; ++c)
+            if (c < nt) {                                                // uniform
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(slab + b_rd + 1024 * c);
+                acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][c], 0, 0, 0);
+                acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][c], 0, 0, 0);
+            }
+        if (ks + 1 < nks) store_w((ks + 1) & 1);                         // the other buffer: last read in step ks - 1, a barrier ago
+        __syncthreads();
+    }
+    // ---- adj^T fragments of this graph under the k permutation (slots 0..3: j = 4 lq .., slots 4..7: j = 16 + 4 lq ..), output node i' = li + 16 it
+    bf16x8 adjf[2];
+    {
+        const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.adj), 0,
+                                                          static_cast<int>(min<int64_t>(static_cast<int64_t>(p.B) * n * n * 2, 0x7fffffff)), 0x00020000);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = 16 * it + li;
+            uint32_t v[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j0 = 16 * h + 4 * lq;
+                // n is arbitrary (<= 32): element-wise 2-byte loads keep rows of odd length and their tails exact
+                uint32_t e[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    e[q] = (g < p.B && i < n && j0 + q < n)
+                               ? __builtin_amdgcn_raw_buffer_load_b16(ra, static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * n + j0 + q) * 2), 0, 0) & 0xffffu
+                               : 0u;
+                v[2 * h] = e[0] | (e[1] << 16);
+                v[2 * h + 1] = e[2] | (e[3] << 16);
+            }
+            adjf[it] = __builtin_bit_cast(bf16x8, u32x4_g{v[0], v[1], v[2], v[3]});
+        }
+    }
+    // ---- out^T tile = support^T . adj^T ; + bias, ReLU, 8-byte stores
+    const auto ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, static_cast<int>(min<int64_t>(rows_total * p.ldo * 2, 0x7fffffff)), 0x00020000);
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.bias ? p.bias : p.x), 0, p.bias ? p.O * 2 : 0, 0x00020000);
+    auto pack2 = [](float a, float b) { return static_cast<uint32_t>(f2bf(a)) | (static_cast<uint32_t>(f2bf(b)) << 16); };
+#pragma unroll
+    for (int c = 0; c < kFusedNT; ++c)
+        if (c < nt) {
+            const bf16x8 sf = __builtin_bit_cast(bf16x8, u32x4_g{pack2(acc[0][c][0], acc[0][c][1]), pack2(acc[0][c][2], acc[0][c][3]),
+                                                                   pack2(acc[1][c][0], acc[1][c][1]), pack2(acc[1][c][2], acc[1][c][3])});
+            const int o0 = 16 * c + 4 * lq;
+            float bv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = bf2f(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rb, static_cast<uint32_t>((o0 + q) * 2), 0, 0)));
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, adjf[it], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const int i = 16 * it + li;                              // C layout: column = node i, rows o0 .. o0 + 3
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q] = r[q] + bv[q]; v[q] = (v[q] > 0.f && o0 + q < p.O) ? v[q] : 0.f; }
+                const uint32_t off = (g < p.B && i < n && o0 < p.ldo) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.ldo + o0) * 2) : 0xfffffff0u;
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2_g{pack2(v[0], v[1]), pack2(v[2], v[3])}, ro, off, 0, 0);
+            }
+        }
+}
+
+bool gcn_fused_ok(const recon_gcn_b16_args* a) {
+    static const bool off = getenv("RECON_GCN_FUSED") && getenv("RECON_GCN_FUSED")[0] == '0';
+    return !off && a->n <= 32 && a->ldo <= kFusedNT * 16 && (a->ldo & 3) == 0 &&
+           static_cast<int64_t>(a->B) * a->n * a->ldx * 2 < 0x7fffffffLL && static_cast<int64_t>(a->B) * a->n * a->ldo * 2 < 0x7fffffffLL;
+}
+
 constexpr int kBiasBlocks = 1024;
 
 int check(const recon_gcn_b16_args* a) {
     if (!a || a->B < 0 || a->n <= 0 || a->in_features <= 0 || a->out_features <= 0) return RECON_ERR_INVALID;
-    if (!a->x || !a->adj || !a->weight || !a->support || !a->out || !a->w_planes) return RECON_ERR_INVALID;
+    if (!a->x || !a->adj || !a->weight || !a->out || !a->w_planes) return RECON_ERR_INVALID;
+    if (!a->support && !gcn_fused_ok(a)) return RECON_ERR_INVALID;    // only the fused forward (n <= 32, out <= 320) does without it
     const int64_t i8 = (a->in_features + 7) / 8 * 8, o8 = (a->out_features + 7) / 8 * 8;
-    if ((a->ldx & 7) || (a->lds & 7) || (a->ldo & 7) || a->ldx < i8 || a->lds < o8 || a->ldo < o8) return RECON_ERR_INVALID;
+    if ((a->ldx & 7) || (a->ldo & 7) || a->ldx < i8 || a->ldo < o8 || (a->support && ((a->lds & 7) || a->lds < o8))) return RECON_ERR_INVALID;
     if ((reinterpret_cast<uintptr_t>(a->x) | reinterpret_cast<uintptr_t>(a->support) | reinterpret_cast<uintptr_t>(a->out) |
          reinterpret_cast<uintptr_t>(a->w_planes)) & 15) return RECON_ERR_INVALID;
     if (a->B > 65535 || a->n > 65535 * 32) return RECON_ERR_UNSUPPORTED;
@@ -174,8 +325,19 @@ extern "C" int recon_gcn_b16_fwd(const recon_gcn_b16_args* a, recon_stream_t str
     // W^T [O][kp(I)] for this product, W [I][kp(O)] for g_x in the backward (both zero padded along k)
     rc = b16_pad_planes(a->weight, O, true, O, I, wp, st);
     if (rc == RECON_OK) rc = b16_pad_planes(a->weight, O, false, I, O, wp + planes_part(O, I), st);
+    if (rc != RECON_OK) return rc;
+    if (!a->support) {                                               // fused: one kernel, `support` stays in registers
+        GcnFusedK k;
+        k.x = static_cast<const uint16_t*>(a->x); k.ldx = a->ldx; k.adj = static_cast<const uint16_t*>(a->adj);
+        k.wt = reinterpret_cast<const uint16_t*>(wp); k.bias = static_cast<const uint16_t*>(a->bias);
+        k.out = static_cast<uint16_t*>(a->out); k.ldo = a->ldo;
+        k.B = a->B; k.n = a->n; k.I = I; k.Ip = b16_kp(I); k.O = O; k.nt = static_cast<int32_t>(ceil_div64(a->ldo, 16));
+        hipLaunchKernelGGL(k_gcn_b16_fused_fwd, dim3(static_cast<unsigned>(ceil_div64(a->B, 4))), dim3(256), 0, st, k);
+        RECON_CHECK_LAUNCH();
+        return RECON_OK;
+    }
     // support = x @ W      (models/layers.py:58)
-    if (rc == RECON_OK) rc = gemm_b16(rows, O, I, a->x, a->ldx, wp, a->support, a->lds, true, st);
+    rc = gemm_b16(rows, O, I, a->x, a->ldx, wp, a->support, a->lds, true, st);
     if (rc != RECON_OK) return rc;
     // out = relu(adj @ support + bias)     (:59-63)
     dim3 grid(static_cast<unsigned>(ceil_div64(a->ldo, 64)), static_cast<unsigned>(a->B), static_cast<unsigned>(ceil_div64(a->n, 32)));

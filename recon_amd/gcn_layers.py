@@ -11,6 +11,7 @@ Extension over the reference: `forward` also accepts a batch, input [B,n,in] wit
 (the reference's torch.mm only takes the 2-D single-graph form).  Any n is accepted (the aggregate kernel tiles
 the adjacency in 32 x 32 blocks); B <= 65 535 graphs per call."""
 import ctypes as C
+import os
 import math
 
 import torch
@@ -120,6 +121,7 @@ def _packed_rows(t, feat, zero_pad):
 
 
 _ZEROS = {}
+_FUSED = os.environ.get("RECON_GCN_FUSED", "1") != "0"
 
 
 def _zero_page(dev):
@@ -153,11 +155,14 @@ class _GcnB16Function(torch.autograd.Function):
             xr, ldx = _packed_rows(x, I, zero_pad=True)
         o8 = (O + 7) // 8 * 8
         bf = dict(dtype=torch.bfloat16, device=dev)
-        sup = torch.empty(B * n, o8, **bf)
+        # `support` = x @ W is only needed again for d adj; without it the forward is ONE kernel (csrc/gcn_b16.hip k_gcn_b16_fused_fwd:
+        # n <= 32, out <= 320) that keeps it in registers
+        fused = (not ctx.needs_input_grad[1]) and n <= 32 and o8 <= 320 and B * n * max(ldx, o8) * 2 < 2 ** 31 - 1 and _FUSED
+        sup = None if fused else torch.empty(B * n, o8, **bf)
         out_p = torch.empty(B * n, o8, **bf)
         weight = weight.contiguous()
         planes = torch.empty(L.recon_gcn_b16_planes_bytes(I, O), dtype=torch.uint8, device=dev)
-        args = _lib.GcnB16Args(B, n, I, O, xr.data_ptr(), ldx, adj3.data_ptr(), weight.data_ptr(), _lib.ptr(bias), sup.data_ptr(), o8,
+        args = _lib.GcnB16Args(B, n, I, O, xr.data_ptr(), ldx, adj3.data_ptr(), weight.data_ptr(), _lib.ptr(bias), _lib.ptr(sup), o8,
                                out_p.data_ptr(), o8, planes.data_ptr())
         with torch.cuda.device(dev):
             _lib.check(L.recon_gcn_b16_fwd(C.byref(args), _lib.current_stream()), "recon_gcn_b16_fwd")
@@ -191,7 +196,7 @@ class _GcnB16Function(torch.autograd.Function):
         g_adj = torch.empty(B, n, n, **bf) if nadj else None
         g_w = torch.empty(I, O, **bf) if nw else None
         g_b = torch.empty(O, **bf) if (nb and bias is not None) else None
-        fwd = _lib.GcnB16Args(B, n, I, O, xr.data_ptr(), ldx, adj3.data_ptr(), weight.data_ptr(), _lib.ptr(bias), sup.data_ptr(), o8,
+        fwd = _lib.GcnB16Args(B, n, I, O, xr.data_ptr(), ldx, adj3.data_ptr(), weight.data_ptr(), _lib.ptr(bias), _lib.ptr(sup), o8,
                               out_p.data_ptr(), o8, planes.data_ptr())
         args = _lib.GcnB16BwdArgs(fwd, gr.data_ptr(), ldg, g_sup.data_ptr(), partial.data_ptr(), _lib.ptr(g_x), i8, _lib.ptr(g_adj),
                                   _lib.ptr(g_w), _lib.ptr(g_b), _zero_page(dev).data_ptr())
