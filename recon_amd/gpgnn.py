@@ -153,22 +153,113 @@ class RECON_EAC(GPGNN):
             p['drop_out_rate_ent'], p['entity_embed_dim'], p['conv_filter_size'], p['entity_conv_filter_size'], self.word_embedding,
             p['char_embed_dim'], p['max_char_len'], char_vocab, p['char_feature_size'])
 
-    def forward(self, sentence_input, entity_markers, num_entities, unique_entites, entity_indices, context_words, context_chars,
-                context_mask, entities_position, max_occurred_entity_in_batch_pos):
+    def relation_features(self, sentence_input, entity_markers, context_words, context_chars, context_mask, entities_position,
+                          max_occurred_entity_in_batch_pos):
+        """Untied branch up to the classifier (:365-484): [B, C, 2d L] head*tail features of every hop."""
         p = self.p
-        if self.tied:
-            return super().forward(sentence_input, entity_markers, num_entities)
         n, L = p['max_num_nodes'], p['layer_number']
         entity_embeddings = self.entity_embedding_module(context_words, context_chars, context_mask)
-        h0 = make_start_entity_embeddings(entity_embeddings, entities_position, unique_entites, p['embedding_dim'],
+        h0 = make_start_entity_embeddings(entity_embeddings, entities_position, None, p['embedding_dim'],
                                           max_occurred_entity_in_batch_pos, self.start_embedding, max_num_nodes=n)     # :365
         rnn_result = self.encode(sentence_input, entity_markers)
-        B = rnn_result.size(0)
         Ts = []
         for i in range(L):                                               # :447-466
             T = self.representation_to_adj[i](rnn_result)
             if p['non-linear1'] != "linear":
                 T = getattr(F, p['non-linear1'])(T)
             Ts.append(T)
-        relation = propagate_blocks(Ts, self.identity_transformation, n, h0, p['non-linear1'], self.head_indices[0], self.tail_indices[0])     # :447-484
-        return self.linear3(relation).view(B * self.MAX_EDGES_PER_GRAPH, -1)
+        return propagate_blocks(Ts, self.identity_transformation, n, h0, p['non-linear1'], self.head_indices[0], self.tail_indices[0])     # :447-484
+
+    def forward(self, sentence_input, entity_markers, num_entities, unique_entites, entity_indices, context_words, context_chars,
+                context_mask, entities_position, max_occurred_entity_in_batch_pos):
+        if self.tied:
+            return GPGNN.forward(self, sentence_input, entity_markers, num_entities)
+        relation = self.relation_features(sentence_input, entity_markers, context_words, context_chars, context_mask, entities_position,
+                                          max_occurred_entity_in_batch_pos)
+        return self.linear3(relation).view(relation.size(0) * self.MAX_EDGES_PER_GRAPH, -1)
+
+
+class RECON_EAC_KGGAT(RECON_EAC):
+    """The reference's `RECON_EAC_KGGAT` (models/models.py:489-701): RECON_EAC whose classifier also sees the stage-A KB-GAT
+    embeddings of each pair's head and tail entity (`gat_entity_embeddings` [B, C, 2 * gat_entity_embedding_dim], concatenated
+    behind the propagation features, :693-697).  Same constructor, forward signature and state_dict keys as the reference.
+
+    The reference's tied-projection branch (:597-649) feeds the propagation features alone to a classifier sized for the
+    concatenation and fails in `linear3`; here it fails with the same exception type before any work is done."""
+
+    def __init__(self, p, embeddings, max_sent_len, n_out, char_vocab, MAX_EDGES_PER_GRAPH=72):
+        super().__init__(p, embeddings, max_sent_len, n_out, char_vocab, MAX_EDGES_PER_GRAPH)
+        self.linear3 = nn.Linear(p['embedding_dim'] * 2 * p['layer_number'] + 2 * p['gat_entity_embedding_dim'], n_out)      # :547-549
+        nn.init.xavier_uniform_(self.linear3.weight)
+
+    def forward(self, sentence_input, entity_markers, num_entities, unique_entites, entity_indices, context_words, context_chars,
+                context_mask, entities_position, max_occurred_entity_in_batch_pos, gat_entity_embeddings):
+        if self.tied:
+            raise RuntimeError("RECON_EAC_KGGAT: the tied projection feeds %d features to a classifier built for %d (models/models.py:622, :647)"
+                               % (self.p['embedding_dim'] * 2 * self.p['layer_number'], self.linear3.in_features))
+        relation = self.relation_features(sentence_input, entity_markers, context_words, context_chars, context_mask, entities_position,
+                                          max_occurred_entity_in_batch_pos)
+        both = torch.cat([relation, gat_entity_embeddings.to(relation.dtype)], dim=-1)                                      # :693-694
+        return self.linear3(both).view(relation.size(0) * self.MAX_EDGES_PER_GRAPH, -1)
+
+
+class RECON(RECON_EAC):
+    """The reference's full model `RECON` (models/models.py:703-968): RECON_EAC + the KB-GAT entity embeddings of every pair +
+    a per-relation triple score in the relation space of GAT_sep_space: for each pair with known embeddings,
+    `|| tanh(head W_r) + g_r - tanh(tail W_r) ||_1` for every output relation r (:940-958), scattered into a [B*C, n_out]
+    block behind the other features.  Constructor arguments, forward signature and state_dict keys follow the reference
+    (`gat_relation_embeddings` trainable, `W_ent2rel` frozen; head / tail index tensors are plain attributes there, :759-768,
+    and non-persistent buffers here so that `.to(device)` moves them and checkpoints stay key-compatible).
+
+    `gat_relation_embeddings` is the dict the reference loads from JSON (string index -> vector), `W_ent2rel_all_rels` the
+    [n_gat_rel, ent_dim, rel_dim] array, `idx2property` output index -> property, `gat_relation2idx` property -> string index."""
+
+    def __init__(self, p, embeddings, max_sent_len, n_out, char_vocab, gat_relation_embeddings, W_ent2rel_all_rels, idx2property,
+                 gat_relation2idx, MAX_EDGES_PER_GRAPH=72):
+        super().__init__(p, embeddings, max_sent_len, n_out, char_vocab, MAX_EDGES_PER_GRAPH)
+        n, d, L = p['max_num_nodes'], p['embedding_dim'], p['layer_number']
+        head, tail = self.head_indices.data, self.tail_indices.data
+        del self.head_indices, self.tail_indices
+        self.register_buffer("head_indices", head, persistent=False)
+        self.register_buffer("tail_indices", tail, persistent=False)
+        self.linear3 = nn.Linear(d * 2 * L + 2 * p['gat_entity_embedding_dim'] + n_out, n_out)                               # :772-773
+        nn.init.xavier_uniform_(self.linear3.weight)
+        W_all = torch.as_tensor(W_ent2rel_all_rels, dtype=torch.float32)
+        rel0 = torch.zeros(n_out, len(gat_relation_embeddings["0"]))                                                        # :779-785
+        W0 = torch.zeros(n_out, W_all.shape[1], W_all.shape[2])                                                             # :787-793
+        for i in range(n_out):
+            gat_idx = gat_relation2idx.get(idx2property[i], None)
+            if gat_idx is not None:
+                rel0[i] = torch.as_tensor(gat_relation_embeddings[gat_idx], dtype=torch.float32)
+                W0[i] = W_all[int(gat_idx)]
+        self.gat_relation_embeddings = nn.Parameter(rel0, requires_grad=True)
+        self.W_ent2rel = nn.Parameter(W0, requires_grad=False)
+
+    def translation_scores(self, nonzero_gat_entity_embeddings):
+        """[M, 2 ent_dim] (head | tail) -> [M, n_out] L1 translation residuals in each output relation's space (:934-953).
+        All relations at once: one [M, ent_dim] x [ent_dim, n_out * rel_dim] product per side on the library-free GEMM."""
+        from .gat_layers import small_mm
+        W = self.W_ent2rel
+        n_out, ent_dim, rel_dim = W.shape
+        half = nonzero_gat_entity_embeddings.shape[-1] // 2
+        emb = nonzero_gat_entity_embeddings.to(device=W.device, dtype=W.dtype)
+        Wf = W.permute(1, 0, 2).reshape(ent_dim, n_out * rel_dim)
+        head = torch.tanh(small_mm(emb[:, :half].contiguous(), Wf)).view(-1, n_out, rel_dim)
+        tail = torch.tanh(small_mm(emb[:, half:].contiguous(), Wf)).view(-1, n_out, rel_dim)
+        return (head + self.gat_relation_embeddings.unsqueeze(0) - tail).abs().sum(-1)
+
+    def forward(self, sentence_input, entity_markers, num_entities, unique_entites, entity_indices, context_words, context_chars,
+                context_mask, entities_position, max_occurred_entity_in_batch_pos, nonzero_gat_entity_embeddings, nonzero_entity_pos,
+                gat_entity_embeddings):
+        if self.tied:
+            raise RuntimeError("RECON: the tied projection feeds %d features to a classifier built for %d (models/models.py:836, :861)"
+                               % (self.p['embedding_dim'] * 2 * self.p['layer_number'], self.linear3.in_features))
+        relation = self.relation_features(sentence_input, entity_markers, context_words, context_chars, context_mask, entities_position,
+                                          max_occurred_entity_in_batch_pos)
+        rows = relation.size(0) * self.MAX_EDGES_PER_GRAPH
+        relation = relation.reshape(rows, -1)                                                                               # :926
+        gat = gat_entity_embeddings.to(relation.dtype).reshape(rows, -1)                                                    # :927
+        scores = torch.zeros(rows, self.W_ent2rel.shape[0], device=relation.device, dtype=relation.dtype)                  # :954-958
+        if nonzero_gat_entity_embeddings.shape[0] > 0:
+            scores = scores.index_put((nonzero_entity_pos.to(relation.device),), self.translation_scores(nonzero_gat_entity_embeddings))
+        return self.linear3(torch.cat([relation, gat, scores], dim=-1))                                                     # :960-961

@@ -11,6 +11,8 @@ Reference entry points executed (unmodified, imported from where they lie):
   GAT/models.py:11-88    SpGAT (heads + out_att)
   models/models.py:85-277  GPGNN.forward (untied branch :238-277 = block adjacency
                            + 3-hop propagation + head*tail gather)
+  models/models.py:279-487, 489-701, 703-968  RECON_EAC, RECON_EAC_KGGAT, RECON (whole models: logits + parameter gradients)
+  GAT_sep_space/models.py:91-245  SpKBGATModified with W_ent2rel (+ the relation-space projection of GAT_sep_space/main.py:359-367)
   models/layers.py:35-68 GraphConvolution
   utils/build_adjecent_matrix.py:6-22
   utils/embedding_utils.py:170-202  make_start_embedding / get_head_indices / get_tail_indices
@@ -403,6 +405,138 @@ def recon_eac_case(name, ref_models):
     save(name, **arrays)
 
 
+KGGAT_P = dict(EAC_P, gat_entity_embedding_dim=3)
+
+
+def _eac_inputs(p, m, U=5, lines=4, wl=3, seed=6):
+    n, B = p["max_num_nodes"], p["batch_size"]
+    C = n * (n - 1)
+    gs = torch.Generator().manual_seed(seed)
+    sent = torch.randint(1, 7, (B, 4), generator=gs)
+    mark = torch.randint(0, 4, (B, C, 4), generator=gs)
+    ctx_words = torch.randint(0, 7, (U, lines, wl), generator=gs)
+    span = p["max_char_len"] + p["conv_filter_size"] - 1
+    ctx_chars = torch.randint(0, 8, (U, lines, p["conv_filter_size"] - 1 + wl * span), generator=gs)
+    mask = torch.rand(U, lines - p["entity_conv_filter_size"] + 1, generator=gs) < 0.4
+    mask[:, 0] = False
+    pos = torch.randint(0, U, (B, C, 2), generator=gs)
+    return sent, mark, ctx_words, ctx_chars, mask, pos, gs
+
+
+def _save_model_case(name, m, out, G, extra):
+    arrays = dict(extra, out=t2n(out), G=t2n(G))
+    for k, v in m.state_dict().items():
+        if k not in ("head_indices", "tail_indices", "start_embedding"):
+            arrays["sd." + k] = t2n(v)
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            arrays["g." + k] = t2n(v.grad)
+    save(name, **arrays)
+
+
+def recon_kggat_case(name, ref_models):
+    """N3 (wider): the reference RECON_EAC_KGGAT (models/models.py:489-701): RECON_EAC + the KB-GAT embeddings of every pair's
+    entities concatenated in front of the classifier."""
+    p = dict(KGGAT_P)
+    n, B = p["max_num_nodes"], p["batch_size"]
+    C = n * (n - 1)
+    emb = hashed_uniform((7, 5), 321, -0.5, 0.5).astype(np.float32)
+    emb[0] = 0.0
+    char_vocab = {c: i for i, c in enumerate("_abcdefg")}
+    torch.manual_seed(17)
+    m = ref_models.RECON_EAC_KGGAT(p, emb, max_sent_len=4, n_out=3, char_vocab=char_vocab)
+    m.eval()
+    sent, mark, ctx_words, ctx_chars, mask, pos, gs = _eac_inputs(p, m, seed=7)
+    gat = torch.randn(B, C, 2 * p["gat_entity_embedding_dim"], generator=gs)
+    out = m(sent, mark, None, None, None, ctx_words, ctx_chars, mask, pos, 2, gat)
+    G = torch.from_numpy(hashed_uniform(tuple(out.shape), 322))
+    (out * G).sum().backward()
+    _save_model_case(name, m, out, G, dict(emb=emb, sent=t2n(sent), mark=t2n(mark), ctx_words=t2n(ctx_words), ctx_chars=t2n(ctx_chars),
+                                            ctx_mask=t2n(mask), pos=t2n(pos), max_occ=np.int32(2), gat=t2n(gat), n_chars=np.int32(len(char_vocab))))
+
+
+def recon_full_case(name, ref_models):
+    """N3 (wider): the reference's full model RECON (models/models.py:703-968): + per-relation translation residuals of the
+    pairs with known KB-GAT embeddings in the relation spaces of GAT_sep_space.  The constructor writes rows of a leaf that
+    requires grad (:779-785), which autograd refuses outside no_grad: built under no_grad, as a checkpoint load would."""
+    p = dict(KGGAT_P)
+    n, B, n_out = p["max_num_nodes"], p["batch_size"], 3
+    C = n * (n - 1)
+    emb = hashed_uniform((7, 5), 331, -0.5, 0.5).astype(np.float32)
+    emb[0] = 0.0
+    char_vocab = {c: i for i, c in enumerate("_abcdefg")}
+    ent_dim, rel_dim, n_gat_rel = p["gat_entity_embedding_dim"], 4, 5
+    rel_table = hashed_uniform((n_gat_rel, rel_dim), 332).astype(np.float32)
+    W_all = hashed_uniform((n_gat_rel, ent_dim, rel_dim), 333).astype(np.float32)
+    gat_rel = {str(i): [float(v) for v in rel_table[i]] for i in range(n_gat_rel)}
+    idx2property = {0: "P0", 1: "P31", 2: "P17"}
+    gat_relation2idx = {"P31": "3", "P17": "1"}                           # output 0 has no KB-GAT relation: its rows stay zero
+    torch.manual_seed(19)
+    saved_cuda = ref_models.CUDA
+    with torch.no_grad():
+        m = ref_models.RECON(p, emb, 4, n_out, char_vocab, gat_rel, W_all, idx2property, gat_relation2idx)
+    m.eval()
+    sent, mark, ctx_words, ctx_chars, mask, pos, gs = _eac_inputs(p, m, seed=8)
+    gat = torch.randn(B, C, 2 * ent_dim, generator=gs)
+    nz_pos = torch.tensor([0, 3, 4, 9, 17, 22])
+    nz = torch.randn(nz_pos.numel(), 2 * ent_dim, generator=gs)
+    entity_indices = torch.zeros(B, C, dtype=torch.long)                  # only its shape is read (:955-957)
+    out = m(sent, mark, None, None, entity_indices, ctx_words, ctx_chars, mask, pos, 2, nz, nz_pos, gat)
+    G = torch.from_numpy(hashed_uniform(tuple(out.shape), 334))
+    (out * G).sum().backward()
+    assert ref_models.CUDA == saved_cuda
+    _save_model_case(name, m, out, G, dict(emb=emb, sent=t2n(sent), mark=t2n(mark), ctx_words=t2n(ctx_words), ctx_chars=t2n(ctx_chars),
+                                            ctx_mask=t2n(mask), pos=t2n(pos), max_occ=np.int32(2), gat=t2n(gat), nz=t2n(nz), nz_pos=t2n(nz_pos),
+                                            rel_table=rel_table, W_all=W_all, n_chars=np.int32(len(char_vocab))))
+
+
+def gen_sep_space():
+    """GAT_sep_space/models.py: SpKBGATModified with W_ent2rel — state_dict, forward, and the per-triple relation-space
+    projection of GAT_sep_space/main.py:359-364 (tanh(bmm(e, W[rel]))) with its gradients."""
+    sep = os.path.join(REF, "GAT_sep_space")
+    for k in ("layers", "models"):
+        sys.modules.pop(k, None)
+    sys.path.insert(0, sep)
+    try:
+        import models as sep_models
+        assert sep_models.__file__.startswith(sep)
+        N, nrel, dim, nhid, nheads = 40, 5, 8, 4, 2
+        g = torch.Generator().manual_seed(41)
+        ent0, rel0 = torch.randn(N, dim, generator=g), torch.randn(nrel, dim, generator=g)
+        edge, etype = torch.randint(0, N, (2, 60), generator=g), torch.randint(0, nrel, (60,), generator=g)
+        nhop = torch.stack([torch.randint(0, N, (20,), generator=g), torch.randint(0, nrel, (20,), generator=g),
+                            torch.randint(0, nrel, (20,), generator=g), torch.randint(0, N, (20,), generator=g)], dim=1)
+        batch_entities = torch.randint(0, N, (25,), generator=g)
+        triples = torch.stack([torch.randint(0, N, (33,), generator=g), torch.randint(0, nrel, (33,), generator=g),
+                               torch.randint(0, N, (33,), generator=g)], dim=1)
+        torch.manual_seed(7)
+        m = sep_models.SpKBGATModified(ent0.clone(), rel0.clone(), [nhid, nhid * nheads], [nhid * nheads, nhid * nheads], 0.0, 0.2,
+                                       [nheads, nheads], None)
+        m.eval()
+        sd0 = {k: t2n(v).copy() for k, v in m.state_dict().items()}
+        out_e, out_r, mask = m(None, batch_entities, (edge, etype), nhop)
+        W = m.W_ent2rel[triples[:, 1]]
+        src = m.nonlinearity_ent2rel(torch.bmm(out_e[triples[:, 0]].unsqueeze(1), W)).squeeze()
+        dst = m.nonlinearity_ent2rel(torch.bmm(out_e[triples[:, 2]].unsqueeze(1), W)).squeeze()
+        x = src + out_r[triples[:, 1]] - dst                               # GAT_sep_space/main.py:366-367
+        norm = torch.norm(x, p=1, dim=1)
+        Gn = torch.randn(norm.shape, generator=torch.Generator().manual_seed(3))
+        (norm * Gn).sum().backward()
+        arrays = dict(edge=t2n(edge), edge_type=t2n(etype), nhop=t2n(nhop), batch_entities=t2n(batch_entities), triples=t2n(triples),
+                      out_entity=t2n(out_e), out_relation=t2n(out_r), mask=t2n(mask), src_rel=t2n(src), dst_rel=t2n(dst), norm=t2n(norm), Gn=t2n(Gn),
+                      nheads=np.int32(nheads), nhid=np.int32(nhid))
+        for k, v in sd0.items():
+            arrays["p0." + k] = v
+        for k, v in m.named_parameters():
+            if v.grad is not None:
+                arrays["g." + k] = t2n(v.grad)
+        save("sepspace1", **arrays)
+    finally:
+        sys.path.remove(sep)
+        for k in ("layers", "models"):
+            sys.modules.pop(k, None)
+
+
 def gen_formats():
     """N4: the reference's own readers / writers (GAT/preprocess.py, GAT/main.py save_embed) on tiny synthetic files."""
     import tempfile, json as _json, importlib
@@ -515,7 +649,9 @@ def gen_gpgnn():
     gpgnn_full_case("gpgnn1_untied", ref_models, "untie")
     gpgnn_full_case("gpgnn2_tied_n9", ref_models, "tie", n=9, d=1, L=2)
     recon_eac_case("eac1_untied", ref_models)
-    if os.environ.get("RECON_GOLDEN_ONLY") == "eac":
+    recon_kggat_case("kggat1_untied", ref_models)
+    recon_full_case("recon1_untied", ref_models)
+    if os.environ.get("RECON_GOLDEN_ONLY") in ("eac", "shells"):
         return
     gpgnn_case("prop_n4d2_shared", ref_models, 4, 2, per_batch_h0=False, salt=1)
     gpgnn_case("prop_n4d2_perbatch", ref_models, 4, 2, per_batch_h0=True, salt=2)
@@ -563,8 +699,10 @@ if __name__ == "__main__" and os.environ.get("RECON_GOLDEN_ONLY") == "formats":
     gen_formats()
     sys.exit(0)
 
-if __name__ == "__main__" and os.environ.get("RECON_GOLDEN_ONLY") == "eac":
+if __name__ == "__main__" and os.environ.get("RECON_GOLDEN_ONLY") in ("eac", "shells"):
     _install_shims()
+    if os.environ.get("RECON_GOLDEN_ONLY") == "shells":
+        gen_sep_space()
     gen_gpgnn()
     sys.exit(0)
 
@@ -579,6 +717,7 @@ if __name__ == "__main__":
     torch.set_num_threads(4)
     _install_shims()
     gen_gat()
+    gen_sep_space()
     # GAT's `layers` / `models` module names collide with the GP-GNN package names: drop them first
     for k in ("layers", "models"):
         sys.modules.pop(k, None)

@@ -873,6 +873,38 @@ def test_spkbgat_golden(name):
     close(tr, g["test_relation"], what="batch_test relation")
 
 
+def test_sep_space_spkbgat_golden():
+    """GAT_sep_space: the stage-A model with W_ent2rel — strict state_dict load, forward, the relation-space projection of every
+    triple's entities (GAT_sep_space/main.py:359-367) grouped by relation instead of gathered per triple, and every gradient of the
+    L1 translation residual (W_ent2rel's included) against the reference."""
+    from recon_amd.sep_space import SpKBGATModified
+    g = load_golden("sepspace1")
+    d = dev()
+    H, nhid = int(g["nheads"]), int(g["nhid"])
+    sd0 = {k[3:]: T(g[k]) for k in g if k.startswith("p0.")}
+    m = SpKBGATModified(sd0["entity_embeddings"].clone(), sd0["relation_embeddings"].clone(), [nhid, nhid * H], [nhid * H, nhid * H], 0.0, 0.2, [H, H], None)
+    m.load_state_dict(sd0, strict=True)
+    m = m.to(d).eval()
+    out_e, out_r, mask = m(None, T(g["batch_entities"]).to(d), (T(g["edge"]).to(d), T(g["edge_type"]).to(d)), T(g["nhop"]).to(d))
+    close(out_e, g["out_entity"], what="out_entity")
+    close(out_r, g["out_relation"], what="out_relation")
+    tri = T(g["triples"]).to(d)
+    src = m.ent2rel(out_e[tri[:, 0]], tri[:, 1])
+    dst = m.ent2rel(out_e[tri[:, 2]], tri[:, 1])
+    close(src, g["src_rel"], atol=2e-5, what="tanh(e_src W_r)")
+    close(dst, g["dst_rel"], atol=2e-5, what="tanh(e_dst W_r)")
+    norm = torch.norm(src + out_r[tri[:, 1]] - dst, p=1, dim=1)
+    close(norm, g["norm"], atol=1e-4, what="L1 residual")
+    (norm * T(g["Gn"]).to(d)).sum().backward()
+    seen = 0
+    for k, p in m.named_parameters():
+        if "g." + k in g:
+            close(p.grad, g["g." + k], atol=2e-5, rel_to_max=1e-4, what="g." + k)
+            seen += 1
+    assert seen == sum(k.startswith("g.") for k in g) and "g.W_ent2rel" in g
+    assert m.ent2rel(out_e[:0], tri[:0, 1]).shape == (0, nhid * H)
+
+
 @pytest.mark.parametrize("N,E,C_,skew", [(5, 4000, 24, True), (300, 1000, 7, False), (64, 70000, 200, True), (1000, 3, 4, False), (237, 50000, 50, True), (9, 0, 5, False),
                                           (40, 3000, 130, False)])          # C = 50, 130: the two-wide column form
 def test_spmm_rowsum_long_and_short_segments(N, E, C_, skew):

@@ -207,6 +207,51 @@ EAC_P = {"max_num_nodes": 3, "embedding_dim": 2, "layer_number": 3, "projection_
          "entity_embed_dim": 2, "conv_filter_size": 2, "entity_conv_filter_size": 2, "max_char_len": 4, "char_feature_size": 3}
 
 
+KGGAT_P = dict(EAC_P, gat_entity_embedding_dim=3)
+
+
+def recon_constructor_tables(g):
+    """The four lookup arguments of RECON's constructor (models/models.py:708) as tests/golden/gen_golden.py::recon_full_case built them."""
+    rel = {str(i): [float(v) for v in g["rel_table"][i]] for i in range(g["rel_table"].shape[0])}
+    return rel, g["W_all"], {0: "P0", 1: "P31", 2: "P17"}, {"P31": "3", "P17": "1"}
+
+
+def test_recon_shells_state_dict_matches_reference():
+    """Wider N3: checkpoint keys and shapes of the reference's RECON_EAC_KGGAT and RECON (fixtures written by their constructors),
+    and RECON's constructor-time table lookups (rows of outputs without a KB-GAT relation stay zero)."""
+    from recon_amd.gpgnn import RECON_EAC_KGGAT, RECON
+    regenerated = {"head_indices", "tail_indices", "start_embedding"}
+    g = load_golden("kggat1_untied")
+    m = RECON_EAC_KGGAT(dict(KGGAT_P), g["emb"], max_sent_len=4, n_out=3, char_vocab=list(range(int(g["n_chars"]))))
+    ref = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    assert set(m.state_dict().keys()) - regenerated == set(ref.keys())
+    for k, v in ref.items():
+        assert tuple(m.state_dict()[k].shape) == tuple(v.shape), k
+    assert m.linear3.in_features == 2 * 2 * 3 + 2 * 3
+    g = load_golden("recon1_untied")
+    m = RECON(dict(KGGAT_P), g["emb"], 4, 3, list(range(int(g["n_chars"]))), *recon_constructor_tables(g))
+    ref = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    assert set(m.state_dict().keys()) - {"start_embedding"} == set(ref.keys())           # no head_indices / tail_indices keys in this class
+    for k, v in ref.items():
+        assert tuple(m.state_dict()[k].shape) == tuple(v.shape), k
+    np.testing.assert_array_equal(m.gat_relation_embeddings.detach().numpy(), ref["gat_relation_embeddings"])
+    np.testing.assert_array_equal(m.W_ent2rel.numpy(), ref["W_ent2rel"])
+    assert not m.gat_relation_embeddings[0].any() and m.gat_relation_embeddings.requires_grad and not m.W_ent2rel.requires_grad
+    assert m.linear3.in_features == 2 * 2 * 3 + 2 * 3 + 3
+
+
+def test_sep_space_state_dict_matches_reference():
+    """GAT_sep_space/models.py:91-245: the GAT tree's keys + W_ent2rel; the reference's own checkpoint loads with strict=True."""
+    from recon_amd.sep_space import SpKBGATModified
+    g = load_golden("sepspace1")
+    sd0 = {k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("p0.")}
+    H, nhid = int(g["nheads"]), int(g["nhid"])
+    m = SpKBGATModified(sd0["entity_embeddings"].clone(), sd0["relation_embeddings"].clone(), [nhid, nhid * H], [nhid * H, nhid * H], 0.0, 0.2, [H, H], None)
+    assert sorted(m.state_dict().keys()) == sorted(sd0.keys())
+    m.load_state_dict(sd0, strict=True)
+    assert m.W_ent2rel.shape == (sd0["relation_embeddings"].shape[0], nhid * H, nhid * H) and m.nonlinearity_ent2rel is torch.tanh
+
+
 def test_recon_eac_state_dict_matches_reference():
     """the reference RECON_EAC's checkpoint keys and shapes (fixture written by running its constructor), and
     its entity-context encoder — stock ops, so it runs here — against the reference's entity vectors (the numerical check of

@@ -421,6 +421,63 @@ def test_recon_eac_model_golden():
     assert seen == sum(k.startswith("g.") for k in g)
 
 
+def _shell_inputs(g):
+    t = lambda k: torch.from_numpy(g[k]).to(dev())
+    return t, (t("sent"), t("mark"), None, None, None, t("ctx_words"), t("ctx_chars"), t("ctx_mask"), t("pos"), int(g["max_occ"]))
+
+
+def _check_model_grads(m, g, out, what):
+    close(out, g["out"], atol=1e-4, what=what + " logits")
+    (out * torch.from_numpy(g["G"]).to(out.device)).sum().backward()
+    seen = 0
+    for k, v in m.named_parameters():
+        if "g." + k in g:
+            close(v.grad, g["g." + k], atol=1e-4, rel_to_max=1e-4, what=what + " grad " + k)
+            seen += 1
+    assert seen == sum(k.startswith("g.") for k in g)
+
+
+def test_recon_eac_kggat_model_golden():
+    """Wider N3: the reference RECON_EAC_KGGAT (models/models.py:489-701) end to end: propagation features + the KB-GAT entity
+    embeddings of every pair in front of the classifier; logits and every parameter gradient; the tied branch fails as it does there."""
+    from recon_amd.gpgnn import RECON_EAC_KGGAT
+    from tests.test_host_cpu import KGGAT_P
+    g = load_golden("kggat1_untied")
+    m = RECON_EAC_KGGAT(dict(KGGAT_P), g["emb"], max_sent_len=4, n_out=3, char_vocab=list(range(int(g["n_chars"]))))
+    missing, unexpected = m.load_state_dict({k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("sd.")}, strict=False)
+    assert set(missing) == {"head_indices", "tail_indices", "start_embedding"} and not unexpected
+    m.train().to(dev())
+    t, args = _shell_inputs(g)
+    _check_model_grads(m, g, m(*args, t("gat")), "recon_eac_kggat")
+    tied = RECON_EAC_KGGAT(dict(KGGAT_P, projection_style="tie"), g["emb"], max_sent_len=4, n_out=3, char_vocab=list(range(int(g["n_chars"])))).to(dev())
+    with pytest.raises(RuntimeError):
+        tied(*args, t("gat"))
+
+
+def test_recon_full_model_golden():
+    """Wider N3: the reference's full model RECON (models/models.py:703-968): + the L1 translation residuals in every output
+    relation's space, scattered to the pairs with known embeddings.  `gat_relation_embeddings` trains, `W_ent2rel` does not."""
+    from recon_amd.gpgnn import RECON
+    from tests.test_host_cpu import KGGAT_P, recon_constructor_tables
+    g = load_golden("recon1_untied")
+    m = RECON(dict(KGGAT_P), g["emb"], 4, 3, list(range(int(g["n_chars"]))), *recon_constructor_tables(g))
+    sd = {k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("sd.")}
+    np.testing.assert_array_equal(m.gat_relation_embeddings.detach().numpy(), sd["gat_relation_embeddings"].numpy())     # the constructor's own table lookup
+    np.testing.assert_array_equal(m.W_ent2rel.numpy(), sd["W_ent2rel"].numpy())
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert set(missing) == {"start_embedding"} and not unexpected            # head / tail indices are not checkpoint keys in this class (:759-768)
+    m.train().to(dev())
+    assert m.head_indices.is_cuda
+    t, args = _shell_inputs(g)
+    out = m(*args, t("nz"), t("nz_pos"), t("gat"))
+    assert out.shape == (4 * 6, 3)
+    _check_model_grads(m, g, out, "recon")
+    assert m.W_ent2rel.grad is None
+    # no pair with known embeddings: the score block stays zero
+    out0 = m(*args, t("nz")[:0], t("nz_pos")[:0], t("gat"))
+    assert torch.isfinite(out0).all()
+
+
 # ------------------------------------------------------------------------------- GraphConvolution in bfloat16 (configs[2])
 def _bf(t):
     return t.to(torch.bfloat16)
