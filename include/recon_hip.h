@@ -318,6 +318,11 @@ typedef struct {
                                      * recon_propagate_form() == 1 (the two-term f16 kernels, whose         *
                                      * per-tensor scales in the backward come from these); the backward     *
                                      * runs its two-term form only when given the same buffer              */
+    void* split_ws;                 /* recon_propagate_ws_bytes() bytes or NULL.  Wide states (160 < S <= 512, e.g. 32 nodes *
+                                     * at 2d = 16): with it the forward runs the two-term f16 form of csrc/prop_hl.hip (A_l  *
+                                     * pre-split into half terms per slice of graphs, 64-channel chunks per workgroup);      *
+                                     * without it, the fp32 matrix-core form                                                 */
+    int64_t split_ws_bytes;
 } recon_prop_args;
 
 int recon_propagate_fwd(const recon_prop_args* args, recon_stream_t stream);
@@ -325,6 +330,9 @@ int recon_propagate_fwd(const recon_prop_args* args, recon_stream_t stream);
  * aligned pointers, RECON_PROP_FWD unset or "h"); bit 1: so does the backward (its LDS image also fits); 0: fp32 matrix-core forms.
  * Block mode (`trans`) needs both bits when gradients are wanted.  The adjacency pointers need not be set for this query. */
 int recon_propagate_form(const recon_prop_args* args);
+/* Bytes of `split_ws` that let recon_propagate_fwd run the wide-state two-term form for this problem (B, S, L; block mode or not),
+ * 0 where that form does not exist (S <= 160: the whole graph fits one workgroup and needs no workspace; S > 512). */
+size_t recon_propagate_ws_bytes(const recon_prop_args* args);
 
 typedef struct {
     recon_prop_args fwd;            /* h_saved filled by the forward call                                 */

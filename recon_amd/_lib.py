@@ -62,7 +62,8 @@ class PropArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("C", C.c_int32), ("S", C.c_int32), ("L", C.c_int32), ("dd", C.c_int32),
                 ("act", C.c_int32), ("adj", C.POINTER(C.c_void_p)), ("h0", c_f32p), ("h0_batch_stride", C.c_int64),
                 ("head_idx", c_i64p), ("tail_idx", c_i64p), ("idx_batch_stride", C.c_int64),
-                ("out", c_f32p), ("h_saved", c_f32p), ("trans", C.POINTER(C.c_void_p)), ("identity", c_f32p), ("stats", c_f32p)]
+                ("out", c_f32p), ("h_saved", c_f32p), ("trans", C.POINTER(C.c_void_p)), ("identity", c_f32p), ("stats", c_f32p),
+                ("split_ws", C.c_void_p), ("split_ws_bytes", C.c_int64)]
 
 
 class PropBwdArgs(C.Structure):
@@ -129,6 +130,7 @@ SYMBOLS = [
     ("recon_propagate_bwd", C.c_int, [C.POINTER(PropBwdArgs), C.c_void_p]),
     ("recon_propagate_form", C.c_int, [C.POINTER(PropArgs)]),
     ("recon_propagate_identity_ws_floats", C.c_size_t, [C.c_int32]),
+    ("recon_propagate_ws_bytes", C.c_size_t, [C.POINTER(PropArgs)]),
     ("recon_start_entity_embeddings", C.c_int, [c_f32p, c_i64p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
                                                 C.c_void_p]),
     ("recon_gcn_split_bytes", C.c_size_t, [C.c_int32, C.c_int32]),

@@ -825,7 +825,8 @@ bool prop_geometry(int C, int S, PropGeom* g) {
     g->pitch = g->Sp + 4;
     const int Cp = (C + 15) / 16 * 16;
     int cc = Cp < 80 ? Cp : 80;                                     // <= 5 MFMA row tiles per block
-    while (cc > 16 && 2ull * cc * g->pitch * sizeof(float) > 120 * 1024) cc -= 16;
+    static const size_t budget = [] { const char* e = getenv("RECON_PROP_LDS_KB"); return static_cast<size_t>(e ? atoi(e) : 150) * 1024; }();      // S = 512: 32-channel chunks instead of 16 (half the re-reads of A_l)
+    while (cc > 16 && 2ull * cc * g->pitch * sizeof(float) > budget) cc -= 16;
     if (2ull * cc * g->pitch * sizeof(float) > 160 * 1024) return false;
     g->CC = cc;
     g->MT = cc / 16;
@@ -947,6 +948,7 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
     p.B = a->B; p.C = a->C; p.S = a->S; p.L = a->L; p.dd = a->dd; p.act = a->act;
     p.CC = g.CC; p.Sp = g.Sp; p.pitch = g.pitch;
     p.stats = a->h_saved ? a->stats : nullptr;
+    p.ws = a->split_ws; p.ws_bytes = a->split_ws_bytes;
     hipStream_t st = as_stream(stream);
     const int NTn = g.Sp / 16;
     const int mtn_s = (a->C + 15) / 16;
@@ -955,6 +957,7 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
         // selects one of the forms below (fp32 MFMA per wave / per workgroup / staged, bf16 x 3), h forces the default
         const char* form = getenv("RECON_PROP_FWD");
         if ((!form || form[0] == 'h' || form[0] == '\0') && prop_fwd_h_supported(p)) return prop_fwd_h(p, st);
+        if ((!form || form[0] == 'h' || form[0] == '\0') && prop_fwd_hl_supported(p)) return prop_fwd_hl(p, st);     // wide states, given a workspace
         if (blk) return RECON_ERR_UNSUPPORTED;                          // the other forms need a materialised adjacency
         const int ntc = (a->C + 15) / 16, ks = (a->S + 31) / 32, mw = (a->S + 15) / 16;
         if (form && form[0] == 'x' && ntc <= 8 && ks <= 4 && mw <= 16) {     // S <= 128: wider states spill in this form             // bf16 x 3 on the bf16 matrix cores: opt-in (see the kernel's header)
@@ -1012,6 +1015,12 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
 static bool prop_h_form_env() {
     const char* form = getenv("RECON_PROP_FWD");
     return !form || form[0] == 'h' || form[0] == '\0';
+}
+
+extern "C" size_t recon_propagate_ws_bytes(const recon_prop_args* a) {
+    if (!a || !prop_h_form_env() || (a->S % 4) != 0 || a->dd < 1) return 0;
+    if (a->trans && (a->dd != 16 || a->S % 16 != 0 || a->C != (a->S / 16) * (a->S / 16 - 1))) return 0;
+    return prop_hl_ws_bytes(a->B, a->S, a->L);
 }
 
 extern "C" size_t recon_propagate_identity_ws_floats(int32_t dd) {

@@ -15,6 +15,7 @@ struct PropK {
     float* stats;             // [B][2L+1] max magnitudes of h^0..h^L, A_1..A_L per graph (two-term forms, with hsave) or null
     const float* trans[kMaxHops];     // block mode (identity != null): transition tensors [B][C][dd*dd]; adj unused
     const float* identity;
+    void* ws; int64_t ws_bytes;       // wide-state two-term form (prop_hl.hip): split workspace or null
 };
 
 // backward of the two-term form (prop_h.hip): all L hops of a graph in one persistent workgroup
@@ -62,6 +63,10 @@ __device__ __forceinline__ float act_bwd(float y, int act) {
 // does not take (the caller then runs a fp32-MFMA form of prop.hip)
 bool prop_fwd_h_supported(const PropK& p);
 int prop_fwd_h(const PropK& p, hipStream_t st);
+// prop_hl.hip: the same arithmetic for wide states (160 < S <= 512) in 64-channel chunks, A_l pre-split into a caller-owned workspace
+size_t prop_hl_ws_bytes(int B, int S, int L);
+bool prop_fwd_hl_supported(const PropK& p);
+int prop_fwd_hl(const PropK& p, hipStream_t st);
 bool prop_bwd_h_shape_ok(int C, int S);   // LDS budget of the backward's two-term form
 int prop_h_grid(int B);               // workgroups the two-term kernels launch for B graphs (one per CU, persistent)
 bool prop_bwd_h_supported(const PropBwdH& p);

@@ -1,0 +1,431 @@
+// K5''' — GP-GNN propagation (models/models.py:260-274) for WIDE states (160 < S <= 512: up to 32 nodes at 2d = 16, BASELINE.json
+// configs[2] "n=32") on the f16 matrix cores with two-term operands, the arithmetic of prop_h.hip (fp32-class accuracy at 3 x
+// v_mfma_f32_16x16x32_f16 per 16x16x32 block).  A graph's state no longer fits one CU's LDS, but channels never mix
+// (h^l[c] = act(A_l h^l-1[c])), so a workgroup owns (graph, 64 channels) for all L hops and the 16 workgroups of a graph share
+// A_l through their XCD's L2:
+//   * k_prop_split_adj (once per slice of graphs): every row of every A_l gets its own power-of-two scale (s.amax in [2^14, 2^15)) and
+//     is written as two half terms IN MFMA FRAGMENT ORDER — one KiB per (16 rows, K step, term), lane after lane — so that the
+//     propagation kernel's operand loads are plain coalesced 16-byte loads with no arithmetic behind them (each A_l is consumed by
+//     C / 64 workgroups: converting it once instead of C / 64 times is what this pass buys).  In block mode it reads the transition
+//     tensors / the identity in place (models/models.py:240-259): the S x S adjacency never exists in fp32.
+//   * k_propagate_fwd_hl: 8 waves; wave w owns rows 16 RT w .. of A_l (RT row tiles at once: a B fragment read from LDS feeds RT MFMAs
+//     per term), walks the K steps with the next step's A fragments in flight (across hop boundaries), keeps its RT x 4 output tiles in
+//     accumulators over the barrier that ends the hop's reads and writes the new state IN PLACE: 64 channels x 512 columns x two
+//     half planes = 128 KiB of LDS, under per-channel power-of-two scales (max magnitude gathered with LDS atomics, as in prop_h.hip);
+//     head (.) tail gather and the saved state are reconstructed from hi + lo.
+// Workgroup -> (graph, chunk) puts the chunks of one graph on ONE XCD (blockIdx.x & 7 is the XCD under round-robin dispatch).
+#include <stdlib.h>
+#include "prop_common.h"
+#include "prop_h_util.h"
+
+namespace recon {
+namespace {
+
+constexpr int kCH = 64;                 // channels per workgroup
+constexpr int kSTEP = kCH * 64;         // bytes of one K step (32 columns) of one plane: 64 bytes per channel
+constexpr int kHLWaves = 8;
+
+struct PropHL {
+    PropK p;
+    unsigned char* split;               // [L][G][RTT = 8 RT][NKS][2 terms][64 lanes x 16 B]
+    float* alpha;                       // [L][G][RP = 128 RT] inverse row scales
+    int32_t g0, G, nchunks, NKS, RT;    // slice = graphs g0 .. g0 + G - 1; NKS even (K padded with zeros)
+};
+
+// ---------------------------------------------------------------------------------------------------------------- split pass
+// One wave per (hop, graph, 16 rows): the rows' fragments for all K steps in registers, row maximum across the four lanes of a row,
+// scale, two half terms, 16-byte stores in fragment order.  K step ks, lane (li, lq): t = 32 ks + 4 lq .. + 3 and 32 ks + 16 + 4 lq .. + 3
+// (the k permutation of prop_h.hip: both pieces are contiguous 16 bytes of the fp32 row).
+template <bool BLK>
+__global__ void __launch_bounds__(256) k_prop_split_adj(const PropHL q) {
+    const PropK& p = q.p;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int RTT = 8 * q.RT, RP = 128 * q.RT, NKS = q.NKS;
+    int64_t unit = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+    const int rt = static_cast<int>(unit % RTT);
+    unit /= RTT;
+    const int g = static_cast<int>(unit % q.G), l = static_cast<int>(unit / q.G);
+    if (l >= p.L) return;
+    const int b = q.g0 + g, S = p.S;
+    constexpr int MAXK = 16;
+    u32x4 raw[MAXK][2];
+    if constexpr (!BLK) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.adj[l] + static_cast<int64_t>(b) * S * S), 0, S * S * 4, 0x00020000);
+        const int row = 16 * rt + li;
+        const uint32_t base = row < S ? static_cast<uint32_t>(row * S + 4 * lq) * 4u : kOOB;
+#pragma unroll
+        for (int ks = 0; ks < MAXK; ++ks)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t0 = 32 * ks + 16 * h + 4 * lq;
+                raw[ks][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, (row < S && t0 < S) ? base + static_cast<uint32_t>(32 * ks + 16 * h) * 4u : kOOB, 0, 0);
+            }
+    } else {
+        // rows of node i = rt: block (i, j) = trans[l][b, e(i, j)] (row li, columns 4 lq ..), the identity on the diagonal
+        const int nn = S >> 4, C = p.C;
+        const auto rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.trans[l] + static_cast<int64_t>(b) * C * 256), 0, C * 1024, 0x00020000);
+        const auto rs_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.identity), 0, 1024, 0x00020000);
+        const uint32_t vb = static_cast<uint32_t>(li * 16 + 4 * lq) * 4u;
+#pragma unroll
+        for (int ks = 0; ks < MAXK; ++ks)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = 2 * ks + h;
+                const bool ok = rt < nn && j < nn, diag = j == rt;
+                const uint32_t e = static_cast<uint32_t>(rt * (nn - 1) + (j < rt ? j : j - 1));
+                const auto rs = diag ? rs_i : rs_t;                     // wave-uniform: a scalar select
+                raw[ks][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? vb : kOOB, diag ? 0 : static_cast<int>(e * 1024u), 0);
+            }
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < MAXK; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const u32x4 v = raw[ks][h];
+            m = fmaxf(fmaxf(fabsf(as_f(v.x)), fabsf(as_f(v.y))), m);
+            m = fmaxf(fmaxf(fabsf(as_f(v.z)), fabsf(as_f(v.w))), m);
+        }
+    m = rows_max(m);
+    const float alpha = hx2_scale_of(m);
+    if (lq == 0) q.alpha[(static_cast<int64_t>(l) * q.G + g) * RP + 16 * rt + li] = hx2_inv(alpha);
+    unsigned char* dst = q.split + (((static_cast<int64_t>(l) * q.G + g) * RTT + rt) * NKS) * 2048 + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < MAXK; ++ks) {
+        if (ks < NKS) {
+            uint32_t hi[4], lo[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32x4 v = raw[ks][h];
+                hx2_split2(as_f(v.x) * alpha, as_f(v.y) * alpha, hi[2 * h], lo[2 * h]);
+                hx2_split2(as_f(v.z) * alpha, as_f(v.w) * alpha, hi[2 * h + 1], lo[2 * h + 1]);
+            }
+            *reinterpret_cast<u32x4*>(dst + ks * 2048) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<u32x4*>(dst + ks * 2048 + 1024) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- propagation
+// State image (as in prop_h.hip, with 64 channels per K step): element (channel c, column t) of plane q lives at byte
+//     q PLANE + (t >> 5) kSTEP + 64 c + 16 (((t >> 2) & 3) ^ ((c >> 1) & 3)) + 8 ((t >> 4) & 1) + 2 (t & 3).
+__device__ __forceinline__ int hl_pos4(int c, int t0) {                 // t0 % 4 == 0: the 8 bytes holding columns t0 .. t0 + 3
+    return (t0 >> 5) * kSTEP + 64 * c + ((((t0 >> 2) & 3) ^ ((c >> 1) & 3)) << 4) + (((t0 >> 4) & 1) << 3);
+}
+
+template <int RT, int NKS>
+__global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const PropK& p = q.p;
+    constexpr int PLANE = NKS * kSTEP, KP = NKS * 32;
+    const int S = p.S, C = p.C, L = p.L;
+    unsigned char* Hs = sm;
+    uint32_t* chmax = reinterpret_cast<uint32_t*>(sm + 2 * PLANE);      // [2][kCH]
+    float* isg = reinterpret_cast<float*>(chmax + 2 * kCH);             // [kCH] inverse channel scales
+    float* atab = isg + kCH;                                            // [L][128 RT] inverse row scales of this graph's A_l
+    uint32_t* gtab = reinterpret_cast<uint32_t*>(atab + p.L * 128 * RT);   // [8][512] gather items of each thread (kept out of the registers)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int wg = blockIdx.x, xcd = wg & 7, rr = wg >> 3;
+    const int chunk = rr % q.nchunks, gs = (rr / q.nchunks) * 8 + xcd;
+    if (gs >= q.G) return;
+    const int b = q.g0 + gs, c0 = chunk * kCH;
+    const int nch = C - c0 < kCH ? C - c0 : kCH;                        // valid channels of this chunk
+    const int RTT = 8 * RT, RP = 128 * RT;
+    const uint32_t hop_bytes = static_cast<uint32_t>(RTT) * NKS * 2048u;
+
+    // ---- A fragments: two slots of one K step each, refilled row tile by row tile two K steps ahead
+    u32x4 ring[2][RT][2];
+    uint32_t voff_rt[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) voff_rt[r] = static_cast<uint32_t>((wave * RT + r) * NKS) * 2048u + lane * 16u;
+    auto rsrc_hop = [&](int l) {
+        return __builtin_amdgcn_make_buffer_rsrc(q.split + (static_cast<int64_t>(l) * q.G + gs) * hop_bytes, 0, static_cast<int>(hop_bytes), 0x00020000);
+    };
+    auto rs_cur = rsrc_hop(0);
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)                                       // K steps 0 and 1 of hop 0 (NKS >= 2)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            ring[sl][r][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, voff_rt[r], sl * 2048, 0);
+            ring[sl][r][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, voff_rt[r] + 1024u, sl * 2048, 0);
+        }
+
+    auto store_state4 = [&](int off, float v0, float v1, float v2, float v3) {
+        uint32_t h0, l0, h1, l1;
+        hx2_split2(v0, v1, h0, l0);
+        hx2_split2(v2, v3, h1, l1);
+        *reinterpret_cast<uint2*>(Hs + off) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(Hs + PLANE + off) = make_uint2(l0, l1);
+    };
+
+    // ---- h^0 of this chunk: wave w stages channels w, w + 8, ... (a whole channel per wave: its max magnitude is a wave reduction), four
+    // channels per batch; columns past S and channels past C come back as zeros and are written as zeros
+    {
+        if (tid < 2 * kCH) chmax[tid] = 0u;
+        for (int i = tid; i < L * RP; i += 64 * kHLWaves) {             // all hops' row scales: no global load inside the hop loop but the A fragments
+            const int l = i / RP;
+            atab[i] = q.alpha[(static_cast<int64_t>(l) * q.G + gs) * RP + (i - l * RP)];
+        }
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.h0 + b * p.h0_bs + static_cast<int64_t>(c0) * S), 0, nch * S * 4, 0x00020000);
+#pragma unroll 1
+        for (int batch = 0; batch < 2; ++batch) {
+            u32x4 hv[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int cl = wave + 8 * (4 * batch + i);
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int t0 = 4 * lane + 256 * ps;
+                    hv[i][ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, (cl < nch && t0 < S) ? static_cast<uint32_t>(cl * S + t0) * 4u : kOOB, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int cl = wave + 8 * (4 * batch + i);
+                float mx = 0.f;
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const u32x4 v = hv[i][ps];
+                    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(as_f(v.x)), fabsf(as_f(v.y))), fmaxf(fabsf(as_f(v.z)), fabsf(as_f(v.w)))));
+                }
+                mx = wave_max(mx);
+                const float sg = hx2_scale_of(mx);
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int t0 = 4 * lane + 256 * ps;
+                    const u32x4 v = hv[i][ps];
+                    if (t0 < KP) store_state4(hl_pos4(cl, t0), as_f(v.x) * sg, as_f(v.y) * sg, as_f(v.z) * sg, as_f(v.w) * sg);
+                }
+                if (lane == 0) isg[cl] = hx2_inv(sg);
+            }
+        }
+    }
+    // ---- gather items of this thread (the same in every hop): (channel cl, x) -> byte positions of head / tail in plane 0
+    const int nitems = nch * p.dd, Ldd = L * p.dd;
+    {
+        uint32_t g_hi[2], g_ti[2], g_o[2], g_c[2];
+        const int64_t* hd = p.head + b * p.idx_bs + static_cast<int64_t>(c0) * p.dd;
+        const int64_t* tl = p.tail + b * p.idx_bs + static_cast<int64_t>(c0) * p.dd;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = min(tid + i * 64 * kHLWaves, nitems - 1);
+            const int cl = idx / p.dd;
+            const int th = static_cast<int>(hd[idx]), tt = static_cast<int>(tl[idx]);
+            g_hi[i] = hl_pos4(cl, th & ~3) + 2 * (th & 3);
+            g_ti[i] = hl_pos4(cl, tt & ~3) + 2 * (tt & 3);
+            g_o[i] = 4u * static_cast<uint32_t>(idx + cl * (Ldd - p.dd));                  // cl L dd + x
+            g_c[i] = 4u * cl;
+            gtab[(4 * i + 0) * 512 + tid] = g_hi[i]; gtab[(4 * i + 1) * 512 + tid] = g_ti[i];
+            gtab[(4 * i + 2) * 512 + tid] = g_o[i]; gtab[(4 * i + 3) * 512 + tid] = g_c[i];
+        }
+    }
+    lds_barrier();
+    float inv_sig[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) inv_sig[j] = isg[16 * j + li];
+
+    const int swz = ((li >> 1) & 3) << 4;
+    const int b_rd = li * 64 + ((lq << 4) ^ swz);                       // B fragment: + 1024 j + kSTEP ks (+ PLANE for the low terms)
+    const bool homog = p.act != RECON_ACT_TANH, relu = p.act == RECON_ACT_RELU;
+
+#pragma unroll 1
+    for (int l = 0; l < L; ++l) {
+        const auto rs_next = rsrc_hop(l + 1 < L ? l + 1 : l);
+        f32x4 acc[RT][4];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // one K step out of ring slot ks & 1.  Row tile after row tile: as soon as a tile's 12 MFMAs are issued its two fragment registers
+        // are free and take the SAME tile of K step ks + 2 (next hop past the end; out of range past the last hop: zeros, no branch) — two K
+        // steps of A in flight in two slots' worth of registers.  The K loop is unrolled: straight-line code lets the compiler count the
+        // outstanding requests (s_waitcnt vmcnt(N) instead of draining them at every step).
+        const uint32_t next_ok = l + 1 < L ? 0u : kOOB;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int BUF = ks & 1;
+            const bool wrap = ks + 2 >= NKS;
+            const auto rs = wrap ? rs_next : rs_cur;
+            const uint32_t so = static_cast<uint32_t>(wrap ? ks + 2 - NKS : ks + 2) * 2048u;
+            const uint32_t oob = wrap ? next_ok : 0u;
+            const unsigned char* hb = Hs + ks * kSTEP + b_rd;
+            f16x8 bh[4], bl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bh[j] = *reinterpret_cast<const f16x8*>(hb + 1024 * j);
+                bl[j] = *reinterpret_cast<const f16x8*>(hb + PLANE + 1024 * j);
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const f16x8 ah = __builtin_bit_cast(f16x8, ring[BUF][r][0]), al = __builtin_bit_cast(f16x8, ring[BUF][r][1]);
+#ifndef RECON_HL_NOMFMA
+                // small terms first; four independent accumulator chains
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], acc[r][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], acc[r][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], acc[r][j], 0, 0, 0);
+#else
+                acc[r][0][0] += static_cast<float>(ah[0]) + static_cast<float>(bl[r & 3][1]); acc[r][1][1] += static_cast<float>(al[7]) + static_cast<float>(bh[r & 3][2]);
+#endif
+#ifndef RECON_HL_NOLOAD
+                ring[BUF][r][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_rt[r] | oob, so, 0);
+                ring[BUF][r][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (voff_rt[r] + 1024u) | oob, so, 0);
+#endif
+                __builtin_amdgcn_sched_barrier(0x078f);                 // everything but VMEM may move across: the requests stay where they are written
+            }
+        }
+        rs_cur = rs_next;
+
+        // ---- epilogue 1: row scales off, activation, channel maxima.  C layout: column (lane & 15) = channel 16 j + li, rows 4 lq + r of row tile r.
+        uint32_t* cm = chmax + (l & 1) * kCH;
+        float4 ia[RT];                                                  // inverse row scales of this wave's rows (C layout: rows 4 lq + r of each row tile)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) ia[r] = *reinterpret_cast<const float4*>(atab + l * RP + 16 * (wave * RT + r) + 4 * lq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float mm = 0.f;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const float u = homog ? 1.f : inv_sig[j];
+                float v0 = acc[r][j][0] * (ia[r].x * u), v1 = acc[r][j][1] * (ia[r].y * u), v2 = acc[r][j][2] * (ia[r].z * u), v3 = acc[r][j][3] * (ia[r].w * u);
+                if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                if (!homog) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
+                acc[r][j] = f32x4{v0, v1, v2, v3};
+                mm = fmaxf(mm, fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))));
+            }
+            atomicMax(cm + 16 * j + li, __builtin_bit_cast(uint32_t, mm));
+        }
+        lds_barrier();                                                  // everybody has read H^l-1; maxima complete
+        // ---- epilogue 2: H^l under its new channel scales, in place
+        if (tid < kCH) chmax[((l + 1) & 1) * kCH + tid] = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float inv_u = homog ? inv_sig[j] : 1.f;               // the unit acc[.][j] is in now
+            const float sg = hx2_scale_of(__builtin_bit_cast(float, cm[16 * j + li]) * inv_u);
+            const float f = sg * inv_u;
+            inv_sig[j] = hx2_inv(sg);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const int t0 = 16 * (wave * RT + r) + 4 * lq;
+                if (t0 < KP) store_state4(hl_pos4(16 * j + li, t0), acc[r][j][0] * f, acc[r][j][1] * f, acc[r][j][2] * f, acc[r][j][3] * f);
+            }
+            if (tid < 16) isg[16 * j + li] = inv_sig[j];
+        }
+        lds_barrier();                                                  // H^l complete
+        // ---- relation_l = gather(h, heads) * gather(h, tails)   (models/models.py:270-273), saved state; values = (hi + lo) / scale
+        auto state_at = [&](uint32_t pos) {
+            return static_cast<float>(*reinterpret_cast<const _Float16*>(Hs + pos)) + static_cast<float>(*reinterpret_cast<const _Float16*>(Hs + PLANE + pos));
+        };
+        char* out = reinterpret_cast<char*>(p.out + ((static_cast<int64_t>(b) * C + c0) * L + l) * p.dd);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (tid + i * 64 * kHLWaves < nitems) {
+                const uint32_t ghi = gtab[(4 * i + 0) * 512 + tid], gti = gtab[(4 * i + 1) * 512 + tid], go = gtab[(4 * i + 2) * 512 + tid], gc = gtab[(4 * i + 3) * 512 + tid];
+                const float k = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(isg) + gc);
+                *reinterpret_cast<float*>(out + go) = (state_at(ghi) * k) * (state_at(gti) * k);
+            }
+        for (int idx = tid + 2 * 64 * kHLWaves; idx < nitems; idx += 64 * kHLWaves) {      // dd > 16
+            const int cl = idx / p.dd, x = idx - cl * p.dd;
+            const int64_t io = b * p.idx_bs + static_cast<int64_t>(c0) * p.dd + idx;
+            const int th = static_cast<int>(p.head[io]), tt = static_cast<int>(p.tail[io]);
+            const float k = isg[cl];
+            reinterpret_cast<float*>(out)[cl * Ldd + x] = (state_at(hl_pos4(cl, th & ~3) + 2 * (th & 3)) * k) * (state_at(hl_pos4(cl, tt & ~3) + 2 * (tt & 3)) * k);
+        }
+        if (p.hsave) {                                                  // wave w: channels w, w + 8, ...; lane = (K step, half, slot), two passes of 256 columns
+            char* hs = reinterpret_cast<char*>(p.hsave + ((static_cast<int64_t>(l) * p.B + b) * C + c0) * S);
+            for (int cl = wave; cl < nch; cl += kHLWaves) {
+                const float k = isg[cl];
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int ts = 256 * ps + 32 * (lane >> 3) + 16 * ((lane >> 2) & 1) + 4 * (lane & 3);
+                    if (ts < S) {
+                        const int off = hl_pos4(cl, ts);
+                        const uint2 hi = *reinterpret_cast<const uint2*>(Hs + off), lo = *reinterpret_cast<const uint2*>(Hs + PLANE + off);
+                        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                        const h2 a0 = __builtin_bit_cast(h2, hi.x), a1 = __builtin_bit_cast(h2, hi.y), b0 = __builtin_bit_cast(h2, lo.x), b1 = __builtin_bit_cast(h2, lo.y);
+                        float4 v;
+                        v.x = (static_cast<float>(a0[0]) + static_cast<float>(b0[0])) * k; v.y = (static_cast<float>(a0[1]) + static_cast<float>(b0[1])) * k;
+                        v.z = (static_cast<float>(a1[0]) + static_cast<float>(b1[0])) * k; v.w = (static_cast<float>(a1[1]) + static_cast<float>(b1[1])) * k;
+                        *reinterpret_cast<float4*>(hs + static_cast<uint32_t>(cl * S + ts) * 4u) = v;
+                    }
+                }
+            }
+        }
+        // the next hop's post-compute barrier orders these reads before its writes
+    }
+}
+
+struct HLGeom { int NKS, RT; size_t per_graph_split, per_graph_alpha, lds; };
+HLGeom hl_geom(int S, int L) {
+    HLGeom g;
+    g.NKS = ((S + 31) / 32 + 1) & ~1;                                   // even: the ring alternates between two slots
+    g.RT = (S + 127) / 128;
+    g.per_graph_split = static_cast<size_t>(L) * 8 * g.RT * g.NKS * 2048;
+    g.per_graph_alpha = static_cast<size_t>(L) * 128 * g.RT * sizeof(float);
+    g.lds = 2ull * g.NKS * kSTEP + 3ull * kCH * sizeof(uint32_t) + static_cast<size_t>(L) * 128 * g.RT * sizeof(float) + 8ull * 512 * sizeof(uint32_t);
+    return g;
+}
+constexpr int kHLSlice = 256;           // graphs per split pass (bounds the workspace: 0.8 GB at S = 512, L = 3)
+
+}  // namespace
+
+size_t prop_hl_ws_bytes(int B, int S, int L) {
+    if (S <= 160 || S > 512 || B <= 0 || L <= 0) return 0;
+    const HLGeom g = hl_geom(S, L);
+    const int G = B < kHLSlice ? B : kHLSlice;
+    return (g.per_graph_split + g.per_graph_alpha) * static_cast<size_t>(G) + 256;
+}
+
+bool prop_fwd_hl_supported(const PropK& p) {
+    if (p.S <= 160 || p.S > 512 || (p.S % 4) != 0 || p.dd < 1 || p.L < 1 || !p.ws) return false;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (p.identity && (p.dd != 16 || (p.S % 16) != 0 || p.C != (p.S / 16) * (p.S / 16 - 1) || !al16(p.identity))) return false;
+    for (int l = 0; l < p.L; ++l) if (!al16(p.identity ? p.trans[l] : p.adj[l])) return false;
+    if (!al16(p.h0) || (p.h0_bs % 4) != 0 || (p.hsave && !al16(p.hsave)) || !al16(p.ws)) return false;
+    if (static_cast<int64_t>(p.C) * p.S * 4 >= (1LL << 31)) return false;
+    const HLGeom g = hl_geom(p.S, p.L);
+    return p.ws_bytes >= static_cast<int64_t>(g.per_graph_split + g.per_graph_alpha + 256);
+}
+
+int prop_fwd_hl(const PropK& p, hipStream_t st) {
+    if (!prop_fwd_hl_supported(p)) return RECON_ERR_UNSUPPORTED;
+    const HLGeom g = hl_geom(p.S, p.L);
+    int64_t G = (p.ws_bytes - 256) / static_cast<int64_t>(g.per_graph_split + g.per_graph_alpha);
+    if (G > p.B) G = p.B;
+    if (G > kHLSlice) G = kHLSlice;
+    PropHL q;
+    q.p = p;
+    q.split = static_cast<unsigned char*>(p.ws);
+    q.alpha = reinterpret_cast<float*>(q.split + ((g.per_graph_split * static_cast<size_t>(G) + 255) & ~static_cast<size_t>(255)));
+    q.NKS = g.NKS; q.RT = g.RT; q.nchunks = (p.C + kCH - 1) / kCH;
+    for (int64_t g0 = 0; g0 < p.B; g0 += G) {
+        q.g0 = static_cast<int32_t>(g0);
+        q.G = static_cast<int32_t>(p.B - g0 < G ? p.B - g0 : G);
+        const int64_t units = static_cast<int64_t>(p.L) * q.G * 8 * g.RT;
+        const dim3 sgrid(static_cast<unsigned>((units + 3) / 4));
+        if (p.identity) hipLaunchKernelGGL(k_prop_split_adj<true>, sgrid, dim3(256), 0, st, q);
+        else hipLaunchKernelGGL(k_prop_split_adj<false>, sgrid, dim3(256), 0, st, q);
+        const dim3 grid(static_cast<unsigned>(((q.G + 7) / 8) * 8 * q.nchunks));
+#define CALL_HL(R_, K_)                                                                                                                 \
+    do {                                                                                                                                \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_fwd_hl<R_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  static_cast<int>(g.lds));                                                                             \
+        hipLaunchKernelGGL((k_propagate_fwd_hl<R_, K_>), grid, dim3(64 * kHLWaves), g.lds, st, q);                                      \
+    } while (0)
+        switch (g.NKS) {                                                // RT = rows / 128 follows from the K steps
+            case 6: CALL_HL(2, 6); break; case 8: CALL_HL(2, 8); break; case 10: CALL_HL(3, 10); break; case 12: CALL_HL(3, 12); break;
+            case 14: CALL_HL(4, 14); break; default: CALL_HL(4, 16); break;
+        }
+#undef CALL_HL
+    }
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+
+}  // namespace recon

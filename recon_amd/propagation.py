@@ -120,6 +120,17 @@ def _ptr_array(tensors):
     return arr
 
 
+def _split_workspace(args, dev):
+    """Workspace of the wide-state two-term forward (include/recon_hip.h: recon_prop_args.split_ws); None where that form does not
+    exist.  Sets the two fields of `args`; the caller keeps the returned tensor alive across the launch."""
+    nbytes = _lib.lib().recon_propagate_ws_bytes(C.byref(args))
+    if not nbytes:
+        return None
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    args.split_ws, args.split_ws_bytes = ws.data_ptr(), nbytes
+    return ws
+
+
 class _Propagate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h0, act, head, tail, *adjs):
@@ -146,7 +157,8 @@ class _Propagate(torch.autograd.Function):
         hs = torch.empty(L, B, Cn, S, dtype=torch.float32, device=dev) if need else None
         parr = _ptr_array(adjs)
         args = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], parr, h0c.data_ptr(), h0_bs, head.data_ptr(),
-                             tail.data_ptr(), idx_bs, out.data_ptr(), _lib.ptr(hs), None, None, None)
+                             tail.data_ptr(), idx_bs, out.data_ptr(), _lib.ptr(hs), None, None, None, None, 0)
+        ws = _split_workspace(args, dev)       # wide states (160 < S <= 512): A_l pre-split into half terms, slice by slice
         stats = None
         if need and _lib.lib().recon_propagate_form(C.byref(args)) & 1:
             # two-term f16 kernels: the forward records per graph the max magnitudes of the states and adjacencies, the backward takes its
@@ -172,7 +184,7 @@ class _Propagate(torch.autograd.Function):
         g_h = torch.empty(B, Cn, S, dtype=torch.float32, device=dev)
         parr, garr = _ptr_array(adjs), _ptr_array(g_adjs)
         fwd = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], parr, h0c.data_ptr(), h0_bs, head.data_ptr(), tail.data_ptr(),
-                            idx_bs, None, hs.data_ptr(), None, None, _lib.ptr(ctx.stats))
+                            idx_bs, None, hs.data_ptr(), None, None, _lib.ptr(ctx.stats), None, 0)
         fwd.out = gout.data_ptr()      # unused by the backward; must be non-null for the argument check
         args = _lib.PropBwdArgs(fwd, gout.data_ptr(), garr, g_h.data_ptr(), None, None, None)
         with torch.cuda.device(dev):
@@ -229,7 +241,8 @@ class _PropagateBlocks(torch.autograd.Function):
         stats = torch.empty(B, 2 * L + 1, dtype=torch.float32, device=dev) if need else None
         tarr = _ptr_array(Ts)
         args = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], None, h0c.data_ptr(), h0_bs, head.data_ptr(), tail.data_ptr(), idx_bs,
-                             out.data_ptr(), _lib.ptr(hs), tarr, identity.data_ptr(), _lib.ptr(stats))
+                             out.data_ptr(), _lib.ptr(hs), tarr, identity.data_ptr(), _lib.ptr(stats), None, 0)
+        ws = _split_workspace(args, dev)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().recon_propagate_fwd(C.byref(args), _lib.current_stream()), "recon_propagate_fwd (block mode)")
         if need:
@@ -250,7 +263,7 @@ class _PropagateBlocks(torch.autograd.Function):
         ws = torch.empty(Lb.recon_propagate_identity_ws_floats(dd), dtype=torch.float32, device=dev) if g_I is not None else None
         tarr, garr = _ptr_array(Ts), _ptr_array(g_Ts)
         fwd = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], None, h0c.data_ptr(), h0_bs, head.data_ptr(), tail.data_ptr(), idx_bs,
-                            gout.data_ptr(), hs.data_ptr(), tarr, identity.data_ptr(), stats.data_ptr())
+                            gout.data_ptr(), hs.data_ptr(), tarr, identity.data_ptr(), stats.data_ptr(), None, 0)
         args = _lib.PropBwdArgs(fwd, gout.data_ptr(), None, g_h.data_ptr(), garr, _lib.ptr(g_I), _lib.ptr(ws))
         with torch.cuda.device(dev):
             _lib.check(Lb.recon_propagate_bwd(C.byref(args), _lib.current_stream()), "recon_propagate_bwd (block mode)")
@@ -262,11 +275,13 @@ class _PropagateBlocks(torch.autograd.Function):
 
 def blocks_mode_available(B, n, dd, h0, need_grad=True):
     """Whether propagate_blocks() runs fused (two-term f16 kernels for the forward and, when gradients are wanted, for the backward:
-    2d = 16, n <= 9 (n = 10 forward only), B within one launch)."""
-    if dd != 16 or n < 2 or n > 10 or B > _MAX_BATCH or B == 0 or os.environ.get("RECON_PROP_BLOCKS", "1") == "0":
+    2d = 16, n <= 9; forward only — inference — for 10 <= n <= 32; B within one launch)."""
+    if dd != 16 or n < 2 or n > 32 or B > _MAX_BATCH or B == 0 or os.environ.get("RECON_PROP_BLOCKS", "1") == "0":
         return False
     Cn, S = n * (n - 1), n * dd
-    probe = _lib.PropArgs(B, Cn, S, 1, dd, 1, None, h0.data_ptr(), Cn * S if h0.dim() == 4 else 0, None, None, 0, None, None, None, None, None)
+    probe = _lib.PropArgs(B, Cn, S, 1, dd, 1, None, h0.data_ptr(), Cn * S if h0.dim() == 4 else 0, None, None, 0, None, None, None, None, None, None, 0)
+    if n > 10:          # wide states: the forward-only form of csrc/prop_hl.hip reads the transition tensors in place too
+        return (not need_grad) and h0.data_ptr() % 16 == 0 and _lib.lib().recon_propagate_ws_bytes(C.byref(probe)) > 0
     form = _lib.lib().recon_propagate_form(C.byref(probe))
     return form == 3 or (form == 1 and not need_grad)
 

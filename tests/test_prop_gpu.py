@@ -140,6 +140,74 @@ def test_propagation_vs_oracle(n, d, L, B, act, per_batch, form, monkeypatch):
         close(gh_h, gh_r, atol=1e-5, what="g_h0")
 
 
+@pytest.mark.parametrize("S,C,dd,L,B,act,per_batch,grad", [
+    (512, 130, 16, 3, 3, "relu", True, False),      # three chunks, the last one of 2 channels; inference
+    (512, 64, 16, 2, 2, "tanh", False, False),      # exactly one chunk, shared h0
+    (176, 5, 8, 3, 4, "linear", True, False),       # RT = 2, K padded from 6 to 6 steps ... 176 = 5.5 steps -> 6
+    (272, 70, 16, 2, 9, "relu", True, True),        # RT = 3, odd K steps padded to even; states saved, fp32 backward
+    (400, 33, 20, 1, 2, "relu", True, False),       # gather width 20: more than two items per thread
+    (256, 96, 4, 3, 11, "tanh", True, True),        # RT = 2 exactly; more than 8 graphs: two XCD rounds
+])
+def test_propagation_wide_states_vs_oracle(S, C, dd, L, B, act, per_batch, grad):
+    """160 < S <= 512: the two-term f16 form of csrc/prop_hl.hip (A_l pre-split per slice of graphs, 64-channel chunks per workgroup)
+    against the float64 oracle, on arbitrary adjacencies, start states and gather indices; with gradients the states it saves feed
+    the fp32 backward."""
+    from recon_amd.propagation import propagate
+    d_ = dev()
+    g = torch.Generator().manual_seed(S + C)
+    adjs = [(torch.rand(B, S, S, generator=g) - 0.45) * (2.0 / S ** 0.5) * (1 + l) for l in range(L)]
+    for a in adjs:
+        a[:, :, ::7] *= 8.0                                            # columns of very different magnitude inside a row
+        a[:, 5] *= 1e-3                                                # and rows: every row has its own scale
+    h0 = torch.randn(B, C, S, 1, generator=g) if per_batch else torch.randn(C, S, 1, generator=g)
+    head = torch.randint(0, S, (C, dd), generator=g)
+    tail = torch.randint(0, S, (C, dd), generator=g)
+    Gr = torch.randn(B, C, dd * L, generator=g)
+
+    def run(device, prop, dt):
+        A = [a.clone().to(device=device, dtype=dt).requires_grad_(grad) for a in adjs]
+        h = h0.clone().to(device=device, dtype=dt).requires_grad_(grad and per_batch)
+        out = prop(A, h, act, head.to(device), tail.to(device))
+        if grad:
+            (out * Gr.to(device=device, dtype=dt)).sum().backward()
+        return out.detach(), [a.grad for a in A], h.grad
+    out_r, gA_r, gh_r = run("cpu", lambda *a: O.propagate(*a, as_gemm=True), torch.float64)
+    out_h, gA_h, gh_h = run(d_, propagate, torch.float32)
+    close(out_h, out_r.float(), atol=1e-4, rel_to_max=1e-5, what="out")
+    if grad:
+        for l in range(L):
+            close(gA_h[l], gA_r[l].float(), atol=1e-5, what="g_adj[%d]" % l)
+        if per_batch:
+            close(gh_h, gh_r.float(), atol=1e-5, what="g_h0")
+
+
+@pytest.mark.parametrize("n,L,B,act", [(11, 3, 3, "relu"), (32, 3, 2, "relu"), (17, 2, 9, "tanh")])
+def test_propagate_blocks_wide_states_inference(n, L, B, act):
+    """Block mode for 10 < n <= 32 (inference): the split pass reads the transition tensors and the identity in place — the S x S
+    adjacency is never built — and must agree bit for bit with the same kernels fed the materialised adjacency, and with the oracle."""
+    from recon_amd.propagation import (build_block_adjacency, propagate, propagate_blocks, blocks_mode_available, make_start_embedding,
+                                       get_head_indices, get_tail_indices)
+    d_ = dev()
+    d = 8
+    C, S, dd = n * (n - 1), 2 * d * n, 2 * d
+    g = torch.Generator().manual_seed(n)
+    Ts = [torch.relu(torch.randn(B, C, dd * dd, generator=g)) * (0.5 / n) for _ in range(L)]
+    ident = torch.eye(dd) + 0.05 * torch.randn(dd, dd, generator=g)
+    tmpl = torch.from_numpy(make_start_embedding(n, d)).float()
+    h0 = torch.randn(B, C, S, 1, generator=g) * tmpl
+    head = torch.from_numpy(get_head_indices(n, d, bs=1)[0])
+    tail = torch.from_numpy(get_tail_indices(n, d, bs=1)[0])
+    with torch.no_grad():
+        assert blocks_mode_available(B, n, dd, h0.to(d_), need_grad=False)
+        assert not blocks_mode_available(B, n, dd, h0.to(d_), need_grad=True)
+        Td, Id, hd = [t.to(d_) for t in Ts], ident.to(d_), h0.to(d_)
+        out_f = propagate_blocks(Td, Id, n, hd, act, head.to(d_), tail.to(d_))
+        out_u = propagate([build_block_adjacency(t, Id, n) for t in Td], hd, act, head.to(d_), tail.to(d_))
+        ref = O.propagate([O.build_block_adjacency(t.double(), ident.double(), n) for t in Ts], h0.double(), act, head, tail, as_gemm=True)
+    assert torch.equal(out_f, out_u)
+    close(out_f, ref.float(), atol=1e-4, rel_to_max=1e-5, what="out")
+
+
 @pytest.mark.parametrize("n,L,B,act,per_batch,tied", [(9, 3, 7, "relu", True, False), (9, 3, 300, "relu", False, False), (4, 2, 5, "tanh", True, False),
                                                        (10, 1, 3, "linear", True, False), (6, 3, 4, "relu", True, True)])
 def test_propagate_blocks_matches_unfused(n, L, B, act, per_batch, tied):

@@ -2,7 +2,7 @@
 and priced with SURVEY 8d's own byte / flop formulas.  bench.py puts these figures into its one JSON line (`secondary`); every
 function returns a dict  {"ms": ..., "bytes" | "flops": ..., "bound": "hbm" | "mfma", "frac": ..., ...}  and frees what it allocated.
 
-Peaks: HBM 8.0 TB/s, fp32 MFMA 157.3 TF/s (/opt/skills/guides/MI355X_MICROARCH.md)."""
+Peaks: HBM 8.0 TB/s, fp32 MFMA 157.3 TF/s, dense f16 MFMA 2.5 PF/s (/opt/skills/guides/MI355X_MICROARCH.md)."""
 import os
 import sys
 
@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 HBM_PEAK = 8.0e12
 MFMA_F32_PEAK = 157.3e12
+MFMA_F16_PEAK = 2500e12
 
 
 def _time(fn, iters, warm=2):
@@ -64,10 +65,12 @@ def propagation(n, B=1024, d=8, L=3, iters=10, with_backward=True):
     tf = _time(fwd, iters)
     res = {"B": B, "n": n, "S": S, "C": C, "L": L, "fwd_ms": tf * 1e3, "bytes": nbytes, "flops": flops,
            "GBps": nbytes / tf / 1e9, "TFLOPs": flops / tf / 1e12}
-    if n <= 16:      # S <= 160: two-term f16 kernel, 11 us of matrix work against one 39 us pass over the adjacency stack: HBM binds
+    if S <= 160:     # two-term f16 kernel, whole graph per workgroup: 11 us of matrix work against one 39 us pass over the adjacency stack: HBM binds
         res.update(bound="hbm", frac=nbytes / tf / HBM_PEAK, kernel="k_propagate_fwd_h")
-    else:            # S = 512 does not fit that kernel: fp32 MFMA form, priced against the fp32 matrix peak
-        res.update(bound="mfma", frac=flops / tf / MFMA_F32_PEAK, kernel="k_propagate_fwd")
+    else:            # wide states: two-term f16 kernel in 64-channel chunks (+ the split pass): 3 f16 MFMAs per fp32 product, priced as issued
+        #              against the dense f16 peak; the 5.5 GB of algorithmic bytes would take 0.7 ms — the matrix pipe binds
+        res.update(bound="mfma", mfma_flops_issued=3 * flops, peak_tflops=MFMA_F16_PEAK / 1e12, frac=3 * flops / tf / MFMA_F16_PEAK,
+                   kernel="k_prop_split_adj + k_propagate_fwd_hl", hbm_frac=nbytes / tf / HBM_PEAK)
     if with_backward:
         tb = _time(fwd_bwd, max(2, iters // 2))
         res["fwd_bwd_incl_adjacency_ms"] = tb * 1e3
