@@ -413,6 +413,8 @@ typedef struct {
     void* support; int64_t lds;     /* [B*n, lds] bf16: x @ W, scratch / saved                                    */
     void* out; int64_t ldo;         /* [B*n, ldo] bf16                                                           */
     void* w_planes;                 /* recon_gcn_b16_planes_bytes() bytes, scratch / saved: W^T and W zero padded along k */
+    int32_t w_planes_valid;         /* != 0: w_planes already holds the planes of `weight` (a caller that keeps them across      *
+                                     * calls while the weight is unchanged — inference — saves the two repacking launches)      */
 } recon_gcn_b16_args;
 
 typedef struct {

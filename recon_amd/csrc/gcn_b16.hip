@@ -6,6 +6,7 @@
 // elements = 16 bytes) so that feature counts like 300 need no repacking between layers: columns past the feature count are
 // written as zeros and read as "times zero".
 #include <stdlib.h>
+#include <type_traits>
 #include "recon_common.h"
 
 namespace recon {
@@ -24,10 +25,12 @@ __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(ui
 // Y[b][i][o] = epilogue( sum_j M[i][j] * Xin[b][j][o] ),  M = adj[b] (TRANS = false) or adj[b]^T; block = (64 columns, graph,
 // 32-row tile), the contraction walked in chunks of 32 through LDS (any n).  MASK: Xin = gout * (fwd_out > 0); EPI: + bias, ReLU.
 // Columns O <= o < ldy are written as zeros.
+// colsum (backward only): per-graph column sums of the masked operand, [B][O] floats — the bias gradient's first pass rides on the tile that is
+// in LDS anyway (row tile 0 of each graph adds the chunks up in k order: fixed order) instead of a pass of its own over grad_out and out.
 template <bool TRANS, bool MASK, bool EPI>
 __global__ void __launch_bounds__(256) k_gcn_b16_aggregate(const uint16_t* __restrict__ adj, const uint16_t* __restrict__ Xin, int64_t ldx,
                                                            const uint16_t* __restrict__ fwd_out, int64_t ldf, const uint16_t* __restrict__ bias,
-                                                           int32_t n, int32_t O, uint16_t* __restrict__ Y, int64_t ldy) {
+                                                           int32_t n, int32_t O, uint16_t* __restrict__ Y, int64_t ldy, float* __restrict__ colsum = nullptr) {
     constexpr int PM = 48, PX = 80;
     __shared__ float Mk[32 * PM];           // Mk[k][i] = M[i0 + i][k0 + k]
     __shared__ float Xs[32 * PX];           // Xs[k][o]
@@ -36,6 +39,8 @@ __global__ void __launch_bounds__(256) k_gcn_b16_aggregate(const uint16_t* __res
     const uint16_t* A = adj + static_cast<int64_t>(b) * n * n;
     const int li = lane & 15, lq = lane >> 4;
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float csum = 0.f;
+    const bool do_colsum = colsum != nullptr && blockIdx.z == 0 && t < 64;
     for (int k0 = 0; k0 < n; k0 += 32) {
         if (k0) __syncthreads();
         for (int idx = t; idx < 32 * 32; idx += 256) {
@@ -63,6 +68,10 @@ __global__ void __launch_bounds__(256) k_gcn_b16_aggregate(const uint16_t* __res
             *reinterpret_cast<float4*>(&Xs[k * PX + 4 * (idx & 15)]) = make_float4(v[0], v[1], v[2], v[3]);
         }
         __syncthreads();
+        if (do_colsum) {
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) csum += Xs[k * PX + t];
+        }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int k = 4 * s + lq;
@@ -71,6 +80,7 @@ __global__ void __launch_bounds__(256) k_gcn_b16_aggregate(const uint16_t* __res
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Mk[k * PM + 16 + li], bx, acc[1], 0, 0, 0);
         }
     }
+    if (do_colsum && o0 + t < O) colsum[static_cast<int64_t>(b) * O + o0 + t] = csum;
     const int o = o0 + 16 * w + li;                                 // C layout: col = lane & 15, row = (lane >> 4) * 4 + r
     if (o < ldy) {
         const float bv = (EPI && bias && o < O) ? bf2f(bias[o]) : 0.f;
@@ -101,28 +111,8 @@ __global__ void __launch_bounds__(256) k_gcn_b16_grad_adj(const uint16_t* __rest
     gadj[static_cast<int64_t>(b) * n * n + idx] = f2bf(s);
 }
 
-// g_bias[o] = sum_rows gpre[row][o]: block = 64 columns x 4 row lanes over a slice of rows (fixed-order LDS combine), then a
-// second pass over the slices (16 columns x 64 slice groups per block, fixed order)
-__global__ void __launch_bounds__(256) k_gcn_b16_bias_partial(const uint16_t* __restrict__ gout, int64_t ldg, const uint16_t* __restrict__ fwd_out, int64_t ldf,
-                                                              int64_t rows, int32_t O, int32_t rows_per_block, float* __restrict__ partial) {
-    __shared__ float red[4][64];
-    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int o = blockIdx.x * 64 + c;
-    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_block;
-    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    float s0 = 0.f, s1 = 0.f;
-    if (o < O) {
-        int64_t r = r0 + rl;
-        for (; r + 4 < r1; r += 8) {
-            s0 += bf2f(fwd_out[r * ldf + o]) > 0.f ? bf2f(gout[r * ldg + o]) : 0.f;
-            s1 += bf2f(fwd_out[(r + 4) * ldf + o]) > 0.f ? bf2f(gout[(r + 4) * ldg + o]) : 0.f;
-        }
-        for (; r < r1; r += 4) s0 += bf2f(fwd_out[r * ldf + o]) > 0.f ? bf2f(gout[r * ldg + o]) : 0.f;
-    }
-    red[rl][c] = s0 + s1;
-    __syncthreads();
-    if (rl == 0 && o < O) partial[static_cast<int64_t>(blockIdx.y) * O + o] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-}
+// g_bias[o] = sum over graphs of the per-graph column sums of gpre (left in `partial` by the aggregate kernel): 16 columns x 64 slice groups
+// per block, fixed order
 __global__ void __launch_bounds__(1024) k_gcn_b16_bias_reduce(const float* __restrict__ partial, int32_t nb, int32_t O, uint16_t* __restrict__ gbias) {
     __shared__ float red[64][17];
     const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -164,15 +154,23 @@ struct GcnFusedK {
     const uint16_t* adj; const uint16_t* wt; const uint16_t* bias;      // wt: W^T planes [O][Ip]
     uint16_t* out; int64_t ldo;
     int32_t B, n, I, Ip, O, nt;                                          // nt = ceil(ldo / 16) <= kFusedNT
+    int32_t adj_vec, bias_vec;                                           // 8-byte loads of adj rows / bias are possible
 };
 
 __device__ __forceinline__ int gf_lds_off(int row, int kq) { return row * 64 + (((kq + 2 * (row >> 3)) & 3) << 4); }
 
-__global__ void __launch_bounds__(256, 1) k_gcn_b16_fused_fwd(const GcnFusedK p) {
+// NS = column parts per graph: wave w works on graph slot w & 3 of the workgroup and on column tiles [part NTP, (part + 1) NTP), part = w >> 2,
+// NTP = kFusedNT / NS — both products are local to a column range (out[:, cols] = adj . support[:, cols]), so the parts never talk; the
+// x fragments are fetched by every part (L1 hits), the W^T slab is staged once per workgroup.  More, lighter waves per SIMD (NS = 4: 40
+// accumulator registers, four waves per SIMD) hide what one wave per SIMD with 160 accumulator registers could not.
+template <int NS, bool VEC>
+__global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_fwd(const GcnFusedK p) {
     __shared__ __attribute__((aligned(16))) unsigned char Ws[2][kFusedNT * 16 * 64];      // one K step of W^T: [o][32 k], 2 x 20 KiB
+    constexpr int NTP = kFusedNT / NS, NTHR = 256 * NS;
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 15, lq = lane >> 4;
-    const int g = blockIdx.x * 4 + w;                                    // this wave's graph (may be past B: loads come back as zeros)
+    const int g = blockIdx.x * 4 + (w & 3);                              // this wave's graph (may be past B: loads come back as zeros)
+    const int c_lo = (w >> 2) * NTP;                                     // its first column tile
     const int n = p.n, nt = p.nt;
     const int64_t rows_total = static_cast<int64_t>(p.B) * n;
     // x: rows of graph g, out-of-range rows / columns read as zeros through the descriptor (the tensor's own extent)
@@ -185,92 +183,138 @@ __global__ void __launch_bounds__(256, 1) k_gcn_b16_fused_fwd(const GcnFusedK p)
         const int i = 16 * rt + li;
         xoff[rt] = (g < p.B && i < n) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.ldx + 8 * lq) * 2) : 0xfffffff0u;
     }
-    // W^T slab staging: piece s = t + 256 q -> (row o = s >> 2, k group s & 3) of the K step; rows past O come back as zeros
-    constexpr int WQ = (kFusedNT * 16 * 4 + 255) / 256;                  // 5 pieces per thread
+    // W^T slab staging: piece s = t + NTHR q -> (row o = s >> 2, k group s & 3) of the K step; rows past O come back as zeros
+    constexpr int WQ = (kFusedNT * 16 * 4 + NTHR - 1) / NTHR;
     uint32_t woff[WQ]; int wlds[WQ];
 #pragma unroll
     for (int q = 0; q < WQ; ++q) {
-        const int s = t + 256 * q, o = s >> 2, kq = s & 3;
+        const int s = t + NTHR * q, o = s >> 2, kq = s & 3;
         woff[q] = (o < 16 * nt) ? static_cast<uint32_t>((o * p.Ip + 8 * kq) * 2) : 0xfffffff0u;
         wlds[q] = o < kFusedNT * 16 ? gf_lds_off(o, kq) : -1;
     }
-    const int nks = p.Ip >> 5;
-    u32x4_g wreg[WQ], areg[2];
-    auto load_w = [&](int ks) {
+    // ---- adj^T fragments of this graph under the k permutation (slots 0..3: j = 4 lq .., slots 4..7: j = 16 + 4 lq ..), output node i' = li + 16 it,
+    // and this lane's bias values — requested HERE, used after the K loop: behind it each would be a dependent round trip of its own
+    // (20 column tiles x one bias load each had been 20 serial L2 latencies: most of the kernel)
+    uint32_t adjraw[2][2][4];
+    u32x2_g adjv[2][2];
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.adj), 0,
+                                                      static_cast<int>(min<int64_t>(static_cast<int64_t>(p.B) * n * n * 2, 0x7fffffff)), 0x00020000);
+    constexpr bool adj_vec = VEC;                                        // n % 4 == 0 and adj 8-byte aligned: one 8-byte load per four nodes
 #pragma unroll
-        for (int q = 0; q < WQ; ++q) wreg[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[q] + 64u * ks, 0, 0);
+    for (int it = 0; it < 2; ++it) {
+        const int i = 16 * it + li;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j0 = 16 * h + 4 * lq;
+            const uint32_t base = static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * n + j0) * 2);
+            if constexpr (adj_vec) {
+                adjv[it][h] = __builtin_amdgcn_raw_buffer_load_b64(ra, (g < p.B && i < n && j0 < n) ? base : 0xfffffff0u, 0, 0);
+            } else {
+                // n is arbitrary (<= 32): element-wise 2-byte loads keep rows of odd length and their tails exact
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    adjraw[it][h][q] = __builtin_amdgcn_raw_buffer_load_b16(ra, (g < p.B && i < n && j0 + q < n) ? base + 2u * q : 0xfffffff0u, 0, 0);
+            }
+        }
+    }
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.bias ? p.bias : p.x), 0, p.bias ? p.O * 2 : 0, 0x00020000);
+    uint32_t braw[NTP][4];
+    u32x2_g bvec[NTP];
+    constexpr bool bias_vec = VEC;                                       // O % 4 == 0 and bias 8-byte aligned
+#pragma unroll
+    for (int c = 0; c < NTP; ++c) {
+        const uint32_t bo = static_cast<uint32_t>((16 * (c_lo + c) + 4 * lq) * 2);
+        if constexpr (bias_vec) bvec[c] = __builtin_amdgcn_raw_buffer_load_b64(rb, bo, 0, 0);
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) braw[c][q] = __builtin_amdgcn_raw_buffer_load_b16(rb, bo + 2u * q, 0, 0);
+        }
+    }
+    const int nks = p.Ip >> 5;
+    // Two K steps of requests in flight: the pieces of W^T for step s are requested during step s - 2 (register set s & 1), written to the
+    // LDS slab s & 1 at the end of step s - 1 (its last readers passed the barrier of step s - 2) and read in step s; x fragments likewise.
+    // One step of MFMAs is ~300 cycles, an L2 round trip several times that: with one step of distance every step waited for its operands.
+    u32x4_g wreg[2][WQ], areg[2][2];
+    auto load_w = [&](auto SET, int ks) {
+        constexpr int S_ = decltype(SET)::value;
+        const uint32_t dead = ks < nks ? 0u : 0xfffffff0u;               // past the end: out of range, zeros, no branch
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) wreg[S_][q] = __builtin_amdgcn_raw_buffer_load_b128(rw, (woff[q] + 64u * ks) | dead, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) areg[S_][rt] = __builtin_amdgcn_raw_buffer_load_b128(rx, (xoff[rt] + 64u * ks) | dead, 0, 0);
     };
-    auto store_w = [&](int buf) {
+    auto store_w = [&](auto SET) {
+        constexpr int S_ = decltype(SET)::value;
 #pragma unroll
         for (int q = 0; q < WQ; ++q)
-            if (wlds[q] >= 0) *reinterpret_cast<u32x4_g*>(&Ws[buf][wlds[q]]) = wreg[q];
+            if (wlds[q] >= 0) *reinterpret_cast<u32x4_g*>(&Ws[S_][wlds[q]]) = wreg[S_][q];
     };
-    auto load_a = [&](int ks) {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) areg[rt] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff[rt] + 64u * ks, 0, 0);
-    };
-    f32x4 acc[2][kFusedNT];
+    f32x4 acc[2][NTP];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int c = 0; c < kFusedNT; ++c) acc[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    load_w(0);
-    load_a(0);
-    store_w(0);
+        for (int c = 0; c < NTP; ++c) acc[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    load_w(S0{}, 0);
+    load_w(S1{}, 1);
+    bf16x8 a_cur[2] = {__builtin_bit_cast(bf16x8, areg[0][0]), __builtin_bit_cast(bf16x8, areg[0][1])};
+    store_w(S0{});
     __syncthreads();
-    const int b_rd = gf_lds_off(li, lq);
-    for (int ks = 0; ks < nks; ++ks) {
-        const bf16x8 a0 = __builtin_bit_cast(bf16x8, areg[0]), a1 = __builtin_bit_cast(bf16x8, areg[1]);
-        if (ks + 1 < nks) { load_w(ks + 1); load_a(ks + 1); }
-        const unsigned char* slab = Ws[ks & 1];
+    const int b_rd = gf_lds_off(li, lq) + 1024 * c_lo;
+    // step ks out of slab / set SET; the other set holds step ks + 1 (requested a step ago)
+    auto step = [&](auto SET, auto OTHER, int ks) {
+        constexpr int S_ = decltype(SET)::value, O_ = decltype(OTHER)::value;
+        const bf16x8 a0 = a_cur[0], a1 = a_cur[1];
+        const bf16x8 n0 = __builtin_bit_cast(bf16x8, areg[O_][0]), n1 = __builtin_bit_cast(bf16x8, areg[O_][1]);      // x fragments of step ks + 1
+        store_w(OTHER);                                                  // slab of step ks + 1: its buffer was last read in step ks - 1, a barrier ago
+        load_w(SET, ks + 2);                                             // set S_ is free: its W pieces are in LDS, its x fragments in a_cur
+        const unsigned char* slab = Ws[S_];
 #pragma unroll
-        for (int c = 0; c < kFusedNT; ++c)
-            if (c < nt) {                                                // uniform
+        for (int c = 0; c < NTP; ++c)
+            if (c_lo + c < nt) {                                         // uniform
                 const bf16x8 b = *reinterpret_cast<const bf16x8*>(slab + b_rd + 1024 * c);
                 acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][c], 0, 0, 0);
                 acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][c], 0, 0, 0);
             }
-        if (ks + 1 < nks) store_w((ks + 1) & 1);                         // the other buffer: last read in step ks - 1, a barrier ago
+        a_cur[0] = n0; a_cur[1] = n1;
         __syncthreads();
+    };
+    for (int ks = 0; ks < nks; ks += 2) {
+        step(S0{}, S1{}, ks);
+        if (ks + 1 < nks) step(S1{}, S0{}, ks + 1);
     }
-    // ---- adj^T fragments of this graph under the k permutation (slots 0..3: j = 4 lq .., slots 4..7: j = 16 + 4 lq ..), output node i' = li + 16 it
     bf16x8 adjf[2];
-    {
-        const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.adj), 0,
-                                                          static_cast<int>(min<int64_t>(static_cast<int64_t>(p.B) * n * n * 2, 0x7fffffff)), 0x00020000);
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int i = 16 * it + li;
-            uint32_t v[4];
+    for (int it = 0; it < 2; ++it) {
+        uint32_t v[4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int j0 = 16 * h + 4 * lq;
-                // n is arbitrary (<= 32): element-wise 2-byte loads keep rows of odd length and their tails exact
-                uint32_t e[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    e[q] = (g < p.B && i < n && j0 + q < n)
-                               ? __builtin_amdgcn_raw_buffer_load_b16(ra, static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * n + j0 + q) * 2), 0, 0) & 0xffffu
-                               : 0u;
-                v[2 * h] = e[0] | (e[1] << 16);
-                v[2 * h + 1] = e[2] | (e[3] << 16);
+        for (int h = 0; h < 2; ++h) {
+            if constexpr (adj_vec) { v[2 * h] = adjv[it][h].x; v[2 * h + 1] = adjv[it][h].y; }
+            else {
+                v[2 * h] = (adjraw[it][h][0] & 0xffffu) | (adjraw[it][h][1] << 16);
+                v[2 * h + 1] = (adjraw[it][h][2] & 0xffffu) | (adjraw[it][h][3] << 16);
             }
-            adjf[it] = __builtin_bit_cast(bf16x8, u32x4_g{v[0], v[1], v[2], v[3]});
         }
+        adjf[it] = __builtin_bit_cast(bf16x8, u32x4_g{v[0], v[1], v[2], v[3]});
     }
-    // ---- out^T tile = support^T . adj^T ; + bias, ReLU, 8-byte stores
+    // ---- out^T tile = support^T . adj^T ; + bias, ReLU, 8-byte stores (pad columns O .. ldo are written as zeros)
     const auto ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, static_cast<int>(min<int64_t>(rows_total * p.ldo * 2, 0x7fffffff)), 0x00020000);
-    const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.bias ? p.bias : p.x), 0, p.bias ? p.O * 2 : 0, 0x00020000);
     auto pack2 = [](float a, float b) { return static_cast<uint32_t>(f2bf(a)) | (static_cast<uint32_t>(f2bf(b)) << 16); };
 #pragma unroll
-    for (int c = 0; c < kFusedNT; ++c)
-        if (c < nt) {
+    for (int c = 0; c < NTP; ++c)
+        if (c_lo + c < nt) {
             const bf16x8 sf = __builtin_bit_cast(bf16x8, u32x4_g{pack2(acc[0][c][0], acc[0][c][1]), pack2(acc[0][c][2], acc[0][c][3]),
                                                                    pack2(acc[1][c][0], acc[1][c][1]), pack2(acc[1][c][2], acc[1][c][3])});
-            const int o0 = 16 * c + 4 * lq;
+            const int o0 = 16 * (c_lo + c) + 4 * lq;
             float bv[4];
+            if constexpr (bias_vec) {
+                bv[0] = bf2f(static_cast<uint16_t>(bvec[c].x & 0xffffu)); bv[1] = bf2f(static_cast<uint16_t>(bvec[c].x >> 16));
+                bv[2] = bf2f(static_cast<uint16_t>(bvec[c].y & 0xffffu)); bv[3] = bf2f(static_cast<uint16_t>(bvec[c].y >> 16));
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bv[q] = bf2f(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rb, static_cast<uint32_t>((o0 + q) * 2), 0, 0)));
+                for (int q = 0; q < 4; ++q) bv[q] = bf2f(static_cast<uint16_t>(braw[c][q]));
+            }
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, adjf[it], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -323,16 +367,26 @@ extern "C" int recon_gcn_b16_fwd(const recon_gcn_b16_args* a, recon_stream_t str
     const int32_t rows = a->B * a->n, I = a->in_features, O = a->out_features;
     char* wp = static_cast<char*>(a->w_planes);
     // W^T [O][kp(I)] for this product, W [I][kp(O)] for g_x in the backward (both zero padded along k)
-    rc = b16_pad_planes(a->weight, O, true, O, I, wp, st);
-    if (rc == RECON_OK) rc = b16_pad_planes(a->weight, O, false, I, O, wp + planes_part(O, I), st);
-    if (rc != RECON_OK) return rc;
+    if (!a->w_planes_valid) {
+        rc = b16_pad_planes(a->weight, O, true, O, I, wp, st);
+        if (rc == RECON_OK) rc = b16_pad_planes(a->weight, O, false, I, O, wp + planes_part(O, I), st);
+        if (rc != RECON_OK) return rc;
+    }
     if (!a->support) {                                               // fused: one kernel, `support` stays in registers
         GcnFusedK k;
         k.x = static_cast<const uint16_t*>(a->x); k.ldx = a->ldx; k.adj = static_cast<const uint16_t*>(a->adj);
         k.wt = reinterpret_cast<const uint16_t*>(wp); k.bias = static_cast<const uint16_t*>(a->bias);
         k.out = static_cast<uint16_t*>(a->out); k.ldo = a->ldo;
         k.B = a->B; k.n = a->n; k.I = I; k.Ip = b16_kp(I); k.O = O; k.nt = static_cast<int32_t>(ceil_div64(a->ldo, 16));
-        hipLaunchKernelGGL(k_gcn_b16_fused_fwd, dim3(static_cast<unsigned>(ceil_div64(a->B, 4))), dim3(256), 0, st, k);
+        k.adj_vec = (a->n % 4 == 0 && (reinterpret_cast<uintptr_t>(a->adj) & 7) == 0) ? 1 : 0;
+        k.bias_vec = (!a->bias || (O % 4 == 0 && (reinterpret_cast<uintptr_t>(a->bias) & 7) == 0)) ? 1 : 0;
+        static const int ns = [] { const char* e = getenv("RECON_GCN_FUSED_PARTS"); const int v = e ? atoi(e) : 4; return v == 1 || v == 2 ? v : 4; }();
+        const dim3 fg(static_cast<unsigned>(ceil_div64(a->B, 4)));
+        const bool vec = k.adj_vec && k.bias_vec;
+#define CALL_F(N_) do { if (vec) hipLaunchKernelGGL((k_gcn_b16_fused_fwd<N_, true>), fg, dim3(256 * N_), 0, st, k); \
+                        else hipLaunchKernelGGL((k_gcn_b16_fused_fwd<N_, false>), fg, dim3(256 * N_), 0, st, k); } while (0)
+        if (ns == 1) CALL_F(1); else if (ns == 2 || !vec) CALL_F(2); else CALL_F(4);      // the element-wise loads of odd shapes need the registers of the two-part form
+#undef CALL_F
         RECON_CHECK_LAUNCH();
         return RECON_OK;
     }
@@ -349,7 +403,7 @@ extern "C" int recon_gcn_b16_fwd(const recon_gcn_b16_args* a, recon_stream_t str
 }
 
 extern "C" size_t recon_gcn_b16_bwd_partial_floats(int32_t B, int32_t n, int32_t in_features, int32_t out_features) {
-    const size_t need = static_cast<size_t>(kBiasBlocks) * (out_features > 0 ? out_features : 0);
+    const size_t need = static_cast<size_t>(B > kBiasBlocks ? B : kBiasBlocks) * (out_features > 0 ? out_features : 0);
     const size_t g = static_cast<size_t>(b16_kmajor_splits(in_features, out_features, B * n)) * in_features * out_features;
     return (g > need ? g : need) + 1;
 }
@@ -368,19 +422,13 @@ extern "C" int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* b, recon_stream_t
     // g_support = adj^T @ (grad_out * (out > 0)); pad columns zeroed (it is the A operand of the next product)
     dim3 grid(static_cast<unsigned>(ceil_div64(a->lds, 64)), static_cast<unsigned>(a->B), static_cast<unsigned>(ceil_div64(n, 32)));
     hipLaunchKernelGGL((k_gcn_b16_aggregate<true, true, false>), grid, dim3(256), 0, st, static_cast<const uint16_t*>(a->adj), gout, b->ldg, fout, a->ldo,
-                       nullptr, n, O, static_cast<uint16_t*>(b->g_support), a->lds);
+                       nullptr, n, O, static_cast<uint16_t*>(b->g_support), a->lds, b->g_bias ? b->partial : nullptr);
     if (b->g_adj)
         hipLaunchKernelGGL(k_gcn_b16_grad_adj, dim3(static_cast<unsigned>(ceil_div64(n * n, 256)), static_cast<unsigned>(a->B)), dim3(256), 0, st, gout,
                            b->ldg, fout, a->ldo, static_cast<const uint16_t*>(a->support), a->lds, n, O, static_cast<uint16_t*>(b->g_adj));
-    if (b->g_bias) {
-        int rpb = static_cast<int>(ceil_div64(rows, kBiasBlocks));
-        if (rpb < 16) rpb = 16;
-        const int nb = static_cast<int>(ceil_div64(rows, rpb));
-        hipLaunchKernelGGL(k_gcn_b16_bias_partial, dim3(static_cast<unsigned>(ceil_div64(O, 64)), static_cast<unsigned>(nb)), dim3(256), 0, st, gout, b->ldg,
-                           fout, a->ldo, static_cast<int64_t>(rows), O, rpb, b->partial);
-        hipLaunchKernelGGL(k_gcn_b16_bias_reduce, dim3(static_cast<unsigned>(ceil_div64(O, 16))), dim3(1024), 0, st, b->partial, nb, O,
+    if (b->g_bias)                                                  // second pass over the per-graph column sums the aggregate kernel left in `partial`
+        hipLaunchKernelGGL(k_gcn_b16_bias_reduce, dim3(static_cast<unsigned>(ceil_div64(O, 16))), dim3(1024), 0, st, b->partial, a->B, O,
                            static_cast<uint16_t*>(b->g_bias));
-    }
     RECON_CHECK_LAUNCH();
     // g_x = g_support @ W^T : B operand = W [I][kp(O)] (k = out contiguous)
     if (b->g_x) {

@@ -630,6 +630,30 @@ def test_gcn_bf16_stack_reads_padded_rows_in_place():
     assert torch.equal(y2d, layers[0](x.detach(), adj)[0])
 
 
+def test_gcn_bf16_frozen_weight_planes_follow_updates():
+    """Inference keeps a frozen layer's repacked weight across calls (keyed on identity + version): an in-place update of the weight
+    must be seen by the next call, and a second call without an update must give the same bits."""
+    from recon_amd.gcn_layers import GraphConvolution
+    d_ = dev()
+    g = torch.Generator().manual_seed(3)
+    x = _bf(torch.randn(5, 32, 300, generator=g)).to(d_)
+    adj = _bf(torch.rand(5, 32, 32, generator=g) / 32).to(d_)
+    torch.manual_seed(2)
+    layer = GraphConvolution(300, 300).to(torch.bfloat16).to(d_)
+    with torch.no_grad():
+        a = layer(x, adj).clone()
+        b = layer(x, adj).clone()
+        assert torch.equal(a, b)
+        layer.weight.mul_(-1.0)                                          # same storage, new version
+        c = layer(x, adj).clone()
+        ref = O.graph_convolution(x.float().cpu(), adj.float().cpu(), layer.weight.float().cpu(), layer.bias.float().cpu())
+    close(c.float(), ref, atol=1e-3, rel_to_max=1.5e-2, what="after the update")
+    assert not torch.equal(a, c)
+    out = layer(x, adj)                                                  # training mode: repacked on every call, planes saved for the backward
+    out.float().sum().backward()
+    assert layer.weight.grad is not None and torch.isfinite(layer.weight.grad.float()).all()
+
+
 def test_gcn_bf16_foreign_padded_view_is_repacked():
     """A caller's own `buf[..., :300]` view of wider rows may hold anything in its pad columns (here: NaN); the bf16 kernels read pad
     columns in place only for rows this module produced, everything else is repacked with zeros — the result must not depend on them."""
