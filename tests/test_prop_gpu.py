@@ -147,6 +147,8 @@ def test_propagation_vs_oracle(n, d, L, B, act, per_batch, form, monkeypatch):
     (272, 70, 16, 2, 9, "relu", True, True),        # RT = 3, odd K steps padded to even; states saved, fp32 backward
     (400, 33, 20, 1, 2, "relu", True, False),       # gather width 20: more than two items per thread
     (256, 96, 4, 3, 11, "tanh", True, True),        # RT = 2 exactly; more than 8 graphs: two XCD rounds
+    (164, 1, 2, 2, 1, "relu", True, False),         # S % 16 != 0: a partial row tile and a partial K step; one channel, one graph
+    (192, 3, 8, 2, 300, "relu", False, False),      # more graphs than one slice of the split workspace (256): two split + propagation rounds
 ])
 def test_propagation_wide_states_vs_oracle(S, C, dd, L, B, act, per_batch, grad):
     """160 < S <= 512: the two-term f16 form of csrc/prop_hl.hip (A_l pre-split per slice of graphs, 64-channel chunks per workgroup)
