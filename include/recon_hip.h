@@ -343,9 +343,12 @@ typedef struct {
                                      * the gradient lands in the transition tensors' own layout, g_adj is ignored           */
     float* g_identity;              /* block mode: [dd,dd] summed over graphs, nodes and hops (fixed order), or NULL         */
     float* identity_ws;             /* block mode: recon_propagate_identity_ws_floats() floats when g_identity is wanted    */
+    float* wide_ws;                 /* recon_propagate_bwd_ws_floats() floats or NULL.  Wide states (S > 160): with it both products *
+                                     * of a hop run as batched GEMMs over the graphs; without it, the channel-chunked kernel         */
 } recon_prop_bwd_args;
 
 size_t recon_propagate_identity_ws_floats(int32_t dd);
+size_t recon_propagate_bwd_ws_floats(const recon_prop_args* fwd);   /* B*C*S for S > 160 (not in block mode), else 0 */
 
 int recon_propagate_bwd(const recon_prop_bwd_args* args, recon_stream_t stream);
 

@@ -68,7 +68,7 @@ class PropArgs(C.Structure):
 
 class PropBwdArgs(C.Structure):
     _fields_ = [("fwd", PropArgs), ("grad_out", c_f32p), ("g_adj", C.POINTER(C.c_void_p)), ("g_h", c_f32p),
-                ("g_trans", C.POINTER(C.c_void_p)), ("g_identity", c_f32p), ("identity_ws", c_f32p)]
+                ("g_trans", C.POINTER(C.c_void_p)), ("g_identity", c_f32p), ("identity_ws", c_f32p), ("wide_ws", c_f32p)]
 
 
 class GcnArgs(C.Structure):
@@ -132,6 +132,7 @@ SYMBOLS = [
     ("recon_propagate_form", C.c_int, [C.POINTER(PropArgs)]),
     ("recon_propagate_identity_ws_floats", C.c_size_t, [C.c_int32]),
     ("recon_propagate_ws_bytes", C.c_size_t, [C.POINTER(PropArgs)]),
+    ("recon_propagate_bwd_ws_floats", C.c_size_t, [C.POINTER(PropArgs)]),
     ("recon_start_entity_embeddings", C.c_int, [c_f32p, c_i64p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
                                                 C.c_void_p]),
     ("recon_gcn_split_bytes", C.c_size_t, [C.c_int32, C.c_int32]),

@@ -1039,6 +1039,84 @@ extern "C" int recon_propagate_form(const recon_prop_args* a) {
     return prop_bwd_h_shape_ok(a->C, a->S) ? 3 : 1;                     // bit 1: the backward's two-term form exists for this shape too
 }
 
+// ------------------------------------------------------------------------------- P2 backward for wide states (S > 160)
+// At S = 512, C = 992 neither product of a hop fits a workgroup's LDS with all channels, and the channel-chunked kernel above pays for
+// it (d A_l needs every channel: chunks meet in atomics; A_l is re-read per chunk).  Written as what they are, both products are plain
+// batched GEMMs over the graphs, on the library's own fp32 matrix-core GEMM (gemm_f32.hip):
+//     (d)  G_l[b]   = Y_l[b] [C x S] . A_l[b] [S x S]              -> d loss / d H^l-1 before the relation term
+//     (c)  dA_l[b]  = Y_l[b]^T [S x C] . H^l-1[b] [C x S]
+// with Y_l = (G_l+1 + relation gradient of hop l) . act'(H^l) produced in place by k_prop_bwd_post (one wave per (graph, channel) row:
+// the row in LDS, the 2 dd scatter terms as LDS float atomics, act', one pass).  Needs one [B, C, S] workspace besides g_h.
+namespace {
+__global__ void __launch_bounds__(256) k_prop_bwd_post(const float* __restrict__ G, const float* __restrict__ Hl, const int64_t* __restrict__ head,
+                                                        const int64_t* __restrict__ tail, int64_t idx_bs, const float* __restrict__ gout, float* __restrict__ Y,
+                                                        int64_t rows, int32_t C, int32_t S, int32_t L, int32_t dd, int32_t hop, int32_t act) {
+    extern __shared__ float rowbuf[];                                   // [4][S]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + w;
+    if (row >= rows) return;
+    const int64_t b = row / C;
+    const int c = static_cast<int>(row - b * C);
+    float* buf = rowbuf + w * S;
+    const float* g = G ? G + row * S : nullptr;
+    const float* h = Hl + row * S;
+    for (int t = lane; t < S; t += 64) buf[t] = g ? g[t] : 0.f;
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                 // this wave's LDS writes have landed (one wave per row: no barrier)
+    const int64_t io = b * idx_bs + static_cast<int64_t>(c) * dd;
+    const float* go = gout + row * (static_cast<int64_t>(L) * dd) + static_cast<int64_t>(hop) * dd;
+    for (int x = lane; x < dd; x += 64) {                               // out = h[head] * h[tail]  (models/models.py:270-273)
+        const int hi = static_cast<int>(head[io + x]), ti = static_cast<int>(tail[io + x]);
+        const float gv = go[x];
+        atomicAdd(buf + hi, gv * h[ti]);
+        atomicAdd(buf + ti, gv * h[hi]);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    float* y = Y + row * S;
+    for (int t = lane; t < S; t += 64) y[t] = buf[t] * act_bwd(h[t], act);
+}
+
+int prop_bwd_wide(const recon_prop_args* a, const recon_prop_bwd_args* ba, hipStream_t st) {
+    const int32_t B = a->B, C = a->C, S = a->S, L = a->L;
+    const int64_t CS = 1LL * C * S, BCS = CS * B, rows = 1LL * B * C;
+    // the last product must land in g_h: the L products alternate between the two buffers
+    float* bufY = (L & 1) ? ba->wide_ws : ba->g_h;                      // holds Y_L first
+    float* bufG = (L & 1) ? ba->g_h : ba->wide_ws;
+    const dim3 pgrid(static_cast<unsigned>(ceil_div64(rows, 4)));
+    const size_t plds = 4ull * S * sizeof(float);
+    hipLaunchKernelGGL(k_prop_bwd_post, pgrid, dim3(256), plds, st, nullptr, a->h_saved + static_cast<int64_t>(L - 1) * BCS, a->head_idx, a->tail_idx,
+                       a->idx_batch_stride, ba->grad_out, bufY, rows, C, S, L, a->dd, L - 1, a->act);
+    for (int l = L; l >= 1; --l) {
+        const float* Hprev = l == 1 ? a->h0 : a->h_saved + static_cast<int64_t>(l - 2) * BCS;
+        const int64_t hprev_bs = l == 1 ? a->h0_batch_stride : CS;
+        GemmBatch bt;
+        bt.batch = B; bt.epilogue = 0;
+        if (ba->g_adj && ba->g_adj[l - 1]) {                            // (c): A = Y_l as [K = c][M = s], B = H^l-1 as [K = c][N = t]
+            bt.a_bs = CS; bt.b_bs = hprev_bs; bt.c_bs = 1LL * S * S;
+            const int rc = gemm_f32_batched(S, S, C, plain_operand(bufY, S), false, plain_operand(Hprev, S), false, plain_output(ba->g_adj[l - 1], S), bt, 1,
+                                            nullptr, st);
+            if (rc != RECON_OK) return rc;
+        }
+        {                                                               // (d): A = Y_l [M = c][K = s], B = A_l as [K = s][N = t]
+            bt.a_bs = CS; bt.b_bs = 1LL * S * S; bt.c_bs = CS;
+            const int rc = gemm_f32_batched(C, S, S, plain_operand(bufY, S), true, plain_operand(a->adj[l - 1], S), false, plain_output(bufG, S), bt, 1,
+                                            nullptr, st);
+            if (rc != RECON_OK) return rc;
+        }
+        if (l > 1)
+            hipLaunchKernelGGL(k_prop_bwd_post, pgrid, dim3(256), plds, st, bufG, a->h_saved + static_cast<int64_t>(l - 2) * BCS, a->head_idx, a->tail_idx,
+                               a->idx_batch_stride, ba->grad_out, bufG, rows, C, S, L, a->dd, l - 2, a->act);
+        float* t = bufY; bufY = bufG; bufG = t;
+    }
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+}  // namespace
+
+extern "C" size_t recon_propagate_bwd_ws_floats(const recon_prop_args* a) {
+    if (!a || a->trans || a->S <= 160 || a->B <= 0) return 0;
+    return static_cast<size_t>(a->B) * a->C * a->S;
+}
+
 extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t stream) {
     if (!ba) return RECON_ERR_INVALID;
     const recon_prop_args* a = &ba->fwd;
@@ -1067,6 +1145,11 @@ extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t
         }
         if (blk) return RECON_ERR_UNSUPPORTED;
     } else if (a->trans) return RECON_ERR_UNSUPPORTED;
+    {
+        static const bool wide_off = getenv("RECON_PROP_BWD_WIDE") && getenv("RECON_PROP_BWD_WIDE")[0] == '0';
+        if (!wide_off && ba->wide_ws && a->S > 160 && 4ull * a->S * sizeof(float) <= 64 * 1024)     // wide states: both products as batched GEMMs
+            return prop_bwd_wide(a, ba, as_stream(stream));
+    }
     PropGeom g;
     if (!prop_geometry(a->C, a->S, &g)) return RECON_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);

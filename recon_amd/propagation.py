@@ -186,7 +186,9 @@ class _Propagate(torch.autograd.Function):
         fwd = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], parr, h0c.data_ptr(), h0_bs, head.data_ptr(), tail.data_ptr(),
                             idx_bs, None, hs.data_ptr(), None, None, _lib.ptr(ctx.stats), None, 0)
         fwd.out = gout.data_ptr()      # unused by the backward; must be non-null for the argument check
-        args = _lib.PropBwdArgs(fwd, gout.data_ptr(), garr, g_h.data_ptr(), None, None, None)
+        nws = _lib.lib().recon_propagate_bwd_ws_floats(C.byref(fwd))     # wide states: both products of a hop as batched GEMMs
+        wide = torch.empty(nws, dtype=torch.float32, device=dev) if nws else None
+        args = _lib.PropBwdArgs(fwd, gout.data_ptr(), garr, g_h.data_ptr(), None, None, None, _lib.ptr(wide))
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().recon_propagate_bwd(C.byref(args), _lib.current_stream()), "recon_propagate_bwd")
         g_h0 = None
@@ -264,7 +266,7 @@ class _PropagateBlocks(torch.autograd.Function):
         tarr, garr = _ptr_array(Ts), _ptr_array(g_Ts)
         fwd = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], None, h0c.data_ptr(), h0_bs, head.data_ptr(), tail.data_ptr(), idx_bs,
                             gout.data_ptr(), hs.data_ptr(), tarr, identity.data_ptr(), stats.data_ptr(), None, 0)
-        args = _lib.PropBwdArgs(fwd, gout.data_ptr(), None, g_h.data_ptr(), garr, _lib.ptr(g_I), _lib.ptr(ws))
+        args = _lib.PropBwdArgs(fwd, gout.data_ptr(), None, g_h.data_ptr(), garr, _lib.ptr(g_I), _lib.ptr(ws), None)
         with torch.cuda.device(dev):
             _lib.check(Lb.recon_propagate_bwd(C.byref(args), _lib.current_stream()), "recon_propagate_bwd (block mode)")
         g_h0 = None

@@ -180,7 +180,7 @@ def powerlaw_spgat(B=64, D=25, F_=200, H=8, nrel=64, iters=10):
 def all_secondary(fast=True):
     it = 6 if fast else 20
     return {"cfg3b_n9_propagation": propagation(9, iters=it),
-            "cfg3b_n32_propagation": propagation(32, iters=2, with_backward=False),
+            "cfg3b_n32_propagation": propagation(32, iters=2),
             "cfg3a_gcn_bf16": gcn_bf16(iters=it),
             "cfg5_powerlaw_spgat": powerlaw_spgat(iters=it)}
 
