@@ -131,6 +131,7 @@ def _zero_page(dev):
     return z
 
 
+_PLANES_CACHE = os.environ.get("RECON_GCN_PLANES_CACHE", "1") != "0"
 _PLANES = {}        # (weight data_ptr, version, in, out, device) -> (planes, weight): repacked weights of frozen layers
 
 
@@ -167,13 +168,14 @@ class _GcnB16Function(torch.autograd.Function):
         # W^T / W repacked for the matrix cores: a frozen weight (inference: no gradient wanted) keeps its planes across calls, keyed on
         # identity + version (an in-place update bumps the version); a weight under training is repacked every step
         key = (weight.data_ptr(), weight._version, I, O, str(dev))
-        hit = _PLANES.get(key) if not ctx.needs_input_grad[2] else None
+        frozen = _PLANES_CACHE and not ctx.needs_input_grad[2]
+        hit = _PLANES.get(key) if frozen else None
         planes = hit[0] if hit is not None else torch.empty(L.recon_gcn_b16_planes_bytes(I, O), dtype=torch.uint8, device=dev)
         args = _lib.GcnB16Args(B, n, I, O, xr.data_ptr(), ldx, adj3.data_ptr(), weight.data_ptr(), _lib.ptr(bias), _lib.ptr(sup), o8,
                                out_p.data_ptr(), o8, planes.data_ptr(), 1 if hit is not None else 0)
         with torch.cuda.device(dev):
             _lib.check(L.recon_gcn_b16_fwd(C.byref(args), _lib.current_stream()), "recon_gcn_b16_fwd")
-        if hit is None and not ctx.needs_input_grad[2]:
+        if hit is None and frozen:
             if len(_PLANES) >= 64:
                 _PLANES.clear()
             _PLANES[key] = (planes, weight)                              # keeps `weight` alive: its data_ptr is the key
