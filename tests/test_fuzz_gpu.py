@@ -271,3 +271,40 @@ def test_fuzz_formulations_inference_and_spkbgat_vs_oracle(monkeypatch):
             chk.bad.append(("exception", cfg, repr(ex)[:300], 0))
     graph_mod.clear_graph_cache()
     assert not chk.bad, chk.bad[:5]
+
+
+def test_fuzz_wide_state_propagation_vs_oracle():
+    """16 random cases of the wide-state forms (160 < S <= 512: split pass + 64-channel chunks forward; both backward products as
+    batched GEMMs): arbitrary S (multiples of 4), channel counts across the chunk edges, gather widths up to 24, every non-linearity,
+    shared / per-batch start states, with and without gradients — against the float64 oracle."""
+    from recon_amd.propagation import propagate
+    d_ = dev()
+    rs = np.random.RandomState(11)
+    chk = _Checker()
+    for it in range(16):
+        g = torch.Generator().manual_seed(2000 + it)
+        S = int(rs.choice([164, 176, 200, 256, 260, 320, 384, 388, 448, 512]))
+        C = int(rs.choice([1, 7, 63, 64, 65, 128, 150]))
+        dd = int(rs.choice([1, 4, 16, 24])); L = int(rs.randint(1, 4)); B = int(rs.choice([1, 3, 9, 20]))
+        act = str(rs.choice(["relu", "tanh", "linear"])); per_batch = bool(rs.randint(0, 2)); grad = bool(rs.randint(0, 2))
+        cfg = ("wide", it, S, C, dd, L, B, act, per_batch, grad)
+        adjs = [(torch.rand(B, S, S, generator=g) - 0.45) * (1.5 / S ** 0.5) for _ in range(L)]
+        for a in adjs:
+            a[:, rs.randint(0, S)] *= 1e-4                              # a row far below the others: per-row scales
+            a[:, :, rs.randint(0, S)] *= 20.0
+        h0 = torch.randn(B, C, S, 1, generator=g) if per_batch else torch.randn(C, S, 1, generator=g)
+        head = torch.randint(0, S, (C, dd), generator=g); tail = torch.randint(0, S, (C, dd), generator=g)
+        Gr = torch.randn(B, C, dd * L, generator=g)
+
+        def run(device, prop, dt):
+            A = [a.clone().to(device=device, dtype=dt).requires_grad_(grad) for a in adjs]
+            h = h0.clone().to(device=device, dtype=dt).requires_grad_(grad and per_batch)
+            out = prop(A, h, act, head.to(device), tail.to(device))
+            if grad:
+                (out * Gr.to(device=device, dtype=dt)).sum().backward()
+            return [out.detach()] + ([a.grad for a in A] + ([h.grad] if per_batch else []) if grad else [])
+        got = run(d_, propagate, torch.float32)
+        ref = run("cpu", lambda *a: O.propagate(*a, as_gemm=True), torch.float64)
+        for k, (x_, y_) in enumerate(zip(got, ref)):
+            chk("wide[%d]" % k, cfg, x_, y_, atol=1e-4 if k == 0 else 1e-5, rel=1e-5 if k == 0 else 1e-4)
+    assert not chk.bad, chk.bad[:5]
