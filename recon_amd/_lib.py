@@ -208,6 +208,34 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+try:                                    # the raw handle without building a torch.cuda.Stream object (3-5 us per call otherwise: a launch-bound
+    from torch._C import _cuda_getCurrentRawStream as _raw_stream      # step makes a dozen of them)
+except ImportError:                     # pragma: no cover
+    _raw_stream = None
+
+
 def current_stream():
     import torch
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
+
+def on_device(dev):
+    """`with on_device(t.device):` — torch.cuda.device(dev) only when it is not the current device already (the usual case: one process
+    per GPU); entering and leaving the real context costs ~4 us per call."""
+    import torch
+    if dev.index is None or torch.cuda.current_device() == dev.index:
+        return _NULL_CTX
+    return torch.cuda.device(dev)

@@ -105,7 +105,7 @@ class SpecialSpmmFunctionFinal(torch.autograd.Function):
         w = edge_w.contiguous().view(g.E, -1 if g.E else int(out_features))       # no edges: the width comes from the argument
         out = torch.empty(N, w.shape[1], dtype=torch.float32, device=w.device)
         ws = torch.empty(L.recon_spmm_rowsum_workspace_floats(g.E, w.shape[1]), dtype=torch.float32, device=w.device)
-        with torch.cuda.device(w.device):
+        with _lib.on_device(w.device):
             _lib.check(L.recon_spmm_rowsum_fwd(C.byref(g.c), w.data_ptr(), w.shape[1], out.data_ptr(), ws.data_ptr(),
                                                _lib.current_stream()), "recon_spmm_rowsum_fwd")
         ctx.graph = g
@@ -121,7 +121,7 @@ class SpecialSpmmFunctionFinal(torch.autograd.Function):
             L = _lib.lib()
             go = grad_output.contiguous()
             grad_values = torch.empty(g.E, ctx.outfeat, dtype=torch.float32, device=go.device)
-            with torch.cuda.device(go.device):
+            with _lib.on_device(go.device):
                 _lib.check(L.recon_spmm_rowsum_bwd(g.edge[0].data_ptr(), g.E, go.data_ptr(), ctx.outfeat,
                                                    grad_values.data_ptr(), _lib.current_stream()),
                            "recon_spmm_rowsum_bwd")
@@ -320,7 +320,7 @@ class _GATHeadsFunction(torch.autograd.Function):
                 sigma, Z = torch.empty(H, E, **f32), torch.empty(H, N, **f32)
             keep = keep.view(H, E)[:, graph.eid_long].contiguous()       # original order -> CSR-slot order
         args = _fwd_args(graph, x, ee, a, a2, keep, P, Q, sigma, Z, out, alpha, concat)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(L.recon_gat_fwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_fwd")
         if need_grad:
             ctx.save_for_backward(x, ee, a, a2, keep, P, Q, sigma, Z, out)
@@ -348,7 +348,7 @@ class _GATHeadsFunction(torch.autograd.Function):
         args = _lib.GatBwdArgs(_fwd_args(graph, x, ee, a, a2, keep, P, Q, sigma, Z, out, ctx.alpha, ctx.concat),
                                grad_out.data_ptr(), grad_out.shape[1], Gm.data_ptr(), gP.data_ptr(),
                                partial.data_ptr(), _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2))
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(L.recon_gat_bwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_bwd")
         return g_x, g_ee, g_a, g_a2, None, None, None, None
 
@@ -576,7 +576,7 @@ def _rowsum_by_index(rows, index, n_rows):
     out = torch.empty(n_rows, rows.shape[1], dtype=torch.float32, device=rows.device)
     L = _lib.lib()
     ws = torch.empty(L.recon_spmm_rowsum_workspace_floats(g.E, rows.shape[1]), dtype=torch.float32, device=rows.device)
-    with torch.cuda.device(rows.device):
+    with _lib.on_device(rows.device):
         _lib.check(L.recon_spmm_rowsum_fwd(C.byref(g.c), rows.data_ptr(), rows.shape[1], out.data_ptr(), ws.data_ptr(), _lib.current_stream()),
                    "recon_spmm_rowsum_fwd")
     return out

@@ -72,7 +72,7 @@ class GraphCSR:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         self.c = _lib.ReconGraph(self.N, self.E, self.rowptr_dst.data_ptr(), self.eid.data_ptr(),
                                  _lib.ptr(self.src), self.dst.data_ptr(), _lib.ptr(self.rowptr_src), _lib.ptr(self.slot_by_src))
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = L.recon_graph_build(edge[0].data_ptr(), edge[1].data_ptr(), C.byref(self.c), ws.data_ptr(),
                                      ws_bytes, _lib.current_stream())
         _lib.check(rc, "recon_graph_build")
@@ -82,7 +82,7 @@ class GraphCSR:
         self.n_hub = self.n_piece = self.n_hub_src = self.n_piece_src = 0
         if HUB_CHUNK > 0 and E > HUB_CHUNK and not rows_only:
             cnt = (C.c_int32 * 4)()
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 _lib.check(L.recon_graph_hubs_count(C.byref(self.c), HUB_CHUNK, ws.data_ptr(), cnt, _lib.current_stream()), "recon_graph_hubs_count")
             if cnt[0] > 0 or cnt[2] > 0:
                 self.n_hub, self.n_piece, self.n_hub_src, self.n_piece_src = (int(v) for v in cnt)
@@ -100,7 +100,7 @@ class GraphCSR:
                     self.c.n_hub_src, self.c.n_piece_src = self.n_hub_src, self.n_piece_src
                     self.c.hub_node_src, self.c.hub_ptr_src, self.c.piece_src = (self.hub_node_src.data_ptr(), self.hub_ptr_src.data_ptr(),
                                                                                  self.piece_src.data_ptr())
-                with torch.cuda.device(dev):
+                with _lib.on_device(dev):
                     _lib.check(L.recon_graph_hubs_fill(C.byref(self.c), _lib.current_stream()), "recon_graph_hubs_fill")
 
     def slot_order_index(self, index, n_rows):

@@ -81,7 +81,7 @@ class _BlockAdjacency(torch.autograd.Function):
         if T.numel() != B * n * (n - 1) * dd * dd:
             raise ValueError("T must hold B x n(n-1) transition matrices of %dx%d" % (dd, dd))
         A = torch.empty(B, n * dd, n * dd, dtype=torch.float32, device=T.device)
-        with torch.cuda.device(T.device):
+        with _lib.on_device(T.device):
             _lib.check(_lib.lib().recon_block_adjacency_fwd(T.data_ptr(), identity.data_ptr(), B, n, dd, A.data_ptr(),
                                                             _lib.current_stream()), "recon_block_adjacency_fwd")
         ctx.dims = (B, n, dd, tuple(T.shape))
@@ -96,7 +96,7 @@ class _BlockAdjacency(torch.autograd.Function):
         L = _lib.lib()
         ws = (torch.empty(L.recon_block_adjacency_bwd_workspace_floats(B, n, dd), dtype=torch.float32, device=gA.device)
               if gI is not None else None)
-        with torch.cuda.device(gA.device):
+        with _lib.on_device(gA.device):
             _lib.check(L.recon_block_adjacency_bwd(gA.data_ptr(), B, n, dd, _lib.ptr(gT), _lib.ptr(gI), _lib.ptr(ws),
                                                    _lib.current_stream()), "recon_block_adjacency_bwd")
         return gT, gI, None
@@ -165,7 +165,7 @@ class _Propagate(torch.autograd.Function):
             # per-tensor scales from them (include/recon_hip.h: recon_prop_args.stats)
             stats = torch.empty(B, 2 * L + 1, dtype=torch.float32, device=dev)
             args.stats = C.cast(stats.data_ptr(), _lib.c_f32p)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(_lib.lib().recon_propagate_fwd(C.byref(args), _lib.current_stream()), "recon_propagate_fwd")
         if need:
             ctx.save_for_backward(h0c, head, tail, hs, *adjs)
@@ -189,7 +189,7 @@ class _Propagate(torch.autograd.Function):
         nws = _lib.lib().recon_propagate_bwd_ws_floats(C.byref(fwd))     # wide states: both products of a hop as batched GEMMs
         wide = torch.empty(nws, dtype=torch.float32, device=dev) if nws else None
         args = _lib.PropBwdArgs(fwd, gout.data_ptr(), garr, g_h.data_ptr(), None, None, None, _lib.ptr(wide))
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(_lib.lib().recon_propagate_bwd(C.byref(args), _lib.current_stream()), "recon_propagate_bwd")
         g_h0 = None
         if ctx.needs_input_grad[0]:
@@ -245,7 +245,7 @@ class _PropagateBlocks(torch.autograd.Function):
         args = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], None, h0c.data_ptr(), h0_bs, head.data_ptr(), tail.data_ptr(), idx_bs,
                              out.data_ptr(), _lib.ptr(hs), tarr, identity.data_ptr(), _lib.ptr(stats), None, 0)
         ws = _split_workspace(args, dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(_lib.lib().recon_propagate_fwd(C.byref(args), _lib.current_stream()), "recon_propagate_fwd (block mode)")
         if need:
             ctx.save_for_backward(h0c, identity, head, tail, hs, stats, *Ts)
@@ -267,7 +267,7 @@ class _PropagateBlocks(torch.autograd.Function):
         fwd = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], None, h0c.data_ptr(), h0_bs, head.data_ptr(), tail.data_ptr(), idx_bs,
                             gout.data_ptr(), hs.data_ptr(), tarr, identity.data_ptr(), stats.data_ptr(), None, 0)
         args = _lib.PropBwdArgs(fwd, gout.data_ptr(), None, g_h.data_ptr(), garr, _lib.ptr(g_I), _lib.ptr(ws), None)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(Lb.recon_propagate_bwd(C.byref(args), _lib.current_stream()), "recon_propagate_bwd (block mode)")
         g_h0 = None
         if ctx.needs_input_grad[0]:
@@ -322,7 +322,7 @@ class _StartEntity(torch.autograd.Function):
         ent = ent.contiguous()
         Cn, S = n * (n - 1), 2 * d * n
         out = torch.empty(B, Cn, S, 1, dtype=torch.float32, device=ent.device)
-        with torch.cuda.device(ent.device):
+        with _lib.on_device(ent.device):
             _lib.check(_lib.lib().recon_start_entity_embeddings(ent.data_ptr(), pos.data_ptr(), templ.data_ptr(), B, n, d,
                                                                 out.data_ptr(), _lib.current_stream()),
                        "recon_start_entity_embeddings")
