@@ -378,6 +378,7 @@ constexpr int kHLSlice = 256;           // graphs per split pass (bounds the wor
 size_t prop_hl_ws_bytes(int B, int S, int L) {
     if (S <= 160 || S > 512 || B <= 0 || L <= 0) return 0;
     const HLGeom g = hl_geom(S, L);
+    if (g.lds > 160 * 1024) return 0;
     const int G = B < kHLSlice ? B : kHLSlice;
     return (g.per_graph_split + g.per_graph_alpha) * static_cast<size_t>(G) + 256;
 }
@@ -390,6 +391,7 @@ bool prop_fwd_hl_supported(const PropK& p) {
     if (!al16(p.h0) || (p.h0_bs % 4) != 0 || (p.hsave && !al16(p.hsave)) || !al16(p.ws)) return false;
     if (static_cast<int64_t>(p.C) * p.S * 4 >= (1LL << 31)) return false;
     const HLGeom g = hl_geom(p.S, p.L);
+    if (g.lds > 160 * 1024) return false;                               // 8 hops at S = 512: the row-scale table no longer fits beside the state
     return p.ws_bytes >= static_cast<int64_t>(g.per_graph_split + g.per_graph_alpha + 256);
 }
 
