@@ -149,6 +149,7 @@ def test_propagation_vs_oracle(n, d, L, B, act, per_batch, form, monkeypatch):
     (256, 96, 4, 3, 11, "tanh", True, True),        # RT = 2 exactly; more than 8 graphs: two XCD rounds
     (164, 1, 2, 2, 1, "relu", True, False),         # S % 16 != 0: a partial row tile and a partial K step; one channel, one graph
     (192, 3, 8, 2, 300, "relu", False, False),      # more graphs than one slice of the split workspace (256): two split + propagation rounds
+    (512, 3, 4, 8, 1, "tanh", False, False),        # eight hops at S = 512: the two-term form's LDS image does not fit, the fp32 form answers
 ])
 def test_propagation_wide_states_vs_oracle(S, C, dd, L, B, act, per_batch, grad):
     """160 < S <= 512: the two-term f16 form of csrc/prop_hl.hip (A_l pre-split per slice of graphs, 64-channel chunks per workgroup)
