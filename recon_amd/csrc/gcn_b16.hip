@@ -14,8 +14,9 @@ int32_t b16_kp(int32_t K);
 int b16_pad_planes(const void* src, int64_t ld, bool transposed, int32_t rows, int32_t K, void* dst, hipStream_t st);
 int gemm_b16(int32_t M, int32_t N, int32_t K, const void* A, int64_t lda, const void* Bp, void* C, int64_t ldc, bool out_bf16, hipStream_t st);
 int b16_kmajor_splits(int32_t M, int32_t N, int32_t K);
+int b16_pad_planes_both(const void* src, int64_t ld, int32_t M, int32_t N, void* dst_t, void* dst_n, hipStream_t st);
 int gemm_b16_kmajor(int32_t M, int32_t N, int32_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* out, int64_t ldo, float* partial,
-                    const void* zeros, hipStream_t st);
+                    const void* zeros, hipStream_t st, const B16ReduceJob* extra);
 
 namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -368,8 +369,7 @@ extern "C" int recon_gcn_b16_fwd(const recon_gcn_b16_args* a, recon_stream_t str
     char* wp = static_cast<char*>(a->w_planes);
     // W^T [O][kp(I)] for this product, W [I][kp(O)] for g_x in the backward (both zero padded along k)
     if (!a->w_planes_valid) {
-        rc = b16_pad_planes(a->weight, O, true, O, I, wp, st);
-        if (rc == RECON_OK) rc = b16_pad_planes(a->weight, O, false, I, O, wp + planes_part(O, I), st);
+        rc = b16_pad_planes_both(a->weight, O, I, O, wp, wp + planes_part(O, I), st);      // one launch for both layouts
         if (rc != RECON_OK) return rc;
     }
     if (!a->support) {                                               // fused: one kernel, `support` stays in registers
@@ -402,10 +402,13 @@ extern "C" int recon_gcn_b16_fwd(const recon_gcn_b16_args* a, recon_stream_t str
     return RECON_OK;
 }
 
+static size_t gcn_b16_gw_partial_floats(int32_t B, int32_t n, int32_t in_features, int32_t out_features) {
+    return static_cast<size_t>(b16_kmajor_splits(in_features, out_features, B * n)) * in_features * out_features;
+}
+
 extern "C" size_t recon_gcn_b16_bwd_partial_floats(int32_t B, int32_t n, int32_t in_features, int32_t out_features) {
-    const size_t need = static_cast<size_t>(B > kBiasBlocks ? B : kBiasBlocks) * (out_features > 0 ? out_features : 0);
-    const size_t g = static_cast<size_t>(b16_kmajor_splits(in_features, out_features, B * n)) * in_features * out_features;
-    return (g > need ? g : need) + 1;
+    // [split-K partials of g_W][per-graph column sums for g_bias]: both second passes run in one launch at the end
+    return gcn_b16_gw_partial_floats(B, n, in_features, out_features) + static_cast<size_t>(B > 0 ? B : 0) * (out_features > 0 ? out_features : 0) + 1;
 }
 
 extern "C" int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* b, recon_stream_t stream) {
@@ -419,17 +422,17 @@ extern "C" int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* b, recon_stream_t
     const int32_t rows = a->B * a->n, I = a->in_features, O = a->out_features, n = a->n;
     const uint16_t* gout = static_cast<const uint16_t*>(b->grad_out);
     const uint16_t* fout = static_cast<const uint16_t*>(a->out);
+    float* colsum = b->partial + gcn_b16_gw_partial_floats(a->B, n, I, O);      // [B][O] per-graph column sums of gpre, behind the split-K partials
     // g_support = adj^T @ (grad_out * (out > 0)); pad columns zeroed (it is the A operand of the next product)
     dim3 grid(static_cast<unsigned>(ceil_div64(a->lds, 64)), static_cast<unsigned>(a->B), static_cast<unsigned>(ceil_div64(n, 32)));
     hipLaunchKernelGGL((k_gcn_b16_aggregate<true, true, false>), grid, dim3(256), 0, st, static_cast<const uint16_t*>(a->adj), gout, b->ldg, fout, a->ldo,
-                       nullptr, n, O, static_cast<uint16_t*>(b->g_support), a->lds, b->g_bias ? b->partial : nullptr);
+                       nullptr, n, O, static_cast<uint16_t*>(b->g_support), a->lds, b->g_bias ? colsum : nullptr);
     if (b->g_adj)
         hipLaunchKernelGGL(k_gcn_b16_grad_adj, dim3(static_cast<unsigned>(ceil_div64(n * n, 256)), static_cast<unsigned>(a->B)), dim3(256), 0, st, gout,
                            b->ldg, fout, a->ldo, static_cast<const uint16_t*>(a->support), a->lds, n, O, static_cast<uint16_t*>(b->g_adj));
-    if (b->g_bias)                                                  // second pass over the per-graph column sums the aggregate kernel left in `partial`
-        hipLaunchKernelGGL(k_gcn_b16_bias_reduce, dim3(static_cast<unsigned>(ceil_div64(O, 16))), dim3(1024), 0, st, b->partial, a->B, O,
-                           static_cast<uint16_t*>(b->g_bias));
     RECON_CHECK_LAUNCH();
+    // g_bias: second pass over the per-graph column sums — in the launch of g_W's second pass when there is one
+    const B16ReduceJob bias_job{colsum, static_cast<uint16_t*>(b->g_bias), O, a->B, 1, O};
     // g_x = g_support @ W^T : B operand = W [I][kp(O)] (k = out contiguous)
     if (b->g_x) {
         const int64_t i8 = (I + 7) / 8 * 8;
@@ -439,8 +442,12 @@ extern "C" int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* b, recon_stream_t
     }
     // g_W = x^T @ g_support   (k-major, split-K over the B*n rows, fixed-order second pass)
     if (b->g_weight) {
-        rc = gemm_b16_kmajor(I, O, rows, a->x, a->ldx, b->g_support, a->lds, b->g_weight, O, b->partial, b->zeros, st);
+        rc = gemm_b16_kmajor(I, O, rows, a->x, a->ldx, b->g_support, a->lds, b->g_weight, O, b->partial, b->zeros, st, b->g_bias ? &bias_job : nullptr);
         if (rc != RECON_OK) return rc;
+    } else if (b->g_bias) {
+        hipLaunchKernelGGL(k_gcn_b16_bias_reduce, dim3(static_cast<unsigned>(ceil_div64(O, 16))), dim3(1024), 0, st, colsum, a->B, O,
+                           static_cast<uint16_t*>(b->g_bias));
+        RECON_CHECK_LAUNCH();
     }
     return RECON_OK;
 }

@@ -279,24 +279,50 @@ __global__ void __launch_bounds__(256) k_b16_pad_planes(const uint16_t* __restri
     dst[static_cast<int64_t>(r) * Kp + k] = k < K ? (TRANS ? src[static_cast<int64_t>(k) * ld + r] : src[static_cast<int64_t>(r) * ld + k]) : 0;
 }
 
-// out (bf16 [M][N], row stride ldo) = sum of `splits` fp32 partials [z][M][N]: 16 elements x 16 split groups per block, fixed order
-__global__ void __launch_bounds__(256) k_b16_reduce(const float* __restrict__ partial, int32_t splits, int32_t M, int32_t N, uint16_t* __restrict__ out,
-                                                    int64_t ldo) {
+// W^T [rows_t = N][kp(K_t = M)] and W [rows_n = M][kp(K_n = N)] of one [M][N] weight in ONE launch (blocks [0, nb_t) the transposed job)
+__global__ void __launch_bounds__(256) k_b16_pad_both(const uint16_t* __restrict__ src, int64_t ld, int32_t M, int32_t N, int32_t Kp_t, int32_t Kp_n,
+                                                      uint16_t* __restrict__ dst_t, uint16_t* __restrict__ dst_n, int32_t nb_t) {
+    if (static_cast<int>(blockIdx.x) < nb_t) {
+        const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+        if (idx >= static_cast<int64_t>(N) * Kp_t) return;
+        const int r = static_cast<int>(idx % N), k = static_cast<int>(idx / N);
+        dst_t[static_cast<int64_t>(r) * Kp_t + k] = k < M ? src[static_cast<int64_t>(k) * ld + r] : 0;
+    } else {
+        const int64_t idx = static_cast<int64_t>(blockIdx.x - nb_t) * 256 + threadIdx.x;
+        if (idx >= static_cast<int64_t>(M) * Kp_n) return;
+        const int r = static_cast<int>(idx / Kp_n), k = static_cast<int>(idx % Kp_n);
+        dst_n[static_cast<int64_t>(r) * Kp_n + k] = k < N ? src[static_cast<int64_t>(r) * ld + k] : 0;
+    }
+}
+
+// out (bf16 [M][N], row stride ldo) = sum of `splits` fp32 partials [z][M][N]: 16 elements x 16 split groups per block, fixed order.
+// A second job of the same shape (the bias gradient of the GraphConvolution backward: [nb][O] column sums -> [O]) rides in the same launch.
+__global__ void __launch_bounds__(256) k_b16_reduce(const B16ReduceJob j0, const B16ReduceJob j1, int32_t nblk0) {
     __shared__ float red[16][17];
+    const bool first = static_cast<int>(blockIdx.x) < nblk0;
+    const B16ReduceJob& j = first ? j0 : j1;
     const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 16 + e, MN = static_cast<int64_t>(M) * N;
-    const int per = (splits + 15) / 16;
-    const int z0 = grp * per, z1 = min(splits, (grp + 1) * per);
+    const int64_t idx = static_cast<int64_t>(first ? blockIdx.x : blockIdx.x - nblk0) * 16 + e, MN = static_cast<int64_t>(j.M) * j.N;
+    const int per = (j.splits + 15) / 16;
+    const int z0 = grp * per, z1 = min(j.splits, (grp + 1) * per);
     float s = 0.f;
-    if (idx < MN)
-        for (int z = z0; z < z1; ++z) s += partial[z * MN + idx];
+    if (idx < MN) {                                                    // eight independent loads in flight: a chain of 64 dependent round trips (the
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // bias job at B = 1024) would cost more than the launch it saves
+        int z = z0;
+        for (; z + 8 <= z1; z += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += j.partial[(z + u) * MN + idx];
+        }
+        for (; z < z1; ++z) a[0] += j.partial[z * MN + idx];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
     red[grp][e] = s;
     __syncthreads();
     if (grp == 0 && idx < MN) {
         float t = 0.f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) t += red[g][e];
-        out[(idx / N) * ldo + idx % N] = f2bf(t);
+        j.out[(idx / j.N) * j.ldo + idx % j.N] = f2bf(t);
     }
 }
 
@@ -311,6 +337,18 @@ int b16_pad_planes(const void* src, int64_t ld, bool transposed, int32_t rows, i
     const dim3 grid(static_cast<unsigned>(ceil_div64(static_cast<int64_t>(rows) * Kp, 256)));
     if (transposed) hipLaunchKernelGGL((k_b16_pad_planes<true>), grid, dim3(256), 0, st, static_cast<const uint16_t*>(src), ld, rows, K, Kp, static_cast<uint16_t*>(dst));
     else hipLaunchKernelGGL((k_b16_pad_planes<false>), grid, dim3(256), 0, st, static_cast<const uint16_t*>(src), ld, rows, K, Kp, static_cast<uint16_t*>(dst));
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+
+// both plane sets of a [M][N] bf16 weight (row stride ld): dst_t = W^T [N][kp(M)], dst_n = W [M][kp(N)], zero padded along k
+int b16_pad_planes_both(const void* src, int64_t ld, int32_t M, int32_t N, void* dst_t, void* dst_n, hipStream_t st) {
+    if (M <= 0 || N <= 0) return RECON_OK;
+    if (!src || !dst_t || !dst_n) return RECON_ERR_INVALID;
+    const int32_t Kp_t = b16_kp(M), Kp_n = b16_kp(N);
+    const int nb_t = static_cast<int>(ceil_div64(static_cast<int64_t>(N) * Kp_t, 256)), nb_n = static_cast<int>(ceil_div64(static_cast<int64_t>(M) * Kp_n, 256));
+    hipLaunchKernelGGL(k_b16_pad_both, dim3(static_cast<unsigned>(nb_t + nb_n)), dim3(256), 0, st, static_cast<const uint16_t*>(src), ld, M, N, Kp_t, Kp_n,
+                       static_cast<uint16_t*>(dst_t), static_cast<uint16_t*>(dst_n), nb_t);
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
 }
@@ -337,7 +375,7 @@ int b16_kmajor_splits(int32_t M, int32_t N, int32_t K) { return bx3_kmajor_split
 // out (bf16 [M][N], row stride ldo) = A[K,M]^T . B[K,N]; lda, ldb % 8 == 0, every row holds (M resp. N rounded up to 8) readable
 // columns; `partial` = b16_kmajor_splits(M, N, K) * M * N floats; `zeros` = 1 KiB of zero bytes
 int gemm_b16_kmajor(int32_t M, int32_t N, int32_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* out, int64_t ldo, float* partial,
-                    const void* zeros, hipStream_t st) {
+                    const void* zeros, hipStream_t st, const B16ReduceJob* extra) {
     if (M < 0 || N < 0 || K < 0) return RECON_ERR_INVALID;
     if (M == 0 || N == 0) return RECON_OK;
     if (!A || !B || !out || !partial || !zeros) return RECON_ERR_INVALID;
@@ -356,8 +394,11 @@ int gemm_b16_kmajor(int32_t M, int32_t N, int32_t K, const void* A, int64_t lda,
     if (a.nsplit != sk || sk > 65535) return RECON_ERR_INVALID;
     const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, BM)), static_cast<unsigned>(sk));
     hipLaunchKernelGGL(k_gemm_b16_kmajor, grid, dim3(NT), 0, st, a);
-    hipLaunchKernelGGL(k_b16_reduce, dim3(static_cast<unsigned>(ceil_div64(static_cast<int64_t>(M) * N, 16))), dim3(256), 0, st, partial, sk, M, N,
-                       static_cast<uint16_t*>(out), ldo);
+    const B16ReduceJob j0{partial, static_cast<uint16_t*>(out), ldo, sk, M, N};
+    const B16ReduceJob j1 = extra ? *extra : B16ReduceJob{nullptr, nullptr, 0, 0, 0, 0};
+    const int nblk0 = static_cast<int>(ceil_div64(static_cast<int64_t>(M) * N, 16));
+    const int nblk1 = extra ? static_cast<int>(ceil_div64(static_cast<int64_t>(j1.M) * j1.N, 16)) : 0;
+    hipLaunchKernelGGL(k_b16_reduce, dim3(static_cast<unsigned>(nblk0 + nblk1)), dim3(256), 0, st, j0, j1, nblk0);
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
 }

@@ -225,6 +225,9 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
                      bool b_k_minor, const OutputDesc& C, const GemmBatch& bt, int32_t split_k, float* partial,
                      hipStream_t stream);
 
+// second pass of a split-K product with bf16 output (gemm_b16.hip): out[M][N] (row stride ldo) = sum of `splits` fp32 partials [z][M][N]
+struct B16ReduceJob { const float* partial; uint16_t* out; int64_t ldo; int32_t splits, M, N; };
+
 // split-precision (bf16 x 3) MFMA GEMM, gemm_bx3.hip: C = act(A . B^T), A fp32 k-contiguous, B pre-split bf16 planes
 // [3][batch][N][bx3_kp(K)] written by bx3_split_planes (transposed = true reads src as [K][rows]).
 int32_t bx3_kp(int32_t K);
