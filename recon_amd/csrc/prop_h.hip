@@ -123,14 +123,6 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
 
     // h^0 of graph bb: this wave's NCW channels, one 16-byte piece per lane
     const uint32_t vo_h = 4 * lane < S ? 16u * lane : kOOB;
-    auto load_h0 = [&](u32x4 (&hv)[NCW], int bb) {
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.h0 + bb * p.h0_bs), 0, C * S * 4, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < NCW; ++i) {
-            const int c = wave + i * NW;
-            hv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, c < C ? vo_h + static_cast<uint32_t>(c * S * 4) : kOOB, 0, 0);
-        }
-    };
     u32x4 raw[NKS][2];
     int b = blockIdx.x;
     if (b < p.B) {
@@ -149,8 +141,6 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
         // measured: 89 -> 95 us — it competes with the adjacency prefetch for the CU's ~12 B/clk share of HBM.)
         float mh0 = 0.f;                                                           // max |h^0| over this wave's channels
         {
-            u32x4 hv[NCW];
-            load_h0(hv, b);
             const int t0 = 4 * lane;
             const int so = col_off(t0);
             if (wave == 0) {
@@ -159,19 +149,34 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_fwd_h(const PropK p) {
                     if (lane + 64 * k < 2 * CH) chmax[lane + 64 * k] = 0u;
                 if (lane < 2 * kMaxHops + 1) gstat[lane] = 0u;
             }
-            float mx[NCW];
+            // in batches of at most 12 channels per wave (cfg 3b: 9, one batch): narrow states with many channels (S <= 32: one or two waves for up
+            // to 96 channels) would otherwise hold every channel's piece at once — 384 registers
+            constexpr int NB = NCW < 12 ? NCW : 12;
+#pragma unroll 1
+            for (int i0 = 0; i0 < NCW; i0 += NB) {
+                u32x4 hv[NB];
+                {
+                    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.h0 + b * p.h0_bs), 0, C * S * 4, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < NCW; ++i)                                           // NCW independent reduction chains
-                mx[i] = wave_max(fmaxf(fmaxf(fabsf(as_f(hv[i].x)), fabsf(as_f(hv[i].y))), fmaxf(fabsf(as_f(hv[i].z)), fabsf(as_f(hv[i].w)))));
+                    for (int i = 0; i < NB; ++i) {
+                        const int c = wave + (i0 + i) * NW;
+                        hv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (c < C && i0 + i < NCW) ? vo_h + static_cast<uint32_t>(c * S * 4) : kOOB, 0, 0);
+                    }
+                }
+                float mx[NB];
 #pragma unroll
-            for (int i = 0; i < NCW; ++i) mh0 = fmaxf(mh0, mx[i]);
+                for (int i = 0; i < NB; ++i)                                        // independent reduction chains
+                    mx[i] = wave_max(fmaxf(fmaxf(fabsf(as_f(hv[i].x)), fabsf(as_f(hv[i].y))), fmaxf(fabsf(as_f(hv[i].z)), fabsf(as_f(hv[i].w)))));
 #pragma unroll
-            for (int i = 0; i < NCW; ++i) {
-                const int c = wave + i * NW;                                        // wave-uniform
-                if (c < CH) {
-                    const float sg = hx2_scale_of(mx[i]);
-                    if (t0 < KP) store_state4((so ^ (((c >> 1) & 3) << 4)) + 64 * c, as_f(hv[i].x) * sg, as_f(hv[i].y) * sg, as_f(hv[i].z) * sg, as_f(hv[i].w) * sg);
-                    if (lane == 0) isg[c] = hx2_inv(sg);
+                for (int i = 0; i < NB; ++i) mh0 = fmaxf(mh0, mx[i]);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int c = wave + (i0 + i) * NW;                             // wave-uniform
+                    if (c < CH && i0 + i < NCW) {
+                        const float sg = hx2_scale_of(mx[i]);
+                        if (t0 < KP) store_state4((so ^ (((c >> 1) & 3) << 4)) + 64 * c, as_f(hv[i].x) * sg, as_f(hv[i].y) * sg, as_f(hv[i].z) * sg, as_f(hv[i].w) * sg);
+                        if (lane == 0) isg[c] = hx2_inv(sg);
+                    }
                 }
             }
         }
