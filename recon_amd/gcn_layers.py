@@ -228,10 +228,8 @@ class _GcnB16Function(torch.autograd.Function):
         if g_x is not None:
             if i8 == I:
                 g_x = g_x.view(xs)
-            else:
-                g_x[:, I:].zero_()
-                g_x = g_x.as_strided(xs, _strides(xs[:-1], i8))
-                g_x._recon_padded = True
+            else:                       # pad columns stay unwritten and the view untagged: nothing reads the pad columns of a gradient
+                g_x = g_x.as_strided(xs, _strides(xs[:-1], i8))   # (_rows_view(..., pads_read=False) in the producer layer's backward)
         return g_x, (g_adj.view(adjs) if g_adj is not None else None), g_w, g_b
 
 
