@@ -80,18 +80,25 @@ def propagation(n, B=1024, d=8, L=3, iters=10, with_backward=True):
     if with_backward:
         tb = _time(fwd_bwd, max(2, iters // 2))
         res["fwd_bwd_incl_adjacency_ms"] = tb * 1e3
-        if blocks_mode_available(B, n, dd, h0):
-            # models/models.py:240-274 in one call: A_l read out of the transition tensors in place, d T written in T's layout
+        # models/models.py:240-274 in one call: A_l read out of the transition tensors in place (inference: any n <= 32; with gradients, where the
+        # backward's two-term form exists: d T written in T's layout)
 
-            def fused():
-                for t in Ts + [ident, h0]:
-                    t.grad = None
-                propagate_blocks(Ts, ident, n, h0, "relu", head, tail).backward(G)
+        def fused():
+            for t in Ts + [ident, h0]:
+                t.grad = None
+            propagate_blocks(Ts, ident, n, h0, "relu", head, tail).backward(G)
 
-            def fused_fwd():
-                with torch.no_grad():
-                    propagate_blocks(Ts, ident, n, h0, "relu", head, tail)
+        def fused_fwd():
+            with torch.no_grad():
+                propagate_blocks(Ts, ident, n, h0, "relu", head, tail)
+
+        def unfused_fwd_incl_adjacency():
+            with torch.no_grad():
+                propagate([build_block_adjacency(t, ident, n) for t in Ts], h0, "relu", head, tail)
+        if blocks_mode_available(B, n, dd, h0, need_grad=False):
+            res["fwd_incl_adjacency_ms"] = _time(unfused_fwd_incl_adjacency, iters) * 1e3
             res["fused_blocks_fwd_ms"] = _time(fused_fwd, iters) * 1e3
+        if blocks_mode_available(B, n, dd, h0):
             res["fused_blocks_fwd_bwd_ms"] = _time(fused, max(2, iters // 2)) * 1e3
     del Ts, adjs, h0, G
     torch.cuda.empty_cache()
