@@ -409,7 +409,9 @@ int recon_gcn_bwd(const recon_gcn_bwd_args* args, recon_stream_t stream);
  * ------------------------------------------------------------------------------------------*/
 typedef struct {
     int32_t B, n, in_features, out_features;
-    const void* x; int64_t ldx;     /* [B*n, ldx] bf16, 16-byte aligned                                          */
+    const void* x; int64_t ldx;     /* [B*n, ldx] bf16, 16-byte aligned.  Fused forward (support == NULL): any even   *
+                                     * ldx >= in_features — the kernel masks the K tail, so rows need no padding and *
+                                     * whatever lies behind a row's last feature is never multiplied                 */
     const void* adj;                /* [B, n, n] bf16                                                            */
     const void* weight;             /* [in, out] bf16, contiguous                                                */
     const void* bias;               /* [out] bf16 or NULL                                                        */

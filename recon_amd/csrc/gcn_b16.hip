@@ -257,6 +257,17 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_fwd(const GcnFuse
         for (int c = 0; c < NTP; ++c) acc[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
+    // columns in_features .. kp(in_features) of a row are whatever lies behind it (pad columns of a padded row, the next row's first elements
+    // of an unpadded one): this lane's x fragment of the LAST K step is masked to the columns that exist, so their content never matters
+    u32x4_g tailmask;
+    {
+        const int k0 = 32 * (nks - 1) + 8 * lq;
+        uint32_t m[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) m[d] = (k0 + 2 * d < p.I ? 0x0000ffffu : 0u) | (k0 + 2 * d + 1 < p.I ? 0xffff0000u : 0u);
+        tailmask = u32x4_g{m[0], m[1], m[2], m[3]};
+    }
+    const u32x4_g allmask = u32x4_g{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     load_w(S0{}, 0);
     load_w(S1{}, 1);
     bf16x8 a_cur[2] = {__builtin_bit_cast(bf16x8, areg[0][0]), __builtin_bit_cast(bf16x8, areg[0][1])};
@@ -266,7 +277,8 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_fwd(const GcnFuse
     // step ks out of slab / set SET; the other set holds step ks + 1 (requested a step ago)
     auto step = [&](auto SET, auto OTHER, int ks) {
         constexpr int S_ = decltype(SET)::value, O_ = decltype(OTHER)::value;
-        const bf16x8 a0 = a_cur[0], a1 = a_cur[1];
+        const u32x4_g km = ks == nks - 1 ? tailmask : allmask;
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4_g, a_cur[0]) & km), a1 = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4_g, a_cur[1]) & km);
         const bf16x8 n0 = __builtin_bit_cast(bf16x8, areg[O_][0]), n1 = __builtin_bit_cast(bf16x8, areg[O_][1]);      // x fragments of step ks + 1
         store_w(OTHER);                                                  // slab of step ks + 1: its buffer was last read in step ks - 1, a barrier ago
         load_w(SET, ks + 2);                                             // set S_ is free: its W pieces are in LDS, its x fragments in a_cur
@@ -342,7 +354,9 @@ int check(const recon_gcn_b16_args* a) {
     if (!a->x || !a->adj || !a->weight || !a->out || !a->w_planes) return RECON_ERR_INVALID;
     if (!a->support && !gcn_fused_ok(a)) return RECON_ERR_INVALID;    // only the fused forward (n <= 32, out <= 320) does without it
     const int64_t i8 = (a->in_features + 7) / 8 * 8, o8 = (a->out_features + 7) / 8 * 8;
-    if ((a->ldx & 7) || (a->ldo & 7) || a->ldx < i8 || a->ldo < o8 || (a->support && ((a->lds & 7) || a->lds < o8))) return RECON_ERR_INVALID;
+    const bool fused = !a->support;                                   // the fused forward masks the K tail: rows need no padding, only 4-byte alignment
+    if (fused ? ((a->ldx & 1) || a->ldx < a->in_features) : ((a->ldx & 7) || a->ldx < i8)) return RECON_ERR_INVALID;
+    if ((a->ldo & 7) || a->ldo < o8 || (a->support && ((a->lds & 7) || a->lds < o8))) return RECON_ERR_INVALID;
     if ((reinterpret_cast<uintptr_t>(a->x) | reinterpret_cast<uintptr_t>(a->support) | reinterpret_cast<uintptr_t>(a->out) |
          reinterpret_cast<uintptr_t>(a->w_planes)) & 15) return RECON_ERR_INVALID;
     if (a->B > 65535 || a->n > 65535 * 32) return RECON_ERR_UNSUPPORTED;

@@ -162,15 +162,20 @@ class _GcnB16Function(torch.autograd.Function):
             raise ValueError("GraphConvolution: inconsistent shapes")
         dev = x.device
         L = _lib.lib()
-        ldx = _rows_view(x, I)
-        xr = x
-        if ldx is None:
-            xr, ldx = _packed_rows(x, I, zero_pad=True)
         o8 = (O + 7) // 8 * 8
         bf = dict(dtype=torch.bfloat16, device=dev)
         # `support` = x @ W is only needed again for d adj; without it the forward is ONE kernel (csrc/gcn_b16.hip k_gcn_b16_fused_fwd:
         # n <= 32, out <= 320) that keeps it in registers
-        fused = (not ctx.needs_input_grad[1]) and n <= 32 and o8 <= 320 and B * n * max(ldx, o8) * 2 < 2 ** 31 - 1 and _FUSED
+        fused = (not ctx.needs_input_grad[1]) and n <= 32 and o8 <= 320 and B * n * max((I + 7) // 8 * 8, o8) * 2 < 2 ** 31 - 1 and _FUSED
+        # inference through the fused kernel: it masks the K tail, so what lies behind a row's last feature is never multiplied — anybody's
+        # padded rows, and unpadded ones (4-byte aligned), are read in place; training keeps rows it can hand to the weight-gradient GEMM
+        masked = fused and not any(ctx.needs_input_grad)
+        ldx = _rows_view(x, I, pads_read=not masked)
+        xr = x
+        if ldx is None and masked and I % 2 == 0 and x.is_contiguous() and x.data_ptr() % 16 == 0:
+            ldx = I
+        elif ldx is None:
+            xr, ldx = _packed_rows(x, I, zero_pad=True)
         sup = None if fused else torch.empty(B * n, o8, **bf)
         out_p = torch.empty(B * n, o8, **bf)
         weight = weight.contiguous()

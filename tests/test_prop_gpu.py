@@ -673,3 +673,12 @@ def test_gcn_bf16_foreign_padded_view_is_repacked():
     layer = GraphConvolution(D, D).to(torch.bfloat16).to(d_)
     y_view, y_plain = layer(buf[..., :D], adj), layer(x, adj)
     assert torch.isfinite(y_view.float()).all() and torch.equal(y_view, y_plain)
+    # inference: the fused kernel reads both in place (the view's NaN pads and the unpadded rows' neighbours sit behind the K-tail mask)
+    with torch.no_grad():
+        z_view, z_plain = layer(buf[..., :D], adj), layer(x, adj)
+        big = x.clone()
+        big[:, 1:, :20] = float("inf")                                   # what an unpadded row's tail fragment would touch in the NEXT row
+        z_row0 = layer(big, adj * torch.eye(n, device=d_, dtype=torch.bfloat16))      # identity-pattern adj: row 0 of each graph depends on its own x only
+    assert torch.isfinite(z_view.float()).all() and torch.equal(z_view, z_plain)
+    close(z_plain.float(), y_plain.float(), atol=1e-3, rel_to_max=1e-2, what="inference vs training forward")
+    assert torch.isfinite(z_row0[:, 0].float()).all()
