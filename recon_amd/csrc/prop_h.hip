@@ -689,16 +689,22 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
                     const unsigned char* sl = ring + (stepno & 1) * 2 * SLAB;
                     const f16x8 a_hi = tr_frag(sl + tr_slab, sl + tr_slab + 4 * RS), a_lo = tr_frag(sl + SLAB + tr_slab, sl + SLAB + tr_slab + 4 * RS);
                     const unsigned char* yk = Ys + yc_lane + 2048 * kc;
+                    // every column tile of the image, unconditionally (tiles past S hold zero columns and are not stored): a uniform `if (n < NW)`
+                    // per tile made ten basic blocks of read -> wait -> three MFMAs; straight-line, with the next tile's fragments requested
+                    // before this tile's MFMAs, the LDS latency rides under the matrix pipe
+                    auto yfrag = [&](int n, f16x8& b_hi, f16x8& b_lo) {
+                        const unsigned char* q0 = yk + (n >> 1) * STEP + 32 * (n & 1);
+                        const unsigned char* q1 = yk + 256 + (n >> 1) * STEP + 32 * ((n & 1) ^ 1);
+                        b_hi = tr_frag(q0, q1); b_lo = tr_frag(q0 + PLANE, q1 + PLANE);
+                    };
+                    f16x8 bh[2], bl[2];
+                    yfrag(0, bh[0], bl[0]);
 #pragma unroll
                     for (int n = 0; n < NTS; ++n) {
-                        if (n < NW) {                                   // uniform
-                            const unsigned char* q0 = yk + (n >> 1) * STEP + 32 * (n & 1);
-                            const unsigned char* q1 = yk + 256 + (n >> 1) * STEP + 32 * ((n & 1) ^ 1);
-                            const f16x8 b_hi = tr_frag(q0, q1), b_lo = tr_frag(q0 + PLANE, q1 + PLANE);
-                            accc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo, accc[n], 0, 0, 0);
-                            accc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi, accc[n], 0, 0, 0);
-                            accc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, accc[n], 0, 0, 0);
-                        }
+                        if (n + 1 < NTS) yfrag(n + 1, bh[(n + 1) & 1], bl[(n + 1) & 1]);
+                        accc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bl[n & 1], accc[n], 0, 0, 0);
+                        accc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, bh[n & 1], accc[n], 0, 0, 0);
+                        accc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bh[n & 1], accc[n], 0, 0, 0);
                     }
                     step_out();
                 }
@@ -741,13 +747,18 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
 
                 const unsigned char* sl = ring + (stepno & 1) * 2 * SLAB;
                 const f16x8 a_hi = tr_frag(sl + tr_slab, sl + tr_slab + 4 * RS), a_lo = tr_frag(sl + SLAB + tr_slab, sl + SLAB + tr_slab + 4 * RS);
+                f16x8 dh[2], dl[2];                                     // the next channel tile's fragments are requested before this tile's MFMAs
+                dh[0] = *reinterpret_cast<const f16x8*>(Ys + ks * STEP + yb_rd);
+                dl[0] = *reinterpret_cast<const f16x8*>(Ys + PLANE + ks * STEP + yb_rd);
 #pragma unroll
                 for (int j = 0; j < NTC; ++j) {
-                    const f16x8 b_hi = *reinterpret_cast<const f16x8*>(Ys + ks * STEP + 1024 * j + yb_rd);
-                    const f16x8 b_lo = *reinterpret_cast<const f16x8*>(Ys + PLANE + ks * STEP + 1024 * j + yb_rd);
-                    accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo, accd[j], 0, 0, 0);
-                    accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi, accd[j], 0, 0, 0);
-                    accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, accd[j], 0, 0, 0);
+                    if (j + 1 < NTC) {
+                        dh[(j + 1) & 1] = *reinterpret_cast<const f16x8*>(Ys + ks * STEP + 1024 * (j + 1) + yb_rd);
+                        dl[(j + 1) & 1] = *reinterpret_cast<const f16x8*>(Ys + PLANE + ks * STEP + 1024 * (j + 1) + yb_rd);
+                    }
+                    accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, dl[j & 1], accd[j], 0, 0, 0);
+                    accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, dh[j & 1], accd[j], 0, 0, 0);
+                    accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, dh[j & 1], accd[j], 0, 0, 0);
                 }
                 step_out();
             }
