@@ -9,12 +9,6 @@ namespace {
 constexpr int kTile = 1024;      // items per block per pass
 constexpr int kThreads = 256;    // 4 waves, each ranks 256 consecutive items
 
-__global__ void k_convert_keys(const int64_t* __restrict__ in, int32_t* __restrict__ keys,
-                               int32_t* __restrict__ vals, int32_t n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { keys[i] = static_cast<int32_t>(in[i]); vals[i] = i; }
-}
-
 __global__ void __launch_bounds__(kThreads) k_radix_hist(const int32_t* __restrict__ keys, int32_t n, int shift,
                                                          int32_t* __restrict__ blockhist, int32_t nblocks) {
     __shared__ int32_t hist[256];
@@ -25,6 +19,30 @@ __global__ void __launch_bounds__(kThreads) k_radix_hist(const int32_t* __restri
     for (int j = 0; j < kTile / kThreads; ++j) {
         int i = base + j * kThreads + threadIdx.x;
         if (i < n) atomicAdd(&hist[(keys[i] >> shift) & 255], 1);
+    }
+    __syncthreads();
+    blockhist[threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
+}
+
+// key conversion (dst -> int32 key, iota value) or source gather (src of slot -> key, slot value) of one 1 024-item tile TOGETHER with the
+// tile's first-pass digit histogram: one launch instead of two at the head of each sort (a graph build is a chain of ~5 us turn-arounds)
+template <bool GATHER>
+__global__ void __launch_bounds__(kThreads) k_keys_hist(const int64_t* __restrict__ in, const int32_t* __restrict__ eid, int32_t n,
+                                                        int32_t* __restrict__ src_out, int32_t* __restrict__ keys, int32_t* __restrict__ vals,
+                                                        int32_t* __restrict__ blockhist, int32_t nblocks) {
+    __shared__ int32_t hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kTile;
+#pragma unroll
+    for (int j = 0; j < kTile / kThreads; ++j) {
+        const int i = base + j * kThreads + threadIdx.x;
+        if (i < n) {
+            const int32_t v = static_cast<int32_t>(GATHER ? in[eid[i]] : in[i]);
+            if (GATHER) src_out[i] = v;
+            keys[i] = v; vals[i] = i;
+            atomicAdd(&hist[v & 255], 1);
+        }
     }
     __syncthreads();
     blockhist[threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
@@ -134,12 +152,6 @@ __global__ void k_rowptr_lower_bound(const int32_t* __restrict__ sorted_keys, in
     rowptr[r] = lo;
 }
 
-__global__ void k_gather_src(const int64_t* __restrict__ edge_src, const int32_t* __restrict__ eid, int32_t E,
-                             int32_t* __restrict__ src_out, int32_t* __restrict__ keys, int32_t* __restrict__ iota) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < E) { const int32_t v = static_cast<int32_t>(edge_src[eid[k]]); src_out[k] = v; keys[k] = v; iota[k] = k; }
-}
-
 __global__ void k_copy_i32(const int32_t* __restrict__ in, int32_t* __restrict__ out, int32_t n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[i];
@@ -152,13 +164,14 @@ struct SortWs { int32_t *kA, *kB, *vA, *vB, *hist; int32_t nblocks; };
 // stable sort of (kA, vA); the LAST pass scatters into (kfinal, vfinal) when given (a copy launch each less per sort: a graph build is
 // launch bound at the stage-A batch sizes), else the result ends up in (*kout, *vout), which point into the ping-pong buffers
 int radix_sort_pairs(SortWs& ws, int32_t n, int32_t key_range, int32_t** kout, int32_t** vout, hipStream_t st, int32_t* kfinal = nullptr,
-                     int32_t* vfinal = nullptr) {
+                     int32_t* vfinal = nullptr, bool first_hist_done = false) {
     const int passes = (bits_for(key_range) + 7) / 8;
     int32_t *ki = ws.kA, *vi = ws.vA, *ko = ws.kB, *vo = ws.vB;
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
         if (p == passes - 1) { if (kfinal) ko = kfinal; if (vfinal) vo = vfinal; }
-        hipLaunchKernelGGL(k_radix_hist, dim3(ws.nblocks), dim3(kThreads), 0, st, ki, n, shift, ws.hist, ws.nblocks);
+        if (p > 0 || !first_hist_done)
+            hipLaunchKernelGGL(k_radix_hist, dim3(ws.nblocks), dim3(kThreads), 0, st, ki, n, shift, ws.hist, ws.nblocks);
         hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, ws.hist, 256 * ws.nblocks);
         hipLaunchKernelGGL(k_radix_scatter, dim3(ws.nblocks), dim3(kThreads), 0, st, ki, vi, ko, vo, n, shift, ws.hist,
                            ws.nblocks);
@@ -287,18 +300,18 @@ extern "C" int recon_graph_build(const int64_t* edge_dst, const int64_t* edge_sr
     ws.vB = reinterpret_cast<int32_t*>(w + 3 * e);
     ws.hist = reinterpret_cast<int32_t*>(w + 4 * e);
     ws.nblocks = static_cast<int32_t>(ceil_div64(E, kTile));
-    const dim3 eb(static_cast<unsigned>(ceil_div64(E, 256))), nb(static_cast<unsigned>(ceil_div64(N + 1, 256)));
+    const dim3 nb(static_cast<unsigned>(ceil_div64(N + 1, 256)));
 
     // destination CSR: stable sort of (dst, edge column)
-    hipLaunchKernelGGL(k_convert_keys, eb, dim3(256), 0, st, edge_dst, ws.kA, ws.vA, E);
+    hipLaunchKernelGGL((k_keys_hist<false>), dim3(ws.nblocks), dim3(kThreads), 0, st, edge_dst, nullptr, E, nullptr, ws.kA, ws.vA, ws.hist, ws.nblocks);
     int32_t *ks, *vs;
-    int rc = radix_sort_pairs(ws, E, N, &ks, &vs, st, g->dst, g->eid);
+    int rc = radix_sort_pairs(ws, E, N, &ks, &vs, st, g->dst, g->eid, true);
     if (rc != RECON_OK) return rc;
     hipLaunchKernelGGL(k_rowptr_lower_bound, nb, dim3(256), 0, st, g->dst, E, N, g->rowptr_dst);
     if (!with_src) { RECON_CHECK_LAUNCH(); return RECON_OK; }
     // source CSC over CSR slots: stable sort of (src of slot, slot)
-    hipLaunchKernelGGL(k_gather_src, eb, dim3(256), 0, st, edge_src, g->eid, E, g->src, ws.kA, ws.vA);
-    rc = radix_sort_pairs(ws, E, N, &ks, &vs, st, nullptr, g->slot_by_src);
+    hipLaunchKernelGGL((k_keys_hist<true>), dim3(ws.nblocks), dim3(kThreads), 0, st, edge_src, g->eid, E, g->src, ws.kA, ws.vA, ws.hist, ws.nblocks);
+    rc = radix_sort_pairs(ws, E, N, &ks, &vs, st, nullptr, g->slot_by_src, true);
     if (rc != RECON_OK) return rc;
     hipLaunchKernelGGL(k_rowptr_lower_bound, nb, dim3(256), 0, st, ks, E, N, g->rowptr_src);
     RECON_CHECK_LAUNCH();
