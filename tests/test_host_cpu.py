@@ -314,3 +314,26 @@ def test_gemm_family_policy(monkeypatch):
     assert 2.0 * 8192 * 600 * 8 * 200 > gat_layers._BX3_MIN_FLOP                          # cfg 2 takes the split-precision kernels
     monkeypatch.setattr(gat_layers, "_GEMM_BX3", "0")
     assert gat_layers._atp_split_buffer(200, 200, 200, 8, "cpu", N=8192) == (None, None)
+
+
+def test_propagation_workspace_queries():
+    """Host-side size queries of the propagation entry points (no device work): the wide-state forms exist for 160 < S <= 512 only, their
+    workspaces are sized per slice of at most 256 graphs / per batch, and block mode is accepted where its shape identities hold."""
+    import ctypes as C
+    from recon_amd import _lib
+    L = _lib.lib()
+
+    def args(B, Cn, S, Lh, dd, trans=False):
+        a = _lib.PropArgs(B, Cn, S, Lh, dd, 1, None, None, 0, None, None, 0, None, None, None, None, None, None, 0)
+        if trans:
+            a.trans = (C.c_void_p * Lh)()
+        return a
+    assert L.recon_propagate_ws_bytes(C.byref(args(1024, 72, 144, 3, 16))) == 0            # whole graph per workgroup: no workspace
+    assert L.recon_propagate_ws_bytes(C.byref(args(1024, 992, 516, 3, 16))) == 0           # wider than the form takes
+    one = L.recon_propagate_ws_bytes(C.byref(args(1, 992, 512, 3, 16)))
+    full = L.recon_propagate_ws_bytes(C.byref(args(1024, 992, 512, 3, 16)))
+    assert one >= 3 * 512 * 512 * 4 and full < 257 * one and full > 200 * one              # 256-graph slices
+    assert L.recon_propagate_ws_bytes(C.byref(args(4, 992, 512, 3, 16, trans=True))) > 0   # n = 32 blocks: S = 16 n, C = n (n - 1)
+    assert L.recon_propagate_ws_bytes(C.byref(args(4, 990, 512, 3, 16, trans=True))) == 0
+    assert L.recon_propagate_bwd_ws_floats(C.byref(args(7, 992, 512, 3, 16))) == 7 * 992 * 512
+    assert L.recon_propagate_bwd_ws_floats(C.byref(args(7, 72, 144, 3, 16))) == 0
