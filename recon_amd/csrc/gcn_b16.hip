@@ -341,6 +341,199 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_fwd(const GcnFuse
         }
 }
 
+// ------------------------------------------------------------------------------------------------ fused backward (n <= 32)
+// g_support = adj^T (grad_out . [out > 0])  and  g_x = g_support W^T  in ONE kernel, the mirror image of the fused forward: the small
+// product comes first here, so its operand has to be TRANSPOSED on the way in — the masked gradient tile of a graph ([32 nodes][out] bf16,
+// 20 KiB) is staged in LDS and read back through ds_read_b64_tr_b16 (rows = the contraction index j), as is adj:
+//   1. per K step of the big product (32 columns o = two 16-row tiles of g_support^T [o][i]): 2 x 2 MFMAs g_support^T = gpre^T . adj, their
+//      accumulators (column = node i, rows = 4 consecutive o) are exactly B fragments of the big product under the k permutation of the
+//      forward (slots 0..3: o = 4 lq .., slots 4..7: o = 16 + 4 lq ..); the same accumulators leave as 8-byte stores of g_support (for the
+//      weight-gradient GEMM), one part of the graph's waves per K step;
+//   2. g_x^T [f][i] += W [f][o] . g_support^T [o][i]: A fragments of W out of the double-buffered LDS slab of the planes W [in][kp(out)] (read
+//      under the same permutation: two 8-byte pieces per lane), 8-byte stores of g_x (four consecutive features per node).
+// The per-graph column sums of the masked gradient (bias gradient, first pass) are taken from the staged tile.
+struct GcnFusedBwdK {
+    const uint16_t* gout; int64_t ldg;
+    const uint16_t* fout; int64_t ldf;
+    const uint16_t* adj; const uint16_t* wn;                              // wn: W planes [I][Op]
+    uint16_t* gsup; int64_t lds;
+    uint16_t* gx; int64_t ldgx;
+    float* colsum;                                                       // [B][O] or null
+    int32_t B, n, I, O, Op, nt;                                          // Op = kp(out); nt = ceil(I8 / 16) <= kFusedNT
+};
+
+constexpr int kRSG = 2 * kFusedNT * 16 + 16;                            // bytes of a row of the staged gradient tile (rows 8 apart on different banks)
+constexpr int kRSA = 2 * 32 + 16;                                       // ... of the adj tile
+
+template <int NS>
+__global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_bwd(const GcnFusedBwdK p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fb_sm[];
+    unsigned char* Ws = fb_sm;                                           // [2][kFusedNT * 16 * 64]
+    unsigned char* Gs = Ws + 2 * kFusedNT * 16 * 64;                     // [4][32][kRSG]
+    unsigned char* As = Gs + 4 * 32 * kRSG;                              // [4][32][kRSA]
+    constexpr int NTP = kFusedNT / NS, NTHR = 256 * NS;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int gsl = w & 3, part = w >> 2;
+    const int g = blockIdx.x * 4 + gsl;
+    const int c_lo = part * NTP;
+    const int n = p.n, nt = p.nt;
+    const int64_t rows_total = static_cast<int64_t>(p.B) * n;
+    const int nks = p.Op >> 5;
+    unsigned char* Gg = Gs + gsl * 32 * kRSG;
+    unsigned char* Ag = As + gsl * 32 * kRSA;
+    // ---- stage the masked gradient tile and adj of this graph (its NS waves share the rows)
+    {
+        const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.gout), 0, static_cast<int>(min<int64_t>(rows_total * p.ldg * 2, 0x7fffffff)), 0x00020000);
+        const auto rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.fout), 0, static_cast<int>(min<int64_t>(rows_total * p.ldf * 2, 0x7fffffff)), 0x00020000);
+        const int npr = kFusedNT * 2;                                    // 16-byte pieces per staged row (320 columns)
+        for (int q = part * 64 + lane; q < 32 * npr; q += 64 * NS) {
+            const int j = q / npr, pc = q - j * npr, o0 = 8 * pc;
+            const bool ok = g < p.B && j < n;
+            const uint32_t og = (ok && o0 < p.ldg) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + j) * p.ldg + o0) * 2) : 0xfffffff0u;
+            const uint32_t of = (ok && o0 < p.ldf) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + j) * p.ldf + o0) * 2) : 0xfffffff0u;
+            const u32x4_g gv = __builtin_amdgcn_raw_buffer_load_b128(rg, og, 0, 0), fv = __builtin_amdgcn_raw_buffer_load_b128(rf, of, 0, 0);
+            uint32_t m[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t gq = gv[d], fq = fv[d];
+                // forward output > 0 (bf16: sign clear and not zero) and the column exists: keep the gradient, else zero
+                const bool k0 = (fq & 0x8000u) == 0 && (fq & 0x7fffu) != 0 && o0 + 2 * d < p.O;
+                const bool k1 = (fq & 0x80000000u) == 0 && (fq & 0x7fff0000u) != 0 && o0 + 2 * d + 1 < p.O;
+                m[d] = (k0 ? gq & 0xffffu : 0u) | (k1 ? gq & 0xffff0000u : 0u);
+            }
+            *reinterpret_cast<u32x4_g*>(Gg + j * kRSG + 16 * pc) = u32x4_g{m[0], m[1], m[2], m[3]};
+        }
+        const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.adj), 0, static_cast<int>(min<int64_t>(static_cast<int64_t>(p.B) * n * n * 2, 0x7fffffff)), 0x00020000);
+        for (int q = part * 64 + lane; q < 32 * 32; q += 64 * NS) {      // adj[j][i], element-wise: any n <= 32
+            const int j = q >> 5, i = q & 31;
+            const uint32_t v = (g < p.B && j < n && i < n) ? __builtin_amdgcn_raw_buffer_load_b16(ra, static_cast<uint32_t>(((static_cast<int64_t>(g) * n + j) * n + i) * 2), 0, 0) : 0u;
+            *reinterpret_cast<uint16_t*>(Ag + j * kRSA + 2 * i) = static_cast<uint16_t>(v);
+        }
+    }
+    // ---- W slab staging (planes W [I][Op], k = o contiguous): piece s -> (row f = s >> 2, k group s & 3) of the K step
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wn), 0, p.I * p.Op * 2, 0x00020000);
+    constexpr int WQ = (kFusedNT * 16 * 4 + NTHR - 1) / NTHR;
+    uint32_t woff[WQ]; int wlds[WQ];
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+        const int s_ = t + NTHR * q, f = s_ >> 2, kq = s_ & 3;
+        woff[q] = (f < 16 * nt && f < p.I) ? static_cast<uint32_t>((f * p.Op + 8 * kq) * 2) : 0xfffffff0u;
+        wlds[q] = f < kFusedNT * 16 ? gf_lds_off(f, kq) : -1;
+    }
+    u32x4_g wreg[2][WQ];
+    auto load_w = [&](auto SET, int ks) {
+        constexpr int S_ = decltype(SET)::value;
+        const uint32_t dead = ks < nks ? 0u : 0xfffffff0u;
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) wreg[S_][q] = __builtin_amdgcn_raw_buffer_load_b128(rw, (woff[q] + 64u * ks) | dead, 0, 0);
+    };
+    auto store_w = [&](auto SET) {
+        constexpr int S_ = decltype(SET)::value;
+#pragma unroll
+        for (int q = 0; q < WQ; ++q)
+            if (wlds[q] >= 0) *reinterpret_cast<u32x4_g*>(Ws + S_ * (kFusedNT * 16 * 64) + wlds[q]) = wreg[S_][q];
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    load_w(S0{}, 0);
+    load_w(S1{}, 1);
+    store_w(S0{});
+    __syncthreads();                                                     // tiles and the first slab are in place
+    // ---- bias gradient, first pass: column sums of the staged tile over the graph's nodes (fixed order), by the part-0 wave of each graph
+    if (p.colsum && part == 0 && g < p.B) {
+        for (int o = lane; o < p.O; o += 64) {
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) sacc += bf2f(*reinterpret_cast<const uint16_t*>(Gg + j * kRSG + 2 * o));
+            p.colsum[static_cast<int64_t>(g) * p.O + o] = sacc;
+        }
+    }
+    // transposing reads: the 16 lanes of group lq address a 4 (k) x 16 (m) block of halves, lane ip at row ip >> 2, columns 4 (ip & 3) ..; lane ip
+    // receives column ip of the four rows; two reads (k rows 8 lq .. + 3 and + 4 .. + 7) make a fragment of 8 consecutive k
+    auto tr_frag = [](const unsigned char* lo_p, const unsigned char* hi_p) {
+        typedef short i16x4 __attribute__((ext_vector_type(4)));
+        const i16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(lo_p));
+        const i16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(hi_p));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    const int tr_row = 8 * lq + (li >> 2), tr_col = 4 * (li & 3);
+    bf16x8 adjf[2];                                                      // B fragments of adj: k = node j, column = node i of tile it
+#pragma unroll
+    for (int it = 0; it < 2; ++it) adjf[it] = tr_frag(Ag + tr_row * kRSA + (16 * it + tr_col) * 2, Ag + (tr_row + 4) * kRSA + (16 * it + tr_col) * 2);
+    f32x4 acc[NTP][2];
+#pragma unroll
+    for (int c = 0; c < NTP; ++c)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) acc[c][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const auto rs_ = __builtin_amdgcn_make_buffer_rsrc(p.gsup, 0, static_cast<int>(min<int64_t>(rows_total * p.lds * 2, 0x7fffffff)), 0x00020000);
+    auto pack2 = [](float a, float b) { return static_cast<uint32_t>(f2bf(a)) | (static_cast<uint32_t>(f2bf(b)) << 16); };
+    // W fragment of row f under the k permutation: k = 4 lq .. + 3 is half (lq & 1) of slot lq >> 1, k = 16 + 4 lq .. of slot 2 + (lq >> 1)
+    const int wrow = li, whalf = 8 * (lq & 1), wk1 = lq >> 1, wk2 = 2 + (lq >> 1);
+    auto step = [&](auto SET, auto OTHER, int ks) {
+        constexpr int S_ = decltype(SET)::value;
+        store_w(OTHER);                                                  // slab of step ks + 1 (its buffer was last read in step ks - 1)
+        load_w(SET, ks + 2);
+        // 1. g_support^T tiles of this K step
+        bf16x8 bfr[2];
+        {
+            f32x4 sa[2][2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int ot = 2 * ks + tt;
+                const bf16x8 af = tr_frag(Gg + tr_row * kRSG + (16 * ot + tr_col) * 2, Gg + (tr_row + 4) * kRSG + (16 * ot + tr_col) * 2);
+#pragma unroll
+                for (int it = 0; it < 2; ++it) sa[tt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, adjf[it], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const uint32_t q0 = pack2(sa[0][it][0], sa[0][it][1]), q1 = pack2(sa[0][it][2], sa[0][it][3]);
+                const uint32_t q2 = pack2(sa[1][it][0], sa[1][it][1]), q3 = pack2(sa[1][it][2], sa[1][it][3]);
+                bfr[it] = __builtin_bit_cast(bf16x8, u32x4_g{q0, q1, q2, q3});
+                if ((ks % NS) == part) {                                 // this part writes the K step's columns of g_support (uniform)
+                    const int i = 16 * it + li;
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int o0 = 16 * (2 * ks + tt) + 4 * lq;
+                        const uint32_t off = (g < p.B && i < n && o0 < p.lds) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.lds + o0) * 2) : 0xfffffff0u;
+                        __builtin_amdgcn_raw_buffer_store_b64(tt == 0 ? u32x2_g{q0, q1} : u32x2_g{q2, q3}, rs_, off, 0, 0);
+                    }
+                }
+            }
+        }
+        // 2. g_x^T += W . g_support^T
+        const unsigned char* slab = Ws + S_ * (kFusedNT * 16 * 64);
+#pragma unroll
+        for (int c = 0; c < NTP; ++c)
+            if (c_lo + c < nt) {                                         // uniform
+                const int f = 16 * (c_lo + c) + wrow;
+                const u32x2_g a1 = *reinterpret_cast<const u32x2_g*>(slab + gf_lds_off(f, wk1) + whalf);
+                const u32x2_g a2 = *reinterpret_cast<const u32x2_g*>(slab + gf_lds_off(f, wk2) + whalf);
+                const bf16x8 af = __builtin_bit_cast(bf16x8, u32x4_g{a1.x, a1.y, a2.x, a2.y});
+                acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[0], acc[c][0], 0, 0, 0);
+                acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[1], acc[c][1], 0, 0, 0);
+            }
+        __syncthreads();
+    };
+    for (int ks = 0; ks < nks; ks += 2) {
+        step(S0{}, S1{}, ks);
+        if (ks + 1 < nks) step(S1{}, S0{}, ks + 1);
+    }
+    // ---- g_x: C layout column = node i, rows = four consecutive features
+    const auto rx_ = __builtin_amdgcn_make_buffer_rsrc(p.gx, 0, static_cast<int>(min<int64_t>(rows_total * p.ldgx * 2, 0x7fffffff)), 0x00020000);
+#pragma unroll
+    for (int c = 0; c < NTP; ++c)
+        if (c_lo + c < nt) {
+            const int f0 = 16 * (c_lo + c) + 4 * lq;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int i = 16 * it + li;
+                const uint32_t off = (g < p.B && i < n && f0 < p.ldgx) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.ldgx + f0) * 2) : 0xfffffff0u;
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2_g{pack2(acc[c][it][0], acc[c][it][1]), pack2(acc[c][it][2], acc[c][it][3])}, rx_, off, 0, 0);
+            }
+        }
+}
+
 bool gcn_fused_ok(const recon_gcn_b16_args* a) {
     static const bool off = getenv("RECON_GCN_FUSED") && getenv("RECON_GCN_FUSED")[0] == '0';
     return !off && a->n <= 32 && a->ldo <= kFusedNT * 16 && (a->ldo & 3) == 0 &&
@@ -437,10 +630,31 @@ extern "C" int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* b, recon_stream_t
     const uint16_t* gout = static_cast<const uint16_t*>(b->grad_out);
     const uint16_t* fout = static_cast<const uint16_t*>(a->out);
     float* colsum = b->partial + gcn_b16_gw_partial_floats(a->B, n, I, O);      // [B][O] per-graph column sums of gpre, behind the split-K partials
+    static const bool fused_bwd_off = getenv("RECON_GCN_FUSED_BWD") && getenv("RECON_GCN_FUSED_BWD")[0] == '0';
+    const int64_t i8f = (I + 7) / 8 * 8;
+    const bool fused_bwd = !fused_bwd_off && !b->g_adj && b->g_x && n <= 32 && a->lds <= kFusedNT * 16 && i8f <= kFusedNT * 16 && b->ldgx >= i8f &&
+                           (b->ldgx & 3) == 0 && (a->lds & 3) == 0 && (b->ldg & 7) == 0 && (a->ldo & 7) == 0 &&
+                           ((reinterpret_cast<uintptr_t>(b->g_x) | reinterpret_cast<uintptr_t>(b->grad_out) | reinterpret_cast<uintptr_t>(a->out)) & 15) == 0 &&
+                           static_cast<int64_t>(rows) * (a->lds > b->ldgx ? a->lds : b->ldgx) * 2 < 0x7fffffffLL &&
+                           static_cast<int64_t>(rows) * (b->ldg > a->ldo ? b->ldg : a->ldo) * 2 < 0x7fffffffLL;
+    if (fused_bwd) {
+        GcnFusedBwdK k;
+        k.gout = gout; k.ldg = b->ldg; k.fout = fout; k.ldf = a->ldo; k.adj = static_cast<const uint16_t*>(a->adj);
+        k.wn = reinterpret_cast<const uint16_t*>(static_cast<const char*>(a->w_planes) + planes_part(O, I));
+        k.gsup = static_cast<uint16_t*>(b->g_support); k.lds = a->lds; k.gx = static_cast<uint16_t*>(b->g_x); k.ldgx = b->ldgx;
+        k.colsum = b->g_bias ? colsum : nullptr;
+        k.B = a->B; k.n = n; k.I = I; k.O = O; k.Op = b16_kp(O); k.nt = static_cast<int32_t>(ceil_div64(i8f, 16));
+        constexpr int NSB = 4;
+        const size_t fl = 2ull * kFusedNT * 16 * 64 + 4ull * 32 * kRSG + 4ull * 32 * kRSA;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gcn_b16_fused_bwd<NSB>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(fl));
+        hipLaunchKernelGGL(k_gcn_b16_fused_bwd<NSB>, dim3(static_cast<unsigned>(ceil_div64(a->B, 4))), dim3(256 * NSB), fl, st, k);
+        RECON_CHECK_LAUNCH();
+    } else {
     // g_support = adj^T @ (grad_out * (out > 0)); pad columns zeroed (it is the A operand of the next product)
     dim3 grid(static_cast<unsigned>(ceil_div64(a->lds, 64)), static_cast<unsigned>(a->B), static_cast<unsigned>(ceil_div64(n, 32)));
     hipLaunchKernelGGL((k_gcn_b16_aggregate<true, true, false>), grid, dim3(256), 0, st, static_cast<const uint16_t*>(a->adj), gout, b->ldg, fout, a->ldo,
                        nullptr, n, O, static_cast<uint16_t*>(b->g_support), a->lds, b->g_bias ? colsum : nullptr);
+    }
     if (b->g_adj)
         hipLaunchKernelGGL(k_gcn_b16_grad_adj, dim3(static_cast<unsigned>(ceil_div64(n * n, 256)), static_cast<unsigned>(a->B)), dim3(256), 0, st, gout,
                            b->ldg, fout, a->ldo, static_cast<const uint16_t*>(a->support), a->lds, n, O, static_cast<uint16_t*>(b->g_adj));
@@ -448,7 +662,7 @@ extern "C" int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* b, recon_stream_t
     // g_bias: second pass over the per-graph column sums — in the launch of g_W's second pass when there is one
     const B16ReduceJob bias_job{colsum, static_cast<uint16_t*>(b->g_bias), O, a->B, 1, O};
     // g_x = g_support @ W^T : B operand = W [I][kp(O)] (k = out contiguous)
-    if (b->g_x) {
+    if (b->g_x && !fused_bwd) {
         const int64_t i8 = (I + 7) / 8 * 8;
         if (b->ldgx < i8 || (reinterpret_cast<uintptr_t>(b->g_x) & 15)) return RECON_ERR_INVALID;
         rc = gemm_b16(rows, I, O, b->g_support, a->lds, static_cast<const char*>(a->w_planes) + planes_part(O, I), b->g_x, b->ldgx, true, st);
