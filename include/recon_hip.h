@@ -353,6 +353,51 @@ size_t recon_propagate_bwd_ws_floats(const recon_prop_args* fwd);   /* B*C*S for
 int recon_propagate_bwd(const recon_prop_bwd_args* args, recon_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * P1 / P2 / K5 in bfloat16 (BASELINE.json configs[2] "GP-GNN Propagation 3 hops ... bf16", configs[4] "mixed GAT+Propagation
+ *     stack, bf16"): the same step (models/models.py:240-274) on bfloat16 tensors — bf16 storage, fp32 accumulation on
+ *     v_mfma_f32_16x16x32_bf16, every state and every gradient tensor rounded to bf16 once where the reference's bf16 tensors
+ *     are (csrc/prop_b16.hip).  All data pointers are bf16 (uint16_t) data, 16-byte aligned, S % 8 == 0.
+ *     recon_propagate_b16_form(): 1 = all hops of a graph in one workgroup (S % 16 == 0, S <= 160, C <= 96, even dd; reads
+ *     `trans` in place in block mode; h_saved optional), 2 = one batched GEMM per hop over the graphs (needs `adj`, h_saved and
+ *     `zeros`), 0 = shape not taken (the caller converts to float32 and runs recon_propagate_fwd).
+ *     The backward works on the materialised adjacency for every shape: both products of a hop as batched GEMMs.
+ * ------------------------------------------------------------------------------------------*/
+typedef struct {
+    int32_t B, C, S, L, dd;         /* as recon_prop_args                                                 */
+    int32_t act;                    /* RECON_ACT_*                                                        */
+    const void* const* adj;         /* HOST array of L device pointers, each [B,S,S] bf16 (ignored with trans) */
+    const void* h0;                 /* [C,S] (h0_batch_stride = 0) or [B,C,S] bf16                        */
+    int64_t h0_batch_stride;        /* elements; multiple of 8                                            */
+    const int64_t* head_idx;        /* [C,dd] (idx_batch_stride = 0) or [B,C,dd]; values in [0,S)         */
+    const int64_t* tail_idx;
+    int64_t idx_batch_stride;
+    void* out;                      /* [B,C,L*dd] bf16                                                    */
+    void* h_saved;                  /* [L,B,C,S] bf16 states after each hop: for the backward; required by form 2 */
+    const void* const* trans;       /* BLOCK MODE (form 1 only) or NULL: L device pointers [B, n(n-1), 256] bf16 */
+    const void* identity;           /* [16,16] bf16, with trans                                           */
+    const void* zeros;              /* >= 1 KiB of zero bytes, 16-byte aligned (K tails of the GEMMs): form 2 and the backward */
+} recon_prop_b16_args;
+
+int recon_propagate_b16_form(const recon_prop_b16_args* args);
+int recon_propagate_b16_fwd(const recon_prop_b16_args* args, recon_stream_t stream);
+
+typedef struct {
+    recon_prop_b16_args fwd;        /* adj, h_saved (filled by the forward), zeros                        */
+    const void* grad_out;           /* [B,C,L*dd] bf16                                                    */
+    void* const* g_adj;             /* HOST array of L device pointers [B,S,S] bf16 (entries may be NULL) */
+    void* g_h;                      /* [B,C,S] bf16; on return d loss / d h0 per batch element            */
+    void* ws;                       /* [B,C,S] bf16 workspace                                             */
+} recon_prop_b16_bwd_args;
+
+int recon_propagate_b16_bwd(const recon_prop_b16_bwd_args* args, recon_stream_t stream);
+
+/* P1 in bf16: recon_block_adjacency_fwd / _bwd on bf16 tensors (the identity gradient is summed in fp32, fixed order, rounded once) */
+int recon_block_adjacency_b16_fwd(const void* T, const void* identity, int32_t B, int32_t n, int32_t dd, void* A, recon_stream_t stream);
+size_t recon_block_adjacency_b16_bwd_workspace_floats(int32_t dd);
+int recon_block_adjacency_b16_bwd(const void* gA, int32_t B, int32_t n, int32_t dd, void* gT, void* g_identity, float* workspace,
+                                  recon_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * P4  make_start_entity_embeddings (utils/context_utils.py:387-426): h0[b,c=(i,j),:] has the first
  *     entity's embedding in node i's first half-slot and the second entity's in node j's second
  *     half-slot, zero elsewhere, times the start-embedding template.

@@ -294,8 +294,18 @@ def build_block_adjacency(T, identity, n):
     return blocks.permute(0, 1, 3, 2, 4).reshape(B, n * dd, n * dd)
 
 
-def propagate(adj_list, h0, nonlinearity, head_indices, tail_indices, as_gemm=False):
+def _stored(t, storage):
+    """`t` as it reads back from a tensor of dtype `storage` (None: unchanged): the rounding a reference run on bfloat16 tensors applies
+    to every tensor it materialises."""
+    return t if storage is None else t.to(storage).to(t.dtype)
+
+
+def propagate(adj_list, h0, nonlinearity, head_indices, tail_indices, as_gemm=False, storage=None, return_states=False):
     """models/models.py:260-274 (copies :470-485, :680-694, :918-932).
+
+    storage (e.g. torch.bfloat16): every tensor the reference materialises per hop — the state after the non-linearity and the
+    relation product — is rounded to that dtype, the arithmetic stays in the inputs' dtype (the reference's ops on bf16 tensors
+    accumulate in fp32 and round the result once).  return_states: also the list of states [B, C, S] after each hop.
 
     adj_list: L tensors [B, S, S]; h0: [C, S, 1] (shared, GPGNN) or [B, C, S, 1] (per batch, RECON*);
     per hop h <- nonlinearity(A_l h); relation_l = gather(h, heads) * gather(h, tails);
@@ -308,7 +318,7 @@ def propagate(adj_list, h0, nonlinearity, head_indices, tail_indices, as_gemm=Fa
     """
     B = adj_list[0].shape[0]
     h = h0
-    rels = []
+    rels, states = [], []
     hi = head_indices if head_indices.dim() == 3 else head_indices[None].expand(B, -1, -1)
     ti = tail_indices if tail_indices.dim() == 3 else tail_indices[None].expand(B, -1, -1)
     if as_gemm and h.dim() == 3:
@@ -320,9 +330,47 @@ def propagate(adj_list, h0, nonlinearity, head_indices, tail_indices, as_gemm=Fa
             h = torch.matmul(A[:, None], h)                 # [B, C, S, 1]
         if nonlinearity != "linear":
             h = getattr(F, nonlinearity)(h) if nonlinearity != "tanh" else torch.tanh(h)
+        h = _stored(h, storage)
         flat = h.reshape(B, h.shape[1], h.shape[2])
-        rels.append(torch.gather(flat, 2, hi) * torch.gather(flat, 2, ti))
-    return torch.cat(rels, dim=-1)
+        states.append(flat)
+        rels.append(_stored(torch.gather(flat, 2, hi) * torch.gather(flat, 2, ti), storage))
+    out = torch.cat(rels, dim=-1)
+    return (out, states) if return_states else out
+
+
+def propagate_backward(adj_list, h0, states, nonlinearity, head_indices, tail_indices, grad_out, storage=None):
+    """models/models.py:260-274 differentiated by hand, from GIVEN states after each hop (so that a low-precision forward's own
+    states — and with them its ReLU mask — can be used): per hop l = L..1
+        Y_l      = (G_l + d relation_l / d h^l) . act'(h^l)        G_L = 0
+        dA_l[b]  = Y_l[b]^T H^l-1[b]                                [S, S]
+        G_l-1[b] = Y_l[b] A_l[b]                                    [C, S]
+    with the relation term  R[c][head[c,x]] += g[c,x] h[c][tail[c,x]],  R[c][tail[c,x]] += g[c,x] h[c][head[c,x]].
+    `storage` rounds Y_l, dA_l and G_l as a run on tensors of that dtype would.  Returns ([dA_1..dA_L], d loss / d h0 per graph [B, C, S]).
+    tests/test_oracle_golden.py checks it against autograd of propagate()."""
+    B, L = adj_list[0].shape[0], len(adj_list)
+    dd = head_indices.shape[-1]
+    hi = head_indices if head_indices.dim() == 3 else head_indices[None].expand(B, -1, -1)
+    ti = tail_indices if tail_indices.dim() == 3 else tail_indices[None].expand(B, -1, -1)
+    h0f = h0.reshape(B, h0.shape[1], h0.shape[2]) if h0.dim() == 4 else h0.reshape(1, h0.shape[0], h0.shape[1]).expand(B, -1, -1)      # as propagate() takes it
+    G = torch.zeros_like(states[-1])
+    g_adj = [None] * L
+    for l in range(L, 0, -1):
+        H = states[l - 1]
+        g = grad_out[:, :, (l - 1) * dd: l * dd]
+        R = torch.zeros_like(H)
+        R.scatter_add_(2, hi, g * torch.gather(H, 2, ti))
+        R.scatter_add_(2, ti, g * torch.gather(H, 2, hi))
+        if nonlinearity == "relu":
+            dact = (H > 0).to(H.dtype)
+        elif nonlinearity == "tanh":
+            dact = 1 - H * H
+        else:
+            dact = torch.ones_like(H)
+        Y = _stored((G + R) * dact, storage)
+        Hprev = states[l - 2] if l >= 2 else h0f
+        g_adj[l - 1] = _stored(torch.bmm(Y.transpose(1, 2), Hprev), storage)
+        G = _stored(torch.bmm(Y, adj_list[l - 1]), storage)
+    return g_adj, G
 
 
 def graph_convolution(x, adj, weight, bias=None):

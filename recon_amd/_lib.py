@@ -71,6 +71,19 @@ class PropBwdArgs(C.Structure):
                 ("g_trans", C.POINTER(C.c_void_p)), ("g_identity", c_f32p), ("identity_ws", c_f32p), ("wide_ws", c_f32p)]
 
 
+class PropB16Args(C.Structure):
+    _fields_ = [("B", C.c_int32), ("C", C.c_int32), ("S", C.c_int32), ("L", C.c_int32), ("dd", C.c_int32),
+                ("act", C.c_int32), ("adj", C.POINTER(C.c_void_p)), ("h0", C.c_void_p), ("h0_batch_stride", C.c_int64),
+                ("head_idx", c_i64p), ("tail_idx", c_i64p), ("idx_batch_stride", C.c_int64),
+                ("out", C.c_void_p), ("h_saved", C.c_void_p), ("trans", C.POINTER(C.c_void_p)), ("identity", C.c_void_p),
+                ("zeros", C.c_void_p)]
+
+
+class PropB16BwdArgs(C.Structure):
+    _fields_ = [("fwd", PropB16Args), ("grad_out", C.c_void_p), ("g_adj", C.POINTER(C.c_void_p)), ("g_h", C.c_void_p),
+                ("ws", C.c_void_p)]
+
+
 class GcnArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("n", C.c_int32), ("in_features", C.c_int32), ("out_features", C.c_int32),
                 ("x", c_f32p), ("adj", c_f32p), ("weight", c_f32p), ("bias", c_f32p), ("support", c_f32p),
@@ -133,6 +146,12 @@ SYMBOLS = [
     ("recon_propagate_identity_ws_floats", C.c_size_t, [C.c_int32]),
     ("recon_propagate_ws_bytes", C.c_size_t, [C.POINTER(PropArgs)]),
     ("recon_propagate_bwd_ws_floats", C.c_size_t, [C.POINTER(PropArgs)]),
+    ("recon_propagate_b16_form", C.c_int, [C.POINTER(PropB16Args)]),
+    ("recon_propagate_b16_fwd", C.c_int, [C.POINTER(PropB16Args), C.c_void_p]),
+    ("recon_propagate_b16_bwd", C.c_int, [C.POINTER(PropB16BwdArgs), C.c_void_p]),
+    ("recon_block_adjacency_b16_fwd", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("recon_block_adjacency_b16_bwd_workspace_floats", C.c_size_t, [C.c_int32]),
+    ("recon_block_adjacency_b16_bwd", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, c_f32p, C.c_void_p]),
     ("recon_start_entity_embeddings", C.c_int, [c_f32p, c_i64p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
                                                 C.c_void_p]),
     ("recon_gcn_split_bytes", C.c_size_t, [C.c_int32, C.c_int32]),

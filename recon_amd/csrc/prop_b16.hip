@@ -1,0 +1,769 @@
+// K5 in bfloat16 — GP-GNN propagation (models/models.py:260-274 and its copies :470-485, :680-694, :918-932) on bf16 tensors:
+// bf16 storage, fp32 accumulation on v_mfma_f32_16x16x32_bf16, every state rounded to bf16 once per hop — what the reference's
+// torch.matmul / relu / gather chain computes when its tensors are bfloat16 (BASELINE.json configs[2], configs[4]).
+// ONE MFMA per 16x16x32 block, no operand splitting, no scale search: the small form below is bound by its single pass over
+// the adjacency stack (L B S^2 2 bytes), the wide form by the matrix pipe.
+//
+//   k_prop_b16_fwd<NKS,NTC,BLK>     S <= 160, C <= 96 (cfg 3b at n = 9): all L hops of a graph in one persistent workgroup, the
+//                                   state resident in LDS (two images, one barrier per hop), A_l fetched once as MFMA A fragments
+//                                   one hop ahead; block mode reads the transition tensors in place.
+//   k_bgemm_b16<PK,QK,...>          batched GEMM over the graphs (any S % 8 == 0): the forward's hops for wide states
+//                                   (H^l = act(H^l-1 A_l^T), n = 32: S = 512, C = 992) and both products of a backward hop
+//                                   (G_l = Y_l A_l,  dA_l = Y_l^T H^l-1).  Operands by LDS-DMA into double-buffered images;
+//                                   k-major operands come out of them through ds_read_b64_tr_b16.
+//   k_prop_b16_ypost                Y_l = (G_l+1 + relation gradient of hop l) . act'(H^l), one wave per (graph, channel) row
+//   k_prop_b16_gather               relation_l = h[head] * h[tail] from the saved states (wide form)
+//   k_block_adj_b16_*               P1 in bf16 (models/models.py:240-259)
+#include <math.h>
+#include <stdlib.h>
+#include "prop_common.h"
+#include "prop_h_util.h"
+
+namespace recon {
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using i16x4 = __attribute__((ext_vector_type(4))) short;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+
+struct PropB16K {
+    const uint16_t* adj[kMaxHops];
+    const uint16_t* trans[kMaxHops];
+    const uint16_t* identity;
+    const uint16_t* h0; int64_t h0_bs;
+    const int64_t* head; const int64_t* tail; int64_t idx_bs;
+    uint16_t* out; uint16_t* hsave;
+    int32_t B, C, S, L, dd, act;
+};
+
+__device__ __forceinline__ float bf2f(uint32_t bits16) { return __builtin_bit_cast(float, bits16 << 16); }
+__device__ __forceinline__ uint32_t pack_bf2(float a, float b) {      // round to nearest even, a in the low half
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == RECON_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == RECON_ACT_TANH) return tanh_fast(v);
+    return v;
+}
+
+// ================================================================================================ small states: fused forward
+// NKS = K steps of 32 (S <= 32 NKS), NTC = channel tiles of 16 (C <= 16 NTC); blockDim.x = 4 S (one wave per 16 rows of A; S % 16 == 0).
+// Dynamic LDS: two state images [NKS][16 NTC][64 B].  Element (channel c, column t) of an image lives at byte
+//     (t >> 5) STEP + 64 c + 16 (((t >> 3) & 3) ^ ((c >> 1) & 3)) + 2 (t & 7):
+// one 64-byte row per (K step, channel); its four 16-byte slots are the B fragments of the four lane groups (natural k order: lane group q
+// holds t = 32 ks + 8 q .. + 7), XOR-rotated by the channel so that the ds_read_b128 of a fragment is conflict free.
+// Hop l reads image `cur` and writes image `cur ^ 1`: one barrier per hop (the prop_h.hip form needs the channel maxima between them).
+template <int NKS, int NTC, bool BLK>
+__global__ void __launch_bounds__(128 * NKS) k_prop_b16_fwd(const PropB16K p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    constexpr int CH = NTC * 16;
+    constexpr int STEP = CH * 64;
+    constexpr int PLANE = NKS * STEP;
+    constexpr int NG = 2;                                               // gather pairs per thread whose positions stay in registers
+    const int S = p.S, C = p.C, L = p.L;
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const uint32_t SSb = static_cast<uint32_t>(S) * S * 2;
+
+    // A fragment of K step ks: row s = 16 wave + li, columns 32 ks + 8 lq .. + 7 (16 bytes); the part of the last K step past S is requested out
+    // of range (zeros).  BLOCK MODE (dd == 16: this wave's rows are node i = wave, a K step covers nodes 2 ks, 2 ks + 1): columns 8 (lq & 1) ..
+    // of row li of trans[l][b, e(i, j)], j = 2 ks + (lq >> 1); the diagonal block comes from `identity` (fetched once per kernel).
+    const uint32_t voff_row = (static_cast<uint32_t>(16 * wave + li) * S + 8 * lq) * 2u;
+    const uint32_t voff_last = (32 * (NKS - 1) + 8 * lq < S) ? voff_row + 64u * (NKS - 1) : kOOB;
+    const int nn = S >> 4;
+    const uint32_t voff_blk = static_cast<uint32_t>(li * 32 + (lq & 1) * 16);
+    auto rsrc_a = [&](int l, int bb) {
+        if constexpr (BLK)
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.trans[l] + static_cast<int64_t>(bb) * C * 256), 0, C * 512, 0x00020000);
+        else
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.adj[l]) + static_cast<int64_t>(bb) * SSb), 0,
+                                                     static_cast<int>(SSb), 0x00020000);
+    };
+    auto a_off = [&](int ks) -> uint32_t {
+        if constexpr (BLK) {
+            const int j = 2 * ks + (lq >> 1);
+            const int e = wave * (nn - 1) + (j < wave ? j : j - 1);
+            return (j < nn && j != wave) ? static_cast<uint32_t>(e) * 512u + voff_blk : kOOB;
+        } else {
+            return ks == NKS - 1 ? voff_last : voff_row + 64u * ks;
+        }
+    };
+    u32x4 diag = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (BLK) {
+        const auto rs_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.identity), 0, 512, 0x00020000);
+        diag = __builtin_amdgcn_raw_buffer_load_b128(rs_i, (lq >> 1) == (wave & 1) ? voff_blk : kOOB, 0, 0);
+    }
+    const int swz = ((li >> 1) & 3) << 4;
+    const int b_rd = li * 64 + ((lq << 4) ^ swz);                       // B fragment of channel 16 j + li: + 1024 j + STEP ks
+    // C layout of the hop's result: channel 16 j + li, columns t = 16 wave + 4 lq .. + 3 -> 8 bytes of the next image
+    const int t0w = 16 * wave + 4 * lq;
+    const int so_w = (wave >> 1) * STEP + 64 * li + (((2 * (wave & 1) + (lq >> 1)) << 4) ^ swz) + 8 * (lq & 1);      // + 1024 j
+    const int nitems = C * p.dd, Ldd = L * p.dd, npairs = nitems >> 1;
+    auto pos = [&](uint32_t c, uint32_t t) {
+        return (t >> 5) * STEP + 64u * c + (((((t >> 3) & 3u) ^ ((c >> 1) & 3u))) << 4) + 2u * (t & 7u);
+    };
+
+    for (int i = tid; i < 2 * PLANE / 16; i += nthreads) reinterpret_cast<uint4*>(sm)[i] = make_uint4(0u, 0u, 0u, 0u);
+    lds_barrier();                                                      // pad columns (t >= S) stay zero for the whole kernel: nobody writes them
+
+    // gather items (pairs of neighbouring x: one 4-byte store): byte positions of head / tail in an image, element offset in `out`
+    uint32_t g_h0[NG], g_h1[NG], g_t0[NG], g_t1[NG], g_o[NG];
+    auto gather_setup = [&](int bb) {
+        const int64_t* hd = p.head + bb * p.idx_bs;
+        const int64_t* tl = p.tail + bb * p.idx_bs;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const uint32_t it = 2u * min(tid + i * nthreads, npairs - 1);
+            const uint32_t c = it / static_cast<uint32_t>(p.dd), x = it - c * p.dd;
+            g_h0[i] = pos(c, static_cast<uint32_t>(hd[it])); g_h1[i] = pos(c, static_cast<uint32_t>(hd[it + 1]));
+            g_t0[i] = pos(c, static_cast<uint32_t>(tl[it])); g_t1[i] = pos(c, static_cast<uint32_t>(tl[it + 1]));
+            g_o[i] = c * Ldd + x;
+        }
+    };
+    if (p.idx_bs == 0) gather_setup(0);
+
+    u32x4 raw[NKS];
+    int b = blockIdx.x;
+    {
+        const auto rs = rsrc_a(0, b < p.B ? b : 0);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) raw[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, b < p.B ? a_off(ks) : kOOB, 0, 0);
+    }
+    int cur = 0;
+    const int s8 = S >> 3, npieces = C * s8;
+#pragma unroll 1
+    for (; b < p.B; b += gridDim.x) {
+        // ---- h^0 of graph b into image `cur`: 16-byte pieces (8 columns of one channel), consecutive threads = consecutive pieces
+        {
+            const uint16_t* h0b = p.h0 + b * p.h0_bs;
+            unsigned char* Hc = sm + cur * PLANE;
+            for (int q = tid; q < npieces; q += nthreads) {
+                const int c = q / s8, t = 8 * (q - c * s8);
+                const u32x4 v = *reinterpret_cast<const u32x4*>(h0b + static_cast<int64_t>(c) * S + t);
+                *reinterpret_cast<u32x4*>(Hc + (t >> 5) * STEP + 64 * c + ((((t >> 3) & 3) ^ ((c >> 1) & 3)) << 4)) = v;
+            }
+        }
+        if (p.idx_bs != 0) gather_setup(b);
+        lds_barrier();
+
+#pragma unroll 1
+        for (int l = 0; l < L; ++l) {
+            const unsigned char* Hc = sm + cur * PLANE;
+            unsigned char* Hn = sm + (cur ^ 1) * PLANE;
+            // the rows of the NEXT step (next hop, or hop 0 of this workgroup's next graph) are requested between the K steps, into the
+            // registers whose fragment the matrix pipe has just been handed
+            const bool more_hops = l + 1 < L;
+            const int nb = more_hops ? b : b + static_cast<int>(gridDim.x);
+            const bool pre = nb < p.B;
+            const auto rs_n = rsrc_a(more_hops ? l + 1 : 0, pre ? nb : b);
+            f32x4 acc[NTC];
+#pragma unroll
+            for (int j = 0; j < NTC; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                u32x4 av = raw[ks];
+                if constexpr (BLK) {
+                    const bool dk = ks == (wave >> 1);                  // wave-uniform
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[e] |= dk ? diag[e] : 0u;
+                }
+                const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+                for (int j = 0; j < NTC; ++j) {
+                    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(Hc + ks * STEP + 1024 * j + b_rd);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf, acc[j], 0, 0, 0);
+                }
+                raw[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_n, pre ? a_off(ks) : kOOB, 0, 0);
+                __builtin_amdgcn_sched_barrier(0x078f);                // everything but VMEM may move across: the requests stay where they are written
+            }
+            // ---- epilogue: activation, bf16, into the other image and (training) the saved states
+            const auto rs_hs = __builtin_amdgcn_make_buffer_rsrc(
+                p.hsave ? p.hsave + ((static_cast<int64_t>(l) * p.B + b) * C) * S : p.out, 0, p.hsave ? C * S * 2 : 0, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < NTC; ++j) {
+                const uint32_t w0 = pack_bf2(act_apply(acc[j][0], p.act), act_apply(acc[j][1], p.act));
+                const uint32_t w1 = pack_bf2(act_apply(acc[j][2], p.act), act_apply(acc[j][3], p.act));
+                *reinterpret_cast<uint2*>(Hn + so_w + 1024 * j) = make_uint2(w0, w1);
+                const int c = 16 * j + li;
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{w0, w1}, rs_hs,
+                                                      (p.hsave && c < C) ? static_cast<uint32_t>(c * S + t0w) * 2u : kOOB, 0, 0);
+            }
+            lds_barrier();                                              // H^l complete; everybody has read H^l-1
+            // ---- relation_l = gather(h, heads) * gather(h, tails)   (models/models.py:270-273)
+            uint16_t* outb = p.out + (static_cast<int64_t>(b) * C * L + l) * p.dd;
+            auto hv = [&](uint32_t q) { return bf2f(*reinterpret_cast<const uint16_t*>(Hn + q)); };
+#pragma unroll
+            for (int i = 0; i < NG; ++i)
+                if (tid + i * nthreads < npairs)
+                    *reinterpret_cast<uint32_t*>(outb + g_o[i]) = pack_bf2(hv(g_h0[i]) * hv(g_t0[i]), hv(g_h1[i]) * hv(g_t1[i]));
+            if (npairs > NG * nthreads) {                               // more items per thread: their index loads wait for the prefetch
+                for (int pi = tid + NG * nthreads; pi < npairs; pi += nthreads) {
+                    const uint32_t it = 2u * pi, c = it / static_cast<uint32_t>(p.dd), x = it - c * p.dd;
+                    const int64_t io = b * p.idx_bs + it;
+                    const float v0 = hv(pos(c, static_cast<uint32_t>(p.head[io]))) * hv(pos(c, static_cast<uint32_t>(p.tail[io])));
+                    const float v1 = hv(pos(c, static_cast<uint32_t>(p.head[io + 1]))) * hv(pos(c, static_cast<uint32_t>(p.tail[io + 1])));
+                    *reinterpret_cast<uint32_t*>(outb + c * Ldd + x) = pack_bf2(v0, v1);
+                }
+            }
+            cur ^= 1;
+        }
+        cur ^= 1;                                                       // the next graph's h^0 goes where nobody gathers from
+    }
+}
+
+// ================================================================================================ batched GEMM over the graphs
+// C[b][m][n] = sum_k Q[b](m, k) . P[b](n, k), bf16 operands, fp32 accumulation, bf16 result with n contiguous.  P is the operand
+// indexed by the output's contiguous index: its fragments are the MFMA's A operand, so that a lane holds four consecutive n of
+// one m (8-byte stores).  Either operand is k-contiguous ([row][k], XK = false) or k-major ([k][row], XK = true):
+//   forward hop        H^l[c][s]   = sum_t H^l-1[c][t] A_l[s][t]          P = A_l   (k-contiguous), Q = H^l-1 (k-contiguous), act
+//   backward (d)       G[c][t]     = sum_s Y[c][s]     A_l[s][t]          P = A_l   (k-major),      Q = Y     (k-contiguous)
+//   backward (c)       dA[s][t]    = sum_c Y[c][s]     H^l-1[c][t]        P = H^l-1 (k-major),      Q = Y     (k-major)
+// Workgroup = WM x WN waves, each MT x NT tiles of 16 x 16; a stage = KSUB K steps of 32, double buffered, one barrier per stage;
+// every operand piece (1 KiB = one wave instruction) is a global -> LDS copy without staging registers.  k-contiguous images:
+// [row][32 k] with the 16-byte slots rotated by 2 (row >> 3) (conflict-free ds_read_b128); k-major images: [32 k][row], 32-byte
+// column slots XORed with (k & 3) | ((k >> 3) & 1) << 2, fragments through the transposing read.  K tails read a page of zeros.
+// Workgroup id -> (graph, tile) keeps the tiles of one graph on one XCD (its L2 serves the re-reads of the operands).
+struct BGemmB16 {
+    const uint16_t* P; int64_t p_bs; int32_t ldp;
+    const uint16_t* Q; int64_t q_bs; int32_t ldq;
+    uint16_t* C; int64_t c_bs; int32_t ldc;
+    const uint16_t* zeros;
+    int32_t M, N, K, batch, tiles_m, tiles_n, act;
+};
+__device__ __forceinline__ int kc_off(int row, int kq) { return row * 64 + (((kq + 2 * (row >> 3)) & 3) << 4); }
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lo_p, const unsigned char* hi_p) {
+    const i16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(lo_p));
+    const i16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(hi_p));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+constexpr int km_slots(int rows) { int s = 8; while (s * 16 < rows) s *= 2; return s; }      // 32-byte column slots per k row (power of two, >= 8)
+
+template <bool PK, bool QK, int WM, int WN, int MT, int NT, int KSUB, bool ACT>
+__global__ void __launch_bounds__(64 * WM * WN) k_bgemm_b16(const BGemmB16 p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    constexpr int NWV = WM * WN, BM = WM * MT * 16, BN = WN * NT * 16;
+    constexpr int PS = km_slots(BN), QS = km_slots(BM);
+    constexpr int P_BYTES = PK ? 32 * PS * 32 : BN * 64, Q_BYTES = QK ? 32 * QS * 32 : BM * 64;
+    constexpr int SUB = P_BYTES + Q_BYTES, STAGE = KSUB * SUB;
+    constexpr int NPP = P_BYTES / 1024, NPQ = Q_BYTES / 1024, NPS = NPP + NPQ, NP = KSUB * NPS, ND = (NP + NWV - 1) / NWV;
+    constexpr int BK = 32 * KSUB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    // ---- (graph, tile) of this workgroup: XCD x = id & 7 owns graphs x, x + 8, ...
+    const int T = p.tiles_m * p.tiles_n;
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int gslot = within / T, tile = within - gslot * T;
+    const int bb = gslot * 8 + xcd;
+    if (bb >= p.batch) return;
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const uint16_t* Pb = p.P + bb * p.p_bs;
+    const uint16_t* Qb = p.Q + bb * p.q_bs;
+    const int wm = wid / WN, wn = wid - wm * WN;
+
+    // ---- copy plan of this wave: piece pc = i NWV + wid of a stage; element offset d_a + (k0 + d_k) * stride of its operand
+    int d_a[ND], d_k[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int pc = min(i * NWV + wid, NP - 1);
+        const int sub = pc / NPS, r = pc - sub * NPS;
+        const bool isp = r < NPP;
+        const int pi = isp ? r : r - NPP;
+        const int s = 64 * pi + lane;
+        const bool kmaj = isp ? PK : QK;
+        const int row0 = isp ? n0 : m0, rows = isp ? p.N : p.M, ld = isp ? p.ldp : p.ldq;
+        if (kmaj) {
+            const int ns2 = 2 * (isp ? PS : QS);                        // 16-byte units per k row
+            const int k = s / ns2, phys = s - k * ns2;
+            const int t = (phys >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2));
+            d_k[i] = 32 * sub + k;
+            d_a[i] = min(row0 + 16 * t + 8 * (phys & 1), ((rows + 7) & ~7) - 8);
+        } else {
+            const int rowL = s >> 2, kq = ((s & 3) - 2 * (rowL >> 3)) & 3;
+            d_k[i] = 32 * sub + 8 * kq;
+            d_a[i] = min(row0 + rowL, rows - 1) * ld;
+        }
+    }
+    const uint16_t* zlane = p.zeros + 8 * lane;
+    auto dma = [&](int k0, int buf) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int pc = i * NWV + wid;                               // wave-uniform
+            if (pc < NP) {
+                const int sub = pc / NPS, r = pc - sub * NPS;
+                const bool isp = r < NPP;
+                const bool kmaj = isp ? PK : QK;
+                const int k = k0 + d_k[i];
+                const uint16_t* base = isp ? Pb : Qb;
+                const int64_t off = kmaj ? static_cast<int64_t>(k) * (isp ? p.ldp : p.ldq) + d_a[i] : static_cast<int64_t>(d_a[i]) + k;
+                const uint16_t* src = k < p.K ? base + off : zlane;
+                unsigned char* dst = sm + buf * STAGE + sub * SUB + (isp ? 0 : P_BYTES) + 1024 * (isp ? r : r - NPP);
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+    // ---- fragment addresses inside a sub-step's images
+    int p_rd[NT], q_rd[MT];
+    const int kk = 8 * lq + (li >> 2);                                  // k row of the first transposing read (+ 4 for the second)
+    const int kx = (li >> 2) | ((lq & 1) << 2);                          // slot XOR of that row (the same for k + 4)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int t = wn * NT + j;
+        p_rd[j] = PK ? kk * (PS * 32) + ((t ^ kx) << 5) + ((li & 3) << 3) : kc_off(16 * t + li, lq);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int t = wm * MT + i;
+        q_rd[i] = P_BYTES + (QK ? kk * (QS * 32) + ((t ^ kx) << 5) + ((li & 3) << 3) : kc_off(16 * t + li, lq));
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    dma(0, 0);
+    int buf = 0;
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this stage's copies have landed ...
+        __syncthreads();                                              // ... everyone's, and nobody still reads the other buffer
+        if (k0 + BK < p.K) dma(k0 + BK, buf ^ 1);
+        const unsigned char* st = sm + buf * STAGE;
+#pragma unroll
+        for (int sub = 0; sub < KSUB; ++sub) {
+            const unsigned char* im = st + sub * SUB;
+            bf16x8 pf[NT], qf[MT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if constexpr (PK) pf[j] = tr_frag(im + p_rd[j], im + p_rd[j] + 4 * PS * 32);
+                else pf[j] = *reinterpret_cast<const bf16x8*>(im + p_rd[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (QK) qf[i] = tr_frag(im + q_rd[i], im + q_rd[i] + 4 * QS * 32);
+                else qf[i] = *reinterpret_cast<const bf16x8*>(im + q_rd[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    // ---- MFMA result: rows (4 lq + r) = n, column li = m
+    uint16_t* Cb = p.C + bb * p.c_bs;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + 16 * (wm * MT + i) + li;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + 16 * (wn * NT + j) + 4 * lq;
+            if (m < p.M && n < p.N) {                                   // N % 4 == 0: a lane's four columns exist together
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if constexpr (ACT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act);
+                }
+                *reinterpret_cast<uint2*>(Cb + static_cast<int64_t>(m) * p.ldc + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            }
+        }
+    }
+}
+
+// ================================================================================================ Y_l of the backward
+// Y[row] = (G[row] + relation gradient of hop `hop`) . act'(H[row]), row = (graph, channel): one wave per row, the row as fp32 in LDS,
+// the 2 dd scatter terms as LDS float atomics (indices are arbitrary).  G == nullptr: the last hop (nothing arrives from above).
+__global__ void __launch_bounds__(256) k_prop_b16_ypost(const uint16_t* __restrict__ G, const uint16_t* __restrict__ Hl, const int64_t* __restrict__ head,
+                                                         const int64_t* __restrict__ tail, int64_t idx_bs, const uint16_t* __restrict__ gout,
+                                                         uint16_t* __restrict__ Y, int64_t rows, int32_t C, int32_t S, int32_t L, int32_t dd, int32_t hop,
+                                                         int32_t act) {
+    extern __shared__ float rowbuf[];                                   // [4][2][S]: gradient row, state row
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + w;
+    if (row >= rows) return;
+    const int64_t b = row / C;
+    const int c = static_cast<int>(row - b * C);
+    float* buf = rowbuf + w * 2 * S;
+    float* hb = buf + S;
+    const uint16_t* g = G ? G + row * S : nullptr;
+    const uint16_t* h = Hl + row * S;
+    for (int t8 = lane; t8 < (S >> 3); t8 += 64) {
+        const u32x4 hv = *reinterpret_cast<const u32x4*>(h + 8 * t8);
+        u32x4 gv = u32x4{0u, 0u, 0u, 0u};
+        if (g) gv = *reinterpret_cast<const u32x4*>(g + 8 * t8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t hw = hv[e], gw = gv[e];
+            hb[8 * t8 + 2 * e] = bf2f(hw & 0xffffu); hb[8 * t8 + 2 * e + 1] = bf2f(hw >> 16);
+            buf[8 * t8 + 2 * e] = bf2f(gw & 0xffffu); buf[8 * t8 + 2 * e + 1] = bf2f(gw >> 16);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                 // this wave's LDS writes have landed (one wave per row: no barrier)
+    const int64_t io = b * idx_bs + static_cast<int64_t>(c) * dd;
+    const uint16_t* go = gout + row * (static_cast<int64_t>(L) * dd) + static_cast<int64_t>(hop) * dd;
+    for (int x = lane; x < dd; x += 64) {                               // out = h[head] * h[tail]  (models/models.py:270-273)
+        const int hi = static_cast<int>(head[io + x]), ti = static_cast<int>(tail[io + x]);
+        const float gv = bf2f(go[x]);
+        atomicAdd(buf + hi, gv * hb[ti]);
+        atomicAdd(buf + ti, gv * hb[hi]);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    uint16_t* y = Y + row * S;
+    for (int t8 = lane; t8 < (S >> 3); t8 += 64) {
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = 8 * t8 + 2 * e;
+            o[e] = pack_bf2(buf[t] * act_bwd(hb[t], act), buf[t + 1] * act_bwd(hb[t + 1], act));
+        }
+        *reinterpret_cast<u32x4*>(y + 8 * t8) = u32x4{o[0], o[1], o[2], o[3]};
+    }
+}
+
+// relation_l for every hop out of the saved states [L][B][C][S]: thread = one element of out [B][C][L][dd]
+__global__ void __launch_bounds__(256) k_prop_b16_gather(const uint16_t* __restrict__ hs, const int64_t* __restrict__ head, const int64_t* __restrict__ tail,
+                                                          int64_t idx_bs, uint16_t* __restrict__ out, int64_t total, int32_t B, int32_t C, int32_t S, int32_t L,
+                                                          int32_t dd) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = static_cast<int>(idx % dd);
+    const int l = static_cast<int>((idx / dd) % L);
+    const int64_t bc = idx / (static_cast<int64_t>(dd) * L);
+    const int64_t b = bc / C;
+    const int c = static_cast<int>(bc - b * C);
+    const int64_t io = b * idx_bs + static_cast<int64_t>(c) * dd + x;
+    const uint16_t* h = hs + ((static_cast<int64_t>(l) * B + b) * C + c) * S;
+    const float v = bf2f(h[head[io]]) * bf2f(h[tail[io]]);
+    out[idx] = static_cast<uint16_t>(pack_bf2(v, 0.f) & 0xffffu);
+}
+
+// ================================================================================================ P1 in bf16
+// A[b, i dd + r, j dd + c] = T[b, e(i, j), r dd + c] (identity on the diagonal blocks); VEC = 8 columns per thread where dd % 8 == 0
+template <int VEC>
+__global__ void __launch_bounds__(256) k_block_adj_b16_fwd(const uint16_t* __restrict__ T, const uint16_t* __restrict__ I, int32_t n, int32_t dd,
+                                                            uint16_t* __restrict__ A) {
+    const int S = n * dd, SV = S / VEC;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= S * SV) return;
+    const int b = blockIdx.y;
+    const int row = t / SV, col = (t - row * SV) * VEC;
+    const int i = row / dd, r = row - i * dd, j = col / dd, c = col - j * dd;
+    const uint16_t* src = i == j ? I + r * dd + c
+                                 : T + (static_cast<int64_t>(b) * n * (n - 1) + i * (n - 1) + (j < i ? j : j - 1)) * dd * dd + r * dd + c;
+    uint16_t* dst = A + static_cast<int64_t>(b) * S * S + static_cast<int64_t>(row) * S + col;
+    if constexpr (VEC == 8) *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+    else *dst = *src;
+}
+template <int VEC>
+__global__ void __launch_bounds__(256) k_block_adj_b16_bwd_T(const uint16_t* __restrict__ gA, int32_t n, int32_t dd, uint16_t* __restrict__ gT) {
+    const int S = n * dd, d2 = dd * dd, Cn = n * (n - 1);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= Cn * (d2 / VEC)) return;
+    const int b = blockIdx.y;
+    const int e = t / (d2 / VEC), rc = (t - e * (d2 / VEC)) * VEC;
+    const int r = rc / dd, c = rc - r * dd;
+    const int i = e / (n - 1);
+    int j = e - i * (n - 1);
+    if (j >= i) ++j;
+    const uint16_t* src = gA + static_cast<int64_t>(b) * S * S + static_cast<int64_t>(i * dd + r) * S + j * dd + c;
+    uint16_t* dst = gT + (static_cast<int64_t>(b) * Cn + e) * d2 + rc;
+    if constexpr (VEC == 8) *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+    else *dst = *src;
+}
+// d loss / d identity: slice `blk` of the (graph, node) pairs, thread e = (r, c), fp32 partial sums [slice][dd dd]; k_sum_rows_b16 adds the
+// slices in a fixed order and rounds once
+constexpr int kIdentSlicesB16 = 256;
+__global__ void __launch_bounds__(256) k_block_adj_b16_bwd_I(const uint16_t* __restrict__ gA, int32_t B, int32_t n, int32_t dd, float* __restrict__ partial) {
+    const int64_t S = 1LL * n * dd, pairs = 1LL * B * n;
+    const int64_t per = (pairs + gridDim.x - 1) / gridDim.x;
+    const int64_t t0 = blockIdx.x * per, t1 = min(pairs, t0 + per);
+    for (int e = threadIdx.x; e < dd * dd; e += 256) {
+        const int r = e / dd, c = e % dd;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        auto at = [&](int64_t t) { const int64_t b = t / n; const int i = static_cast<int>(t % n); return bf2f(gA[(b * S + i * dd + r) * S + i * dd + c]); };
+        int64_t t = t0;
+        for (; t + 4 <= t1; t += 4) { s0 += at(t); s1 += at(t + 1); s2 += at(t + 2); s3 += at(t + 3); }
+        for (; t < t1; ++t) s0 += at(t);
+        partial[static_cast<int64_t>(blockIdx.x) * dd * dd + e] = (s0 + s1) + (s2 + s3);
+    }
+}
+__global__ void __launch_bounds__(256) k_sum_rows_b16(const float* __restrict__ partial, int32_t nrows, int32_t O, uint16_t* __restrict__ out) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= O) return;
+    float s = 0.f;
+    for (int r = 0; r < nrows; ++r) s += partial[static_cast<int64_t>(r) * O + o];
+    out[o] = static_cast<uint16_t>(pack_bf2(s, 0.f) & 0xffffu);
+}
+
+// ================================================================================================ host side
+bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+int num_cus_b16() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+int check_b16(const recon_prop_b16_args* a) {
+    if (!a) return RECON_ERR_INVALID;
+    if (a->B < 0 || a->C <= 0 || a->S <= 0 || a->L <= 0 || a->dd <= 0) return RECON_ERR_INVALID;
+    if (a->L > kMaxHops || a->B > 65535) return RECON_ERR_UNSUPPORTED;
+    if (a->act < 0 || a->act > 2) return RECON_ERR_INVALID;
+    if (!a->h0 || !a->head_idx || !a->tail_idx || !a->out) return RECON_ERR_INVALID;
+    if (a->trans) {
+        if (!a->identity) return RECON_ERR_INVALID;
+        for (int l = 0; l < a->L; ++l) if (!a->trans[l]) return RECON_ERR_INVALID;
+        const int n = a->S / 16;
+        if (a->dd != 16 || a->S != 16 * n || a->C != n * (n - 1)) return RECON_ERR_UNSUPPORTED;
+        return RECON_OK;
+    }
+    if (!a->adj) return RECON_ERR_INVALID;
+    for (int l = 0; l < a->L; ++l) if (!a->adj[l]) return RECON_ERR_INVALID;
+    return RECON_OK;
+}
+
+size_t fused_lds(int nks, int ntc) { return 2ull * nks * ntc * 16 * 64; }
+
+// 1: the fused small-state kernel, 2: the batched-GEMM form (materialised adjacency, saved states, zeros page), 0: neither
+int form_b16(const recon_prop_b16_args* a, bool check_ptrs) {
+    if (a->S % 8 != 0 || a->S < 8) return 0;
+    const bool blk = a->trans != nullptr;
+    if (check_ptrs) {
+        if (!al16(a->h0) || (a->h0_batch_stride % 8) != 0 || (a->h_saved && !al16(a->h_saved)) || (reinterpret_cast<uintptr_t>(a->out) & 3)) return 0;
+        for (int l = 0; l < a->L; ++l) if (!al16(blk ? a->trans[l] : a->adj[l])) return 0;
+        if (blk && !al16(a->identity)) return 0;
+    }
+    const char* env = getenv("RECON_PROP_B16");                         // "g": the GEMM form everywhere (tests, A/B)
+    const bool force_gemm = env && env[0] == 'g';
+    if (!force_gemm && a->S % 16 == 0 && a->S <= 160 && a->C <= 96 && (a->dd % 2) == 0 && ((a->C * a->dd) & 1) == 0) return 1;
+    if (blk) return 0;
+    if (static_cast<int64_t>(a->C) * a->S >= (1LL << 31) || static_cast<int64_t>(a->S) * a->S >= (1LL << 31)) return 0;
+    return 2;
+}
+
+template <bool PK, bool QK, bool ACT>
+int launch_bgemm(const BGemmB16& g0, hipStream_t st) {
+    BGemmB16 g = g0;
+    const bool mid = g.M <= 144 && g.N <= 144;
+    if (mid) {
+        constexpr int WM = 3, WN = 3, MT = 3, NT = 3, KSUB = 1;
+        constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+        constexpr size_t lds = 2ull * KSUB * ((PK ? 32 * km_slots(BN) * 32 : BN * 64) + (QK ? 32 * km_slots(BM) * 32 : BM * 64));
+        g.tiles_m = (g.M + BM - 1) / BM; g.tiles_n = (g.N + BN - 1) / BN;
+        const int64_t nblk = ceil_div64(g.batch, 8) * 8 * g.tiles_m * g.tiles_n;
+        auto kern = k_bgemm_b16<PK, QK, WM, WN, MT, NT, KSUB, ACT>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nblk)), dim3(64 * WM * WN), lds, st, g);
+    } else {
+        constexpr int WM = 2, WN = 2, MT = 4, NT = 4, KSUB = 2;
+        constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+        constexpr size_t lds = 2ull * KSUB * ((PK ? 32 * km_slots(BN) * 32 : BN * 64) + (QK ? 32 * km_slots(BM) * 32 : BM * 64));
+        g.tiles_m = (g.M + BM - 1) / BM; g.tiles_n = (g.N + BN - 1) / BN;
+        const int64_t nblk = ceil_div64(g.batch, 8) * 8 * g.tiles_m * g.tiles_n;
+        if (nblk >= (1LL << 31)) return RECON_ERR_UNSUPPORTED;
+        auto kern = k_bgemm_b16<PK, QK, WM, WN, MT, NT, KSUB, ACT>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nblk)), dim3(64 * WM * WN), lds, st, g);
+    }
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+
+int fwd_fused(const recon_prop_b16_args* a, hipStream_t st) {
+    PropB16K p{};
+    const bool blk = a->trans != nullptr;
+    for (int l = 0; l < kMaxHops; ++l) {
+        p.adj[l] = (l < a->L && !blk) ? static_cast<const uint16_t*>(a->adj[l]) : nullptr;
+        p.trans[l] = (l < a->L && blk) ? static_cast<const uint16_t*>(a->trans[l]) : nullptr;
+    }
+    p.identity = blk ? static_cast<const uint16_t*>(a->identity) : nullptr;
+    p.h0 = static_cast<const uint16_t*>(a->h0); p.h0_bs = a->h0_batch_stride;
+    p.head = a->head_idx; p.tail = a->tail_idx; p.idx_bs = a->idx_batch_stride;
+    p.out = static_cast<uint16_t*>(a->out); p.hsave = static_cast<uint16_t*>(a->h_saved);
+    p.B = a->B; p.C = a->C; p.S = a->S; p.L = a->L; p.dd = a->dd; p.act = a->act;
+    const int nks = (a->S + 31) / 32, ntc = (a->C + 15) / 16, nw = a->S / 16;
+    const size_t lds = fused_lds(nks, ntc);
+#define CALL_F(K_, N_, X_)                                                                                                              \
+    do {                                                                                                                                \
+        auto kern = k_prop_b16_fwd<K_, N_, X_>;                                                                                         \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                       static_cast<int>(lds));                                                         \
+        int occ = 0;                                                                                                                    \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * nw, lds) != hipSuccess || occ < 1) occ = 1;                   \
+        const int64_t cap = static_cast<int64_t>(occ) * num_cus_b16();                                                                  \
+        const int64_t rounds = ceil_div64(a->B, cap);                                                                                   \
+        const int grid = static_cast<int>(ceil_div64(a->B, rounds));      /* every workgroup walks `rounds` graphs (the last ones one less) */ \
+        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * nw), lds, st, p);                                         \
+    } while (0)
+    if (blk) {                                                          // block mode: S = 16 n, C = n (n - 1): one (NKS, NTC) per n
+        switch (nw) { case 2: CALL_F(1, 1, true); break; case 3: case 4: CALL_F(2, 1, true); break; case 5: case 6: CALL_F(3, 2, true); break;
+                      case 7: CALL_F(4, 3, true); break; case 8: CALL_F(4, 4, true); break; case 9: CALL_F(5, 5, true); break; case 10: CALL_F(5, 6, true); break;
+                      default: return RECON_ERR_UNSUPPORTED; }
+    } else {
+#define CALL_FN(K_)                                                                                                                     \
+    switch (ntc) { case 1: CALL_F(K_, 1, false); break; case 2: CALL_F(K_, 2, false); break; case 3: CALL_F(K_, 3, false); break; case 4: CALL_F(K_, 4, false); break; \
+                   case 5: CALL_F(K_, 5, false); break; default: CALL_F(K_, 6, false); break; }
+        switch (nks) { case 1: CALL_FN(1); break; case 2: CALL_FN(2); break; case 3: CALL_FN(3); break; case 4: CALL_FN(4); break; default: CALL_FN(5); break; }
+#undef CALL_FN
+    }
+#undef CALL_F
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+
+int fwd_gemm(const recon_prop_b16_args* a, hipStream_t st) {
+    if (!a->h_saved || !a->zeros || !al16(a->zeros)) return RECON_ERR_INVALID;
+    const int32_t B = a->B, C = a->C, S = a->S, L = a->L;
+    const int64_t CS = 1LL * C * S, BCS = CS * B;
+    uint16_t* hs = static_cast<uint16_t*>(a->h_saved);
+    for (int l = 1; l <= L; ++l) {
+        BGemmB16 g{};
+        g.P = static_cast<const uint16_t*>(a->adj[l - 1]); g.p_bs = 1LL * S * S; g.ldp = S;
+        g.Q = l == 1 ? static_cast<const uint16_t*>(a->h0) : hs + (l - 2) * BCS; g.q_bs = l == 1 ? a->h0_batch_stride : CS; g.ldq = S;
+        g.C = hs + (l - 1) * BCS; g.c_bs = CS; g.ldc = S;
+        g.zeros = static_cast<const uint16_t*>(a->zeros);
+        g.M = C; g.N = S; g.K = S; g.batch = B; g.act = a->act;
+        const int rc = launch_bgemm<false, false, true>(g, st);
+        if (rc != RECON_OK) return rc;
+    }
+    const int64_t total = 1LL * B * C * L * a->dd;
+    hipLaunchKernelGGL(k_prop_b16_gather, dim3(static_cast<unsigned>(ceil_div64(total, 256))), dim3(256), 0, st, hs, a->head_idx, a->tail_idx,
+                       a->idx_batch_stride, static_cast<uint16_t*>(a->out), total, B, C, S, L, a->dd);
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+
+}  // namespace
+}  // namespace recon
+
+using namespace recon;
+
+extern "C" int recon_propagate_b16_form(const recon_prop_b16_args* a) {
+    if (!a || a->B < 0 || a->C <= 0 || a->S <= 0 || a->L <= 0 || a->L > kMaxHops || a->dd <= 0) return 0;
+    if (a->trans && (a->dd != 16 || a->S % 16 != 0 || a->C != (a->S / 16) * (a->S / 16 - 1))) return 0;
+    return form_b16(a, false);
+}
+
+extern "C" int recon_propagate_b16_fwd(const recon_prop_b16_args* a, recon_stream_t stream) {
+    const int rc = check_b16(a);
+    if (rc != RECON_OK) return rc;
+    if (a->B == 0) return RECON_OK;
+    const int form = form_b16(a, true);
+    if (form == 1) return fwd_fused(a, as_stream(stream));
+    if (form == 2) return fwd_gemm(a, as_stream(stream));
+    return RECON_ERR_UNSUPPORTED;
+}
+
+// Both products of every hop as batched GEMMs over the graphs; Y_l in place of G_l+1 (k_prop_b16_ypost).  The L products of kind (d)
+// alternate between `ws` and g_h so that the last one (d loss / d h^0 per graph) lands in g_h.
+extern "C" int recon_propagate_b16_bwd(const recon_prop_b16_bwd_args* ba, recon_stream_t stream) {
+    if (!ba) return RECON_ERR_INVALID;
+    const recon_prop_b16_args* a = &ba->fwd;
+    const int rc0 = check_b16(a);
+    if (rc0 != RECON_OK) return rc0;
+    if (a->trans) return RECON_ERR_UNSUPPORTED;                         // the backward works on a materialised adjacency
+    if (!a->h_saved || !ba->grad_out || !ba->g_h || !ba->ws || !a->zeros) return RECON_ERR_INVALID;
+    if (a->B == 0) return RECON_OK;
+    const int32_t B = a->B, C = a->C, S = a->S, L = a->L;
+    if (S % 8 != 0 || !al16(a->h0) || (a->h0_batch_stride % 8) != 0 || !al16(a->h_saved) || !al16(ba->g_h) || !al16(ba->ws) || !al16(a->zeros) ||
+        static_cast<int64_t>(C) * S >= (1LL << 31) || static_cast<int64_t>(S) * S >= (1LL << 31) || 8ull * S * sizeof(float) > 64 * 1024)
+        return RECON_ERR_UNSUPPORTED;
+    for (int l = 0; l < L; ++l)
+        if (!al16(a->adj[l]) || (ba->g_adj && ba->g_adj[l] && !al16(ba->g_adj[l]))) return RECON_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const int64_t CS = 1LL * C * S, BCS = CS * B, rows = 1LL * B * C;
+    const uint16_t* hs = static_cast<const uint16_t*>(a->h_saved);
+    const uint16_t* gout = static_cast<const uint16_t*>(ba->grad_out);
+    uint16_t* bufY = static_cast<uint16_t*>((L & 1) ? ba->ws : ba->g_h);
+    uint16_t* bufG = static_cast<uint16_t*>((L & 1) ? ba->g_h : ba->ws);
+    const dim3 pgrid(static_cast<unsigned>(ceil_div64(rows, 4)));
+    const size_t plds = 8ull * S * sizeof(float);
+    hipLaunchKernelGGL(k_prop_b16_ypost, pgrid, dim3(256), plds, st, nullptr, hs + (L - 1) * BCS, a->head_idx, a->tail_idx, a->idx_batch_stride, gout, bufY,
+                       rows, C, S, L, a->dd, L - 1, a->act);
+    for (int l = L; l >= 1; --l) {
+        const uint16_t* Hprev = l == 1 ? static_cast<const uint16_t*>(a->h0) : hs + (l - 2) * BCS;
+        const int64_t hprev_bs = l == 1 ? a->h0_batch_stride : CS;
+        if (ba->g_adj && ba->g_adj[l - 1]) {                            // (c): dA[s][t] = sum_c Y[c][s] H^l-1[c][t]
+            BGemmB16 g{};
+            g.P = Hprev; g.p_bs = hprev_bs; g.ldp = S;
+            g.Q = bufY; g.q_bs = CS; g.ldq = S;
+            g.C = static_cast<uint16_t*>(ba->g_adj[l - 1]); g.c_bs = 1LL * S * S; g.ldc = S;
+            g.zeros = static_cast<const uint16_t*>(a->zeros);
+            g.M = S; g.N = S; g.K = C; g.batch = B; g.act = 0;
+            const int rc = launch_bgemm<true, true, false>(g, st);
+            if (rc != RECON_OK) return rc;
+        }
+        {                                                               // (d): G[c][t] = sum_s Y[c][s] A_l[s][t]
+            BGemmB16 g{};
+            g.P = static_cast<const uint16_t*>(a->adj[l - 1]); g.p_bs = 1LL * S * S; g.ldp = S;
+            g.Q = bufY; g.q_bs = CS; g.ldq = S;
+            g.C = bufG; g.c_bs = CS; g.ldc = S;
+            g.zeros = static_cast<const uint16_t*>(a->zeros);
+            g.M = C; g.N = S; g.K = S; g.batch = B; g.act = 0;
+            const int rc = launch_bgemm<true, false, false>(g, st);
+            if (rc != RECON_OK) return rc;
+        }
+        if (l > 1)
+            hipLaunchKernelGGL(k_prop_b16_ypost, pgrid, dim3(256), plds, st, bufG, hs + (l - 2) * BCS, a->head_idx, a->tail_idx, a->idx_batch_stride, gout,
+                               bufG, rows, C, S, L, a->dd, l - 2, a->act);
+        uint16_t* t = bufY; bufY = bufG; bufG = t;
+    }
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+
+extern "C" int recon_block_adjacency_b16_fwd(const void* T, const void* identity, int32_t B, int32_t n, int32_t dd, void* A, recon_stream_t stream) {
+    if (B < 0 || n < 1 || dd < 1 || !identity || !A || (n > 1 && B > 0 && !T)) return RECON_ERR_INVALID;
+    if (B > 65535) return RECON_ERR_UNSUPPORTED;
+    if (B == 0) return RECON_OK;
+    const int S = n * dd;
+    const bool v8 = dd % 8 == 0 && !((reinterpret_cast<uintptr_t>(T) | reinterpret_cast<uintptr_t>(identity) | reinterpret_cast<uintptr_t>(A)) & 15);
+    const uint16_t* Tp = static_cast<const uint16_t*>(T);
+    const uint16_t* Ip = static_cast<const uint16_t*>(identity);
+    if (v8) hipLaunchKernelGGL(k_block_adj_b16_fwd<8>, dim3(static_cast<unsigned>(ceil_div64(1LL * S * S / 8, 256)), static_cast<unsigned>(B)), dim3(256), 0,
+                               as_stream(stream), Tp, Ip, n, dd, static_cast<uint16_t*>(A));
+    else hipLaunchKernelGGL(k_block_adj_b16_fwd<1>, dim3(static_cast<unsigned>(ceil_div64(1LL * S * S, 256)), static_cast<unsigned>(B)), dim3(256), 0,
+                            as_stream(stream), Tp, Ip, n, dd, static_cast<uint16_t*>(A));
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+extern "C" size_t recon_block_adjacency_b16_bwd_workspace_floats(int32_t dd) {
+    return static_cast<size_t>(kIdentSlicesB16) * (dd > 0 ? dd : 1) * (dd > 0 ? dd : 1);
+}
+
+extern "C" int recon_block_adjacency_b16_bwd(const void* gA, int32_t B, int32_t n, int32_t dd, void* gT, void* g_identity, float* workspace,
+                                             recon_stream_t stream) {
+    if (B < 0 || n < 1 || dd < 1 || !gA) return RECON_ERR_INVALID;
+    if (g_identity && !workspace) return RECON_ERR_INVALID;
+    if (B > 65535) return RECON_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const uint16_t* g = static_cast<const uint16_t*>(gA);
+    const int64_t per_graph = 1LL * n * (n - 1) * dd * dd;
+    if (gT && per_graph > 0 && B > 0) {
+        const bool v8 = dd % 8 == 0 && !((reinterpret_cast<uintptr_t>(gA) | reinterpret_cast<uintptr_t>(gT)) & 15);
+        if (v8) hipLaunchKernelGGL(k_block_adj_b16_bwd_T<8>, dim3(static_cast<unsigned>(ceil_div64(per_graph / 8, 256)), static_cast<unsigned>(B)), dim3(256), 0,
+                                   st, g, n, dd, static_cast<uint16_t*>(gT));
+        else hipLaunchKernelGGL(k_block_adj_b16_bwd_T<1>, dim3(static_cast<unsigned>(ceil_div64(per_graph, 256)), static_cast<unsigned>(B)), dim3(256), 0, st, g,
+                                n, dd, static_cast<uint16_t*>(gT));
+    }
+    if (g_identity) {
+        const int64_t pairs = 1LL * B * n;
+        const int slices = static_cast<int>(pairs < kIdentSlicesB16 ? (pairs > 0 ? pairs : 1) : kIdentSlicesB16);
+        hipLaunchKernelGGL(k_block_adj_b16_bwd_I, dim3(slices), dim3(256), 0, st, g, B, n, dd, workspace);
+        hipLaunchKernelGGL(k_sum_rows_b16, dim3(static_cast<unsigned>(ceil_div64(dd * dd, 256))), dim3(256), 0, st, workspace, slices, dd * dd,
+                           static_cast<uint16_t*>(g_identity));
+    }
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}

@@ -21,14 +21,33 @@ import torch
 from . import _lib
 
 
-def _req(*ts):
+def _req(*ts, dtype=torch.float32):
     for t in ts:
         if t is None:
             continue
         if not t.is_cuda:
             raise RuntimeError("recon_amd: expected a GPU tensor (this package has no CPU path)")
-        if t.is_floating_point() and t.dtype != torch.float32:
-            raise TypeError("recon_amd: the HIP kernels compute in float32, got %s" % t.dtype)
+        if t.is_floating_point() and t.dtype != dtype:
+            raise TypeError("recon_amd: this call runs the %s kernels, got a %s tensor" % (dtype, t.dtype))
+
+
+def _float_dtype(*ts):
+    """float32 or bfloat16: the one floating dtype of the call's tensors (the kernels exist for these two)."""
+    dts = {t.dtype for t in ts if t is not None and t.is_floating_point()}
+    if len(dts) != 1 or next(iter(dts)) not in (torch.float32, torch.bfloat16):
+        raise TypeError("recon_amd: the propagation kernels take float32 or bfloat16 tensors of ONE dtype, got %s" % sorted(map(str, dts)))
+    return next(iter(dts))
+
+
+_ZEROS = {}
+
+
+def _zeros_page(dev):
+    """1 KiB of zero bytes per device: what the K tails of the bf16 GEMMs read (include/recon_hip.h: recon_prop_b16_args.zeros)."""
+    z = _ZEROS.get(dev)
+    if z is None:
+        z = _ZEROS[dev] = torch.zeros(1024, dtype=torch.uint8, device=dev)
+    return z
 
 
 # ------------------------------------------------------------------------------- host-side index builders
@@ -102,10 +121,49 @@ class _BlockAdjacency(torch.autograd.Function):
         return gT, gI, None
 
 
+class _BlockAdjacencyB16(torch.autograd.Function):
+    """P1 on bfloat16 tensors (csrc/prop_b16.hip)."""
+
+    @staticmethod
+    def forward(ctx, T, identity, n):
+        _req(T, identity, dtype=torch.bfloat16)
+        T, identity = T.contiguous(), identity.contiguous()
+        B = T.shape[0]
+        dd = identity.shape[0]
+        if T.numel() != B * n * (n - 1) * dd * dd:
+            raise ValueError("T must hold B x n(n-1) transition matrices of %dx%d" % (dd, dd))
+        A = torch.empty(B, n * dd, n * dd, dtype=torch.bfloat16, device=T.device)
+        with _lib.on_device(T.device):
+            for b0 in range(0, B, _MAX_BATCH):
+                nb = min(B, b0 + _MAX_BATCH) - b0
+                _lib.check(_lib.lib().recon_block_adjacency_b16_fwd(T[b0:].data_ptr(), identity.data_ptr(), nb, n, dd, A[b0:].data_ptr(),
+                                                                    _lib.current_stream()), "recon_block_adjacency_b16_fwd")
+        ctx.dims = (B, n, dd, tuple(T.shape))
+        return A
+
+    @staticmethod
+    def backward(ctx, gA):
+        B, n, dd, tshape = ctx.dims
+        gA = gA.contiguous()
+        if B > _MAX_BATCH:
+            raise NotImplementedError("bfloat16 block adjacency backward: more than %d graphs per call" % _MAX_BATCH)
+        gT = torch.empty(tshape, dtype=torch.bfloat16, device=gA.device) if ctx.needs_input_grad[0] else None
+        gI = torch.empty(dd, dd, dtype=torch.bfloat16, device=gA.device) if ctx.needs_input_grad[1] else None
+        L = _lib.lib()
+        ws = (torch.empty(L.recon_block_adjacency_b16_bwd_workspace_floats(dd), dtype=torch.float32, device=gA.device)
+              if gI is not None else None)
+        with _lib.on_device(gA.device):
+            _lib.check(L.recon_block_adjacency_b16_bwd(gA.data_ptr(), B, n, dd, _lib.ptr(gT), _lib.ptr(gI), _lib.ptr(ws),
+                                                       _lib.current_stream()), "recon_block_adjacency_b16_bwd")
+        return gT, gI, None
+
+
 def build_block_adjacency(T, identity, n):
     """models/models.py:240-259: T [B, n-1, n, (2d)^2] or [B, n(n-1), (2d)^2] (AFTER the non-linearity),
     identity [2d,2d] -> A [B, S, S], A[b, i*2d+r, j*2d+c] = T[b, e(i,j)].view(2d,2d)[r,c], identity on the
-    diagonal blocks."""
+    diagonal blocks.  float32 or bfloat16 (both tensors alike)."""
+    if _float_dtype(T, identity) == torch.bfloat16:
+        return _BlockAdjacencyB16.apply(T, identity, n)
     return _BlockAdjacency.apply(T, identity, n)
 
 
@@ -197,6 +255,85 @@ class _Propagate(torch.autograd.Function):
         return (g_h0, None, None, None) + tuple(g.view(sh) if g is not None else None for g, sh in zip(g_adjs, adj_shapes))
 
 
+def _b16_args(B, Cn, S, L, dd, act, adjs, h0c, h0_bs, head, tail, idx_bs, out, hs, trans=None, identity=None):
+    return _lib.PropB16Args(B, Cn, S, L, dd, _lib.ACT[act], _ptr_array(adjs) if adjs is not None else None, h0c.data_ptr(), h0_bs,
+                            head.data_ptr(), tail.data_ptr(), idx_bs, _lib.ptr(out), _lib.ptr(hs),
+                            _ptr_array(trans) if trans is not None else None, _lib.ptr(identity), _zeros_page(h0c.device).data_ptr())
+
+
+_KEEP_STATES = False        # tests: keep the states the last bfloat16 forward saved (the backward's ReLU mask is theirs)
+_LAST_STATES = None
+
+
+class _PropagateB16(torch.autograd.Function):
+    """models/models.py:260-274 on bfloat16 tensors (csrc/prop_b16.hip): bf16 storage, fp32 accumulation, every state rounded to bf16 once
+    per hop, gradients in bf16."""
+
+    @staticmethod
+    def forward(ctx, h0, act, head, tail, *adjs):
+        _req(h0, head, tail, *adjs, dtype=torch.bfloat16)
+        L = len(adjs)
+        adj_shapes = [tuple(a.shape) for a in adjs]
+        adjs = [a.contiguous().view(a.shape[0], a.shape[-2], a.shape[-1]) for a in adjs]
+        B, S = adjs[0].shape[0], adjs[0].shape[-1]
+        h0c = h0.contiguous()
+        if h0c.dim() == 4:
+            Cn, h0_bs = h0c.shape[1], h0c.shape[1] * S
+        else:
+            Cn, h0_bs = h0c.shape[0], 0
+        head, tail = head.contiguous(), tail.contiguous()
+        dd = head.shape[-1]
+        idx_bs = Cn * dd if head.dim() == 3 and head.shape[0] > 1 else 0
+        if head.dim() == 3 and head.shape[0] < B and head.shape[0] > 1:
+            raise ValueError("head/tail indices hold %d batch rows but the batch has %d" % (head.shape[0], B))
+        dev = h0.device
+        out = torch.empty(B, Cn, L * dd, dtype=torch.bfloat16, device=dev)
+        need = any(ctx.needs_input_grad)
+        args = _b16_args(B, Cn, S, L, dd, act, adjs, h0c, h0_bs, head, tail, idx_bs, out, None)
+        form = _lib.lib().recon_propagate_b16_form(C.byref(args))
+        hs = torch.empty(L, B, Cn, S, dtype=torch.bfloat16, device=dev) if (need or form == 2) else None
+        args.h_saved = _lib.ptr(hs)
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().recon_propagate_b16_fwd(C.byref(args), _lib.current_stream()), "recon_propagate_b16_fwd")
+        if need:
+            ctx.save_for_backward(h0c, head, tail, hs, *adjs)
+            ctx.meta = (B, Cn, S, L, dd, act, h0_bs, idx_bs, tuple(h0.shape), adj_shapes)
+            if _KEEP_STATES:
+                global _LAST_STATES
+                _LAST_STATES = hs
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        h0c, head, tail, hs, *adjs = ctx.saved_tensors
+        B, Cn, S, L, dd, act, h0_bs, idx_bs, h0_shape, adj_shapes = ctx.meta
+        dev = gout.device
+        gout = gout.contiguous()
+        g_adjs = [torch.empty(B, S, S, dtype=torch.bfloat16, device=dev) if ctx.needs_input_grad[4 + l] else None for l in range(L)]
+        g_h = torch.empty(B, Cn, S, dtype=torch.bfloat16, device=dev)
+        ws = torch.empty(B, Cn, S, dtype=torch.bfloat16, device=dev)
+        fwd = _b16_args(B, Cn, S, L, dd, act, adjs, h0c, h0_bs, head, tail, idx_bs, gout, hs)     # `out` is unused by the backward
+        args = _lib.PropB16BwdArgs(fwd, gout.data_ptr(), _ptr_array(g_adjs), g_h.data_ptr(), ws.data_ptr())
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().recon_propagate_b16_bwd(C.byref(args), _lib.current_stream()), "recon_propagate_b16_bwd")
+        g_h0 = None
+        if ctx.needs_input_grad[0]:
+            g_h0 = (g_h if h0_bs else g_h.sum(0, dtype=torch.float32).to(torch.bfloat16)).view(h0_shape)
+        return (g_h0, None, None, None) + tuple(g.view(sh) if g is not None else None for g, sh in zip(g_adjs, adj_shapes))
+
+
+def _propagate_b16(adj_list, h0, nonlinearity, head_indices, tail_indices):
+    B, S = adj_list[0].shape[0], adj_list[0].shape[-1]
+    Cn = h0.shape[1] if h0.dim() == 4 else h0.shape[0]
+    probe = _lib.PropB16Args(B, Cn, S, len(adj_list), head_indices.shape[-1], 1, None, None, 0, None, None, 0, None, None, None, None, None)
+    aligned = all(a.data_ptr() % 16 == 0 for a in adj_list) and h0.data_ptr() % 16 == 0
+    if not aligned or _lib.lib().recon_propagate_b16_form(C.byref(probe)) == 0:
+        # shapes the bf16 kernels do not take (S % 8 != 0): bf16 storage around the float32 kernels
+        out = _Propagate.apply(h0.float(), nonlinearity, head_indices, tail_indices, *[a.float() for a in adj_list])
+        return out.to(torch.bfloat16)
+    return _PropagateB16.apply(h0, nonlinearity, head_indices, tail_indices, *adj_list)
+
+
 def propagate(adj_list, h0, nonlinearity, head_indices, tail_indices):
     """models/models.py:260-274.  adj_list: L tensors [B,S,S] (or [B,1,S,S] as the reference views them);
     h0 [C,S,1] shared (GPGNN) or [B,C,S,1] per batch (RECON*); nonlinearity 'relu' | 'tanh' | 'linear'
@@ -205,6 +342,7 @@ def propagate(adj_list, h0, nonlinearity, head_indices, tail_indices):
     if nonlinearity not in _lib.ACT:
         raise NotImplementedError(nonlinearity)
     B = adj_list[0].shape[0] if adj_list else 0
+    one = _propagate_b16 if _float_dtype(h0, *adj_list) == torch.bfloat16 else (lambda adjs, h, act, hi, ti: _Propagate.apply(h, act, hi, ti, *adjs))
     if B > _MAX_BATCH:                    # the kernels index graphs with a 16-bit grid dimension; graphs are independent: run slices
         outs = []
         for b0 in range(0, B, _MAX_BATCH):
@@ -212,9 +350,9 @@ def propagate(adj_list, h0, nonlinearity, head_indices, tail_indices):
             hs = h0[sl] if h0.dim() == 4 else h0
             hi = head_indices[sl] if head_indices.dim() == 3 and head_indices.shape[0] == B else head_indices
             ti = tail_indices[sl] if tail_indices.dim() == 3 and tail_indices.shape[0] == B else tail_indices
-            outs.append(_Propagate.apply(hs, nonlinearity, hi, ti, *[a[sl] for a in adj_list]))
+            outs.append(one([a[sl] for a in adj_list], hs, nonlinearity, hi, ti))
         return torch.cat(outs, dim=0)
-    return _Propagate.apply(h0, nonlinearity, head_indices, tail_indices, *adj_list)
+    return one(adj_list, h0, nonlinearity, head_indices, tail_indices)
 
 
 class _PropagateBlocks(torch.autograd.Function):
@@ -288,6 +426,32 @@ def blocks_mode_available(B, n, dd, h0, need_grad=True):
     return form == 3 or (form == 1 and not need_grad)
 
 
+def _blocks_b16_available(B, n, dd, h0, T_list, identity):
+    if dd != 16 or n < 2 or n > 10 or B > _MAX_BATCH or B == 0 or os.environ.get("RECON_PROP_BLOCKS", "1") == "0":
+        return False
+    if h0.data_ptr() % 16 or identity.data_ptr() % 16 or any(T.data_ptr() % 16 or not T.is_contiguous() for T in T_list):
+        return False
+    probe = _lib.PropB16Args(B, n * (n - 1), n * dd, len(T_list), dd, 1, None, None, 0, None, None, 0, None, None, None, None, None)
+    return _lib.lib().recon_propagate_b16_form(C.byref(probe)) == 1
+
+
+def _propagate_blocks_b16(T_list, identity, n, h0, act, head, tail):
+    """Inference: block adjacency + propagation in one launch on bfloat16 tensors; A_l is never written."""
+    _req(h0, identity, head, tail, *T_list, dtype=torch.bfloat16)
+    L, dd, B = len(T_list), identity.shape[0], T_list[0].shape[0]
+    S, Cn = n * dd, n * (n - 1)
+    Ts = [t.contiguous().view(B, Cn, dd * dd) for t in T_list]
+    identity, h0c = identity.contiguous(), h0.contiguous()
+    h0_bs = Cn * S if h0c.dim() == 4 else 0
+    head, tail = head.contiguous(), tail.contiguous()
+    idx_bs = Cn * dd if head.dim() == 3 and head.shape[0] > 1 else 0
+    out = torch.empty(B, Cn, L * dd, dtype=torch.bfloat16, device=h0.device)
+    args = _b16_args(B, Cn, S, L, dd, act, None, h0c, h0_bs, head, tail, idx_bs, out, None, trans=Ts, identity=identity)
+    with _lib.on_device(h0.device):
+        _lib.check(_lib.lib().recon_propagate_b16_fwd(C.byref(args), _lib.current_stream()), "recon_propagate_b16_fwd (block mode)")
+    return out
+
+
 def propagate_blocks(T_list, identity, n, h0, nonlinearity, head_indices, tail_indices):
     """models/models.py:240-274 in one call: T_list = L transition tensors [B, n(n-1), (2d)^2] (or [B, n-1, n, (2d)^2]) AFTER their
     non-linearity, identity [2d, 2d]; equivalent to
@@ -297,6 +461,12 @@ def propagate_blocks(T_list, identity, n, h0, nonlinearity, head_indices, tail_i
         raise NotImplementedError(nonlinearity)
     B, dd = T_list[0].shape[0], identity.shape[0]
     need_grad = torch.is_grad_enabled() and (identity.requires_grad or h0.requires_grad or any(T.requires_grad for T in T_list))
+    if _float_dtype(h0, identity, *T_list) == torch.bfloat16:
+        # bfloat16: inference on small states reads the transition tensors in place (csrc/prop_b16.hip, block mode); training and wide
+        # states go through the materialised bf16 adjacency (both backward products are batched GEMMs over it)
+        if not need_grad and _blocks_b16_available(B, n, dd, h0, T_list, identity):
+            return _propagate_blocks_b16(T_list, identity, n, h0, nonlinearity, head_indices, tail_indices)
+        return propagate([build_block_adjacency(T, identity, n) for T in T_list], h0, nonlinearity, head_indices, tail_indices)
     if not blocks_mode_available(B, n, dd, h0, need_grad):
         return propagate([build_block_adjacency(T, identity, n) for T in T_list], h0, nonlinearity, head_indices, tail_indices)
     return _PropagateBlocks.apply(h0, identity, nonlinearity, head_indices, tail_indices, n, *T_list)

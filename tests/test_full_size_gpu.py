@@ -273,3 +273,50 @@ def test_cfg5_bf16_stack_gradients_layer_by_layer():
     assert xd.grad.dtype == torch.bfloat16 and eed.grad.dtype == torch.bfloat16
     close(xd.grad.float(), g_x.float(), atol=1e-5, rel_to_max=2.0 ** -8, what="cfg5 g_x (bf16 out)")          # one rounding to bf16
     close(eed.grad.float(), g_ee.float(), atol=1e-5, rel_to_max=2.0 ** -8, what="cfg5 g_edge_embed (bf16 out)")
+
+
+# ------------------------------------------------------------------------------- cfg 3b in bf16 at B = 1 024 (BASELINE.json configs[2])
+@pytest.mark.parametrize("n,copies_of", [(9, 512), (32, 8)])
+def test_cfg3b_bf16_full_batch_forward_and_all_gradients(n, copies_of):
+    """BASELINE.json configs[2] "GP-GNN Propagation 3 hops, batch 1024 graphs, 32 nodes ... bf16" (and the reference's own n = 9): block
+    adjacency + three hops + every gradient on bf16 tensors at B = 1 024.  The batch is 1 024 / copies_of copies of `copies_of` graphs:
+    (i) the first graphs against the fp32 oracle on the same bf16 operands, states rounded hop by hop, gradients from the forward's own
+    states (tests/test_prop_b16_gpu.py has the method), (ii) every copy bit-equal to the first (graphs are independent, the kernels
+    deterministic)."""
+    from recon_amd import propagation as P
+    d_ = dev()
+    d, L, B, act = 8, 3, 1024, "relu"
+    C, S, dd = n * (n - 1), 16 * n, 16
+    Ts, ident, h0, head, tail, Gr = _prop_problem(n, d, L, copies_of, seed=21, scale=1.2 / S ** 0.5)
+    reps = B // copies_of
+    Tb = [_bf(t).to(d_).repeat(reps, 1, 1).requires_grad_(True) for t in Ts]
+    Ib = _bf(ident).to(d_).requires_grad_(True)
+    hb = _bf(h0).to(d_).repeat(reps, 1, 1, 1).requires_grad_(True)
+    Gb = _bf(Gr).to(d_).repeat(reps, 1, 1)
+    P._KEEP_STATES, P._LAST_STATES = True, None
+    try:
+        adjs = [P.build_block_adjacency(t, Ib, n) for t in Tb]
+        for a in adjs:
+            a.retain_grad()
+        out = P.propagate(adjs, hb, act, head.to(d_), tail.to(d_))
+        states = P._LAST_STATES
+    finally:
+        P._KEEP_STATES, P._LAST_STATES = False, None
+    assert out.shape == (B, C, dd * L) and out.dtype == torch.bfloat16
+    (out.float() * Gb.float()).sum().backward()
+    k = 2                                                             # graphs checked against the oracle
+    adj_r = [O.build_block_adjacency(_bf(t[:k]).float(), _bf(ident).float(), n) for t in Ts]
+    h0_r = _bf(h0[:k]).float()
+    ref = O.propagate(adj_r, h0_r, act, head, tail, as_gemm=True, storage=torch.bfloat16)
+    close(out[:k].float(), ref, atol=1e-3, rel_to_max=1.5e-2, what="cfg3b bf16 n=%d out" % n)
+    g_adj_r, g_h_r = O.propagate_backward(adj_r, h0_r, [s[:k].float().cpu() for s in states], act, head, tail, _bf(Gr[:k]).float(), storage=torch.bfloat16)
+    for l in range(L):
+        close(adjs[l].grad[:k].float(), g_adj_r[l], atol=1e-3, rel_to_max=2e-2, what="cfg3b bf16 n=%d g_adj[%d]" % (n, l))
+        blocks = adjs[l].grad[:k].float().cpu().reshape(k, n, dd, n, dd).permute(0, 1, 3, 2, 4)
+        off = torch.stack([blocks[:, i, j] for i in range(n) for j in range(n) if i != j], 1).reshape(k, C, dd * dd)
+        assert torch.equal(Tb[l].grad[:k].float().cpu(), off), "d T is the off-diagonal blocks of d A"
+    close(hb.grad[:k].float().reshape(g_h_r.shape), g_h_r, atol=1e-3, rel_to_max=2e-2, what="cfg3b bf16 n=%d g_h0" % n)
+    assert torch.isfinite(Ib.grad.float()).all()
+    for t in [out, hb.grad] + [a.grad for a in adjs]:
+        v = t.view(reps, copies_of, -1)
+        assert torch.equal(v[1], v[0]) and torch.equal(v[reps - 1], v[0]), "copies of the same graphs differ"

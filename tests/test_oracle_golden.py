@@ -171,6 +171,32 @@ def test_block_adjacency_and_propagation(name, as_gemm):
     np.testing.assert_array_equal(O.make_start_embedding(n, d).astype(np.float32), g["h0_shared"])
 
 
+@pytest.mark.parametrize("act,per_batch", [("relu", True), ("tanh", False), ("linear", True)])
+def test_propagate_backward_formulas_match_autograd(act, per_batch):
+    """oracle.propagate_backward (the closed form the bf16 kernels are checked against, evaluated from given states) equals autograd
+    of the pinned oracle.propagate in float64, arbitrary gather indices (duplicates included); with storage=bfloat16 the forward's
+    states are bf16 values and a float32 re-run from them reproduces the outputs."""
+    g = torch.Generator().manual_seed(5)
+    B, C, S, dd, L = 3, 7, 24, 6, 3
+    adjs = [((torch.rand(B, S, S, generator=g, dtype=torch.float64) - 0.45) * 0.5).requires_grad_(True) for _ in range(L)]
+    h0 = (torch.randn(B, C, S, 1, generator=g, dtype=torch.float64) if per_batch else torch.randn(C, S, 1, generator=g, dtype=torch.float64)).requires_grad_(True)
+    head, tail = torch.randint(0, S, (C, dd), generator=g), torch.randint(0, S, (C, dd), generator=g)
+    Gr = torch.randn(B, C, L * dd, generator=g, dtype=torch.float64)
+    out, states = O.propagate(adjs, h0, act, head, tail, as_gemm=True, return_states=True)
+    (out * Gr).sum().backward()
+    g_adj, g_h = O.propagate_backward([a.detach() for a in adjs], h0.detach(), [s_.detach() for s_ in states], act, head, tail, Gr)
+    for l in range(L):
+        np.testing.assert_allclose(g_adj[l].numpy(), adjs[l].grad.numpy(), atol=1e-12)
+    np.testing.assert_allclose((g_h if per_batch else g_h.sum(0)).numpy(), h0.grad.squeeze(-1).numpy(), atol=1e-12)
+    # storage rounding: states are exactly representable in bf16, outputs too
+    out_b, st_b = O.propagate([a.detach().float() for a in adjs], h0.detach().float(), act, head, tail, as_gemm=True, storage=torch.bfloat16,
+                              return_states=True)
+    for s_ in st_b:
+        assert torch.equal(s_.to(torch.bfloat16).float(), s_)
+    assert torch.equal(out_b.to(torch.bfloat16).float(), out_b)
+    np.testing.assert_allclose(out_b.numpy(), out.detach().numpy(), atol=0.05 * out.detach().abs().max().item())
+
+
 def test_start_entity_embeddings():
     g = load_golden("prop3_start_entity")
     out = O.make_start_entity_embeddings(T(g["entity_embeddings"]), T(g["pos"]), int(g["d"]), T(g["template"]),

@@ -105,6 +105,58 @@ def propagation(n, B=1024, d=8, L=3, iters=10, with_backward=True):
     return res
 
 
+def propagation_bf16(n, B=1024, d=8, L=3, iters=10, with_backward=True):
+    """cfg 3b in bfloat16 (BASELINE.json configs[2] as stated): the same step on bf16 tensors — bf16 storage, fp32 accumulation, one MFMA per
+    product (csrc/prop_b16.hip).  Bytes: SURVEY 8d's formula at s = 2: 2 (L B S^2 + B C S + B C 2d L); flops 2 B S^2 C L."""
+    from recon_amd.propagation import (build_block_adjacency, propagate, propagate_blocks, make_start_embedding, get_head_indices, get_tail_indices)
+    dv = torch.device("cuda:0")
+    bf = torch.bfloat16
+    C, S, dd = n * (n - 1), 2 * d * n, 2 * d
+    g = torch.Generator().manual_seed(0)
+    small = 8
+    reps = B // small if n > 16 else 1
+    Bh = small if n > 16 else B
+    Ts = [(torch.relu(torch.randn(Bh, C, dd * dd, generator=g)) * (0.1 if n <= 16 else 0.02)).to(bf).to(dv).repeat(reps, 1, 1).requires_grad_(True)
+          for _ in range(L)]
+    ident = torch.eye(dd, device=dv, dtype=bf, requires_grad=True)
+    tmpl = torch.from_numpy(make_start_embedding(n, d)).float()
+    h0 = (torch.randn(Bh, C, S, 1, generator=g) * tmpl).to(bf).to(dv).repeat(reps, 1, 1, 1).requires_grad_(True)
+    head = torch.from_numpy(get_head_indices(n, d, bs=1)[0]).to(dv)
+    tail = torch.from_numpy(get_tail_indices(n, d, bs=1)[0]).to(dv)
+    G = torch.randn(Bh, C, dd * L, generator=g).to(bf).to(dv).repeat(reps, 1, 1)
+    with torch.no_grad():
+        adjs = [build_block_adjacency(t, ident, n) for t in Ts]
+
+    def fwd():
+        with torch.no_grad():
+            propagate(adjs, h0.detach(), "relu", head, tail)
+
+    def fwd_blocks():
+        with torch.no_grad():
+            propagate_blocks(Ts, ident, n, h0, "relu", head, tail)
+
+    def fwd_bwd():
+        for t in Ts + [ident, h0]:
+            t.grad = None
+        propagate_blocks(Ts, ident, n, h0, "relu", head, tail).backward(G)
+    nbytes = 2.0 * (L * B * S * S + B * C * S + B * C * dd * L)
+    flops = 2.0 * B * S * S * C * L
+    tf = _time(fwd, iters)
+    res = {"B": B, "n": n, "S": S, "C": C, "L": L, "dtype": "bf16", "fwd_ms": tf * 1e3, "bytes": nbytes, "flops": flops,
+           "GBps": nbytes / tf / 1e9, "TFLOPs": flops / tf / 1e12}
+    if S <= 160:
+        res.update(bound="hbm", frac=nbytes / tf / HBM_PEAK, kernel="k_prop_b16_fwd")
+    else:
+        res.update(bound="mfma", peak_tflops=MFMA_F16_PEAK / 1e12, frac=flops / tf / MFMA_F16_PEAK, kernel="k_bgemm_b16 x L + k_prop_b16_gather",
+                   hbm_frac=nbytes / tf / HBM_PEAK)
+    res["fwd_from_transition_tensors_ms"] = _time(fwd_blocks, iters) * 1e3
+    if with_backward:
+        res["fwd_bwd_incl_adjacency_ms"] = _time(fwd_bwd, max(2, iters // 2)) * 1e3
+    del Ts, adjs, h0, G
+    torch.cuda.empty_cache()
+    return res
+
+
 def gcn_bf16(B=1024, n=32, D=300, hops=3, iters=10):
     """cfg 3a: GraphConvolution x 3 (models/layers.py:57-63) in bf16 storage / fp32 accumulation.  Bytes (unfused, s = 2):
     per hop 2 B n D s + B n^2 s + D^2 s; flops per hop 2 B n D (D + n)."""
@@ -194,6 +246,8 @@ def all_secondary(fast=True):
     it = 6 if fast else 20
     return {"cfg3b_n9_propagation": propagation(9, iters=it),
             "cfg3b_n32_propagation": propagation(32, iters=2),
+            "cfg3b_n9_bf16": propagation_bf16(9, iters=it),
+            "cfg3b_n32_bf16": propagation_bf16(32, iters=2),
             "cfg3a_gcn_bf16": gcn_bf16(iters=it),
             "cfg5_powerlaw_spgat": powerlaw_spgat(iters=it)}
 
