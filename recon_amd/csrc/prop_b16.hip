@@ -16,6 +16,7 @@
 //   k_block_adj_b16_*               P1 in bf16 (models/models.py:240-259)
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "prop_common.h"
 #include "prop_h_util.h"
 
@@ -47,6 +48,17 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == RECON_ACT_RELU) return fmaxf(v, 0.f);
     if (act == RECON_ACT_TANH) return tanh_fast(v);
     return v;
+}
+
+// COMPILER HAZARD (hipcc, ROCm 7.2, gfx950): the wait states between an MFMA and the first read of its result are inserted by the compiler
+// and counted along the FALL-THROUGH path only: with the accumulators in AGPRs (one accumulator tile per wave) and a uniform branch between
+// the last MFMA and v_accvgpr_read — taken in inference, where the saved-state address arithmetic is skipped — the read came two
+// instructions behind the MFMA and returned rows 2, 3 of the tile before they were written (block mode, n = 4, tanh: wrong values in
+// exactly the columns t % 4 >= 2).  Every accumulator read-out below is preceded by an unconditional gap longer than the MFMA.
+__device__ __forceinline__ void mfma_drain() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // ================================================================================================ small states: fused forward
@@ -160,6 +172,8 @@ __global__ void __launch_bounds__(128 * NKS) k_prop_b16_fwd(const PropB16K p) {
             const int nb = more_hops ? b : b + static_cast<int>(gridDim.x);
             const bool pre = nb < p.B;
             const auto rs_n = rsrc_a(more_hops ? l + 1 : 0, pre ? nb : b);
+            const auto rs_hs = __builtin_amdgcn_make_buffer_rsrc(
+                p.hsave ? p.hsave + ((static_cast<int64_t>(l) * p.B + b) * C) * S : p.out, 0, p.hsave ? C * S * 2 : 0, 0x00020000);
             f32x4 acc[NTC];
 #pragma unroll
             for (int j = 0; j < NTC; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -180,18 +194,25 @@ __global__ void __launch_bounds__(128 * NKS) k_prop_b16_fwd(const PropB16K p) {
                 raw[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_n, pre ? a_off(ks) : kOOB, 0, 0);
                 __builtin_amdgcn_sched_barrier(0x078f);                // everything but VMEM may move across: the requests stay where they are written
             }
-            // ---- epilogue: activation, bf16, into the other image and (training) the saved states
-            const auto rs_hs = __builtin_amdgcn_make_buffer_rsrc(
-                p.hsave ? p.hsave + ((static_cast<int64_t>(l) * p.B + b) * C) * S : p.out, 0, p.hsave ? C * S * 2 : 0, 0x00020000);
+            mfma_drain();
+            // ---- epilogue: activation, bf16, into the other image and (training) the saved states.  One straight-line copy per activation
+            // (a run-time `act` inside the element loop became four basic blocks per value)
+            auto epilogue = [&](auto act_c) {
+                constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-            for (int j = 0; j < NTC; ++j) {
-                const uint32_t w0 = pack_bf2(act_apply(acc[j][0], p.act), act_apply(acc[j][1], p.act));
-                const uint32_t w1 = pack_bf2(act_apply(acc[j][2], p.act), act_apply(acc[j][3], p.act));
-                *reinterpret_cast<uint2*>(Hn + so_w + 1024 * j) = make_uint2(w0, w1);
-                const int c = 16 * j + li;
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2{w0, w1}, rs_hs,
-                                                      (p.hsave && c < C) ? static_cast<uint32_t>(c * S + t0w) * 2u : kOOB, 0, 0);
-            }
+                for (int j = 0; j < NTC; ++j) {
+                    float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = ACT == RECON_ACT_RELU ? fmaxf(v[r], 0.f) : (ACT == RECON_ACT_TANH ? tanh_fast(v[r]) : v[r]);
+                    const uint32_t w0 = pack_bf2(v[0], v[1]), w1 = pack_bf2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(Hn + so_w + 1024 * j) = make_uint2(w0, w1);
+                    const int c = 16 * j + li;
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{w0, w1}, rs_hs, (p.hsave && c < C) ? static_cast<uint32_t>(c * S + t0w) * 2u : kOOB, 0, 0);
+                }
+            };
+            if (p.act == RECON_ACT_RELU) epilogue(std::integral_constant<int, RECON_ACT_RELU>{});
+            else if (p.act == RECON_ACT_TANH) epilogue(std::integral_constant<int, RECON_ACT_TANH>{});
+            else epilogue(std::integral_constant<int, RECON_ACT_LINEAR>{});
             lds_barrier();                                              // H^l complete; everybody has read H^l-1
             // ---- relation_l = gather(h, heads) * gather(h, tails)   (models/models.py:270-273)
             uint16_t* outb = p.out + (static_cast<int64_t>(b) * C * L + l) * p.dd;
@@ -233,6 +254,7 @@ struct BGemmB16 {
     uint16_t* C; int64_t c_bs; int32_t ldc;
     const uint16_t* zeros;
     int32_t M, N, K, batch, tiles_m, tiles_n, act;
+    int32_t ablate;             // timing experiments only (RECON_BGEMM_ABL): 1 copies read the zero page, 2 no copies, 4 no stores
 };
 __device__ __forceinline__ int kc_off(int row, int kq) { return row * 64 + (((kq + 2 * (row >> 3)) & 3) << 4); }
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lo_p, const unsigned char* hi_p) {
@@ -242,38 +264,48 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lo_p, const unsig
 }
 constexpr int km_slots(int rows) { int s = 8; while (s * 16 < rows) s *= 2; return s; }      // 32-byte column slots per k row (power of two, >= 8)
 
-template <bool PK, bool QK, int WM, int WN, int MT, int NT, int KSUB, bool ACT>
-__global__ void __launch_bounds__(64 * WM * WN) k_bgemm_b16(const BGemmB16 p) {
+// Persistent form.  A workgroup keeps ONE tile position (tm, tn) and walks graphs g = g0, g0 + gstride, ...: the copy plan (row / column
+// offsets inside a graph) is computed once, and the copy pipeline runs across tile boundaries — with K = 512 a tile is only 16 K steps,
+// and a pipeline that restarts per tile spends as long waiting for its first operands and draining its stores as it computes (first form
+// of this kernel: 128 x 128 tiles, one workgroup per tile, vmcnt(0) + __syncthreads per stage: 0.20 of the dense peak at n = 32).
+// NBUF LDS stages of one K step (32) each; at step s the wave waits until ITS copies of step s have landed (counted vmcnt: the copies of
+// the NBUF - 2 following steps stay in flight), passes a raw s_barrier (everybody's copies of step s are there, everybody is done reading
+// stage (s - 1) % NBUF), requests step s + NBUF - 1 into that stage, reads its fragments and issues the MFMAs.  Every wave issues exactly
+// ND copy instructions per step (missing pieces and steps past the end copy a page of zeros to a scratch KiB): s_waitcnt takes an
+// immediate.  After a tile's stores the next wait is vmcnt(0): loads and stores share the counter and complete out of order with respect
+// to each other.
+template <bool PK, bool QK, int WM, int WN, int MT, int NT, int NBUF, bool ACT>
+__global__ void __launch_bounds__(64 * WM * WN, (MT * NT >= 32 ? 2 : 3) * WM * WN / 4 > 0 ? (MT * NT >= 32 ? 2 : 3) : 1) k_bgemm_b16(const BGemmB16 p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     constexpr int NWV = WM * WN, BM = WM * MT * 16, BN = WN * NT * 16;
     constexpr int PS = km_slots(BN), QS = km_slots(BM);
     constexpr int P_BYTES = PK ? 32 * PS * 32 : BN * 64, Q_BYTES = QK ? 32 * QS * 32 : BM * 64;
-    constexpr int SUB = P_BYTES + Q_BYTES, STAGE = KSUB * SUB;
-    constexpr int NPP = P_BYTES / 1024, NPQ = Q_BYTES / 1024, NPS = NPP + NPQ, NP = KSUB * NPS, ND = (NP + NWV - 1) / NWV;
-    constexpr int BK = 32 * KSUB;
+    constexpr int STAGE = P_BYTES + Q_BYTES;
+    constexpr int NPP = P_BYTES / 1024, NPQ = Q_BYTES / 1024, NP = NPP + NPQ, ND = (NP + NWV - 1) / NWV;
+    constexpr int SCRATCH = NBUF * STAGE;                               // 1 KiB nobody reads
+    static_assert((NBUF - 2) * ND <= 63, "vmcnt field");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
-    // ---- (graph, tile) of this workgroup: XCD x = id & 7 owns graphs x, x + 8, ...
+    // ---- tile position and graph sequence of this workgroup: XCD x = id & 7 owns graphs x, x + 8, ...; its workgroups are `groups` sets
+    // of T tile positions, set q walking graphs x + 8 q, x + 8 (q + groups), ...: the tiles of one graph run side by side on one XCD
     const int T = p.tiles_m * p.tiles_n;
     const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
-    const int gslot = within / T, tile = within - gslot * T;
-    const int bb = gslot * 8 + xcd;
-    if (bb >= p.batch) return;
+    const int grp = within / T, tile = within - grp * T;
+    const int groups = (gridDim.x >> 3) / T;
+    const int g0 = xcd + 8 * grp, gstride = 8 * groups;
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const uint16_t* Pb = p.P + bb * p.p_bs;
-    const uint16_t* Qb = p.Q + bb * p.q_bs;
     const int wm = wid / WN, wn = wid - wm * WN;
+    const int KT = (p.K + 31) >> 5;
 
-    // ---- copy plan of this wave: piece pc = i NWV + wid of a stage; element offset d_a + (k0 + d_k) * stride of its operand
+    // ---- copy plan of this wave: piece pc = i NWV + wid of a stage; element offset d_a + (k0 + d_k) * stride inside the graph's operand
     int d_a[ND], d_k[ND];
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
         const int pc = min(i * NWV + wid, NP - 1);
-        const int sub = pc / NPS, r = pc - sub * NPS;
-        const bool isp = r < NPP;
-        const int pi = isp ? r : r - NPP;
+        const bool isp = pc < NPP;
+        const int pi = isp ? pc : pc - NPP;
         const int s = 64 * pi + lane;
         const bool kmaj = isp ? PK : QK;
         const int row0 = isp ? n0 : m0, rows = isp ? p.N : p.M, ld = isp ? p.ldp : p.ldq;
@@ -281,33 +313,42 @@ __global__ void __launch_bounds__(64 * WM * WN) k_bgemm_b16(const BGemmB16 p) {
             const int ns2 = 2 * (isp ? PS : QS);                        // 16-byte units per k row
             const int k = s / ns2, phys = s - k * ns2;
             const int t = (phys >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2));
-            d_k[i] = 32 * sub + k;
+            d_k[i] = k;
             d_a[i] = min(row0 + 16 * t + 8 * (phys & 1), ((rows + 7) & ~7) - 8);
         } else {
             const int rowL = s >> 2, kq = ((s & 3) - 2 * (rowL >> 3)) & 3;
-            d_k[i] = 32 * sub + 8 * kq;
+            d_k[i] = 8 * kq;
             d_a[i] = min(row0 + rowL, rows - 1) * ld;
         }
     }
     const uint16_t* zlane = p.zeros + 8 * lane;
-    auto dma = [&](int k0, int buf) {
-#pragma unroll
-        for (int i = 0; i < ND; ++i) {
-            const int pc = i * NWV + wid;                               // wave-uniform
-            if (pc < NP) {
-                const int sub = pc / NPS, r = pc - sub * NPS;
-                const bool isp = r < NPP;
-                const bool kmaj = isp ? PK : QK;
-                const int k = k0 + d_k[i];
-                const uint16_t* base = isp ? Pb : Qb;
-                const int64_t off = kmaj ? static_cast<int64_t>(k) * (isp ? p.ldp : p.ldq) + d_a[i] : static_cast<int64_t>(d_a[i]) + k;
-                const uint16_t* src = k < p.K ? base + off : zlane;
-                unsigned char* dst = sm + buf * STAGE + sub * SUB + (isp ? 0 : P_BYTES) + 1024 * (isp ? r : r - NPP);
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
-        }
+    // issue side of the pipeline: step (graph gi, K step ki) goes to stage ib
+    int gi = g0, ki = 0, ib = 0;
+    const uint16_t* Pi = p.P + g0 * p.p_bs;
+    const uint16_t* Qi = p.Q + g0 * p.q_bs;
+    auto issue_piece = [&](int i) {                                     // copy instruction i of this wave for step (gi, ki)
+        const bool live = gi < p.batch;
+        const int pc = i * NWV + wid;                                   // wave-uniform
+        const bool real = live && pc < NP;
+        const bool isp = pc < NPP;
+        const bool kmaj = isp ? PK : QK;
+        const int k = 32 * ki + d_k[i];
+        const uint16_t* base = isp ? Pi : Qi;
+        const int64_t off = kmaj ? static_cast<int64_t>(k) * (isp ? p.ldp : p.ldq) + d_a[i] : static_cast<int64_t>(d_a[i]) + k;
+        const uint16_t* src = (real && k < p.K && !(p.ablate & 1)) ? base + off : zlane;
+        unsigned char* dst = sm + (real ? ib * STAGE + 1024 * pc : SCRATCH);
+        if (!(p.ablate & 2)) __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
-    // ---- fragment addresses inside a sub-step's images
+    auto issue_advance = [&]() {
+        if (++ki == KT) { ki = 0; gi += gstride; Pi += gstride * p.p_bs; Qi += gstride * p.q_bs; }
+        ib = ib + 1 == NBUF ? 0 : ib + 1;
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) issue_piece(i);
+        issue_advance();
+    };
+    // ---- fragment addresses inside a stage
     int p_rd[NT], q_rd[MT];
     const int kk = 8 * lq + (li >> 2);                                  // k row of the first transposing read (+ 4 for the second)
     const int kx = (li >> 2) | ((lq & 1) << 2);                          // slot XOR of that row (the same for k + 4)
@@ -321,58 +362,96 @@ __global__ void __launch_bounds__(64 * WM * WN) k_bgemm_b16(const BGemmB16 p) {
         const int t = wm * MT + i;
         q_rd[i] = P_BYTES + (QK ? kk * (QS * 32) + ((t ^ kx) << 5) + ((li & 3) << 3) : kc_off(16 * t + li, lq));
     }
-    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < NBUF - 1; ++i) issue();
+    int cb = 0;
+    bool stores_pending = false;
+#pragma unroll 1
+    for (int g = g0; g < p.batch; g += gstride) {
+        f32x4 acc[MT][NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    dma(0, 0);
-    int buf = 0;
-    for (int k0 = 0; k0 < p.K; k0 += BK) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this stage's copies have landed ...
-        __syncthreads();                                              // ... everyone's, and nobody still reads the other buffer
-        if (k0 + BK < p.K) dma(k0 + BK, buf ^ 1);
-        const unsigned char* st = sm + buf * STAGE;
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int sub = 0; sub < KSUB; ++sub) {
-            const unsigned char* im = st + sub * SUB;
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int ks = 0; ks < KT; ++ks) {
+            if (stores_pending) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stores_pending = false; }
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * ND) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // fragments in the order of their use, the step's copy instructions (for step s + NBUF - 1: into the stage everybody has just
+            // left) spread behind the first rows of MFMAs: a wave that issued 12 reads + 4 copies and only then its 32 MFMAs left the
+            // matrix pipe idle for a third of the step (PMC: MFMA busy 33 %, waves parked 33 % — all waves of a workgroup are in the
+            // same phase at the same time)
+            const unsigned char* im = sm + cb * STAGE;
             bf16x8 pf[NT], qf[MT];
+            auto read_q = [&](int i) {
+                if constexpr (QK) qf[i] = tr_frag(im + q_rd[i], im + q_rd[i] + 4 * QS * 32);
+                else qf[i] = *reinterpret_cast<const bf16x8*>(im + q_rd[i]);
+            };
+            read_q(0);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 if constexpr (PK) pf[j] = tr_frag(im + p_rd[j], im + p_rd[j] + 4 * PS * 32);
                 else pf[j] = *reinterpret_cast<const bf16x8*>(im + p_rd[j]);
             }
+            if constexpr (MT > 1) read_q(1);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                if constexpr (QK) qf[i] = tr_frag(im + q_rd[i], im + q_rd[i] + 4 * QS * 32);
-                else qf[i] = *reinterpret_cast<const bf16x8*>(im + q_rd[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
+                if (i + 2 < MT) read_q(i + 2);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[i][j], 0, 0, 0);
-        }
-        buf ^= 1;
-    }
-    // ---- MFMA result: rows (4 lq + r) = n, column li = m
-    uint16_t* Cb = p.C + bb * p.c_bs;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int m = m0 + 16 * (wm * MT + i) + li;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = n0 + 16 * (wn * NT + j) + 4 * lq;
-            if (m < p.M && n < p.N) {                                   // N % 4 == 0: a lane's four columns exist together
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if constexpr (ACT) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act);
-                }
-                *reinterpret_cast<uint2*>(Cb + static_cast<int64_t>(m) * p.ldc + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                if (i < ND) issue_piece(i);
             }
+#pragma unroll
+            for (int i = MT; i < ND; ++i) issue_piece(i);
+            issue_advance();
+            // this wave's fragment reads are complete before it reaches the next barrier (the MFMAs have consumed them)
+            cb = cb + 1 == NBUF ? 0 : cb + 1;
         }
+        mfma_drain();
+        // ---- MFMA result: rows (4 lq + r) = n, column li = m.  One straight-line copy of the store loop per activation.
+        uint16_t* Cb = p.C + g * p.c_bs;
+        // Stores are ISSUE bound (one store instruction occupies the CU's store path for ~70 cycles whatever it carries): neighbouring
+        // column tiles exchange halves between lane rows (v_permlane16_swap) so that a lane holds EIGHT consecutive columns of one row —
+        // half as many instructions, 16 bytes each, 64-byte runs per row.
+        auto store_tile = [&](auto act_c) {
+            constexpr int A = decltype(act_c)::value;
+            auto fin = [&](const f32x4& a, uint32_t& w0, uint32_t& w1) {
+                float v[4] = {a[0], a[1], a[2], a[3]};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = A == RECON_ACT_RELU ? fmaxf(v[r], 0.f) : (A == RECON_ACT_TANH ? tanh_fast(v[r]) : v[r]);
+                w0 = pack_bf2(v[0], v[1]); w1 = pack_bf2(v[2], v[3]);
+            };
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = m0 + 16 * (wm * MT + i) + li;
+                uint16_t* crow = Cb + static_cast<int64_t>(m) * p.ldc;
+#pragma unroll
+                for (int j = 0; j + 1 < NT; j += 2) {
+                    uint32_t a0, a1, b0, b1;
+                    fin(acc[i][j], a0, a1);
+                    fin(acc[i][j + 1], b0, b1);
+                    const auto x0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                    const auto x1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                    const int n = n0 + 16 * (wn * NT + j + (lq & 1)) + 8 * (lq >> 1);
+                    if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(crow + n) = u32x4{x0[0], x1[0], x0[1], x1[1]};      // N % 8 == 0
+                }
+                if constexpr (NT & 1) {
+                    uint32_t a0, a1;
+                    fin(acc[i][NT - 1], a0, a1);
+                    const int n = n0 + 16 * (wn * NT + NT - 1) + 4 * lq;
+                    if (m < p.M && n < p.N) *reinterpret_cast<uint2*>(crow + n) = make_uint2(a0, a1);
+                }
+            }
+        };
+        if (p.ablate & 4) { asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[MT - 1][NT - 1][3])); }
+        else if (ACT && p.act == RECON_ACT_RELU) store_tile(std::integral_constant<int, RECON_ACT_RELU>{});
+        else if (ACT && p.act == RECON_ACT_TANH) store_tile(std::integral_constant<int, RECON_ACT_TANH>{});
+        else store_tile(std::integral_constant<int, RECON_ACT_LINEAR>{});
+        stores_pending = true;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the dummy copies of the last steps target this workgroup's LDS
 }
 
 // ================================================================================================ Y_l of the backward
@@ -495,8 +574,14 @@ __global__ void __launch_bounds__(256) k_block_adj_b16_bwd_I(const uint16_t* __r
 __global__ void __launch_bounds__(256) k_sum_rows_b16(const float* __restrict__ partial, int32_t nrows, int32_t O, uint16_t* __restrict__ out) {
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= O) return;
-    float s = 0.f;
-    for (int r = 0; r < nrows; ++r) s += partial[static_cast<int64_t>(r) * O + o];
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};              // eight loads in flight: one chain of 256 dependent round trips took 59 us
+    int r = 0;
+    for (; r + 8 <= nrows; r += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += partial[static_cast<int64_t>(r + u) * O + o];
+    }
+    for (; r < nrows; ++r) a[0] += partial[static_cast<int64_t>(r) * O + o];
+    const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     out[o] = static_cast<uint16_t>(pack_bf2(s, 0.f) & 0xffffu);
 }
 
@@ -551,32 +636,48 @@ int form_b16(const recon_prop_b16_args* a, bool check_ptrs) {
     return 2;
 }
 
-template <bool PK, bool QK, bool ACT>
-int launch_bgemm(const BGemmB16& g0, hipStream_t st) {
-    BGemmB16 g = g0;
-    const bool mid = g.M <= 144 && g.N <= 144;
-    if (mid) {
-        constexpr int WM = 3, WN = 3, MT = 3, NT = 3, KSUB = 1;
-        constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
-        constexpr size_t lds = 2ull * KSUB * ((PK ? 32 * km_slots(BN) * 32 : BN * 64) + (QK ? 32 * km_slots(BM) * 32 : BM * 64));
-        g.tiles_m = (g.M + BM - 1) / BM; g.tiles_n = (g.N + BN - 1) / BN;
-        const int64_t nblk = ceil_div64(g.batch, 8) * 8 * g.tiles_m * g.tiles_n;
-        auto kern = k_bgemm_b16<PK, QK, WM, WN, MT, NT, KSUB, ACT>;
+template <bool PK, bool QK, bool ACT, int WM, int WN, int MT, int NT, int NBUF>
+int launch_bgemm_cfg(BGemmB16 g, hipStream_t st) {
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+    constexpr size_t lds = static_cast<size_t>(NBUF) * ((PK ? 32 * km_slots(BN) * 32 : BN * 64) + (QK ? 32 * km_slots(BM) * 32 : BM * 64)) + 1024;
+    g.tiles_m = (g.M + BM - 1) / BM; g.tiles_n = (g.N + BN - 1) / BN;
+    { const char* ab = getenv("RECON_BGEMM_ABL"); g.ablate = ab ? atoi(ab) : 0; }
+    const int64_t T = static_cast<int64_t>(g.tiles_m) * g.tiles_n;
+    auto kern = k_bgemm_b16<PK, QK, WM, WN, MT, NT, NBUF, ACT>;
+    static int occ = 0;                                                 // per instantiation
+    if (occ == 0) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nblk)), dim3(64 * WM * WN), lds, st, g);
-    } else {
-        constexpr int WM = 2, WN = 2, MT = 4, NT = 4, KSUB = 2;
-        constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
-        constexpr size_t lds = 2ull * KSUB * ((PK ? 32 * km_slots(BN) * 32 : BN * 64) + (QK ? 32 * km_slots(BM) * 32 : BM * 64));
-        g.tiles_m = (g.M + BM - 1) / BM; g.tiles_n = (g.N + BN - 1) / BN;
-        const int64_t nblk = ceil_div64(g.batch, 8) * 8 * g.tiles_m * g.tiles_n;
-        if (nblk >= (1LL << 31)) return RECON_ERR_UNSUPPORTED;
-        auto kern = k_bgemm_b16<PK, QK, WM, WN, MT, NT, KSUB, ACT>;
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nblk)), dim3(64 * WM * WN), lds, st, g);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * WM * WN, lds) != hipSuccess || occ < 1) occ = 1;
     }
+    // resident capacity per XCD / tile positions = sets of tile positions per XCD; no more sets than graphs per XCD
+    const int64_t cap_xcd = static_cast<int64_t>(occ) * num_cus_b16() / 8;
+    int64_t groups = cap_xcd / T;
+    if (groups < 1) groups = 1;
+    const int64_t per_xcd = ceil_div64(g.batch, 8);
+    if (groups > per_xcd) groups = per_xcd;
+    const int64_t rounds = ceil_div64(per_xcd, groups);
+    groups = ceil_div64(per_xcd, rounds);                               // the same number of rounds with fewer idle sets
+    const int64_t nblk = 8 * groups * T;
+    if (nblk >= (1LL << 31)) return RECON_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nblk)), dim3(64 * WM * WN), lds, st, g);
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
+}
+
+template <bool PK, bool QK, bool ACT>
+int launch_bgemm(const BGemmB16& g, hipStream_t st) {
+    if (g.M <= 144 && g.N <= 144) return launch_bgemm_cfg<PK, QK, ACT, 3, 3, 3, 3, 3>(g, st);     // a whole graph of <= 9 nodes per workgroup
+    const char* cfg = getenv("RECON_BGEMM_CFG");                        // tile shape A/B (tools/b16_gemm_cfgs.py)
+    switch (cfg ? cfg[0] : 'c') {
+        case 'b': return launch_bgemm_cfg<PK, QK, ACT, 4, 2, 4, 4, 3>(g, st);      // 256 x 128, 8 waves
+        case 'c': return launch_bgemm_cfg<PK, QK, ACT, 2, 4, 8, 4, 3>(g, st);      // 256 x 256, 8 waves of 128 x 64
+        case 'd': return launch_bgemm_cfg<PK, QK, ACT, 2, 4, 4, 4, 3>(g, st);      // 128 x 256, 8 waves
+        case 'e': return launch_bgemm_cfg<PK, QK, ACT, 2, 2, 4, 4, 4>(g, st);      // 128 x 128, four stages
+        case 'f': return launch_bgemm_cfg<PK, QK, ACT, 2, 2, 8, 4, 3>(g, st);      // 256 x 128, 4 waves of 128 x 64: two workgroups per CU
+        case 'g': return launch_bgemm_cfg<PK, QK, ACT, 2, 2, 4, 8, 3>(g, st);      // 128 x 256, 4 waves of 64 x 128
+        case 'a': return launch_bgemm_cfg<PK, QK, ACT, 2, 2, 4, 4, 3>(g, st);      // 128 x 128, 4 waves
+        default: return launch_bgemm_cfg<PK, QK, ACT, 2, 4, 8, 4, 3>(g, st);
+    }
 }
 
 int fwd_fused(const recon_prop_b16_args* a, hipStream_t st) {
