@@ -35,6 +35,7 @@ struct PropB16K {
     const int64_t* head; const int64_t* tail; int64_t idx_bs;
     uint16_t* out; uint16_t* hsave;
     int32_t B, C, S, L, dd, act;
+    int32_t ablate;             // timing experiments only (RECON_PROP_B16_ABL): 1 = the A fragments are not fetched (zeros)
 };
 
 __device__ __forceinline__ float bf2f(uint32_t bits16) { return __builtin_bit_cast(float, bits16 << 16); }
@@ -233,6 +234,234 @@ __global__ void __launch_bounds__(128 * NKS) k_prop_b16_fwd(const PropB16K p) {
             cur ^= 1;
         }
         cur ^= 1;                                                       // the next graph's h^0 goes where nobody gathers from
+    }
+}
+
+// ================================================================================================ wide states: fused forward
+// 160 < S <= 512 (S % 32 == 0; n = 32: S = 512, C = 992).  The state of a graph no longer fits a CU, but channels never mix: a workgroup
+// owns (graph, 128 channels) for ALL hops, the chunk's state [NKS][128][64 B] (128 KiB at S = 512) resident in LDS and updated IN PLACE,
+// so that no state travels through HBM between hops (the batched-GEMM form writes and re-reads 1 GB per hop at B = 1024: it is bound by
+// that traffic, 2.5 GB per hop at ~5 TB/s, not by its 213 us of MFMA time).  Wave w of 8 owns RT row tiles of every A_l and fetches their
+// A fragments straight into registers two K steps ahead (the 8 chunks of a graph run on one XCD: its L2 serves 7 of the 8 reads of A_l);
+// one B fragment from LDS feeds RT MFMAs.  Per hop: K loop (fully unrolled: the compiler counts the outstanding requests only in
+// straight-line code), barrier, epilogue (activation, bf16, 16-byte LDS / saved-state writes after a lane-row exchange between
+// neighbouring row tiles), barrier, gather.  Block mode reads the transition tensors in place.
+template <int NKS, int RT, bool BLK>
+__global__ void __launch_bounds__(512, 2) k_prop_b16_fwd_wide(const PropB16K p, const int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    constexpr int NTC = 8, CH = 128, STEP = CH * 64, PD = 2, NG = 2;
+    static_assert(NKS % 2 == 0 && NKS >= PD, "the request ring is two steps deep");
+    const int S = p.S, C = p.C, L = p.L;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int gslot = within / nchunk, chunk = within - gslot * nchunk;
+    const int b = gslot * 8 + xcd;
+    if (b >= p.B) return;
+    const int c0 = chunk * CH, cn = min(CH, C - c0);
+    const uint32_t SSb = static_cast<uint32_t>(S) * S * 2;
+    const int nn = S >> 4;
+
+    auto rsrc_a = [&](int l) {
+        if constexpr (BLK)
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.trans[l] + static_cast<int64_t>(b) * C * 256), 0, C * 512, 0x00020000);
+        else
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.adj[l]) + static_cast<int64_t>(b) * SSb), 0,
+                                                     static_cast<int>(SSb), 0x00020000);
+    };
+    // A fragment of (row tile R = wave RT + r, K step ks): one lane offset per row tile, the K step in the instruction's scalar offset (the
+    // offsets of all 16 K steps, hoisted out of the hop loop, had cost 64 registers and spilled).  BLOCK MODE: columns 8 (lq & 1) .. of row li
+    // of trans[l][b, e(R, j)], j = 2 ks + (lq >> 1), e = R (nn - 1) + j - [j > R]; the diagonal block comes from `identity`.
+    const uint32_t voff_blk = static_cast<uint32_t>(li * 32 + (lq & 1) * 16);
+    uint32_t voff_r[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int R = wave * RT + r;
+        if constexpr (BLK) voff_r[r] = voff_blk + 512u * static_cast<uint32_t>(R * (nn - 1) + (lq >> 1));
+        else voff_r[r] = R < nn ? (static_cast<uint32_t>(16 * R + li) * S + 8 * lq) * 2u : kOOB;
+    }
+    auto load_a = [&](decltype(rsrc_a(0)) rs, int r, int ks, int lq_hi, bool live) -> u32x4 {
+        if constexpr (BLK) {
+            const int R = wave * RT + r, j = 2 * ks + lq_hi;
+            const bool valid = live && R < nn && j < nn && j != R;
+            // (the whole offset in the lane part: the range check looks at the lane offset alone, and R = 0 would make it negative)
+            return __builtin_amdgcn_raw_buffer_load_b128(rs, valid ? voff_r[r] + 1024u * ks - (j > R ? 512u : 0u) : kOOB, 0, 0);
+        } else {
+            return __builtin_amdgcn_raw_buffer_load_b128(rs, (live && !(p.ablate & 1)) ? voff_r[r] : kOOB, 64 * ks, 0);
+        }
+    };
+    u32x4 dpar[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};   // identity rows for row tiles of even / odd node index
+    if constexpr (BLK) {
+        const auto rs_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.identity), 0, 512, 0x00020000);
+        const u32x4 idv = __builtin_amdgcn_raw_buffer_load_b128(rs_i, voff_blk, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dpar[0][e] = (lq >> 1) == 0 ? idv[e] : 0u; dpar[1][e] = (lq >> 1) == 1 ? idv[e] : 0u; }
+    }
+    // ---- gather items of this chunk (pairs of neighbouring x), positions in the image
+    auto pos = [&](uint32_t c, uint32_t t) {
+        return (t >> 5) * STEP + 64u * c + (((((t >> 3) & 3u) ^ ((c >> 1) & 3u))) << 4) + 2u * (t & 7u);
+    };
+    const int Ldd = L * p.dd, npairs = (cn * p.dd) >> 1;
+    uint32_t* gtab = reinterpret_cast<uint32_t*>(sm + NKS * STEP);     // [NG][5][512]: the positions live in LDS, not in registers (the K loop needs them all)
+    {
+        const int64_t* hd = p.head + b * p.idx_bs + static_cast<int64_t>(c0) * p.dd;
+        const int64_t* tl = p.tail + b * p.idx_bs + static_cast<int64_t>(c0) * p.dd;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const uint32_t it = 2u * min(tid + i * 512, npairs - 1);
+            const uint32_t c = it / static_cast<uint32_t>(p.dd), x = it - c * p.dd;
+            uint32_t* g = gtab + i * 5 * 512 + tid;
+            g[0] = pos(c, static_cast<uint32_t>(hd[it])); g[512] = pos(c, static_cast<uint32_t>(hd[it + 1]));
+            g[1024] = pos(c, static_cast<uint32_t>(tl[it])); g[1536] = pos(c, static_cast<uint32_t>(tl[it + 1]));
+            g[2048] = c * Ldd + x;
+        }
+    }
+    // ---- h^0 of the chunk into the image
+    {
+        const uint16_t* h0b = p.h0 + b * p.h0_bs + static_cast<int64_t>(c0) * S;
+        const int s8 = S >> 3, npieces = cn * s8;
+        for (int q = tid; q < npieces; q += 512) {
+            const int c = q / s8, t = 8 * (q - c * s8);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(h0b + static_cast<int64_t>(c) * S + t);
+            *reinterpret_cast<u32x4*>(sm + (t >> 5) * STEP + 64 * c + ((((t >> 3) & 3) ^ ((c >> 1) & 3)) << 4)) = v;
+        }
+        const int zp = (CH - cn) * s8;                                  // channels past the chunk's last: zeros (their results are never stored)
+        for (int q = tid; q < zp; q += 512) {
+            const int c = cn + q / s8, t = 8 * (q % s8);
+            *reinterpret_cast<u32x4*>(sm + (t >> 5) * STEP + 64 * c + ((((t >> 3) & 3) ^ ((c >> 1) & 3)) << 4)) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    // ---- A fragments of the first PD steps of the first hop
+    u32x4 ar[PD][RT];
+    {
+        const auto rs = rsrc_a(0);
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) ar[d][r] = load_a(rs, r, d, lq >> 1, true);
+    }
+    const int swz = ((li >> 1) & 3) << 4;
+    const int b_rd = li * 64 + ((lq << 4) ^ swz);
+    lds_barrier();
+
+#pragma unroll 1
+    for (int l = 0; l < L; ++l) {
+        const auto rs_cur = rsrc_a(l);
+        const auto rs_nxt = rsrc_a(l + 1 < L ? l + 1 : l);
+        const bool more = l + 1 < L;
+        int lq_hi = lq >> 1;
+        asm volatile("" : "+v"(lq_hi));                                 // keeps the block-mode offset arithmetic inside the hop (not hoisted: registers)
+        if constexpr (BLK) {                                            // likewise the masked identity rows of all (row tile, K step) pairs
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t d0 = dpar[0][e], d1 = dpar[1][e];
+                asm volatile("" : "+v"(d0), "+v"(d1));
+                dpar[0][e] = d0; dpar[1][e] = d1;
+            }
+        }
+        f32x4 acc[RT][NTC];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int j = 0; j < NTC; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            bf16x8 a[RT];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                u32x4 av = ar[ks % PD][r];
+                if constexpr (BLK) {
+                    const int R = wave * RT + r;
+                    const bool dk = ks == (R >> 1);                     // wave-uniform
+                    const bool odd = R & 1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[e] |= dk ? (odd ? dpar[1][e] : dpar[0][e]) : 0u;
+                }
+                a[r] = __builtin_bit_cast(bf16x8, av);
+            }
+#pragma unroll
+            for (int j = 0; j < NTC; ++j) {
+                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(sm + ks * STEP + 1024 * j + b_rd);
+#pragma unroll
+                for (int r = 0; r < RT; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r], bf, acc[r][j], 0, 0, 0);
+            }
+            // the fragments of step ks + PD (of the next hop behind this hop's last steps) into the registers just consumed.  Measured and not
+            // kept: the state's fragments one step ahead in a second register set (pinned with sched_barrier: the scheduler otherwise sinks
+            // every LDS read to its use) — no change; requests in pairs of K steps four steps ahead (both halves of a 128-byte line back to
+            // back) — no change either.  Without the requests the kernel takes 1.39 ms at n = 32, with them 2.15.
+            if (ks + PD < NKS) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r) ar[ks % PD][r] = load_a(rs_cur, r, ks + PD, lq_hi, true);
+            } else {
+#pragma unroll
+                for (int r = 0; r < RT; ++r) ar[ks % PD][r] = load_a(rs_nxt, r, ks + PD - NKS, lq_hi, more);
+            }
+            __builtin_amdgcn_sched_barrier(0x078f);                    // everything but VMEM may move across
+        }
+        mfma_drain();
+        lds_barrier();                                                  // everybody has read H^l-1
+        // ---- epilogue: activation, bf16; row tiles r, r + 1 exchange halves between lane rows: a lane then holds 8 consecutive columns
+        // of one channel — 16-byte writes into the image and into the saved states
+        const auto rs_hs = __builtin_amdgcn_make_buffer_rsrc(
+            p.hsave ? p.hsave + ((static_cast<int64_t>(l) * p.B + b) * C + c0) * S : p.out, 0, p.hsave ? cn * S * 2 : 0, 0x00020000);
+        int li_e = li, lq_e = lq;                                       // laundered: the 32 write positions below are loop invariant, and hoisted
+        asm volatile("" : "+v"(li_e), "+v"(lq_e));                      // out of the hop loop they stay live through the K loop (spills)
+        auto epilogue = [&](auto act_c) {
+            constexpr int A = decltype(act_c)::value;
+            auto fin = [&](const f32x4& v4, uint32_t& w0, uint32_t& w1) {
+                float v[4] = {v4[0], v4[1], v4[2], v4[3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = A == RECON_ACT_RELU ? fmaxf(v[e], 0.f) : (A == RECON_ACT_TANH ? tanh_fast(v[e]) : v[e]);
+                w0 = pack_bf2(v[0], v[1]); w1 = pack_bf2(v[2], v[3]);
+            };
+            const int csw = ((li_e >> 1) & 3);
+#pragma unroll
+            for (int j = 0; j < NTC; ++j) {
+                const int c = 16 * j + li_e;
+#pragma unroll
+                for (int r = 0; r + 1 < RT; r += 2) {
+                    uint32_t a0, a1, b0, b1;
+                    fin(acc[r][j], a0, a1);
+                    fin(acc[r + 1][j], b0, b1);
+                    const auto x0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                    const auto x1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                    const int t = 16 * (wave * RT + r + (lq_e & 1)) + 8 * (lq_e >> 1);
+                    const u32x4 v = u32x4{x0[0], x1[0], x0[1], x1[1]};
+                    if (t < S) *reinterpret_cast<u32x4*>(sm + (t >> 5) * STEP + 64 * c + ((((t >> 3) & 3) ^ csw) << 4)) = v;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_hs, (p.hsave && c < cn && t < S) ? static_cast<uint32_t>(c * S + t) * 2u : kOOB, 0, 0);
+                }
+                if constexpr (RT & 1) {
+                    uint32_t a0, a1;
+                    fin(acc[RT - 1][j], a0, a1);
+                    const int t = 16 * (wave * RT + RT - 1) + 4 * lq_e;
+                    if (t < S) *reinterpret_cast<uint2*>(sm + (t >> 5) * STEP + 64 * c + ((((t >> 3) & 3) ^ csw) << 4) + 2 * (t & 7)) = make_uint2(a0, a1);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{a0, a1}, rs_hs, (p.hsave && c < cn && t < S) ? static_cast<uint32_t>(c * S + t) * 2u : kOOB, 0, 0);
+                }
+            }
+        };
+        if (p.act == RECON_ACT_RELU) epilogue(std::integral_constant<int, RECON_ACT_RELU>{});
+        else if (p.act == RECON_ACT_TANH) epilogue(std::integral_constant<int, RECON_ACT_TANH>{});
+        else epilogue(std::integral_constant<int, RECON_ACT_LINEAR>{});
+        lds_barrier();                                                  // H^l complete
+        // ---- relation_l = gather(h, heads) * gather(h, tails)   (models/models.py:270-273)
+        uint16_t* outb = p.out + ((static_cast<int64_t>(b) * C + c0) * L + l) * p.dd;
+        auto hv = [&](uint32_t q) { return bf2f(*reinterpret_cast<const uint16_t*>(sm + q)); };
+#pragma unroll
+        for (int i = 0; i < NG; ++i)
+            if (tid + i * 512 < npairs) {
+                const uint32_t* g = gtab + i * 5 * 512 + tid;
+                *reinterpret_cast<uint32_t*>(outb + g[2048]) = pack_bf2(hv(g[0]) * hv(g[1024]), hv(g[512]) * hv(g[1536]));
+            }
+        if (npairs > NG * 512) {
+            for (int pi = tid + NG * 512; pi < npairs; pi += 512) {
+                const uint32_t it = 2u * pi, c = it / static_cast<uint32_t>(p.dd), x = it - c * p.dd;
+                const int64_t io = b * p.idx_bs + static_cast<int64_t>(c0) * p.dd + it;
+                const float v0 = hv(pos(c, static_cast<uint32_t>(p.head[io]))) * hv(pos(c, static_cast<uint32_t>(p.tail[io])));
+                const float v1 = hv(pos(c, static_cast<uint32_t>(p.head[io + 1]))) * hv(pos(c, static_cast<uint32_t>(p.tail[io + 1])));
+                *reinterpret_cast<uint32_t*>(outb + c * Ldd + x) = pack_bf2(v0, v1);
+            }
+        }
     }
 }
 
@@ -631,6 +860,8 @@ int form_b16(const recon_prop_b16_args* a, bool check_ptrs) {
     const char* env = getenv("RECON_PROP_B16");                         // "g": the GEMM form everywhere (tests, A/B)
     const bool force_gemm = env && env[0] == 'g';
     if (!force_gemm && a->S % 16 == 0 && a->S <= 160 && a->C <= 96 && (a->dd % 2) == 0 && ((a->C * a->dd) & 1) == 0) return 1;
+    // wide states in LDS: S = 32 NKS, NKS even in 6 .. 16 (S % 64 == 0, 192 <= S <= 512), even dd; inference or training alike
+    if (!force_gemm && !(env && env[0] == 'n') && a->S % 64 == 0 && a->S >= 192 && a->S <= 512 && (a->dd % 2) == 0) return 3;
     if (blk) return 0;
     if (static_cast<int64_t>(a->C) * a->S >= (1LL << 31) || static_cast<int64_t>(a->S) * a->S >= (1LL << 31)) return 0;
     return 2;
@@ -722,6 +953,40 @@ int fwd_fused(const recon_prop_b16_args* a, hipStream_t st) {
     return RECON_OK;
 }
 
+int fwd_wide(const recon_prop_b16_args* a, hipStream_t st) {
+    PropB16K p{};
+    const bool blk = a->trans != nullptr;
+    for (int l = 0; l < kMaxHops; ++l) {
+        p.adj[l] = (l < a->L && !blk) ? static_cast<const uint16_t*>(a->adj[l]) : nullptr;
+        p.trans[l] = (l < a->L && blk) ? static_cast<const uint16_t*>(a->trans[l]) : nullptr;
+    }
+    p.identity = blk ? static_cast<const uint16_t*>(a->identity) : nullptr;
+    p.h0 = static_cast<const uint16_t*>(a->h0); p.h0_bs = a->h0_batch_stride;
+    p.head = a->head_idx; p.tail = a->tail_idx; p.idx_bs = a->idx_batch_stride;
+    p.out = static_cast<uint16_t*>(a->out); p.hsave = static_cast<uint16_t*>(a->h_saved);
+    p.B = a->B; p.C = a->C; p.S = a->S; p.L = a->L; p.dd = a->dd; p.act = a->act;
+    const int nks = a->S / 32, nchunk = (a->C + 127) / 128;
+    { const char* ab = getenv("RECON_PROP_B16_ABL"); p.ablate = ab ? atoi(ab) : 0; }
+    const size_t lds = static_cast<size_t>(nks) * 128 * 64 + 2 * 5 * 512 * sizeof(uint32_t);
+    const int64_t nblk = ceil_div64(a->B, 8) * 8 * nchunk;
+    if (nblk >= (1LL << 31)) return RECON_ERR_UNSUPPORTED;
+#define CALL_W(K_, R_, X_)                                                                                                              \
+    do {                                                                                                                                \
+        auto kern = k_prop_b16_fwd_wide<K_, R_, X_>;                                                                                    \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                       static_cast<int>(lds));                                                         \
+        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nblk)), dim3(512), lds, st, p, nchunk);                                     \
+    } while (0)
+#define CALL_WK(X_)                                                                                                                     \
+    switch (nks) { case 6: CALL_W(6, 2, X_); break; case 8: CALL_W(8, 2, X_); break; case 10: CALL_W(10, 3, X_); break; case 12: CALL_W(12, 3, X_); break; \
+                   case 14: CALL_W(14, 4, X_); break; case 16: CALL_W(16, 4, X_); break; default: return RECON_ERR_UNSUPPORTED; }
+    if (blk) { CALL_WK(true); } else { CALL_WK(false); }
+#undef CALL_WK
+#undef CALL_W
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+
 int fwd_gemm(const recon_prop_b16_args* a, hipStream_t st) {
     if (!a->h_saved || !a->zeros || !al16(a->zeros)) return RECON_ERR_INVALID;
     const int32_t B = a->B, C = a->C, S = a->S, L = a->L;
@@ -762,6 +1027,7 @@ extern "C" int recon_propagate_b16_fwd(const recon_prop_b16_args* a, recon_strea
     const int form = form_b16(a, true);
     if (form == 1) return fwd_fused(a, as_stream(stream));
     if (form == 2) return fwd_gemm(a, as_stream(stream));
+    if (form == 3) return fwd_wide(a, as_stream(stream));
     return RECON_ERR_UNSUPPORTED;
 }
 

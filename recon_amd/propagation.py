@@ -427,12 +427,12 @@ def blocks_mode_available(B, n, dd, h0, need_grad=True):
 
 
 def _blocks_b16_available(B, n, dd, h0, T_list, identity):
-    if dd != 16 or n < 2 or n > 10 or B > _MAX_BATCH or B == 0 or os.environ.get("RECON_PROP_BLOCKS", "1") == "0":
+    if dd != 16 or n < 2 or n > 32 or B > _MAX_BATCH or B == 0 or os.environ.get("RECON_PROP_BLOCKS", "1") == "0":
         return False
     if h0.data_ptr() % 16 or identity.data_ptr() % 16 or any(T.data_ptr() % 16 or not T.is_contiguous() for T in T_list):
         return False
     probe = _lib.PropB16Args(B, n * (n - 1), n * dd, len(T_list), dd, 1, None, None, 0, None, None, 0, None, None, None, None, None)
-    return _lib.lib().recon_propagate_b16_form(C.byref(probe)) == 1
+    return _lib.lib().recon_propagate_b16_form(C.byref(probe)) in (1, 3)     # the kernels with the state in LDS read T in place
 
 
 def _propagate_blocks_b16(T_list, identity, n, h0, act, head, tail):

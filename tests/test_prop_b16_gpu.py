@@ -92,16 +92,25 @@ def test_propagation_b16_vs_oracle(n, d, L, B, act, per_batch, form, monkeypatch
 
 
 @pytest.mark.parametrize("S,C,dd,L,B,act,per_batch", [
-    (512, 130, 16, 3, 3, "relu", True),      # wide states: M = 130 = one full tile + 2 rows, four column tiles
+    (512, 130, 16, 3, 3, "relu", True),      # wide states: M = 130 = one full tile + 2 rows; two channel chunks, the second of 2 channels
     (176, 5, 8, 3, 4, "linear", True),       # K = 176: a partial stage (5.5 K steps), M = 5
     (168, 20, 4, 2, 9, "relu", False),       # S % 16 != 0 (S % 8 == 0): partial row / column tiles; more than 8 graphs: two XCD rounds
-    (256, 96, 6, 2, 11, "tanh", True),       # exactly two tiles each way
+    (256, 96, 6, 2, 11, "tanh", True),       # exactly two tiles each way; NKS = 8, two row tiles per wave
     (144, 150, 16, 2, 3, "relu", True),      # S <= 160 but C > 96: the mid-size tile (144 x 144) with two row tiles
     (40, 3, 2, 8, 2, "tanh", False),         # eight hops, tiny states, duplicates in the gather indices
+    (192, 40, 8, 3, 9, "relu", True),        # NKS = 6: twelve row tiles on eight waves (two waves idle)
+    (320, 200, 16, 2, 3, "relu", False),     # NKS = 10, three row tiles per wave (an unpaired one in the epilogue), shared h0
+    (384, 129, 4, 2, 2, "tanh", True),       # NKS = 12
+    (448, 70, 16, 2, 2, "linear", True),     # NKS = 14: 28 row tiles on 8 x 4
+    (512, 300, 20, 2, 2, "relu", True),      # gather width 20: more items than the position table holds
 ])
-def test_propagation_b16_gemm_form_vs_oracle(S, C, dd, L, B, act, per_batch):
-    """Shapes the fused kernel does not take: one batched GEMM per hop over the graphs; arbitrary adjacencies, start states and
-    gather indices (duplicates included)."""
+@pytest.mark.parametrize("form", ["auto", "gemm"])
+def test_propagation_b16_gemm_form_vs_oracle(S, C, dd, L, B, act, per_batch, form, monkeypatch):
+    """Shapes the small fused kernel does not take.  `auto`: S % 64 == 0, 192 <= S <= 512 runs the wide fused kernel (the state of 128
+    channels resident in LDS for all hops), everything else one batched GEMM per hop over the graphs; `gemm`: the GEMM form everywhere.
+    Arbitrary adjacencies, start states and gather indices (duplicates included); the backward is the GEMM form in both."""
+    if form == "gemm":
+        monkeypatch.setenv("RECON_PROP_B16", "g")
     g = torch.Generator().manual_seed(S + C)
     adjs = [_bf((torch.rand(B, S, S, generator=g) - 0.45) * (2.0 / S ** 0.5)) for _ in range(L)]
     h0 = _bf(torch.randn(B, C, S, 1, generator=g) if per_batch else torch.randn(C, S, 1, generator=g))
@@ -153,7 +162,9 @@ def test_block_adjacency_b16(n, B):
 
 
 @pytest.mark.parametrize("n,L,B,act,per_batch", [(9, 3, 7, "relu", True), (9, 3, 300, "relu", False), (4, 2, 5, "tanh", True), (2, 3, 3, "relu", True),
-                                                  (10, 2, 4, "relu", True), (7, 3, 5, "linear", False)])
+                                                  (10, 2, 4, "relu", True), (7, 3, 5, "linear", False),
+                                                  (12, 2, 3, "relu", True), (16, 3, 9, "tanh", True), (20, 2, 2, "relu", False), (28, 2, 2, "relu", True),
+                                                  (32, 3, 3, "relu", True), (11, 2, 3, "relu", True)])      # n = 11: no fused form, materialised
 def test_propagate_blocks_b16_inference_matches_materialised(n, L, B, act, per_batch):
     """Block mode of the fused bf16 kernel (the transition tensors read in place, A_l never written) gives the bits of the path through
     build_block_adjacency: the same fragments reach the same MFMAs in the same order."""
