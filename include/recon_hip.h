@@ -465,13 +465,21 @@ typedef struct {
     void* w_planes;                 /* recon_gcn_b16_planes_bytes() bytes, scratch / saved: W^T and W zero padded along k */
     int32_t w_planes_valid;         /* != 0: w_planes already holds the planes of `weight` (a caller that keeps them across      *
                                      * calls while the weight is unchanged — inference — saves the two repacking launches)      */
+    /* RAGGED batch (BASELINE.json configs[4]: graphs of up to 256 nodes each, every one its own size), or NULL / 0: graph b owns node  *
+     * rows node_ptr[b] .. node_ptr[b+1] of x / support / out (total_rows = node_ptr[B] rows in all) and a dense n_b x n_b adjacency   *
+     * at adj + adj_ptr[b] (elements); `n` is then the LARGEST n_b.  The layer of models/layers.py:57-63 applied to every graph:        *
+     * x @ W over all rows at once, the aggregate per graph.  `support` is required.                                                    */
+    const int32_t* node_ptr;        /* [B+1] device, ascending, node_ptr[0] = 0                                  */
+    const int64_t* adj_ptr;         /* [B+1] device: adj_ptr[b] = sum over b' < b of n_b'^2                      */
+    int64_t total_rows;
 } recon_gcn_b16_args;
 
 typedef struct {
     recon_gcn_b16_args fwd;
     const void* grad_out; int64_t ldg;   /* [B*n, ldg] bf16                                                      */
     void* g_support;                /* [B*n, fwd.lds] bf16 workspace                                             */
-    float* partial;                 /* recon_gcn_b16_bwd_partial_floats() floats                                 */
+    float* partial;                 /* recon_gcn_b16_bwd_partial_floats() floats; ragged batch:                  *
+                                     * recon_gcn_b16_bwd_partial_floats(1, total_rows, in, out) + B * out floats  */
     void* g_x; int64_t ldgx;        /* [B*n, ldgx] bf16 or NULL                                                  */
     void* g_adj;                    /* [B, n, n] bf16 or NULL                                                    */
     void* g_weight;                 /* [in, out] bf16 or NULL                                                    */

@@ -99,7 +99,7 @@ class GcnB16Args(C.Structure):
     _fields_ = [("B", C.c_int32), ("n", C.c_int32), ("in_features", C.c_int32), ("out_features", C.c_int32),
                 ("x", C.c_void_p), ("ldx", C.c_int64), ("adj", C.c_void_p), ("weight", C.c_void_p), ("bias", C.c_void_p),
                 ("support", C.c_void_p), ("lds", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64), ("w_planes", C.c_void_p),
-                ("w_planes_valid", C.c_int32)]
+                ("w_planes_valid", C.c_int32), ("node_ptr", C.c_void_p), ("adj_ptr", C.c_void_p), ("total_rows", C.c_int64)]
 
 
 class GcnB16BwdArgs(C.Structure):

@@ -31,13 +31,22 @@ __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(ui
 template <bool TRANS, bool MASK, bool EPI>
 __global__ void __launch_bounds__(256) k_gcn_b16_aggregate(const uint16_t* __restrict__ adj, const uint16_t* __restrict__ Xin, int64_t ldx,
                                                            const uint16_t* __restrict__ fwd_out, int64_t ldf, const uint16_t* __restrict__ bias,
-                                                           int32_t n, int32_t O, uint16_t* __restrict__ Y, int64_t ldy, float* __restrict__ colsum = nullptr) {
+                                                           int32_t n, int32_t O, uint16_t* __restrict__ Y, int64_t ldy, float* __restrict__ colsum = nullptr,
+                                                           const int32_t* __restrict__ node_ptr = nullptr, const int64_t* __restrict__ adj_ptr = nullptr) {
     constexpr int PM = 48, PX = 80;
     __shared__ float Mk[32 * PM];           // Mk[k][i] = M[i0 + i][k0 + k]
     __shared__ float Xs[32 * PX];           // Xs[k][o]
     const int b = blockIdx.y, o0 = blockIdx.x * 64, i0 = blockIdx.z * 32;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    // RAGGED batch (node_ptr): graph b owns node rows node_ptr[b] .. node_ptr[b + 1] and a dense n_b x n_b adjacency at adj + adj_ptr[b]
+    int64_t rowbase = static_cast<int64_t>(b) * n;
     const uint16_t* A = adj + static_cast<int64_t>(b) * n * n;
+    if (node_ptr) {
+        rowbase = node_ptr[b];
+        n = node_ptr[b + 1] - node_ptr[b];
+        A = adj + adj_ptr[b];
+        if (i0 >= n) return;                                           // uniform for the block
+    }
     const int li = lane & 15, lq = lane >> 4;
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     float csum = 0.f;
@@ -55,7 +64,7 @@ __global__ void __launch_bounds__(256) k_gcn_b16_aggregate(const uint16_t* __res
             const int k = idx >> 4, oq = o0 + 4 * (idx & 15);              // multiples of 8 elements, so a quad never straddles a row)
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (k0 + k < n && oq < ldx) {                                  // columns in [O, ldx) hold zeros (or are masked below)
-                const int64_t row = static_cast<int64_t>(b) * n + k0 + k;
+                const int64_t row = rowbase + k0 + k;
                 const uint2 raw = *reinterpret_cast<const uint2*>(Xin + row * ldx + oq);
                 v[0] = bf2f(raw.x & 0xffffu); v[1] = bf2f(raw.x >> 16); v[2] = bf2f(raw.y & 0xffffu); v[3] = bf2f(raw.y >> 16);
                 if constexpr (MASK) {
@@ -93,7 +102,7 @@ __global__ void __launch_bounds__(256) k_gcn_b16_aggregate(const uint16_t* __res
                 if (i < n) {
                     float v = acc[tt][r];
                     if constexpr (EPI) { v += bv; v = v > 0.f ? v : 0.f; }
-                    Y[(static_cast<int64_t>(b) * n + i) * ldy + o] = o < O ? f2bf(v) : static_cast<uint16_t>(0);
+                    Y[(rowbase + i) * ldy + o] = o < O ? f2bf(v) : static_cast<uint16_t>(0);
                 }
             }
     }
@@ -101,15 +110,18 @@ __global__ void __launch_bounds__(256) k_gcn_b16_aggregate(const uint16_t* __res
 
 // g_adj[b][i][j] = sum_o gpre[b][i][o] * support[b][j][o]
 __global__ void __launch_bounds__(256) k_gcn_b16_grad_adj(const uint16_t* __restrict__ gout, int64_t ldg, const uint16_t* __restrict__ fwd_out, int64_t ldf,
-                                                          const uint16_t* __restrict__ sup, int64_t lds, int32_t n, int32_t O, uint16_t* __restrict__ gadj) {
+                                                          const uint16_t* __restrict__ sup, int64_t lds, int32_t n, int32_t O, uint16_t* __restrict__ gadj,
+                                                          const int32_t* __restrict__ node_ptr = nullptr, const int64_t* __restrict__ adj_ptr = nullptr) {
     const int b = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    int64_t rowbase = static_cast<int64_t>(b) * n, abase = static_cast<int64_t>(b) * n * n;
+    if (node_ptr) { rowbase = node_ptr[b]; n = node_ptr[b + 1] - node_ptr[b]; abase = adj_ptr[b]; }
     if (idx >= n * n) return;
     const int i = idx / n, j = idx % n;
-    const int64_t ri = static_cast<int64_t>(b) * n + i, rj = static_cast<int64_t>(b) * n + j;
+    const int64_t ri = rowbase + i, rj = rowbase + j;
     float s = 0.f;
     for (int o = 0; o < O; ++o) s = fmaf(bf2f(fwd_out[ri * ldf + o]) > 0.f ? bf2f(gout[ri * ldg + o]) : 0.f, bf2f(sup[rj * lds + o]), s);
-    gadj[static_cast<int64_t>(b) * n * n + idx] = f2bf(s);
+    gadj[abase + idx] = f2bf(s);
 }
 
 // g_bias[o] = sum over graphs of the per-graph column sums of gpre (left in `partial` by the aggregate kernel): 16 columns x 64 slice groups
@@ -545,6 +557,7 @@ constexpr int kBiasBlocks = 1024;
 int check(const recon_gcn_b16_args* a) {
     if (!a || a->B < 0 || a->n <= 0 || a->in_features <= 0 || a->out_features <= 0) return RECON_ERR_INVALID;
     if (!a->x || !a->adj || !a->weight || !a->out || !a->w_planes) return RECON_ERR_INVALID;
+    if (a->node_ptr && (!a->adj_ptr || !a->support || a->total_rows < 0)) return RECON_ERR_INVALID;      // ragged batch: the two-kernel form
     if (!a->support && !gcn_fused_ok(a)) return RECON_ERR_INVALID;    // only the fused forward (n <= 32, out <= 320) does without it
     const int64_t i8 = (a->in_features + 7) / 8 * 8, o8 = (a->out_features + 7) / 8 * 8;
     const bool fused = !a->support;                                   // the fused forward masks the K tail: rows need no padding, only 4-byte alignment
@@ -572,7 +585,8 @@ extern "C" int recon_gcn_b16_fwd(const recon_gcn_b16_args* a, recon_stream_t str
     if (rc != RECON_OK) return rc;
     if (a->B == 0) return RECON_OK;
     hipStream_t st = as_stream(stream);
-    const int32_t rows = a->B * a->n, I = a->in_features, O = a->out_features;
+    if (a->node_ptr && (a->total_rows == 0 || a->total_rows > 0x7fffffffLL)) return a->total_rows == 0 ? RECON_OK : RECON_ERR_UNSUPPORTED;
+    const int32_t rows = a->node_ptr ? static_cast<int32_t>(a->total_rows) : a->B * a->n, I = a->in_features, O = a->out_features;
     char* wp = static_cast<char*>(a->w_planes);
     // W^T [O][kp(I)] for this product, W [I][kp(O)] for g_x in the backward (both zero padded along k)
     if (!a->w_planes_valid) {
@@ -604,7 +618,7 @@ extern "C" int recon_gcn_b16_fwd(const recon_gcn_b16_args* a, recon_stream_t str
     dim3 grid(static_cast<unsigned>(ceil_div64(a->ldo, 64)), static_cast<unsigned>(a->B), static_cast<unsigned>(ceil_div64(a->n, 32)));
     hipLaunchKernelGGL((k_gcn_b16_aggregate<false, false, true>), grid, dim3(256), 0, st, static_cast<const uint16_t*>(a->adj),
                        static_cast<const uint16_t*>(a->support), a->lds, nullptr, 0, static_cast<const uint16_t*>(a->bias), a->n, O,
-                       static_cast<uint16_t*>(a->out), a->ldo);
+                       static_cast<uint16_t*>(a->out), a->ldo, nullptr, a->node_ptr, a->adj_ptr);
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }
@@ -626,13 +640,15 @@ extern "C" int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* b, recon_stream_t
     if (!b->grad_out || !b->g_support || !b->partial || !b->zeros || (b->ldg & 7) || (b->ldgx & 7)) return RECON_ERR_INVALID;
     if (a->B == 0) return RECON_OK;
     hipStream_t st = as_stream(stream);
-    const int32_t rows = a->B * a->n, I = a->in_features, O = a->out_features, n = a->n;
+    if (a->node_ptr && (a->total_rows == 0 || a->total_rows > 0x7fffffffLL)) return a->total_rows == 0 ? RECON_OK : RECON_ERR_UNSUPPORTED;
+    const int32_t rows = a->node_ptr ? static_cast<int32_t>(a->total_rows) : a->B * a->n, I = a->in_features, O = a->out_features, n = a->n;
     const uint16_t* gout = static_cast<const uint16_t*>(b->grad_out);
     const uint16_t* fout = static_cast<const uint16_t*>(a->out);
-    float* colsum = b->partial + gcn_b16_gw_partial_floats(a->B, n, I, O);      // [B][O] per-graph column sums of gpre, behind the split-K partials
+    // [B][O] per-graph column sums of gpre, behind the split-K partials (ragged batch: the partials of a product over total_rows rows)
+    float* colsum = b->partial + (a->node_ptr ? gcn_b16_gw_partial_floats(1, rows, I, O) : gcn_b16_gw_partial_floats(a->B, n, I, O));
     static const bool fused_bwd_off = getenv("RECON_GCN_FUSED_BWD") && getenv("RECON_GCN_FUSED_BWD")[0] == '0';
     const int64_t i8f = (I + 7) / 8 * 8;
-    const bool fused_bwd = !fused_bwd_off && !b->g_adj && b->g_x && n <= 32 && a->lds <= kFusedNT * 16 && i8f <= kFusedNT * 16 && b->ldgx >= i8f &&
+    const bool fused_bwd = !fused_bwd_off && !a->node_ptr && !b->g_adj && b->g_x && n <= 32 && a->lds <= kFusedNT * 16 && i8f <= kFusedNT * 16 && b->ldgx >= i8f &&
                            (b->ldgx & 3) == 0 && (a->lds & 3) == 0 && (b->ldg & 7) == 0 && (a->ldo & 7) == 0 &&
                            ((reinterpret_cast<uintptr_t>(b->g_x) | reinterpret_cast<uintptr_t>(b->grad_out) | reinterpret_cast<uintptr_t>(a->out)) & 15) == 0 &&
                            static_cast<int64_t>(rows) * (a->lds > b->ldgx ? a->lds : b->ldgx) * 2 < 0x7fffffffLL &&
@@ -653,11 +669,12 @@ extern "C" int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* b, recon_stream_t
     // g_support = adj^T @ (grad_out * (out > 0)); pad columns zeroed (it is the A operand of the next product)
     dim3 grid(static_cast<unsigned>(ceil_div64(a->lds, 64)), static_cast<unsigned>(a->B), static_cast<unsigned>(ceil_div64(n, 32)));
     hipLaunchKernelGGL((k_gcn_b16_aggregate<true, true, false>), grid, dim3(256), 0, st, static_cast<const uint16_t*>(a->adj), gout, b->ldg, fout, a->ldo,
-                       nullptr, n, O, static_cast<uint16_t*>(b->g_support), a->lds, b->g_bias ? colsum : nullptr);
+                       nullptr, n, O, static_cast<uint16_t*>(b->g_support), a->lds, b->g_bias ? colsum : nullptr, a->node_ptr, a->adj_ptr);
     }
     if (b->g_adj)
         hipLaunchKernelGGL(k_gcn_b16_grad_adj, dim3(static_cast<unsigned>(ceil_div64(n * n, 256)), static_cast<unsigned>(a->B)), dim3(256), 0, st, gout,
-                           b->ldg, fout, a->ldo, static_cast<const uint16_t*>(a->support), a->lds, n, O, static_cast<uint16_t*>(b->g_adj));
+                           b->ldg, fout, a->ldo, static_cast<const uint16_t*>(a->support), a->lds, n, O, static_cast<uint16_t*>(b->g_adj), a->node_ptr,
+                           a->adj_ptr);
     RECON_CHECK_LAUNCH();
     // g_bias: second pass over the per-graph column sums — in the launch of g_W's second pass when there is one
     const B16ReduceJob bias_job{colsum, static_cast<uint16_t*>(b->g_bias), O, a->B, 1, O};

@@ -133,7 +133,7 @@ def _zero_page(dev):
 
 class _NoGradCtx:
     """Stands in for autograd's ctx when a forward runs outside autograd (torch.no_grad())."""
-    needs_input_grad = (False, False, False, False)
+    needs_input_grad = (False, False, False, False, False)
 
     def save_for_backward(self, *tensors):
         pass
@@ -150,7 +150,7 @@ class _GcnB16Function(torch.autograd.Function):
     buffers; the result is returned as a [..., :out] view of one, which the next layer reads in place."""
 
     @staticmethod
-    def forward(ctx, x, adj, weight, bias):
+    def forward(ctx, x, adj, weight, bias, keep_planes=False):
         for t in (x, adj, weight, bias):
             if t is not None and (not t.is_cuda or t.dtype != torch.bfloat16):
                 raise TypeError("recon_amd: the bfloat16 GraphConvolution path needs bfloat16 GPU tensors for input, adj, weight and bias")
@@ -179,14 +179,15 @@ class _GcnB16Function(torch.autograd.Function):
         sup = None if fused else torch.empty(B * n, o8, **bf)
         out_p = torch.empty(B * n, o8, **bf)
         weight = weight.contiguous()
-        # W^T / W repacked for the matrix cores: a frozen weight (inference: no gradient wanted) keeps its planes across calls, keyed on
-        # identity + version (an in-place update bumps the version); a weight under training is repacked every step
+        # W^T / W repacked for the matrix cores: the weight of a module in eval() mode keeps its planes across calls (`keep_planes`), keyed
+        # on identity + version (an in-place update through the tensor bumps the version; one through `.data` does NOT — the module drops
+        # its planes in reset_parameters / load_state_dict / _apply and offers invalidate_planes()); otherwise repacked every call
         key = (weight.data_ptr(), weight._version, I, O, str(dev))
-        frozen = _PLANES_CACHE and not ctx.needs_input_grad[2]
+        frozen = _PLANES_CACHE and keep_planes and not ctx.needs_input_grad[2]
         hit = _PLANES.get(key) if frozen else None
         planes = hit[0] if hit is not None else torch.empty(L.recon_gcn_b16_planes_bytes(I, O), dtype=torch.uint8, device=dev)
         args = _lib.GcnB16Args(B, n, I, O, xr.data_ptr(), ldx, adj3.data_ptr(), weight.data_ptr(), _lib.ptr(bias), _lib.ptr(sup), o8,
-                               out_p.data_ptr(), o8, planes.data_ptr(), 1 if hit is not None else 0)
+                               out_p.data_ptr(), o8, planes.data_ptr(), 1 if hit is not None else 0, None, None, 0)
         with _lib.on_device(dev):
             _lib.check(L.recon_gcn_b16_fwd(C.byref(args), _lib.current_stream()), "recon_gcn_b16_fwd")
         if hit is None and frozen:
@@ -210,7 +211,7 @@ class _GcnB16Function(torch.autograd.Function):
         dev = gout.device
         L = _lib.lib()
         bf = dict(dtype=torch.bfloat16, device=dev)
-        nx, nadj, nw, nb = ctx.needs_input_grad
+        nx, nadj, nw, nb = ctx.needs_input_grad[:4]
         if gout.dtype != torch.bfloat16:
             gout = gout.to(torch.bfloat16)
         ldg = _rows_view(gout, O, pads_read=False)                 # pad columns of a gradient are never read
@@ -225,7 +226,7 @@ class _GcnB16Function(torch.autograd.Function):
         g_w = torch.empty(I, O, **bf) if nw else None
         g_b = torch.empty(O, **bf) if (nb and bias is not None) else None
         fwd = _lib.GcnB16Args(B, n, I, O, xr.data_ptr(), ldx, adj3.data_ptr(), weight.data_ptr(), _lib.ptr(bias), _lib.ptr(sup), o8,
-                              out_p.data_ptr(), o8, planes.data_ptr(), 1)
+                              out_p.data_ptr(), o8, planes.data_ptr(), 1, None, None, 0)
         args = _lib.GcnB16BwdArgs(fwd, gr.data_ptr(), ldg, g_sup.data_ptr(), partial.data_ptr(), _lib.ptr(g_x), i8, _lib.ptr(g_adj),
                                   _lib.ptr(g_w), _lib.ptr(g_b), _zero_page(dev).data_ptr())
         with _lib.on_device(dev):
@@ -235,7 +236,113 @@ class _GcnB16Function(torch.autograd.Function):
                 g_x = g_x.view(xs)
             else:                       # pad columns stay unwritten and the view untagged: nothing reads the pad columns of a gradient
                 g_x = g_x.as_strided(xs, _strides(xs[:-1], i8))   # (_rows_view(..., pads_read=False) in the producer layer's backward)
-        return g_x, (g_adj.view(adjs) if g_adj is not None else None), g_w, g_b
+        return g_x, (g_adj.view(adjs) if g_adj is not None else None), g_w, g_b, None
+
+
+class RaggedAdjacency:
+    """A batch of graphs of DIFFERENT sizes for GraphConvolution (BASELINE.json configs[4]: power-law graphs of up to 256 nodes each):
+    graph b owns node rows node_ptr[b] .. node_ptr[b+1] of the layer's input [N, in] and a dense n_b x n_b adjacency stored at
+    values[adj_ptr[b] : adj_ptr[b] + n_b^2] (row major).  Equivalent to the reference layer (models/layers.py:57-63) applied to each graph,
+    i.e. to one block-diagonal adjacency over all N nodes.  `values` is a bfloat16 GPU tensor and may require grad."""
+
+    def __init__(self, values, sizes):
+        sizes = [int(v) for v in sizes]
+        if any(v <= 0 for v in sizes):
+            raise ValueError("RaggedAdjacency: every graph needs at least one node")
+        self.sizes = sizes
+        self.B = len(sizes)
+        self.n_max = max(sizes) if sizes else 0
+        self.total_rows = sum(sizes)
+        if values.dim() != 1 or values.numel() != sum(v * v for v in sizes):
+            raise ValueError("RaggedAdjacency: `values` must be the flat concatenation of the graphs' n_b x n_b adjacencies")
+        self.values = values
+        npt = torch.tensor([0] + sizes, dtype=torch.int64).cumsum(0)
+        apt = torch.tensor([0] + [v * v for v in sizes], dtype=torch.int64).cumsum(0)
+        self.node_ptr = npt.to(dtype=torch.int32, device=values.device)
+        self.adj_ptr = apt.to(device=values.device)
+
+    @classmethod
+    def from_dense(cls, mats):
+        """From a list of [n_b, n_b] tensors."""
+        return cls(torch.cat([m.reshape(-1) for m in mats]), [m.shape[0] for m in mats])
+
+    def block(self, b):
+        o, n = int(self.adj_ptr[b]), self.sizes[b]
+        return self.values[o:o + n * n].view(n, n)
+
+
+class _GcnB16RaggedFunction(torch.autograd.Function):
+    """GraphConvolution over a ragged batch in bfloat16: x @ W over all node rows at once (bf16 matrix cores), the aggregate per graph."""
+
+    @staticmethod
+    def forward(ctx, x, values, weight, bias, ragged):
+        for t in (x, values, weight, bias):
+            if t is not None and (not t.is_cuda or t.dtype != torch.bfloat16):
+                raise TypeError("recon_amd: the ragged GraphConvolution path needs bfloat16 GPU tensors for input, adjacency values, weight and bias")
+        if x.dim() != 2 or x.shape[0] != ragged.total_rows or weight.shape[0] != x.shape[1]:
+            raise ValueError("GraphConvolution (ragged): input must be [total nodes, in_features]")
+        if ragged.B > _MAX_BATCH:
+            raise NotImplementedError("GraphConvolution (ragged): more than %d graphs per call" % _MAX_BATCH)
+        N, I = x.shape
+        O = weight.shape[1]
+        dev = x.device
+        L = _lib.lib()
+        o8 = (O + 7) // 8 * 8
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        ldx = _rows_view(x, I)
+        xr = x
+        if ldx is None:
+            xr, ldx = _packed_rows(x, I, zero_pad=True)
+        values = values.contiguous()
+        sup = torch.empty(N, o8, **bf)
+        out_p = torch.empty(N, o8, **bf)
+        weight = weight.contiguous()
+        planes = torch.empty(L.recon_gcn_b16_planes_bytes(I, O), dtype=torch.uint8, device=dev)
+        args = _lib.GcnB16Args(ragged.B, ragged.n_max, I, O, xr.data_ptr(), ldx, values.data_ptr(), weight.data_ptr(), _lib.ptr(bias), sup.data_ptr(), o8,
+                               out_p.data_ptr(), o8, planes.data_ptr(), 0, ragged.node_ptr.data_ptr(), ragged.adj_ptr.data_ptr(), N)
+        with _lib.on_device(dev):
+            _lib.check(L.recon_gcn_b16_fwd(C.byref(args), _lib.current_stream()), "recon_gcn_b16_fwd (ragged)")
+        ctx.save_for_backward(xr, values, weight, bias, sup, out_p, planes)
+        ctx.ragged = ragged
+        ctx.meta = (N, I, O, ldx, o8)
+        if o8 == O:
+            return out_p
+        out_p[:, O:].zero_()
+        out = out_p.as_strided((N, O), (o8, 1))
+        out._recon_padded = True
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xr, values, weight, bias, sup, out_p, planes = ctx.saved_tensors
+        N, I, O, ldx, o8 = ctx.meta
+        rg = ctx.ragged
+        dev = gout.device
+        L = _lib.lib()
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        nx, nadj, nw, nb, _ = ctx.needs_input_grad
+        if gout.dtype != torch.bfloat16:
+            gout = gout.to(torch.bfloat16)
+        ldg = _rows_view(gout, O, pads_read=False)
+        gr = gout
+        if ldg is None:
+            gr, ldg = _packed_rows(gout, O, zero_pad=False)
+        i8 = (I + 7) // 8 * 8
+        g_sup = torch.empty(N, o8, **bf)
+        partial = torch.empty(L.recon_gcn_b16_bwd_partial_floats(1, N, I, O) + rg.B * O, dtype=torch.float32, device=dev)
+        g_x = torch.empty(N, i8, **bf) if nx else None
+        g_adj = torch.empty_like(values) if nadj else None
+        g_w = torch.empty(I, O, **bf) if nw else None
+        g_b = torch.empty(O, **bf) if (nb and bias is not None) else None
+        fwd = _lib.GcnB16Args(rg.B, rg.n_max, I, O, xr.data_ptr(), ldx, values.data_ptr(), weight.data_ptr(), _lib.ptr(bias), sup.data_ptr(), o8,
+                              out_p.data_ptr(), o8, planes.data_ptr(), 1, rg.node_ptr.data_ptr(), rg.adj_ptr.data_ptr(), N)
+        args = _lib.GcnB16BwdArgs(fwd, gr.data_ptr(), ldg, g_sup.data_ptr(), partial.data_ptr(), _lib.ptr(g_x), i8, _lib.ptr(g_adj),
+                                  _lib.ptr(g_w), _lib.ptr(g_b), _zero_page(dev).data_ptr())
+        with _lib.on_device(dev):
+            _lib.check(L.recon_gcn_b16_bwd(C.byref(args), _lib.current_stream()), "recon_gcn_b16_bwd (ragged)")
+        if g_x is not None and i8 != I:
+            g_x = g_x.as_strided((N, I), (i8, 1))
+        return g_x, g_adj, g_w, g_b, None
 
 
 def _strides(lead, ld):
@@ -295,18 +402,36 @@ class GraphConvolution(Module):
         self.weight.data.uniform_(-stdv, stdv)
         if self.bias is not None:
             self.bias.data.uniform_(-stdv, stdv)
+        self.invalidate_planes()
+
+    def invalidate_planes(self):
+        """Drop the repacked copies of `weight` an eval()-mode bfloat16 layer keeps across calls.  Needed after an in-place write through
+        `weight.data` (which autograd's version counter does not see); reset_parameters, load_state_dict and .to() / .cuda() call it."""
+        for k in [k for k, v in _PLANES.items() if v[1] is getattr(self, "weight", None) or k[0] == self.weight.data_ptr()]:
+            _PLANES.pop(k, None)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.invalidate_planes()
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_planes()
+        return super()._apply(fn, *args, **kwargs)
 
     def forward(self, input, adj):
+        if isinstance(adj, RaggedAdjacency):                  # graphs of different sizes (bfloat16): input [total nodes, in]
+            return _GcnB16RaggedFunction.apply(input, adj.values, self.weight, self.bias, adj)
         fn = _GcnB16Function if input.dtype == torch.bfloat16 else _GcnFunction     # bf16 storage / fp32 accumulate (module.to(torch.bfloat16))
+        extra = (not self.training,) if fn is _GcnB16Function else ()              # eval(): the repacked weight planes are kept across calls
         if input.dim() == 3 and input.shape[0] > _MAX_BATCH:   # 16-bit grid dimension over the graphs; graphs are independent: run slices
             B = input.shape[0]
-            return torch.cat([fn.apply(input[b0:b0 + _MAX_BATCH], adj[b0:b0 + _MAX_BATCH] if adj.dim() == 3 else adj, self.weight, self.bias)
+            return torch.cat([fn.apply(input[b0:b0 + _MAX_BATCH], adj[b0:b0 + _MAX_BATCH] if adj.dim() == 3 else adj, self.weight, self.bias, *extra)
                               for b0 in range(0, B, _MAX_BATCH)], dim=0)
         if fn is _GcnB16Function and not torch.is_grad_enabled():
             # inference: nothing is recorded, so the autograd.Function machinery (~10 us per call, a third of this layer's host time at
             # cfg 3a) is skipped; the same forward runs with a context that saves nothing
-            return _GcnB16Function.forward(_NO_GRAD_CTX, input, adj, self.weight, self.bias)
-        return fn.apply(input, adj, self.weight, self.bias)
+            return _GcnB16Function.forward(_NO_GRAD_CTX, input, adj, self.weight, self.bias, *extra)
+        return fn.apply(input, adj, self.weight, self.bias, *extra)
 
     def __repr__(self):
         return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'

@@ -320,3 +320,75 @@ def test_cfg3b_bf16_full_batch_forward_and_all_gradients(n, copies_of):
     for t in [out, hb.grad] + [a.grad for a in adjs]:
         v = t.view(reps, copies_of, -1)
         assert torch.equal(v[1], v[0]) and torch.equal(v[reps - 1], v[0]), "copies of the same graphs differ"
+
+
+def test_cfg5_bf16_ragged_stack_at_256_nodes():
+    """BASELINE.json configs[4] as stated: power-law graphs of up to 256 nodes / 4 096 edges each, an H-head attention layer with bf16
+    features in / out, then three bf16 GraphConvolutions applied PER GRAPH (every graph its own row-normalised dense adjacency: a ragged
+    batch, recon_amd.gcn_layers.RaggedAdjacency).  Every layer's backward against the oracle's gradient of that layer, given the layer's
+    own bf16 inputs and the upstream gradient the stack delivered (GAT/layers.py:111-178 in float64; models/layers.py:57-63 by hand)."""
+    from recon_amd import gat_layers
+    from recon_amd.graph import prepare_graph
+    from recon_amd.gcn_layers import GraphConvolution, RaggedAdjacency
+    d = dev()
+    rs = np.random.RandomState(5)
+    sizes = [256, 256] + [int(v) for v in rs.randint(16, 257, size=10)]
+    dsts, srcs, mats, base = [], [], [], 0
+    for n in sizes:                                                     # SURVEY 8d cfg-5 generator, sizes fixed so that two graphs have 256 nodes
+        e = min(4096, 16 * n)
+        p = 1.0 / np.arange(1, n + 1)
+        p /= p.sum()
+        dl, sl = rs.choice(n, size=e, p=p), rs.randint(0, n, size=e)
+        a = torch.zeros(n, n)
+        a[torch.from_numpy(dl), torch.from_numpy(sl)] = 1.0
+        a += torch.eye(n)
+        mats.append(_bf(a / a.sum(-1, keepdim=True)))
+        dsts.append(dl + base); srcs.append(sl + base)
+        base += n
+    N = base
+    edge = torch.from_numpy(np.stack([np.concatenate(dsts), np.concatenate(srcs)])).long()
+    E = edge.shape[1]
+    assert max(sizes) == 256 and E >= 2 * 4096
+    F_, R, D, H = 32, 16, 16, 4
+    g = torch.Generator().manual_seed(0)
+    x = _bf(torch.randn(N, F_, generator=g))
+    ee = _bf(torch.randn(E, R, generator=g) * 0.5)
+    a = torch.stack([O.xavier_normal((D, 2 * F_ + R), 1.414, g) for _ in range(H)]) * 0.5
+    a2 = torch.cat([O.xavier_normal((1, D), 1.414, g) for _ in range(H)])
+    xd, eed = x.to(d).requires_grad_(True), ee.to(d).requires_grad_(True)
+    ad, a2d = a.to(d).requires_grad_(True), a2.to(d).requires_grad_(True)
+    h = gat_layers.gat_heads(xd, eed, ad, a2d, prepare_graph(edge.to(d), None, N), None, 0.2, True)
+    h.retain_grad()
+    torch.manual_seed(2)
+    rag = RaggedAdjacency.from_dense([m.to(d) for m in mats])
+    layers = [GraphConvolution(H * D, H * D).to(torch.bfloat16).to(d) for _ in range(3)]
+    hs = [h]
+    for l in layers:
+        cur = l(hs[-1], rag)
+        cur.retain_grad()
+        hs.append(cur)
+    Gr = _bf(torch.randn(N, H * D, generator=g))
+    (hs[-1] * Gr.to(d)).sum().backward()
+    for l, layer in enumerate(layers):
+        w, b = layer.weight.detach().float().cpu(), layer.bias.detach().float().cpu()
+        xin, out, gup = hs[l].detach().float().cpu(), hs[l + 1].detach().float().cpu(), hs[l + 1].grad.float().cpu()
+        gx_ref, gw_ref, gb_ref, r0 = torch.zeros_like(xin), torch.zeros_like(w), torch.zeros_like(b), 0
+        for n, m in zip(sizes, mats):
+            mf = m.float()
+            close(out[r0:r0 + n], O.graph_convolution(xin[r0:r0 + n], mf, w, b), atol=1e-3, rel_to_max=1.5e-2, what="cfg5 ragged conv %d out (n=%d)" % (l, n))
+            gpre = gup[r0:r0 + n] * (out[r0:r0 + n] > 0)
+            g_sup = _bf(mf.t() @ gpre).float()
+            gx_ref[r0:r0 + n] = g_sup @ w.t()
+            gw_ref += xin[r0:r0 + n].t() @ g_sup
+            gb_ref += gpre.sum(0)
+            r0 += n
+        close(hs[l].grad.float().cpu(), gx_ref, atol=1e-3, rel_to_max=1e-2, what="cfg5 ragged conv %d g_x" % l)
+        close(layer.weight.grad.float().cpu(), gw_ref, atol=1e-3, rel_to_max=1e-2, what="cfg5 ragged conv %d g_weight" % l)
+        close(layer.bias.grad.float().cpu(), gb_ref, atol=1e-3, rel_to_max=1e-2, what="cfg5 ragged conv %d g_bias" % l)
+    gup = h.grad.float().cpu().double()
+    g_x = 0
+    for hh in range(H):
+        r = O.gat_layer_backward(x.double(), edge, ee.double(), None, None, a[hh].double(), a2[hh:hh + 1].double(), 0.2, True, gup[:, hh * D:(hh + 1) * D])
+        close(h.detach().float().cpu()[:, hh * D:(hh + 1) * D], r["out"].float(), atol=1e-3, rel_to_max=1e-2, what="cfg5 ragged gat out h%d" % hh)
+        g_x = g_x + r["g_x"]
+    close(xd.grad.float().cpu(), g_x.float(), atol=1e-3, rel_to_max=1e-2, what="cfg5 ragged gat g_x")

@@ -634,27 +634,93 @@ def test_gcn_bf16_stack_reads_padded_rows_in_place():
 
 
 def test_gcn_bf16_frozen_weight_planes_follow_updates():
-    """Inference keeps a frozen layer's repacked weight across calls (keyed on identity + version): an in-place update of the weight
-    must be seen by the next call, and a second call without an update must give the same bits."""
+    """A layer in eval() mode keeps its repacked weight across calls (keyed on identity + version): an in-place update of the weight
+    must be seen by the next call, a second call without an update must give the same bits; a write through `.data` (invisible to the
+    version counter) is picked up after invalidate_planes(), and load_state_dict / reset_parameters invalidate by themselves; in
+    train() mode nothing is kept."""
     from recon_amd.gcn_layers import GraphConvolution
     d_ = dev()
     g = torch.Generator().manual_seed(3)
     x = _bf(torch.randn(5, 32, 300, generator=g)).to(d_)
     adj = _bf(torch.rand(5, 32, 32, generator=g) / 32).to(d_)
     torch.manual_seed(2)
-    layer = GraphConvolution(300, 300).to(torch.bfloat16).to(d_)
+    layer = GraphConvolution(300, 300).to(torch.bfloat16).to(d_).eval()
+
+    def ref():
+        return O.graph_convolution(x.float().cpu(), adj.float().cpu(), layer.weight.float().cpu(), layer.bias.float().cpu())
     with torch.no_grad():
         a = layer(x, adj).clone()
         b = layer(x, adj).clone()
         assert torch.equal(a, b)
         layer.weight.mul_(-1.0)                                          # same storage, new version
         c = layer(x, adj).clone()
-        ref = O.graph_convolution(x.float().cpu(), adj.float().cpu(), layer.weight.float().cpu(), layer.bias.float().cpu())
-    close(c.float(), ref, atol=1e-3, rel_to_max=1.5e-2, what="after the update")
-    assert not torch.equal(a, c)
-    out = layer(x, adj)                                                  # training mode: repacked on every call, planes saved for the backward
+        close(c.float(), ref(), atol=1e-3, rel_to_max=1.5e-2, what="after the update")
+        assert not torch.equal(a, c)
+        layer.weight.data.mul_(0.5)                                      # `.data`: no version bump — the planes are stale until invalidated
+        layer.invalidate_planes()
+        close(layer(x, adj).float(), ref(), atol=1e-3, rel_to_max=1.5e-2, what="after a .data write + invalidate_planes()")
+        sd = {k: v.clone() * 2 for k, v in layer.state_dict().items()}
+        layer.load_state_dict(sd)                                        # copies through .data: the hook invalidates
+        close(layer(x, adj).float(), ref(), atol=1e-3, rel_to_max=1.5e-2, what="after load_state_dict")
+        layer.reset_parameters()
+        close(layer(x, adj).float(), ref(), atol=1e-3, rel_to_max=1.5e-2, what="after reset_parameters")
+        layer.train()
+        e1 = layer(x, adj).clone()
+        layer.weight.data.mul_(-1.0)                                     # train(): repacked on every call, nothing to go stale
+        close(layer(x, adj).float(), ref(), atol=1e-3, rel_to_max=1.5e-2, what="train mode after a .data write")
+        assert not torch.equal(e1, layer(x, adj))
+    out = layer(x, adj)                                                  # training: planes saved for the backward
     out.float().sum().backward()
     assert layer.weight.grad is not None and torch.isfinite(layer.weight.grad.float()).all()
+
+
+@pytest.mark.parametrize("sizes,I,O_", [([5, 32, 17, 256, 100, 1, 33], 40, 136), ([256, 256, 200], 300, 300), ([1], 7, 5), ([3] * 70, 24, 16), ([129, 64], 33, 64)])
+def test_gcn_bf16_ragged_vs_oracle(sizes, I, O_):
+    """Graphs of different sizes in one call (BASELINE.json configs[4]: up to 256 nodes per graph): x @ W over all node rows, the
+    aggregate per graph with its own dense adjacency.  Forward against the fp32 oracle per graph on the bf16 operands; gradients from
+    models/layers.py:57-63 differentiated by hand under the forward's own ReLU mask (the test_gcn_bf16_vs_oracle method)."""
+    from recon_amd.gcn_layers import GraphConvolution, RaggedAdjacency
+    d_ = dev()
+    g = torch.Generator().manual_seed(sum(sizes) + I)
+    N = sum(sizes)
+    x = _bf(torch.randn(N, I, generator=g))
+    mats = []
+    for n in sizes:
+        a = (torch.rand(n, n, generator=g) < max(0.05, 4.0 / n)).float() + torch.eye(n)
+        mats.append(_bf(a / a.sum(-1, keepdim=True)))
+    torch.manual_seed(1)
+    layer = GraphConvolution(I, O_).to(torch.bfloat16)
+    w, b = layer.weight.detach().clone().float(), layer.bias.detach().clone().float()
+    Gr = _bf(torch.randn(N, O_, generator=g))
+    layer = layer.to(d_)
+    xd = x.to(d_).requires_grad_(True)
+    rag = RaggedAdjacency.from_dense([m.to(d_) for m in mats])
+    rag.values.requires_grad_(True)
+    out = layer(xd, rag)
+    assert out.dtype == torch.bfloat16 and out.shape == (N, O_)
+    (out * Gr.to(d_)).sum().backward()
+    outc, gx, gv = out.detach().float().cpu(), xd.grad.float().cpu(), rag.values.grad.float().cpu()
+    gw_ref, gb_ref = torch.zeros(I, O_), torch.zeros(O_)
+    r0, a0 = 0, 0
+    for n, m in zip(sizes, mats):
+        xs, mf = x[r0:r0 + n].float(), m.float()
+        ref = O.graph_convolution(xs, mf, w, b)
+        close(outc[r0:r0 + n], ref, atol=1e-3, rel_to_max=1.5e-2, what="ragged out (n=%d)" % n)
+        sup = (xs @ w).to(torch.bfloat16).float()
+        gpre = Gr[r0:r0 + n].float() * (outc[r0:r0 + n] > 0)
+        g_sup = (mf.t() @ gpre).to(torch.bfloat16).float()
+        close(gx[r0:r0 + n], g_sup @ w.t(), atol=1e-3, rel_to_max=1e-2, what="ragged g_x (n=%d)" % n)
+        close(gv[a0:a0 + n * n].view(n, n), gpre @ sup.t(), atol=1e-3, rel_to_max=1e-2, what="ragged g_adj (n=%d)" % n)
+        gw_ref += xs.t() @ g_sup
+        gb_ref += gpre.sum(0)
+        r0, a0 = r0 + n, a0 + n * n
+    close(layer.weight.grad.float(), gw_ref, atol=1e-3, rel_to_max=1e-2, what="ragged g_weight")
+    close(layer.bias.grad.float(), gb_ref, atol=1e-3, rel_to_max=1e-2, what="ragged g_bias")
+    if len(set(sizes)) == 1:                                             # equal sizes: the batched [B, n, in] call computes the same thing
+        n = sizes[0]
+        with torch.no_grad():
+            dense = layer(x.to(d_).view(len(sizes), n, I), torch.stack([m.to(d_) for m in mats]).requires_grad_(True))
+        close(dense.reshape(N, O_).float(), outc, atol=1e-3, rel_to_max=1e-2, what="ragged vs batched")
 
 
 def test_gcn_bf16_foreign_padded_view_is_repacked():

@@ -242,6 +242,66 @@ def powerlaw_spgat(B=64, D=25, F_=200, H=8, nrel=64, iters=10):
             "note": "frac prices SURVEY 8d's B_G of both layers against the WHOLE forward (GEMMs, row sums, hub combines included)"}
 
 
+def powerlaw_mixed_stack_bf16(B=64, D=32, F_=200, H=8, iters=10):
+    """BASELINE.json configs[4] as stated: power-law graphs of up to 256 nodes / 4 096 edges, a mixed stack in bfloat16 — an H-head attention
+    layer (bf16 features in / out, GAT/layers.py:111-178) followed by three GraphConvolutions applied per graph (every graph its own dense
+    row-normalised adjacency: a ragged batch, models/layers.py:57-63).  Bytes: SURVEY 8d's B_G for the attention layer's forward edge stage +
+    per convolution 2 N D s + sum n_b^2 s + D^2 s at s = 2."""
+    from recon_amd import gat_layers
+    from recon_amd.graph import prepare_graph
+    from recon_amd.gcn_layers import GraphConvolution, RaggedAdjacency
+    dv = torch.device("cuda:0")
+    bf = torch.bfloat16
+    rs = np.random.RandomState(0)
+    dsts, srcs, mats, sizes, base = [], [], [], [], 0
+    for _ in range(B):
+        n = int(rs.randint(16, 257))
+        e = min(4096, 16 * n)
+        p = 1.0 / np.arange(1, n + 1)
+        p /= p.sum()
+        dl, sl = rs.choice(n, size=e, p=p), rs.randint(0, n, size=e)
+        a = torch.zeros(n, n)
+        a[torch.from_numpy(dl), torch.from_numpy(sl)] = 1.0
+        a += torch.eye(n)
+        mats.append((a / a.sum(-1, keepdim=True)).to(bf))
+        dsts.append(dl + base); srcs.append(sl + base); sizes.append(n)
+        base += n
+    N = base
+    edge = torch.from_numpy(np.stack([np.concatenate(dsts), np.concatenate(srcs)])).long().to(dv)
+    E = edge.shape[1]
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, F_, generator=g).to(bf).to(dv).requires_grad_(True)
+    ee = (torch.randn(E, F_, generator=g) * 0.5).to(bf).to(dv)
+    HD = H * D
+    a = (torch.randn(H, D, 3 * F_, generator=g) * (2.0 / (3 * F_ + D)) ** 0.5).to(dv).requires_grad_(True)
+    a2 = (torch.randn(H, D, generator=g) * (2.0 / (D + 1)) ** 0.5).to(dv).requires_grad_(True)
+    graph = prepare_graph(edge, None, N)
+    rag = RaggedAdjacency.from_dense([m.to(dv) for m in mats])
+    torch.manual_seed(0)
+    layers = [GraphConvolution(HD, HD).to(bf).to(dv) for _ in range(3)]
+    G = torch.randn(N, HD, generator=g).to(bf).to(dv)
+
+    def stack():
+        h = gat_layers.gat_heads(x, ee, a, a2, graph, None, 0.2, True)
+        for l in layers:
+            h = l(h, rag)
+        return h
+
+    def fwd():
+        with torch.no_grad():
+            stack()
+
+    def fwd_bwd():
+        for q in [x, a, a2] + [t for l in layers for t in l.parameters()]:
+            q.grad = None
+        stack().backward(G)
+    b_g = 4.0 * HD * (E + 3 * N) + 4.0 * (E + N + 1) + 4.0 * HD
+    b_c = 3 * (2.0 * N * HD * 2 + sum(v * v for v in sizes) * 2.0 + HD * HD * 2.0)
+    tf, tb = _time(fwd, iters), _time(fwd_bwd, max(2, iters // 2))
+    return {"graphs": B, "N": N, "E": E, "max_nodes": max(sizes), "heads": H, "D_per_head": D, "dtype": "bf16 storage (attention arithmetic fp32)",
+            "fwd_ms": tf * 1e3, "fwd_bwd_ms": tb * 1e3, "edges_per_s_fwd_bwd": E / tb, "bytes": b_g + b_c, "bound": "hbm", "frac": (b_g + b_c) / tf / HBM_PEAK}
+
+
 def all_secondary(fast=True):
     it = 6 if fast else 20
     return {"cfg3b_n9_propagation": propagation(9, iters=it),
@@ -249,7 +309,8 @@ def all_secondary(fast=True):
             "cfg3b_n9_bf16": propagation_bf16(9, iters=it),
             "cfg3b_n32_bf16": propagation_bf16(32, iters=2),
             "cfg3a_gcn_bf16": gcn_bf16(iters=it),
-            "cfg5_powerlaw_spgat": powerlaw_spgat(iters=it)}
+            "cfg5_powerlaw_spgat": powerlaw_spgat(iters=it),
+            "cfg5_mixed_stack_bf16": powerlaw_mixed_stack_bf16(iters=it)}
 
 
 if __name__ == "__main__":
