@@ -8,8 +8,10 @@ one batch of synthetic graphs, inputs resident in HBM.  Default workload = BASEL
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, every rank owns its own `--graphs` graphs (weak scaling); the parameter
-gradients are averaged over RCCL with the big term (G = V^T g_h, 3.85 MB) sent off before the backward's
+N > 1: one process per GPU, every rank owns its own graphs (weak scaling) — BASELINE.json configs[3]: 8 192 graphs sharded over 8 GPUs,
+i.e. 1 024 graphs per GPU, is the default whenever --gpus > 1 (`--workload cfg4`; N = 1 runs configs[1], 512 graphs); `--workload cfg5`
+runs configs[4]'s power-law graphs (up to 256 nodes / 4 096 edges each), dealt to the ranks by edge count (recon_amd.dist.shard_by_edges).
+The parameter gradients are averaged over RCCL with the big term (G = V^T g_h, 3.85 MB) sent off before the backward's
 edge chain and the few KB that depend on it afterwards (recon_amd/dist.py).  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -36,7 +38,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--graphs", type=int, default=512, help="graphs per GPU")
+    ap.add_argument("--graphs", type=int, default=None, help="graphs per GPU (default: 512 on one GPU = configs[1], 1024 per GPU otherwise = configs[3])")
+    ap.add_argument("--workload", choices=("auto", "cfg2", "cfg4", "cfg5"), default="auto",
+                    help="auto: cfg2 on one GPU, cfg4 (8192 graphs / 8 GPUs = 1024 per GPU) on several; cfg5: power-law graphs sharded by edge count")
     ap.add_argument("--nodes", type=int, default=16)
     ap.add_argument("--edges", type=int, default=64, help="edges per graph")
     ap.add_argument("--feat", type=int, default=200, help="F = R")
@@ -85,10 +89,43 @@ def main():
     from recon_amd.dist import FlatGradBucket, OverlappedWeightGradSync
     from recon_amd import synth
 
+    workload = args.workload if args.workload != "auto" else ("cfg2" if world == 1 else "cfg4")
+    if args.graphs is None:
+        args.graphs = 512 if workload == "cfg2" else (1024 if workload == "cfg4" else 64)
     B, n, e, F_, D, H = args.graphs, args.nodes, args.edges, args.feat, args.dim, args.heads
     R = F_
-    N, E = B * n, B * e
-    x, edge, ee = synth.synthetic_batched_graph(B, n, e, F_, R, seed=rank)   # this rank's own graphs
+    if workload == "cfg5":
+        # BASELINE.json configs[4]: power-law degree graphs of up to 256 nodes / 4 096 edges (SURVEY 8d's generator: n ~ U{16..256},
+        # e = min(4096, 16 n), destinations ~ Zipf(1)); `--graphs` graphs per GPU, generated identically on every rank and dealt out by
+        # edge count (longest-processing-time packing) so that the ranks' edge loads — what the step's time follows — are level
+        import numpy as np
+        from recon_amd.dist import shard_by_edges
+        rs = np.random.RandomState(0)
+        sizes = [int(rs.randint(16, 257)) for _ in range(B * world)]
+        ecount = [min(4096, 16 * v) for v in sizes]
+        mine = shard_by_edges(ecount, world)[rank]
+        dsts, srcs, base = [], [], 0
+        for gi in mine:
+            rg = np.random.RandomState(1000 + gi)
+            p = 1.0 / np.arange(1, sizes[gi] + 1)
+            p /= p.sum()
+            dsts.append(rg.choice(sizes[gi], size=ecount[gi], p=p) + base)
+            srcs.append(rg.randint(0, sizes[gi], size=ecount[gi]) + base)
+            base += sizes[gi]
+        N = base
+        edge = torch.from_numpy(np.stack([np.concatenate(dsts), np.concatenate(srcs)])).long()
+        E = edge.shape[1]
+        gx = torch.Generator().manual_seed(rank)
+        x, ee = torch.randn(N, F_, generator=gx), torch.randn(E, R, generator=gx) * 0.5
+        E_global = sum(ecount)
+        desc = "cfg5: power-law graphs (<= 256 nodes / 4096 edges each), %d graphs over %d GPU(s) dealt by edge count, H-head KB-GAT attention stage fwd+bwd" % (B * world, world)
+    else:
+        N, E = B * n, B * e
+        x, edge, ee = synth.synthetic_batched_graph(B, n, e, F_, R, seed=rank)   # this rank's own graphs
+        E_global = world * E
+        desc = ("cfg2: H-head KB-GAT attention stage fwd+bwd (heads only, dropout 0)" if workload == "cfg2" else
+                "cfg4: BASELINE.json configs[3] — 8-head KB-GAT attention stage fwd+bwd, %d graphs sharded over %d GPU(s) (%d per GPU), "
+                "RCCL grad all-reduce; unmeasured on multi-GPU hardware by the builder" % (B * world, world, B))
     torch.manual_seed(0)                                                      # identical parameters on every rank
     model = SpGAT(N, F_, D, R, dropout=0.0, alpha=0.2, nheads=H)
     head_params = [p for att in model.attentions for p in (att.a, att.a_2)]
@@ -142,15 +179,15 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    edges_per_s = world * E * args.steps / dt
+    edges_per_s = E_global * args.steps / dt
 
     result = {
         "metric": "edges aggregated/sec (GAT fwd+bwd) on synthetic KG-context graphs",
         "value": edges_per_s, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",      # fp32 in, fp32 out, fp32 accumulation; the GEMMs run fp32 operands as 2 f16 (or 3 bf16) terms each
-        "config": {"workload": "cfg2: H-head KB-GAT attention stage fwd+bwd (heads only, dropout 0)",
-                   "graphs_per_gpu": B, "nodes_per_graph": n, "edges_per_graph": e, "F": F_, "R": R,
+        "config": {"workload": desc,
+                   "graphs_per_gpu": B, "nodes_per_graph": n if workload != "cfg5" else "16..256", "edges_per_graph": e if workload != "cfg5" else "min(4096, 16 n)", "F": F_, "R": R,
                    "D_per_head": D, "heads": H, "N_per_gpu": N, "E_per_gpu": E,
                    "parallelism": "dp%d (whole graphs sharded, %s)" % (world, "weight-gradient all-reduce overlapped with the backward's edge chain" if overlap
                                                                          else "flat grad all-reduce after the backward")},
@@ -235,10 +272,10 @@ def main():
             result["roofline"]["survey_definition"] = {"bytes": algorithmic_bytes_fwd(N, E, H, D), "time_us": (t_scores + t_edge) * 1e6,
                                                        "frac": algorithmic_bytes_fwd(N, E, H, D) / (t_scores + t_edge) / HBM_PEAK}
         try:            # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot collect PMC itself)
-            pmc_file = next(f for f in ("round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json")
+            pmc_file = next(f for f in ("round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json")
                             if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
-            if (B, n, e, F_, D, H) == (512, 16, 64, 200, 200, 8) and kname in pmc:
+            if workload == "cfg2" and (B, n, e, F_, D, H) == (512, 16, 64, 200, 200, 8) and kname in pmc:
                 result["roofline"]["traffic"] = pmc[kname]["total_bytes"]
                 result["roofline"]["traffic_is_from_profiles"] = True
                 result["roofline"]["traffic_source"] = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of this command, collected "

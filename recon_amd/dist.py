@@ -80,18 +80,48 @@ class FlatGradBucket:
         for p, v in zip(self.params, self.views):
             p.grad = v
 
-    def allreduce_mean(self, async_op=False):
+    def allreduce_mean(self, async_op=False, skip=None):
+        """Average the bucket over the ranks.  `skip`: gradient tensors that ARE averaged already (OverlappedWeightGradSync.reduced: the
+        attention layers' a / a_2, reduced inside their backward) — they are packed like the rest but left out of the collective, which
+        then runs over the remaining contiguous pieces of the flat buffer (one all-reduce per piece; the same pieces on every rank, since
+        the parameters and the layers that reduce in-backward are the same).  Everything else in the bucket (W, W_entities, embeddings ...)
+        is averaged here: a bucket over a whole model needs this call, pack() alone averages nothing."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            self.pack()
             return None
         w = dist.get_world_size(self.group)
+        done = set()
+        if skip:
+            ids = {id(t) for t in skip}
+            ptrs = {(t.data_ptr(), t.numel()) for t in skip}
+            for i, p in enumerate(self.params):
+                g = p.grad
+                if g is not None and (id(g) in ids or (g.data_ptr(), g.numel()) in ptrs):
+                    done.add(i)
         self.pack()
+        if not done:
+            return self._allreduce(self.flat, w, async_op)
+        handles, off, start = [], 0, None
+        for i, p in enumerate(self.params):                             # maximal runs of parameters still to be averaged
+            if i in done:
+                if start is not None:
+                    handles.append(self._allreduce(self.flat[start:off], w, async_op))
+                    start = None
+            elif start is None:
+                start = off
+            off += p.numel()
+        if start is not None:
+            handles.append(self._allreduce(self.flat[start:off], w, async_op))
+        return handles if async_op else None
+
+    def _allreduce(self, t, w, async_op):
         if dist.get_backend(self.group) == "nccl" and self._avg_ok:    # RCCL averages inside the collective: no extra pass
             try:
-                return dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+                return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
             except (RuntimeError, ValueError):                          # a build without ncclAvg: same on every rank
                 self._avg_ok = False
-        self.flat.div_(w)
-        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        t.div_(w)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
 
 class OverlappedWeightGradSync:
@@ -108,8 +138,11 @@ class OverlappedWeightGradSync:
         sync = OverlappedWeightGradSync()
         with sync.installed():
             out.backward(G)
-        bucket.pack()                        # p.grad views of the flat buffer, already averaged
+        bucket.allreduce_mean(skip=sync.reduced)     # averages what the backward did not (W, W_entities, embeddings ...); with a bucket of
+                                                     # attention-layer parameters only, bucket.pack() is enough
 
+    Every rank must take the same formulation of the layer: with more than one rank gat_layers.gat_path_for() chooses by the layer
+    widths alone (never by this rank's E / N), so the collectives inside the backward match across ranks.
     world size 1 / no process group: every call is a no-op and the backward runs its usual single pass."""
 
     def __init__(self, process_group=None, force_sync=False):

@@ -588,10 +588,18 @@ def gat_path_for(N, E, F_, R, D, H):
     `gat_layers._GAT_PATH` = 'atp' | 'proj' forces one."""
     if _GAT_PATH == "proj":
         return "proj"
-    ok = _lib.lib().recon_gat_atp_supported(N, E, F_, R, D, H) == 1
-    if _GAT_PATH == "atp":
+    ok = _lib.lib().recon_gat_atp_supported(N, E, F_, R, D, H) == 1        # a function of the widths only: the same on every rank
+    if _GAT_PATH == "atp" or _data_parallel():
+        # Data parallelism: every rank has its own batch, so a rule that looks at E / N could send one rank down 'atp' (whose backward
+        # issues two collectives under an OverlappedWeightGradSync) and another down 'proj' (which issues none): mismatched collectives
+        # hang.  With more than one rank the choice depends on the layer widths alone.
         return "atp" if ok else "proj"
     return "atp" if (ok and 2 * E >= N) else "proj"
+
+
+def _data_parallel():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=True, keep_max=None, ee_index=None):

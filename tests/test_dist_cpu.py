@@ -228,3 +228,110 @@ def test_weight_grad_sync_is_inert_without_a_process_group():
     assert not sync.active() and sync.all_reduce_mean(torch.ones(3)) is None
     with sync.installed():
         assert gat_layers._WEIGHT_GRAD_SYNC is None                        # world size 1: the backward keeps its single pass
+
+
+# ------------------------------------------------------------------------------- the FULL stack's bucket (heads + out_att + a non-attention parameter)
+def _full_stack_worker(rank, world, port, ret, mode):
+    """SpGAT's parameter set in ONE FlatGradBucket: two attention layers (the heads, then out_att — backward order: out_att first) whose
+    a / a_2 are averaged inside their backward (overlapped_weight_grad_schedule: the big term asynchronously under the edge chain), plus a
+    parameter no attention backward reduces (W of GAT/models.py:75).  mode 'overlap': asynchronous collectives + allreduce_mean(skip=
+    sync.reduced); 'serial': the same with blocking collectives; 'plain': nothing in-backward, one flat all-reduce of everything.
+    The compute phases are played by the oracle's closed-form backward (the kernels are tested on the GPU)."""
+    from recon_amd.dist import OverlappedWeightGradSync, overlapped_weight_grad_schedule
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    B, x, edge, ee, a, a2, G, node_ptr, edge_ptr = _problem()
+    lo, hi = shard_range(B, rank, world)
+    xs, es, ees = take_graph_shard(x, edge, ee, node_ptr, edge_ptr, lo, hi)
+    Gs = G[int(node_ptr[lo]):int(node_ptr[hi])] * float(world)
+    gen = torch.Generator().manual_seed(7)
+    a_o, a2_o = O.xavier_normal(tuple(a.shape), 1.414, gen), O.xavier_normal(tuple(a2.shape), 1.414, gen)
+    layers = []
+    for (la, la2, scale) in ((a_o, a2_o, 0.5), (a, a2, 1.0)):              # backward order: out_att, then the heads
+        r = O.gat_layer_backward(xs, es, ees, None, None, la, la2, 0.2, True, Gs * scale)
+        layers.append((la, la2, r, torch.cat((xs[es[0]], xs[es[1]], ees), dim=1)))
+    W = torch.nn.Parameter(torch.arange(6.0).view(2, 3))
+    params = [torch.nn.Parameter(a.clone()), torch.nn.Parameter(a2.clone()), W, torch.nn.Parameter(a_o.clone()), torch.nn.Parameter(a2_o.clone())]
+    bucket = FlatGradBucket(params)                                           # W sits BETWEEN the attention parameters: two pieces to reduce
+    sync = OverlappedWeightGradSync(force_sync=(mode == "serial"))
+    bucket.zero()
+    sync.reduced = []
+    W.grad = torch.full((2, 3), float(rank + 1)) * float(world)
+    for li, (la, la2, r, edge_h) in enumerate(layers):
+        g_big, g_small, g_a2 = torch.empty_like(la), torch.empty(1, la.shape[1]), torch.empty_like(la2)
+
+        def run_phase(name):
+            if name == "weights_sum":
+                g_big.copy_((r["gm"] - r["g_sigma"][:, None] * la2[0][None, :]).t() @ edge_h)
+            elif name == "inputs":
+                g_small.copy_((r["g_sigma"][None, :] @ edge_h))
+            elif name == "finish":
+                g_big.add_(la2.t() @ g_small)
+                g_a2.copy_(g_small @ la.t())
+        if mode == "plain":
+            for name in ("prepare", "weights_sum", "inputs", "finish"):
+                run_phase(name)
+        else:
+            overlapped_weight_grad_schedule(run_phase, g_big, g_small, sync)
+            sync.mark_reduced(g_big, g_a2)
+        pa, pa2 = (params[3], params[4]) if li == 0 else (params[0], params[1])
+        pa.grad, pa2.grad = g_big, g_a2
+    bucket.allreduce_mean(skip=None if mode == "plain" else sync.reduced)
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+    ret[rank] = [p.grad.clone().numpy() for p in params]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_full_stack(mode):
+    world = 2
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_full_stack_worker, args=(world, _free_port(), ret, mode), nprocs=world, join=True)
+    return ret
+
+
+def test_full_stack_bucket_overlapped_equals_blocking_and_plain():
+    """A bucket over a WHOLE model under the overlapped schedule: (i) bit-equal to the same schedule with blocking collectives, (ii) the
+    same on both ranks, (iii) the parameter no attention backward touches (W) IS averaged (pack() alone would leave every rank its own
+    value — the advisor's finding), (iv) equal to the plain flat all-reduce of the complete local gradients."""
+    over, serial, plain = _run_full_stack("overlap"), _run_full_stack("serial"), _run_full_stack("plain")
+    for k in range(5):
+        np.testing.assert_array_equal(over[0][k], over[1][k])
+        np.testing.assert_array_equal(over[0][k], serial[0][k])
+        np.testing.assert_allclose(over[0][k], plain[0][k], atol=1e-5, rtol=1e-5)
+    np.testing.assert_array_equal(over[0][2], np.full((2, 3), 3.0, np.float32))     # mean over ranks of world * (rank + 1) = 2 * 1.5
+
+
+def _path_worker(rank, world, port, ret):
+    from recon_amd import gat_layers
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    before = gat_layers._data_parallel()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ret[rank] = (before, gat_layers._data_parallel())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_formulation_choice_ignores_the_local_batch_under_data_parallelism(monkeypatch):
+    """gat_path_for() must give every rank the same answer: with more than one rank it may not look at this rank's E / N (one rank on
+    'atp' — two collectives inside its backward — and another on 'proj' — none — would hang).  The kernels' own support query is a
+    function of the widths only (csrc/gat_atp.hip: recon_gat_atp_supported ignores N and E)."""
+    from recon_amd import gat_layers
+
+    class _Lib:
+        @staticmethod
+        def recon_gat_atp_supported(N, E, F, R, D, H):
+            return 1
+    monkeypatch.setattr(gat_layers._lib, "lib", lambda: _Lib)
+    monkeypatch.setattr(gat_layers, "_GAT_PATH", "auto")
+    assert gat_layers.gat_path_for(1000, 100, 8, 8, 8, 2) == "proj"          # one process: sparse batches project first
+    monkeypatch.setattr(gat_layers, "_data_parallel", lambda: True)
+    assert gat_layers.gat_path_for(1000, 100, 8, 8, 8, 2) == "atp" and gat_layers.gat_path_for(10, 100, 8, 8, 8, 2) == "atp"
+    monkeypatch.undo()
+    world = 2
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_path_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret[r] == (False, True) for r in range(world))
