@@ -492,6 +492,23 @@ int recon_gcn_b16_fwd(const recon_gcn_b16_args* args, recon_stream_t stream);
 size_t recon_gcn_b16_bwd_partial_floats(int32_t B, int32_t n, int32_t in_features, int32_t out_features);
 int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* args, recon_stream_t stream);
 
+/* L GraphConvolutions that share one adjacency (models/layers.py:57-63 applied L times, as the reference's stacks do), INFERENCE, in one
+ * launch: the activations of a graph stay in LDS between the layers ("fused 3-hop, H resident in LDS").  Results are bit-equal
+ * to L calls of recon_gcn_b16_fwd's fused form.  Layer 0: in_features -> hidden; layers 1 .. L-1: hidden -> hidden.  Shapes: n <= 32,
+ * n % 4 == 0, hidden % 4 == 0, hidden <= 320; everything else answers RECON_ERR_UNSUPPORTED (the caller then runs layer by layer). */
+typedef struct {
+    int32_t B, n, in_features, hidden, L;
+    const void* x; int64_t ldx;     /* [B*n, ldx] bf16, any even ldx >= in_features (the K tail is masked)                      */
+    const void* adj;                /* [B, n, n] bf16, 8-byte aligned                                                          */
+    const void* const* w_planes;    /* HOST array of L device pointers: W_l^T zero padded along k, [hidden][kp(in_l)] bf16,     *
+                                     * written by recon_gcn_b16_transposed_planes() (kp = rounded up to 32)                     */
+    const void* const* bias;        /* HOST array of L device pointers [hidden] bf16 (entries, or the array, may be NULL)       */
+    void* out; int64_t ldo;         /* [B*n, ldo] bf16, ldo % 8 == 0; columns hidden .. ldo are written as zeros                */
+} recon_gcn_b16_stack_args;
+int recon_gcn_b16_stack_fwd(const recon_gcn_b16_stack_args* args, recon_stream_t stream);
+/* planes [out_features][kp(in_features)] (bf16, (out_features * kp(in_features) * 2 bytes) of a weight [in_features][out_features] */
+int recon_gcn_b16_transposed_planes(const void* weight, int32_t in_features, int32_t out_features, void* planes, recon_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * K4  fp32 MFMA GEMM used by the projections, exported for tests:
  *     C[M,N] = A[M,K] * B (B given as [N,K] when b_is_nk != 0, else [K,N]); plain row-major.

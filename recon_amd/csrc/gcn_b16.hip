@@ -353,6 +353,186 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_fwd(const GcnFuse
         }
 }
 
+// ------------------------------------------------------------------------------------------------ fused STACK forward (n <= 32, inference)
+// L GraphConvolutions with one adjacency (models/layers.py:57-63 called L times, as the reference's stacks do) in ONE kernel: the fused
+// forward above, looped over the layers with the activations of a graph resident in LDS between them — [K step][32 nodes][64 B] images
+// (the A fragments of the next layer's x @ W are 16-byte LDS reads of exactly the bits the per-layer kernel would have written to and
+// re-read from HBM: results are bit-equal to L calls of it).  HBM traffic: x once, the last layer's result once, adj once; the W^T planes
+// of every layer through the LDS slab from L2 ("fused 3-hop, H resident in LDS, 19 KB per graph: 42 MB" at cfg 3a against
+// 125 MB layer by layer).  Workgroup = 4 graphs x NS column parts as above; between the K loop of a layer and the writes of its result into
+// the image, and again before the next layer reads it, a workgroup barrier.
+constexpr int kMaxStack = 8;
+struct GcnStackK {
+    const uint16_t* x; int64_t ldx;
+    const uint16_t* adj;
+    const uint16_t* wt[kMaxStack];                                       // W_l^T planes [D][kp(in_l)]
+    const uint16_t* bias[kMaxStack];
+    uint16_t* out; int64_t ldo;
+    int32_t B, n, I0, D, L, nt;                                          // in_0 = I0, every layer's out = in_{l+1} = D; nt = ceil(ldo / 16)
+};
+
+template <int NS>
+__global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStackK p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char st_sm[];      // W^T slab [2][20 KiB] | activations [4 graphs][NKH][2 KiB]
+    constexpr int NTP = kFusedNT / NS, NTHR = 256 * NS, SLAB = kFusedNT * 16 * 64;
+    unsigned char* Ws0 = st_sm;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int g = blockIdx.x * 4 + (w & 3);
+    const int c_lo = (w >> 2) * NTP;
+    const int n = p.n, nt = p.nt, D = p.D;
+    const int nkh = (D + 31) >> 5;                                       // K steps of the layers whose input is the image
+    unsigned char* Hg = st_sm + 2 * SLAB + (w & 3) * nkh * 2048;
+    const int64_t rows_total = static_cast<int64_t>(p.B) * n;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0,
+                                                      static_cast<int>(min<int64_t>(rows_total * p.ldx * 2, 0x7fffffff)), 0x00020000);
+    uint32_t xoff[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int i = 16 * rt + li;
+        xoff[rt] = (g < p.B && i < n) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.ldx + 8 * lq) * 2) : 0xfffffff0u;
+    }
+    constexpr int WQ = (kFusedNT * 16 * 4 + NTHR - 1) / NTHR;
+    // adj^T fragments (8-byte loads: n % 4 == 0, adj 8-byte aligned — checked by the host), kept for all layers
+    u32x2_g adjv[2][2];
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.adj), 0,
+                                                      static_cast<int>(min<int64_t>(static_cast<int64_t>(p.B) * n * n * 2, 0x7fffffff)), 0x00020000);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = 16 * it + li;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j0 = 16 * h + 4 * lq;
+            const uint32_t base = static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * n + j0) * 2);
+            adjv[it][h] = __builtin_amdgcn_raw_buffer_load_b64(ra, (g < p.B && i < n && j0 < n) ? base : 0xfffffff0u, 0, 0);
+        }
+    }
+    bf16x8 adjf[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) adjf[it] = __builtin_bit_cast(bf16x8, u32x4_g{adjv[it][0].x, adjv[it][0].y, adjv[it][1].x, adjv[it][1].y});
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const u32x4_g allmask = u32x4_g{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    const int b_rd = gf_lds_off(li, lq) + 1024 * c_lo;
+    const auto ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, static_cast<int>(min<int64_t>(rows_total * p.ldo * 2, 0x7fffffff)), 0x00020000);
+    auto pack2 = [](float a, float b) { return static_cast<uint32_t>(f2bf(a)) | (static_cast<uint32_t>(f2bf(b)) << 16); };
+
+#pragma unroll 1
+    for (int l = 0; l < p.L; ++l) {
+        const bool first = l == 0, last = l == p.L - 1;
+        const int I = first ? p.I0 : D, Ip = (I + 31) & ~31, nks = Ip >> 5;
+        const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wt[l]), 0, D * Ip * 2, 0x00020000);
+        uint32_t woff[WQ]; int wlds[WQ];
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int s = t + NTHR * q, o = s >> 2, kq = s & 3;
+            woff[q] = (o < 16 * nt) ? static_cast<uint32_t>((o * Ip + 8 * kq) * 2) : 0xfffffff0u;
+            wlds[q] = o < kFusedNT * 16 ? gf_lds_off(o, kq) : -1;
+        }
+        const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.bias[l] ? p.bias[l] : p.x), 0, p.bias[l] ? D * 2 : 0, 0x00020000);
+        u32x2_g bvec[NTP];
+#pragma unroll
+        for (int c = 0; c < NTP; ++c) bvec[c] = __builtin_amdgcn_raw_buffer_load_b64(rb, static_cast<uint32_t>((16 * (c_lo + c) + 4 * lq) * 2), 0, 0);
+        u32x4_g tailmask;
+        {
+            const int k0 = 32 * (nks - 1) + 8 * lq;
+            uint32_t m[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) m[d] = (k0 + 2 * d < I ? 0x0000ffffu : 0u) | (k0 + 2 * d + 1 < I ? 0xffff0000u : 0u);
+            tailmask = u32x4_g{m[0], m[1], m[2], m[3]};
+        }
+        f32x4 acc[2][NTP];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int c = 0; c < NTP; ++c) acc[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the K loop in two copies — x from global memory (layer 0: fragments requested two steps ahead) or from the image (16-byte LDS
+        // reads) — so that neither carries the other's registers
+        auto kloop = [&](auto FIRST) {
+            constexpr bool GLB = decltype(FIRST)::value;
+            u32x4_g wreg[2][WQ], areg[2][GLB ? 2 : 1];
+            auto load_w = [&](auto SET, int ks) {
+                constexpr int S_ = decltype(SET)::value;
+                const uint32_t dead = ks < nks ? 0u : 0xfffffff0u;
+#pragma unroll
+                for (int q = 0; q < WQ; ++q) wreg[S_][q] = __builtin_amdgcn_raw_buffer_load_b128(rw, (woff[q] + 64u * ks) | dead, 0, 0);
+                if constexpr (GLB) {
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) areg[S_][rt] = __builtin_amdgcn_raw_buffer_load_b128(rx, (xoff[rt] + 64u * ks) | dead, 0, 0);
+                }
+            };
+            auto store_w = [&](auto SET) {
+                constexpr int S_ = decltype(SET)::value;
+#pragma unroll
+                for (int q = 0; q < WQ; ++q)
+                    if (wlds[q] >= 0) *reinterpret_cast<u32x4_g*>(Ws0 + S_ * SLAB + wlds[q]) = wreg[S_][q];
+            };
+            load_w(S0{}, 0);
+            load_w(S1{}, 1);
+            u32x4_g a_cur[2];
+            if constexpr (GLB) { a_cur[0] = areg[0][0]; a_cur[1] = areg[0][1]; }
+            store_w(S0{});
+            __syncthreads();                                             // slab 0 visible; the image of the previous layer complete
+            auto step = [&](auto SET, auto OTHER, int ks) {
+                constexpr int S_ = decltype(SET)::value, O_ = decltype(OTHER)::value;
+                const u32x4_g km = ks == nks - 1 ? tailmask : allmask;
+                u32x4_g c0, c1;
+                if constexpr (GLB) { c0 = a_cur[0]; c1 = a_cur[1]; }
+                else {                                                   // A fragment of the image: row 16 rt + li, K step ks, k group lq
+                    c0 = *reinterpret_cast<const u32x4_g*>(Hg + ks * 2048 + gf_lds_off(li, lq));
+                    c1 = *reinterpret_cast<const u32x4_g*>(Hg + ks * 2048 + gf_lds_off(16 + li, lq));
+                }
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, c0 & km), a1 = __builtin_bit_cast(bf16x8, c1 & km);
+                if constexpr (GLB) { a_cur[0] = areg[O_][0]; a_cur[1] = areg[O_][1]; }
+                store_w(OTHER);
+                load_w(SET, ks + 2);
+                const unsigned char* slab = Ws0 + S_ * SLAB;
+#pragma unroll
+                for (int c = 0; c < NTP; ++c)
+                    if (c_lo + c < nt) {
+                        const bf16x8 b = *reinterpret_cast<const bf16x8*>(slab + b_rd + 1024 * c);
+                        acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][c], 0, 0, 0);
+                        acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][c], 0, 0, 0);
+                    }
+                __syncthreads();
+            };
+            for (int ks = 0; ks < nks; ks += 2) {
+                step(S0{}, S1{}, ks);
+                if (ks + 1 < nks) step(S1{}, S0{}, ks + 1);
+            }
+        };
+        if (first) kloop(std::true_type{}); else kloop(std::false_type{});
+        // every wave is past its last read of the image (the K loop's final barrier): the result may overwrite it
+#pragma unroll
+        for (int c = 0; c < NTP; ++c)
+            if (c_lo + c < nt) {
+                const bf16x8 sf = __builtin_bit_cast(bf16x8, u32x4_g{pack2(acc[0][c][0], acc[0][c][1]), pack2(acc[0][c][2], acc[0][c][3]),
+                                                                       pack2(acc[1][c][0], acc[1][c][1]), pack2(acc[1][c][2], acc[1][c][3])});
+                const int o0 = 16 * (c_lo + c) + 4 * lq;
+                float bv[4];
+                bv[0] = bf2f(static_cast<uint16_t>(bvec[c].x & 0xffffu)); bv[1] = bf2f(static_cast<uint16_t>(bvec[c].x >> 16));
+                bv[2] = bf2f(static_cast<uint16_t>(bvec[c].y & 0xffffu)); bv[3] = bf2f(static_cast<uint16_t>(bvec[c].y >> 16));
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, adjf[it], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const int i = 16 * it + li;
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[q] = r[q] + bv[q]; v[q] = (v[q] > 0.f && o0 + q < D) ? v[q] : 0.f; }
+                    const u32x2_g pk = u32x2_g{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                    if (last) {
+                        const uint32_t off = (g < p.B && i < n && o0 < p.ldo) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.ldo + o0) * 2) : 0xfffffff0u;
+                        __builtin_amdgcn_raw_buffer_store_b64(pk, ro, off, 0, 0);
+                    } else if (o0 < 32 * nkh) {
+                        // rows of nodes past n hold relu(bias): the per-layer kernel never stores them and reads them back as zeros; adj's
+                        // columns for them are zero (out-of-range loads), so they never reach a result
+                        *reinterpret_cast<u32x2_g*>(Hg + (o0 >> 5) * 2048 + gf_lds_off(i, (o0 & 31) >> 3) + 2 * (o0 & 7)) = pk;
+                    }
+                }
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ fused backward (n <= 32)
 // g_support = adj^T (grad_out . [out > 0])  and  g_x = g_support W^T  in ONE kernel, the mirror image of the fused forward: the small
 // product comes first here, so its operand has to be TRANSPOSED on the way in — the masked gradient tile of a graph ([32 nodes][out] bf16,
@@ -695,4 +875,45 @@ extern "C" int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* b, recon_stream_t
         RECON_CHECK_LAUNCH();
     }
     return RECON_OK;
+}
+
+extern "C" int recon_gcn_b16_stack_fwd(const recon_gcn_b16_stack_args* a, recon_stream_t stream) {
+    if (!a || a->B < 0 || a->n <= 0 || a->in_features <= 0 || a->hidden <= 0 || a->L < 1 || a->L > kMaxStack) return RECON_ERR_INVALID;
+    if (!a->x || !a->adj || !a->out || !a->w_planes) return RECON_ERR_INVALID;
+    for (int l = 0; l < a->L; ++l) if (!a->w_planes[l]) return RECON_ERR_INVALID;
+    const int64_t o8 = (a->hidden + 7) / 8 * 8;
+    if ((a->ldx & 1) || a->ldx < a->in_features || (a->ldo & 7) || a->ldo < o8) return RECON_ERR_INVALID;
+    // the shapes of the fused single-layer forward, with 8-byte adjacency / bias loads: n % 4 == 0, hidden % 4 == 0
+    if (a->n > 32 || (a->n & 3) || a->ldo > kFusedNT * 16 || (a->hidden & 3) || a->B > 65535 * 4) return RECON_ERR_UNSUPPORTED;
+    if (static_cast<int64_t>(a->B) * a->n * a->ldx * 2 >= 0x7fffffffLL || static_cast<int64_t>(a->B) * a->n * a->ldo * 2 >= 0x7fffffffLL) return RECON_ERR_UNSUPPORTED;
+    uintptr_t al = reinterpret_cast<uintptr_t>(a->x) | reinterpret_cast<uintptr_t>(a->out);
+    for (int l = 0; l < a->L; ++l) al |= reinterpret_cast<uintptr_t>(a->w_planes[l]);
+    if ((al & 15) || (reinterpret_cast<uintptr_t>(a->adj) & 7)) return RECON_ERR_UNSUPPORTED;
+    for (int l = 0; l < a->L; ++l) if (a->bias && a->bias[l] && (reinterpret_cast<uintptr_t>(a->bias[l]) & 7)) return RECON_ERR_UNSUPPORTED;
+    if (a->B == 0) return RECON_OK;
+    GcnStackK k{};
+    k.x = static_cast<const uint16_t*>(a->x); k.ldx = a->ldx; k.adj = static_cast<const uint16_t*>(a->adj);
+    for (int l = 0; l < a->L; ++l) {
+        k.wt[l] = static_cast<const uint16_t*>(a->w_planes[l]);
+        k.bias[l] = (a->bias && a->bias[l]) ? static_cast<const uint16_t*>(a->bias[l]) : nullptr;
+    }
+    k.out = static_cast<uint16_t*>(a->out); k.ldo = a->ldo;
+    k.B = a->B; k.n = a->n; k.I0 = a->in_features; k.D = a->hidden; k.L = a->L; k.nt = static_cast<int32_t>(ceil_div64(a->ldo, 16));
+    const size_t lds = 2ull * kFusedNT * 16 * 64 + 4ull * ((a->hidden + 31) / 32) * 2048;
+    // column parts per graph: 2 (eight waves of 80 accumulator registers) — with 4 the sixteen waves' 128 registers spill (63 against 49 us at cfg 3a)
+    static const int ns = [] { const char* e = getenv("RECON_GCN_STACK_PARTS"); const int v = e ? atoi(e) : 2; return v == 4 ? 4 : 2; }();
+    if (ns == 4) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gcn_b16_stack_fwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        hipLaunchKernelGGL(k_gcn_b16_stack_fwd<4>, dim3(static_cast<unsigned>(ceil_div64(a->B, 4))), dim3(1024), lds, as_stream(stream), k);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gcn_b16_stack_fwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        hipLaunchKernelGGL(k_gcn_b16_stack_fwd<2>, dim3(static_cast<unsigned>(ceil_div64(a->B, 4))), dim3(512), lds, as_stream(stream), k);
+    }
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+extern "C" int recon_gcn_b16_transposed_planes(const void* weight, int32_t in_features, int32_t out_features, void* planes, recon_stream_t stream) {
+    if (!weight || !planes || in_features <= 0 || out_features <= 0) return RECON_ERR_INVALID;
+    return b16_pad_planes(weight, out_features, true, out_features, in_features, planes, as_stream(stream));     // W^T [out][kp(in)], zero padded along k
 }

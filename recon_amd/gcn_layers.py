@@ -383,6 +383,73 @@ def _mm(a, b, a_t, b_t):
     return torch.mm(a.t() if a_t else a, b.t() if b_t else b)
 
 
+_STACK_PLANES = {}     # (weight data_ptr, version, in, out, device) -> (W^T planes, weight)
+
+
+def invalidate_stack_planes():
+    """Drop the repacked weights gcn_stack() keeps (after an in-place write through `weight.data`)."""
+    _STACK_PLANES.clear()
+
+
+def gcn_stack(x, adj, layers):
+    """`for l in layers: x = l(x, adj)` — the reference's stacks of GraphConvolutions over one adjacency (models/layers.py:57-63 applied
+    len(layers) times) — as ONE launch where that is possible: bfloat16 tensors, inference (torch.no_grad() or nothing requiring grad),
+    graphs of n <= 32 nodes with n % 4 == 0, every layer hidden -> hidden after the first with hidden % 4 == 0, hidden <= 320.  The
+    activations of a graph stay in LDS between the layers (csrc/gcn_b16.hip: k_gcn_b16_stack_fwd); the result is bit-equal to the loop,
+    which is also what runs for every other case.  Repacked weights are kept per weight tensor (identity + version); call
+    invalidate_stack_planes() after writing through `weight.data`."""
+    layers = list(layers)
+    need_grad = torch.is_grad_enabled() and (x.requires_grad or adj.requires_grad or any(p.requires_grad for l in layers for p in l.parameters()))
+    ok = (len(layers) >= 2 and len(layers) <= 8 and not need_grad and x.is_cuda and x.dtype == torch.bfloat16 and adj.dtype == torch.bfloat16
+          and x.dim() in (2, 3) and os.environ.get("RECON_GCN_STACK", "1") != "0")
+    if ok:
+        n, I = x.shape[-2], x.shape[-1]
+        B = x.numel() // (n * I) if x.numel() else 0
+        D = layers[0].out_features
+        ok = (B > 0 and n <= 32 and n % 4 == 0 and D % 4 == 0 and (D + 7) // 8 * 8 <= 320 and layers[0].in_features == I
+              and all(l.in_features == D and l.out_features == D for l in layers[1:])
+              and all(l.weight.dtype == torch.bfloat16 and (l.bias is None or l.bias.data_ptr() % 8 == 0) for l in layers)
+              and x.is_contiguous() and I % 2 == 0 and x.data_ptr() % 16 == 0 and adj.is_contiguous() and adj.data_ptr() % 8 == 0
+              and adj.numel() == B * n * n and B * n * max(I, (D + 7) // 8 * 8) * 2 < 2 ** 31 - 1 and B <= 4 * _MAX_BATCH)
+    if not ok:
+        for l in layers:
+            x = l(x, adj)
+        return x
+    dev = x.device
+    L = _lib.lib()
+    o8 = (D + 7) // 8 * 8
+    planes = []
+    with _lib.on_device(dev):
+        for l in layers:
+            w = l.weight
+            key = (w.data_ptr(), w._version, l.in_features, D, str(dev))
+            hit = _STACK_PLANES.get(key)
+            if hit is None:
+                kp = (l.in_features + 31) // 32 * 32
+                pl = torch.empty(D * kp, dtype=torch.bfloat16, device=dev)
+                _lib.check(L.recon_gcn_b16_transposed_planes(w.detach().contiguous().data_ptr(), l.in_features, D, pl.data_ptr(), _lib.current_stream()),
+                           "recon_gcn_b16_transposed_planes")
+                if len(_STACK_PLANES) >= 64:
+                    _STACK_PLANES.clear()
+                hit = _STACK_PLANES[key] = (pl, w)
+            planes.append(hit[0])
+        out_p = torch.empty(B * n, o8, dtype=torch.bfloat16, device=dev)
+        parr = (C.c_void_p * len(layers))(*[pl.data_ptr() for pl in planes])
+        barr = (C.c_void_p * len(layers))(*[(l.bias.data_ptr() if l.bias is not None else None) for l in layers])
+        args = _lib.GcnB16StackArgs(B, n, I, D, len(layers), x.data_ptr(), I, adj.data_ptr(), parr, barr, out_p.data_ptr(), o8)
+        rc = L.recon_gcn_b16_stack_fwd(C.byref(args), _lib.current_stream())
+    if rc == -2:                                                            # RECON_ERR_UNSUPPORTED: layer by layer
+        for l in layers:
+            x = l(x, adj)
+        return x
+    _lib.check(rc, "recon_gcn_b16_stack_fwd")
+    if o8 == D:
+        return out_p.view(x.shape[:-1] + (D,))
+    out = out_p.as_strided(x.shape[:-1] + (D,), _strides(x.shape[:-1], o8))
+    out._recon_padded = True
+    return out
+
+
 class GraphConvolution(Module):
     """Simple GCN layer, models/layers.py:35-68: relu(adj @ (input @ weight) + bias)."""
 

@@ -633,6 +633,35 @@ def test_gcn_bf16_stack_reads_padded_rows_in_place():
     assert torch.equal(y2d, layers[0](x.detach(), adj)[0])
 
 
+@pytest.mark.parametrize("B,n,I,D,L", [(9, 32, 300, 300, 3), (5, 32, 40, 136, 2), (7, 8, 300, 64, 4), (1030, 32, 300, 300, 3), (3, 12, 22, 320, 3), (6, 31, 300, 300, 3)])
+def test_gcn_stack_bf16_is_bit_equal_to_the_layers(B, n, I, D, L, monkeypatch):
+    """gcn_stack(): L GraphConvolutions over one adjacency in one launch, the activations in LDS between the layers — the bits of the
+    layer-by-layer loop (same fragments, same MFMA order), and within bf16 rounding of the fp32 oracle.  (n = 31: not a multiple of 4,
+    the loop runs.)  Parts = 2 and 4 waves per graph."""
+    from recon_amd.gcn_layers import GraphConvolution, gcn_stack
+    d_ = dev()
+    g = torch.Generator().manual_seed(B + n + I)
+    x = _bf(torch.randn(B, n, I, generator=g)).to(d_)
+    adj = (torch.rand(B, n, n, generator=g) < 0.2).float() + torch.eye(n)
+    adj = _bf(adj / adj.sum(-1, keepdim=True)).to(d_)
+    torch.manual_seed(4)
+    layers = [GraphConvolution(I if l == 0 else D, D).to(torch.bfloat16).to(d_).eval() for l in range(L)]
+    with torch.no_grad():
+        fused = gcn_stack(x, adj, layers)
+        h = x
+        for l in layers:
+            h = l(h, adj)
+    assert fused.shape == h.shape and fused.dtype == torch.bfloat16
+    assert torch.equal(fused, h), "fused stack differs from the layer loop: max %g" % (fused.float() - h.float()).abs().max().item()
+    hr = x.float().cpu()
+    for l in layers:
+        hr = O.graph_convolution(hr, adj.float().cpu(), l.weight.detach().float().cpu(), l.bias.detach().float().cpu())
+    close(fused.float(), hr, atol=2e-3, rel_to_max=4e-2, what="stack vs oracle")
+    y = gcn_stack(x.requires_grad_(True), adj, layers)                   # gradients wanted: the loop, with autograd
+    y.float().sum().backward()
+    assert x.grad is not None
+
+
 def test_gcn_bf16_frozen_weight_planes_follow_updates():
     """A layer in eval() mode keeps its repacked weight across calls (keyed on identity + version): an in-place update of the weight
     must be seen by the next call, a second call without an update must give the same bits; a write through `.data` (invisible to the

@@ -3,4 +3,4 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 torch.autograd.set_multithreading_enabled(False)
 from tools import secondary as S
-print(json.dumps({"cfg5_mixed_stack_bf16": S.powerlaw_mixed_stack_bf16(iters=6)}))
+print(json.dumps({"cfg3a_gcn_bf16": S.gcn_bf16(iters=10)}))
