@@ -371,68 +371,94 @@ struct GcnStackK {
     int32_t B, n, I0, D, L, nt;                                          // in_0 = I0, every layer's out = in_{l+1} = D; nt = ceil(ldo / 16)
 };
 
+// Every operand arrives by range-checked LDS-DMA (buffer_load ... lds: no staging registers, rows / columns that do not exist come back as
+// zeros): the graphs' x tiles straight into the activation images at the start, the W^T slabs of ALL layers through a ring of three
+// 20-KiB slabs two K steps ahead (counted vmcnt, raw s_barrier: the copies stay in flight across the barriers; the first form of this
+// kernel staged W through registers one step ahead and waited for it at every step).  One K-loop body for every layer; NS = 4 column parts
+// = 16 waves per CU fit without spills because nothing but accumulators and fragments lives in registers.
 template <int NS>
 __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStackK p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char st_sm[];      // W^T slab [2][20 KiB] | activations [4 graphs][NKH][2 KiB]
-    constexpr int NTP = kFusedNT / NS, NTHR = 256 * NS, SLAB = kFusedNT * 16 * 64;
-    unsigned char* Ws0 = st_sm;
+    extern __shared__ __attribute__((aligned(16))) unsigned char st_sm[];      // W^T slabs [3][20 KiB] | activations [4 graphs][NKI][2 KiB] | scratch 1 KiB
+    constexpr int NTP = kFusedNT / NS, NW = 4 * NS, SLAB = kFusedNT * 16 * 64, NRING = 3;
+    constexpr int SP = kFusedNT;                                         // pieces (16 rows x 64 B) of a slab
+    constexpr int NDW = (SP + NW - 1) / NW;                               // copy instructions per wave and slab (waves past the last piece: scratch)
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 15, lq = lane >> 4;
-    const int g = blockIdx.x * 4 + (w & 3);
+    const int gw = w & 3, g = blockIdx.x * 4 + gw;
     const int c_lo = (w >> 2) * NTP;
     const int n = p.n, nt = p.nt, D = p.D;
-    const int nkh = (D + 31) >> 5;                                       // K steps of the layers whose input is the image
-    unsigned char* Hg = st_sm + 2 * SLAB + (w & 3) * nkh * 2048;
+    const int nk0 = (p.I0 + 31) >> 5, nkh = (D + 31) >> 5, nki = nk0 > nkh ? nk0 : nkh;      // K steps of layer 0 / of the others / of an image
+    unsigned char* Hg = st_sm + NRING * SLAB + gw * nki * 2048;
+    const int scratch = NRING * SLAB + 4 * nki * 2048;
     const int64_t rows_total = static_cast<int64_t>(p.B) * n;
-    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0,
-                                                      static_cast<int>(min<int64_t>(rows_total * p.ldx * 2, 0x7fffffff)), 0x00020000);
-    uint32_t xoff[2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        const int i = 16 * rt + li;
-        xoff[rt] = (g < p.B && i < n) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.ldx + 8 * lq) * 2) : 0xfffffff0u;
-    }
-    constexpr int WQ = (kFusedNT * 16 * 4 + NTHR - 1) / NTHR;
-    // adj^T fragments (8-byte loads: n % 4 == 0, adj 8-byte aligned — checked by the host), kept for all layers
-    u32x2_g adjv[2][2];
-    const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.adj), 0,
-                                                      static_cast<int>(min<int64_t>(static_cast<int64_t>(p.B) * n * n * 2, 0x7fffffff)), 0x00020000);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int i = 16 * it + li;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int j0 = 16 * h + 4 * lq;
-            const uint32_t base = static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * n + j0) * 2);
-            adjv[it][h] = __builtin_amdgcn_raw_buffer_load_b64(ra, (g < p.B && i < n && j0 < n) ? base : 0xfffffff0u, 0, 0);
+    // copy lanes: LDS slot s = 64 piece + lane of a [16 rows][64 B] piece -> (row s >> 2, k group under the slot rotation of gf_lds_off)
+    const int c_row = lane >> 2, c_kq = ((lane & 3) - 2 * (c_row >> 3)) & 3;
+    // ---- x tiles of the workgroup's four graphs into the images: piece = (graph, K step, row half); rows past n and graphs past B read as zeros
+    {
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0,
+                                                          static_cast<int>(min<int64_t>(rows_total * p.ldx * 2, 0x7fffffff)), 0x00020000);
+        const int npc = 4 * nk0 * 2;
+        for (int pc = w; pc < npc; pc += NW) {                          // wave-uniform
+            const int gq = pc / (2 * nk0), r = pc - gq * 2 * nk0, ks = r >> 1, half = r & 1;
+            const int gg = blockIdx.x * 4 + gq, i = 16 * half + c_row;
+            const uint32_t off = (gg < p.B && i < n) ? static_cast<uint32_t>(((static_cast<int64_t>(gg) * n + i) * p.ldx + 32 * ks + 8 * c_kq) * 2) : 0xfffffff0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(st_sm + NRING * SLAB + gq * nki * 2048 + ks * 2048 + half * 1024), 16, off, 0, 0, 0);
         }
     }
-    bf16x8 adjf[2];
+    // ---- the W^T slab of flat step f = (layer, K step): this wave's pieces; steps past the end copy nothing real (scratch)
+    int il = 0, ik = 0, ib = 0;                                          // issue side: layer, K step, ring slot
+    auto issue = [&]() {
+        const bool live = il < p.L;
+        const int I = il == 0 ? p.I0 : D, Ip = (I + 31) & ~31;
+        const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wt[live ? il : 0]), 0, live ? D * Ip * 2 : 0, 0x00020000);
 #pragma unroll
-    for (int it = 0; it < 2; ++it) adjf[it] = __builtin_bit_cast(bf16x8, u32x4_g{adjv[it][0].x, adjv[it][0].y, adjv[it][1].x, adjv[it][1].y});
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
+        for (int q = 0; q < NDW; ++q) {
+            const int pc = q * NW + w;                                   // wave-uniform
+            const bool real = live && pc < SP;
+            const int o = 16 * pc + c_row;
+            const uint32_t off = (real && o < 16 * nt) ? static_cast<uint32_t>((o * Ip + 32 * ik + 8 * c_kq) * 2) : 0xfffffff0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st_sm + (real ? ib * SLAB + 1024 * pc : scratch)), 16, off, 0, 0, 0);
+        }
+        const int nk = il == 0 ? nk0 : nkh;
+        if (++ik >= nk) { ik = 0; ++il; }
+        ib = ib + 1 == NRING ? 0 : ib + 1;
+    };
+    issue();
+    issue();
+    // adj^T fragments (8-byte loads: n % 4 == 0, adj 8-byte aligned — checked by the host), kept for all layers
+    bf16x8 adjf[2];
+    {
+        const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.adj), 0,
+                                                          static_cast<int>(min<int64_t>(static_cast<int64_t>(p.B) * n * n * 2, 0x7fffffff)), 0x00020000);
+        u32x2_g adjv[2][2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = 16 * it + li;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j0 = 16 * h + 4 * lq;
+                const uint32_t base = static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * n + j0) * 2);
+                adjv[it][h] = __builtin_amdgcn_raw_buffer_load_b64(ra, (g < p.B && i < n && j0 < n) ? base : 0xfffffff0u, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) adjf[it] = __builtin_bit_cast(bf16x8, u32x4_g{adjv[it][0].x, adjv[it][0].y, adjv[it][1].x, adjv[it][1].y});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the x tiles, the first two slabs, adj
     const u32x4_g allmask = u32x4_g{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     const int b_rd = gf_lds_off(li, lq) + 1024 * c_lo;
+    const int a_rd0 = gf_lds_off(li, lq), a_rd1 = gf_lds_off(16 + li, lq);
     const auto ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, static_cast<int>(min<int64_t>(rows_total * p.ldo * 2, 0x7fffffff)), 0x00020000);
     auto pack2 = [](float a, float b) { return static_cast<uint32_t>(f2bf(a)) | (static_cast<uint32_t>(f2bf(b)) << 16); };
+    int cb = 0;                                                          // ring slot of the step being computed
+    bool started = false;
 
 #pragma unroll 1
     for (int l = 0; l < p.L; ++l) {
-        const bool first = l == 0, last = l == p.L - 1;
-        const int I = first ? p.I0 : D, Ip = (I + 31) & ~31, nks = Ip >> 5;
-        const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wt[l]), 0, D * Ip * 2, 0x00020000);
-        uint32_t woff[WQ]; int wlds[WQ];
-#pragma unroll
-        for (int q = 0; q < WQ; ++q) {
-            const int s = t + NTHR * q, o = s >> 2, kq = s & 3;
-            woff[q] = (o < 16 * nt) ? static_cast<uint32_t>((o * Ip + 8 * kq) * 2) : 0xfffffff0u;
-            wlds[q] = o < kFusedNT * 16 ? gf_lds_off(o, kq) : -1;
-        }
+        const bool last = l == p.L - 1;
+        const int I = l == 0 ? p.I0 : D, nks = l == 0 ? nk0 : nkh;
         const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.bias[l] ? p.bias[l] : p.x), 0, p.bias[l] ? D * 2 : 0, 0x00020000);
         u32x2_g bvec[NTP];
-#pragma unroll
-        for (int c = 0; c < NTP; ++c) bvec[c] = __builtin_amdgcn_raw_buffer_load_b64(rb, static_cast<uint32_t>((16 * (c_lo + c) + 4 * lq) * 2), 0, 0);
         u32x4_g tailmask;
         {
             const int k0 = 32 * (nks - 1) + 8 * lq;
@@ -446,91 +472,65 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int c = 0; c < NTP; ++c) acc[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // the K loop in two copies — x from global memory (layer 0: fragments requested two steps ahead) or from the image (16-byte LDS
-        // reads) — so that neither carries the other's registers
-        auto kloop = [&](auto FIRST) {
-            constexpr bool GLB = decltype(FIRST)::value;
-            u32x4_g wreg[2][WQ], areg[2][GLB ? 2 : 1];
-            auto load_w = [&](auto SET, int ks) {
-                constexpr int S_ = decltype(SET)::value;
-                const uint32_t dead = ks < nks ? 0u : 0xfffffff0u;
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ++ks) {
+            // this wave's copies of this step have landed (those of the next step may still travel) ...
+            if (started) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDW) : "memory");
+            started = true;
+            // ... everybody's have, everybody is past the previous step's reads of the slab that is requested next, and (first step of a
+            // layer) the image written by the previous layer's epilogue is complete
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue();
+            const unsigned char* slab = st_sm + cb * SLAB;
+            const u32x4_g km = ks == nks - 1 ? tailmask : allmask;
+            const u32x4_g c0 = *reinterpret_cast<const u32x4_g*>(Hg + ks * 2048 + a_rd0), c1 = *reinterpret_cast<const u32x4_g*>(Hg + ks * 2048 + a_rd1);
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, c0 & km), a1 = __builtin_bit_cast(bf16x8, c1 & km);
+            bf16x8 bq[NTP];
 #pragma unroll
-                for (int q = 0; q < WQ; ++q) wreg[S_][q] = __builtin_amdgcn_raw_buffer_load_b128(rw, (woff[q] + 64u * ks) | dead, 0, 0);
-                if constexpr (GLB) {
+            for (int c = 0; c < NTP; ++c) bq[c] = *reinterpret_cast<const bf16x8*>(slab + b_rd + 1024 * c);
 #pragma unroll
-                    for (int rt = 0; rt < 2; ++rt) areg[S_][rt] = __builtin_amdgcn_raw_buffer_load_b128(rx, (xoff[rt] + 64u * ks) | dead, 0, 0);
-                }
-            };
-            auto store_w = [&](auto SET) {
-                constexpr int S_ = decltype(SET)::value;
-#pragma unroll
-                for (int q = 0; q < WQ; ++q)
-                    if (wlds[q] >= 0) *reinterpret_cast<u32x4_g*>(Ws0 + S_ * SLAB + wlds[q]) = wreg[S_][q];
-            };
-            load_w(S0{}, 0);
-            load_w(S1{}, 1);
-            u32x4_g a_cur[2];
-            if constexpr (GLB) { a_cur[0] = areg[0][0]; a_cur[1] = areg[0][1]; }
-            store_w(S0{});
-            __syncthreads();                                             // slab 0 visible; the image of the previous layer complete
-            auto step = [&](auto SET, auto OTHER, int ks) {
-                constexpr int S_ = decltype(SET)::value, O_ = decltype(OTHER)::value;
-                const u32x4_g km = ks == nks - 1 ? tailmask : allmask;
-                u32x4_g c0, c1;
-                if constexpr (GLB) { c0 = a_cur[0]; c1 = a_cur[1]; }
-                else {                                                   // A fragment of the image: row 16 rt + li, K step ks, k group lq
-                    c0 = *reinterpret_cast<const u32x4_g*>(Hg + ks * 2048 + gf_lds_off(li, lq));
-                    c1 = *reinterpret_cast<const u32x4_g*>(Hg + ks * 2048 + gf_lds_off(16 + li, lq));
-                }
-                const bf16x8 a0 = __builtin_bit_cast(bf16x8, c0 & km), a1 = __builtin_bit_cast(bf16x8, c1 & km);
-                if constexpr (GLB) { a_cur[0] = areg[O_][0]; a_cur[1] = areg[O_][1]; }
-                store_w(OTHER);
-                load_w(SET, ks + 2);
-                const unsigned char* slab = Ws0 + S_ * SLAB;
-#pragma unroll
-                for (int c = 0; c < NTP; ++c)
-                    if (c_lo + c < nt) {
-                        const bf16x8 b = *reinterpret_cast<const bf16x8*>(slab + b_rd + 1024 * c);
-                        acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][c], 0, 0, 0);
-                        acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][c], 0, 0, 0);
-                    }
-                __syncthreads();
-            };
-            for (int ks = 0; ks < nks; ks += 2) {
-                step(S0{}, S1{}, ks);
-                if (ks + 1 < nks) step(S1{}, S0{}, ks + 1);
+            for (int c = 0; c < NTP; ++c) {
+                acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq[c], acc[0][c], 0, 0, 0);
+                acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq[c], acc[1][c], 0, 0, 0);
             }
-        };
-        if (first) kloop(std::true_type{}); else kloop(std::false_type{});
-        // every wave is past its last read of the image (the K loop's final barrier): the result may overwrite it
+            cb = cb + 1 == NRING ? 0 : cb + 1;
+        }
 #pragma unroll
-        for (int c = 0; c < NTP; ++c)
-            if (c_lo + c < nt) {
-                const bf16x8 sf = __builtin_bit_cast(bf16x8, u32x4_g{pack2(acc[0][c][0], acc[0][c][1]), pack2(acc[0][c][2], acc[0][c][3]),
-                                                                       pack2(acc[1][c][0], acc[1][c][1]), pack2(acc[1][c][2], acc[1][c][3])});
-                const int o0 = 16 * (c_lo + c) + 4 * lq;
-                float bv[4];
-                bv[0] = bf2f(static_cast<uint16_t>(bvec[c].x & 0xffffu)); bv[1] = bf2f(static_cast<uint16_t>(bvec[c].x >> 16));
-                bv[2] = bf2f(static_cast<uint16_t>(bvec[c].y & 0xffffu)); bv[3] = bf2f(static_cast<uint16_t>(bvec[c].y >> 16));
+        for (int c = 0; c < NTP; ++c) bvec[c] = __builtin_amdgcn_raw_buffer_load_b64(rb, static_cast<uint32_t>((16 * (c_lo + c) + 4 * lq) * 2), 0, 0);
+        // every wave must be past its last read of the image before the result overwrites it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the bias values (and the copies in flight: the next step waits for them anyway)
+        started = false;
 #pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, adjf[it], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    const int i = 16 * it + li;
-                    float v[4];
+        for (int c = 0; c < NTP; ++c) {
+            const bf16x8 sf = __builtin_bit_cast(bf16x8, u32x4_g{pack2(acc[0][c][0], acc[0][c][1]), pack2(acc[0][c][2], acc[0][c][3]),
+                                                                   pack2(acc[1][c][0], acc[1][c][1]), pack2(acc[1][c][2], acc[1][c][3])});
+            const int o0 = 16 * (c_lo + c) + 4 * lq;
+            float bv[4];
+            bv[0] = bf2f(static_cast<uint16_t>(bvec[c].x & 0xffffu)); bv[1] = bf2f(static_cast<uint16_t>(bvec[c].x >> 16));
+            bv[2] = bf2f(static_cast<uint16_t>(bvec[c].y & 0xffffu)); bv[3] = bf2f(static_cast<uint16_t>(bvec[c].y >> 16));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { v[q] = r[q] + bv[q]; v[q] = (v[q] > 0.f && o0 + q < D) ? v[q] : 0.f; }
-                    const u32x2_g pk = u32x2_g{pack2(v[0], v[1]), pack2(v[2], v[3])};
-                    if (last) {
-                        const uint32_t off = (g < p.B && i < n && o0 < p.ldo) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.ldo + o0) * 2) : 0xfffffff0u;
-                        __builtin_amdgcn_raw_buffer_store_b64(pk, ro, off, 0, 0);
-                    } else if (o0 < 32 * nkh) {
-                        // rows of nodes past n hold relu(bias): the per-layer kernel never stores them and reads them back as zeros; adj's
-                        // columns for them are zero (out-of-range loads), so they never reach a result
-                        *reinterpret_cast<u32x2_g*>(Hg + (o0 >> 5) * 2048 + gf_lds_off(i, (o0 & 31) >> 3) + 2 * (o0 & 7)) = pk;
-                    }
-                }
+            for (int it = 0; it < 2; ++it) {
+                f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, adjf[it], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const int i = 16 * it + li;
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q] = r[q] + bv[q]; v[q] = (v[q] > 0.f && o0 + q < D) ? v[q] : 0.f; }
+                const u32x2_g pk = u32x2_g{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                // the last layer's result to memory (masked by an out-of-range offset), every other one into the image (tiles past it: scratch).
+                // Rows of nodes past n hold relu(bias): the per-layer kernel never stores them and reads them back as zeros; adj's columns
+                // for them are zero (out-of-range loads), so they never reach a result
+                const uint32_t off = (last && g < p.B && i < n && o0 < p.ldo) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.ldo + o0) * 2) : 0xfffffff0u;
+                __builtin_amdgcn_raw_buffer_store_b64(pk, ro, off, 0, 0);
+                unsigned char* hd = (!last && o0 < 32 * nkh) ? Hg + (o0 >> 5) * 2048 + gf_lds_off(i, (o0 & 31) >> 3) + 2 * (o0 & 7) : st_sm + scratch;
+                *reinterpret_cast<u32x2_g*>(hd) = pk;
             }
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // copies of steps past the end target this workgroup's LDS
 }
 
 // ------------------------------------------------------------------------------------------------ fused backward (n <= 32)
@@ -883,6 +883,7 @@ extern "C" int recon_gcn_b16_stack_fwd(const recon_gcn_b16_stack_args* a, recon_
     for (int l = 0; l < a->L; ++l) if (!a->w_planes[l]) return RECON_ERR_INVALID;
     const int64_t o8 = (a->hidden + 7) / 8 * 8;
     if ((a->ldx & 1) || a->ldx < a->in_features || (a->ldo & 7) || a->ldo < o8) return RECON_ERR_INVALID;
+    if (a->in_features > 16 * kFusedNT * 2) return RECON_ERR_UNSUPPORTED;
     // the shapes of the fused single-layer forward, with 8-byte adjacency / bias loads: n % 4 == 0, hidden % 4 == 0
     if (a->n > 32 || (a->n & 3) || a->ldo > kFusedNT * 16 || (a->hidden & 3) || a->B > 65535 * 4) return RECON_ERR_UNSUPPORTED;
     if (static_cast<int64_t>(a->B) * a->n * a->ldx * 2 >= 0x7fffffffLL || static_cast<int64_t>(a->B) * a->n * a->ldo * 2 >= 0x7fffffffLL) return RECON_ERR_UNSUPPORTED;
@@ -899,9 +900,11 @@ extern "C" int recon_gcn_b16_stack_fwd(const recon_gcn_b16_stack_args* a, recon_
     }
     k.out = static_cast<uint16_t*>(a->out); k.ldo = a->ldo;
     k.B = a->B; k.n = a->n; k.I0 = a->in_features; k.D = a->hidden; k.L = a->L; k.nt = static_cast<int32_t>(ceil_div64(a->ldo, 16));
-    const size_t lds = 2ull * kFusedNT * 16 * 64 + 4ull * ((a->hidden + 31) / 32) * 2048;
-    // column parts per graph: 2 (eight waves of 80 accumulator registers) — with 4 the sixteen waves' 128 registers spill (63 against 49 us at cfg 3a)
-    static const int ns = [] { const char* e = getenv("RECON_GCN_STACK_PARTS"); const int v = e ? atoi(e) : 2; return v == 4 ? 4 : 2; }();
+    const int64_t nki = ((a->in_features > a->hidden ? a->in_features : a->hidden) + 31) / 32;
+    const size_t lds = 3ull * kFusedNT * 16 * 64 + 4ull * nki * 2048 + 1024;
+    if (lds > 160 * 1024) return RECON_ERR_UNSUPPORTED;                 // in_features > 384: layer by layer
+    // column parts per graph: 4 (sixteen waves per CU; nothing but accumulators and fragments lives in registers)
+    static const int ns = [] { const char* e = getenv("RECON_GCN_STACK_PARTS"); const int v = e ? atoi(e) : 4; return v == 2 ? 2 : 4; }();
     if (ns == 4) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gcn_b16_stack_fwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         hipLaunchKernelGGL(k_gcn_b16_stack_fwd<4>, dim3(static_cast<unsigned>(ceil_div64(a->B, 4))), dim3(1024), lds, as_stream(stream), k);
