@@ -178,7 +178,10 @@ __device__ __forceinline__ int gf_lds_off(int row, int kq) { return row * 64 + (
 // accumulator registers, four waves per SIMD) hide what one wave per SIMD with 160 accumulator registers could not.
 template <int NS, bool VEC>
 __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_fwd(const GcnFusedK p) {
-    __shared__ __attribute__((aligned(16))) unsigned char Ws[2][kFusedNT * 16 * 64];      // one K step of W^T: [o][32 k], 2 x 20 KiB
+    constexpr int SLABF = kFusedNT * 16 * 64;
+    __shared__ __attribute__((aligned(16))) unsigned char Wsf[2 * SLABF + 16];     // one K step of W^T: [o][32 k], 2 x 20 KiB; 16 bytes nobody reads
+    // (pieces / column tiles that do not exist are written there / computed anyway: a guard per piece or tile is a basic block each, and
+    // the compiler drains its counters at every join — the K step had been ten times  LDS read -> wait -> two MFMAs  behind branches)
     constexpr int NTP = kFusedNT / NS, NTHR = 256 * NS;
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 15, lq = lane >> 4;
@@ -259,8 +262,7 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_fwd(const GcnFuse
     auto store_w = [&](auto SET) {
         constexpr int S_ = decltype(SET)::value;
 #pragma unroll
-        for (int q = 0; q < WQ; ++q)
-            if (wlds[q] >= 0) *reinterpret_cast<u32x4_g*>(&Ws[S_][wlds[q]]) = wreg[S_][q];
+        for (int q = 0; q < WQ; ++q) *reinterpret_cast<u32x4_g*>(Wsf + (wlds[q] >= 0 ? S_ * SLABF + wlds[q] : 2 * SLABF)) = wreg[S_][q];
     };
     f32x4 acc[2][NTP];
 #pragma unroll
@@ -294,14 +296,20 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_fwd(const GcnFuse
         const bf16x8 n0 = __builtin_bit_cast(bf16x8, areg[O_][0]), n1 = __builtin_bit_cast(bf16x8, areg[O_][1]);      // x fragments of step ks + 1
         store_w(OTHER);                                                  // slab of step ks + 1: its buffer was last read in step ks - 1, a barrier ago
         load_w(SET, ks + 2);                                             // set S_ is free: its W pieces are in LDS, its x fragments in a_cur
-        const unsigned char* slab = Ws[S_];
+        const unsigned char* slab = Wsf + S_ * SLABF;
+        constexpr int CG = NTP < 4 ? NTP : 4;                            // column tiles read ahead of their MFMAs (tiles past nt read zero rows of the slab)
 #pragma unroll
-        for (int c = 0; c < NTP; ++c)
-            if (c_lo + c < nt) {                                         // uniform
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(slab + b_rd + 1024 * c);
-                acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][c], 0, 0, 0);
-                acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][c], 0, 0, 0);
-            }
+        for (int c0 = 0; c0 < NTP; c0 += CG) {
+            bf16x8 bq[CG];
+#pragma unroll
+            for (int c = 0; c < CG; ++c) if (c0 + c < NTP) bq[c] = *reinterpret_cast<const bf16x8*>(slab + b_rd + 1024 * (c0 + c));
+#pragma unroll
+            for (int c = 0; c < CG; ++c)
+                if (c0 + c < NTP) {
+                    acc[0][c0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq[c], acc[0][c0 + c], 0, 0, 0);
+                    acc[1][c0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq[c], acc[1][c0 + c], 0, 0, 0);
+                }
+        }
         a_cur[0] = n0; a_cur[1] = n1;
         __syncthreads();
     };
