@@ -740,8 +740,6 @@ bool gcn_fused_ok(const recon_gcn_b16_args* a) {
            static_cast<int64_t>(a->B) * a->n * a->ldx * 2 < 0x7fffffffLL && static_cast<int64_t>(a->B) * a->n * a->ldo * 2 < 0x7fffffffLL;
 }
 
-constexpr int kBiasBlocks = 1024;
-
 int check(const recon_gcn_b16_args* a) {
     if (!a || a->B < 0 || a->n <= 0 || a->in_features <= 0 || a->out_features <= 0) return RECON_ERR_INVALID;
     if (!a->x || !a->adj || !a->weight || !a->out || !a->w_planes) return RECON_ERR_INVALID;

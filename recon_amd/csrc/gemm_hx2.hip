@@ -118,7 +118,6 @@ __device__ __forceinline__ void hx2_store_plain(const f32x4 (&acc)[2][TN], float
 
 constexpr int B_TILE_BYTES = T * BN * 64;                        // 26624: one buffer of the B image
 constexpr int B_PIECES = B_TILE_BYTES / 1024;                    // 26 pieces of 1 KiB (one LDS-DMA instruction of one wave each)
-constexpr int B_DMA = (B_PIECES + 3) / 4;                        // 7 rounds over the 4 waves
 
 // C = act(A . B^T / (s_a s_b)), both operands k-contiguous half planes.  A never touches LDS: the rows of a wave's
 // 32 x 208 block are private to that wave, so every lane loads its own MFMA fragments (row lane & 15, 8 consecutive k,

@@ -595,7 +595,11 @@ __global__ void __launch_bounds__(1024) k_propagate_fwd_s(const PropK p) {
                 // completion); the waits that matter for the ring are the explicit ones below.
                 const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(
                     static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void*)(dst + 1024 * i))));
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "m0", "memory");
+                // m0 is saved and restored inside the one asm block (listing it as a clobber is undefined behaviour for a reserved register:
+                // the compiler keeps its own LDS base there for its own LDS-DMA / GWS uses)
+                uint32_t m0_saved;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(m0_saved) : "v"(src), "s"(lds_addr) : "memory");
             }
         }
     };

@@ -392,3 +392,64 @@ def test_cfg5_bf16_ragged_stack_at_256_nodes():
         close(h.detach().float().cpu()[:, hh * D:(hh + 1) * D], r["out"].float(), atol=1e-3, rel_to_max=1e-2, what="cfg5 ragged gat out h%d" % hh)
         g_x = g_x + r["g_x"]
     close(xd.grad.float().cpu(), g_x.float(), atol=1e-3, rel_to_max=1e-2, what="cfg5 ragged gat g_x")
+
+
+# ------------------------------------------------------------------------------- cfg 3b at n = 32 in float32: the backward at the full batch
+@pytest.mark.parametrize("B,copies_of", [(300, 150), (1024, 8)])
+def test_cfg3b_n32_fp32_backward_across_slices_and_full_batch(B, copies_of):
+    """The wide-state backward (both products of a hop as batched GEMMs, csrc/prop.hip prop_bwd_wide) where round 3 had no gradient check:
+    B = 300 crosses a slice boundary of the forward's split workspace (256 graphs per slice), B = 1 024 is the benchmarked batch.  The
+    batch is copies of `copies_of` graphs: (i) the first two graphs — forward and EVERY gradient (d T_l, d identity through the block
+    adjacency, d h0) — against the float64 oracle, (ii) every copy bit-equal to the first (graphs are independent, the kernels
+    deterministic), which covers the graphs past the slice boundary."""
+    from recon_amd.propagation import build_block_adjacency, propagate
+    d_ = dev()
+    n, d, L, act = 32, 8, 3, "relu"
+    C, S, dd = n * (n - 1), 16 * n, 16
+    Ts, ident, h0, head, tail, Gr = _prop_problem(n, d, L, copies_of, seed=31, scale=0.02)
+    reps = B // copies_of
+    Tb = [t.to(d_).repeat(reps, 1, 1).requires_grad_(True) for t in Ts]
+    Ib = ident.to(d_).requires_grad_(True)
+    hb = h0.to(d_).repeat(reps, 1, 1, 1).requires_grad_(True)
+    Gb = Gr.to(d_).repeat(reps, 1, 1)
+    adjs = [build_block_adjacency(t, Ib, n) for t in Tb]
+    out = propagate(adjs, hb, act, head.to(d_), tail.to(d_))
+    (out * Gb).sum().backward()
+    del adjs
+    k = 2
+    Tr = [t[:k].double().requires_grad_(True) for t in Ts]
+    Ir = ident.double().requires_grad_(True)
+    hr = h0[:k].double().requires_grad_(True)
+    ref = O.propagate([O.build_block_adjacency(t, Ir, n) for t in Tr], hr, act, head, tail, as_gemm=True)
+    (ref * Gr[:k].double()).sum().backward()
+    close(out[:k], ref.detach().float(), atol=1e-4, rel_to_max=1e-5, what="n32 fp32 B=%d out" % B)
+    for l in range(L):
+        close(Tb[l].grad[:k], Tr[l].grad.float(), atol=1e-5, what="n32 fp32 B=%d g_T[%d]" % (B, l))
+    close(hb.grad[:k], hr.grad.float(), atol=1e-5, what="n32 fp32 B=%d g_h0" % B)
+    assert torch.isfinite(Ib.grad).all()
+    for t in [out, hb.grad] + [t.grad for t in Tb]:
+        v = t.reshape(reps, copies_of, -1)
+        assert torch.equal(v[1], v[0]) and torch.equal(v[reps - 1], v[0]), "copies of the same graphs differ"
+
+
+def test_propagate_blocks_trains_at_n32():
+    """propagate_blocks() with gradients at n = 32 (no fused block-mode backward exists there: block adjacency + propagation, both with
+    their own backward): forward and every gradient against the float64 oracle."""
+    from recon_amd.propagation import propagate_blocks
+    d_ = dev()
+    n, d, L, B, act = 32, 8, 2, 3, "tanh"
+    Ts, ident, h0, head, tail, Gr = _prop_problem(n, d, L, B, seed=17, scale=0.02)
+    Tl = [t.to(d_).requires_grad_(True) for t in Ts]
+    I = ident.to(d_).requires_grad_(True)
+    h = h0.to(d_).requires_grad_(True)
+    out = propagate_blocks(Tl, I, n, h, act, head.to(d_), tail.to(d_))
+    (out * Gr.to(d_)).sum().backward()
+    Tr = [t.double().requires_grad_(True) for t in Ts]
+    Ir, hr = ident.double().requires_grad_(True), h0.double().requires_grad_(True)
+    ref = O.propagate([O.build_block_adjacency(t, Ir, n) for t in Tr], hr, act, head, tail, as_gemm=True)
+    (ref * Gr.double()).sum().backward()
+    close(out, ref.detach().float(), atol=1e-4, rel_to_max=1e-5, what="blocks n32 training out")
+    close(I.grad, Ir.grad.float(), atol=1e-5, what="blocks n32 g_identity")
+    close(h.grad, hr.grad.float(), atol=1e-5, what="blocks n32 g_h0")
+    for l in range(L):
+        close(Tl[l].grad, Tr[l].grad.float(), atol=1e-5, what="blocks n32 g_T[%d]" % l)
