@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .graph import prepare_graph, _has_nhop, trust, trusted
+from .graph import prepare_graph, _has_nhop, trust, trusted, trust_bounds
 
 CUDA = torch.cuda.is_available()          # GAT/layers.py:9
 _DEBUG_NAN = os.environ.get("RECON_DEBUG_NAN", "0") == "1"
@@ -271,7 +271,7 @@ def _segment_key(index):
             _KEY_CACHE.clear()
         key = torch.stack((index, index))
         if trusted(index):
-            trust(key)
+            trust(key, bound=trust_bounds(index)[0])
         hit = _KEY_CACHE[k] = (key, index)      # keeps `index` alive: its data_ptr is the key
     return hit[0]
 
@@ -663,8 +663,8 @@ def _extended_index(index, n_rows, n_extra):
     hit = _INDEX_CACHE.get(key)
     if hit is None:
         ext = torch.cat((index, torch.arange(n_rows, n_rows + n_extra, dtype=torch.int64, device=index.device)))
-        if trusted(index):
-            trust(ext)
+        if trusted(index, n_rows):
+            trust(ext, bound=int(n_rows) + int(n_extra))
         hit = (ext, index)
         _INDEX_CACHE[key] = hit
         while len(_INDEX_CACHE) > 8:

@@ -18,18 +18,31 @@ _CACHE_MAX = 8
 _VALIDATE = os.environ.get("RECON_VALIDATE_EDGES", "1") != "0"
 
 
-def trust(*tensors):
+def trust(*tensors, bound=None, rel_bound=None):
     """Mark index tensors whose values are in range BY CONSTRUCTION (produced on the device from already validated data: the
     neighbour sampler's batches, keys derived inside this package).  Validation costs a host synchronisation per fresh tensor
-    (`aminmax` -> int()), and in the stage-A loop every iteration brings fresh tensors (GAT/main.py:478-516).  Returns its argument(s)."""
+    (`aminmax` -> int()), and in the stage-A loop every iteration brings fresh tensors (GAT/main.py:478-516).  The mark records the
+    tensor's version and the bound its values were validated against (`bound`: all values < bound; `rel_bound`: the second kind of id
+    in a mixed tensor — the 2-hop quadruples hold entity and relation ids — handed down to the tensors derived from it): it is honoured
+    only while the tensor has not been written to since, and only by a consumer whose own limit is not smaller.  Returns its argument(s)."""
     for t in tensors:
         if torch.is_tensor(t):
-            t._recon_trusted = True
+            t._recon_trusted = (t._version, None if bound is None else int(bound), None if rel_bound is None else int(rel_bound))
     return tensors[0] if len(tensors) == 1 else tensors
 
 
-def trusted(t):
-    return getattr(t, "_recon_trusted", False)
+def trusted(t, limit=None):
+    """Whether `t` carries a valid mark for a consumer that indexes `limit` rows: unmodified since it was marked, and validated against a
+    bound <= limit (a mark without a bound — keys built inside this package for exactly the table they index — passes)."""
+    m = getattr(t, "_recon_trusted", None)
+    if m is None or m[0] != t._version:
+        return False
+    return limit is None or m[1] is None or m[1] <= int(limit)
+
+
+def trust_bounds(t):
+    m = getattr(t, "_recon_trusted", None)
+    return (None, None) if m is None else (m[1], m[2])
 
 
 HUB_CHUNK = 64          # RECON_HUB_CHUNK (include/recon_hip.h); 0 switches the splitting of long destination rows off (tests compare both)
@@ -50,7 +63,7 @@ class GraphCSR:
         if N >= 2 ** 31 or E >= 2 ** 31:
             raise ValueError("graph too large for int32 indices")
         dev = edge.device
-        if E > 0 and _VALIDATE and validate and not trusted(edge):
+        if E > 0 and _VALIDATE and validate and not trusted(edge, N):
             # once per cached graph (one host sync): ids outside [0, N) would be truncated to int32, sorted on too few bits
             # and make the edge kernels read out of bounds; the reference fails on the same input (index out of range)
             lo, hi = torch.aminmax(edge)
@@ -109,13 +122,13 @@ class GraphCSR:
         key = (index.data_ptr(), index._version, tuple(index.stride()))
         hit = self._slot_idx.get(key)
         if hit is None:
-            if _VALIDATE and self.E > 0 and not trusted(index):
+            if _VALIDATE and self.E > 0 and not trusted(index, n_rows):
                 lo, hi = torch.aminmax(index)
                 if int(lo) < 0 or int(hi) >= n_rows:
                     raise IndexError("recon_amd: row index out of range: [%d, %d] into a table of %d rows" % (int(lo), int(hi), n_rows))
             slot_long = index[self.eid_long].contiguous()
-            if trusted(index):
-                trust(slot_long)                                              # a permutation of trusted values
+            if trusted(index, n_rows):
+                trust(slot_long, bound=trust_bounds(index)[0])                # a permutation of trusted values
             hit = (slot_long.to(torch.int32), slot_long, index)              # `index` pins data_ptr identity while cached
             if len(self._slot_idx) >= 4:
                 self._slot_idx.pop(next(iter(self._slot_idx)))
@@ -168,7 +181,7 @@ def prepare_graph(edge, edge_list_nhop, N, rows_only=False):
         _CACHE.move_to_end(key)
         return g
     full = torch.cat((edge, edge_list_nhop), dim=1) if nh else edge
-    g = GraphCSR(full, N, rows_only, validate=not (trusted(edge) and (not nh or trusted(edge_list_nhop))))
+    g = GraphCSR(full, N, rows_only, validate=not (trusted(edge, N) and (not nh or trusted(edge_list_nhop, N))))
     g._keepalive = (edge, edge_list_nhop if nh else None)   # pins data_ptr identity while cached
     _CACHE[key] = g
     while len(_CACHE) > _CACHE_MAX:

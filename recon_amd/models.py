@@ -7,7 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed, gather_rows, small_mm, IndexedRows
-from .graph import prepare_graph, trust, trusted
+from .graph import prepare_graph, trust, trusted, trust_bounds
 
 
 class _AliasHeadParams(torch.autograd.Function):
@@ -83,7 +83,7 @@ class SpGAT(nn.Module):
         if has_nhop:
             t0, t1 = edge_type_nhop[:, 0], edge_type_nhop[:, 1]
             if trusted(edge_type_nhop):
-                trust(t0, t1)                                             # views do not inherit the mark
+                trust(t0, t1, bound=trust_bounds(edge_type_nhop)[0])      # views do not inherit the mark
             edge_embed_nhop = gather_rows(relation_embed, t0) + gather_rows(relation_embed, t1)
         else:
             edge_embed_nhop = torch.tensor([])
@@ -140,7 +140,9 @@ class SpKBGATModified(nn.Module):
             q = train_indices_nhop.to(dev)
             edge_nhop, type_nhop = torch.stack((q[:, 3], q[:, 0])).contiguous(), q[:, 1:3].contiguous()
             if trusted(train_indices_nhop):
-                trust(edge_nhop, type_nhop)
+                eb, rb = trust_bounds(train_indices_nhop)                 # entity ids in columns 0 / 3, relation ids in 1 / 2
+                trust(edge_nhop, bound=eb)
+                trust(type_nhop, bound=rb)
             hit = (key, edge_nhop, type_nhop, train_indices_nhop)
             self._nhop_cache = hit
         return hit[1], hit[2]

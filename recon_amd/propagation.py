@@ -413,13 +413,16 @@ class _PropagateBlocks(torch.autograd.Function):
         return (g_h0, g_I, None, None, None, None) + tuple(g.view(sh) if g is not None else None for g, sh in zip(g_Ts, t_shapes))
 
 
-def blocks_mode_available(B, n, dd, h0, need_grad=True):
+def blocks_mode_available(B, n, dd, h0, need_grad=True, L=1, T_list=None):
     """Whether propagate_blocks() runs fused (two-term f16 kernels for the forward and, when gradients are wanted, for the backward:
-    2d = 16, n <= 9; forward only — inference — for 10 <= n <= 32; B within one launch)."""
+    2d = 16, n <= 9; forward only — inference — for 10 <= n <= 32; B within one launch).  `L` (hops) and `T_list` (the transition tensors:
+    16-byte alignment) make the probe exact: the wide form's LDS budget grows with the hop count."""
     if dd != 16 or n < 2 or n > 32 or B > _MAX_BATCH or B == 0 or os.environ.get("RECON_PROP_BLOCKS", "1") == "0":
         return False
+    if T_list is not None and any(t.data_ptr() % 16 for t in T_list):
+        return False
     Cn, S = n * (n - 1), n * dd
-    probe = _lib.PropArgs(B, Cn, S, 1, dd, 1, None, h0.data_ptr(), Cn * S if h0.dim() == 4 else 0, None, None, 0, None, None, None, None, None, None, 0)
+    probe = _lib.PropArgs(B, Cn, S, max(1, int(L)), dd, 1, None, h0.data_ptr(), Cn * S if h0.dim() == 4 else 0, None, None, 0, None, None, None, None, None, None, 0)
     if n > 10:          # wide states: the forward-only form of csrc/prop_hl.hip reads the transition tensors in place too
         return (not need_grad) and h0.data_ptr() % 16 == 0 and _lib.lib().recon_propagate_ws_bytes(C.byref(probe)) > 0
     form = _lib.lib().recon_propagate_form(C.byref(probe))
@@ -467,7 +470,7 @@ def propagate_blocks(T_list, identity, n, h0, nonlinearity, head_indices, tail_i
         if not need_grad and _blocks_b16_available(B, n, dd, h0, T_list, identity):
             return _propagate_blocks_b16(T_list, identity, n, h0, nonlinearity, head_indices, tail_indices)
         return propagate([build_block_adjacency(T, identity, n) for T in T_list], h0, nonlinearity, head_indices, tail_indices)
-    if not blocks_mode_available(B, n, dd, h0, need_grad):
+    if not blocks_mode_available(B, n, dd, h0, need_grad, L=len(T_list), T_list=T_list):
         return propagate([build_block_adjacency(T, identity, n) for T in T_list], h0, nonlinearity, head_indices, tail_indices)
     return _PropagateBlocks.apply(h0, identity, nonlinearity, head_indices, tail_indices, n, *T_list)
 

@@ -337,3 +337,22 @@ def test_propagation_workspace_queries():
     assert L.recon_propagate_ws_bytes(C.byref(args(4, 990, 512, 3, 16, trans=True))) == 0
     assert L.recon_propagate_bwd_ws_floats(C.byref(args(7, 992, 512, 3, 16))) == 7 * 992 * 512
     assert L.recon_propagate_bwd_ws_floats(C.byref(args(7, 72, 144, 3, 16))) == 0
+
+
+def test_trust_marks_carry_version_and_bound():
+    """graph.trust(): a mark is honoured only while the tensor is unmodified and only by a consumer whose table is at least as large as
+    the bound the values were validated against (advisor, round 3: a permanent object tag let an edited tensor, or a smaller entity table,
+    skip the only range check)."""
+    import torch
+    from recon_amd.graph import trust, trusted, trust_bounds
+    t = torch.arange(10)
+    assert not trusted(t)
+    trust(t, bound=10)
+    assert trusted(t) and trusted(t, 10) and trusted(t, 50)
+    assert not trusted(t, 9)                                              # a table of 9 rows: values up to 9 were allowed
+    t[3] = 1000                                                           # an in-place edit bumps the version: the mark is void
+    assert not trusted(t)
+    q = trust(torch.zeros(4, 4, dtype=torch.int64), bound=7, rel_bound=3)  # mixed ids (the 2-hop quadruples): both bounds handed down
+    assert trust_bounds(q) == (7, 3) and trust_bounds(torch.zeros(1)) == (None, None)
+    k = trust(torch.arange(5))                                            # keys built for exactly the table they index: no bound
+    assert trusted(k, 5) and trusted(k, 1)

@@ -263,6 +263,26 @@ def test_propagate_blocks_matches_unfused(n, L, B, act, per_batch, tied):
         close(a, b.float(), atol=1e-5, what="g_T vs oracle")
 
 
+def test_propagate_blocks_many_hops_at_wide_states_falls_back():
+    """n = 32 with eight hops: the wide two-term form's LDS image does not fit that many hops (its budget grows with L), so propagate_blocks()
+    must answer through block adjacency + propagate instead of raising (advisor, round 3: the availability probe used L = 1)."""
+    from recon_amd.propagation import propagate_blocks, blocks_mode_available, make_start_embedding, get_head_indices, get_tail_indices
+    d_ = dev()
+    n, d, L, B = 32, 8, 8, 1
+    dd, C, S = 16, n * (n - 1), 16 * n
+    g = torch.Generator().manual_seed(2)
+    Ts = [torch.relu(torch.randn(B, C, dd * dd, generator=g)) * 0.01 for _ in range(L)]
+    ident = torch.eye(dd)
+    h0 = torch.randn(B, C, S, 1, generator=g) * torch.from_numpy(make_start_embedding(n, d)).float()
+    head = torch.from_numpy(get_head_indices(n, d, bs=1)[0])
+    tail = torch.from_numpy(get_tail_indices(n, d, bs=1)[0])
+    assert blocks_mode_available(B, n, dd, h0.to(d_), need_grad=False, L=1) and not blocks_mode_available(B, n, dd, h0.to(d_), need_grad=False, L=L)
+    with torch.no_grad():
+        out = propagate_blocks([t.to(d_) for t in Ts], ident.to(d_), n, h0.to(d_), "tanh", head.to(d_), tail.to(d_))
+    ref = O.propagate([O.build_block_adjacency(t.double(), ident.double(), n) for t in Ts], h0.double(), "tanh", head, tail, as_gemm=True)
+    close(out, ref.float(), atol=1e-4, rel_to_max=1e-5, what="blocks n=32 L=8")
+
+
 def test_start_entity_embeddings_golden():
     from recon_amd.propagation import make_start_entity_embeddings
     g = load_golden("prop3_start_entity")
