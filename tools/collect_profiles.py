@@ -31,19 +31,26 @@ if ks:
     shutil.copy(ks[0], os.path.join(P, "round%s_bench_cfg2_kernel_stats.csv" % rnd))
 acc = defaultdict(lambda: {"fetch": [0, 0.0], "write": [0, 0.0]})
 for tag, ctr, key in (("pmc_fetch", "FETCH_SIZE", "fetch"), ("pmc_write", "WRITE_SIZE", "write")):
+    raw_rows = []
     for f in glob.glob(os.path.join(bench_dir, tag, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") == ctr and "recon" in r["Kernel_Name"] or r.get("Counter_Name") == ctr and r["Kernel_Name"].startswith("k_"):
                 a = acc[short(r["Kernel_Name"])][key]
                 a[0] += 1
                 a[1] += float(r["Counter_Value"])
+                raw_rows.append((r.get("Dispatch_Id", ""), short(r["Kernel_Name"]), r.get("Grid_Size", ""), r.get("Workgroup_Size", ""), ctr, r["Counter_Value"]))
+    # the raw counter dump behind the rounded JSON (one row per dispatch of a recon kernel, values as rocprofv3 reports them: KiB)
+    with open(os.path.join(P, "round%s_pmc_%s_raw.csv" % (rnd, key)), "w") as fh:
+        w = csv.writer(fh)
+        w.writerow(("dispatch_id", "kernel", "grid_size", "workgroup_size", "counter", "value_KiB_as_reported"))
+        w.writerows(raw_rows)
 out = {"source": "tools/profile_bench.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bench.py --steps 10 --warmup 3 --no-extras), "
                  "profiles/round%s_bench_cfg2_summary.txt" % rnd,
        "correction": "FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; KiB -> bytes"}
 for k, v in sorted(acc.items()):
     fb = 2 * v["fetch"][1] / max(v["fetch"][0], 1) * 1024.0
     wb = v["write"][1] / max(v["write"][0], 1) * 1024.0
-    out[k] = {"fetch_bytes": int(round(fb, -5)), "write_bytes": int(round(wb, -5)), "total_bytes": int(round(fb, -5) + round(wb, -5)),
+    out[k] = {"fetch_bytes": int(round(fb)), "write_bytes": int(round(wb)), "total_bytes": int(round(fb) + round(wb)),
               "launches": v["fetch"][0]}
 json.dump(out, open(os.path.join(P, "round%s_pmc_traffic.json" % rnd), "w"), indent=1)
 print("k_gat_atp_fwd:", out.get("k_gat_atp_fwd"))
