@@ -357,10 +357,11 @@ int recon_propagate_bwd(const recon_prop_bwd_args* args, recon_stream_t stream);
  *     stack, bf16"): the same step (models/models.py:240-274) on bfloat16 tensors — bf16 storage, fp32 accumulation on
  *     v_mfma_f32_16x16x32_bf16, every state and every gradient tensor rounded to bf16 once where the reference's bf16 tensors
  *     are (csrc/prop_b16.hip).  All data pointers are bf16 (uint16_t) data, 16-byte aligned, S % 8 == 0.
- *     recon_propagate_b16_form(): 1 = all hops of a graph in one workgroup (S % 16 == 0, S <= 160, C <= 96, even dd; reads
- *     `trans` in place in block mode; h_saved optional), 2 = one batched GEMM per hop over the graphs (needs `adj`, h_saved and
- *     `zeros`), 0 = shape not taken (the caller converts to float32 and runs recon_propagate_fwd).
- *     The backward works on the materialised adjacency for every shape: both products of a hop as batched GEMMs.
+ *     recon_propagate_b16_form(): 1 = all hops of a graph in one workgroup (S % 16 == 0, S <= 160, C <= 96, even dd; h_saved
+ *     optional), 3 = wide states (S % 64 == 0, 192 <= S <= 512): the state of 128 channels in LDS for all hops, 2 = one batched GEMM
+ *     per hop over the graphs (needs h_saved and `zeros`), 0 = shape not taken (the caller converts to float32 and runs
+ *     recon_propagate_fwd).  Every form reads `trans` in place in block mode.
+ *     The backward runs both products of a hop as batched GEMMs over the graphs for every shape, in block mode without an adjacency.
  * ------------------------------------------------------------------------------------------*/
 typedef struct {
     int32_t B, C, S, L, dd;         /* as recon_prop_args                                                 */
@@ -382,13 +383,23 @@ int recon_propagate_b16_form(const recon_prop_b16_args* args);
 int recon_propagate_b16_fwd(const recon_prop_b16_args* args, recon_stream_t stream);
 
 typedef struct {
-    recon_prop_b16_args fwd;        /* adj, h_saved (filled by the forward), zeros                        */
+    recon_prop_b16_args fwd;        /* adj or trans + identity, h_saved (filled by the forward), zeros    */
     const void* grad_out;           /* [B,C,L*dd] bf16                                                    */
     void* const* g_adj;             /* HOST array of L device pointers [B,S,S] bf16 (entries may be NULL) */
     void* g_h;                      /* [B,C,S] bf16; on return d loss / d h0 per batch element            */
     void* ws;                       /* [B,C,S] bf16 workspace                                             */
+    const int32_t* head_blk;        /* [C] device or NULL: the gather indices are BLOCKS of dd consecutive columns (head_idx[c, x] =     *
+                                     * head_blk[c] + x, likewise tail; what utils/embedding_utils.py:184-202 builds) — the caller has   *
+                                     * checked it, idx_batch_stride == 0, head_blk[c] != tail_blk[c]: Y_l is then formed in the GEMM   *
+                                     * epilogues instead of by a pass of its own                                                        */
+    const int32_t* tail_blk;
+    void* const* g_trans;           /* BLOCK MODE (fwd.trans): HOST array of L device pointers [B, n(n-1), 256] bf16 (entries may be NULL) */
+    void* g_identity;               /* block mode: [16,16] bf16 summed over graphs, nodes and hops (fp32, fixed order), or NULL          */
+    void* diag_ws;                  /* block mode with g_identity: recon_propagate_b16_bwd_diag_elems() bf16 elements                   */
+    float* ident_ws;                /* block mode with g_identity: recon_block_adjacency_b16_bwd_workspace_floats(16) floats            */
 } recon_prop_b16_bwd_args;
 
+size_t recon_propagate_b16_bwd_diag_elems(const recon_prop_b16_args* fwd);
 int recon_propagate_b16_bwd(const recon_prop_b16_bwd_args* args, recon_stream_t stream);
 
 /* P1 in bf16: recon_block_adjacency_fwd / _bwd on bf16 tensors (the identity gradient is summed in fp32, fixed order, rounded once) */

@@ -81,7 +81,8 @@ class PropB16Args(C.Structure):
 
 class PropB16BwdArgs(C.Structure):
     _fields_ = [("fwd", PropB16Args), ("grad_out", C.c_void_p), ("g_adj", C.POINTER(C.c_void_p)), ("g_h", C.c_void_p),
-                ("ws", C.c_void_p)]
+                ("ws", C.c_void_p), ("head_blk", C.c_void_p), ("tail_blk", C.c_void_p), ("g_trans", C.POINTER(C.c_void_p)),
+                ("g_identity", C.c_void_p), ("diag_ws", C.c_void_p), ("ident_ws", c_f32p)]
 
 
 class GcnArgs(C.Structure):
@@ -155,6 +156,7 @@ SYMBOLS = [
     ("recon_propagate_b16_form", C.c_int, [C.POINTER(PropB16Args)]),
     ("recon_propagate_b16_fwd", C.c_int, [C.POINTER(PropB16Args), C.c_void_p]),
     ("recon_propagate_b16_bwd", C.c_int, [C.POINTER(PropB16BwdArgs), C.c_void_p]),
+    ("recon_propagate_b16_bwd_diag_elems", C.c_size_t, [C.POINTER(PropB16Args)]),
     ("recon_block_adjacency_b16_fwd", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     ("recon_block_adjacency_b16_bwd_workspace_floats", C.c_size_t, [C.c_int32]),
     ("recon_block_adjacency_b16_bwd", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, c_f32p, C.c_void_p]),

@@ -38,6 +38,8 @@ struct PropB16K {
     int32_t ablate;             // timing experiments only (RECON_PROP_B16_ABL): 1 = the A fragments are not fetched (zeros)
 };
 
+// by-value helper: __builtin_bit_cast applied directly to a vector ELEMENT yields element 0 (prop_h_util.h)
+__device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(uint32_t, f); }
 __device__ __forceinline__ float bf2f(uint32_t bits16) { return __builtin_bit_cast(float, bits16 << 16); }
 __device__ __forceinline__ uint32_t pack_bf2(float a, float b) {      // round to nearest even, a in the low half
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -484,7 +486,17 @@ struct BGemmB16 {
     const uint16_t* zeros;
     int32_t M, N, K, batch, tiles_m, tiles_n, act;
     int32_t ablate;             // timing experiments only (RECON_BGEMM_ABL): 1 copies read the zero page, 2 no copies, 4 no stores
+    // PBLK: the P operand is a block adjacency read IN PLACE — P = transition tensors [batch][nodes (nodes - 1)][256], p_ident = identity
+    // [256]: element (s, t) = P[e(s >> 4, t >> 4)][s & 15][t & 15], the identity on the diagonal blocks (models/models.py:240-259)
+    int32_t p_nodes; const uint16_t* p_ident;
+    // EPI_YPOST: the result G becomes Y = (G + relation gradient) . act'(H) before it is stored (structured gather indices: channel c reads
+    // the dd consecutive columns from yp_head[c] and from yp_tail[c]): yp_h = H [batch][M][N], yp_g = grad_out + hop offset [batch][M][yp_ldg]
+    const uint16_t* yp_h; const uint16_t* yp_g; int64_t yp_g_bs; int32_t yp_ldg, yp_dd; const int32_t* yp_head; const int32_t* yp_tail;
+    // EPI_BLOCKS: the result (a gradient of a block adjacency) leaves in the transition tensors' layout: C = g_T [batch][nodes (nodes - 1)][256]
+    // (or null), the diagonal blocks into blk_diag [batch][nodes][256] (or null)
+    uint16_t* blk_diag;
 };
+enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_YPOST = 2, EPI_BLOCKS = 3 };
 __device__ __forceinline__ int kc_off(int row, int kq) { return row * 64 + (((kq + 2 * (row >> 3)) & 3) << 4); }
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lo_p, const unsigned char* hi_p) {
     const i16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(lo_p));
@@ -503,7 +515,7 @@ constexpr int km_slots(int rows) { int s = 8; while (s * 16 < rows) s *= 2; retu
 // ND copy instructions per step (missing pieces and steps past the end copy a page of zeros to a scratch KiB): s_waitcnt takes an
 // immediate.  After a tile's stores the next wait is vmcnt(0): loads and stores share the counter and complete out of order with respect
 // to each other.
-template <bool PK, bool QK, int WM, int WN, int MT, int NT, int NBUF, bool ACT>
+template <bool PK, bool QK, int WM, int WN, int MT, int NT, int NBUF, int EPI, bool PBLK>
 __global__ void __launch_bounds__(64 * WM * WN, (MT * NT >= 32 ? 2 : 3) * WM * WN / 4 > 0 ? (MT * NT >= 32 ? 2 : 3) : 1) k_bgemm_b16(const BGemmB16 p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     constexpr int NWV = WM * WN, BM = WM * MT * 16, BN = WN * NT * 16;
@@ -547,7 +559,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MT * NT >= 32 ? 2 : 3) * WM * W
         } else {
             const int rowL = s >> 2, kq = ((s & 3) - 2 * (rowL >> 3)) & 3;
             d_k[i] = 8 * kq;
-            d_a[i] = min(row0 + rowL, rows - 1) * ld;
+            d_a[i] = min(row0 + rowL, rows - 1) * ((PBLK && isp) ? 1 : ld);      // block mode: the row index itself
         }
     }
     const uint16_t* zlane = p.zeros + 8 * lane;
@@ -563,7 +575,16 @@ __global__ void __launch_bounds__(64 * WM * WN, (MT * NT >= 32 ? 2 : 3) * WM * W
         const bool kmaj = isp ? PK : QK;
         const int k = 32 * ki + d_k[i];
         const uint16_t* base = isp ? Pi : Qi;
-        const int64_t off = kmaj ? static_cast<int64_t>(k) * (isp ? p.ldp : p.ldq) + d_a[i] : static_cast<int64_t>(d_a[i]) + k;
+        int64_t off = kmaj ? static_cast<int64_t>(k) * (isp ? p.ldp : p.ldq) + d_a[i] : static_cast<int64_t>(d_a[i]) + k;
+        if constexpr (PBLK) {
+            if (isp) {                                                  // (row s, eight columns t ..) of the block adjacency: one 16-byte piece of a block row
+                const int sr = PK ? k : d_a[i], tc = PK ? d_a[i] : k;
+                const int bi = sr >> 4, bj = tc >> 4, e = bi * (p.p_nodes - 1) + (bj < bi ? bj : bj - 1);
+                const int in_blk = (sr & 15) * 16 + (tc & 15);
+                base = bi == bj ? p.p_ident : Pi;
+                off = bi == bj ? in_blk : e * 256 + in_blk;
+            }
+        }
         const uint16_t* src = (real && k < p.K && !(p.ablate & 1)) ? base + off : zlane;
         unsigned char* dst = sm + (real ? ib * STAGE + 1024 * pc : SCRATCH);
         if (!(p.ablate & 2)) __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -639,44 +660,100 @@ __global__ void __launch_bounds__(64 * WM * WN, (MT * NT >= 32 ? 2 : 3) * WM * W
             cb = cb + 1 == NBUF ? 0 : cb + 1;
         }
         mfma_drain();
-        // ---- MFMA result: rows (4 lq + r) = n, column li = m.  One straight-line copy of the store loop per activation.
-        uint16_t* Cb = p.C + g * p.c_bs;
+        // ---- MFMA result: rows (4 lq + r) = n, column li = m.
         // Stores are ISSUE bound (one store instruction occupies the CU's store path for ~70 cycles whatever it carries): neighbouring
         // column tiles exchange halves between lane rows (v_permlane16_swap) so that a lane holds EIGHT consecutive columns of one row —
-        // half as many instructions, 16 bytes each, 64-byte runs per row.
+        // half as many instructions, 16 bytes each, 64-byte runs per row.  EPI_YPOST works on the eight fp32 values before they are rounded.
+        uint16_t* Cb = p.C + g * p.c_bs;
+        auto put8 = [&](int m, int n, const float (&v)[8]) {            // eight consecutive columns n .. n + 7 of row m
+            if (m >= p.M || n >= p.N) return;                           // N % 8 == 0
+            const u32x4 w = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+            if constexpr (EPI == EPI_BLOCKS) {
+                const int bi = m >> 4, bj = n >> 4, in_blk = (m & 15) * 16 + (n & 15);
+                if (bi != bj) {
+                    if (p.C) *reinterpret_cast<u32x4*>(Cb + (bi * (p.p_nodes - 1) + (bj < bi ? bj : bj - 1)) * 256 + in_blk) = w;
+                } else if (p.blk_diag) {
+                    *reinterpret_cast<u32x4*>(p.blk_diag + (static_cast<int64_t>(g) * p.p_nodes + bi) * 256 + in_blk) = w;
+                }
+            } else {
+                *reinterpret_cast<u32x4*>(Cb + static_cast<int64_t>(m) * p.ldc + n) = w;
+            }
+        };
         auto store_tile = [&](auto act_c) {
             constexpr int A = decltype(act_c)::value;
-            auto fin = [&](const f32x4& a, uint32_t& w0, uint32_t& w1) {
-                float v[4] = {a[0], a[1], a[2], a[3]};
+            auto rsrc_of = [&](const uint16_t* q, int64_t elems) {
+                return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(q), 0, static_cast<int>(elems * 2), 0x00020000);
+            };
+            const auto rs_h = rsrc_of(EPI == EPI_YPOST ? p.yp_h + g * p.c_bs : p.zeros, EPI == EPI_YPOST ? static_cast<int64_t>(p.M) * p.N : 0);
+            const auto rs_g = rsrc_of(EPI == EPI_YPOST ? p.yp_g + g * p.yp_g_bs : p.zeros, EPI == EPI_YPOST ? static_cast<int64_t>(p.M) * p.yp_ldg : 0);
+            auto finish8 = [&](int m, int n, float (&v)[8]) {
+                if constexpr (EPI == EPI_ACT) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = A == RECON_ACT_RELU ? fmaxf(v[r], 0.f) : (A == RECON_ACT_TANH ? tanh_fast(v[r]) : v[r]);
-                w0 = pack_bf2(v[0], v[1]); w1 = pack_bf2(v[2], v[3]);
+                    for (int r = 0; r < 8; ++r) v[r] = A == RECON_ACT_RELU ? fmaxf(v[r], 0.f) : (A == RECON_ACT_TANH ? tanh_fast(v[r]) : v[r]);
+                } else if constexpr (EPI == EPI_YPOST) {
+                    // Y = (G + R) . act'(H): H's eight values; the relation term where the columns lie in the channel's head block (partner:
+                    // the same offset in its tail block) or tail block (partner in the head block) — out-of-range offsets read zeros
+                    const bool ok = m < p.M && n < p.N;
+                    const int hb = ok ? p.yp_head[m] : 0, tb = ok ? p.yp_tail[m] : 0;
+                    const bool in_h = ok && n >= hb && n < hb + p.yp_dd, in_t = ok && !in_h && n >= tb && n < tb + p.yp_dd;
+                    const int x = n - (in_h ? hb : tb);
+                    const u32x4 h8 = __builtin_amdgcn_raw_buffer_load_b128(rs_h, ok ? static_cast<uint32_t>(m * p.N + n) * 2u : kOOB, 0, 0);
+                    const u32x4 g8 = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (in_h || in_t) ? static_cast<uint32_t>(m * p.yp_ldg + x) * 2u : kOOB, 0, 0);
+                    const u32x4 p8 = __builtin_amdgcn_raw_buffer_load_b128(rs_h, (in_h || in_t) ? static_cast<uint32_t>(m * p.N + (in_h ? tb : hb) + x) * 2u : kOOB, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t hw = h8[e], gw = g8[e], pw = p8[e];
+                        const float h0 = bf2f(hw & 0xffffu), h1 = bf2f(hw >> 16);
+                        const float y0 = v[2 * e] + bf2f(gw & 0xffffu) * bf2f(pw & 0xffffu), y1 = v[2 * e + 1] + bf2f(gw >> 16) * bf2f(pw >> 16);
+                        v[2 * e] = y0 * (A == RECON_ACT_RELU ? (h0 > 0.f ? 1.f : 0.f) : (A == RECON_ACT_TANH ? 1.f - h0 * h0 : 1.f));
+                        v[2 * e + 1] = y1 * (A == RECON_ACT_RELU ? (h1 > 0.f ? 1.f : 0.f) : (A == RECON_ACT_TANH ? 1.f - h1 * h1 : 1.f));
+                    }
+                }
             };
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int m = m0 + 16 * (wm * MT + i) + li;
-                uint16_t* crow = Cb + static_cast<int64_t>(m) * p.ldc;
 #pragma unroll
                 for (int j = 0; j + 1 < NT; j += 2) {
-                    uint32_t a0, a1, b0, b1;
-                    fin(acc[i][j], a0, a1);
-                    fin(acc[i][j + 1], b0, b1);
-                    const auto x0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
-                    const auto x1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {                       // rows of lanes exchange: even rows keep tile j, odd rows tile j + 1
+                        const auto x = __builtin_amdgcn_permlane16_swap(as_u(acc[i][j][r]), as_u(acc[i][j + 1][r]), false, false);
+                        v[r] = as_f(x[0]); v[4 + r] = as_f(x[1]);
+                    }
                     const int n = n0 + 16 * (wn * NT + j + (lq & 1)) + 8 * (lq >> 1);
-                    if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(crow + n) = u32x4{x0[0], x1[0], x0[1], x1[1]};      // N % 8 == 0
+                    finish8(m, n, v);
+                    put8(m, n, v);
                 }
-                if constexpr (NT & 1) {
-                    uint32_t a0, a1;
-                    fin(acc[i][NT - 1], a0, a1);
+                if constexpr (NT & 1) {                                 // the unpaired tile: the same through a half-filled group (four columns)
                     const int n = n0 + 16 * (wn * NT + NT - 1) + 4 * lq;
-                    if (m < p.M && n < p.N) *reinterpret_cast<uint2*>(crow + n) = make_uint2(a0, a1);
+                    if constexpr (EPI == EPI_PLAIN || EPI == EPI_ACT) {
+                        float v[4] = {acc[i][NT - 1][0], acc[i][NT - 1][1], acc[i][NT - 1][2], acc[i][NT - 1][3]};
+                        if constexpr (EPI == EPI_ACT) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = A == RECON_ACT_RELU ? fmaxf(v[r], 0.f) : (A == RECON_ACT_TANH ? tanh_fast(v[r]) : v[r]);
+                        }
+                        if (m < p.M && n < p.N) *reinterpret_cast<uint2*>(Cb + static_cast<int64_t>(m) * p.ldc + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    } else {
+                        // lane rows exchange inside the tile: rows lq = 0 / 1 and 2 / 3 pair up, the even row takes both halves of eight columns
+                        float v[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const uint32_t own = as_u(acc[i][NT - 1][r]);
+                            const auto x = __builtin_amdgcn_permlane16_swap(own, own, false, false);      // x[1] on an even row = the odd partner's value
+                            v[r] = as_f(own); v[4 + r] = as_f(x[1]);
+                        }
+                        const int n8 = n0 + 16 * (wn * NT + NT - 1) + 8 * (lq >> 1);
+                        const bool even = (lq & 1) == 0;
+                        finish8(even ? m : p.M, n8, v);                 // odd rows: masked out (their values travel with the even partner)
+                        put8(even ? m : p.M, n8, v);
+                    }
                 }
             }
         };
         if (p.ablate & 4) { asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[MT - 1][NT - 1][3])); }
-        else if (ACT && p.act == RECON_ACT_RELU) store_tile(std::integral_constant<int, RECON_ACT_RELU>{});
-        else if (ACT && p.act == RECON_ACT_TANH) store_tile(std::integral_constant<int, RECON_ACT_TANH>{});
+        else if ((EPI == EPI_ACT || EPI == EPI_YPOST) && p.act == RECON_ACT_RELU) store_tile(std::integral_constant<int, RECON_ACT_RELU>{});
+        else if ((EPI == EPI_ACT || EPI == EPI_YPOST) && p.act == RECON_ACT_TANH) store_tile(std::integral_constant<int, RECON_ACT_TANH>{});
         else store_tile(std::integral_constant<int, RECON_ACT_LINEAR>{});
         stores_pending = true;
     }
@@ -862,19 +939,18 @@ int form_b16(const recon_prop_b16_args* a, bool check_ptrs) {
     if (!force_gemm && a->S % 16 == 0 && a->S <= 160 && a->C <= 96 && (a->dd % 2) == 0 && ((a->C * a->dd) & 1) == 0) return 1;
     // wide states in LDS: S = 32 NKS, NKS even in 6 .. 16 (S % 64 == 0, 192 <= S <= 512), even dd; inference or training alike
     if (!force_gemm && !(env && env[0] == 'n') && a->S % 64 == 0 && a->S >= 192 && a->S <= 512 && (a->dd % 2) == 0) return 3;
-    if (blk) return 0;
     if (static_cast<int64_t>(a->C) * a->S >= (1LL << 31) || static_cast<int64_t>(a->S) * a->S >= (1LL << 31)) return 0;
-    return 2;
+    return 2;                                                           // block mode too: the GEMMs read the transition tensors in place
 }
 
-template <bool PK, bool QK, bool ACT, int WM, int WN, int MT, int NT, int NBUF>
+template <bool PK, bool QK, int EPI, bool PBLK, int WM, int WN, int MT, int NT, int NBUF>
 int launch_bgemm_cfg(BGemmB16 g, hipStream_t st) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     constexpr size_t lds = static_cast<size_t>(NBUF) * ((PK ? 32 * km_slots(BN) * 32 : BN * 64) + (QK ? 32 * km_slots(BM) * 32 : BM * 64)) + 1024;
     g.tiles_m = (g.M + BM - 1) / BM; g.tiles_n = (g.N + BN - 1) / BN;
     { const char* ab = getenv("RECON_BGEMM_ABL"); g.ablate = ab ? atoi(ab) : 0; }
     const int64_t T = static_cast<int64_t>(g.tiles_m) * g.tiles_n;
-    auto kern = k_bgemm_b16<PK, QK, WM, WN, MT, NT, NBUF, ACT>;
+    auto kern = k_bgemm_b16<PK, QK, WM, WN, MT, NT, NBUF, EPI, PBLK>;
     static int occ = 0;                                                 // per instantiation
     if (occ == 0) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -895,20 +971,14 @@ int launch_bgemm_cfg(BGemmB16 g, hipStream_t st) {
     return RECON_OK;
 }
 
-template <bool PK, bool QK, bool ACT>
+// Tile shapes: a whole graph of <= 9 nodes per workgroup (144 x 144, 9 waves); 256 x 256 with 8 waves of 128 x 64 otherwise (the copies come
+// from L2 at ~30 TB/s chip-wide: bytes per flop halve against 128 x 128, measured 657 -> 495 TF/s the other way); RECON_BGEMM_CFG=a: 128 x 128.
+template <bool PK, bool QK, int EPI, bool PBLK>
 int launch_bgemm(const BGemmB16& g, hipStream_t st) {
-    if (g.M <= 144 && g.N <= 144) return launch_bgemm_cfg<PK, QK, ACT, 3, 3, 3, 3, 3>(g, st);     // a whole graph of <= 9 nodes per workgroup
-    const char* cfg = getenv("RECON_BGEMM_CFG");                        // tile shape A/B (tools/b16_gemm_cfgs.py)
-    switch (cfg ? cfg[0] : 'c') {
-        case 'b': return launch_bgemm_cfg<PK, QK, ACT, 4, 2, 4, 4, 3>(g, st);      // 256 x 128, 8 waves
-        case 'c': return launch_bgemm_cfg<PK, QK, ACT, 2, 4, 8, 4, 3>(g, st);      // 256 x 256, 8 waves of 128 x 64
-        case 'd': return launch_bgemm_cfg<PK, QK, ACT, 2, 4, 4, 4, 3>(g, st);      // 128 x 256, 8 waves
-        case 'e': return launch_bgemm_cfg<PK, QK, ACT, 2, 2, 4, 4, 4>(g, st);      // 128 x 128, four stages
-        case 'f': return launch_bgemm_cfg<PK, QK, ACT, 2, 2, 8, 4, 3>(g, st);      // 256 x 128, 4 waves of 128 x 64: two workgroups per CU
-        case 'g': return launch_bgemm_cfg<PK, QK, ACT, 2, 2, 4, 8, 3>(g, st);      // 128 x 256, 4 waves of 64 x 128
-        case 'a': return launch_bgemm_cfg<PK, QK, ACT, 2, 2, 4, 4, 3>(g, st);      // 128 x 128, 4 waves
-        default: return launch_bgemm_cfg<PK, QK, ACT, 2, 4, 8, 4, 3>(g, st);
-    }
+    if (g.M <= 144 && g.N <= 144) return launch_bgemm_cfg<PK, QK, EPI, PBLK, 3, 3, 3, 3, 3>(g, st);
+    const char* cfg = getenv("RECON_BGEMM_CFG");
+    if (cfg && cfg[0] == 'a') return launch_bgemm_cfg<PK, QK, EPI, PBLK, 2, 2, 4, 4, 3>(g, st);
+    return launch_bgemm_cfg<PK, QK, EPI, PBLK, 2, 4, 8, 4, 3>(g, st);
 }
 
 int fwd_fused(const recon_prop_b16_args* a, hipStream_t st) {
@@ -994,12 +1064,14 @@ int fwd_gemm(const recon_prop_b16_args* a, hipStream_t st) {
     uint16_t* hs = static_cast<uint16_t*>(a->h_saved);
     for (int l = 1; l <= L; ++l) {
         BGemmB16 g{};
-        g.P = static_cast<const uint16_t*>(a->adj[l - 1]); g.p_bs = 1LL * S * S; g.ldp = S;
+        const bool blk = a->trans != nullptr;
+        g.P = static_cast<const uint16_t*>(blk ? a->trans[l - 1] : a->adj[l - 1]); g.p_bs = blk ? 1LL * C * 256 : 1LL * S * S; g.ldp = S;
+        g.p_nodes = blk ? S / 16 : 0; g.p_ident = static_cast<const uint16_t*>(a->identity);
         g.Q = l == 1 ? static_cast<const uint16_t*>(a->h0) : hs + (l - 2) * BCS; g.q_bs = l == 1 ? a->h0_batch_stride : CS; g.ldq = S;
         g.C = hs + (l - 1) * BCS; g.c_bs = CS; g.ldc = S;
         g.zeros = static_cast<const uint16_t*>(a->zeros);
         g.M = C; g.N = S; g.K = S; g.batch = B; g.act = a->act;
-        const int rc = launch_bgemm<false, false, true>(g, st);
+        const int rc = blk ? launch_bgemm<false, false, EPI_ACT, true>(g, st) : launch_bgemm<false, false, EPI_ACT, false>(g, st);
         if (rc != RECON_OK) return rc;
     }
     const int64_t total = 1LL * B * C * L * a->dd;
@@ -1031,59 +1103,103 @@ extern "C" int recon_propagate_b16_fwd(const recon_prop_b16_args* a, recon_strea
     return RECON_ERR_UNSUPPORTED;
 }
 
-// Both products of every hop as batched GEMMs over the graphs; Y_l in place of G_l+1 (k_prop_b16_ypost).  The L products of kind (d)
-// alternate between `ws` and g_h so that the last one (d loss / d h^0 per graph) lands in g_h.
+// Both products of every hop as batched GEMMs over the graphs.  Y_l = (G_l+1 + relation gradient) . act'(H^l) is formed in the epilogue of the
+// product that delivers G_l+1 where the gather indices are blocks of dd consecutive columns (head_blk / tail_blk: what the GP-GNN models
+// use), else in place by k_prop_b16_ypost.  The L products of kind (d) alternate between `ws` and g_h so that the last one (d loss / d h^0
+// per graph) lands in g_h.  BLOCK MODE (fwd.trans): A_l is read out of the transition tensors in place, d A_l leaves in their layout
+// (g_trans) and its diagonal blocks are summed into g_identity (fp32, fixed order, rounded once) — no adjacency is ever materialised.
+namespace {
+__global__ void __launch_bounds__(256) k_diag_partial_b16(const uint16_t* __restrict__ diag, int64_t nblk, float* __restrict__ partial) {
+    const int64_t per = (nblk + gridDim.x - 1) / gridDim.x;
+    const int64_t t0 = blockIdx.x * per, t1 = min(nblk, t0 + per);
+    const int e = threadIdx.x;                                          // 256 elements of a 16 x 16 block
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t t = t0;
+    for (; t + 4 <= t1; t += 4) { s0 += bf2f(diag[t * 256 + e]); s1 += bf2f(diag[(t + 1) * 256 + e]); s2 += bf2f(diag[(t + 2) * 256 + e]); s3 += bf2f(diag[(t + 3) * 256 + e]); }
+    for (; t < t1; ++t) s0 += bf2f(diag[t * 256 + e]);
+    partial[static_cast<int64_t>(blockIdx.x) * 256 + e] = (s0 + s1) + (s2 + s3);
+}
+}  // namespace
+
+extern "C" size_t recon_propagate_b16_bwd_diag_elems(const recon_prop_b16_args* a) {
+    if (!a || !a->trans || a->S % 16 != 0 || a->B <= 0 || a->L <= 0) return 0;
+    return static_cast<size_t>(a->L) * a->B * (a->S / 16) * 256;
+}
+
 extern "C" int recon_propagate_b16_bwd(const recon_prop_b16_bwd_args* ba, recon_stream_t stream) {
     if (!ba) return RECON_ERR_INVALID;
     const recon_prop_b16_args* a = &ba->fwd;
     const int rc0 = check_b16(a);
     if (rc0 != RECON_OK) return rc0;
-    if (a->trans) return RECON_ERR_UNSUPPORTED;                         // the backward works on a materialised adjacency
     if (!a->h_saved || !ba->grad_out || !ba->g_h || !ba->ws || !a->zeros) return RECON_ERR_INVALID;
     if (a->B == 0) return RECON_OK;
     const int32_t B = a->B, C = a->C, S = a->S, L = a->L;
+    const bool blk = a->trans != nullptr;
+    if (blk && ba->g_identity && (!ba->diag_ws || !ba->ident_ws)) return RECON_ERR_INVALID;
     if (S % 8 != 0 || !al16(a->h0) || (a->h0_batch_stride % 8) != 0 || !al16(a->h_saved) || !al16(ba->g_h) || !al16(ba->ws) || !al16(a->zeros) ||
         static_cast<int64_t>(C) * S >= (1LL << 31) || static_cast<int64_t>(S) * S >= (1LL << 31) || 8ull * S * sizeof(float) > 64 * 1024)
         return RECON_ERR_UNSUPPORTED;
-    for (int l = 0; l < L; ++l)
-        if (!al16(a->adj[l]) || (ba->g_adj && ba->g_adj[l] && !al16(ba->g_adj[l]))) return RECON_ERR_UNSUPPORTED;
+    for (int l = 0; l < L; ++l) {
+        if (!al16(blk ? a->trans[l] : a->adj[l])) return RECON_ERR_UNSUPPORTED;
+        if (blk ? (ba->g_trans && ba->g_trans[l] && !al16(ba->g_trans[l])) : (ba->g_adj && ba->g_adj[l] && !al16(ba->g_adj[l]))) return RECON_ERR_UNSUPPORTED;
+    }
+    if (blk && (!al16(a->identity) || (ba->diag_ws && !al16(ba->diag_ws)))) return RECON_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
     const int64_t CS = 1LL * C * S, BCS = CS * B, rows = 1LL * B * C;
+    const int nn = S / 16;
     const uint16_t* hs = static_cast<const uint16_t*>(a->h_saved);
     const uint16_t* gout = static_cast<const uint16_t*>(ba->grad_out);
     uint16_t* bufY = static_cast<uint16_t*>((L & 1) ? ba->ws : ba->g_h);
     uint16_t* bufG = static_cast<uint16_t*>((L & 1) ? ba->g_h : ba->ws);
     const dim3 pgrid(static_cast<unsigned>(ceil_div64(rows, 4)));
     const size_t plds = 8ull * S * sizeof(float);
+    // the fused Y: structured gather indices shared by the batch, dd and L dd multiples of 8 (16-byte pieces of grad_out rows)
+    const bool fuse_y = ba->head_blk && ba->tail_blk && a->idx_batch_stride == 0 && (a->dd % 8) == 0 && !(getenv("RECON_PROP_B16_YPOST") && getenv("RECON_PROP_B16_YPOST")[0] == 'k');
     hipLaunchKernelGGL(k_prop_b16_ypost, pgrid, dim3(256), plds, st, nullptr, hs + (L - 1) * BCS, a->head_idx, a->tail_idx, a->idx_batch_stride, gout, bufY,
                        rows, C, S, L, a->dd, L - 1, a->act);
     for (int l = L; l >= 1; --l) {
         const uint16_t* Hprev = l == 1 ? static_cast<const uint16_t*>(a->h0) : hs + (l - 2) * BCS;
         const int64_t hprev_bs = l == 1 ? a->h0_batch_stride : CS;
-        if (ba->g_adj && ba->g_adj[l - 1]) {                            // (c): dA[s][t] = sum_c Y[c][s] H^l-1[c][t]
+        void* gdst = blk ? (ba->g_trans ? ba->g_trans[l - 1] : nullptr) : (ba->g_adj ? ba->g_adj[l - 1] : nullptr);
+        uint16_t* diag = (blk && ba->g_identity) ? static_cast<uint16_t*>(ba->diag_ws) + static_cast<int64_t>(l - 1) * B * nn * 256 : nullptr;
+        if (gdst || diag) {                                             // (c): dA[s][t] = sum_c Y[c][s] H^l-1[c][t]
             BGemmB16 g{};
             g.P = Hprev; g.p_bs = hprev_bs; g.ldp = S;
             g.Q = bufY; g.q_bs = CS; g.ldq = S;
-            g.C = static_cast<uint16_t*>(ba->g_adj[l - 1]); g.c_bs = 1LL * S * S; g.ldc = S;
+            g.C = static_cast<uint16_t*>(gdst); g.c_bs = blk ? 1LL * C * 256 : 1LL * S * S; g.ldc = S;
             g.zeros = static_cast<const uint16_t*>(a->zeros);
             g.M = S; g.N = S; g.K = C; g.batch = B; g.act = 0;
-            const int rc = launch_bgemm<true, true, false>(g, st);
+            g.p_nodes = nn; g.blk_diag = diag;
+            const int rc = blk ? launch_bgemm<true, true, EPI_BLOCKS, false>(g, st) : launch_bgemm<true, true, EPI_PLAIN, false>(g, st);
             if (rc != RECON_OK) return rc;
         }
-        {                                                               // (d): G[c][t] = sum_s Y[c][s] A_l[s][t]
+        {                                                               // (d): G[c][t] = sum_s Y[c][s] A_l[s][t]   (+ the next Y in its epilogue)
             BGemmB16 g{};
-            g.P = static_cast<const uint16_t*>(a->adj[l - 1]); g.p_bs = 1LL * S * S; g.ldp = S;
+            g.P = static_cast<const uint16_t*>(blk ? a->trans[l - 1] : a->adj[l - 1]); g.p_bs = blk ? 1LL * C * 256 : 1LL * S * S; g.ldp = S;
+            g.p_nodes = blk ? nn : 0; g.p_ident = static_cast<const uint16_t*>(a->identity);
             g.Q = bufY; g.q_bs = CS; g.ldq = S;
             g.C = bufG; g.c_bs = CS; g.ldc = S;
             g.zeros = static_cast<const uint16_t*>(a->zeros);
-            g.M = C; g.N = S; g.K = S; g.batch = B; g.act = 0;
-            const int rc = launch_bgemm<true, false, false>(g, st);
+            g.M = C; g.N = S; g.K = S; g.batch = B; g.act = a->act;
+            const bool yp = fuse_y && l > 1;
+            if (yp) {
+                g.yp_h = hs + (l - 2) * BCS; g.yp_g = gout + static_cast<int64_t>(l - 2) * a->dd; g.yp_g_bs = 1LL * C * L * a->dd; g.yp_ldg = L * a->dd;
+                g.yp_dd = a->dd; g.yp_head = ba->head_blk; g.yp_tail = ba->tail_blk;
+            }
+            const int rc = blk ? (yp ? launch_bgemm<true, false, EPI_YPOST, true>(g, st) : launch_bgemm<true, false, EPI_PLAIN, true>(g, st))
+                               : (yp ? launch_bgemm<true, false, EPI_YPOST, false>(g, st) : launch_bgemm<true, false, EPI_PLAIN, false>(g, st));
             if (rc != RECON_OK) return rc;
         }
-        if (l > 1)
+        if (l > 1 && !fuse_y)
             hipLaunchKernelGGL(k_prop_b16_ypost, pgrid, dim3(256), plds, st, bufG, hs + (l - 2) * BCS, a->head_idx, a->tail_idx, a->idx_batch_stride, gout,
                                bufG, rows, C, S, L, a->dd, l - 2, a->act);
         uint16_t* t = bufY; bufY = bufG; bufG = t;
+    }
+    if (blk && ba->g_identity) {                                        // every hop's diagonal blocks -> one [16][16] sum
+        const int64_t nb = static_cast<int64_t>(L) * B * nn;
+        const int slices = static_cast<int>(nb < kIdentSlicesB16 ? nb : kIdentSlicesB16);
+        hipLaunchKernelGGL(k_diag_partial_b16, dim3(slices), dim3(256), 0, st, static_cast<const uint16_t*>(ba->diag_ws), nb, ba->ident_ws);
+        hipLaunchKernelGGL(k_sum_rows_b16, dim3(1), dim3(256), 0, st, ba->ident_ws, slices, 256, static_cast<uint16_t*>(ba->g_identity));
     }
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;

@@ -261,6 +261,32 @@ def _b16_args(B, Cn, S, L, dd, act, adjs, h0c, h0_bs, head, tail, idx_bs, out, h
                             _ptr_array(trans) if trans is not None else None, _lib.ptr(identity), _zeros_page(h0c.device).data_ptr())
 
 
+_BLK_IDX = {}
+
+
+def _index_blocks(head, tail, dd, S):
+    """(head_blk, tail_blk) int32 [C] device tensors when the gather indices are blocks of dd consecutive columns — head[c, x] = head[c, 0] + x,
+    likewise tail, every block inside [0, S], head and tail blocks of a channel distinct — shared by the batch; else None.  That is what
+    utils/embedding_utils.py:184-202 builds; the bfloat16 backward then forms Y_l in its GEMM epilogues.  One host read per index tensor
+    pair (cached on identity + version)."""
+    key = (head.data_ptr(), head._version, tail.data_ptr(), tail._version, tuple(head.shape), int(dd), int(S))
+    hit = _BLK_IDX.get(key)
+    if hit is None:
+        res = None
+        if dd % 8 == 0 and (head.dim() == 2 or head.shape[0] == 1):
+            h2, t2 = head.reshape(-1, dd), tail.reshape(-1, dd)
+            ar = torch.arange(dd, device=head.device)
+            ok = ((h2 == h2[:, :1] + ar).all() & (t2 == t2[:, :1] + ar).all() & (h2[:, 0] % 8 == 0).all() & (t2[:, 0] % 8 == 0).all()
+                  & (h2[:, 0] >= 0).all() & (t2[:, 0] >= 0).all() & (h2[:, 0] + dd <= S).all() & (t2[:, 0] + dd <= S).all()
+                  & ((h2[:, 0] - t2[:, 0]).abs() >= dd).all())
+            if bool(ok):
+                res = (h2[:, 0].to(torch.int32).contiguous(), t2[:, 0].to(torch.int32).contiguous())
+        if len(_BLK_IDX) >= 16:
+            _BLK_IDX.clear()
+        hit = _BLK_IDX[key] = (res, head, tail)                         # pins the tensors while cached
+    return hit[0]
+
+
 _KEEP_STATES = False        # tests: keep the states the last bfloat16 forward saved (the backward's ReLU mask is theirs)
 _LAST_STATES = None
 
@@ -313,7 +339,9 @@ class _PropagateB16(torch.autograd.Function):
         g_h = torch.empty(B, Cn, S, dtype=torch.bfloat16, device=dev)
         ws = torch.empty(B, Cn, S, dtype=torch.bfloat16, device=dev)
         fwd = _b16_args(B, Cn, S, L, dd, act, adjs, h0c, h0_bs, head, tail, idx_bs, gout, hs)     # `out` is unused by the backward
-        args = _lib.PropB16BwdArgs(fwd, gout.data_ptr(), _ptr_array(g_adjs), g_h.data_ptr(), ws.data_ptr())
+        blk_idx = _index_blocks(head, tail, dd, S) if idx_bs == 0 else None
+        args = _lib.PropB16BwdArgs(fwd, gout.data_ptr(), _ptr_array(g_adjs), g_h.data_ptr(), ws.data_ptr(),
+                                   _lib.ptr(blk_idx[0]) if blk_idx else None, _lib.ptr(blk_idx[1]) if blk_idx else None, None, None, None, None)
         with _lib.on_device(dev):
             _lib.check(_lib.lib().recon_propagate_b16_bwd(C.byref(args), _lib.current_stream()), "recon_propagate_b16_bwd")
         g_h0 = None
@@ -455,6 +483,74 @@ def _propagate_blocks_b16(T_list, identity, n, h0, act, head, tail):
     return out
 
 
+class _PropagateBlocksB16(torch.autograd.Function):
+    """models/models.py:240-274 on bfloat16 tensors WITH gradients and without an adjacency: the forward reads the transition tensors in
+    place (and saves the states), the backward's products read them in place again, write d T_l in T's layout and sum the diagonal
+    blocks of every hop into d identity (fp32, fixed order, rounded once)."""
+
+    @staticmethod
+    def forward(ctx, h0, identity, act, head, tail, n, *Ts):
+        _req(h0, identity, head, tail, *Ts, dtype=torch.bfloat16)
+        L, dd, B = len(Ts), identity.shape[0], Ts[0].shape[0]
+        S, Cn = n * dd, n * (n - 1)
+        t_shapes = [tuple(t.shape) for t in Ts]
+        Ts = [t.contiguous().view(B, Cn, dd * dd) for t in Ts]
+        identity, h0c = identity.contiguous(), h0.contiguous()
+        h0_bs = Cn * S if h0c.dim() == 4 else 0
+        head, tail = head.contiguous(), tail.contiguous()
+        idx_bs = Cn * dd if head.dim() == 3 and head.shape[0] > 1 else 0
+        dev = h0.device
+        out = torch.empty(B, Cn, L * dd, dtype=torch.bfloat16, device=dev)
+        hs = torch.empty(L, B, Cn, S, dtype=torch.bfloat16, device=dev)
+        args = _b16_args(B, Cn, S, L, dd, act, None, h0c, h0_bs, head, tail, idx_bs, out, hs, trans=Ts, identity=identity)
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().recon_propagate_b16_fwd(C.byref(args), _lib.current_stream()), "recon_propagate_b16_fwd (block mode)")
+        ctx.save_for_backward(h0c, identity, head, tail, hs, *Ts)
+        ctx.meta = (B, Cn, S, L, dd, act, h0_bs, idx_bs, tuple(h0.shape), t_shapes)
+        if _KEEP_STATES:
+            global _LAST_STATES
+            _LAST_STATES = hs
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        h0c, identity, head, tail, hs, *Ts = ctx.saved_tensors
+        B, Cn, S, L, dd, act, h0_bs, idx_bs, h0_shape, t_shapes = ctx.meta
+        dev = gout.device
+        gout = gout.contiguous()
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        g_Ts = [torch.empty(B, Cn, dd * dd, **bf) if ctx.needs_input_grad[6 + l] else None for l in range(L)]
+        g_I = torch.empty(dd, dd, **bf) if ctx.needs_input_grad[1] else None
+        g_h, ws = torch.empty(B, Cn, S, **bf), torch.empty(B, Cn, S, **bf)
+        Lb = _lib.lib()
+        fwd = _b16_args(B, Cn, S, L, dd, act, None, h0c, h0_bs, head, tail, idx_bs, gout, hs, trans=Ts, identity=identity)
+        diag = torch.empty(Lb.recon_propagate_b16_bwd_diag_elems(C.byref(fwd)), **bf) if g_I is not None else None
+        iws = torch.empty(Lb.recon_block_adjacency_b16_bwd_workspace_floats(dd), dtype=torch.float32, device=dev) if g_I is not None else None
+        blk_idx = _index_blocks(head, tail, dd, S) if idx_bs == 0 else None
+        args = _lib.PropB16BwdArgs(fwd, gout.data_ptr(), None, g_h.data_ptr(), ws.data_ptr(),
+                                   _lib.ptr(blk_idx[0]) if blk_idx else None, _lib.ptr(blk_idx[1]) if blk_idx else None,
+                                   _ptr_array(g_Ts), _lib.ptr(g_I), _lib.ptr(diag), _lib.ptr(iws))
+        with _lib.on_device(dev):
+            _lib.check(Lb.recon_propagate_b16_bwd(C.byref(args), _lib.current_stream()), "recon_propagate_b16_bwd (block mode)")
+        g_h0 = None
+        if ctx.needs_input_grad[0]:
+            g_h0 = (g_h if h0_bs else g_h.sum(0, dtype=torch.float32).to(torch.bfloat16)).view(h0_shape)
+        return (g_h0, g_I, None, None, None, None) + tuple(g.view(sh) if g is not None else None for g, sh in zip(g_Ts, t_shapes))
+
+
+def _blocks_b16_trainable(B, n, dd, h0, T_list, identity):
+    """Block mode with gradients: 2d = 16 and a state size the bfloat16 kernels take (S = 16 n: always a multiple of 8)."""
+    if dd != 16 or n < 2 or B > _MAX_BATCH or B == 0 or os.environ.get("RECON_PROP_BLOCKS", "1") == "0":
+        return False
+    if h0.data_ptr() % 16 or identity.data_ptr() % 16 or any(T.data_ptr() % 16 for T in T_list):
+        return False
+    Cn, S = n * (n - 1), n * dd
+    if Cn * S >= 2 ** 31 or 8 * S * 4 > 64 * 1024:
+        return False
+    probe = _lib.PropB16Args(B, Cn, S, len(T_list), dd, 1, None, None, 0, None, None, 0, None, None, None, None, None)
+    return _lib.lib().recon_propagate_b16_form(C.byref(probe)) != 0
+
+
 def propagate_blocks(T_list, identity, n, h0, nonlinearity, head_indices, tail_indices):
     """models/models.py:240-274 in one call: T_list = L transition tensors [B, n(n-1), (2d)^2] (or [B, n-1, n, (2d)^2]) AFTER their
     non-linearity, identity [2d, 2d]; equivalent to
@@ -465,10 +561,12 @@ def propagate_blocks(T_list, identity, n, h0, nonlinearity, head_indices, tail_i
     B, dd = T_list[0].shape[0], identity.shape[0]
     need_grad = torch.is_grad_enabled() and (identity.requires_grad or h0.requires_grad or any(T.requires_grad for T in T_list))
     if _float_dtype(h0, identity, *T_list) == torch.bfloat16:
-        # bfloat16: inference on small states reads the transition tensors in place (csrc/prop_b16.hip, block mode); training and wide
-        # states go through the materialised bf16 adjacency (both backward products are batched GEMMs over it)
+        # bfloat16: the kernels read the transition tensors in place (csrc/prop_b16.hip, block mode) — inference through the fused forms,
+        # training through _PropagateBlocksB16 (no adjacency is materialised in either direction); other shapes: block adjacency + propagate
         if not need_grad and _blocks_b16_available(B, n, dd, h0, T_list, identity):
             return _propagate_blocks_b16(T_list, identity, n, h0, nonlinearity, head_indices, tail_indices)
+        if need_grad and _blocks_b16_trainable(B, n, dd, h0, T_list, identity):
+            return _PropagateBlocksB16.apply(h0, identity, nonlinearity, head_indices, tail_indices, n, *T_list)
         return propagate([build_block_adjacency(T, identity, n) for T in T_list], h0, nonlinearity, head_indices, tail_indices)
     if not blocks_mode_available(B, n, dd, h0, need_grad, L=len(T_list), T_list=T_list):
         return propagate([build_block_adjacency(T, identity, n) for T in T_list], h0, nonlinearity, head_indices, tail_indices)
