@@ -277,6 +277,49 @@ def test_cfg5_bf16_stack_gradients_layer_by_layer():
 
 # ------------------------------------------------------------------------------- cfg 3b in bf16 at B = 1 024 (BASELINE.json configs[2])
 @pytest.mark.parametrize("n,copies_of", [(9, 512), (32, 8)])
+def test_cfg3b_bf16_full_batch_block_mode_training(n, copies_of):
+    """The same configuration through propagate_blocks() with gradients — what a bfloat16 GPGNN / RECON_EAC training step runs: no
+    adjacency is materialised, d T_l comes back in T's layout, d identity as one [16, 16] sum over graphs, nodes and hops.  (i) the first
+    graphs (forward, d T, d h0) against the oracle from the forward's own states, (ii) d identity against the oracle's diagonal blocks
+    summed over ALL graphs, (iii) copies bit-equal."""
+    from recon_amd import propagation as P
+    d_ = dev()
+    d, L, B, act = 8, 3, 1024, "relu"
+    C, S, dd = n * (n - 1), 16 * n, 16
+    Ts, ident, h0, head, tail, Gr = _prop_problem(n, d, L, copies_of, seed=23, scale=1.2 / S ** 0.5)
+    reps = B // copies_of
+    Tb = [_bf(t).to(d_).repeat(reps, 1, 1).requires_grad_(True) for t in Ts]
+    Ib = _bf(ident).to(d_).requires_grad_(True)
+    hb = _bf(h0).to(d_).repeat(reps, 1, 1, 1).requires_grad_(True)
+    Gb = _bf(Gr).to(d_).repeat(reps, 1, 1)
+    P._KEEP_STATES, P._LAST_STATES = True, None
+    try:
+        out = P.propagate_blocks(Tb, Ib, n, hb, act, head.to(d_), tail.to(d_))
+        states = P._LAST_STATES
+    finally:
+        P._KEEP_STATES, P._LAST_STATES = False, None
+    assert states is not None and out.shape == (B, C, dd * L) and out.dtype == torch.bfloat16
+    (out.float() * Gb.float()).sum().backward()
+    k = copies_of if n <= 16 else 8                                    # graphs the oracle runs (all distinct ones: d identity sums over them)
+    adj_r = [O.build_block_adjacency(_bf(t[:k]).float(), _bf(ident).float(), n) for t in Ts]
+    h0_r = _bf(h0[:k]).float()
+    ref = O.propagate(adj_r, h0_r, act, head, tail, as_gemm=True, storage=torch.bfloat16)
+    close(out[:k].float(), ref, atol=1e-3, rel_to_max=1.5e-2, what="blocks bf16 n=%d out" % n)
+    g_adj_r, g_h_r = O.propagate_backward(adj_r, h0_r, [s_[:k].float().cpu() for s_ in states], act, head, tail, _bf(Gr[:k]).float(), storage=torch.bfloat16)
+    gI = torch.zeros(dd, dd)
+    for l in range(L):
+        blocks = g_adj_r[l].reshape(k, n, dd, n, dd).permute(0, 1, 3, 2, 4)
+        off = torch.stack([blocks[:, i, j] for i in range(n) for j in range(n) if i != j], 1).reshape(k, C, dd * dd)
+        close(Tb[l].grad[:k].float(), off, atol=1e-3, rel_to_max=2e-2, what="blocks bf16 n=%d g_T[%d]" % (n, l))
+        gI += torch.stack([blocks[:, i, i] for i in range(n)], 1).sum((0, 1))
+    close(hb.grad[:k].float().reshape(g_h_r.shape), g_h_r, atol=1e-3, rel_to_max=2e-2, what="blocks bf16 n=%d g_h0" % n)
+    close(Ib.grad.float(), gI * (B // k), atol=1e-2, rel_to_max=2e-2, what="blocks bf16 n=%d g_identity" % n)
+    for t in [out, hb.grad] + [t.grad for t in Tb]:
+        v = t.view(reps, copies_of, -1)
+        assert torch.equal(v[1], v[0]) and torch.equal(v[reps - 1], v[0]), "copies of the same graphs differ"
+
+
+@pytest.mark.parametrize("n,copies_of", [(9, 512), (32, 8)])
 def test_cfg3b_bf16_full_batch_forward_and_all_gradients(n, copies_of):
     """BASELINE.json configs[2] "GP-GNN Propagation 3 hops, batch 1024 graphs, 32 nodes ... bf16" (and the reference's own n = 9): block
     adjacency + three hops + every gradient on bf16 tensors at B = 1 024.  The batch is 1 024 / copies_of copies of `copies_of` graphs:

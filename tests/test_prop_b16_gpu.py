@@ -188,12 +188,17 @@ def test_propagate_blocks_b16_inference_matches_materialised(n, L, B, act, per_b
     close(fused.float(), ref, atol=1e-3, rel_to_max=1.5e-2, what="blocks b16 n=%d" % n)
 
 
-def test_propagate_blocks_b16_training_vs_oracle():
-    """models/models.py:240-274 on bf16 tensors with gradients: transition tensors -> relu -> block adjacency -> 3 hops -> loss, all
-    gradients (d T_l, d identity, d h0) against the oracle's autograd run from the forward's own states."""
+@pytest.mark.parametrize("n,L,B,ypost", [(9, 3, 6, "fused"), (9, 3, 6, "kernel"), (11, 2, 3, "fused"), (12, 2, 10, "fused"), (4, 3, 5, "fused")])
+def test_propagate_blocks_b16_training_vs_oracle(n, L, B, ypost, monkeypatch):
+    """models/models.py:240-274 on bf16 tensors with gradients, no adjacency materialised in either direction: transition tensors -> relu ->
+    [block adjacency read in place] -> L hops -> loss, all gradients (d T_l in T's layout, d identity, d h0) against the oracle's closed
+    form run from the forward's own states.  n = 9 / 4: fused small forward; n = 11: every hop a batched GEMM reading T in place; n = 12:
+    the wide fused forward.  `kernel`: Y_l by the separate pass instead of the GEMM epilogue (RECON_PROP_B16_YPOST=k)."""
+    if ypost == "kernel":
+        monkeypatch.setenv("RECON_PROP_B16_YPOST", "k")
     from recon_amd import propagation as P
     d_ = dev()
-    n, d, L, B = 9, 8, 3, 6
+    d = 8
     dd, C, S = 16, n * (n - 1), 16 * n
     g = torch.Generator().manual_seed(11)
     Ts = [_bf((torch.rand(B, C, dd * dd, generator=g) - 0.3) * (1.5 / S ** 0.5)) for _ in range(L)]
