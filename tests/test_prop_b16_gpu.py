@@ -230,3 +230,32 @@ def test_propagate_blocks_b16_training_vs_oracle(n, L, B, ypost, monkeypatch):
         close(Td[l].grad.float(), gT, atol=1e-3, rel_to_max=2e-2, what="blocks b16 g_T[%d]" % l)
         gI += torch.stack([blocks[:, i, i] for i in range(n)], 1).sum((0, 1))
     close(Id.grad.float(), gI, atol=1e-2, rel_to_max=3e-2, what="blocks b16 g_identity")      # L sums of bf16-rounded per-hop sums
+
+
+@pytest.mark.parametrize("name", ["gpgnn1_untied", "gpgnn2_tied_n9"])
+def test_gpgnn_model_runs_in_bfloat16(name):
+    """`GPGNN(...).to(torch.bfloat16)` (models/models.py:85-277 with bfloat16 parameters): the stock encoder in bf16, transition tensors ->
+    block adjacency -> propagation through the bfloat16 kernels (block mode, with gradients).  Logits against the reference's own float32
+    logits of the same checkpoint (bf16 rounding of every stage: 5e-2 of the largest logit), every trainable parameter gets a finite
+    gradient whose direction agrees with the reference's."""
+    from conftest import load_golden
+    from recon_amd.gpgnn import GPGNN
+    g = load_golden(name)
+    p = {"max_num_nodes": int(g["n"]), "embedding_dim": int(g["d"]), "layer_number": int(g["L"]), "projection_style": str(g["style"]),
+         "non-linear1": "relu", "non-linear": "tanh", "dropout1": 0.0, "position_emb": 3, "units1": 4, "rnn1_layers": 1,
+         "bidirectional": 1, "batch_size": int(g["B"])}
+    m = GPGNN(p, g["emb"], max_sent_len=4, n_out=3)
+    m.load_state_dict({k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("sd.")}, strict=False)
+    m.train().to(dev()).to(BF)
+    out = m(torch.from_numpy(g["sent"]).to(dev()), torch.from_numpy(g["mark"]).to(dev()), None)
+    assert out.dtype == BF
+    close(out.float(), g["out"], atol=2e-3, rel_to_max=5e-2, what="gpgnn bf16 logits")
+    (out.float() * torch.from_numpy(g["G"]).to(dev())).sum().backward()
+    for k, v in m.named_parameters():
+        if "g." + k in g and v.requires_grad:
+            assert v.grad is not None and v.grad.dtype == BF and torch.isfinite(v.grad.float()).all(), k
+            ref = torch.from_numpy(np.asarray(g["g." + k])).flatten()
+            got = v.grad.float().cpu().flatten()
+            if ref.norm() > 1e-6:
+                cos = float((ref @ got) / (ref.norm() * got.norm() + 1e-30))
+                assert cos > 0.98, "grad %s: cosine %.4f against the float32 reference" % (k, cos)
