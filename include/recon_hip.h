@@ -345,10 +345,18 @@ typedef struct {
     float* identity_ws;             /* block mode: recon_propagate_identity_ws_floats() floats when g_identity is wanted    */
     float* wide_ws;                 /* recon_propagate_bwd_ws_floats() floats or NULL.  Wide states (S > 160): with it both products *
                                      * of a hop run as batched GEMMs over the graphs; without it, the channel-chunked kernel         */
+    const int32_t* head_blk;        /* [C] device or NULL: the gather indices are BLOCKS of 16 consecutive columns (head_idx[c, x] =   *
+                                     * head_blk[c] + x, likewise tail; dd = 16, block starts multiples of 16, head and tail blocks of  *
+                                     * a channel distinct, idx_batch_stride = 0 — what utils/embedding_utils.py:184-202 builds; the    *
+                                     * caller has checked it).  With chain_ws and fwd.split_ws the wide backward then runs its chain   *
+                                     * d loss / d H^l-1 = A_l^T Y_l on the forward's two-term f16 kernel, all hops in one launch       */
+    const int32_t* tail_blk;
+    float* chain_ws;                /* recon_propagate_bwd_chain_ws_floats() floats or NULL                                            */
 } recon_prop_bwd_args;
 
 size_t recon_propagate_identity_ws_floats(int32_t dd);
 size_t recon_propagate_bwd_ws_floats(const recon_prop_args* fwd);   /* B*C*S for S > 160 (not in block mode), else 0 */
+size_t recon_propagate_bwd_chain_ws_floats(const recon_prop_args* fwd);   /* L * (graphs per slice) * C * S where the chain form exists (160 < S <= 512, dd = 16, shared indices, fwd.split_ws set), else 0 */
 
 int recon_propagate_bwd(const recon_prop_bwd_args* args, recon_stream_t stream);
 

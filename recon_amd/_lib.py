@@ -68,7 +68,8 @@ class PropArgs(C.Structure):
 
 class PropBwdArgs(C.Structure):
     _fields_ = [("fwd", PropArgs), ("grad_out", c_f32p), ("g_adj", C.POINTER(C.c_void_p)), ("g_h", c_f32p),
-                ("g_trans", C.POINTER(C.c_void_p)), ("g_identity", c_f32p), ("identity_ws", c_f32p), ("wide_ws", c_f32p)]
+                ("g_trans", C.POINTER(C.c_void_p)), ("g_identity", c_f32p), ("identity_ws", c_f32p), ("wide_ws", c_f32p),
+                ("head_blk", C.c_void_p), ("tail_blk", C.c_void_p), ("chain_ws", c_f32p)]
 
 
 class PropB16Args(C.Structure):
@@ -153,6 +154,7 @@ SYMBOLS = [
     ("recon_propagate_identity_ws_floats", C.c_size_t, [C.c_int32]),
     ("recon_propagate_ws_bytes", C.c_size_t, [C.POINTER(PropArgs)]),
     ("recon_propagate_bwd_ws_floats", C.c_size_t, [C.POINTER(PropArgs)]),
+    ("recon_propagate_bwd_chain_ws_floats", C.c_size_t, [C.POINTER(PropArgs)]),
     ("recon_propagate_b16_form", C.c_int, [C.POINTER(PropB16Args)]),
     ("recon_propagate_b16_fwd", C.c_int, [C.POINTER(PropB16Args), C.c_void_p]),
     ("recon_propagate_b16_bwd", C.c_int, [C.POINTER(PropB16BwdArgs), C.c_void_p]),

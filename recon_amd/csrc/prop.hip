@@ -1114,7 +1114,61 @@ int prop_bwd_wide(const recon_prop_args* a, const recon_prop_bwd_args* ba, hipSt
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
 }
+
+// The same backward with the chain G_{l-1} = Y_l A_l, Y_{l-1} = (G_{l-1} + relation gradient) . act'(H^{l-1}) on the forward's two-term f16 kernel
+// (prop_hl.hip: k_propagate_fwd_hl<.., true> over the TRANSPOSED adjacencies, all L steps of a slice of graphs in one launch — no G round
+// trip, no row kernel between the hops); the Y_l leave as fp32 and feed the d A_l products.  Needs the gather indices as blocks of 16 columns
+// (GP-GNN's: utils/embedding_utils.py:184-202), the forward's split workspace and L slices of [G, C, S] floats.
+int prop_bwd_wide_chain(const recon_prop_args* a, const recon_prop_bwd_args* ba, hipStream_t st) {
+    const int32_t B = a->B, C = a->C, S = a->S, L = a->L;
+    const int64_t CS = 1LL * C * S, BCS = CS * B;
+    const int64_t G = prop_bwd_hl_slice(C, S, L, a->split_ws_bytes, B);
+    if (G <= 0) return RECON_ERR_UNSUPPORTED;
+    const size_t plds = 4ull * S * sizeof(float);
+    for (int64_t g0 = 0; g0 < B; g0 += G) {
+        const int32_t Gs = static_cast<int32_t>(B - g0 < G ? B - g0 : G);
+        PropBwdHL c{};
+        c.G = Gs; c.C = C; c.S = S; c.L = L; c.dd = a->dd; c.act = a->act; c.ws = a->split_ws; c.ws_bytes = a->split_ws_bytes;
+        c.gout = ba->grad_out + g0 * C * L * a->dd; c.hblk = ba->head_blk; c.tblk = ba->tail_blk;
+        float* yb[kMaxHops];
+        for (int k = 0; k < L; ++k) yb[k] = ba->chain_ws + static_cast<int64_t>(k) * G * CS;            // Y_L, Y_{L-1}, ..., Y_1
+        // Y_L = relation gradient of the last hop . act'(H^L)
+        hipLaunchKernelGGL(k_prop_bwd_post, dim3(static_cast<unsigned>(ceil_div64(1LL * Gs * C, 4))), dim3(256), plds, st, nullptr,
+                           a->h_saved + static_cast<int64_t>(L - 1) * BCS + g0 * CS, a->head_idx, a->tail_idx, 0, c.gout, yb[0], 1LL * Gs * C, C, S, L, a->dd,
+                           L - 1, a->act);
+        c.y_in = yb[0];
+        for (int k = 0; k < L; ++k) {
+            const int l = L - k;
+            c.adj_step[k] = a->adj[l - 1] + g0 * S * S;
+            c.hmask[k] = l >= 2 ? a->h_saved + static_cast<int64_t>(l - 2) * BCS + g0 * CS : nullptr;
+            c.ysave[k] = l >= 2 ? yb[k + 1] : ba->g_h + g0 * CS;
+            c.gout_off[k] = l >= 2 ? (l - 2) * a->dd : 0;
+        }
+        int rc = prop_bwd_hl_chain(c, st);
+        if (rc != RECON_OK) return rc;
+        for (int k = 0; k < L; ++k) {                                   // d A_l[b] = Y_l[b]^T [S x C] . H^l-1[b] [C x S]
+            const int l = L - k;
+            if (!(ba->g_adj && ba->g_adj[l - 1])) continue;
+            const float* Hprev = l == 1 ? a->h0 + g0 * a->h0_batch_stride : a->h_saved + static_cast<int64_t>(l - 2) * BCS + g0 * CS;
+            GemmBatch bt;
+            bt.batch = Gs; bt.epilogue = 0;
+            bt.a_bs = CS; bt.b_bs = l == 1 ? a->h0_batch_stride : CS; bt.c_bs = 1LL * S * S;
+            rc = gemm_f32_batched(S, S, C, plain_operand(yb[k], S), false, plain_operand(Hprev, S), false, plain_output(ba->g_adj[l - 1] + g0 * S * S, S), bt, 1,
+                                  nullptr, st);
+            if (rc != RECON_OK) return rc;
+        }
+    }
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
 }  // namespace
+
+extern "C" size_t recon_propagate_bwd_chain_ws_floats(const recon_prop_args* a) {
+    if (!a || a->trans || a->B <= 0 || a->dd != 16 || a->idx_batch_stride != 0 || !a->split_ws) return 0;
+    const int64_t G = prop_bwd_hl_slice(a->C, a->S, a->L, a->split_ws_bytes, a->B);
+    static const bool off = getenv("RECON_PROP_BWD_CHAIN") && getenv("RECON_PROP_BWD_CHAIN")[0] == '0';
+    return (G <= 0 || off) ? 0 : static_cast<size_t>(a->L) * G * a->C * a->S;
+}
 
 extern "C" size_t recon_propagate_bwd_ws_floats(const recon_prop_args* a) {
     if (!a || a->trans || a->S <= 160 || a->B <= 0) return 0;
@@ -1151,6 +1205,8 @@ extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t
     } else if (a->trans) return RECON_ERR_UNSUPPORTED;
     {
         static const bool wide_off = getenv("RECON_PROP_BWD_WIDE") && getenv("RECON_PROP_BWD_WIDE")[0] == '0';
+        if (!wide_off && ba->chain_ws && ba->head_blk && ba->tail_blk && a->S > 160 && recon_propagate_bwd_chain_ws_floats(a) > 0)
+            return prop_bwd_wide_chain(a, ba, as_stream(stream));      // wide states, structured indices: the chain on the two-term f16 kernel
         if (!wide_off && ba->wide_ws && a->S > 160 && 4ull * a->S * sizeof(float) <= 64 * 1024)     // wide states: both products as batched GEMMs
             return prop_bwd_wide(a, ba, as_stream(stream));
     }

@@ -67,6 +67,21 @@ int prop_fwd_h(const PropK& p, hipStream_t st);
 size_t prop_hl_ws_bytes(int B, int S, int L);
 bool prop_fwd_hl_supported(const PropK& p);
 int prop_fwd_hl(const PropK& p, hipStream_t st);
+// prop_hl.hip: the backward's chain d loss / d H^{l-1} = A_l^T Y_l, Y_{l-1} = (. + relation gradient) act'(H^{l-1}) for a SLICE of G graphs
+// (all pointers slice-local) on the forward's kernel; step k = 0 .. L-1 is hop l = L - k
+struct PropBwdHL {
+    const float* adj_step[kMaxHops];  // A_{L-k} [G][S][S]
+    const float* y_in;                // Y_L [G][C][S]
+    const float* hmask[kMaxHops];     // H^{l-1} [G][C][S], null for the last step (l = 1)
+    float* ysave[kMaxHops];           // Y_{l-1} [G][C][S]; the last step's is d loss / d h^0
+    const float* gout;                // [G][C][L dd]
+    const int32_t* hblk; const int32_t* tblk;   // [C] first columns of the head / tail blocks (multiples of 16; dd = 16)
+    int32_t gout_off[kMaxHops];       // (l - 2) dd
+    int32_t G, C, S, L, dd, act;
+    void* ws; int64_t ws_bytes;       // split workspace (recon_propagate_ws_bytes)
+};
+int64_t prop_bwd_hl_slice(int C, int S, int L, int64_t ws_bytes, int B);   // graphs per slice the workspace allows (0: form not available)
+int prop_bwd_hl_chain(const PropBwdHL& a, hipStream_t st);
 bool prop_bwd_h_shape_ok(int C, int S);   // LDS budget of the backward's two-term form
 int prop_h_grid(int B);               // workgroups the two-term kernels launch for B graphs (one per CU, persistent)
 bool prop_bwd_h_supported(const PropBwdH& p);

@@ -30,13 +30,20 @@ struct PropHL {
     unsigned char* split;               // [L][G][RTT = 8 RT][NKS][2 terms][64 lanes x 16 B]
     float* alpha;                       // [L][G][RP = 128 RT] inverse row scales
     int32_t g0, G, nchunks, NKS, RT;    // slice = graphs g0 .. g0 + G - 1; NKS even (K padded with zeros)
+    // ---- backward chain (k_propagate_fwd_hl<.., true>): step k multiplies by A_{L-k}^T (p.adj[k], split TRANSPOSED) and forms
+    //      Y_{l-1} = (G + relation gradient of hop l-1) . act'(H^{l-1}) in its epilogue, l = L - k
+    const float* hmask[kMaxHops];       // H^{l-1} of step k ([G][C][S], slice-local) or null (l = 1: the product itself is d loss / d h^0)
+    float* ysave[kMaxHops];             // where step k's new state goes ([G][C][S]): Y_{l-1}, the last one d loss / d h^0
+    const float* gout;                  // [G][C][gout_ld]
+    const int32_t* hblk; const int32_t* tblk;   // [C]: head / tail indices are blocks of 16 columns starting here (multiples of 16)
+    int32_t gout_ld, gout_off[kMaxHops];        // L dd; column of step k's relation gradient ((l - 2) dd)
 };
 
 // ---------------------------------------------------------------------------------------------------------------- split pass
 // One wave per (hop, graph, 16 rows): the rows' fragments for all K steps in registers, row maximum across the four lanes of a row,
 // scale, two half terms, 16-byte stores in fragment order.  K step ks, lane (li, lq): t = 32 ks + 4 lq .. + 3 and 32 ks + 16 + 4 lq .. + 3
 // (the k permutation of prop_h.hip: both pieces are contiguous 16 bytes of the fp32 row).
-template <bool BLK>
+template <bool BLK, bool TRANS = false>
 __global__ void __launch_bounds__(256) k_prop_split_adj(const PropHL q) {
     const PropK& p = q.p;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -50,7 +57,22 @@ __global__ void __launch_bounds__(256) k_prop_split_adj(const PropHL q) {
     const int b = q.g0 + g, S = p.S;
     constexpr int MAXK = 16;
     u32x4 raw[MAXK][2];
-    if constexpr (!BLK) {
+    if constexpr (TRANS) {
+        // rows of A_l^T: element (row, t) = A_l[t][row]; the 16 lanes li of a group read 64 contiguous bytes of row t of A_l
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.adj[l] + static_cast<int64_t>(b) * S * S), 0, S * S * 4, 0x00020000);
+        const int row = 16 * rt + li;
+#pragma unroll
+        for (int ks = 0; ks < MAXK; ++ks)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t0 = 32 * ks + 16 * h + 4 * lq;
+                uint32_t e[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    e[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, (row < S && t0 + i < S) ? static_cast<uint32_t>((t0 + i) * S + row) * 4u : kOOB, 0, 0);
+                raw[ks][h] = u32x4{e[0], e[1], e[2], e[3]};
+            }
+    } else if constexpr (!BLK) {
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.adj[l] + static_cast<int64_t>(b) * S * S), 0, S * S * 4, 0x00020000);
         const int row = 16 * rt + li;
         const uint32_t base = row < S ? static_cast<uint32_t>(row * S + 4 * lq) * 4u : kOOB;
@@ -114,7 +136,7 @@ __device__ __forceinline__ int hl_pos4(int c, int t0) {                 // t0 % 
     return (t0 >> 5) * kSTEP + 64 * c + ((((t0 >> 2) & 3) ^ ((c >> 1) & 3)) << 4) + (((t0 >> 4) & 1) << 3);
 }
 
-template <int RT, int NKS>
+template <int RT, int NKS, bool BWD = false>
 __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const PropK& p = q.p;
@@ -205,7 +227,7 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
     }
     // ---- gather items of this thread (the same in every hop): (channel cl, x) -> byte positions of head / tail in plane 0
     const int nitems = nch * p.dd, Ldd = L * p.dd;
-    {
+    if constexpr (!BWD) {
         uint32_t g_hi[2], g_ti[2], g_o[2], g_c[2];
         const int64_t* hd = p.head + b * p.idx_bs + static_cast<int64_t>(c0) * p.dd;
         const int64_t* tl = p.tail + b * p.idx_bs + static_cast<int64_t>(c0) * p.dd;
@@ -229,7 +251,16 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
 
     const int swz = ((li >> 1) & 3) << 4;
     const int b_rd = li * 64 + ((lq << 4) ^ swz);                       // B fragment: + 1024 j + kSTEP ks (+ PLANE for the low terms)
-    const bool homog = p.act != RECON_ACT_TANH, relu = p.act == RECON_ACT_RELU;
+    // backward chain: everything a step applies to its product is linear in it (a mask, 1 - h^2, an added term): the channel scale commutes
+    const bool homog = BWD || p.act != RECON_ACT_TANH, relu = !BWD && p.act == RECON_ACT_RELU;
+    // BWD: first columns of the channels' head / tail blocks live in the (otherwise unused) gather table: [0 .. 63] head, [64 .. 127] tail
+    if constexpr (BWD) {
+        if (tid < 2 * kCH) {
+            const int cc = min(c0 + (tid & (kCH - 1)), C - 1);
+            gtab[tid] = static_cast<uint32_t>(tid < kCH ? q.hblk[cc] : q.tblk[cc]);
+        }
+        lds_barrier();
+    }
 
 #pragma unroll 1
     for (int l = 0; l < L; ++l) {
@@ -286,16 +317,62 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
         uint32_t* cm = chmax + (l & 1) * kCH;
         float4 ia[RT];                                                  // inverse row scales of this wave's rows (C layout: rows 4 lq + r of each row tile)
 #pragma unroll
-        for (int r = 0; r < RT; ++r) ia[r] = *reinterpret_cast<const float4*>(atab + l * RP + 16 * (wave * RT + r) + 4 * lq);
+        for (int r = 0; r < RT; ++r) if constexpr (!BWD) ia[r] = *reinterpret_cast<const float4*>(atab + l * RP + 16 * (wave * RT + r) + 4 * lq);
+        const float* ia_lds = atab + l * RP + 16 * wave * RT + 4 * lq;   // BWD re-reads them where they are used (registers)
+        // BWD: H^{l-1} of this chunk (activation derivative, relation gradient) and grad_out as range-checked buffers: rows past S and
+        // channels past C read zeros
+        const float* hm = nullptr;
+        __amdgpu_buffer_rsrc_t rs_hm, rs_go;
+        if constexpr (BWD) {
+            hm = q.hmask[l];
+            const int64_t row0 = static_cast<int64_t>(b) * C + c0;
+            rs_hm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((hm ? hm : p.h0) + row0 * S), 0, nch * S * 4, 0x00020000);
+            rs_go = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.gout + row0 * q.gout_ld + q.gout_off[l]), 0,
+                                                      (nch * q.gout_ld - q.gout_off[l]) * 4, 0x00020000);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float mm = 0.f;
+            [[maybe_unused]] u32x4 dm[RT];                              // BWD: H^{l-1}[c][rows of this lane], all row tiles requested at once
+            [[maybe_unused]] float sig = 1.f;
+            if constexpr (BWD) {
+                if (hm) {
+                    const uint32_t cb = static_cast<uint32_t>((16 * j + li) * S) * 4u;
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        const int t0 = 16 * (wave * RT + r) + 4 * lq;
+                        dm[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_hm, t0 < S ? cb + static_cast<uint32_t>(t0) * 4u : kOOB, 0, 0);
+                    }
+                    sig = hx2_inv(inv_sig[j]);                          // the product is in units of the old channel scale: so is what is added to it
+                }
+            }
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
                 const float u = homog ? 1.f : inv_sig[j];
+                if constexpr (BWD) {
+                    const f32x4 t = *reinterpret_cast<const volatile f32x4*>(ia_lds + 16 * r);
+                    ia[r] = make_float4(t[0], t[1], t[2], t[3]);
+                }
                 float v0 = acc[r][j][0] * (ia[r].x * u), v1 = acc[r][j][1] * (ia[r].y * u), v2 = acc[r][j][2] * (ia[r].z * u), v3 = acc[r][j][3] * (ia[r].w * u);
                 if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                 if (!homog) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
+                if constexpr (BWD) {
+                    if (hm) {
+                        // relation gradient of hop l-1 (models/models.py:270-273 backwards): out = h[head] * h[tail] puts grad_out * h[tail block]
+                        // on the head block's rows and grad_out * h[head block] on the tail block's — this row tile is one of them for few channels
+                        const int T16 = 16 * (wave * RT + r);
+                        const int hbj = static_cast<int>(gtab[16 * j + li]), tbj = static_cast<int>(gtab[kCH + 16 * j + li]);
+                        const int sel = T16 == hbj ? tbj : (T16 == tbj ? hbj : -1);
+                        if (sel >= 0 && 16 * j + li < nch) {
+                            const u32x4 g4 = __builtin_amdgcn_raw_buffer_load_b128(rs_go, static_cast<uint32_t>((16 * j + li) * q.gout_ld + 4 * lq) * 4u, 0, 0);
+                            const u32x4 h4 = __builtin_amdgcn_raw_buffer_load_b128(rs_hm, static_cast<uint32_t>((16 * j + li) * S + sel + 4 * lq) * 4u, 0, 0);
+                            v0 += as_f(g4.x) * as_f(h4.x) * sig; v1 += as_f(g4.y) * as_f(h4.y) * sig;
+                            v2 += as_f(g4.z) * as_f(h4.z) * sig; v3 += as_f(g4.w) * as_f(h4.w) * sig;
+                        }
+                        const u32x4 d = dm[r];
+                        v0 *= act_bwd(as_f(d.x), p.act); v1 *= act_bwd(as_f(d.y), p.act); v2 *= act_bwd(as_f(d.z), p.act); v3 *= act_bwd(as_f(d.w), p.act);
+                    }
+                }
                 acc[r][j] = f32x4{v0, v1, v2, v3};
                 mm = fmaxf(mm, fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))));
             }
@@ -322,7 +399,8 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
         auto state_at = [&](uint32_t pos) {
             return static_cast<float>(*reinterpret_cast<const _Float16*>(Hs + pos)) + static_cast<float>(*reinterpret_cast<const _Float16*>(Hs + PLANE + pos));
         };
-        char* out = reinterpret_cast<char*>(p.out + ((static_cast<int64_t>(b) * C + c0) * L + l) * p.dd);
+        char* out = BWD ? nullptr : reinterpret_cast<char*>(p.out + ((static_cast<int64_t>(b) * C + c0) * L + l) * p.dd);
+        if constexpr (!BWD) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             if (tid + i * 64 * kHLWaves < nitems) {
@@ -337,8 +415,10 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
             const float k = isg[cl];
             reinterpret_cast<float*>(out)[cl * Ldd + x] = (state_at(hl_pos4(cl, th & ~3) + 2 * (th & 3)) * k) * (state_at(hl_pos4(cl, tt & ~3) + 2 * (tt & 3)) * k);
         }
-        if (p.hsave) {                                                  // wave w: channels w, w + 8, ...; lane = (K step, half, slot), two passes of 256 columns
-            char* hs = reinterpret_cast<char*>(p.hsave + ((static_cast<int64_t>(l) * p.B + b) * C + c0) * S);
+        }
+        if (BWD || p.hsave) {                                           // wave w: channels w, w + 8, ...; lane = (K step, half, slot), two passes of 256 columns
+            char* hs = BWD ? reinterpret_cast<char*>(q.ysave[l] + (static_cast<int64_t>(b) * C + c0) * S)
+                           : reinterpret_cast<char*>(p.hsave + ((static_cast<int64_t>(l) * p.B + b) * C + c0) * S);
             for (int cl = wave; cl < nch; cl += kHLWaves) {
                 const float k = isg[cl];
 #pragma unroll
@@ -426,6 +506,50 @@ int prop_fwd_hl(const PropK& p, hipStream_t st) {
         }
 #undef CALL_HL
     }
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- backward chain
+// d loss / d H^{l-1} = A_l^T Y_l is a propagation with the transposed adjacencies, Y_{l-1} = (that + relation gradient) . act'(H^{l-1}) its
+// "activation": the forward's kernel with another epilogue (k_propagate_fwd_hl<.., true>) runs all L steps of a slice of graphs in one
+// launch, the Y_l (operands of the d A_l products) leaving as fp32 like the forward's saved states.
+int64_t prop_bwd_hl_slice(int C, int S, int L, int64_t ws_bytes, int B) {
+    if (S <= 160 || S > 512 || (S % 16) != 0 || L < 1 || L > kMaxHops || B <= 0) return 0;
+    const HLGeom g = hl_geom(S, L);
+    if (g.lds > 160 * 1024 || static_cast<int64_t>(C) * S * 4 >= (1LL << 31)) return 0;
+    int64_t G = (ws_bytes - 256) / static_cast<int64_t>(g.per_graph_split + g.per_graph_alpha);
+    if (G > B) G = B;
+    if (G > kHLSlice) G = kHLSlice;
+    return G < 0 ? 0 : G;
+}
+
+int prop_bwd_hl_chain(const PropBwdHL& a, hipStream_t st) {
+    const int64_t G = prop_bwd_hl_slice(a.C, a.S, a.L, a.ws_bytes, a.G);
+    if (G < a.G || a.dd != 16 || !a.hblk || !a.tblk) return RECON_ERR_UNSUPPORTED;
+    const HLGeom g = hl_geom(a.S, a.L);
+    PropHL q{};
+    q.p.B = a.G; q.p.C = a.C; q.p.S = a.S; q.p.L = a.L; q.p.dd = a.dd; q.p.act = a.act;
+    q.p.h0 = a.y_in; q.p.h0_bs = static_cast<int64_t>(a.C) * a.S;
+    for (int k = 0; k < a.L; ++k) { q.p.adj[k] = a.adj_step[k]; q.hmask[k] = a.hmask[k]; q.ysave[k] = a.ysave[k]; q.gout_off[k] = a.gout_off[k]; }
+    q.gout = a.gout; q.gout_ld = a.L * a.dd; q.hblk = a.hblk; q.tblk = a.tblk;
+    q.split = static_cast<unsigned char*>(a.ws);
+    q.alpha = reinterpret_cast<float*>(q.split + ((g.per_graph_split * static_cast<size_t>(a.G) + 255) & ~static_cast<size_t>(255)));
+    q.NKS = g.NKS; q.RT = g.RT; q.nchunks = (a.C + kCH - 1) / kCH; q.g0 = 0; q.G = a.G;
+    const int64_t units = static_cast<int64_t>(a.L) * q.G * 8 * g.RT;
+    hipLaunchKernelGGL((k_prop_split_adj<false, true>), dim3(static_cast<unsigned>((units + 3) / 4)), dim3(256), 0, st, q);
+    const dim3 grid(static_cast<unsigned>(((q.G + 7) / 8) * 8 * q.nchunks));
+#define CALL_HLB(R_, K_)                                                                                                                      \
+    do {                                                                                                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_fwd_hl<R_, K_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  static_cast<int>(g.lds));                                                                                   \
+        hipLaunchKernelGGL((k_propagate_fwd_hl<R_, K_, true>), grid, dim3(64 * kHLWaves), g.lds, st, q);                                      \
+    } while (0)
+    switch (g.NKS) {
+        case 6: CALL_HLB(2, 6); break; case 8: CALL_HLB(2, 8); break; case 10: CALL_HLB(3, 10); break; case 12: CALL_HLB(3, 12); break;
+        case 14: CALL_HLB(4, 14); break; default: CALL_HLB(4, 16); break;
+    }
+#undef CALL_HLB
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
 }

@@ -244,9 +244,20 @@ class _Propagate(torch.autograd.Function):
         fwd = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], parr, h0c.data_ptr(), h0_bs, head.data_ptr(), tail.data_ptr(),
                             idx_bs, None, hs.data_ptr(), None, None, _lib.ptr(ctx.stats), None, 0)
         fwd.out = gout.data_ptr()      # unused by the backward; must be non-null for the argument check
-        nws = _lib.lib().recon_propagate_bwd_ws_floats(C.byref(fwd))     # wide states: both products of a hop as batched GEMMs
-        wide = torch.empty(nws, dtype=torch.float32, device=dev) if nws else None
-        args = _lib.PropBwdArgs(fwd, gout.data_ptr(), garr, g_h.data_ptr(), None, None, None, _lib.ptr(wide))
+        # wide states (S > 160): GP-GNN's block-structured gather indices let the chain of products run on the forward's two-term f16 kernel
+        # (all hops in one launch); otherwise both products of a hop are batched fp32 GEMMs
+        blk = chain = ws = wide = None
+        if S > 160 and dd == 16 and not idx_bs:
+            blk = _index_blocks(head, tail, dd, S, align=16)
+            if blk is not None:
+                ws = _split_workspace(fwd, dev)
+                nch = _lib.lib().recon_propagate_bwd_chain_ws_floats(C.byref(fwd)) if ws is not None else 0
+                chain = torch.empty(nch, dtype=torch.float32, device=dev) if nch else None
+        if chain is None:
+            nws = _lib.lib().recon_propagate_bwd_ws_floats(C.byref(fwd))
+            wide = torch.empty(nws, dtype=torch.float32, device=dev) if nws else None
+        args = _lib.PropBwdArgs(fwd, gout.data_ptr(), garr, g_h.data_ptr(), None, None, None, _lib.ptr(wide),
+                                blk[0].data_ptr() if chain is not None else None, blk[1].data_ptr() if chain is not None else None, _lib.ptr(chain))
         with _lib.on_device(dev):
             _lib.check(_lib.lib().recon_propagate_bwd(C.byref(args), _lib.current_stream()), "recon_propagate_bwd")
         g_h0 = None
@@ -264,19 +275,19 @@ def _b16_args(B, Cn, S, L, dd, act, adjs, h0c, h0_bs, head, tail, idx_bs, out, h
 _BLK_IDX = {}
 
 
-def _index_blocks(head, tail, dd, S):
+def _index_blocks(head, tail, dd, S, align=8):
     """(head_blk, tail_blk) int32 [C] device tensors when the gather indices are blocks of dd consecutive columns — head[c, x] = head[c, 0] + x,
     likewise tail, every block inside [0, S], head and tail blocks of a channel distinct — shared by the batch; else None.  That is what
     utils/embedding_utils.py:184-202 builds; the bfloat16 backward then forms Y_l in its GEMM epilogues.  One host read per index tensor
     pair (cached on identity + version)."""
-    key = (head.data_ptr(), head._version, tail.data_ptr(), tail._version, tuple(head.shape), int(dd), int(S))
+    key = (head.data_ptr(), head._version, tail.data_ptr(), tail._version, tuple(head.shape), int(dd), int(S), int(align))
     hit = _BLK_IDX.get(key)
     if hit is None:
         res = None
         if dd % 8 == 0 and (head.dim() == 2 or head.shape[0] == 1):
             h2, t2 = head.reshape(-1, dd), tail.reshape(-1, dd)
             ar = torch.arange(dd, device=head.device)
-            ok = ((h2 == h2[:, :1] + ar).all() & (t2 == t2[:, :1] + ar).all() & (h2[:, 0] % 8 == 0).all() & (t2[:, 0] % 8 == 0).all()
+            ok = ((h2 == h2[:, :1] + ar).all() & (t2 == t2[:, :1] + ar).all() & (h2[:, 0] % align == 0).all() & (t2[:, 0] % align == 0).all()
                   & (h2[:, 0] >= 0).all() & (t2[:, 0] >= 0).all() & (h2[:, 0] + dd <= S).all() & (t2[:, 0] + dd <= S).all()
                   & ((h2[:, 0] - t2[:, 0]).abs() >= dd).all())
             if bool(ok):
