@@ -1130,18 +1130,19 @@ int prop_bwd_wide_chain(const recon_prop_args* a, const recon_prop_bwd_args* ba,
         PropBwdHL c{};
         c.G = Gs; c.C = C; c.S = S; c.L = L; c.dd = a->dd; c.act = a->act; c.ws = a->split_ws; c.ws_bytes = a->split_ws_bytes;
         c.gout = ba->grad_out + g0 * C * L * a->dd; c.hblk = ba->head_blk; c.tblk = ba->tail_blk;
-        float* yb[kMaxHops];
-        for (int k = 0; k < L; ++k) yb[k] = ba->chain_ws + static_cast<int64_t>(k) * G * CS;            // Y_L, Y_{L-1}, ..., Y_1
+        float* y_in; unsigned char* planes; float* isg; size_t pset, iset;
+        prop_bwd_hl_ws_layout(C, S, L, G, ba->chain_ws, &y_in, &planes, &isg, &pset, &iset);
+        c.yplanes = planes; c.yisg = isg;
         // Y_L = relation gradient of the last hop . act'(H^L)
         hipLaunchKernelGGL(k_prop_bwd_post, dim3(static_cast<unsigned>(ceil_div64(1LL * Gs * C, 4))), dim3(256), plds, st, nullptr,
-                           a->h_saved + static_cast<int64_t>(L - 1) * BCS + g0 * CS, a->head_idx, a->tail_idx, 0, c.gout, yb[0], 1LL * Gs * C, C, S, L, a->dd,
+                           a->h_saved + static_cast<int64_t>(L - 1) * BCS + g0 * CS, a->head_idx, a->tail_idx, 0, c.gout, y_in, 1LL * Gs * C, C, S, L, a->dd,
                            L - 1, a->act);
-        c.y_in = yb[0];
+        c.y_in = y_in;
         for (int k = 0; k < L; ++k) {
             const int l = L - k;
             c.adj_step[k] = a->adj[l - 1] + g0 * S * S;
             c.hmask[k] = l >= 2 ? a->h_saved + static_cast<int64_t>(l - 2) * BCS + g0 * CS : nullptr;
-            c.ysave[k] = l >= 2 ? yb[k + 1] : ba->g_h + g0 * CS;
+            c.ysave[k] = l >= 2 ? nullptr : ba->g_h + g0 * CS;           // the Y_l leave as fragment planes
             c.gout_off[k] = l >= 2 ? (l - 2) * a->dd : 0;
         }
         int rc = prop_bwd_hl_chain(c, st);
@@ -1150,11 +1151,9 @@ int prop_bwd_wide_chain(const recon_prop_args* a, const recon_prop_bwd_args* ba,
             const int l = L - k;
             if (!(ba->g_adj && ba->g_adj[l - 1])) continue;
             const float* Hprev = l == 1 ? a->h0 + g0 * a->h0_batch_stride : a->h_saved + static_cast<int64_t>(l - 2) * BCS + g0 * CS;
-            GemmBatch bt;
-            bt.batch = Gs; bt.epilogue = 0;
-            bt.a_bs = CS; bt.b_bs = l == 1 ? a->h0_batch_stride : CS; bt.c_bs = 1LL * S * S;
-            rc = gemm_f32_batched(S, S, C, plain_operand(yb[k], S), false, plain_operand(Hprev, S), false, plain_output(ba->g_adj[l - 1] + g0 * S * S, S), bt, 1,
-                                  nullptr, st);
+            // NOTE: plane sets / scale sets are laid out for slices of G graphs; a short last slice uses the front of each set
+            rc = prop_bwd_hl_gadj(planes + static_cast<size_t>(k) * (pset / G) * Gs, isg + static_cast<size_t>(k) * (iset / G) * Gs, Hprev,
+                                  l == 1 ? a->h0_batch_stride : CS, ba->g_adj[l - 1] + g0 * S * S, Gs, C, S, st);
             if (rc != RECON_OK) return rc;
         }
     }
@@ -1167,7 +1166,7 @@ extern "C" size_t recon_propagate_bwd_chain_ws_floats(const recon_prop_args* a) 
     if (!a || a->trans || a->B <= 0 || a->dd != 16 || a->idx_batch_stride != 0 || !a->split_ws) return 0;
     const int64_t G = prop_bwd_hl_slice(a->C, a->S, a->L, a->split_ws_bytes, a->B);
     static const bool off = getenv("RECON_PROP_BWD_CHAIN") && getenv("RECON_PROP_BWD_CHAIN")[0] == '0';
-    return (G <= 0 || off) ? 0 : static_cast<size_t>(a->L) * G * a->C * a->S;
+    return (G <= 0 || off) ? 0 : prop_bwd_hl_ws_floats(a->C, a->S, a->L, G);
 }
 
 extern "C" size_t recon_propagate_bwd_ws_floats(const recon_prop_args* a) {

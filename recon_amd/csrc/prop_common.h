@@ -79,9 +79,14 @@ struct PropBwdHL {
     int32_t gout_off[kMaxHops];       // (l - 2) dd
     int32_t G, C, S, L, dd, act;
     void* ws; int64_t ws_bytes;       // split workspace (recon_propagate_ws_bytes)
+    unsigned char* yplanes; float* yisg;   // plane sets / scale sets of Y_L, Y_{L-1}, .., Y_1 for the d A products (prop_bwd_hl_ws_layout), or null
 };
 int64_t prop_bwd_hl_slice(int C, int S, int L, int64_t ws_bytes, int B);   // graphs per slice the workspace allows (0: form not available)
 int prop_bwd_hl_chain(const PropBwdHL& a, hipStream_t st);
+size_t prop_bwd_hl_ws_floats(int C, int S, int L, int64_t G);
+void prop_bwd_hl_ws_layout(int C, int S, int L, int64_t G, float* ws, float** y_in, unsigned char** planes, float** isg, size_t* plane_set_bytes, size_t* isg_set_floats);
+// d A_l[g] = Y_l[g]^T H^{l-1}[g] from one plane set of the chain kernel
+int prop_bwd_hl_gadj(const unsigned char* yplanes, const float* yisg, const float* Hprev, int64_t h_bs, float* out, int G, int C, int S, hipStream_t st);
 bool prop_bwd_h_shape_ok(int C, int S);   // LDS budget of the backward's two-term form
 int prop_h_grid(int B);               // workgroups the two-term kernels launch for B graphs (one per CU, persistent)
 bool prop_bwd_h_supported(const PropBwdH& p);

@@ -37,6 +37,11 @@ struct PropHL {
     const float* gout;                  // [G][C][gout_ld]
     const int32_t* hblk; const int32_t* tblk;   // [C]: head / tail indices are blocks of 16 columns starting here (multiples of 16)
     int32_t gout_ld, gout_off[kMaxHops];        // L dd; column of step k's relation gradient ((l - 2) dd)
+    // the states Y_L, Y_{L-1}, .., Y_1 leave as the d A products' streamed operand: two half planes in MFMA fragment order, rows = state
+    // column s, K = channel, as they sit in LDS (i.e. times the channel's power-of-two scale, whose inverse goes to yisg)
+    unsigned char* yplanes;             // [L emissions][G][RTT][NKC][2][1 KiB] or null
+    float* yisg;                        // [L emissions][G][32 NKC]
+    int32_t NKC;                        // K steps of the d A products: channels / 32, rounded up to a multiple of 2
 };
 
 // ---------------------------------------------------------------------------------------------------------------- split pass
@@ -183,6 +188,35 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
         *reinterpret_cast<uint2*>(Hs + PLANE + off) = make_uint2(l0, l1);
     };
 
+    // BWD: the state image -> fragment planes of Y^T for the d A product (lane (li, lq) of row tile T, K step ks: s = 16 T + li, channels
+    // 32 ks + 4 lq .. + 3 and + 16): two transposing reads per plane — lane ip of a 16-lane group addresses the 8 bytes (4 columns) of
+    // channel base + (ip >> 2), columns 16 T + 4 (ip & 3) .., and receives column 16 T + ip of the 4 channels
+    [[maybe_unused]] auto emit_planes = [&](int e) {
+        if constexpr (BWD) {
+            if (!q.yplanes) return;
+            typedef short i16x4_t __attribute__((ext_vector_type(4)));
+            unsigned char* dst = q.yplanes + ((static_cast<int64_t>(e) * q.G + gs) * RTT) * q.NKC * 2048 + lane * 16;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const int T = wave * RT + r, t4 = 16 * T + 4 * (li & 3);
+                if (16 * T >= KP) continue;                             // wave-uniform: row tiles past the image (their rows of d A are not stored)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const int ca = 32 * kk + 4 * lq + (li >> 2);
+                        const unsigned char* a0 = Hs + pl * PLANE + hl_pos4(ca, t4);
+                        const unsigned char* a1 = Hs + pl * PLANE + hl_pos4(ca + 16, t4);
+                        const i16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4_t*)(a0));
+                        const i16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4_t*)(a1));
+                        const u32x4 v = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                        *reinterpret_cast<u32x4*>(dst + ((static_cast<int64_t>(T) * q.NKC + 2 * chunk + kk) * 2 + pl) * 1024) = v;
+                    }
+            }
+            if (tid < kCH) q.yisg[(static_cast<int64_t>(e) * q.G + gs) * 32 * q.NKC + c0 + tid] = isg[tid];
+        }
+    };
+
     // ---- h^0 of this chunk: wave w stages channels w, w + 8, ... (a whole channel per wave: its max magnitude is a wave reduction), four
     // channels per batch; columns past S and channels past C come back as zeros and are written as zeros
     {
@@ -245,6 +279,7 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
         }
     }
     lds_barrier();
+    emit_planes(0);                                                     // Y_L
     float inv_sig[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) inv_sig[j] = isg[16 * j + li];
@@ -395,6 +430,7 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
             if (tid < 16) isg[16 * j + li] = inv_sig[j];
         }
         lds_barrier();                                                  // H^l complete
+        if constexpr (BWD) { if (l + 1 < L) emit_planes(l + 1); }
         // ---- relation_l = gather(h, heads) * gather(h, tails)   (models/models.py:270-273), saved state; values = (hi + lo) / scale
         auto state_at = [&](uint32_t pos) {
             return static_cast<float>(*reinterpret_cast<const _Float16*>(Hs + pos)) + static_cast<float>(*reinterpret_cast<const _Float16*>(Hs + PLANE + pos));
@@ -416,7 +452,7 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
             reinterpret_cast<float*>(out)[cl * Ldd + x] = (state_at(hl_pos4(cl, th & ~3) + 2 * (th & 3)) * k) * (state_at(hl_pos4(cl, tt & ~3) + 2 * (tt & 3)) * k);
         }
         }
-        if (BWD || p.hsave) {                                           // wave w: channels w, w + 8, ...; lane = (K step, half, slot), two passes of 256 columns
+        if (BWD ? q.ysave[l] != nullptr : p.hsave != nullptr) {                                           // wave w: channels w, w + 8, ...; lane = (K step, half, slot), two passes of 256 columns
             char* hs = BWD ? reinterpret_cast<char*>(q.ysave[l] + (static_cast<int64_t>(b) * C + c0) * S)
                            : reinterpret_cast<char*>(p.hsave + ((static_cast<int64_t>(l) * p.B + b) * C + c0) * S);
             for (int cl = wave; cl < nch; cl += kHLWaves) {
@@ -438,6 +474,173 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
             }
         }
         // the next hop's post-compute barrier orders these reads before its writes
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- d A_l products
+// d A_l[s][t] = sum_c Y_l[c][s] H^{l-1}[c][t] per graph, K = channels.  The chain kernel left Y_l^T as fragment planes UNDER ITS CHANNEL SCALES
+// (Yhat[c][s] = sigma_c Y[c][s], sigma_c a power of two) — a scale on the contraction index, which the other operand absorbs exactly:
+//     d A_l[s][t] = sum_c Yhat[c][s] (H[c][t] / sigma_c).
+// Workgroup = (graph, 64 columns t): Htilde = H / sigma as a two-term image [64 t][K = up to 512 channels] in LDS under per-column scales
+// (max over ALL channels, so the passes over K share one unit and the accumulators run through), Yhat^T fragments straight from global memory
+// into registers two K steps ahead — the forward's loop with the roles of state and adjacency taken by H and Y.  K > 512 (n = 32: 992
+// channels): the image is restaged between the passes.
+struct PropGadj {
+    const unsigned char* yplanes;       // [G][RTT][NKC][2][1 KiB]
+    const float* yisg;                  // [G][32 NKC] inverse channel scales of Y_l
+    const float* Hprev; int64_t h_bs;   // H^{l-1} [G][C][S] (h_bs = 0: one h^0 for all graphs)
+    float* out;                         // d A_l [G][S][S]
+    int32_t G, C, S, NKC, npass, nchunks;
+};
+
+template <int RT, int NKS>
+__global__ void __launch_bounds__(64 * kHLWaves) k_prop_gadj_hl(const PropGadj q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    constexpr int PLANE = NKS * kSTEP, KP = NKS * 32, RTT = 8 * RT;
+    unsigned char* Hs = sm;
+    uint32_t* chmax = reinterpret_cast<uint32_t*>(sm + 2 * PLANE);      // [kCH]
+    float* isg_t = reinterpret_cast<float*>(chmax + kCH);               // [kCH] inverse column scales
+    float* fy = isg_t + kCH;                                            // [KP] inverse channel scales of Y for the current pass
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int wg = blockIdx.x, xcd = wg & 7, rr = wg >> 3;
+    const int chunk = rr % q.nchunks, gs = (rr / q.nchunks) * 8 + xcd;
+    if (gs >= q.G) return;
+    const int S = q.S, C = q.C, NKC = q.NKC, t0 = chunk * kCH;
+
+    // ---- Y fragments: ring of two K steps, as in the forward
+    u32x4 ring[2][RT][2];
+    uint32_t voff_rt[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) voff_rt[r] = static_cast<uint32_t>((wave * RT + r) * NKC) * 2048u + lane * 16u;
+    const uint32_t ybytes = static_cast<uint32_t>(RTT) * NKC * 2048u;
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(q.yplanes) + static_cast<int64_t>(gs) * ybytes, 0, static_cast<int>(ybytes), 0x00020000);
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            ring[sl][r][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, voff_rt[r], sl * 2048, 0);
+            ring[sl][r][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, voff_rt[r] + 1024u, sl * 2048, 0);
+        }
+
+    auto store_state4 = [&](int off, float v0, float v1, float v2, float v3) {
+        uint32_t h0, l0, h1, l1;
+        hx2_split2(v0, v1, h0, l0);
+        hx2_split2(v2, v3, h1, l1);
+        *reinterpret_cast<uint2*>(Hs + off) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(Hs + PLANE + off) = make_uint2(l0, l1);
+    };
+
+    // ---- H^{l-1}[c][t0 .. t0 + 63] of this graph: lane (li, lq) takes columns 16 jj + li and channels 4 lq .. + 3 of a 16-channel group
+    const auto rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.Hprev + gs * q.h_bs), 0, C * S * 4, 0x00020000);
+    const float* yi = q.yisg + static_cast<int64_t>(gs) * 32 * NKC;
+    if (tid < kCH) chmax[tid] = 0u;
+    lds_barrier();
+    {   // column maxima of Htilde over all channels: wave w takes the 16-channel groups w, w + 8, ...
+        float m[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int cg = wave; 16 * cg < C; cg += kHLWaves) {
+            const int cb = 16 * cg + 4 * lq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float f = cb + i < C ? yi[cb + i] : 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int t = t0 + 16 * jj + li;
+                    const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(rs_h, (cb + i < C && t < S) ? static_cast<uint32_t>((cb + i) * S + t) * 4u : kOOB, 0, 0);
+                    m[jj] = fmaxf(m[jj], fabsf(as_f(v) * f));
+                }
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const float mm = rows_max(m[jj]);
+            if (lq == 0) atomicMax(chmax + 16 * jj + li, __builtin_bit_cast(uint32_t, mm));
+        }
+    }
+    lds_barrier();
+    float sg_t[4];                                                      // scales of this lane's four columns
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) sg_t[jj] = hx2_scale_of(__builtin_bit_cast(float, chmax[16 * jj + li]));
+    if (tid < kCH) isg_t[tid] = hx2_inv(hx2_scale_of(__builtin_bit_cast(float, chmax[tid])));
+
+    f32x4 acc[RT][4];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int swz = ((li >> 1) & 3) << 4;
+    const int b_rd = li * 64 + ((lq << 4) ^ swz);
+
+#pragma unroll 1
+    for (int pass = 0; pass < q.npass; ++pass) {
+        const int c_pass = pass * KP;
+        lds_barrier();                                                  // the previous pass's reads of the image are done (pass 0: isg_t visible)
+        for (int i = tid; i < KP; i += 64 * kHLWaves) fy[i] = c_pass + i < C ? yi[c_pass + i] : 0.f;
+        lds_barrier();
+        // stage: wave w converts the 16-channel groups w, w + 8, ... of this pass
+        for (int cg = wave; cg < 2 * NKS; cg += kHLWaves) {
+            const int cl = 16 * cg + 4 * lq, cb = c_pass + cl;
+            const float4 f4 = *reinterpret_cast<const float4*>(fy + cl);
+            const float f[4] = {f4.x, f4.y, f4.z, f4.w};
+            float v[4][4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int t = t0 + 16 * jj + li;
+                    v[jj][i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rs_h, (cb + i < C && t < S) ? static_cast<uint32_t>((cb + i) * S + t) * 4u : kOOB, 0, 0));
+                }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                store_state4(hl_pos4(16 * jj + li, cl), v[jj][0] * (f[0] * sg_t[jj]), v[jj][1] * (f[1] * sg_t[jj]), v[jj][2] * (f[2] * sg_t[jj]),
+                             v[jj][3] * (f[3] * sg_t[jj]));
+        }
+        lds_barrier();
+        const int kg0 = pass * NKS;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int BUF = ks & 1;
+            const int kg = kg0 + ks + 2;                                // the K step requested now (zeros past the last one)
+            const uint32_t so = static_cast<uint32_t>(kg) * 2048u;
+            const uint32_t oob = kg < NKC ? 0u : kOOB;
+            const unsigned char* hb = Hs + ks * kSTEP + b_rd;
+            f16x8 bh[4], bl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bh[j] = *reinterpret_cast<const f16x8*>(hb + 1024 * j);
+                bl[j] = *reinterpret_cast<const f16x8*>(hb + PLANE + 1024 * j);
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const f16x8 ah = __builtin_bit_cast(f16x8, ring[BUF][r][0]), al = __builtin_bit_cast(f16x8, ring[BUF][r][1]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], acc[r][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], acc[r][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], acc[r][j], 0, 0, 0);
+                ring[BUF][r][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, voff_rt[r] | oob, so, 0);
+                ring[BUF][r][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (voff_rt[r] + 1024u) | oob, so, 0);
+                __builtin_amdgcn_sched_barrier(0x078f);
+            }
+        }
+    }
+    // ---- d A_l[s][t]: C layout — column (lane & 15) = t0 + 16 j + li, rows s = 16 (wave RT + r) + 4 lq + i; 64-byte runs per row
+    float* out = q.out + static_cast<int64_t>(gs) * S * S;
+    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(out, 0, S * S * 4, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float k = isg_t[16 * j + li];
+        const int t = t0 + 16 * j + li;
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int s_ = 16 * (wave * RT + r) + 4 * lq + i;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[r][j][i] * k), rs_o,
+                                                      (s_ < S && t < S) ? static_cast<uint32_t>(s_ * S + t) * 4u : kOOB, 0, 0);
+            }
     }
 }
 
@@ -524,6 +727,45 @@ int64_t prop_bwd_hl_slice(int C, int S, int L, int64_t ws_bytes, int B) {
     return G < 0 ? 0 : G;
 }
 
+// chain workspace of a slice of G graphs, in floats: Y_L as fp32 [G][C][S] | L plane sets [G][RTT][NKC][2][256 floats] | L x [G][32 NKC] scales
+static int hl_nkc(int C) { return 2 * ((C + kCH - 1) / kCH); }
+size_t prop_bwd_hl_ws_floats(int C, int S, int L, int64_t G) {
+    const HLGeom g = hl_geom(S, L);
+    const size_t planes = static_cast<size_t>(8) * g.RT * hl_nkc(C) * 512;
+    return static_cast<size_t>(G) * (static_cast<size_t>(C) * S + static_cast<size_t>(L) * (planes + 32ull * hl_nkc(C)));
+}
+void prop_bwd_hl_ws_layout(int C, int S, int L, int64_t G, float* ws, float** y_in, unsigned char** planes, float** isg, size_t* plane_set_bytes, size_t* isg_set_floats) {
+    const HLGeom g = hl_geom(S, L);
+    *plane_set_bytes = static_cast<size_t>(G) * 8 * g.RT * hl_nkc(C) * 2048;
+    *isg_set_floats = static_cast<size_t>(G) * 32 * hl_nkc(C);
+    *y_in = ws;
+    *planes = reinterpret_cast<unsigned char*>(ws + static_cast<size_t>(G) * C * S);
+    *isg = reinterpret_cast<float*>(*planes + static_cast<size_t>(L) * *plane_set_bytes);
+}
+
+int prop_bwd_hl_gadj(const unsigned char* yplanes, const float* yisg, const float* Hprev, int64_t h_bs, float* out, int G, int C, int S, hipStream_t st) {
+    const HLGeom g = hl_geom(S, 1);
+    PropGadj q{};
+    q.yplanes = yplanes; q.yisg = yisg; q.Hprev = Hprev; q.h_bs = h_bs; q.out = out;
+    q.G = G; q.C = C; q.S = S; q.NKC = hl_nkc(C); q.nchunks = (S + kCH - 1) / kCH;
+    const int NKS = q.NKC <= 8 ? 8 : 16;
+    q.npass = (q.NKC + NKS - 1) / NKS;
+    if (static_cast<int64_t>(C) * S * 4 >= (1LL << 31)) return RECON_ERR_UNSUPPORTED;
+    const size_t lds = 2ull * NKS * kSTEP + 2ull * kCH * sizeof(uint32_t) + static_cast<size_t>(NKS) * 32 * sizeof(float);
+    const dim3 grid(static_cast<unsigned>(((G + 7) / 8) * 8 * q.nchunks));
+#define CALL_GA(R_, K_)                                                                                                             \
+    do {                                                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prop_gadj_hl<R_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  static_cast<int>(lds));                                                                           \
+        hipLaunchKernelGGL((k_prop_gadj_hl<R_, K_>), grid, dim3(64 * kHLWaves), lds, st, q);                                        \
+    } while (0)
+    if (NKS == 8) { if (g.RT == 2) CALL_GA(2, 8); else if (g.RT == 3) CALL_GA(3, 8); else CALL_GA(4, 8); }
+    else { if (g.RT == 2) CALL_GA(2, 16); else if (g.RT == 3) CALL_GA(3, 16); else CALL_GA(4, 16); }
+#undef CALL_GA
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+
 int prop_bwd_hl_chain(const PropBwdHL& a, hipStream_t st) {
     const int64_t G = prop_bwd_hl_slice(a.C, a.S, a.L, a.ws_bytes, a.G);
     if (G < a.G || a.dd != 16 || !a.hblk || !a.tblk) return RECON_ERR_UNSUPPORTED;
@@ -533,6 +775,7 @@ int prop_bwd_hl_chain(const PropBwdHL& a, hipStream_t st) {
     q.p.h0 = a.y_in; q.p.h0_bs = static_cast<int64_t>(a.C) * a.S;
     for (int k = 0; k < a.L; ++k) { q.p.adj[k] = a.adj_step[k]; q.hmask[k] = a.hmask[k]; q.ysave[k] = a.ysave[k]; q.gout_off[k] = a.gout_off[k]; }
     q.gout = a.gout; q.gout_ld = a.L * a.dd; q.hblk = a.hblk; q.tblk = a.tblk;
+    q.yplanes = a.yplanes; q.yisg = a.yisg; q.NKC = hl_nkc(a.C);
     q.split = static_cast<unsigned char*>(a.ws);
     q.alpha = reinterpret_cast<float*>(q.split + ((g.per_graph_split * static_cast<size_t>(a.G) + 255) & ~static_cast<size_t>(255)));
     q.NKS = g.NKS; q.RT = g.RT; q.nchunks = (a.C + kCH - 1) / kCH; q.g0 = 0; q.G = a.G;

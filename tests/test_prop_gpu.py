@@ -797,3 +797,52 @@ def test_gcn_bf16_foreign_padded_view_is_repacked():
     assert torch.isfinite(z_view.float()).all() and torch.equal(z_view, z_plain)
     close(z_plain.float(), y_plain.float(), atol=1e-3, rel_to_max=1e-2, what="inference vs training forward")
     assert torch.isfinite(z_row0[:, 0].float()).all()
+
+
+# ------------------------------------------------------------------------------- wide-state float32 backward on the two-term f16 kernels
+@pytest.mark.parametrize("n,L,B,act,per_batch", [
+    (12, 3, 3, "relu", True),        # S = 192, C = 132: RT = 2, three channel chunks (the last of 4 channels), d A in one pass of 8 K steps
+    (11, 2, 9, "tanh", False),       # S = 176: partial last row tile; shared h0; more than 8 graphs
+    (17, 3, 2, "relu", True),        # S = 272, C = 272: RT = 3, odd K steps padded; d A in one pass of 16 K steps (10 used)
+    (24, 2, 2, "linear", True),      # S = 384, C = 552: d A in two passes
+    (13, 1, 300, "relu", False),     # one hop; two slices of the split workspace
+])
+def test_wide_backward_chain_form_vs_oracle(n, L, B, act, per_batch):
+    """160 < S <= 512 with GP-GNN's block-structured gather indices (utils/embedding_utils.py:184-202): the backward's chain
+    d loss / d H^l-1 = A_l^T Y_l runs on the forward's two-term f16 kernel over transposed split adjacencies, the d A_l products on its mirror
+    image (csrc/prop_hl.hip: k_propagate_fwd_hl<.., true>, k_prop_gadj_hl).  Arbitrary dense adjacencies with rows and columns of very
+    different magnitude; every gradient against the float64 oracle."""
+    import ctypes as C
+    from recon_amd import _lib
+    from recon_amd.propagation import propagate, get_head_indices, get_tail_indices
+    d_ = dev()
+    d = 8
+    Cn, S, dd = n * (n - 1), 16 * n, 16
+    g = torch.Generator().manual_seed(100 * n + L)
+    adjs = [(torch.rand(B, S, S, generator=g) - 0.45) * (2.0 / S ** 0.5) * (1 + l) for l in range(L)]
+    for a in adjs:
+        a[:, :, ::7] *= 8.0
+        a[:, 5] *= 1e-3
+    h0 = torch.randn(B, Cn, S, 1, generator=g) if per_batch else torch.randn(Cn, S, 1, generator=g)
+    head = torch.from_numpy(get_head_indices(n, d, bs=1)[0])
+    tail = torch.from_numpy(get_tail_indices(n, d, bs=1)[0])
+    Gr = torch.randn(B, Cn, dd * L, generator=g)
+    Gr[:, 3] = 0.0                                                     # a channel without gradient: its Y rows are zero (scale of a zero row)
+
+    probe = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], None, None, 0, None, None, 0, None, None, None, None, None, None, 0)
+    probe.split_ws_bytes = _lib.lib().recon_propagate_ws_bytes(C.byref(probe))
+    probe.split_ws = 1                                                 # any non-null value: the query looks at the size
+    assert _lib.lib().recon_propagate_bwd_chain_ws_floats(C.byref(probe)) > 0, "chain form not offered for this shape"
+
+    def run(device, prop, dt):
+        A = [a.clone().to(device=device, dtype=dt).requires_grad_(True) for a in adjs]
+        h = h0.clone().to(device=device, dtype=dt).requires_grad_(True)
+        out = prop(A, h, act, head.to(device), tail.to(device))
+        (out * Gr.to(device=device, dtype=dt)).sum().backward()
+        return out.detach(), [a.grad for a in A], h.grad
+    out_r, gA_r, gh_r = run("cpu", lambda *a: O.propagate(*a, as_gemm=True), torch.float64)
+    out_h, gA_h, gh_h = run(d_, propagate, torch.float32)
+    close(out_h, out_r.float(), atol=1e-4, rel_to_max=1e-5, what="out")
+    for l in range(L):
+        close(gA_h[l], gA_r[l].float(), atol=1e-5, what="chain g_adj[%d]" % l)
+    close(gh_h, gh_r.float(), atol=1e-5, what="chain g_h0")
