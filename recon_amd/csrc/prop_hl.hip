@@ -368,8 +368,13 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float mm = 0.f;
-            [[maybe_unused]] u32x4 dm[RT];                              // BWD: H^{l-1}[c][rows of this lane], all row tiles requested at once
-            [[maybe_unused]] float sig = 1.f;
+            // BWD: everything this column of tiles needs from memory is requested at once, branch-free (what does not exist reads zeros):
+            // H^{l-1}[c][rows of this lane] for the activation derivative, and the relation gradient of hop l-1 (models/models.py:270-273
+            // backwards: out = h[head] * h[tail] puts grad_out * h[tail block] on the head block's rows and grad_out * h[head block] on the
+            // tail block's) — the head / tail block of channel c is ONE row tile each, owned by one wave
+            [[maybe_unused]] u32x4 dm[RT], g4, hx, hy;
+            [[maybe_unused]] float sig = 0.f;
+            [[maybe_unused]] int rh = -1, rt_ = -1;
             if constexpr (BWD) {
                 if (hm) {
                     const uint32_t cb = static_cast<uint32_t>((16 * j + li) * S) * 4u;
@@ -378,6 +383,13 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
                         const int t0 = 16 * (wave * RT + r) + 4 * lq;
                         dm[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_hm, t0 < S ? cb + static_cast<uint32_t>(t0) * 4u : kOOB, 0, 0);
                     }
+                    const int hbj = static_cast<int>(gtab[16 * j + li]), tbj = static_cast<int>(gtab[kCH + 16 * j + li]);
+                    const bool okc = 16 * j + li < nch;
+                    rh = (hbj >> 4) - wave * RT; rt_ = (tbj >> 4) - wave * RT;
+                    const bool has_h = okc && rh >= 0 && rh < RT, has_t = okc && rt_ >= 0 && rt_ < RT;
+                    g4 = __builtin_amdgcn_raw_buffer_load_b128(rs_go, (has_h || has_t) ? static_cast<uint32_t>((16 * j + li) * q.gout_ld + 4 * lq) * 4u : kOOB, 0, 0);
+                    hx = __builtin_amdgcn_raw_buffer_load_b128(rs_hm, has_h ? cb + static_cast<uint32_t>(tbj + 4 * lq) * 4u : kOOB, 0, 0);
+                    hy = __builtin_amdgcn_raw_buffer_load_b128(rs_hm, has_t ? cb + static_cast<uint32_t>(hbj + 4 * lq) * 4u : kOOB, 0, 0);
                     sig = hx2_inv(inv_sig[j]);                          // the product is in units of the old channel scale: so is what is added to it
                 }
             }
@@ -393,17 +405,9 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
                 if (!homog) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
                 if constexpr (BWD) {
                     if (hm) {
-                        // relation gradient of hop l-1 (models/models.py:270-273 backwards): out = h[head] * h[tail] puts grad_out * h[tail block]
-                        // on the head block's rows and grad_out * h[head block] on the tail block's — this row tile is one of them for few channels
-                        const int T16 = 16 * (wave * RT + r);
-                        const int hbj = static_cast<int>(gtab[16 * j + li]), tbj = static_cast<int>(gtab[kCH + 16 * j + li]);
-                        const int sel = T16 == hbj ? tbj : (T16 == tbj ? hbj : -1);
-                        if (sel >= 0 && 16 * j + li < nch) {
-                            const u32x4 g4 = __builtin_amdgcn_raw_buffer_load_b128(rs_go, static_cast<uint32_t>((16 * j + li) * q.gout_ld + 4 * lq) * 4u, 0, 0);
-                            const u32x4 h4 = __builtin_amdgcn_raw_buffer_load_b128(rs_hm, static_cast<uint32_t>((16 * j + li) * S + sel + 4 * lq) * 4u, 0, 0);
-                            v0 += as_f(g4.x) * as_f(h4.x) * sig; v1 += as_f(g4.y) * as_f(h4.y) * sig;
-                            v2 += as_f(g4.z) * as_f(h4.z) * sig; v3 += as_f(g4.w) * as_f(h4.w) * sig;
-                        }
+                        const float sh = r == rh ? sig : 0.f, st_ = r == rt_ ? sig : 0.f;
+                        v0 += as_f(g4.x) * (as_f(hx.x) * sh + as_f(hy.x) * st_); v1 += as_f(g4.y) * (as_f(hx.y) * sh + as_f(hy.y) * st_);
+                        v2 += as_f(g4.z) * (as_f(hx.z) * sh + as_f(hy.z) * st_); v3 += as_f(g4.w) * (as_f(hx.w) * sh + as_f(hy.w) * st_);
                         const u32x4 d = dm[r];
                         v0 *= act_bwd(as_f(d.x), p.act); v1 *= act_bwd(as_f(d.y), p.act); v2 *= act_bwd(as_f(d.z), p.act); v3 *= act_bwd(as_f(d.w), p.act);
                     }
@@ -537,25 +541,30 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_prop_gadj_hl(const PropGadj q
     const float* yi = q.yisg + static_cast<int64_t>(gs) * 32 * NKC;
     if (tid < kCH) chmax[tid] = 0u;
     lds_barrier();
-    {   // column maxima of Htilde over all channels: wave w takes the 16-channel groups w, w + 8, ...
-        float m[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int cg = wave; 16 * cg < C; cg += kHLWaves) {
-            const int cb = 16 * cg + 4 * lq;
+    {   // column maxima of Htilde over all channels, 16-byte loads: lane (tq, cq) takes columns t0 + 4 tq .. + 3 of channel 4 (wave + 8 it) + cq,
+        // eight channels in flight per lane
+        float m4[4] = {0.f, 0.f, 0.f, 0.f};
+        const int tq = lane & 15, cq = lane >> 4, tt = t0 + 4 * tq;
+        constexpr int U = 8;
+        for (int c4 = 4 * wave; c4 < C; c4 += 4 * kHLWaves * U) {
+            u32x4 v[U];
+            float f[U];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float f = cb + i < C ? yi[cb + i] : 0.f;
+            for (int u = 0; u < U; ++u) {
+                const int c = c4 + 4 * kHLWaves * u + cq;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_h, (c < C && tt < S) ? static_cast<uint32_t>(c * S + tt) * 4u : kOOB, 0, 0);
+                f[u] = c < C ? yi[c] : 0.f;
+            }
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int t = t0 + 16 * jj + li;
-                    const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(rs_h, (cb + i < C && t < S) ? static_cast<uint32_t>((cb + i) * S + t) * 4u : kOOB, 0, 0);
-                    m[jj] = fmaxf(m[jj], fabsf(as_f(v) * f));
-                }
+            for (int u = 0; u < U; ++u) {
+                m4[0] = fmaxf(m4[0], fabsf(as_f(v[u].x) * f[u])); m4[1] = fmaxf(m4[1], fabsf(as_f(v[u].y) * f[u]));
+                m4[2] = fmaxf(m4[2], fabsf(as_f(v[u].z) * f[u])); m4[3] = fmaxf(m4[3], fabsf(as_f(v[u].w) * f[u]));
             }
         }
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const float mm = rows_max(m[jj]);
-            if (lq == 0) atomicMax(chmax + 16 * jj + li, __builtin_bit_cast(uint32_t, mm));
+        for (int i = 0; i < 4; ++i) {
+            const float mm = rows_max(m4[i]);
+            if (cq == 0) atomicMax(chmax + 4 * tq + i, __builtin_bit_cast(uint32_t, mm));
         }
     }
     lds_barrier();
