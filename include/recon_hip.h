@@ -417,6 +417,19 @@ int recon_block_adjacency_b16_bwd(const void* gA, int32_t B, int32_t n, int32_t 
                                   recon_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * The GAT_sep_space variant's entity -> relation-space map (GAT_sep_space/main.py:359-364, :372-377; GAT_sep_space/models.py:316-320):
+ *     out[t] = x[t] . W[rel[t]]      x [T, in_dim], W [R, in_dim, out_dim], rel [T] in [0, R)
+ * without the [T, in_dim, out_dim] gather the reference feeds to torch.bmm.  `order` [T] int32 = the rows in relation order (a stable
+ * argsort of rel), `seg_ptr` [R+1] int32 = where each relation's rows start in that order.  transpose_w: W is [R, out_dim, in_dim] and
+ * read transposed (the input gradient g_x[t] = g[t] . W[rel[t]]^T).  _wgrad: g_W[r] = sum over the rows t of relation r of x[t]^T g[t]
+ * (dense [R, in_dim, out_dim]: relations without rows get zeros), fixed summation order.  in_dim <= 1024, out_dim <= 512 for _wgrad.
+ * ------------------------------------------------------------------------------------------*/
+int recon_rel_rows_mm(const float* x, const int32_t* order, const int64_t* rel, const float* W, int32_t T, int32_t in_dim, int32_t out_dim,
+                      int32_t transpose_w, float* out, recon_stream_t stream);
+int recon_rel_rows_mm_wgrad(const float* x, const float* g, const int32_t* order, const int32_t* seg_ptr, int32_t R, int32_t in_dim,
+                            int32_t out_dim, float* gW, recon_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * P4  make_start_entity_embeddings (utils/context_utils.py:387-426): h0[b,c=(i,j),:] has the first
  *     entity's embedding in node i's first half-slot and the second entity's in node j's second
  *     half-slot, zero elsewhere, times the start-embedding template.

@@ -1093,3 +1093,40 @@ def test_wide_dynamic_range_inputs(xs, es, gs, p):
     for name, u, v in zip(("g_x", "g_edge_embed", "g_a", "g_a_2"), grads, rg):
         assert torch.isfinite(u).all(), name
         close(u, v.float(), atol=0.0, rel_to_max=1e-4, what=name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,D,Dout,R,skew", [
+    (1000, 200, 200, 237, "zipf"),      # GAT_sep_space's shape: entity_out_dim_1 * nheads = 200, FB15k-237's relations, few frequent ones
+    (37, 48, 24, 5, "uniform"),         # T % 16 != 0, rectangular matrices
+    (300, 64, 300, 300, "uniform"),     # about one row per relation: every tile holds many runs; Dout > 256 (two columns per thread)
+    (64, 8, 8, 3, "single"),            # one relation for all rows, two relations without rows
+    (0, 16, 16, 4, "uniform"),          # no rows
+])
+def test_rel_rows_mm_vs_bmm(T, D, Dout, R, skew):
+    """recon_rel_rows_mm / _wgrad (csrc/rel_mm.hip) against the reference's own expression `torch.bmm(x.unsqueeze(1), W[rel])`
+    (GAT_sep_space/main.py:359-364): forward, d x, d W (relations without rows: zeros)."""
+    from recon_amd.sep_space import rel_rows_mm
+    d = dev()
+    g = torch.Generator().manual_seed(T + D)
+    x = torch.randn(T, D, generator=g)
+    W = torch.randn(R, D, Dout, generator=g) / D ** 0.5
+    if skew == "zipf":
+        p = 1.0 / torch.arange(1, R + 1, dtype=torch.float64)
+        rel = torch.multinomial(p / p.sum(), T, replacement=True, generator=g)
+    elif skew == "single":
+        rel = torch.full((T,), 1, dtype=torch.int64)
+    else:
+        rel = torch.randint(0, R, (T,), generator=g)
+    G = torch.randn(T, Dout, generator=g)
+    xr, Wr = x.double().requires_grad_(True), W.double().requires_grad_(True)
+    ref = torch.bmm(xr.unsqueeze(1), Wr[rel]).squeeze(1)
+    (ref * G.double()).sum().backward()
+    xd, Wd = x.to(d).requires_grad_(True), W.to(d).requires_grad_(True)
+    out = rel_rows_mm(xd, rel.to(d), Wd)
+    (out * G.to(d)).sum().backward()
+    close(out, ref.detach().float(), atol=1e-5, rel_to_max=1e-5, what="rel_rows_mm out")
+    close(xd.grad, xr.grad.float(), atol=1e-5, rel_to_max=1e-5, what="rel_rows_mm g_x")
+    close(Wd.grad, Wr.grad.float(), atol=1e-5, rel_to_max=1e-5, what="rel_rows_mm g_W")
+    out2 = rel_rows_mm(xd.detach(), rel.to(d), Wd.detach())
+    assert torch.equal(out2, out.detach()), "not deterministic"

@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--no-2hop", action="store_true")
     ap.add_argument("--ratio", type=int, default=2)
     ap.add_argument("--loss-rows", choices=["torch", "recon"], default="torch", help="table[index] (the reference's loss code) or recon_amd.gat_layers.gather_rows")
+    ap.add_argument("--profile", action="store_true", help="cProfile of the host side of fresh iterations (top functions by own time)")
     args = ap.parse_args()
     dv = torch.device("cuda:0")
     torch.autograd.set_multithreading_enabled(False)
@@ -110,6 +111,14 @@ def main():
     for _ in range(3):
         train_iter(one)
         train_iter(make_batch())
+    if args.profile:
+        import cProfile, pstats
+        pr = cProfile.Profile(); pr.enable()
+        for _ in range(args.iters):
+            train_iter(make_batch())
+        pr.disable(); torch.cuda.synchronize()
+        pstats.Stats(pr).sort_stats("tottime").print_stats(45)
+        return
     t_batch = timed(make_batch, args.iters)
     t_cached = timed(lambda: train_iter(one), args.iters)
     t_fresh = timed(lambda: train_iter(make_batch()), args.iters)
