@@ -136,8 +136,9 @@ def main():
     edged = edge.to(dev)
     nohop = torch.tensor([])
     Gd = torch.randn(N, H * D, generator=torch.Generator().manual_seed(1)).to(dev)
-    head_params = [p for att in model.attentions for p in (att.a, att.a_2)]
-    bucket = FlatGradBucket(head_params)
+    head_params = model.head_parameters()                                     # every a, then every a_2: the fused gradients [H, D, W] / [H, D] of the
+    bucket = FlatGradBucket(head_params)                                      # heads' backward are then two contiguous pieces of the flat buffer,
+    model.write_head_gradients_into(bucket)                                   # written in place (no pack copy before the all-reduce)
     graph = prepare_graph(edged, nohop, N)                                    # CSR built once per batch (cached)
 
     # N > 1: the weight gradient's big term travels (RCCL all-reduce, asynchronous) under the backward's edge chain and comes back from

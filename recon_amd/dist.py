@@ -58,6 +58,17 @@ class FlatGradBucket:
         for p in self.params:
             p.grad = None
 
+    def region(self, params):
+        """The piece of the flat buffer that holds `params` back to back in this order (a 1-d view), or None when they are not laid
+        out that way.  A producer that writes its gradients THERE (models.SpGAT.write_head_gradients_into) saves pack() its copy:
+        the gradients autograd assigns are already views of the buffer."""
+        ids = {id(p): i for i, p in enumerate(self.params)}
+        idx = [ids.get(id(p)) for p in params]
+        if not idx or any(i is None for i in idx) or any(b != a + 1 for a, b in zip(idx, idx[1:])):
+            return None
+        off = sum(p.numel() for p in self.params[:idx[0]])
+        return self.flat[off:off + sum(p.numel() for p in params)]
+
     def pack(self):
         """Bring every gradient into the flat buffer.  A gradient that already IS its view of the buffer (a second step
         without zero(), optimizer.zero_grad(set_to_none=False)) stays where it is; a missing one (unused parameter, empty

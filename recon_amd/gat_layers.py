@@ -33,6 +33,26 @@ _OVERLAP = os.environ.get("RECON_OVERLAP", "0") == "1"
 # is installed, the backward of the aggregate-then-project heads reduces its weight gradients across ranks ITSELF and returns them already
 # averaged: G = V^T g_h is summed over split-K and sent off before the edge chain (INPUTS) runs, so the big collective travels under it.
 _WEIGHT_GRAD_SYNC = None
+_GRAD_DEST = {}             # data_ptr of a fused [H, D, W] weight -> (g_a, g_a_2) tensors the heads' backward writes its weight gradients into
+
+
+def set_weight_grad_destination(a, g_a, g_a_2):
+    """Have the backward of gat_heads(..., a, ...) write the gradients of `a` [H, D, W] / `a_2` [H, D] into the given tensors (e.g. a
+    data-parallel gradient bucket's own storage: dist.FlatGradBucket.region) instead of fresh ones; None removes the entry."""
+    if g_a is None:
+        _GRAD_DEST.pop(a.data_ptr(), None)
+    else:
+        if len(_GRAD_DEST) >= 64:
+            _GRAD_DEST.clear()
+        _GRAD_DEST[a.data_ptr()] = (g_a, g_a_2)
+
+
+def _weight_grad_tensors(a, H, D, W, f32):
+    dest = _GRAD_DEST.get(a.data_ptr())
+    if dest is not None and dest[0].shape == (H, D, W) and dest[1].shape == (H, D) and dest[0].device == a.device \
+            and dest[0].is_contiguous() and dest[1].is_contiguous():
+        return dest
+    return torch.empty(H, D, W, **f32), torch.empty(H, D, **f32)
 
 
 def set_weight_grad_sync(sync):
@@ -525,8 +545,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
             4 * H * W, 4 * N * H, partial_b, partial2_b, ghs_b if use_gh_planes else None))
         g_x = torch.empty(N, F_, **f32) if nx else None
         g_ee = torch.empty(E, R, **f32) if ne else None
-        g_a = torch.empty(H, D, W, **f32) if want_a else None
-        g_a2 = torch.empty(H, D, **f32) if want_a else None
+        g_a, g_a2 = _weight_grad_tensors(a, H, D, W, f32) if want_a else (None, None)
         fwd = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, ctx.alpha, ctx.concat, a_split, aux,
                         ctx.keep_max, ctx.idx_slot)
         args = _lib.GatAtpBwdArgs(fwd, grad_out.data_ptr(), grad_out.shape[1], g_h, g_V, g_sigma, Gxs, gxd, Gs, g_u, q, partial, partial2,

@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed, gather_rows, small_mm, IndexedRows
+from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed, gather_rows, small_mm, IndexedRows, set_weight_grad_destination
 from .graph import prepare_graph, trust, trusted, trust_bounds
 
 
@@ -60,7 +60,32 @@ class SpGAT(nn.Module):
                     att.a_2.data = A2[i:i + 1]
             params = [att.a for att in atts] + [att.a_2 for att in atts]
             self._fused_heads = (A, A2, [p.data_ptr() for p in params])
+        bucket = getattr(self, "_head_grad_bucket", None)
+        if bucket is not None:                                          # the heads' weight gradients land in the bucket's own storage
+            bound = getattr(self, "_head_grad_bound", None)
+            if bound is None or bound[0] != A.data_ptr():
+                ra, ra2 = bucket.region([att.a for att in atts]), bucket.region([att.a_2 for att in atts])
+                ok = ra is not None and ra2 is not None and ra.device == A.device
+                bound = self._head_grad_bound = (A.data_ptr(), (ra.view_as(A), ra2.view_as(A2)) if ok else None)
+            # only when this backward's gradients will be ASSIGNED: a parameter that still holds a gradient (accumulation over several
+            # backward calls) may hold a view of the very same storage, and "old + new" must not read the new values on both sides
+            if bound[1] is not None and all(p.grad is None for p in params):
+                set_weight_grad_destination(A, *bound[1])
+            else:
+                set_weight_grad_destination(A, None, None)
         return _AliasHeadParams.apply(A, A2, *params)
+
+    def write_head_gradients_into(self, bucket):
+        """Let the H heads' backward write d a / d a_2 straight into `bucket` (dist.FlatGradBucket) — possible when the bucket holds
+        attention_0.a .. attention_{H-1}.a back to back and likewise the a_2 (build it from `head_parameters()`); then autograd assigns views
+        of the bucket as the parameters' gradients and bucket.pack() / allreduce_mean() copy nothing.  Returns whether the layout allows it."""
+        self._head_grad_bucket, self._head_grad_bound = bucket, None
+        return (bucket.region([att.a for att in self.attentions]) is not None and
+                bucket.region([att.a_2 for att in self.attentions]) is not None)
+
+    def head_parameters(self):
+        """The heads' parameters in the order that lets a gradient bucket alias the fused gradients: every a, then every a_2."""
+        return [att.a for att in self.attentions] + [att.a_2 for att in self.attentions]
 
     def heads_forward(self, x, edge_list, edge_embed, edge_list_nhop, edge_embed_nhop):
         """The H-head attention stage (GAT/models.py:71-72) as one fused call."""

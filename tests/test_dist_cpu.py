@@ -335,3 +335,14 @@ def test_formulation_choice_ignores_the_local_batch_under_data_parallelism(monke
     ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_path_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret[r] == (False, True) for r in range(world))
+
+
+def test_bucket_region_finds_consecutive_parameters():
+    """FlatGradBucket.region: the flat piece holding a run of parameters in bucket order, None for anything else."""
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (3, 5, 2, 4)]
+    b = FlatGradBucket(ps)
+    r = b.region(ps[1:3])
+    assert r is not None and r.data_ptr() == b.flat.data_ptr() + 4 * 3 and r.numel() == 7
+    assert b.region(ps).numel() == 14 and b.region([ps[3]]).numel() == 4
+    assert b.region([ps[0], ps[2]]) is None and b.region([ps[1], ps[0]]) is None and b.region([]) is None
+    assert b.region([torch.nn.Parameter(torch.zeros(3))]) is None

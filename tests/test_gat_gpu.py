@@ -1130,3 +1130,45 @@ def test_rel_rows_mm_vs_bmm(T, D, Dout, R, skew):
     close(Wd.grad, Wr.grad.float(), atol=1e-5, rel_to_max=1e-5, what="rel_rows_mm g_W")
     out2 = rel_rows_mm(xd.detach(), rel.to(d), Wd.detach())
     assert torch.equal(out2, out.detach()), "not deterministic"
+
+
+@pytest.mark.gpu
+def test_head_gradients_written_into_the_bucket():
+    """models.SpGAT.write_head_gradients_into(bucket): the heads' backward writes d a / d a_2 into the flat gradient buffer itself — the
+    parameters' gradients are views of it, pack() copies nothing, the values equal the plain path's bit for bit; a second backward without
+    zero() (gradient accumulation) must still add, not alias."""
+    from recon_amd.models import SpGAT
+    from recon_amd.dist import FlatGradBucket
+    from recon_amd import synth
+    d = dev()
+    B, n, e, F_, D, H = 6, 8, 24, 16, 16, 4
+    N = B * n
+    x, edge, ee = synth.synthetic_batched_graph(B, n, e, F_, F_, seed=3)
+    nohop = torch.tensor([])
+    G = torch.randn(N, H * D, generator=torch.Generator().manual_seed(5)).to(d)
+
+    def make():
+        torch.manual_seed(0)
+        return SpGAT(N, F_, D, F_, dropout=0.0, alpha=0.2, nheads=H).to(d)
+    plain, bound = make(), make()
+    pb = FlatGradBucket([p for att in plain.attentions for p in (att.a, att.a_2)])
+    bb = FlatGradBucket(bound.head_parameters())
+    assert bound.write_head_gradients_into(bb)
+    assert not make().write_head_gradients_into(FlatGradBucket([p for att in plain.attentions for p in (att.a, att.a_2)]))   # foreign / interleaved layout
+    xd, eed, ed = x.to(d), ee.to(d), edge.to(d)
+    for model, bucket in ((plain, pb), (bound, bb)):
+        bucket.zero()
+        model.heads_forward(xd, ed, eed, nohop, nohop).backward(G)
+    lo, hi = bb.flat.data_ptr(), bb.flat.data_ptr() + 4 * bb.flat.numel()
+    assert all(lo <= p.grad.data_ptr() < hi for p in bound.head_parameters()), "gradients are not views of the bucket"
+    before = bb.flat.clone()
+    bb.allreduce_mean()
+    assert torch.equal(bb.flat, before)                                 # nothing to copy, world size 1
+    pb.allreduce_mean()
+    for a, b in zip(plain.attentions, bound.attentions):
+        assert torch.equal(a.a.grad, b.a.grad) and torch.equal(a.a_2.grad, b.a_2.grad)
+    # accumulation: a second backward while the gradients are still set
+    first = [p.grad.clone() for p in bound.head_parameters()]
+    bound.heads_forward(xd, ed, eed, nohop, nohop).backward(G)
+    for p, g1 in zip(bound.head_parameters(), first):
+        close(p.grad, 2 * g1, atol=1e-6, rel_to_max=1e-6, what="accumulated head gradient")
