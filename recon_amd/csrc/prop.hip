@@ -1122,14 +1122,19 @@ int prop_bwd_wide(const recon_prop_args* a, const recon_prop_bwd_args* ba, hipSt
 int prop_bwd_wide_chain(const recon_prop_args* a, const recon_prop_bwd_args* ba, hipStream_t st) {
     const int32_t B = a->B, C = a->C, S = a->S, L = a->L;
     const int64_t CS = 1LL * C * S, BCS = CS * B;
+    const bool blk = a->trans != nullptr;                               // block mode: transition tensors read / d T written in place, no adjacency
+    const int nn = S / 16;
     const int64_t G = prop_bwd_hl_slice(C, S, L, a->split_ws_bytes, B);
     if (G <= 0) return RECON_ERR_UNSUPPORTED;
     const size_t plds = 4ull * S * sizeof(float);
+    float* diag_ws = blk ? ba->chain_ws + prop_bwd_hl_ws_floats(C, S, L, G) : nullptr;      // [L][B][n][256]
+    const bool want_ident = blk && ba->g_identity;
     for (int64_t g0 = 0; g0 < B; g0 += G) {
         const int32_t Gs = static_cast<int32_t>(B - g0 < G ? B - g0 : G);
         PropBwdHL c{};
         c.G = Gs; c.C = C; c.S = S; c.L = L; c.dd = a->dd; c.act = a->act; c.ws = a->split_ws; c.ws_bytes = a->split_ws_bytes;
         c.gout = ba->grad_out + g0 * C * L * a->dd; c.hblk = ba->head_blk; c.tblk = ba->tail_blk;
+        c.identity = blk ? a->identity : nullptr;
         float* y_in; unsigned char* planes; float* isg; size_t pset, iset;
         prop_bwd_hl_ws_layout(C, S, L, G, ba->chain_ws, &y_in, &planes, &isg, &pset, &iset);
         c.yplanes = planes; c.yisg = isg;
@@ -1140,7 +1145,7 @@ int prop_bwd_wide_chain(const recon_prop_args* a, const recon_prop_bwd_args* ba,
         c.y_in = y_in;
         for (int k = 0; k < L; ++k) {
             const int l = L - k;
-            c.adj_step[k] = a->adj[l - 1] + g0 * S * S;
+            c.adj_step[k] = blk ? a->trans[l - 1] + g0 * C * 256 : a->adj[l - 1] + g0 * S * S;
             c.hmask[k] = l >= 2 ? a->h_saved + static_cast<int64_t>(l - 2) * BCS + g0 * CS : nullptr;
             c.ysave[k] = l >= 2 ? nullptr : ba->g_h + g0 * CS;           // the Y_l leave as fragment planes
             c.gout_off[k] = l >= 2 ? (l - 2) * a->dd : 0;
@@ -1149,24 +1154,32 @@ int prop_bwd_wide_chain(const recon_prop_args* a, const recon_prop_bwd_args* ba,
         if (rc != RECON_OK) return rc;
         for (int k = 0; k < L; ++k) {                                   // d A_l[b] = Y_l[b]^T [S x C] . H^l-1[b] [C x S]
             const int l = L - k;
-            if (!(ba->g_adj && ba->g_adj[l - 1])) continue;
+            float* gA = (!blk && ba->g_adj) ? ba->g_adj[l - 1] : nullptr;
+            float* gT = (blk && ba->g_trans) ? ba->g_trans[l - 1] : nullptr;
+            if (!gA && !gT && !want_ident) continue;
             const float* Hprev = l == 1 ? a->h0 + g0 * a->h0_batch_stride : a->h_saved + static_cast<int64_t>(l - 2) * BCS + g0 * CS;
             // NOTE: plane sets / scale sets are laid out for slices of G graphs; a short last slice uses the front of each set
             rc = prop_bwd_hl_gadj(planes + static_cast<size_t>(k) * (pset / G) * Gs, isg + static_cast<size_t>(k) * (iset / G) * Gs, Hprev,
-                                  l == 1 ? a->h0_batch_stride : CS, ba->g_adj[l - 1] + g0 * S * S, Gs, C, S, st);
+                                  l == 1 ? a->h0_batch_stride : CS, gA ? gA + g0 * S * S : nullptr, gT ? gT + g0 * C * 256 : nullptr,
+                                  blk ? diag_ws + (static_cast<int64_t>(l - 1) * B + g0) * nn * 256 : nullptr, Gs, C, S, st);
             if (rc != RECON_OK) return rc;
         }
     }
+    if (want_ident)                                                     // d identity = the diagonal blocks of every hop, graph and node, fixed order
+        hipLaunchKernelGGL(k_sum_rows, dim3(16), dim3(1024), 0, st, diag_ws, static_cast<int32_t>(1LL * L * B * nn), 256, ba->g_identity);
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
 }
 }  // namespace
 
 extern "C" size_t recon_propagate_bwd_chain_ws_floats(const recon_prop_args* a) {
-    if (!a || a->trans || a->B <= 0 || a->dd != 16 || a->idx_batch_stride != 0 || !a->split_ws) return 0;
+    if (!a || a->B <= 0 || a->dd != 16 || a->idx_batch_stride != 0 || !a->split_ws) return 0;
+    if (a->trans && (!a->identity || a->S != 16 * (a->S / 16) || a->C != (a->S / 16) * (a->S / 16 - 1))) return 0;
+    if (1LL * a->L * a->B * (a->S / 16) >= (1LL << 31)) return 0;
     const int64_t G = prop_bwd_hl_slice(a->C, a->S, a->L, a->split_ws_bytes, a->B);
     static const bool off = getenv("RECON_PROP_BWD_CHAIN") && getenv("RECON_PROP_BWD_CHAIN")[0] == '0';
-    return (G <= 0 || off) ? 0 : prop_bwd_hl_ws_floats(a->C, a->S, a->L, G);
+    if (G <= 0 || off) return 0;
+    return prop_bwd_hl_ws_floats(a->C, a->S, a->L, G) + (a->trans ? static_cast<size_t>(a->L) * a->B * (a->S / 16) * 256 : 0);
 }
 
 extern "C" size_t recon_propagate_bwd_ws_floats(const recon_prop_args* a) {
@@ -1181,6 +1194,10 @@ extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t
     if (rc != RECON_OK) return rc;
     if (!a->h_saved || !ba->grad_out || !ba->g_h) return RECON_ERR_INVALID;
     if (a->B == 0) return RECON_OK;
+    if (a->S > 160 && ba->chain_ws && ba->head_blk && ba->tail_blk && recon_propagate_bwd_chain_ws_floats(a) > 0 &&
+        !(getenv("RECON_PROP_BWD_WIDE") && getenv("RECON_PROP_BWD_WIDE")[0] == '0')) {
+        return prop_bwd_wide_chain(a, ba, as_stream(stream));          // wide states, structured indices: chain + d A on the two-term f16 kernels (block mode too)
+    }
     if (a->stats && prop_h_form_env() && !(getenv("RECON_PROP_BWD") && getenv("RECON_PROP_BWD")[0] == 'f')) {      // two-term f16 form (RECON_PROP_BWD=f: fp32 MFMA form)
         PropBwdH q{};
         const bool blk = a->trans != nullptr;
@@ -1204,8 +1221,6 @@ extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t
     } else if (a->trans) return RECON_ERR_UNSUPPORTED;
     {
         static const bool wide_off = getenv("RECON_PROP_BWD_WIDE") && getenv("RECON_PROP_BWD_WIDE")[0] == '0';
-        if (!wide_off && ba->chain_ws && ba->head_blk && ba->tail_blk && a->S > 160 && recon_propagate_bwd_chain_ws_floats(a) > 0)
-            return prop_bwd_wide_chain(a, ba, as_stream(stream));      // wide states, structured indices: the chain on the two-term f16 kernel
         if (!wide_off && ba->wide_ws && a->S > 160 && 4ull * a->S * sizeof(float) <= 64 * 1024)     // wide states: both products as batched GEMMs
             return prop_bwd_wide(a, ba, as_stream(stream));
     }

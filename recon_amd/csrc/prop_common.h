@@ -70,7 +70,8 @@ int prop_fwd_hl(const PropK& p, hipStream_t st);
 // prop_hl.hip: the backward's chain d loss / d H^{l-1} = A_l^T Y_l, Y_{l-1} = (. + relation gradient) act'(H^{l-1}) for a SLICE of G graphs
 // (all pointers slice-local) on the forward's kernel; step k = 0 .. L-1 is hop l = L - k
 struct PropBwdHL {
-    const float* adj_step[kMaxHops];  // A_{L-k} [G][S][S]
+    const float* adj_step[kMaxHops];  // A_{L-k} [G][S][S]; block mode (identity != null): the transition tensor T_{L-k} [G][C][256]
+    const float* identity;            // block mode: [16][16]
     const float* y_in;                // Y_L [G][C][S]
     const float* hmask[kMaxHops];     // H^{l-1} [G][C][S], null for the last step (l = 1)
     float* ysave[kMaxHops];           // Y_{l-1} [G][C][S]; the last step's is d loss / d h^0
@@ -86,7 +87,9 @@ int prop_bwd_hl_chain(const PropBwdHL& a, hipStream_t st);
 size_t prop_bwd_hl_ws_floats(int C, int S, int L, int64_t G);
 void prop_bwd_hl_ws_layout(int C, int S, int L, int64_t G, float* ws, float** y_in, unsigned char** planes, float** isg, size_t* plane_set_bytes, size_t* isg_set_floats);
 // d A_l[g] = Y_l[g]^T H^{l-1}[g] from one plane set of the chain kernel
-int prop_bwd_hl_gadj(const unsigned char* yplanes, const float* yisg, const float* Hprev, int64_t h_bs, float* out, int G, int C, int S, hipStream_t st);
+// block mode (gdiag != null): the off-diagonal blocks go to gtrans [G][C][256] (may be null), the diagonal ones to gdiag [G][S / 16][256]; out unused
+int prop_bwd_hl_gadj(const unsigned char* yplanes, const float* yisg, const float* Hprev, int64_t h_bs, float* out, float* gtrans, float* gdiag, int G,
+                     int C, int S, hipStream_t st);
 bool prop_bwd_h_shape_ok(int C, int S);   // LDS budget of the backward's two-term form
 int prop_h_grid(int B);               // workgroups the two-term kernels launch for B graphs (one per CU, persistent)
 bool prop_bwd_h_supported(const PropBwdH& p);

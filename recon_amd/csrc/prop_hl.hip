@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) k_prop_split_adj(const PropHL q) {
     const int b = q.g0 + g, S = p.S;
     constexpr int MAXK = 16;
     u32x4 raw[MAXK][2];
-    if constexpr (TRANS) {
+    if constexpr (TRANS && !BLK) {
         // rows of A_l^T: element (row, t) = A_l[t][row]; the 16 lanes li of a group read 64 contiguous bytes of row t of A_l
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.adj[l] + static_cast<int64_t>(b) * S * S), 0, S * S * 4, 0x00020000);
         const int row = 16 * rt + li;
@@ -87,6 +87,25 @@ __global__ void __launch_bounds__(256) k_prop_split_adj(const PropHL q) {
             for (int h = 0; h < 2; ++h) {
                 const int t0 = 32 * ks + 16 * h + 4 * lq;
                 raw[ks][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, (row < S && t0 < S) ? base + static_cast<uint32_t>(32 * ks + 16 * h) * 4u : kOOB, 0, 0);
+            }
+    } else if constexpr (BLK && TRANS) {
+        // rows of node i = rt of A_l^T: block (i, j) = trans[l][b, e(j, i)]^T — element (li, c) = T[e(j, i)][c][li] — identity^T on the diagonal
+        const int nn = S >> 4, C = p.C;
+        const auto rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.trans[l] + static_cast<int64_t>(b) * C * 256), 0, C * 1024, 0x00020000);
+        const auto rs_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.identity), 0, 1024, 0x00020000);
+#pragma unroll
+        for (int ks = 0; ks < MAXK; ++ks)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = 2 * ks + h;
+                const bool ok = rt < nn && j < nn, diag = j == rt;
+                const uint32_t e = static_cast<uint32_t>(j * (nn - 1) + (rt < j ? rt : rt - 1));
+                const auto rs = diag ? rs_i : rs_t;
+                uint32_t v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    v[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? static_cast<uint32_t>((4 * lq + i) * 16 + li) * 4u : kOOB, diag ? 0 : static_cast<int>(e * 1024u), 0);
+                raw[ks][h] = u32x4{v[0], v[1], v[2], v[3]};
             }
     } else {
         // rows of node i = rt: block (i, j) = trans[l][b, e(i, j)] (row li, columns 4 lq ..), the identity on the diagonal
@@ -494,6 +513,8 @@ struct PropGadj {
     const float* yisg;                  // [G][32 NKC] inverse channel scales of Y_l
     const float* Hprev; int64_t h_bs;   // H^{l-1} [G][C][S] (h_bs = 0: one h^0 for all graphs)
     float* out;                         // d A_l [G][S][S]
+    float* gtrans;                      // BLOCK MODE (gdiag != null): d T_l [G][C][256] in the transition tensor's layout, or null
+    float* gdiag;                       // block mode: the diagonal blocks of d A_l, [G][n][256] (summed into d identity by the caller)
     int32_t G, C, S, NKC, npass, nchunks;
 };
 
@@ -636,6 +657,28 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_prop_gadj_hl(const PropGadj q
         }
     }
     // ---- d A_l[s][t]: C layout — column (lane & 15) = t0 + 16 j + li, rows s = 16 (wave RT + r) + 4 lq + i; 64-byte runs per row
+    if (q.gdiag) {
+        // block mode (S = 16 n): row tile = node i, column tile = node j; block (i, j) goes to T's layout [e(i, j)][row][column], the diagonal
+        // blocks to their own buffer
+        const int nn = S >> 4;
+        float* gt = q.gtrans ? q.gtrans + static_cast<int64_t>(gs) * C * 256 : nullptr;
+        float* gd = q.gdiag + static_cast<int64_t>(gs) * nn * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float k = isg_t[16 * j + li];
+            const int jn = (t0 >> 4) + j;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const int in_ = wave * RT + r;
+                if (in_ >= nn || jn >= nn) continue;                    // wave-uniform
+                float* dst = in_ == jn ? gd + in_ * 256 : (gt ? gt + static_cast<int64_t>(in_ * (nn - 1) + (jn < in_ ? jn : jn - 1)) * 256 : nullptr);
+                if (!dst) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dst[(4 * lq + i) * 16 + li] = acc[r][j][i] * k;
+            }
+        }
+        return;
+    }
     float* out = q.out + static_cast<int64_t>(gs) * S * S;
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(out, 0, S * S * 4, 0x00020000);
 #pragma unroll
@@ -752,10 +795,11 @@ void prop_bwd_hl_ws_layout(int C, int S, int L, int64_t G, float* ws, float** y_
     *isg = reinterpret_cast<float*>(*planes + static_cast<size_t>(L) * *plane_set_bytes);
 }
 
-int prop_bwd_hl_gadj(const unsigned char* yplanes, const float* yisg, const float* Hprev, int64_t h_bs, float* out, int G, int C, int S, hipStream_t st) {
+int prop_bwd_hl_gadj(const unsigned char* yplanes, const float* yisg, const float* Hprev, int64_t h_bs, float* out, float* gtrans, float* gdiag, int G,
+                     int C, int S, hipStream_t st) {
     const HLGeom g = hl_geom(S, 1);
     PropGadj q{};
-    q.yplanes = yplanes; q.yisg = yisg; q.Hprev = Hprev; q.h_bs = h_bs; q.out = out;
+    q.yplanes = yplanes; q.yisg = yisg; q.Hprev = Hprev; q.h_bs = h_bs; q.out = out; q.gtrans = gtrans; q.gdiag = gdiag;
     q.G = G; q.C = C; q.S = S; q.NKC = hl_nkc(C); q.nchunks = (S + kCH - 1) / kCH;
     const int NKS = q.NKC <= 8 ? 8 : 16;
     q.npass = (q.NKC + NKS - 1) / NKS;
@@ -789,7 +833,13 @@ int prop_bwd_hl_chain(const PropBwdHL& a, hipStream_t st) {
     q.alpha = reinterpret_cast<float*>(q.split + ((g.per_graph_split * static_cast<size_t>(a.G) + 255) & ~static_cast<size_t>(255)));
     q.NKS = g.NKS; q.RT = g.RT; q.nchunks = (a.C + kCH - 1) / kCH; q.g0 = 0; q.G = a.G;
     const int64_t units = static_cast<int64_t>(a.L) * q.G * 8 * g.RT;
-    hipLaunchKernelGGL((k_prop_split_adj<false, true>), dim3(static_cast<unsigned>((units + 3) / 4)), dim3(256), 0, st, q);
+    if (a.identity) {
+        for (int k = 0; k < a.L; ++k) q.p.trans[k] = a.adj_step[k];    // block mode: the steps' transition tensors [G][C][256]
+        q.p.identity = a.identity;
+        hipLaunchKernelGGL((k_prop_split_adj<true, true>), dim3(static_cast<unsigned>((units + 3) / 4)), dim3(256), 0, st, q);
+    } else {
+        hipLaunchKernelGGL((k_prop_split_adj<false, true>), dim3(static_cast<unsigned>((units + 3) / 4)), dim3(256), 0, st, q);
+    }
     const dim3 grid(static_cast<unsigned>(((q.G + 7) / 8) * 8 * q.nchunks));
 #define CALL_HLB(R_, K_)                                                                                                                      \
     do {                                                                                                                                      \
