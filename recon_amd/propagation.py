@@ -417,7 +417,7 @@ class _PropagateBlocks(torch.autograd.Function):
         out = torch.empty(B, Cn, L * dd, dtype=torch.float32, device=dev)
         need = any(ctx.needs_input_grad)
         hs = torch.empty(L, B, Cn, S, dtype=torch.float32, device=dev) if need else None
-        stats = torch.empty(B, 2 * L + 1, dtype=torch.float32, device=dev) if need else None
+        stats = torch.empty(B, 2 * L + 1, dtype=torch.float32, device=dev) if (need and S <= 160) else None
         tarr = _ptr_array(Ts)
         args = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], None, h0c.data_ptr(), h0_bs, head.data_ptr(), tail.data_ptr(), idx_bs,
                              out.data_ptr(), _lib.ptr(hs), tarr, identity.data_ptr(), _lib.ptr(stats), None, 0)
@@ -439,17 +439,40 @@ class _PropagateBlocks(torch.autograd.Function):
         g_I = torch.empty(dd, dd, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         g_h = torch.empty(B, Cn, S, dtype=torch.float32, device=dev)
         Lb = _lib.lib()
-        ws = torch.empty(Lb.recon_propagate_identity_ws_floats(dd), dtype=torch.float32, device=dev) if g_I is not None else None
         tarr, garr = _ptr_array(Ts), _ptr_array(g_Ts)
         fwd = _lib.PropArgs(B, Cn, S, L, dd, _lib.ACT[act], None, h0c.data_ptr(), h0_bs, head.data_ptr(), tail.data_ptr(), idx_bs,
-                            gout.data_ptr(), hs.data_ptr(), tarr, identity.data_ptr(), stats.data_ptr(), None, 0)
-        args = _lib.PropBwdArgs(fwd, gout.data_ptr(), None, g_h.data_ptr(), garr, _lib.ptr(g_I), _lib.ptr(ws), None)
+                            gout.data_ptr(), hs.data_ptr(), tarr, identity.data_ptr(), _lib.ptr(stats), None, 0)
+        if S > 160:
+            # wide states: chain + d T products on the two-term f16 kernels of csrc/prop_hl.hip (block-structured indices: propagate_blocks checked)
+            blk = _index_blocks(head, tail, dd, S, align=16)
+            sws = _split_workspace(fwd, dev)
+            chain = torch.empty(Lb.recon_propagate_bwd_chain_ws_floats(C.byref(fwd)), dtype=torch.float32, device=dev)
+            args = _lib.PropBwdArgs(fwd, gout.data_ptr(), None, g_h.data_ptr(), garr, _lib.ptr(g_I), None, None,
+                                    blk[0].data_ptr(), blk[1].data_ptr(), chain.data_ptr())
+        else:
+            ws = torch.empty(Lb.recon_propagate_identity_ws_floats(dd), dtype=torch.float32, device=dev) if g_I is not None else None
+            args = _lib.PropBwdArgs(fwd, gout.data_ptr(), None, g_h.data_ptr(), garr, _lib.ptr(g_I), _lib.ptr(ws), None)
         with _lib.on_device(dev):
             _lib.check(Lb.recon_propagate_bwd(C.byref(args), _lib.current_stream()), "recon_propagate_bwd (block mode)")
         g_h0 = None
         if ctx.needs_input_grad[0]:
             g_h0 = (g_h if h0_bs else g_h.sum(0)).view(h0_shape)
         return (g_h0, g_I, None, None, None, None) + tuple(g.view(sh) if g is not None else None for g, sh in zip(g_Ts, t_shapes))
+
+
+def _blocks_wide_trainable(B, n, dd, h0, L, head, tail):
+    """10 < n <= 32 with gradients in float32: the forward reads the transition tensors in place (csrc/prop_hl.hip) and the backward's chain /
+    d T products run on its mirror images — for GP-GNN's block-structured gather indices shared by the batch."""
+    if head.dim() == 3 and head.shape[0] > 1:
+        return False
+    Cn, S = n * (n - 1), n * dd
+    if _index_blocks(head.contiguous(), tail.contiguous(), dd, S, align=16) is None:
+        return False
+    probe = _lib.PropArgs(B, Cn, S, max(1, int(L)), dd, 1, None, h0.data_ptr(), Cn * S if h0.dim() == 4 else 0, None, None, 0, None, None, (C.c_void_p * 1)(),
+                          16, None, None, 0)
+    probe.split_ws_bytes = _lib.lib().recon_propagate_ws_bytes(C.byref(probe))
+    probe.split_ws = 1
+    return probe.split_ws_bytes > 0 and _lib.lib().recon_propagate_bwd_chain_ws_floats(C.byref(probe)) > 0
 
 
 def blocks_mode_available(B, n, dd, h0, need_grad=True, L=1, T_list=None):
@@ -579,7 +602,11 @@ def propagate_blocks(T_list, identity, n, h0, nonlinearity, head_indices, tail_i
         if need_grad and _blocks_b16_trainable(B, n, dd, h0, T_list, identity):
             return _PropagateBlocksB16.apply(h0, identity, nonlinearity, head_indices, tail_indices, n, *T_list)
         return propagate([build_block_adjacency(T, identity, n) for T in T_list], h0, nonlinearity, head_indices, tail_indices)
-    if not blocks_mode_available(B, n, dd, h0, need_grad, L=len(T_list), T_list=T_list):
+    ok = blocks_mode_available(B, n, dd, h0, need_grad, L=len(T_list), T_list=T_list)
+    if not ok and need_grad and n > 10:
+        ok = (blocks_mode_available(B, n, dd, h0, False, L=len(T_list), T_list=T_list) and identity.data_ptr() % 16 == 0 and
+              _blocks_wide_trainable(B, n, dd, h0, len(T_list), head_indices, tail_indices))
+    if not ok:
         return propagate([build_block_adjacency(T, identity, n) for T in T_list], h0, nonlinearity, head_indices, tail_indices)
     return _PropagateBlocks.apply(h0, identity, nonlinearity, head_indices, tail_indices, n, *T_list)
 

@@ -476,10 +476,12 @@ def test_cfg3b_n32_fp32_backward_across_slices_and_full_batch(B, copies_of):
 
 
 def test_propagate_blocks_trains_at_n32():
-    """propagate_blocks() with gradients at n = 32 (no fused block-mode backward exists there: block adjacency + propagation, both with
-    their own backward): forward and every gradient against the float64 oracle."""
-    from recon_amd.propagation import propagate_blocks
+    """propagate_blocks() with gradients at n = 32: the forward reads the transition tensors in place, the backward's chain and d T products
+    run on the two-term f16 kernels of csrc/prop_hl.hip (transposed split straight from T, d T written in T's layout, diagonal blocks summed
+    into d identity) — no adjacency in either direction.  Forward and every gradient against the float64 oracle."""
+    from recon_amd.propagation import propagate_blocks, _blocks_wide_trainable
     d_ = dev()
+    assert _blocks_wide_trainable(3, 32, 16, torch.zeros(3, 992, 512, 1, device=d_), 2, _prop_problem(32, 8, 1, 1, 0, 1.0)[3], _prop_problem(32, 8, 1, 1, 0, 1.0)[4])
     n, d, L, B, act = 32, 8, 2, 3, "tanh"
     Ts, ident, h0, head, tail, Gr = _prop_problem(n, d, L, B, seed=17, scale=0.02)
     Tl = [t.to(d_).requires_grad_(True) for t in Ts]

@@ -846,3 +846,48 @@ def test_wide_backward_chain_form_vs_oracle(n, L, B, act, per_batch):
     for l in range(L):
         close(gA_h[l], gA_r[l].float(), atol=1e-5, what="chain g_adj[%d]" % l)
     close(gh_h, gh_r.float(), atol=1e-5, what="chain g_h0")
+
+
+@pytest.mark.parametrize("n,L,B,act,per_batch", [
+    (12, 3, 3, "relu", True),        # S = 192: RT = 2
+    (17, 2, 2, "tanh", False),       # S = 272: RT = 3; shared h0
+    (24, 2, 2, "relu", True),        # S = 384, C = 552: d T in two K passes
+    (11, 1, 300, "tanh", False),     # one hop; two slices of the split workspace (tanh: among 6 M pre-activations one lands within the two-term
+                                     # arithmetic's 1e-7 of zero and flips its ReLU mask against the float64 oracle — seen with this seed)
+])
+def test_propagate_blocks_trains_at_wide_states(n, L, B, act, per_batch):
+    """propagate_blocks() with gradients for 10 < n <= 32 in float32 (csrc/prop_hl.hip in block mode, both directions): against the float64
+    oracle, and d identity / d T against the route through the materialised adjacency (RECON_PROP_BLOCKS=0 is process-wide: compared through
+    propagate + build_block_adjacency here)."""
+    from recon_amd.propagation import propagate_blocks, propagate, build_block_adjacency, get_head_indices, get_tail_indices, make_start_embedding, _blocks_wide_trainable
+    d_ = dev()
+    d = 8
+    Cn, S, dd = n * (n - 1), 16 * n, 16
+    g = torch.Generator().manual_seed(7 * n + L)
+    Ts = [torch.relu(torch.randn(B, Cn, dd * dd, generator=g)) * (0.6 / n) for _ in range(L)]
+    for t in Ts:
+        t[:, ::5] *= 6.0                                               # blocks of very different magnitude
+    ident = torch.eye(dd) + 0.02 * torch.randn(dd, dd, generator=g)
+    tmpl = torch.from_numpy(make_start_embedding(n, d)).float()
+    h0 = (torch.randn(B, Cn, S, 1, generator=g) if per_batch else torch.randn(Cn, S, 1, generator=g)) * tmpl
+    head = torch.from_numpy(get_head_indices(n, d, bs=1)[0])
+    tail = torch.from_numpy(get_tail_indices(n, d, bs=1)[0])
+    Gr = torch.randn(B, Cn, dd * L, generator=g)
+    assert _blocks_wide_trainable(B, n, dd, h0.to(d_), L, head.to(d_), tail.to(d_))
+
+    def run(device, dt, fn):
+        Tl = [t.clone().to(device=device, dtype=dt).requires_grad_(True) for t in Ts]
+        I = ident.clone().to(device=device, dtype=dt).requires_grad_(True)
+        h = h0.clone().to(device=device, dtype=dt).requires_grad_(True)
+        out = fn(Tl, I, h, head.to(device), tail.to(device))
+        (out * Gr.to(device=device, dtype=dt)).sum().backward()
+        return out.detach(), [t.grad for t in Tl], I.grad, h.grad
+    ref = run("cpu", torch.float64, lambda Tl, I, h, hd, tl: O.propagate([O.build_block_adjacency(t, I, n) for t in Tl], h, act, hd, tl, as_gemm=True))
+    blk = run(d_, torch.float32, lambda Tl, I, h, hd, tl: propagate_blocks(Tl, I, n, h, act, hd, tl))
+    dense = run(d_, torch.float32, lambda Tl, I, h, hd, tl: propagate([build_block_adjacency(t, I, n) for t in Tl], h, act, hd, tl))
+    for name, got in (("blocks", blk), ("dense", dense)):
+        close(got[0], ref[0].float(), atol=1e-4, rel_to_max=1e-5, what=name + " out")
+        for l in range(L):
+            close(got[1][l], ref[1][l].float(), atol=1e-5, what="%s g_T[%d]" % (name, l))
+        close(got[2], ref[2].float(), atol=1e-5, rel_to_max=2e-5, what=name + " g_identity")
+        close(got[3], ref[3].float(), atol=1e-5, what=name + " g_h0")

@@ -98,7 +98,8 @@ def propagation(n, B=1024, d=8, L=3, iters=10, with_backward=True):
         if blocks_mode_available(B, n, dd, h0, need_grad=False):
             res["fwd_incl_adjacency_ms"] = _time(unfused_fwd_incl_adjacency, iters) * 1e3
             res["fused_blocks_fwd_ms"] = _time(fused_fwd, iters) * 1e3
-        if blocks_mode_available(B, n, dd, h0):
+        from recon_amd.propagation import _blocks_wide_trainable
+        if blocks_mode_available(B, n, dd, h0) or (n > 10 and _blocks_wide_trainable(B, n, dd, h0, L, head, tail)):
             res["fused_blocks_fwd_bwd_ms"] = _time(fused, max(2, iters // 2)) * 1e3
     del Ts, adjs, h0, G
     torch.cuda.empty_cache()
