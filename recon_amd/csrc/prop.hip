@@ -1126,7 +1126,6 @@ int prop_bwd_wide_chain(const recon_prop_args* a, const recon_prop_bwd_args* ba,
     const int nn = S / 16;
     const int64_t G = prop_bwd_hl_slice(C, S, L, a->split_ws_bytes, B);
     if (G <= 0) return RECON_ERR_UNSUPPORTED;
-    const size_t plds = 4ull * S * sizeof(float);
     float* diag_ws = blk ? ba->chain_ws + prop_bwd_hl_ws_floats(C, S, L, G) : nullptr;      // [L][B][n][256]
     const bool want_ident = blk && ba->g_identity;
     for (int64_t g0 = 0; g0 < B; g0 += G) {
@@ -1138,11 +1137,8 @@ int prop_bwd_wide_chain(const recon_prop_args* a, const recon_prop_bwd_args* ba,
         float* y_in; unsigned char* planes; float* isg; size_t pset, iset;
         prop_bwd_hl_ws_layout(C, S, L, G, ba->chain_ws, &y_in, &planes, &isg, &pset, &iset);
         c.yplanes = planes; c.yisg = isg;
-        // Y_L = relation gradient of the last hop . act'(H^L)
-        hipLaunchKernelGGL(k_prop_bwd_post, dim3(static_cast<unsigned>(ceil_div64(1LL * Gs * C, 4))), dim3(256), plds, st, nullptr,
-                           a->h_saved + static_cast<int64_t>(L - 1) * BCS + g0 * CS, a->head_idx, a->tail_idx, 0, c.gout, y_in, 1LL * Gs * C, C, S, L, a->dd,
-                           L - 1, a->act);
-        c.y_in = y_in;
+        c.y_in = nullptr;
+        c.hlast = a->h_saved + static_cast<int64_t>(L - 1) * BCS + g0 * CS;  // Y_L = relation gradient of the last hop . act'(H^L), formed by the chain kernel
         for (int k = 0; k < L; ++k) {
             const int l = L - k;
             c.adj_step[k] = blk ? a->trans[l - 1] + g0 * C * 256 : a->adj[l - 1] + g0 * S * S;

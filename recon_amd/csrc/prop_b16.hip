@@ -27,6 +27,14 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using i16x4 = __attribute__((ext_vector_type(4))) short;
 using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
 
+// buffer-load aux bit 31 = a volatile access: the request stays where it is written.  As plain read-only loads the compiler sinks the A-fragment
+// requests of a K loop that writes no memory towards their uses (found in csrc/prop_hl.hip's k_prop_gadj_hl: the prefetch distance was compiled away)
+#ifdef RECON_B16_PLAIN_LOADS
+constexpr int kPinnedLoad = 0;
+#else
+constexpr int kPinnedLoad = static_cast<int>(0x80000000u);
+#endif
+
 struct PropB16K {
     const uint16_t* adj[kMaxHops];
     const uint16_t* trans[kMaxHops];
@@ -288,9 +296,9 @@ __global__ void __launch_bounds__(512, 2) k_prop_b16_fwd_wide(const PropB16K p, 
             const int R = wave * RT + r, j = 2 * ks + lq_hi;
             const bool valid = live && R < nn && j < nn && j != R;
             // (the whole offset in the lane part: the range check looks at the lane offset alone, and R = 0 would make it negative)
-            return __builtin_amdgcn_raw_buffer_load_b128(rs, valid ? voff_r[r] + 1024u * ks - (j > R ? 512u : 0u) : kOOB, 0, 0);
+            return __builtin_amdgcn_raw_buffer_load_b128(rs, valid ? voff_r[r] + 1024u * ks - (j > R ? 512u : 0u) : kOOB, 0, kPinnedLoad);
         } else {
-            return __builtin_amdgcn_raw_buffer_load_b128(rs, (live && !(p.ablate & 1)) ? voff_r[r] : kOOB, 64 * ks, 0);
+            return __builtin_amdgcn_raw_buffer_load_b128(rs, (live && !(p.ablate & 1)) ? voff_r[r] : kOOB, 64 * ks, kPinnedLoad);
         }
     };
     u32x4 dpar[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};   // identity rows for row tiles of even / odd node index

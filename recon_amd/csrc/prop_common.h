@@ -72,7 +72,8 @@ int prop_fwd_hl(const PropK& p, hipStream_t st);
 struct PropBwdHL {
     const float* adj_step[kMaxHops];  // A_{L-k} [G][S][S]; block mode (identity != null): the transition tensor T_{L-k} [G][C][256]
     const float* identity;            // block mode: [16][16]
-    const float* y_in;                // Y_L [G][C][S]
+    const float* y_in;                // Y_L [G][C][S], or null with hlast
+    const float* hlast;               // H^L [G][C][S]: the chain kernel forms Y_L in its prologue (no row kernel, no [G, C, S] round trip)
     const float* hmask[kMaxHops];     // H^{l-1} [G][C][S], null for the last step (l = 1)
     float* ysave[kMaxHops];           // Y_{l-1} [G][C][S]; the last step's is d loss / d h^0
     const float* gout;                // [G][C][L dd]

@@ -24,6 +24,13 @@ namespace {
 constexpr int kCH = 64;                 // channels per workgroup
 constexpr int kSTEP = kCH * 64;         // bytes of one K step (32 columns) of one plane: 64 bytes per channel
 constexpr int kHLWaves = 8;
+// buffer-load aux bit 31: a volatile access — the compiler neither moves nor merges it (see k_prop_gadj_hl: as plain read-only loads the A-fragment
+// requests of a loop without stores were sunk next to their uses, i.e. the two-K-step prefetch was compiled away)
+#ifdef RECON_HL_PLAIN_LOADS
+constexpr int kVolatileLoad = 0;
+#else
+constexpr int kVolatileLoad = static_cast<int>(0x80000000u);
+#endif
 
 struct PropHL {
     PropK p;
@@ -39,6 +46,7 @@ struct PropHL {
     int32_t gout_ld, gout_off[kMaxHops];        // L dd; column of step k's relation gradient ((l - 2) dd)
     // the states Y_L, Y_{L-1}, .., Y_1 leave as the d A products' streamed operand: two half planes in MFMA fragment order, rows = state
     // column s, K = channel, as they sit in LDS (i.e. times the channel's power-of-two scale, whose inverse goes to yisg)
+    const float* hlast;                 // H^L [G][C][S]: the first state Y_L = relation gradient of hop L . act'(H^L) is formed in the prologue (p.h0 unused)
     unsigned char* yplanes;             // [L emissions][G][RTT][NKC][2][1 KiB] or null
     float* yisg;                        // [L emissions][G][32 NKC]
     int32_t NKC;                        // K steps of the d A products: channels / 32, rounded up to a multiple of 2
@@ -244,9 +252,63 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
             const int l = i / RP;
             atab[i] = q.alpha[(static_cast<int64_t>(l) * q.G + gs) * RP + (i - l * RP)];
         }
+        if constexpr (BWD) {
+            {
+                // (compile-time branch: a run-time one in front of the hop loop left the request counters of the two paths different at the
+                // loop header, and the compiler answered with s_waitcnt vmcnt(0) at every K step — 1.77 -> 2.8 ms per slice)
+                // Y_L[c][s] = grad_out[c][L-1][x] H^L[c][partner block + x] act'(H^L[c][s]) on the 16 + 16 columns of channel c's head and tail
+                // blocks, zero everywhere else: 48 values per channel come from memory instead of a [C, S] tensor written by a kernel of its own
+                const int64_t row0 = static_cast<int64_t>(b) * C + c0;
+                const auto rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.hlast + row0 * S), 0, nch * S * 4, 0x00020000);
+                const int goff = (L - 1) * p.dd;
+                const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.gout + row0 * q.gout_ld + goff), 0, (nch * q.gout_ld - goff) * 4, 0x00020000);
+                constexpr int NC = kCH / kHLWaves;                      // channels per wave: every request of all of them is issued before the first use
+                int mine[NC], other[NC];
+                const int x = lane & 15;
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const int cc = min(c0 + wave + kHLWaves * i, C - 1);
+                    const int hbc = q.hblk[cc], tbc = q.tblk[cc];
+                    mine[i] = (lane < 16 ? hbc : tbc) + x; other[i] = (lane < 16 ? tbc : hbc) + x;
+                }
+                float gv[NC], ho[NC], hm_[NC];
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const int cl = wave + kHLWaves * i;
+                    const bool ok = cl < nch && lane < 32;
+                    gv[i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rs_g, ok ? static_cast<uint32_t>(cl * q.gout_ld + x) * 4u : kOOB, 0, 0));
+                    ho[i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rs_h, ok ? static_cast<uint32_t>(cl * S + other[i]) * 4u : kOOB, 0, 0));
+                    hm_[i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rs_h, ok ? static_cast<uint32_t>(cl * S + mine[i]) * 4u : kOOB, 0, 0));
+                }
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const int cl = wave + kHLWaves * i;
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        const int t0 = 4 * lane + 256 * ps;
+                        if (t0 < KP) store_state4(hl_pos4(cl, t0), 0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+                lds_wait();                                             // this wave's zeros have landed: the 32 values per channel go on top
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const int cl = wave + kHLWaves * i;
+                    const float v = gv[i] * ho[i] * act_bwd(hm_[i], p.act);
+                    const float sg = hx2_scale_of(wave_max(fabsf(v)));
+                    if (cl < nch && lane < 32) {
+                        uint32_t h, l_;
+                        hx2_split2(v * sg, 0.f, h, l_);
+                        const int pos = hl_pos4(cl, mine[i] & ~3) + 2 * (mine[i] & 3);
+                        *reinterpret_cast<uint16_t*>(Hs + pos) = static_cast<uint16_t>(h & 0xffffu);
+                        *reinterpret_cast<uint16_t*>(Hs + PLANE + pos) = static_cast<uint16_t>(l_ & 0xffffu);
+                    }
+                    if (lane == 0) isg[cl] = hx2_inv(sg);
+                }
+            }
+        }
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.h0 + b * p.h0_bs + static_cast<int64_t>(c0) * S), 0, nch * S * 4, 0x00020000);
 #pragma unroll 1
-        for (int batch = 0; batch < 2; ++batch) {
+        for (int batch = 0; batch < (BWD ? 0 : 2); ++batch) {
             u32x4 hv[4][2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -359,6 +421,8 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
                 acc[r][0][0] += static_cast<float>(ah[0]) + static_cast<float>(bl[r & 3][1]); acc[r][1][1] += static_cast<float>(al[7]) + static_cast<float>(bh[r & 3][2]);
 #endif
 #ifndef RECON_HL_NOLOAD
+                // (plain loads here: the compiler keeps them 8 .. 9 requests ahead of their uses; as volatile ones — 14 .. 15 ahead — the forward is
+                // unchanged at 1.24 ms per slice and the chain form spills 57 registers: 1.69 -> 1.82 ms)
                 ring[BUF][r][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_rt[r] | oob, so, 0);
                 ring[BUF][r][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (voff_rt[r] + 1024u) | oob, so, 0);
 #endif
@@ -606,10 +670,14 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_prop_gadj_hl(const PropGadj q
     for (int pass = 0; pass < q.npass; ++pass) {
         const int c_pass = pass * KP;
         lds_barrier();                                                  // the previous pass's reads of the image are done (pass 0: isg_t visible)
-        for (int i = tid; i < KP; i += 64 * kHLWaves) fy[i] = c_pass + i < C ? yi[c_pass + i] : 0.f;
+        static_assert(KP <= 64 * kHLWaves && (2 * NKS) % kHLWaves == 0, "one table element per thread; whole rounds of 16-channel groups");
+        if (tid < KP) fy[tid] = c_pass + tid < C ? yi[c_pass + tid] : 0.f;
         lds_barrier();
-        // stage: wave w converts the 16-channel groups w, w + 8, ... of this pass
-        for (int cg = wave; cg < 2 * NKS; cg += kHLWaves) {
+        // stage: wave w converts the 16-channel groups w, w + 8, ... of this pass.  Straight-line (compile-time trip count): with a run-time loop
+        // between the ring's requests and the K loop the compiler cannot count what is outstanding and drains (s_waitcnt vmcnt(0)) at every K step
+#pragma unroll
+        for (int it = 0; it < 2 * NKS / kHLWaves; ++it) {
+            const int cg = wave + kHLWaves * it;
             const int cl = 16 * cg + 4 * lq, cb = c_pass + cl;
             const float4 f4 = *reinterpret_cast<const float4*>(fy + cl);
             const float f[4] = {f4.x, f4.y, f4.z, f4.w};
@@ -650,9 +718,13 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_prop_gadj_hl(const PropGadj q
                 for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], acc[r][j], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], acc[r][j], 0, 0, 0);
-                ring[BUF][r][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, voff_rt[r] | oob, so, 0);
-                ring[BUF][r][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (voff_rt[r] + 1024u) | oob, so, 0);
-                __builtin_amdgcn_sched_barrier(0x078f);
+                // aux bit 31 = volatile: these requests stay WHERE THEY ARE WRITTEN.  As plain read-only loads the compiler sank them one K step down,
+                // next to their uses (nothing in this loop writes memory, so nothing stopped it): every fragment was then awaited right behind its
+                // request (s_waitcnt vmcnt(1) / vmcnt(0) throughout, RT = 2 and 4; the RT = 3 instances kept their place by luck of a heuristic)
+                ring[BUF][r][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, voff_rt[r] | oob, so, kVolatileLoad);
+                ring[BUF][r][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (voff_rt[r] + 1024u) | oob, so, kVolatileLoad);
+                __builtin_amdgcn_sched_barrier(0x0787);                 // MFMA and VMEM stay on their side: at 255 registers the scheduler otherwise runs each row tile's
+                                                                        // accumulator chain depth-first to free the ring early — every fragment is then awaited right behind its request
             }
         }
     }
@@ -828,7 +900,8 @@ int prop_bwd_hl_chain(const PropBwdHL& a, hipStream_t st) {
     q.p.h0 = a.y_in; q.p.h0_bs = static_cast<int64_t>(a.C) * a.S;
     for (int k = 0; k < a.L; ++k) { q.p.adj[k] = a.adj_step[k]; q.hmask[k] = a.hmask[k]; q.ysave[k] = a.ysave[k]; q.gout_off[k] = a.gout_off[k]; }
     q.gout = a.gout; q.gout_ld = a.L * a.dd; q.hblk = a.hblk; q.tblk = a.tblk;
-    q.yplanes = a.yplanes; q.yisg = a.yisg; q.NKC = hl_nkc(a.C);
+    q.yplanes = a.yplanes; q.yisg = a.yisg; q.NKC = hl_nkc(a.C); q.hlast = a.hlast;
+    if (a.hlast) { q.p.h0 = a.hlast; q.p.h0_bs = 0; }                   // (unused: the prologue forms Y_L itself)
     q.split = static_cast<unsigned char*>(a.ws);
     q.alpha = reinterpret_cast<float*>(q.split + ((g.per_graph_split * static_cast<size_t>(a.G) + 255) & ~static_cast<size_t>(255)));
     q.NKS = g.NKS; q.RT = g.RT; q.nchunks = (a.C + kCH - 1) / kCH; q.g0 = 0; q.G = a.G;
