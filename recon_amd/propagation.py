@@ -237,6 +237,8 @@ class _Propagate(torch.autograd.Function):
         B, Cn, S, L, dd, act, h0_bs, idx_bs, h0_shape, adj_shapes = ctx.meta
         dev = gout.device
         gout = gout.contiguous()
+        if gout.data_ptr() % 16:
+            gout = gout.clone()                                         # (a view at an odd offset: the wide-state kernels read 16-byte pieces)
         g_adjs = [torch.empty(B, S, S, dtype=torch.float32, device=dev) if ctx.needs_input_grad[4 + l] else None
                   for l in range(L)]
         g_h = torch.empty(B, Cn, S, dtype=torch.float32, device=dev)
@@ -247,7 +249,7 @@ class _Propagate(torch.autograd.Function):
         # wide states (S > 160): GP-GNN's block-structured gather indices let the chain of products run on the forward's two-term f16 kernel
         # (all hops in one launch); otherwise both products of a hop are batched fp32 GEMMs
         blk = chain = ws = wide = None
-        if S > 160 and dd == 16 and not idx_bs:
+        if S > 160 and dd == 16 and not idx_bs and h0c.data_ptr() % 16 == 0 and all(a.data_ptr() % 16 == 0 for a in adjs):
             blk = _index_blocks(head, tail, dd, S, align=16)
             if blk is not None:
                 ws = _split_workspace(fwd, dev)
@@ -435,6 +437,8 @@ class _PropagateBlocks(torch.autograd.Function):
         B, Cn, S, L, dd, act, h0_bs, idx_bs, h0_shape, t_shapes = ctx.meta
         dev = gout.device
         gout = gout.contiguous()
+        if gout.data_ptr() % 16:
+            gout = gout.clone()
         g_Ts = [torch.empty(B, Cn, dd * dd, dtype=torch.float32, device=dev) if ctx.needs_input_grad[6 + l] else None for l in range(L)]
         g_I = torch.empty(dd, dd, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         g_h = torch.empty(B, Cn, S, dtype=torch.float32, device=dev)

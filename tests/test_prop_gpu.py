@@ -891,3 +891,28 @@ def test_propagate_blocks_trains_at_wide_states(n, L, B, act, per_batch):
             close(got[1][l], ref[1][l].float(), atol=1e-5, what="%s g_T[%d]" % (name, l))
         close(got[2], ref[2].float(), atol=1e-5, rel_to_max=2e-5, what=name + " g_identity")
         close(got[3], ref[3].float(), atol=1e-5, what=name + " g_h0")
+
+
+def test_wide_backward_takes_a_gradient_view_at_an_odd_offset():
+    """The wide-state backward reads grad_out in 16-byte pieces: a contiguous view that starts 4 bytes into its storage is copied first — same
+    gradients, bit for bit, as with an aligned tensor."""
+    from recon_amd.propagation import propagate, get_head_indices, get_tail_indices
+    d_ = dev()
+    n, L, B = 12, 2, 2
+    Cn, S, dd = n * (n - 1), 16 * n, 16
+    g = torch.Generator().manual_seed(5)
+    adjs = [((torch.rand(B, S, S, generator=g) - 0.45) * (2.0 / S ** 0.5)).to(d_) for _ in range(L)]
+    h0 = torch.randn(B, Cn, S, 1, generator=g).to(d_)
+    head = torch.from_numpy(get_head_indices(n, 8, bs=1)[0]).to(d_)
+    tail = torch.from_numpy(get_tail_indices(n, 8, bs=1)[0]).to(d_)
+    Gr = torch.randn(B * Cn * dd * L + 1, generator=g).to(d_)
+    odd = Gr[1:].view(B, Cn, dd * L)
+    assert odd.data_ptr() % 16 != 0 and odd.is_contiguous()
+    res = []
+    for G in (odd, odd.clone()):
+        A = [a.clone().requires_grad_(True) for a in adjs]
+        h = h0.clone().requires_grad_(True)
+        propagate(A, h, "relu", head, tail).backward(G)
+        res.append([a.grad for a in A] + [h.grad])
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
