@@ -472,7 +472,7 @@ def test_cfg3b_n32_fp32_backward_across_slices_and_full_batch(B, copies_of):
     assert torch.isfinite(Ib.grad).all()
     for t in [out, hb.grad] + [t.grad for t in Tb]:
         v = t.reshape(reps, copies_of, -1)
-        assert torch.equal(v[1], v[0]) and torch.equal(v[reps - 1], v[0]), "copies of the same graphs differ"
+        assert not bool((v != v[:1]).any()), "copies of the same graphs differ"          # EVERY copy, not a sample: a race shows up in a few workgroups only
 
 
 def test_propagate_blocks_trains_at_n32():
