@@ -547,13 +547,15 @@ __global__ void __launch_bounds__(128 * NKS) k_propagate_bwd_h(const PropBwdH p)
         if (stamp) STAMP(13);
         lds_barrier();                                                  // slab `stepno` (and a freshly written Y image) visible; the other slot is free
         if (stamp) STAMP(14);
-        const int q = (stepno + 1) & 1;
-        store_slab(stg[q], q, stg_sc[q]);
+        // (the register set is selected by a uniform BRANCH, not by an index: indexed, the compiler addressed the sets through s_set_gpr_idx moves,
+        // and a move of a register a request is still filling waits for the request — the two-slab prefetch was awaited right behind its issue)
+        if ((stepno + 1) & 1) store_slab(stg[1], 1, stg_sc[1]);
+        else store_slab(stg[0], 0, stg_sc[0]);
         if (stamp) STAMP(15);
     };
     auto step_out = [&]() {                                              // behind the step's products: the request (its issue waits on the CU's memory queue)
-        const int q = (stepno + 1) & 1;
-        request(stg[q], stg_sc[q]);
+        if ((stepno + 1) & 1) request(stg[1], stg_sc[1]);
+        else request(stg[0], stg_sc[0]);
         ++stepno;
     };
 
