@@ -308,3 +308,44 @@ def test_fuzz_wide_state_propagation_vs_oracle():
         for k, (x_, y_) in enumerate(zip(got, ref)):
             chk("wide[%d]" % k, cfg, x_, y_, atol=1e-4 if k == 0 else 1e-5, rel=1e-5 if k == 0 else 1e-4)
     assert not chk.bad, chk.bad[:5]
+
+
+def test_fuzz_wide_state_training_paths_vs_oracle():
+    """Ten random GP-GNN problems with 11 .. 32 nodes (float32, block-structured gather indices): forward and EVERY gradient of the dense
+    route (block adjacency + propagate: backward chain and d A products on the two-term f16 kernels) and of propagate_blocks (no adjacency
+    in either direction) against the float64 oracle.  tools/probe/fuzz_wide_bwd.py is the long form (worst relative error over 24 cases: 1.1e-6)."""
+    import random
+    from recon_amd.propagation import (propagate, propagate_blocks, build_block_adjacency, get_head_indices, get_tail_indices, make_start_embedding)
+    d_ = dev()
+    rng = random.Random(7)
+    chk = _Checker()
+    for case in range(10):
+        n, L, B = rng.randint(11, 32), rng.randint(1, 3), rng.choice([1, 2, 3, 5])
+        act, per_batch, mode = rng.choice(["relu", "tanh", "linear"]), rng.random() < 0.6, ("dense", "blocks")[case % 2]
+        d = 8
+        Cn, S, dd = n * (n - 1), 16 * n, 16
+        g = torch.Generator().manual_seed(977 * case + n)
+        Ts = [torch.relu(torch.randn(B, Cn, dd * dd, generator=g)) * (0.6 / n) for _ in range(L)]
+        ident = torch.eye(dd) + 0.02 * torch.randn(dd, dd, generator=g)
+        tmpl = torch.from_numpy(make_start_embedding(n, d)).float()
+        h0 = (torch.randn(B, Cn, S, 1, generator=g) if per_batch else torch.randn(Cn, S, 1, generator=g)) * tmpl
+        head = torch.from_numpy(get_head_indices(n, d, bs=1)[0])
+        tail = torch.from_numpy(get_tail_indices(n, d, bs=1)[0])
+        Gr = torch.randn(B, Cn, dd * L, generator=g)
+
+        def run(device, dt, fn):
+            Tl = [t.clone().to(device=device, dtype=dt).requires_grad_(True) for t in Ts]
+            I = ident.clone().to(device=device, dtype=dt).requires_grad_(True)
+            h = h0.clone().to(device=device, dtype=dt).requires_grad_(True)
+            out = fn(Tl, I, h, head.to(device), tail.to(device))
+            (out * Gr.to(device=device, dtype=dt)).sum().backward()
+            return [out.detach()] + [t.grad for t in Tl] + [I.grad, h.grad]
+        ref = run("cpu", torch.float64, lambda Tl, I, h, hd, tl: O.propagate([O.build_block_adjacency(t, I, n) for t in Tl], h, act, hd, tl, as_gemm=True))
+        if mode == "dense":
+            got = run(d_, torch.float32, lambda Tl, I, h, hd, tl: propagate([build_block_adjacency(t, I, n) for t in Tl], h, act, hd, tl))
+        else:
+            got = run(d_, torch.float32, lambda Tl, I, h, hd, tl: propagate_blocks(Tl, I, n, h, act, hd, tl))
+        cfg = dict(n=n, L=L, B=B, act=act, per_batch=per_batch, mode=mode)
+        for i, (a, b) in enumerate(zip(got, ref)):
+            chk("tensor %d" % i, cfg, a, b, atol=1e-6, rel=2e-5)
+    assert not chk.bad, chk.bad[:4]
