@@ -771,6 +771,40 @@ __global__ void __launch_bounds__(64 * WM * WN, (MT * NT >= 32 ? 2 : 3) * WM * W
 // ================================================================================================ Y_l of the backward
 // Y[row] = (G[row] + relation gradient of hop `hop`) . act'(H[row]), row = (graph, channel): one wave per row, the row as fp32 in LDS,
 // the 2 dd scatter terms as LDS float atomics (indices are arbitrary).  G == nullptr: the last hop (nothing arrives from above).
+// The FIRST Y of a backward, Y_L = (relation gradient of the last hop) . act'(H^L), for block-structured gather indices: a row is zero except for the dd
+// columns of its head block and of its tail block, so it is written in one pass of 16-byte pieces — zeros, or for the (at most 2 dd / 8) pieces inside a block
+// grad_out[x] h[partner block + x] act'(h[this column]) from three 16-byte loads — instead of being assembled through LDS atomics (1.0 -> 0.3 ms at n = 32)
+__global__ void __launch_bounds__(256) k_prop_b16_y_last(const uint16_t* __restrict__ Hl, const int32_t* __restrict__ hblk, const int32_t* __restrict__ tblk,
+                                                          const uint16_t* __restrict__ gout, uint16_t* __restrict__ Y, int64_t rows, int32_t C, int32_t S,
+                                                          int32_t L, int32_t dd, int32_t hop, int32_t act) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + w;
+    if (row >= rows) return;
+    const int c = static_cast<int>(row % C);
+    const int hb = hblk[c], tb = tblk[c];
+    const uint16_t* h = Hl + row * S;
+    const uint16_t* go = gout + row * (static_cast<int64_t>(L) * dd) + static_cast<int64_t>(hop) * dd;
+    uint16_t* y = Y + row * S;
+    for (int t8 = lane; t8 < (S >> 3); t8 += 64) {
+        const int col = 8 * t8;
+        const bool in_h = col >= hb && col < hb + dd, in_t = col >= tb && col < tb + dd;
+        u32x4 o = u32x4{0u, 0u, 0u, 0u};
+        if (in_h || in_t) {
+            const int x = col - (in_h ? hb : tb);
+            const u32x4 g8 = *reinterpret_cast<const u32x4*>(go + x);
+            const u32x4 p8 = *reinterpret_cast<const u32x4*>(h + (in_h ? tb : hb) + x);
+            const u32x4 m8 = *reinterpret_cast<const u32x4*>(h + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t gw = g8[e], pw = p8[e], mw = m8[e];
+                o[e] = pack_bf2((bf2f(gw & 0xffffu) * bf2f(pw & 0xffffu)) * act_bwd(bf2f(mw & 0xffffu), act),
+                                (bf2f(gw >> 16) * bf2f(pw >> 16)) * act_bwd(bf2f(mw >> 16), act));
+            }
+        }
+        *reinterpret_cast<u32x4*>(y + col) = o;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_prop_b16_ypost(const uint16_t* __restrict__ G, const uint16_t* __restrict__ Hl, const int64_t* __restrict__ head,
                                                          const int64_t* __restrict__ tail, int64_t idx_bs, const uint16_t* __restrict__ gout,
                                                          uint16_t* __restrict__ Y, int64_t rows, int32_t C, int32_t S, int32_t L, int32_t dd, int32_t hop,
@@ -1163,8 +1197,12 @@ extern "C" int recon_propagate_b16_bwd(const recon_prop_b16_bwd_args* ba, recon_
     const size_t plds = 8ull * S * sizeof(float);
     // the fused Y: structured gather indices shared by the batch, dd and L dd multiples of 8 (16-byte pieces of grad_out rows)
     const bool fuse_y = ba->head_blk && ba->tail_blk && a->idx_batch_stride == 0 && (a->dd % 8) == 0 && !(getenv("RECON_PROP_B16_YPOST") && getenv("RECON_PROP_B16_YPOST")[0] == 'k');
-    hipLaunchKernelGGL(k_prop_b16_ypost, pgrid, dim3(256), plds, st, nullptr, hs + (L - 1) * BCS, a->head_idx, a->tail_idx, a->idx_batch_stride, gout, bufY,
-                       rows, C, S, L, a->dd, L - 1, a->act);
+    if (fuse_y)
+        hipLaunchKernelGGL(k_prop_b16_y_last, pgrid, dim3(256), 0, st, hs + (L - 1) * BCS, ba->head_blk, ba->tail_blk, gout, bufY, rows, C, S, L, a->dd, L - 1,
+                           a->act);
+    else
+        hipLaunchKernelGGL(k_prop_b16_ypost, pgrid, dim3(256), plds, st, nullptr, hs + (L - 1) * BCS, a->head_idx, a->tail_idx, a->idx_batch_stride, gout, bufY,
+                           rows, C, S, L, a->dd, L - 1, a->act);
     for (int l = L; l >= 1; --l) {
         const uint16_t* Hprev = l == 1 ? static_cast<const uint16_t*>(a->h0) : hs + (l - 2) * BCS;
         const int64_t hprev_bs = l == 1 ? a->h0_batch_stride : CS;
