@@ -313,7 +313,7 @@ def test_fuzz_wide_state_propagation_vs_oracle():
 def test_fuzz_wide_state_training_paths_vs_oracle():
     """Ten random GP-GNN problems with 11 .. 32 nodes (float32, block-structured gather indices): forward and EVERY gradient of the dense
     route (block adjacency + propagate: backward chain and d A products on the two-term f16 kernels) and of propagate_blocks (no adjacency
-    in either direction) against the float64 oracle.  tools/probe/fuzz_wide_bwd.py is the long form (worst relative error over 24 cases: 1.1e-6)."""
+    in either direction) against the float64 oracle.  (A longer run of the same sweep, 24 cases: worst relative error 1.1e-6.)"""
     import random
     from recon_amd.propagation import (propagate, propagate_blocks, build_block_adjacency, get_head_indices, get_tail_indices, make_start_embedding)
     d_ = dev()
