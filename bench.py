@@ -346,6 +346,20 @@ def main():
             clear_graph_cache()
             result["uncached"] = {"ms_per_step": ms_u, "edges_per_s": E / ms_u * 1e3, "steps": n_x,
                                   "what": "same step with the graph preparation (COO -> CSR + CSC, hub tables) rebuilt from a fresh edge tensor every step"}
+            # the same with edge tensors the producer vouches for (graph.trust: what recon_amd.sampler hands out) — no range check, one host read less per build
+            from recon_amd.graph import trust
+            fresh = [trust(edged.clone(), bound=N) for _ in range(n_x + 3)]
+            it = iter(fresh)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            for _ in range(n_x):
+                step_uncached()
+            torch.cuda.synchronize()
+            ms_t = (time.perf_counter() - tq) / n_x * 1e3
+            clear_graph_cache()
+            result["uncached"]["trusted_edges_ms_per_step"] = ms_t
             # ---- the other BASELINE.json configurations that fit one GPU (SURVEY 8d's cfg 3a / 3b / 5), priced with 8d's own formulas
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
