@@ -410,6 +410,9 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
             for (int r = 0; r < RT; ++r) {
                 const f16x8 ah = __builtin_bit_cast(f16x8, ring[BUF][r][0]), al = __builtin_bit_cast(f16x8, ring[BUF][r][1]);
 #ifndef RECON_HL_NOMFMA
+                // the wave that issues matrix-core work goes first (the other wave of the SIMD is typically waiting for its fragments): -3 % on the forward;
+                // the chain form (heavier epilogue, spills) loses 10 % with it
+                if constexpr (!BWD) { if (r == 0) __builtin_amdgcn_s_setprio(2); }
                 // small terms first; four independent accumulator chains
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], acc[r][j], 0, 0, 0);
@@ -428,6 +431,7 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_propagate_fwd_hl(const PropHL
 #endif
                 __builtin_amdgcn_sched_barrier(0x078f);                 // everything but VMEM may move across: the requests stay where they are written
             }
+            if constexpr (!BWD) __builtin_amdgcn_s_setprio(0);
         }
         rs_cur = rs_next;
 
@@ -712,6 +716,7 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_prop_gadj_hl(const PropGadj q
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
                 const f16x8 ah = __builtin_bit_cast(f16x8, ring[BUF][r][0]), al = __builtin_bit_cast(f16x8, ring[BUF][r][1]);
+                if (r == 0) __builtin_amdgcn_s_setprio(2);              // (as in the forward: -2 %)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], acc[r][j], 0, 0, 0);
 #pragma unroll
@@ -726,6 +731,7 @@ __global__ void __launch_bounds__(64 * kHLWaves) k_prop_gadj_hl(const PropGadj q
                 __builtin_amdgcn_sched_barrier(0x0787);                 // MFMA and VMEM stay on their side: at 255 registers the scheduler otherwise runs each row tile's
                                                                         // accumulator chain depth-first to free the ring early — every fragment is then awaited right behind its request
             }
+            __builtin_amdgcn_s_setprio(0);
         }
     }
     // ---- d A_l[s][t]: C layout — column (lane & 15) = t0 + 16 j + li, rows s = 16 (wave RT + r) + 4 lq + i; 64-byte runs per row
