@@ -35,6 +35,17 @@ constexpr int kPinnedLoad = 0;
 constexpr int kPinnedLoad = static_cast<int>(0x80000000u);
 #endif
 
+// timing experiments are compile-time builds (make EXTRA="-DRECON_BGEMM_ABLATE=2"): a run-time switch in front of a copy or a request costs the
+// product kernels their counted waits.  k_bgemm_b16: 1 copies read the zero page, 2 no copies, 4 no stores; k_prop_b16_fwd_wide: 1 = the A
+// fragments are not fetched
+#ifndef RECON_BGEMM_ABLATE
+#define RECON_BGEMM_ABLATE 0
+#endif
+#ifndef RECON_PROP_B16_ABLATE
+#define RECON_PROP_B16_ABLATE 0
+#endif
+constexpr int kBGemmAblate = RECON_BGEMM_ABLATE, kWideAblate = RECON_PROP_B16_ABLATE;
+
 struct PropB16K {
     const uint16_t* adj[kMaxHops];
     const uint16_t* trans[kMaxHops];
@@ -43,7 +54,6 @@ struct PropB16K {
     const int64_t* head; const int64_t* tail; int64_t idx_bs;
     uint16_t* out; uint16_t* hsave;
     int32_t B, C, S, L, dd, act;
-    int32_t ablate;             // timing experiments only (RECON_PROP_B16_ABL): 1 = the A fragments are not fetched (zeros)
 };
 
 // by-value helper: __builtin_bit_cast applied directly to a vector ELEMENT yields element 0 (prop_h_util.h)
@@ -298,7 +308,7 @@ __global__ void __launch_bounds__(512, 2) k_prop_b16_fwd_wide(const PropB16K p, 
             // (the whole offset in the lane part: the range check looks at the lane offset alone, and R = 0 would make it negative)
             return __builtin_amdgcn_raw_buffer_load_b128(rs, valid ? voff_r[r] + 1024u * ks - (j > R ? 512u : 0u) : kOOB, 0, kPinnedLoad);
         } else {
-            return __builtin_amdgcn_raw_buffer_load_b128(rs, (live && !(p.ablate & 1)) ? voff_r[r] : kOOB, 64 * ks, kPinnedLoad);
+            return __builtin_amdgcn_raw_buffer_load_b128(rs, (live && !(kWideAblate & 1)) ? voff_r[r] : kOOB, 64 * ks, kPinnedLoad);
         }
     };
     u32x4 dpar[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};   // identity rows for row tiles of even / odd node index
@@ -493,7 +503,6 @@ struct BGemmB16 {
     uint16_t* C; int64_t c_bs; int32_t ldc;
     const uint16_t* zeros;
     int32_t M, N, K, batch, tiles_m, tiles_n, act;
-    int32_t ablate;             // timing experiments only (RECON_BGEMM_ABL): 1 copies read the zero page, 2 no copies, 4 no stores
     // PBLK: the P operand is a block adjacency read IN PLACE — P = transition tensors [batch][nodes (nodes - 1)][256], p_ident = identity
     // [256]: element (s, t) = P[e(s >> 4, t >> 4)][s & 15][t & 15], the identity on the diagonal blocks (models/models.py:240-259)
     int32_t p_nodes; const uint16_t* p_ident;
@@ -593,9 +602,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (MT * NT >= 32 ? 2 : 3) * WM * W
                 off = bi == bj ? in_blk : e * 256 + in_blk;
             }
         }
-        const uint16_t* src = (real && k < p.K && !(p.ablate & 1)) ? base + off : zlane;
+        const uint16_t* src = (real && k < p.K && !(kBGemmAblate & 1)) ? base + off : zlane;
         unsigned char* dst = sm + (real ? ib * STAGE + 1024 * pc : SCRATCH);
-        if (!(p.ablate & 2)) __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        // hidden from the compiler's LDS bookkeeping (recon_common.h): through the builtin every copy below was followed by a vmcnt(0) in front
+        // of the next fragment read, and the loop-head barrier by another — the three-stage ring ran as a serial loop
+        if constexpr (!(kBGemmAblate & 2)) dma16_to_lds(src, dst);
     };
     auto issue_advance = [&]() {
         if (++ki == KT) { ki = 0; gi += gstride; Pi += gstride * p.p_bs; Qi += gstride * p.q_bs; }
@@ -623,7 +634,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (MT * NT >= 32 ? 2 : 3) * WM * W
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i) issue();
     int cb = 0;
-    bool stores_pending = false;
 #pragma unroll 1
     for (int g = g0; g < p.batch; g += gstride) {
         f32x4 acc[MT][NT];
@@ -633,8 +643,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (MT * NT >= 32 ? 2 : 3) * WM * W
             for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int ks = 0; ks < KT; ++ks) {
-            if (stores_pending) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stores_pending = false; }
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * ND) : "memory");
+            // the one wait of a step.  It also holds behind a tile's stores: requests of one kind complete in order and the counter counts both,
+            // so "at most (NBUF - 2) ND requests outstanding" leaves at most that many COPIES outstanding — the youngest ones
+            dma_wait<(NBUF - 2) * ND>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             // fragments in the order of their use, the step's copy instructions (for step s + NBUF - 1: into the stage everybody has just
@@ -759,11 +770,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (MT * NT >= 32 ? 2 : 3) * WM * W
                 }
             }
         };
-        if (p.ablate & 4) { asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[MT - 1][NT - 1][3])); }
+        if constexpr (kBGemmAblate & 4) { asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[MT - 1][NT - 1][3])); }
         else if ((EPI == EPI_ACT || EPI == EPI_YPOST) && p.act == RECON_ACT_RELU) store_tile(std::integral_constant<int, RECON_ACT_RELU>{});
         else if ((EPI == EPI_ACT || EPI == EPI_YPOST) && p.act == RECON_ACT_TANH) store_tile(std::integral_constant<int, RECON_ACT_TANH>{});
         else store_tile(std::integral_constant<int, RECON_ACT_LINEAR>{});
-        stores_pending = true;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the dummy copies of the last steps target this workgroup's LDS
 }
@@ -990,7 +1000,6 @@ int launch_bgemm_cfg(BGemmB16 g, hipStream_t st) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     constexpr size_t lds = static_cast<size_t>(NBUF) * ((PK ? 32 * km_slots(BN) * 32 : BN * 64) + (QK ? 32 * km_slots(BM) * 32 : BM * 64)) + 1024;
     g.tiles_m = (g.M + BM - 1) / BM; g.tiles_n = (g.N + BN - 1) / BN;
-    { const char* ab = getenv("RECON_BGEMM_ABL"); g.ablate = ab ? atoi(ab) : 0; }
     const int64_t T = static_cast<int64_t>(g.tiles_m) * g.tiles_n;
     auto kern = k_bgemm_b16<PK, QK, WM, WN, MT, NT, NBUF, EPI, PBLK>;
     static int occ = 0;                                                 // per instantiation
@@ -1078,7 +1087,6 @@ int fwd_wide(const recon_prop_b16_args* a, hipStream_t st) {
     p.out = static_cast<uint16_t*>(a->out); p.hsave = static_cast<uint16_t*>(a->h_saved);
     p.B = a->B; p.C = a->C; p.S = a->S; p.L = a->L; p.dd = a->dd; p.act = a->act;
     const int nks = a->S / 32, nchunk = (a->C + 127) / 128;
-    { const char* ab = getenv("RECON_PROP_B16_ABL"); p.ablate = ab ? atoi(ab) : 0; }
     const size_t lds = static_cast<size_t>(nks) * 128 * 64 + 2 * 5 * 512 * sizeof(uint32_t);
     const int64_t nblk = ceil_div64(a->B, 8) * 8 * nchunk;
     if (nblk >= (1LL << 31)) return RECON_ERR_UNSUPPORTED;

@@ -71,6 +71,24 @@ __device__ __forceinline__ float multi_sum(float (&v)[NV], int lane) {
     }
 }
 
+// ---- global -> LDS copy (16 bytes per lane: LDS[dst + 16 lane] = *src) the compiler does not see -----------------------------
+// Through __builtin_amdgcn_global_load_lds hipcc (ROCm 7.2) knows that an LDS write is in flight and, unable to tell the stages of a ring
+// apart, drains the request counter (s_waitcnt vmcnt(0)) in front of the next ds_read of ANY LDS address: behind the loop-head barrier
+// and behind every copy issued between the MFMA rows of a step — a three-stage ring runs as a serial copy / compute loop (k_bgemm_b16,
+// round 4: four exposed L2 -> LDS latencies per 32 MFMAs).  Issued as inline asm the copy is invisible to that bookkeeping; the waits
+// that order it are the caller's counted `s_waitcnt vmcnt(N)` + s_barrier (dma_wait<N>()).  Unknown requests in flight only make the
+// compiler's own counted waits for ITS loads conservative (requests of a kind return in order), never wrong.  m0 (the LDS base of the
+// instruction) is saved and restored inside the block: the register is reserved, naming it as a clobber is not allowed.
+// `lds_dst` must be wave-uniform.
+__device__ __forceinline__ void dma16_to_lds(const void* src, const void* lds_dst) {
+    const uint32_t a = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)(lds_dst))));
+    uint32_t m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "v"(src), "s"(a) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <int VEC> struct VecT;
 template <> struct VecT<1> { using type = float; };
 template <> struct VecT<2> { using type = float2; };
