@@ -52,6 +52,35 @@ def parse():
     return ap.parse_args()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv=None, script=None):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    bench.py <same arguments>` as a CHILD process (this process has not touched the GPU and never will: a process that has must not be
+    replaced), relay rank 0's JSON line on stdout (everything else the ranks print goes to stderr) and return the child's exit code —
+    non-zero too when the ranks ended without a result line."""
+    import subprocess
+    argv = sys.argv[1:] if argv is None else argv
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), script or os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc != 0 else (0 if line is not None else 1)
+
+
 def algorithmic_bytes_fwd(N, E, H, D):
     """bytes the fused forward edge-aggregation must move (fp32 values, int32 CSR):
     Q [E,HD] once, P_dst and P_src [N,HD] once each, out [N,HD] once, CSR, a_2."""
@@ -61,22 +90,30 @@ def algorithmic_bytes_fwd(N, E, H, D):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))                         # before anything touches the GPU: the ranks are child processes
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)" % args.gpus)
-    ndev = max(1, torch.cuda.device_count())
+        sys.exit("bench.py --gpus %d under WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
+    ndev = max(1, torch.cuda.device_count())                 # counting devices does not initialise the GPU
+    force = os.environ.get("RECON_DIST_FORCE", "0") == "1"   # world size 1 with every collective executed (recon_amd/dist.py)
+    backend = None
+    if world > 1 or force:
+        # "nccl" = RCCL over xGMI.  Fewer GPUs than ranks (a 1-GPU box): RCCL refuses two ranks on one device, so the ranks share the GPU
+        # and talk over gloo — exercises the launcher and the schedule, measures nothing.  RECON_DIST_BACKEND overrides.
+        backend = os.environ.get("RECON_DIST_BACKEND", "nccl" if ndev >= world else "gloo")
     torch.cuda.set_device(local_rank % ndev)                 # one GPU per rank on a real node (ndev >= world)
     dev = torch.device("cuda", local_rank % ndev)
-    if world > 1:
-        # "nccl" = RCCL over xGMI.  RECON_DIST_BACKEND=gloo exists only to exercise this path on a 1-GPU box.
-        backend = os.environ.get("RECON_DIST_BACKEND", "nccl")
+    if backend is not None:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # One process per GPU: the autograd engine's per-device worker threads buy nothing and the hand-over costs ~0.2 ms of host
     # time per backward call — as much as 40 % of this step's GPU time (measured: host enqueue 0.40 -> 0.21 ms/step).
@@ -147,7 +184,7 @@ def main():
     sync = OverlappedWeightGradSync()
     # default: on with RCCL (stream-asynchronous collectives); off with the gloo diagnostic backend, whose device-tensor all-reduce
     # blocks the host at its start (measured with 2 processes on one GPU: 2.42 ms overlapped against 1.99 ms plain)
-    want = os.environ.get("RECON_DP_OVERLAP", "1" if (world > 1 and dist.get_backend() == "nccl") else "0")
+    want = os.environ.get("RECON_DP_OVERLAP", "1" if (backend == "nccl") else "0")
     overlap = sync.active() and want != "0"
 
     def step():
@@ -164,7 +201,7 @@ def main():
             bucket.allreduce_mean()
 
     def barrier_sync():
-        if world > 1:
+        if backend is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -176,7 +213,7 @@ def main():
         step()
     barrier_sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if backend is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -191,7 +228,9 @@ def main():
                    "graphs_per_gpu": B, "nodes_per_graph": n if workload != "cfg5" else "16..256", "edges_per_graph": e if workload != "cfg5" else "min(4096, 16 n)", "F": F_, "R": R,
                    "D_per_head": D, "heads": H, "N_per_gpu": N, "E_per_gpu": E,
                    "parallelism": "dp%d (whole graphs sharded, %s)" % (world, "weight-gradient all-reduce overlapped with the backward's edge chain" if overlap
-                                                                         else "flat grad all-reduce after the backward")},
+                                                                         else "flat grad all-reduce after the backward"),
+                   "backend": ({"nccl": "nccl (RCCL)"}.get(backend, backend) + (", %d ranks on %d GPU(s): schedule exercised, nothing measured" % (world, ndev) if ndev < world else "")
+                               + (", RECON_DIST_FORCE=1: every collective executed at world size 1" if (force and world == 1) else "")) if backend else None},
     }
 
     if rank == 0:
@@ -336,7 +375,7 @@ def main():
                 eed.grad = None
                 model.heads_forward(xd, ed, eed, nohop, nohop).backward(Gd)
             for _ in range(3):
-                step()
+                step_uncached()
             torch.cuda.synchronize()
             tq = time.perf_counter()
             for _ in range(n_x):
@@ -351,7 +390,7 @@ def main():
             fresh = [trust(edged.clone(), bound=N) for _ in range(n_x + 3)]
             it = iter(fresh)
             for _ in range(3):
-                step()
+                step_uncached()
             torch.cuda.synchronize()
             tq = time.perf_counter()
             for _ in range(n_x):
@@ -430,7 +469,7 @@ def main():
             except Exception as exc:                                   # an op of the sequence unsupported by this build
                 result["eager_rocm_baseline"] = {"value": None, "error": repr(exc)[:200]}
         print(json.dumps(result))
-    if world > 1:
+    if backend is not None:
         dist.barrier()
         dist.destroy_process_group()
 

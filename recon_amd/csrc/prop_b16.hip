@@ -634,6 +634,14 @@ __global__ void __launch_bounds__(64 * WM * WN, (MT * NT >= 32 ? 2 : 3) * WM * W
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i) issue();
     int cb = 0;
+    // EPI_YPOST: the head / tail block starts of this lane's MT rows — the tile position is fixed, they are the same for every graph
+    int yp_hb[MT], yp_tb[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + 16 * (wm * MT + i) + li;
+        yp_hb[i] = (EPI == EPI_YPOST && m < p.M) ? p.yp_head[m] : 0;
+        yp_tb[i] = (EPI == EPI_YPOST && m < p.M) ? p.yp_tail[m] : 0;
+    }
 #pragma unroll 1
     for (int g = g0; g < p.batch; g += gstride) {
         f32x4 acc[MT][NT];
@@ -705,32 +713,57 @@ __global__ void __launch_bounds__(64 * WM * WN, (MT * NT >= 32 ? 2 : 3) * WM * W
             };
             const auto rs_h = rsrc_of(EPI == EPI_YPOST ? p.yp_h + g * p.c_bs : p.zeros, EPI == EPI_YPOST ? static_cast<int64_t>(p.M) * p.N : 0);
             const auto rs_g = rsrc_of(EPI == EPI_YPOST ? p.yp_g + g * p.yp_g_bs : p.zeros, EPI == EPI_YPOST ? static_cast<int64_t>(p.M) * p.yp_ldg : 0);
+            // Y = (G + R) . act'(H): H's eight values; the relation term where the columns lie in the channel's head block (partner: the same
+            // offset in its tail block) or tail block (partner in the head block) — out-of-range offsets read zeros.  Requests and arithmetic are
+            // separate steps: the epilogue asks for the operands of a whole batch of column groups before it touches the first (issued group by
+            // group in front of each group's stores, the compiler kept them there — a store may alias a later load — and a tile's epilogue was
+            // sixteen dependent round trips: 1.21 ms for the product that takes 0.71 without this epilogue)
+            struct YpOps { u32x4 h8, g8, p8; };
+            auto yp_load = [&](int m, int hb, int tb, int n) {
+                const bool ok = m < p.M && n < p.N;
+                const bool in_h = ok && n >= hb && n < hb + p.yp_dd, in_t = ok && !in_h && n >= tb && n < tb + p.yp_dd;
+                const int x = n - (in_h ? hb : tb);
+                YpOps o;
+                o.h8 = __builtin_amdgcn_raw_buffer_load_b128(rs_h, ok ? static_cast<uint32_t>(m * p.N + n) * 2u : kOOB, 0, 0);
+                o.g8 = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (in_h || in_t) ? static_cast<uint32_t>(m * p.yp_ldg + x) * 2u : kOOB, 0, 0);
+                o.p8 = __builtin_amdgcn_raw_buffer_load_b128(rs_h, (in_h || in_t) ? static_cast<uint32_t>(m * p.N + (in_h ? tb : hb) + x) * 2u : kOOB, 0, 0);
+                return o;
+            };
+            auto yp_apply = [&](float (&v)[8], const YpOps& o) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t hw = o.h8[e], gw = o.g8[e], pw = o.p8[e];
+                    const float h0 = bf2f(hw & 0xffffu), h1 = bf2f(hw >> 16);
+                    const float y0 = v[2 * e] + bf2f(gw & 0xffffu) * bf2f(pw & 0xffffu), y1 = v[2 * e + 1] + bf2f(gw >> 16) * bf2f(pw >> 16);
+                    v[2 * e] = y0 * (A == RECON_ACT_RELU ? (h0 > 0.f ? 1.f : 0.f) : (A == RECON_ACT_TANH ? 1.f - h0 * h0 : 1.f));
+                    v[2 * e + 1] = y1 * (A == RECON_ACT_RELU ? (h1 > 0.f ? 1.f : 0.f) : (A == RECON_ACT_TANH ? 1.f - h1 * h1 : 1.f));
+                }
+            };
             auto finish8 = [&](int m, int n, float (&v)[8]) {
                 if constexpr (EPI == EPI_ACT) {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] = A == RECON_ACT_RELU ? fmaxf(v[r], 0.f) : (A == RECON_ACT_TANH ? tanh_fast(v[r]) : v[r]);
                 } else if constexpr (EPI == EPI_YPOST) {
-                    // Y = (G + R) . act'(H): H's eight values; the relation term where the columns lie in the channel's head block (partner:
-                    // the same offset in its tail block) or tail block (partner in the head block) — out-of-range offsets read zeros
                     const bool ok = m < p.M && n < p.N;
-                    const int hb = ok ? p.yp_head[m] : 0, tb = ok ? p.yp_tail[m] : 0;
-                    const bool in_h = ok && n >= hb && n < hb + p.yp_dd, in_t = ok && !in_h && n >= tb && n < tb + p.yp_dd;
-                    const int x = n - (in_h ? hb : tb);
-                    const u32x4 h8 = __builtin_amdgcn_raw_buffer_load_b128(rs_h, ok ? static_cast<uint32_t>(m * p.N + n) * 2u : kOOB, 0, 0);
-                    const u32x4 g8 = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (in_h || in_t) ? static_cast<uint32_t>(m * p.yp_ldg + x) * 2u : kOOB, 0, 0);
-                    const u32x4 p8 = __builtin_amdgcn_raw_buffer_load_b128(rs_h, (in_h || in_t) ? static_cast<uint32_t>(m * p.N + (in_h ? tb : hb) + x) * 2u : kOOB, 0, 0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const uint32_t hw = h8[e], gw = g8[e], pw = p8[e];
-                        const float h0 = bf2f(hw & 0xffffu), h1 = bf2f(hw >> 16);
-                        const float y0 = v[2 * e] + bf2f(gw & 0xffffu) * bf2f(pw & 0xffffu), y1 = v[2 * e + 1] + bf2f(gw >> 16) * bf2f(pw >> 16);
-                        v[2 * e] = y0 * (A == RECON_ACT_RELU ? (h0 > 0.f ? 1.f : 0.f) : (A == RECON_ACT_TANH ? 1.f - h0 * h0 : 1.f));
-                        v[2 * e + 1] = y1 * (A == RECON_ACT_RELU ? (h1 > 0.f ? 1.f : 0.f) : (A == RECON_ACT_TANH ? 1.f - h1 * h1 : 1.f));
-                    }
+                    yp_apply(v, yp_load(m, ok ? p.yp_head[m] : 0, ok ? p.yp_tail[m] : 0, n));
                 }
             };
+            constexpr int NG = NT / 2;                                  // paired column groups per row of tiles
+            constexpr int RB = EPI == EPI_YPOST ? (MT % 2 == 0 ? 2 : 1) : 1;                          // rows of tiles per batch of requests (4: the 256 x 256 tile spills)
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
+            for (int i0 = 0; i0 < MT; i0 += RB) {
+                YpOps ops[RB][NG > 0 ? NG : 1];
+                if constexpr (EPI == EPI_YPOST) {
+#pragma unroll
+                    for (int ii = 0; ii < RB; ++ii) {
+                        const int m = m0 + 16 * (wm * MT + i0 + ii) + li;
+#pragma unroll
+                        for (int jj = 0; jj < NG; ++jj)
+                            ops[ii][jj] = yp_load(m, yp_hb[i0 + ii], yp_tb[i0 + ii], n0 + 16 * (wn * NT + 2 * jj + (lq & 1)) + 8 * (lq >> 1));
+                    }
+                }
+#pragma unroll
+            for (int i = i0; i < i0 + RB; ++i) {
                 const int m = m0 + 16 * (wm * MT + i) + li;
 #pragma unroll
                 for (int j = 0; j + 1 < NT; j += 2) {
@@ -741,7 +774,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (MT * NT >= 32 ? 2 : 3) * WM * W
                         v[r] = as_f(x[0]); v[4 + r] = as_f(x[1]);
                     }
                     const int n = n0 + 16 * (wn * NT + j + (lq & 1)) + 8 * (lq >> 1);
-                    finish8(m, n, v);
+                    if constexpr (EPI == EPI_YPOST) yp_apply(v, ops[i - i0][j / 2]);
+                    else finish8(m, n, v);
                     put8(m, n, v);
                 }
                 if constexpr (NT & 1) {                                 // the unpaired tile: the same through a half-filled group (four columns)
@@ -769,6 +803,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MT * NT >= 32 ? 2 : 3) * WM * W
                     }
                 }
             }
+            }
         };
         if constexpr (kBGemmAblate & 4) { asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[MT - 1][NT - 1][3])); }
         else if ((EPI == EPI_ACT || EPI == EPI_YPOST) && p.act == RECON_ACT_RELU) store_tile(std::integral_constant<int, RECON_ACT_RELU>{});
@@ -784,34 +819,52 @@ __global__ void __launch_bounds__(64 * WM * WN, (MT * NT >= 32 ? 2 : 3) * WM * W
 // The FIRST Y of a backward, Y_L = (relation gradient of the last hop) . act'(H^L), for block-structured gather indices: a row is zero except for the dd
 // columns of its head block and of its tail block, so it is written in one pass of 16-byte pieces — zeros, or for the (at most 2 dd / 8) pieces inside a block
 // grad_out[x] h[partner block + x] act'(h[this column]) from three 16-byte loads — instead of being assembled through LDS atomics (1.0 -> 0.3 ms at n = 32)
+// A wave writes kYLastRows consecutive rows: with one row per wave (1 M rows at n = 32 = 254 k workgroups of a few hundred cycles each) the launch ran at the
+// dispatcher's pace, 2.3 TB/s of zeros
+constexpr int kYLastRows = 8;
 __global__ void __launch_bounds__(256) k_prop_b16_y_last(const uint16_t* __restrict__ Hl, const int32_t* __restrict__ hblk, const int32_t* __restrict__ tblk,
                                                           const uint16_t* __restrict__ gout, uint16_t* __restrict__ Y, int64_t rows, int32_t C, int32_t S,
                                                           int32_t L, int32_t dd, int32_t hop, int32_t act) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + w;
-    if (row >= rows) return;
-    const int c = static_cast<int>(row % C);
-    const int hb = hblk[c], tb = tblk[c];
-    const uint16_t* h = Hl + row * S;
-    const uint16_t* go = gout + row * (static_cast<int64_t>(L) * dd) + static_cast<int64_t>(hop) * dd;
-    uint16_t* y = Y + row * S;
+    const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * 4 + w) * kYLastRows;
+    if (row0 >= rows) return;
+    // the block starts of the wave's rows with ONE request (lane r: row r), then every row's operands before the first store: as a loop over rows
+    // each row cost two dependent round trips (block starts -> operands -> store)
+    const int64_t myrow = row0 + (lane & (kYLastRows - 1));
+    const int myc = static_cast<int>((myrow < rows ? myrow : row0) % C);
+    const int hb_l = hblk[myc], tb_l = tblk[myc];
+    // broadcast HERE, with every lane active: read inside the column loop (where only S / 8 lanes are), the compiler sinks the two loads into
+    // that region too and the lanes that hold rows 4 .. 7 never execute them (S = 32: wrong block starts, caught by the n = 2 oracle test)
+    int hbs[kYLastRows], tbs[kYLastRows];
+#pragma unroll
+    for (int rr = 0; rr < kYLastRows; ++rr) { hbs[rr] = __builtin_amdgcn_readlane(hb_l, rr); tbs[rr] = __builtin_amdgcn_readlane(tb_l, rr); }
     for (int t8 = lane; t8 < (S >> 3); t8 += 64) {
         const int col = 8 * t8;
-        const bool in_h = col >= hb && col < hb + dd, in_t = col >= tb && col < tb + dd;
-        u32x4 o = u32x4{0u, 0u, 0u, 0u};
-        if (in_h || in_t) {
-            const int x = col - (in_h ? hb : tb);
-            const u32x4 g8 = *reinterpret_cast<const u32x4*>(go + x);
-            const u32x4 p8 = *reinterpret_cast<const u32x4*>(h + (in_h ? tb : hb) + x);
-            const u32x4 m8 = *reinterpret_cast<const u32x4*>(h + col);
+        u32x4 o[kYLastRows];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t gw = g8[e], pw = p8[e], mw = m8[e];
-                o[e] = pack_bf2((bf2f(gw & 0xffffu) * bf2f(pw & 0xffffu)) * act_bwd(bf2f(mw & 0xffffu), act),
-                                (bf2f(gw >> 16) * bf2f(pw >> 16)) * act_bwd(bf2f(mw >> 16), act));
+        for (int rr = 0; rr < kYLastRows; ++rr) {
+            const int64_t row = row0 + rr;
+            const int hb = hbs[rr], tb = tbs[rr];
+            const bool in_h = col >= hb && col < hb + dd, in_t = col >= tb && col < tb + dd;
+            o[rr] = u32x4{0u, 0u, 0u, 0u};
+            if ((in_h || in_t) && row < rows) {
+                const uint16_t* h = Hl + row * S;
+                const uint16_t* go = gout + row * (static_cast<int64_t>(L) * dd) + static_cast<int64_t>(hop) * dd;
+                const int x = col - (in_h ? hb : tb);
+                const u32x4 g8 = *reinterpret_cast<const u32x4*>(go + x);
+                const u32x4 p8 = *reinterpret_cast<const u32x4*>(h + (in_h ? tb : hb) + x);
+                const u32x4 m8 = *reinterpret_cast<const u32x4*>(h + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t gw = g8[e], pw = p8[e], mw = m8[e];
+                    o[rr][e] = pack_bf2((bf2f(gw & 0xffffu) * bf2f(pw & 0xffffu)) * act_bwd(bf2f(mw & 0xffffu), act),
+                                        (bf2f(gw >> 16) * bf2f(pw >> 16)) * act_bwd(bf2f(mw >> 16), act));
+                }
             }
         }
-        *reinterpret_cast<u32x4*>(y + col) = o;
+#pragma unroll
+        for (int rr = 0; rr < kYLastRows; ++rr)
+            if (row0 + rr < rows) *reinterpret_cast<u32x4*>(Y + (row0 + rr) * S + col) = o[rr];
     }
 }
 
@@ -1002,7 +1055,10 @@ int launch_bgemm_cfg(BGemmB16 g, hipStream_t st) {
     g.tiles_m = (g.M + BM - 1) / BM; g.tiles_n = (g.N + BN - 1) / BN;
     const int64_t T = static_cast<int64_t>(g.tiles_m) * g.tiles_n;
     auto kern = k_bgemm_b16<PK, QK, WM, WN, MT, NT, NBUF, EPI, PBLK>;
-    static int occ = 0;                                                 // per instantiation
+    static int occ_dev[16] = {};                                        // per instantiation and device (the attribute is per device too)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& occ = occ_dev[dev & 15];
     if (occ == 0) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * WM * WN, lds) != hipSuccess || occ < 1) occ = 1;
@@ -1029,6 +1085,7 @@ int launch_bgemm(const BGemmB16& g, hipStream_t st) {
     if (g.M <= 144 && g.N <= 144) return launch_bgemm_cfg<PK, QK, EPI, PBLK, 3, 3, 3, 3, 3>(g, st);
     const char* cfg = getenv("RECON_BGEMM_CFG");
     if (cfg && cfg[0] == 'a') return launch_bgemm_cfg<PK, QK, EPI, PBLK, 2, 2, 4, 4, 3>(g, st);
+    if (cfg && cfg[0] == 'h') return launch_bgemm_cfg<PK, QK, EPI, PBLK, 1, 4, 8, 4, 3>(g, st);
     return launch_bgemm_cfg<PK, QK, EPI, PBLK, 2, 4, 8, 4, 3>(g, st);
 }
 
@@ -1202,11 +1259,12 @@ extern "C" int recon_propagate_b16_bwd(const recon_prop_b16_bwd_args* ba, recon_
     uint16_t* bufY = static_cast<uint16_t*>((L & 1) ? ba->ws : ba->g_h);
     uint16_t* bufG = static_cast<uint16_t*>((L & 1) ? ba->g_h : ba->ws);
     const dim3 pgrid(static_cast<unsigned>(ceil_div64(rows, 4)));
+    const dim3 ylgrid(static_cast<unsigned>(ceil_div64(rows, 4 * kYLastRows)));
     const size_t plds = 8ull * S * sizeof(float);
     // the fused Y: structured gather indices shared by the batch, dd and L dd multiples of 8 (16-byte pieces of grad_out rows)
     const bool fuse_y = ba->head_blk && ba->tail_blk && a->idx_batch_stride == 0 && (a->dd % 8) == 0 && !(getenv("RECON_PROP_B16_YPOST") && getenv("RECON_PROP_B16_YPOST")[0] == 'k');
     if (fuse_y)
-        hipLaunchKernelGGL(k_prop_b16_y_last, pgrid, dim3(256), 0, st, hs + (L - 1) * BCS, ba->head_blk, ba->tail_blk, gout, bufY, rows, C, S, L, a->dd, L - 1,
+        hipLaunchKernelGGL(k_prop_b16_y_last, ylgrid, dim3(256), 0, st, hs + (L - 1) * BCS, ba->head_blk, ba->tail_blk, gout, bufY, rows, C, S, L, a->dd, L - 1,
                            a->act);
     else
         hipLaunchKernelGGL(k_prop_b16_ypost, pgrid, dim3(256), plds, st, nullptr, hs + (L - 1) * BCS, a->head_idx, a->tail_idx, a->idx_batch_stride, gout, bufY,

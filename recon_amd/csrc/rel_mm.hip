@@ -117,6 +117,10 @@ extern "C" int recon_rel_rows_mm(const float* x, const int32_t* order, const int
     const dim3 grid(static_cast<unsigned>((T + recon::kRows - 1) / recon::kRows));
     const size_t lds = sizeof(float) * recon::kRows * in_dim;
     hipStream_t st = as_stream(stream);
+    if (lds > 48 * 1024) {                                               // in_dim > 768: above the default dynamic-LDS limit
+        const void* kern = transpose_w ? reinterpret_cast<const void*>(recon::k_rel_rows_mm<true>) : reinterpret_cast<const void*>(recon::k_rel_rows_mm<false>);
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return RECON_ERR_LAUNCH;
+    }
     if (transpose_w) hipLaunchKernelGGL(recon::k_rel_rows_mm<true>, grid, dim3(256), lds, st, x, order, rel, W, T, in_dim, out_dim, out);
     else hipLaunchKernelGGL(recon::k_rel_rows_mm<false>, grid, dim3(256), lds, st, x, order, rel, W, T, in_dim, out_dim, out);
     return hipGetLastError() == hipSuccess ? RECON_OK : RECON_ERR_LAUNCH;

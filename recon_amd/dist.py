@@ -2,8 +2,19 @@
 across ranks (no edge crosses graphs, so any partition of whole graphs is exact and needs no
 data-path collective), parameter gradients summed with ONE all-reduce over a flat fp32 bucket
 (torch.distributed backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests)."""
+import os
+
 import torch
 import torch.distributed as dist
+
+# RECON_DIST_FORCE=1: run every collective even at world size 1 (with a process group initialised) — the way to execute the RCCL calls of
+# the data-parallel schedule (init with device_id, ReduceOp.AVG and its fallback, asynchronous handles under the backward, the bucket's
+# per-region all-reduces) on a box with one GPU.  The results are unchanged (a mean over one rank).
+FORCE_COLLECTIVES = os.environ.get("RECON_DIST_FORCE", "0") == "1"
+
+
+def _collectives_on(group):
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVES)
 
 
 def shard_range(num_graphs, rank, world):
@@ -97,17 +108,27 @@ class FlatGradBucket:
         then runs over the remaining contiguous pieces of the flat buffer (one all-reduce per piece; the same pieces on every rank, since
         the parameters and the layers that reduce in-backward are the same).  Everything else in the bucket (W, W_entities, embeddings ...)
         is averaged here: a bucket over a whole model needs this call, pack() alone averages nothing."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if not _collectives_on(self.group):
             self.pack()
             return None
         w = dist.get_world_size(self.group)
         done = set()
         if skip:
+            # a parameter's gradient counts as averaged when it IS one of the marked tensors or lies inside one: the heads' backward marks
+            # the fused [H, D, W] / [H, D] gradients, autograd hands each head its unbind() / split() view of them
             ids = {id(t) for t in skip}
-            ptrs = {(t.data_ptr(), t.numel()) for t in skip}
+            spans = [(t.untyped_storage().data_ptr(), t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in skip if t.is_contiguous()]
             for i, p in enumerate(self.params):
                 g = p.grad
-                if g is not None and (id(g) in ids or (g.data_ptr(), g.numel()) in ptrs):
+                if g is None:
+                    continue
+                if id(g) in ids:
+                    done.add(i)
+                    continue
+                if not g.is_contiguous():
+                    continue
+                st, lo, hi = g.untyped_storage().data_ptr(), g.data_ptr(), g.data_ptr() + g.numel() * g.element_size()
+                if any(st == s0 and lo >= a0 and hi <= a1 for s0, a0, a1 in spans):
                     done.add(i)
         self.pack()
         if not done:
@@ -163,7 +184,7 @@ class OverlappedWeightGradSync:
         self._avg_ok = True
 
     def active(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return _collectives_on(self.group)
 
     def all_reduce_mean(self, t, async_op=False):
         if not self.active():

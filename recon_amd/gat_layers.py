@@ -36,22 +36,44 @@ _WEIGHT_GRAD_SYNC = None
 _GRAD_DEST = {}             # data_ptr of a fused [H, D, W] weight -> (g_a, g_a_2) tensors the heads' backward writes its weight gradients into
 
 
-def set_weight_grad_destination(a, g_a, g_a_2):
+class _GradDest:
+    """Where one fused weight's gradients may be written, and whether a backward has done so since the owner last released it."""
+    __slots__ = ("g_a", "g_a_2", "claimed")
+
+    def __init__(self, g_a, g_a_2):
+        self.g_a, self.g_a_2, self.claimed = g_a, g_a_2, False
+
+
+def set_weight_grad_destination(a, g_a, g_a_2, release=True):
     """Have the backward of gat_heads(..., a, ...) write the gradients of `a` [H, D, W] / `a_2` [H, D] into the given tensors (e.g. a
-    data-parallel gradient bucket's own storage: dist.FlatGradBucket.region) instead of fresh ones; None removes the entry."""
+    data-parallel gradient bucket's own storage: dist.FlatGradBucket.region) instead of fresh ones; None removes the entry.
+
+    The destination is handed out ONCE per release: the first backward that asks for it claims it, every later one (a second forward
+    before any backward — loss(batch1) + loss(batch2), positive / negative passes, a checkpoint re-forward — or gradient accumulation
+    over several steps) gets fresh tensors, so that "old + new" never reads the new values on both sides.  The owner releases the claim
+    (`release=True`) when it knows that nothing live views the storage any more: SpGAT.fused_head_params does so in a forward that finds
+    every parameter's .grad None; `release=False` re-registers the same tensors without touching the claim."""
     if g_a is None:
         _GRAD_DEST.pop(a.data_ptr(), None)
-    else:
-        if len(_GRAD_DEST) >= 64:
-            _GRAD_DEST.clear()
-        _GRAD_DEST[a.data_ptr()] = (g_a, g_a_2)
+        return
+    d = _GRAD_DEST.get(a.data_ptr())
+    if d is not None and d.g_a is g_a and d.g_a_2 is g_a_2:
+        if release:
+            d.claimed = False
+        return
+    if len(_GRAD_DEST) >= 64:
+        _GRAD_DEST.clear()
+    d = _GRAD_DEST[a.data_ptr()] = _GradDest(g_a, g_a_2)
+    d.claimed = not release
 
 
 def _weight_grad_tensors(a, H, D, W, f32):
-    dest = _GRAD_DEST.get(a.data_ptr())
-    if dest is not None and dest[0].shape == (H, D, W) and dest[1].shape == (H, D) and dest[0].device == a.device \
-            and dest[0].is_contiguous() and dest[1].is_contiguous():
-        return dest
+    """Decided at BACKWARD time: the registered destination if nobody has claimed it since its release, else fresh tensors."""
+    d = _GRAD_DEST.get(a.data_ptr())
+    if d is not None and not d.claimed and d.g_a.shape == (H, D, W) and d.g_a_2.shape == (H, D) and d.g_a.device == a.device \
+            and d.g_a.is_contiguous() and d.g_a_2.is_contiguous():
+        d.claimed = True
+        return d.g_a, d.g_a_2
     return torch.empty(H, D, W, **f32), torch.empty(H, D, **f32)
 
 

@@ -67,10 +67,12 @@ class SpGAT(nn.Module):
                 ra, ra2 = bucket.region([att.a for att in atts]), bucket.region([att.a_2 for att in atts])
                 ok = ra is not None and ra2 is not None and ra.device == A.device
                 bound = self._head_grad_bound = (A.data_ptr(), (ra.view_as(A), ra2.view_as(A2)) if ok else None)
-            # only when this backward's gradients will be ASSIGNED: a parameter that still holds a gradient (accumulation over several
-            # backward calls) may hold a view of the very same storage, and "old + new" must not read the new values on both sides
-            if bound[1] is not None and all(p.grad is None for p in params):
-                set_weight_grad_destination(A, *bound[1])
+            # The destination is claimed by the FIRST backward that runs after a release (gat_layers._weight_grad_tensors decides there, not
+            # here: two forwards before one backward both see .grad None).  It is released only by a forward that finds every gradient
+            # None — nothing live views the bucket region then; with gradients still in place (accumulation) the claim stands and the
+            # next backward returns fresh tensors for autograd to add.
+            if bound[1] is not None:
+                set_weight_grad_destination(A, *bound[1], release=all(p.grad is None for p in params))
             else:
                 set_weight_grad_destination(A, None, None)
         return _AliasHeadParams.apply(A, A2, *params)

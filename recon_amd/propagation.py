@@ -348,6 +348,8 @@ class _PropagateB16(torch.autograd.Function):
         B, Cn, S, L, dd, act, h0_bs, idx_bs, h0_shape, adj_shapes = ctx.meta
         dev = gout.device
         gout = gout.contiguous()
+        if gout.data_ptr() % 16:                 # a contiguous view at an odd storage offset: the kernels read grad_out in 16-byte pieces
+            gout = gout.clone()
         g_adjs = [torch.empty(B, S, S, dtype=torch.bfloat16, device=dev) if ctx.needs_input_grad[4 + l] else None for l in range(L)]
         g_h = torch.empty(B, Cn, S, dtype=torch.bfloat16, device=dev)
         ws = torch.empty(B, Cn, S, dtype=torch.bfloat16, device=dev)
@@ -556,6 +558,8 @@ class _PropagateBlocksB16(torch.autograd.Function):
         B, Cn, S, L, dd, act, h0_bs, idx_bs, h0_shape, t_shapes = ctx.meta
         dev = gout.device
         gout = gout.contiguous()
+        if gout.data_ptr() % 16:
+            gout = gout.clone()
         bf = dict(dtype=torch.bfloat16, device=dev)
         g_Ts = [torch.empty(B, Cn, dd * dd, **bf) if ctx.needs_input_grad[6 + l] else None for l in range(L)]
         g_I = torch.empty(dd, dd, **bf) if ctx.needs_input_grad[1] else None

@@ -1172,3 +1172,17 @@ def test_head_gradients_written_into_the_bucket():
     bound.heads_forward(xd, ed, eed, nohop, nohop).backward(G)
     for p, g1 in zip(bound.head_parameters(), first):
         close(p.grad, 2 * g1, atol=1e-6, rel_to_max=1e-6, what="accumulated head gradient")
+    # two forwards before one backward (loss(batch 1) + loss(batch 2), positive / negative passes, a checkpoint re-forward): both forwards see
+    # .grad None, both backwards run inside ONE autograd pass — only the first may take the bucket region, the other must add to it
+    x2 = (xd * 0.5 + 0.25).contiguous()
+    grads = {}
+    for name, model, bucket in (("plain", plain, pb), ("bound", bound, bb)):
+        bucket.zero()
+        o1 = model.heads_forward(xd, ed, eed, nohop, nohop)
+        o2 = model.heads_forward(x2, ed, eed, nohop, nohop)
+        ((o1 * G).sum() + (o2 * G).sum()).backward()
+        grads[name] = [p.grad.clone() for p in (model.head_parameters() if name == "bound" else [p for att in model.attentions for p in (att.a, att.a_2)])]
+    ref = {id(p): g for p, g in zip([p for att in plain.attentions for p in (att.a, att.a_2)], grads["plain"])}
+    for att_p, att_b in zip(plain.attentions, bound.attentions):
+        for pp, pbnd in ((att_p.a, att_b.a), (att_p.a_2, att_b.a_2)):
+            close(pbnd.grad, ref[id(pp)], atol=1e-6, rel_to_max=1e-6, what="head gradient of two forwards under one backward")
