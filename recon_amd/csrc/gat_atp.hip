@@ -184,10 +184,17 @@ __global__ void __launch_bounds__(256) k_atp_weights_finish(const float* __restr
 __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy, int32_t ld_gy, const float* __restrict__ y,
                                                     int32_t ld_y, int32_t N, int32_t H, int32_t D, int32_t concat,
                                                     float* __restrict__ gh, float* __restrict__ q, uint16_t* __restrict__ ghp,
-                                                    int64_t ld_p, int64_t plane_p, int32_t f16x2, const Hx2Scale gsc) {
+                                                    int64_t ld_p, int64_t plane_p, int32_t f16x2, const Hx2Scale gsc,
+                                                    float* __restrict__ row_inv, int64_t row_inv_ld, uint32_t* __restrict__ amax_q) {
     // ghp (optional): term planes of g_h for the split-precision GEMMs — three bfloat16 planes [3][N][ld_p], or (f16x2) the
-    // half terms of s_g * g_h, head-major [H][N][2][D] (ld_p = 2 D, plane_p = D), s_g from the published max |grad_out|
-    // (|elu'| <= 1, so it bounds |g_h|)
+    // half terms of s * g_h, head-major [H][N][2][D] (ld_p = 2 D, plane_p = D).  The scale s:
+    //   row_inv == nullptr   one per tensor, from the published max |grad_out| (|elu'| <= 1, so it bounds |g_h|): a pass over grad_out
+    //                        (k_hx2_amax, 52 MB at cfg 2) has to run first;
+    //   row_inv              (D <= 256) ONE PER ROW (node, head), a power of two from the row's own maximum, found in the wave that holds
+    //                        the row: no pass in front.  1 / s goes to row_inv[h][node] (row stride row_inv_ld, padded with ones to a
+    //                        multiple of 8 nodes), the tensor's maximum to amax_q on the way.  The consumers: g_V = g_h a has the rows on its
+    //                        M index (the epilogue multiplies row-wise), g_a^T = V^T g_h contracts over them (the product multiplies V's
+    //                        fragments by s_tensor / s_row, gemm_hx2.hip).
     constexpr int IPW = 4;                                               // (node, head) rows per wave, loads batched
     const int lane = threadIdx.x & 63;
     const int item0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * IPW;      // N*H < 2^31 (checked by the host)
@@ -209,20 +216,47 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
             g4[j] = *reinterpret_cast<const float4*>(gy + static_cast<int64_t>(node) * ld_gy + h * D + cc);
             y4[j] = *reinterpret_cast<const float4*>(y + static_cast<int64_t>(node) * ld_y + h * D + cc);
         }
-        const float gs = f16x2 ? hx2_scale_wave(gsc) : 1.f;
+        const float gs_t = (f16x2 && !row_inv) ? hx2_scale_wave(gsc) : 1.f;
+        float ov[IPW][4], pv[IPW], rmx[IPW];
 #pragma unroll
         for (int j = 0; j < IPW; ++j) {
-            const int it = item0 + j;
             const float gv[4] = {g4[j].x, g4[j].y, g4[j].z, g4[j].w}, yv[4] = {y4[j].x, y4[j].y, y4[j].z, y4[j].w};
-            float o[4], part = 0.f;
+            float part = 0.f, mx = 0.f;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 float g = gv[v], hv = yv[v];
                 if (concat && yv[v] <= 0.f) { const float e = yv[v] + 1.f; g = gv[v] * e; hv = e > 0.f ? __logf(e) : 0.f; }   // h = log(y+1); its error is multiplied by exp(h) <= 1
-                o[v] = g;
+                ov[j][v] = g;
                 part = fmaf(g, hv, part);
+                mx = fmaxf(mx, fabsf(g));
             }
-            const float tot = group_sum<64>(cok ? part : 0.f);
+            pv[j] = cok ? part : 0.f;
+            rmx[j] = cok ? mx : 0.f;
+        }
+        float gs_row[IPW], wave_amax = 0.f;
+        static_assert(IPW == 4, "row reductions below");
+        // the IPW row sums q with 3 permutes + DPP steps (multi_sum: row j's total lands in lanes [16 j, 16 j + 16)) instead of IPW full butterflies
+        const float tot_l = multi_sum<4>(pv, lane);
+        if (row_inv) {
+            const float m = multi_max4(rmx, lane);                      // row j's maximum in lanes [16 j, 16 j + 16)
+            float all = 0.f;
+#pragma unroll
+            for (int j = 0; j < IPW; ++j) {
+                const float rm = lane_bcast(m, 16 * j);
+                gs_row[j] = hx2_scale_of(rm);
+                if (item0 + j < total) all = fmaxf(all, rm);
+            }
+            wave_amax = all;
+        } else {
+#pragma unroll
+            for (int j = 0; j < IPW; ++j) gs_row[j] = gs_t;
+        }
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) {
+            const int it = item0 + j;
+            const float gs = gs_row[j];
+            const float (&o)[4] = ov[j];
+            const float tot = lane_bcast(tot_l, 16 * j);
             if (it < total) {
                 if (gh && c < D) *reinterpret_cast<float4*>(gh + static_cast<int64_t>(it) * D + c) = make_float4(o[0], o[1], o[2], o[3]);
                 if (ghp && c < D) {
@@ -250,9 +284,17 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
                         *reinterpret_cast<uint2*>(dst + pq * plane_p) = make_uint2(w[0], w[1]);
                     }
                 }
-                if (lane == 0) q[it] = tot;
+                if (lane == 0) {
+                    q[it] = tot;
+                    if (row_inv) row_inv[static_cast<int64_t>(it % H) * row_inv_ld + it / H] = hx2_inv(gs);
+                }
+                if (row_inv && it / H == N - 1 && lane >= 1 && lane <= ((8 - (N & 7)) & 7))      // the table's padding rows: scale 1
+                    row_inv[static_cast<int64_t>(it % H) * row_inv_ld + N - 1 + lane] = 1.f;
             }
         }
+        // the tensor's maximum goes out LAST: the commit reads its slot first (a device-scope round trip), and in front of the stores it held
+        // every wave's stores back by that trip
+        if (row_inv && amax_q) hx2_amax_commit_uniform(wave_amax, amax_q);
         return;
     }
     const float gs = f16x2 ? hx2_scale_wave(gsc) : 1.f;
@@ -1706,8 +1748,16 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
     const bool gh_planes = hx2 || (b->gh_split && a->a_split && !(reinterpret_cast<uintptr_t>(b->gh_split) & 15) && (D % 8) == 0 &&
                                    ((b->ld_gout | a->ld_out) & 3) == 0);
     uint16_t* ghp = gh_planes ? static_cast<uint16_t*>(b->gh_split) : nullptr;
+    // f16 x 2 with heads of at most 256 columns: the planes of g_h carry PER-ROW scales (k_elu_grad_q finds a row's maximum in the wave that
+    // holds the row), so no pass over grad_out for a tensor-wide maximum runs in front (k_hx2_amax: 52 MB, 14 us + a launch at cfg 2).  The
+    // inverse scales [H][ldi] live behind the two planes, in the room of the third plane that only the bf16 x 3 family uses.
+    const int64_t ldi = (static_cast<int64_t>(N) + 7) / 8 * 8;
+    const size_t inv_off = align_up(static_cast<size_t>(2) * N * bx3_kp(static_cast<int32_t>(HD)) * 2, 256);
+    const bool row_scaled = hx2 && D <= 256 && ((a->ld_out | b->ld_gout) & 3) == 0 &&
+                            inv_off + static_cast<size_t>(H) * ldi * sizeof(float) <= recon_gat_atp_bwd_split_bytes(N, D, H);
+    float* row_inv = row_scaled ? reinterpret_cast<float*>(static_cast<char*>(b->gh_split) + inv_off) : nullptr;
     if (phases & RECON_ATP_BWD_PREPARE) {
-        if (hx2) {                                                // max |grad_out| bounds |g_h| (|elu'| <= 1): the scale of the g_h planes
+        if (hx2 && !row_scaled) {                                 // max |grad_out| bounds |g_h| (|elu'| <= 1): the scale of the g_h planes
             // quantity 3 is zero here: the scores stage cleared all of aux, and a backward pass clears it again when it is done with it
             // (k_score_vec_bwd) — a fill of its own cost 5 us per step
             rc = hx2_amax(b->grad_out, N, static_cast<int32_t>(HD), b->ld_gout, atp_q(a, 3), st);
@@ -1716,7 +1766,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         hipLaunchKernelGGL(k_elu_grad_q, dim3(static_cast<unsigned>(ceil_div64(1LL * N * H, 16))), dim3(256), 0, st, b->grad_out, b->ld_gout, a->out,
                            a->ld_out, N, H, D, a->concat, (a->concat && !hx2) ? b->g_h : nullptr, b->q, ghp, hx2 ? 2LL * D : ld_ghp,
                            hx2 ? static_cast<int64_t>(D) : static_cast<int64_t>(N) * ld_ghp, hx2 ? 1 : 0,
-                           hx2 ? atp_scale_g(a) : Hx2Scale{nullptr, nullptr, 1.f});
+                           hx2 ? atp_scale_g(a) : Hx2Scale{nullptr, nullptr, 1.f}, row_inv, ldi, row_scaled ? atp_q(a, 3) : nullptr);
     }
     if (a->concat) { gh = b->g_h; ld_gh = static_cast<int32_t>(HD); }
     GemmBatch bt;
@@ -1730,7 +1780,8 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         bt.a_bs = D; bt.b_bs = static_cast<int64_t>(D) * W; bt.c_bs = W;
         if (hx2)
             rc = gemm_hx2_batched(N, W, D, b->gh_split, D, 2LL * D, 2LL * N * D,             // g_h terms [H][N][2][D]
-                                  static_cast<const char*>(a->a_split) + split_part_bytes(D, W, H), C, bt, atp_scale_g(a), atp_scale_a(a), st);
+                                  static_cast<const char*>(a->a_split) + split_part_bytes(D, W, H), C, bt,
+                                  row_scaled ? Hx2Scale{nullptr, nullptr, 1.f} : atp_scale_g(a), atp_scale_a(a), st, 0, row_inv, ldi);
         else if (a->a_split && bx3_supported(A, D, bt))
             rc = gemm_bx3_batched(N, W, D, A, static_cast<const char*>(a->a_split) + split_part_bytes(D, W, H), C, bt, st);
         else
@@ -1803,7 +1854,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
                 const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));
                 rc = gemm_hx2_kmajor_batched(W, D, N, a->V, 2LL * W, W, 2LL * N * W, b->gh_split, 2LL * D, D, 2LL * N * D,
                                              H, sk, b->partial, static_cast<const char*>(a->aux) + kHx2ZeroPageOffset, atp_scale_v(a), atp_scale_g(a), st,
-                                             atp_dst_shared(a));
+                                             atp_dst_shared(a), row_inv, ldi);
                 // its second pass runs in FINISH, fused with the score path's terms (k_atp_weights_finish) — unless the caller wants G now
                 if (rc == RECON_OK && (phases & RECON_ATP_BWD_EARLY_SUM)) rc = splitk_reduce(b->partial, sk, W, D, C, bw.c_bs, H, 0, true, st);
             } else if (gh_planes && bx3_kmajor_supported(a->V, ldv, W, ld_ghp, D, W, D)) {    // split-precision MFMA, both operands k-major

@@ -40,6 +40,7 @@ struct Hx2Args {
     int32_t epilogue, c_vec4, xcd_remap, c_plain;
     int32_t a_shared_k;            // A's columns k < a_shared_k are the same for every batch entry and are read from entry 0 (0: none)
     Hx2Scale sa, sb;
+    const float* row_inv; int64_t row_inv_bs;      // per-row inverse scales of A (see gemm_hx2_batched) or null
 };
 
 // byte offset of (row, k group kq of 8 halves) inside one plane of the B tile image (see gemm_bx3.hip)
@@ -61,12 +62,13 @@ __device__ __forceinline__ void hx2_products(f32x4 (&acc)[2][TN], const f16x8 (&
 
 // MFMA C layout col = lane&15, row = (lane>>4)*4 + r; columns through the B row permutation (tile 4q+t <-> columns 64q+4i+t)
 __device__ __forceinline__ void hx2_store(const f32x4 (&acc)[2][TN], const OutputDesc& C, float* base, int M, int N, int m0, int n0,
-                                          int mb, int li, int lq, int epi, int c_vec4, float ia, float ib) {
-    auto fin = [&](float v) { return gemm_epilogue(v * ia * ib, epi); };
+                                          int mb, int li, int lq, int epi, int c_vec4, const float (&rsc)[2][4]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            const float scale = rsc[i][r];
+            auto fin = [&](float v) { return gemm_epilogue(v * scale, epi); };
             const int row = m0 + mb + 16 * i + 4 * lq + r;
             if (row >= M) continue;
             float* crow = base + out_row_off(C, row);
@@ -93,8 +95,7 @@ __device__ __forceinline__ void hx2_store(const f32x4 (&acc)[2][TN], const Outpu
 // store, a few branches each; a wave spends several hundred cycles per store instruction in it.
 template <int EPI>
 __device__ __forceinline__ void hx2_store_plain(const f32x4 (&acc)[2][TN], float* base, int64_t ld, int M, int N, int m0, int n0, int mb,
-                                                int li, int lq, float scale) {
-    auto fin = [&](float v) { return __builtin_bit_cast(uint32_t, gemm_epilogue(v * scale, EPI)); };
+                                                int li, int lq, const float (&rsc)[2][4]) {
     // buffer stores: a lane whose offset lies outside the region is dropped by the hardware — no exec mask, no branch per store
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, static_cast<int>((static_cast<int64_t>(M - 1) * ld + N) * 4), 0x00020000);
     constexpr int kOut = 0x7ffffff0;
@@ -102,6 +103,8 @@ __device__ __forceinline__ void hx2_store_plain(const f32x4 (&acc)[2][TN], float
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            const float scale = rsc[i][r];
+            auto fin = [&](float v) { return __builtin_bit_cast(uint32_t, gemm_epilogue(v * scale, EPI)); };
             const int row = m0 + mb + 16 * i + 4 * lq + r;
             const int rowoff = static_cast<int>(row * ld) + n0;          // < 2^29 (checked on the host)
 #pragma unroll
@@ -225,6 +228,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) k_gemm_hx2(const Hx2
     load_a(0);
     // the operands' scales (32 amax slots each): read here, under the first tile's round trip, not in front of the stores
     const float ia = hx2_inv(hx2_scale_wave(p.sa)), ib = hx2_inv(hx2_scale_wave(p.sb));
+    // per-row scales of A (rows past M re-read the last row; they are never stored)
+    float rsc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            rsc[i][r] = p.row_inv ? p.row_inv[bz * p.row_inv_bs + min(m0 + mb + 16 * i + 4 * lq + r, p.M - 1)] : 1.f;
     take_a();
     __syncthreads();
     int buf = 0;
@@ -238,11 +248,15 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) k_gemm_hx2(const Hx2
         __syncthreads();
         buf ^= 1;
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rsc[i][r] *= ia * ib;
     if (p.c_plain) {                                                 // uniform
-        if (p.epilogue == GEMM_EPI_ELU) hx2_store_plain<GEMM_EPI_ELU>(acc, p.C.base + bz * p.c_bs, p.C.S1, p.M, p.N, m0, n0, mb, li, lq, ia * ib);
-        else hx2_store_plain<GEMM_EPI_NONE>(acc, p.C.base + bz * p.c_bs, p.C.S1, p.M, p.N, m0, n0, mb, li, lq, ia * ib);
+        if (p.epilogue == GEMM_EPI_ELU) hx2_store_plain<GEMM_EPI_ELU>(acc, p.C.base + bz * p.c_bs, p.C.S1, p.M, p.N, m0, n0, mb, li, lq, rsc);
+        else hx2_store_plain<GEMM_EPI_NONE>(acc, p.C.base + bz * p.c_bs, p.C.S1, p.M, p.N, m0, n0, mb, li, lq, rsc);
     } else {
-        hx2_store(acc, p.C, p.C.base + bz * p.c_bs, p.M, p.N, m0, n0, mb, li, lq, p.epilogue, p.c_vec4, ia, ib);
+        hx2_store(acc, p.C, p.C.base + bz * p.c_bs, p.M, p.N, m0, n0, mb, li, lq, p.epilogue, p.c_vec4, rsc);
     }
 }
 
@@ -262,6 +276,7 @@ struct Hx2KmArgs {
     int32_t m_ld, n_ld;            // columns present in the planes (multiples of 8, >= M / N; the excess is zero padding)
     int32_t a_shared_m;            // A's columns m < a_shared_m are the same for every batch entry and are read from entry 0 (0: none)
     Hx2Scale sa, sb;
+    const float* k_inv; int64_t k_inv_bs;          // per-k inverse scales of B's rows (see gemm_hx2_kmajor_batched) or null
 };
 
 constexpr int KB_SLOTS = 28;
@@ -277,7 +292,7 @@ __device__ __forceinline__ f16x8 tr_frag(const unsigned char* base, int off_lo, 
     return __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int OCC>
+template <int OCC, bool KSC>
 __global__ void __launch_bounds__(NT, OCC) k_gemm_hx2_kmajor(const Hx2KmArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char S[T * KA_PLANE + T * KB_PLANE];      // A image | B image: 45056 B
     unsigned char* const As = S;
@@ -353,12 +368,33 @@ __global__ void __launch_bounds__(NT, OCC) k_gemm_hx2_kmajor(const Hx2KmArgs p) 
         b_rot[hh] = (k & 8) != 0;
     }
     auto b_off = [&](int j, int hh) { return b_row[hh] + (2 * j + ((ip & 3) >> 1) + (b_rot[hh] ? 2 : 0)) * 16; };
+    // KSC: B's rows k carry their own scales; lane group g's fragments hold k = k0 + 8 g .. + 7, whose factors s_g / s_k ride in kf (requested
+    // one step ahead, next to the copies)
+    float4 kin[2];
+    float sg = 1.f;
+    auto load_kinv = [&](int k0) {
+        if constexpr (KSC) {
+            const float* q = p.k_inv + bz * p.k_inv_bs + min(k0 + 8 * g, ((p.K + 7) & ~7) - 8);   // the table is padded to a multiple of 8 rows; rows past the split are zeros anyway
+            kin[0] = *reinterpret_cast<const float4*>(q);
+            kin[1] = *reinterpret_cast<const float4*>(q + 4);
+        }
+    };
     auto mma_tile = [&]() {
         f16x8 a[2][T];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int q = 0; q < T; ++q) a[i][q] = tr_frag(As + q * KA_PLANE, a_off[i][0], a_off[i][1]);
+        if constexpr (KSC) {
+            const float f[8] = {kin[0].x, kin[0].y, kin[0].z, kin[0].w, kin[1].x, kin[1].y, kin[1].z, kin[1].w};
+            f16x8 kf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kf[e] = static_cast<_Float16>(fminf(f[e] * sg, 1.f));      // a power of two <= 1 (zero rows: s_k = 1)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < T; ++q) a[i][q] = a[i][q] * kf;
+        }
         f16x8 b[2][2][T];
         auto read_pair = [&](int j0, f16x8 (&dst)[2][T]) {
 #pragma unroll
@@ -382,14 +418,16 @@ __global__ void __launch_bounds__(NT, OCC) k_gemm_hx2_kmajor(const Hx2KmArgs p) 
 
     // ONE buffer per operand: the DMA of tile t+1 starts once every wave is done with tile t; the co-resident workgroups'
     // MFMA phases cover its flight
-    if (k_begin < k_end) dma(k_begin);
-    const float ia = hx2_inv(hx2_scale_wave(p.sa)), ib = hx2_inv(hx2_scale_wave(p.sb));      // under the first tile's round trip
+    if (k_begin < k_end) { dma(k_begin); load_kinv(k_begin); }
+    const float ia = hx2_inv(hx2_scale_wave(p.sa));
+    sg = hx2_scale_wave(p.sb);                                        // under the first tile's round trip
+    const float ib = hx2_inv(sg);
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         mma_tile();
         __syncthreads();
-        if (k0 + BK < k_end) dma(k0 + BK);
+        if (k0 + BK < k_end) { dma(k0 + BK); load_kinv(k0 + BK); }
     }
     // 104 four-byte stores per wave, rows past M and columns past N masked out: as buffer stores whose offset lies outside the tile's
     // M x N region for a masked lane (the hardware drops those), i.e. without an exec mask and a branch around every one of them
@@ -538,7 +576,8 @@ bool hx2_supported(const void* Ap, int64_t a_plane, int64_t a_row, int64_t a_bs,
 
 // A: half planes, element (plane q, batch z, row m, k) at Ap[q*a_plane + z*a_bs + m*a_row + k]; B planes [2][batch][N][hx2_kp(K)]
 int gemm_hx2_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t a_plane, int64_t a_row, int64_t a_bs, const void* Bplanes,
-                     const OutputDesc& C, const GemmBatch& bt, const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st, int32_t a_shared_k) {
+                     const OutputDesc& C, const GemmBatch& bt, const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st, int32_t a_shared_k,
+                     const float* row_inv, int64_t row_inv_bs) {
     if (M < 0 || N < 0 || K < 0 || bt.batch < 0) return RECON_ERR_INVALID;
     if (M == 0 || N == 0 || bt.batch == 0) return RECON_OK;
     if (!Ap || !Bplanes || !C.base) return RECON_ERR_INVALID;
@@ -560,6 +599,8 @@ int gemm_hx2_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t a_
     a.a_shared_k = a_shared_k;
     a.c_plain = (a.c_vec4 && !C.scatter && C.P >= M && C.Dseg >= N && (static_cast<int64_t>(M) * C.S1 + N) * 4 < (1LL << 31)) ? 1 : 0;   // plain rows: the straight-line store
     a.sa = sa; a.sb = sb;
+    a.row_inv = row_inv; a.row_inv_bs = row_inv_bs;
+    if (row_inv && sa.p0) return RECON_ERR_INVALID;                      // per-row scales: no tensor scale beside them
     // 256-row workgroups for long K and enough rows to fill the chip with them (see k_gemm_hx2)
     const bool wide = K >= 1024 && ceil_div64(M, 256) * ceil_div64(N, BN) * bt.batch >= 256;
     const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, wide ? 256 : BM)), static_cast<unsigned>(bt.batch));
@@ -582,7 +623,7 @@ bool hx2_kmajor_supported(const void* Ap, int64_t lda, int64_t a_plane, int64_t 
 // split_k must be bx3_kmajor_splits(K, requested) (same K-tile rounding as the bf16 x 3 kernel)
 int gemm_hx2_kmajor_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t lda, int64_t a_plane, int64_t a_bs, const void* Bp,
                             int64_t ldb, int64_t b_plane, int64_t b_bs, int32_t batch, int32_t split_k, float* partial, const void* zeros,
-                            const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st, int32_t a_shared_m) {
+                            const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st, int32_t a_shared_m, const float* k_inv, int64_t k_inv_bs) {
     if (M < 0 || N < 0 || K < 0 || batch < 0 || split_k < 1) return RECON_ERR_INVALID;
     if (M == 0 || N == 0 || batch == 0) return RECON_OK;
     if (!Ap || !Bp || !partial || !zeros || (reinterpret_cast<uintptr_t>(zeros) & 15)) return RECON_ERR_INVALID;
@@ -602,7 +643,11 @@ int gemm_hx2_kmajor_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int
     if (a_shared_m < 0 || (a_shared_m & 7)) return RECON_ERR_UNSUPPORTED;
     a.a_shared_m = a_shared_m;
     const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, BM)), static_cast<unsigned>(batch * split_k));
-    hipLaunchKernelGGL((k_gemm_hx2_kmajor<2>), grid, dim3(NT), 0, st, a);      // three workgroups per CU (<= 168 registers) spill: 241 us against 70
+    a.k_inv = k_inv; a.k_inv_bs = k_inv_bs;
+    if (k_inv && ((k_inv_bs & 3) || k_inv_bs < ((K + 7) & ~7) || (reinterpret_cast<uintptr_t>(k_inv) & 15))) return RECON_ERR_UNSUPPORTED;
+    // three workgroups per CU (<= 168 registers) spill: 241 us against 70
+    if (k_inv) hipLaunchKernelGGL((k_gemm_hx2_kmajor<2, true>), grid, dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((k_gemm_hx2_kmajor<2, false>), grid, dim3(NT), 0, st, a);
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
 }

@@ -89,6 +89,22 @@ __device__ __forceinline__ void dma16_to_lds(const void* src, const void* lds_ds
 template <int N>
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// max over aligned groups of 16 lanes (DPP only), every lane of the group receives it
+__device__ __forceinline__ float group_max16(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return v;
+}
+// FOUR per-lane values -> their maxima over the wave, value j's in lanes [16 j, 16 j + 16): two halving exchanges (3 permutes) + the DPP steps
+__device__ __forceinline__ float multi_max4(const float (&v)[4], int lane) {
+    const bool up = lane & 32, up2 = lane & 16;
+    const float w0 = fmaxf(up ? v[2] : v[0], __shfl_xor(up ? v[0] : v[2], 32, 64));
+    const float w1 = fmaxf(up ? v[3] : v[1], __shfl_xor(up ? v[1] : v[3], 32, 64));
+    return group_max16(fmaxf(up2 ? w1 : w0, __shfl_xor(up2 ? w0 : w1, 16, 64)));
+}
+
 template <int VEC> struct VecT;
 template <> struct VecT<1> { using type = float; };
 template <> struct VecT<2> { using type = float2; };
@@ -192,6 +208,16 @@ __device__ __forceinline__ void hx2_amax_commit(float m, uint32_t* quantity) {
     if ((threadIdx.x & 63) == 0) {
         const uint32_t w = (blockIdx.x + blockIdx.y * gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
         uint32_t* slot = quantity + ((w * 2654435761u) >> 27) * kHx2SlotStride;          // top 5 bits of a multiplicative hash
+        const uint32_t bits = __builtin_bit_cast(uint32_t, m);
+        if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+    }
+}
+
+// the same for a maximum that is already wave-uniform (no butterfly)
+__device__ __forceinline__ void hx2_amax_commit_uniform(float m, uint32_t* quantity) {
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t w = (blockIdx.x + blockIdx.y * gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        uint32_t* slot = quantity + ((w * 2654435761u) >> 27) * kHx2SlotStride;
         const uint32_t bits = __builtin_bit_cast(uint32_t, m);
         if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
     }
@@ -319,13 +345,21 @@ bool hx2_split_both_args(const float* src, int64_t src_bs, int32_t R, int32_t C_
 int hx2_split_planes_both(const float* src, int64_t src_bs, int32_t R, int32_t C_, int32_t batch, void* dst_n, void* dst_t, const Hx2Scale& sc,
                           hipStream_t st, uint32_t* blkmax_quantity = nullptr, int32_t nblk = 0);
 bool hx2_supported(const void* Ap, int64_t a_plane, int64_t a_row, int64_t a_bs, int32_t K);
+// row_inv (optional): A's rows carry PER-ROW power-of-two scales instead of one per tensor — row m of batch entry z was scaled by
+// 1 / row_inv[z * row_inv_bs + m] when its planes were written (k_elu_grad_q: no pass over the tensor for a global maximum first); the
+// epilogue multiplies the row by it.  `sa` must then describe no scale.
 int gemm_hx2_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t a_plane, int64_t a_row, int64_t a_bs, const void* Bplanes,
-                     const OutputDesc& C, const GemmBatch& bt, const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st, int32_t a_shared_k = 0);
+                     const OutputDesc& C, const GemmBatch& bt, const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st, int32_t a_shared_k = 0,
+                     const float* row_inv = nullptr, int64_t row_inv_bs = 0);
 bool hx2_kmajor_supported(const void* Ap, int64_t lda, int64_t a_plane, int64_t a_bs, const void* Bp, int64_t ldb, int64_t b_plane,
                           int64_t b_bs, int32_t M, int32_t N);
 int gemm_hx2_kmajor_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t lda, int64_t a_plane, int64_t a_bs, const void* Bp,
                             int64_t ldb, int64_t b_plane, int64_t b_bs, int32_t batch, int32_t split_k, float* partial, const void* zeros,
-                            const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st, int32_t a_shared_m = 0);
+                            const Hx2Scale& sa, const Hx2Scale& sb, hipStream_t st, int32_t a_shared_m = 0, const float* k_inv = nullptr,
+                            int64_t k_inv_bs = 0);
+// k_inv (optional): B's rows (the contraction index k) carry per-row power-of-two scales s_k = 1 / k_inv[z * k_inv_bs + k] while `sb`
+// names the tensor's global maximum (scale s_g <= every s_k).  The kernel brings the rows to the common scale on the OTHER operand: A's
+// fragments are multiplied by s_g / s_k (a power of two <= 1, exact in half precision down to its subnormals) as they leave LDS.
 // C = epilogue(sum over splits of partial[batch][split][M][N]) through C's addressing; transpose: element (m, n) -> C(n, m)
 int splitk_reduce(const float* partial, int32_t splits, int32_t M, int32_t N, const OutputDesc& C, int64_t c_bs, int32_t batch,
                   int32_t epilogue, bool transpose, hipStream_t st);

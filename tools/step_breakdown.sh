@@ -3,7 +3,7 @@
 TAG=${1:-x}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/bd_$TAG -o t -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bd_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/bd_$TAG -o t -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-extras > gpurun_out/bd_$TAG.log 2>&1
 python3 - <<PY
 import csv,glob
 f=glob.glob("gpurun_out/bd_$TAG/**/*kernel_stats.csv",recursive=True)[0]
