@@ -43,6 +43,14 @@ typedef void* recon_stream_t; /* hipStream_t */
 int recon_version(void);
 const char* recon_error_string(int code);
 
+/* Run-time switches (recon_amd/csrc/config.hip): one table, filled from the environment variables of the same names (RECON_GEMM_CFG,
+ * RECON_PROP_FWD ... — INTEGRATION.md lists them) the first time the library needs one; every switch chooses between kernels that
+ * compute the same result.  recon_config_set overrides one entry (value NULL: unset), recon_config_get returns the current value or NULL.
+ * Call them between launches, from the launching thread.  The reference has no counterpart (its only switch is the module-level CUDA flag,
+ * GAT/layers.py:10). */
+int recon_config_set(const char* name, const char* value);
+const char* recon_config_get(const char* name);
+
 /* --------------------------------------------------------------------------------------------
  * K3  graph preparation: COO edge list -> destination-CSR + source-CSC views.
  * Replaces the implicit coalesce/sort inside torch.sparse.sum at GAT/layers.py:56-58 (and the

@@ -193,6 +193,8 @@ SYMBOLS = [
     ("recon_sgemm_bx3_tn_workspace_bytes", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     ("recon_sgemm_bx3_tn", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32,
                                      C.c_void_p, C.c_void_p]),
+    ("recon_config_set", C.c_int, [C.c_char_p, C.c_char_p]),
+    ("recon_config_get", C.c_char_p, [C.c_char_p]),
     ("recon_hx2_aux_bytes", C.c_size_t, []),
     ("recon_sgemm_hx2_workspace_bytes", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     ("recon_sgemm_hx2", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32,
@@ -229,6 +231,32 @@ def lib():
             raise RuntimeError("librecon_hip.so ABI version mismatch")
         _lib = h
     return _lib
+
+
+def config_set(name, value):
+    """Override one run-time switch of the library (csrc/config.hip; value None: unset).  Returns the previous value (or None)."""
+    h = lib()
+    prev = h.recon_config_get(name.encode())
+    prev = prev.decode() if prev is not None else None
+    check(h.recon_config_set(name.encode(), None if value is None else str(value).encode()), "recon_config_set(%s)" % name)
+    return prev
+
+
+class config:
+    """`with _lib.config(RECON_PROP_FWD="w"): ...` — switches set for the block, restored afterwards (tests, A/B tools)."""
+
+    def __init__(self, **kv):
+        self.kv, self.prev = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.prev[k] = config_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            config_set(k, v)
+        return False
 
 
 def check(code, what):

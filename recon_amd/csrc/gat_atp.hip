@@ -1753,7 +1753,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
     // inverse scales [H][ldi] live behind the two planes, in the room of the third plane that only the bf16 x 3 family uses.
     const int64_t ldi = (static_cast<int64_t>(N) + 7) / 8 * 8;
     const size_t inv_off = align_up(static_cast<size_t>(2) * N * bx3_kp(static_cast<int32_t>(HD)) * 2, 256);
-    const bool row_scaled = hx2 && D <= 256 && ((a->ld_out | b->ld_gout) & 3) == 0 &&
+    const bool row_scaled = hx2 && D <= 256 && ((a->ld_out | b->ld_gout) & 3) == 0 && cfg_char(CFG_ATP_ROW_SCALE) != '0' &&
                             inv_off + static_cast<size_t>(H) * ldi * sizeof(float) <= recon_gat_atp_bwd_split_bytes(N, D, H);
     float* row_inv = row_scaled ? reinterpret_cast<float*>(static_cast<char*>(b->gh_split) + inv_off) : nullptr;
     if (phases & RECON_ATP_BWD_PREPARE) {

@@ -735,7 +735,7 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_bwd(const GcnFuse
 }
 
 bool gcn_fused_ok(const recon_gcn_b16_args* a) {
-    static const bool off = getenv("RECON_GCN_FUSED") && getenv("RECON_GCN_FUSED")[0] == '0';
+    const bool off = cfg_char(CFG_GCN_FUSED) == '0';
     return !off && a->n <= 32 && a->ldo <= kFusedNT * 16 && (a->ldo & 3) == 0 &&
            static_cast<int64_t>(a->B) * a->n * a->ldx * 2 < 0x7fffffffLL && static_cast<int64_t>(a->B) * a->n * a->ldo * 2 < 0x7fffffffLL;
 }
@@ -787,7 +787,7 @@ extern "C" int recon_gcn_b16_fwd(const recon_gcn_b16_args* a, recon_stream_t str
         k.B = a->B; k.n = a->n; k.I = I; k.Ip = b16_kp(I); k.O = O; k.nt = static_cast<int32_t>(ceil_div64(a->ldo, 16));
         k.adj_vec = (a->n % 4 == 0 && (reinterpret_cast<uintptr_t>(a->adj) & 7) == 0) ? 1 : 0;
         k.bias_vec = (!a->bias || (O % 4 == 0 && (reinterpret_cast<uintptr_t>(a->bias) & 7) == 0)) ? 1 : 0;
-        static const int ns = [] { const char* e = getenv("RECON_GCN_FUSED_PARTS"); const int v = e ? atoi(e) : 4; return v == 1 || v == 2 ? v : 4; }();
+        const int ns = [] { const int v = cfg_int(CFG_GCN_FUSED_PARTS, 4); return v == 1 || v == 2 ? v : 4; }();
         const dim3 fg(static_cast<unsigned>(ceil_div64(a->B, 4)));
         const bool vec = k.adj_vec && k.bias_vec;
 #define CALL_F(N_) do { if (vec) hipLaunchKernelGGL((k_gcn_b16_fused_fwd<N_, true>), fg, dim3(256 * N_), 0, st, k); \
@@ -832,7 +832,7 @@ extern "C" int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* b, recon_stream_t
     const uint16_t* fout = static_cast<const uint16_t*>(a->out);
     // [B][O] per-graph column sums of gpre, behind the split-K partials (ragged batch: the partials of a product over total_rows rows)
     float* colsum = b->partial + (a->node_ptr ? gcn_b16_gw_partial_floats(1, rows, I, O) : gcn_b16_gw_partial_floats(a->B, n, I, O));
-    static const bool fused_bwd_off = getenv("RECON_GCN_FUSED_BWD") && getenv("RECON_GCN_FUSED_BWD")[0] == '0';
+    const bool fused_bwd_off = cfg_char(CFG_GCN_FUSED_BWD) == '0';
     const int64_t i8f = (I + 7) / 8 * 8;
     const bool fused_bwd = !fused_bwd_off && !a->node_ptr && !b->g_adj && b->g_x && n <= 32 && a->lds <= kFusedNT * 16 && i8f <= kFusedNT * 16 && b->ldgx >= i8f &&
                            (b->ldgx & 3) == 0 && (a->lds & 3) == 0 && (b->ldg & 7) == 0 && (a->ldo & 7) == 0 &&
@@ -910,7 +910,7 @@ extern "C" int recon_gcn_b16_stack_fwd(const recon_gcn_b16_stack_args* a, recon_
     const size_t lds = 3ull * kFusedNT * 16 * 64 + 4ull * nki * 2048 + 1024;
     if (lds > 160 * 1024) return RECON_ERR_UNSUPPORTED;                 // in_features > 384: layer by layer
     // column parts per graph: 4 (sixteen waves per CU; nothing but accumulators and fragments lives in registers)
-    static const int ns = [] { const char* e = getenv("RECON_GCN_STACK_PARTS"); const int v = e ? atoi(e) : 4; return v == 2 ? 2 : 4; }();
+    const int ns = cfg_int(CFG_GCN_STACK_PARTS, 4) == 2 ? 2 : 4;
     if (ns == 4) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gcn_b16_stack_fwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         hipLaunchKernelGGL(k_gcn_b16_stack_fwd<4>, dim3(static_cast<unsigned>(ceil_div64(a->B, 4))), dim3(1024), lds, as_stream(stream), k);

@@ -460,9 +460,9 @@ bool operand_linear(const OperandDesc& d, bool k_minor, int32_t K) {
 }
 
 // Outputs 129..208 columns wide take ONE 208-wide column tile of 13 16x16 MFMA tiles (4 % padding at N = 200)
-// instead of two 128-wide tiles (28 % padding).  RECON_GEMM_CFG=1 forces 128x128 (read per call: in-process A/B).
+// instead of two 128-wide tiles (28 % padding).  RECON_GEMM_CFG=1 forces 128x128 (config.hip).
 bool use_narrow(int32_t N, bool a_k_minor, bool b_k_minor, bool v4) {
-    const int force = getenv("RECON_GEMM_CFG") ? atoi(getenv("RECON_GEMM_CFG")) : 0;
+    const int force = cfg_int(CFG_GEMM_CFG, 0);
     if (force == 1) return false;
     (void)a_k_minor; (void)b_k_minor;
     return v4 && N > 128 && N <= 208;
@@ -478,7 +478,7 @@ bool output_vec4(const OutputDesc& C, int32_t N, int64_t c_bs, const float* part
 }  // namespace
 
 int gemm_pick_split_k(int32_t M, int32_t N, int32_t K, int32_t batch) {
-    static const int force = getenv("RECON_GEMM_SPLITK") ? atoi(getenv("RECON_GEMM_SPLITK")) : 0;   // tuning knob
+    const int force = cfg_int(CFG_GEMM_SPLITK, 0);   // tuning knob
     if (force > 0) return force;
     const bool narrow = N > 128 && N <= 208;                       // 128 x 208 kernel (when the operands are float4-able)
     const int bn = narrow ? 208 : 128;
@@ -503,7 +503,7 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
     GemmArgs a;
     a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K;
     a.a_bs = bt.a_bs; a.b_bs = bt.b_bs; a.c_bs = bt.c_bs; a.epilogue = bt.epilogue;
-    a.xcd_remap = (getenv("RECON_GEMM_XCD") && atoi(getenv("RECON_GEMM_XCD")) == 0) ? 0 : 1;   // read per call: in-process A/B
+    a.xcd_remap = cfg_int(CFG_GEMM_XCD, 1) == 0 ? 0 : 1;
     const bool v4 = operand_vec4(A, a_k_minor ? K : M) && operand_vec4(B, b_k_minor ? K : N) && (bt.batch == 1 || (!(bt.a_bs & 3) && !(bt.b_bs & 3)));
     const int bk = BK16;
     int64_t kps = ceil_div64(K > 0 ? K : 1, split_k);
@@ -516,7 +516,7 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
     {
         const bool narrow = use_narrow(N, a_k_minor, b_k_minor, v4);
         const bool lin = v4 && operand_linear(A, a_k_minor, K) && operand_linear(B, b_k_minor, K) &&
-                         !(getenv("RECON_GEMM_LIN") && atoi(getenv("RECON_GEMM_LIN")) == 0);
+                         cfg_int(CFG_GEMM_LIN, 1) != 0;
         a.c_vec4 = output_vec4(C, N, bt.c_bs, a.partial) ? 1 : 0;
         dim3 grid(static_cast<unsigned>(ceil_div64(N, narrow ? 208 : 128)), static_cast<unsigned>(ceil_div64(M, 128)),
                   static_cast<unsigned>(split_k * bt.batch));

@@ -829,7 +829,7 @@ bool prop_geometry(int C, int S, PropGeom* g) {
     g->pitch = g->Sp + 4;
     const int Cp = (C + 15) / 16 * 16;
     int cc = Cp < 80 ? Cp : 80;                                     // <= 5 MFMA row tiles per block
-    static const size_t budget = [] { const char* e = getenv("RECON_PROP_LDS_KB"); return static_cast<size_t>(e ? atoi(e) : 150) * 1024; }();      // S = 512: 32-channel chunks instead of 16 (half the re-reads of A_l)
+    const size_t budget = static_cast<size_t>(cfg_int(CFG_PROP_LDS_KB, 150)) * 1024;      // S = 512: 32-channel chunks instead of 16 (half the re-reads of A_l)
     while (cc > 16 && 2ull * cc * g->pitch * sizeof(float) > budget) cc -= 16;
     if (2ull * cc * g->pitch * sizeof(float) > 160 * 1024) return false;
     g->CC = cc;
@@ -959,7 +959,7 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
     {
         // default: two-term half operands on the f16 matrix cores (prop_h.hip) wherever that form exists; RECON_PROP_FWD = w | b | s | x
         // selects one of the forms below (fp32 MFMA per wave / per workgroup / staged, bf16 x 3), h forces the default
-        const char* form = getenv("RECON_PROP_FWD");
+        const char* form = cfg(CFG_PROP_FWD);
         if ((!form || form[0] == 'h' || form[0] == '\0') && prop_fwd_h_supported(p)) return prop_fwd_h(p, st);
         if ((!form || form[0] == 'h' || form[0] == '\0') && prop_fwd_hl_supported(p)) return prop_fwd_hl(p, st);     // wide states, given a workspace
         if (blk) return RECON_ERR_UNSUPPORTED;                          // the other forms need a materialised adjacency
@@ -977,7 +977,7 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
             if (launched) { RECON_CHECK_LAUNCH(); return RECON_OK; }
         }
     }
-    if (NTn <= 9 && (a->S % 16) == 0 && v4 && mtn_s <= 16 && g.pitch == a->S + 4 && getenv("RECON_PROP_FWD") && getenv("RECON_PROP_FWD")[0] == 's') {   // staged form
+    if (NTn <= 9 && (a->S % 16) == 0 && v4 && mtn_s <= 16 && g.pitch == a->S + 4 && cfg_char(CFG_PROP_FWD) == 's') {   // staged form
         const size_t slds = 3ull * 16 * (a->S + 4) * sizeof(float) + static_cast<size_t>(mtn_s) * 16 * g.pitch * sizeof(float);
 #define CALL_S(N_) do { if (slds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_propagate_fwd_s<N_>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(slds)); \
                         hipLaunchKernelGGL((k_propagate_fwd_s<N_>), dim3(static_cast<unsigned>(a->B)), dim3(64 * mtn_s), slds, st, p); } while (0)
@@ -988,7 +988,7 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
         RECON_CHECK_LAUNCH();
         return RECON_OK;
     }
-    if (NTn <= 9 && !(getenv("RECON_PROP_FWD") && getenv("RECON_PROP_FWD")[0] == 'b')) {      // wave-independent form (RECON_PROP_FWD=w, or shapes the bf16 form does not take)
+    if (NTn <= 9 && cfg_char(CFG_PROP_FWD) != 'b') {      // wave-independent form (RECON_PROP_FWD=w, or shapes the bf16 form does not take)
         const int64_t units = 1LL * a->B * ((a->C + 15) / 16);
         dim3 wgrid(static_cast<unsigned>(ceil_div64(units, 4)));
         const size_t wlds = 4ull * 16 * g.pitch * sizeof(float);
@@ -1017,7 +1017,7 @@ extern "C" int recon_propagate_fwd(const recon_prop_args* a, recon_stream_t stre
 }
 
 static bool prop_h_form_env() {
-    const char* form = getenv("RECON_PROP_FWD");
+    const char* form = cfg(CFG_PROP_FWD);
     return !form || form[0] == 'h' || form[0] == '\0';
 }
 
@@ -1173,7 +1173,7 @@ extern "C" size_t recon_propagate_bwd_chain_ws_floats(const recon_prop_args* a) 
     if (a->trans && (!a->identity || a->S != 16 * (a->S / 16) || a->C != (a->S / 16) * (a->S / 16 - 1))) return 0;
     if (1LL * a->L * a->B * (a->S / 16) >= (1LL << 31)) return 0;
     const int64_t G = prop_bwd_hl_slice(a->C, a->S, a->L, a->split_ws_bytes, a->B);
-    static const bool off = getenv("RECON_PROP_BWD_CHAIN") && getenv("RECON_PROP_BWD_CHAIN")[0] == '0';
+    const bool off = cfg_char(CFG_PROP_BWD_CHAIN) == '0';
     if (G <= 0 || off) return 0;
     return prop_bwd_hl_ws_floats(a->C, a->S, a->L, G) + (a->trans ? static_cast<size_t>(a->L) * a->B * (a->S / 16) * 256 : 0);
 }
@@ -1191,10 +1191,10 @@ extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t
     if (!a->h_saved || !ba->grad_out || !ba->g_h) return RECON_ERR_INVALID;
     if (a->B == 0) return RECON_OK;
     if (a->S > 160 && ba->chain_ws && ba->head_blk && ba->tail_blk && recon_propagate_bwd_chain_ws_floats(a) > 0 &&
-        !(getenv("RECON_PROP_BWD_WIDE") && getenv("RECON_PROP_BWD_WIDE")[0] == '0')) {
+        cfg_char(CFG_PROP_BWD_WIDE) != '0') {
         return prop_bwd_wide_chain(a, ba, as_stream(stream));          // wide states, structured indices: chain + d A on the two-term f16 kernels (block mode too)
     }
-    if (a->stats && prop_h_form_env() && !(getenv("RECON_PROP_BWD") && getenv("RECON_PROP_BWD")[0] == 'f')) {      // two-term f16 form (RECON_PROP_BWD=f: fp32 MFMA form)
+    if (a->stats && prop_h_form_env() && cfg_char(CFG_PROP_BWD) != 'f') {      // two-term f16 form (RECON_PROP_BWD=f: fp32 MFMA form)
         PropBwdH q{};
         const bool blk = a->trans != nullptr;
         for (int l = 0; l < kMaxHops; ++l) {
@@ -1216,7 +1216,7 @@ extern "C" int recon_propagate_bwd(const recon_prop_bwd_args* ba, recon_stream_t
         if (blk) return RECON_ERR_UNSUPPORTED;
     } else if (a->trans) return RECON_ERR_UNSUPPORTED;
     {
-        static const bool wide_off = getenv("RECON_PROP_BWD_WIDE") && getenv("RECON_PROP_BWD_WIDE")[0] == '0';
+        const bool wide_off = cfg_char(CFG_PROP_BWD_WIDE) == '0';
         if (!wide_off && ba->wide_ws && a->S > 160 && 4ull * a->S * sizeof(float) <= 64 * 1024)     // wide states: both products as batched GEMMs
             return prop_bwd_wide(a, ba, as_stream(stream));
     }

@@ -1039,7 +1039,7 @@ int form_b16(const recon_prop_b16_args* a, bool check_ptrs) {
         for (int l = 0; l < a->L; ++l) if (!al16(blk ? a->trans[l] : a->adj[l])) return 0;
         if (blk && !al16(a->identity)) return 0;
     }
-    const char* env = getenv("RECON_PROP_B16");                         // "g": the GEMM form everywhere (tests, A/B)
+    const char* env = cfg(CFG_PROP_B16);                                // "g": the GEMM form everywhere (tests, A/B)
     const bool force_gemm = env && env[0] == 'g';
     if (!force_gemm && a->S % 16 == 0 && a->S <= 160 && a->C <= 96 && (a->dd % 2) == 0 && ((a->C * a->dd) & 1) == 0) return 1;
     // wide states in LDS: S = 32 NKS, NKS even in 6 .. 16 (S % 64 == 0, 192 <= S <= 512), even dd; inference or training alike
@@ -1083,9 +1083,9 @@ int launch_bgemm_cfg(BGemmB16 g, hipStream_t st) {
 template <bool PK, bool QK, int EPI, bool PBLK>
 int launch_bgemm(const BGemmB16& g, hipStream_t st) {
     if (g.M <= 144 && g.N <= 144) return launch_bgemm_cfg<PK, QK, EPI, PBLK, 3, 3, 3, 3, 3>(g, st);
-    const char* cfg = getenv("RECON_BGEMM_CFG");
-    if (cfg && cfg[0] == 'a') return launch_bgemm_cfg<PK, QK, EPI, PBLK, 2, 2, 4, 4, 3>(g, st);
-    if (cfg && cfg[0] == 'h') return launch_bgemm_cfg<PK, QK, EPI, PBLK, 1, 4, 8, 4, 3>(g, st);
+    const char tile = cfg_char(CFG_BGEMM_CFG);
+    if (tile == 'a') return launch_bgemm_cfg<PK, QK, EPI, PBLK, 2, 2, 4, 4, 3>(g, st);
+    if (tile == 'h') return launch_bgemm_cfg<PK, QK, EPI, PBLK, 1, 4, 8, 4, 3>(g, st);
     return launch_bgemm_cfg<PK, QK, EPI, PBLK, 2, 4, 8, 4, 3>(g, st);
 }
 
@@ -1262,7 +1262,7 @@ extern "C" int recon_propagate_b16_bwd(const recon_prop_b16_bwd_args* ba, recon_
     const dim3 ylgrid(static_cast<unsigned>(ceil_div64(rows, 4 * kYLastRows)));
     const size_t plds = 8ull * S * sizeof(float);
     // the fused Y: structured gather indices shared by the batch, dd and L dd multiples of 8 (16-byte pieces of grad_out rows)
-    const bool fuse_y = ba->head_blk && ba->tail_blk && a->idx_batch_stride == 0 && (a->dd % 8) == 0 && !(getenv("RECON_PROP_B16_YPOST") && getenv("RECON_PROP_B16_YPOST")[0] == 'k');
+    const bool fuse_y = ba->head_blk && ba->tail_blk && a->idx_batch_stride == 0 && (a->dd % 8) == 0 && cfg_char(CFG_PROP_B16_YPOST) != 'k';
     if (fuse_y)
         hipLaunchKernelGGL(k_prop_b16_y_last, ylgrid, dim3(256), 0, st, hs + (L - 1) * BCS, ba->head_blk, ba->tail_blk, gout, bufY, rows, C, S, L, a->dd, L - 1,
                            a->act);

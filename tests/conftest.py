@@ -62,3 +62,17 @@ def gemm_family(request, monkeypatch):
         from recon_amd import gat_layers
         monkeypatch.setattr(gat_layers, "_GEMM_BX3", fam)
     yield fam
+
+
+@pytest.fixture
+def recon_config():
+    """`recon_config("RECON_PROP_FWD", "w")`: one run-time switch of the library (csrc/config.hip) for the rest of the test, restored afterwards."""
+    from recon_amd import _lib
+    prev = {}
+
+    def set_(name, value):
+        before = _lib.config_set(name, value)
+        prev.setdefault(name, before)
+    yield set_
+    for name, value in prev.items():
+        _lib.config_set(name, value)

@@ -80,9 +80,9 @@ def test_graph_cache_distinguishes_strided_views():
 @pytest.mark.parametrize("cfg", ["0", "1"])        # RECON_GEMM_CFG: default tile choice / 128x128 forced
 @pytest.mark.parametrize("M,N,K,nk", [(128, 128, 16, 1), (200, 72, 50, 1), (33, 257, 19, 0), (1000, 400, 200, 0),
                                       (256, 1600, 200, 1), (700, 200, 600, 1), (513, 600, 200, 0), (300, 204, 37, 1)])
-def test_sgemm(M, N, K, nk, cfg, monkeypatch):
+def test_sgemm(M, N, K, nk, cfg, recon_config):
     from recon_amd import _lib
-    monkeypatch.setenv("RECON_GEMM_CFG", cfg)
+    recon_config("RECON_GEMM_CFG", cfg)
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g)
     B = torch.randn(N, K, generator=g) if nk else torch.randn(K, N, generator=g)

@@ -71,11 +71,11 @@ def _run_b16(adjs_b, h0_b, head, tail, act, Gr_b, grad=True):
     (3, 24, 2, 3, "tanh", True),       # 2d = 48: S = 144, C = 6, 288 gather items
 ])
 @pytest.mark.parametrize("form", ["fused", "gemm"])
-def test_propagation_b16_vs_oracle(n, d, L, B, act, per_batch, form, monkeypatch):
+def test_propagation_b16_vs_oracle(n, d, L, B, act, per_batch, form, recon_config):
     """Small states (S <= 160, C <= 96): all hops of a graph in one workgroup (`fused`), and the same problems through the batched-GEMM
     form the wide states use (`gemm`: RECON_PROP_B16=g) — forward, saved states and every gradient."""
     if form == "gemm":
-        monkeypatch.setenv("RECON_PROP_B16", "g")
+        recon_config("RECON_PROP_B16", "g")
     from recon_amd.propagation import make_start_embedding, get_head_indices, get_tail_indices
     C, S, dd = n * (n - 1), 2 * d * n, 2 * d
     g = torch.Generator().manual_seed(n * 100 + d)
@@ -105,12 +105,12 @@ def test_propagation_b16_vs_oracle(n, d, L, B, act, per_batch, form, monkeypatch
     (512, 300, 20, 2, 2, "relu", True),      # gather width 20: more items than the position table holds
 ])
 @pytest.mark.parametrize("form", ["auto", "gemm"])
-def test_propagation_b16_gemm_form_vs_oracle(S, C, dd, L, B, act, per_batch, form, monkeypatch):
+def test_propagation_b16_gemm_form_vs_oracle(S, C, dd, L, B, act, per_batch, form, recon_config):
     """Shapes the small fused kernel does not take.  `auto`: S % 64 == 0, 192 <= S <= 512 runs the wide fused kernel (the state of 128
     channels resident in LDS for all hops), everything else one batched GEMM per hop over the graphs; `gemm`: the GEMM form everywhere.
     Arbitrary adjacencies, start states and gather indices (duplicates included); the backward is the GEMM form in both."""
     if form == "gemm":
-        monkeypatch.setenv("RECON_PROP_B16", "g")
+        recon_config("RECON_PROP_B16", "g")
     g = torch.Generator().manual_seed(S + C)
     adjs = [_bf((torch.rand(B, S, S, generator=g) - 0.45) * (2.0 / S ** 0.5)) for _ in range(L)]
     h0 = _bf(torch.randn(B, C, S, 1, generator=g) if per_batch else torch.randn(C, S, 1, generator=g))
@@ -189,13 +189,13 @@ def test_propagate_blocks_b16_inference_matches_materialised(n, L, B, act, per_b
 
 
 @pytest.mark.parametrize("n,L,B,ypost", [(9, 3, 6, "fused"), (9, 3, 6, "kernel"), (11, 2, 3, "fused"), (12, 2, 10, "fused"), (4, 3, 5, "fused")])
-def test_propagate_blocks_b16_training_vs_oracle(n, L, B, ypost, monkeypatch):
+def test_propagate_blocks_b16_training_vs_oracle(n, L, B, ypost, recon_config):
     """models/models.py:240-274 on bf16 tensors with gradients, no adjacency materialised in either direction: transition tensors -> relu ->
     [block adjacency read in place] -> L hops -> loss, all gradients (d T_l in T's layout, d identity, d h0) against the oracle's closed
     form run from the forward's own states.  n = 9 / 4: fused small forward; n = 11: every hop a batched GEMM reading T in place; n = 12:
     the wide fused forward.  `kernel`: Y_l by the separate pass instead of the GEMM epilogue (RECON_PROP_B16_YPOST=k)."""
     if ypost == "kernel":
-        monkeypatch.setenv("RECON_PROP_B16_YPOST", "k")
+        recon_config("RECON_PROP_B16_YPOST", "k")
     from recon_amd import propagation as P
     d_ = dev()
     d = 8

@@ -105,11 +105,11 @@ def test_propagation_beyond_4_gib_per_hop():
     (12, 4, 2, 2, "relu", False),      # C = 132 > 80: two channel chunks per graph
 ])
 @pytest.mark.parametrize("form", ["f16x2", "bf16x3", "wave", "block"])
-def test_propagation_vs_oracle(n, d, L, B, act, per_batch, form, monkeypatch):
+def test_propagation_vs_oracle(n, d, L, B, act, per_batch, form, recon_config):
     """`form`: the forward kernel runs on the f16 matrix cores with two-term operands (the default where S % 4 == 0, S <= 160,
     C <= 96), on the fp32 matrix cores with the channel states in registers per wave (S <= 144) / in LDS per workgroup, or
     (opt-in) on the bf16 matrix cores with three-term split operands."""
-    monkeypatch.setenv("RECON_PROP_FWD", {"f16x2": "h", "block": "b", "wave": "w", "bf16x3": "x"}[form])
+    recon_config("RECON_PROP_FWD", {"f16x2": "h", "block": "b", "wave": "w", "bf16x3": "x"}[form])
     from recon_amd.propagation import build_block_adjacency, propagate, make_start_embedding, get_head_indices, get_tail_indices
     d_ = dev()
     C, S, dd = n * (n - 1), 2 * d * n, 2 * d

@@ -3,6 +3,7 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tools.secondary import _time
+from recon_amd import _lib
 from recon_amd.propagation import propagate, make_start_embedding, get_head_indices, get_tail_indices
 
 if __name__ == "__main__":
@@ -27,7 +28,7 @@ if __name__ == "__main__":
         propagate(adjs, h0, "relu", head, tail).backward(G)
     ref = None
     for cfg in (sys.argv[1:] or ["a", "b", "c", "d", "e"]):
-        os.environ["RECON_BGEMM_CFG"] = cfg
+        _lib.config_set("RECON_BGEMM_CFG", cfg)
         with torch.no_grad():
             out = propagate(adjs, h0.detach(), "relu", head, tail)
         if ref is None:
