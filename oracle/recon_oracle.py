@@ -163,6 +163,19 @@ def spkbgat_forward(entity_embeddings, relation_embeddings, batch_entities, edge
 
 
 # ------------------------------------------------------------------------------- stage-A batch builders
+def batch_gat_loss(train_indices, entity_embed, relation_embed, valid_invalid_ratio_gat=2, margin=1.0):
+    """GAT/main.py:344-376 with gat_loss_func = nn.MarginRankingLoss(margin) (:470 of the same file builds it): the positive triples,
+    repeated 2 * ratio times, against the corrupted copies behind them; L1 norm of head + relation - tail; target y = -1."""
+    reps = int(valid_invalid_ratio_gat) * 2
+    n_pos = int(train_indices.shape[0] / (reps + 1))                                        # :345-346
+    pos = train_indices[:n_pos].repeat(reps, 1)                                             # :348-351
+    neg = train_indices[n_pos:]
+    pos_norm = torch.norm(entity_embed[pos[:, 0]] + relation_embed[pos[:, 1]] - entity_embed[pos[:, 2]], p=1, dim=1)      # :353-358
+    neg_norm = torch.norm(entity_embed[neg[:, 0]] + relation_embed[neg[:, 1]] - entity_embed[neg[:, 2]], p=1, dim=1)      # :360-365
+    y = -torch.ones(reps * n_pos, dtype=pos_norm.dtype)                                     # :367-370
+    return torch.nn.functional.margin_ranking_loss(pos_norm, neg_norm, y, margin=margin)    # :372
+
+
 def kg_graph(adj_indices, adj_values):
     """Corpus.get_graph (GAT/create_batch.py:708-732): graph[source][target] = [relations...] in insertion order;
     adj_indices [2,T] has the TARGET in row 0 and the SOURCE in row 1 (GAT/preprocess.py: rows = e2, cols = e1)."""

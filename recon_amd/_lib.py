@@ -193,6 +193,8 @@ SYMBOLS = [
     ("recon_sgemm_bx3_tn_workspace_bytes", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     ("recon_sgemm_bx3_tn", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32,
                                      C.c_void_p, C.c_void_p]),
+    ("recon_transe_margin_fwd", C.c_int, [c_f32p, c_f32p, c_i64p, C.c_int64, C.c_int32, C.c_int32, C.c_float, c_f32p, c_f32p, c_i64p, c_i64p, C.c_void_p, C.c_void_p]),
+    ("recon_transe_margin_bwd", C.c_int, [c_f32p, c_f32p, c_i64p, C.c_int64, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     ("recon_config_set", C.c_int, [C.c_char_p, C.c_char_p]),
     ("recon_config_get", C.c_char_p, [C.c_char_p]),
     ("recon_hx2_aux_bytes", C.c_size_t, []),

@@ -131,6 +131,11 @@ constexpr int B_PIECES = B_TILE_BYTES / 1024;                    // 26 pieces of
 // on out_att-sized products in isolation, 3-8 % slower inside the layer's step at K = 200 / 600.  By elimination on the
 // projection shape: 59.5 us in full, 49.6 without the epilogue stores, 48.1 without A loads, 50.4 without B copies, 33.0 for
 // MFMAs + fragment reads + barriers alone.)
+// Round 5, measured and not kept: A's fragments requested TWO K tiles ahead (a second register set; the A stream is latency bound by
+// Little's law — 16 KB of requests in flight per workgroup, 2 per CU, 256 CUs = 8 MB per ~3 us round trip = 2.7 TB/s) with the B copies
+// hidden from the compiler and one counted wait + raw barrier per tile: the unrolled loop needs 256 registers + 252 bytes of scratch
+// (scratch loads inside the K loop) against 198 for this form — the 2 x 13 accumulator tiles (104) leave no room for a second A set at two
+// waves per SIMD.
 // NW waves per workgroup: 4 (128 rows, two workgroups per CU: the layer's K = 200 / 600 products) or 8 (256 rows, one workgroup per
 // CU: every B tile copied into LDS serves twice the rows — out_att-sized products, K >= 1024, where the copies of B and the re-reads
 // of A through L2 are what the loop waits for).
@@ -228,13 +233,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) k_gemm_hx2(const Hx2
     load_a(0);
     // the operands' scales (32 amax slots each): read here, under the first tile's round trip, not in front of the stores
     const float ia = hx2_inv(hx2_scale_wave(p.sa)), ib = hx2_inv(hx2_scale_wave(p.sb));
-    // per-row scales of A (rows past M re-read the last row; they are never stored)
-    float rsc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            rsc[i][r] = p.row_inv ? p.row_inv[bz * p.row_inv_bs + min(m0 + mb + 16 * i + 4 * lq + r, p.M - 1)] : 1.f;
+
     take_a();
     __syncthreads();
     int buf = 0;
@@ -248,10 +247,14 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) k_gemm_hx2(const Hx2
         __syncthreads();
         buf ^= 1;
     }
+    // per-row scales of A (rows past M re-read the last row; they are never stored).  Requested here, behind the loop: eight more live
+    // registers across the K loop cost 15 of the loop's 256 (213 against 198)
+    float rsc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rsc[i][r] *= ia * ib;
+        for (int r = 0; r < 4; ++r)
+            rsc[i][r] = (p.row_inv ? p.row_inv[bz * p.row_inv_bs + min(m0 + mb + 16 * i + 4 * lq + r, p.M - 1)] : 1.f) * (ia * ib);
     if (p.c_plain) {                                                 // uniform
         if (p.epilogue == GEMM_EPI_ELU) hx2_store_plain<GEMM_EPI_ELU>(acc, p.C.base + bz * p.c_bs, p.C.S1, p.M, p.N, m0, n0, mb, li, lq, rsc);
         else hx2_store_plain<GEMM_EPI_NONE>(acc, p.C.base + bz * p.c_bs, p.C.S1, p.M, p.N, m0, n0, mb, li, lq, rsc);

@@ -623,6 +623,18 @@ def _rowsum_by_index(rows, index, n_rows):
     return out
 
 
+def _rowsum_keyed(rows, key, n_rows):
+    """_rowsum_by_index for a caller that already holds the [2, E] segment key (losses.py: written by its forward kernel)."""
+    g = prepare_graph(key, None, n_rows, rows_only=True)
+    out = torch.empty(n_rows, rows.shape[1], dtype=torch.float32, device=rows.device)
+    L = _lib.lib()
+    ws = torch.empty(L.recon_spmm_rowsum_workspace_floats(g.E, rows.shape[1]), dtype=torch.float32, device=rows.device)
+    with _lib.on_device(rows.device):
+        _lib.check(L.recon_spmm_rowsum_fwd(C.byref(g.c), rows.data_ptr(), rows.shape[1], out.data_ptr(), ws.data_ptr(), _lib.current_stream()),
+                   "recon_spmm_rowsum_fwd")
+    return out
+
+
 def gat_path_for(N, E, F_, R, D, H):
     """Which formulation gat_heads uses: 'atp' (aggregate, then project) when instantiated for the shape and
     the graph is not much sparser than its node set, else 'proj' (project, then aggregate).  RECON_GAT_PATH /

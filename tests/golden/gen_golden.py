@@ -19,6 +19,7 @@ Reference entry points executed (unmodified, imported from where they lie):
   utils/context_utils.py:387-426    make_start_entity_embeddings
   GAT/create_batch.py:391-436, 708-732, 788-895  Corpus.get_graph / bfs / get_further_neighbors /
                            get_batch_adj_data / get_batch_nhop_neighbors_all
+  GAT/main.py:344-376    batch_gat_loss (the function's source is cut out of the file at generation time and executed)
 
 Shims (live in a temp dir, never in the repo): a directory with `RECON ->
 /root/reference` (models/models.py:6 imports `RECON.parsing...`), a stub `nltk`
@@ -695,6 +696,37 @@ def gen_gpgnn():
         save("gcn1_" + tag, **arrays)
 
 
+def gen_loss():
+    """N1: batch_gat_loss (GAT/main.py:344-376) + nn.MarginRankingLoss.  main.py trains at import time, so the function's OWN source is
+    cut out of the file where it lies (ast, at generation time — nothing of it is stored) and executed against a stub `args` / CUDA = False."""
+    import ast
+    path = os.path.join(REF, "GAT", "main.py")
+    src = open(path).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "batch_gat_loss")
+    code = "\n".join(src.split("\n")[fn.lineno - 1:fn.end_lineno])
+    for name, (n_ent, n_rel, D, n_pos, ratio, margin, seed) in (("loss1_small", (9, 3, 8, 5, 2, 1.0, 0)), ("loss2_wide", (40, 6, 200, 33, 2, 5.0, 1)),
+                                                               ("loss3_ratio1", (17, 4, 50, 12, 1, 0.5, 2))):
+        ns = {"torch": torch, "args": types.SimpleNamespace(valid_invalid_ratio_gat=ratio), "CUDA": False}
+        exec(compile(code, path, "exec"), ns)
+        rs = np.random.RandomState(seed)
+        ent = torch.from_numpy(hashed_uniform((n_ent, D), 90 + seed)).requires_grad_(True)
+        rel = torch.from_numpy(hashed_uniform((n_rel, D), 95 + seed)).requires_grad_(True)
+        pos = np.stack([rs.randint(0, n_ent, n_pos), rs.randint(0, n_rel, n_pos), rs.randint(0, n_ent, n_pos)], 1)
+        neg = np.tile(pos, (2 * ratio, 1))
+        half = neg.shape[0] // 2
+        neg[:half, 0] = rs.randint(0, n_ent, half); neg[half:, 2] = rs.randint(0, n_ent, neg.shape[0] - half)
+        neg[0] = pos[0]                                              # a pair whose two norms are equal: the term sits exactly at the margin
+        tri = torch.from_numpy(np.concatenate([pos, neg]).astype(np.int64))
+        loss = ns["batch_gat_loss"](torch.nn.MarginRankingLoss(margin=margin), tri, ent, rel)
+        loss.backward()
+        save(name, entity=t2n(ent), relation=t2n(rel), train_indices=t2n(tri), ratio=np.int32(ratio), margin=np.float32(margin),
+             loss=t2n(loss), g_entity=t2n(ent.grad), g_relation=t2n(rel.grad))
+
+
+if __name__ == "__main__" and os.environ.get("RECON_GOLDEN_ONLY") == "loss":
+    gen_loss()
+    sys.exit(0)
+
 if __name__ == "__main__" and os.environ.get("RECON_GOLDEN_ONLY") == "formats":
     gen_formats()
     sys.exit(0)
@@ -725,3 +757,4 @@ if __name__ == "__main__":
     gen_gpgnn()
     gen_formats()
     gen_sampler()
+    gen_loss()

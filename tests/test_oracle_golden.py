@@ -251,3 +251,17 @@ def test_kg_batch_builders_vs_reference(name):
         np.testing.assert_array_equal(O.kg_batch_nhop_neighbors(n2, ents), g["b%d_nhop" % b])
         np.testing.assert_array_equal(O.kg_batch_nhop_neighbors(n2, ents, partial_2hop=True), g["b%d_nhop_partial" % b])
     assert sum(g["b%d_nhop" % b].shape[0] for b in range(int(g["n_batches"]))) > 20        # the cases are not vacuous
+
+
+@pytest.mark.parametrize("name", ["loss1_small", "loss2_wide", "loss3_ratio1"])
+def test_batch_gat_loss_vs_reference(name):
+    """N1: the oracle's batch_gat_loss against the reference's own function (GAT/main.py:344-376, executed by gen_golden.py): loss and
+    both table gradients."""
+    g = load_golden(name)
+    ent = torch.from_numpy(g["entity"]).requires_grad_(True)
+    rel = torch.from_numpy(g["relation"]).requires_grad_(True)
+    loss = O.batch_gat_loss(torch.from_numpy(g["train_indices"]), ent, rel, int(g["ratio"]), float(g["margin"]))
+    loss.backward()
+    np.testing.assert_allclose(loss.detach().numpy(), g["loss"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ent.grad.numpy(), g["g_entity"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rel.grad.numpy(), g["g_relation"], rtol=1e-6, atol=1e-7)

@@ -92,3 +92,56 @@ def test_sampler_feeds_spkbgat():
         out_e2, out_r2, mask2 = m2(None, torch.tensor(sorted(sset | tset), device=d), (e2.to(d), t2.to(d)), q2.to(d))
     assert torch.equal(out_e, out_e2) and torch.equal(out_r, out_r2) and torch.equal(mask, mask2)
     assert torch.isfinite(out_e).all() and float(mask.sum()) == len(sset | tset)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["loss1_small", "loss2_wide", "loss3_ratio1"])
+def test_batch_gat_loss_golden(name, golden):
+    """recon_amd.losses.batch_gat_loss (one launch forward; gradient rows + two fixed-order segment sums backward) against the reference's
+    own batch_gat_loss on the same triples: loss and both table gradients; and against the fallback (the reference's op sequence on
+    gather_rows), which any other loss function takes."""
+    from recon_amd.losses import batch_gat_loss
+    g = golden(name)
+    d = torch.device("cuda:0")
+    tri = torch.from_numpy(g["train_indices"]).to(d)
+    margin, ratio = float(g["margin"]), int(g["ratio"])
+    for loss_fn in (torch.nn.MarginRankingLoss(margin=margin), lambda a, b, y: torch.nn.functional.margin_ranking_loss(a, b, y, margin=margin)):
+        ent = torch.from_numpy(g["entity"]).to(d).requires_grad_(True)
+        rel = torch.from_numpy(g["relation"]).to(d).requires_grad_(True)
+        loss = batch_gat_loss(loss_fn, tri, ent, rel, valid_invalid_ratio_gat=ratio)
+        (loss * 1.5).backward()
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), g["loss"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(ent.grad.cpu().numpy(), 1.5 * g["g_entity"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(rel.grad.cpu().numpy(), 1.5 * g["g_relation"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_batch_gat_loss_vs_oracle_at_stage_a_size_and_odd_width():
+    """Stage-A sizes (2 000 positives, 200-wide tables, ratio 2) and a width that is not a multiple of four (the scalar path); twice in a
+    row (the arrival counter must come back to zero); ids out of range raise like the reference's indexing."""
+    from recon_amd.losses import batch_gat_loss
+    from oracle import recon_oracle as O
+    d = torch.device("cuda:0")
+    for n_ent, n_rel, D, n_pos, ratio in ((14541, 237, 200, 2000, 2), (50, 7, 37, 101, 3)):
+        gen = torch.Generator().manual_seed(D)
+        ent, rel = torch.randn(n_ent, D, generator=gen), torch.randn(n_rel, D, generator=gen)
+        pos = torch.stack((torch.randint(0, n_ent, (n_pos,), generator=gen), torch.randint(0, n_rel, (n_pos,), generator=gen),
+                           torch.randint(0, n_ent, (n_pos,), generator=gen)), 1)
+        neg = pos.repeat(2 * ratio, 1)
+        neg[: neg.shape[0] // 2, 0] = torch.randint(0, n_ent, (neg.shape[0] // 2,), generator=gen)
+        neg[neg.shape[0] // 2:, 2] = torch.randint(0, n_ent, (neg.shape[0] - neg.shape[0] // 2,), generator=gen)
+        tri = torch.cat((pos, neg))
+        er, rr = ent.clone().double().requires_grad_(True), rel.clone().double().requires_grad_(True)
+        ref = O.batch_gat_loss(tri, er, rr, ratio, margin=2.0)
+        ref.backward()
+        for _ in range(2):
+            ed, rd = ent.to(d).requires_grad_(True), rel.to(d).requires_grad_(True)
+            loss = batch_gat_loss(torch.nn.MarginRankingLoss(margin=2.0), tri.to(d), ed, rd, valid_invalid_ratio_gat=ratio)
+            loss.backward()
+            np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-5)
+            np.testing.assert_allclose(ed.grad.cpu().numpy(), er.grad.float().numpy(), rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(rd.grad.cpu().numpy(), rr.grad.float().numpy(), rtol=1e-4, atol=1e-6)
+    bad = tri.clone()
+    bad[3, 2] = n_ent
+    with pytest.raises(IndexError):
+        batch_gat_loss(torch.nn.MarginRankingLoss(margin=1.0), bad.to(d), ent.to(d), rel.to(d), valid_invalid_ratio_gat=ratio)

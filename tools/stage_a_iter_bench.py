@@ -73,10 +73,9 @@ def main():
     sources_all = torch.unique(adj_idx[1])
 
     rows = None
-    if args.loss_rows == "recon":
-        from recon_amd.gat_layers import gather_rows
-        from recon_amd.graph import trust
-        rows = lambda table, index: gather_rows(table, trust(index.contiguous()))
+    fused_loss = args.loss_rows == "recon"                           # recon_amd.losses.batch_gat_loss: the reference's function as one fused op
+    from recon_amd.graph import trust
+    from recon_amd.losses import batch_gat_loss as recon_batch_gat_loss
 
     def make_batch():
         ents = sources_all[torch.randperm(sources_all.numel(), generator=g)[:args.entities]].to(dv)
@@ -88,13 +87,17 @@ def main():
         half = neg.shape[0] // 2
         neg[:half, 0] = torch.randint(0, N, (half,), device=dv)
         neg[half:, 2] = torch.randint(0, N, (neg.shape[0] - half,), device=dv)
-        return ents, (edge, edge_type), quads, torch.cat((pos, neg), dim=0)
+        # ids of the sampler's edges + randint(0, N): in range by construction (the loss does not validate them with a host round trip)
+        return ents, (edge, edge_type), quads, trust(torch.cat((pos, neg), dim=0), bound=N, rel_bound=nrel)
 
     def train_iter(batch):
         ents, adj, quads, train_indices = batch
         entity_embed, relation_embed, _ = model(None, ents, adj, quads)
         opt.zero_grad()
-        loss = batch_gat_loss(loss_fn, train_indices, entity_embed, relation_embed, args.ratio, rows)
+        if fused_loss:
+            loss = recon_batch_gat_loss(loss_fn, train_indices, entity_embed, relation_embed, valid_invalid_ratio_gat=args.ratio)
+        else:
+            loss = batch_gat_loss(loss_fn, train_indices, entity_embed, relation_embed, args.ratio, rows)
         loss.backward()
         opt.step()
         return loss.data.item()                                       # the reference reads the loss back every iteration
