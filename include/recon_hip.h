@@ -621,6 +621,36 @@ int recon_transe_margin_fwd(const float* entity, const float* relation, const in
 int recon_transe_margin_bwd(const float* entity, const float* relation, const int64_t* triples, int64_t n_pos, int32_t reps, int32_t D,
                             const float* terms, const float* g_loss, float* g_ent_rows, float* g_rel_rows, recon_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * N1  the stage-A batch builders on the device: Corpus.get_batch_adj_data (GAT/create_batch.py:391-436) and
+ * Corpus.get_batch_nhop_neighbors_all (:871-895) over the 2-hop neighbourhoods that Corpus.bfs / get_further_neighbors (:788-869) precompute
+ * on the host.  The knowledge graph is the grouped CSR recon_amd.sampler.KGNeighbourSampler builds once: (source, target) pairs grouped
+ * by source in order of first appearance, the relations of a pair contiguous in insertion order.  All ids int64, device memory.
+ *
+ * recon_kg_adj_count: per batch position its number of edges nrel [B]; the LAST workgroup scans them (rel_off [B], totals[0] = E) and
+ *   compacts the marks into the sorted unique entity / target id lists (uniq_ent, uniq_tgt: room for num_entities ids; totals[1], totals[2]
+ *   = their lengths).  ent_mark / tgt_mark: num_entities zeroed bytes each, handed back zeroed; counter: one zeroed uint32, handed back zero.
+ * recon_kg_adj_fill: edge int64 [2][E] (row 0 targets, row 1 sources) and edge_type [E], after the caller has read E.
+ * recon_kg_nhop: write = 0 counts the quadruples of every source (qcount [S], quad_off [S], total[0]), write = 1 writes them
+ *   (quads int64 [total][4] = source, first relation source -> parent, first relation parent -> target, target) in BFS discovery order.
+ *   One wave per source, its visited set as a bitmap in LDS (recon_kg_nhop_lds_bytes; RECON_ERR_UNSUPPORTED beyond a CU's LDS). */
+typedef struct recon_kg {
+    int64_t num_entities;
+    const int64_t* pair_ptr;        /* [num_entities + 1] pairs of source s: [pair_ptr[s], pair_ptr[s + 1]) */
+    const int64_t* pair_tgt;        /* [P] */
+    const int64_t* pair_first_rel;  /* [P] first relation of the pair */
+    const uint8_t* not_loop;        /* [P] 0 for (s, s) pairs */
+    const int64_t* rel_ptr;         /* [P + 1] relations of pair p: [rel_ptr[p], rel_ptr[p + 1]) */
+    const int64_t* rel_sorted;      /* [T] */
+} recon_kg;
+size_t recon_kg_nhop_lds_bytes(int64_t num_entities);
+int recon_kg_adj_count(const recon_kg* kg, const int64_t* entities, int32_t B, int64_t* nrel, uint8_t* ent_mark, uint8_t* tgt_mark,
+                       int64_t* rel_off, int64_t* uniq_ent, int64_t* uniq_tgt, int64_t* totals, uint32_t* counter, recon_stream_t stream);
+int recon_kg_adj_fill(const recon_kg* kg, const int64_t* entities, int32_t B, const int64_t* rel_off, int64_t E, int64_t* edge,
+                      int64_t* edge_type, recon_stream_t stream);
+int recon_kg_nhop(const recon_kg* kg, const int64_t* sources, int32_t S, int32_t partial_2hop, int32_t write, int64_t* qcount, int64_t* quad_off,
+                  int64_t* quads, int64_t* total, uint32_t* counter, recon_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,11 @@ class PropB16BwdArgs(C.Structure):
                 ("g_identity", C.c_void_p), ("diag_ws", C.c_void_p), ("ident_ws", c_f32p)]
 
 
+class ReconKG(C.Structure):
+    _fields_ = [("num_entities", C.c_int64), ("pair_ptr", C.c_void_p), ("pair_tgt", C.c_void_p), ("pair_first_rel", C.c_void_p),
+                ("not_loop", C.c_void_p), ("rel_ptr", C.c_void_p), ("rel_sorted", C.c_void_p)]
+
+
 class GcnArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("n", C.c_int32), ("in_features", C.c_int32), ("out_features", C.c_int32),
                 ("x", c_f32p), ("adj", c_f32p), ("weight", c_f32p), ("bias", c_f32p), ("support", c_f32p),
@@ -195,6 +200,10 @@ SYMBOLS = [
                                      C.c_void_p, C.c_void_p]),
     ("recon_transe_margin_fwd", C.c_int, [c_f32p, c_f32p, c_i64p, C.c_int64, C.c_int32, C.c_int32, C.c_float, c_f32p, c_f32p, c_i64p, c_i64p, C.c_void_p, C.c_void_p]),
     ("recon_transe_margin_bwd", C.c_int, [c_f32p, c_f32p, c_i64p, C.c_int64, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    ("recon_kg_nhop_lds_bytes", C.c_size_t, [C.c_int64]),
+    ("recon_kg_adj_count", C.c_int, [C.POINTER(ReconKG), c_i64p, C.c_int32, c_i64p, C.c_void_p, C.c_void_p, c_i64p, c_i64p, c_i64p, c_i64p, C.c_void_p, C.c_void_p]),
+    ("recon_kg_adj_fill", C.c_int, [C.POINTER(ReconKG), c_i64p, C.c_int32, c_i64p, C.c_int64, c_i64p, c_i64p, C.c_void_p]),
+    ("recon_kg_nhop", C.c_int, [C.POINTER(ReconKG), c_i64p, C.c_int32, C.c_int32, C.c_int32, c_i64p, c_i64p, c_i64p, c_i64p, C.c_void_p, C.c_void_p]),
     ("recon_config_set", C.c_int, [C.c_char_p, C.c_char_p]),
     ("recon_config_get", C.c_char_p, [C.c_char_p]),
     ("recon_hx2_aux_bytes", C.c_size_t, []),

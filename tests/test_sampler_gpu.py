@@ -17,8 +17,16 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=["kernels", "torch_primitives"])
+def impl(request, monkeypatch):
+    """Both implementations of the batch builders: csrc/sampler.hip (the default) and the torch-primitive assembly."""
+    from recon_amd import sampler
+    monkeypatch.setattr(sampler, "_KERNELS", request.param == "kernels")
+    return request.param
+
+
 @pytest.mark.parametrize("name", ["sampler1_small", "sampler2_medium"])
-def test_sampler_golden(name):
+def test_sampler_golden(name, impl):
     from recon_amd.sampler import KGNeighbourSampler
     g = load_golden(name)
     sm = KGNeighbourSampler(T(g["adj_indices"]).to(dev()), T(g["adj_values"]).to(dev()), int(g["n_ent"]))
@@ -32,8 +40,9 @@ def test_sampler_golden(name):
         np.testing.assert_array_equal(sm.batch_nhop_neighbors(ents, partial_2hop=True).cpu().numpy(), g["b%d_nhop_partial" % b])
 
 
-@pytest.mark.parametrize("Ne,Tn,n_rel,B,seed", [(500, 6000, 20, 128, 5), (3000, 9000, 237, 128, 6), (40, 2000, 3, 40, 7), (64, 0, 4, 8, 8)])
-def test_sampler_vs_oracle_random(Ne, Tn, n_rel, B, seed):
+@pytest.mark.parametrize("Ne,Tn,n_rel,B,seed", [(500, 6000, 20, 128, 5), (3000, 9000, 237, 128, 6), (40, 2000, 3, 40, 7), (64, 0, 4, 8, 8),
+                                                (2000, 60000, 50, 700, 9)])
+def test_sampler_vs_oracle_random(Ne, Tn, n_rel, B, seed, impl):
     """Dense, sparse, tiny-and-saturated and empty graphs; batch entities in random order (as the reference iterates a shuffled list)."""
     from recon_amd.sampler import KGNeighbourSampler
     rs = np.random.RandomState(seed)
@@ -51,6 +60,14 @@ def test_sampler_vs_oracle_random(Ne, Tn, n_rel, B, seed):
     np.testing.assert_array_equal(q.cpu().numpy(), O.kg_batch_nhop_neighbors(n2, ents))
     if Tn:
         assert edge.shape[1] > 0 and q.shape[0] > 0
+    # a second batch through the same sampler: the kernels' marks and counters must have come back zeroed; duplicates in the batch
+    ents2 = rs.permutation(Ne)[:max(1, B // 3)].tolist()
+    ents2 = ents2 + ents2[:2]
+    (edge, et), (ss, ts) = sm.batch_adj_data(torch.tensor(ents2, device=dev()))
+    e2, t2, sset, tset = O.kg_batch_adj_data(n1, ents2)
+    assert torch.equal(edge.cpu(), e2) and torch.equal(et.cpu(), t2)
+    assert ss.tolist() == sorted(sset) and ts.tolist() == sorted(tset)
+    np.testing.assert_array_equal(sm.batch_nhop_neighbors(ss, partial_2hop=True).cpu().numpy(), O.kg_batch_nhop_neighbors(n2, ss.tolist(), partial_2hop=True))
 
 
 def test_sampler_rejects_bad_input():
@@ -59,6 +76,11 @@ def test_sampler_rejects_bad_input():
         KGNeighbourSampler(torch.zeros(2, 3, dtype=torch.long), torch.zeros(3, dtype=torch.long), 4)       # CPU tensors
     with pytest.raises(IndexError):
         KGNeighbourSampler(torch.tensor([[0, 5], [1, 2]], device=dev()), torch.zeros(2, dtype=torch.long, device=dev()), 4)
+    sm = KGNeighbourSampler(torch.tensor([[0, 3], [1, 2]], device=dev()), torch.zeros(2, dtype=torch.long, device=dev()), 4)
+    with pytest.raises(IndexError):                                   # an unknown entity in the batch (the reference: KeyError)
+        sm.batch_adj_data(torch.tensor([1, 4], device=dev()))
+    with pytest.raises(IndexError):
+        sm.batch_nhop_neighbors(torch.tensor([-1], device=dev()))
 
 
 def test_sampler_feeds_spkbgat():

@@ -74,7 +74,7 @@ if __name__ == "__main__":
 
     def iteration():
         mark(0)
-        ents = sources_all[torch.randperm(sources_all.numel(), generator=g)[:128]].to(dv)
+        ents = trust(sources_all[torch.randperm(sources_all.numel(), generator=g)[:128]].to(dv), bound=N)
         (edge, edge_type), (srcs, _) = sampler.batch_adj_data(ents)
         mark(1)
         quads = sampler.batch_nhop_neighbors(srcs)

@@ -78,7 +78,7 @@ def main():
     from recon_amd.losses import batch_gat_loss as recon_batch_gat_loss
 
     def make_batch():
-        ents = sources_all[torch.randperm(sources_all.numel(), generator=g)[:args.entities]].to(dv)
+        ents = trust(sources_all[torch.randperm(sources_all.numel(), generator=g)[:args.entities]].to(dv), bound=N)     # drawn from the graph's own sources
         (edge, edge_type), (srcs, _) = sampler.batch_adj_data(ents)
         quads = torch.tensor([], dtype=torch.long) if args.no_2hop else sampler.batch_nhop_neighbors(srcs)
         # training triples of the batch (head, relation, tail) + 2 * ratio corrupted copies (Corpus.get_iteration_triples_batch)
