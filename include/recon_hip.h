@@ -610,9 +610,9 @@ int recon_sgemm_hx2_tn_presplit(int32_t M, int32_t N, int32_t K, float* C, int32
  *     triples int64 [n_pos (1 + reps)][3] = (head, relation, tail): n_pos positives, then reps corrupted copies of the block
  *     (reps = 2 * valid_invalid_ratio_gat); pair j compares positive j % n_pos with negative j:
  *     loss = mean_j max(0, |e[h] + r[rel] - e[t]|_1 (positive) - |...|_1 (negative) + margin).
- * fwd: terms [pairs], loss [1]; ent_key int64 [2][4 pairs] / rel_key int64 [2][2 pairs] (optional) receive the table row of every
- * gradient row the backward writes — the segment keys of recon_spmm_rowsum_fwd (row 0 = key, row 1 = copy).  `counter` (one zeroed
- * uint32, left zero): the workgroup that arrives last adds the terms in index order.
+ * fwd (two launches): terms [pairs], loss [1]; ent_key int64 [2][4 pairs] / rel_key int64 [2][2 pairs] (optional) receive the table row of every
+ * gradient row the backward writes — the segment keys of recon_spmm_rowsum_fwd (row 0 = key, row 1 = copy).  `counter`: unused (may be NULL);
+ * one workgroup adds the terms in index order.
  * bwd: g_ent_rows [4 pairs][D] (positive heads | positive tails | negative heads | negative tails), g_rel_rows [2 pairs][D]
  * (positive | negative); the tables' gradients are their sums by key.  Ids are not range-checked (the caller validates, as for edges). */
 int recon_transe_margin_fwd(const float* entity, const float* relation, const int64_t* triples, int64_t n_pos, int32_t reps, int32_t D,

@@ -7,6 +7,7 @@
 namespace {
 
 constexpr int kTile = 1024;      // items per block per pass
+constexpr int kFoldScanBlocks = 128;   // up to this many tiles (131 072 items) the scatter kernel scans the histogram itself: a launch less per pass
 constexpr int kThreads = 256;    // 4 waves, each ranks 256 consecutive items
 
 __global__ void __launch_bounds__(kThreads) k_radix_hist(const int32_t* __restrict__ keys, int32_t n, int shift,
@@ -89,6 +90,10 @@ __global__ void __launch_bounds__(1024) k_scan_exclusive(int32_t* __restrict__ d
     }
 }
 
+// SCANNED: `blockhist` holds the exclusive scan over (digit, block) (k_scan_exclusive ran in front).  Otherwise it holds the raw per-block
+// digit counts and every workgroup derives its own bases from them — digit t's total over all blocks, the digits' exclusive scan, plus
+// digit t's counts of the blocks in front of this one: nblocks loads per thread instead of a launch (kFoldScanBlocks: where that is cheap).
+template <bool SCANNED>
 __global__ void __launch_bounds__(kThreads) k_radix_scatter(const int32_t* __restrict__ keys_in,
                                                             const int32_t* __restrict__ vals_in,
                                                             int32_t* __restrict__ keys_out,
@@ -96,6 +101,7 @@ __global__ void __launch_bounds__(kThreads) k_radix_scatter(const int32_t* __res
                                                             const int32_t* __restrict__ blockhist_scanned,
                                                             int32_t nblocks) {
     __shared__ int32_t wcount[4][256];
+    __shared__ int32_t dig[256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 4 * 256; i += kThreads) (&wcount[0][0])[i] = 0;
     __syncthreads();
@@ -126,7 +132,23 @@ __global__ void __launch_bounds__(kThreads) k_radix_scatter(const int32_t* __res
     __syncthreads();
     {   // thread t owns digit t: global base of this block + exclusive prefix over the 4 waves
         const int t = threadIdx.x;
-        int32_t run = blockhist_scanned[t * nblocks + blockIdx.x];
+        int32_t run;
+        if constexpr (SCANNED) {
+            run = blockhist_scanned[t * nblocks + blockIdx.x];
+        } else {
+            int32_t tot = 0, before = 0;
+            const int32_t* row = blockhist_scanned + t * nblocks;
+            for (int b = 0; b < nblocks; ++b) { const int32_t c = row[b]; tot += c; before += b < static_cast<int>(blockIdx.x) ? c : 0; }
+            dig[t] = tot;
+            __syncthreads();
+            for (int off = 1; off < 256; off <<= 1) {                    // Hillis-Steele inclusive scan over the digits
+                const int32_t v = (t >= off) ? dig[t - off] : 0;
+                __syncthreads();
+                dig[t] += v;
+                __syncthreads();
+            }
+            run = dig[t] - tot + before;
+        }
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) { int32_t c = wcount[ww][t]; wcount[ww][t] = run; run += c; }
     }
@@ -172,9 +194,12 @@ int radix_sort_pairs(SortWs& ws, int32_t n, int32_t key_range, int32_t** kout, i
         if (p == passes - 1) { if (kfinal) ko = kfinal; if (vfinal) vo = vfinal; }
         if (p > 0 || !first_hist_done)
             hipLaunchKernelGGL(k_radix_hist, dim3(ws.nblocks), dim3(kThreads), 0, st, ki, n, shift, ws.hist, ws.nblocks);
-        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, ws.hist, 256 * ws.nblocks);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(ws.nblocks), dim3(kThreads), 0, st, ki, vi, ko, vo, n, shift, ws.hist,
-                           ws.nblocks);
+        if (ws.nblocks <= kFoldScanBlocks) {
+            hipLaunchKernelGGL((k_radix_scatter<false>), dim3(ws.nblocks), dim3(kThreads), 0, st, ki, vi, ko, vo, n, shift, ws.hist, ws.nblocks);
+        } else {
+            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, ws.hist, 256 * ws.nblocks);
+            hipLaunchKernelGGL((k_radix_scatter<true>), dim3(ws.nblocks), dim3(kThreads), 0, st, ki, vi, ko, vo, n, shift, ws.hist, ws.nblocks);
+        }
         int32_t* t;
         t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
@@ -192,6 +217,11 @@ __global__ void __launch_bounds__(1024) k_hub_scan(const int32_t* __restrict__ r
                                                    int32_t* __restrict__ hub_node, int32_t* __restrict__ hub_ptr, int4* __restrict__ piece) {
     __shared__ int32_t sh[1024], sp[1024];
     const int t = threadIdx.x;
+    if (!FILL && blockIdx.x == 1) {                                      // count form, second workgroup: the other row pointer rides in `piece`
+        rowptr = reinterpret_cast<const int32_t*>(piece);
+        counts += 2;
+        if (!rowptr) { if (t == 0) { counts[0] = 0; counts[1] = 0; } return; }
+    }
     const int per = (N + 1023) / 1024;                                   // every thread owns `per` consecutive nodes
     const int lo = min(t * per, N), hi = min(lo + per, N);
     int h = 0, p = 0;
@@ -225,6 +255,144 @@ __global__ void __launch_bounds__(1024) k_hub_scan(const int32_t* __restrict__ r
     } else if (t == 1023) { counts[0] = sh[t]; counts[1] = sp[t]; }
 }
 
+// ---- the whole build of a SMALL graph in ONE launch (E <= kSmallE, N <= kSmallN): the chain of 14 launches above is a chain of turn-arounds on
+// the device and ~0.1 ms of launch work on the host per graph.  One workgroup of 16 waves:
+//   counts[key] in LDS -> exclusive scan -> rowptr;   then the stable LSD radix sort, a pass = every wave counts the digits of ITS
+//   contiguous segment (LDS), one scan over (digit, wave), and every wave walks its segment again in order, 64 items a round, ranking
+//   equal digits with ballots (as k_radix_scatter) — positions are a pure function of the input: the same tables on every run.
+// Buffers written in one pass are read in the next by other waves of the same workgroup (same CU, behind a barrier).
+// Measured on the stage-A batches (E = 17 k .. 34 k): 86 us rows-only / 239 us with the source view against ~35 / ~75 us for the chain —
+// one workgroup is latency bound on its scattered stores — so the limit sits where the one launch still wins (E <= 8 192: ~15 us).
+constexpr int kSmallE = 8192, kSmallN = 32768, kSmallUnroll = 8;
+
+// (kA, vA) is the input; the passes ping-pong between the two buffer pairs, the last one writes (k_final, v_final)
+__device__ __forceinline__ void small_sort(int32_t E, int passes, int32_t* kA, int32_t* vA, int32_t* kB, int32_t* vB, int32_t* k_final, int32_t* v_final,
+                                           int32_t* wc, int32_t* part) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int seg = ((E + 15) / 16 + 63) & ~63;                          // items per wave, a multiple of 64
+    const int lo = w * seg, hi = min(E, lo + seg);
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int32_t* ki = kA; const int32_t* vi = vA;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * p;
+        int32_t* ko = (p == passes - 1) ? k_final : ((p & 1) ? kA : kB);
+        int32_t* vo = (p == passes - 1) ? v_final : ((p & 1) ? vA : vB);
+        for (int i = t; i < 4096; i += 1024) wc[i] = 0;
+        __syncthreads();
+        // (rounds of 64 items, kSmallUnroll rounds' loads in flight together: one round per dependent load made this kernel a chain of
+        // ~250 L2 round trips — 0.1 ms per graph, slower than the launches it replaces)
+        for (int i0 = lo; i0 < hi; i0 += 64 * kSmallUnroll) {
+            int32_t kk[kSmallUnroll];
+#pragma unroll
+            for (int u = 0; u < kSmallUnroll; ++u) { const int i = i0 + 64 * u + lane; kk[u] = i < hi ? ki[i] : -1; }
+#pragma unroll
+            for (int u = 0; u < kSmallUnroll; ++u) if (kk[u] >= 0) atomicAdd(&wc[((kk[u] >> shift) & 255) * 16 + w], 1);      // [digit][wave]
+        }
+        __syncthreads();
+        {   // exclusive scan over the 4 096 (digit, wave) counters: four per thread
+            int32_t c[4], s = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { c[j] = wc[4 * t + j]; s += c[j]; }
+            int32_t x = s;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_up(x, off, 64); if (lane >= off) x += o; }
+            if (lane == 63) part[w] = x;
+            __syncthreads();
+            int32_t base = 0;
+            for (int i = 0; i < w; ++i) base += part[i];
+            int32_t run = base + x - s;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wc[4 * t + j] = run; run += c[j]; }
+        }
+        __syncthreads();
+        for (int j0 = lo; j0 < hi; j0 += 64 * kSmallUnroll) {            // wave-uniform trip counts
+          int32_t kk[kSmallUnroll], vv[kSmallUnroll];
+#pragma unroll
+          for (int u = 0; u < kSmallUnroll; ++u) { const int i = j0 + 64 * u + lane; kk[u] = i < hi ? ki[i] : 0; vv[u] = i < hi ? vi[i] : 0; }
+#pragma unroll
+          for (int u = 0; u < kSmallUnroll; ++u) {
+            const int i0 = j0 + 64 * u;
+            if (i0 >= hi) break;
+            const int i = i0 + lane;
+            const bool valid = i < hi;
+            const int32_t key = kk[u], val = vv[u];
+            const int digit = (key >> shift) & 255;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (digit >> b) & 1;
+                const unsigned long long m = __ballot(valid && bit);
+                peers &= bit ? m : ~m;
+            }
+            if (valid) {
+                const int32_t prior = wc[digit * 16 + w];               // every peer reads before the leader adds (one wave: LDS operations in order)
+                const int rank = __popcll(peers & lt);
+                if (rank == 0) wc[digit * 16 + w] = prior + __popcll(peers);
+                ko[prior + rank] = key;
+                vo[prior + rank] = val;
+            }
+          }
+        }
+        __syncthreads();
+        ki = ko; vi = vo;
+    }
+}
+
+template <bool WITH_SRC>
+__global__ void __launch_bounds__(1024) k_graph_build_small(const int64_t* __restrict__ edge_dst, const int64_t* __restrict__ edge_src, int32_t N, int32_t E,
+                                                             int32_t* __restrict__ rowptr_dst, int32_t* __restrict__ eid, int32_t* __restrict__ src_out,
+                                                             int32_t* __restrict__ dst_out, int32_t* __restrict__ rowptr_src,
+                                                             int32_t* __restrict__ slot_by_src, int32_t* __restrict__ kA, int32_t* __restrict__ vA,
+                                                             int32_t* __restrict__ kB, int32_t* __restrict__ vB) {
+    extern __shared__ int32_t lds_i[];
+    int32_t* wc = lds_i;                                                // [256][16]
+    int32_t* part = lds_i + 4096;                                       // [16] (+ padding)
+    int32_t* counts = lds_i + 4096 + 64;                                // [N + 1]
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    int bits = 1;
+    while (bits < 31 && (1 << bits) < N) ++bits;
+    const int passes = (bits + 7) / 8;
+    const int per = (N + 1 + 1023) / 1024;                              // counters per thread in the scans below
+    for (int side = 0; side < (WITH_SRC ? 2 : 1); ++side) {
+        int32_t* rowptr = side ? rowptr_src : rowptr_dst;
+        for (int i = t; i <= N; i += 1024) counts[i] = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < E; i0 += 1024 * kSmallUnroll) {
+            int32_t k[kSmallUnroll], e[kSmallUnroll];
+#pragma unroll
+            for (int u = 0; u < kSmallUnroll; ++u) { const int i = i0 + 1024 * u + t; e[u] = (side && i < E) ? eid[i] : i; }
+#pragma unroll
+            for (int u = 0; u < kSmallUnroll; ++u) { const int i = i0 + 1024 * u + t; k[u] = i < E ? static_cast<int32_t>(side ? edge_src[e[u]] : edge_dst[i]) : 0; }
+#pragma unroll
+            for (int u = 0; u < kSmallUnroll; ++u) {
+                const int i = i0 + 1024 * u + t;
+                if (i >= E) break;
+                if (side) src_out[i] = k[u];
+                kA[i] = k[u]; vA[i] = i;
+                atomicAdd(&counts[k[u]], 1);
+            }
+        }
+        __syncthreads();
+        {   // rowptr = exclusive scan of the counts
+            const int a = min(t * per, N + 1), b = min(a + per, N + 1);
+            int32_t s = 0;
+            for (int i = a; i < b; ++i) s += counts[i];
+            int32_t x = s;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_up(x, off, 64); if (lane >= off) x += o; }
+            if (lane == 63) part[w] = x;
+            __syncthreads();
+            int32_t base = 0;
+            for (int i = 0; i < w; ++i) base += part[i];
+            int32_t run = base + x - s;
+            for (int i = a; i < b; ++i) { rowptr[i] = run; run += counts[i]; }
+        }
+        __syncthreads();
+        if (side == 0) small_sort(E, passes, kA, vA, kB, vB, dst_out, eid, wc, part);
+        else small_sort(E, passes, kA, vA, kB, vB, (passes & 1) ? kB : kA, slot_by_src, wc, part);      // the sorted source keys are not kept: into the buffer the last pass does not read
+    }
+}
+
 }  // namespace
 
 extern "C" int recon_graph_hubs_count(const recon_graph* g, int32_t chunk, void* workspace, int32_t* counts, recon_stream_t stream) {
@@ -234,9 +402,8 @@ extern "C" int recon_graph_hubs_count(const recon_graph* g, int32_t chunk, void*
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 3)) return RECON_ERR_INVALID;
     hipStream_t st = as_stream(stream);
     int32_t* d = static_cast<int32_t*>(workspace);
-    hipLaunchKernelGGL((k_hub_scan<false>), dim3(1), dim3(1024), 0, st, g->rowptr_dst, g->N, chunk, d, nullptr, nullptr, nullptr);
-    if (g->rowptr_src) hipLaunchKernelGGL((k_hub_scan<false>), dim3(1), dim3(1024), 0, st, g->rowptr_src, g->N, chunk, d + 2, nullptr, nullptr, nullptr);
-    else if (hipMemsetAsync(d + 2, 0, 2 * sizeof(int32_t), st) != hipSuccess) return RECON_ERR_LAUNCH;
+    // workgroup 0 counts the destination side, workgroup 1 the source side (or writes zeros): one launch
+    hipLaunchKernelGGL((k_hub_scan<false>), dim3(2), dim3(1024), 0, st, g->rowptr_dst, g->N, chunk, d, nullptr, nullptr, reinterpret_cast<int4*>(g->rowptr_src));
     RECON_CHECK_LAUNCH();
     if (hipMemcpyAsync(counts, d, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
         return RECON_ERR_LAUNCH;
@@ -301,6 +468,17 @@ extern "C" int recon_graph_build(const int64_t* edge_dst, const int64_t* edge_sr
     ws.hist = reinterpret_cast<int32_t*>(w + 4 * e);
     ws.nblocks = static_cast<int32_t>(ceil_div64(E, kTile));
     const dim3 nb(static_cast<unsigned>(ceil_div64(N + 1, 256)));
+    if (E <= kSmallE && N <= kSmallN && recon::cfg_char(recon::CFG_GRAPH_SMALL) != '0') {       // one launch (k_graph_build_small)
+        const size_t lds = (4096 + 64 + static_cast<size_t>(N) + 1) * sizeof(int32_t);
+        const void* kern = with_src ? reinterpret_cast<const void*>(k_graph_build_small<true>) : reinterpret_cast<const void*>(k_graph_build_small<false>);
+        if (lds > 48 * 1024 && hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return RECON_ERR_LAUNCH;
+        if (with_src) hipLaunchKernelGGL((k_graph_build_small<true>), dim3(1), dim3(1024), lds, st, edge_dst, edge_src, N, E, g->rowptr_dst, g->eid, g->src, g->dst,
+                                         g->rowptr_src, g->slot_by_src, ws.kA, ws.vA, ws.kB, ws.vB);
+        else hipLaunchKernelGGL((k_graph_build_small<false>), dim3(1), dim3(1024), lds, st, edge_dst, edge_src, N, E, g->rowptr_dst, g->eid, g->src, g->dst,
+                                g->rowptr_src, g->slot_by_src, ws.kA, ws.vA, ws.kB, ws.vB);
+        RECON_CHECK_LAUNCH();
+        return RECON_OK;
+    }
 
     // destination CSR: stable sort of (dst, edge column)
     hipLaunchKernelGGL((k_keys_hist<false>), dim3(ws.nblocks), dim3(kThreads), 0, st, edge_dst, nullptr, E, nullptr, ws.kA, ws.vA, ws.hist, ws.nblocks);

@@ -4,9 +4,9 @@
 //     loss = mean_j max(0, pos_norm_j - neg_norm_j + margin)                                        (y = -1)
 // As the reference writes it this is 6 gathers, 4 adds, 2 norms, the ranking loss (28 launches) and, backwards, 6 sort-based index
 // gradients (~75 launches with recon_amd.gather_rows' segment sums, one CSR per gather).  Here:
-//   recon_transe_margin_fwd   ONE launch: a wave per pair j reads its six rows, writes term_j and the segment keys of the backward
-//                             (entity rows: pos heads | pos tails | neg heads | neg tails, relation rows: pos | neg); the workgroup that
-//                             finishes last adds the terms in index order (fixed order: deterministic) and divides by their number;
+//   recon_transe_margin_fwd   TWO launches: a wave per pair j reads its six rows, writes term_j and the segment keys of the backward
+//                             (entity rows: pos heads | pos tails | neg heads | neg tails, relation rows: pos | neg); one workgroup
+//                             adds the terms in index order (fixed order: deterministic) and divides by their number;
 //   recon_transe_margin_bwd   ONE launch: the six gradient rows of every pair (+- w sign(x), w = g_loss / pairs where the term is
 //                             active); the tables' gradients are then two fixed-order segment sums by key (recon_spmm_rowsum_fwd).
 #include "recon_common.h"
@@ -44,8 +44,8 @@ __device__ __forceinline__ float row_l1(const TransE& p, int64_t t, int lane, fl
     return s;
 }
 
-__global__ void __launch_bounds__(256) k_transe_margin_fwd(const TransE p, float* __restrict__ terms, float* __restrict__ loss, int64_t* __restrict__ ent_key,
-                                                            int64_t* __restrict__ rel_key, uint32_t* __restrict__ counter) {
+__global__ void __launch_bounds__(256) k_transe_margin_fwd(const TransE p, float* __restrict__ terms, int64_t* __restrict__ ent_key,
+                                                            int64_t* __restrict__ rel_key) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t j = static_cast<int64_t>(blockIdx.x) * 4 + w;
     float sg[8];
@@ -67,24 +67,22 @@ __global__ void __launch_bounds__(256) k_transe_margin_fwd(const TransE p, float
             }
         }
     }
-    // ---- the workgroup that arrives last adds the terms in index order (release: stores -> fence -> ticket; acquire: ticket -> fence -> loads)
-    __shared__ uint32_t ticket;
+}
+
+// loss = mean of the terms, added in index order by ONE workgroup (fixed order: deterministic).  A launch of its own: the "last workgroup
+// reduces" form in the kernel above cost every one of its 2 128 workgroups a device-scope release fence (an L2 write-back each): 208 us
+// for a kernel whose work takes 10.
+__global__ void __launch_bounds__(256) k_transe_mean(const float* __restrict__ terms, int64_t pairs, float* __restrict__ loss) {
     __shared__ float red[256];
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) ticket = atomicAdd(counter, 1u);
-    __syncthreads();
-    if (ticket != gridDim.x - 1) return;
-    __threadfence();
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < p.pairs; i += 256) s += terms[i];       // thread t: terms t, t + 256, ... in order
+    for (int64_t i = threadIdx.x; i < pairs; i += 256) s += terms[i];          // thread t: terms t, t + 256, ... in order
     red[threadIdx.x] = s;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { loss[0] = red[0] / static_cast<float>(p.pairs); *counter = 0u; }       // the counter is ready for the next call
+    if (threadIdx.x == 0) loss[0] = red[0] / static_cast<float>(pairs);
 }
 
 // gradient rows: g_ent [4 P][D] in the key order of the forward (pos heads | pos tails | neg heads | neg tails), g_rel [2 P][D] (pos | neg)
@@ -141,10 +139,11 @@ extern "C" int recon_transe_margin_fwd(const float* entity, const float* relatio
                                        recon_stream_t stream) {
     recon::TransE p;
     if (n_pos == 0 && reps > 0 && D > 0) return RECON_ERR_INVALID;      // the mean of nothing (the reference returns nan here)
-    if (!recon::fill(&p, entity, relation, triples, n_pos, reps, D, margin) || !terms || !loss || !counter) return RECON_ERR_INVALID;
+    if (!recon::fill(&p, entity, relation, triples, n_pos, reps, D, margin) || !terms || !loss) return RECON_ERR_INVALID;
     if (p.pairs > (1LL << 31) - 4) return RECON_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(recon::k_transe_margin_fwd, dim3(static_cast<unsigned>(ceil_div64(p.pairs, 4))), dim3(256), 0, as_stream(stream), p, terms, loss,
-                       ent_key, rel_key, counter);
+    (void)counter;
+    hipLaunchKernelGGL(recon::k_transe_margin_fwd, dim3(static_cast<unsigned>(ceil_div64(p.pairs, 4))), dim3(256), 0, as_stream(stream), p, terms, ent_key, rel_key);
+    hipLaunchKernelGGL(recon::k_transe_mean, dim3(1), dim3(256), 0, as_stream(stream), terms, p.pairs, loss);
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }

@@ -110,11 +110,10 @@ __global__ void __launch_bounds__(256) k_kg_adj_fill(const KG g, const int64_t* 
 // ---- 2-hop: one wave per source with the visited set of its BFS as a bitmap in LDS (the source, its level-1 nodes, then every target as it
 // is discovered).  Parents in pair order, a parent's neighbours in pair order (their targets are distinct): first visit wins, as in
 // Corpus.bfs.  WRITE = false counts, true writes the quadruples (source, first relation source -> parent, first relation parent -> target,
-// target) from quad_off[b] on.  The count pass's last workgroup scans the counts.
+// target) from quad_off[b] on; k_kg_scan turns the counts into offsets.
 template <bool WRITE>
 __global__ void __launch_bounds__(64) k_kg_nhop(const KG g, const int64_t* __restrict__ srcs, int32_t S, int32_t partial, int64_t* __restrict__ qcount,
-                                                 int64_t* __restrict__ quad_off, int64_t* __restrict__ quads, int64_t* __restrict__ total,
-                                                 uint32_t* __restrict__ counter) {
+                                                 const int64_t* __restrict__ quad_off, int64_t* __restrict__ quads) {
     extern __shared__ uint32_t seen[];
     const int lane = threadIdx.x, b = blockIdx.x;
     const int words = static_cast<int>((g.Ne + 31) >> 5);
@@ -128,38 +127,45 @@ __global__ void __launch_bounds__(64) k_kg_nhop(const KG g, const int64_t* __res
     int64_t count = 0;
     const int64_t base = WRITE ? quad_off[b] : 0;
     const int64_t limit = WRITE ? qcount[b] : (partial ? 1 : (1LL << 62));
-    for (int64_t pa = p0; pa < p1 && count < limit; ++pa) {             // wave-uniform
-        if (!g.not_loop[pa]) continue;
-        const int64_t u = g.pair_tgt[pa], r1 = g.pair_first_rel[pa];
-        const int64_t c0 = g.pair_ptr[u], c1 = g.pair_ptr[u + 1];
-        for (int64_t cc = c0; cc < c1 && count < limit; cc += 64) {
-            const int64_t c = cc + lane;
-            bool fresh = false;
-            int64_t v = 0;
-            if (c < c1) {
-                v = g.pair_tgt[c];
-                const uint32_t bit = 1u << (v & 31);
-                fresh = !(atomicOr(&seen[v >> 5], bit) & bit);
+    // parents in batches of 64: lane i requests parent i's target, first relation and pair range (two dependent round trips per BATCH; one
+    // parent at a time they were three per parent, and a source with a few hundred parents set the kernel's time), then the batch is
+    // walked in order with the values handed round by shuffles
+    for (int64_t pb = p0; pb < p1 && count < limit; pb += 64) {
+        const int64_t pa_l = pb + lane;
+        const bool ok_l = pa_l < p1 && g.not_loop[pa_l];
+        const int64_t u_l = ok_l ? g.pair_tgt[pa_l] : 0, r1_l = ok_l ? g.pair_first_rel[pa_l] : 0;
+        const int64_t c0_l = ok_l ? g.pair_ptr[u_l] : 0, c1_l = ok_l ? g.pair_ptr[u_l + 1] : 0;
+        const int nb = static_cast<int>(min<int64_t>(64, p1 - pb));
+        for (int k = 0; k < nb && count < limit; ++k) {                  // wave-uniform
+            const int64_t c0 = __shfl(c0_l, k, 64), c1 = __shfl(c1_l, k, 64), r1 = __shfl(r1_l, k, 64);
+            for (int64_t cc = c0; cc < c1 && count < limit; cc += 64) {  // a loop parent has c0 = c1 = 0
+                const int64_t c = cc + lane;
+                bool fresh = false;
+                int64_t v = 0;
+                if (c < c1) {
+                    v = g.pair_tgt[c];
+                    const uint32_t bit = 1u << (v & 31);
+                    fresh = !(atomicOr(&seen[v >> 5], bit) & bit);      // a parent's targets are distinct: no two lanes ask for the same bit
+                }
+                const uint64_t m = __ballot(fresh);
+                const int before = __popcll(m & ((1ull << lane) - 1ull));
+                if (WRITE && fresh && count + before < limit) {
+                    int64_t* q = quads + 4 * (base + count + before);
+                    q[0] = s; q[1] = r1; q[2] = g.pair_first_rel[c]; q[3] = v;
+                }
+                count += __popcll(m);
             }
-            const uint64_t m = __ballot(fresh);
-            const int before = __popcll(m & ((1ull << lane) - 1ull));
-            if (WRITE && fresh && count + before < limit) {
-                int64_t* q = quads + 4 * (base + count + before);
-                q[0] = s; q[1] = r1; q[2] = g.pair_first_rel[c]; q[3] = v;
-            }
-            count += __popcll(m);
         }
     }
     if (WRITE) return;
     if (count > limit) count = limit;
     if (lane == 0) qcount[b] = count;
-    // last workgroup: offsets of the sources' quadruples
-    __shared__ uint32_t ticket;
-    __threadfence();
-    if (lane == 0) ticket = atomicAdd(counter, 1u);
-    __syncthreads();
-    if (ticket != gridDim.x - 1) return;
-    __threadfence();
+}
+
+// offsets of the sources' quadruples: exclusive scan of the counts by one wave (a launch of its own: "last workgroup scans" costs every
+// workgroup a device-scope fence)
+__global__ void __launch_bounds__(64) k_kg_scan(const int64_t* __restrict__ qcount, int32_t S, int64_t* __restrict__ quad_off, int64_t* __restrict__ total) {
+    const int lane = threadIdx.x;
     int64_t carry = 0;
     for (int i0 = 0; i0 < S; i0 += 64) {
         const int i = i0 + lane;
@@ -170,7 +176,7 @@ __global__ void __launch_bounds__(64) k_kg_nhop(const KG g, const int64_t* __res
         if (i < S) quad_off[i] = carry + x - v;
         carry += __shfl(x, 63, 64);
     }
-    if (lane == 0) { total[0] = carry; *counter = 0u; }
+    if (lane == 0) total[0] = carry;
 }
 
 bool kg_ok(const recon_kg* k) {
@@ -210,15 +216,19 @@ extern "C" int recon_kg_nhop(const recon_kg* kg, const int64_t* sources, int32_t
                              int64_t* quads, int64_t* total, uint32_t* counter, recon_stream_t stream) {
     if (!recon::kg_ok(kg) || S < 0) return RECON_ERR_INVALID;
     if (S == 0) return RECON_OK;
-    if (!sources || !qcount || !quad_off || (write ? !quads : (!total || !counter))) return RECON_ERR_INVALID;
+    (void)counter;
+    if (!sources || !qcount || !quad_off || (write ? !quads : !total)) return RECON_ERR_INVALID;
     const size_t lds = recon_kg_nhop_lds_bytes(kg->num_entities);
     if (lds > 160 * 1024 - 64) return RECON_ERR_UNSUPPORTED;             // the visited set of one source must fit a CU's LDS (5.2 M entities)
     const void* kern = write ? reinterpret_cast<const void*>(recon::k_kg_nhop<true>) : reinterpret_cast<const void*>(recon::k_kg_nhop<false>);
     if (lds > 48 * 1024 && hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return RECON_ERR_LAUNCH;
     if (write) hipLaunchKernelGGL(recon::k_kg_nhop<true>, dim3(static_cast<unsigned>(S)), dim3(64), lds, as_stream(stream), recon::kg_of(kg), sources, S, partial_2hop,
-                                  qcount, quad_off, quads, total, counter);
-    else hipLaunchKernelGGL(recon::k_kg_nhop<false>, dim3(static_cast<unsigned>(S)), dim3(64), lds, as_stream(stream), recon::kg_of(kg), sources, S, partial_2hop,
-                            qcount, quad_off, quads, total, counter);
+                                  qcount, quad_off, quads);
+    else {
+        hipLaunchKernelGGL(recon::k_kg_nhop<false>, dim3(static_cast<unsigned>(S)), dim3(64), lds, as_stream(stream), recon::kg_of(kg), sources, S, partial_2hop,
+                           qcount, quad_off, quads);
+        hipLaunchKernelGGL(recon::k_kg_scan, dim3(1), dim3(64), 0, as_stream(stream), qcount, S, quad_off, total);
+    }
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }

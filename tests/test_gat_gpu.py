@@ -30,11 +30,19 @@ def close(actual, desired, atol=1e-4, rel_to_max=1e-4, what=""):
 
 
 # ------------------------------------------------------------------------------- K3
-@pytest.mark.parametrize("N,E,seed", [(12, 40, 0), (1, 5, 1), (300, 5000, 2), (70000, 200000, 3), (50, 0, 4)])
-def test_graph_build(N, E, seed):
+@pytest.mark.parametrize("small", ["one_launch", "sort_chain"])
+@pytest.mark.parametrize("N,E,seed", [(12, 40, 0), (1, 5, 1), (300, 5000, 2), (70000, 200000, 3), (50, 0, 4), (14541, 8000, 5), (32768, 8192, 6), (200, 8193, 7),
+                                      (32769, 1000, 8), (3, 7000, 9)])
+def test_graph_build(N, E, seed, small, recon_config):
+    """Both builds: the one-launch kernel for small graphs (E <= 8 192, N <= 32 768) and the chain of radix-sort
+    launches (RECON_GRAPH_SMALL=0 and everything larger): one-, two- and three-digit keys, hub rows, the limits themselves."""
     from recon_amd.graph import GraphCSR
+    if small == "sort_chain":
+        recon_config("RECON_GRAPH_SMALL", "0")
     g = torch.Generator().manual_seed(seed)
     edge = torch.randint(0, N, (2, E), generator=g)
+    if E > 3000:
+        edge[0, : E // 10] = N // 2                                    # a hub row
     G = GraphCSR(edge.to(dev()), N)
     torch.cuda.synchronize()
     order = torch.sort(edge[0], stable=True).indices
