@@ -114,6 +114,10 @@ size_t recon_spmm_rowsum_workspace_floats(int32_t E, int32_t out_features);
 int recon_spmm_rowsum_fwd(const recon_graph* g, const float* edge_w /*[E,out_features]*/,
                           int32_t out_features, float* out /*[N,out_features]*/,
                           float* workspace /* recon_spmm_rowsum_workspace_floats() floats */, recon_stream_t stream);
+/* the same with `row_mod` > 0: slot e reads row (eid[e] % row_mod) of edge_w — several keys share one value row (the gradient of
+ * table[i0] + table[i1]: keys (i0 | i1), E value rows) */
+int recon_spmm_rowsum_mod_fwd(const recon_graph* g, const float* edge_w, int32_t out_features, int32_t row_mod, float* out,
+                              float* workspace, recon_stream_t stream);
 int recon_spmm_rowsum_bwd(const int64_t* edge_dst /*[E]*/, int64_t E, const float* grad_out /*[N,out]*/,
                           int32_t out_features, float* grad_edge_w /*[E,out]*/, recon_stream_t stream);
 

@@ -590,14 +590,14 @@ namespace {
 //         and the (at most two) segments that cross its range boundary to carry[wave][0 = continues from the
 //         left | 1 = continues to the right];
 // pass 2: one wave per destination that spans several ranges adds its carries in slot order.  Fixed order,
-//         no atomics.  `out` must be zeroed first (rows without edges).
+//         no atomics; rows without slots get their zeros here (no memset of `out` in front).
 // 128 slots per wave, sixteen rows in flight: a wave's walk is a chain of dependent round trips (8 of them now; 256 slots x 8 rows in
 // flight = 32 took 75 - 105 us per call whatever the width, and 100 k slots filled only 98 workgroups)
 constexpr int kSL = 128;
 template <int VEC>
 __global__ void __launch_bounds__(256) k_rowsum_walk(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ dst,
                                                      const int32_t* __restrict__ eid, const float* __restrict__ w, int32_t E,
-                                                     int32_t C, float* __restrict__ out, float* __restrict__ carry) {
+                                                     int32_t C, float* __restrict__ out, float* __restrict__ carry, int32_t row_mod) {
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int k0 = wv * kSL;
@@ -630,6 +630,7 @@ __global__ void __launch_bounds__(256) k_rowsum_walk(const int32_t* __restrict__
             const int kk = min(k + u, k1 - 1);
             d[u] = dst[kk];
             e[u] = eid[kk];
+            if (row_mod) e[u] %= row_mod;                            // several keys share one row of `w` (gather_rows_pair: key k and key k + E)
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) load_vec<VEC>(t[u], w + static_cast<int64_t>(e[u]) * C + cc);
@@ -651,7 +652,13 @@ __global__ void __launch_bounds__(256) k_rowsum_fix(const int32_t* __restrict__ 
     const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (node >= N) return;
     const int b = rowptr[node], e = rowptr[node + 1];
-    if (e <= b) return;
+    if (e <= b) {                                                   // a row without slots: its zeros (the memset launch this replaces cleared all of `out`)
+        float z[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) z[v] = 0.f;
+        for (int c = lane * VEC; c < C; c += 64 * VEC) store_vec<VEC>(out + static_cast<int64_t>(node) * C + c, z);
+        return;
+    }
     const int wa = b / kSL, wb = (e - 1) / kSL;
     if (wa == wb) return;                                           // lay inside one range: already written
     for (int c = lane * VEC; c < C; c += 64 * VEC) {
@@ -692,12 +699,19 @@ extern "C" size_t recon_spmm_rowsum_workspace_floats(int32_t E, int32_t out_feat
 
 extern "C" int recon_spmm_rowsum_fwd(const recon_graph* g, const float* edge_w, int32_t out_features, float* out,
                                      float* workspace, recon_stream_t stream) {
-    if (!g || !out || out_features <= 0 || (g->E > 0 && (!edge_w || !workspace))) return RECON_ERR_INVALID;
+    return recon_spmm_rowsum_mod_fwd(g, edge_w, out_features, 0, out, workspace, stream);
+}
+
+extern "C" int recon_spmm_rowsum_mod_fwd(const recon_graph* g, const float* edge_w, int32_t out_features, int32_t row_mod, float* out,
+                                         float* workspace, recon_stream_t stream) {
+    if (!g || !out || out_features <= 0 || row_mod < 0 || (g->E > 0 && (!edge_w || !workspace))) return RECON_ERR_INVALID;
     const int64_t total = static_cast<int64_t>(g->N) * out_features;
     if (total == 0) return RECON_OK;
     hipStream_t st = as_stream(stream);
-    (void)hipMemsetAsync(out, 0, sizeof(float) * total, st);
-    if (g->E == 0) return RECON_OK;
+    if (g->E == 0) {                                                 // no slots: every row is zero
+        if (hipMemsetAsync(out, 0, sizeof(float) * total, st) != hipSuccess) return RECON_ERR_LAUNCH;
+        return RECON_OK;
+    }
     const int C = out_features;
     const int vec = (C % 4 == 0 && al(edge_w, 16) && al(out, 16) && al(workspace, 16)) ? 4
                   : ((C % 2 == 0 && al(edge_w, 8) && al(out, 8) && al(workspace, 8)) ? 2 : 1);       // C = 50: the reference's relation width
@@ -705,13 +719,13 @@ extern "C" int recon_spmm_rowsum_fwd(const recon_graph* g, const float* edge_w, 
     dim3 grid(static_cast<unsigned>(ceil_div64(nw, 4)), static_cast<unsigned>(ceil_div64(C, 64 * vec)));
     dim3 fgrid(static_cast<unsigned>(ceil_div64(g->N, 4)));
     if (vec == 4) {
-        hipLaunchKernelGGL((k_rowsum_walk<4>), grid, dim3(256), 0, st, g->rowptr_dst, g->dst, g->eid, edge_w, g->E, C, out, workspace);
+        hipLaunchKernelGGL((k_rowsum_walk<4>), grid, dim3(256), 0, st, g->rowptr_dst, g->dst, g->eid, edge_w, g->E, C, out, workspace, row_mod);
         hipLaunchKernelGGL((k_rowsum_fix<4>), fgrid, dim3(256), 0, st, g->rowptr_dst, g->N, C, workspace, out);
     } else if (vec == 2) {
-        hipLaunchKernelGGL((k_rowsum_walk<2>), grid, dim3(256), 0, st, g->rowptr_dst, g->dst, g->eid, edge_w, g->E, C, out, workspace);
+        hipLaunchKernelGGL((k_rowsum_walk<2>), grid, dim3(256), 0, st, g->rowptr_dst, g->dst, g->eid, edge_w, g->E, C, out, workspace, row_mod);
         hipLaunchKernelGGL((k_rowsum_fix<2>), fgrid, dim3(256), 0, st, g->rowptr_dst, g->N, C, workspace, out);
     } else {
-        hipLaunchKernelGGL((k_rowsum_walk<1>), grid, dim3(256), 0, st, g->rowptr_dst, g->dst, g->eid, edge_w, g->E, C, out, workspace);
+        hipLaunchKernelGGL((k_rowsum_walk<1>), grid, dim3(256), 0, st, g->rowptr_dst, g->dst, g->eid, edge_w, g->E, C, out, workspace, row_mod);
         hipLaunchKernelGGL((k_rowsum_fix<1>), fgrid, dim3(256), 0, st, g->rowptr_dst, g->N, C, workspace, out);
     }
     RECON_CHECK_LAUNCH();

@@ -186,6 +186,61 @@ class _GatherRows(torch.autograd.Function):
         return _rowsum_by_index(grad.contiguous(), ctx.index, ctx.n_rows), None
 
 
+class _GatherRowsPair(torch.autograd.Function):
+    """table[idx[:, 0]] + table[idx[:, 1]] for idx int64 [E, 2] — the n-hop relation embedding of GAT/models.py:64-65 / :80-81
+    (`relation_embed[edge_type_nhop[:, 0]] + relation_embed[edge_type_nhop[:, 1]]`).  One gather-and-add forward; backward ONE fixed-order
+    segment sum over the 2 E keys (idx[:, 0] | idx[:, 1]) whose slot k reads gradient row k % E (recon_spmm_rowsum_mod_fwd) — as two
+    gather_rows it was two key tensors, two CSR builds, two segment sums and an add per table."""
+
+    @staticmethod
+    def forward(ctx, table, idx2):
+        _require_gpu_f32(table)
+        ctx.n_rows, ctx.idx2 = table.shape[0], idx2
+        return torch.nn.functional.embedding_bag(idx2, table, mode="sum")
+
+    @staticmethod
+    def backward(ctx, grad):
+        idx2 = ctx.idx2
+        E = idx2.shape[0]
+        grad = grad.contiguous()
+        g = prepare_graph(_pair_key(idx2), None, ctx.n_rows, rows_only=True)
+        out = torch.empty(ctx.n_rows, grad.shape[1], dtype=torch.float32, device=grad.device)
+        L = _lib.lib()
+        ws = torch.empty(L.recon_spmm_rowsum_workspace_floats(g.E, grad.shape[1]), dtype=torch.float32, device=grad.device)
+        with _lib.on_device(grad.device):
+            _lib.check(L.recon_spmm_rowsum_mod_fwd(C.byref(g.c), grad.data_ptr(), grad.shape[1], E, out.data_ptr(), ws.data_ptr(), _lib.current_stream()),
+                       "recon_spmm_rowsum_mod_fwd")
+        return out, None
+
+
+def _pair_key(idx2):
+    """[2, 2 E] segment key (idx[:, 0] | idx[:, 1]) of an [E, 2] index tensor, one per tensor (identity + version): the two tables of a SpGAT
+    forward share it, and with it the CSR that prepare_graph caches."""
+    k = ("pair", idx2.data_ptr(), idx2._version, tuple(idx2.shape), tuple(idx2.stride()))
+    hit = _KEY_CACHE.get(k)
+    if hit is None:
+        if len(_KEY_CACHE) > 16:
+            _KEY_CACHE.clear()
+        flat = idx2.t().reshape(1, -1)
+        key = flat.expand(2, -1).contiguous()
+        if trusted(idx2):
+            trust(key, bound=trust_bounds(idx2)[0])
+        hit = _KEY_CACHE[k] = (key, idx2)
+    return hit[0]
+
+
+def gather_rows_pair(table, idx2):
+    """table[idx2[:, 0]] + table[idx2[:, 1]] with a deterministic single-pass backward (see _GatherRowsPair)."""
+    if idx2.numel() and _VALIDATE_PAIR and not trusted(idx2, table.shape[0]):
+        lo, hi = torch.aminmax(idx2)
+        if int(lo) < 0 or int(hi) >= table.shape[0]:
+            raise IndexError("recon_amd: row index out of range: [%d, %d] into a table of %d rows" % (int(lo), int(hi), table.shape[0]))
+    return _GatherRowsPair.apply(table, idx2.contiguous())
+
+
+_VALIDATE_PAIR = True
+
+
 class _SmallMM(torch.autograd.Function):
     """A @ B for the models' small dense products (relation_embed.mm(W), GAT/models.py:75: 64..237 rows) on a kernel made for them
     (csrc/gemm_f32.hip k_gemm_small): the library GEMM behind torch.mm takes ~40 us for these 10-MFLOP products on MI355X (rocprofv3, full SpGAT step: 4 calls =

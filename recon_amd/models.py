@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed, gather_rows, small_mm, IndexedRows, set_weight_grad_destination
+from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed, gather_rows, gather_rows_pair, small_mm, IndexedRows, set_weight_grad_destination
 from .graph import prepare_graph, trust, trusted, trust_bounds
 
 
@@ -108,10 +108,9 @@ class SpGAT(nn.Module):
             # the relation table in place instead of an E x R copy of it
             edge_embed = IndexedRows(relation_embed, edge_type)
         if has_nhop:
-            t0, t1 = edge_type_nhop[:, 0], edge_type_nhop[:, 1]
-            if trusted(edge_type_nhop):
-                trust(t0, t1, bound=trust_bounds(edge_type_nhop)[0])      # views do not inherit the mark
-            edge_embed_nhop = gather_rows(relation_embed, t0) + gather_rows(relation_embed, t1)
+            # relation_embed[edge_type_nhop[:, 0]] + relation_embed[edge_type_nhop[:, 1]] (:64-65) as one op: one gather-and-add forward, one
+            # segment sum over both columns' keys backward (two gather_rows: two key tensors, two CSR builds, two sums and an add per table)
+            edge_embed_nhop = gather_rows_pair(relation_embed, edge_type_nhop)
         else:
             edge_embed_nhop = torch.tensor([])
         x = self.heads_forward(x, edge_list, edge_embed, edge_list_nhop, edge_embed_nhop)
@@ -119,7 +118,7 @@ class SpGAT(nn.Module):
         out_relation_1 = small_mm(relation_embed.to(self.W.dtype), self.W)    # (a reduced-precision relation table meets the fp32 parameter here)
         edge_embed = IndexedRows(out_relation_1, edge_type)               # out_relation_1[edge_type] (:79), read in place by the layer
         if has_nhop:
-            edge_embed_nhop = gather_rows(out_relation_1, t0) + gather_rows(out_relation_1, t1)
+            edge_embed_nhop = gather_rows_pair(out_relation_1, edge_type_nhop)
         else:
             edge_embed_nhop = torch.tensor([])
         x = self.out_att(x, edge_list, edge_embed, edge_list_nhop, edge_embed_nhop, elu=True)        # F.elu(out_att(...)), :86-87, in the epilogue
