@@ -655,6 +655,15 @@ int recon_kg_adj_fill(const recon_kg* kg, const int64_t* entities, int32_t B, co
 int recon_kg_nhop(const recon_kg* kg, const int64_t* sources, int32_t S, int32_t partial_2hop, int32_t write, int64_t* qcount, int64_t* quad_off,
                   int64_t* quads, int64_t* total, uint32_t* counter, recon_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * N1  the tail of SpKBGATModified (GAT/models.py:167-180) and the row normalisation of the entity table (:160):
+ *     y[r] = t / max(|t|_2, eps),  t = ew[r] + mask[r] * skip[r]        (skip, mask may be NULL: plain F.normalize(ew, p=2, dim=1); y may alias ew)
+ * norm [N] (optional) receives |t|_2 for the backward:  g_t = (g_y - y (y . g_y)) / |t|  (g_y / eps below the clamp), g_skip = mask * g_t. */
+int recon_rows_normalize_fwd(const float* ew, const float* skip, const float* mask, int64_t N, int32_t C, float eps, float* y, float* norm,
+                             recon_stream_t stream);
+int recon_rows_normalize_bwd(const float* g_y, const float* y, const float* norm, const float* mask, int64_t N, int32_t C, float eps, float* g_t,
+                             float* g_skip, recon_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

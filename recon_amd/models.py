@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
 from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed, gather_rows, gather_rows_pair, small_mm, IndexedRows, set_weight_grad_destination
 from .graph import prepare_graph, trust, trusted, trust_bounds
 
@@ -125,6 +126,45 @@ class SpGAT(nn.Module):
         return x, out_relation_1
 
 
+class _SkipMaskNormalize(torch.autograd.Function):
+    """F.normalize(ew + mask.unsqueeze(-1) * skip, p=2, dim=1) — the tail of GAT/models.py:177-180 — as one launch each way (csrc/norm.hip)."""
+
+    @staticmethod
+    def forward(ctx, ew, skip, mask):
+        ew, skip = ew.contiguous(), skip.contiguous()
+        N, Cw = ew.shape
+        y = torch.empty_like(ew)
+        norm = torch.empty(N, dtype=torch.float32, device=ew.device)
+        with _lib.on_device(ew.device):
+            _lib.check(_lib.lib().recon_rows_normalize_fwd(ew.data_ptr(), skip.data_ptr(), mask.data_ptr(), N, Cw, 1e-12, y.data_ptr(), norm.data_ptr(),
+                                                           _lib.current_stream()), "recon_rows_normalize_fwd")
+        ctx.save_for_backward(y, norm, mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, norm, mask = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, Cw = y.shape
+        gt = torch.empty_like(y)
+        gs = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        with _lib.on_device(y.device):
+            _lib.check(_lib.lib().recon_rows_normalize_bwd(gy.data_ptr(), y.data_ptr(), norm.data_ptr(), mask.data_ptr(), N, Cw, 1e-12, gt.data_ptr(),
+                                                           _lib.ptr(gs), _lib.current_stream()), "recon_rows_normalize_bwd")
+        return gt, gs, None
+
+
+def normalize_rows_(t):
+    """t <- F.normalize(t, p=2, dim=1) in place (no gradient): GAT/models.py:160, one launch."""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous()):
+        t.copy_(F.normalize(t, p=2, dim=1))
+        return t
+    with _lib.on_device(t.device):
+        _lib.check(_lib.lib().recon_rows_normalize_fwd(t.data_ptr(), None, None, t.shape[0], t.shape[1], 1e-12, t.data_ptr(), None, _lib.current_stream()),
+                   "recon_rows_normalize_fwd")
+    return t
+
+
 class SpKBGATModified(nn.Module):
     """Stage-A KB-GAT model, shaped like GAT/models.py:91-239 (same constructor, `forward` / `batch_test`
     signatures and state_dict keys: final_entity_embeddings, final_relation_embeddings, entity_embeddings,
@@ -183,11 +223,14 @@ class SpKBGATModified(nn.Module):
                                                      None, edge_list_nhop, edge_type_nhop)
         mask = torch.zeros(entity_embeddings.shape[0], device=dev)
         mask[batch_entities.to(dev)] = 1.0               # the reference takes torch.unique first (:167-170): same mask, but a host round trip
-        out_entity = small_mm(entity_embeddings, self.W_entities) + mask.unsqueeze(-1) * out_entity
+        ew = small_mm(entity_embeddings, self.W_entities)
+        if ew.dtype == torch.float32 and out_entity.dtype == torch.float32:
+            return _SkipMaskNormalize.apply(ew, out_entity, mask), out_relation, mask      # :177-180 in one launch each way
+        out_entity = ew + mask.unsqueeze(-1) * out_entity
         return F.normalize(out_entity, p=2, dim=1), out_relation, mask
 
     def forward(self, Corpus_, batch_entities, adj, train_indices_nhop):
-        self.entity_embeddings.data = F.normalize(self.entity_embeddings.data, p=2, dim=1).detach()     # :160, in place
+        normalize_rows_(self.entity_embeddings.data)                                                    # :160, in place
         out_entity, out_relation, mask = self._encode(Corpus_, self.entity_embeddings, self.relation_embeddings,
                                                       batch_entities, adj, train_indices_nhop)
         self.final_entity_embeddings.data = out_entity.data
