@@ -690,6 +690,17 @@ def _rowsum_keyed(rows, key, n_rows):
     return out
 
 
+_ONES = {}
+
+
+def _ones(n, device):
+    """A view of n ones (one read-only buffer per device, grown as needed): draw_keep asks for one per head and forward — a fill launch each."""
+    buf = _ONES.get(device)
+    if buf is None or buf.numel() < n:
+        buf = _ONES[device] = torch.ones(max(n, 1 << 16), dtype=torch.float32, device=device)
+    return buf[:n]
+
+
 def gat_path_for(N, E, F_, R, D, H):
     """Which formulation gat_heads uses: 'atp' (aggregate, then project) when instantiated for the shape and
     the graph is not much sparser than its node set, else 'proj' (project, then aggregate).  RECON_GAT_PATH /
@@ -819,7 +830,7 @@ class SpGraphAttentionLayer(nn.Module):
         """Dropout factors for the E un-normalised attention weights, drawn exactly as the reference
         draws them (one nn.Dropout call on an E-vector, GAT/layers.py:158); None in eval mode."""
         if self.training and self.dropout.p > 0:
-            return self.dropout(torch.ones(E, dtype=torch.float32, device=device)).view(1, E)
+            return self.dropout(_ones(E, device)).view(1, E)
         return None
 
     def keep_bound(self):
