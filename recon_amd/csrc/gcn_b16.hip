@@ -431,6 +431,12 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
         if (++ik >= nk) { ik = 0; ++il; }
         ib = ib + 1 == NRING ? 0 : ib + 1;
     };
+    // every layer's bias row into LDS (behind the scratch KiB): [L][kFusedNT * 16] bf16, zeros where a layer has none / past D
+    const int bias_sm = scratch + 1024;
+    for (int i = t; i < p.L * kFusedNT * 16; i += 256 * NS) {
+        const int l = i / (kFusedNT * 16), o = i - l * (kFusedNT * 16);
+        reinterpret_cast<uint16_t*>(st_sm + bias_sm)[i] = (p.bias[l] && o < D) ? p.bias[l][o] : static_cast<uint16_t>(0);
+    }
     issue();
     issue();
     // adj^T fragments (8-byte loads: n % 4 == 0, adj 8-byte aligned — checked by the host), kept for all layers
@@ -460,12 +466,15 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
     auto pack2 = [](float a, float b) { return static_cast<uint32_t>(f2bf(a)) | (static_cast<uint32_t>(f2bf(b)) << 16); };
     int cb = 0;                                                          // ring slot of the step being computed
     bool started = false;
+#ifdef RECON_STAMPS
+    uint64_t stamp[48]; int ns_ = 0;
+    stamp[ns_++] = __builtin_readcyclecounter();
+#endif
 
 #pragma unroll 1
     for (int l = 0; l < p.L; ++l) {
         const bool last = l == p.L - 1;
         const int I = l == 0 ? p.I0 : D, nks = l == 0 ? nk0 : nkh;
-        const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.bias[l] ? p.bias[l] : p.x), 0, p.bias[l] ? D * 2 : 0, 0x00020000);
         u32x2_g bvec[NTP];
         u32x4_g tailmask;
         {
@@ -488,8 +497,14 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
             // ... everybody's have, everybody is past the previous step's reads of the slab that is requested next, and (first step of a
             // layer) the image written by the previous layer's epilogue is complete
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef RECON_STAMPS
+            if (ns_ < 46) stamp[ns_++] = __builtin_readcyclecounter();
+#endif
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+#ifdef RECON_STAMPS
+            if (ns_ < 46) stamp[ns_++] = __builtin_readcyclecounter();
+#endif
             issue();
             const unsigned char* slab = st_sm + cb * SLAB;
             const u32x4_g km = ks == nks - 1 ? tailmask : allmask;
@@ -505,13 +520,14 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
             }
             cb = cb + 1 == NRING ? 0 : cb + 1;
         }
+        // the layer's bias values out of LDS (copied there once, at the start: requested here from memory, they made this point a vmcnt(0) that
+        // drained the slab ring at the end of every layer)
 #pragma unroll
-        for (int c = 0; c < NTP; ++c) bvec[c] = __builtin_amdgcn_raw_buffer_load_b64(rb, static_cast<uint32_t>((16 * (c_lo + c) + 4 * lq) * 2), 0, 0);
+        for (int c = 0; c < NTP; ++c) bvec[c] = *reinterpret_cast<const u32x2_g*>(st_sm + bias_sm + l * (kFusedNT * 32) + (16 * (c_lo + c) + 4 * lq) * 2);
         // every wave must be past its last read of the image before the result overwrites it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the bias values (and the copies in flight: the next step waits for them anyway)
-        started = false;
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int c = 0; c < NTP; ++c) {
             const bf16x8 sf = __builtin_bit_cast(bf16x8, u32x4_g{pack2(acc[0][c][0], acc[0][c][1]), pack2(acc[0][c][2], acc[0][c][3]),
@@ -539,152 +555,20 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // copies of steps past the end target this workgroup's LDS
+#ifdef RECON_STAMPS
+    stamp[ns_++] = __builtin_readcyclecounter();
+    if (blockIdx.x == 7 && t == 64) { uint64_t* o = reinterpret_cast<uint64_t*>(p.out); for (int i = 0; i < ns_; ++i) o[i] = stamp[i]; o[47] = ns_; }
+#endif
 }
 
-// The same kernel with the W^T fragments requested straight into registers (see the K loop) instead of through the LDS slab ring.
-template <int NS>
-__global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd_direct(const GcnStackK p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char st_sm[];      // activations [4 graphs][NKI][2 KiB] | scratch 1 KiB
-    constexpr int NTP = kFusedNT / NS, NW = 4 * NS, SLAB = 0, NRING = 0;
-    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int li = lane & 15, lq = lane >> 4;
-    const int gw = w & 3, g = blockIdx.x * 4 + gw;
-    const int c_lo = (w >> 2) * NTP;
-    const int n = p.n, D = p.D;
-    const int nk0 = (p.I0 + 31) >> 5, nkh = (D + 31) >> 5, nki = nk0 > nkh ? nk0 : nkh;      // K steps of layer 0 / of the others / of an image
-    unsigned char* Hg = st_sm + NRING * SLAB + gw * nki * 2048;
-    const int scratch = NRING * SLAB + 4 * nki * 2048;
-    const int64_t rows_total = static_cast<int64_t>(p.B) * n;
-    // copy lanes: LDS slot s = 64 piece + lane of a [16 rows][64 B] piece -> (row s >> 2, k group under the slot rotation of gf_lds_off)
-    const int c_row = lane >> 2, c_kq = ((lane & 3) - 2 * (c_row >> 3)) & 3;
-    // ---- x tiles of the workgroup's four graphs into the images: piece = (graph, K step, row half); rows past n and graphs past B read as zeros
-    {
-        const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0,
-                                                          static_cast<int>(min<int64_t>(rows_total * p.ldx * 2, 0x7fffffff)), 0x00020000);
-        const int npc = 4 * nk0 * 2;
-        for (int pc = w; pc < npc; pc += NW) {                          // wave-uniform
-            const int gq = pc / (2 * nk0), r = pc - gq * 2 * nk0, ks = r >> 1, half = r & 1;
-            const int gg = blockIdx.x * 4 + gq, i = 16 * half + c_row;
-            const uint32_t off = (gg < p.B && i < n) ? static_cast<uint32_t>(((static_cast<int64_t>(gg) * n + i) * p.ldx + 32 * ks + 8 * c_kq) * 2) : 0xfffffff0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(st_sm + NRING * SLAB + gq * nki * 2048 + ks * 2048 + half * 1024), 16, off, 0, 0, 0);
-        }
-    }
-    // adj^T fragments (8-byte loads: n % 4 == 0, adj 8-byte aligned — checked by the host), kept for all layers
-    bf16x8 adjf[2];
-    {
-        const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.adj), 0,
-                                                          static_cast<int>(min<int64_t>(static_cast<int64_t>(p.B) * n * n * 2, 0x7fffffff)), 0x00020000);
-        u32x2_g adjv[2][2];
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int i = 16 * it + li;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int j0 = 16 * h + 4 * lq;
-                const uint32_t base = static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * n + j0) * 2);
-                adjv[it][h] = __builtin_amdgcn_raw_buffer_load_b64(ra, (g < p.B && i < n && j0 < n) ? base : 0xfffffff0u, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) adjf[it] = __builtin_bit_cast(bf16x8, u32x4_g{adjv[it][0].x, adjv[it][0].y, adjv[it][1].x, adjv[it][1].y});
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the x tiles, adj
-    __syncthreads();
-    const u32x4_g allmask = u32x4_g{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-    const int a_rd0 = gf_lds_off(li, lq), a_rd1 = gf_lds_off(16 + li, lq);
-    const auto ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, static_cast<int>(min<int64_t>(rows_total * p.ldo * 2, 0x7fffffff)), 0x00020000);
-    auto pack2 = [](float a, float b) { return static_cast<uint32_t>(f2bf(a)) | (static_cast<uint32_t>(f2bf(b)) << 16); };
-
-#pragma unroll 1
-    for (int l = 0; l < p.L; ++l) {
-        const bool last = l == p.L - 1;
-        const int I = l == 0 ? p.I0 : D, nks = l == 0 ? nk0 : nkh;
-        const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.bias[l] ? p.bias[l] : p.x), 0, p.bias[l] ? D * 2 : 0, 0x00020000);
-        u32x2_g bvec[NTP];
-        u32x4_g tailmask;
-        {
-            const int k0 = 32 * (nks - 1) + 8 * lq;
-            uint32_t m[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) m[d] = (k0 + 2 * d < I ? 0x0000ffffu : 0u) | (k0 + 2 * d + 1 < I ? 0xffff0000u : 0u);
-            tailmask = u32x4_g{m[0], m[1], m[2], m[3]};
-        }
-        f32x4 acc[2][NTP];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int c = 0; c < NTP; ++c) acc[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // W^T fragments straight from memory (L2) into registers, one K step ahead, two register sets: no slab ring, no copy counters and
-        // no barrier inside a layer — the image is read-only until the layer's epilogue, so the sixteen waves drift apart and hide each other's
-        // round trips (the ring form ran every K step behind a barrier and a counted copy wait: 1.4 us per step of 160 cycles of MFMA).
-        // A lane's fragment of column tile c, K step ks: row 16 (c_lo + c) + li of W^T, k = 32 ks + 8 lq .. + 7; rows past the planes' end and
-        // steps past the layer's last read zeros (out-of-range offsets), which add nothing.
-        const int Ip = (I + 31) & ~31;
-        const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wt[l]), 0, D * Ip * 2, 0x00020000);
-        uint32_t wrow[NTP];
-#pragma unroll
-        for (int c = 0; c < NTP; ++c) { const int o = 16 * (c_lo + c) + li; wrow[c] = o < D ? static_cast<uint32_t>((o * Ip + 8 * lq) * 2) : 0xfffffff0u; }
-        auto load_w = [&](int ks, u32x4_g (&dst)[NTP]) {
-#pragma unroll
-            for (int c = 0; c < NTP; ++c) dst[c] = __builtin_amdgcn_raw_buffer_load_b128(rw, (ks < nks && wrow[c] != 0xfffffff0u) ? wrow[c] + 64u * ks : 0xfffffff0u, 0, 0);
-        };
-        auto step = [&](int ks, const u32x4_g (&bw)[NTP]) {
-            const int kc = ks < nks ? ks : nks - 1;                      // steps past the end: B is zero, any A will do
-            const u32x4_g km = ks == nks - 1 ? tailmask : allmask;
-            const u32x4_g c0 = *reinterpret_cast<const u32x4_g*>(Hg + kc * 2048 + a_rd0), c1 = *reinterpret_cast<const u32x4_g*>(Hg + kc * 2048 + a_rd1);
-            const bf16x8 a0 = __builtin_bit_cast(bf16x8, c0 & km), a1 = __builtin_bit_cast(bf16x8, c1 & km);
-#pragma unroll
-            for (int c = 0; c < NTP; ++c) {
-                const bf16x8 bq = __builtin_bit_cast(bf16x8, bw[c]);
-                acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq, acc[0][c], 0, 0, 0);
-                acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq, acc[1][c], 0, 0, 0);
-            }
-        };
-        u32x4_g w0[NTP], w1[NTP];                                        // (a third set, two steps ahead, spills at the 128 registers of sixteen waves per CU)
-        load_w(0, w0);
-#pragma unroll 1
-        for (int ks = 0; ks < nks; ks += 2) {
-            load_w(ks + 1, w1);
-            step(ks, w0);
-            load_w(ks + 2, w0);
-            step(ks + 1, w1);
-        }
-#pragma unroll
-        for (int c = 0; c < NTP; ++c) bvec[c] = __builtin_amdgcn_raw_buffer_load_b64(rb, static_cast<uint32_t>((16 * (c_lo + c) + 4 * lq) * 2), 0, 0);
-        // every wave must be past its last read of the image before the result overwrites it
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the bias values
-#pragma unroll
-        for (int c = 0; c < NTP; ++c) {
-            const bf16x8 sf = __builtin_bit_cast(bf16x8, u32x4_g{pack2(acc[0][c][0], acc[0][c][1]), pack2(acc[0][c][2], acc[0][c][3]),
-                                                                   pack2(acc[1][c][0], acc[1][c][1]), pack2(acc[1][c][2], acc[1][c][3])});
-            const int o0 = 16 * (c_lo + c) + 4 * lq;
-            float bv[4];
-            bv[0] = bf2f(static_cast<uint16_t>(bvec[c].x & 0xffffu)); bv[1] = bf2f(static_cast<uint16_t>(bvec[c].x >> 16));
-            bv[2] = bf2f(static_cast<uint16_t>(bvec[c].y & 0xffffu)); bv[3] = bf2f(static_cast<uint16_t>(bvec[c].y >> 16));
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, adjf[it], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                const int i = 16 * it + li;
-                float v[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { v[q] = r[q] + bv[q]; v[q] = (v[q] > 0.f && o0 + q < D) ? v[q] : 0.f; }
-                const u32x2_g pk = u32x2_g{pack2(v[0], v[1]), pack2(v[2], v[3])};
-                // the last layer's result to memory (masked by an out-of-range offset), every other one into the image (tiles past it: scratch).
-                // Rows of nodes past n hold relu(bias): the per-layer kernel never stores them and reads them back as zeros; adj's columns
-                // for them are zero (out-of-range loads), so they never reach a result
-                const uint32_t off = (last && g < p.B && i < n && o0 < p.ldo) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.ldo + o0) * 2) : 0xfffffff0u;
-                __builtin_amdgcn_raw_buffer_store_b64(pk, ro, off, 0, 0);
-                unsigned char* hd = (!last && o0 < 32 * nkh) ? Hg + (o0 >> 5) * 2048 + gf_lds_off(i, (o0 & 31) >> 3) + 2 * (o0 & 7) : st_sm + scratch;
-                *reinterpret_cast<u32x2_g*>(hd) = pk;
-            }
-        }
-        __syncthreads();                                                 // the image of the next layer is complete
-    }
-}
-
-
+// Round 5, measured and not kept (tools/probe/gcn_stack_scan.py, gcn_stack_stamps.py):
+//  * the W^T fragments requested straight into registers (no slab ring, no barrier inside a layer): 88 us against 41 — one K step of
+//    lookahead in 128 registers does not cover the round trip that two steps of LDS-DMA cover;
+//  * the kernel is bound by a workgroup's LATENCY, not by throughput: 256 graphs (64 workgroups) take 37 us, 1 024 take 43; a layer costs
+//    11.5 us = 10 K steps of ~1 800 cycles (640 of them the matrix pipe: four waves per SIMD x 10 MFMAs; the rest the barrier, the
+//    fragment reads behind it and the copy wait — cycle stamps of one wave: ~900 cycles at the barrier, ~900 from it to the next) + ~10 k
+//    cycles at each layer boundary (the epilogue's dependent MFMA -> add -> ReLU -> image write chains, four waves per SIMD).  Halving the
+//    barriers needs 64-wide K steps, whose double buffer (2 x 40 KiB) + four images (80 KiB) is exactly the CU's 160 KiB.
 // ------------------------------------------------------------------------------------------------ fused backward (n <= 32)
 // g_support = adj^T (grad_out . [out > 0])  and  g_x = g_support W^T  in ONE kernel, the mirror image of the fused forward: the small
 // product comes first here, so its operand has to be TRANSPOSED on the way in — the masked gradient tile of a graph ([32 nodes][out] bf16,
@@ -1051,15 +935,8 @@ extern "C" int recon_gcn_b16_stack_fwd(const recon_gcn_b16_stack_args* a, recon_
     k.out = static_cast<uint16_t*>(a->out); k.ldo = a->ldo;
     k.B = a->B; k.n = a->n; k.I0 = a->in_features; k.D = a->hidden; k.L = a->L; k.nt = static_cast<int32_t>(ceil_div64(a->ldo, 16));
     const int64_t nki = ((a->in_features > a->hidden ? a->in_features : a->hidden) + 31) / 32;
-    const bool direct = cfg_char(CFG_GCN_STACK_DIRECT) != '0';
-    const size_t lds = (direct ? 0ull : 3ull * kFusedNT * 16 * 64) + 4ull * nki * 2048 + 1024;
+    const size_t lds = 3ull * kFusedNT * 16 * 64 + static_cast<size_t>(kMaxStack) * kFusedNT * 32 + 4ull * nki * 2048 + 1024;
     if (lds > 160 * 1024) return RECON_ERR_UNSUPPORTED;                 // in_features > 384: layer by layer
-    if (direct) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gcn_b16_stack_fwd_direct<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        hipLaunchKernelGGL(k_gcn_b16_stack_fwd_direct<4>, dim3(static_cast<unsigned>(ceil_div64(a->B, 4))), dim3(1024), lds, as_stream(stream), k);
-        RECON_CHECK_LAUNCH();
-        return RECON_OK;
-    }
     // column parts per graph: 4 (sixteen waves per CU; nothing but accumulators and fragments lives in registers)
     const int ns = cfg_int(CFG_GCN_STACK_PARTS, 4) == 2 ? 2 : 4;
     if (ns == 4) {
