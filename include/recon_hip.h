@@ -97,6 +97,13 @@ size_t recon_graph_workspace_bytes(int32_t N, int32_t E);
 int recon_graph_hubs_count(const recon_graph* g, int32_t chunk, void* workspace /* device, 16 bytes */, int32_t* counts /* host [4] */,
                            recon_stream_t stream);
 int recon_graph_hubs_fill(const recon_graph* g, recon_stream_t stream);
+/* The same two calls with the build's range check riding along: recon_graph_build_checked sets *bad (device int32, zero on entry) when an
+ * id lies outside [0, N) — the tables are then garbage and must not be used; recon_graph_hubs_count_checked copies the flag to *bad_host in
+ * the round trip it makes anyway (the reference fails on such input with an index error: GAT/layers.py:56, torch.sparse_coo_tensor). */
+int recon_graph_build_checked(const int64_t* edge_dst, const int64_t* edge_src, recon_graph* g, void* workspace, size_t workspace_bytes,
+                              int32_t* bad, recon_stream_t stream);
+int recon_graph_hubs_count_checked(const recon_graph* g, int32_t chunk, void* workspace, int32_t* counts, const int32_t* bad, int32_t* bad_host,
+                                   recon_stream_t stream);
 /* floats of hub_ws one KB-GAT layer call (forward or backward) on this graph needs */
 size_t recon_graph_hub_ws_floats(const recon_graph* g, int32_t F, int32_t R, int32_t H);
 

@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(kThreads) k_radix_hist(const int32_t* __restri
 template <bool GATHER>
 __global__ void __launch_bounds__(kThreads) k_keys_hist(const int64_t* __restrict__ in, const int32_t* __restrict__ eid, int32_t n,
                                                         int32_t* __restrict__ src_out, int32_t* __restrict__ keys, int32_t* __restrict__ vals,
-                                                        int32_t* __restrict__ blockhist, int32_t nblocks) {
+                                                        int32_t* __restrict__ blockhist, int32_t nblocks, int32_t N, int32_t* __restrict__ bad) {
     __shared__ int32_t hist[256];
     hist[threadIdx.x] = 0;
     __syncthreads();
@@ -39,7 +39,9 @@ __global__ void __launch_bounds__(kThreads) k_keys_hist(const int64_t* __restric
     for (int j = 0; j < kTile / kThreads; ++j) {
         const int i = base + j * kThreads + threadIdx.x;
         if (i < n) {
-            const int32_t v = static_cast<int32_t>(GATHER ? in[eid[i]] : in[i]);
+            const int64_t v64 = GATHER ? in[eid[i]] : in[i];
+            if (bad && (v64 < 0 || v64 >= N)) *bad = 1;                // an id outside [0, N): reported with the hub counts (no round trip of its own)
+            const int32_t v = static_cast<int32_t>(v64);
             if (GATHER) src_out[i] = v;
             keys[i] = v; vals[i] = i;
             atomicAdd(&hist[v & 255], 1);
@@ -343,7 +345,7 @@ __global__ void __launch_bounds__(1024) k_graph_build_small(const int64_t* __res
                                                              int32_t* __restrict__ rowptr_dst, int32_t* __restrict__ eid, int32_t* __restrict__ src_out,
                                                              int32_t* __restrict__ dst_out, int32_t* __restrict__ rowptr_src,
                                                              int32_t* __restrict__ slot_by_src, int32_t* __restrict__ kA, int32_t* __restrict__ vA,
-                                                             int32_t* __restrict__ kB, int32_t* __restrict__ vB) {
+                                                             int32_t* __restrict__ kB, int32_t* __restrict__ vB, int32_t* __restrict__ bad) {
     extern __shared__ int32_t lds_i[];
     int32_t* wc = lds_i;                                                // [256][16]
     int32_t* part = lds_i + 4096;                                       // [16] (+ padding)
@@ -362,7 +364,13 @@ __global__ void __launch_bounds__(1024) k_graph_build_small(const int64_t* __res
 #pragma unroll
             for (int u = 0; u < kSmallUnroll; ++u) { const int i = i0 + 1024 * u + t; e[u] = (side && i < E) ? eid[i] : i; }
 #pragma unroll
-            for (int u = 0; u < kSmallUnroll; ++u) { const int i = i0 + 1024 * u + t; k[u] = i < E ? static_cast<int32_t>(side ? edge_src[e[u]] : edge_dst[i]) : 0; }
+            for (int u = 0; u < kSmallUnroll; ++u) {
+                const int i = i0 + 1024 * u + t;
+                const int64_t v64 = i < E ? (side ? edge_src[e[u]] : edge_dst[i]) : 0;
+                const bool oob = v64 < 0 || v64 >= N;                   // reported (`bad`), and kept away from the LDS counters
+                if (oob && bad) *bad = 1;
+                k[u] = oob ? 0 : static_cast<int32_t>(v64);
+            }
 #pragma unroll
             for (int u = 0; u < kSmallUnroll; ++u) {
                 const int i = i0 + 1024 * u + t;
@@ -396,15 +404,27 @@ __global__ void __launch_bounds__(1024) k_graph_build_small(const int64_t* __res
 }  // namespace
 
 extern "C" int recon_graph_hubs_count(const recon_graph* g, int32_t chunk, void* workspace, int32_t* counts, recon_stream_t stream) {
-    if (!g || !counts || chunk <= 0 || g->N < 0 || !g->rowptr_dst) return RECON_ERR_INVALID;
+    return recon_graph_hubs_count_checked(g, chunk, workspace, counts, nullptr, nullptr, stream);
+}
+
+extern "C" int recon_graph_hubs_count_checked(const recon_graph* g, int32_t chunk, void* workspace, int32_t* counts, const int32_t* bad, int32_t* bad_host,
+                                              recon_stream_t stream) {
+    if (!g || !counts || chunk <= 0 || g->N < 0 || !g->rowptr_dst || (bad && !bad_host)) return RECON_ERR_INVALID;
     counts[0] = counts[1] = counts[2] = counts[3] = 0;
-    if (g->N == 0 || g->E <= chunk) return RECON_OK;
+    if (bad_host) *bad_host = 0;
+    if (g->N == 0 || g->E <= chunk) {
+        if (bad && (hipMemcpyAsync(bad_host, bad, sizeof(int32_t), hipMemcpyDeviceToHost, as_stream(stream)) != hipSuccess ||
+                    hipStreamSynchronize(as_stream(stream)) != hipSuccess)) return RECON_ERR_LAUNCH;
+        return RECON_OK;
+    }
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 3)) return RECON_ERR_INVALID;
     hipStream_t st = as_stream(stream);
     int32_t* d = static_cast<int32_t*>(workspace);
     // workgroup 0 counts the destination side, workgroup 1 the source side (or writes zeros): one launch
     hipLaunchKernelGGL((k_hub_scan<false>), dim3(2), dim3(1024), 0, st, g->rowptr_dst, g->N, chunk, d, nullptr, nullptr, reinterpret_cast<int4*>(g->rowptr_src));
     RECON_CHECK_LAUNCH();
+    // the range-check flag of the build rides in the same round trip (second copy, one synchronisation)
+    if (bad && hipMemcpyAsync(bad_host, bad, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return RECON_ERR_LAUNCH;
     if (hipMemcpyAsync(counts, d, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
         return RECON_ERR_LAUNCH;
     return RECON_OK;
@@ -445,6 +465,11 @@ extern "C" size_t recon_graph_workspace_bytes(int32_t N, int32_t E) {
 
 extern "C" int recon_graph_build(const int64_t* edge_dst, const int64_t* edge_src, recon_graph* g, void* workspace,
                                  size_t workspace_bytes, recon_stream_t stream) {
+    return recon_graph_build_checked(edge_dst, edge_src, g, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int recon_graph_build_checked(const int64_t* edge_dst, const int64_t* edge_src, recon_graph* g, void* workspace,
+                                         size_t workspace_bytes, int32_t* bad, recon_stream_t stream) {
     if (!g || g->N < 0 || g->E < 0) return RECON_ERR_INVALID;
     if (!g->rowptr_dst) return RECON_ERR_INVALID;
     const bool with_src = g->rowptr_src != nullptr;                 // NULL: destination CSR only (row sums need no source view)
@@ -473,22 +498,22 @@ extern "C" int recon_graph_build(const int64_t* edge_dst, const int64_t* edge_sr
         const void* kern = with_src ? reinterpret_cast<const void*>(k_graph_build_small<true>) : reinterpret_cast<const void*>(k_graph_build_small<false>);
         if (lds > 48 * 1024 && hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return RECON_ERR_LAUNCH;
         if (with_src) hipLaunchKernelGGL((k_graph_build_small<true>), dim3(1), dim3(1024), lds, st, edge_dst, edge_src, N, E, g->rowptr_dst, g->eid, g->src, g->dst,
-                                         g->rowptr_src, g->slot_by_src, ws.kA, ws.vA, ws.kB, ws.vB);
+                                         g->rowptr_src, g->slot_by_src, ws.kA, ws.vA, ws.kB, ws.vB, bad);
         else hipLaunchKernelGGL((k_graph_build_small<false>), dim3(1), dim3(1024), lds, st, edge_dst, edge_src, N, E, g->rowptr_dst, g->eid, g->src, g->dst,
-                                g->rowptr_src, g->slot_by_src, ws.kA, ws.vA, ws.kB, ws.vB);
+                                g->rowptr_src, g->slot_by_src, ws.kA, ws.vA, ws.kB, ws.vB, bad);
         RECON_CHECK_LAUNCH();
         return RECON_OK;
     }
 
     // destination CSR: stable sort of (dst, edge column)
-    hipLaunchKernelGGL((k_keys_hist<false>), dim3(ws.nblocks), dim3(kThreads), 0, st, edge_dst, nullptr, E, nullptr, ws.kA, ws.vA, ws.hist, ws.nblocks);
+    hipLaunchKernelGGL((k_keys_hist<false>), dim3(ws.nblocks), dim3(kThreads), 0, st, edge_dst, nullptr, E, nullptr, ws.kA, ws.vA, ws.hist, ws.nblocks, N, bad);
     int32_t *ks, *vs;
     int rc = radix_sort_pairs(ws, E, N, &ks, &vs, st, g->dst, g->eid, true);
     if (rc != RECON_OK) return rc;
     hipLaunchKernelGGL(k_rowptr_lower_bound, nb, dim3(256), 0, st, g->dst, E, N, g->rowptr_dst);
     if (!with_src) { RECON_CHECK_LAUNCH(); return RECON_OK; }
     // source CSC over CSR slots: stable sort of (src of slot, slot)
-    hipLaunchKernelGGL((k_keys_hist<true>), dim3(ws.nblocks), dim3(kThreads), 0, st, edge_src, g->eid, E, g->src, ws.kA, ws.vA, ws.hist, ws.nblocks);
+    hipLaunchKernelGGL((k_keys_hist<true>), dim3(ws.nblocks), dim3(kThreads), 0, st, edge_src, g->eid, E, g->src, ws.kA, ws.vA, ws.hist, ws.nblocks, N, bad);
     rc = radix_sort_pairs(ws, E, N, &ks, &vs, st, nullptr, g->slot_by_src, true);
     if (rc != RECON_OK) return rc;
     hipLaunchKernelGGL(k_rowptr_lower_bound, nb, dim3(256), 0, st, ks, E, N, g->rowptr_src);

@@ -45,6 +45,17 @@ def trust_bounds(t):
     return (None, None) if m is None else (m[1], m[2])
 
 
+_BAD = {}
+
+
+def _bad_flag(dev):
+    """One zeroed int32 per device: the build kernels set it when they meet an id outside [0, N) (GraphCSR reads it back with the hub counts)."""
+    f = _BAD.get(dev)
+    if f is None:
+        f = _BAD[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return f
+
+
 HUB_CHUNK = 64          # RECON_HUB_CHUNK (include/recon_hip.h); 0 switches the splitting of long destination rows off (tests compare both)
 
 
@@ -63,9 +74,12 @@ class GraphCSR:
         if N >= 2 ** 31 or E >= 2 ** 31:
             raise ValueError("graph too large for int32 indices")
         dev = edge.device
-        if E > 0 and _VALIDATE and validate and not trusted(edge, N):
-            # once per cached graph (one host sync): ids outside [0, N) would be truncated to int32, sorted on too few bits
-            # and make the edge kernels read out of bounds; the reference fails on the same input (index out of range)
+        check = E > 0 and _VALIDATE and validate and not trusted(edge, N)
+        # ids outside [0, N) would be truncated to int32, sorted on too few bits and make the edge kernels read out of bounds; the reference
+        # fails on the same input (index out of range).  Full graphs with more than HUB_CHUNK edges are checked BY THE BUILD (a flag that comes
+        # back with the hub counts: no round trip of its own); everything else with one aminmax here (one host sync per cached graph).
+        in_build = check and not rows_only and HUB_CHUNK > 0 and E > HUB_CHUNK
+        if check and not in_build:
             lo, hi = torch.aminmax(edge)
             lo, hi = int(lo), int(hi)
             if lo < 0 or hi >= N:
@@ -85,9 +99,10 @@ class GraphCSR:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         self.c = _lib.ReconGraph(self.N, self.E, self.rowptr_dst.data_ptr(), self.eid.data_ptr(),
                                  _lib.ptr(self.src), self.dst.data_ptr(), _lib.ptr(self.rowptr_src), _lib.ptr(self.slot_by_src))
+        bad = _bad_flag(dev) if in_build else None
         with _lib.on_device(dev):
-            rc = L.recon_graph_build(edge[0].data_ptr(), edge[1].data_ptr(), C.byref(self.c), ws.data_ptr(),
-                                     ws_bytes, _lib.current_stream())
+            rc = L.recon_graph_build_checked(edge[0].data_ptr(), edge[1].data_ptr(), C.byref(self.c), ws.data_ptr(),
+                                             ws_bytes, _lib.ptr(bad), _lib.current_stream())
         _lib.check(rc, "recon_graph_build")
         self._eid_long = None
         self._slot_idx = {}
@@ -95,8 +110,14 @@ class GraphCSR:
         self.n_hub = self.n_piece = self.n_hub_src = self.n_piece_src = 0
         if HUB_CHUNK > 0 and E > HUB_CHUNK and not rows_only:
             cnt = (C.c_int32 * 4)()
+            bad_host = C.c_int32(0)
             with _lib.on_device(dev):
-                _lib.check(L.recon_graph_hubs_count(C.byref(self.c), HUB_CHUNK, ws.data_ptr(), cnt, _lib.current_stream()), "recon_graph_hubs_count")
+                _lib.check(L.recon_graph_hubs_count_checked(C.byref(self.c), HUB_CHUNK, ws.data_ptr(), cnt, _lib.ptr(bad), C.byref(bad_host) if bad is not None else None,
+                                                            _lib.current_stream()), "recon_graph_hubs_count")
+            if bad_host.value:
+                bad.zero_()                                             # the flag is shared by the device's builds: hand it back clear
+                lo, hi = (int(v) for v in torch.aminmax(edge))
+                raise IndexError("recon_amd: edge index out of range: ids span [%d, %d] but input has %d rows" % (lo, hi, N))
             if cnt[0] > 0 or cnt[2] > 0:
                 self.n_hub, self.n_piece, self.n_hub_src, self.n_piece_src = (int(v) for v in cnt)
                 self.c.hub_chunk = HUB_CHUNK
