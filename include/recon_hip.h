@@ -48,6 +48,10 @@ const char* recon_error_string(int code);
  * compute the same result.  recon_config_set overrides one entry (value NULL: unset), recon_config_get returns the current value or NULL.
  * Call them between launches, from the launching thread.  The reference has no counterpart (its only switch is the module-level CUDA flag,
  * GAT/layers.py:10). */
+/* Optional NaN word of a device (int32, device memory, zeroed by the caller; NULL: off): the attention kernels store 1 into it when a row sum
+ * of attention weights comes out NaN or infinite — the condition behind the reference's three `assert not torch.isnan(...)` per layer call
+ * (GAT/layers.py:147, :167, :172), without their three host round trips: nothing waits for the word, the caller reads it when it likes. */
+int recon_set_nan_flag(int32_t device, int32_t* flag);
 int recon_config_set(const char* name, const char* value);
 const char* recon_config_get(const char* name);
 

@@ -209,6 +209,7 @@ SYMBOLS = [
     ("recon_kg_nhop", C.c_int, [C.POINTER(ReconKG), c_i64p, C.c_int32, C.c_int32, C.c_int32, c_i64p, c_i64p, c_i64p, c_i64p, C.c_void_p, C.c_void_p]),
     ("recon_rows_normalize_fwd", C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_f32p, c_f32p, C.c_void_p]),
     ("recon_rows_normalize_bwd", C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_f32p, c_f32p, C.c_void_p]),
+    ("recon_set_nan_flag", C.c_int, [C.c_int32, C.c_void_p]),
     ("recon_config_set", C.c_int, [C.c_char_p, C.c_char_p]),
     ("recon_config_get", C.c_char_p, [C.c_char_p]),
     ("recon_hx2_aux_bytes", C.c_size_t, []),

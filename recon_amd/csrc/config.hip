@@ -41,6 +41,31 @@ int cfg_int(CfgKey k, int dflt) { const char* v = cfg(k); return v ? atoi(v) : d
 char cfg_char(CfgKey k) { const char* v = cfg(k); return v ? v[0] : '\0'; }
 }  // namespace recon
 
+// ---- the optional NaN flag (the reference asserts `not torch.isnan(...).any()` on edge_e, e_rowsum and h_prime, GAT/layers.py:147,167,172:
+// three device -> host round trips per layer call).  Here the attention kernels raise ONE device word per device when a row sum comes out
+// NaN / infinite (which is what every one of those asserts comes down to: the weights' sum, and Inf / Inf in the division); nobody waits
+// for it — the caller reads the word when it likes (recon_amd.gat_layers.nan_raised(), every call under RECON_DEBUG_NAN=1).
+namespace recon {
+namespace {
+int32_t* g_nan[16] = {};
+bool g_nan_any = false;
+}  // namespace
+int32_t* nan_flag() {
+    if (!g_nan_any) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    return g_nan[dev & 15];
+}
+}  // namespace recon
+
+extern "C" int recon_set_nan_flag(int32_t device, int32_t* flag) {
+    if (device < 0 || device >= 16) return RECON_ERR_INVALID;
+    recon::g_nan[device] = flag;
+    recon::g_nan_any = false;
+    for (int i = 0; i < 16; ++i) recon::g_nan_any = recon::g_nan_any || recon::g_nan[i] != nullptr;
+    return RECON_OK;
+}
+
 extern "C" int recon_config_set(const char* name, const char* value) {
     std::call_once(recon::g_once, recon::load_env);
     const int k = recon::key_of(name);

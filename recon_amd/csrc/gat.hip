@@ -37,6 +37,7 @@ struct EdgeFwdArgs {
     float* out; float* sigma; float* Z;
     int32_t N, E, D, H, ld_out, concat;
     float alpha;
+    int32_t* nan_flag;          // optional (config.hip: recon_set_nan_flag)
 };
 
 template <int VEC, int G, int KR, bool TRAIN>
@@ -113,6 +114,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_edge_fwd(const EdgeFwdArgs p) {
         }
     }
     if (Zs == 0.f) Zs = 1e-12f;                          // GAT/layers.py:152
+    if (p.nan_flag && !(fabsf(Zs) <= 3.0e38f)) *p.nan_flag = 1;     // the reference's asserts (:147, :167, :172)
     if constexpr (TRAIN) { if (lig == 0) p.Z[static_cast<int64_t>(h) * p.N + node] = Zs; }
     float* o = p.out + static_cast<int64_t>(node) * p.ld_out + h * D;
 #pragma unroll
@@ -441,6 +443,7 @@ extern "C" int recon_gat_edge_fwd(const recon_graph* g, const recon_gat_fwd_args
     p.rowptr = g->rowptr_dst; p.src = g->src; p.P = a->P; p.Q = a->Q; p.a2 = a->a_2; p.keep = a->keep;
     p.out = a->out; p.sigma = a->sigma; p.Z = a->Z;
     p.N = a->N; p.E = a->E; p.D = a->D; p.H = a->H; p.ld_out = a->ld_out; p.concat = a->concat; p.alpha = a->alpha;
+    p.nan_flag = recon::nan_flag();
     const bool a4 = al(a->P, 16) && al(a->Q, 16) && al(a->a_2, 16) && al(a->out, 16) && a->ld_out % 4 == 0;
     const bool a2ok = al(a->P, 8) && al(a->Q, 8) && al(a->a_2, 8) && al(a->out, 8) && a->ld_out % 2 == 0;
     Shape s;

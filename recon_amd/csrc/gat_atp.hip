@@ -553,6 +553,7 @@ struct AtpFwdK {
     int32_t hub_chunk, n_piece;
     const int4* piece;
     float* hubS; float* hubZ;
+    int32_t* nan_flag;          // optional device word raised when a row sum is NaN / infinite (config.hip: recon_set_nan_flag)
 };
 
 // two half planes of VEC consecutive ALREADY SCALED values: 2 * VEC bytes per plane.  Values are clamped to half's range: the
@@ -747,6 +748,7 @@ __global__ void __launch_bounds__(kBlock, KR >= 8 ? 2 : 1) k_gat_atp_fwd(const A
             return;
         }
         const float Zc = (Zl == 0.f) ? 1e-12f : Zl;                     // GAT/layers.py:152
+        if (p.nan_flag && hv && lane < HT && !(fabsf(Zc) <= 3.0e38f)) *p.nan_flag = 1;      // the reference's asserts (:147, :167, :172)
         const float inv = 1.f / Zc;
         if constexpr (TRAIN) {
             if (hv && lane < HT) { p.Z[static_cast<int64_t>(node) * H + myh] = Zc; p.Zk[static_cast<int64_t>(node) * H + myh] = Zkl; }
@@ -837,6 +839,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_hub_fwd(const AtpFwdK p, con
     for (int q = p0 + lane; q < p1; q += 64) { zl += p.hubZ[(static_cast<int64_t>(q) * 2) * H + h]; zkl += p.hubZ[(static_cast<int64_t>(q) * 2 + 1) * H + h]; }
     const float Zl = group_sum<64>(zl), Zkl = group_sum<64>(zkl);
     const float Zc = (Zl == 0.f) ? 1e-12f : Zl;                         // GAT/layers.py:152
+    if (p.nan_flag && lane == 0 && !(fabsf(Zc) <= 3.0e38f)) *p.nan_flag = 1;
     if (p.Z && lane == 0) { p.Z[static_cast<int64_t>(node) * H + h] = Zc; p.Zk[static_cast<int64_t>(node) * H + h] = Zkl; }
     const float invh = (1.f / Zc) * vscale, zk = Zkl * invh;
     float* Vr = p.V + (static_cast<int64_t>(node) * H + h) * W;
@@ -1625,6 +1628,7 @@ extern "C" int recon_gat_atp_aggregate(const recon_graph* g, const recon_gat_atp
     p.rowptr = g->rowptr_dst; p.src = g->src; p.eid = a->ee_index ? a->ee_index : g->eid;       // the row of edge_embed a slot reads
     p.x = a->x; p.ee = a->edge_embed; p.c_node = a->c_node; p.c_rel = a->c_rel; p.keep = a->keep;
     p.V = a->V; p.sigma = a->sigma; p.Z = a->Z; p.Zk = a->Zk;
+    p.nan_flag = nan_flag();
     p.N = a->N; p.E = a->E; p.F = a->F; p.R = a->R; p.H = a->H; p.alpha = a->alpha;
     p.crel_by_row = a->ee_index ? 1 : 0;
     p.planes = atp_hx2(a) ? ((a->F % 8 == 0 && a->R % 8 == 0) ? 2 : 1) : 0;

@@ -24,6 +24,7 @@ enum CfgKey { CFG_BGEMM_CFG, CFG_GCN_FUSED, CFG_GCN_FUSED_BWD, CFG_GCN_FUSED_PAR
 const char* cfg(CfgKey k);
 int cfg_int(CfgKey k, int dflt);
 char cfg_char(CfgKey k);                  // first character, '\0' when unset
+int32_t* nan_flag();                      // the calling device's NaN word (recon_set_nan_flag) or nullptr
 
 // ---- DPP cross-lane adds (VALU, no LDS traffic) -------------------------------------------
 template <int CTRL>

@@ -690,6 +690,31 @@ def _rowsum_keyed(rows, key, n_rows):
     return out
 
 
+_NAN_FLAGS = {}
+
+
+def enable_nan_flag(device):
+    """Give the attention kernels of `device` a word to raise when a row sum of attention weights comes out NaN / infinite — the condition
+    behind the reference's `assert not torch.isnan(...)` on edge_e, e_rowsum and h_prime (GAT/layers.py:147, :167, :172) — without their
+    host round trips.  Read it with nan_raised() whenever convenient (end of an epoch, next to loss.item()).  Returns the flag tensor."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    f = _NAN_FLAGS.get(idx)
+    if f is None:
+        f = _NAN_FLAGS[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+        _lib.check(_lib.lib().recon_set_nan_flag(idx, f.data_ptr()), "recon_set_nan_flag")
+    return f
+
+
+def nan_raised(device, reset=True):
+    """Whether a kernel has raised the device's NaN word since the last reset (one host round trip).  Enables the word on first use."""
+    f = enable_nan_flag(device)
+    hit = bool(int(f.item()))
+    if hit and reset:
+        f.zero_()
+    return hit
+
+
 _ONES = {}
 
 
@@ -848,8 +873,8 @@ class SpGraphAttentionLayer(nn.Module):
         keep = self.draw_keep(graph.E, input.device)
         out = gat_heads(input, ee, self.a.unsqueeze(0), self.a_2, graph, keep, self.alpha, self.concat if elu is None else bool(elu),
                         keep_max=self.keep_bound() if keep is not None else None, ee_index=ee_index)
-        if _DEBUG_NAN:                                       # the reference's asserts (:147,:167,:172)
-            assert not torch.isnan(out).any()
+        if _DEBUG_NAN:                                       # the reference's asserts (:147,:167,:172), at their price: a host round trip per call
+            assert not nan_raised(input.device) and not torch.isnan(out).any()
         return out
 
     def __repr__(self):

@@ -300,16 +300,12 @@ def _index_blocks(head, tail, dd, S, align=8):
     return hit[0]
 
 
-_KEEP_STATES = False        # tests: keep the states the last bfloat16 forward saved (the backward's ReLU mask is theirs)
-_LAST_STATES = None
-
-
 class _PropagateB16(torch.autograd.Function):
     """models/models.py:260-274 on bfloat16 tensors (csrc/prop_b16.hip): bf16 storage, fp32 accumulation, every state rounded to bf16 once
     per hop, gradients in bf16."""
 
     @staticmethod
-    def forward(ctx, h0, act, head, tail, *adjs):
+    def forward(ctx, h0, act, head, tail, want_states, *adjs):
         _req(h0, head, tail, *adjs, dtype=torch.bfloat16)
         L = len(adjs)
         adj_shapes = [tuple(a.shape) for a in adjs]
@@ -330,27 +326,27 @@ class _PropagateB16(torch.autograd.Function):
         need = any(ctx.needs_input_grad)
         args = _b16_args(B, Cn, S, L, dd, act, adjs, h0c, h0_bs, head, tail, idx_bs, out, None)
         form = _lib.lib().recon_propagate_b16_form(C.byref(args))
-        hs = torch.empty(L, B, Cn, S, dtype=torch.bfloat16, device=dev) if (need or form == 2) else None
+        hs = torch.empty(L, B, Cn, S, dtype=torch.bfloat16, device=dev) if (need or form == 2 or want_states) else None
         args.h_saved = _lib.ptr(hs)
         with _lib.on_device(dev):
             _lib.check(_lib.lib().recon_propagate_b16_fwd(C.byref(args), _lib.current_stream()), "recon_propagate_b16_fwd")
         if need:
             ctx.save_for_backward(h0c, head, tail, hs, *adjs)
             ctx.meta = (B, Cn, S, L, dd, act, h0_bs, idx_bs, tuple(h0.shape), adj_shapes)
-            if _KEEP_STATES:
-                global _LAST_STATES
-                _LAST_STATES = hs
+        if want_states:                                                   # the states H^1 .. H^L [L, B, C, S] as the forward stored them (no gradient)
+            ctx.mark_non_differentiable(hs)
+            return out, hs
         return out
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, *_unused):
         h0c, head, tail, hs, *adjs = ctx.saved_tensors
         B, Cn, S, L, dd, act, h0_bs, idx_bs, h0_shape, adj_shapes = ctx.meta
         dev = gout.device
         gout = gout.contiguous()
         if gout.data_ptr() % 16:                 # a contiguous view at an odd storage offset: the kernels read grad_out in 16-byte pieces
             gout = gout.clone()
-        g_adjs = [torch.empty(B, S, S, dtype=torch.bfloat16, device=dev) if ctx.needs_input_grad[4 + l] else None for l in range(L)]
+        g_adjs = [torch.empty(B, S, S, dtype=torch.bfloat16, device=dev) if ctx.needs_input_grad[5 + l] else None for l in range(L)]
         g_h = torch.empty(B, Cn, S, dtype=torch.bfloat16, device=dev)
         ws = torch.empty(B, Cn, S, dtype=torch.bfloat16, device=dev)
         fwd = _b16_args(B, Cn, S, L, dd, act, adjs, h0c, h0_bs, head, tail, idx_bs, gout, hs)     # `out` is unused by the backward
@@ -362,10 +358,10 @@ class _PropagateB16(torch.autograd.Function):
         g_h0 = None
         if ctx.needs_input_grad[0]:
             g_h0 = (g_h if h0_bs else g_h.sum(0, dtype=torch.float32).to(torch.bfloat16)).view(h0_shape)
-        return (g_h0, None, None, None) + tuple(g.view(sh) if g is not None else None for g, sh in zip(g_adjs, adj_shapes))
+        return (g_h0, None, None, None, None) + tuple(g.view(sh) if g is not None else None for g, sh in zip(g_adjs, adj_shapes))
 
 
-def _propagate_b16(adj_list, h0, nonlinearity, head_indices, tail_indices):
+def _propagate_b16(adj_list, h0, nonlinearity, head_indices, tail_indices, return_states=False):
     B, S = adj_list[0].shape[0], adj_list[0].shape[-1]
     Cn = h0.shape[1] if h0.dim() == 4 else h0.shape[0]
     probe = _lib.PropB16Args(B, Cn, S, len(adj_list), head_indices.shape[-1], 1, None, None, 0, None, None, 0, None, None, None, None, None)
@@ -374,17 +370,24 @@ def _propagate_b16(adj_list, h0, nonlinearity, head_indices, tail_indices):
         # shapes the bf16 kernels do not take (S % 8 != 0): bf16 storage around the float32 kernels
         out = _Propagate.apply(h0.float(), nonlinearity, head_indices, tail_indices, *[a.float() for a in adj_list])
         return out.to(torch.bfloat16)
-    return _PropagateB16.apply(h0, nonlinearity, head_indices, tail_indices, *adj_list)
+    return _PropagateB16.apply(h0, nonlinearity, head_indices, tail_indices, bool(return_states), *adj_list)
 
 
-def propagate(adj_list, h0, nonlinearity, head_indices, tail_indices):
+def propagate(adj_list, h0, nonlinearity, head_indices, tail_indices, return_states=False):
     """models/models.py:260-274.  adj_list: L tensors [B,S,S] (or [B,1,S,S] as the reference views them);
     h0 [C,S,1] shared (GPGNN) or [B,C,S,1] per batch (RECON*); nonlinearity 'relu' | 'tanh' | 'linear'
     (model_params.json "non-linear1"); head/tail_indices int64 [C,2d] or [bs,C,2d] as the reference
-    stores them.  Returns cat(relation_1..L, -1): [B, C, 2d*L]."""
+    stores them.  Returns cat(relation_1..L, -1): [B, C, 2d*L].
+    return_states (bfloat16 kernels, one launch's worth of graphs): also the states H^1 .. H^L [L, B, C, S] as the forward rounded and
+    stored them — what its backward takes the activation's derivative from (the parity tests hand them to the oracle)."""
     if nonlinearity not in _lib.ACT:
         raise NotImplementedError(nonlinearity)
     B = adj_list[0].shape[0] if adj_list else 0
+    if return_states:
+        if _float_dtype(h0, *adj_list) != torch.bfloat16 or B > _MAX_BATCH:
+            raise NotImplementedError("return_states: bfloat16 tensors, at most %d graphs" % _MAX_BATCH)
+        res = _propagate_b16(adj_list, h0, nonlinearity, head_indices, tail_indices, return_states=True)
+        return res if isinstance(res, tuple) else (res, None)          # None: the shape ran on the float32 kernels behind casts (no bf16 states)
     one = _propagate_b16 if _float_dtype(h0, *adj_list) == torch.bfloat16 else (lambda adjs, h, act, hi, ti: _Propagate.apply(h, act, hi, ti, *adjs))
     if B > _MAX_BATCH:                    # the kernels index graphs with a 16-bit grid dimension; graphs are independent: run slices
         outs = []
@@ -529,7 +532,7 @@ class _PropagateBlocksB16(torch.autograd.Function):
     blocks of every hop into d identity (fp32, fixed order, rounded once)."""
 
     @staticmethod
-    def forward(ctx, h0, identity, act, head, tail, n, *Ts):
+    def forward(ctx, h0, identity, act, head, tail, n, want_states, *Ts):
         _req(h0, identity, head, tail, *Ts, dtype=torch.bfloat16)
         L, dd, B = len(Ts), identity.shape[0], Ts[0].shape[0]
         S, Cn = n * dd, n * (n - 1)
@@ -547,13 +550,13 @@ class _PropagateBlocksB16(torch.autograd.Function):
             _lib.check(_lib.lib().recon_propagate_b16_fwd(C.byref(args), _lib.current_stream()), "recon_propagate_b16_fwd (block mode)")
         ctx.save_for_backward(h0c, identity, head, tail, hs, *Ts)
         ctx.meta = (B, Cn, S, L, dd, act, h0_bs, idx_bs, tuple(h0.shape), t_shapes)
-        if _KEEP_STATES:
-            global _LAST_STATES
-            _LAST_STATES = hs
+        if want_states:
+            ctx.mark_non_differentiable(hs)
+            return out, hs
         return out
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, *_unused):
         h0c, identity, head, tail, hs, *Ts = ctx.saved_tensors
         B, Cn, S, L, dd, act, h0_bs, idx_bs, h0_shape, t_shapes = ctx.meta
         dev = gout.device
@@ -561,7 +564,7 @@ class _PropagateBlocksB16(torch.autograd.Function):
         if gout.data_ptr() % 16:
             gout = gout.clone()
         bf = dict(dtype=torch.bfloat16, device=dev)
-        g_Ts = [torch.empty(B, Cn, dd * dd, **bf) if ctx.needs_input_grad[6 + l] else None for l in range(L)]
+        g_Ts = [torch.empty(B, Cn, dd * dd, **bf) if ctx.needs_input_grad[7 + l] else None for l in range(L)]
         g_I = torch.empty(dd, dd, **bf) if ctx.needs_input_grad[1] else None
         g_h, ws = torch.empty(B, Cn, S, **bf), torch.empty(B, Cn, S, **bf)
         Lb = _lib.lib()
@@ -577,7 +580,7 @@ class _PropagateBlocksB16(torch.autograd.Function):
         g_h0 = None
         if ctx.needs_input_grad[0]:
             g_h0 = (g_h if h0_bs else g_h.sum(0, dtype=torch.float32).to(torch.bfloat16)).view(h0_shape)
-        return (g_h0, g_I, None, None, None, None) + tuple(g.view(sh) if g is not None else None for g, sh in zip(g_Ts, t_shapes))
+        return (g_h0, g_I, None, None, None, None, None) + tuple(g.view(sh) if g is not None else None for g, sh in zip(g_Ts, t_shapes))
 
 
 def _blocks_b16_trainable(B, n, dd, h0, T_list, identity):
@@ -593,7 +596,7 @@ def _blocks_b16_trainable(B, n, dd, h0, T_list, identity):
     return _lib.lib().recon_propagate_b16_form(C.byref(probe)) != 0
 
 
-def propagate_blocks(T_list, identity, n, h0, nonlinearity, head_indices, tail_indices):
+def propagate_blocks(T_list, identity, n, h0, nonlinearity, head_indices, tail_indices, return_states=False):
     """models/models.py:240-274 in one call: T_list = L transition tensors [B, n(n-1), (2d)^2] (or [B, n-1, n, (2d)^2]) AFTER their
     non-linearity, identity [2d, 2d]; equivalent to
         propagate([build_block_adjacency(T, identity, n) for T in T_list], h0, nonlinearity, head_indices, tail_indices)
@@ -608,8 +611,12 @@ def propagate_blocks(T_list, identity, n, h0, nonlinearity, head_indices, tail_i
         if not need_grad and _blocks_b16_available(B, n, dd, h0, T_list, identity):
             return _propagate_blocks_b16(T_list, identity, n, h0, nonlinearity, head_indices, tail_indices)
         if need_grad and _blocks_b16_trainable(B, n, dd, h0, T_list, identity):
-            return _PropagateBlocksB16.apply(h0, identity, nonlinearity, head_indices, tail_indices, n, *T_list)
+            return _PropagateBlocksB16.apply(h0, identity, nonlinearity, head_indices, tail_indices, n, bool(return_states), *T_list)
+        if return_states:
+            raise NotImplementedError("return_states: the bfloat16 training form only")
         return propagate([build_block_adjacency(T, identity, n) for T in T_list], h0, nonlinearity, head_indices, tail_indices)
+    if return_states:
+        raise NotImplementedError("return_states: bfloat16 tensors only")
     ok = blocks_mode_available(B, n, dd, h0, need_grad, L=len(T_list), T_list=T_list)
     if not ok and need_grad and n > 10:
         ok = (blocks_mode_available(B, n, dd, h0, False, L=len(T_list), T_list=T_list) and identity.data_ptr() % 16 == 0 and

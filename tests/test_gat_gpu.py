@@ -1194,3 +1194,39 @@ def test_head_gradients_written_into_the_bucket():
     for att_p, att_b in zip(plain.attentions, bound.attentions):
         for pp, pbnd in ((att_p.a, att_b.a), (att_p.a_2, att_b.a_2)):
             close(pbnd.grad, ref[id(pp)], atol=1e-6, rel_to_max=1e-6, what="head gradient of two forwards under one backward")
+
+
+@pytest.mark.gpu
+def test_device_nan_flag_is_raised_without_a_round_trip():
+    """The reference asserts `not torch.isnan(...)` three times per layer call (GAT/layers.py:147, :167, :172: three host syncs); here the
+    kernels raise a device word instead and nobody waits for it.  Clean inputs leave it zero on both formulations; a NaN feature row, an
+    overflowing score (exp(-leakyrelu) = inf: the reference's h_prime = inf / inf) and a NaN weight raise it."""
+    from recon_amd import gat_layers
+    from recon_amd.gat_layers import gat_heads, nan_raised, enable_nan_flag
+    from recon_amd.graph import prepare_graph
+    d = dev()
+    enable_nan_flag(d)
+    B, n, e, F_, D, H = 4, 8, 24, 16, 16, 2
+    x, edge, ee = O.synthetic_batched_graph(B, n, e, F_, F_, seed=1)
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(H, D, 3 * F_, generator=g) * 0.1
+    a2 = torch.randn(H, D, generator=g) * 0.1
+    graph = prepare_graph(edge.to(d), None, B * n)
+    for path in ("atp", "proj"):
+        saved = gat_layers._GAT_PATH
+        gat_layers._GAT_PATH = path
+        try:
+            assert not nan_raised(d)
+            out = gat_heads(x.to(d), ee.to(d), a.to(d), a2.to(d), graph, None, 0.2, True)
+            assert torch.isfinite(out).all() and not nan_raised(d), path
+            xb = x.clone(); xb[3, 5] = float("nan")
+            gat_heads(xb.to(d), ee.to(d), a.to(d), a2.to(d), graph, None, 0.2, True)
+            assert nan_raised(d), path + ": NaN feature"
+            assert not nan_raised(d), "the word is cleared by the read"
+            gat_heads(x.to(d), ee.to(d), (a * 1e4).to(d), (a2 * 1e4).to(d), graph, None, 0.2, True)      # scores of -1e6: exp overflows
+            assert nan_raised(d), path + ": overflowing weights"
+            ab = a.clone(); ab[1, 2, 3] = float("nan")
+            gat_heads(x.to(d), ee.to(d), ab.to(d), a2.to(d), graph, None, 0.2, True)
+            assert nan_raised(d), path + ": NaN parameter"
+        finally:
+            gat_layers._GAT_PATH = saved

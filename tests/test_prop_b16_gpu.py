@@ -49,12 +49,7 @@ def _run_b16(adjs_b, h0_b, head, tail, act, Gr_b, grad=True):
     d_ = dev()
     A = [a.clone().to(d_).requires_grad_(grad) for a in adjs_b]
     h = h0_b.clone().to(d_).requires_grad_(grad)
-    P._KEEP_STATES, P._LAST_STATES = True, None
-    try:
-        out = P.propagate(A, h, act, head.to(d_), tail.to(d_))
-        states = P._LAST_STATES
-    finally:
-        P._KEEP_STATES, P._LAST_STATES = False, None
+    out, states = P.propagate(A, h, act, head.to(d_), tail.to(d_), return_states=True)
     if not grad:
         return out.detach(), None, None
     (out.float() * Gr_b.to(d_).float()).sum().backward()
@@ -210,12 +205,7 @@ def test_propagate_blocks_b16_training_vs_oracle(n, L, B, ypost, recon_config):
     Gr = _bf(torch.randn(B, C, dd * L, generator=g))
     Td = [t.to(d_).requires_grad_(True) for t in Ts]
     Id, hd = I.to(d_).requires_grad_(True), h0.to(d_).requires_grad_(True)
-    P._KEEP_STATES, P._LAST_STATES = True, None
-    try:
-        out = P.propagate_blocks([torch.relu(t) for t in Td], Id, n, hd, "relu", head.to(d_), tail.to(d_))
-        states = P._LAST_STATES
-    finally:
-        P._KEEP_STATES, P._LAST_STATES = False, None
+    out, states = P.propagate_blocks([torch.relu(t) for t in Td], Id, n, hd, "relu", head.to(d_), tail.to(d_), return_states=True)
     (out.float() * Gr.to(d_).float()).sum().backward()
     adjs = [O.build_block_adjacency(torch.relu(t.float()), I.float(), n) for t in Ts]
     ref = O.propagate(adjs, h0.float(), "relu", head, tail, as_gemm=True, storage=BF)
