@@ -379,7 +379,7 @@ def propagate(adj_list, h0, nonlinearity, head_indices, tail_indices, return_sta
     (model_params.json "non-linear1"); head/tail_indices int64 [C,2d] or [bs,C,2d] as the reference
     stores them.  Returns cat(relation_1..L, -1): [B, C, 2d*L].
     return_states (bfloat16 kernels, one launch's worth of graphs): also the states H^1 .. H^L [L, B, C, S] as the forward rounded and
-    stored them — what its backward takes the activation's derivative from (the parity tests hand them to the oracle)."""
+    stored them — what its backward takes the activation's derivative from (the parity tests compare gradients on exactly these)."""
     if nonlinearity not in _lib.ACT:
         raise NotImplementedError(nonlinearity)
     B = adj_list[0].shape[0] if adj_list else 0
