@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librecon_hip.so")
+# RECON_HIP_LIB: another build of the library (A/B of two builds in one gpurun call: tools/ab_builds.sh); default: the in-tree one
+LIB_PATH = os.environ.get("RECON_HIP_LIB") or os.path.join(_HERE, "csrc", "librecon_hip.so")
 
 ERRORS = {0: "ok", -1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failed",
           -4: "workspace too small"}

@@ -136,6 +136,7 @@ constexpr int B_PIECES = B_TILE_BYTES / 1024;                    // 26 pieces of
 // hidden from the compiler and one counted wait + raw barrier per tile: the unrolled loop needs 256 registers + 252 bytes of scratch
 // (scratch loads inside the K loop) against 198 for this form — the 2 x 13 accumulator tiles (104) leave no room for a second A set at two
 // waves per SIMD.
+// s_setprio 1 around the MFMA groups (what bought 3 % in the wide-state propagation kernels): 0.409 ms per cfg 2 step with and without.
 // NW waves per workgroup: 4 (128 rows, two workgroups per CU: the layer's K = 200 / 600 products) or 8 (256 rows, one workgroup per
 // CU: every B tile copied into LDS serves twice the rows — out_att-sized products, K >= 1024, where the copies of B and the re-reads
 // of A through L2 are what the loop waits for).
