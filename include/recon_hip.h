@@ -244,7 +244,12 @@ typedef struct {
                                  * used); summing those rows by ee_index gives the table's gradient (recon_spmm_rowsum_fwd).            */
     int32_t ee_rows;            /* rows of the table when ee_index is set (ignored otherwise).  c_rel then holds max(E, ee_rows) x H    *
                                  * floats: the score terms r.u_rel are computed once per table ROW and looked up per edge               */
+    int32_t io_bf16;            /* 1: x [N,F] and edge_embed [E,R] are BFLOAT16 (same shapes, 8-byte aligned) and the forward's kernels   *
+                                 * read them in place (BASELINE.json configs[4]: "mixed GAT+Propagation stack, bf16"; everything else     *
+                                 * of the call is unchanged: fp32 arithmetic, fp32 out).  Forward calls only (scores, aggregate,          *
+                                 * project), shapes of recon_gat_atp_bf16_io_supported(), no ee_index; the backward takes fp32 copies.    */
 } recon_gat_atp_args;
+int recon_gat_atp_bf16_io_supported(int32_t F, int32_t R, int32_t D, int32_t H);
 
 size_t recon_gat_atp_split_bytes(int32_t F, int32_t R, int32_t D, int32_t H);
 /* 1 if the RECON_SPLIT_F16X2 mode takes this shape ((2F+R) % 8 == 0, D % 8 == 0, plane offsets within 32 bits); given that,

@@ -49,7 +49,8 @@ class GatAtpArgs(C.Structure):
                 ("x", c_f32p), ("edge_embed", c_f32p), ("a", c_f32p), ("a_2", c_f32p), ("keep", c_f32p),
                 ("u", c_f32p), ("c_node", c_f32p), ("c_rel", c_f32p), ("V", c_f32p), ("sigma", c_f32p),
                 ("Z", c_f32p), ("Zk", c_f32p), ("out", c_f32p), ("ld_out", C.c_int32), ("a_split", C.c_void_p),
-                ("split_mode", C.c_int32), ("keep_max", C.c_float), ("aux", C.c_void_p), ("ee_index", c_i32p), ("ee_rows", C.c_int32)]
+                ("split_mode", C.c_int32), ("keep_max", C.c_float), ("aux", C.c_void_p), ("ee_index", c_i32p), ("ee_rows", C.c_int32),
+                ("io_bf16", C.c_int32)]
 
 
 class GatAtpBwdArgs(C.Structure):
@@ -210,6 +211,7 @@ SYMBOLS = [
     ("recon_kg_nhop", C.c_int, [C.POINTER(ReconKG), c_i64p, C.c_int32, C.c_int32, C.c_int32, c_i64p, c_i64p, c_i64p, c_i64p, C.c_void_p, C.c_void_p]),
     ("recon_rows_normalize_fwd", C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_f32p, c_f32p, C.c_void_p]),
     ("recon_rows_normalize_bwd", C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_f32p, c_f32p, C.c_void_p]),
+    ("recon_gat_atp_bf16_io_supported", C.c_int, [C.c_int32] * 4),
     ("recon_set_nan_flag", C.c_int, [C.c_int32, C.c_void_p]),
     ("recon_config_set", C.c_int, [C.c_char_p, C.c_char_p]),
     ("recon_config_get", C.c_char_p, [C.c_char_p]),

@@ -25,6 +25,27 @@ __device__ __forceinline__ int xcd_block(int b, int nb) {
     const int q = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
+// VEC consecutive elements of a feature / embedding row: float32, or (B16) bfloat16 storage widened on the way in — the layer's boundary in
+// BASELINE.json configs[4] ("mixed GAT+Propagation stack, bf16"): x and edge_embed are read as they are stored, not from up-cast copies
+template <int VEC, bool B16>
+__device__ __forceinline__ void load_in(float (&r)[VEC], const float* base, int64_t e) {
+    if constexpr (!B16) {
+        load_vec<VEC>(r, base + e);
+    } else {
+        const uint16_t* b = reinterpret_cast<const uint16_t*>(base) + e;
+        if constexpr (VEC == 4) {
+            const uint2 t = *reinterpret_cast<const uint2*>(b);
+            r[0] = __builtin_bit_cast(float, t.x << 16); r[1] = __builtin_bit_cast(float, t.x & 0xffff0000u);
+            r[2] = __builtin_bit_cast(float, t.y << 16); r[3] = __builtin_bit_cast(float, t.y & 0xffff0000u);
+        } else if constexpr (VEC == 2) {
+            const uint32_t t = *reinterpret_cast<const uint32_t*>(b);
+            r[0] = __builtin_bit_cast(float, t << 16); r[1] = __builtin_bit_cast(float, t & 0xffff0000u);
+        } else {
+            r[0] = __builtin_bit_cast(float, static_cast<uint32_t>(*b) << 16);
+        }
+    }
+}
+
 __device__ __forceinline__ float lane_bcast(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
@@ -455,6 +476,7 @@ using f32x4_t = __attribute__((ext_vector_type(4))) float;
 __device__ __host__ inline int row_dots_kp(int K) { return (K % 8 == 0) ? K + 4 : K; }
 // The last nsplit blocks write the half planes of a and a^T (hx2_split_both_block): that pass needs only what
 // the kernel in front of this one published, and as a launch of its own it cost 10 us of which 5 are kernel turn-around.
+template <bool B16>
 __global__ void __launch_bounds__(kBlock) k_row_dots_x(const RowDotsJob j0, const RowDotsJob j1, const float* __restrict__ u, int32_t H,
                                                        int32_t W, const Hx2SplitBoth sp, int32_t nsplit) {
     extern __shared__ __attribute__((aligned(16))) float U[];     // [NJ][Kp] (the launch reserves max NJ = 2 H rows)
@@ -482,7 +504,7 @@ __global__ void __launch_bounds__(kBlock) k_row_dots_x(const RowDotsJob j0, cons
     for (int tile = bid * (kBlock / 64) + wave; tile < ntiles || !staged; tile += nblocks * (kBlock / 64)) {
         const bool live = tile < ntiles;                                  // a wave without a tile still takes part in the staging
         const int row = min(tile * 16 + i, rows - 1);                    // rows past the end recompute the last row, not stored
-        const float* xr = X + static_cast<int64_t>(gather ? gather[row] : row) * K;
+        const int64_t xr = static_cast<int64_t>(gather ? gather[row] : row) * K;      // element offset of the row (the rows are float32 or bfloat16)
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         // two register batches of GU groups: batch b+1 is requested in front of batch b's MFMAs (rows wider than 256 columns —
         // out_att-sized inputs — were one dependent round trip per batch: 150 us for 262 MB)
@@ -494,8 +516,9 @@ __global__ void __launch_bounds__(kBlock) k_row_dots_x(const RowDotsJob j0, cons
                 const int c = 16 * (g0 + t) + 4 * q;
                 const bool ok = c < K;
                 cc[buf][t] = ok ? c : 0;
-                xv[buf][t] = *reinterpret_cast<const f32x4_t*>(xr + cc[buf][t]);
-                if (!ok) xv[buf][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                float xq[4];
+                load_in<4, B16>(xq, X, xr + cc[buf][t]);
+                xv[buf][t] = ok ? f32x4_t{xq[0], xq[1], xq[2], xq[3]} : f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
         };
         request(0, 0);
@@ -610,7 +633,7 @@ __device__ __forceinline__ void store_planes_paired(_Float16* hi_p, int64_t plan
 // under 160 MB of writes, not its own chain (same for 4 rows in flight instead of 2, for 4 or 2 heads per wave, for 8- or 16-byte
 // stores: 35.5 - 41 us).  Kept at 1.
 constexpr int kK1NodesPerWave = 1;
-template <int VEC, int KR, int HT, bool TRAIN, int PL>
+template <int VEC, int KR, int HT, bool TRAIN, int PL, bool B16 = false>
 __global__ void __launch_bounds__(kBlock, KR >= 8 ? 2 : 1) k_gat_atp_fwd(const AtpFwdK p) {      // KR = 8: 260 registers unbounded, one short of two waves per SIMD
     // edges in flight per wave: their rows are requested together, so a node of degree <= UNR costs ONE row round trip
     constexpr int UNR = (KR * HT >= 16 || KR >= 8) ? 1 : 2;       // KR = 8: two edges in flight are 128 registers of rows
@@ -660,7 +683,7 @@ __global__ void __launch_bounds__(kBlock, KR >= 8 ? 2 : 1) k_gat_atp_fwd(const A
         if (beg < end) { const int kk = beg + min(lane, min(64, end - beg) - 1); q.srcv = p.src[kk]; q.eidv = p.eid[kk]; }
         q.cd = p.c_node[static_cast<int64_t>(node) * 2 * H + myhc];
 #pragma unroll
-        for (int r = 0; r < KR; ++r) load_vec<VEC>(q.xi[r], p.x + static_cast<int64_t>(node) * F + cfF[r]);
+        for (int r = 0; r < KR; ++r) load_in<VEC, B16>(q.xi[r], p.x, static_cast<int64_t>(node) * F + cfF[r]);
     };
     NodeIn cur, nxt;
     request(cur, first, begs[0], ends[0]);
@@ -697,12 +720,11 @@ __global__ void __launch_bounds__(kBlock, KR >= 8 ? 2 : 1) k_gat_atp_fwd(const A
                     const int j = min(j0 + u, cn - 1);
                     const int64_t k = c0 + j;
                     const int s = __builtin_amdgcn_readlane(srcv, j), e = __builtin_amdgcn_readlane(eidv, j);
-                    const float* xr = p.x + static_cast<int64_t>(s) * F;
-                    const float* rr = p.ee + static_cast<int64_t>(e) * R;
+                    const int64_t xr = static_cast<int64_t>(s) * F, rr = static_cast<int64_t>(e) * R;
 #pragma unroll
                     for (int r = 0; r < KR; ++r) {
-                        load_vec<VEC>(xs[u][r], xr + cfF[r]);
-                        load_vec<VEC>(re[u][r], rr + cfR[r]);
+                        load_in<VEC, B16>(xs[u][r], p.x, xr + cfF[r]);
+                        load_in<VEC, B16>(re[u][r], p.ee, rr + cfR[r]);
                     }
                     sc[u] = cd + p.c_node[static_cast<int64_t>(s) * 2 * H + H + myhc] + p.c_rel[(p.crel_by_row ? static_cast<int64_t>(e) : k) * H + myhc];
                     kf[u] = p.keep ? p.keep[k * H + myhc] : 1.f;
@@ -823,7 +845,7 @@ __device__ __forceinline__ void sum_pieces(float (&acc)[VEC], const float* __res
 
 // The second half of a hub's forward: wave = one (hub, head).  Sums the pieces' partial sums in table order (fixed: results do not
 // depend on scheduling), normalises as the epilogue above does and writes the node's V rows, Z and Zk.  8-byte plane stores: hubs are few.
-template <int VEC, int PL>
+template <int VEC, int PL, bool B16 = false>
 __global__ void __launch_bounds__(kBlock) k_gat_atp_hub_fwd(const AtpFwdK p, const int32_t* __restrict__ hub_node, const int32_t* __restrict__ hub_ptr,
                                                             int32_t n_hub) {
     const int lane = threadIdx.x & 63;
@@ -860,7 +882,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_hub_fwd(const AtpFwdK p, con
     if (!(p.dst_shared && h > 0)) {
         for (int c = lane * VEC; c < F; c += 64 * VEC) {
             float xv[VEC];
-            load_vec<VEC>(xv, p.x + static_cast<int64_t>(node) * F + c);
+            load_in<VEC, B16>(xv, p.x, static_cast<int64_t>(node) * F + c);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) xv[v] *= zk;
             put(c, xv);
@@ -1522,6 +1544,14 @@ static bool atp_hx2(const recon_gat_atp_args* a) {
     return !((reinterpret_cast<uintptr_t>(a->a_split) & 15) || (reinterpret_cast<uintptr_t>(a->aux) & 255) || (reinterpret_cast<uintptr_t>(a->V) & 15));
 }
 extern "C" int recon_gat_atp_f16x2_supported(int32_t F, int32_t R, int32_t D, int32_t H) { return atp_hx2_shape(F, R, D, H) ? 1 : 0; }
+// bfloat16 x / edge_embed read in place by the forward (recon_gat_atp_args.io_bf16): the f16 x 2 family with 16-byte plane stores and the
+// matrix-core score dots — F % 8 == 0, R % 8 == 0, at most 8 heads
+extern "C" int recon_gat_atp_bf16_io_supported(int32_t F, int32_t R, int32_t D, int32_t H) {
+    if (!atp_hx2_shape(F, R, D, H) || (F % 8) || (R % 8) || 2 * H > 16) return 0;
+    recon::AtpShape s;
+    recon::atp_shape(F, R, H, &s);
+    return s.vec == 4 ? 1 : 0;
+}
 // The destination part of V is one row for all heads when there is no attention dropout (Zk = Z): K1' writes it for head 0 only and
 // the projection / weight-gradient GEMMs read head 0's copy for every head (52 MB less written and, twice, less read at cfg 2).
 // F % 8 == 0 so that the shared columns are whole 16-byte groups; the heads' planes lie within 2^31 elements.
@@ -1549,6 +1579,11 @@ static int atp_fwd_common(const recon_graph* g, const recon_gat_atp_args* a, Atp
     if (train && (!a->Zk || (a->E > 0 && !a->sigma))) return RECON_ERR_INVALID;
     if (a->keep && !train) return RECON_ERR_INVALID;
     atp_shape(a->F, a->R, a->H, s);
+    if (a->io_bf16) {                                               // x / edge_embed stored as bfloat16: the f16 x 2 family's forward kernels only
+        if (!recon_gat_atp_bf16_io_supported(a->F, a->R, a->D, a->H) || !atp_hx2(a) || a->ee_index) return RECON_ERR_UNSUPPORTED;
+        if (!al(a->x, 8) || !al(a->edge_embed, 8) || !al(a->V, 16) || !al(a->u, 16)) return RECON_ERR_UNSUPPORTED;
+        return RECON_OK;
+    }
     if (!al(a->x, 4 * s->vec) || !al(a->edge_embed, 4 * s->vec) || !al(a->V, 16) || !al(a->u, 16)) return RECON_ERR_UNSUPPORTED;
     return RECON_OK;
 }
@@ -1607,8 +1642,10 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
             jn.nb = static_cast<int>(ceil_div64(N, 64) < 4096 ? ceil_div64(N, 64) : 4096);
             je.nb = erows > 0 ? static_cast<int>(ceil_div64(erows, 64) < 8192 ? ceil_div64(erows, 64) : 8192) : 0;
             const int kpm = row_dots_kp(F) > row_dots_kp(R) ? row_dots_kp(F) : row_dots_kp(R);
-            hipLaunchKernelGGL(k_row_dots_x, dim3(static_cast<unsigned>(jn.nb + je.nb + nsplit)), dim3(kBlock), sizeof(float) * (2 * H) * kpm, st,
-                               jn, je, a->u, H, W, sp, nsplit);
+            if (a->io_bf16) hipLaunchKernelGGL(k_row_dots_x<true>, dim3(static_cast<unsigned>(jn.nb + je.nb + nsplit)), dim3(kBlock), sizeof(float) * (2 * H) * kpm, st,
+                                               jn, je, a->u, H, W, sp, nsplit);
+            else hipLaunchKernelGGL(k_row_dots_x<false>, dim3(static_cast<unsigned>(jn.nb + je.nb + nsplit)), dim3(kBlock), sizeof(float) * (2 * H) * kpm, st,
+                                    jn, je, a->u, H, W, sp, nsplit);
         } else if (s.vec == 4) hipLaunchKernelGGL((k_row_dots<4>), grid, dim3(kBlock), lds, st, jn, je, a->u, H, W);
         else hipLaunchKernelGGL((k_row_dots<2>), grid, dim3(kBlock), lds, st, jn, je, a->u, H, W);
     }
@@ -1643,7 +1680,9 @@ extern "C" int recon_gat_atp_aggregate(const recon_graph* g, const recon_gat_atp
               static_cast<unsigned>(ceil_div64(a->H, s.ht)));
 #define CALL_FWD(V_, K_, H_)                                                                                   \
     do {                                                                                                       \
-        if (p.planes == 2 && V_ == 4) { if (train) hipLaunchKernelGGL((k_gat_atp_fwd<V_, K_, H_, true, 2>), grid, dim3(kBlock), 0, st, p);  \
+        if (p.planes == 2 && V_ == 4 && a->io_bf16) { if (train) hipLaunchKernelGGL((k_gat_atp_fwd<4, K_, H_, true, 2, true>), grid, dim3(kBlock), 0, st, p);  \
+                            else hipLaunchKernelGGL((k_gat_atp_fwd<4, K_, H_, false, 2, true>), grid, dim3(kBlock), 0, st, p); }     \
+        else if (p.planes == 2 && V_ == 4) { if (train) hipLaunchKernelGGL((k_gat_atp_fwd<V_, K_, H_, true, 2>), grid, dim3(kBlock), 0, st, p);  \
                             else hipLaunchKernelGGL((k_gat_atp_fwd<V_, K_, H_, false, 2>), grid, dim3(kBlock), 0, st, p); }     \
         else if (p.planes) { if (train) hipLaunchKernelGGL((k_gat_atp_fwd<V_, K_, H_, true, 1>), grid, dim3(kBlock), 0, st, p);  \
                             else hipLaunchKernelGGL((k_gat_atp_fwd<V_, K_, H_, false, 1>), grid, dim3(kBlock), 0, st, p); }     \
@@ -1654,7 +1693,8 @@ extern "C" int recon_gat_atp_aggregate(const recon_graph* g, const recon_gat_atp
 #undef CALL_FWD
     if (hubs) {
         const dim3 gh(static_cast<unsigned>(ceil_div64(1LL * g->n_hub * a->H, kBlock / 64)));
-        if (s.vec == 4) { if (p.planes) hipLaunchKernelGGL((k_gat_atp_hub_fwd<4, 1>), gh, dim3(kBlock), 0, st, p, g->hub_node, g->hub_ptr, g->n_hub);
+        if (s.vec == 4 && a->io_bf16) hipLaunchKernelGGL((k_gat_atp_hub_fwd<4, 1, true>), gh, dim3(kBlock), 0, st, p, g->hub_node, g->hub_ptr, g->n_hub);
+        else if (s.vec == 4) { if (p.planes) hipLaunchKernelGGL((k_gat_atp_hub_fwd<4, 1>), gh, dim3(kBlock), 0, st, p, g->hub_node, g->hub_ptr, g->n_hub);
                           else hipLaunchKernelGGL((k_gat_atp_hub_fwd<4, 0>), gh, dim3(kBlock), 0, st, p, g->hub_node, g->hub_ptr, g->n_hub); }
         else { if (p.planes) hipLaunchKernelGGL((k_gat_atp_hub_fwd<2, 1>), gh, dim3(kBlock), 0, st, p, g->hub_node, g->hub_ptr, g->n_hub);
                else hipLaunchKernelGGL((k_gat_atp_hub_fwd<2, 0>), gh, dim3(kBlock), 0, st, p, g->hub_node, g->hub_ptr, g->n_hub); }

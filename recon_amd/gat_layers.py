@@ -456,14 +456,14 @@ def _p(t):
 
 
 def _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split=None, aux=None,
-              keep_max=1.0, ee_index=None):
+              keep_max=1.0, ee_index=None, io_bf16=False):
     """recon_gat_atp_args from tensors or raw device pointers (workspace slices)."""
     H, D = a2.shape
     return _lib.GatAtpArgs(graph.N, graph.E, x.shape[1], ee.shape[1], D, H, int(bool(concat)), float(alpha),
                            x.data_ptr(), ee.data_ptr(), a.data_ptr(), a2.data_ptr(), _p(keep), _p(u),
                            _p(c_node), _p(c_rel), _p(V), _p(sigma), _p(Z), _p(Zk),
                            out.data_ptr(), out.shape[1], _p(a_split), SPLIT_F16X2 if aux is not None else SPLIT_BF16X3,
-                           float(keep_max), _p(aux), _p(ee_index), ee.shape[0] if ee_index is not None else 0)
+                           float(keep_max), _p(aux), _p(ee_index), ee.shape[0] if ee_index is not None else 0, int(bool(io_bf16)))
 
 
 _PAD_MIN_OUT = 1 << 18            # below this many output elements the padding's extra launches cost more than the aligned GEMMs win
@@ -556,8 +556,16 @@ class _GATHeadsATPFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ee, a, a2, graph, keep, alpha, concat, keep_max, ee_index=None):
-        """ee_index (int64 [E], original edge order) makes `ee` a table: edge e uses row ee_index[e] (see gat_heads)."""
-        _require_gpu_f32(x, ee, a, a2, keep)
+        """ee_index (int64 [E], original edge order) makes `ee` a table: edge e uses row ee_index[e] (see gat_heads).
+        x and ee may both be bfloat16 (gat_heads checks the shape: recon_gat_atp_bf16_io_supported): the forward kernels read them in
+        place; the result and the arithmetic stay float32; the backward widens them once and hands back bfloat16 gradients."""
+        io16 = x.dtype == torch.bfloat16
+        if io16:
+            if ee.dtype != torch.bfloat16 or ee_index is not None or not (x.is_cuda and ee.is_cuda):
+                raise ValueError("recon_amd.gat_heads: bfloat16 features need bfloat16 edge embeddings on the GPU (no table mode)")
+            _require_gpu_f32(a, a2, keep)
+        else:
+            _require_gpu_f32(x, ee, a, a2, keep)
         L = _lib.lib()
         x, ee, a, a2 = x.contiguous(), ee.contiguous(), a.contiguous(), a2.contiguous()
         H, D = a2.shape
@@ -575,7 +583,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:4])
         train = need_grad or keep is not None
         out = torch.empty(N, H * D, dtype=torch.float32, device=dev)
-        mode = _atp_split_mode(F_, R, D, H, N)
+        mode = 2 if io16 else _atp_split_mode(F_, R, D, H, N)           # bfloat16 inputs: the f16 x 2 family's kernels only
         split_bytes, aux_bytes = _lib_sizes(N, E, F_, R, D, H)[:2]
         # u [H,W], c_node [N,2H], c_rel [E,H], V [N,H,W], sigma [E,H], Z [N,H], Zk [N,H], a_split, aux: one allocation
         ws, (u, c_node, c_rel, V, sigma, Z, Zk, a_split, aux) = _carve(dev, (
@@ -587,7 +595,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
             keep_max = 1.0
         elif keep_max is None:                                  # explicit factors without a bound: one host read (tests)
             keep_max = float(keep.max()) if aux is not None and keep.numel() else 1.0
-        args = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split, aux, keep_max, idx_slot)
+        args = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split, aux, keep_max, idx_slot, io16)
         gstruct, _hub_keep = graph.call_struct(F_, R, H)
         with _on_device(dev):
             _lib.check(L.recon_gat_atp_fwd(C.byref(gstruct), C.byref(args), _lib.current_stream()), "recon_gat_atp_fwd")
@@ -608,6 +616,9 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         N, E, F_, R = graph.N, graph.E, x.shape[1], ee.shape[1]
         W = 2 * F_ + R
         dev = x.device
+        io16 = x.dtype == torch.bfloat16
+        if io16:                                                # the backward's kernels read float32 rows: widened here, once, only when training
+            x, ee = x.float(), ee.float()
         f32 = dict(dtype=torch.float32, device=dev)
         grad_out = grad_out.contiguous()
         nx, ne, na, na2 = ctx.needs_input_grad[:4]
@@ -663,6 +674,9 @@ class _GATHeadsATPFunction(torch.autograd.Function):
             # table mode: g_ee holds one row per CSR slot; the table's gradient is their sum by row index (fixed order: the same
             # segment walk as SpecialSpmmFinal)
             g_ee = _rowsum_by_index(g_ee, graph.slot_index_long(ctx.idx_slot), ee.shape[0])
+        if io16:
+            g_x = g_x.to(torch.bfloat16) if g_x is not None else None
+            g_ee = g_ee.to(torch.bfloat16) if g_ee is not None else None
         return g_x, g_ee, (g_a if na else None), (g_a2 if na2 else None), None, None, None, None, None, None
 
 
@@ -764,6 +778,13 @@ def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=Tru
         # backward; reduced-precision tables go through index_select, whose autograd is native)
         rows = gather_rows(edge_embed_all, ee_index) if edge_embed_all.dtype == torch.float32 else edge_embed_all.index_select(0, ee_index)
         return gat_heads(x, rows, a, a_2, graph, keep, alpha, concat, keep_max)
+    if (x.dtype == torch.bfloat16 and edge_embed_all.dtype == torch.bfloat16 and ee_index is None and x.is_cuda and D % 8 == 0 and
+            gat_path_for(graph.N, graph.E, x.shape[1], edge_embed_all.shape[1], D, H) == "atp" and
+            _lib.lib().recon_gat_atp_bf16_io_supported(x.shape[1], edge_embed_all.shape[1], D, H) == 1 and _GEMM_BX3 in ("auto", "2")):
+        # bfloat16 at the layer's boundary, read IN PLACE by the forward's kernels (csrc/gat_atp.hip, io_bf16): no up-cast copies of x and of the
+        # E x R edge embeddings (174 MB of traffic at BASELINE.json configs[4]'s 145 k edges); arithmetic and parameters stay float32
+        out = _GATHeadsATPFunction.apply(x, edge_embed_all, a.float(), a_2.float(), graph, keep, alpha, concat, keep_max, None)
+        return out.to(x.dtype)
     if x.dtype in (torch.bfloat16, torch.float16):
         # Reduced-precision STORAGE at the layer boundary (BASELINE.json configs[4]: "mixed GAT+Propagation stack, bf16"): features
         # and edge embeddings arrive and leave in x.dtype; scores, softmax, aggregation and projections run the fp32 kernels (the

@@ -848,6 +848,49 @@ def test_cfg5_bf16_gat_then_gcn_stack():
         assert bool(torch.isfinite(t.float()).all()) and float(t.float().abs().max()) > 0
 
 
+def test_cfg5_bf16_attention_at_the_benched_shapes():
+    """The attention leg of the benched configs[4] stack (tools/secondary.py powerlaw_mixed_stack_bf16: F = R = 200, D = 32, H = 8, 64
+    power-law graphs of up to 256 nodes) with bfloat16 x / edge_embed read IN PLACE by the forward kernels (recon_gat_atp_args.io_bf16)
+    against the float64 oracle on the same bf16-rounded inputs: every head's forward; the input gradients for an upstream gradient that
+    lives in heads 0 and 7 (the oracle's two heads' contributions); parameters' gradients of those heads at the float32 bar."""
+    from recon_amd import gat_layers, _lib
+    from recon_amd.graph import prepare_graph
+    d = dev()
+    edge, N = _power_law_batch(64, seed=0, max_n=256)
+    E = edge.shape[1]
+    F_, R, D, H = 200, 200, 32, 8
+    assert _lib.lib().recon_gat_atp_bf16_io_supported(F_, R, D, H) == 1
+    g = torch.Generator().manual_seed(1)
+    bf = lambda t: t.to(torch.bfloat16)
+    x, ee = bf(torch.randn(N, F_, generator=g)), bf(torch.randn(E, R, generator=g) * 0.5)
+    a = torch.randn(H, D, 3 * F_, generator=g) * (2.0 / (3 * F_ + D)) ** 0.5
+    a2 = torch.randn(H, D, generator=g) * (2.0 / (D + 1)) ** 0.5
+    xd, eed = x.to(d).requires_grad_(True), ee.to(d).requires_grad_(True)
+    ad, a2d = a.to(d).requires_grad_(True), a2.to(d).requires_grad_(True)
+    graph = prepare_graph(edge.to(d), None, N)
+    assert graph.n_hub > 0                                            # power-law rows: the hub pieces' kernels read bf16 rows too
+    h = gat_layers.gat_heads(xd, eed, ad, a2d, graph, None, 0.2, True)
+    assert h.dtype == torch.bfloat16 and h.shape == (N, H * D)
+    G = torch.zeros(N, H * D)
+    G[:, :D] = torch.randn(N, D, generator=g)
+    G[:, 7 * D:] = torch.randn(N, D, generator=g)
+    h.backward(bf(G).to(d))
+    g_x, g_ee = 0, 0
+    for i in range(H):
+        if i in (0, 7):
+            r = O.gat_layer_backward(x.double(), edge, ee.double(), None, None, a[i].double(), a2[i:i + 1].double(), 0.2, True, bf(G[:, i * D:(i + 1) * D]).double())
+            ref_i = r["out"]
+            g_x, g_ee = g_x + r["g_x"], g_ee + r["g_edge_embed"]
+            close(ad.grad[i], r["g_a"].float(), atol=1e-5, rel_to_max=1e-4, what="benched cfg5 g_a head %d" % i)
+            close(a2d.grad[i], r["g_a_2"].float().reshape(-1), atol=1e-5, rel_to_max=1e-4, what="benched cfg5 g_a_2 head %d" % i)
+        else:
+            ref_i = O.gat_layer_forward(x.double(), edge, ee.double(), None, None, a[i].double(), a2[i:i + 1].double(), 0.2, True)
+        close(h.float()[:, i * D:(i + 1) * D], ref_i.float(), atol=1e-5, rel_to_max=2.0 ** -8, what="benched cfg5 out head %d (one rounding to bf16)" % i)
+    assert xd.grad.dtype == torch.bfloat16 and eed.grad.dtype == torch.bfloat16
+    close(xd.grad.float(), g_x.float(), atol=1e-5, rel_to_max=2.0 ** -8, what="benched cfg5 g_x (bf16 out)")
+    close(eed.grad.float(), g_ee.float(), atol=1e-5, rel_to_max=2.0 ** -8, what="benched cfg5 g_edge_embed (bf16 out)")
+
+
 @pytest.mark.parametrize("name", ["spkbgat1_nhop", "spkbgat2_1hop"])
 def test_spkbgat_golden(name):
     """G7: the stage-A model (whole entity table, one entity batch of edges) vs the reference SpKBGATModified:
