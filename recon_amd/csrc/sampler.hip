@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(64) k_kg_nhop(const KG g, const int64_t* __res
                                                  const int64_t* __restrict__ quad_off, int64_t* __restrict__ quads) {
     extern __shared__ uint32_t seen[];
     const int lane = threadIdx.x, b = blockIdx.x;
-    const int words = static_cast<int>((g.Ne + 31) >> 5);
+    const int words = static_cast<int>((g.Ne + 63) >> 6) * 2;          // a multiple of two: the parent tables behind it stay 8-byte aligned
     const int64_t s = srcs[b], p0 = g.pair_ptr[s], p1 = g.pair_ptr[s + 1];
     for (int i = lane; i < words; i += 64) seen[i] = 0u;
     __syncthreads();
@@ -127,34 +127,55 @@ __global__ void __launch_bounds__(64) k_kg_nhop(const KG g, const int64_t* __res
     int64_t count = 0;
     const int64_t base = WRITE ? quad_off[b] : 0;
     const int64_t limit = WRITE ? qcount[b] : (partial ? 1 : (1LL << 62));
-    // parents in batches of 64: lane i requests parent i's target, first relation and pair range (two dependent round trips per BATCH; one
-    // parent at a time they were three per parent, and a source with a few hundred parents set the kernel's time), then the batch is
-    // walked in order with the values handed round by shuffles
+    // Parents in batches of 64 (lane i requests parent i's target, first relation and pair range: two dependent round trips per batch), and the
+    // batch's candidates — parent-major, pair order: the BFS's discovery order — as ONE flat sequence walked 64 at a time, whatever the
+    // parents' degrees (one parent at a time, a source with a few hundred low-degree parents was a chain of as many round trips: 0.5 ms
+    // per batch of 128 sources).  A parent's targets are distinct; the same target under two parents of one chunk is resolved by lane
+    // order (equal-value peers through ballots: the lowest lane is the first visit).
+    int32_t* poff = reinterpret_cast<int32_t*>(seen + words);           // [64] first candidate of parent i within the batch
+    int64_t* pc0 = reinterpret_cast<int64_t*>(poff + 64);               // [64] its pair range's start
+    int64_t* pr1 = pc0 + 64;                                            // [64] its first relation
+    int vbits = 1;
+    while (vbits < 63 && (1LL << vbits) < g.Ne) ++vbits;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int64_t pb = p0; pb < p1 && count < limit; pb += 64) {
         const int64_t pa_l = pb + lane;
         const bool ok_l = pa_l < p1 && g.not_loop[pa_l];
-        const int64_t u_l = ok_l ? g.pair_tgt[pa_l] : 0, r1_l = ok_l ? g.pair_first_rel[pa_l] : 0;
+        const int64_t u_l = ok_l ? g.pair_tgt[pa_l] : 0;
         const int64_t c0_l = ok_l ? g.pair_ptr[u_l] : 0, c1_l = ok_l ? g.pair_ptr[u_l + 1] : 0;
-        const int nb = static_cast<int>(min<int64_t>(64, p1 - pb));
-        for (int k = 0; k < nb && count < limit; ++k) {                  // wave-uniform
-            const int64_t c0 = __shfl(c0_l, k, 64), c1 = __shfl(c1_l, k, 64), r1 = __shfl(r1_l, k, 64);
-            for (int64_t cc = c0; cc < c1 && count < limit; cc += 64) {  // a loop parent has c0 = c1 = 0
-                const int64_t c = cc + lane;
-                bool fresh = false;
-                int64_t v = 0;
-                if (c < c1) {
-                    v = g.pair_tgt[c];
-                    const uint32_t bit = 1u << (v & 31);
-                    fresh = !(atomicOr(&seen[v >> 5], bit) & bit);      // a parent's targets are distinct: no two lanes ask for the same bit
-                }
-                const uint64_t m = __ballot(fresh);
-                const int before = __popcll(m & ((1ull << lane) - 1ull));
-                if (WRITE && fresh && count + before < limit) {
-                    int64_t* q = quads + 4 * (base + count + before);
-                    q[0] = s; q[1] = r1; q[2] = g.pair_first_rel[c]; q[3] = v;
-                }
-                count += __popcll(m);
+        const int deg = static_cast<int>(c1_l - c0_l);
+        int x = deg;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(x, off, 64); if (lane >= off) x += t; }
+        const int T = __shfl(x, 63, 64);
+        __syncthreads();                                                 // the previous batch's readers are done with the tables
+        poff[lane] = x - deg; pc0[lane] = c0_l; pr1[lane] = ok_l ? g.pair_first_rel[pa_l] : 0;
+        __syncthreads();
+        for (int x0 = 0; x0 < T && count < limit; x0 += 64) {            // wave-uniform
+            const int xi = x0 + lane;
+            const bool valid = xi < T;
+            int lo = 0;                                                  // the last parent whose first candidate is <= xi (parents without candidates share an offset with the next)
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) if (lo + step < 64 && poff[lo + step] <= xi) lo += step;
+            const int64_t c = pc0[lo] + (xi - poff[lo]);
+            const int64_t v = valid ? g.pair_tgt[c] : 0;
+            const uint32_t bit = 1u << (v & 31);
+            const bool unseen = valid && !(seen[v >> 5] & bit);
+            unsigned long long peers = __ballot(unseen);                 // unseen lanes with the same target: the lowest one is the first visit
+            for (int bb = 0; bb < vbits; ++bb) {
+                const bool on = (v >> bb) & 1;
+                const unsigned long long m = __ballot(unseen && on);
+                peers &= on ? m : ~m;
             }
+            const bool fresh = unseen && (peers & lt) == 0;
+            if (fresh) atomicOr(&seen[v >> 5], bit);
+            const uint64_t m = __ballot(fresh);
+            const int before = __popcll(m & lt);
+            if (WRITE && fresh && count + before < limit) {
+                int64_t* q = quads + 4 * (base + count + before);
+                q[0] = s; q[1] = pr1[lo]; q[2] = g.pair_first_rel[c]; q[3] = v;
+            }
+            count += __popcll(m);
         }
     }
     if (WRITE) return;
@@ -188,7 +209,8 @@ KG kg_of(const recon_kg* k) {
 }  // namespace
 }  // namespace recon
 
-extern "C" size_t recon_kg_nhop_lds_bytes(int64_t num_entities) { return static_cast<size_t>((num_entities + 31) / 32) * 4; }
+// the visited bitmap of one source + the parent tables of a batch (64 x (4 + 8 + 8) bytes, behind an 8-byte boundary)
+extern "C" size_t recon_kg_nhop_lds_bytes(int64_t num_entities) { return static_cast<size_t>((num_entities + 63) / 64) * 8 + 64 * 20; }
 
 extern "C" int recon_kg_adj_count(const recon_kg* kg, const int64_t* entities, int32_t B, int64_t* nrel, uint8_t* ent_mark, uint8_t* tgt_mark,
                                   int64_t* rel_off, int64_t* uniq_ent, int64_t* uniq_tgt, int64_t* totals, uint32_t* counter, recon_stream_t stream) {

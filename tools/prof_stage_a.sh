@@ -2,7 +2,7 @@
 # per-kernel times of tools/stage_a_iter_bench.py (runs on the GPU box)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
-rm -rf gpurun_out/prof_stage_a; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stage_a -o t -- python3 tools/stage_a_iter_bench.py --iters 20 > gpurun_out/prof_stage_a.log 2>&1
+rm -rf gpurun_out/prof_stage_a; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stage_a -o t -- python3 tools/stage_a_iter_bench.py --iters 20 --loss-rows recon > gpurun_out/prof_stage_a.log 2>&1
 python3 - <<PY
 import csv,glob
 f=glob.glob("gpurun_out/prof_stage_a/**/*kernel_stats.csv",recursive=True)[0]
