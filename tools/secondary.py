@@ -316,9 +316,9 @@ def powerlaw_mixed_stack_bf16(B=64, D=32, F_=200, H=8, iters=10):
 def all_secondary(fast=True):
     it = 6 if fast else 20
     return {"cfg3b_n9_propagation": propagation(9, iters=it),
-            "cfg3b_n32_propagation": propagation(32, iters=2),
+            "cfg3b_n32_propagation": propagation(32, iters=10),          # training legs: max(2, iters // 2) = 5 timed iterations, twice
             "cfg3b_n9_bf16": propagation_bf16(9, iters=it),
-            "cfg3b_n32_bf16": propagation_bf16(32, iters=2),
+            "cfg3b_n32_bf16": propagation_bf16(32, iters=10),
             "cfg3a_gcn_bf16": gcn_bf16(iters=it),
             "cfg5_powerlaw_spgat": powerlaw_spgat(iters=it),
             "cfg5_mixed_stack_bf16": powerlaw_mixed_stack_bf16(iters=it)}
