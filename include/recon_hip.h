@@ -566,6 +566,36 @@ typedef struct {
     void* out; int64_t ldo;         /* [B*n, ldo] bf16, ldo % 8 == 0; columns hidden .. ldo are written as zeros                */
 } recon_gcn_b16_stack_args;
 int recon_gcn_b16_stack_fwd(const recon_gcn_b16_stack_args* args, recon_stream_t stream);
+/* The same stack WITH gradients (training; `gcn_layers.gcn_stack` under autograd): models/layers.py:57-63 applied L times + autograd.
+ *   forward : one launch — the kernel above, which also keeps every layer's result (`acts`: the backward's ReLU masks and the operands of the
+ *             weight gradients) — behind one repacking launch per layer (`planes`);
+ *   backward: one launch for the whole chain g_support_l = adj^T (g_l . [act_l > 0]),  g_{l-1} = g_support_l W_l^T  (the gradient of a graph
+ *             stays in LDS between the layers), then ONE k-major split-K launch for every layer's g_W_l = x_l^T g_support_l and one second
+ *             pass that also finishes the g_bias_l.
+ * Output, g_x and g_bias are bit-equal to L calls of recon_gcn_b16_fwd / recon_gcn_b16_bwd; g_W differs from theirs by the summation
+ * order of the split-K partials only (fixed, run-to-run reproducible).  Shapes as for recon_gcn_b16_stack_fwd, and in_features <= 320. */
+typedef struct {
+    int32_t B, n, in_features, hidden, L;
+    const void* x; int64_t ldx;         /* [B*n, ldx] bf16, ldx % 8 == 0, columns in_features .. ldx zero (operand of layer 0's weight gradient) */
+    const void* adj;                    /* [B, n, n] bf16, 8-byte aligned                                                                      */
+    const void* const* weight;          /* HOST array of L device pointers W_l [in_l][hidden] bf16, contiguous                                 */
+    const void* const* bias;            /* HOST array of L device pointers [hidden] bf16 (entries, or the array, may be NULL)                  */
+    void* const* planes;                /* HOST array of L workspaces of recon_gcn_b16_planes_bytes(in_l, hidden) bytes: written by the        *
+                                         * forward, read by the backward                                                                      */
+    void* const* acts; int64_t ldo;     /* HOST array of L buffers [B*n, ldo] bf16 (ldo % 8 == 0): the result of every layer, acts[L-1] = the  *
+                                         * stack's result; columns hidden .. ldo are written as zeros                                         */
+    /* ---- backward only ---- */
+    const void* grad_out; int64_t ldg;  /* [B*n, ldg] bf16: gradient of acts[L-1]; any even ldg >= hidden, 4-byte aligned (read in place)      */
+    void* const* g_support;             /* HOST array of L workspaces [B*n, ldo] bf16                                                          */
+    float* partial;                     /* recon_gcn_b16_stack_bwd_partial_floats() floats                                                     */
+    void* g_x; int64_t ldgx;            /* [B*n, ldgx] bf16 or NULL                                                                            */
+    void* const* g_weight;              /* HOST array of L device pointers [in_l][hidden] bf16 (entries, or the array, may be NULL)            */
+    void* const* g_bias;                /* HOST array of L device pointers [hidden] bf16 (entries, or the array, may be NULL)                  */
+    const void* zeros;                  /* >= 1 KiB of zero bytes, 16-byte aligned                                                             */
+} recon_gcn_b16_stack_train_args;
+int recon_gcn_b16_stack_train_fwd(const recon_gcn_b16_stack_train_args* args, recon_stream_t stream);
+size_t recon_gcn_b16_stack_bwd_partial_floats(int32_t B, int32_t n, int32_t in_features, int32_t hidden, int32_t L);
+int recon_gcn_b16_stack_train_bwd(const recon_gcn_b16_stack_train_args* args, recon_stream_t stream);
 /* planes [out_features][kp(in_features)] (bf16, (out_features * kp(in_features) * 2 bytes) of a weight [in_features][out_features] */
 int recon_gcn_b16_transposed_planes(const void* weight, int32_t in_features, int32_t out_features, void* planes, recon_stream_t stream);
 

@@ -123,6 +123,15 @@ class GcnB16StackArgs(C.Structure):
                 ("out", C.c_void_p), ("ldo", C.c_int64)]
 
 
+class GcnB16StackTrainArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("n", C.c_int32), ("in_features", C.c_int32), ("hidden", C.c_int32), ("L", C.c_int32),
+                ("x", C.c_void_p), ("ldx", C.c_int64), ("adj", C.c_void_p), ("weight", C.POINTER(C.c_void_p)), ("bias", C.POINTER(C.c_void_p)),
+                ("planes", C.POINTER(C.c_void_p)), ("acts", C.POINTER(C.c_void_p)), ("ldo", C.c_int64),
+                ("grad_out", C.c_void_p), ("ldg", C.c_int64), ("g_support", C.POINTER(C.c_void_p)), ("partial", C.c_void_p),
+                ("g_x", C.c_void_p), ("ldgx", C.c_int64), ("g_weight", C.POINTER(C.c_void_p)), ("g_bias", C.POINTER(C.c_void_p)),
+                ("zeros", C.c_void_p)]
+
+
 ACT = {"linear": 0, "relu": 1, "tanh": 2}
 
 # every symbol include/recon_hip.h declares: (name, restype, argtypes)
@@ -187,6 +196,9 @@ SYMBOLS = [
     ("recon_gcn_b16_bwd", C.c_int, [C.POINTER(GcnB16BwdArgs), C.c_void_p]),
     ("recon_gcn_b16_stack_fwd", C.c_int, [C.POINTER(GcnB16StackArgs), C.c_void_p]),
     ("recon_gcn_b16_transposed_planes", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("recon_gcn_b16_stack_train_fwd", C.c_int, [C.POINTER(GcnB16StackTrainArgs), C.c_void_p]),
+    ("recon_gcn_b16_stack_bwd_partial_floats", C.c_size_t, [C.c_int32] * 5),
+    ("recon_gcn_b16_stack_train_bwd", C.c_int, [C.POINTER(GcnB16StackTrainArgs), C.c_void_p]),
     ("recon_sgemm_small_workspace_floats", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     ("recon_sgemm_ex_workspace_floats", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     ("recon_sgemm_ex", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32,

@@ -17,11 +17,16 @@ int b16_kmajor_splits(int32_t M, int32_t N, int32_t K);
 int b16_pad_planes_both(const void* src, int64_t ld, int32_t M, int32_t N, void* dst_t, void* dst_n, hipStream_t st);
 int gemm_b16_kmajor(int32_t M, int32_t N, int32_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* out, int64_t ldo, float* partial,
                     const void* zeros, hipStream_t st, const B16ReduceJob* extra);
+int b16_kmajor_splits_multi(int32_t M, int32_t N, int32_t K, int32_t count);
+int gemm_b16_kmajor_multi(int32_t count, const B16KmProduct* pr, int32_t K, const void* zeros, hipStream_t st, const B16ReduceJob* extra, int32_t n_extra);
 
 namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 __device__ __forceinline__ float bf2f(uint16_t v) { return __builtin_bit_cast(float, static_cast<uint32_t>(v) << 16); }
 __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(uint16_t, static_cast<__bf16>(v)); }
+// byte extents of buffer descriptors: integer arithmetic only (`min<int64_t>(v, 0x7fffffff)` resolves to a double-precision minimum in
+// the HIP headers: the extent then lives in vector registers and EVERY access through the descriptor is wrapped in a readfirstlane loop)
+__device__ __forceinline__ int sat_i32(int64_t v) { return v < 0x7fffffffLL ? static_cast<int>(v) : 0x7fffffff; }
 
 // Y[b][i][o] = epilogue( sum_j M[i][j] * Xin[b][j][o] ),  M = adj[b] (TRANS = false) or adj[b]^T; block = (64 columns, graph,
 // 32-row tile), the contraction walked in chunks of 32 through LDS (any n).  MASK: Xin = gout * (fwd_out > 0); EPI: + bias, ReLU.
@@ -191,7 +196,7 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_fwd(const GcnFuse
     const int64_t rows_total = static_cast<int64_t>(p.B) * n;
     // x: rows of graph g, out-of-range rows / columns read as zeros through the descriptor (the tensor's own extent)
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0,
-                                                      static_cast<int>(min<int64_t>(rows_total * p.ldx * 2, 0x7fffffff)), 0x00020000);
+                                                      sat_i32(rows_total * p.ldx * 2), 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wt), 0, p.O * p.Ip * 2, 0x00020000);
     uint32_t xoff[2];
 #pragma unroll
@@ -214,7 +219,7 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_fwd(const GcnFuse
     uint32_t adjraw[2][2][4];
     u32x2_g adjv[2][2];
     const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.adj), 0,
-                                                      static_cast<int>(min<int64_t>(static_cast<int64_t>(p.B) * n * n * 2, 0x7fffffff)), 0x00020000);
+                                                      sat_i32(static_cast<int64_t>(p.B) * n * n * 2), 0x00020000);
     constexpr bool adj_vec = VEC;                                        // n % 4 == 0 and adj 8-byte aligned: one 8-byte load per four nodes
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -332,7 +337,7 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_fwd(const GcnFuse
         adjf[it] = __builtin_bit_cast(bf16x8, u32x4_g{v[0], v[1], v[2], v[3]});
     }
     // ---- out^T tile = support^T . adj^T ; + bias, ReLU, 8-byte stores (pad columns O .. ldo are written as zeros)
-    const auto ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, static_cast<int>(min<int64_t>(rows_total * p.ldo * 2, 0x7fffffff)), 0x00020000);
+    const auto ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, sat_i32(rows_total * p.ldo * 2), 0x00020000);
     auto pack2 = [](float a, float b) { return static_cast<uint32_t>(f2bf(a)) | (static_cast<uint32_t>(f2bf(b)) << 16); };
 #pragma unroll
     for (int c = 0; c < NTP; ++c)
@@ -376,6 +381,7 @@ struct GcnStackK {
     const uint16_t* wt[kMaxStack];                                       // W_l^T planes [D][kp(in_l)]
     const uint16_t* bias[kMaxStack];
     uint16_t* out; int64_t ldo;
+    uint16_t* save[kMaxStack];                                           // training: the result of layer l < L - 1, [B*n][ldo] (null: not kept)
     int32_t B, n, I0, D, L, nt;                                          // in_0 = I0, every layer's out = in_{l+1} = D; nt = ceil(ldo / 16)
 };
 
@@ -404,7 +410,7 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
     // ---- x tiles of the workgroup's four graphs into the images: piece = (graph, K step, row half); rows past n and graphs past B read as zeros
     {
         const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0,
-                                                          static_cast<int>(min<int64_t>(rows_total * p.ldx * 2, 0x7fffffff)), 0x00020000);
+                                                          sat_i32(rows_total * p.ldx * 2), 0x00020000);
         const int npc = 4 * nk0 * 2;
         for (int pc = w; pc < npc; pc += NW) {                          // wave-uniform
             const int gq = pc / (2 * nk0), r = pc - gq * 2 * nk0, ks = r >> 1, half = r & 1;
@@ -443,7 +449,7 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
     bf16x8 adjf[2];
     {
         const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.adj), 0,
-                                                          static_cast<int>(min<int64_t>(static_cast<int64_t>(p.B) * n * n * 2, 0x7fffffff)), 0x00020000);
+                                                          sat_i32(static_cast<int64_t>(p.B) * n * n * 2), 0x00020000);
         u32x2_g adjv[2][2];
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -462,7 +468,6 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
     const u32x4_g allmask = u32x4_g{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     const int b_rd = gf_lds_off(li, lq) + 1024 * c_lo;
     const int a_rd0 = gf_lds_off(li, lq), a_rd1 = gf_lds_off(16 + li, lq);
-    const auto ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, static_cast<int>(min<int64_t>(rows_total * p.ldo * 2, 0x7fffffff)), 0x00020000);
     auto pack2 = [](float a, float b) { return static_cast<uint32_t>(f2bf(a)) | (static_cast<uint32_t>(f2bf(b)) << 16); };
     int cb = 0;                                                          // ring slot of the step being computed
     bool started = false;
@@ -475,6 +480,10 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
     for (int l = 0; l < p.L; ++l) {
         const bool last = l == p.L - 1;
         const int I = l == 0 ? p.I0 : D, nks = l == 0 ? nk0 : nkh;
+        // where this layer's result goes in memory: the last one to `out`, the others to their `save` buffer when the caller keeps them
+        // (training: the backward's ReLU masks and the weight gradients' operands); a descriptor of zero bytes drops every store
+        uint16_t* const dstp = last ? p.out : p.save[l];
+        const auto ro = __builtin_amdgcn_make_buffer_rsrc(dstp ? dstp : p.out, 0, dstp ? sat_i32(rows_total * p.ldo * 2) : 0, 0x00020000);
         u32x2_g bvec[NTP];
         u32x4_g tailmask;
         {
@@ -547,7 +556,7 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
                 // the last layer's result to memory (masked by an out-of-range offset), every other one into the image (tiles past it: scratch).
                 // Rows of nodes past n hold relu(bias): the per-layer kernel never stores them and reads them back as zeros; adj's columns
                 // for them are zero (out-of-range loads), so they never reach a result
-                const uint32_t off = (last && g < p.B && i < n && o0 < p.ldo) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.ldo + o0) * 2) : 0xfffffff0u;
+                const uint32_t off = (g < p.B && i < n && o0 < p.ldo) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.ldo + o0) * 2) : 0xfffffff0u;
                 __builtin_amdgcn_raw_buffer_store_b64(pk, ro, off, 0, 0);
                 unsigned char* hd = (!last && o0 < 32 * nkh) ? Hg + (o0 >> 5) * 2048 + gf_lds_off(i, (o0 & 31) >> 3) + 2 * (o0 & 7) : st_sm + scratch;
                 *reinterpret_cast<u32x2_g*>(hd) = pk;
@@ -612,8 +621,8 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_bwd(const GcnFuse
     unsigned char* Ag = As + gsl * 32 * kRSA;
     // ---- stage the masked gradient tile and adj of this graph (its NS waves share the rows)
     {
-        const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.gout), 0, static_cast<int>(min<int64_t>(rows_total * p.ldg * 2, 0x7fffffff)), 0x00020000);
-        const auto rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.fout), 0, static_cast<int>(min<int64_t>(rows_total * p.ldf * 2, 0x7fffffff)), 0x00020000);
+        const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.gout), 0, sat_i32(rows_total * p.ldg * 2), 0x00020000);
+        const auto rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.fout), 0, sat_i32(rows_total * p.ldf * 2), 0x00020000);
         const int npr = kFusedNT * 2;                                    // 16-byte pieces per staged row (320 columns)
         for (int q = part * 64 + lane; q < 32 * npr; q += 64 * NS) {
             const int j = q / npr, pc = q - j * npr, o0 = 8 * pc;
@@ -632,7 +641,7 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_bwd(const GcnFuse
             }
             *reinterpret_cast<u32x4_g*>(Gg + j * kRSG + 16 * pc) = u32x4_g{m[0], m[1], m[2], m[3]};
         }
-        const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.adj), 0, static_cast<int>(min<int64_t>(static_cast<int64_t>(p.B) * n * n * 2, 0x7fffffff)), 0x00020000);
+        const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.adj), 0, sat_i32(static_cast<int64_t>(p.B) * n * n * 2), 0x00020000);
         for (int q = part * 64 + lane; q < 32 * 32; q += 64 * NS) {      // adj[j][i], element-wise: any n <= 32
             const int j = q >> 5, i = q & 31;
             const uint32_t v = (g < p.B && j < n && i < n) ? __builtin_amdgcn_raw_buffer_load_b16(ra, static_cast<uint32_t>(((static_cast<int64_t>(g) * n + j) * n + i) * 2), 0, 0) : 0u;
@@ -694,7 +703,7 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_bwd(const GcnFuse
     for (int c = 0; c < NTP; ++c)
 #pragma unroll
         for (int it = 0; it < 2; ++it) acc[c][it] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const auto rs_ = __builtin_amdgcn_make_buffer_rsrc(p.gsup, 0, static_cast<int>(min<int64_t>(rows_total * p.lds * 2, 0x7fffffff)), 0x00020000);
+    const auto rs_ = __builtin_amdgcn_make_buffer_rsrc(p.gsup, 0, sat_i32(rows_total * p.lds * 2), 0x00020000);
     auto pack2 = [](float a, float b) { return static_cast<uint32_t>(f2bf(a)) | (static_cast<uint32_t>(f2bf(b)) << 16); };
     // W fragment of row f under the k permutation: k = 4 lq .. + 3 is half (lq & 1) of slot lq >> 1, k = 16 + 4 lq .. of slot 2 + (lq >> 1)
     const int wrow = li, whalf = 8 * (lq & 1), wk1 = lq >> 1, wk2 = 2 + (lq >> 1);
@@ -748,7 +757,7 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_bwd(const GcnFuse
         if (ks + 1 < nks) step(S1{}, S0{}, ks + 1);
     }
     // ---- g_x: C layout column = node i, rows = four consecutive features
-    const auto rx_ = __builtin_amdgcn_make_buffer_rsrc(p.gx, 0, static_cast<int>(min<int64_t>(rows_total * p.ldgx * 2, 0x7fffffff)), 0x00020000);
+    const auto rx_ = __builtin_amdgcn_make_buffer_rsrc(p.gx, 0, sat_i32(rows_total * p.ldgx * 2), 0x00020000);
 #pragma unroll
     for (int c = 0; c < NTP; ++c)
         if (c_lo + c < nt) {
@@ -760,6 +769,218 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_bwd(const GcnFuse
                 __builtin_amdgcn_raw_buffer_store_b64(u32x2_g{pack2(acc[c][it][0], acc[c][it][1]), pack2(acc[c][it][2], acc[c][it][3])}, rx_, off, 0, 0);
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------------ fused STACK backward (n <= 32)
+// The backward of L GraphConvolutions over one adjacency in ONE kernel — the fused backward above looped over the layers, last to first, with
+// the gradient of a graph resident in LDS between them (the mirror image of k_gcn_b16_stack_fwd):
+//   layer l:  gpre_l = g_l . [act_l > 0]            (the staged tile: from grad_out for the last layer, from the previous step's accumulators else)
+//             g_support_l = adj^T gpre_l            -> memory (operand of the weight gradient x_l^T g_support_l, a k-major GEMM behind this kernel)
+//             g_{l-1} = g_support_l W_l^T           -> masked by act_{l-1} (8-byte loads requested at the top of the layer) into the staged tile;
+//                                                      layer 0: to memory as g_x when wanted
+// W planes [in_l][kp(hidden)] of every layer arrive by LDS-DMA through a ring of three slabs two K steps ahead, exactly as in the forward; a
+// K step ends with ONE 8-byte store per lane of g_support (each of the graph's four parts owns one 16 x 16 tile of the step), so the request
+// counter at the loop-head wait never holds more than the two copies of the next slab + that store.  Results are bit-equal to the per-layer
+// kernels (same products, same roundings, same summation orders).
+struct GcnStackBwdK {
+    const uint16_t* gout; int64_t ldg;
+    const uint16_t* act[kMaxStack]; int64_t lda;                         // act[l] = output of layer l, [B*n][lda]
+    const uint16_t* adj;
+    const uint16_t* wn[kMaxStack];                                       // W_l planes [in_l][Op]
+    uint16_t* gsup[kMaxStack]; int64_t lds;
+    uint16_t* gx; int64_t ldgx;                                          // null: not wanted
+    float* colsum[kMaxStack];                                            // [B][D] per layer, or null
+    int32_t B, n, I0, D, Op, L;
+};
+
+__global__ void __launch_bounds__(1024, 1) k_gcn_b16_stack_bwd(const GcnStackBwdK p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sb_sm[];      // W slabs [3][20 KiB] | gradient tiles [4][32][kRSG] | adj [4][32][kRSA] | scratch 1 KiB
+    constexpr int NS = 4, NTP = kFusedNT / NS, NW = 4 * NS, SLAB = kFusedNT * 16 * 64, NRING = 3, SP = kFusedNT;
+    constexpr int NDW = (SP + NW - 1) / NW;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int gsl = w & 3, part = w >> 2;
+    const int g = blockIdx.x * 4 + gsl;
+    const int c_lo = part * NTP;
+    const int n = p.n, D = p.D;
+    const int64_t rows_total = static_cast<int64_t>(p.B) * n;
+    const int nks = p.Op >> 5;
+    unsigned char* Gg = sb_sm + NRING * SLAB + gsl * 32 * kRSG;
+    unsigned char* Ag = sb_sm + NRING * SLAB + 4 * 32 * kRSG + gsl * 32 * kRSA;
+    const int scratch = NRING * SLAB + 4 * 32 * kRSG + 4 * 32 * kRSA;
+    const int c_row = lane >> 2, c_kq = ((lane & 3) - 2 * (c_row >> 3)) & 3;
+    // ---- the W slab of flat step (layer L-1 .. 0, K step): this wave's pieces; steps past the end copy nothing real (scratch)
+    int il = p.L - 1, ik = 0, ib = 0;
+    auto issue = [&]() {
+        const bool live = il >= 0;
+        const int I = il == 0 ? p.I0 : D;
+        // (as inline asm: through the builtin the compiler drains the request counter in front of the transposing LDS reads of every K step)
+        const dma_u32x4 rw = dma_descriptor(p.wn[live ? il : 0], live ? static_cast<uint32_t>(I * p.Op * 2) : 0u);
+#pragma unroll
+        for (int q = 0; q < NDW; ++q) {
+            const int pc = q * NW + w;                                   // wave-uniform
+            const bool real = live && pc < SP;
+            const int f = 16 * pc + c_row;
+            const uint32_t off = real ? static_cast<uint32_t>((f * p.Op + 32 * ik + 8 * c_kq) * 2) : 0xfffffff0u;      // rows past in_l: out of range, zeros
+            dma16_buffer_to_lds(rw, off, sb_sm + (real ? ib * SLAB + 1024 * pc : scratch));
+        }
+        if (++ik >= nks) { ik = 0; --il; }
+        ib = ib + 1 == NRING ? 0 : ib + 1;
+    };
+    issue();
+    issue();
+    // ---- stage the last layer's masked gradient tile and adj of this graph (its four waves share the rows)
+    {
+        const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.gout), 0, sat_i32(rows_total * p.ldg * 2), 0x00020000);
+        const auto rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.act[p.L - 1]), 0, sat_i32(rows_total * p.lda * 2), 0x00020000);
+        const int npr = kFusedNT * 2;                                    // 16-byte pieces per staged row (320 columns)
+        for (int q = part * 64 + lane; q < 32 * npr; q += 64 * NS) {
+            const int j = q / npr, pc = q - j * npr, o0 = 8 * pc;
+            const bool ok = g < p.B && j < n;
+            const uint32_t og = (ok && o0 < p.ldg) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + j) * p.ldg + o0) * 2) : 0xfffffff0u;
+            const uint32_t of = (ok && o0 < p.lda) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + j) * p.lda + o0) * 2) : 0xfffffff0u;
+            const u32x4_g gv = __builtin_amdgcn_raw_buffer_load_b128(rg, og, 0, 0), fv = __builtin_amdgcn_raw_buffer_load_b128(rf, of, 0, 0);
+            uint32_t m[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t gq = gv[d], fq = fv[d];
+                const bool k0 = (fq & 0x8000u) == 0 && (fq & 0x7fffu) != 0 && o0 + 2 * d < D;
+                const bool k1 = (fq & 0x80000000u) == 0 && (fq & 0x7fff0000u) != 0 && o0 + 2 * d + 1 < D;
+                m[d] = (k0 ? gq & 0xffffu : 0u) | (k1 ? gq & 0xffff0000u : 0u);
+            }
+            *reinterpret_cast<u32x4_g*>(Gg + j * kRSG + 16 * pc) = u32x4_g{m[0], m[1], m[2], m[3]};
+        }
+        const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.adj), 0, sat_i32(static_cast<int64_t>(p.B) * n * n * 2), 0x00020000);
+        for (int q = part * 64 + lane; q < 32 * 32; q += 64 * NS) {      // adj[j][i], element-wise: any n <= 32
+            const int j = q >> 5, i = q & 31;
+            const uint32_t v = (g < p.B && j < n && i < n) ? __builtin_amdgcn_raw_buffer_load_b16(ra, static_cast<uint32_t>(((static_cast<int64_t>(g) * n + j) * n + i) * 2), 0, 0) : 0u;
+            *reinterpret_cast<uint16_t*>(Ag + j * kRSA + 2 * i) = static_cast<uint16_t>(v);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // the first two slabs too
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    auto tr_frag = [](const unsigned char* lo_p, const unsigned char* hi_p) {
+        typedef short i16x4 __attribute__((ext_vector_type(4)));
+        const i16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(lo_p));
+        const i16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(hi_p));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    const int tr_row = 8 * lq + (li >> 2), tr_col = 4 * (li & 3);
+    bf16x8 adjf[2];                                                      // B fragments of adj: k = node j, column = node i of tile it
+#pragma unroll
+    for (int it = 0; it < 2; ++it) adjf[it] = tr_frag(Ag + tr_row * kRSA + (16 * it + tr_col) * 2, Ag + (tr_row + 4) * kRSA + (16 * it + tr_col) * 2);
+    auto pack2 = [](float a, float b) { return static_cast<uint32_t>(f2bf(a)) | (static_cast<uint32_t>(f2bf(b)) << 16); };
+    const int wrow = li, whalf = 8 * (lq & 1), wk1 = lq >> 1, wk2 = 2 + (lq >> 1);
+    const int my_tt = part >> 1, my_it = part & 1;                       // the 16 x 16 tile of a K step's g_support this part stores
+    int cb = 0;
+    bool started = false;
+    f32x4 acc[NTP][2];
+
+#pragma unroll 1
+    for (int l = p.L - 1; l >= 0; --l) {
+#pragma unroll
+        for (int c = 0; c < NTP; ++c)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) acc[c][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the ReLU mask of the NEXT tile (output of layer l - 1) for this lane's accumulators: requested now, used behind the K loop
+        u32x2_g fm[NTP][2];
+        {
+            const uint16_t* ap = l > 0 ? p.act[l - 1] : p.adj;
+            const auto rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ap), 0, l > 0 ? sat_i32(rows_total * p.lda * 2) : 0, 0x00020000);
+#pragma unroll
+            for (int c = 0; c < NTP; ++c)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int i = 16 * it + li, f0 = 16 * (c_lo + c) + 4 * lq;
+                    const uint32_t off = (g < p.B && i < n && f0 < p.lda) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.lda + f0) * 2) : 0xfffffff0u;
+                    fm[c][it] = __builtin_amdgcn_raw_buffer_load_b64(rf, off, 0, 0);
+                }
+        }
+        const auto rs_ = __builtin_amdgcn_make_buffer_rsrc(p.gsup[l], 0, sat_i32(rows_total * p.lds * 2), 0x00020000);
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ++ks) {
+            if (started) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDW) : "memory");      // this wave's copies of this step (and everything older) have landed
+            started = true;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                // everybody's have; the tile written by the previous layer's epilogue is complete
+            asm volatile("" ::: "memory");
+            issue();
+            // 1. g_support^T tiles of this K step (32 columns o)
+            bf16x8 bfr[2];
+            {
+                f32x4 sa[2][2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int ot = 2 * ks + tt;
+                    const bf16x8 af = tr_frag(Gg + tr_row * kRSG + (16 * ot + tr_col) * 2, Gg + (tr_row + 4) * kRSG + (16 * ot + tr_col) * 2);
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) sa[tt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, adjf[it], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                }
+                uint32_t q[2][2][2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) { q[tt][it][0] = pack2(sa[tt][it][0], sa[tt][it][1]); q[tt][it][1] = pack2(sa[tt][it][2], sa[tt][it][3]); }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) bfr[it] = __builtin_bit_cast(bf16x8, u32x4_g{q[0][it][0], q[0][it][1], q[1][it][0], q[1][it][1]});
+                const int i = 16 * my_it + li, o0 = 16 * (2 * ks + my_tt) + 4 * lq;
+                const uint32_t off = (g < p.B && i < n && o0 < p.lds) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.lds + o0) * 2) : 0xfffffff0u;
+                const u32x2_g sv = my_tt == 0 ? (my_it == 0 ? u32x2_g{q[0][0][0], q[0][0][1]} : u32x2_g{q[0][1][0], q[0][1][1]})
+                                              : (my_it == 0 ? u32x2_g{q[1][0][0], q[1][0][1]} : u32x2_g{q[1][1][0], q[1][1][1]});
+                __builtin_amdgcn_raw_buffer_store_b64(sv, rs_, off, 0, 0);
+            }
+            // 2. g_x^T += W . g_support^T
+            const unsigned char* slab = sb_sm + cb * SLAB;
+#pragma unroll
+            for (int c = 0; c < NTP; ++c) {
+                const int f = 16 * (c_lo + c) + wrow;
+                const u32x2_g a1 = *reinterpret_cast<const u32x2_g*>(slab + gf_lds_off(f, wk1) + whalf);
+                const u32x2_g a2 = *reinterpret_cast<const u32x2_g*>(slab + gf_lds_off(f, wk2) + whalf);
+                const bf16x8 af = __builtin_bit_cast(bf16x8, u32x4_g{a1.x, a1.y, a2.x, a2.y});
+                acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[0], acc[c][0], 0, 0, 0);
+                acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[1], acc[c][1], 0, 0, 0);
+            }
+            cb = cb + 1 == NRING ? 0 : cb + 1;
+        }
+        // bias gradient, first pass: column sums of the staged tile over the graph's nodes (fixed order), each part its 80 columns
+        if (p.colsum[l] && g < p.B) {
+            for (int o = 16 * c_lo + lane; o < 16 * (c_lo + NTP) && o < D; o += 64) {
+                float sacc = 0.f;
+#pragma unroll 8
+                for (int j = 0; j < 32; ++j) sacc += bf2f(*reinterpret_cast<const uint16_t*>(Gg + j * kRSG + 2 * o));
+                p.colsum[l][static_cast<int64_t>(g) * D + o] = sacc;
+            }
+        }
+        // every wave must be past its last read of the tile before the next one overwrites it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (l > 0) {
+#pragma unroll
+            for (int c = 0; c < NTP; ++c)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int i = 16 * it + li, f0 = 16 * (c_lo + c) + 4 * lq;
+                    uint32_t v0 = pack2(acc[c][it][0], acc[c][it][1]), v1 = pack2(acc[c][it][2], acc[c][it][3]);
+                    const uint32_t m0 = fm[c][it].x, m1 = fm[c][it].y;
+                    v0 = (((m0 & 0x8000u) == 0 && (m0 & 0x7fffu) != 0) ? v0 & 0xffffu : 0u) | (((m0 & 0x80000000u) == 0 && (m0 & 0x7fff0000u) != 0) ? v0 & 0xffff0000u : 0u);
+                    v1 = (((m1 & 0x8000u) == 0 && (m1 & 0x7fffu) != 0) ? v1 & 0xffffu : 0u) | (((m1 & 0x80000000u) == 0 && (m1 & 0x7fff0000u) != 0) ? v1 & 0xffff0000u : 0u);
+                    *reinterpret_cast<u32x2_g*>(Gg + i * kRSG + 2 * f0) = u32x2_g{v0, v1};
+                }
+        } else if (p.gx) {
+            const auto rx_ = __builtin_amdgcn_make_buffer_rsrc(p.gx, 0, sat_i32(rows_total * p.ldgx * 2), 0x00020000);
+#pragma unroll
+            for (int c = 0; c < NTP; ++c)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int i = 16 * it + li, f0 = 16 * (c_lo + c) + 4 * lq;
+                    const uint32_t off = (g < p.B && i < n && f0 < p.ldgx) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.ldgx + f0) * 2) : 0xfffffff0u;
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2_g{pack2(acc[c][it][0], acc[c][it][1]), pack2(acc[c][it][2], acc[c][it][3])}, rx_, off, 0, 0);
+                }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // copies of steps past the end target this workgroup's LDS
 }
 
 bool gcn_fused_ok(const recon_gcn_b16_args* a) {
@@ -947,6 +1168,136 @@ extern "C" int recon_gcn_b16_stack_fwd(const recon_gcn_b16_stack_args* a, recon_
         hipLaunchKernelGGL(k_gcn_b16_stack_fwd<2>, dim3(static_cast<unsigned>(ceil_div64(a->B, 4))), dim3(512), lds, as_stream(stream), k);
     }
     RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+// ---- the stack with gradients: forward = the kernel above keeping every layer's result, backward = k_gcn_b16_stack_bwd + one k-major GEMM per layer
+static int stack_train_check(const recon_gcn_b16_stack_train_args* a, bool bwd) {
+    if (!a || a->B < 0 || a->n <= 0 || a->in_features <= 0 || a->hidden <= 0 || a->L < 1 || a->L > kMaxStack) return RECON_ERR_INVALID;
+    if (!a->x || !a->adj || !a->weight || !a->planes || !a->acts) return RECON_ERR_INVALID;
+    const int64_t o8 = (a->hidden + 7) / 8 * 8, i8 = (a->in_features + 7) / 8 * 8;
+    if ((a->ldx & 7) || a->ldx < i8 || (a->ldo & 7) || a->ldo < o8) return RECON_ERR_INVALID;
+    uintptr_t al = reinterpret_cast<uintptr_t>(a->x);
+    for (int l = 0; l < a->L; ++l) {
+        if (!a->weight[l] || !a->planes[l] || !a->acts[l]) return RECON_ERR_INVALID;
+        al |= reinterpret_cast<uintptr_t>(a->planes[l]) | reinterpret_cast<uintptr_t>(a->acts[l]);
+        if (a->bias && a->bias[l] && (reinterpret_cast<uintptr_t>(a->bias[l]) & 7)) return RECON_ERR_UNSUPPORTED;
+    }
+    if (a->n > 32 || (a->n & 3) || a->ldo > kFusedNT * 16 || (a->hidden & 3) || a->B > 65535 * 4) return RECON_ERR_UNSUPPORTED;
+    if (a->in_features > 16 * kFusedNT) return RECON_ERR_UNSUPPORTED;                 // g_x of layer 0 is a tile of at most 320 columns
+    if (static_cast<int64_t>(a->B) * a->n * a->ldx * 2 >= 0x7fffffffLL || static_cast<int64_t>(a->B) * a->n * a->ldo * 2 >= 0x7fffffffLL) return RECON_ERR_UNSUPPORTED;
+    if ((al & 15) || (reinterpret_cast<uintptr_t>(a->adj) & 7)) return RECON_ERR_UNSUPPORTED;
+    if (bwd) {
+        // grad_out is read in place through masked 16-byte loads: any even row stride >= hidden, 4-byte aligned
+        if (!a->grad_out || !a->g_support || !a->partial || !a->zeros || (a->ldg & 1) || a->ldg < a->hidden) return RECON_ERR_INVALID;
+        if (a->g_x && ((a->ldgx & 7) || a->ldgx < i8)) return RECON_ERR_INVALID;
+        if (reinterpret_cast<uintptr_t>(a->grad_out) & 3) return RECON_ERR_UNSUPPORTED;
+        uintptr_t bl = reinterpret_cast<uintptr_t>(a->g_x) | reinterpret_cast<uintptr_t>(a->zeros);
+        for (int l = 0; l < a->L; ++l) {
+            if (!a->g_support[l]) return RECON_ERR_INVALID;
+            bl |= reinterpret_cast<uintptr_t>(a->g_support[l]);
+        }
+        if (bl & 15) return RECON_ERR_UNSUPPORTED;
+        if (static_cast<int64_t>(a->B) * a->n * a->ldg * 2 >= 0x7fffffffLL || (a->g_x && static_cast<int64_t>(a->B) * a->n * a->ldgx * 2 >= 0x7fffffffLL)) return RECON_ERR_UNSUPPORTED;
+    }
+    return RECON_OK;
+}
+
+extern "C" int recon_gcn_b16_stack_train_fwd(const recon_gcn_b16_stack_train_args* a, recon_stream_t stream) {
+    int rc = stack_train_check(a, false);
+    if (rc != RECON_OK) return rc;
+    if (a->B == 0) return RECON_OK;
+    hipStream_t st = as_stream(stream);
+    const int32_t D = a->hidden;
+    GcnStackK k{};
+    k.x = static_cast<const uint16_t*>(a->x); k.ldx = a->ldx; k.adj = static_cast<const uint16_t*>(a->adj);
+    for (int l = 0; l < a->L; ++l) {
+        const int32_t I = l == 0 ? a->in_features : D;
+        char* wp = static_cast<char*>(a->planes[l]);
+        rc = b16_pad_planes_both(a->weight[l], D, I, D, wp, wp + planes_part(D, I), st);       // W^T [D][kp(I)] for this pass, W [I][kp(D)] for the backward
+        if (rc != RECON_OK) return rc;
+        k.wt[l] = reinterpret_cast<const uint16_t*>(wp);
+        k.bias[l] = (a->bias && a->bias[l]) ? static_cast<const uint16_t*>(a->bias[l]) : nullptr;
+        k.save[l] = l < a->L - 1 ? static_cast<uint16_t*>(a->acts[l]) : nullptr;
+    }
+    k.out = static_cast<uint16_t*>(a->acts[a->L - 1]); k.ldo = a->ldo;
+    k.B = a->B; k.n = a->n; k.I0 = a->in_features; k.D = D; k.L = a->L; k.nt = static_cast<int32_t>(ceil_div64(a->ldo, 16));
+    const int64_t nki = ((a->in_features > D ? a->in_features : D) + 31) / 32;
+    const size_t lds = 3ull * kFusedNT * 16 * 64 + static_cast<size_t>(kMaxStack) * kFusedNT * 32 + 4ull * nki * 2048 + 1024;
+    if (lds > 160 * 1024) return RECON_ERR_UNSUPPORTED;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gcn_b16_stack_fwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipLaunchKernelGGL(k_gcn_b16_stack_fwd<4>, dim3(static_cast<unsigned>(ceil_div64(a->B, 4))), dim3(1024), lds, st, k);
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+// floats of the split-K partials of the stack's weight gradients: [layer 0: sk x in x hidden][layers 1 ..: sk x hidden x hidden each]
+// (sized for the largest split count any subset of the layers' products may run with: a frozen layer drops out of the launch)
+static int stack_gw_splits(int32_t B, int32_t n, int32_t in_features, int32_t hidden, int32_t L) {
+    int sk = 1;
+    for (int32_t Mx : {in_features > hidden ? in_features : hidden, hidden})
+        for (int c = 1; c <= L; ++c) {
+            const int v = c == 1 ? b16_kmajor_splits(Mx, hidden, B * n) : b16_kmajor_splits_multi(Mx, hidden, B * n, c);
+            sk = v > sk ? v : sk;
+        }
+    return sk;
+}
+static size_t stack_gw_partial_floats(int32_t B, int32_t n, int32_t in_features, int32_t hidden, int32_t L) {
+    const size_t sk = static_cast<size_t>(stack_gw_splits(B, n, in_features, hidden, L));
+    return sk * in_features * hidden + static_cast<size_t>(L - 1) * sk * hidden * hidden;
+}
+
+extern "C" size_t recon_gcn_b16_stack_bwd_partial_floats(int32_t B, int32_t n, int32_t in_features, int32_t hidden, int32_t L) {
+    if (B <= 0 || n <= 0 || in_features <= 0 || hidden <= 0 || L <= 0) return 1;
+    // [split-K partials of every layer's g_W][L x per-graph column sums for the g_bias]
+    return stack_gw_partial_floats(B, n, in_features, hidden, L) + static_cast<size_t>(L) * B * hidden + 1;
+}
+
+extern "C" int recon_gcn_b16_stack_train_bwd(const recon_gcn_b16_stack_train_args* a, recon_stream_t stream) {
+    int rc = stack_train_check(a, true);
+    if (rc != RECON_OK) return rc;
+    if (a->B == 0) return RECON_OK;
+    hipStream_t st = as_stream(stream);
+    const int32_t D = a->hidden, rows = a->B * a->n;
+    float* colsum = a->partial + stack_gw_partial_floats(a->B, a->n, a->in_features, D, a->L);
+    GcnStackBwdK k{};
+    k.gout = static_cast<const uint16_t*>(a->grad_out); k.ldg = a->ldg; k.lda = a->ldo; k.adj = static_cast<const uint16_t*>(a->adj);
+    k.lds = a->ldo; k.gx = static_cast<uint16_t*>(a->g_x); k.ldgx = a->ldgx;
+    k.B = a->B; k.n = a->n; k.I0 = a->in_features; k.D = D; k.Op = b16_kp(D); k.L = a->L;
+    for (int l = 0; l < a->L; ++l) {
+        const int32_t I = l == 0 ? a->in_features : D;
+        k.act[l] = static_cast<const uint16_t*>(a->acts[l]);
+        k.wn[l] = reinterpret_cast<const uint16_t*>(static_cast<const char*>(a->planes[l]) + planes_part(D, I));
+        k.gsup[l] = static_cast<uint16_t*>(a->g_support[l]);
+        k.colsum[l] = (a->g_bias && a->g_bias[l]) ? colsum + static_cast<size_t>(l) * a->B * D : nullptr;
+    }
+    const size_t lds = 3ull * kFusedNT * 16 * 64 + 4ull * 32 * kRSG + 4ull * 32 * kRSA + 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gcn_b16_stack_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipLaunchKernelGGL(k_gcn_b16_stack_bwd, dim3(static_cast<unsigned>(ceil_div64(a->B, 4))), dim3(1024), lds, st, k);
+    RECON_CHECK_LAUNCH();
+    // g_W_l = x_l^T @ g_support_l for every layer in ONE k-major launch (split-K over the B*n rows) + one fixed-order second pass that also
+    // finishes the bias gradients
+    B16KmProduct pr[kMaxStack];
+    B16ReduceJob bj[kMaxStack];
+    int np = 0, nbj = 0;
+    const size_t sk = static_cast<size_t>(stack_gw_splits(a->B, a->n, a->in_features, D, a->L));
+    float* part = a->partial;
+    for (int l = 0; l < a->L; ++l) {
+        const int32_t I = l == 0 ? a->in_features : D;
+        if (a->g_weight && a->g_weight[l])
+            pr[np++] = B16KmProduct{l == 0 ? a->x : a->acts[l - 1], l == 0 ? a->ldx : a->ldo, a->g_support[l], a->ldo, a->g_weight[l], D, part, I, D};
+        part += sk * I * D;
+        if (a->g_bias && a->g_bias[l]) bj[nbj++] = B16ReduceJob{k.colsum[l], static_cast<uint16_t*>(a->g_bias[l]), D, a->B, 1, D};
+    }
+    if (np > 0) {
+        rc = gemm_b16_kmajor_multi(np, pr, rows, a->zeros, st, nbj ? bj : nullptr, nbj);
+        if (rc != RECON_OK) return rc;
+    } else {
+        for (int j = 0; j < nbj; ++j) {
+            hipLaunchKernelGGL(k_gcn_b16_bias_reduce, dim3(static_cast<unsigned>(ceil_div64(D, 16))), dim3(1024), 0, st, bj[j].partial, a->B, D, bj[j].out);
+            RECON_CHECK_LAUNCH();
+        }
+    }
     return RECON_OK;
 }
 

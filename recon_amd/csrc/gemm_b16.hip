@@ -164,11 +164,13 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_b16(const B16Args p) {
 
 // ---- k-major form: partial[z][M][N] = A[ks..ke, :M]^T . B[ks..ke, :N]; both tiles by LDS-DMA into row-major images, fragments
 //      through the transposing read (layouts of gemm_hx2.hip / gemm_bx3.hip); rows past the K range come from a page of zeros
+constexpr int kKmJobs = 8;                                           // products of one launch (the layers of a GraphConvolution stack)
 struct B16KmArgs {
-    const uint16_t* A; const uint16_t* B; const uint16_t* zeros;
-    int64_t lda, ldb;
-    float* partial;
-    int32_t M, N, K, k_per_split, nsplit, m_ld, n_ld;
+    const uint16_t* A[kKmJobs]; const uint16_t* B[kKmJobs]; const uint16_t* zeros;
+    int64_t lda[kKmJobs], ldb[kKmJobs];
+    float* partial[kKmJobs];
+    int32_t M[kKmJobs], N[kKmJobs], m_ld[kKmJobs], n_ld[kKmJobs];
+    int32_t K, k_per_split, nsplit;                                    // shared: grid.z = jobs x nsplit
 };
 constexpr int KB_SLOTS = 28;
 constexpr int KA_BYTES = BK * 256, KB_BYTES = BK * KB_SLOTS * 16;                      // 8192, 14336
@@ -185,7 +187,13 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_b16_kmajor(const B16KmArgs p) {
     const int t = threadIdx.x, lane = t & 63;
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const TileId tile = xcd_tile(1);
-    const int m0 = tile.y * BM, n0 = tile.x * BN, zs = tile.z;
+    const int job = tile.z / p.nsplit, zs = tile.z - job * p.nsplit;
+    const int m0 = tile.y * BM, n0 = tile.x * BN;
+    const int pM = p.M[job], pN = p.N[job], p_m_ld = p.m_ld[job], p_n_ld = p.n_ld[job];
+    if (m0 >= pM || n0 >= pN) return;                                  // (the grid covers the largest job)
+    const uint16_t* const pA = p.A[job];
+    const uint16_t* const pB = p.B[job];
+    const int64_t p_lda = p.lda[job], p_ldb = p.ldb[job];
     const int k_begin = zs * p.k_per_split, k_end = min(p.K, k_begin + p.k_per_split);
     // pieces 0..7: A image (piece = 4 k rows of 16 slots), pieces 8..21: B image (64 slots each, 28 per k row): 22 pieces over 4 waves
     constexpr int NP = KA_PIECES + KB_PIECES, ND = (NP + 3) / 4;
@@ -196,13 +204,13 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_b16_kmajor(const B16KmArgs p) {
         if (pc < KA_PIECES) {
             const int s = 64 * pc + lane, k = s >> 4, phys = s & 15;
             d_k[i] = k;
-            d_col[i] = min(m0 + 16 * ((phys >> 1) ^ ka_h(k)) + 8 * (phys & 1), p.m_ld - 8);
+            d_col[i] = min(m0 + 16 * ((phys >> 1) ^ ka_h(k)) + 8 * (phys & 1), p_m_ld - 8);
         } else {
             const int s = 64 * (pc - KA_PIECES) + lane, k = s / KB_SLOTS, phys = s % KB_SLOTS;
             int slot = phys - ((k & 8) ? 2 : 0);
             if (slot < 0 || slot >= 26) slot = 0;
             d_k[i] = k;
-            d_col[i] = min(n0 + 8 * slot, p.n_ld - 8);
+            d_col[i] = min(n0 + 8 * slot, p_n_ld - 8);
         }
     }
     const uint16_t* zlane = p.zeros + 8 * lane;
@@ -212,7 +220,7 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_b16_kmajor(const B16KmArgs p) {
             if (4 * i + wid < NP) {                                       // wave-uniform
                 const int pc = 4 * i + wid, k = k0 + d_k[i];
                 const bool isa = pc < KA_PIECES;
-                const uint16_t* q = k < k_end ? (isa ? p.A + static_cast<int64_t>(k) * p.lda : p.B + static_cast<int64_t>(k) * p.ldb) + d_col[i] : zlane;
+                const uint16_t* q = k < k_end ? (isa ? pA + static_cast<int64_t>(k) * p_lda : pB + static_cast<int64_t>(k) * p_ldb) + d_col[i] : zlane;
                 unsigned char* dst = S[buf] + (isa ? 1024 * pc : KA_BYTES + 1024 * (pc - KA_PIECES));
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(q), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
             }
@@ -254,17 +262,17 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_b16_kmajor(const B16KmArgs p) {
         }
         buf ^= 1;
     }
-    float* base = p.partial + static_cast<int64_t>(tile.z) * p.M * p.N;
+    float* base = p.partial[job] + static_cast<int64_t>(zs) * pM * pN;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + mb + 16 * i + 4 * g + r;
-            if (row >= p.M) continue;
+            if (row >= pM) continue;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + 16 * j + ip;
-                if (col < p.N) base[static_cast<int64_t>(row) * p.N + col] = acc[i][j][r];
+                if (col < pN) base[static_cast<int64_t>(row) * pN + col] = acc[i][j][r];
             }
         }
 }
@@ -308,6 +316,39 @@ __global__ void __launch_bounds__(256) k_b16_reduce(const B16ReduceJob j0, const
     float s = 0.f;
     if (idx < MN) {                                                    // eight independent loads in flight: a chain of 64 dependent round trips (the
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // bias job at B = 1024) would cost more than the launch it saves
+        int z = z0;
+        for (; z + 8 <= z1; z += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += j.partial[(z + u) * MN + idx];
+        }
+        for (; z < z1; ++z) a[0] += j.partial[z * MN + idx];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    red[grp][e] = s;
+    __syncthreads();
+    if (grp == 0 && idx < MN) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][e];
+        j.out[(idx / j.N) * j.ldo + idx % j.N] = f2bf(t);
+    }
+}
+
+// The same second pass for up to 2 x kKmJobs jobs in one launch (the weight and bias gradients of every layer of a stack): blocks
+// [first[j], first[j + 1]) belong to job j; per element the same grouping and order as k_b16_reduce.
+struct B16ReduceMulti { B16ReduceJob job[2 * kKmJobs]; int32_t first[2 * kKmJobs + 1]; int32_t count; };
+__global__ void __launch_bounds__(256) k_b16_reduce_multi(const B16ReduceMulti q) {
+    __shared__ float red[16][17];
+    int ji = 0;
+    while (ji + 1 < q.count && static_cast<int>(blockIdx.x) >= q.first[ji + 1]) ++ji;
+    const B16ReduceJob& j = q.job[ji];
+    const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int64_t idx = static_cast<int64_t>(blockIdx.x - q.first[ji]) * 16 + e, MN = static_cast<int64_t>(j.M) * j.N;
+    const int per = (j.splits + 15) / 16;
+    const int z0 = grp * per, z1 = min(j.splits, (grp + 1) * per);
+    float s = 0.f;
+    if (idx < MN) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int z = z0;
         for (; z + 8 <= z1; z += 8) {
 #pragma unroll
@@ -371,36 +412,67 @@ int gemm_b16(int32_t M, int32_t N, int32_t K, const void* A, int64_t lda, const 
 }
 
 int b16_kmajor_splits(int32_t M, int32_t N, int32_t K) { return bx3_kmajor_splits(K, bx3_kmajor_split_k(M, N, K, 1)); }
+// splits of a launch of `count` products that share K (M, N: the largest)
+int b16_kmajor_splits_multi(int32_t M, int32_t N, int32_t K, int32_t count) { return bx3_kmajor_splits(K, bx3_kmajor_split_k(M, N, K, count)); }
 
-// out (bf16 [M][N], row stride ldo) = A[K,M]^T . B[K,N]; lda, ldb % 8 == 0, every row holds (M resp. N rounded up to 8) readable
-// columns; `partial` = b16_kmajor_splits(M, N, K) * M * N floats; `zeros` = 1 KiB of zero bytes
-int gemm_b16_kmajor(int32_t M, int32_t N, int32_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* out, int64_t ldo, float* partial,
-                    const void* zeros, hipStream_t st, const B16ReduceJob* extra) {
-    if (M < 0 || N < 0 || K < 0) return RECON_ERR_INVALID;
-    if (M == 0 || N == 0) return RECON_OK;
-    if (!A || !B || !out || !partial || !zeros) return RECON_ERR_INVALID;
-    const int32_t m_ld = (M + 7) / 8 * 8, n_ld = (N + 7) / 8 * 8;
-    if ((lda & 7) || (ldb & 7) || m_ld > lda || n_ld > ldb ||
-        ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(zeros)) & 15))
-        return RECON_ERR_UNSUPPORTED;
-    B16KmArgs a;
-    a.A = static_cast<const uint16_t*>(A); a.B = static_cast<const uint16_t*>(B); a.zeros = static_cast<const uint16_t*>(zeros);
-    a.lda = lda; a.ldb = ldb; a.partial = partial; a.M = M; a.N = N; a.K = K; a.m_ld = m_ld; a.n_ld = n_ld;
-    const int sk = b16_kmajor_splits(M, N, K);
+// out_j (bf16 [M_j][N_j], row stride ldo_j) = A_j[K,M_j]^T . B_j[K,N_j] for `count` <= 8 products over the same K rows in ONE launch + one
+// second pass (which also runs the `extra` jobs: the bias gradients); lda, ldb % 8 == 0, every row holds (M resp. N rounded up to 8)
+// readable columns; partial_j = `splits` * M_j * N_j floats (splits = b16_kmajor_splits for one product, _multi for several)
+int gemm_b16_kmajor_multi(int32_t count, const B16KmProduct* pr, int32_t K, const void* zeros, hipStream_t st, const B16ReduceJob* extra, int32_t n_extra) {
+    if (count < 1 || count > kKmJobs || !pr || K < 0 || n_extra < 0 || n_extra > kKmJobs || !zeros || (reinterpret_cast<uintptr_t>(zeros) & 15)) return RECON_ERR_INVALID;
+    B16KmArgs a{};
+    int32_t Mx = 0, Nx = 0;
+    for (int j = 0; j < count; ++j) {
+        const B16KmProduct& q = pr[j];
+        if (q.M <= 0 || q.N <= 0 || !q.A || !q.B || !q.out || !q.partial) return RECON_ERR_INVALID;
+        const int32_t m_ld = (q.M + 7) / 8 * 8, n_ld = (q.N + 7) / 8 * 8;
+        if ((q.lda & 7) || (q.ldb & 7) || m_ld > q.lda || n_ld > q.ldb || ((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B)) & 15))
+            return RECON_ERR_UNSUPPORTED;
+        a.A[j] = static_cast<const uint16_t*>(q.A); a.B[j] = static_cast<const uint16_t*>(q.B); a.lda[j] = q.lda; a.ldb[j] = q.ldb;
+        a.partial[j] = q.partial; a.M[j] = q.M; a.N[j] = q.N; a.m_ld[j] = m_ld; a.n_ld[j] = n_ld;
+        Mx = q.M > Mx ? q.M : Mx; Nx = q.N > Nx ? q.N : Nx;
+    }
+    a.zeros = static_cast<const uint16_t*>(zeros); a.K = K;
+    const int sk = count == 1 ? b16_kmajor_splits(Mx, Nx, K) : b16_kmajor_splits_multi(Mx, Nx, K, count);
     int64_t kps = ceil_div64(K > 0 ? K : 1, sk);
     kps = ceil_div64(kps, BK) * BK;
     a.k_per_split = static_cast<int32_t>(kps);
     a.nsplit = static_cast<int32_t>(ceil_div64(K > 0 ? K : 1, kps));
-    if (a.nsplit != sk || sk > 65535) return RECON_ERR_INVALID;
-    const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, BM)), static_cast<unsigned>(sk));
+    if (a.nsplit != sk || static_cast<int64_t>(sk) * count > 65535) return RECON_ERR_INVALID;
+    const dim3 grid(static_cast<unsigned>(ceil_div64(Nx, BN)), static_cast<unsigned>(ceil_div64(Mx, BM)), static_cast<unsigned>(sk * count));
     hipLaunchKernelGGL(k_gemm_b16_kmajor, grid, dim3(NT), 0, st, a);
-    const B16ReduceJob j0{partial, static_cast<uint16_t*>(out), ldo, sk, M, N};
-    const B16ReduceJob j1 = extra ? *extra : B16ReduceJob{nullptr, nullptr, 0, 0, 0, 0};
-    const int nblk0 = static_cast<int>(ceil_div64(static_cast<int64_t>(M) * N, 16));
-    const int nblk1 = extra ? static_cast<int>(ceil_div64(static_cast<int64_t>(j1.M) * j1.N, 16)) : 0;
-    hipLaunchKernelGGL(k_b16_reduce, dim3(static_cast<unsigned>(nblk0 + nblk1)), dim3(256), 0, st, j0, j1, nblk0);
+    if (count == 1 && n_extra <= 1) {
+        const B16ReduceJob j0{pr[0].partial, static_cast<uint16_t*>(pr[0].out), pr[0].ldo, sk, pr[0].M, pr[0].N};
+        const B16ReduceJob j1 = n_extra ? extra[0] : B16ReduceJob{nullptr, nullptr, 0, 0, 0, 0};
+        const int nblk0 = static_cast<int>(ceil_div64(static_cast<int64_t>(j0.M) * j0.N, 16));
+        const int nblk1 = n_extra ? static_cast<int>(ceil_div64(static_cast<int64_t>(j1.M) * j1.N, 16)) : 0;
+        hipLaunchKernelGGL(k_b16_reduce, dim3(static_cast<unsigned>(nblk0 + nblk1)), dim3(256), 0, st, j0, j1, nblk0);
+    } else {
+        B16ReduceMulti q{};
+        int nb = 0;
+        for (int j = 0; j < count; ++j) {
+            q.job[q.count] = B16ReduceJob{pr[j].partial, static_cast<uint16_t*>(pr[j].out), pr[j].ldo, sk, pr[j].M, pr[j].N};
+            q.first[q.count++] = nb;
+            nb += static_cast<int>(ceil_div64(static_cast<int64_t>(pr[j].M) * pr[j].N, 16));
+        }
+        for (int j = 0; j < n_extra; ++j) {
+            q.job[q.count] = extra[j];
+            q.first[q.count++] = nb;
+            nb += static_cast<int>(ceil_div64(static_cast<int64_t>(extra[j].M) * extra[j].N, 16));
+        }
+        q.first[q.count] = nb;
+        hipLaunchKernelGGL(k_b16_reduce_multi, dim3(static_cast<unsigned>(nb)), dim3(256), 0, st, q);
+    }
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
+}
+
+int gemm_b16_kmajor(int32_t M, int32_t N, int32_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* out, int64_t ldo, float* partial,
+                    const void* zeros, hipStream_t st, const B16ReduceJob* extra) {
+    if (M < 0 || N < 0 || K < 0) return RECON_ERR_INVALID;
+    if (M == 0 || N == 0) return RECON_OK;
+    const B16KmProduct pr{A, lda, B, ldb, out, ldo, partial, M, N};
+    return gemm_b16_kmajor_multi(1, &pr, K, zeros, st, extra, extra ? 1 : 0);
 }
 
 }  // namespace recon

@@ -95,6 +95,20 @@ __device__ __forceinline__ void dma16_to_lds(const void* src, const void* lds_ds
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(m0_saved) : "v"(src), "s"(a) : "memory");
 }
+// The same through a buffer descriptor (range-checked: a lane whose offset lies past `bytes` copies zeros), for rings whose tails and dead
+// pieces rely on that.  `base`, `bytes` and `lds_dst` must be wave-uniform.
+typedef uint32_t dma_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dma_u32x4 dma_descriptor(const void* base, uint32_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    auto uni = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(v)); };
+    return dma_u32x4{uni(static_cast<uint32_t>(a)), uni(static_cast<uint32_t>(a >> 32) & 0xffffu), uni(bytes), 0x00020000u};
+}
+__device__ __forceinline__ void dma16_buffer_to_lds(dma_u32x4 desc, uint32_t byte_offset, const void* lds_dst) {
+    const uint32_t a = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)(lds_dst))));
+    uint32_t m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "v"(byte_offset), "s"(desc), "s"(a) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -280,6 +294,7 @@ int gemm_f32_batched(int32_t M, int32_t N, int32_t K, const OperandDesc& A, bool
 
 // second pass of a split-K product with bf16 output (gemm_b16.hip): out[M][N] (row stride ldo) = sum of `splits` fp32 partials [z][M][N]
 struct B16ReduceJob { const float* partial; uint16_t* out; int64_t ldo; int32_t splits, M, N; };
+struct B16KmProduct { const void* A; int64_t lda; const void* B; int64_t ldb; void* out; int64_t ldo; float* partial; int32_t M, N; };
 
 // split-precision (bf16 x 3) MFMA GEMM, gemm_bx3.hip: C = act(A . B^T), A fp32 k-contiguous, B pre-split bf16 planes
 // [3][batch][N][bx3_kp(K)] written by bx3_split_planes (transposed = true reads src as [K][rows]).

@@ -109,6 +109,22 @@ def _rows_view(t, feat, pads_read=True):
     return ld
 
 
+def _rows_in_place(t, feat):
+    """Row stride of a [..., n, feat] bf16 tensor a kernel with masked row tails can read where it lies: rows of feat contiguous elements
+    at a regular EVEN stride >= feat, 4-byte aligned.  None: repack."""
+    if t.dim() < 2 or t.stride(-1) != 1:
+        return None
+    ld = t.stride(-2)
+    if ld % 2 or ld < feat or t.data_ptr() % 4:
+        return None
+    rows = t.shape[-2]
+    for d in range(t.dim() - 3, -1, -1):
+        if t.shape[d] != 1 and t.stride(d) != rows * ld:
+            return None
+        rows *= t.shape[d]
+    return ld
+
+
 def _packed_rows(t, feat, zero_pad):
     """[rows, ld] bf16 buffer holding t's rows (ld = feat rounded up to 8); pad columns zeroed when the kernels multiply them."""
     ld = (feat + 7) // 8 * 8
@@ -391,17 +407,100 @@ def invalidate_stack_planes():
     _STACK_PLANES.clear()
 
 
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[(t.data_ptr() if t is not None else None) for t in tensors])
+
+
+class _GcnB16StackFunction(torch.autograd.Function):
+    """`for l in layers: x = l(x, adj)` with gradients, as one launch forward and one launch + one weight-gradient GEMM per layer backward
+    (csrc/gcn_b16.hip: k_gcn_b16_stack_fwd keeping every layer's result, k_gcn_b16_stack_bwd): models/layers.py:57-63 applied L times.
+    Bit-equal to the loop over _GcnB16Function in outputs and in every gradient.  `adj` gets no gradient here (gcn_stack() routes such
+    calls through the loop)."""
+
+    @staticmethod
+    def forward(ctx, x, adj, n_layers, *params):
+        ws, bs = list(params[0::2]), list(params[1::2])
+        n, I = x.shape[-2], x.shape[-1]
+        D = ws[0].shape[1]
+        B = x.numel() // (n * I)
+        dev = x.device
+        L = _lib.lib()
+        o8 = (D + 7) // 8 * 8
+        ldx = _rows_view(x, I)                                          # rows the weight-gradient GEMM can read: stride % 8 == 0, zero pads
+        xr = x
+        if ldx is None:
+            xr, ldx = _packed_rows(x, I, zero_pad=True)
+        adj3 = adj.contiguous().view(-1, n, n)
+        ws = [w.contiguous() for w in ws]
+        acts = [torch.empty(B * n, o8, dtype=torch.bfloat16, device=dev) for _ in range(n_layers)]
+        planes = [torch.empty(L.recon_gcn_b16_planes_bytes(w.shape[0], D), dtype=torch.uint8, device=dev) for w in ws]
+        args = _lib.GcnB16StackTrainArgs(B, n, I, D, n_layers, xr.data_ptr(), ldx, adj3.data_ptr(), _ptr_array(ws), _ptr_array(bs), _ptr_array(planes),
+                                         _ptr_array(acts), o8)
+        with _lib.on_device(dev):
+            _lib.check(L.recon_gcn_b16_stack_train_fwd(C.byref(args), _lib.current_stream()), "recon_gcn_b16_stack_train_fwd")
+        ctx.save_for_backward(xr, adj3, *ws, *[b for b in bs if b is not None], *acts, *planes)
+        ctx.meta = (B, n, I, D, n_layers, ldx, o8, tuple(x.shape), [b is not None for b in bs])
+        out_p = acts[-1]
+        if o8 == D:
+            return out_p.view(x.shape[:-1] + (D,))
+        out = out_p.as_strided(x.shape[:-1] + (D,), _strides(x.shape[:-1], o8))
+        out._recon_padded = True
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        B, n, I, D, nl, ldx, o8, xs, has_b = ctx.meta
+        sv = list(ctx.saved_tensors)
+        xr, adj3 = sv[0], sv[1]
+        ws = sv[2:2 + nl]
+        nb = sum(has_b)
+        bl = sv[2 + nl:2 + nl + nb]
+        bs, it = [], iter(bl)
+        for h in has_b:
+            bs.append(next(it) if h else None)
+        acts = sv[2 + nl + nb:2 + 2 * nl + nb]
+        planes = sv[2 + 2 * nl + nb:]
+        dev = gout.device
+        L = _lib.lib()
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        if gout.dtype != torch.bfloat16:
+            gout = gout.to(torch.bfloat16)
+        ldg = _rows_in_place(gout, D)                               # read in place through masked loads: any even row stride
+        gr = gout
+        if ldg is None:
+            gr, ldg = _packed_rows(gout, D, zero_pad=False)
+        i8 = (I + 7) // 8 * 8
+        need = ctx.needs_input_grad
+        g_sup = [torch.empty(B * n, o8, **bf) for _ in range(nl)]
+        partial = torch.empty(L.recon_gcn_b16_stack_bwd_partial_floats(B, n, I, D, nl), dtype=torch.float32, device=dev)
+        g_x = torch.empty(B * n, i8, **bf) if need[0] else None
+        g_w = [torch.empty(w.shape[0], D, **bf) if need[3 + 2 * l] else None for l, w in enumerate(ws)]
+        g_b = [torch.empty(D, **bf) if (bs[l] is not None and need[4 + 2 * l]) else None for l in range(nl)]
+        args = _lib.GcnB16StackTrainArgs(B, n, I, D, nl, xr.data_ptr(), ldx, adj3.data_ptr(), _ptr_array(ws), _ptr_array(bs), _ptr_array(planes),
+                                         _ptr_array(acts), o8, gr.data_ptr(), ldg, _ptr_array(g_sup), partial.data_ptr(), _lib.ptr(g_x), i8,
+                                         _ptr_array(g_w), _ptr_array(g_b), _zero_page(dev).data_ptr())
+        with _lib.on_device(dev):
+            _lib.check(L.recon_gcn_b16_stack_train_bwd(C.byref(args), _lib.current_stream()), "recon_gcn_b16_stack_train_bwd")
+        if g_x is not None:
+            g_x = g_x.view(xs) if i8 == I else g_x.as_strided(xs, _strides(xs[:-1], i8))
+        grads = []
+        for l in range(nl):
+            grads += [g_w[l], g_b[l]]
+        return (g_x, None, None, *grads)
+
+
 def gcn_stack(x, adj, layers):
     """`for l in layers: x = l(x, adj)` — the reference's stacks of GraphConvolutions over one adjacency (models/layers.py:57-63 applied
-    len(layers) times) — as ONE launch where that is possible: bfloat16 tensors, inference (torch.no_grad() or nothing requiring grad),
-    graphs of n <= 32 nodes with n % 4 == 0, every layer hidden -> hidden after the first with hidden % 4 == 0, hidden <= 320.  The
-    activations of a graph stay in LDS between the layers (csrc/gcn_b16.hip: k_gcn_b16_stack_fwd); the result is bit-equal to the loop,
-    which is also what runs for every other case.  Repacked weights are kept per weight tensor (identity + version); call
+    len(layers) times) — as ONE launch where that is possible: bfloat16 tensors, graphs of n <= 32 nodes with n % 4 == 0, every layer
+    hidden -> hidden after the first with hidden % 4 == 0, hidden <= 320.  The activations of a graph stay in LDS between the layers
+    (csrc/gcn_b16.hip: k_gcn_b16_stack_fwd); with gradients (anything but `adj` requiring grad, in_features <= 320) the forward also keeps
+    every layer's result and the backward is the mirror-image kernel + one weight-gradient GEMM per layer (_GcnB16StackFunction).  Results
+    and gradients are bit-equal to the loop, which is also what runs for every other case.  Repacked weights are kept per weight tensor (identity + version); call
     invalidate_stack_planes() after writing through `weight.data`."""
     layers = list(layers)
     need_grad = torch.is_grad_enabled() and (x.requires_grad or adj.requires_grad or any(p.requires_grad for l in layers for p in l.parameters()))
-    ok = (len(layers) >= 2 and len(layers) <= 8 and not need_grad and x.is_cuda and x.dtype == torch.bfloat16 and adj.dtype == torch.bfloat16
-          and x.dim() in (2, 3) and os.environ.get("RECON_GCN_STACK", "1") != "0")
+    ok = (len(layers) >= 2 and len(layers) <= 8 and x.is_cuda and x.dtype == torch.bfloat16 and adj.dtype == torch.bfloat16
+          and x.dim() in (2, 3) and os.environ.get("RECON_GCN_STACK", "1") != "0" and not (need_grad and adj.requires_grad))
     if ok:
         n, I = x.shape[-2], x.shape[-1]
         B = x.numel() // (n * I) if x.numel() else 0
@@ -409,8 +508,17 @@ def gcn_stack(x, adj, layers):
         ok = (B > 0 and n <= 32 and n % 4 == 0 and D % 4 == 0 and (D + 7) // 8 * 8 <= 320 and layers[0].in_features == I
               and all(l.in_features == D and l.out_features == D for l in layers[1:])
               and all(l.weight.dtype == torch.bfloat16 and (l.bias is None or l.bias.data_ptr() % 8 == 0) for l in layers)
-              and x.is_contiguous() and I % 2 == 0 and x.data_ptr() % 16 == 0 and adj.is_contiguous() and adj.data_ptr() % 8 == 0
-              and adj.numel() == B * n * n and B * n * max(I, (D + 7) // 8 * 8) * 2 < 2 ** 31 - 1 and B <= 4 * _MAX_BATCH)
+              and adj.is_contiguous() and adj.data_ptr() % 8 == 0
+              and adj.numel() == B * n * n and B * n * max((I + 7) // 8 * 8, (D + 7) // 8 * 8) * 2 < 2 ** 31 - 1 and B <= 4 * _MAX_BATCH)
+        if ok and need_grad:
+            ok = (I + 7) // 8 * 8 <= 320 and os.environ.get("RECON_GCN_STACK_TRAIN", "1") != "0"
+        elif ok:
+            ok = x.is_contiguous() and I % 2 == 0 and x.data_ptr() % 16 == 0
+    if ok and need_grad:
+        params = []
+        for l in layers:
+            params += [l.weight, l.bias]
+        return _GcnB16StackFunction.apply(x, adj, len(layers), *params)
     if not ok:
         for l in layers:
             x = l(x, adj)

@@ -194,15 +194,22 @@ def gcn_bf16(B=1024, n=32, D=300, hops=3, iters=10):
     def fwd_stack():
         with torch.no_grad():
             gcn_stack(x, adj, layers)
+    def fwd_bwd_stack():
+        for l in layers:
+            l.weight.grad = None
+            l.bias.grad = None
+        x.grad = None
+        gcn_stack(x, adj, layers).backward(G)
     s = 2.0
     nbytes = hops * (2 * B * n * D * s + B * n * n * s + D * D * s)
     nbytes_fused = 2 * B * n * D * s + B * n * n * s + hops * D * D * s          # H resident on chip across the hops
     flops = hops * 2.0 * B * n * D * (D + n)
     tf, tb, ts = _time(fwd, iters), _time(fwd_bwd, max(2, iters // 2)), _time(fwd_stack, iters)
+    tsb = _time(fwd_bwd_stack, max(2, iters // 2))
     return {"B": B, "n": n, "D": D, "hops": hops, "dtype": "bf16", "fwd_ms": tf * 1e3, "fwd_bwd_ms": tb * 1e3, "bytes": nbytes, "flops": flops,
             "bound": "hbm", "frac": nbytes / tf / HBM_PEAK, "GBps": nbytes / tf / 1e9, "TFLOPs": flops / tf / 1e12,
             "dense_edges_per_s_fwd": B * n * n * hops / tf,
-            "fused_stack": {"fwd_ms": ts * 1e3, "bytes": nbytes_fused, "frac": nbytes_fused / ts / HBM_PEAK, "frac_of_bf16_mfma": flops / ts / MFMA_F16_PEAK,
+            "fused_stack": {"fwd_ms": ts * 1e3, "fwd_bwd_ms": tsb * 1e3, "bytes": nbytes_fused, "frac": nbytes_fused / ts / HBM_PEAK, "frac_of_bf16_mfma": flops / ts / MFMA_F16_PEAK,
                             "kernel": "k_gcn_b16_stack_fwd (gcn_stack(): all hops in one launch, activations in LDS)"}}
 
 
