@@ -576,7 +576,9 @@ int recon_gcn_b16_stack_fwd(const recon_gcn_b16_stack_args* args, recon_stream_t
  * order of the split-K partials only (fixed, run-to-run reproducible).  Shapes as for recon_gcn_b16_stack_fwd, and in_features <= 320. */
 typedef struct {
     int32_t B, n, in_features, hidden, L;
-    const void* x; int64_t ldx;         /* [B*n, ldx] bf16, ldx % 8 == 0, columns in_features .. ldx zero (operand of layer 0's weight gradient) */
+    const void* x; int64_t ldx;         /* [B*n, ldx] bf16; ldx % 8 == 0 — or, with x_rows set, any even ldx >= in_features (read in place)     */
+    void* x_rows; int64_t ldxr;         /* optional [B*n, ldxr] bf16, ldxr % 8 == 0: the forward leaves x here with 16-byte aligned rows for     *
+                                         * layer 0's weight gradient (feature counts like 300: no repacking pass in front of the call)          */
     const void* adj;                    /* [B, n, n] bf16, 8-byte aligned                                                                      */
     const void* const* weight;          /* HOST array of L device pointers W_l [in_l][hidden] bf16, contiguous                                 */
     const void* const* bias;            /* HOST array of L device pointers [hidden] bf16 (entries, or the array, may be NULL)                  */
@@ -588,7 +590,7 @@ typedef struct {
     const void* grad_out; int64_t ldg;  /* [B*n, ldg] bf16: gradient of acts[L-1]; any even ldg >= hidden, 4-byte aligned (read in place)      */
     void* const* g_support;             /* HOST array of L workspaces [B*n, ldo] bf16                                                          */
     float* partial;                     /* recon_gcn_b16_stack_bwd_partial_floats() floats                                                     */
-    void* g_x; int64_t ldgx;            /* [B*n, ldgx] bf16 or NULL                                                                            */
+    void* g_x; int64_t ldgx;            /* [B*n, ldgx] bf16 or NULL; ldgx % 4 == 0, >= in_features rounded up to 4, 8-byte aligned              */
     void* const* g_weight;              /* HOST array of L device pointers [in_l][hidden] bf16 (entries, or the array, may be NULL)            */
     void* const* g_bias;                /* HOST array of L device pointers [hidden] bf16 (entries, or the array, may be NULL)                  */
     const void* zeros;                  /* >= 1 KiB of zero bytes, 16-byte aligned                                                             */

@@ -125,7 +125,8 @@ class GcnB16StackArgs(C.Structure):
 
 class GcnB16StackTrainArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("n", C.c_int32), ("in_features", C.c_int32), ("hidden", C.c_int32), ("L", C.c_int32),
-                ("x", C.c_void_p), ("ldx", C.c_int64), ("adj", C.c_void_p), ("weight", C.POINTER(C.c_void_p)), ("bias", C.POINTER(C.c_void_p)),
+                ("x", C.c_void_p), ("ldx", C.c_int64), ("x_rows", C.c_void_p), ("ldxr", C.c_int64), ("adj", C.c_void_p),
+                ("weight", C.POINTER(C.c_void_p)), ("bias", C.POINTER(C.c_void_p)),
                 ("planes", C.POINTER(C.c_void_p)), ("acts", C.POINTER(C.c_void_p)), ("ldo", C.c_int64),
                 ("grad_out", C.c_void_p), ("ldg", C.c_int64), ("g_support", C.POINTER(C.c_void_p)), ("partial", C.c_void_p),
                 ("g_x", C.c_void_p), ("ldgx", C.c_int64), ("g_weight", C.POINTER(C.c_void_p)), ("g_bias", C.POINTER(C.c_void_p)),

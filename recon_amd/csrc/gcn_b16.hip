@@ -17,6 +17,7 @@ int b16_kmajor_splits(int32_t M, int32_t N, int32_t K);
 int b16_pad_planes_both(const void* src, int64_t ld, int32_t M, int32_t N, void* dst_t, void* dst_n, hipStream_t st);
 int gemm_b16_kmajor(int32_t M, int32_t N, int32_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* out, int64_t ldo, float* partial,
                     const void* zeros, hipStream_t st, const B16ReduceJob* extra);
+int b16_pad_planes_both_multi(int32_t count, const void* const* src, const int32_t* M, const int32_t* N, void* const* dst_t, void* const* dst_n, hipStream_t st);
 int b16_kmajor_splits_multi(int32_t M, int32_t N, int32_t K, int32_t count);
 int gemm_b16_kmajor_multi(int32_t count, const B16KmProduct* pr, int32_t K, const void* zeros, hipStream_t st, const B16ReduceJob* extra, int32_t n_extra);
 
@@ -382,6 +383,7 @@ struct GcnStackK {
     const uint16_t* bias[kMaxStack];
     uint16_t* out; int64_t ldo;
     uint16_t* save[kMaxStack];                                           // training: the result of layer l < L - 1, [B*n][ldo] (null: not kept)
+    uint16_t* xcopy; int64_t ldxc;                                       // training: a copy of x with 16-byte aligned rows (operand of layer 0's weight gradient), or null
     int32_t B, n, I0, D, L, nt;                                          // in_0 = I0, every layer's out = in_{l+1} = D; nt = ceil(ldo / 16)
 };
 
@@ -465,6 +467,19 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
         for (int it = 0; it < 2; ++it) adjf[it] = __builtin_bit_cast(bf16x8, u32x4_g{adjv[it][0].x, adjv[it][0].y, adjv[it][1].x, adjv[it][1].y});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the x tiles, the first two slabs, adj
+    if (p.xcopy) {
+        // every wave writes the x pieces it copied itself back out with aligned rows (what lies behind a row's last feature goes along:
+        // those columns of the weight-gradient GEMM's operand only reach rows of the product that are never stored)
+        const auto rc = __builtin_amdgcn_make_buffer_rsrc(p.xcopy, 0, sat_i32(rows_total * p.ldxc * 2), 0x00020000);
+        const int npc = 4 * nk0 * 2;
+        for (int pc = w; pc < npc; pc += NW) {
+            const int gq = pc / (2 * nk0), r = pc - gq * 2 * nk0, ks = r >> 1, half = r & 1;
+            const int gg = blockIdx.x * 4 + gq, i = 16 * half + c_row, col = 32 * ks + 8 * c_kq;
+            const u32x4_g v = *reinterpret_cast<const u32x4_g*>(st_sm + NRING * SLAB + gq * nki * 2048 + ks * 2048 + half * 1024 + lane * 16);
+            const uint32_t off = (gg < p.B && i < n && col < p.ldxc) ? static_cast<uint32_t>(((static_cast<int64_t>(gg) * n + i) * p.ldxc + col) * 2) : 0xfffffff0u;
+            __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
+        }
+    }
     const u32x4_g allmask = u32x4_g{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     const int b_rd = gf_lds_off(li, lq) + 1024 * c_lo;
     const int a_rd0 = gf_lds_off(li, lq), a_rd1 = gf_lds_off(16 + li, lq);
@@ -1176,8 +1191,11 @@ static int stack_train_check(const recon_gcn_b16_stack_train_args* a, bool bwd) 
     if (!a || a->B < 0 || a->n <= 0 || a->in_features <= 0 || a->hidden <= 0 || a->L < 1 || a->L > kMaxStack) return RECON_ERR_INVALID;
     if (!a->x || !a->adj || !a->weight || !a->planes || !a->acts) return RECON_ERR_INVALID;
     const int64_t o8 = (a->hidden + 7) / 8 * 8, i8 = (a->in_features + 7) / 8 * 8;
-    if ((a->ldx & 7) || a->ldx < i8 || (a->ldo & 7) || a->ldo < o8) return RECON_ERR_INVALID;
-    uintptr_t al = reinterpret_cast<uintptr_t>(a->x);
+    if ((a->ldo & 7) || a->ldo < o8) return RECON_ERR_INVALID;
+    // x either has rows the weight-gradient GEMM can read (stride % 8 == 0), or the forward leaves a copy with such rows in x_rows
+    if (a->x_rows ? ((a->ldx & 1) || a->ldx < a->in_features || (a->ldxr & 7) || a->ldxr < i8) : ((a->ldx & 7) || a->ldx < i8)) return RECON_ERR_INVALID;
+    uintptr_t al = reinterpret_cast<uintptr_t>(a->x) | reinterpret_cast<uintptr_t>(a->x_rows);
+    if (a->x_rows && static_cast<int64_t>(a->B) * a->n * a->ldxr * 2 >= 0x7fffffffLL) return RECON_ERR_UNSUPPORTED;
     for (int l = 0; l < a->L; ++l) {
         if (!a->weight[l] || !a->planes[l] || !a->acts[l]) return RECON_ERR_INVALID;
         al |= reinterpret_cast<uintptr_t>(a->planes[l]) | reinterpret_cast<uintptr_t>(a->acts[l]);
@@ -1190,9 +1208,10 @@ static int stack_train_check(const recon_gcn_b16_stack_train_args* a, bool bwd) 
     if (bwd) {
         // grad_out is read in place through masked 16-byte loads: any even row stride >= hidden, 4-byte aligned
         if (!a->grad_out || !a->g_support || !a->partial || !a->zeros || (a->ldg & 1) || a->ldg < a->hidden) return RECON_ERR_INVALID;
-        if (a->g_x && ((a->ldgx & 7) || a->ldgx < i8)) return RECON_ERR_INVALID;
-        if (reinterpret_cast<uintptr_t>(a->grad_out) & 3) return RECON_ERR_UNSUPPORTED;
-        uintptr_t bl = reinterpret_cast<uintptr_t>(a->g_x) | reinterpret_cast<uintptr_t>(a->zeros);
+        // g_x leaves the kernel as 8-byte stores of four features: any row stride % 4 == 0 >= in_features rounded up to 4, 8-byte aligned
+        if (a->g_x && ((a->ldgx & 3) || a->ldgx < (a->in_features + 3) / 4 * 4)) return RECON_ERR_INVALID;
+        if ((reinterpret_cast<uintptr_t>(a->grad_out) & 3) || (reinterpret_cast<uintptr_t>(a->g_x) & 7)) return RECON_ERR_UNSUPPORTED;
+        uintptr_t bl = reinterpret_cast<uintptr_t>(a->zeros);
         for (int l = 0; l < a->L; ++l) {
             if (!a->g_support[l]) return RECON_ERR_INVALID;
             bl |= reinterpret_cast<uintptr_t>(a->g_support[l]);
@@ -1211,16 +1230,23 @@ extern "C" int recon_gcn_b16_stack_train_fwd(const recon_gcn_b16_stack_train_arg
     const int32_t D = a->hidden;
     GcnStackK k{};
     k.x = static_cast<const uint16_t*>(a->x); k.ldx = a->ldx; k.adj = static_cast<const uint16_t*>(a->adj);
+    // every layer's W^T [D][kp(I)] (this pass) and W [I][kp(D)] (the backward) in one launch
+    int32_t pm[kMaxStack], pn[kMaxStack];
+    void* pt[kMaxStack]; void* pnn[kMaxStack];
     for (int l = 0; l < a->L; ++l) {
-        const int32_t I = l == 0 ? a->in_features : D;
+        pm[l] = l == 0 ? a->in_features : D; pn[l] = D;
+        pt[l] = a->planes[l]; pnn[l] = static_cast<char*>(a->planes[l]) + planes_part(D, pm[l]);
+    }
+    rc = b16_pad_planes_both_multi(a->L, a->weight, pm, pn, pt, pnn, st);
+    if (rc != RECON_OK) return rc;
+    for (int l = 0; l < a->L; ++l) {
         char* wp = static_cast<char*>(a->planes[l]);
-        rc = b16_pad_planes_both(a->weight[l], D, I, D, wp, wp + planes_part(D, I), st);       // W^T [D][kp(I)] for this pass, W [I][kp(D)] for the backward
-        if (rc != RECON_OK) return rc;
         k.wt[l] = reinterpret_cast<const uint16_t*>(wp);
         k.bias[l] = (a->bias && a->bias[l]) ? static_cast<const uint16_t*>(a->bias[l]) : nullptr;
         k.save[l] = l < a->L - 1 ? static_cast<uint16_t*>(a->acts[l]) : nullptr;
     }
     k.out = static_cast<uint16_t*>(a->acts[a->L - 1]); k.ldo = a->ldo;
+    k.xcopy = static_cast<uint16_t*>(a->x_rows); k.ldxc = a->ldxr;
     k.B = a->B; k.n = a->n; k.I0 = a->in_features; k.D = D; k.L = a->L; k.nt = static_cast<int32_t>(ceil_div64(a->ldo, 16));
     const int64_t nki = ((a->in_features > D ? a->in_features : D) + 31) / 32;
     const size_t lds = 3ull * kFusedNT * 16 * 64 + static_cast<size_t>(kMaxStack) * kFusedNT * 32 + 4ull * nki * 2048 + 1024;
@@ -1285,7 +1311,8 @@ extern "C" int recon_gcn_b16_stack_train_bwd(const recon_gcn_b16_stack_train_arg
     for (int l = 0; l < a->L; ++l) {
         const int32_t I = l == 0 ? a->in_features : D;
         if (a->g_weight && a->g_weight[l])
-            pr[np++] = B16KmProduct{l == 0 ? a->x : a->acts[l - 1], l == 0 ? a->ldx : a->ldo, a->g_support[l], a->ldo, a->g_weight[l], D, part, I, D};
+            pr[np++] = B16KmProduct{l == 0 ? (a->x_rows ? a->x_rows : a->x) : a->acts[l - 1], l == 0 ? (a->x_rows ? a->ldxr : a->ldx) : a->ldo, a->g_support[l], a->ldo,
+                                    a->g_weight[l], D, part, I, D};
         part += sk * I * D;
         if (a->g_bias && a->g_bias[l]) bj[nbj++] = B16ReduceJob{k.colsum[l], static_cast<uint16_t*>(a->g_bias[l]), D, a->B, 1, D};
     }

@@ -12,6 +12,7 @@
 #include "gemm_common.h"
 
 namespace recon {
+int32_t b16_kp(int32_t K);
 namespace {
 
 constexpr int BM = 128, BN = 208, BK = 32, NT = 256, TN = 13;
@@ -334,16 +335,53 @@ __global__ void __launch_bounds__(256) k_b16_reduce(const B16ReduceJob j0, const
     }
 }
 
+// k_b16_pad_both for the weights of up to kKmJobs layers in one launch: blocks [first[j], first[j + 1]) belong to layer j
+struct B16PadMulti { const uint16_t* src[kKmJobs]; uint16_t* dst_t[kKmJobs]; uint16_t* dst_n[kKmJobs]; int32_t M[kKmJobs], N[kKmJobs], nb_t[kKmJobs], first[kKmJobs + 1]; int32_t count; };
+__global__ void __launch_bounds__(256) k_b16_pad_both_multi(const B16PadMulti q) {
+    int j = 0;
+    while (j + 1 < q.count && static_cast<int>(blockIdx.x) >= q.first[j + 1]) ++j;
+    const int blk = static_cast<int>(blockIdx.x) - q.first[j];
+    const int32_t M = q.M[j], N = q.N[j], Kp_t = (M + 31) & ~31, Kp_n = (N + 31) & ~31;
+    const uint16_t* __restrict__ src = q.src[j];
+    // (weights of a layer: M * kp(N) < 2^31 — 32-bit index arithmetic, the 64-bit divisions were most of this kernel)
+    if (blk < q.nb_t[j]) {
+        // W^T: 32 x 32 tiles through LDS, reads along a row of W and writes along a row of W^T both contiguous (element by element the
+        // writes had been one cache line per lane)
+        __shared__ uint16_t tile[32][33];
+        const int ntr = (N + 31) >> 5;                                  // tiles along r (rows of W^T)
+        const int kt = blk / ntr, rt = blk - kt * ntr;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 32 * kt + ty + 8 * i, r = 32 * rt + tx;
+            tile[ty + 8 * i][tx] = (k < M && r < N) ? src[static_cast<uint32_t>(k) * N + r] : static_cast<uint16_t>(0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 32 * rt + ty + 8 * i, k = 32 * kt + tx;
+            if (r < N) q.dst_t[j][static_cast<uint32_t>(r) * Kp_t + k] = tile[tx][ty + 8 * i];
+        }
+    } else {
+        const uint32_t idx = static_cast<uint32_t>(blk - q.nb_t[j]) * 256u + threadIdx.x;
+        if (idx >= static_cast<uint32_t>(M) * Kp_n) return;
+        const uint32_t r = idx / static_cast<uint32_t>(Kp_n), k = idx - r * Kp_n;
+        q.dst_n[j][r * Kp_n + k] = static_cast<int>(k) < N ? src[r * N + k] : 0;
+    }
+}
+
 // The same second pass for up to 2 x kKmJobs jobs in one launch (the weight and bias gradients of every layer of a stack): blocks
 // [first[j], first[j + 1]) belong to job j; per element the same grouping and order as k_b16_reduce.
 struct B16ReduceMulti { B16ReduceJob job[2 * kKmJobs]; int32_t first[2 * kKmJobs + 1]; int32_t count; };
-__global__ void __launch_bounds__(256) k_b16_reduce_multi(const B16ReduceMulti q) {
-    __shared__ float red[16][17];
+__global__ void __launch_bounds__(1024) k_b16_reduce_multi(const B16ReduceMulti q) {
+    // 64 consecutive elements x the sixteen split groups per block (a wave reads 256 contiguous bytes of a partial; k_b16_reduce's 16-element
+    // blocks read 64): per element the same grouping and order, so the bits are those of k_b16_reduce
+    __shared__ float red[16][65];
     int ji = 0;
     while (ji + 1 < q.count && static_cast<int>(blockIdx.x) >= q.first[ji + 1]) ++ji;
     const B16ReduceJob& j = q.job[ji];
-    const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int64_t idx = static_cast<int64_t>(blockIdx.x - q.first[ji]) * 16 + e, MN = static_cast<int64_t>(j.M) * j.N;
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t idx = static_cast<int64_t>(blockIdx.x - q.first[ji]) * 64 + e, MN = static_cast<int64_t>(j.M) * j.N;
     const int per = (j.splits + 15) / 16;
     const int z0 = grp * per, z1 = min(j.splits, (grp + 1) * per);
     float s = 0.f;
@@ -390,6 +428,26 @@ int b16_pad_planes_both(const void* src, int64_t ld, int32_t M, int32_t N, void*
     const int nb_t = static_cast<int>(ceil_div64(static_cast<int64_t>(N) * Kp_t, 256)), nb_n = static_cast<int>(ceil_div64(static_cast<int64_t>(M) * Kp_n, 256));
     hipLaunchKernelGGL(k_b16_pad_both, dim3(static_cast<unsigned>(nb_t + nb_n)), dim3(256), 0, st, static_cast<const uint16_t*>(src), ld, M, N, Kp_t, Kp_n,
                        static_cast<uint16_t*>(dst_t), static_cast<uint16_t*>(dst_n), nb_t);
+    if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+
+// W_j^T [N_j][kp(M_j)] and W_j [M_j][kp(N_j)] of `count` <= 8 contiguous weights [M_j][N_j] in one launch
+int b16_pad_planes_both_multi(int32_t count, const void* const* src, const int32_t* M, const int32_t* N, void* const* dst_t, void* const* dst_n, hipStream_t st) {
+    if (count < 1 || count > kKmJobs) return RECON_ERR_INVALID;
+    B16PadMulti q{};
+    int nb = 0;
+    for (int j = 0; j < count; ++j) {
+        if (M[j] <= 0 || N[j] <= 0 || !src[j] || !dst_t[j] || !dst_n[j]) return RECON_ERR_INVALID;
+        if (static_cast<int64_t>(M[j]) * b16_kp(N[j]) >= (1LL << 31) || static_cast<int64_t>(N[j]) * b16_kp(M[j]) >= (1LL << 31)) return RECON_ERR_UNSUPPORTED;
+        q.src[j] = static_cast<const uint16_t*>(src[j]); q.dst_t[j] = static_cast<uint16_t*>(dst_t[j]); q.dst_n[j] = static_cast<uint16_t*>(dst_n[j]);
+        q.M[j] = M[j]; q.N[j] = N[j];
+        q.nb_t[j] = (b16_kp(M[j]) / 32) * static_cast<int>(ceil_div64(N[j], 32));          // 32 x 32 tiles of W^T [N][kp(M)]
+        q.first[j] = nb;
+        nb += q.nb_t[j] + static_cast<int>(ceil_div64(static_cast<int64_t>(M[j]) * b16_kp(N[j]), 256));
+    }
+    q.first[count] = nb; q.count = count;
+    hipLaunchKernelGGL(k_b16_pad_both_multi, dim3(static_cast<unsigned>(nb)), dim3(256), 0, st, q);
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
 }
@@ -453,15 +511,15 @@ int gemm_b16_kmajor_multi(int32_t count, const B16KmProduct* pr, int32_t K, cons
         for (int j = 0; j < count; ++j) {
             q.job[q.count] = B16ReduceJob{pr[j].partial, static_cast<uint16_t*>(pr[j].out), pr[j].ldo, sk, pr[j].M, pr[j].N};
             q.first[q.count++] = nb;
-            nb += static_cast<int>(ceil_div64(static_cast<int64_t>(pr[j].M) * pr[j].N, 16));
+            nb += static_cast<int>(ceil_div64(static_cast<int64_t>(pr[j].M) * pr[j].N, 64));
         }
         for (int j = 0; j < n_extra; ++j) {
             q.job[q.count] = extra[j];
             q.first[q.count++] = nb;
-            nb += static_cast<int>(ceil_div64(static_cast<int64_t>(extra[j].M) * extra[j].N, 16));
+            nb += static_cast<int>(ceil_div64(static_cast<int64_t>(extra[j].M) * extra[j].N, 64));
         }
         q.first[q.count] = nb;
-        hipLaunchKernelGGL(k_b16_reduce_multi, dim3(static_cast<unsigned>(nb)), dim3(256), 0, st, q);
+        hipLaunchKernelGGL(k_b16_reduce_multi, dim3(static_cast<unsigned>(nb)), dim3(1024), 0, st, q);
     }
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;

@@ -411,11 +411,17 @@ def _ptr_array(tensors):
     return (C.c_void_p * len(tensors))(*[(t.data_ptr() if t is not None else None) for t in tensors])
 
 
+def _ptrs(base, offsets):
+    return (C.c_void_p * len(offsets))(*[base + o for o in offsets])
+
+
 class _GcnB16StackFunction(torch.autograd.Function):
-    """`for l in layers: x = l(x, adj)` with gradients, as one launch forward and one launch + one weight-gradient GEMM per layer backward
-    (csrc/gcn_b16.hip: k_gcn_b16_stack_fwd keeping every layer's result, k_gcn_b16_stack_bwd): models/layers.py:57-63 applied L times.
-    Bit-equal to the loop over _GcnB16Function in outputs and in every gradient.  `adj` gets no gradient here (gcn_stack() routes such
-    calls through the loop)."""
+    """`for l in layers: x = l(x, adj)` with gradients, as one launch forward and three launches backward (csrc/gcn_b16.hip:
+    k_gcn_b16_stack_fwd keeping every layer's result; k_gcn_b16_stack_bwd; one split-K launch + one second pass for all weight and bias
+    gradients): models/layers.py:57-63 applied L times.  Output, g_x and g_bias are bit-equal to the loop over _GcnB16Function, g_W up to
+    the summation order of its split-K partials.  `adj` gets no gradient here (gcn_stack() routes such calls through the loop).
+    Host side: one allocation per KIND of buffer (results, repacked weights, g_support, gradients), not per layer — at cfg 3a the loop's
+    ~40 small allocations and launches were as long as its kernels."""
 
     @staticmethod
     def forward(ctx, x, adj, n_layers, *params):
@@ -426,40 +432,47 @@ class _GcnB16StackFunction(torch.autograd.Function):
         dev = x.device
         L = _lib.lib()
         o8 = (D + 7) // 8 * 8
-        ldx = _rows_view(x, I)                                          # rows the weight-gradient GEMM can read: stride % 8 == 0, zero pads
-        xr = x
+        # rows the weight-gradient GEMM of layer 0 can read: 16-byte aligned, stride % 8 == 0 (its pad columns only reach rows of the product
+        # that are never stored, so they need no zeros; the forward kernel masks its own K tail)
+        ldx = _rows_view(x, I, pads_read=False)
+        xr, xin, ldin = x, x, ldx
         if ldx is None:
-            xr, ldx = _packed_rows(x, I, zero_pad=True)
+            ldin = _rows_in_place(x, I)
+            if ldin is not None and x.data_ptr() % 16 == 0:          # the forward kernel reads x where it lies and leaves the aligned copy itself
+                ldx = (I + 7) // 8 * 8
+                xr = torch.empty(B * n, ldx, dtype=torch.bfloat16, device=dev)
+            else:
+                xr, ldx = _packed_rows(x, I, zero_pad=False)
+                xin, ldin = xr, ldx
         adj3 = adj.contiguous().view(-1, n, n)
         ws = [w.contiguous() for w in ws]
-        acts = [torch.empty(B * n, o8, dtype=torch.bfloat16, device=dev) for _ in range(n_layers)]
-        planes = [torch.empty(L.recon_gcn_b16_planes_bytes(w.shape[0], D), dtype=torch.uint8, device=dev) for w in ws]
-        args = _lib.GcnB16StackTrainArgs(B, n, I, D, n_layers, xr.data_ptr(), ldx, adj3.data_ptr(), _ptr_array(ws), _ptr_array(bs), _ptr_array(planes),
-                                         _ptr_array(acts), o8)
+        acts = torch.empty(n_layers, B * n, o8, dtype=torch.bfloat16, device=dev)
+        pb = [(L.recon_gcn_b16_planes_bytes(w.shape[0], D) + 255) // 256 * 256 for w in ws]
+        poff = [sum(pb[:l]) for l in range(n_layers)]
+        planes = torch.empty(sum(pb), dtype=torch.uint8, device=dev)
+        args = _lib.GcnB16StackTrainArgs(B, n, I, D, n_layers, xin.data_ptr(), ldin, xr.data_ptr() if xr is not xin else None, ldx, adj3.data_ptr(),
+                                         _ptr_array(ws), _ptr_array(bs),
+                                         _ptrs(planes.data_ptr(), poff), _ptrs(acts.data_ptr(), [l * B * n * o8 * 2 for l in range(n_layers)]), o8)
         with _lib.on_device(dev):
             _lib.check(L.recon_gcn_b16_stack_train_fwd(C.byref(args), _lib.current_stream()), "recon_gcn_b16_stack_train_fwd")
-        ctx.save_for_backward(xr, adj3, *ws, *[b for b in bs if b is not None], *acts, *planes)
-        ctx.meta = (B, n, I, D, n_layers, ldx, o8, tuple(x.shape), [b is not None for b in bs])
-        out_p = acts[-1]
+        ctx.save_for_backward(xr, adj3, acts, planes, *ws, *[b for b in bs if b is not None])
+        ctx.meta = (B, n, I, D, n_layers, ldx, o8, tuple(x.shape), [b is not None for b in bs], poff)
+        out_p = acts[n_layers - 1]
         if o8 == D:
             return out_p.view(x.shape[:-1] + (D,))
-        out = out_p.as_strided(x.shape[:-1] + (D,), _strides(x.shape[:-1], o8))
+        out = out_p.as_strided(x.shape[:-1] + (D,), _strides(x.shape[:-1], o8), out_p.storage_offset())
         out._recon_padded = True
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        B, n, I, D, nl, ldx, o8, xs, has_b = ctx.meta
-        sv = list(ctx.saved_tensors)
-        xr, adj3 = sv[0], sv[1]
-        ws = sv[2:2 + nl]
-        nb = sum(has_b)
-        bl = sv[2 + nl:2 + nl + nb]
-        bs, it = [], iter(bl)
+        B, n, I, D, nl, ldx, o8, xs, has_b, poff = ctx.meta
+        sv = ctx.saved_tensors
+        xr, adj3, acts, planes = sv[0], sv[1], sv[2], sv[3]
+        ws = sv[4:4 + nl]
+        bs, it = [], iter(sv[4 + nl:])
         for h in has_b:
             bs.append(next(it) if h else None)
-        acts = sv[2 + nl + nb:2 + 2 * nl + nb]
-        planes = sv[2 + 2 * nl + nb:]
         dev = gout.device
         L = _lib.lib()
         bf = dict(dtype=torch.bfloat16, device=dev)
@@ -469,16 +482,21 @@ class _GcnB16StackFunction(torch.autograd.Function):
         gr = gout
         if ldg is None:
             gr, ldg = _packed_rows(gout, D, zero_pad=False)
-        i8 = (I + 7) // 8 * 8
+        i8 = I if I % 4 == 0 else (I + 7) // 8 * 8                  # g_x leaves the kernel as 8-byte stores: a dense [.., I] result where I % 4 == 0
         need = ctx.needs_input_grad
-        g_sup = [torch.empty(B * n, o8, **bf) for _ in range(nl)]
+        rows = B * n
+        g_sup = torch.empty(nl, rows, o8, **bf)
         partial = torch.empty(L.recon_gcn_b16_stack_bwd_partial_floats(B, n, I, D, nl), dtype=torch.float32, device=dev)
-        g_x = torch.empty(B * n, i8, **bf) if need[0] else None
-        g_w = [torch.empty(w.shape[0], D, **bf) if need[3 + 2 * l] else None for l, w in enumerate(ws)]
-        g_b = [torch.empty(D, **bf) if (bs[l] is not None and need[4 + 2 * l]) else None for l in range(nl)]
-        args = _lib.GcnB16StackTrainArgs(B, n, I, D, nl, xr.data_ptr(), ldx, adj3.data_ptr(), _ptr_array(ws), _ptr_array(bs), _ptr_array(planes),
-                                         _ptr_array(acts), o8, gr.data_ptr(), ldg, _ptr_array(g_sup), partial.data_ptr(), _lib.ptr(g_x), i8,
-                                         _ptr_array(g_w), _ptr_array(g_b), _zero_page(dev).data_ptr())
+        g_x = torch.empty(rows, i8, **bf) if need[0] else None
+        # the parameters' gradients: one buffer [g_W_0 | g_W_1 .. | g_b_0 ..], handed back as views
+        wn = [w.shape[0] * D for w in ws]
+        gbuf = torch.empty(sum(wn) + nl * D, **bf)
+        g_w = [gbuf[sum(wn[:l]):sum(wn[:l + 1])].view(ws[l].shape[0], D) if need[3 + 2 * l] else None for l in range(nl)]
+        g_b = [gbuf[sum(wn) + l * D:sum(wn) + (l + 1) * D] if (bs[l] is not None and need[4 + 2 * l]) else None for l in range(nl)]
+        args = _lib.GcnB16StackTrainArgs(B, n, I, D, nl, xr.data_ptr(), ldx, None, 0, adj3.data_ptr(), _ptr_array(ws), _ptr_array(bs),
+                                         _ptrs(planes.data_ptr(), poff), _ptrs(acts.data_ptr(), [l * rows * o8 * 2 for l in range(nl)]), o8,
+                                         gr.data_ptr(), ldg, _ptrs(g_sup.data_ptr(), [l * rows * o8 * 2 for l in range(nl)]), partial.data_ptr(),
+                                         _lib.ptr(g_x), i8, _ptr_array(g_w), _ptr_array(g_b), _zero_page(dev).data_ptr())
         with _lib.on_device(dev):
             _lib.check(L.recon_gcn_b16_stack_train_bwd(C.byref(args), _lib.current_stream()), "recon_gcn_b16_stack_train_bwd")
         if g_x is not None:
