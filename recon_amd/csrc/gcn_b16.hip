@@ -25,6 +25,11 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 __device__ __forceinline__ float bf2f(uint16_t v) { return __builtin_bit_cast(float, static_cast<uint32_t>(v) << 16); }
 __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(uint16_t, static_cast<__bf16>(v)); }
+// two floats -> two bf16 in one register: ONE v_cvt_pk_bf16_f32 (converted one by one and combined by hand the compiler emits two
+// conversions, a shift and an or: the epilogues of the fused kernels are mostly this)
+typedef __bf16 bf16x2_g __attribute__((ext_vector_type(2)));
+typedef float f32x2_g __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf2(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_g{a, b}, bf16x2_g)); }
 // byte extents of buffer descriptors: integer arithmetic only (`min<int64_t>(v, 0x7fffffff)` resolves to a double-precision minimum in
 // the HIP headers: the extent then lives in vector registers and EVERY access through the descriptor is wrapped in a readfirstlane loop)
 __device__ __forceinline__ int sat_i32(int64_t v) { return v < 0x7fffffffLL ? static_cast<int>(v) : 0x7fffffff; }
@@ -339,7 +344,7 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_fwd(const GcnFuse
     }
     // ---- out^T tile = support^T . adj^T ; + bias, ReLU, 8-byte stores (pad columns O .. ldo are written as zeros)
     const auto ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, sat_i32(rows_total * p.ldo * 2), 0x00020000);
-    auto pack2 = [](float a, float b) { return static_cast<uint32_t>(f2bf(a)) | (static_cast<uint32_t>(f2bf(b)) << 16); };
+    auto pack2 = [](float a, float b) { return pack_bf2(a, b); };
 #pragma unroll
     for (int c = 0; c < NTP; ++c)
         if (c_lo + c < nt) {
@@ -392,16 +397,19 @@ struct GcnStackK {
 // 20-KiB slabs two K steps ahead (counted vmcnt, raw s_barrier: the copies stay in flight across the barriers; the first form of this
 // kernel staged W through registers one step ahead and waited for it at every step).  One K-loop body for every layer; NS = 4 column parts
 // = 16 waves per CU fit without spills because nothing but accumulators and fragments lives in registers.
-template <int NS>
-__global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStackK p) {
+// GPW = graphs per wave: a wave that works on two graphs reads each W^T fragment ONCE for both — the K step of the 16-wave form is bound by
+// LDS reads (16 waves x (2 x-fragments + 5 W^T fragments) x 1 KiB = 112 KiB per step at 128 B per clock: ~900 of a step's ~1 800 cycles, in
+// lockstep with the barrier, against 640 cycles of matrix pipe); 8 waves x (2 x 2 + 5) KiB = 72 KiB.
+template <int NS, int GPW>
+__global__ void __launch_bounds__(256 * NS / GPW, 1) k_gcn_b16_stack_fwd(const GcnStackK p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char st_sm[];      // W^T slabs [3][20 KiB] | activations [4 graphs][NKI][2 KiB] | scratch 1 KiB
-    constexpr int NTP = kFusedNT / NS, NW = 4 * NS, SLAB = kFusedNT * 16 * 64, NRING = 3;
+    constexpr int NTP = kFusedNT / NS, NGS = 4 / GPW, NW = NGS * NS, SLAB = kFusedNT * 16 * 64, NRING = 3;      // NGS = graph slots of waves
     constexpr int SP = kFusedNT;                                         // pieces (16 rows x 64 B) of a slab
     constexpr int NDW = (SP + NW - 1) / NW;                               // copy instructions per wave and slab (waves past the last piece: scratch)
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 15, lq = lane >> 4;
-    const int gw = w & 3, g = blockIdx.x * 4 + gw;
-    const int c_lo = (w >> 2) * NTP;
+    const int gw = (w % NGS) * GPW, g0 = blockIdx.x * 4 + gw;            // this wave's first graph (slot in the workgroup, index in the batch)
+    const int c_lo = (w / NGS) * NTP;
     const int n = p.n, nt = p.nt, D = p.D;
     const int nk0 = (p.I0 + 31) >> 5, nkh = (D + 31) >> 5, nki = nk0 > nkh ? nk0 : nkh;      // K steps of layer 0 / of the others / of an image
     unsigned char* Hg = st_sm + NRING * SLAB + gw * nki * 2048;
@@ -421,50 +429,69 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(st_sm + NRING * SLAB + gq * nki * 2048 + ks * 2048 + half * 1024), 16, off, 0, 0, 0);
         }
     }
-    // ---- the W^T slab of flat step f = (layer, K step): this wave's pieces; steps past the end copy nothing real (scratch)
+    // ---- the W^T slab of flat step f = (layer, K step): this wave's pieces.  Everything that does not change from step to step is set up
+    // per LAYER (descriptor, step count) or once (this lane's offsets under the two plane widths, the pieces' places in a slab): the K step
+    // itself advances a scalar offset.  (Computed inside every step, pointer load and branches included, the issue was ~400 of a step's
+    // ~1 900 cycles — cycle stamps — on every wave's path between the barrier and its fragment reads.)  Steps past the last layer run
+    // on a descriptor of zero bytes: zeros into a slab nobody reads.
     int il = 0, ik = 0, ib = 0;                                          // issue side: layer, K step, ring slot
+    const int Ip0 = (p.I0 + 31) & ~31, Iph = (D + 31) & ~31;
+    uint32_t voff0[NDW], voffh[NDW];
+#pragma unroll
+    for (int q = 0; q < NDW; ++q) {
+        const int pc = q * NW + w, o = 16 * pc + c_row;
+        const bool ok = pc < SP && o < 16 * nt;
+        voff0[q] = ok ? static_cast<uint32_t>((o * Ip0 + 8 * c_kq) * 2) : 0xfffffff0u;
+        voffh[q] = ok ? static_cast<uint32_t>((o * Iph + 8 * c_kq) * 2) : 0xfffffff0u;
+    }
+    const uint16_t* wcur = p.wt[0];                                      // the layer being copied: planes and their extent (a pointer and an int, not
+    int wbytes = D * Ip0 * 2, nk_issue = nk0;                            // the descriptor: a variable of that type does not survive the host pass)
     auto issue = [&]() {
-        const bool live = il < p.L;
-        const int I = il == 0 ? p.I0 : D, Ip = (I + 31) & ~31;
-        const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wt[live ? il : 0]), 0, live ? D * Ip * 2 : 0, 0x00020000);
+        const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wcur), 0, wbytes, 0x00020000);
 #pragma unroll
         for (int q = 0; q < NDW; ++q) {
             const int pc = q * NW + w;                                   // wave-uniform
-            const bool real = live && pc < SP;
-            const int o = 16 * pc + c_row;
-            const uint32_t off = (real && o < 16 * nt) ? static_cast<uint32_t>((o * Ip + 32 * ik + 8 * c_kq) * 2) : 0xfffffff0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st_sm + (real ? ib * SLAB + 1024 * pc : scratch)), 16, off, 0, 0, 0);
+            const int vo = static_cast<int>(il == 0 ? voff0[q] : voffh[q]), so = 64 * ik;      // (as locals: passed as expressions the host pass drops the kernel)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st_sm + (pc < SP ? ib * SLAB + 1024 * pc : scratch)), 16, vo, so, 0, 0);
         }
-        const int nk = il == 0 ? nk0 : nkh;
-        if (++ik >= nk) { ik = 0; ++il; }
+        if (++ik >= nk_issue) {
+            ik = 0; ++il; nk_issue = nkh;
+            const bool live = il < p.L;
+            wcur = p.wt[live ? il : 0]; wbytes = live ? D * Iph * 2 : 0;
+        }
         ib = ib + 1 == NRING ? 0 : ib + 1;
     };
     // every layer's bias row into LDS (behind the scratch KiB): [L][kFusedNT * 16] bf16, zeros where a layer has none / past D
     const int bias_sm = scratch + 1024;
-    for (int i = t; i < p.L * kFusedNT * 16; i += 256 * NS) {
+    for (int i = t; i < p.L * kFusedNT * 16; i += 64 * NW) {
         const int l = i / (kFusedNT * 16), o = i - l * (kFusedNT * 16);
         reinterpret_cast<uint16_t*>(st_sm + bias_sm)[i] = (p.bias[l] && o < D) ? p.bias[l][o] : static_cast<uint16_t>(0);
     }
     issue();
     issue();
     // adj^T fragments (8-byte loads: n % 4 == 0, adj 8-byte aligned — checked by the host), kept for all layers
-    bf16x8 adjf[2];
+    bf16x8 adjf[GPW][2];
     {
         const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.adj), 0,
                                                           sat_i32(static_cast<int64_t>(p.B) * n * n * 2), 0x00020000);
-        u32x2_g adjv[2][2];
+        u32x2_g adjv[GPW][2][2];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int i = 16 * it + li;
+        for (int gi = 0; gi < GPW; ++gi)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int j0 = 16 * h + 4 * lq;
-                const uint32_t base = static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * n + j0) * 2);
-                adjv[it][h] = __builtin_amdgcn_raw_buffer_load_b64(ra, (g < p.B && i < n && j0 < n) ? base : 0xfffffff0u, 0, 0);
+            for (int it = 0; it < 2; ++it) {
+                const int i = 16 * it + li, g = g0 + gi;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j0 = 16 * h + 4 * lq;
+                    const uint32_t base = static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * n + j0) * 2);
+                    adjv[gi][it][h] = __builtin_amdgcn_raw_buffer_load_b64(ra, (g < p.B && i < n && j0 < n) ? base : 0xfffffff0u, 0, 0);
+                }
             }
-        }
 #pragma unroll
-        for (int it = 0; it < 2; ++it) adjf[it] = __builtin_bit_cast(bf16x8, u32x4_g{adjv[it][0].x, adjv[it][0].y, adjv[it][1].x, adjv[it][1].y});
+        for (int gi = 0; gi < GPW; ++gi)
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+                adjf[gi][it] = __builtin_bit_cast(bf16x8, u32x4_g{adjv[gi][it][0].x, adjv[gi][it][0].y, adjv[gi][it][1].x, adjv[gi][it][1].y});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the x tiles, the first two slabs, adj
     if (p.xcopy) {
@@ -483,7 +510,7 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
     const u32x4_g allmask = u32x4_g{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     const int b_rd = gf_lds_off(li, lq) + 1024 * c_lo;
     const int a_rd0 = gf_lds_off(li, lq), a_rd1 = gf_lds_off(16 + li, lq);
-    auto pack2 = [](float a, float b) { return static_cast<uint32_t>(f2bf(a)) | (static_cast<uint32_t>(f2bf(b)) << 16); };
+    auto pack2 = [](float a, float b) { return pack_bf2(a, b); };
     int cb = 0;                                                          // ring slot of the step being computed
     bool started = false;
 #ifdef RECON_STAMPS
@@ -508,11 +535,13 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
             for (int d = 0; d < 4; ++d) m[d] = (k0 + 2 * d < I ? 0x0000ffffu : 0u) | (k0 + 2 * d + 1 < I ? 0xffff0000u : 0u);
             tailmask = u32x4_g{m[0], m[1], m[2], m[3]};
         }
-        f32x4 acc[2][NTP];
+        f32x4 acc[GPW][2][NTP];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int gi = 0; gi < GPW; ++gi)
 #pragma unroll
-            for (int c = 0; c < NTP; ++c) acc[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int c = 0; c < NTP; ++c) acc[gi][rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int ks = 0; ks < nks; ++ks) {
             // this wave's copies of this step have landed (those of the next step may still travel) ...
@@ -529,19 +558,36 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
 #ifdef RECON_STAMPS
             if (ns_ < 46) stamp[ns_++] = __builtin_readcyclecounter();
 #endif
-            issue();
             const unsigned char* slab = st_sm + cb * SLAB;
             const u32x4_g km = ks == nks - 1 ? tailmask : allmask;
-            const u32x4_g c0 = *reinterpret_cast<const u32x4_g*>(Hg + ks * 2048 + a_rd0), c1 = *reinterpret_cast<const u32x4_g*>(Hg + ks * 2048 + a_rd1);
-            const bf16x8 a0 = __builtin_bit_cast(bf16x8, c0 & km), a1 = __builtin_bit_cast(bf16x8, c1 & km);
+            bf16x8 af[GPW][2];
+#pragma unroll
+            for (int gi = 0; gi < GPW; ++gi) {
+                const u32x4_g c0 = *reinterpret_cast<const u32x4_g*>(Hg + gi * nki * 2048 + ks * 2048 + a_rd0);
+                const u32x4_g c1 = *reinterpret_cast<const u32x4_g*>(Hg + gi * nki * 2048 + ks * 2048 + a_rd1);
+                af[gi][0] = __builtin_bit_cast(bf16x8, c0 & km); af[gi][1] = __builtin_bit_cast(bf16x8, c1 & km);
+            }
             bf16x8 bq[NTP];
 #pragma unroll
             for (int c = 0; c < NTP; ++c) bq[c] = *reinterpret_cast<const bf16x8*>(slab + b_rd + 1024 * c);
+            // the copies of step ks + 2 are requested BEHIND this step's fragment reads: a slab's 20 KiB pass the CU's vector-memory path in
+            // ~300 cycles (cycle stamps; 64 B per clock), which in front of the reads was dead time for every wave — here it runs under the
+            // reads' latency and the first matrix instructions
+#ifdef RECON_STAMPS
+            if (ns_ < 46) stamp[ns_++] = __builtin_readcyclecounter();
+#endif
+            issue();
+#ifdef RECON_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (ns_ < 46) stamp[ns_++] = __builtin_readcyclecounter();
+#endif
 #pragma unroll
-            for (int c = 0; c < NTP; ++c) {
-                acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq[c], acc[0][c], 0, 0, 0);
-                acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq[c], acc[1][c], 0, 0, 0);
-            }
+            for (int c = 0; c < NTP; ++c)
+#pragma unroll
+                for (int gi = 0; gi < GPW; ++gi) {
+                    acc[gi][0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[gi][0], bq[c], acc[gi][0][c], 0, 0, 0);
+                    acc[gi][1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[gi][1], bq[c], acc[gi][1][c], 0, 0, 0);
+                }
             cb = cb + 1 == NRING ? 0 : cb + 1;
         }
         // the layer's bias values out of LDS (copied there once, at the start: requested here from memory, they made this point a vmcnt(0) that
@@ -554,27 +600,31 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_stack_fwd(const GcnStac
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int c = 0; c < NTP; ++c) {
-            const bf16x8 sf = __builtin_bit_cast(bf16x8, u32x4_g{pack2(acc[0][c][0], acc[0][c][1]), pack2(acc[0][c][2], acc[0][c][3]),
-                                                                   pack2(acc[1][c][0], acc[1][c][1]), pack2(acc[1][c][2], acc[1][c][3])});
             const int o0 = 16 * (c_lo + c) + 4 * lq;
             float bv[4];
             bv[0] = bf2f(static_cast<uint16_t>(bvec[c].x & 0xffffu)); bv[1] = bf2f(static_cast<uint16_t>(bvec[c].x >> 16));
             bv[2] = bf2f(static_cast<uint16_t>(bvec[c].y & 0xffffu)); bv[3] = bf2f(static_cast<uint16_t>(bvec[c].y >> 16));
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, adjf[it], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                const int i = 16 * it + li;
-                float v[4];
+            for (int gi = 0; gi < GPW; ++gi) {
+                const int g = g0 + gi;
+                const bf16x8 sf = __builtin_bit_cast(bf16x8, u32x4_g{pack2(acc[gi][0][c][0], acc[gi][0][c][1]), pack2(acc[gi][0][c][2], acc[gi][0][c][3]),
+                                                                       pack2(acc[gi][1][c][0], acc[gi][1][c][1]), pack2(acc[gi][1][c][2], acc[gi][1][c][3])});
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { v[q] = r[q] + bv[q]; v[q] = (v[q] > 0.f && o0 + q < D) ? v[q] : 0.f; }
-                const u32x2_g pk = u32x2_g{pack2(v[0], v[1]), pack2(v[2], v[3])};
-                // the last layer's result to memory (masked by an out-of-range offset), every other one into the image (tiles past it: scratch).
-                // Rows of nodes past n hold relu(bias): the per-layer kernel never stores them and reads them back as zeros; adj's columns
-                // for them are zero (out-of-range loads), so they never reach a result
-                const uint32_t off = (g < p.B && i < n && o0 < p.ldo) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.ldo + o0) * 2) : 0xfffffff0u;
-                __builtin_amdgcn_raw_buffer_store_b64(pk, ro, off, 0, 0);
-                unsigned char* hd = (!last && o0 < 32 * nkh) ? Hg + (o0 >> 5) * 2048 + gf_lds_off(i, (o0 & 31) >> 3) + 2 * (o0 & 7) : st_sm + scratch;
-                *reinterpret_cast<u32x2_g*>(hd) = pk;
+                for (int it = 0; it < 2; ++it) {
+                    f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, adjf[gi][it], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const int i = 16 * it + li;
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[q] = r[q] + bv[q]; v[q] = (v[q] > 0.f && o0 + q < D) ? v[q] : 0.f; }
+                    const u32x2_g pk = u32x2_g{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                    // the last layer's result to memory (masked by an out-of-range offset), every other one into the image (tiles past it: scratch).
+                    // Rows of nodes past n hold relu(bias): the per-layer kernel never stores them and reads them back as zeros; adj's columns
+                    // for them are zero (out-of-range loads), so they never reach a result
+                    const uint32_t off = (g < p.B && i < n && o0 < p.ldo) ? static_cast<uint32_t>(((static_cast<int64_t>(g) * n + i) * p.ldo + o0) * 2) : 0xfffffff0u;
+                    __builtin_amdgcn_raw_buffer_store_b64(pk, ro, off, 0, 0);
+                    unsigned char* hd = (!last && o0 < 32 * nkh) ? Hg + gi * nki * 2048 + (o0 >> 5) * 2048 + gf_lds_off(i, (o0 & 31) >> 3) + 2 * (o0 & 7) : st_sm + scratch;
+                    *reinterpret_cast<u32x2_g*>(hd) = pk;
+                }
             }
         }
     }
@@ -719,7 +769,7 @@ __global__ void __launch_bounds__(256 * NS, 1) k_gcn_b16_fused_bwd(const GcnFuse
 #pragma unroll
         for (int it = 0; it < 2; ++it) acc[c][it] = f32x4{0.f, 0.f, 0.f, 0.f};
     const auto rs_ = __builtin_amdgcn_make_buffer_rsrc(p.gsup, 0, sat_i32(rows_total * p.lds * 2), 0x00020000);
-    auto pack2 = [](float a, float b) { return static_cast<uint32_t>(f2bf(a)) | (static_cast<uint32_t>(f2bf(b)) << 16); };
+    auto pack2 = [](float a, float b) { return pack_bf2(a, b); };
     // W fragment of row f under the k permutation: k = 4 lq .. + 3 is half (lq & 1) of slot lq >> 1, k = 16 + 4 lq .. of slot 2 + (lq >> 1)
     const int wrow = li, whalf = 8 * (lq & 1), wk1 = lq >> 1, wk2 = 2 + (lq >> 1);
     auto step = [&](auto SET, auto OTHER, int ks) {
@@ -824,22 +874,28 @@ __global__ void __launch_bounds__(1024, 1) k_gcn_b16_stack_bwd(const GcnStackBwd
     unsigned char* Ag = sb_sm + NRING * SLAB + 4 * 32 * kRSG + gsl * 32 * kRSA;
     const int scratch = NRING * SLAB + 4 * 32 * kRSG + 4 * 32 * kRSA;
     const int c_row = lane >> 2, c_kq = ((lane & 3) - 2 * (c_row >> 3)) & 3;
-    // ---- the W slab of flat step (layer L-1 .. 0, K step): this wave's pieces; steps past the end copy nothing real (scratch)
+    // ---- the W slab of flat step (layer L-1 .. 0, K step): this wave's pieces; per-layer descriptor, per-lane offsets computed once, the K
+    // step as a scalar offset (see the forward); steps past the end run on a descriptor of zero bytes
+    // (as inline asm: through the builtin the compiler drains the request counter in front of the transposing LDS reads of every K step)
     int il = p.L - 1, ik = 0, ib = 0;
+    uint32_t voff[NDW];
+#pragma unroll
+    for (int q = 0; q < NDW; ++q) {
+        const int pc = q * NW + w, f = 16 * pc + c_row;
+        voff[q] = pc < SP ? static_cast<uint32_t>((f * p.Op + 8 * c_kq) * 2) : 0xfffffff0u;       // rows past in_l: out of range, zeros
+    }
+    auto layer_desc = [&](int l) {
+        const bool live = l >= 0;
+        return dma_descriptor(p.wn[live ? l : 0], live ? static_cast<uint32_t>((l == 0 ? p.I0 : D) * p.Op * 2) : 0u);
+    };
+    dma_u32x4 rw = layer_desc(il);
     auto issue = [&]() {
-        const bool live = il >= 0;
-        const int I = il == 0 ? p.I0 : D;
-        // (as inline asm: through the builtin the compiler drains the request counter in front of the transposing LDS reads of every K step)
-        const dma_u32x4 rw = dma_descriptor(p.wn[live ? il : 0], live ? static_cast<uint32_t>(I * p.Op * 2) : 0u);
 #pragma unroll
         for (int q = 0; q < NDW; ++q) {
             const int pc = q * NW + w;                                   // wave-uniform
-            const bool real = live && pc < SP;
-            const int f = 16 * pc + c_row;
-            const uint32_t off = real ? static_cast<uint32_t>((f * p.Op + 32 * ik + 8 * c_kq) * 2) : 0xfffffff0u;      // rows past in_l: out of range, zeros
-            dma16_buffer_to_lds(rw, off, sb_sm + (real ? ib * SLAB + 1024 * pc : scratch));
+            dma16_buffer_to_lds(rw, voff[q], sb_sm + (pc < SP ? ib * SLAB + 1024 * pc : scratch), static_cast<uint32_t>(64 * ik));
         }
-        if (++ik >= nks) { ik = 0; --il; }
+        if (++ik >= nks) { ik = 0; --il; rw = layer_desc(il); }
         ib = ib + 1 == NRING ? 0 : ib + 1;
     };
     issue();
@@ -885,7 +941,7 @@ __global__ void __launch_bounds__(1024, 1) k_gcn_b16_stack_bwd(const GcnStackBwd
     bf16x8 adjf[2];                                                      // B fragments of adj: k = node j, column = node i of tile it
 #pragma unroll
     for (int it = 0; it < 2; ++it) adjf[it] = tr_frag(Ag + tr_row * kRSA + (16 * it + tr_col) * 2, Ag + (tr_row + 4) * kRSA + (16 * it + tr_col) * 2);
-    auto pack2 = [](float a, float b) { return static_cast<uint32_t>(f2bf(a)) | (static_cast<uint32_t>(f2bf(b)) << 16); };
+    auto pack2 = [](float a, float b) { return pack_bf2(a, b); };
     const int wrow = li, whalf = 8 * (lq & 1), wk1 = lq >> 1, wk2 = 2 + (lq >> 1);
     const int my_tt = part >> 1, my_it = part & 1;                       // the 16 x 16 tile of a K step's g_support this part stores
     int cb = 0;
@@ -1147,6 +1203,18 @@ extern "C" int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* b, recon_stream_t
     return RECON_OK;
 }
 
+// four column parts per graph, one graph per wave (16 waves); RECON_GCN_STACK_GPW=2: two graphs per wave (8 waves; measured 36 us against 34 at cfg 3a)
+static void launch_stack_fwd(const GcnStackK& k, size_t lds, hipStream_t st) {
+    const dim3 grid(static_cast<unsigned>(ceil_div64(k.B, 4)));
+    if (cfg_int(CFG_GCN_STACK_GPW, 1) != 2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gcn_b16_stack_fwd<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        hipLaunchKernelGGL((k_gcn_b16_stack_fwd<4, 1>), grid, dim3(1024), lds, st, k);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gcn_b16_stack_fwd<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        hipLaunchKernelGGL((k_gcn_b16_stack_fwd<4, 2>), grid, dim3(512), lds, st, k);
+    }
+}
+
 extern "C" int recon_gcn_b16_stack_fwd(const recon_gcn_b16_stack_args* a, recon_stream_t stream) {
     if (!a || a->B < 0 || a->n <= 0 || a->in_features <= 0 || a->hidden <= 0 || a->L < 1 || a->L > kMaxStack) return RECON_ERR_INVALID;
     if (!a->x || !a->adj || !a->out || !a->w_planes) return RECON_ERR_INVALID;
@@ -1176,11 +1244,10 @@ extern "C" int recon_gcn_b16_stack_fwd(const recon_gcn_b16_stack_args* a, recon_
     // column parts per graph: 4 (sixteen waves per CU; nothing but accumulators and fragments lives in registers)
     const int ns = cfg_int(CFG_GCN_STACK_PARTS, 4) == 2 ? 2 : 4;
     if (ns == 4) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gcn_b16_stack_fwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        hipLaunchKernelGGL(k_gcn_b16_stack_fwd<4>, dim3(static_cast<unsigned>(ceil_div64(a->B, 4))), dim3(1024), lds, as_stream(stream), k);
+        launch_stack_fwd(k, lds, as_stream(stream));
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gcn_b16_stack_fwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        hipLaunchKernelGGL(k_gcn_b16_stack_fwd<2>, dim3(static_cast<unsigned>(ceil_div64(a->B, 4))), dim3(512), lds, as_stream(stream), k);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gcn_b16_stack_fwd<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        hipLaunchKernelGGL((k_gcn_b16_stack_fwd<2, 1>), dim3(static_cast<unsigned>(ceil_div64(a->B, 4))), dim3(512), lds, as_stream(stream), k);
     }
     RECON_CHECK_LAUNCH();
     return RECON_OK;
@@ -1251,8 +1318,7 @@ extern "C" int recon_gcn_b16_stack_train_fwd(const recon_gcn_b16_stack_train_arg
     const int64_t nki = ((a->in_features > D ? a->in_features : D) + 31) / 32;
     const size_t lds = 3ull * kFusedNT * 16 * 64 + static_cast<size_t>(kMaxStack) * kFusedNT * 32 + 4ull * nki * 2048 + 1024;
     if (lds > 160 * 1024) return RECON_ERR_UNSUPPORTED;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gcn_b16_stack_fwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    hipLaunchKernelGGL(k_gcn_b16_stack_fwd<4>, dim3(static_cast<unsigned>(ceil_div64(a->B, 4))), dim3(1024), lds, st, k);
+    launch_stack_fwd(k, lds, st);
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }

@@ -30,6 +30,9 @@ struct B16Args {
 
 __device__ __forceinline__ int lds_off(int row, int kq) { return row * 64 + (((kq + 2 * (row >> 3)) & 3) << 4); }
 __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(uint16_t, static_cast<__bf16>(v)); }
+typedef __bf16 bf16x2_b __attribute__((ext_vector_type(2)));
+typedef float f32x2_b __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf2(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_b{a, b}, bf16x2_b)); }   // one v_cvt_pk_bf16_f32
 
 constexpr int B_TILE_BYTES = BN * 64;                            // 13312
 constexpr int B_PIECES = B_TILE_BYTES / 1024;                    // 13
@@ -138,8 +141,7 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_b16(const B16Args p) {
                 if constexpr (OUT_BF16) {
                     uint16_t* crow = static_cast<uint16_t*>(p.C) + static_cast<int64_t>(row) * p.ldc;
                     if (v4 && col + 3 < p.N) {
-                        *reinterpret_cast<uint2*>(crow + col) = make_uint2(f2bf(v0) | (static_cast<uint32_t>(f2bf(v1)) << 16),
-                                                                           f2bf(v2) | (static_cast<uint32_t>(f2bf(v3)) << 16));
+                        *reinterpret_cast<uint2*>(crow + col) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
                     } else {
                         const float vv[4] = {v0, v1, v2, v3};
 #pragma unroll
@@ -373,35 +375,54 @@ __global__ void __launch_bounds__(256) k_b16_pad_both_multi(const B16PadMulti q)
 // The same second pass for up to 2 x kKmJobs jobs in one launch (the weight and bias gradients of every layer of a stack): blocks
 // [first[j], first[j + 1]) belong to job j; per element the same grouping and order as k_b16_reduce.
 struct B16ReduceMulti { B16ReduceJob job[2 * kKmJobs]; int32_t first[2 * kKmJobs + 1]; int32_t count; };
+// V = elements per thread (4: 16-byte loads of the partials, one 8-byte store of four bf16 — every job's N, M N and row stride are multiples
+// of 4 and its buffers aligned, checked by the host; 1: any shape)
+template <int V>
 __global__ void __launch_bounds__(1024) k_b16_reduce_multi(const B16ReduceMulti q) {
-    // 64 consecutive elements x the sixteen split groups per block (a wave reads 256 contiguous bytes of a partial; k_b16_reduce's 16-element
-    // blocks read 64): per element the same grouping and order, so the bits are those of k_b16_reduce
-    __shared__ float red[16][65];
+    // 64 V consecutive elements x the sixteen split groups per block (a wave reads 256 V contiguous bytes of a partial; k_b16_reduce's
+    // 16-element blocks read 64): per element the same grouping and order, so the bits are those of k_b16_reduce
+    typedef float fv __attribute__((ext_vector_type(V)));
+    __shared__ fv red[16][65];
     int ji = 0;
     while (ji + 1 < q.count && static_cast<int>(blockIdx.x) >= q.first[ji + 1]) ++ji;
     const B16ReduceJob& j = q.job[ji];
     const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int64_t idx = static_cast<int64_t>(blockIdx.x - q.first[ji]) * 64 + e, MN = static_cast<int64_t>(j.M) * j.N;
+    const int64_t idx = (static_cast<int64_t>(blockIdx.x - q.first[ji]) * 64 + e) * V, MN = static_cast<int64_t>(j.M) * j.N;
     const int per = (j.splits + 15) / 16;
     const int z0 = grp * per, z1 = min(j.splits, (grp + 1) * per);
-    float s = 0.f;
+    fv s = 0.f;
     if (idx < MN) {
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        fv a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = 0.f;
         int z = z0;
+        // long chains (the bias jobs: 64 partials per group) keep NB x 8 loads in flight and add them in the order of the 8-wide loop
+        constexpr int NB = V == 4 ? 2 : 4;
+        for (; z + 8 * NB <= z1; z += 8 * NB) {
+            fv x[8 * NB];
+#pragma unroll
+            for (int u = 0; u < 8 * NB; ++u) x[u] = *reinterpret_cast<const fv*>(j.partial + (z + u) * MN + idx);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] += x[8 * b + u];
+        }
         for (; z + 8 <= z1; z += 8) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] += j.partial[(z + u) * MN + idx];
+            for (int u = 0; u < 8; ++u) a[u] += *reinterpret_cast<const fv*>(j.partial + (z + u) * MN + idx);
         }
-        for (; z < z1; ++z) a[0] += j.partial[z * MN + idx];
+        for (; z < z1; ++z) a[0] += *reinterpret_cast<const fv*>(j.partial + z * MN + idx);
         s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     red[grp][e] = s;
     __syncthreads();
     if (grp == 0 && idx < MN) {
-        float t = 0.f;
+        fv t = 0.f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) t += red[g][e];
-        j.out[(idx / j.N) * j.ldo + idx % j.N] = f2bf(t);
+        uint16_t* o = j.out + (idx / j.N) * j.ldo + idx % j.N;
+        if constexpr (V == 4) *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf2(t[0], t[1]), pack_bf2(t[2], t[3]));
+        else o[0] = f2bf(t[0]);
     }
 }
 
@@ -507,19 +528,22 @@ int gemm_b16_kmajor_multi(int32_t count, const B16KmProduct* pr, int32_t K, cons
         hipLaunchKernelGGL(k_b16_reduce, dim3(static_cast<unsigned>(nblk0 + nblk1)), dim3(256), 0, st, j0, j1, nblk0);
     } else {
         B16ReduceMulti q{};
-        int nb = 0;
-        for (int j = 0; j < count; ++j) {
-            q.job[q.count] = B16ReduceJob{pr[j].partial, static_cast<uint16_t*>(pr[j].out), pr[j].ldo, sk, pr[j].M, pr[j].N};
-            q.first[q.count++] = nb;
-            nb += static_cast<int>(ceil_div64(static_cast<int64_t>(pr[j].M) * pr[j].N, 64));
+        // the extra jobs first: few blocks with long chains (a bias gradient sums 1 024 per-graph rows) — started last they were the launch's tail
+        for (int j = 0; j < n_extra; ++j) q.job[q.count++] = extra[j];
+        for (int j = 0; j < count; ++j) q.job[q.count++] = B16ReduceJob{pr[j].partial, static_cast<uint16_t*>(pr[j].out), pr[j].ldo, sk, pr[j].M, pr[j].N};
+        bool vec = true;                                                // four elements per thread where every job allows it
+        for (int j = 0; j < q.count; ++j) {
+            const B16ReduceJob& b = q.job[j];
+            vec = vec && (b.N & 3) == 0 && (b.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(b.partial) & 15) == 0 && (reinterpret_cast<uintptr_t>(b.out) & 7) == 0;
         }
-        for (int j = 0; j < n_extra; ++j) {
-            q.job[q.count] = extra[j];
-            q.first[q.count++] = nb;
-            nb += static_cast<int>(ceil_div64(static_cast<int64_t>(extra[j].M) * extra[j].N, 64));
+        int nb = 0;
+        for (int j = 0; j < q.count; ++j) {
+            q.first[j] = nb;
+            nb += static_cast<int>(ceil_div64(static_cast<int64_t>(q.job[j].M) * q.job[j].N, vec ? 256 : 64));
         }
         q.first[q.count] = nb;
-        hipLaunchKernelGGL(k_b16_reduce_multi, dim3(static_cast<unsigned>(nb)), dim3(1024), 0, st, q);
+        if (vec) hipLaunchKernelGGL(k_b16_reduce_multi<4>, dim3(static_cast<unsigned>(nb)), dim3(1024), 0, st, q);
+        else hipLaunchKernelGGL(k_b16_reduce_multi<1>, dim3(static_cast<unsigned>(nb)), dim3(1024), 0, st, q);
     }
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;

@@ -20,7 +20,7 @@ constexpr int kWave = 64;
 // ---- run-time switches (config.hip): read from the environment once, at first use; nullptr = unset, like getenv ----------------------
 enum CfgKey { CFG_BGEMM_CFG, CFG_GCN_FUSED, CFG_GCN_FUSED_BWD, CFG_GCN_FUSED_PARTS, CFG_GCN_STACK_PARTS, CFG_GEMM_CFG, CFG_GEMM_LIN, CFG_GEMM_SPLITK,
               CFG_GEMM_XCD, CFG_PROP_B16, CFG_PROP_B16_YPOST, CFG_PROP_BWD, CFG_PROP_BWD_CHAIN, CFG_PROP_BWD_WIDE, CFG_PROP_FWD, CFG_PROP_LDS_KB,
-              CFG_ATP_ROW_SCALE, CFG_GRAPH_SMALL, CFG_COUNT };
+              CFG_ATP_ROW_SCALE, CFG_GRAPH_SMALL, CFG_GCN_STACK_GPW, CFG_COUNT };
 const char* cfg(CfgKey k);
 int cfg_int(CfgKey k, int dflt);
 char cfg_char(CfgKey k);                  // first character, '\0' when unset
@@ -103,11 +103,13 @@ __device__ __forceinline__ dma_u32x4 dma_descriptor(const void* base, uint32_t b
     auto uni = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(v)); };
     return dma_u32x4{uni(static_cast<uint32_t>(a)), uni(static_cast<uint32_t>(a >> 32) & 0xffffu), uni(bytes), 0x00020000u};
 }
-__device__ __forceinline__ void dma16_buffer_to_lds(dma_u32x4 desc, uint32_t byte_offset, const void* lds_dst) {
+// (`scalar_offset` is added to every lane's address AFTER the range check of `byte_offset`: a K-step advance that keeps masked lanes masked)
+__device__ __forceinline__ void dma16_buffer_to_lds(dma_u32x4 desc, uint32_t byte_offset, const void* lds_dst, uint32_t scalar_offset = 0) {
     const uint32_t a = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)(lds_dst))));
+    const uint32_t so = __builtin_amdgcn_readfirstlane(scalar_offset);
     uint32_t m0_saved;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(m0_saved) : "v"(byte_offset), "s"(desc), "s"(a) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "v"(byte_offset), "s"(desc), "s"(a), "s"(so) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

@@ -21,5 +21,6 @@ print("stamps", ns, "total cycles", st[-1] - st[0])
 d = st[1:] - st[:-1]
 print("prologue->first wait", d[0])
 pairs = d[1:-1]
-print("per step: [barrier wait, rest of step + next wait]")
-print([int(v) for v in pairs])
+print("per step: [barrier wait, copy issue, fragment reads landed, matrix pipe + wait for this wave's copies]")
+for i in range(0, len(pairs) - 3, 4):
+    print([int(v) for v in pairs[i:i + 4]])
