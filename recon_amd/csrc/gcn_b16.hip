@@ -23,6 +23,9 @@ int gemm_b16_kmajor_multi(int32_t count, const B16KmProduct* pr, int32_t K, cons
 
 namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4_g = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2_g = __attribute__((ext_vector_type(2))) uint32_t;
 __device__ __forceinline__ float bf2f(uint16_t v) { return __builtin_bit_cast(float, static_cast<uint32_t>(v) << 16); }
 __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(uint16_t, static_cast<__bf16>(v)); }
 // two floats -> two bf16 in one register: ONE v_cvt_pk_bf16_f32 (converted one by one and combined by hand the compiler emits two
@@ -35,7 +38,8 @@ __device__ __forceinline__ uint32_t pack_bf2(float a, float b) { return __builti
 __device__ __forceinline__ int sat_i32(int64_t v) { return v < 0x7fffffffLL ? static_cast<int>(v) : 0x7fffffff; }
 
 // Y[b][i][o] = epilogue( sum_j M[i][j] * Xin[b][j][o] ),  M = adj[b] (TRANS = false) or adj[b]^T; block = (64 columns, graph,
-// 32-row tile), the contraction walked in chunks of 32 through LDS (any n).  MASK: Xin = gout * (fwd_out > 0); EPI: + bias, ReLU.
+// 32-row tile), the contraction walked in chunks of 32 through LDS on the bf16 matrix cores (any n).  MASK: Xin = gout * (fwd_out > 0);
+// EPI: + bias, ReLU.
 // Columns O <= o < ldy are written as zeros.
 // colsum (backward only): per-graph column sums of the masked operand, [B][O] floats — the bias gradient's first pass rides on the tile that is
 // in LDS anyway (row tile 0 of each graph adds the chunks up in k order: fixed order) instead of a pass of its own over grad_out and out.
@@ -44,9 +48,14 @@ __global__ void __launch_bounds__(256) k_gcn_b16_aggregate(const uint16_t* __res
                                                            const uint16_t* __restrict__ fwd_out, int64_t ldf, const uint16_t* __restrict__ bias,
                                                            int32_t n, int32_t O, uint16_t* __restrict__ Y, int64_t ldy, float* __restrict__ colsum = nullptr,
                                                            const int32_t* __restrict__ node_ptr = nullptr, const int64_t* __restrict__ adj_ptr = nullptr) {
-    constexpr int PM = 48, PX = 80;
-    __shared__ float Mk[32 * PM];           // Mk[k][i] = M[i0 + i][k0 + k]
-    __shared__ float Xs[32 * PX];           // Xs[k][o]
+    // Round 5: both tiles staged as bf16 (no widening), ONE v_mfma_f32_16x16x32_bf16 per row tile and chunk of 32 contraction rows (the first
+    // form widened to fp32 in LDS and issued sixteen 16x16x4 fp32 MFMAs behind 24 four-byte LDS reads per chunk: 31-36 us per layer on the
+    // ragged cfg 5 batch for 0.75 GFLOP).  M's chunk lies in LDS as [i][32 k] (row stride 80 B: the sixteen 16-byte fragment reads of a quarter
+    // wave fall on distinct banks) whichever way it is read from memory — TRANS costs nothing; X's chunk as [k][64 o] (row stride 144 B), its
+    // fragments (8 consecutive k of one column) through the transposing read.
+    constexpr int RSA = 80, RSX = 144;
+    __shared__ __attribute__((aligned(16))) unsigned char As[32 * RSA];
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[32 * RSX];
     const int b = blockIdx.y, o0 = blockIdx.x * 64, i0 = blockIdx.z * 32;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     // RAGGED batch (node_ptr): graph b owns node rows node_ptr[b] .. node_ptr[b + 1] and a dense n_b x n_b adjacency at adj + adj_ptr[b]
@@ -62,43 +71,79 @@ __global__ void __launch_bounds__(256) k_gcn_b16_aggregate(const uint16_t* __res
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     float csum = 0.f;
     const bool do_colsum = colsum != nullptr && blockIdx.z == 0 && t < 64;
-    for (int k0 = 0; k0 < n; k0 += 32) {
-        if (k0) __syncthreads();
-        for (int idx = t; idx < 32 * 32; idx += 256) {
-            const int k = idx >> 5, i = idx & 31;
-            float v = 0.f;
-            if (k0 + k < n && i0 + i < n)
-                v = bf2f(TRANS ? A[static_cast<int64_t>(k0 + k) * n + i0 + i] : A[static_cast<int64_t>(i0 + i) * n + k0 + k]);
-            Mk[k * PM + i] = v;
-        }
-        for (int idx = t; idx < 32 * 16; idx += 256) {                     // 4 consecutive columns per thread: 8-byte loads (row strides are
-            const int k = idx >> 4, oq = o0 + 4 * (idx & 15);              // multiples of 8 elements, so a quad never straddles a row)
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (k0 + k < n && oq < ldx) {                                  // columns in [O, ldx) hold zeros (or are masked below)
-                const int64_t row = rowbase + k0 + k;
-                const uint2 raw = *reinterpret_cast<const uint2*>(Xin + row * ldx + oq);
-                v[0] = bf2f(raw.x & 0xffffu); v[1] = bf2f(raw.x >> 16); v[2] = bf2f(raw.y & 0xffffu); v[3] = bf2f(raw.y >> 16);
-                if constexpr (MASK) {
-                    const uint2 m = oq < ldf ? *reinterpret_cast<const uint2*>(fwd_out + row * ldf + oq) : make_uint2(0, 0);
-                    v[0] = bf2f(m.x & 0xffffu) > 0.f ? v[0] : 0.f; v[1] = bf2f(m.x >> 16) > 0.f ? v[1] : 0.f;
-                    v[2] = bf2f(m.y & 0xffffu) > 0.f ? v[2] : 0.f; v[3] = bf2f(m.y >> 16) > 0.f ? v[3] : 0.f;
-                }
+    // EIGHT chunks requested at once, in registers: with one MFMA per row tile a chunk's arithmetic covers nothing, so every chunk requested
+    // one ahead still exposed a whole memory round trip (22.8 us per layer at cfg 5); a graph of <= 256 nodes now pays one
+    constexpr int NCH = 8;
+    uint16_t mraw[NCH][4];
+    uint2 xraw[NCH][2], fraw[NCH][2];
+    auto tr_frag = [](const unsigned char* lo_p, const unsigned char* hi_p) {
+        typedef short i16x4 __attribute__((ext_vector_type(4)));
+        const i16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(lo_p));
+        const i16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(hi_p));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    const int tr_row = 8 * lq + (li >> 2), tr_col = 16 * w + 4 * (li & 3);
+    bool first = true;
+    for (int kg = 0; kg < n; kg += 32 * NCH) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = oq + q < O ? v[q] : 0.f;
+        for (int c = 0; c < NCH; ++c) {
+            const int k0 = kg + 32 * c;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                // the lanes of a wave walk the CONTIGUOUS index of the adjacency (k for adj, i for adj^T): 32 two-byte elements = one or two
+                // cache lines per request instead of 32 (the element-wise gather of adj rows was what the kernel waited for)
+                const int idx = t + 256 * u, k = TRANS ? idx >> 5 : idx & 31, i = TRANS ? idx & 31 : idx >> 5;
+                mraw[c][u] = (k0 + k < n && i0 + i < n) ? (TRANS ? A[static_cast<int64_t>(k0 + k) * n + i0 + i] : A[static_cast<int64_t>(i0 + i) * n + k0 + k])
+                                                        : static_cast<uint16_t>(0);
             }
-            *reinterpret_cast<float4*>(&Xs[k * PX + 4 * (idx & 15)]) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-        __syncthreads();
-        if (do_colsum) {
-#pragma unroll 8
-            for (int k = 0; k < 32; ++k) csum += Xs[k * PX + t];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {                                  // 4 consecutive columns per thread: 8-byte loads (row strides are
+                const int idx = t + 256 * u, k = idx >> 4, oq = o0 + 4 * (idx & 15);  // multiples of 8 elements, so a quad never straddles a row)
+                const bool ok = k0 + k < n && oq < ldx;
+                const int64_t row = rowbase + k0 + k;
+                xraw[c][u] = ok ? *reinterpret_cast<const uint2*>(Xin + row * ldx + oq) : make_uint2(0, 0);
+                if constexpr (MASK) fraw[c][u] = (ok && oq < ldf) ? *reinterpret_cast<const uint2*>(fwd_out + row * ldf + oq) : make_uint2(0, 0);
+            }
         }
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int k = 4 * s + lq;
-            const float bx = Xs[k * PX + 16 * w + li];
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Mk[k * PM + li], bx, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Mk[k * PM + 16 + li], bx, acc[1], 0, 0, 0);
+        for (int c = 0; c < NCH; ++c) {
+            if (kg + 32 * c >= n) break;                                  // uniform for the block
+            if (!first) __syncthreads();
+            first = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = t + 256 * u, k = TRANS ? idx >> 5 : idx & 31, i = TRANS ? idx & 31 : idx >> 5;
+                *reinterpret_cast<uint16_t*>(As + i * RSA + 2 * k) = mraw[c][u];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = t + 256 * u, k = idx >> 4, oq = o0 + 4 * (idx & 15);
+                uint32_t v[2] = {xraw[c][u].x, xraw[c][u].y};
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    // columns in [O, ldx) hold zeros or are cleared here; MASK: gradient kept where the forward output is positive (bf16: sign
+                    // clear and not zero)
+                    bool k0_ = oq + 2 * d < O, k1_ = oq + 2 * d + 1 < O;
+                    if constexpr (MASK) {
+                        const uint32_t m = d == 0 ? fraw[c][u].x : fraw[c][u].y;
+                        k0_ = k0_ && (m & 0x8000u) == 0 && (m & 0x7fffu) != 0;
+                        k1_ = k1_ && (m & 0x80000000u) == 0 && (m & 0x7fff0000u) != 0;
+                    }
+                    v[d] &= (k0_ ? 0xffffu : 0u) | (k1_ ? 0xffff0000u : 0u);
+                }
+                *reinterpret_cast<uint2*>(Xs + k * RSX + 8 * (idx & 15)) = make_uint2(v[0], v[1]);
+            }
+            __syncthreads();
+            if (do_colsum) {
+#pragma unroll 8
+                for (int k = 0; k < 32; ++k) csum += bf2f(*reinterpret_cast<const uint16_t*>(Xs + k * RSX + 2 * t));
+            }
+            const bf16x8 bfrag = tr_frag(Xs + tr_row * RSX + 2 * tr_col, Xs + (tr_row + 4) * RSX + 2 * tr_col);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(As + (16 * rt + li) * RSA + 16 * lq);
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag, acc[rt], 0, 0, 0);
+            }
         }
     }
     if (do_colsum && o0 + t < O) colsum[static_cast<int64_t>(b) * O + o0 + t] = csum;
@@ -168,9 +213,6 @@ __global__ void __launch_bounds__(1024) k_gcn_b16_bias_reduce(const float* __res
 // Traffic per layer: x once, out once, adj, W from L2 — 41 MB at cfg 3a (B = 1024, n = 32, D = 300) against 19.7 MB x 4 + the support
 // round trip of the GEMM + aggregate pair.  `support` is not written (the backward recomputes nothing from it unless d adj is wanted,
 // and then the unfused path runs).
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using u32x4_g = __attribute__((ext_vector_type(4))) uint32_t;
-using u32x2_g = __attribute__((ext_vector_type(2))) uint32_t;
 constexpr int kFusedNT = 20;                      // column tiles of 16: out_features <= 320
 
 struct GcnFusedK {

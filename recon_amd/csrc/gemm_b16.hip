@@ -185,8 +185,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int off_lo,
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+// Three-stage ring of 22-KiB images, copies two K steps ahead, ONE counted wait + a raw barrier per step (round 5; the first form
+// double-buffered behind `vmcnt(0)` + __syncthreads and exposed one L2 -> LDS round trip in every step: 37 steps of a cfg 3a weight
+// gradient were 29 us for 416 cycles of MFMA per step).  The copies are issued as inline asm (dma16_to_lds): through the builtin the
+// compiler drains the request counter in front of the transposing reads.
+constexpr int KM_STAGES = 3, KM_STAGE_BYTES = KA_BYTES + KB_BYTES;
 __global__ void __launch_bounds__(NT, 2) k_gemm_b16_kmajor(const B16KmArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char S[2][KA_BYTES + KB_BYTES];      // double buffered: 2 x 22 KiB
+    extern __shared__ __attribute__((aligned(16))) unsigned char km_sm[];                  // [KM_STAGES][22 KiB]
     const int t = threadIdx.x, lane = t & 63;
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const TileId tile = xcd_tile(1);
@@ -224,8 +229,8 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_b16_kmajor(const B16KmArgs p) {
                 const int pc = 4 * i + wid, k = k0 + d_k[i];
                 const bool isa = pc < KA_PIECES;
                 const uint16_t* q = k < k_end ? (isa ? pA + static_cast<int64_t>(k) * p_lda : pB + static_cast<int64_t>(k) * p_ldb) + d_col[i] : zlane;
-                unsigned char* dst = S[buf] + (isa ? 1024 * pc : KA_BYTES + 1024 * (pc - KA_PIECES));
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(q), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                unsigned char* dst = km_sm + buf * KM_STAGE_BYTES + (isa ? 1024 * pc : KA_BYTES + 1024 * (pc - KA_PIECES));
+                dma16_to_lds(q, dst);
             }
     };
     f32x4 acc[2][TN];
@@ -247,13 +252,18 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_b16_kmajor(const B16KmArgs p) {
     }
     auto b_off = [&](int j, int hh) { return b_row[hh] + (2 * j + ((ip & 3) >> 1) + (b_rot[hh] ? 2 : 0)) * 16; };
     if (k_begin < k_end) dma(k_begin, 0);
+    if (k_begin + BK < k_end) dma(k_begin + BK, 1);
     int buf = 0;
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this tile's copies have landed ...
-        __syncthreads();                                              // ... everyone's, and nobody still reads the other buffer
-        if (k0 + BK < k_end) dma(k0 + BK, buf ^ 1);
-        const unsigned char* As = S[buf];
-        const unsigned char* Bs = S[buf] + KA_BYTES;
+        // this wave's copies of this step have landed — those of the next step (ND per wave, ND - 1 for the waves that own one piece less:
+        // the smaller count is right for both) may still travel; at the last step nothing newer exists
+        if (k0 + BK < k_end) dma_wait<ND - 1>(); else dma_wait<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                 // ... everyone's have, and nobody still reads the buffer requested next
+        asm volatile("" ::: "memory");
+        if (k0 + 2 * BK < k_end) dma(k0 + 2 * BK, buf + 2 >= KM_STAGES ? buf + 2 - KM_STAGES : buf + 2);
+        const unsigned char* As = km_sm + buf * KM_STAGE_BYTES;
+        const unsigned char* Bs = As + KA_BYTES;
         bf16x8 a[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) a[i] = tr_frag(As, a_off[i][0], a_off[i][1]);
@@ -263,7 +273,7 @@ __global__ void __launch_bounds__(NT, 2) k_gemm_b16_kmajor(const B16KmArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][j], 0, 0, 0);
         }
-        buf ^= 1;
+        buf = buf + 1 == KM_STAGES ? 0 : buf + 1;
     }
     float* base = p.partial[job] + static_cast<int64_t>(zs) * pM * pN;
 #pragma unroll
@@ -519,7 +529,8 @@ int gemm_b16_kmajor_multi(int32_t count, const B16KmProduct* pr, int32_t K, cons
     a.nsplit = static_cast<int32_t>(ceil_div64(K > 0 ? K : 1, kps));
     if (a.nsplit != sk || static_cast<int64_t>(sk) * count > 65535) return RECON_ERR_INVALID;
     const dim3 grid(static_cast<unsigned>(ceil_div64(Nx, BN)), static_cast<unsigned>(ceil_div64(Mx, BM)), static_cast<unsigned>(sk * count));
-    hipLaunchKernelGGL(k_gemm_b16_kmajor, grid, dim3(NT), 0, st, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_b16_kmajor), hipFuncAttributeMaxDynamicSharedMemorySize, KM_STAGES * KM_STAGE_BYTES);
+    hipLaunchKernelGGL(k_gemm_b16_kmajor, grid, dim3(NT), KM_STAGES * KM_STAGE_BYTES, st, a);
     if (count == 1 && n_extra <= 1) {
         const B16ReduceJob j0{pr[0].partial, static_cast<uint16_t*>(pr[0].out), pr[0].ldo, sk, pr[0].M, pr[0].N};
         const B16ReduceJob j1 = n_extra ? extra[0] : B16ReduceJob{nullptr, nullptr, 0, 0, 0, 0};
