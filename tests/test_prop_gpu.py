@@ -653,6 +653,52 @@ def test_gcn_bf16_stack_reads_padded_rows_in_place():
     assert torch.equal(y2d, layers[0](x.detach(), adj)[0])
 
 
+def test_gcn_stack_bf16_trains_with_a_frozen_layer_and_a_padded_input():
+    """The training form of gcn_stack() with (i) a frozen layer in the middle — its weight-gradient product drops out of the one split-K
+    launch, the others keep their places in the partial workspace — and (ii) an input that is itself the padded output of a bf16
+    GraphConvolution (row stride 304 for 300 features: read in place, no aligned copy written).  Everything that has a gradient carries the
+    bits (g_W: the values) of the layer loop."""
+    import recon_amd.gcn_layers as GL
+    from recon_amd.gcn_layers import GraphConvolution, gcn_stack
+    d_ = dev()
+    B, n, D, L = 6, 32, 300, 3
+    g = torch.Generator().manual_seed(11)
+    x0 = _bf(torch.randn(B, n, 64, generator=g)).to(d_)
+    adj = (torch.rand(B, n, n, generator=g) < 0.2).float() + torch.eye(n)
+    adj = _bf(adj / adj.sum(-1, keepdim=True)).to(d_)
+    torch.manual_seed(6)
+    pre = GraphConvolution(64, D).to(torch.bfloat16).to(d_)
+    layers = [GraphConvolution(D, D).to(torch.bfloat16).to(d_) for _ in range(L)]
+    layers[1].weight.requires_grad_(False)
+    layers[1].bias.requires_grad_(False)
+    G = _bf(torch.randn(B, n, D, generator=g)).to(d_)
+    params = [p for m in [pre] + layers for p in m.parameters()]
+
+    def run(fn):
+        for p in params:
+            p.grad = None
+        h = pre(x0, adj)                                            # [B, n, 300] view of rows of 304: `_recon_padded`
+        assert h.stride(-2) == 304
+        y = fn(h)
+        y.backward(G)
+        return [y.detach().clone()] + [p.grad.clone() if p.grad is not None else None for p in params]
+    a = run(lambda h: gcn_stack(h, adj, layers))
+
+    def loop(h):
+        for l in layers:
+            h = l(h, adj)
+        return h
+    b = run(loop)
+    assert a[3 + 2] is None and a[3 + 3] is None and b[3 + 2] is None          # the frozen layer's parameters (after pre's two and layer 0's two)
+    for i, (u, v) in enumerate(zip(a, b)):
+        if u is None:
+            continue
+        if u.dim() == 2 and i >= 3:                                    # stack weights: another split-K order
+            close(u.float(), v.float(), atol=1e-4, rel_to_max=1.6e-2, what="tensor %d (a weight gradient of the stack)" % i)
+        else:
+            assert torch.equal(u, v), "tensor %d differs from the loop: max %g" % (i, (u.float() - v.float()).abs().max().item())
+
+
 @pytest.mark.parametrize("B,n,I,D,L", [(9, 32, 300, 300, 3), (5, 32, 40, 136, 2), (7, 8, 300, 64, 4), (1030, 32, 300, 300, 3), (3, 12, 22, 320, 3), (6, 31, 300, 300, 3)])
 def test_gcn_stack_bf16_is_bit_equal_to_the_layers(B, n, I, D, L, monkeypatch):
     """gcn_stack(): L GraphConvolutions over one adjacency in one launch, the activations in LDS between the layers — the bits of the
