@@ -516,6 +516,10 @@ def gcn_stack(x, adj, layers):
     and gradients are bit-equal to the loop, which is also what runs for every other case.  Repacked weights are kept per weight tensor (identity + version); call
     invalidate_stack_planes() after writing through `weight.data`."""
     layers = list(layers)
+    if isinstance(adj, RaggedAdjacency):                                    # graphs of different sizes: layer by layer (GEMM over all rows + aggregate per graph;
+        for l in layers:                                                    # the one-kernel form of a layer was measured and is no faster there, DESIGN 9)
+            x = l(x, adj)
+        return x
     need_grad = torch.is_grad_enabled() and (x.requires_grad or adj.requires_grad or any(p.requires_grad for l in layers for p in l.parameters()))
     ok = (len(layers) >= 2 and len(layers) <= 8 and x.is_cuda and x.dtype == torch.bfloat16 and adj.dtype == torch.bfloat16
           and x.dim() in (2, 3) and os.environ.get("RECON_GCN_STACK", "1") != "0" and not (need_grad and adj.requires_grad))

@@ -653,6 +653,26 @@ def test_gcn_bf16_stack_reads_padded_rows_in_place():
     assert torch.equal(y2d, layers[0](x.detach(), adj)[0])
 
 
+def test_gcn_stack_takes_a_ragged_batch():
+    """gcn_stack() with a RaggedAdjacency (BASELINE.json configs[4]'s graphs of different sizes): the layer loop, same bits as calling the layers."""
+    from recon_amd.gcn_layers import GraphConvolution, RaggedAdjacency, gcn_stack
+    d_ = dev()
+    g = torch.Generator().manual_seed(2)
+    sizes = [5, 40, 17, 256, 33]
+    mats = [_bf(torch.rand(n, n, generator=g) / n).to(d_) for n in sizes]
+    rag = RaggedAdjacency.from_dense(mats)
+    x = _bf(torch.randn(sum(sizes), 48, generator=g)).to(d_).requires_grad_(True)
+    torch.manual_seed(8)
+    layers = [GraphConvolution(48 if l == 0 else 64, 64).to(torch.bfloat16).to(d_) for l in range(3)]
+    y = gcn_stack(x, rag, layers)
+    h = x
+    for l in layers:
+        h = l(h, rag)
+    assert torch.equal(y, h)
+    y.float().sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad.float()).all()
+
+
 def test_gcn_stack_bf16_trains_with_a_frozen_layer_and_a_padded_input():
     """The training form of gcn_stack() with (i) a frozen layer in the middle — its weight-gradient product drops out of the one split-K
     launch, the others keep their places in the partial workspace — and (ii) an input that is itself the padded output of a bf16
