@@ -913,7 +913,9 @@ struct AtpBwdK {
 constexpr int kK2Ring = 2, kK2WavesPerSimd = 3;
 // Wide rows (KR >= 4 register rows per lane: out_att-sized inputs) get the register budget of two waves per SIMD, KR = 8 of one: at
 // three the KR = 8 form spilled 259 registers (0.73 ms per call at N = 8 192, F = R = 1 600).
-template <int VEC, int KR, int HT>
+// B16: x and edge_embed are stored as bfloat16 and read where they lie (recon_gat_atp_args.io_bf16; round 5: the backward no longer needs
+// up-cast copies of them — at cfg 5, 62 MB read + 124 MB written by two cast kernels, and half of this kernel's gathered row bytes)
+template <int VEC, int KR, int HT, bool B16 = false>
 __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >= 4 || KR * HT >= 8 && KR >= 2) ? 2 : kK2WavesPerSimd)) k_gat_atp_bwd(const AtpBwdK p) {
     extern __shared__ __attribute__((aligned(16))) float U[];          // [H][W]: u_dst | u_src | u_rel per head
     const int F = p.F, R = p.R, H = p.H, W = 2 * F + R;
@@ -954,7 +956,7 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
     for (int r = 0; r < KR; ++r) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) gxd[r][v] = 0.f;
-        load_vec<VEC>(xi[r], p.x + static_cast<int64_t>(node) * F + cfF[r]);
+        load_in<VEC, B16>(xi[r], p.x, static_cast<int64_t>(node) * F + cfF[r]);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) xi[r][v] = aF[r] ? xi[r][v] : 0.f;
     }
@@ -978,8 +980,8 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
             const int s_ = __builtin_amdgcn_readlane(srcv, j), e_ = __builtin_amdgcn_readlane(eidv, j);
 #pragma unroll
             for (int r = 0; r < KR; ++r) {                               // lanes past F / R: garbage x 0 (their g_V terms are zeroed)
-                load_vec<VEC>(xs_r[slot][r], p.x + static_cast<int64_t>(s_) * F + cfF[r]);
-                load_vec<VEC>(re_r[slot][r], p.ee + static_cast<int64_t>(e_) * R + cfR[r]);
+                load_in<VEC, B16>(xs_r[slot][r], p.x, static_cast<int64_t>(s_) * F + cfF[r]);
+                load_in<VEC, B16>(re_r[slot][r], p.ee, static_cast<int64_t>(e_) * R + cfR[r]);
             }
             sg_r[slot] = p.sigma[static_cast<int64_t>(c0 + j) * H + mh];
             kf_r[slot] = keepp[static_cast<int64_t>(c0 + j) * H + mh];  // eval: re-reads sigma, replaced by 1 at the use (no branch)
@@ -1335,7 +1337,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_hub_src(const AtpSrcK p, con
 // pass 1: block b sums its slice of rows into partial[b][j][c]; pass 2 adds the slices in order.
 // Up to two independent products per launch (blocks [0, j0.nb) run job 0, the rest job 1), like k_row_dots.
 struct SkinnyJob { const float* G; const float* X; const int32_t* gather; float* partial; int32_t ldg, nj, rows, K, rpb, nb; };
-template <int NJ>
+template <int NJ, bool B16 = false>
 __global__ void __launch_bounds__(256) k_skinny_tn_partial(const SkinnyJob j0, const SkinnyJob j1, const SkinnyJob j2) {
     // 4 waves split the block's rows; lane l owns columns 4l..4l+3 of a 256-column stripe; fixed-order LDS combine
     __shared__ float red[3][NJ][256];
@@ -1376,8 +1378,12 @@ __global__ void __launch_bounds__(256) k_skinny_tn_partial(const SkinnyJob j0, c
                 xv[q][0] = xv[q][1] = xv[q][2] = xv[q][3] = 0.f;
                 if (r < r1) {
                     const int64_t row = gather ? __builtin_amdgcn_readlane(gi, q) : r;
-                    if (c + 3 < K) { const float4 t = *reinterpret_cast<const float4*>(X + row * K + c); xv[q][0] = t.x; xv[q][1] = t.y; xv[q][2] = t.z; xv[q][3] = t.w; }
-                    else { for (int v = 0; v < 4; ++v) if (c + v < K) xv[q][v] = X[row * K + c + v]; }
+                    if constexpr (B16) {                                  // rows of bfloat16 (K % 8 == 0: a quad is inside the row or past it)
+                        if (c + 3 < K) load_in<4, true>(xv[q], X, row * K + c);
+                    } else {
+                        if (c + 3 < K) { const float4 t = *reinterpret_cast<const float4*>(X + row * K + c); xv[q][0] = t.x; xv[q][1] = t.y; xv[q][2] = t.z; xv[q][3] = t.w; }
+                        else { for (int v = 0; v < 4; ++v) if (c + v < K) xv[q][v] = X[row * K + c + v]; }
+                    }
                 }
             }
             gi = gnext;
@@ -1846,7 +1852,8 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         p.hub_chunk = hubs ? g->hub_chunk : 0; p.n_piece = hubs ? g->n_piece : 0;
         p.piece = reinterpret_cast<const int4*>(g->piece); p.hubG = g->hub_ws;
         dim3 grid(static_cast<unsigned>(ceil_div64(N, kBlock / 64) + ceil_div64(p.n_piece, kBlock / 64)));
-#define CALL_BWD(V_, K_, H_) hipLaunchKernelGGL((k_gat_atp_bwd<V_, K_, H_>), grid, dim3(kBlock), lds_k2, st, p)
+#define CALL_BWD(V_, K_, H_) do { if (V_ == 4 && a->io_bf16) hipLaunchKernelGGL((k_gat_atp_bwd<4, K_, H_, true>), grid, dim3(kBlock), lds_k2, st, p); \
+                                  else hipLaunchKernelGGL((k_gat_atp_bwd<V_, K_, H_>), grid, dim3(kBlock), lds_k2, st, p); } while (0)
         ATP_DISPATCH(s, CALL_BWD);
 #undef CALL_BWD
         if (hubs) {
@@ -1943,7 +1950,10 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
                 }
                 if (nb_total == 0) return;
                 const dim3 gp(static_cast<unsigned>(nb_total));
-                if (nj_max <= 8) hipLaunchKernelGGL((k_skinny_tn_partial<8>), gp, dim3(256), 0, st, sj[0], sj[1], sj[2]);
+                if (a->io_bf16) {                                        // (at most 8 heads there: recon_gat_atp_bf16_io_supported)
+                    if (nj_max <= 8) hipLaunchKernelGGL((k_skinny_tn_partial<8, true>), gp, dim3(256), 0, st, sj[0], sj[1], sj[2]);
+                    else hipLaunchKernelGGL((k_skinny_tn_partial<16, true>), gp, dim3(256), 0, st, sj[0], sj[1], sj[2]);
+                } else if (nj_max <= 8) hipLaunchKernelGGL((k_skinny_tn_partial<8>), gp, dim3(256), 0, st, sj[0], sj[1], sj[2]);
                 else hipLaunchKernelGGL((k_skinny_tn_partial<16>), gp, dim3(256), 0, st, sj[0], sj[1], sj[2]);
                 hipLaunchKernelGGL(k_skinny_reduce, dim3(static_cast<unsigned>(nr_total)), dim3(1024), 0, st, rj[0], rj[1], rj[2]);
             };

@@ -558,7 +558,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
     def forward(ctx, x, ee, a, a2, graph, keep, alpha, concat, keep_max, ee_index=None):
         """ee_index (int64 [E], original edge order) makes `ee` a table: edge e uses row ee_index[e] (see gat_heads).
         x and ee may both be bfloat16 (gat_heads checks the shape: recon_gat_atp_bf16_io_supported): the forward kernels read them in
-        place; the result and the arithmetic stay float32; the backward widens them once and hands back bfloat16 gradients."""
+        place, as do the backward's; the result and the arithmetic stay float32 and the two input gradients are rounded to bfloat16 at the end."""
         io16 = x.dtype == torch.bfloat16
         if io16:
             if ee.dtype != torch.bfloat16 or ee_index is not None or not (x.is_cuda and ee.is_cuda):
@@ -616,9 +616,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         N, E, F_, R = graph.N, graph.E, x.shape[1], ee.shape[1]
         W = 2 * F_ + R
         dev = x.device
-        io16 = x.dtype == torch.bfloat16
-        if io16:                                                # the backward's kernels read float32 rows: widened here, once, only when training
-            x, ee = x.float(), ee.float()
+        io16 = x.dtype == torch.bfloat16                        # bfloat16 rows are read in place by the backward's kernels too (round 5)
         f32 = dict(dtype=torch.float32, device=dev)
         grad_out = grad_out.contiguous()
         nx, ne, na, na2 = ctx.needs_input_grad[:4]
@@ -635,7 +633,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         g_ee = torch.empty(E, R, **f32) if ne else None
         g_a, g_a2 = _weight_grad_tensors(a, H, D, W, f32) if want_a else (None, None)
         fwd = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, ctx.alpha, ctx.concat, a_split, aux,
-                        ctx.keep_max, ctx.idx_slot)
+                        ctx.keep_max, ctx.idx_slot, io16)
         args = _lib.GatAtpBwdArgs(fwd, grad_out.data_ptr(), grad_out.shape[1], g_h, g_V, g_sigma, Gxs, gxd, Gs, g_u, q, partial, partial2,
                                   _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2), gh_split)
         gstruct, _hub_keep = graph.call_struct(F_, R, H)
