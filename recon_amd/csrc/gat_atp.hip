@@ -476,6 +476,90 @@ using f32x4_t = __attribute__((ext_vector_type(4))) float;
 __device__ __host__ inline int row_dots_kp(int K) { return (K % 8 == 0) ? K + 4 : K; }
 // The last nsplit blocks write the half planes of a and a^T (hx2_split_both_block): that pass needs only what
 // the kernel in front of this one published, and as a launch of its own it cost 10 us of which 5 are kernel turn-around.
+// The same dots for rows stored as bfloat16, on the bf16 matrix cores: a lane's 16-byte piece of a row IS an A fragment of
+// v_mfma_f32_16x16x32_bf16 (row lane & 15, eight consecutive k), and the score vectors lie in LDS as TWO bf16 terms (u = hi + lo, relative
+// error 2^-17: the rows themselves carry 2^-9), one 16-byte B fragment each — 2 MFMAs of 16 cycles per 32 columns where the float32 form
+// issues eight 16x16x4 MFMAs of 32 (34 us for 62 MB at cfg 5: the kernel was bound by its own matrix instructions).
+__device__ __forceinline__ int row_dots_b16_stride(int K) { return ((K / 8) & 1) ? K * 2 : K * 2 + 16; }      // bytes; (stride / 16) odd: 16 rows on distinct banks
+__device__ __forceinline__ void row_dots_b16(const RowDotsJob& jb, int bid, const float* __restrict__ u, int32_t H, int32_t W, unsigned char* Usm) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    const uint16_t* __restrict__ X = reinterpret_cast<const uint16_t*>(jb.X);
+    const int32_t* __restrict__ gather = jb.gather;
+    float* __restrict__ out = jb.out;
+    const int rows = jb.rows, K = jb.K, F = jb.F, off = jb.off, NJ = jb.NJ, nblocks = jb.nb;
+    const int RS = row_dots_b16_stride(K);
+    unsigned char* Uh = Usm;                                             // [NJ][RS] bf16 high terms
+    unsigned char* Ul = Usm + 16 * RS;                                   // ... low terms
+    constexpr int GU = 4;
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntiles = (rows + 15) / 16, G = (K + 31) / 32;
+    const bool iu = i < NJ;
+    float mx = 0.f;
+    bool staged = false;
+    for (int tile = bid * (kBlock / 64) + wave; tile < ntiles || !staged; tile += nblocks * (kBlock / 64)) {
+        const bool live = tile < ntiles;
+        const int row = min(tile * 16 + i, rows - 1);
+        const int64_t xr = static_cast<int64_t>(gather ? gather[row] : row) * K;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        uint4 xv[2][GU];
+        int cc[2][GU];
+        auto request = [&](int g0, int buf) {
+#pragma unroll
+            for (int t = 0; t < GU; ++t) {                                // branch free: groups past K re-read column 0 and are zeroed
+                const int c = 32 * (g0 + t) + 8 * q;
+                const bool ok = c < K;
+                cc[buf][t] = ok ? c : 0;
+                const uint4 raw = *reinterpret_cast<const uint4*>(X + xr + cc[buf][t]);
+                xv[buf][t] = ok ? raw : make_uint4(0, 0, 0, 0);
+            }
+        };
+        request(0, 0);
+        if (!staged) {
+            for (int idx = threadIdx.x; idx < NJ * K; idx += kBlock) {
+                const int j = idx / K, k = idx - j * K;
+                const float v = u[static_cast<int64_t>(j % H) * W + (j / H) * F + off + k];
+                const __bf16 hi = static_cast<__bf16>(v);
+                const __bf16 lo = static_cast<__bf16>(v - static_cast<float>(hi));
+                *reinterpret_cast<__bf16*>(Uh + j * RS + 2 * k) = hi;
+                *reinterpret_cast<__bf16*>(Ul + j * RS + 2 * k) = lo;
+            }
+            __syncthreads();
+            staged = true;
+        }
+        for (int g0 = 0; g0 < G; g0 += 2 * GU) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int gb = g0 + half * GU;
+                if (gb >= G) break;                                       // wave-uniform
+                if (gb + GU < G) request(gb + GU, half ^ 1);
+#pragma unroll
+                for (int t = 0; t < GU; ++t) {
+                    const uint4 xr4 = xv[half][t];
+                    const uint32_t w4[4] = {xr4.x, xr4.y, xr4.z, xr4.w};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        mx = fmaxf(mx, fmaxf(fabsf(__builtin_bit_cast(float, w4[d] << 16)), fabsf(__builtin_bit_cast(float, w4[d] & 0xffff0000u))));
+                    uint4 bh = *reinterpret_cast<const uint4*>(Uh + (iu ? i : 0) * RS + 2 * cc[half][t]);
+                    uint4 bl = *reinterpret_cast<const uint4*>(Ul + (iu ? i : 0) * RS + 2 * cc[half][t]);
+                    if (!iu) { bh = make_uint4(0, 0, 0, 0); bl = make_uint4(0, 0, 0, 0); }
+                    const bf16x8_t af = __builtin_bit_cast(bf16x8_t, xr4);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8_t, bl), acc, 0, 0, 0);
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                 // C layout: row 4 q + r, column i
+                const int ro = tile * 16 + 4 * q + r;
+                if (ro < rows && i < NJ) out[static_cast<int64_t>(ro) * NJ + i] = acc[r];
+            }
+        }
+    }
+    if (jb.amax) hx2_amax_commit(mx, jb.amax);
+}
+
 template <bool B16>
 __global__ void __launch_bounds__(kBlock) k_row_dots_x(const RowDotsJob j0, const RowDotsJob j1, const float* __restrict__ u, int32_t H,
                                                        int32_t W, const Hx2SplitBoth sp, int32_t nsplit) {
@@ -488,15 +572,19 @@ __global__ void __launch_bounds__(kBlock) k_row_dots_x(const RowDotsJob j0, cons
     const int bx = blockIdx.x;
     const bool second = bx >= j0.nb;
     const RowDotsJob& jb = second ? j1 : j0;
+    if constexpr (B16) { row_dots_b16(jb, second ? bx - j0.nb : bx, u, H, W, reinterpret_cast<unsigned char*>(U)); return; }
     const float* __restrict__ X = jb.X;
     const int32_t* __restrict__ gather = jb.gather;
     float* __restrict__ out = jb.out;
     const int rows = jb.rows, K = jb.K, F = jb.F, off = jb.off, NJ = jb.NJ, Kp = row_dots_kp(jb.K);
     const int bid = second ? bx - j0.nb : bx, nblocks = jb.nb;
-    constexpr int GU = 8;                                                // groups per register batch, two batches in flight
+    // VW elements per lane and request: bfloat16 rows are read 16 bytes at a time as float32 rows are (8 elements: with 4 a request moved
+    // half the bytes for the same issue slot — 40 us for 62 MB at cfg 5 — and a wave instruction costs the vector-memory path the same
+    // whatever it moves); a group is then 4 VW columns and half as many groups are in a register batch
+    constexpr int VW = B16 ? 8 : 4, GU = B16 ? 4 : 8;                    // groups per register batch, two batches in flight
     const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ntiles = (rows + 15) / 16, G = (K + 15) / 16;
+    const int ntiles = (rows + 15) / 16, G = (K + 4 * VW - 1) / (4 * VW);
     const bool iu = i < NJ;                                              // columns past NJ multiply by zero: U holds NJ rows only
     const float* Ui = U + (iu ? i : 0) * Kp;
     float mx = 0.f;
@@ -508,17 +596,25 @@ __global__ void __launch_bounds__(kBlock) k_row_dots_x(const RowDotsJob j0, cons
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         // two register batches of GU groups: batch b+1 is requested in front of batch b's MFMAs (rows wider than 256 columns —
         // out_att-sized inputs — were one dependent round trip per batch: 150 us for 262 MB)
-        f32x4_t xv[2][GU];
+        float xv[2][GU][VW];
         int cc[2][GU];
         auto request = [&](int g0, int buf) {
 #pragma unroll
             for (int t = 0; t < GU; ++t) {                                // branch free: groups past K re-read column 0 and are zeroed
-                const int c = 16 * (g0 + t) + 4 * q;
+                const int c = 4 * VW * (g0 + t) + VW * q;
                 const bool ok = c < K;
                 cc[buf][t] = ok ? c : 0;
-                float xq[4];
-                load_in<4, B16>(xq, X, xr + cc[buf][t]);
-                xv[buf][t] = ok ? f32x4_t{xq[0], xq[1], xq[2], xq[3]} : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                float xq[VW];
+                if constexpr (B16) {
+                    const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(X) + xr + cc[buf][t]);
+                    const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) { xq[2 * d] = __builtin_bit_cast(float, w4[d] << 16); xq[2 * d + 1] = __builtin_bit_cast(float, w4[d] & 0xffff0000u); }
+                } else {
+                    load_in<4, false>(xq, X, xr + cc[buf][t]);
+                }
+#pragma unroll
+                for (int e = 0; e < VW; ++e) xv[buf][t][e] = ok ? xq[e] : 0.f;
             }
         };
         request(0, 0);
@@ -538,12 +634,15 @@ __global__ void __launch_bounds__(kBlock) k_row_dots_x(const RowDotsJob j0, cons
                 if (gb + GU < G) request(gb + GU, half ^ 1);
 #pragma unroll
                 for (int t = 0; t < GU; ++t) {
-                    f32x4_t uv = *reinterpret_cast<const f32x4_t*>(Ui + cc[half][t]);
-                    if (!iu) uv = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        mx = fmaxf(mx, fabsf(xv[half][t][e]));
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[half][t][e], uv[e], acc, 0, 0, 0);
+                    for (int e0 = 0; e0 < VW; e0 += 4) {
+                        f32x4_t uv = *reinterpret_cast<const f32x4_t*>(Ui + cc[half][t] + e0);
+                        if (!iu) uv = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            mx = fmaxf(mx, fabsf(xv[half][t][e0 + e]));
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[half][t][e0 + e], uv[e], acc, 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -1587,7 +1686,7 @@ static int atp_fwd_common(const recon_graph* g, const recon_gat_atp_args* a, Atp
     atp_shape(a->F, a->R, a->H, s);
     if (a->io_bf16) {                                               // x / edge_embed stored as bfloat16: the f16 x 2 family's forward kernels only
         if (!recon_gat_atp_bf16_io_supported(a->F, a->R, a->D, a->H) || !atp_hx2(a) || a->ee_index) return RECON_ERR_UNSUPPORTED;
-        if (!al(a->x, 8) || !al(a->edge_embed, 8) || !al(a->V, 16) || !al(a->u, 16)) return RECON_ERR_UNSUPPORTED;
+        if (!al(a->x, 16) || !al(a->edge_embed, 16) || !al(a->V, 16) || !al(a->u, 16)) return RECON_ERR_UNSUPPORTED;     // rows are read 16 bytes at a time
         return RECON_OK;
     }
     if (!al(a->x, 4 * s->vec) || !al(a->edge_embed, 4 * s->vec) || !al(a->V, 16) || !al(a->u, 16)) return RECON_ERR_UNSUPPORTED;
@@ -1648,8 +1747,11 @@ extern "C" int recon_gat_atp_scores(const recon_graph* g, const recon_gat_atp_ar
             jn.nb = static_cast<int>(ceil_div64(N, 64) < 4096 ? ceil_div64(N, 64) : 4096);
             je.nb = erows > 0 ? static_cast<int>(ceil_div64(erows, 64) < 8192 ? ceil_div64(erows, 64) : 8192) : 0;
             const int kpm = row_dots_kp(F) > row_dots_kp(R) ? row_dots_kp(F) : row_dots_kp(R);
-            if (a->io_bf16) hipLaunchKernelGGL(k_row_dots_x<true>, dim3(static_cast<unsigned>(jn.nb + je.nb + nsplit)), dim3(kBlock), sizeof(float) * (2 * H) * kpm, st,
-                                               jn, je, a->u, H, W, sp, nsplit);
+            if (a->io_bf16) {
+                const int kx = F > R ? F : R;                          // two bf16 term planes of 16 score vectors (row stride: row_dots_b16_stride)
+                hipLaunchKernelGGL(k_row_dots_x<true>, dim3(static_cast<unsigned>(jn.nb + je.nb + nsplit)), dim3(kBlock), 2 * 16 * (static_cast<size_t>(kx) * 2 + 16), st,
+                                   jn, je, a->u, H, W, sp, nsplit);
+            }
             else hipLaunchKernelGGL(k_row_dots_x<false>, dim3(static_cast<unsigned>(jn.nb + je.nb + nsplit)), dim3(kBlock), sizeof(float) * (2 * H) * kpm, st,
                                     jn, je, a->u, H, W, sp, nsplit);
         } else if (s.vec == 4) hipLaunchKernelGGL((k_row_dots<4>), grid, dim3(kBlock), lds, st, jn, je, a->u, H, W);
