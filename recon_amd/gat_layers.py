@@ -400,9 +400,6 @@ class _GATHeadsFunction(torch.autograd.Function):
         _require_gpu_f32(x, ee, a, a2, keep)
         L = _lib.lib()
         x, ee, a, a2 = x.contiguous(), ee.contiguous(), a.contiguous(), a2.contiguous()
-        if io16:                                                    # bfloat16 rows are read 16 bytes at a time: a view at an odd storage offset is copied
-            x = x if x.data_ptr() % 16 == 0 else x.clone()
-            ee = ee if ee.data_ptr() % 16 == 0 else ee.clone()
         H, D = a2.shape
         N, E = graph.N, graph.E
         if x.shape[0] != N or ee.shape[0] != E or a.shape != (H, D, 2 * x.shape[1] + ee.shape[1]):
@@ -571,6 +568,9 @@ class _GATHeadsATPFunction(torch.autograd.Function):
             _require_gpu_f32(x, ee, a, a2, keep)
         L = _lib.lib()
         x, ee, a, a2 = x.contiguous(), ee.contiguous(), a.contiguous(), a2.contiguous()
+        if io16:                                                    # bfloat16 rows are read 16 bytes at a time: a view at an odd storage offset is copied
+            x = x if x.data_ptr() % 16 == 0 else x.clone()
+            ee = ee if ee.data_ptr() % 16 == 0 else ee.clone()
         H, D = a2.shape
         N, E = graph.N, graph.E
         F_, R = x.shape[1], ee.shape[1]
