@@ -30,9 +30,20 @@ __global__ void __launch_bounds__(kThreads) k_radix_hist(const int32_t* __restri
 template <bool GATHER>
 __global__ void __launch_bounds__(kThreads) k_keys_hist(const int64_t* __restrict__ in, const int32_t* __restrict__ eid, int32_t n,
                                                         int32_t* __restrict__ src_out, int32_t* __restrict__ keys, int32_t* __restrict__ vals,
-                                                        int32_t* __restrict__ blockhist, int32_t nblocks, int32_t N, int32_t* __restrict__ bad) {
+                                                        int32_t* __restrict__ blockhist, int32_t nblocks, int32_t N, int32_t* __restrict__ bad,
+                                                        int32_t* __restrict__ nexthist, const int32_t* __restrict__ lb_keys = nullptr,
+                                                        int32_t* __restrict__ lb_rowptr = nullptr) {
+    if (static_cast<int>(blockIdx.x) >= nblocks) {                       // trailing blocks: the row pointers of the sort that just finished
+        const int r = (blockIdx.x - nblocks) * kThreads + threadIdx.x;  // (k_rowptr_lower_bound's work: a launch less per build)
+        if (r > N) return;
+        int lo = 0, hi = n;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (lb_keys[mid] < r) lo = mid + 1; else hi = mid; }
+        lb_rowptr[r] = lo;
+        return;
+    }
     __shared__ int32_t hist[256];
     hist[threadIdx.x] = 0;
+    if (nexthist) nexthist[threadIdx.x * nblocks + blockIdx.x] = 0;     // the second pass' histogram, counted by the first pass' scatter
     __syncthreads();
     const int base = blockIdx.x * kTile;
 #pragma unroll
@@ -95,13 +106,15 @@ __global__ void __launch_bounds__(1024) k_scan_exclusive(int32_t* __restrict__ d
 // SCANNED: `blockhist` holds the exclusive scan over (digit, block) (k_scan_exclusive ran in front).  Otherwise it holds the raw per-block
 // digit counts and every workgroup derives its own bases from them — digit t's total over all blocks, the digits' exclusive scan, plus
 // digit t's counts of the blocks in front of this one: nblocks loads per thread instead of a launch (kFoldScanBlocks: where that is cheap).
+// `nexthist` (zeroed by k_keys_hist): the per-tile digit histogram of the NEXT pass, counted here where every item's new position is known
+// — integer atomics, so the counts are the same on every run — instead of by a launch of k_radix_hist between the passes.
 template <bool SCANNED>
 __global__ void __launch_bounds__(kThreads) k_radix_scatter(const int32_t* __restrict__ keys_in,
                                                             const int32_t* __restrict__ vals_in,
                                                             int32_t* __restrict__ keys_out,
                                                             int32_t* __restrict__ vals_out, int32_t n, int shift,
                                                             const int32_t* __restrict__ blockhist_scanned,
-                                                            int32_t nblocks) {
+                                                            int32_t nblocks, int32_t* __restrict__ nexthist = nullptr) {
     __shared__ int32_t wcount[4][256];
     __shared__ int32_t dig[256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -162,6 +175,7 @@ __global__ void __launch_bounds__(kThreads) k_radix_scatter(const int32_t* __res
             const int pos = wcount[w][(key[j] >> shift) & 255] + rank[j];
             keys_out[pos] = key[j];
             vals_out[pos] = val[j];
+            if (nexthist) atomicAdd(&nexthist[((key[j] >> (shift + 8)) & 255) * nblocks + pos / kTile], 1);
         }
     }
 }
@@ -183,7 +197,7 @@ __global__ void k_copy_i32(const int32_t* __restrict__ in, int32_t* __restrict__
 
 int bits_for(int32_t n) { int b = 1; while (b < 31 && (1 << b) < n) ++b; return b; }
 
-struct SortWs { int32_t *kA, *kB, *vA, *vB, *hist; int32_t nblocks; };
+struct SortWs { int32_t *kA, *kB, *vA, *vB, *hist, *hist2; int32_t nblocks; };
 
 // stable sort of (kA, vA); the LAST pass scatters into (kfinal, vfinal) when given (a copy launch each less per sort: a graph build is
 // launch bound at the stage-A batch sizes), else the result ends up in (*kout, *vout), which point into the ping-pong buffers
@@ -191,16 +205,21 @@ int radix_sort_pairs(SortWs& ws, int32_t n, int32_t key_range, int32_t** kout, i
                      int32_t* vfinal = nullptr, bool first_hist_done = false) {
     const int passes = (bits_for(key_range) + 7) / 8;
     int32_t *ki = ws.kA, *vi = ws.vA, *ko = ws.kB, *vo = ws.vB;
+    // two passes with the first histogram already counted (k_keys_hist, which also zeroed hist2): the first scatter counts the second
+    // pass' histogram into hist2 — four launches per sort instead of five
+    const bool chain = passes == 2 && first_hist_done && ws.hist2;
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
         if (p == passes - 1) { if (kfinal) ko = kfinal; if (vfinal) vo = vfinal; }
-        if (p > 0 || !first_hist_done)
-            hipLaunchKernelGGL(k_radix_hist, dim3(ws.nblocks), dim3(kThreads), 0, st, ki, n, shift, ws.hist, ws.nblocks);
+        int32_t* hist = (chain && p == 1) ? ws.hist2 : ws.hist;
+        int32_t* next = (chain && p == 0) ? ws.hist2 : nullptr;
+        if (!(chain && p == 1) && (p > 0 || !first_hist_done))
+            hipLaunchKernelGGL(k_radix_hist, dim3(ws.nblocks), dim3(kThreads), 0, st, ki, n, shift, hist, ws.nblocks);
         if (ws.nblocks <= kFoldScanBlocks) {
-            hipLaunchKernelGGL((k_radix_scatter<false>), dim3(ws.nblocks), dim3(kThreads), 0, st, ki, vi, ko, vo, n, shift, ws.hist, ws.nblocks);
+            hipLaunchKernelGGL((k_radix_scatter<false>), dim3(ws.nblocks), dim3(kThreads), 0, st, ki, vi, ko, vo, n, shift, hist, ws.nblocks, next);
         } else {
-            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, ws.hist, 256 * ws.nblocks);
-            hipLaunchKernelGGL((k_radix_scatter<true>), dim3(ws.nblocks), dim3(kThreads), 0, st, ki, vi, ko, vo, n, shift, ws.hist, ws.nblocks);
+            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, hist, 256 * ws.nblocks);
+            hipLaunchKernelGGL((k_radix_scatter<true>), dim3(ws.nblocks), dim3(kThreads), 0, st, ki, vi, ko, vo, n, shift, hist, ws.nblocks, next);
         }
         int32_t* t;
         t = ki; ki = ko; ko = t;
@@ -460,7 +479,7 @@ extern "C" size_t recon_graph_workspace_bytes(int32_t N, int32_t E) {
     (void)N;
     const size_t e = align_up(static_cast<size_t>(E > 0 ? E : 1) * sizeof(int32_t), 256);
     const size_t nblocks = static_cast<size_t>(ceil_div64(E > 0 ? E : 1, kTile));
-    return 4 * e + align_up(256 * nblocks * sizeof(int32_t), 256);
+    return 4 * e + 2 * align_up(256 * nblocks * sizeof(int32_t), 256);     // two histograms: the second pass' is counted while the first pass scatters
 }
 
 extern "C" int recon_graph_build(const int64_t* edge_dst, const int64_t* edge_src, recon_graph* g, void* workspace,
@@ -492,6 +511,7 @@ extern "C" int recon_graph_build_checked(const int64_t* edge_dst, const int64_t*
     ws.vB = reinterpret_cast<int32_t*>(w + 3 * e);
     ws.hist = reinterpret_cast<int32_t*>(w + 4 * e);
     ws.nblocks = static_cast<int32_t>(ceil_div64(E, kTile));
+    ws.hist2 = reinterpret_cast<int32_t*>(w + 4 * e + align_up(256 * static_cast<size_t>(ws.nblocks) * sizeof(int32_t), 256));
     const dim3 nb(static_cast<unsigned>(ceil_div64(N + 1, 256)));
     if (E <= kSmallE && N <= kSmallN && recon::cfg_char(recon::CFG_GRAPH_SMALL) != '0') {       // one launch (k_graph_build_small)
         const size_t lds = (4096 + 64 + static_cast<size_t>(N) + 1) * sizeof(int32_t);
@@ -506,14 +526,19 @@ extern "C" int recon_graph_build_checked(const int64_t* edge_dst, const int64_t*
     }
 
     // destination CSR: stable sort of (dst, edge column)
-    hipLaunchKernelGGL((k_keys_hist<false>), dim3(ws.nblocks), dim3(kThreads), 0, st, edge_dst, nullptr, E, nullptr, ws.kA, ws.vA, ws.hist, ws.nblocks, N, bad);
+    hipLaunchKernelGGL((k_keys_hist<false>), dim3(ws.nblocks), dim3(kThreads), 0, st, edge_dst, nullptr, E, nullptr, ws.kA, ws.vA, ws.hist, ws.nblocks, N, bad, ws.hist2);
     int32_t *ks, *vs;
     int rc = radix_sort_pairs(ws, E, N, &ks, &vs, st, g->dst, g->eid, true);
     if (rc != RECON_OK) return rc;
-    hipLaunchKernelGGL(k_rowptr_lower_bound, nb, dim3(256), 0, st, g->dst, E, N, g->rowptr_dst);
-    if (!with_src) { RECON_CHECK_LAUNCH(); return RECON_OK; }
-    // source CSC over CSR slots: stable sort of (src of slot, slot)
-    hipLaunchKernelGGL((k_keys_hist<true>), dim3(ws.nblocks), dim3(kThreads), 0, st, edge_src, g->eid, E, g->src, ws.kA, ws.vA, ws.hist, ws.nblocks, N, bad);
+    if (!with_src) {
+        hipLaunchKernelGGL(k_rowptr_lower_bound, nb, dim3(256), 0, st, g->dst, E, N, g->rowptr_dst);
+        RECON_CHECK_LAUNCH();
+        return RECON_OK;
+    }
+    // source CSC over CSR slots: stable sort of (src of slot, slot); the destination row pointers ride in the same launch (trailing blocks)
+    static_assert(kThreads == 256, "the row-pointer blocks of k_keys_hist cover 256 rows each");
+    hipLaunchKernelGGL((k_keys_hist<true>), dim3(ws.nblocks + nb.x), dim3(kThreads), 0, st, edge_src, g->eid, E, g->src, ws.kA, ws.vA, ws.hist, ws.nblocks, N, bad,
+                       ws.hist2, g->dst, g->rowptr_dst);
     rc = radix_sort_pairs(ws, E, N, &ks, &vs, st, nullptr, g->slot_by_src, true);
     if (rc != RECON_OK) return rc;
     hipLaunchKernelGGL(k_rowptr_lower_bound, nb, dim3(256), 0, st, ks, E, N, g->rowptr_src);

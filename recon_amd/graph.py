@@ -87,21 +87,29 @@ class GraphCSR:
         self.N, self.E, self.device = int(N), int(E), dev
         self.edge = edge
         i32 = dict(dtype=torch.int32, device=dev)
-        self.rowptr_dst = torch.empty(N + 1, **i32)
         self.rows_only = bool(rows_only)
-        self.rowptr_src = None if rows_only else torch.empty(N + 1, **i32)
-        self.eid = torch.empty(E, **i32)
-        self.src = None if rows_only else torch.empty(E, **i32)
-        self.dst = torch.empty(E, **i32)
-        self.slot_by_src = None if rows_only else torch.empty(E, **i32)
         L = _lib.lib()
         ws_bytes = L.recon_graph_workspace_bytes(self.N, self.E)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        self.c = _lib.ReconGraph(self.N, self.E, self.rowptr_dst.data_ptr(), self.eid.data_ptr(),
-                                 _lib.ptr(self.src), self.dst.data_ptr(), _lib.ptr(self.rowptr_src), _lib.ptr(self.slot_by_src))
+        # ONE allocation for the six index arrays and the sort workspace (a fresh graph per iteration — the reference's stage-A regime — is
+        # host bound: seven allocations and two row views were a fifth of a build's 125 us); the arrays are handed out as views on first use
+        a64 = lambda v: (v + 63) // 64 * 64                                  # 256-byte aligned parts, in int32 elements
+        nr, ne = a64(N + 1), a64(max(E, 1))
+        parts = [("rowptr_dst", N + 1, nr), ("eid", E, ne), ("dst", E, ne)]
+        if not rows_only:
+            parts += [("rowptr_src", N + 1, nr), ("src", E, ne), ("slot_by_src", E, ne)]
+        total = sum(p_[2] for p_ in parts)
+        self._buf = torch.empty(total + a64((ws_bytes + 3) // 4), **i32)
+        self._parts, off = {}, 0
+        for name, n_, room in parts:
+            self._parts[name] = (off, n_)
+            off += room
+        base = self._buf.data_ptr()
+        ptr = lambda name: base + 4 * self._parts[name][0] if name in self._parts else None
+        self.c = _lib.ReconGraph(self.N, self.E, ptr("rowptr_dst"), ptr("eid"), ptr("src"), ptr("dst"), ptr("rowptr_src"), ptr("slot_by_src"))
+        ws_ptr = base + 4 * total
         bad = _bad_flag(dev) if in_build else None
         with _lib.on_device(dev):
-            rc = L.recon_graph_build_checked(edge[0].data_ptr(), edge[1].data_ptr(), C.byref(self.c), ws.data_ptr(),
+            rc = L.recon_graph_build_checked(edge.data_ptr(), edge.data_ptr() + 8 * E, C.byref(self.c), ws_ptr,
                                              ws_bytes, _lib.ptr(bad), _lib.current_stream())
         _lib.check(rc, "recon_graph_build")
         self._eid_long = None
@@ -112,7 +120,7 @@ class GraphCSR:
             cnt = (C.c_int32 * 4)()
             bad_host = C.c_int32(0)
             with _lib.on_device(dev):
-                _lib.check(L.recon_graph_hubs_count_checked(C.byref(self.c), HUB_CHUNK, ws.data_ptr(), cnt, _lib.ptr(bad), C.byref(bad_host) if bad is not None else None,
+                _lib.check(L.recon_graph_hubs_count_checked(C.byref(self.c), HUB_CHUNK, ws_ptr, cnt, _lib.ptr(bad), C.byref(bad_host) if bad is not None else None,
                                                             _lib.current_stream()), "recon_graph_hubs_count")
             if bad_host.value:
                 bad.zero_()                                             # the flag is shared by the device's builds: hand it back clear
@@ -136,6 +144,18 @@ class GraphCSR:
                                                                                  self.piece_src.data_ptr())
                 with _lib.on_device(dev):
                     _lib.check(L.recon_graph_hubs_fill(C.byref(self.c), _lib.current_stream()), "recon_graph_hubs_fill")
+
+    def _part(self, name):
+        """View of one index array inside the graph's single allocation (None where a destination-only graph has none)."""
+        hit = self._parts.get(name)
+        return None if hit is None else self._buf[hit[0]:hit[0] + hit[1]]
+
+    rowptr_dst = property(lambda self: self._part("rowptr_dst"))
+    rowptr_src = property(lambda self: self._part("rowptr_src"))
+    eid = property(lambda self: self._part("eid"))
+    src = property(lambda self: self._part("src"))
+    dst = property(lambda self: self._part("dst"))
+    slot_by_src = property(lambda self: self._part("slot_by_src"))
 
     def slot_order_index(self, index, n_rows):
         """int32 [E]: index (int64 [E], original edge order) permuted to CSR-slot order — the table row each slot reads
