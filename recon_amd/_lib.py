@@ -144,6 +144,8 @@ SYMBOLS = [
     ("recon_graph_hubs_count", C.c_int, [C.POINTER(ReconGraph), C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     ("recon_graph_build_checked", C.c_int, [c_i64p, c_i64p, C.POINTER(ReconGraph), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     ("recon_graph_hubs_count_checked", C.c_int, [C.POINTER(ReconGraph), C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    ("recon_graph_build_counted", C.c_int, [c_i64p, c_i64p, C.POINTER(ReconGraph), C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.c_void_p]),
+    ("recon_graph_hubs_read", C.c_int, [C.POINTER(ReconGraph), C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     ("recon_graph_hubs_fill", C.c_int, [C.POINTER(ReconGraph), C.c_void_p]),
     ("recon_graph_hub_ws_floats", C.c_size_t, [C.POINTER(ReconGraph), C.c_int32, C.c_int32, C.c_int32]),
     ("recon_spmm_rowsum_workspace_floats", C.c_size_t, [C.c_int32, C.c_int32]),

@@ -32,7 +32,8 @@ __global__ void __launch_bounds__(kThreads) k_keys_hist(const int64_t* __restric
                                                         int32_t* __restrict__ src_out, int32_t* __restrict__ keys, int32_t* __restrict__ vals,
                                                         int32_t* __restrict__ blockhist, int32_t nblocks, int32_t N, int32_t* __restrict__ bad,
                                                         int32_t* __restrict__ nexthist, const int32_t* __restrict__ lb_keys = nullptr,
-                                                        int32_t* __restrict__ lb_rowptr = nullptr) {
+                                                        int32_t* __restrict__ lb_rowptr = nullptr, int32_t* __restrict__ zero4 = nullptr) {
+    if (zero4 && blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0;      // the hub counts of recon_graph_build_counted
     if (static_cast<int>(blockIdx.x) >= nblocks) {                       // trailing blocks: the row pointers of the sort that just finished
         const int r = (blockIdx.x - nblocks) * kThreads + threadIdx.x;  // (k_rowptr_lower_bound's work: a launch less per build)
         if (r > N) return;
@@ -188,6 +189,27 @@ __global__ void k_rowptr_lower_bound(const int32_t* __restrict__ sorted_keys, in
     int lo = 0, hi = E;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (sorted_keys[mid] < r) lo = mid + 1; else hi = mid; }
     rowptr[r] = lo;
+}
+
+// The last launch of a full build when the caller wants the hub-table sizes as well (recon_graph_build_counted): the source row pointers
+// as above and, from them and the finished destination row pointers, counts[4] = (hubs, pieces) of both sides — what k_hub_scan<false>
+// counts in a launch of its own.  A thread's upper neighbour's result comes through LDS (the block's last thread searches once more);
+// integer atomics into zeroed words: the same counts on every run.
+__global__ void __launch_bounds__(256) k_rowptr_lower_bound_count(const int32_t* __restrict__ sorted_keys, int32_t E, int32_t N, int32_t* __restrict__ rowptr,
+                                                                  const int32_t* __restrict__ rowptr_other, int32_t chunk, int32_t* __restrict__ counts) {
+    __shared__ int32_t lb[257];
+    const int t = threadIdx.x, r = blockIdx.x * 256 + t;
+    auto search = [&](int key) { int lo = 0, hi = E; while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] < key) lo = mid + 1; else hi = mid; } return lo; };
+    const int mine = r <= N ? search(r) : E;
+    lb[t] = mine;
+    if (t == 255) lb[256] = r + 1 <= N ? search(r + 1) : E;
+    if (r <= N) rowptr[r] = mine;
+    __syncthreads();
+    if (r < N) {
+        const int deg = lb[t + 1] - mine, deg_o = rowptr_other[r + 1] - rowptr_other[r];
+        if (deg_o > chunk) { atomicAdd(&counts[0], 1); atomicAdd(&counts[1], (deg_o + chunk - 1) / chunk); }
+        if (deg > chunk) { atomicAdd(&counts[2], 1); atomicAdd(&counts[3], (deg + chunk - 1) / chunk); }
+    }
 }
 
 __global__ void k_copy_i32(const int32_t* __restrict__ in, int32_t* __restrict__ out, int32_t n) {
@@ -479,7 +501,10 @@ extern "C" size_t recon_graph_workspace_bytes(int32_t N, int32_t E) {
     (void)N;
     const size_t e = align_up(static_cast<size_t>(E > 0 ? E : 1) * sizeof(int32_t), 256);
     const size_t nblocks = static_cast<size_t>(ceil_div64(E > 0 ? E : 1, kTile));
-    return 4 * e + 2 * align_up(256 * nblocks * sizeof(int32_t), 256);     // two histograms: the second pass' is counted while the first pass scatters
+    return 4 * e + 2 * align_up(256 * nblocks * sizeof(int32_t), 256) + 256;     // two histograms (the second pass' is counted while the first pass scatters) + the hub counts
+}
+static int32_t* graph_ws_counts(void* workspace, int32_t N, int32_t E) {
+    return reinterpret_cast<int32_t*>(static_cast<char*>(workspace) + recon_graph_workspace_bytes(N, E) - 256);
 }
 
 extern "C" int recon_graph_build(const int64_t* edge_dst, const int64_t* edge_src, recon_graph* g, void* workspace,
@@ -487,8 +512,31 @@ extern "C" int recon_graph_build(const int64_t* edge_dst, const int64_t* edge_sr
     return recon_graph_build_checked(edge_dst, edge_src, g, workspace, workspace_bytes, nullptr, stream);
 }
 
+static int graph_build(const int64_t* edge_dst, const int64_t* edge_src, recon_graph* g, void* workspace, size_t workspace_bytes, int32_t* bad, int32_t chunk,
+                       recon_stream_t stream);
 extern "C" int recon_graph_build_checked(const int64_t* edge_dst, const int64_t* edge_src, recon_graph* g, void* workspace,
                                          size_t workspace_bytes, int32_t* bad, recon_stream_t stream) {
+    return graph_build(edge_dst, edge_src, g, workspace, workspace_bytes, bad, 0, stream);
+}
+// The build with the hub-table sizes for `chunk` counted on the way (its last launch, or one k_hub_scan launch behind the single-launch
+// build): they stay in the workspace and recon_graph_hubs_read() fetches them — a launch less per build than build + hubs_count.
+extern "C" int recon_graph_build_counted(const int64_t* edge_dst, const int64_t* edge_src, recon_graph* g, void* workspace, size_t workspace_bytes,
+                                         int32_t* bad, int32_t chunk, recon_stream_t stream) {
+    if (chunk <= 0 || !g || !g->rowptr_src) return RECON_ERR_INVALID;
+    return graph_build(edge_dst, edge_src, g, workspace, workspace_bytes, bad, chunk, stream);
+}
+extern "C" int recon_graph_hubs_read(const recon_graph* g, void* workspace, int32_t* counts, const int32_t* bad, int32_t* bad_host, recon_stream_t stream) {
+    if (!g || !counts || !workspace || g->N < 0 || g->E < 0 || (bad && !bad_host)) return RECON_ERR_INVALID;
+    hipStream_t st = as_stream(stream);
+    counts[0] = counts[1] = counts[2] = counts[3] = 0;
+    if (bad_host) *bad_host = 0;
+    if (bad && hipMemcpyAsync(bad_host, bad, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return RECON_ERR_LAUNCH;
+    if (g->E > 0 && hipMemcpyAsync(counts, graph_ws_counts(workspace, g->N, g->E), 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return RECON_ERR_LAUNCH;
+    if (hipStreamSynchronize(st) != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+static int graph_build(const int64_t* edge_dst, const int64_t* edge_src, recon_graph* g, void* workspace, size_t workspace_bytes, int32_t* bad, int32_t chunk,
+                       recon_stream_t stream) {
     if (!g || g->N < 0 || g->E < 0) return RECON_ERR_INVALID;
     if (!g->rowptr_dst) return RECON_ERR_INVALID;
     const bool with_src = g->rowptr_src != nullptr;                 // NULL: destination CSR only (row sums need no source view)
@@ -521,12 +569,16 @@ extern "C" int recon_graph_build_checked(const int64_t* edge_dst, const int64_t*
                                          g->rowptr_src, g->slot_by_src, ws.kA, ws.vA, ws.kB, ws.vB, bad);
         else hipLaunchKernelGGL((k_graph_build_small<false>), dim3(1), dim3(1024), lds, st, edge_dst, edge_src, N, E, g->rowptr_dst, g->eid, g->src, g->dst,
                                 g->rowptr_src, g->slot_by_src, ws.kA, ws.vA, ws.kB, ws.vB, bad);
+        if (chunk > 0)
+            hipLaunchKernelGGL((k_hub_scan<false>), dim3(2), dim3(1024), 0, st, g->rowptr_dst, N, chunk, graph_ws_counts(workspace, N, E), nullptr, nullptr,
+                               reinterpret_cast<int4*>(g->rowptr_src));
         RECON_CHECK_LAUNCH();
         return RECON_OK;
     }
 
     // destination CSR: stable sort of (dst, edge column)
-    hipLaunchKernelGGL((k_keys_hist<false>), dim3(ws.nblocks), dim3(kThreads), 0, st, edge_dst, nullptr, E, nullptr, ws.kA, ws.vA, ws.hist, ws.nblocks, N, bad, ws.hist2);
+    hipLaunchKernelGGL((k_keys_hist<false>), dim3(ws.nblocks), dim3(kThreads), 0, st, edge_dst, nullptr, E, nullptr, ws.kA, ws.vA, ws.hist, ws.nblocks, N, bad, ws.hist2,
+                       nullptr, nullptr, chunk > 0 ? graph_ws_counts(workspace, N, E) : nullptr);
     int32_t *ks, *vs;
     int rc = radix_sort_pairs(ws, E, N, &ks, &vs, st, g->dst, g->eid, true);
     if (rc != RECON_OK) return rc;
@@ -541,7 +593,8 @@ extern "C" int recon_graph_build_checked(const int64_t* edge_dst, const int64_t*
                        ws.hist2, g->dst, g->rowptr_dst);
     rc = radix_sort_pairs(ws, E, N, &ks, &vs, st, nullptr, g->slot_by_src, true);
     if (rc != RECON_OK) return rc;
-    hipLaunchKernelGGL(k_rowptr_lower_bound, nb, dim3(256), 0, st, ks, E, N, g->rowptr_src);
+    if (chunk > 0) hipLaunchKernelGGL(k_rowptr_lower_bound_count, nb, dim3(256), 0, st, ks, E, N, g->rowptr_src, g->rowptr_dst, chunk, graph_ws_counts(workspace, N, E));
+    else hipLaunchKernelGGL(k_rowptr_lower_bound, nb, dim3(256), 0, st, ks, E, N, g->rowptr_src);
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }

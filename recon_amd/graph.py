@@ -108,20 +108,25 @@ class GraphCSR:
         self.c = _lib.ReconGraph(self.N, self.E, ptr("rowptr_dst"), ptr("eid"), ptr("src"), ptr("dst"), ptr("rowptr_src"), ptr("slot_by_src"))
         ws_ptr = base + 4 * total
         bad = _bad_flag(dev) if in_build else None
+        hubs = HUB_CHUNK > 0 and E > HUB_CHUNK and not rows_only            # the hub-table sizes are counted by the build's last launch
         with _lib.on_device(dev):
-            rc = L.recon_graph_build_checked(edge.data_ptr(), edge.data_ptr() + 8 * E, C.byref(self.c), ws_ptr,
-                                             ws_bytes, _lib.ptr(bad), _lib.current_stream())
+            if hubs:
+                rc = L.recon_graph_build_counted(edge.data_ptr(), edge.data_ptr() + 8 * E, C.byref(self.c), ws_ptr, ws_bytes, _lib.ptr(bad), HUB_CHUNK,
+                                                 _lib.current_stream())
+            else:
+                rc = L.recon_graph_build_checked(edge.data_ptr(), edge.data_ptr() + 8 * E, C.byref(self.c), ws_ptr,
+                                                 ws_bytes, _lib.ptr(bad), _lib.current_stream())
         _lib.check(rc, "recon_graph_build")
         self._eid_long = None
         self._slot_idx = {}
         # hub rows (include/recon_hip.h): destinations with more than HUB_CHUNK in-edges are cut into pieces, one wavefront each
         self.n_hub = self.n_piece = self.n_hub_src = self.n_piece_src = 0
-        if HUB_CHUNK > 0 and E > HUB_CHUNK and not rows_only:
+        if hubs:
             cnt = (C.c_int32 * 4)()
             bad_host = C.c_int32(0)
             with _lib.on_device(dev):
-                _lib.check(L.recon_graph_hubs_count_checked(C.byref(self.c), HUB_CHUNK, ws_ptr, cnt, _lib.ptr(bad), C.byref(bad_host) if bad is not None else None,
-                                                            _lib.current_stream()), "recon_graph_hubs_count")
+                _lib.check(L.recon_graph_hubs_read(C.byref(self.c), ws_ptr, cnt, _lib.ptr(bad), C.byref(bad_host) if bad is not None else None,
+                                                   _lib.current_stream()), "recon_graph_hubs_read")
             if bad_host.value:
                 bad.zero_()                                             # the flag is shared by the device's builds: hand it back clear
                 lo, hi = (int(v) for v in torch.aminmax(edge))
