@@ -66,17 +66,48 @@ __global__ void __launch_bounds__(1024) k_kg_adj_count(const KG g, const int64_t
         if (i < B) rel_off[i] = ex;
     }
     if (threadIdx.x == 0) totals[0] = carry;
-    for (int which = 0; which < 2; ++which) {                           // sorted unique ids out of the marks
+    // sorted unique ids out of the marks: 16 marks per thread and pass (one 16-byte load where the array allows it), so that an FB15k-sized
+    // entity set is ONE scan per array — a mark per thread and pass was 15 dependent passes of a single workgroup per array, 45 of the
+    // launch's 59 us
+    __shared__ int32_t wsum32[16];
+    for (int which = 0; which < 2; ++which) {
         uint8_t* mark = which ? tgt_mark : ent_mark;
         int64_t* out = which ? uniq_tgt : uniq_ent;
-        carry = 0;
-        for (int64_t i0 = 0; i0 < g.Ne; i0 += 1024) {
-            const int64_t i = i0 + threadIdx.x;
-            const int64_t v = (i < g.Ne && mark[i]) ? 1 : 0;
-            const int64_t ex = block_scan_1024(v, wsum, carry);
-            if (v) { out[ex] = i; mark[i] = 0; }
+        const bool vec_ok = (reinterpret_cast<uintptr_t>(mark) & 15) == 0;
+        int32_t carry32 = 0;
+        for (int64_t i0 = 0; i0 < g.Ne; i0 += 16 * 1024) {
+            const int64_t i = i0 + 16 * static_cast<int64_t>(threadIdx.x);
+            const bool full = vec_ok && i + 16 <= g.Ne;
+            uint32_t wd[4] = {0u, 0u, 0u, 0u};
+            if (full) { const uint4 q = *reinterpret_cast<const uint4*>(mark + i); wd[0] = q.x; wd[1] = q.y; wd[2] = q.z; wd[3] = q.w; }
+            else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (i + k < g.Ne && mark[i + k]) wd[k >> 2] |= 1u << (8 * (k & 3));
+            }
+            int32_t cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cnt += ((wd[k >> 2] >> (8 * (k & 3))) & 0xffu) != 0u;
+            // exclusive scan of cnt over the workgroup
+            int32_t x = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_up(x, off, 64); if (lane >= off) x += o; }
+            if (lane == 63) wsum32[w] = x;
+            __syncthreads();
+            int32_t base = 0, tot = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { const int32_t sj = wsum32[j]; if (j < w) base += sj; tot += sj; }
+            __syncthreads();
+            int64_t at = carry32 + base + x - cnt;
+            carry32 += tot;
+            if (cnt) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if ((wd[k >> 2] >> (8 * (k & 3))) & 0xffu) { out[at++] = i + k; if (!full) mark[i + k] = 0; }
+                if (full) *reinterpret_cast<uint4*>(mark + i) = make_uint4(0u, 0u, 0u, 0u);
+            }
         }
-        if (threadIdx.x == 0) totals[1 + which] = carry;
+        if (threadIdx.x == 0) totals[1 + which] = carry32;
     }
     if (threadIdx.x == 0) *counter = 0u;
 }
@@ -138,44 +169,88 @@ __global__ void __launch_bounds__(64) k_kg_nhop(const KG g, const int64_t* __res
     int vbits = 1;
     while (vbits < 63 && (1LL << vbits) < g.Ne) ++vbits;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int64_t pb = p0; pb < p1 && count < limit; pb += 64) {
+    // The walk of one source is a chain: a chunk's candidates are looked up in `seen` after the chunk before it has marked its own.  What the
+    // chain does NOT order are the loads: where a candidate lies (parent tables) and what it is (its target, its first relation) depend on the
+    // knowledge graph alone.  So the targets of the next kChunks chunks are requested before a chunk is resolved, and the next 64 parents'
+    // pair ranges before a batch's candidates are walked — a long source (a hub among its parents: tens of thousands of candidates) was one
+    // exposed round trip per 64 candidates, 0.78 ms for the slowest of 128 sources.
+    constexpr int kChunks = 4;
+    // parents two stages ahead: stage 1 (a parent's target, loop mark, first relation) for the batch after the next, stage 2 (the target's
+    // pair range — needs stage 1's answer as its address) for the next; raw values only, combined where they are used, so that nothing in
+    // front of a batch's walk waits for them.  Lanes past the source's last pair re-read its first pair and count as loops.
+    struct Stage1 { bool in; uint8_t nl; int64_t u, r1; };
+    struct Stage2 { int64_t c0, c1; };
+    auto request1 = [&](int64_t pb) {
+        Stage1 r;
         const int64_t pa_l = pb + lane;
-        const bool ok_l = pa_l < p1 && g.not_loop[pa_l];
-        const int64_t u_l = ok_l ? g.pair_tgt[pa_l] : 0;
-        const int64_t c0_l = ok_l ? g.pair_ptr[u_l] : 0, c1_l = ok_l ? g.pair_ptr[u_l + 1] : 0;
-        const int deg = static_cast<int>(c1_l - c0_l);
+        r.in = pa_l < p1;
+        const int64_t pa_c = r.in ? pa_l : p0;
+        r.nl = g.not_loop[pa_c]; r.u = g.pair_tgt[pa_c]; r.r1 = g.pair_first_rel[pa_c];
+        return r;
+    };
+    auto request2 = [&](const Stage1& a) { return Stage2{g.pair_ptr[a.u], g.pair_ptr[a.u + 1]}; };
+    Stage1 a1{false, 0, 0, 0}, b1{false, 0, 0, 0};
+    Stage2 a2{0, 0};
+    if (p0 < p1) { a1 = request1(p0); b1 = request1(p0 + 64); a2 = request2(a1); }
+    for (int64_t pb = p0; pb < p1 && count < limit; pb += 64) {
+        const bool ok = a1.in && a1.nl;
+        const int deg = ok ? static_cast<int>(a2.c1 - a2.c0) : 0;
         int x = deg;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(x, off, 64); if (lane >= off) x += t; }
         const int T = __shfl(x, 63, 64);
         __syncthreads();                                                 // the previous batch's readers are done with the tables
-        poff[lane] = x - deg; pc0[lane] = c0_l; pr1[lane] = ok_l ? g.pair_first_rel[pa_l] : 0;
+        poff[lane] = x - deg; pc0[lane] = ok ? a2.c0 : 0; pr1[lane] = a1.r1;
         __syncthreads();
-        for (int x0 = 0; x0 < T && count < limit; x0 += 64) {            // wave-uniform
+        a1 = b1; a2 = request2(b1); b1 = request1(pb + 128);            // under this batch's walk
+        int64_t v_r[kChunks], f_r[kChunks]; int lo_r[kChunks];
+        auto request = [&](int slot, int x0) {                           // chunks past T: every lane invalid, reads candidate 0 of parent 0's range
             const int xi = x0 + lane;
             const bool valid = xi < T;
-            int lo = 0;                                                  // the last parent whose first candidate is <= xi (parents without candidates share an offset with the next)
+            // the last parent whose first candidate is <= xi (parents without candidates share an offset with the next): a 4-ary search over
+            // the non-decreasing offsets, three dependent LDS round trips instead of a binary search's six
+            int lo;
+            { const int a = poff[16], b = poff[32], c = poff[48]; lo = c <= xi ? 48 : (b <= xi ? 32 : (a <= xi ? 16 : 0)); }
+            { const int a = poff[lo + 4], b = poff[lo + 8], c = poff[lo + 12]; lo += c <= xi ? 12 : (b <= xi ? 8 : (a <= xi ? 4 : 0)); }
+            { const int a = poff[lo + 1], b = poff[lo + 2], c = poff[lo + 3]; lo += c <= xi ? 3 : (b <= xi ? 2 : (a <= xi ? 1 : 0)); }
+            const int64_t c = valid ? pc0[lo] + (xi - poff[lo]) : 0;
+            v_r[slot] = g.pair_tgt[c]; f_r[slot] = g.pair_first_rel[c]; lo_r[slot] = lo;
+        };
 #pragma unroll
-            for (int step = 32; step > 0; step >>= 1) if (lo + step < 64 && poff[lo + step] <= xi) lo += step;
-            const int64_t c = pc0[lo] + (xi - poff[lo]);
-            const int64_t v = valid ? g.pair_tgt[c] : 0;
-            const uint32_t bit = 1u << (v & 31);
-            const bool unseen = valid && !(seen[v >> 5] & bit);
-            unsigned long long peers = __ballot(unseen);                 // unseen lanes with the same target: the lowest one is the first visit
-            for (int bb = 0; bb < vbits; ++bb) {
-                const bool on = (v >> bb) & 1;
-                const unsigned long long m = __ballot(unseen && on);
-                peers &= on ? m : ~m;
+        for (int d = 0; d < kChunks; ++d) request(d, 64 * d);
+        for (int x0 = 0; x0 < T && count < limit; x0 += 64 * kChunks) {  // wave-uniform
+#pragma unroll
+            for (int d = 0; d < kChunks; ++d) {
+                __builtin_amdgcn_sched_barrier(0);                       // a chunk's wait stays in front of that chunk
+                const int xi = x0 + 64 * d + lane;
+                const bool valid = xi < T && count < limit;
+                const int64_t v = valid ? v_r[d] : 0, fr = f_r[d];
+                const int lo = lo_r[d];
+                const uint32_t bit = 1u << (v & 31);
+                const bool unseen = valid && !(seen[v >> 5] & bit);
+                // mark; the lane whose atomic found the bit clear is A first visit of its target.  It is THE first visit (the lowest lane, the
+                // BFS's order) unless two unseen lanes of this chunk carry the same target — then fewer lanes won than were unseen, and the
+                // equal-value peers are found through ballots over the value's bits (rare: a target is unseen once)
+                bool fresh = unseen && !(atomicOr(&seen[v >> 5], unseen ? bit : 0u) & bit);
+                const unsigned long long un = __ballot(unseen);
+                if (__popcll(un) != __popcll(__ballot(fresh))) {         // wave-uniform
+                    unsigned long long peers = un;
+                    for (int bb = 0; bb < vbits; ++bb) {
+                        const bool on = (v >> bb) & 1;
+                        const unsigned long long m = __ballot(unseen && on);
+                        peers &= on ? m : ~m;
+                    }
+                    fresh = unseen && (peers & lt) == 0;
+                }
+                const uint64_t m = __ballot(fresh);
+                const int before = __popcll(m & lt);
+                if (WRITE && fresh && count + before < limit) {
+                    int64_t* q = quads + 4 * (base + count + before);
+                    q[0] = s; q[1] = pr1[lo]; q[2] = fr; q[3] = v;
+                }
+                count += __popcll(m);
+                request(d, x0 + 64 * (d + kChunks));                     // behind the slot's last use: no copies of the ring (they would wait for the loads)
             }
-            const bool fresh = unseen && (peers & lt) == 0;
-            if (fresh) atomicOr(&seen[v >> 5], bit);
-            const uint64_t m = __ballot(fresh);
-            const int before = __popcll(m & lt);
-            if (WRITE && fresh && count + before < limit) {
-                int64_t* q = quads + 4 * (base + count + before);
-                q[0] = s; q[1] = pr1[lo]; q[2] = g.pair_first_rel[c]; q[3] = v;
-            }
-            count += __popcll(m);
         }
     }
     if (WRITE) return;

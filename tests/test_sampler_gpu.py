@@ -41,7 +41,7 @@ def test_sampler_golden(name, impl):
 
 
 @pytest.mark.parametrize("Ne,Tn,n_rel,B,seed", [(500, 6000, 20, 128, 5), (3000, 9000, 237, 128, 6), (40, 2000, 3, 40, 7), (64, 0, 4, 8, 8),
-                                                (2000, 60000, 50, 700, 9)])
+                                                (2000, 60000, 50, 700, 9), (20011, 30000, 11, 256, 10)])   # the last: more entities than one pass of the mark compaction covers
 def test_sampler_vs_oracle_random(Ne, Tn, n_rel, B, seed, impl):
     """Dense, sparse, tiny-and-saturated and empty graphs; batch entities in random order (as the reference iterates a shuffled list)."""
     from recon_amd.sampler import KGNeighbourSampler
