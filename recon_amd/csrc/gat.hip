@@ -598,7 +598,7 @@ namespace {
 // flight = 32 took 75 - 105 us per call whatever the width, and 100 k slots filled only 98 workgroups)
 constexpr int kSL = 128;
 template <int VEC>
-__global__ void __launch_bounds__(256) k_rowsum_walk(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ dst,
+__global__ void __launch_bounds__(256) k_rowsum_walk(const int32_t* __restrict__ dst,
                                                      const int32_t* __restrict__ eid, const float* __restrict__ w, int32_t E,
                                                      int32_t C, float* __restrict__ out, float* __restrict__ carry, int32_t row_mod) {
     const int lane = threadIdx.x & 63;
@@ -612,11 +612,18 @@ __global__ void __launch_bounds__(256) k_rowsum_walk(const int32_t* __restrict__
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
     int cur = dst[k0];
-    auto flush = [&](int node) {
-        const int b = rowptr[node], e = rowptr[node + 1];
+    // Which run of equal destinations crosses the range's ends follows from the two slots just outside it — requested here, under the first
+    // rows' round trip.  (Looking the run's row up in rowptr at every change of destination was a dependent round trip per run: at the
+    // stage-A graphs' 2-20 slots per row, most of a wave's time.)
+    const bool left_cross = k0 > 0 && dst[k0 - 1] == cur;
+    const bool right_cross = k1 < E && dst[k1] == dst[k1 - 1];
+    bool first = true;
+    auto flush = [&](int node, bool last) {
         float* target;
-        if (b >= k0 && e <= k1) target = out + static_cast<int64_t>(node) * C;                        // complete here
-        else target = carry + (static_cast<int64_t>(wv) * 2 + ((b < k0) ? 0 : 1)) * C;               // crosses the range
+        if (first && left_cross) target = carry + (static_cast<int64_t>(wv) * 2 + 0) * C;            // continues from the left
+        else if (last && right_cross) target = carry + (static_cast<int64_t>(wv) * 2 + 1) * C;       // continues to the right only
+        else target = out + static_cast<int64_t>(node) * C;                                          // complete here
+        first = false;
         if (ca) store_vec<VEC>(target + c, acc);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
@@ -640,13 +647,13 @@ __global__ void __launch_bounds__(256) k_rowsum_walk(const int32_t* __restrict__
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (k + u < k1) {
-                if (d[u] != cur) { flush(cur); cur = d[u]; }        // wave-uniform
+                if (d[u] != cur) { flush(cur, false); cur = d[u]; } // wave-uniform
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) acc[v] += t[u][v];
             }
         }
     }
-    flush(cur);
+    flush(cur, true);
 }
 template <int VEC>
 __global__ void __launch_bounds__(256) k_rowsum_fix(const int32_t* __restrict__ rowptr, int32_t N, int32_t C,
@@ -722,13 +729,13 @@ extern "C" int recon_spmm_rowsum_mod_fwd(const recon_graph* g, const float* edge
     dim3 grid(static_cast<unsigned>(ceil_div64(nw, 4)), static_cast<unsigned>(ceil_div64(C, 64 * vec)));
     dim3 fgrid(static_cast<unsigned>(ceil_div64(g->N, 4)));
     if (vec == 4) {
-        hipLaunchKernelGGL((k_rowsum_walk<4>), grid, dim3(256), 0, st, g->rowptr_dst, g->dst, g->eid, edge_w, g->E, C, out, workspace, row_mod);
+        hipLaunchKernelGGL((k_rowsum_walk<4>), grid, dim3(256), 0, st, g->dst, g->eid, edge_w, g->E, C, out, workspace, row_mod);
         hipLaunchKernelGGL((k_rowsum_fix<4>), fgrid, dim3(256), 0, st, g->rowptr_dst, g->N, C, workspace, out);
     } else if (vec == 2) {
-        hipLaunchKernelGGL((k_rowsum_walk<2>), grid, dim3(256), 0, st, g->rowptr_dst, g->dst, g->eid, edge_w, g->E, C, out, workspace, row_mod);
+        hipLaunchKernelGGL((k_rowsum_walk<2>), grid, dim3(256), 0, st, g->dst, g->eid, edge_w, g->E, C, out, workspace, row_mod);
         hipLaunchKernelGGL((k_rowsum_fix<2>), fgrid, dim3(256), 0, st, g->rowptr_dst, g->N, C, workspace, out);
     } else {
-        hipLaunchKernelGGL((k_rowsum_walk<1>), grid, dim3(256), 0, st, g->rowptr_dst, g->dst, g->eid, edge_w, g->E, C, out, workspace, row_mod);
+        hipLaunchKernelGGL((k_rowsum_walk<1>), grid, dim3(256), 0, st, g->dst, g->eid, edge_w, g->E, C, out, workspace, row_mod);
         hipLaunchKernelGGL((k_rowsum_fix<1>), fgrid, dim3(256), 0, st, g->rowptr_dst, g->N, C, workspace, out);
     }
     RECON_CHECK_LAUNCH();
