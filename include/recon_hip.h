@@ -139,6 +139,11 @@ int recon_spmm_rowsum_mod_fwd(const recon_graph* g, const float* edge_w, int32_t
                               float* workspace, recon_stream_t stream);
 int recon_spmm_rowsum_bwd(const int64_t* edge_dst /*[E]*/, int64_t E, const float* grad_out /*[N,out]*/,
                           int32_t out_features, float* grad_edge_w /*[E,out]*/, recon_stream_t stream);
+/* out[k,:] = table[idx2[k,0],:] + table[idx2[k,1],:] — the n-hop relation embedding `relation_embed[edge_type_nhop[:, 0]] +
+ * relation_embed[edge_type_nhop[:, 1]]` (GAT/models.py:64-65, 80-81) in one pass; the indices are the caller's to validate
+ * (0 <= idx2 < table rows); its gradient is recon_spmm_rowsum_mod_fwd over the keys (idx2[:,0] | idx2[:,1]) */
+int recon_gather_rows_pair_fwd(const float* table /*[rows,width]*/, const int64_t* idx2 /*[E,2]*/, int64_t E, int32_t width,
+                               float* out /*[E,width]*/, recon_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * G4  SpGraphAttentionLayer.forward for H heads that share inputs (GAT/layers.py:111-178; the

@@ -151,6 +151,7 @@ SYMBOLS = [
     ("recon_spmm_rowsum_workspace_floats", C.c_size_t, [C.c_int32, C.c_int32]),
     ("recon_spmm_rowsum_fwd", C.c_int, [C.POINTER(ReconGraph), c_f32p, C.c_int32, c_f32p, c_f32p, C.c_void_p]),
     ("recon_spmm_rowsum_mod_fwd", C.c_int, [C.POINTER(ReconGraph), c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_void_p]),
+    ("recon_gather_rows_pair_fwd", C.c_int, [c_f32p, c_i64p, C.c_int64, C.c_int32, c_f32p, C.c_void_p]),
     ("recon_spmm_rowsum_bwd", C.c_int, [c_i64p, C.c_int64, c_f32p, C.c_int32, c_f32p, C.c_void_p]),
     ("recon_gat_fwd", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatFwdArgs), C.c_void_p]),
     ("recon_gat_project", C.c_int, [C.POINTER(ReconGraph), C.POINTER(GatFwdArgs), C.c_void_p]),

@@ -701,7 +701,41 @@ __global__ void k_spmm_rowsum_bwd(const int64_t* __restrict__ dst, int64_t E, in
     if (idx >= E * C) return;
     gw[idx] = gout[dst[idx / C] * C + idx % C];
 }
+// table[i0] + table[i1] per output row: one thread per VEC columns of a row (the two index words of a row are one 16-byte line for its threads)
+template <int VEC>
+__global__ void __launch_bounds__(256) k_gather_rows_pair(const float* __restrict__ table, const int64_t* __restrict__ idx2, int64_t E, int32_t C,
+                                                           float* __restrict__ out) {
+    const int cpr = C / VEC;
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= E * cpr) return;
+    const int64_t r = t / cpr;
+    const int c = static_cast<int>(t - r * cpr) * VEC;
+    const int64_t i0 = idx2[2 * r], i1 = idx2[2 * r + 1];
+    float x[VEC], y[VEC];
+    load_vec<VEC>(x, table + i0 * C + c);
+    load_vec<VEC>(y, table + i1 * C + c);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) x[v] += y[v];
+    store_vec<VEC>(out + r * C + c, x);
+}
 }  // namespace
+
+extern "C" int recon_gather_rows_pair_fwd(const float* table, const int64_t* idx2, int64_t E, int32_t width, float* out, recon_stream_t stream) {
+    if (E < 0 || width <= 0) return RECON_ERR_INVALID;
+    if (E == 0) return RECON_OK;
+    if (!table || !idx2 || !out) return RECON_ERR_INVALID;
+    hipStream_t st = as_stream(stream);
+    const int vec = (width % 4 == 0 && al(table, 16) && al(out, 16)) ? 4 : ((width % 2 == 0 && al(table, 8) && al(out, 8)) ? 2 : 1);
+    const int64_t threads = E * (width / vec);
+    const int64_t blocks = ceil_div64(threads, 256);
+    if (blocks > 0x7fffffffLL) return RECON_ERR_UNSUPPORTED;
+    const dim3 grid(static_cast<unsigned>(blocks));
+    if (vec == 4) hipLaunchKernelGGL((k_gather_rows_pair<4>), grid, dim3(256), 0, st, table, idx2, E, width, out);
+    else if (vec == 2) hipLaunchKernelGGL((k_gather_rows_pair<2>), grid, dim3(256), 0, st, table, idx2, E, width, out);
+    else hipLaunchKernelGGL((k_gather_rows_pair<1>), grid, dim3(256), 0, st, table, idx2, E, width, out);
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
 
 extern "C" size_t recon_spmm_rowsum_workspace_floats(int32_t E, int32_t out_features) {
     return static_cast<size_t>(ceil_div64(E > 0 ? E : 1, kSL)) * 2 * static_cast<size_t>(out_features > 0 ? out_features : 1);

@@ -196,7 +196,12 @@ class _GatherRowsPair(torch.autograd.Function):
     def forward(ctx, table, idx2):
         _require_gpu_f32(table)
         ctx.n_rows, ctx.idx2 = table.shape[0], idx2
-        return torch.nn.functional.embedding_bag(idx2, table, mode="sum")
+        table = table.contiguous()
+        out = torch.empty(idx2.shape[0], table.shape[1], dtype=torch.float32, device=table.device)
+        with _lib.on_device(table.device):
+            _lib.check(_lib.lib().recon_gather_rows_pair_fwd(table.data_ptr(), idx2.data_ptr(), idx2.shape[0], table.shape[1], out.data_ptr(),
+                                                             _lib.current_stream()), "recon_gather_rows_pair_fwd")
+        return out
 
     @staticmethod
     def backward(ctx, grad):
@@ -235,7 +240,7 @@ def gather_rows_pair(table, idx2):
         lo, hi = torch.aminmax(idx2)
         if int(lo) < 0 or int(hi) >= table.shape[0]:
             raise IndexError("recon_amd: row index out of range: [%d, %d] into a table of %d rows" % (int(lo), int(hi), table.shape[0]))
-    return _GatherRowsPair.apply(table, idx2.contiguous())
+    return _GatherRowsPair.apply(table, idx2.long().contiguous())
 
 
 _VALIDATE_PAIR = True

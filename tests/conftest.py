@@ -42,7 +42,7 @@ GEMM_FAMILIES = ("2", "1", "0")     # values of recon_amd.gat_layers._GEMM_BX3 (
 _NO_FAMILY = ("test_graph_build", "test_hub_tables", "test_small_mm", "test_thin_weight", "test_index_range", "test_gcn_beyond", "test_propagation_beyond", "test_batches_above", "test_fuzz", "test_sgemm", "test_spmm", "test_full_size_cfg2_split_precision_vs_fp32_gemm",
               "test_block_adjacency", "test_propagation", "test_start_entity", "test_gpgnn", "test_phased_backward",
               "test_sampler_golden", "test_sampler_vs", "test_sampler_rejects", "test_gcn_bf16", "test_cfg3b", "test_cfg3a_bf16",
-              "test_propagate_blocks", "test_gcn_stack", "test_wide_backward")       # propagation / bf16 stack kernels: no GEMM family involved
+              "test_propagate_blocks", "test_gcn_stack", "test_wide_backward", "test_gather_rows_pair")       # propagation / bf16 stack kernels: no GEMM family involved
 
 
 def pytest_generate_tests(metafunc):

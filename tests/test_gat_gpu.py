@@ -1273,3 +1273,28 @@ def test_device_nan_flag_is_raised_without_a_round_trip():
             assert nan_raised(d), path + ": NaN parameter"
         finally:
             gat_layers._GAT_PATH = saved
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,width,E", [(237, 50, 25849), (237, 100, 4001), (64, 37, 513), (5, 3, 7), (9, 200, 0)])
+def test_gather_rows_pair_is_the_sum_of_two_gathers(rows, width, E):
+    """relation_embed[t[:, 0]] + relation_embed[t[:, 1]] (GAT/models.py:64-65, 80-81): forward bit-equal to the two indexings added, the
+    table gradient equal to index_add over both columns (float64 reference); widths for each vector form, int32 indices, no rows."""
+    from recon_amd import gat_layers
+    d = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(rows + width)
+    table = torch.randn(rows, width, generator=gen).to(d).requires_grad_(True)
+    idx = torch.randint(0, rows, (E, 2), generator=gen).to(d)
+    out = gat_layers.gather_rows_pair(table, idx)
+    assert out.shape == (E, width)
+    assert torch.equal(out, table.detach()[idx[:, 0]] + table.detach()[idx[:, 1]])
+    assert torch.equal(gat_layers.gather_rows_pair(table.detach(), idx.int()), out)
+    G = torch.randn(E, width, generator=gen).to(d)
+    out.backward(G)
+    ref = torch.zeros(rows, width, dtype=torch.float64, device=d)
+    ref.index_add_(0, idx[:, 0], G.double()); ref.index_add_(0, idx[:, 1], G.double())
+    assert torch.allclose(table.grad.double(), ref, rtol=1e-5, atol=1e-5)
+    with pytest.raises(IndexError):
+        bad = idx.clone() if E else torch.zeros(1, 2, dtype=torch.long, device=d)
+        bad[0, 1] = rows
+        gat_layers.gather_rows_pair(table.detach(), bad)
