@@ -120,16 +120,45 @@ __global__ void __launch_bounds__(kThreads) k_radix_scatter(const int32_t* __res
     __shared__ int32_t dig[256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 4 * 256; i += kThreads) (&wcount[0][0])[i] = 0;
-    __syncthreads();
+    // unscanned: digit t's counts of every tile are requested here, together with the items — they depend on the previous launch only, and
+    // behind the ranking they were a round trip of their own in every pass
+    int32_t tot = 0, before = 0;
+    if constexpr (!SCANNED) {
+        const int32_t* row = blockhist_scanned + threadIdx.x * nblocks;
+        const int me = static_cast<int>(blockIdx.x);
+        auto take = [&](int b, int32_t c) { if (b < nblocks) { tot += c; before += b < me ? c : 0; } };
+        if ((nblocks & 3) == 0 && !(reinterpret_cast<uintptr_t>(blockhist_scanned) & 15)) {          // sixteen counts per round trip
+            for (int b0 = 0; b0 < nblocks; b0 += 16) {
+                int4 c[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) c[u] = *reinterpret_cast<const int4*>(row + min(b0 + 4 * u, nblocks - 4));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { take(b0 + 4 * u, c[u].x); take(b0 + 4 * u + 1, c[u].y); take(b0 + 4 * u + 2, c[u].z); take(b0 + 4 * u + 3, c[u].w); }
+            }
+        } else {
+            for (int b0 = 0; b0 < nblocks; b0 += 8) {
+                int32_t c[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) c[u] = row[min(b0 + u, nblocks - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) take(b0 + u, c[u]);
+            }
+        }
+    }
     const int base = blockIdx.x * kTile + w * 256;
     int32_t key[4], val[4], rank[4];
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
+    for (int j = 0; j < 4; ++j) {                                        // (in front of the barrier: it waits for every request made so far)
+        const int i = base + j * 64 + lane;
+        key[j] = i < n ? keys_in[i] : 0;
+        val[j] = i < n ? vals_in[i] : 0;
+    }
+    __syncthreads();
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int i = base + j * 64 + lane;
         const bool valid = i < n;
-        key[j] = valid ? keys_in[i] : 0;
-        val[j] = valid ? vals_in[i] : 0;
         const int digit = (key[j] >> shift) & 255;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -152,18 +181,15 @@ __global__ void __launch_bounds__(kThreads) k_radix_scatter(const int32_t* __res
         if constexpr (SCANNED) {
             run = blockhist_scanned[t * nblocks + blockIdx.x];
         } else {
-            int32_t tot = 0, before = 0;
-            const int32_t* row = blockhist_scanned + t * nblocks;
-            for (int b = 0; b < nblocks; ++b) { const int32_t c = row[b]; tot += c; before += b < static_cast<int>(blockIdx.x) ? c : 0; }
-            dig[t] = tot;
+            int32_t x = tot;                                             // inclusive scan over the digits: within the wave, then over the four waves' sums
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_up(x, off, 64); if (lane >= off) x += o; }
+            if (lane == 63) dig[w] = x;
             __syncthreads();
-            for (int off = 1; off < 256; off <<= 1) {                    // Hillis-Steele inclusive scan over the digits
-                const int32_t v = (t >= off) ? dig[t - off] : 0;
-                __syncthreads();
-                dig[t] += v;
-                __syncthreads();
-            }
-            run = dig[t] - tot + before;
+            int32_t wbase = 0;
+#pragma unroll
+            for (int ww = 0; ww < 3; ++ww) wbase += ww < w ? dig[ww] : 0;
+            run = wbase + x - tot + before;
         }
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) { int32_t c = wcount[ww][t]; wcount[ww][t] = run; run += c; }
