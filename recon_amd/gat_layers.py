@@ -604,9 +604,19 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         elif keep_max is None:                                  # explicit factors without a bound: one host read (tests)
             keep_max = float(keep.max()) if aux is not None and keep.numel() else 1.0
         args = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split, aux, keep_max, idx_slot, io16)
+        # a graph built a moment ago has not read its hub-table sizes back yet (graph.GraphCSR.resolve: a host synchronisation).  The score
+        # stage needs none of them: it goes out first, so that the device has work behind the build while the host waits and launches again
+        early = graph.pending and graph.build_stream == _lib.current_stream()
+        if early:
+            with _on_device(dev):
+                _lib.check(L.recon_gat_atp_scores(C.byref(graph.raw_struct()), C.byref(args), _lib.current_stream()), "recon_gat_atp_scores")
         gstruct, _hub_keep = graph.call_struct(F_, R, H)
         with _on_device(dev):
-            _lib.check(L.recon_gat_atp_fwd(C.byref(gstruct), C.byref(args), _lib.current_stream()), "recon_gat_atp_fwd")
+            if early:
+                _lib.check(L.recon_gat_atp_aggregate(C.byref(gstruct), C.byref(args), _lib.current_stream()), "recon_gat_atp_aggregate")
+                _lib.check(L.recon_gat_atp_project(C.byref(gstruct), C.byref(args), _lib.current_stream()), "recon_gat_atp_project")
+            else:
+                _lib.check(L.recon_gat_atp_fwd(C.byref(gstruct), C.byref(args), _lib.current_stream()), "recon_gat_atp_fwd")
         if need_grad:
             ctx.save_for_backward(x, ee, a, a2, keep, out, ws)
             ctx.ptrs = (u, c_node, c_rel, V, sigma, Z, Zk, a_split, aux)

@@ -56,6 +56,7 @@ def _bad_flag(dev):
     return f
 
 
+DEFER_HUB_READ = True   # the host read of a fresh graph's hub-table sizes (and of its id-range flag) waits until something needs them: see GraphCSR.resolve
 HUB_CHUNK = 64          # RECON_HUB_CHUNK (include/recon_hip.h); 0 switches the splitting of long destination rows off (tests compare both)
 
 
@@ -105,50 +106,95 @@ class GraphCSR:
             off += room
         base = self._buf.data_ptr()
         ptr = lambda name: base + 4 * self._parts[name][0] if name in self._parts else None
-        self.c = _lib.ReconGraph(self.N, self.E, ptr("rowptr_dst"), ptr("eid"), ptr("src"), ptr("dst"), ptr("rowptr_src"), ptr("slot_by_src"))
+        self._c = _lib.ReconGraph(self.N, self.E, ptr("rowptr_dst"), ptr("eid"), ptr("src"), ptr("dst"), ptr("rowptr_src"), ptr("slot_by_src"))
         ws_ptr = base + 4 * total
         bad = _bad_flag(dev) if in_build else None
         hubs = HUB_CHUNK > 0 and E > HUB_CHUNK and not rows_only            # the hub-table sizes are counted by the build's last launch
+        stream = _lib.current_stream()
         with _lib.on_device(dev):
             if hubs:
-                rc = L.recon_graph_build_counted(edge.data_ptr(), edge.data_ptr() + 8 * E, C.byref(self.c), ws_ptr, ws_bytes, _lib.ptr(bad), HUB_CHUNK,
-                                                 _lib.current_stream())
+                rc = L.recon_graph_build_counted(edge.data_ptr(), edge.data_ptr() + 8 * E, C.byref(self._c), ws_ptr, ws_bytes, _lib.ptr(bad), HUB_CHUNK, stream)
             else:
-                rc = L.recon_graph_build_checked(edge.data_ptr(), edge.data_ptr() + 8 * E, C.byref(self.c), ws_ptr,
-                                                 ws_bytes, _lib.ptr(bad), _lib.current_stream())
+                rc = L.recon_graph_build_checked(edge.data_ptr(), edge.data_ptr() + 8 * E, C.byref(self._c), ws_ptr, ws_bytes, _lib.ptr(bad), stream)
         _lib.check(rc, "recon_graph_build")
         self._eid_long = None
         self._slot_idx = {}
-        # hub rows (include/recon_hip.h): destinations with more than HUB_CHUNK in-edges are cut into pieces, one wavefront each
+        # hub rows (include/recon_hip.h): destinations with more than HUB_CHUNK in-edges are cut into pieces, one wavefront each.  Their
+        # number comes back from the device — a host synchronisation, which with a fresh graph per iteration (the reference's regime) drains
+        # the whole queue once per step and leaves the device idle until the host has launched again.  So the read waits (resolve()) until
+        # something needs the sizes: the attention layer's score stage does not, and runs first (gat_layers._GATHeadsATPFunction).
+        self._error = None
+        self._pending = (ws_ptr, bad, stream) if hubs else None
+        if not hubs:
+            self.n_hub = self.n_piece = self.n_hub_src = self.n_piece_src = 0
+        elif not DEFER_HUB_READ:
+            self.resolve()
+
+    pending = property(lambda self: self._pending is not None)
+    build_stream = property(lambda self: self._pending[2] if self._pending is not None else None)
+
+    def raw_struct(self):
+        """The `recon_graph` without hub tables, valid for work ordered behind the build on ITS stream that reads only the index arrays
+        (recon_gat_atp_scores) — everything else goes through `.c` / call_struct(), which resolve first."""
+        return self._c
+
+    @property
+    def c(self):
+        self.resolve()
+        return self._c
+
+    def __getattr__(self, name):
+        # the hub tables and their sizes exist once the counts have been read
+        if name in ("n_hub", "n_piece", "n_hub_src", "n_piece_src", "hub_node", "hub_ptr", "piece", "hub_node_src", "hub_ptr_src", "piece_src") \
+                and self.__dict__.get("_pending") is not None:
+            self.resolve()
+            if name in self.__dict__:
+                return self.__dict__[name]
+        raise AttributeError(name)
+
+    def resolve(self):
+        """Read the hub-table sizes (and the build's id-range flag) back and fill the tables: one host synchronisation on the build's stream."""
+        if self._error is not None:
+            raise IndexError(self._error)
+        if self._pending is None:
+            return
+        ws_ptr, bad, stream = self._pending
+        L, dev = _lib.lib(), self.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        cnt = (C.c_int32 * 4)()
+        bad_host = C.c_int32(0)
+        with _lib.on_device(dev):
+            _lib.check(L.recon_graph_hubs_read(C.byref(self._c), ws_ptr, cnt, _lib.ptr(bad), C.byref(bad_host) if bad is not None else None, stream),
+                       "recon_graph_hubs_read")
+        self._pending = None
         self.n_hub = self.n_piece = self.n_hub_src = self.n_piece_src = 0
-        if hubs:
-            cnt = (C.c_int32 * 4)()
-            bad_host = C.c_int32(0)
+        if bad_host.value:
+            # the flag is shared by the device's builds: it is this graph's if its own ids are out of range (then hand it back clear)
+            lo, hi = (int(v) for v in torch.aminmax(self.edge))
+            if lo < 0 or hi >= self.N:
+                bad.zero_()
+                self._error = "recon_amd: edge index out of range: ids span [%d, %d] but input has %d rows" % (lo, hi, self.N)
+                raise IndexError(self._error)
+        if cnt[0] > 0 or cnt[2] > 0:
+            self.n_hub, self.n_piece, self.n_hub_src, self.n_piece_src = (int(v) for v in cnt)
+            self._c.hub_chunk = HUB_CHUNK
+            if self.n_hub:
+                self.hub_node = torch.empty(self.n_hub, **i32)
+                self.hub_ptr = torch.empty(self.n_hub + 1, **i32)
+                self.piece = torch.empty(self.n_piece, 4, **i32)
+                self._c.n_hub, self._c.n_piece = self.n_hub, self.n_piece
+                self._c.hub_node, self._c.hub_ptr, self._c.piece = self.hub_node.data_ptr(), self.hub_ptr.data_ptr(), self.piece.data_ptr()
+            if self.n_hub_src:
+                self.hub_node_src = torch.empty(self.n_hub_src, **i32)
+                self.hub_ptr_src = torch.empty(self.n_hub_src + 1, **i32)
+                self.piece_src = torch.empty(self.n_piece_src, 4, **i32)
+                self._c.n_hub_src, self._c.n_piece_src = self.n_hub_src, self.n_piece_src
+                self._c.hub_node_src, self._c.hub_ptr_src, self._c.piece_src = (self.hub_node_src.data_ptr(), self.hub_ptr_src.data_ptr(),
+                                                                                self.piece_src.data_ptr())
             with _lib.on_device(dev):
-                _lib.check(L.recon_graph_hubs_read(C.byref(self.c), ws_ptr, cnt, _lib.ptr(bad), C.byref(bad_host) if bad is not None else None,
-                                                   _lib.current_stream()), "recon_graph_hubs_read")
-            if bad_host.value:
-                bad.zero_()                                             # the flag is shared by the device's builds: hand it back clear
-                lo, hi = (int(v) for v in torch.aminmax(edge))
-                raise IndexError("recon_amd: edge index out of range: ids span [%d, %d] but input has %d rows" % (lo, hi, N))
-            if cnt[0] > 0 or cnt[2] > 0:
-                self.n_hub, self.n_piece, self.n_hub_src, self.n_piece_src = (int(v) for v in cnt)
-                self.c.hub_chunk = HUB_CHUNK
-                if self.n_hub:
-                    self.hub_node = torch.empty(self.n_hub, **i32)
-                    self.hub_ptr = torch.empty(self.n_hub + 1, **i32)
-                    self.piece = torch.empty(self.n_piece, 4, **i32)
-                    self.c.n_hub, self.c.n_piece = self.n_hub, self.n_piece
-                    self.c.hub_node, self.c.hub_ptr, self.c.piece = self.hub_node.data_ptr(), self.hub_ptr.data_ptr(), self.piece.data_ptr()
-                if self.n_hub_src:
-                    self.hub_node_src = torch.empty(self.n_hub_src, **i32)
-                    self.hub_ptr_src = torch.empty(self.n_hub_src + 1, **i32)
-                    self.piece_src = torch.empty(self.n_piece_src, 4, **i32)
-                    self.c.n_hub_src, self.c.n_piece_src = self.n_hub_src, self.n_piece_src
-                    self.c.hub_node_src, self.c.hub_ptr_src, self.c.piece_src = (self.hub_node_src.data_ptr(), self.hub_ptr_src.data_ptr(),
-                                                                                 self.piece_src.data_ptr())
-                with _lib.on_device(dev):
-                    _lib.check(L.recon_graph_hubs_fill(C.byref(self.c), _lib.current_stream()), "recon_graph_hubs_fill")
+                _lib.check(L.recon_graph_hubs_fill(C.byref(self._c), stream), "recon_graph_hubs_fill")
+                if _lib.current_stream() != stream:                       # resolved from another stream than the build's: its work must see the tables
+                    torch.cuda.synchronize(dev)
 
     def _part(self, name):
         """View of one index array inside the graph's single allocation (None where a destination-only graph has none)."""

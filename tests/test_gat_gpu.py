@@ -71,6 +71,56 @@ def test_graph_build_rejects_out_of_range_ids():
     GraphCSR(edge, 6)
 
 
+def test_graph_build_flags_out_of_range_ids_found_by_the_build():
+    """More than HUB_CHUNK edges: the id check rides in the build and its flag comes back with the hub-table sizes — when something first
+    needs the graph (GraphCSR.resolve), or at construction with the deferral off.  A clean graph between two bad ones is not blamed."""
+    from recon_amd import graph as G
+    gen = torch.Generator().manual_seed(5)
+    N, E = 50, 300
+    good = torch.randint(0, N, (2, E), generator=gen).to(dev())
+    bad = good.clone()
+    bad[1, 137] = N
+    g_bad = G.GraphCSR(bad, N)
+    g_ok = G.GraphCSR(good.clone(), N)
+    assert g_bad.pending and g_ok.pending
+    assert g_ok.n_hub >= 0 and not g_ok.pending                       # resolves; the shared flag is up, but these ids are fine
+    for _ in range(2):                                                # the error is the graph's: every use raises it
+        with pytest.raises(IndexError):
+            g_bad.c
+    assert G.GraphCSR(good.clone(), N).c.E == E
+    G.DEFER_HUB_READ = False
+    try:
+        with pytest.raises(IndexError):
+            G.GraphCSR(bad.clone(), N)
+        assert not G.GraphCSR(good.clone(), N).pending
+    finally:
+        G.DEFER_HUB_READ = True
+    # through the layer: the reference fails inside forward() too (index out of range)
+    from recon_amd import gat_layers
+    x = torch.randn(N, 8, generator=gen).to(dev()); ee = torch.randn(E, 4, generator=gen).to(dev())
+    a = torch.randn(2, 6, 20, generator=gen).to(dev()); a2 = torch.randn(2, 6, generator=gen).to(dev())
+    with pytest.raises(IndexError):
+        gat_layers.gat_heads(x, ee, a, a2, G.prepare_graph(bad.clone(), None, N), None, 0.2, True)
+    out = gat_layers.gat_heads(x, ee, a, a2, G.prepare_graph(good.clone(), None, N), None, 0.2, True)
+    assert torch.isfinite(out).all()
+
+
+def test_graph_deferred_hub_read_gives_the_same_layer_output():
+    """gat_heads on a graph whose hub sizes are still on the device (score stage first, then the read) against the same call on the resolved graph."""
+    from recon_amd import graph as G, gat_layers
+    gen = torch.Generator().manual_seed(6)
+    N, E = 40, 2000                                                    # in-degrees ~50 +- : some rows beyond HUB_CHUNK = 64
+    edge = torch.stack((torch.randint(0, 8, (E,), generator=gen) * 5, torch.randint(0, N, (E,), generator=gen))).to(dev())
+    x = torch.randn(N, 12, generator=gen).to(dev()); ee = torch.randn(E, 8, generator=gen).to(dev())
+    a = torch.randn(3, 5, 32, generator=gen).to(dev()); a2 = torch.randn(3, 5, generator=gen).to(dev())
+    g1 = G.GraphCSR(edge, N)
+    assert g1.pending
+    o1 = gat_layers.gat_heads(x, ee, a, a2, g1, None, 0.2, True)
+    assert not g1.pending and g1.n_hub > 0
+    o2 = gat_layers.gat_heads(x, ee, a, a2, g1, None, 0.2, True)
+    assert torch.equal(o1, o2)
+
+
 def test_graph_cache_distinguishes_strided_views():
     """Two views of one storage with equal data_ptr and shape but different strides are different edge lists."""
     from recon_amd.graph import prepare_graph
