@@ -222,9 +222,11 @@ __global__ void k_rowptr_lower_bound(const int32_t* __restrict__ sorted_keys, in
 // counts in a launch of its own.  A thread's upper neighbour's result comes through LDS (the block's last thread searches once more);
 // integer atomics into zeroed words: the same counts on every run.
 __global__ void __launch_bounds__(256) k_rowptr_lower_bound_count(const int32_t* __restrict__ sorted_keys, int32_t E, int32_t N, int32_t* __restrict__ rowptr,
-                                                                  const int32_t* __restrict__ rowptr_other, int32_t chunk, int32_t* __restrict__ counts) {
+                                                                  const int32_t* __restrict__ rowptr_other, int32_t chunk, int32_t* __restrict__ counts,
+                                                                  const int32_t* __restrict__ bad) {
     __shared__ int32_t lb[257];
     const int t = threadIdx.x, r = blockIdx.x * 256 + t;
+    if (blockIdx.x == 0 && t == 0) counts[4] = bad ? *bad : 0;           // the build's id-range flag (set by earlier launches) travels with the counts: one copy back
     auto search = [&](int key) { int lo = 0, hi = E; while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] < key) lo = mid + 1; else hi = mid; } return lo; };
     const int mine = r <= N ? search(r) : E;
     lb[t] = mine;
@@ -286,6 +288,7 @@ __global__ void __launch_bounds__(1024) k_hub_scan(const int32_t* __restrict__ r
                                                    int32_t* __restrict__ hub_node, int32_t* __restrict__ hub_ptr, int4* __restrict__ piece) {
     __shared__ int32_t sh[1024], sp[1024];
     const int t = threadIdx.x;
+    if (!FILL && blockIdx.x == 0 && t == 0 && hub_ptr) counts[4] = hub_node ? *hub_node : 0;   // count form behind a build: its id-range flag rides in `hub_node` (hub_ptr: non-null marks that form)
     if (!FILL && blockIdx.x == 1) {                                      // count form, second workgroup: the other row pointer rides in `piece`
         rowptr = reinterpret_cast<const int32_t*>(piece);
         counts += 2;
@@ -556,9 +559,13 @@ extern "C" int recon_graph_hubs_read(const recon_graph* g, void* workspace, int3
     hipStream_t st = as_stream(stream);
     counts[0] = counts[1] = counts[2] = counts[3] = 0;
     if (bad_host) *bad_host = 0;
-    if (bad && hipMemcpyAsync(bad_host, bad, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return RECON_ERR_LAUNCH;
-    if (g->E > 0 && hipMemcpyAsync(counts, graph_ws_counts(workspace, g->N, g->E), 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return RECON_ERR_LAUNCH;
-    if (hipStreamSynchronize(st) != hipSuccess) return RECON_ERR_LAUNCH;
+    if (g->E > 0) {                                                      // sizes and flag in ONE copy (the build's last launch put the flag behind the sizes)
+        int32_t five[5] = {0, 0, 0, 0, 0};
+        if (hipMemcpyAsync(five, graph_ws_counts(workspace, g->N, g->E), 5 * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return RECON_ERR_LAUNCH;
+        if (hipStreamSynchronize(st) != hipSuccess) return RECON_ERR_LAUNCH;
+        for (int i = 0; i < 4; ++i) counts[i] = five[i];
+        if (bad) *bad_host = five[4];
+    } else if (hipStreamSynchronize(st) != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
 }
 static int graph_build(const int64_t* edge_dst, const int64_t* edge_src, recon_graph* g, void* workspace, size_t workspace_bytes, int32_t* bad, int32_t chunk,
@@ -596,8 +603,8 @@ static int graph_build(const int64_t* edge_dst, const int64_t* edge_src, recon_g
         else hipLaunchKernelGGL((k_graph_build_small<false>), dim3(1), dim3(1024), lds, st, edge_dst, edge_src, N, E, g->rowptr_dst, g->eid, g->src, g->dst,
                                 g->rowptr_src, g->slot_by_src, ws.kA, ws.vA, ws.kB, ws.vB, bad);
         if (chunk > 0)
-            hipLaunchKernelGGL((k_hub_scan<false>), dim3(2), dim3(1024), 0, st, g->rowptr_dst, N, chunk, graph_ws_counts(workspace, N, E), nullptr, nullptr,
-                               reinterpret_cast<int4*>(g->rowptr_src));
+            hipLaunchKernelGGL((k_hub_scan<false>), dim3(2), dim3(1024), 0, st, g->rowptr_dst, N, chunk, graph_ws_counts(workspace, N, E), bad,
+                               graph_ws_counts(workspace, N, E), reinterpret_cast<int4*>(g->rowptr_src));
         RECON_CHECK_LAUNCH();
         return RECON_OK;
     }
@@ -619,7 +626,7 @@ static int graph_build(const int64_t* edge_dst, const int64_t* edge_src, recon_g
                        ws.hist2, g->dst, g->rowptr_dst);
     rc = radix_sort_pairs(ws, E, N, &ks, &vs, st, nullptr, g->slot_by_src, true);
     if (rc != RECON_OK) return rc;
-    if (chunk > 0) hipLaunchKernelGGL(k_rowptr_lower_bound_count, nb, dim3(256), 0, st, ks, E, N, g->rowptr_src, g->rowptr_dst, chunk, graph_ws_counts(workspace, N, E));
+    if (chunk > 0) hipLaunchKernelGGL(k_rowptr_lower_bound_count, nb, dim3(256), 0, st, ks, E, N, g->rowptr_src, g->rowptr_dst, chunk, graph_ws_counts(workspace, N, E), bad);
     else hipLaunchKernelGGL(k_rowptr_lower_bound, nb, dim3(256), 0, st, ks, E, N, g->rowptr_src);
     RECON_CHECK_LAUNCH();
     return RECON_OK;
