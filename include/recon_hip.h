@@ -110,8 +110,9 @@ int recon_graph_hubs_count_checked(const recon_graph* g, int32_t chunk, void* wo
                                    recon_stream_t stream);
 /* Build + hub-table sizes in one chain: recon_graph_build_counted is recon_graph_build_checked whose last launch also counts, for rows
  * of more than `chunk` slots, the four sizes recon_graph_hubs_count would return (they stay in the workspace: one launch less per build —
- * a build is a chain of small dependent launches); recon_graph_hubs_read copies them (and the range-check flag, as above) to the host
- * with the one synchronisation of the pair.  The graph needs both views (rowptr_src set); `workspace` is the build's. */
+ * a build is a chain of small dependent launches); recon_graph_hubs_read copies them (and the range-check flag, which that last launch
+ * stores behind the sizes: `bad` given to recon_graph_hubs_read only says that *bad_host is wanted — it must be the build's) to the host in
+ * one copy, with the one synchronisation of the pair.  The graph needs both views (rowptr_src set); `workspace` is the build's. */
 int recon_graph_build_counted(const int64_t* edge_dst, const int64_t* edge_src, recon_graph* g, void* workspace, size_t workspace_bytes,
                               int32_t* bad, int32_t chunk, recon_stream_t stream);
 int recon_graph_hubs_read(const recon_graph* g, void* workspace, int32_t* counts /* host [4] */, const int32_t* bad, int32_t* bad_host,
