@@ -594,9 +594,11 @@ namespace {
 //         left | 1 = continues to the right];
 // pass 2: one wave per destination that spans several ranges adds its carries in slot order.  Fixed order,
 //         no atomics; rows without slots get their zeros here (no memset of `out` in front).
-// 128 slots per wave, sixteen rows in flight: a wave's walk is a chain of dependent round trips (8 of them now; 256 slots x 8 rows in
-// flight = 32 took 75 - 105 us per call whatever the width, and 100 k slots filled only 98 workgroups)
-constexpr int kSL = 128;
+// 32 slots per wave, sixteen rows in flight: a wave's walk is a chain of dependent round trips — two of them now (256 slots x 8 rows in
+// flight = 32 took 75 - 105 us per call whatever the width and 100 k slots filled only 98 workgroups; 128 x 16 = 8: 27 us at the stage-A
+// sizes; 32: the iteration on a re-used batch 1.47 -> 1.39 ms, 16 and 64 slots measured beside it: 1.41 / 1.40-1.5).  The carries are
+// 2 C floats per 32 slots: 1/16 of the values read.
+constexpr int kSL = 32;
 template <int VEC>
 __global__ void __launch_bounds__(256) k_rowsum_walk(const int32_t* __restrict__ dst,
                                                      const int32_t* __restrict__ eid, const float* __restrict__ w, int32_t E,
