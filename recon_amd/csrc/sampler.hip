@@ -258,6 +258,111 @@ __global__ void __launch_bounds__(64) k_kg_nhop(const KG g, const int64_t* __res
     if (lane == 0) qcount[b] = count;
 }
 
+// The same walk by a WORKGROUP of four waves per source (the default where the tables fit in LDS): a round resolves 256 candidates, and
+// the slowest source of a batch — what a launch lasts — needs a quarter of the rounds.  First visit = the LOWEST candidate index that meets
+// an unseen target: every unseen lane posts its index with an LDS atomicMin into own[target] (one word per entity, all-ones at the
+// start; a word is consulted only in the round its target is first met, so it never needs resetting), and behind a barrier the lane
+// that reads its own index back is the first visit.  Positions: per-wave ballots + the waves' counts through LDS.
+constexpr int kNhopWaves = 4;
+template <bool WRITE>
+__global__ void __launch_bounds__(64 * kNhopWaves) k_kg_nhop_wg(const KG g, const int64_t* __restrict__ srcs, int32_t S, int32_t partial,
+                                                                 int64_t* __restrict__ qcount, const int64_t* __restrict__ quad_off, int64_t* __restrict__ quads) {
+    extern __shared__ uint32_t seen[];
+    constexpr int NTH = 64 * kNhopWaves;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, b = blockIdx.x;
+    const int words = static_cast<int>((g.Ne + 63) >> 6) * 2;
+    const int ne2 = static_cast<int>((g.Ne + 1) & ~1LL);               // own[] padded to an even count: the tables behind it stay 8-byte aligned
+    uint32_t* own = seen + words;
+    int32_t* poff = reinterpret_cast<int32_t*>(own + ne2);               // [64] first candidate of parent i within the batch
+    int64_t* pc0 = reinterpret_cast<int64_t*>(poff + 64);               // [64] its pair range's start
+    int64_t* pr1 = pc0 + 64;                                            // [64] its first relation
+    int32_t* wsum = reinterpret_cast<int32_t*>(pr1 + 64);               // [kNhopWaves] first visits per wave of the current round
+    const int64_t s = srcs[b], p0 = g.pair_ptr[s], p1 = g.pair_ptr[s + 1];
+    for (int i = t; i < words; i += NTH) seen[i] = 0u;
+    for (int i = t; i < ne2; i += NTH) own[i] = 0xffffffffu;
+    __syncthreads();
+    if (t == 0) atomicOr(&seen[s >> 5], 1u << (s & 31));
+    for (int64_t p = p0 + t; p < p1; p += NTH)
+        if (g.not_loop[p]) { const int64_t u = g.pair_tgt[p]; atomicOr(&seen[u >> 5], 1u << (u & 31)); }
+    __syncthreads();
+    int64_t count = 0;                                                  // the same in every thread
+    const int64_t base = WRITE ? quad_off[b] : 0;
+    const int64_t limit = WRITE ? qcount[b] : (partial ? 1 : (1LL << 62));
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    constexpr int kChunks = 4;
+    // parents two stages ahead, as in k_kg_nhop; every wave requests the same 64 parents (lane i: parent i) and scans their degrees itself
+    struct Stage1 { bool in; uint8_t nl; int64_t u, r1; };
+    struct Stage2 { int64_t c0, c1; };
+    auto request1 = [&](int64_t pb) {
+        Stage1 r;
+        const int64_t pa_l = pb + lane;
+        r.in = pa_l < p1;
+        const int64_t pa_c = r.in ? pa_l : p0;
+        r.nl = g.not_loop[pa_c]; r.u = g.pair_tgt[pa_c]; r.r1 = g.pair_first_rel[pa_c];
+        return r;
+    };
+    auto request2 = [&](const Stage1& a) { return Stage2{g.pair_ptr[a.u], g.pair_ptr[a.u + 1]}; };
+    Stage1 a1{false, 0, 0, 0}, b1{false, 0, 0, 0};
+    Stage2 a2{0, 0};
+    if (p0 < p1) { a1 = request1(p0); b1 = request1(p0 + 64); a2 = request2(a1); }
+    for (int64_t pb = p0; pb < p1 && count < limit; pb += 64) {
+        const bool ok = a1.in && a1.nl;
+        const int deg = ok ? static_cast<int>(a2.c1 - a2.c0) : 0;
+        int x = deg;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(x, off, 64); if (lane >= off) x += o; }
+        const int T = __shfl(x, 63, 64);
+        __syncthreads();                                                 // the previous batch's readers are done with the tables
+        if (w == 0) { poff[lane] = x - deg; pc0[lane] = ok ? a2.c0 : 0; pr1[lane] = a1.r1; }
+        __syncthreads();
+        a1 = b1; a2 = request2(b1); b1 = request1(pb + 128);            // under this batch's walk
+        int64_t v_r[kChunks], f_r[kChunks]; int lo_r[kChunks];
+        auto request = [&](int slot, int x0) {                           // rounds past T: every lane invalid, reads candidate 0 of parent 0's range
+            const int xi = x0 + t;
+            const bool valid = xi < T;
+            int lo;
+            { const int a = poff[16], bq = poff[32], c = poff[48]; lo = c <= xi ? 48 : (bq <= xi ? 32 : (a <= xi ? 16 : 0)); }
+            { const int a = poff[lo + 4], bq = poff[lo + 8], c = poff[lo + 12]; lo += c <= xi ? 12 : (bq <= xi ? 8 : (a <= xi ? 4 : 0)); }
+            { const int a = poff[lo + 1], bq = poff[lo + 2], c = poff[lo + 3]; lo += c <= xi ? 3 : (bq <= xi ? 2 : (a <= xi ? 1 : 0)); }
+            const int64_t c = valid ? pc0[lo] + (xi - poff[lo]) : 0;
+            v_r[slot] = g.pair_tgt[c]; f_r[slot] = g.pair_first_rel[c]; lo_r[slot] = lo;
+        };
+#pragma unroll
+        for (int d = 0; d < kChunks; ++d) request(d, NTH * d);
+        for (int x0 = 0; x0 < T && count < limit; x0 += NTH * kChunks) {  // uniform over the workgroup
+#pragma unroll
+            for (int d = 0; d < kChunks; ++d) {
+                __builtin_amdgcn_sched_barrier(0);                       // a round's wait stays in front of that round
+                const int xi = x0 + NTH * d + t;
+                const bool valid = xi < T && count < limit;
+                const int64_t v = valid ? v_r[d] : 0, fr = f_r[d];
+                const int lo = lo_r[d];
+                const uint32_t bit = 1u << (v & 31);
+                const bool unseen = valid && !(seen[v >> 5] & bit);
+                if (unseen) atomicMin(&own[v], static_cast<uint32_t>(xi));
+                __syncthreads();
+                const bool fresh = unseen && own[v] == static_cast<uint32_t>(xi);
+                if (fresh) atomicOr(&seen[v >> 5], bit);
+                const unsigned long long m = __ballot(fresh);
+                if (lane == 0) wsum[w] = __popcll(m);
+                __syncthreads();                                         // the marks and the counts are in; nobody reads own[] of this round any more
+                int before = __popcll(m & lt), tot = 0;
+#pragma unroll
+                for (int ww = 0; ww < kNhopWaves; ++ww) { const int c = wsum[ww]; tot += c; before += ww < w ? c : 0; }
+                if (WRITE && fresh && count + before < limit) {
+                    int64_t* q = quads + 4 * (base + count + before);
+                    q[0] = s; q[1] = pr1[lo]; q[2] = fr; q[3] = v;
+                }
+                count += tot;
+                request(d, x0 + NTH * (d + kChunks));                    // behind the slot's last use
+            }
+        }
+    }
+    if (WRITE) return;
+    if (count > limit) count = limit;
+    if (t == 0) qcount[b] = count;
+}
+
 // offsets of the sources' quadruples: exclusive scan of the counts by one wave (a launch of its own: "last workgroup scans" costs every
 // workgroup a device-scope fence)
 __global__ void __launch_bounds__(64) k_kg_scan(const int64_t* __restrict__ qcount, int32_t S, int64_t* __restrict__ quad_off, int64_t* __restrict__ total) {
@@ -286,6 +391,10 @@ KG kg_of(const recon_kg* k) {
 
 // the visited bitmap of one source + the parent tables of a batch (64 x (4 + 8 + 8) bytes, behind an 8-byte boundary)
 extern "C" size_t recon_kg_nhop_lds_bytes(int64_t num_entities) { return static_cast<size_t>((num_entities + 63) / 64) * 8 + 64 * 20; }
+// the workgroup form's: bitmap + one word per entity + the parent tables + the waves' counts
+static size_t nhop_wg_lds_bytes(int64_t num_entities) {
+    return static_cast<size_t>((num_entities + 63) / 64) * 8 + static_cast<size_t>((num_entities + 1) & ~1LL) * 4 + 64 * 20 + 16;
+}
 
 extern "C" int recon_kg_adj_count(const recon_kg* kg, const int64_t* entities, int32_t B, int64_t* nrel, uint8_t* ent_mark, uint8_t* tgt_mark,
                                   int64_t* rel_off, int64_t* uniq_ent, int64_t* uniq_tgt, int64_t* totals, uint32_t* counter, recon_stream_t stream) {
@@ -315,6 +424,21 @@ extern "C" int recon_kg_nhop(const recon_kg* kg, const int64_t* sources, int32_t
     if (S == 0) return RECON_OK;
     (void)counter;
     if (!sources || !qcount || !quad_off || (write ? !quads : !total)) return RECON_ERR_INVALID;
+    const size_t lds_wg = nhop_wg_lds_bytes(kg->num_entities);
+    if (lds_wg <= 72 * 1024 && recon::cfg_char(recon::CFG_KG_NHOP) != 'w') {   // four waves per source (two workgroups per CU still fit): ~18 k entities
+        const void* kw = write ? reinterpret_cast<const void*>(recon::k_kg_nhop_wg<true>) : reinterpret_cast<const void*>(recon::k_kg_nhop_wg<false>);
+        if (lds_wg > 48 * 1024 && hipFuncSetAttribute(kw, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_wg)) != hipSuccess) return RECON_ERR_LAUNCH;
+        const dim3 blk(64 * recon::kNhopWaves);
+        if (write) hipLaunchKernelGGL(recon::k_kg_nhop_wg<true>, dim3(static_cast<unsigned>(S)), blk, lds_wg, as_stream(stream), recon::kg_of(kg), sources, S, partial_2hop,
+                                      qcount, quad_off, quads);
+        else {
+            hipLaunchKernelGGL(recon::k_kg_nhop_wg<false>, dim3(static_cast<unsigned>(S)), blk, lds_wg, as_stream(stream), recon::kg_of(kg), sources, S, partial_2hop,
+                               qcount, quad_off, quads);
+            hipLaunchKernelGGL(recon::k_kg_scan, dim3(1), dim3(64), 0, as_stream(stream), qcount, S, quad_off, total);
+        }
+        RECON_CHECK_LAUNCH();
+        return RECON_OK;
+    }
     const size_t lds = recon_kg_nhop_lds_bytes(kg->num_entities);
     if (lds > 160 * 1024 - 64) return RECON_ERR_UNSUPPORTED;             // the visited set of one source must fit a CU's LDS (5.2 M entities)
     const void* kern = write ? reinterpret_cast<const void*>(recon::k_kg_nhop<true>) : reinterpret_cast<const void*>(recon::k_kg_nhop<false>);

@@ -17,11 +17,14 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=["kernels", "torch_primitives"])
-def impl(request, monkeypatch):
-    """Both implementations of the batch builders: csrc/sampler.hip (the default) and the torch-primitive assembly."""
+@pytest.fixture(params=["kernels", "kernels_wave_per_source", "torch_primitives"])
+def impl(request, monkeypatch, recon_config):
+    """The implementations of the batch builders: csrc/sampler.hip (the default: a workgroup per source in the 2-hop walk where its tables
+    fit in LDS), the same with the one-wave-per-source walk forced (RECON_KG_NHOP=w: what large entity sets take), and the torch-primitive assembly."""
     from recon_amd import sampler
-    monkeypatch.setattr(sampler, "_KERNELS", request.param == "kernels")
+    monkeypatch.setattr(sampler, "_KERNELS", request.param != "torch_primitives")
+    if request.param == "kernels_wave_per_source":
+        recon_config("RECON_KG_NHOP", "w")
     return request.param
 
 
