@@ -81,6 +81,26 @@ def launch_ranks(args, argv=None, script=None):
     return rc if rc != 0 else (0 if line is not None else 1)
 
 
+def timed_region(step, steps, barrier_sync, reduce_max=None):
+    """EXACTLY `steps` calls of `step` bracketed by barrier + device synchronisation on both sides; seconds, MAX over the ranks."""
+    barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier_sync()
+    dt = time.perf_counter() - t0
+    return reduce_max(dt) if reduce_max is not None else dt
+
+
+def scaling_fields(edges_per_gpu, steps, dt_comm, dt_no_comm):
+    """What an N > 1 line carries so that ONE run separates communication cost from shard-size effects: the same step with
+    every collective skipped, timed in the same process right before the measured loop (max over ranks, as the measured loop is)."""
+    return {"per_gpu_no_comm_edges_per_s": edges_per_gpu * steps / dt_no_comm,
+            "per_gpu_no_comm_ms_per_step": 1e3 * dt_no_comm / steps,
+            "comm_overhead_ms": 1e3 * (dt_comm - dt_no_comm) / steps,
+            "efficiency_vs_no_comm": dt_no_comm / dt_comm}
+
+
 def algorithmic_bytes_fwd(N, E, H, D):
     """bytes the fused forward edge-aggregation must move (fp32 values, int32 CSR):
     Q [E,HD] once, P_dst and P_src [N,HD] once each, out [N,HD] once, CSR, a_2."""
@@ -200,23 +220,36 @@ def main():
             out.backward(Gd)
             bucket.allreduce_mean()
 
+    def step_no_comm():                                                       # the same step, every collective skipped (the plain single-GPU schedule)
+        bucket.zero()
+        xd.grad = None
+        eed.grad = None
+        model.heads_forward(xd, edged, eed, nohop, nohop).backward(Gd)
+        bucket.pack()
+
     def barrier_sync():
         if backend is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def reduce_max(v):
+        if backend is None:
+            return v
+        t = torch.tensor([v], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    dt_no_comm = None
+    if backend is not None:
+        # N > 1: the per-GPU base of the scaling curve, measured HERE — same process, same shard, same clocks — so that value(N) / (N * this)
+        # is communication + straggler cost alone, whatever the shard size does to a GPU's own rate (1 024-graph shards run
+        # ~8 % more edges/s per GPU than the 512-graph N = 1 workload)
+        for _ in range(args.warmup):
+            step_no_comm()
+        dt_no_comm = timed_region(step_no_comm, args.steps, barrier_sync, reduce_max)
     for _ in range(args.warmup):
         step()
-    barrier_sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier_sync()
-    dt = time.perf_counter() - t0
-    if backend is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed_region(step, args.steps, barrier_sync, reduce_max)
     edges_per_s = E_global * args.steps / dt
 
     result = {
@@ -232,6 +265,12 @@ def main():
                    "backend": ({"nccl": "nccl (RCCL)"}.get(backend, backend) + (", %d ranks on %d GPU(s): schedule exercised, nothing measured" % (world, ndev) if ndev < world else "")
                                + (", RECON_DIST_FORCE=1: every collective executed at world size 1" if (force and world == 1) else "")) if backend else None},
     }
+
+    if dt_no_comm is not None:
+        result.update(scaling_fields(E_global / world, args.steps, dt, dt_no_comm))
+        result["scaling_base"] = ("per_gpu_no_comm_*: the same %d steps of the same shard with every collective skipped, timed in this process before "
+                                  "the measured loop (max over ranks); efficiency_vs_no_comm = that time / the measured time.  The N = 1 line's "
+                                  "secondary.cfg4_shard_1gpu is the same shard size on one GPU in its own process" % args.steps)
 
     if rank == 0:
         # ---- roofline of the HBM-bound forward edge aggregation (K1', k_gat_atp_fwd: the kernel SURVEY 8d names),

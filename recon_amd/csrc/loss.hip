@@ -45,7 +45,7 @@ __device__ __forceinline__ float row_l1(const TransE& p, int64_t t, int lane, fl
 }
 
 __global__ void __launch_bounds__(256) k_transe_margin_fwd(const TransE p, float* __restrict__ terms, int64_t* __restrict__ ent_key,
-                                                            int64_t* __restrict__ rel_key) {
+                                                            int64_t* __restrict__ rel_key, int32_t* __restrict__ nan_word) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t j = static_cast<int64_t>(blockIdx.x) * 4 + w;
     float sg[8];
@@ -53,7 +53,10 @@ __global__ void __launch_bounds__(256) k_transe_margin_fwd(const TransE p, float
         const int64_t tp = j % p.n_pos, tn = p.n_pos + j;
         const float pn = group_sum<64>(row_l1<false>(p, tp, lane, sg)), nn = group_sum<64>(row_l1<false>(p, tn, lane, sg));
         if (lane == 0) {
-            terms[j] = fmaxf(0.f, pn - nn + p.margin);
+            // clamp_min of the reference propagates NaN (GAT/main.py:374 then asserts on the loss); fmaxf alone would return the 0
+            const float v = pn - nn + p.margin;
+            terms[j] = (v != v) ? v : fmaxf(0.f, v);
+            if (nan_word && !(fabsf(v) <= 3.0e38f)) *nan_word = 1;
             const int64_t P = p.pairs;
             if (ent_key) {                                          // both rows of the [2][4 P] key tensor (row 1 is ignored by the row sum)
                 const int64_t k[4] = {p.tri[3 * tp], p.tri[3 * tp + 2], p.tri[3 * tn], p.tri[3 * tn + 2]};
@@ -142,7 +145,8 @@ extern "C" int recon_transe_margin_fwd(const float* entity, const float* relatio
     if (!recon::fill(&p, entity, relation, triples, n_pos, reps, D, margin) || !terms || !loss) return RECON_ERR_INVALID;
     if (p.pairs > (1LL << 31) - 4) return RECON_ERR_UNSUPPORTED;
     (void)counter;
-    hipLaunchKernelGGL(recon::k_transe_margin_fwd, dim3(static_cast<unsigned>(ceil_div64(p.pairs, 4))), dim3(256), 0, as_stream(stream), p, terms, ent_key, rel_key);
+    hipLaunchKernelGGL(recon::k_transe_margin_fwd, dim3(static_cast<unsigned>(ceil_div64(p.pairs, 4))), dim3(256), 0, as_stream(stream), p, terms, ent_key, rel_key,
+                       recon::nan_flag());
     hipLaunchKernelGGL(recon::k_transe_mean, dim3(1), dim3(256), 0, as_stream(stream), terms, p.pairs, loss);
     RECON_CHECK_LAUNCH();
     return RECON_OK;

@@ -48,12 +48,19 @@ def trust_bounds(t):
 _BAD = {}
 
 
+_BAD_SLOTS = 4096
+
+
 def _bad_flag(dev):
-    """One zeroed int32 per device: the build kernels set it when they meet an id outside [0, N) (GraphCSR reads it back with the hub counts)."""
-    f = _BAD.get(dev)
-    if f is None:
-        f = _BAD[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
-    return f
+    """A zeroed int32 slot OF ITS OWN for every build (a ring of _BAD_SLOTS per device): the build kernels set it when they meet an id outside
+    [0, N) and GraphCSR.resolve() reads it back with the hub counts.  A bad graph that is dropped unresolved leaves its slot set; the build
+    that takes the slot a ring later pays one verification for it and clears it — nobody else ever sees it."""
+    ring = _BAD.get(dev)
+    if ring is None:
+        ring = _BAD[dev] = [torch.zeros(_BAD_SLOTS, dtype=torch.int32, device=dev), 0]
+    i = ring[1]
+    ring[1] = (i + 1) % _BAD_SLOTS
+    return ring[0][i:i + 1]
 
 
 DEFER_HUB_READ = True   # the host read of a fresh graph's hub-table sizes (and of its id-range flag) waits until something needs them: see GraphCSR.resolve
@@ -110,8 +117,8 @@ class GraphCSR:
         ws_ptr = base + 4 * total
         bad = _bad_flag(dev) if in_build else None
         hubs = HUB_CHUNK > 0 and E > HUB_CHUNK and not rows_only            # the hub-table sizes are counted by the build's last launch
-        stream = _lib.current_stream()
         with _lib.on_device(dev):
+            stream = _lib.current_stream()                                   # of `dev`, which need not be the current device
             if hubs:
                 rc = L.recon_graph_build_counted(edge.data_ptr(), edge.data_ptr() + 8 * E, C.byref(self._c), ws_ptr, ws_bytes, _lib.ptr(bad), HUB_CHUNK, stream)
             else:
@@ -169,10 +176,12 @@ class GraphCSR:
         self._pending = None
         self.n_hub = self.n_piece = self.n_hub_src = self.n_piece_src = 0
         if bad_host.value:
-            # the flag is shared by the device's builds: it is this graph's if its own ids are out of range (then hand it back clear)
+            # the slot is this build's own unless a bad graph that took it a ring ago was dropped unresolved: verify, and hand it back clear
+            # (on the build's stream, which hubs_read has just drained: ordered in front of whichever build takes the slot next)
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.default_stream(dev)):
+                bad.zero_()
             lo, hi = (int(v) for v in torch.aminmax(self.edge))
             if lo < 0 or hi >= self.N:
-                bad.zero_()
                 self._error = "recon_amd: edge index out of range: ids span [%d, %d] but input has %d rows" % (lo, hi, self.N)
                 raise IndexError(self._error)
         if cnt[0] > 0 or cnt[2] > 0:

@@ -83,7 +83,10 @@ def batch_gat_loss(gat_loss_func, train_indices, entity_embed, relation_embed, v
     ratio = int(valid_invalid_ratio_gat)
     reps = 2 * ratio
     n_pos = int(train_indices.shape[0] / (reps + 1))
+    if entity_embed.is_cuda and train_indices.device != entity_embed.device:
+        train_indices = train_indices.to(entity_embed.device)            # the reference indexes a CUDA table with a CPU LongTensor (GAT/main.py:344-376)
     fused = (isinstance(gat_loss_func, torch.nn.MarginRankingLoss) and gat_loss_func.reduction == "mean" and entity_embed.is_cuda and
+             relation_embed.is_cuda and relation_embed.device == entity_embed.device and
              entity_embed.dtype == torch.float32 and relation_embed.dtype == torch.float32 and train_indices.dtype == torch.int64 and
              train_indices.dim() == 2 and train_indices.shape[1] == 3 and n_pos > 0 and train_indices.shape[0] == n_pos * (reps + 1) and
              entity_embed.shape[1] == relation_embed.shape[1])
@@ -92,7 +95,10 @@ def batch_gat_loss(gat_loss_func, train_indices, entity_embed, relation_embed, v
         return _TransEMarginLoss.apply(entity_embed, relation_embed, train_indices, n_pos, reps, float(gat_loss_func.margin))
     # the reference's op sequence (any loss function, any dtype): rows through gather_rows where the tables are GPU float32
     from .gat_layers import gather_rows
-    rows = (lambda t, i: gather_rows(t, i.contiguous())) if (entity_embed.is_cuda and entity_embed.dtype == torch.float32) else (lambda t, i: t[i])
+    def rows(t, i):                                                      # chosen per table: each may live elsewhere / in another dtype
+        if t.is_cuda and t.dtype == torch.float32:
+            return gather_rows(t, i.to(t.device).contiguous())
+        return t[i.to(t.device)]
     pos = train_indices[:n_pos].repeat(reps, 1)
     neg = train_indices[n_pos:]
     pos_norm = torch.norm(rows(entity_embed, pos[:, 0]) + rows(relation_embed, pos[:, 1]) - rows(entity_embed, pos[:, 2]), p=1, dim=1)

@@ -446,3 +446,52 @@ def test_bench_launcher_relays_the_result_line_and_the_exit_code(tmp_path, capsy
     assert bench.launch_ranks(args, argv=["--mode", "fail"], script=str(script)) != 0
     capsys.readouterr()
     assert bench.launch_ranks(args, argv=["--mode", "silent"], script=str(script)) == 1
+
+
+def _scaling_fields_worker(rank, world, port, ret):
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        t = torch.ones(1 << 16)
+        calls = {"comm": 0, "local": 0}
+
+        def step_no_comm():
+            calls["local"] += 1
+            time.sleep(0.002 * (rank + 1))                              # rank 1 is the straggler: the MAX over ranks must carry its time
+
+        def step():
+            calls["comm"] += 1
+            time.sleep(0.002 * (rank + 1))
+            dist.all_reduce(t)
+
+        def reduce_max(v):
+            x = torch.tensor([v], dtype=torch.float64)
+            dist.all_reduce(x, op=dist.ReduceOp.MAX)
+            return float(x.item())
+        steps, E = 10, 1000
+        dt0 = bench.timed_region(step_no_comm, steps, dist.barrier, reduce_max)
+        dt1 = bench.timed_region(step, steps, dist.barrier, reduce_max)
+        f = bench.scaling_fields(E, steps, dt1, dt0)
+        ret[rank] = (dict(f), dt0, dt1, dict(calls))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_line_carries_a_no_collective_baseline_at_world_size_2():
+    """VERDICT r5 #2 / SURVEY 8e: at N > 1 the bench line holds the SAME steps timed with every collective skipped (same process, max over
+    ranks), so that one run yields communication overhead and an efficiency that does not mix shard sizes."""
+    world = 2
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_scaling_fields_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    f0, dt0, dt1, calls = ret[0]
+    assert ret[1][1] == dt0 and ret[1][2] == dt1                        # max over ranks: every rank holds the same two times
+    assert calls == {"comm": 10, "local": 10}                           # EXACTLY `steps` calls inside each timed region
+    assert set(f0) == {"per_gpu_no_comm_edges_per_s", "per_gpu_no_comm_ms_per_step", "comm_overhead_ms", "efficiency_vs_no_comm"}
+    assert dt0 >= 10 * 0.004 * 0.95                                     # the straggler's 4 ms per step, not rank 0's 2
+    assert abs(f0["per_gpu_no_comm_edges_per_s"] - 1000 * 10 / dt0) < 1e-6 * f0["per_gpu_no_comm_edges_per_s"]
+    assert abs(f0["comm_overhead_ms"] - 1e3 * (dt1 - dt0) / 10) < 1e-9 and abs(f0["efficiency_vs_no_comm"] - dt0 / dt1) < 1e-12
+    assert 0.2 < f0["efficiency_vs_no_comm"] < 1.2

@@ -31,7 +31,7 @@ def run(M, N, K, nk, cfgs, rounds=5, iters=10):
     if nk: res["bx3"] = []
     for r in range(rounds + 1):
         for c in cfgs:
-            os.environ["RECON_GEMM_CFG"] = str(c)
+            _lib.config_set("RECON_GEMM_CFG", str(c))
             t = time_once(mine, iters)
             if r: res[c].append(t)
         t = time_once(ref, iters)

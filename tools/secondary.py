@@ -320,9 +320,49 @@ def powerlaw_mixed_stack_bf16(B=64, D=32, F_=200, H=8, iters=10):
             "fwd_ms": tf * 1e3, "fwd_bwd_ms": tb * 1e3, "edges_per_s_fwd_bwd": E / tb, "bytes": b_g + b_c, "bound": "hbm", "frac": (b_g + b_c) / tf / HBM_PEAK}
 
 
+def gat_heads_shard(B=1024, n=16, e=64, F_=200, D=200, H=8, iters=50):
+    """cfg4_shard_1gpu: BASELINE.json configs[3]'s per-GPU shard (8 192 graphs / 8 GPUs = 1 024 graphs) as ONE GPU runs it — bench.py's own
+    step (H-head attention stage forward + backward, gradients into the flat bucket, no collective).  The base of the scaling curve:
+    value(N) of an N-GPU run over N x this figure is shard-for-shard comparable, which value(N) / value(1) of the 512-graph N = 1 line is not."""
+    from recon_amd import synth
+    from recon_amd.models import SpGAT
+    from recon_amd.graph import prepare_graph, clear_graph_cache
+    from recon_amd.dist import FlatGradBucket
+    dv = torch.device("cuda:0")
+    N, E = B * n, B * e
+    x, edge, ee = synth.synthetic_batched_graph(B, n, e, F_, F_, seed=0)
+    torch.manual_seed(0)
+    model = SpGAT(N, F_, D, F_, dropout=0.0, alpha=0.2, nheads=H).to(dv)
+    xd, eed, edged = x.to(dv).requires_grad_(True), ee.to(dv).requires_grad_(True), edge.to(dv)
+    nohop = torch.tensor([])
+    Gd = torch.randn(N, H * D, generator=torch.Generator().manual_seed(1)).to(dv)
+    bucket = FlatGradBucket(model.head_parameters())
+    model.write_head_gradients_into(bucket)
+    prepare_graph(edged, nohop, N)
+
+    def step():
+        bucket.zero()
+        xd.grad = None
+        eed.grad = None
+        model.heads_forward(xd, edged, eed, nohop, nohop).backward(Gd)
+        bucket.pack()
+    t = _time(step, iters, warm=10)
+    clear_graph_cache()
+    return {"graphs": B, "N": N, "E": E, "F": F_, "D_per_head": D, "heads": H, "ms_per_step": t * 1e3, "edges_per_s": E / t, "steps": iters,
+            "what": "configs[3]'s per-GPU shard (1 024 graphs) on one GPU, bench.py's step without collectives: the shard-for-shard base of a scaling curve"}
+
+
+def stage_a_iteration(iters=20):
+    """N1's caller as the reference runs it (GAT/main.py:478-525): tools/stage_a_iter_bench.py with the fused loss, `iters` fresh iterations."""
+    import stage_a_iter_bench
+    return stage_a_iter_bench.run(iters=iters, loss_rows="recon", launches=True)
+
+
 def all_secondary(fast=True):
     it = 6 if fast else 20
-    return {"cfg3b_n9_propagation": propagation(9, iters=it),
+    return {"cfg4_shard_1gpu": gat_heads_shard(iters=50),
+            "stage_a_iteration": stage_a_iteration(iters=20),
+            "cfg3b_n9_propagation": propagation(9, iters=it),
             "cfg3b_n32_propagation": propagation(32, iters=10),          # training legs: max(2, iters // 2) = 5 timed iterations, twice
             "cfg3b_n9_bf16": propagation_bf16(9, iters=it),
             "cfg3b_n32_bf16": propagation_bf16(32, iters=10),

@@ -50,7 +50,23 @@ def batch_gat_loss(loss_fn, train_indices, entity_embed, relation_embed, ratio=2
     return loss_fn(pos_norm, neg_norm, y)
 
 
-def main():
+def count_launches(fn, iters=3):
+    """Device launches (kernels, copies, fills) per call of `fn`, from torch.profiler's device-side events; None where the profiler
+    records none (no roctracer in the build)."""
+    try:
+        from torch.profiler import profile, ProfilerActivity
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize()
+        n = sum(1 for ev in prof.events() if str(getattr(ev, "device_type", "")).endswith("CUDA"))
+        return round(n / iters, 1) if n else None
+    except Exception:
+        return None
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--entities", type=int, default=128)
@@ -58,7 +74,8 @@ def main():
     ap.add_argument("--ratio", type=int, default=2)
     ap.add_argument("--loss-rows", choices=["torch", "recon"], default="torch", help="table[index] (the reference's loss code) or recon_amd.gat_layers.gather_rows")
     ap.add_argument("--profile", action="store_true", help="cProfile of the host side of fresh iterations (top functions by own time)")
-    args = ap.parse_args()
+    ap.add_argument("--launches", action="store_true", help="also count the device launches of a fresh iteration (torch.profiler)")
+    args = ap.parse_args(argv)
     dv = torch.device("cuda:0")
     torch.autograd.set_multithreading_enabled(False)
     N, nrel = 14541, 237
@@ -131,12 +148,22 @@ def main():
     it = iter(distinct)
     t_distinct = timed(lambda: train_iter(next(it)), args.iters)
     E1, E2 = one[1][0].shape[1], (0 if args.no_2hop else one[2].shape[0])
-    print(json.dumps({"workload": "stage-A iteration (GAT/main.py:478-525): sampler batch -> SpKBGATModified fwd -> margin loss -> bwd -> SGD, FB15k-237-sized synthetic KG",
+    launches = count_launches(lambda: train_iter(make_batch())) if args.launches else None
+    res = ({"workload": "stage-A iteration (GAT/main.py:478-525): sampler batch -> SpKBGATModified fwd -> margin loss -> bwd -> SGD, FB15k-237-sized synthetic KG",
                       "entities_per_batch": args.entities, "loss_rows": args.loss_rows, "edges_1hop": E1, "quads_2hop": E2,
                       "batch_assembly_ms": t_batch, "iteration_cached_batch_ms": t_cached, "iteration_fresh_batch_ms": t_fresh,
                       "model_step_distinct_batches_ms": t_distinct, "distinct_over_cached": t_distinct / t_cached,
                       "assembly_hidden_ms": t_batch + t_distinct - t_fresh,
-                      "edges_per_s_fresh": (E1 + E2) / t_fresh * 1e3}))
+                      "edges_per_s_fresh": (E1 + E2) / t_fresh * 1e3, "iters": args.iters,
+                      "launches_per_fresh_iteration": launches})
+    if argv is None:
+        print(json.dumps(res))
+    return res
+
+
+def run(iters=20, loss_rows="recon", launches=True):
+    """The bench line's `secondary.stage_a_iteration` (bench.py): `iters` fresh iterations per leg."""
+    return main(["--iters", str(iters), "--loss-rows", loss_rows] + (["--launches"] if launches else []))
 
 
 if __name__ == "__main__":
