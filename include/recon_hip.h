@@ -479,6 +479,13 @@ int recon_rel_rows_mm_wgrad(const float* x, const float* g, const int32_t* order
 int recon_start_entity_embeddings(const float* entity_embeddings /*[U,d]*/, const int64_t* pos /*[B,C,2]*/,
                                   const float* templ /*[C,S]*/, int32_t B, int32_t n, int32_t d,
                                   float* out /*[B,C,S]*/, recon_stream_t stream);
+/* Its backward, first half (the reference has none of its own: autograd's index_put_ backward of context_utils.py:413-420, whose
+ * float atomics fix no summation order): rows [2][B*C][d] = the d-wide pieces of (grad_out * templ) that belong to pos[..., 0]
+ * (node i's first half-slot) and pos[..., 1] (node j's second half-slot), and — when `key` is given — key [2][2*B*C] = those entity
+ * ids twice (the [2, E] segment key of recon_spmm_rowsum_fwd over a destination-only recon_graph: the fixed-order second half). */
+int recon_start_entity_embeddings_bwd(const float* grad_out /*[B,C,S]*/, const int64_t* pos /*[B,C,2]*/, const float* templ /*[C,S]*/,
+                                      int32_t B, int32_t n, int32_t d, float* rows /*[2,B*C,d]*/, int64_t* key /*[2,2*B*C] or NULL*/,
+                                      recon_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * P5 / K6  GraphConvolution (models/layers.py:57-63), batched over B graphs (B = 1 is the

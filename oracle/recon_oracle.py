@@ -119,8 +119,10 @@ def gat_layer_backward(x, edge, edge_embed, edge_list_nhop, edge_embed_nhop, a, 
 
 
 def spgat_forward(x, relation_embed, edge_list, edge_type, edge_embed, edge_list_nhop, edge_type_nhop,
-                  head_a, head_a2, W, out_a, out_a2, alpha, masks=None, aten_sequence=False):
-    """SpGAT.forward in eval mode / dropout 0   (GAT/models.py:47-88).
+                  head_a, head_a2, W, out_a, out_a2, alpha, masks=None, aten_sequence=False, layer_mask=None, out_mask=None):
+    """SpGAT.forward   (GAT/models.py:47-88).  Eval mode / dropout 0 by default; train mode with the dropout factors handed in, in the
+    order the reference draws them: `masks[h]` — head h's E-vector (GAT/layers.py:158, drawn inside the list comprehension of :71-72),
+    `layer_mask` — dropout_layer on the concatenated heads [N, H*D] (:73), `out_mask` — out_att's E-vector (:86).
 
     head_a / head_a2: lists of per-head parameters (attention_i.a, attention_i.a_2).
     Returns (x_out [N, H*D], out_relation_1 [n_rel, H*D]).
@@ -132,11 +134,13 @@ def spgat_forward(x, relation_embed, edge_list, edge_type, edge_embed, edge_list
                                mask=None if masks is None else masks[i], aten_sequence=aten_sequence)
              for i, (a, a2) in enumerate(zip(head_a, head_a2))]
     xc = torch.cat(heads, dim=1)                                       # :71-72
+    if layer_mask is not None:
+        xc = xc * layer_mask.to(xc.dtype)                              # :73
     out_rel = relation_embed @ W                                       # :77
     ee = out_rel[edge_type]                                            # :79
     ee_nhop = (out_rel[edge_type_nhop[:, 0]] + out_rel[edge_type_nhop[:, 1]]) if has_nhop else None
     y = F.elu(gat_layer_forward(xc, edge_list, ee, nhop, ee_nhop, out_a, out_a2, alpha, False,
-                                aten_sequence=aten_sequence))          # :86-87
+                                mask=out_mask, aten_sequence=aten_sequence))          # :86-87
     return y, out_rel
 
 
@@ -149,13 +153,15 @@ def nhop_edges(train_indices_nhop):
 
 
 def spkbgat_forward(entity_embeddings, relation_embeddings, batch_entities, edge_list, edge_type, train_indices_nhop,
-                    head_a, head_a2, W, out_a, out_a2, W_entities, alpha):
-    """SpKBGATModified.forward / batch_test in eval mode (GAT/models.py:136-185, 188-239).
+                    head_a, head_a2, W, out_a, out_a2, W_entities, alpha, masks=None, layer_mask=None, out_mask=None):
+    """SpKBGATModified.forward / batch_test (GAT/models.py:136-185, 188-239); eval mode unless the dropout factors are handed in
+    (spgat_forward).
     `entity_embeddings` is the table AFTER the in-place L2 normalisation of :160 (the reference normalises
     `.data`, so no gradient flows through that normalisation).  Returns (out_entity, out_relation, mask)."""
     nhop_list, nhop_type = nhop_edges(train_indices_nhop)
     x, out_rel = spgat_forward(entity_embeddings, relation_embeddings, edge_list, edge_type, relation_embeddings[edge_type],
-                               nhop_list, nhop_type, head_a, head_a2, W, out_a, out_a2, alpha)
+                               nhop_list, nhop_type, head_a, head_a2, W, out_a, out_a2, alpha, masks=masks, layer_mask=layer_mask,
+                               out_mask=out_mask)
     mask = torch.zeros(entity_embeddings.shape[0], dtype=entity_embeddings.dtype)
     mask[torch.unique(batch_entities)] = 1.0                                    # :167-177
     out = entity_embeddings @ W_entities + mask[:, None] * x                    # :179-181

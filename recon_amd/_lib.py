@@ -189,6 +189,7 @@ SYMBOLS = [
     ("recon_rel_rows_mm_wgrad", C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p] * 2),
     ("recon_start_entity_embeddings", C.c_int, [c_f32p, c_i64p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
                                                 C.c_void_p]),
+    ("recon_start_entity_embeddings_bwd", C.c_int, [c_f32p, c_i64p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_void_p, C.c_void_p]),
     ("recon_gcn_split_bytes", C.c_size_t, [C.c_int32, C.c_int32]),
     ("recon_gcn_fwd", C.c_int, [C.POINTER(GcnArgs), C.c_void_p]),
     ("recon_gcn_bwd_partial_floats", C.c_size_t, [C.c_int32] * 4),

@@ -153,6 +153,25 @@ __global__ void k_start_entity(const float* __restrict__ ent, const int64_t* __r
     out[idx] = v * templ[c * S + s];
 }
 
+// rows [2][B C][d]: slot 0 = node i's first half-slot of (g * templ), slot 1 = node j's second half-slot; key [2][2 B C] = pos[..., slot]
+__global__ void k_start_entity_bwd(const float* __restrict__ g, const int64_t* __restrict__ pos, const float* __restrict__ templ, int32_t B, int32_t n,
+                                   int32_t d, float* __restrict__ rows, int64_t* __restrict__ key) {
+    const int64_t S = 2LL * d * n, C = 1LL * n * (n - 1), BC = B * C;
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= 2 * BC * d) return;
+    const int k = static_cast<int>(idx % d);
+    const int64_t r = idx / d;                                     // slot * BC + bc
+    const int slot = r >= BC ? 1 : 0;
+    const int64_t bc = r - slot * BC;
+    const int c = static_cast<int>(bc % C);
+    const int i = c / (n - 1);
+    int j = c % (n - 1);
+    if (j >= i) ++j;
+    const int off = slot ? 2 * d * j + d : 2 * d * i;
+    rows[idx] = g[bc * S + off + k] * templ[c * S + off + k];
+    if (key && k == 0) { const int64_t e = pos[bc * 2 + slot]; key[r] = e; key[2 * BC + r] = e; }
+}
+
 // ------------------------------------------------------------------------------- P2 forward
 template <bool VEC4>
 __device__ __forceinline__ void load_a_row4(float (&v)[4], const float* A, int S, int row, int col, bool row_ok) {
@@ -917,6 +936,17 @@ extern "C" int recon_start_entity_embeddings(const float* ent, const int64_t* po
     if (total == 0) return RECON_OK;
     hipLaunchKernelGGL(k_start_entity, dim3(static_cast<unsigned>(ceil_div64(total, 256))), dim3(256), 0, as_stream(stream), ent, pos,
                        templ, B, n, d, out);
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+extern "C" int recon_start_entity_embeddings_bwd(const float* grad_out, const int64_t* pos, const float* templ, int32_t B, int32_t n, int32_t d,
+                                                 float* rows, int64_t* key, recon_stream_t stream) {
+    if (B < 0 || n < 2 || d < 1 || !grad_out || !pos || !templ || !rows) return RECON_ERR_INVALID;
+    const int64_t total = 2LL * B * n * (n - 1) * d;
+    if (total == 0) return RECON_OK;
+    hipLaunchKernelGGL(k_start_entity_bwd, dim3(static_cast<unsigned>(ceil_div64(total, 256))), dim3(256), 0, as_stream(stream), grad_out, pos, templ, B,
+                       n, d, rows, key);
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }

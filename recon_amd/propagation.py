@@ -631,7 +631,7 @@ def make_start_entity_embeddings(entity_embeddings, entity_pos_indices, unique_e
                                  max_occurred_entity_in_batch_pos, start_embedding_template, max_num_nodes=9):
     """utils/context_utils.py:387-426, same argument list (unique_entities and the most-frequent-entity
     hint only steer a speed trick there and do not change the result).  Returns [B, C, 2dn, 1].
-    Forward only on the GPU kernel; gradients to `entity_embeddings` flow through an index_add."""
+    Forward and backward are kernels; the gradient of `entity_embeddings` is a fixed-order segment sum (bitwise run-to-run)."""
     _req(entity_embeddings, start_embedding_template)
     n, d = max_num_nodes, embedding_dim
     B, Cn = entity_pos_indices.shape[:2]
@@ -656,16 +656,29 @@ class _StartEntity(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        """Fixed summation order, no torch op: one kernel cuts the two d-wide pieces per (b, c) out of g * templ, the
+        SpecialSpmmFinal walk (csrc/gat.hip: k_rowsum_walk / _fix over a destination-only CSR keyed on the entity ids) adds the rows of
+        each entity in slot order.  The segment key — and with it the CSR, through prepare_graph's cache — is kept per position tensor."""
+        from .gat_layers import _rowsum_keyed
         pos, templ = ctx.saved_tensors
         B, n, d, U = ctx.dims
-        Cn, S = n * (n - 1), 2 * d * n
-        g = (g.view(B, Cn, S) * templ).view(B, Cn, n, 2, d)
-        pi = torch.tensor([i for i in range(n) for j in range(n) if i != j], device=g.device)
-        pj = torch.tensor([j for i in range(n) for j in range(n) if i != j], device=g.device)
-        ar = torch.arange(Cn, device=g.device)
-        g_first = g[:, ar, pi, 0]          # [B,C,d]  node i, first half-slot
-        g_second = g[:, ar, pj, 1]         # [B,C,d]  node j, second half-slot
-        ge = torch.zeros(U, d, dtype=torch.float32, device=g.device)
-        ge.index_add_(0, pos[..., 0].reshape(-1), g_first.reshape(-1, d))
-        ge.index_add_(0, pos[..., 1].reshape(-1), g_second.reshape(-1, d))
-        return ge, None, None, None, None, None
+        Cn = n * (n - 1)
+        dev = g.device
+        g = g.contiguous()
+        if g.dtype != torch.float32:
+            g = g.float()
+        rows = torch.empty(2 * B * Cn, d, dtype=torch.float32, device=dev)
+        ck = (pos.data_ptr(), pos._version, tuple(pos.shape), str(dev))
+        hit = _P4_KEYS.get(ck)
+        key = None if hit is not None else torch.empty(2, 2 * B * Cn, dtype=torch.int64, device=dev)
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().recon_start_entity_embeddings_bwd(g.data_ptr(), pos.data_ptr(), templ.data_ptr(), B, n, d, rows.data_ptr(),
+                                                                    _lib.ptr(key), _lib.current_stream()), "recon_start_entity_embeddings_bwd")
+        if hit is None:
+            if len(_P4_KEYS) >= 4:
+                _P4_KEYS.pop(next(iter(_P4_KEYS)))
+            hit = _P4_KEYS[ck] = (key, pos)                               # `pos` pins data_ptr identity while cached
+        return _rowsum_keyed(rows, hit[0], U), None, None, None, None, None
+
+
+_P4_KEYS = {}

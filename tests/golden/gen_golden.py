@@ -223,6 +223,7 @@ def gen_gat():
             arrays["g." + k] = t2n(v.grad)
         save(name, **arrays)
     gen_kbgat(gat_models)
+    gen_kbgat_train(gat_models)
 
 
 def gen_kbgat(gat_models):
@@ -261,6 +262,88 @@ def gen_kbgat(gat_models):
             if v.grad is not None:
                 arrays["g." + k] = t2n(v.grad)
         save(name, **arrays)
+
+
+def _ref_batch_gat_loss(ratio):
+    """The reference's own batch_gat_loss (GAT/main.py:344-376): main.py trains at import time, so the function's source is cut out of the
+    file where it lies (ast, at generation time — nothing of it is stored) and executed against a stub `args` / CUDA = False."""
+    import ast
+    path = os.path.join(REF, "GAT", "main.py")
+    src = open(path).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "batch_gat_loss")
+    code = "\n".join(src.split("\n")[fn.lineno - 1:fn.end_lineno])
+    ns = {"torch": torch, "args": types.SimpleNamespace(valid_invalid_ratio_gat=ratio), "CUDA": False}
+    exec(compile(code, path, "exec"), ns)
+    return ns["batch_gat_loss"]
+
+
+def gen_kbgat_train(gat_models):
+    """The regime stage A actually runs (GAT/main.py:478-525): SpKBGATModified in train() with drop_GAT = 0.3, three iterations of
+    forward -> batch_gat_loss -> backward -> SGD(lr = 1e-3, the reference's default) on three DIFFERENT batches.  Every nn.Dropout of the
+    model (GAT/models.py:71-73: one E-vector per head in head order, then dropout_layer on the concatenated heads, then out_att's E-vector;
+    GAT/layers.py:158) draws its factors on a tensor of ones and multiplies — numerically what nn.Dropout does — so that the factors can be
+    recorded in CALL ORDER and replayed by the GPU test."""
+    N, nrel, dim, nhid, nheads, ratio, p_drop, lr, margin = 60, 7, 16, 8, 2, 2, 0.3, 1e-3, 1.0
+    g = torch.Generator().manual_seed(41)
+    ent0 = torch.randn(N, dim, generator=g)
+    rel0 = torch.randn(nrel, dim, generator=g)
+    torch.manual_seed(9)
+    m = gat_models.SpKBGATModified(ent0.clone(), rel0.clone(), [nhid, nhid * nheads], [nhid * nheads, nhid * nheads],
+                                   p_drop, 0.2, [nheads, nheads], None)
+    m.train()
+    arrays = {"p0." + k: t2n(v).copy() for k, v in m.state_dict().items()}
+    record = []
+
+    def recording(mod, name):
+        def fwd(x):
+            assert mod.training
+            f = torch.nn.functional.dropout(torch.ones_like(x), mod.p, True)
+            record.append((name, t2n(f).astype(np.float32)))
+            return x * f
+        return fwd
+    names = []
+    for name, mod in m.named_modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.forward = recording(mod, name)
+            names.append(name)
+    assert sorted(names) == sorted(["sparse_gat_1.dropout_layer", "sparse_gat_1.out_att.dropout"] +
+                                   ["sparse_gat_1.attention_%d.dropout" % h for h in range(nheads)]), names
+    loss_fn = torch.nn.MarginRankingLoss(margin=margin)
+    ref_loss = _ref_batch_gat_loss(ratio)
+    opt = torch.optim.SGD(m.parameters(), lr=lr)
+    losses = []
+    torch.manual_seed(77)
+    for it in range(3):
+        E1, E2, n_pos = 80 + 7 * it, 30 + 5 * it, 20
+        edge = torch.randint(0, N, (2, E1), generator=g)
+        etype = torch.randint(0, nrel, (E1,), generator=g)
+        nhop = torch.stack([torch.randint(0, N, (E2,), generator=g), torch.randint(0, nrel, (E2,), generator=g),
+                            torch.randint(0, nrel, (E2,), generator=g), torch.randint(0, N, (E2,), generator=g)], dim=1)
+        batch_entities = torch.randint(0, N, (25,), generator=g)
+        pos = torch.stack([edge[1, :n_pos], etype[:n_pos], edge[0, :n_pos]], dim=1)
+        neg = pos.repeat(2 * ratio, 1)
+        half = neg.shape[0] // 2
+        neg[:half, 0] = torch.randint(0, N, (half,), generator=g)
+        neg[half:, 2] = torch.randint(0, N, (neg.shape[0] - half,), generator=g)
+        tri = torch.cat([pos, neg])
+        record.clear()
+        out_e, out_r, mask = m(None, batch_entities, (edge, etype), nhop)
+        opt.zero_grad()
+        loss = ref_loss(loss_fn, tri, out_e, out_r)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        assert [n for n, _ in record] == ["sparse_gat_1.attention_%d.dropout" % h for h in range(nheads)] + \
+            ["sparse_gat_1.dropout_layer", "sparse_gat_1.out_att.dropout"], [n for n, _ in record]
+        arrays.update({"it%d.edge" % it: t2n(edge), "it%d.edge_type" % it: t2n(etype), "it%d.nhop" % it: t2n(nhop),
+                       "it%d.batch_entities" % it: t2n(batch_entities), "it%d.train_indices" % it: t2n(tri),
+                       "it%d.out_entity" % it: t2n(out_e), "it%d.out_relation" % it: t2n(out_r)})
+        for k, (n_, f) in enumerate(record):
+            arrays["it%d.mask%d" % (it, k)] = f
+    for k, v in m.state_dict().items():
+        arrays["p3." + k] = t2n(v)
+    save("spkbgat3_train", losses=np.asarray(losses, dtype=np.float64), nheads=np.int32(nheads), nhid=np.int32(nhid), alpha=np.float64(0.2),
+         p_drop=np.float32(p_drop), lr=np.float64(lr), margin=np.float32(margin), ratio=np.int32(ratio), **arrays)
 
 
 # --------------------------------------------------------------------------- GP-GNN cases
@@ -699,15 +782,9 @@ def gen_gpgnn():
 def gen_loss():
     """N1: batch_gat_loss (GAT/main.py:344-376) + nn.MarginRankingLoss.  main.py trains at import time, so the function's OWN source is
     cut out of the file where it lies (ast, at generation time — nothing of it is stored) and executed against a stub `args` / CUDA = False."""
-    import ast
-    path = os.path.join(REF, "GAT", "main.py")
-    src = open(path).read()
-    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "batch_gat_loss")
-    code = "\n".join(src.split("\n")[fn.lineno - 1:fn.end_lineno])
     for name, (n_ent, n_rel, D, n_pos, ratio, margin, seed) in (("loss1_small", (9, 3, 8, 5, 2, 1.0, 0)), ("loss2_wide", (40, 6, 200, 33, 2, 5.0, 1)),
                                                                ("loss3_ratio1", (17, 4, 50, 12, 1, 0.5, 2))):
-        ns = {"torch": torch, "args": types.SimpleNamespace(valid_invalid_ratio_gat=ratio), "CUDA": False}
-        exec(compile(code, path, "exec"), ns)
+        ref_loss = _ref_batch_gat_loss(ratio)
         rs = np.random.RandomState(seed)
         ent = torch.from_numpy(hashed_uniform((n_ent, D), 90 + seed)).requires_grad_(True)
         rel = torch.from_numpy(hashed_uniform((n_rel, D), 95 + seed)).requires_grad_(True)
@@ -717,11 +794,19 @@ def gen_loss():
         neg[:half, 0] = rs.randint(0, n_ent, half); neg[half:, 2] = rs.randint(0, n_ent, neg.shape[0] - half)
         neg[0] = pos[0]                                              # a pair whose two norms are equal: the term sits exactly at the margin
         tri = torch.from_numpy(np.concatenate([pos, neg]).astype(np.int64))
-        loss = ns["batch_gat_loss"](torch.nn.MarginRankingLoss(margin=margin), tri, ent, rel)
+        loss = ref_loss(torch.nn.MarginRankingLoss(margin=margin), tri, ent, rel)
         loss.backward()
         save(name, entity=t2n(ent), relation=t2n(rel), train_indices=t2n(tri), ratio=np.int32(ratio), margin=np.float32(margin),
              loss=t2n(loss), g_entity=t2n(ent.grad), g_relation=t2n(rel.grad))
 
+
+if __name__ == "__main__" and os.environ.get("RECON_GOLDEN_ONLY") == "kbgat_train":
+    _install_shims()
+    sys.path.insert(0, os.path.join(REF, "GAT"))
+    import models as _gat_models
+    assert _gat_models.__file__.startswith(REF)
+    gen_kbgat_train(_gat_models)
+    sys.exit(0)
 
 if __name__ == "__main__" and os.environ.get("RECON_GOLDEN_ONLY") == "loss":
     gen_loss()

@@ -974,6 +974,57 @@ def test_spkbgat_golden(name):
     close(tr, g["test_relation"], what="batch_test relation")
 
 
+@pytest.mark.parametrize("family", ["2", "1", "0"])
+@pytest.mark.parametrize("path", ["atp", "proj"])
+def test_spkbgat_train_mode_three_sgd_iterations_golden(family, path, monkeypatch):
+    """The regime stage A runs (GAT/main.py:478-525): SpKBGATModified with drop_GAT = 0.3 in train(), three iterations of
+    forward -> batch_gat_loss -> backward -> SGD(lr = 1e-3) on three different batches, against the REFERENCE's losses and final parameters.
+    The reference's dropout factors were recorded in call order — one E-vector per head (GAT/layers.py:158 inside GAT/models.py:71-72),
+    dropout_layer on the concatenated heads (:73), out_att's E-vector (:86) — and are replayed here through draw_keep / dropout_layer.
+    Every GEMM family (f16 x 2, bf16 x 3, exact fp32) and both formulations."""
+    from recon_amd import gat_layers
+    from recon_amd.models import SpKBGATModified
+    from recon_amd.losses import batch_gat_loss
+    monkeypatch.setattr(gat_layers, "_GEMM_BX3", family)
+    monkeypatch.setattr(gat_layers, "_GAT_PATH", path)
+    g = load_golden("spkbgat3_train")
+    d = dev()
+    H, nhid, ratio = int(g["nheads"]), int(g["nhid"]), int(g["ratio"])
+    sd0 = {k[3:]: T(g[k]) for k in g if k.startswith("p0.")}
+    m = SpKBGATModified(sd0["entity_embeddings"].clone(), sd0["relation_embeddings"].clone(), [nhid, nhid * H], [nhid * H, nhid * H],
+                        float(g["p_drop"]), float(g["alpha"]), [H, H], None)
+    m.load_state_dict(sd0, strict=True)
+    m = m.to(d).train()
+    sg = m.sparse_gat_1
+    assert abs(sg.attentions[0].keep_bound() - 1.0 / (1.0 - float(g["p_drop"]))) < 1e-6
+    opt = torch.optim.SGD(m.parameters(), lr=float(g["lr"]))
+    loss_fn = torch.nn.MarginRankingLoss(margin=float(g["margin"]))
+    drawn = []
+    for it in range(3):
+        masks = [T(g["it%d.mask%d" % (it, k)]).to(d) for k in range(H + 2)]
+        assert float(masks[0].max()) <= sg.attentions[0].keep_bound() + 1e-6
+        for h, att in enumerate(sg.attentions):
+            att.draw_keep = (lambda mk, tag: (lambda E, device: (drawn.append(tag), mk.view(1, E))[1]))(masks[h], "head%d" % h)
+        sg.dropout_layer.forward = (lambda mk: (lambda x: (drawn.append("layer"), x * mk)[1]))(masks[H])
+        sg.out_att.draw_keep = (lambda mk: (lambda E, device: (drawn.append("out"), mk.view(1, E))[1]))(masks[H + 1])
+        drawn.clear()
+        out_e, out_r, _ = m(None, T(g["it%d.batch_entities" % it]).to(d), (T(g["it%d.edge" % it]).to(d), T(g["it%d.edge_type" % it]).to(d)),
+                            T(g["it%d.nhop" % it]).to(d))
+        assert drawn == ["head%d" % h for h in range(H)] + ["layer", "out"], drawn          # the reference's draw order
+        close(out_e, g["it%d.out_entity" % it], atol=2e-5, what="train-mode out_entity, iteration %d" % it)
+        close(out_r, g["it%d.out_relation" % it], atol=2e-5, what="train-mode out_relation, iteration %d" % it)
+        opt.zero_grad()
+        loss = batch_gat_loss(loss_fn, T(g["it%d.train_indices" % it]).to(d), out_e, out_r, valid_invalid_ratio_gat=ratio)
+        loss.backward()
+        opt.step()
+        np.testing.assert_allclose(loss.item(), g["losses"][it], rtol=1e-4, err_msg="loss of iteration %d" % it)
+    for k, v in m.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), g["p3." + k], atol=1e-5, rtol=0, err_msg=k)
+        if k not in ("entity_embeddings", "final_entity_embeddings", "final_relation_embeddings"):
+            d_ref = g["p3." + k] - g["p0." + k]                                               # the three SGD updates themselves
+            np.testing.assert_allclose(v.cpu().numpy() - g["p0." + k], d_ref, atol=5e-3 * np.abs(d_ref).max() + 1e-9, err_msg="delta " + k)
+
+
 def test_sep_space_spkbgat_golden():
     """GAT_sep_space: the stage-A model with W_ent2rel — strict state_dict load, forward, the relation-space projection of every
     triple's entities (GAT_sep_space/main.py:359-367) grouped by relation instead of gathered per triple, and every gradient of the

@@ -120,6 +120,39 @@ def test_spkbgat(name):
     np.testing.assert_allclose(tr.numpy(), g["test_relation"], atol=2e-5, rtol=1e-5)
 
 
+def test_spkbgat_train_mode_three_sgd_iterations():
+    """The regime stage A runs (GAT/main.py:478-525): drop_GAT = 0.3, train(), three iterations of forward -> batch_gat_loss -> backward ->
+    SGD on three different batches; the reference's dropout factors (recorded in call order: one E-vector per head, dropout_layer on the
+    concatenated heads, out_att's E-vector — GAT/models.py:71-73, :86; GAT/layers.py:158) are replayed through the oracle."""
+    g = load_golden("spkbgat3_train")
+    H, alpha, lr = int(g["nheads"]), float(g["alpha"]), float(g["lr"])
+    P = {k[3:]: T(g[k]).clone() for k in g if k.startswith("p0.")}
+    trained = [k for k in P if k not in ("final_entity_embeddings", "final_relation_embeddings")]
+    for it in range(3):
+        P["entity_embeddings"] = torch.nn.functional.normalize(P["entity_embeddings"], p=2, dim=1)        # :160, on .data
+        leaves = {k: P[k].clone().requires_grad_(True) for k in trained}
+        masks = [T(g["it%d.mask%d" % (it, h)]) for h in range(H)]
+        out_e, out_r, _ = O.spkbgat_forward(
+            leaves["entity_embeddings"], leaves["relation_embeddings"], T(g["it%d.batch_entities" % it]), T(g["it%d.edge" % it]),
+            T(g["it%d.edge_type" % it]), T(g["it%d.nhop" % it]),
+            [leaves["sparse_gat_1.attention_%d.a" % i] for i in range(H)], [leaves["sparse_gat_1.attention_%d.a_2" % i] for i in range(H)],
+            leaves["sparse_gat_1.W"], leaves["sparse_gat_1.out_att.a"], leaves["sparse_gat_1.out_att.a_2"], leaves["W_entities"], alpha,
+            masks=masks, layer_mask=T(g["it%d.mask%d" % (it, H)]), out_mask=T(g["it%d.mask%d" % (it, H + 1)]))
+        np.testing.assert_allclose(out_e.detach().numpy(), g["it%d.out_entity" % it], atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(out_r.detach().numpy(), g["it%d.out_relation" % it], atol=2e-5, rtol=1e-5)
+        loss = O.batch_gat_loss(T(g["it%d.train_indices" % it]), out_e, out_r, int(g["ratio"]), float(g["margin"]))
+        np.testing.assert_allclose(loss.item(), g["losses"][it], rtol=1e-5)
+        loss.backward()
+        with torch.no_grad():
+            for k in trained:
+                P[k] = leaves[k] - lr * leaves[k].grad
+    for k in trained:
+        d_ref = g["p3." + k] - (g["p0." + k] if k != "entity_embeddings" else g["p3." + k] * 0 + g["p0." + k])
+        np.testing.assert_allclose(P[k].numpy(), g["p3." + k], atol=1e-6, rtol=1e-5, err_msg=k)
+        if k != "entity_embeddings":                                                                       # the SGD updates themselves (lr = 1e-3: tiny against the values)
+            np.testing.assert_allclose(P[k].numpy() - g["p0." + k], d_ref, atol=2e-3 * np.abs(d_ref).max() + 1e-9, err_msg="delta " + k)
+
+
 def _prop_inputs(g):
     n, d, L, B, salt = (int(g[k]) for k in ("n", "d", "L", "B", "salt"))
     C, S, dd = n * (n - 1), 2 * d * n, (2 * d) ** 2

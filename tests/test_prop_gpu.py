@@ -299,6 +299,36 @@ def test_start_entity_embeddings_golden():
     close(ent.grad, ent_c.grad, atol=1e-5, what="g_entity_embeddings")
 
 
+def test_start_entity_embeddings_backward_is_a_fixed_order_kernel():
+    """the backward of make_start_entity_embeddings (utils/context_utils.py:387-426) runs as kernels — pieces of g * templ,
+    then the SpecialSpmmFinal segment walk keyed on the entity ids — no torch op, so two runs are bit-equal (index_add_'s float atomics
+    were not) and the result matches the oracle's autograd at RECON's sizes (B = 50, n = 9, d = 8) with heavily repeated entities."""
+    from recon_amd.propagation import make_start_entity_embeddings, make_start_embedding
+    d_ = dev()
+    B, n, d, U = 50, 9, 8, 37
+    Cn, S = n * (n - 1), 2 * d * n
+    gen = torch.Generator().manual_seed(12)
+    ent = torch.randn(U, d, generator=gen)
+    pos = torch.randint(0, U, (B, Cn, 2), generator=gen)
+    pos[:, :, 0][pos[:, :, 0] % 3 == 0] = 5                            # one entity that owns a third of all first slots: a long segment
+    templ = torch.from_numpy(make_start_embedding(n, d)).float().view(1, Cn, S, 1) * (1.0 + torch.rand(1, Cn, S, 1, generator=gen))
+    Gr = torch.randn(B, Cn, S, 1, generator=gen)
+    grads = []
+    for _ in range(2):
+        e = ent.to(d_).requires_grad_(True)
+        out = make_start_entity_embeddings(e, pos.to(d_), None, d, 0, templ.to(d_), max_num_nodes=n)
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+            out.backward(Gr.to(d_))
+        grads.append(e.grad.clone())
+        ops = {ev.name for ev in prof.events()}
+        assert not any("index_add" in o or "index_put" in o or "scatter" in o for o in ops), sorted(ops)
+    assert torch.equal(grads[0], grads[1])
+    ec = ent.double().requires_grad_(True)
+    ref = O.make_start_entity_embeddings(ec, pos, d, templ.double(), max_num_nodes=n)
+    (ref * Gr.double()).sum().backward()
+    close(grads[0], ec.grad.float(), atol=1e-5, rel_to_max=2e-6, what="g_entity_embeddings (kernel backward)")
+
+
 @pytest.mark.parametrize("name", ["gcn1_bias", "gcn1_nobias"])
 def test_gcn_golden(name):
     """GraphConvolution drop-in (2-D reference form, 72x72 line-graph adjacency) vs the reference."""

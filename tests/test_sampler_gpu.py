@@ -170,3 +170,38 @@ def test_batch_gat_loss_vs_oracle_at_stage_a_size_and_odd_width():
     bad[3, 2] = n_ent
     with pytest.raises(IndexError):
         batch_gat_loss(torch.nn.MarginRankingLoss(margin=1.0), bad.to(d), ent.to(d), rel.to(d), valid_invalid_ratio_gat=ratio)
+
+
+@pytest.mark.gpu
+def test_batch_gat_loss_propagates_nan_and_takes_indices_from_the_host():
+    """ADVICE r5: (1) a NaN embedding row must reach the loss (the reference's clamp_min propagates NaN and GAT/main.py:374 asserts on it;
+    `fmaxf(0, NaN)` is 0) — fused path and fallback — and raise the device NaN word; (2) the reference indexes its CUDA tables with whatever
+    LongTensor it is given, a CPU one included: same loss as with device indices, no device fault."""
+    from recon_amd.losses import batch_gat_loss
+    from recon_amd.gat_layers import nan_raised, enable_nan_flag
+    d = torch.device("cuda:0")
+    enable_nan_flag(d)
+    gen = torch.Generator().manual_seed(5)
+    n_ent, n_rel, D, n_pos, ratio = 40, 5, 16, 12, 2
+    ent, rel = torch.randn(n_ent, D, generator=gen), torch.randn(n_rel, D, generator=gen)
+    pos = torch.stack((torch.randint(0, n_ent, (n_pos,), generator=gen), torch.randint(0, n_rel, (n_pos,), generator=gen),
+                       torch.randint(0, n_ent, (n_pos,), generator=gen)), 1)
+    neg = pos.repeat(2 * ratio, 1)
+    neg[:, 0] = torch.randint(0, n_ent, (neg.shape[0],), generator=gen)
+    tri = torch.cat((pos, neg))
+    fn = torch.nn.MarginRankingLoss(margin=1.0)
+    assert not nan_raised(d)
+    clean = batch_gat_loss(fn, tri.to(d), ent.to(d), rel.to(d), valid_invalid_ratio_gat=ratio)
+    assert torch.isfinite(clean) and not nan_raised(d)
+    host_idx = batch_gat_loss(fn, tri, ent.to(d), rel.to(d), valid_invalid_ratio_gat=ratio)               # CPU LongTensor into CUDA tables
+    assert torch.equal(host_idx, clean)
+    bad = ent.clone()
+    bad[int(pos[3, 0])] = float("nan")
+    for f in (fn, lambda a, b, y: torch.nn.functional.margin_ranking_loss(a, b, y, margin=1.0)):          # fused, then the fallback
+        e = bad.to(d).requires_grad_(True)
+        loss = batch_gat_loss(f, tri.to(d), e, rel.to(d), valid_invalid_ratio_gat=ratio)
+        assert torch.isnan(loss), "a NaN row must reach the loss"
+    assert nan_raised(d), "the fused loss raises the device word"
+    big = ent.clone() * 3e37                                                                               # two overflowing L1 norms: inf - inf
+    loss = batch_gat_loss(fn, tri.to(d), big.to(d), rel.to(d), valid_invalid_ratio_gat=ratio)
+    assert torch.isnan(loss) and nan_raised(d)
