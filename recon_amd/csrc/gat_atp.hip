@@ -16,6 +16,8 @@
 #include <stdlib.h>
 #include "recon_common.h"
 
+#include <type_traits>
+
 namespace recon {
 namespace {
 
@@ -45,6 +47,9 @@ __device__ __forceinline__ void load_in(float (&r)[VEC], const float* base, int6
         }
     }
 }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }      // v_pk_fma_f32
 
 __device__ __forceinline__ float lane_bcast(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
@@ -1005,6 +1010,57 @@ struct AtpBwdK {
     int32_t gee_by_slot;        // edge_embed is a table read through `eid` (recon_gat_atp_args.ee_index): g_ee rows go by CSR slot
 };
 
+// ---- raw buffer access through wave-uniform ROW descriptors (round 6) -------------------------------------------------------------
+// Every row k_gat_atp_bwd touches has a wave-uniform base (a node's block of g_V, the x / edge_embed row of an edge handed out by
+// readlane, the per-slot rows of sigma / g_sigma / Gxs / g_edge_embed).  A descriptor per row — 4 SGPRs, built on the scalar unit —
+// with num_records = the row's bytes makes the hardware's range check the mask: a lane whose byte offset lies past the row loads
+// zeros and stores nothing, so the walk needs neither `lane < F ? v : 0` selects nor exec-masked store blocks, and an access costs
+// ONE VGPR (the lane's byte offset, shared by all rows of an element size) instead of a 64-bit VGPR address (round 5: seven lane base
+// pointers live across the walk, a v_lshl_add_u64 per access — the compiler re-associates `uniform row + lane offset` into
+// `(tensor + lane offset) + uniform`, whatever the source says — and spills among them once anything else grew).
+// On gfx9 soffset IS part of the check (a raw buffer access is dropped when voffset + inst_offset >= num_records - soffset: measured —
+// a window of F x 4 bytes moved by soffset returned zeros for every row but the first), so where one descriptor serves several rows
+// (a node's g_V block, a chunk's per-slot rows: the row / part goes into soffset) num_records covers them all and the lane mask
+// rides in voffset itself: lanes past the row hold an offset no descriptor reaches (kK2Oob).
+constexpr uint32_t kK2Oob = 0x7ffffff0u;
+typedef uint32_t k2_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t k2_u32x2 __attribute__((ext_vector_type(2)));
+#define K2_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(ptr)), 0, static_cast<int>(bytes), 0x00020000)
+template <int VEC>
+__device__ __forceinline__ void buf_load_f32(float (&r)[VEC], __amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+    if constexpr (VEC == 4) {
+        // (elements copied to scalars first: __builtin_bit_cast(float, t.y) on the vector's element reads element 0 — clang 20 / ROCm 7.2)
+        const k2_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+        const uint32_t a = t.x, b = t.y, c = t.z, d = t.w;
+        r[0] = __builtin_bit_cast(float, a); r[1] = __builtin_bit_cast(float, b); r[2] = __builtin_bit_cast(float, c); r[3] = __builtin_bit_cast(float, d);
+    } else {
+        const k2_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+        const uint32_t a = t.x, b = t.y;
+        r[0] = __builtin_bit_cast(float, a); r[1] = __builtin_bit_cast(float, b);
+    }
+}
+template <int VEC, bool B16>
+__device__ __forceinline__ void buf_load_in(float (&r)[VEC], __amdgpu_buffer_rsrc_t rs, uint32_t voff) {      // voff in bytes of the stored element type
+    if constexpr (!B16) {
+        buf_load_f32<VEC>(r, rs, voff, 0);
+    } else if constexpr (VEC == 4) {
+        const k2_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
+        r[0] = __builtin_bit_cast(float, t.x << 16); r[1] = __builtin_bit_cast(float, t.x & 0xffff0000u);
+        r[2] = __builtin_bit_cast(float, t.y << 16); r[3] = __builtin_bit_cast(float, t.y & 0xffff0000u);
+    } else {
+        const uint32_t t = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0);
+        r[0] = __builtin_bit_cast(float, t << 16); r[1] = __builtin_bit_cast(float, t & 0xffff0000u);
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void buf_store_f32(const float (&r)[VEC], __amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff = 0) {
+    if constexpr (VEC == 4)
+        __builtin_amdgcn_raw_buffer_store_b128(k2_u32x4{__builtin_bit_cast(uint32_t, r[0]), __builtin_bit_cast(uint32_t, r[1]), __builtin_bit_cast(uint32_t, r[2]),
+                                                        __builtin_bit_cast(uint32_t, r[3])}, rs, voff, soff, 0);
+    else
+        __builtin_amdgcn_raw_buffer_store_b64(k2_u32x2{__builtin_bit_cast(uint32_t, r[0]), __builtin_bit_cast(uint32_t, r[1])}, rs, voff, soff, 0);
+}
+
 // wave = one destination node; head groups of HT are walked one after the other by the SAME wave so the
 // per-edge outputs (g_edge_embed row, Gxs row) can be accumulated across groups without atomics.
 // Two rows in flight per wave at three waves per SIMD (<= 168 registers) is the measured optimum at cfg 2: a four-deep ring needs
@@ -1039,25 +1095,39 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
     const int cn0 = min(64, end - beg);
     int srcv0 = 0, eidv0 = 0;
     if (beg < end) { const int kk = beg + min(lane, cn0 - 1); srcv0 = p.src[kk]; eidv0 = p.eid[kk]; }
-    for (int idx = threadIdx.x; idx < H * W; idx += kBlock) U[idx] = p.u[idx];
+    if (((H * W) & 3) == 0) {                                            // 16 bytes per request (H W / 4 <= 5 per thread at cfg 2; it was 19 dwords)
+        for (int idx = threadIdx.x; idx < (H * W) >> 2; idx += kBlock) reinterpret_cast<float4*>(U)[idx] = reinterpret_cast<const float4*>(p.u)[idx];
+    } else {
+        for (int idx = threadIdx.x; idx < H * W; idx += kBlock) U[idx] = p.u[idx];
+    }
     __syncthreads();
     if (node >= p.N) return;
-    int cf[KR]; bool aF[KR], aR[KR];
-#pragma unroll
-    for (int r = 0; r < KR; ++r) { cf[r] = (r * 64 + lane) * VEC; aF[r] = cf[r] < F; aR[r] = cf[r] < R; }
-    // branch-free loads throughout (see k_gat_atp_fwd): lanes past F / R read column 0 and are masked by a select or by
-    // never being stored
-    int cfF[KR], cfR[KR];
-#pragma unroll
-    for (int r = 0; r < KR; ++r) { cfF[r] = aF[r] ? cf[r] : 0; cfR[r] = aR[r] ? cf[r] : 0; }
-    float xi[KR][VEC], gxd[KR][VEC];
+    node = __builtin_amdgcn_readfirstlane(node); beg = __builtin_amdgcn_readfirstlane(beg); end = __builtin_amdgcn_readfirstlane(end);
+    constexpr uint32_t ES = B16 ? 2u : 4u;                               // bytes per stored element of x / edge_embed
+    auto in_row = [](const float* base, int64_t row, int width) -> const float* {      // uniform base of row `row` of a [.][width] table of input elements
+        if constexpr (B16) return reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(base) + row * width);
+        else return base + row * width;
+    };
+    // the lane's columns: byte offsets into fp32 rows of F / R columns (voF / voR) and input rows (viF / viR), out of every range for lanes
+    // past the row; uF / uR: the same columns clamped for the LDS rows of u
+    uint32_t voF[KR], voR[KR], viF[KR], viR[KR];
+    int uF[KR], uR[KR];
 #pragma unroll
     for (int r = 0; r < KR; ++r) {
+        const int c = (r * 64 + lane) * VEC;
+        voF[r] = c < F ? static_cast<uint32_t>(c) * 4u : kK2Oob; voR[r] = c < R ? static_cast<uint32_t>(c) * 4u : kK2Oob;
+        viF[r] = c < F ? static_cast<uint32_t>(c) * ES : kK2Oob; viR[r] = c < R ? static_cast<uint32_t>(c) * ES : kK2Oob;
+        uF[r] = c < F ? c : 0; uR[r] = c < R ? c : 0;
+    }
+    float xi[KR][VEC], gxd[KR][VEC];
+    {
+        const auto rxi = K2_RSRC(in_row(p.x, node, F), F * ES);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) gxd[r][v] = 0.f;
-        load_in<VEC, B16>(xi[r], p.x, static_cast<int64_t>(node) * F + cfF[r]);
+        for (int r = 0; r < KR; ++r) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) xi[r][v] = aF[r] ? xi[r][v] : 0.f;
+            for (int v = 0; v < VEC; ++v) gxd[r][v] = 0.f;
+            buf_load_in<VEC, B16>(xi[r], rxi, viF[r]);                   // lanes past F: zeros
+        }
     }
     // lane l works for head h0 + (l >> SH) (the layout multi_sum leaves its totals in); lane h << SH speaks for head h
     constexpr int SH = HT == 8 ? 3 : HT == 4 ? 4 : HT == 2 ? 5 : 6;
@@ -1071,19 +1141,30 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
         // ring of PF register slots (static indices: the loop body is unrolled PF times) holding the rows / score of the next
         // PF edges; filled for the first edges BEFORE the g_V rows are requested, so both are in flight together
         constexpr int PF = KR == 1 ? kK2Ring : (KR == 2 ? 2 : 1);
-        const int mh = hv ? myh : h0;
+        const uint32_t mh4 = static_cast<uint32_t>(hv ? myh : h0) * 4u;
         int c0 = beg, cn = cn0, srcv = srcv0, eidv = eidv0;
         const float* keepp = p.keep ? p.keep : p.sigma;
+        // per-slot rows (sigma, keep, g_sigma, Gxs, g_edge_embed by slot) of a CHUNK of up to 64 slots share one descriptor each, built once
+        // per chunk: base = the chunk's first row, the slot's row in soffset (<= 64 rows: far below 4 GB), num_records = the chunk.
+        // Per edge that leaves the two gathered rows to describe.
+        const uint32_t Hb = static_cast<uint32_t>(H) * 4u, Fb = static_cast<uint32_t>(F) * 4u, Rb = static_cast<uint32_t>(R) * 4u;
+        auto rsg = K2_RSRC(p.sigma + static_cast<int64_t>(c0) * H, 64 * Hb), rkf = K2_RSRC(keepp + static_cast<int64_t>(c0) * H, 64 * Hb);
+        auto rgs = K2_RSRC(p.gsigma + static_cast<int64_t>(c0) * H, 64 * Hb);
+        auto rGx = K2_RSRC(p.Gxs + static_cast<int64_t>(c0) * F, 64 * Fb);
+        auto rGe = K2_RSRC((p.g_ee && p.gee_by_slot) ? p.g_ee + static_cast<int64_t>(c0) * R : p.Gxs, (p.g_ee && p.gee_by_slot) ? 64 * Rb : 0u);
         float xs_r[PF][KR][VEC], re_r[PF][KR][VEC], sg_r[PF], kf_r[PF];
         auto fetch_edge = [&](int slot, int j) {                         // j: position inside the chunk (uniform), clamped by the caller
             const int s_ = __builtin_amdgcn_readlane(srcv, j), e_ = __builtin_amdgcn_readlane(eidv, j);
+            const auto rx = K2_RSRC(in_row(p.x, s_, F), F * ES);
+            const auto re = K2_RSRC(in_row(p.ee, e_, R), R * ES);
 #pragma unroll
-            for (int r = 0; r < KR; ++r) {                               // lanes past F / R: garbage x 0 (their g_V terms are zeroed)
-                load_in<VEC, B16>(xs_r[slot][r], p.x, static_cast<int64_t>(s_) * F + cfF[r]);
-                load_in<VEC, B16>(re_r[slot][r], p.ee, static_cast<int64_t>(e_) * R + cfR[r]);
+            for (int r = 0; r < KR; ++r) {                               // lanes past F / R: zeros
+                buf_load_in<VEC, B16>(xs_r[slot][r], rx, viF[r]);
+                buf_load_in<VEC, B16>(re_r[slot][r], re, viR[r]);
             }
-            sg_r[slot] = p.sigma[static_cast<int64_t>(c0 + j) * H + mh];
-            kf_r[slot] = keepp[static_cast<int64_t>(c0 + j) * H + mh];  // eval: re-reads sigma, replaced by 1 at the use (no branch)
+            const uint32_t so = static_cast<uint32_t>(j) * Hb;
+            sg_r[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsg, mh4, so, 0));
+            kf_r[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rkf, mh4, so, 0));     // eval: re-reads sigma, replaced by 1 at the use (no branch)
         };
         if (beg < end) {
 #pragma unroll
@@ -1095,17 +1176,19 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
         float gVs[HT][KR][VEC], gVr[HT][KR][VEC];
         float pdv[HT];
         const float ql = hv ? p.q[static_cast<int64_t>(node) * H + myh] : 0.f;
+        // the node's rows of g_V: ONE descriptor over the group's rows, the row / part of a request in soffset, the lane mask in voffset
+        const float* gvn = p.gV + (static_cast<int64_t>(node) * H + h0) * W;
+        const auto rgv = K2_RSRC(gvn, min(HT, H - h0) * W * 4);
         if (h0 + HT <= H) {
             // Every head of the group exists (the common case): no guard per head, all 3 HT rows requested together.  A guard around
             // one head's loads is a basic block of its own, and at the join behind it the compiler drains the load counter: eight
             // dependent round trips per node, 20 k of a wave's 45 k cycles (s_memtime stamps at cfg 2: 5.8 k until the score vectors
             // are staged, 20.2 k for these rows, 17.1 k in the edge loop, 2.2 k to the end).  Straight-line, the compiler interleaves
-            // requests and arithmetic within 165 registers; 85 -> 76.6 us (two batches of four heads: 77.2).  The asm keeps the
-            // batch's arithmetic in front of what follows.
+            // requests and arithmetic; 85 -> 76.6 us (two batches of four heads: 77.2).  The asm keeps the batch's arithmetic in front
+            // of what follows.
             // (Measured on top and not kept: the edge loop without its `break` / guarded refill, so that no vmcnt(0) is left at the top
             // of an edge — 80 us, 2 spills; touching every line of the node's rows up front so that the guarded form hits L2 — 90 us.)
             constexpr int HB = HT >= 8 ? 8 : HT;
-            const float* gvn = p.gV + (static_cast<int64_t>(node) * H + h0) * W;
 #pragma unroll
             for (int hb = 0; hb < HT; hb += HB) {
                 float gd[HB][KR][VEC];
@@ -1113,10 +1196,10 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                 for (int t = 0; t < HB; ++t)
 #pragma unroll
                     for (int r = 0; r < KR; ++r) {
-                        const float* row = gvn + static_cast<int64_t>(hb + t) * W;
-                        load_vec<VEC>(gd[t][r], row + cfF[r]);
-                        load_vec<VEC>(gVs[hb + t][r], row + F + cfF[r]);
-                        load_vec<VEC>(gVr[hb + t][r], row + 2 * F + cfR[r]);
+                        const uint32_t row = static_cast<uint32_t>((hb + t) * W) * 4u;
+                        buf_load_f32<VEC>(gd[t][r], rgv, voF[r], row);
+                        buf_load_f32<VEC>(gVs[hb + t][r], rgv, voF[r], row + static_cast<uint32_t>(F) * 4u);
+                        buf_load_f32<VEC>(gVr[hb + t][r], rgv, voR[r], row + static_cast<uint32_t>(2 * F) * 4u);
                     }
 #pragma unroll
                 for (int t = 0; t < HB; ++t) {
@@ -1127,11 +1210,8 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                     for (int r = 0; r < KR; ++r)
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
-                            const float g = aF[r] ? gd[t][r][v] : 0.f;
-                            gVs[h][r][v] = aF[r] ? gVs[h][r][v] : 0.f;
-                            gVr[h][r][v] = aR[r] ? gVr[h][r][v] : 0.f;
-                            pd = fmaf(g, xi[r][v], pd);
-                            gxd[r][v] = fmaf(zr, g, gxd[r][v]);
+                            pd = fmaf(gd[t][r][v], xi[r][v], pd);
+                            gxd[r][v] = fmaf(zr, gd[t][r][v], gxd[r][v]);
                         }
                     pdv[h] = pd;
                 }
@@ -1141,7 +1221,7 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
         // (Requesting all 3 HT rows at once — branch free, the destination part staged through LDS-DMA — was measured: the
         // extra live registers spill at 3 waves per SIMD and the kernel gets slower, 80 -> 91 us at cfg 2; so was a persistent
         // node-pipelined form with the next node's rows in flight: 107 us at the one wave per SIMD its 346 registers allow.
-        // PMC: 1 580 VALU instructions per node keep a SIMD's issue port busy for 42 us of the kernel's 80 as it is.)
+        // PMC: 1 580 VALU instructions per node keep a SIMD's issue port busy for 42 us of the kernel's 80 as it was in round 5.)
 #pragma unroll
         for (int h = 0; h < HT; ++h) {
             float pd = 0.f;
@@ -1152,16 +1232,13 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) { gVs[h][r][v] = 0.f; gVr[h][r][v] = 0.f; }
                 if (hok) {                                                // wave-uniform
-                    const int64_t base = (static_cast<int64_t>(node) * H + h0 + h) * W;
+                    const uint32_t row = static_cast<uint32_t>(h * W) * 4u;
                     float gd[VEC];
-                    load_vec<VEC>(gd, p.gV + base + cfF[r]);
-                    load_vec<VEC>(gVs[h][r], p.gV + base + F + cfF[r]);
-                    load_vec<VEC>(gVr[h][r], p.gV + base + 2 * F + cfR[r]);
+                    buf_load_f32<VEC>(gd, rgv, voF[r], row);
+                    buf_load_f32<VEC>(gVs[h][r], rgv, voF[r], row + static_cast<uint32_t>(F) * 4u);
+                    buf_load_f32<VEC>(gVr[h][r], rgv, voR[r], row + static_cast<uint32_t>(2 * F) * 4u);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
-                        gd[v] = aF[r] ? gd[v] : 0.f;
-                        gVs[h][r][v] = aF[r] ? gVs[h][r][v] : 0.f;
-                        gVr[h][r][v] = aR[r] ? gVr[h][r][v] : 0.f;
                         pd = fmaf(gd[v], xi[r][v], pd);
                         gxd[r][v] = fmaf(zr, gd[v], gxd[r][v]);           // direct path: V_dst = x_i Zk/Z
                     }
@@ -1173,13 +1250,23 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
         const float tdl = multi_sum<HT>(pdv, lane);
         const float gZl = -ql * invl;                                     // d loss / d Z   (every part of V is ~ 1/Z)
         float sum_gs = 0.f;
+        // The walk.  FULL = every head of the group exists (wave-uniform, the common case): the body of an edge is then straight-line code
+        // apart from the ring refill.  Round 6: (1) the rows of u come out of LDS branch-free (clamped columns) — under `if (lane < F)` /
+        // `if (h0 + h < H)` every one of the 16 ds_read_b128 of an edge sat in a block of its own with `s_waitcnt lgkmcnt(0)` right
+        // behind it: sixteen exposed LDS round trips per edge at three waves per SIMD; (2) the dots and the row updates are packed
+        // (v_pk_fma_f32: two fp32 lanes per instruction, the rate the 157 TF/s vector peak is quoted at); (3) the 8-value reduction is
+        // VALU only (multi_sum: v_permlane32/16_swap instead of ds_bpermute); (4) the score path's share of the row bound for
+        // x[src_e], g_sigma[e][h] u_src[h], left this kernel: summed over the edges of a source it is Gs_src[j][h] u_src[h] — once per
+        // node in k_gat_atp_src instead of once per edge here (8 LDS reads and 32 FMAs per edge); (5) rows through buffer descriptors.
+        auto walk = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
         while (c0 < end) {
             for (int j0 = 0; j0 < cn; j0 += PF) {
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     const int j = j0 + u;
                     if (j >= cn) break;                                  // wave-uniform
-                    const int k = c0 + j;                    const int e = __builtin_amdgcn_readlane(eidv, j);
+                    const int e = __builtin_amdgcn_readlane(eidv, j);
                     float xs[KR][VEC], re[KR][VEC];
 #pragma unroll
                     for (int r = 0; r < KR; ++r)
@@ -1190,11 +1277,15 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                     float part[HT];
 #pragma unroll
                     for (int h = 0; h < HT; ++h) {
-                        part[h] = 0.f;
+                        f32x2 acc = {0.f, 0.f};
 #pragma unroll
                         for (int r = 0; r < KR; ++r)
 #pragma unroll
-                            for (int v = 0; v < VEC; ++v) part[h] = fmaf(gVs[h][r][v], xs[r][v], fmaf(gVr[h][r][v], re[r][v], part[h]));
+                            for (int v = 0; v < VEC; v += 2) {
+                                acc = pk_fma(f32x2{gVs[h][r][v], gVs[h][r][v + 1]}, f32x2{xs[r][v], xs[r][v + 1]}, acc);
+                                acc = pk_fma(f32x2{gVr[h][r][v], gVr[h][r][v + 1]}, f32x2{re[r][v], re[r][v + 1]}, acc);
+                            }
+                        part[h] = acc.x + acc.y;
                     }
                     const float tl = multi_sum<HT>(part, lane);
                     const float w = hv ? __expf(-(sg > 0.f ? sg : p.alpha * sg)) : 0.f;      // v_exp_f32: 2 ulp, enough for a gradient factor
@@ -1202,49 +1293,55 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                     const float gs = hv ? -gw * w * (sg > 0.f ? 1.f : p.alpha) : 0.f;
                     const float al_ = kf * w * invl;
                     sum_gs += gs;
-                    if (hv && writer) p.gsigma[static_cast<int64_t>(k) * H + myh] = gs;
-                    float gxs[KR][VEC], gr[KR][VEC];
+                    if (hv && writer) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, gs), rgs, mh4, static_cast<uint32_t>(j) * Hb, 0);
+                    f32x2 gxs[KR][VEC / 2], gr[KR][VEC / 2];
 #pragma unroll
                     for (int r = 0; r < KR; ++r)
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) { gxs[r][v] = 0.f; gr[r][v] = 0.f; }
+                        for (int v = 0; v < VEC / 2; ++v) { gxs[r][v] = f32x2{0.f, 0.f}; gr[r][v] = f32x2{0.f, 0.f}; }
+                    // the rows of u are the same for every edge: left alone, the compiler hoists all HT KR reads out of the walk and then
+                    // spills them.  An offset it cannot see through keeps them here.
+                    int u_off = 0;
+                    asm volatile("" : "+v"(u_off));
+                    // a head's two factors are wave-uniform (readlane): as v_pk_fma_f32 operands each would take an SGPR PAIR of which only the
+                    // low half is read; {al, gs} of a head share ONE pair instead, broadcast by op_sel (low half / high half) — 2 HT scalar
+                    // registers, not 4 HT: the walk runs out of them otherwise (forty spill reloads, v_readlane from a spill register, per edge)
 #pragma unroll
                     for (int h = 0; h < HT; ++h) {
-                        if (h0 + h < H) {
-                            const float ah = lane_bcast(al_, h << SH), bh = lane_bcast(gs, h << SH);
-                            const float* uh = U + (h0 + h) * W;
+                        if (FULL || h0 + h < H) {                         // (not FULL: wave-uniform)
+                            const f32x2 ab = {lane_bcast(al_, h << SH), lane_bcast(gs, h << SH)};
+                            const f32x2 ah2 = __builtin_shufflevector(ab, ab, 0, 0), bh2 = __builtin_shufflevector(ab, ab, 1, 1);
+                            const float* uh = U + (h0 + h) * W + 2 * F + u_off;
 #pragma unroll
                             for (int r = 0; r < KR; ++r) {
-                                float us[VEC], ur[VEC];
-                                if (aF[r]) {
-                                    load_vec<VEC>(us, uh + F + cf[r]);
+                                float ur[VEC];
+                                load_vec<VEC>(ur, uh + uR[r]);
 #pragma unroll
-                                    for (int v = 0; v < VEC; ++v) gxs[r][v] = fmaf(ah, gVs[h][r][v], fmaf(bh, us[v], gxs[r][v]));
-                                }
-                                if (aR[r]) {
-                                    load_vec<VEC>(ur, uh + 2 * F + cf[r]);
-#pragma unroll
-                                    for (int v = 0; v < VEC; ++v) gr[r][v] = fmaf(ah, gVr[h][r][v], fmaf(bh, ur[v], gr[r][v]));
+                                for (int v = 0; v < VEC; v += 2) {
+                                    gxs[r][v / 2] = pk_fma(ah2, f32x2{gVs[h][r][v], gVs[h][r][v + 1]}, gxs[r][v / 2]);
+                                    gr[r][v / 2] = pk_fma(ah2, f32x2{gVr[h][r][v], gVr[h][r][v + 1]}, pk_fma(bh2, f32x2{ur[v], ur[v + 1]}, gr[r][v / 2]));
                                 }
                             }
                         }
                     }
+                    // g_edge_embed rows go by slot (a table read through an index: the caller sums them per table row) or by edge id
+                    const bool ge_edge = p.g_ee && !p.gee_by_slot;       // wave-uniform
+                    const auto rGee = ge_edge ? K2_RSRC(p.g_ee + static_cast<int64_t>(e) * R, Rb) : rGe;
+                    const uint32_t sox = static_cast<uint32_t>(j) * Fb, soe = ge_edge ? 0u : static_cast<uint32_t>(j) * Rb;
 #pragma unroll
                     for (int r = 0; r < KR; ++r) {
-                        if (aF[r]) {
-                            float* dst = p.Gxs + static_cast<int64_t>(k) * F + cf[r];
-                            if (hg > 0) { float o[VEC]; load_vec<VEC>(o, dst);
+                        float ox[VEC], orr[VEC];
 #pragma unroll
-                                for (int v = 0; v < VEC; ++v) gxs[r][v] += o[v]; }
-                            store_vec<VEC>(dst, gxs[r]);
-                        }
-                        if (aR[r] && p.g_ee) {
-                            float* dst = p.g_ee + static_cast<int64_t>(p.gee_by_slot ? k : e) * R + cf[r];
-                            if (hg > 0) { float o[VEC]; load_vec<VEC>(o, dst);
+                        for (int v = 0; v < VEC; v += 2) { ox[v] = gxs[r][v / 2].x; ox[v + 1] = gxs[r][v / 2].y; orr[v] = gr[r][v / 2].x; orr[v + 1] = gr[r][v / 2].y; }
+                        if (hg > 0) {                                    // wave-uniform: a later head group adds to the rows the first one wrote
+                            float o1[VEC], o2[VEC];
+                            buf_load_f32<VEC>(o1, rGx, voF[r], sox);
+                            buf_load_f32<VEC>(o2, rGee, voR[r], soe);
 #pragma unroll
-                                for (int v = 0; v < VEC; ++v) gr[r][v] += o[v]; }
-                            store_vec<VEC>(dst, gr[r]);
+                            for (int v = 0; v < VEC; ++v) { ox[v] += o1[v]; orr[v] += o2[v]; }
                         }
+                        buf_store_f32<VEC>(ox, rGx, voF[r], sox);       // lanes past F / R (and every lane without g_edge_embed): dropped by the range check
+                        buf_store_f32<VEC>(orr, rGee, voR[r], soe);
                     }
                 }
             }
@@ -1253,10 +1350,16 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                 cn = min(64, end - c0);
                 const int kk = c0 + min(lane, cn - 1);
                 srcv = p.src[kk]; eidv = p.eid[kk];
+                rsg = K2_RSRC(p.sigma + static_cast<int64_t>(c0) * H, 64 * Hb); rkf = K2_RSRC(keepp + static_cast<int64_t>(c0) * H, 64 * Hb);
+                rgs = K2_RSRC(p.gsigma + static_cast<int64_t>(c0) * H, 64 * Hb);
+                rGx = K2_RSRC(p.Gxs + static_cast<int64_t>(c0) * F, 64 * Fb);
+                rGe = K2_RSRC((p.g_ee && p.gee_by_slot) ? p.g_ee + static_cast<int64_t>(c0) * R : p.Gxs, (p.g_ee && p.gee_by_slot) ? 64 * Rb : 0u);
 #pragma unroll
                 for (int u = 0; u < PF; ++u) fetch_edge(u, min(u, cn - 1));
             }
         }
+        };
+        if (h0 + HT <= H) walk(std::true_type{}); else walk(std::false_type{});
         if (hv && writer) {
             if (is_piece) p.hubG[static_cast<int64_t>(widx) * H + myh] = sum_gs;
             else p.Gs_dst[static_cast<int64_t>(node) * 2 * H + myh] = sum_gs;
@@ -1267,20 +1370,19 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                 const float sh = lane_bcast(sum_gs, h << SH);
                 const float* uh = U + (h0 + h) * W;
 #pragma unroll
-                for (int r = 0; r < KR; ++r)
-                    if (aF[r]) {
-                        float ud[VEC];
-                        load_vec<VEC>(ud, uh + cf[r]);
+                for (int r = 0; r < KR; ++r) {
+                    float ud[VEC];
+                    load_vec<VEC>(ud, uh + uF[r]);                      // lanes past F: column 0, never stored
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) gxd[r][v] = fmaf(sh, ud[v], gxd[r][v]);
-                    }
+                    for (int v = 0; v < VEC; ++v) gxd[r][v] = fmaf(sh, ud[v], gxd[r][v]);
+                }
             }
         }
     }
     if (is_piece) return;                                                // k_gat_atp_hub_bwd adds the pieces' share to the node's row
+    const auto rgx = K2_RSRC(p.gxd + static_cast<int64_t>(node) * F, F * 4);
 #pragma unroll
-    for (int r = 0; r < KR; ++r)
-        if (aF[r]) store_vec<VEC>(p.gxd + static_cast<int64_t>(node) * F + cf[r], gxd[r]);
+    for (int r = 0; r < KR; ++r) buf_store_f32<VEC>(gxd[r], rgx, voF[r]);
 }
 
 // The second half of a hub's backward: wave = one hub.  Adds the pieces' sums of g_sigma in table order to Gs_dst (the node's own
@@ -1319,6 +1421,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_hub_bwd(const AtpBwdK p, con
 struct AtpSrcK {
     const int32_t* rowptr_src; const int32_t* slot_by_src; const float* Gxs; const float* gxd; const float* gsigma;
     float* g_x; float* Gs_src;
+    const float* u; int32_t W;  // score vectors [H][W]: the row of node j also takes sum_h Gs_src[j][h] u_src[h] (k_gat_atp_bwd leaves that term to this pass)
     int32_t N, F, H;
     // hub rows of the CSC view (recon_graph): the first n_piece waves sum one piece each into hubP [n_piece][F + H] (g_x part | sums of
     // g_sigma); the wave of a node with more than hub_chunk positions leaves its row to k_gat_atp_hub_src.  hub_chunk = 0: off.
@@ -1394,6 +1497,29 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_src(const AtpSrcK p) {
     float* gs_out = is_piece ? p.hubP + static_cast<int64_t>(widx) * (F + H) + F : p.Gs_src + static_cast<int64_t>(node) * 2 * H + H;
     float* row_out = is_piece ? p.hubP + static_cast<int64_t>(widx) * (F + H) : p.g_x + static_cast<int64_t>(node) * F;
     if (lane < H) gs_out[lane] = gs;
+    if (!is_piece && p.g_x) {                                            // uniform.  + sum_h Gs_src[node][h] u_src[h][:], heads in order (H <= 64)
+        constexpr int HBK = KR <= 2 ? 8 : 2;                             // rows of u requested together (L2 hits: one round trip per batch, not per head)
+        for (int hb = 0; hb < H; hb += HBK) {
+            float us[HBK][KR][VEC];
+#pragma unroll
+            for (int t = 0; t < HBK; ++t) {
+                const float* uh = p.u + static_cast<int64_t>(min(hb + t, H - 1)) * p.W + F;
+#pragma unroll
+                for (int r = 0; r < KR; ++r) {
+                    const int c = (r * 64 + lane) * VEC;
+                    load_vec<VEC>(us[t][r], uh + (c < F ? c : 0));
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < HBK; ++t) {
+                const float sh = hb + t < H ? lane_bcast(gs, min(hb + t, 63)) : 0.f;      // heads in order; past H: + 0
+#pragma unroll
+                for (int r = 0; r < KR; ++r)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[r][v] = fmaf(sh, us[t][r][v], acc[r][v]);
+            }
+        }
+    }
     if (p.g_x) {
 #pragma unroll
         for (int r = 0; r < KR; ++r) {
@@ -1419,15 +1545,15 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_hub_src(const AtpSrcK p, con
     if (idx >= n_hub * stripes) return;
     const int t = idx / stripes, c = (idx - t * stripes) * 64 + lane;
     const int node = hub_node[t], p0 = hub_ptr[t], p1 = hub_ptr[t + 1];
-    if (c < H) {                                                         // stripe 0 (H <= 64)
-        float gs[1] = {0.f};
-        sum_pieces<1>(gs, p.hubP + F + c, F + H, p0, p1);
-        p.Gs_src[static_cast<int64_t>(node) * 2 * H + H + c] = gs[0];
-    }
-    if (!p.g_x || c >= F) return;
-    float a[1] = {p.gxd[static_cast<int64_t>(node) * F + c]};
-    sum_pieces<1>(a, p.hubP + c, F + H, p0, p1);
-    p.g_x[static_cast<int64_t>(node) * F + c] = a[0];
+    // every wave of the hub needs all H sums (its stripe of the row takes sum_h Gs_src[h] u_src[h]): lane h < H adds them up, in table order
+    float gsl[1] = {0.f};
+    if (lane < H) sum_pieces<1>(gsl, p.hubP + F + lane, F + H, p0, p1);
+    if (c < H) p.Gs_src[static_cast<int64_t>(node) * 2 * H + H + c] = gsl[0];      // stripe 0: c == lane
+    if (!p.g_x) return;
+    float a[1] = {c < F ? p.gxd[static_cast<int64_t>(node) * F + c] : 0.f};
+    if (c < F) sum_pieces<1>(a, p.hubP + c, F + H, p0, p1);
+    for (int h = 0; h < H; ++h) a[0] = fmaf(lane_bcast(gsl[0], h), p.u[static_cast<int64_t>(h) * p.W + F + (c < F ? c : 0)], a[0]);
+    if (c < F) p.g_x[static_cast<int64_t>(node) * F + c] = a[0];
 }
 
 
@@ -1969,7 +2095,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
     {
         AtpSrcK p;
         p.rowptr_src = g->rowptr_src; p.slot_by_src = g->slot_by_src; p.Gxs = b->Gxs; p.gxd = b->gxd; p.gsigma = b->g_sigma;
-        p.g_x = b->g_x; p.Gs_src = b->Gs;
+        p.g_x = b->g_x; p.Gs_src = b->Gs; p.u = a->u; p.W = W;
         p.N = N; p.F = F; p.H = H;
         const bool hubs = g->hub_chunk > 0 && g->n_hub_src > 0 && g->n_piece_src > 0 && g->hub_node_src && g->hub_ptr_src && g->piece_src && g->hub_ws;
         if (hubs && static_cast<size_t>(g->hub_ws_floats) < recon_graph_hub_ws_floats(g, F, R, H)) return RECON_ERR_WORKSPACE;

@@ -32,9 +32,20 @@ __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
+__device__ __forceinline__ float swap_add32(float a, float b) {          // lanes < 32: a[l] + a[l + 32];  lanes >= 32: b[l - 32] + b[l]
+    // (elements copied to scalars first: __builtin_bit_cast applied to an element of an ext_vector reads element 0 — clang 20 / ROCm 7.2)
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ float swap_add16(float a, float b) {          // even 16-lane rows: a[l] + a[l + 16];  odd rows: b[l - 16] + b[l]
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
 // Sum over aligned groups of G consecutive lanes (G = 4..64, power of two); every lane of the
-// group receives the total.  Quad and row steps are DPP; the 32- and 64-lane steps go through
-// ds_bpermute (__shfl_xor).  Summation order is fixed => deterministic.
+// group receives the total.  Quad and row steps are DPP; the 32- and 64-lane steps are v_permlane16_swap / v_permlane32_swap
+// (round 6; they went through ds_bpermute: same operands per add, bit-identical sums).  Summation order is fixed => deterministic.
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
     static_assert(G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "group width");
@@ -42,14 +53,19 @@ __device__ __forceinline__ float group_sum(float v) {
     v += dpp_mov<0x4E>(v);                      // quad_perm [2,3,0,1]
     if constexpr (G >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror
     if constexpr (G >= 16) v += dpp_mov<0x140>(v);  // row_mirror
-    if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
-    if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
+    if constexpr (G >= 32) v = swap_add16(v, v);
+    if constexpr (G >= 64) v = swap_add32(v, v);
     return v;
 }
 
 // Reduce NV per-lane values over the 64 lanes of a wave at once: each halving step exchanges HALF of the
 // remaining values with the lane whose bit (32, 16, 8) differs, so NV values cost NV-1 exchanges + log2(64/NV)
 // DPP steps instead of NV full reductions.  Lane l ends up with the total of value index l >> (6 - log2 NV).
+// The exchanges across lane bits 32 and 16 are v_permlane32_swap / v_permlane16_swap (gfx950): ONE VALU instruction swaps the upper
+// 32-lane (odd 16-lane) rows of one register with the lower (even) rows of another — both halves of a butterfly step — where
+// __shfl_xor went through the LDS crossbar (ds_bpermute + two selects per value, and an lgkmcnt wait in front of every add: 31
+// instructions and seven exposed LDS round trips per 8 values in k_gat_atp_bwd's edge loop, now 18 and none).  Same operands per
+// add as before: results are bit-identical.
 template <int NV>
 __device__ __forceinline__ float multi_sum(float (&v)[NV], int lane) {
     static_assert(NV == 1 || NV == 2 || NV == 4 || NV == 8, "values per wave");
@@ -57,23 +73,20 @@ __device__ __forceinline__ float multi_sum(float (&v)[NV], int lane) {
         return group_sum<64>(v[0]);
     } else {
         float w[NV / 2];
-        const bool up = lane & 32;
 #pragma unroll
-        for (int j = 0; j < NV / 2; ++j) w[j] = (up ? v[j + NV / 2] : v[j]) + __shfl_xor(up ? v[j] : v[j + NV / 2], 32, 64);
+        for (int j = 0; j < NV / 2; ++j) w[j] = swap_add32(v[j], v[j + NV / 2]);
         if constexpr (NV == 2) {
-            float r = w[0];
-            r += __shfl_xor(r, 16, 64);
-            return group_sum<16>(r);
+            return group_sum<16>(swap_add16(w[0], w[0]));
         } else {
             float x[NV / 4];
-            const bool up2 = lane & 16;
 #pragma unroll
-            for (int j = 0; j < NV / 4; ++j) x[j] = (up2 ? w[j + NV / 4] : w[j]) + __shfl_xor(up2 ? w[j] : w[j + NV / 4], 16, 64);
+            for (int j = 0; j < NV / 4; ++j) x[j] = swap_add16(w[j], w[j + NV / 4]);
             if constexpr (NV == 4) {
                 return group_sum<16>(x[0]);
             } else {
                 const bool up3 = lane & 8;
-                const float r = (up3 ? x[1] : x[0]) + __shfl_xor(up3 ? x[0] : x[1], 8, 64);
+                const float mine = up3 ? x[1] : x[0], other = up3 ? x[0] : x[1];
+                const float r = mine + dpp_mov<0x128>(other);             // row_ror:8 — lane l reads lane l ^ 8 of its 16-lane row
                 return group_sum<8>(r);
             }
         }
