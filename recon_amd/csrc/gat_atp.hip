@@ -1008,6 +1008,7 @@ struct AtpBwdK {
     const int4* piece;
     float* hubG;
     int32_t gee_by_slot;        // edge_embed is a table read through `eid` (recon_gat_atp_args.ee_index): g_ee rows go by CSR slot
+    int32_t pieces;             // 1: this launch walks the hub pieces, one per wave; 0: the nodes, persistent waves (k_gat_atp_bwd)
 };
 
 // ---- raw buffer access through wave-uniform ROW descriptors (round 6) -------------------------------------------------------------
@@ -1064,7 +1065,8 @@ __device__ __forceinline__ void buf_store_f32(const float (&r)[VEC], __amdgpu_bu
 // wave = one destination node; head groups of HT are walked one after the other by the SAME wave so the
 // per-edge outputs (g_edge_embed row, Gxs row) can be accumulated across groups without atomics.
 // Two rows in flight per wave at three waves per SIMD (<= 168 registers) is the measured optimum at cfg 2: a four-deep ring needs
-// 197 registers (two waves per SIMD: 101 us against 80), four deep at three waves spills (130 us).
+// 197 registers (two waves per SIMD: 101 us against 80), four deep at three waves spills (130 us; round 6, with the walk's registers down
+// by the packed arithmetic: still 256 bytes of scratch inside the walk).
 constexpr int kK2Ring = 2, kK2WavesPerSimd = 3;
 // Wide rows (KR >= 4 register rows per lane: out_att-sized inputs) get the register budget of two waves per SIMD, KR = 8 of one: at
 // three the KR = 8 form spilled 259 registers (0.73 ms per call at N = 8 192, F = R = 1 600).
@@ -1073,28 +1075,37 @@ constexpr int kK2Ring = 2, kK2WavesPerSimd = 3;
 template <int VEC, int KR, int HT, bool B16 = false>
 __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >= 4 || KR * HT >= 8 && KR >= 2) ? 2 : kK2WavesPerSimd)) k_gat_atp_bwd(const AtpBwdK p) {
     extern __shared__ __attribute__((aligned(16))) float U[];          // [H][W]: u_dst | u_src | u_rel per head
+#ifdef RECON_K2_STAMPS                                                   // cycle stamps of every wave, left in its gxd row instead of the gradient (tools/probe/k2_stamps.py)
+    uint64_t stamp_[6];
+    stamp_[0] = __builtin_readcyclecounter();
+#endif
     const int F = p.F, R = p.R, H = p.H, W = 2 * F + R;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // pieces first (they are the longest rows of the launch), in blockIdx order so that they are dealt round over the XCDs; the
-    // nodes behind them in XCD-contiguous ranges
-    const int npb = (p.n_piece + kBlock / 64 - 1) / (kBlock / 64);
-    const int widx = blockIdx.x * (kBlock / 64) + wave;                  // piece id in a piece block
-    const bool is_piece = static_cast<int>(blockIdx.x) < npb && widx < p.n_piece;
-    int node = static_cast<int>(blockIdx.x) < npb ? p.N : xcd_block(blockIdx.x - npb, gridDim.x - npb) * (kBlock / 64) + wave;
+    // Two launches of this kernel (p.pieces): the hub PIECES, one per wave (the longest rows: their own grid, dealt round over the XCDs
+    // in blockIdx order), and the NODES by persistent waves — round 6.  Cycle stamps of the one-node-per-wave form at cfg 2 (39 k cycles
+    // per wave): 9.4 k from entry until the row pointers, the slot indices (two dependent round trips) and the block's copy of u were
+    // there, 18.7 k for the node's rows of g_V, 10.6 k for the walk — a wave asked the memory system for nothing during half of its
+    // life.  A persistent wave stages u once and has the NEXT node's row pointers and index vectors in flight under the current node's
+    // rows: a node then starts with its requests.  XCD x (blocks x, x + 8, ...) owns the nodes [x, x + 1) * ceil(N / 8): the rows of x a
+    // batched graph's edges gather stay in ONE L2.
+    const bool is_piece = p.pieces != 0;                                 // uniform over the launch
+    const int widx = blockIdx.x * (kBlock / 64) + wave;                  // piece id in a pieces launch
+    const int xcd = blockIdx.x & 7, nbx = (gridDim.x + 7 - xcd) >> 3;    // blocks of this XCD (any grid size)
+    const int nchunk = (p.N + 7) >> 3;
+    const int node_hi = min(p.N, (xcd + 1) * nchunk), node_stride = nbx * (kBlock / 64);
+    int node = is_piece ? p.N : xcd * nchunk + (blockIdx.x >> 3) * (kBlock / 64) + wave;
     // The walk is a chain of dependent round trips (row pointers -> slot indices -> rows); start it before anything else:
     // the slot -> (source node, edge id) indices of the first 64 slots come with ONE coalesced load per array (lane j holds
     // slot beg + j) and are handed out with v_readlane instead of an index load in front of every row load.
-    int beg, end;
-    if (is_piece) { const int4 pc = p.piece[widx]; node = pc.x; beg = pc.y; end = pc.z; }
-    else {
-        const int nodec = min(node, p.N - 1);
-        beg = p.rowptr[nodec]; end = p.rowptr[nodec + 1];
+    int beg = 0, end = 0;
+    if (is_piece) { if (widx < p.n_piece) { const int4 pc = p.piece[widx]; node = pc.x; beg = pc.y; end = pc.z; } }
+    else if (node < node_hi) {
+        beg = p.rowptr[node]; end = p.rowptr[node + 1];
         if (p.hub_chunk && end - beg > p.hub_chunk) end = beg;           // a hub: its pieces walk the row
-    }
-    const int cn0 = min(64, end - beg);
+    } else node = p.N;
     int srcv0 = 0, eidv0 = 0;
-    if (beg < end) { const int kk = beg + min(lane, cn0 - 1); srcv0 = p.src[kk]; eidv0 = p.eid[kk]; }
+    if (beg < end) { const int kk = beg + min(lane, min(64, end - beg) - 1); srcv0 = p.src[kk]; eidv0 = p.eid[kk]; }
     if (((H * W) & 3) == 0) {                                            // 16 bytes per request (H W / 4 <= 5 per thread at cfg 2; it was 19 dwords)
         for (int idx = threadIdx.x; idx < (H * W) >> 2; idx += kBlock) reinterpret_cast<float4*>(U)[idx] = reinterpret_cast<const float4*>(p.u)[idx];
     } else {
@@ -1102,7 +1113,6 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
     }
     __syncthreads();
     if (node >= p.N) return;
-    node = __builtin_amdgcn_readfirstlane(node); beg = __builtin_amdgcn_readfirstlane(beg); end = __builtin_amdgcn_readfirstlane(end);
     constexpr uint32_t ES = B16 ? 2u : 4u;                               // bytes per stored element of x / edge_embed
     auto in_row = [](const float* base, int64_t row, int width) -> const float* {      // uniform base of row `row` of a [.][width] table of input elements
         if constexpr (B16) return reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(base) + row * width);
@@ -1119,6 +1129,21 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
         viF[r] = c < F ? static_cast<uint32_t>(c) * ES : kK2Oob; viR[r] = c < R ? static_cast<uint32_t>(c) * ES : kK2Oob;
         uF[r] = c < F ? c : 0; uR[r] = c < R ? c : 0;
     }
+#pragma unroll 1
+    for (;;) {                                                           // ---- one node (or piece) per iteration
+#ifdef RECON_K2_STAMPS
+    stamp_[1] = __builtin_readcyclecounter();
+#endif
+    node = __builtin_amdgcn_readfirstlane(node); beg = __builtin_amdgcn_readfirstlane(beg); end = __builtin_amdgcn_readfirstlane(end);
+    const int cn0 = min(64, end - beg);
+    // the next node of this wave: its row pointers are requested now, its index vectors below (behind this node's first requests)
+    const int nnode = is_piece ? p.N : node + node_stride;
+    const bool more = nnode < node_hi;                                   // wave-uniform
+    int nbeg = 0, nend = 0;
+    if (more) { nbeg = p.rowptr[nnode]; nend = p.rowptr[nnode + 1]; }
+    // its index vectors wait in LDS (2 x 256 bytes per wave behind the rows of u), not in registers: two more live registers across the
+    // walk were spilled the moment they arrived — a vmcnt(0) each, in front of the g_V requests
+    int* const nidx = reinterpret_cast<int*>(U + H * W) + wave * 128 + lane;
     float xi[KR][VEC], gxd[KR][VEC];
     {
         const auto rxi = K2_RSRC(in_row(p.x, node, F), F * ES);
@@ -1170,12 +1195,22 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
 #pragma unroll
             for (int u = 0; u < PF; ++u) fetch_edge(u, min(u, cn - 1));
         }
-        const float Zl = hv ? p.Z[static_cast<int64_t>(node) * H + myh] : 1.f;
-        const float Zkl = hv ? p.Zk[static_cast<int64_t>(node) * H + myh] : 0.f;
-        const float invl = 1.f / Zl;
+        // Z, Zk, q of the node's heads through one descriptor each (lanes of missing heads read head h0's and are masked at the use): requested
+        // BEHIND the rows of g_V below — in front of them the three words were spilled as they arrived, a vmcnt(0) each, and the batch of
+        // g_V requests left a round trip late
+        const auto rZ = K2_RSRC(p.Z + static_cast<int64_t>(node) * H, H * 4), rZk = K2_RSRC(p.Zk + static_cast<int64_t>(node) * H, H * 4);
+        const auto rq = K2_RSRC(p.q + static_cast<int64_t>(node) * H, H * 4);
+        float Zl, Zkl, ql;
+        auto load_norms = [&]() {
+            Zl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rZ, mh4, 0, 0));
+            Zkl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rZk, mh4, 0, 0));
+            ql = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rq, mh4, 0, 0));
+        };
         float gVs[HT][KR][VEC], gVr[HT][KR][VEC];
         float pdv[HT];
-        const float ql = hv ? p.q[static_cast<int64_t>(node) * H + myh] : 0.f;
+        if (hg == 0 && more && p.hub_chunk && nend - nbeg > p.hub_chunk) nend = nbeg;      // (wave-uniform) a hub: its pieces walk the row
+        const bool nfetch = hg == 0 && more && nbeg < nend;              // wave-uniform
+        int nsrcv = 0, neidv = 0;
         // the node's rows of g_V: ONE descriptor over the group's rows, the row / part of a request in soffset, the lane mask in voffset
         const float* gvn = p.gV + (static_cast<int64_t>(node) * H + h0) * W;
         const auto rgv = K2_RSRC(gvn, min(HT, H - h0) * W * 4);
@@ -1201,10 +1236,19 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                         buf_load_f32<VEC>(gVs[hb + t][r], rgv, voF[r], row + static_cast<uint32_t>(F) * 4u);
                         buf_load_f32<VEC>(gVr[hb + t][r], rgv, voR[r], row + static_cast<uint32_t>(2 * F) * 4u);
                     }
+                if (hb == 0) load_norms();
+                if (hb == 0 && nfetch) { const int kk = nbeg + min(lane, min(64, nend - nbeg) - 1); nsrcv = p.src[kk]; neidv = p.eid[kk]; }
+                // every request of the batch is issued before the first of them is waited for: left to itself the scheduler (it works
+                // towards the three-waves-per-SIMD register budget) loads a head's three rows, waits, folds the destination row away, and
+                // only then asks for the next head — eight dependent round trips per node (cycle stamps: 21.6 k of a wave's 38.6 k cycles)
+                __builtin_amdgcn_sched_barrier(0);
+                if (hb == 0) { Zl = hv ? Zl : 1.f; Zkl = hv ? Zkl : 0.f; ql = hv ? ql : 0.f; }
+                if (hb == 0 && nfetch) { nidx[0] = nsrcv; nidx[64] = neidv; }
+                const float zrl = Zkl / Zl;
 #pragma unroll
                 for (int t = 0; t < HB; ++t) {
                     const int h = hb + t;
-                    const float zr = lane_bcast(Zkl * invl, h << SH);
+                    const float zr = lane_bcast(zrl, h << SH);
                     float pd = 0.f;
 #pragma unroll
                     for (int r = 0; r < KR; ++r)
@@ -1222,11 +1266,15 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
         // extra live registers spill at 3 waves per SIMD and the kernel gets slower, 80 -> 91 us at cfg 2; so was a persistent
         // node-pipelined form with the next node's rows in flight: 107 us at the one wave per SIMD its 346 registers allow.
         // PMC: 1 580 VALU instructions per node keep a SIMD's issue port busy for 42 us of the kernel's 80 as it was in round 5.)
+        load_norms();
+        if (nfetch) { const int kk = nbeg + min(lane, min(64, nend - nbeg) - 1); nidx[0] = p.src[kk]; nidx[64] = p.eid[kk]; }
+        Zl = hv ? Zl : 1.f; Zkl = hv ? Zkl : 0.f; ql = hv ? ql : 0.f;
+        const float zrl = Zkl / Zl;
 #pragma unroll
         for (int h = 0; h < HT; ++h) {
             float pd = 0.f;
             const bool hok = h0 + h < H;                                  // wave-uniform
-            const float zr = lane_bcast(Zkl * invl, h << SH);
+            const float zr = lane_bcast(zrl, h << SH);
 #pragma unroll
             for (int r = 0; r < KR; ++r) {
 #pragma unroll
@@ -1247,7 +1295,11 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
             pdv[h] = pd;
         }
         }
+        const float invl = 1.f / Zl;
         const float tdl = multi_sum<HT>(pdv, lane);
+#ifdef RECON_K2_STAMPS
+        stamp_[2] = __builtin_readcyclecounter();
+#endif
         const float gZl = -ql * invl;                                     // d loss / d Z   (every part of V is ~ 1/Z)
         float sum_gs = 0.f;
         // The walk.  FULL = every head of the group exists (wave-uniform, the common case): the body of an edge is then straight-line code
@@ -1301,11 +1353,9 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                         for (int v = 0; v < VEC / 2; ++v) { gxs[r][v] = f32x2{0.f, 0.f}; gr[r][v] = f32x2{0.f, 0.f}; }
                     // the rows of u are the same for every edge: left alone, the compiler hoists all HT KR reads out of the walk and then
                     // spills them.  An offset it cannot see through keeps them here.
+                    // (a head's two factors are wave-uniform — readlane — and reach v_pk_fma_f32 as scalar operands broadcast by op_sel)
                     int u_off = 0;
                     asm volatile("" : "+v"(u_off));
-                    // a head's two factors are wave-uniform (readlane): as v_pk_fma_f32 operands each would take an SGPR PAIR of which only the
-                    // low half is read; {al, gs} of a head share ONE pair instead, broadcast by op_sel (low half / high half) — 2 HT scalar
-                    // registers, not 4 HT: the walk runs out of them otherwise (forty spill reloads, v_readlane from a spill register, per edge)
 #pragma unroll
                     for (int h = 0; h < HT; ++h) {
                         if (FULL || h0 + h < H) {                         // (not FULL: wave-uniform)
@@ -1314,6 +1364,9 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                             const float* uh = U + (h0 + h) * W + 2 * F + u_off;
 #pragma unroll
                             for (int r = 0; r < KR; ++r) {
+                                // (the score path's share of the row bound for x[src_e], g_sigma[e][h] u_src[h], is NOT added here: summed
+                                // over the edges of a source it is Gs_src[j][h] u_src[h] — once per node in k_gat_atp_src instead of once
+                                // per edge here: 8 LDS reads and 32 FMAs less per edge, and the registers they took)
                                 float ur[VEC];
                                 load_vec<VEC>(ur, uh + uR[r]);
 #pragma unroll
@@ -1360,6 +1413,10 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
         }
         };
         if (h0 + HT <= H) walk(std::true_type{}); else walk(std::false_type{});
+#ifdef RECON_K2_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (stores included)
+        stamp_[3] = __builtin_readcyclecounter();
+#endif
         if (hv && writer) {
             if (is_piece) p.hubG[static_cast<int64_t>(widx) * H + myh] = sum_gs;
             else p.Gs_dst[static_cast<int64_t>(node) * 2 * H + myh] = sum_gs;
@@ -1379,10 +1436,26 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
             }
         }
     }
-    if (is_piece) return;                                                // k_gat_atp_hub_bwd adds the pieces' share to the node's row
+    if (is_piece) return;                                                // k_gat_atp_hub_bwd adds the pieces' share to the node's row (one piece per wave)
+#ifdef RECON_K2_STAMPS
+    stamp_[4] = __builtin_readcyclecounter();
+    stamp_[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);             // HW_ID: wave, SIMD, CU, SE, XCC
+    if (lane == 0) {
+        uint64_t* o = reinterpret_cast<uint64_t*>(p.gxd + static_cast<int64_t>(node) * F);
+        for (int i = 0; i < 6; ++i) o[i] = stamp_[i];
+        o[6] = static_cast<uint64_t>(end - beg);
+    }
+    if (!more) return;
+    node = nnode; beg = nbeg; end = nend; srcv0 = nidx[0]; eidv0 = nidx[64];       // (zero-degree nodes: never read)
+    stamp_[0] = __builtin_readcyclecounter();
+    continue;
+#endif
     const auto rgx = K2_RSRC(p.gxd + static_cast<int64_t>(node) * F, F * 4);
 #pragma unroll
     for (int r = 0; r < KR; ++r) buf_store_f32<VEC>(gxd[r], rgx, voF[r]);
+    if (!more) return;
+    node = nnode; beg = nbeg; end = nend; srcv0 = nidx[0]; eidv0 = nidx[64];       // (zero-degree nodes: never read)
+    }
 }
 
 // The second half of a hub's backward: wave = one hub.  Adds the pieces' sums of g_sigma in table order to Gs_dst (the node's own
@@ -1735,6 +1808,22 @@ int check_atp(const recon_graph* g, const recon_gat_atp_args* a) {
 
 using namespace recon;
 
+// workgroups of k_gat_atp_bwd a device keeps resident: waves per SIMD as its launch bounds allow (1 / 2 / 3: see the kernel), capped by the
+// LDS a workgroup's copy of u takes; a multiple of 8
+static int64_t k2_resident_blocks(int kr, int ht, size_t lds_bytes) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    const int waves_per_simd = (kr * ht >= 8 && kr >= 8) ? 1 : ((kr >= 4 || (kr * ht >= 8 && kr >= 2)) ? 2 : 3);
+    int per_cu = waves_per_simd;                                         // 4 SIMDs x waves / 4 waves per workgroup
+    const int by_lds = static_cast<int>((160 * 1024) / (lds_bytes + 256));
+    if (by_lds < per_cu) per_cu = by_lds < 1 ? 1 : by_lds;
+    return static_cast<int64_t>(cus) * per_cu / 8 * 8;
+}
+
 extern "C" int recon_gat_atp_supported(int32_t N, int32_t E, int32_t F, int32_t R, int32_t D, int32_t H) {
     (void)N; (void)E; (void)D;
     AtpShape s;
@@ -2016,7 +2105,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
     atp_shape(F, R, H, &s);
     const size_t lds_u = static_cast<size_t>(H) * W * sizeof(float);
     if (lds_u > 64 * 1024) return RECON_ERR_UNSUPPORTED;
-    const size_t lds_k2 = lds_u;
+    const size_t lds_k2 = lds_u + (kBlock / 64) * 512;                 // + the next node's index vectors, per wave (k_gat_atp_bwd)
 
     // (0) through the ELU, and q = g_h . h per (node, head)
     const float* gh = b->grad_out;
@@ -2079,10 +2168,24 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         if (hubs && static_cast<size_t>(g->hub_ws_floats) < recon_graph_hub_ws_floats(g, F, R, H)) return RECON_ERR_WORKSPACE;
         p.hub_chunk = hubs ? g->hub_chunk : 0; p.n_piece = hubs ? g->n_piece : 0;
         p.piece = reinterpret_cast<const int4*>(g->piece); p.hubG = g->hub_ws;
-        dim3 grid(static_cast<unsigned>(ceil_div64(N, kBlock / 64) + ceil_div64(p.n_piece, kBlock / 64)));
+        // nodes: persistent waves, as many workgroups as the kernel's occupancy keeps resident (k2_resident_blocks), a multiple of 8
+        // (one share per XCD) and never more than the nodes need; pieces: a launch of their own, one piece per wave
+        dim3 grid;
 #define CALL_BWD(V_, K_, H_) do { if (V_ == 4 && a->io_bf16) hipLaunchKernelGGL((k_gat_atp_bwd<4, K_, H_, true>), grid, dim3(kBlock), lds_k2, st, p); \
                                   else hipLaunchKernelGGL((k_gat_atp_bwd<V_, K_, H_>), grid, dim3(kBlock), lds_k2, st, p); } while (0)
-        ATP_DISPATCH(s, CALL_BWD);
+        if (p.n_piece > 0) {
+            p.pieces = 1;
+            grid = dim3(static_cast<unsigned>(ceil_div64(p.n_piece, kBlock / 64)));
+            ATP_DISPATCH(s, CALL_BWD);
+        }
+        p.pieces = 0;
+        {
+            const int64_t need = ceil_div64(N, kBlock / 64);
+            int64_t nb = k2_resident_blocks(s.kr, s.ht, lds_k2);
+            if (nb > need) nb = (need + 7) / 8 * 8;
+            grid = dim3(static_cast<unsigned>(nb));
+            ATP_DISPATCH(s, CALL_BWD);
+        }
 #undef CALL_BWD
         if (hubs) {
             const dim3 gh(static_cast<unsigned>(ceil_div64(g->n_hub, kBlock / 64)));

@@ -41,6 +41,7 @@ struct Hx2Args {
     int32_t a_shared_k;            // A's columns k < a_shared_k are the same for every batch entry and are read from entry 0 (0: none)
     Hx2Scale sa, sb;
     const float* row_inv; int64_t row_inv_bs;      // per-row inverse scales of A (see gemm_hx2_batched) or null
+    int32_t a_span_bytes;          // k_gemm_hx2_r3: bytes from Ap to the end of the last fragment any lane reads (0: not below 2^31, the ring form is not used)
 };
 
 // byte offset of (row, k group kq of 8 halves) inside one plane of the B tile image (see gemm_bx3.hip)
@@ -250,6 +251,146 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) k_gemm_hx2(const Hx2
     }
     // per-row scales of A (rows past M re-read the last row; they are never stored).  Requested here, behind the loop: eight more live
     // registers across the K loop cost 15 of the loop's 256 (213 against 198)
+    float rsc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            rsc[i][r] = (p.row_inv ? p.row_inv[bz * p.row_inv_bs + min(m0 + mb + 16 * i + 4 * lq + r, p.M - 1)] : 1.f) * (ia * ib);
+    if (p.c_plain) {                                                 // uniform
+        if (p.epilogue == GEMM_EPI_ELU) hx2_store_plain<GEMM_EPI_ELU>(acc, p.C.base + bz * p.c_bs, p.C.S1, p.M, p.N, m0, n0, mb, li, lq, rsc);
+        else hx2_store_plain<GEMM_EPI_NONE>(acc, p.C.base + bz * p.c_bs, p.C.S1, p.M, p.N, m0, n0, mb, li, lq, rsc);
+    } else {
+        hx2_store(acc, p.C, p.C.base + bz * p.c_bs, p.M, p.N, m0, n0, mb, li, lq, p.epilogue, p.c_vec4, rsc);
+    }
+}
+
+// ---- round 6: the same product with A THREE tiles deep -------------------------------------------------------------------------------
+// The kernel above asks for the A fragments of tile k + 1 at the top of tile k and waits for them (and for B's copies: vmcnt(0)) behind
+// tile k's 78 MFMAs: requests are one MMA phase old when they are needed.  With K = 200 / 600 there are 7 / 19 K tiles per workgroup,
+// the 512 workgroups of the projection are ONE round over 256 CUs x 2, and the kernel's time is 19 x (a tile's step): 3.2 us per step
+// where the MFMAs of the two co-resident workgroups take 1.7 — every step ends in a wait for HBM (A = V is streamed from HBM, 157 MB;
+// B = the layer's a sits in L2).  Here A lives in THREE register sets used in rotation WITHOUT a masked copy (fragments go straight from
+// the load's registers into the MFMAs: rows past K are dropped by the buffer descriptor's range check, not by a select), A of tile
+// k + 2 is requested inside tile k, B's copies are issued from inline asm (the compiler does not see them: through the builtin it
+// drains the request counter in front of the next LDS read) and ONE counted wait per tile — s_waitcnt vmcnt(4): everything but the four
+// youngest requests, which are A(k + 1) — stands in front of a raw s_barrier.  Requests are two MMA phases old when they are needed.
+// The K loop runs in whole triples (register sets are named statically) with the remainder peeled behind it; every wave issues the
+// same number of requests per tile (missing B pieces copy into a scratch KiB), so the wait's immediate holds.
+// Host condition: A's span below 2^31 bytes (32-bit buffer offsets), 128-row workgroups.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, 2) k_gemm_hx2_r3(const Hx2Args p) {
+    static_assert(NW == 4, "128-row workgroups");
+    constexpr int BMW = 32 * NW, B_DMAW = (B_PIECES + NW - 1) / NW;       // 7 copies per wave and tile
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * B_TILE_BYTES + 1024];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const TileId tile = xcd_tile(p.xcd_remap);
+    const int m0 = tile.y * BMW, n0 = tile.x * BN, bz = tile.z;
+    const int mb = wid * 32;
+    const int li = lane & 15, lq = lane >> 4;
+    const int KT = (p.K + BK - 1) / BK, Kp = KT * BK;
+
+    // ---- A: one descriptor over the tensor, byte offsets per (row tile, term); the k part is added per tile
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.Ap), 0, p.a_span_bytes, 0x00020000);
+    uint32_t a_off[2][T];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < T; ++q)
+            a_off[i][q] = static_cast<uint32_t>((bz * p.a_bs + q * p.a_plane + static_cast<int64_t>(min(m0 + mb + 16 * i + li, p.M - 1)) * p.a_row + 8 * lq) * 2);
+    const uint32_t a_back = static_cast<uint32_t>(bz * p.a_bs * 2);
+    u32x4 araw[3][2][T];
+    auto load_a = [&](u32x4 (&dst)[2][T], int kt) {                  // tile kt (any value: tiles past K read nothing and come back as zeros)
+        const int k = kt * BK + 8 * lq;
+        uint32_t ko = k < p.K ? static_cast<uint32_t>(kt * BK * 2) : 0x7ffffff0u;
+        if (k < p.a_shared_k) ko -= a_back;                           // shared columns: batch entry 0's copy (lane predicate, no branch)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < T; ++q) dst[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off[i][q] + ko, 0, 0);
+    };
+    // ---- B: the copy plan of gemm_hx2 (piece pc = NW i + wave of the tile image), missing pieces go to the scratch KiB
+    int b_goff[B_DMAW];
+    const _Float16* bbase = p.Bp + bz * p.b_bs;
+#pragma unroll
+    for (int i = 0; i < B_DMAW; ++i) {
+        const int s = min(64 * (NW * i + wid) + lane, B_TILE_BYTES / 16 - 1);
+        const int plane = s / (BN * 4), rem = s % (BN * 4), rowL = rem >> 2, pslot = rem & 3;
+        const int kq = (pslot - 2 * (rowL >> 3)) & 3;                 // inverse of lds_off's rotation
+        const int j = rowL >> 4, rho = rowL & 15;
+        const int col = j < 12 ? 64 * (j >> 2) + 4 * rho + (j & 3) : 192 + rho;
+        b_goff[i] = static_cast<int>(plane * p.b_plane + static_cast<int64_t>(min(n0 + col, p.N - 1)) * p.b_row + 8 * kq);
+    }
+    auto dma_b = [&](int kt, int buf) {                              // kt past the end: the last tile again, into scratch
+        const bool real = kt < KT;
+        const int k0 = min(kt, KT - 1) * BK;
+#pragma unroll
+        for (int i = 0; i < B_DMAW; ++i) {
+            const bool piece = real && NW * i + wid < B_PIECES;       // wave-uniform
+            dma16_to_lds(bbase + b_goff[i] + k0, Bs + (piece ? buf * B_TILE_BYTES + 1024 * (NW * i + wid) : 2 * B_TILE_BYTES));
+        }
+    };
+
+    f32x4 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int b_rd = lds_off(li, lq);
+
+    // one tile: wait, barrier, first MFMA group, the tile's requests, the other groups
+    auto step = [&](int kt, const u32x4 (&acur)[2][T], u32x4 (&anext2)[2][T]) {
+        dma_wait<4>();                                               // A(kt) and B(kt) have landed; A(kt + 1) may be in flight
+        __builtin_amdgcn_s_barrier();                                 // everybody's pieces of B(kt) are there; everybody is past tile kt - 1
+        asm volatile("" ::: "memory");
+        const unsigned char* Bt = Bs + (kt & 1) * B_TILE_BYTES;
+        f16x8 af[2][T];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < T; ++q) af[i][q] = __builtin_bit_cast(f16x8, acur[i][q]);
+        f16x8 b[2][2][T];
+        auto read_pair = [&](int j0, f16x8 (&dst)[2][T]) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+                if (j0 + jj < TN) {
+#pragma unroll
+                    for (int q = 0; q < T; ++q) dst[jj][q] = *reinterpret_cast<const f16x8*>(Bt + q * (BN * 64) + b_rd + (j0 + jj) * 1024);
+                }
+        };
+        read_pair(0, b[0]);
+#pragma unroll
+        for (int g = 0; g < (TN + 1) / 2; ++g) {
+            if (2 * g + 2 < TN) read_pair(2 * g + 2, b[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (2 * g + 1 < TN) hx2_products<2>(acc, af, b[g & 1], 2 * g);
+            else hx2_products<1>(acc, af, b[g & 1], 2 * g);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g == 0) {                                             // behind the first group: the tile's requests (B first: it is needed first)
+                dma_b(kt + 1, (kt + 1) & 1);
+                load_a(anext2, kt + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    dma_b(0, 0);
+    load_a(araw[0], 0);
+    load_a(araw[1], 1);
+    // the operands' scales (32 amax slots each): read here, under the first tile's round trip, not in front of the stores
+    const float ia = hx2_inv(hx2_scale_wave(p.sa)), ib = hx2_inv(hx2_scale_wave(p.sb));
+    int kt = 0;
+#pragma unroll 1
+    for (; kt + 3 <= KT; kt += 3) {
+        step(kt, araw[0], araw[2]);
+        step(kt + 1, araw[1], araw[0]);
+        step(kt + 2, araw[2], araw[1]);
+    }
+    if (kt < KT) step(kt, araw[0], araw[2]);
+    if (kt + 1 < KT) step(kt + 1, araw[1], araw[0]);
+    (void)Kp;
+    dma_wait<0>();                                                   // the last tiles' look-ahead copies (scratch KiB) must not outlive the workgroup's LDS
     float rsc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -608,7 +749,12 @@ int gemm_hx2_batched(int32_t M, int32_t N, int32_t K, const void* Ap, int64_t a_
     // 256-row workgroups for long K and enough rows to fill the chip with them (see k_gemm_hx2)
     const bool wide = K >= 1024 && ceil_div64(M, 256) * ceil_div64(N, BN) * bt.batch >= 256;
     const dim3 grid(static_cast<unsigned>(ceil_div64(N, BN)), static_cast<unsigned>(ceil_div64(M, wide ? 256 : BM)), static_cast<unsigned>(bt.batch));
+    // the three-deep A ring (k_gemm_hx2_r3) wherever 32-bit byte offsets reach all of A; RECON_HX2_RING=0: the two-stage form
+    const int64_t a_span = ((T - 1) * a_plane + (bt.batch - 1) * a_bs + static_cast<int64_t>(M - 1) * a_row + hx2_kp(K) + 8) * 2;
+    a.a_span_bytes = (a_plane >= 0 && a_bs >= 0 && a_row >= 0 && a_span < (1LL << 31) - 64) ? static_cast<int32_t>(a_span) : 0;
+    const bool ring = !wide && a.a_span_bytes > 0 && cfg_char(CFG_HX2_RING) != '0';
     if (wide) hipLaunchKernelGGL((k_gemm_hx2<8>), grid, dim3(512), 0, st, a);
+    else if (ring) hipLaunchKernelGGL((k_gemm_hx2_r3<4>), grid, dim3(NT), 0, st, a);
     else hipLaunchKernelGGL((k_gemm_hx2<4>), grid, dim3(NT), 0, st, a);
     if (hipGetLastError() != hipSuccess) return RECON_ERR_LAUNCH;
     return RECON_OK;
