@@ -1072,9 +1072,19 @@ constexpr int kK2Ring = 2, kK2WavesPerSimd = 3;
 // three the KR = 8 form spilled 259 registers (0.73 ms per call at N = 8 192, F = R = 1 600).
 // B16: x and edge_embed are stored as bfloat16 and read where they lie (recon_gat_atp_args.io_bf16; round 5: the backward no longer needs
 // up-cast copies of them — at cfg 5, 62 MB read + 124 MB written by two cast kernels, and half of this kernel's gathered row bytes)
-template <int VEC, int KR, int HT, bool B16 = false>
+// LR (round 6; rows of at most 1 KiB: VEC = 4, KR = 1): the gathered rows x[src_e] / r_e of the next kK2LdsRing edges wait in LDS, copied
+// there by LDS-DMA, instead of two edges' rows in registers.  Cycle stamps with the register ring: at cfg 2 (degree 4) the second pair of
+// edges cost the walk a round trip (14.6 k of a node's 34 k cycles); at cfg 5's bfloat16 leg — per-edge rows streamed from HBM, rows of
+// up to 64 slots per chunk — the walk was half of a wave's life (p50 22.6 k of 45 k cycles): two edges ahead cover L2's latency, not
+// HBM's.  A slot is refilled as soon as its rows have been read into registers; ONE counted wait in front of a slot's reads — every
+// iteration issues the same seven requests (the two copies of the rows of the edge RING ahead, three stores, the two score words of that
+// edge; missing edges copy nothing through a zero-sized descriptor), so "all but the 5 + 7 (RING - 1) youngest" is exactly "this slot's
+// copies have landed".  Eight registers less than the register ring.
+constexpr int kK2LdsRingBytes = 8192;                                  // per wave: 4 slots of 2 x 1 KiB
+template <int VEC, int KR, int HT, bool B16 = false, bool LR = false>
 __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >= 4 || KR * HT >= 8 && KR >= 2) ? 2 : kK2WavesPerSimd)) k_gat_atp_bwd(const AtpBwdK p) {
-    extern __shared__ __attribute__((aligned(16))) float U[];          // [H][W]: u_dst | u_src | u_rel per head
+    static_assert(!LR || (VEC == 4 && KR == 1), "LDS row ring: rows of at most 1 KiB");
+    extern __shared__ __attribute__((aligned(16))) float U[];          // [H][F + R]: u_dst | u_rel per head (u_src is k_gat_atp_src's business now)
 #ifdef RECON_K2_STAMPS                                                   // cycle stamps of every wave, left in its gxd row instead of the gradient (tools/probe/k2_stamps.py)
     uint64_t stamp_[6];
     stamp_[0] = __builtin_readcyclecounter();
@@ -1106,10 +1116,22 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
     } else node = p.N;
     int srcv0 = 0, eidv0 = 0;
     if (beg < end) { const int kk = beg + min(lane, min(64, end - beg) - 1); srcv0 = p.src[kk]; eidv0 = p.eid[kk]; }
-    if (((H * W) & 3) == 0) {                                            // 16 bytes per request (H W / 4 <= 5 per thread at cfg 2; it was 19 dwords)
-        for (int idx = threadIdx.x; idx < (H * W) >> 2; idx += kBlock) reinterpret_cast<float4*>(U)[idx] = reinterpret_cast<const float4*>(p.u)[idx];
+    const int UW = F + R;                                                // a head's row of U
+    if (((F | R) & 3) == 0) {                                            // 16 bytes per request
+        for (int idx = threadIdx.x; idx < (H * UW) >> 2; idx += kBlock) {
+            const int h = (4 * idx) / UW, c = 4 * idx - h * UW;
+            reinterpret_cast<float4*>(U)[idx] = *reinterpret_cast<const float4*>(p.u + h * W + (c < F ? c : F + c));
+        }
     } else {
-        for (int idx = threadIdx.x; idx < H * W; idx += kBlock) U[idx] = p.u[idx];
+        for (int idx = threadIdx.x; idx < H * UW; idx += kBlock) { const int h = idx / UW, c = idx - h * UW; U[idx] = p.u[h * W + (c < F ? c : F + c)]; }
+    }
+    // (a copy instruction writes 64 lanes x 16 bytes whatever the row's length — lanes past the row write zeros: a row's room is 1 KiB)
+    constexpr int RING = 4, ROWB = 1024, SLOTB = 2 * ROWB;                              // (LR) slots per wave, bytes per row / per slot
+    static_assert(RING == 4, "the walk names the ring's slots");
+    unsigned char* const ringb = reinterpret_cast<unsigned char*>(U + H * UW) + (kBlock / 64) * 512 + (LR ? wave * kK2LdsRingBytes : 0);
+    if constexpr (LR) {                                                  // lanes past a row's end read what was here before the row: zeros, never NaN bit patterns
+#pragma unroll
+        for (int i = 0; i < kK2LdsRingBytes / 1024; ++i) reinterpret_cast<float4*>(ringb + 1024 * i)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     if (node >= p.N) return;
@@ -1143,7 +1165,7 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
     if (more) { nbeg = p.rowptr[nnode]; nend = p.rowptr[nnode + 1]; }
     // its index vectors wait in LDS (2 x 256 bytes per wave behind the rows of u), not in registers: two more live registers across the
     // walk were spilled the moment they arrived — a vmcnt(0) each, in front of the g_V requests
-    int* const nidx = reinterpret_cast<int*>(U + H * W) + wave * 128 + lane;
+    int* const nidx = reinterpret_cast<int*>(U + H * UW) + wave * 128 + lane;
     float xi[KR][VEC], gxd[KR][VEC];
     {
         const auto rxi = K2_RSRC(in_row(p.x, node, F), F * ES);
@@ -1165,7 +1187,10 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
         const bool hv = myh < H;
         // ring of PF register slots (static indices: the loop body is unrolled PF times) holding the rows / score of the next
         // PF edges; filled for the first edges BEFORE the g_V rows are requested, so both are in flight together
-        constexpr int PF = KR == 1 ? kK2Ring : (KR == 2 ? 2 : 1);
+        // (LR: the walk is unrolled over the ring's slots — the two score words of an edge travel at the ring's distance too, in registers:
+        // the compiler waits for ITS loads by counting the requests it knows, and a score word requested behind a copy and needed two edges
+        // later would make it wait for that copy — in-order completion — whatever the ring's depth)
+        constexpr int PF = LR ? 4 : (KR == 1 ? kK2Ring : (KR == 2 ? 2 : 1));
         const uint32_t mh4 = static_cast<uint32_t>(hv ? myh : h0) * 4u;
         int c0 = beg, cn = cn0, srcv = srcv0, eidv = eidv0;
         const float* keepp = p.keep ? p.keep : p.sigma;
@@ -1177,23 +1202,45 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
         auto rgs = K2_RSRC(p.gsigma + static_cast<int64_t>(c0) * H, 64 * Hb);
         auto rGx = K2_RSRC(p.Gxs + static_cast<int64_t>(c0) * F, 64 * Fb);
         auto rGe = K2_RSRC((p.g_ee && p.gee_by_slot) ? p.g_ee + static_cast<int64_t>(c0) * R : p.Gxs, (p.g_ee && p.gee_by_slot) ? 64 * Rb : 0u);
-        float xs_r[PF][KR][VEC], re_r[PF][KR][VEC], sg_r[PF], kf_r[PF];
-        auto fetch_edge = [&](int slot, int j) {                         // j: position inside the chunk (uniform), clamped by the caller
+        float xs_r[LR ? 1 : PF][KR][VEC], re_r[LR ? 1 : PF][KR][VEC], sg_r[PF], kf_r[PF];
+        auto fetch_scores = [&](int slot, int j) {                       // the edge's score word and keep factor for this lane's head
+            const uint32_t so = static_cast<uint32_t>(j) * Hb;
+            sg_r[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsg, mh4, so, 0));
+            kf_r[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rkf, mh4, so, 0));     // eval: re-reads sigma, replaced by 1 at the use (no branch)
+        };
+        auto fetch_edge = [&](int slot, int j) {                         // register ring.  j: position inside the chunk (uniform), clamped by the caller
             const int s_ = __builtin_amdgcn_readlane(srcv, j), e_ = __builtin_amdgcn_readlane(eidv, j);
             const auto rx = K2_RSRC(in_row(p.x, s_, F), F * ES);
             const auto re = K2_RSRC(in_row(p.ee, e_, R), R * ES);
 #pragma unroll
             for (int r = 0; r < KR; ++r) {                               // lanes past F / R: zeros
-                buf_load_in<VEC, B16>(xs_r[slot][r], rx, viF[r]);
-                buf_load_in<VEC, B16>(re_r[slot][r], re, viR[r]);
+                buf_load_in<VEC, B16>(xs_r[LR ? 0 : slot][r], rx, viF[r]);
+                buf_load_in<VEC, B16>(re_r[LR ? 0 : slot][r], re, viR[r]);
             }
-            const uint32_t so = static_cast<uint32_t>(j) * Hb;
-            sg_r[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsg, mh4, so, 0));
-            kf_r[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rkf, mh4, so, 0));     // eval: re-reads sigma, replaced by 1 at the use (no branch)
+            fetch_scores(slot, j);
+        };
+        // LDS ring: both rows of the edge at position j of the chunk into slot j % RING (two copies; a position past the chunk copies nothing)
+        const uint32_t vd = static_cast<uint32_t>(lane) * 16u;
+        auto fill_rows = [&](int j) {
+            const bool live = j < cn;                                    // wave-uniform
+            const int jc = min(j, cn - 1);
+            const int s_ = __builtin_amdgcn_readlane(srcv, jc), e_ = __builtin_amdgcn_readlane(eidv, jc);
+            const dma_u32x4 dx = dma_descriptor(in_row(p.x, s_, F), live ? static_cast<uint32_t>(F) * ES : 0u);
+            const dma_u32x4 de = dma_descriptor(in_row(p.ee, e_, R), live ? static_cast<uint32_t>(R) * ES : 0u);
+            unsigned char* slot = ringb + (j & (RING - 1)) * SLOTB;
+            dma16_buffer_to_lds(dx, vd, slot);
+            dma16_buffer_to_lds(de, vd, slot + ROWB);
         };
         if (beg < end) {
+            if constexpr (LR) {
 #pragma unroll
-            for (int u = 0; u < PF; ++u) fetch_edge(u, min(u, cn - 1));
+                for (int u = 0; u < RING; ++u) fill_rows(u);
+#pragma unroll
+                for (int u = 0; u < PF; ++u) fetch_scores(u, min(u, cn - 1));
+            } else {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) fetch_edge(u, min(u, cn - 1));
+            }
         }
         // Z, Zk, q of the node's heads through one descriptor each (lanes of missing heads read head h0's and are masked at the use): requested
         // BEHIND the rows of g_V below — in front of them the three words were spilled as they arrived, a vmcnt(0) each, and the batch of
@@ -1312,7 +1359,132 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
         // node in k_gat_atp_src instead of once per edge here (8 LDS reads and 32 FMAs per edge); (5) rows through buffer descriptors.
         auto walk = [&](auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;
+        // one edge: scores, gradient of its score, its two output rows.  j: position in the chunk, e: its edge id, xs / re: its gathered rows
+        auto edge = [&](int j, int e, const float (&xs)[KR][VEC], const float (&re)[KR][VEC], float sg, float kf) {
+                float part[HT];
+#pragma unroll
+                for (int h = 0; h < HT; ++h) {
+                    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < KR; ++r)
+#pragma unroll
+                        for (int v = 0; v < VEC; v += 2) {
+                            acc = pk_fma(f32x2{gVs[h][r][v], gVs[h][r][v + 1]}, f32x2{xs[r][v], xs[r][v + 1]}, acc);
+                            acc = pk_fma(f32x2{gVr[h][r][v], gVr[h][r][v + 1]}, f32x2{re[r][v], re[r][v + 1]}, acc);
+                        }
+                    part[h] = acc.x + acc.y;
+                }
+                const float tl = multi_sum<HT>(part, lane);
+                const float w = hv ? __expf(-(sg > 0.f ? sg : p.alpha * sg)) : 0.f;      // v_exp_f32: 2 ulp, enough for a gradient factor
+                const float gw = fmaf(kf * (tl + tdl), invl, gZl);
+                const float gs = hv ? -gw * w * (sg > 0.f ? 1.f : p.alpha) : 0.f;
+                const float al_ = kf * w * invl;
+                sum_gs += gs;
+                if (hv && writer) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, gs), rgs, mh4, static_cast<uint32_t>(j) * Hb, 0);
+                f32x2 gxs[KR][VEC / 2], gr[KR][VEC / 2];
+#pragma unroll
+                for (int r = 0; r < KR; ++r)
+#pragma unroll
+                    for (int v = 0; v < VEC / 2; ++v) { gxs[r][v] = f32x2{0.f, 0.f}; gr[r][v] = f32x2{0.f, 0.f}; }
+                // the rows of u are the same for every edge: left alone, the compiler hoists all HT KR reads out of the walk and then
+                // spills them.  An offset it cannot see through keeps them here.
+                // (a head's two factors are wave-uniform — readlane — and reach v_pk_fma_f32 as scalar operands broadcast by op_sel)
+                int u_off = 0;
+                asm volatile("" : "+v"(u_off));
+#pragma unroll
+                for (int h = 0; h < HT; ++h) {
+                    if (FULL || h0 + h < H) {                         // (not FULL: wave-uniform)
+                        const f32x2 ab = {lane_bcast(al_, h << SH), lane_bcast(gs, h << SH)};
+                        const f32x2 ah2 = __builtin_shufflevector(ab, ab, 0, 0), bh2 = __builtin_shufflevector(ab, ab, 1, 1);
+                        const float* uh = U + (h0 + h) * UW + F + u_off;
+#pragma unroll
+                        for (int r = 0; r < KR; ++r) {
+                            // (the score path's share of the row bound for x[src_e], g_sigma[e][h] u_src[h], is NOT added here: summed
+                            // over the edges of a source it is Gs_src[j][h] u_src[h] — once per node in k_gat_atp_src instead of once
+                            // per edge here: 8 LDS reads and 32 FMAs less per edge, and the registers they took)
+                            float ur[VEC];
+                            load_vec<VEC>(ur, uh + uR[r]);
+#pragma unroll
+                            for (int v = 0; v < VEC; v += 2) {
+                                gxs[r][v / 2] = pk_fma(ah2, f32x2{gVs[h][r][v], gVs[h][r][v + 1]}, gxs[r][v / 2]);
+                                gr[r][v / 2] = pk_fma(ah2, f32x2{gVr[h][r][v], gVr[h][r][v + 1]}, pk_fma(bh2, f32x2{ur[v], ur[v + 1]}, gr[r][v / 2]));
+                            }
+                        }
+                    }
+                }
+                // g_edge_embed rows go by slot (a table read through an index: the caller sums them per table row) or by edge id
+                const bool ge_edge = p.g_ee && !p.gee_by_slot;       // wave-uniform
+                const auto rGee = ge_edge ? K2_RSRC(p.g_ee + static_cast<int64_t>(e) * R, Rb) : rGe;
+                const uint32_t sox = static_cast<uint32_t>(j) * Fb, soe = ge_edge ? 0u : static_cast<uint32_t>(j) * Rb;
+#pragma unroll
+                for (int r = 0; r < KR; ++r) {
+                    float ox[VEC], orr[VEC];
+#pragma unroll
+                    for (int v = 0; v < VEC; v += 2) { ox[v] = gxs[r][v / 2].x; ox[v + 1] = gxs[r][v / 2].y; orr[v] = gr[r][v / 2].x; orr[v + 1] = gr[r][v / 2].y; }
+                    if (hg > 0) {                                    // wave-uniform: a later head group adds to the rows the first one wrote
+                        float o1[VEC], o2[VEC];
+                        buf_load_f32<VEC>(o1, rGx, voF[r], sox);
+                        buf_load_f32<VEC>(o2, rGee, voR[r], soe);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) { ox[v] += o1[v]; orr[v] += o2[v]; }
+                    }
+                    buf_store_f32<VEC>(ox, rGx, voF[r], sox);       // lanes past F / R (and every lane without g_edge_embed): dropped by the range check
+                    buf_store_f32<VEC>(orr, rGee, voR[r], soe);
+                }
+        };
         while (c0 < end) {
+            if constexpr (LR) {
+                // the chunk's first RING edges were requested in front of everything this wave has waited for since (first chunk: the node's
+                // g_V rows); later chunks: their fills have to land
+                // (the builtin, not inline asm: the compiler then KNOWS nothing of its own is in flight at the loop's entry — otherwise a load it
+                // issued on the way in (the chunk's first score words) may still be pending in registers the loop body overwrites, and the
+                // wait for it lands inside the loop header: a vmcnt(0) per group of edges)
+                __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0), nothing else
+                asm volatile("" ::: "memory");
+                // whole groups of RING edges run without a branch (a run-time condition around an edge's requests makes the compiler count
+                // the FEWEST requests any path issues, and its waits for the score words then reach into the copies in flight: with
+                // `if (j < cn)` around every edge it waited for all but seven requests where seventeen were its own); the chunk's last
+                // 1 .. RING - 1 edges follow, guarded
+                auto lr_edge = [&](int j, auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    const int e = __builtin_amdgcn_readlane(eidv, j);
+                    float xs[KR][VEC], re[KR][VEC];
+                    dma_wait<5 + 7 * (RING - 1)>();                      // this slot's copies (issued RING edges ago: five requests and RING - 1 whole edges behind them) have landed
+                    asm volatile("" ::: "memory");
+                    const unsigned char* slot = ringb + u * SLOTB;       // (j % RING == u: chunks start at slot 0)
+                    if constexpr (B16) {
+                        const uint2 tx = reinterpret_cast<const uint2*>(slot)[lane], te = reinterpret_cast<const uint2*>(slot + ROWB)[lane];
+                        xs[0][0] = __builtin_bit_cast(float, tx.x << 16); xs[0][1] = __builtin_bit_cast(float, tx.x & 0xffff0000u);
+                        xs[0][2] = __builtin_bit_cast(float, tx.y << 16); xs[0][3] = __builtin_bit_cast(float, tx.y & 0xffff0000u);
+                        re[0][0] = __builtin_bit_cast(float, te.x << 16); re[0][1] = __builtin_bit_cast(float, te.x & 0xffff0000u);
+                        re[0][2] = __builtin_bit_cast(float, te.y << 16); re[0][3] = __builtin_bit_cast(float, te.y & 0xffff0000u);
+                    } else {
+                        const float4 tx = reinterpret_cast<const float4*>(slot)[lane], te = reinterpret_cast<const float4*>(slot + ROWB)[lane];
+                        xs[0][0] = tx.x; xs[0][1] = tx.y; xs[0][2] = tx.z; xs[0][3] = tx.w;
+                        re[0][0] = te.x; re[0][1] = te.y; re[0][2] = te.z; re[0][3] = te.w;
+                    }
+                    // the slot is free once these reads have executed: the next copies into it are issued behind them
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xs[0][0]), "+v"(re[0][0]) : : "memory");
+                    const float sg = sg_r[u], kf = p.keep ? kf_r[u] : 1.f;
+                    // in this order (the count and order of an edge's requests are part of the waits): the copies of the edge RING ahead, the
+                    // arithmetic, the two score words of that edge — BEHIND the last use of this edge's (one register each for the ring's
+                    // whole life: requested earlier they were live beside this edge's words and had to be copied into their names at the
+                    // loop's back edge, behind a vmcnt(0)) — and behind the copies (in-order completion: a word the compiler waits for takes
+                    // every older request with it)
+                    fill_rows(j + RING);                                 // two copies; a position past the chunk copies nothing
+                    edge(j, e, xs, re, sg, kf);
+                    asm volatile("" ::: "memory");
+                    fetch_scores(u, min(j + RING, cn - 1));
+                };
+                int j0 = 0;
+                for (; j0 + RING <= cn; j0 += RING) {
+                    lr_edge(j0, std::integral_constant<int, 0>{}); lr_edge(j0 + 1, std::integral_constant<int, 1>{});
+                    lr_edge(j0 + 2, std::integral_constant<int, 2>{}); lr_edge(j0 + 3, std::integral_constant<int, 3>{});
+                }
+                if (j0 < cn) lr_edge(j0, std::integral_constant<int, 0>{});
+                if (j0 + 1 < cn) lr_edge(j0 + 1, std::integral_constant<int, 1>{});
+                if (j0 + 2 < cn) lr_edge(j0 + 2, std::integral_constant<int, 2>{});
+            } else {
             for (int j0 = 0; j0 < cn; j0 += PF) {
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
@@ -1326,77 +1498,9 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                         for (int v = 0; v < VEC; ++v) { xs[r][v] = xs_r[u][r][v]; re[r][v] = re_r[u][r][v]; }
                     const float sg = sg_r[u], kf = p.keep ? kf_r[u] : 1.f;
                     if (j + PF < cn) fetch_edge(u, j + PF);              // wave-uniform; refills the slot just consumed
-                    float part[HT];
-#pragma unroll
-                    for (int h = 0; h < HT; ++h) {
-                        f32x2 acc = {0.f, 0.f};
-#pragma unroll
-                        for (int r = 0; r < KR; ++r)
-#pragma unroll
-                            for (int v = 0; v < VEC; v += 2) {
-                                acc = pk_fma(f32x2{gVs[h][r][v], gVs[h][r][v + 1]}, f32x2{xs[r][v], xs[r][v + 1]}, acc);
-                                acc = pk_fma(f32x2{gVr[h][r][v], gVr[h][r][v + 1]}, f32x2{re[r][v], re[r][v + 1]}, acc);
-                            }
-                        part[h] = acc.x + acc.y;
-                    }
-                    const float tl = multi_sum<HT>(part, lane);
-                    const float w = hv ? __expf(-(sg > 0.f ? sg : p.alpha * sg)) : 0.f;      // v_exp_f32: 2 ulp, enough for a gradient factor
-                    const float gw = fmaf(kf * (tl + tdl), invl, gZl);
-                    const float gs = hv ? -gw * w * (sg > 0.f ? 1.f : p.alpha) : 0.f;
-                    const float al_ = kf * w * invl;
-                    sum_gs += gs;
-                    if (hv && writer) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, gs), rgs, mh4, static_cast<uint32_t>(j) * Hb, 0);
-                    f32x2 gxs[KR][VEC / 2], gr[KR][VEC / 2];
-#pragma unroll
-                    for (int r = 0; r < KR; ++r)
-#pragma unroll
-                        for (int v = 0; v < VEC / 2; ++v) { gxs[r][v] = f32x2{0.f, 0.f}; gr[r][v] = f32x2{0.f, 0.f}; }
-                    // the rows of u are the same for every edge: left alone, the compiler hoists all HT KR reads out of the walk and then
-                    // spills them.  An offset it cannot see through keeps them here.
-                    // (a head's two factors are wave-uniform — readlane — and reach v_pk_fma_f32 as scalar operands broadcast by op_sel)
-                    int u_off = 0;
-                    asm volatile("" : "+v"(u_off));
-#pragma unroll
-                    for (int h = 0; h < HT; ++h) {
-                        if (FULL || h0 + h < H) {                         // (not FULL: wave-uniform)
-                            const f32x2 ab = {lane_bcast(al_, h << SH), lane_bcast(gs, h << SH)};
-                            const f32x2 ah2 = __builtin_shufflevector(ab, ab, 0, 0), bh2 = __builtin_shufflevector(ab, ab, 1, 1);
-                            const float* uh = U + (h0 + h) * W + 2 * F + u_off;
-#pragma unroll
-                            for (int r = 0; r < KR; ++r) {
-                                // (the score path's share of the row bound for x[src_e], g_sigma[e][h] u_src[h], is NOT added here: summed
-                                // over the edges of a source it is Gs_src[j][h] u_src[h] — once per node in k_gat_atp_src instead of once
-                                // per edge here: 8 LDS reads and 32 FMAs less per edge, and the registers they took)
-                                float ur[VEC];
-                                load_vec<VEC>(ur, uh + uR[r]);
-#pragma unroll
-                                for (int v = 0; v < VEC; v += 2) {
-                                    gxs[r][v / 2] = pk_fma(ah2, f32x2{gVs[h][r][v], gVs[h][r][v + 1]}, gxs[r][v / 2]);
-                                    gr[r][v / 2] = pk_fma(ah2, f32x2{gVr[h][r][v], gVr[h][r][v + 1]}, pk_fma(bh2, f32x2{ur[v], ur[v + 1]}, gr[r][v / 2]));
-                                }
-                            }
-                        }
-                    }
-                    // g_edge_embed rows go by slot (a table read through an index: the caller sums them per table row) or by edge id
-                    const bool ge_edge = p.g_ee && !p.gee_by_slot;       // wave-uniform
-                    const auto rGee = ge_edge ? K2_RSRC(p.g_ee + static_cast<int64_t>(e) * R, Rb) : rGe;
-                    const uint32_t sox = static_cast<uint32_t>(j) * Fb, soe = ge_edge ? 0u : static_cast<uint32_t>(j) * Rb;
-#pragma unroll
-                    for (int r = 0; r < KR; ++r) {
-                        float ox[VEC], orr[VEC];
-#pragma unroll
-                        for (int v = 0; v < VEC; v += 2) { ox[v] = gxs[r][v / 2].x; ox[v + 1] = gxs[r][v / 2].y; orr[v] = gr[r][v / 2].x; orr[v + 1] = gr[r][v / 2].y; }
-                        if (hg > 0) {                                    // wave-uniform: a later head group adds to the rows the first one wrote
-                            float o1[VEC], o2[VEC];
-                            buf_load_f32<VEC>(o1, rGx, voF[r], sox);
-                            buf_load_f32<VEC>(o2, rGee, voR[r], soe);
-#pragma unroll
-                            for (int v = 0; v < VEC; ++v) { ox[v] += o1[v]; orr[v] += o2[v]; }
-                        }
-                        buf_store_f32<VEC>(ox, rGx, voF[r], sox);       // lanes past F / R (and every lane without g_edge_embed): dropped by the range check
-                        buf_store_f32<VEC>(orr, rGee, voR[r], soe);
-                    }
+                    edge(j, e, xs, re, sg, kf);
                 }
+            }
             }
             c0 += 64;
             if (c0 < end) {                                              // next chunk of a long row: new index vectors, refill the ring
@@ -1407,8 +1511,16 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                 rgs = K2_RSRC(p.gsigma + static_cast<int64_t>(c0) * H, 64 * Hb);
                 rGx = K2_RSRC(p.Gxs + static_cast<int64_t>(c0) * F, 64 * Fb);
                 rGe = K2_RSRC((p.g_ee && p.gee_by_slot) ? p.g_ee + static_cast<int64_t>(c0) * R : p.Gxs, (p.g_ee && p.gee_by_slot) ? 64 * Rb : 0u);
+                if constexpr (LR) {
+                    // (the previous chunk's last iterations copied nothing into the slots: they are free)
 #pragma unroll
-                for (int u = 0; u < PF; ++u) fetch_edge(u, min(u, cn - 1));
+                    for (int u = 0; u < RING; ++u) fill_rows(u);
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) fetch_scores(u, min(u, cn - 1));
+                } else {
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) fetch_edge(u, min(u, cn - 1));
+                }
             }
         }
         };
@@ -1425,7 +1537,7 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
         for (int h = 0; h < HT; ++h) {
             if (h0 + h < H) {
                 const float sh = lane_bcast(sum_gs, h << SH);
-                const float* uh = U + (h0 + h) * W;
+                const float* uh = U + (h0 + h) * UW;
 #pragma unroll
                 for (int r = 0; r < KR; ++r) {
                     float ud[VEC];
@@ -2103,8 +2215,8 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
     const int64_t HD = 1LL * H * D;
     AtpShape s;
     atp_shape(F, R, H, &s);
-    const size_t lds_u = static_cast<size_t>(H) * W * sizeof(float);
-    if (lds_u > 64 * 1024) return RECON_ERR_UNSUPPORTED;
+    const size_t lds_u = static_cast<size_t>(H) * (F + R) * sizeof(float);                  // k_gat_atp_bwd's copy of u: the dst and rel parts
+    if (lds_u > 60 * 1024) return RECON_ERR_UNSUPPORTED;
     const size_t lds_k2 = lds_u + (kBlock / 64) * 512;                 // + the next node's index vectors, per wave (k_gat_atp_bwd)
 
     // (0) through the ELU, and q = g_h . h per (node, head)
@@ -2171,8 +2283,14 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         // nodes: persistent waves, as many workgroups as the kernel's occupancy keeps resident (k2_resident_blocks), a multiple of 8
         // (one share per XCD) and never more than the nodes need; pieces: a launch of their own, one piece per wave
         dim3 grid;
-#define CALL_BWD(V_, K_, H_) do { if (V_ == 4 && a->io_bf16) hipLaunchKernelGGL((k_gat_atp_bwd<4, K_, H_, true>), grid, dim3(kBlock), lds_k2, st, p); \
-                                  else hipLaunchKernelGGL((k_gat_atp_bwd<V_, K_, H_>), grid, dim3(kBlock), lds_k2, st, p); } while (0)
+        // the LDS row ring (LR) for rows of at most 1 KiB wherever it fits the 64 KiB a launch gets without asking; RECON_K2_LDS_RING=0: off
+        const bool lring = s.vec == 4 && s.kr == 1 && lds_k2 + (kBlock / 64) * kK2LdsRingBytes <= 64 * 1024 && cfg_char(CFG_K2_LDS_RING) != '0';
+        const size_t lds_run = lds_k2 + (lring ? (kBlock / 64) * kK2LdsRingBytes : 0);
+#define CALL_BWD(V_, K_, H_) do { constexpr bool LRC = V_ == 4 && K_ == 1;                                                                   \
+                                  if (V_ == 4 && a->io_bf16) { if (LRC && lring) hipLaunchKernelGGL((k_gat_atp_bwd<4, K_, H_, true, LRC>), grid, dim3(kBlock), lds_run, st, p); \
+                                                               else hipLaunchKernelGGL((k_gat_atp_bwd<4, K_, H_, true>), grid, dim3(kBlock), lds_run, st, p); }          \
+                                  else if (LRC && lring) hipLaunchKernelGGL((k_gat_atp_bwd<V_, K_, H_, false, LRC>), grid, dim3(kBlock), lds_run, st, p);              \
+                                  else hipLaunchKernelGGL((k_gat_atp_bwd<V_, K_, H_>), grid, dim3(kBlock), lds_run, st, p); } while (0)
         if (p.n_piece > 0) {
             p.pieces = 1;
             grid = dim3(static_cast<unsigned>(ceil_div64(p.n_piece, kBlock / 64)));
@@ -2181,7 +2299,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         p.pieces = 0;
         {
             const int64_t need = ceil_div64(N, kBlock / 64);
-            int64_t nb = k2_resident_blocks(s.kr, s.ht, lds_k2);
+            int64_t nb = k2_resident_blocks(s.kr, s.ht, lds_run);
             if (nb > need) nb = (need + 7) / 8 * 8;
             grid = dim3(static_cast<unsigned>(nb));
             ATP_DISPATCH(s, CALL_BWD);

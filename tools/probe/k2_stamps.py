@@ -23,19 +23,34 @@ def carve(dev, sizes):
 
 gat_layers._carve = carve
 d = torch.device("cuda:0")
-B, n, e, F_, D, H = 512, 16, 64, 200, 200, 8
-N, E = B * n, B * e
-x, edge, ee = synth.synthetic_batched_graph(B, n, e, F_, F_, seed=0)
-g = torch.Generator().manual_seed(2)
-a = (torch.randn(H, D, 3 * F_, generator=g) * 0.05).to(d).requires_grad_(True)
-a2 = (torch.randn(H, D, generator=g) * 0.05).to(d).requires_grad_(True)
-G = torch.randn(N, H * D, generator=g).to(d)
-graph = prepare_graph(edge.to(d), None, N)
-xd, eed = x.to(d).requires_grad_(True), ee.to(d).requires_grad_(True)
-for _ in range(5):
-    gat_heads(xd, eed, a, a2, graph, None, 0.2, True).backward(G)
+workload = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+if workload == "cfg2":
+    B, n, e, F_, D, H = 512, 16, 64, 200, 200, 8
+    N, E = B * n, B * e
+    x, edge, ee = synth.synthetic_batched_graph(B, n, e, F_, F_, seed=0)
+    g = torch.Generator().manual_seed(2)
+    a = (torch.randn(H, D, 3 * F_, generator=g) * 0.05).to(d).requires_grad_(True)
+    a2 = (torch.randn(H, D, generator=g) * 0.05).to(d).requires_grad_(True)
+    G = torch.randn(N, H * D, generator=g).to(d)
+    graph = prepare_graph(edge.to(d), None, N)
+    xd, eed = x.to(d).requires_grad_(True), ee.to(d).requires_grad_(True)
+    for _ in range(5):
+        gat_heads(xd, eed, a, a2, graph, None, 0.2, True).backward(G)
+else:                                                                    # cfg5f32 / cfg5bf16: the attention layers of tools/secondary.py's power-law legs
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    torch.autograd.set_multithreading_enabled(False)
+    import secondary as S
+    (S.powerlaw_spgat if workload == "cfg5f32" else S.powerlaw_mixed_stack_bf16)(iters=2)
+    F_ = 200
+    N = None
 torch.cuda.synchronize()
+if N is None:
+    N = (gat_layers._lib_sizes.__self__ if False else 0) or 0
+if not N:                                                                 # size of the gxd slice: up to the next slice of the carve
+    N = (int(cap["ptrs"][5]) - int(cap["ptrs"][4])) // (4 * F_)
 raw = gat_layers._view_f32(cap["ws"], cap["ptrs"][4], N * F_).view(N, F_)[:, :14].contiguous().cpu().numpy().view(np.uint64)   # [N, 7]
+raw = raw[raw[:, 0] != 0]                                                 # (padding rows of the slice; hub nodes' rows are written by their own wave too)
+N = raw.shape[0]
 st = raw[:, :5].astype(np.int64)
 hw = raw[:, 5]
 deg = raw[:, 6]
