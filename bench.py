@@ -351,7 +351,7 @@ def main():
             result["roofline"]["survey_definition"] = {"bytes": algorithmic_bytes_fwd(N, E, H, D), "time_us": (t_scores + t_edge) * 1e6,
                                                        "frac": algorithmic_bytes_fwd(N, E, H, D) / (t_scores + t_edge) / HBM_PEAK}
         try:            # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot collect PMC itself)
-            pmc_file = next(f for f in ("round5_pmc_traffic.json", "round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json")
+            pmc_file = next(f for f in ("round6_pmc_traffic.json", "round5_pmc_traffic.json", "round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json")
                             if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             if workload == "cfg2" and (B, n, e, F_, D, H) == (512, 16, 64, 200, 200, 8) and kname in pmc:

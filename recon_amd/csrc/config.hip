@@ -14,7 +14,7 @@ namespace {
 const char* const kNames[CFG_COUNT] = {
     "RECON_BGEMM_CFG", "RECON_GCN_FUSED", "RECON_GCN_FUSED_BWD", "RECON_GCN_FUSED_PARTS", "RECON_GCN_STACK_PARTS", "RECON_GEMM_CFG", "RECON_GEMM_LIN",
     "RECON_GEMM_SPLITK", "RECON_GEMM_XCD", "RECON_PROP_B16", "RECON_PROP_B16_YPOST", "RECON_PROP_BWD", "RECON_PROP_BWD_CHAIN", "RECON_PROP_BWD_WIDE",
-    "RECON_PROP_FWD", "RECON_PROP_LDS_KB", "RECON_ATP_ROW_SCALE", "RECON_GRAPH_SMALL", "RECON_GCN_STACK_GPW", "RECON_KG_NHOP", "RECON_HX2_RING", "RECON_K2_LDS_RING"};
+    "RECON_PROP_FWD", "RECON_PROP_LDS_KB", "RECON_ATP_ROW_SCALE", "RECON_GRAPH_SMALL", "RECON_GCN_STACK_GPW", "RECON_KG_NHOP", "RECON_HX2_RING", "RECON_K2_LDS_RING", "RECON_K2_PERSIST"};
 char g_val[CFG_COUNT][32];
 bool g_set[CFG_COUNT];
 std::once_flag g_once;

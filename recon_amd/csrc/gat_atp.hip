@@ -740,6 +740,8 @@ constexpr int kK1NodesPerWave = 1;
 template <int VEC, int KR, int HT, bool TRAIN, int PL, bool B16 = false>
 __global__ void __launch_bounds__(kBlock, KR >= 8 ? 2 : 1) k_gat_atp_fwd(const AtpFwdK p) {      // KR = 8: 260 registers unbounded, one short of two waves per SIMD
     // edges in flight per wave: their rows are requested together, so a node of degree <= UNR costs ONE row round trip
+    // (four edges in flight for one-row inputs, round 6: 30.9 against 29.6 us at cfg 2 — three waves per SIMD instead of four —, 63 against 69 us
+    // on cfg 5's bfloat16 leg, 64 against 63 on its float32 leg: not kept)
     constexpr int UNR = (KR * HT >= 16 || KR >= 8) ? 1 : 2;       // KR = 8: two edges in flight are 128 registers of rows
     constexpr int NPW = kK1NodesPerWave;
     const int lane = threadIdx.x & 63;
@@ -1008,7 +1010,7 @@ struct AtpBwdK {
     const int4* piece;
     float* hubG;
     int32_t gee_by_slot;        // edge_embed is a table read through `eid` (recon_gat_atp_args.ee_index): g_ee rows go by CSR slot
-    int32_t pieces;             // 1: this launch walks the hub pieces, one per wave; 0: the nodes, persistent waves (k_gat_atp_bwd)
+    int32_t persist;            // k_gat_atp_bwd: 1 = persistent waves over XCD-contiguous node ranges (graphs without hub pieces), 0 = one piece / node per wave
 };
 
 // ---- raw buffer access through wave-uniform ROW descriptors (round 6) -------------------------------------------------------------
@@ -1092,24 +1094,35 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
     const int F = p.F, R = p.R, H = p.H, W = 2 * F + R;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // Two launches of this kernel (p.pieces): the hub PIECES, one per wave (the longest rows: their own grid, dealt round over the XCDs
-    // in blockIdx order), and the NODES by persistent waves — round 6.  Cycle stamps of the one-node-per-wave form at cfg 2 (39 k cycles
-    // per wave): 9.4 k from entry until the row pointers, the slot indices (two dependent round trips) and the block's copy of u were
-    // there, 18.7 k for the node's rows of g_V, 10.6 k for the walk — a wave asked the memory system for nothing during half of its
-    // life.  A persistent wave stages u once and has the NEXT node's row pointers and index vectors in flight under the current node's
-    // rows: a node then starts with its requests.  XCD x (blocks x, x + 8, ...) owns the nodes [x, x + 1) * ceil(N / 8): the rows of x a
-    // batched graph's edges gather stay in ONE L2.
-    const bool is_piece = p.pieces != 0;                                 // uniform over the launch
-    const int widx = blockIdx.x * (kBlock / 64) + wave;                  // piece id in a pieces launch
-    const int xcd = blockIdx.x & 7, nbx = (gridDim.x + 7 - xcd) >> 3;    // blocks of this XCD (any grid size)
+    // Two ways of handing out the work (p.persist, chosen per launch by the host):
+    //  * graphs WITHOUT hub rows (batched sentence / context graphs: every node costs about the same) — PERSISTENT waves, round 6.  Cycle
+    //    stamps of the one-node-per-wave form at cfg 2 (39 k cycles per wave): 9.4 k from entry until the row pointers, the slot indices
+    //    (two dependent round trips) and the block's copy of u were there, 18.7 k for the node's rows of g_V, 10.6 k for the walk — a wave
+    //    asked the memory system for nothing during half of its life.  A persistent wave stages u once and has the NEXT node's row
+    //    pointers and index vectors in flight under the current node's rows: a node then starts with its requests.  XCD x (blocks x,
+    //    x + 8, ...) owns the nodes [x, x + 1) * ceil(N / 8): the rows of x a batched graph's edges gather stay in ONE L2.
+    //  * graphs WITH hub rows (knowledge graphs, power-law batches: a node costs anything between nothing and 64 slots) — one piece or
+    //    node per wave, workgroups dealt by the hardware as they finish: pieces first (the longest rows of the launch, in blockIdx order so
+    //    that they go round the XCDs), the nodes behind them in XCD-contiguous ranges.  Measured in between and not kept (K2' time per
+    //    backward pass at cfg 5 float32 / stage A layer 1; this form: 156 / 44 us): persistent nodes with the pieces as a launch of their
+    //    own (192 / 2 x 45: the pieces' 64-slot walks are a second kernel's worth of time), pieces dealt by wave number in front of a static
+    //    share of nodes (156 / 62: the waves that got a piece run a whole share behind), pieces and nodes CLAIMED from counters (atomicAdd,
+    //    one per XCD's range 256 bytes apart, claimed a node ahead, self-resetting: 197 / 91, cfg 2 73 against 53 — ~1 400 atomics per
+    //    address cost more than the imbalance they removed).
+    const bool persist = p.persist != 0;                                 // uniform over the launch
+    const int npb = persist ? 0 : (p.n_piece + kBlock / 64 - 1) / (kBlock / 64);
+    const int widx = blockIdx.x * (kBlock / 64) + wave;                  // piece id in a piece block
+    const bool is_piece = static_cast<int>(blockIdx.x) < npb && widx < p.n_piece;
+    const int xcd = blockIdx.x & 7, nbx = (gridDim.x + 7 - xcd) >> 3;    // (persist) blocks of this XCD, any grid size
     const int nchunk = (p.N + 7) >> 3;
-    const int node_hi = min(p.N, (xcd + 1) * nchunk), node_stride = nbx * (kBlock / 64);
-    int node = is_piece ? p.N : xcd * nchunk + (blockIdx.x >> 3) * (kBlock / 64) + wave;
+    const int node_hi = persist ? min(p.N, (xcd + 1) * nchunk) : p.N, node_stride = nbx * (kBlock / 64);
+    int node = persist ? xcd * nchunk + (blockIdx.x >> 3) * (kBlock / 64) + wave
+                       : (static_cast<int>(blockIdx.x) < npb ? p.N : xcd_block(blockIdx.x - npb, gridDim.x - npb) * (kBlock / 64) + wave);
     // The walk is a chain of dependent round trips (row pointers -> slot indices -> rows); start it before anything else:
     // the slot -> (source node, edge id) indices of the first 64 slots come with ONE coalesced load per array (lane j holds
     // slot beg + j) and are handed out with v_readlane instead of an index load in front of every row load.
     int beg = 0, end = 0;
-    if (is_piece) { if (widx < p.n_piece) { const int4 pc = p.piece[widx]; node = pc.x; beg = pc.y; end = pc.z; } }
+    if (is_piece) { const int4 pc = p.piece[widx]; node = pc.x; beg = pc.y; end = pc.z; }
     else if (node < node_hi) {
         beg = p.rowptr[node]; end = p.rowptr[node + 1];
         if (p.hub_chunk && end - beg > p.hub_chunk) end = beg;           // a hub: its pieces walk the row
@@ -1159,7 +1172,7 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
     node = __builtin_amdgcn_readfirstlane(node); beg = __builtin_amdgcn_readfirstlane(beg); end = __builtin_amdgcn_readfirstlane(end);
     const int cn0 = min(64, end - beg);
     // the next node of this wave: its row pointers are requested now, its index vectors below (behind this node's first requests)
-    const int nnode = is_piece ? p.N : node + node_stride;
+    const int nnode = persist ? node + node_stride : p.N;
     const bool more = nnode < node_hi;                                   // wave-uniform
     int nbeg = 0, nend = 0;
     if (more) { nbeg = p.rowptr[nnode]; nend = p.rowptr[nnode + 1]; }
@@ -2280,8 +2293,8 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         if (hubs && static_cast<size_t>(g->hub_ws_floats) < recon_graph_hub_ws_floats(g, F, R, H)) return RECON_ERR_WORKSPACE;
         p.hub_chunk = hubs ? g->hub_chunk : 0; p.n_piece = hubs ? g->n_piece : 0;
         p.piece = reinterpret_cast<const int4*>(g->piece); p.hubG = g->hub_ws;
-        // nodes: persistent waves, as many workgroups as the kernel's occupancy keeps resident (k2_resident_blocks), a multiple of 8
-        // (one share per XCD) and never more than the nodes need; pieces: a launch of their own, one piece per wave
+        // persistent waves (no hub pieces): as many workgroups as the kernel's occupancy keeps resident (k2_resident_blocks), a multiple of 8
+        // (one share per XCD) and never more than the nodes need; with hub pieces: one piece / node per wave, the pieces' blocks in front
         dim3 grid;
         // the LDS row ring (LR) for rows of at most 1 KiB wherever it fits the 64 KiB a launch gets without asking; RECON_K2_LDS_RING=0: off
         const bool lring = s.vec == 4 && s.kr == 1 && lds_k2 + (kBlock / 64) * kK2LdsRingBytes <= 64 * 1024 && cfg_char(CFG_K2_LDS_RING) != '0';
@@ -2291,19 +2304,16 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
                                                                else hipLaunchKernelGGL((k_gat_atp_bwd<4, K_, H_, true>), grid, dim3(kBlock), lds_run, st, p); }          \
                                   else if (LRC && lring) hipLaunchKernelGGL((k_gat_atp_bwd<V_, K_, H_, false, LRC>), grid, dim3(kBlock), lds_run, st, p);              \
                                   else hipLaunchKernelGGL((k_gat_atp_bwd<V_, K_, H_>), grid, dim3(kBlock), lds_run, st, p); } while (0)
-        if (p.n_piece > 0) {
-            p.pieces = 1;
-            grid = dim3(static_cast<unsigned>(ceil_div64(p.n_piece, kBlock / 64)));
-            ATP_DISPATCH(s, CALL_BWD);
-        }
-        p.pieces = 0;
-        {
+        p.persist = (p.n_piece == 0 && cfg_char(CFG_K2_PERSIST) != '0') ? 1 : 0;
+        if (p.persist) {
             const int64_t need = ceil_div64(N, kBlock / 64);
             int64_t nb = k2_resident_blocks(s.kr, s.ht, lds_run);
             if (nb > need) nb = (need + 7) / 8 * 8;
             grid = dim3(static_cast<unsigned>(nb));
-            ATP_DISPATCH(s, CALL_BWD);
+        } else {
+            grid = dim3(static_cast<unsigned>(ceil_div64(N, kBlock / 64) + ceil_div64(p.n_piece, kBlock / 64)));
         }
+        ATP_DISPATCH(s, CALL_BWD);
 #undef CALL_BWD
         if (hubs) {
             const dim3 gh(static_cast<unsigned>(ceil_div64(g->n_hub, kBlock / 64)));

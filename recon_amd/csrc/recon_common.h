@@ -20,7 +20,7 @@ constexpr int kWave = 64;
 // ---- run-time switches (config.hip): read from the environment once, at first use; nullptr = unset, like getenv ----------------------
 enum CfgKey { CFG_BGEMM_CFG, CFG_GCN_FUSED, CFG_GCN_FUSED_BWD, CFG_GCN_FUSED_PARTS, CFG_GCN_STACK_PARTS, CFG_GEMM_CFG, CFG_GEMM_LIN, CFG_GEMM_SPLITK,
               CFG_GEMM_XCD, CFG_PROP_B16, CFG_PROP_B16_YPOST, CFG_PROP_BWD, CFG_PROP_BWD_CHAIN, CFG_PROP_BWD_WIDE, CFG_PROP_FWD, CFG_PROP_LDS_KB,
-              CFG_ATP_ROW_SCALE, CFG_GRAPH_SMALL, CFG_GCN_STACK_GPW, CFG_KG_NHOP, CFG_HX2_RING, CFG_K2_LDS_RING, CFG_COUNT };
+              CFG_ATP_ROW_SCALE, CFG_GRAPH_SMALL, CFG_GCN_STACK_GPW, CFG_KG_NHOP, CFG_HX2_RING, CFG_K2_LDS_RING, CFG_K2_PERSIST, CFG_COUNT };
 const char* cfg(CfgKey k);
 int cfg_int(CfgKey k, int dflt);
 char cfg_char(CfgKey k);                  // first character, '\0' when unset
