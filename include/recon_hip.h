@@ -89,6 +89,16 @@ typedef struct {
     float* hub_ws;              /* scratch of the piece partial sums, reused by every call on this graph (calls on one graph
                                    are stream ordered): at least recon_graph_hub_ws_floats() floats for the widest layer   */
     int64_t hub_ws_floats;
+    /* Row compaction (optional; n_rows = 0: every node is a row).  A knowledge-graph batch (GAT/main.py:478-516) aggregates into the
+     * batch's ~128 entities of a 14 541-entity table: all other destination rows are empty, their layer output is exactly 0
+     * (GAT/layers.py:152-158: 0 / 1e-12, elu(0) = 0) and so is everything they contribute backward.  With these tables the
+     * aggregate-then-project kernels run their node-parallel stages (V, the three GEMMs, g_V, the destination walk of the backward)
+     * over the n_rows rows WITH edges; `out` / `grad_out` of recon_gat_atp_args then hold n_rows rows / are read through row_node.
+     * The hub tables of the destination side name ROWS when these are set.  Filled by recon_graph_rows_compact().            */
+    int32_t n_rows;             /* destination nodes with at least one in-edge                                              */
+    int32_t* row_node;          /* [n_rows]     node id of each row, ascending                                              */
+    int32_t* rowptr_rows;       /* [n_rows + 1] first CSR slot of each row (rowptr_dst without the empty rows)              */
+    int32_t* node_row;          /* [N]          row of each node, -1: none                                                  */
 } recon_graph;
 
 #define RECON_HUB_CHUNK 64
@@ -119,6 +129,16 @@ int recon_graph_hubs_read(const recon_graph* g, void* workspace, int32_t* counts
                           recon_stream_t stream);
 /* floats of hub_ws one KB-GAT layer call (forward or backward) on this graph needs */
 size_t recon_graph_hub_ws_floats(const recon_graph* g, int32_t F, int32_t R, int32_t H);
+/* recon_graph_hubs_read that also returns the number of destination rows with edges (*live_rows; counted by recon_graph_build_counted's
+ * last launch): the caller decides on row compaction from it.  recon_graph_rows_compact: g->n_rows = that count, row_node / rowptr_rows /
+ * node_row point to device arrays of n_rows / n_rows + 1 / N int32; one launch; call it BEFORE recon_graph_hubs_fill (whose destination
+ * tables are then built over the rows). */
+int recon_graph_counts_read(const recon_graph* g, void* workspace, int32_t* counts /* host [4] */, int32_t* live_rows /* host, may be NULL */,
+                            const int32_t* bad, int32_t* bad_host, recon_stream_t stream);
+int recon_graph_rows_compact(const recon_graph* g, recon_stream_t stream);
+/* out[n, :] = rows[node_row[n], :] or 0 (node_row[n] < 0): the layer output of a row-compacted graph back in node order. */
+int recon_rows_expand(const float* rows, int32_t ld_rows, const int32_t* node_row, int32_t N, int32_t width, float* out, int32_t ld_out,
+                      recon_stream_t stream);
 
 /* edge_dst / edge_src: the two rows of the reference's int64 [2,E] edge tensor (row 0 =
  * aggregation target, row 1 = neighbour; GAT/create_batch.py:429-433).  Returns RECON_ERR_INVALID
@@ -231,7 +251,7 @@ typedef struct {
     float* sigma;               /* [E,H] saved scores (CSR-slot order); NULL iff Z NULL      */
     float* Z;                   /* [N,H] saved clamped row sums; NULL = inference call       */
     float* Zk;                  /* [N,H] saved sum_e k_e w_e                                 */
-    float* out;                 /* [N, ld_out]                                               */
+    float* out;                 /* [N, ld_out]; with a row-compacted graph (recon_graph.n_rows > 0): [n_rows, ld_out], row r = node row_node[r] */
     int32_t ld_out;
     void* a_split;              /* recon_gat_atp_split_bytes() bytes, workspace / saved: the three   *
                                  * bfloat16 term planes of a and a^T for the split-precision GEMMs   *
@@ -278,9 +298,9 @@ int recon_gat_atp_project(const recon_graph* g, const recon_gat_atp_args* args, 
 
 typedef struct {
     recon_gat_atp_args fwd;     /* same tensors as the forward call (u, V, sigma, Z, Zk, out filled)  */
-    const float* grad_out;      /* [N, ld_gout]                                                      */
+    const float* grad_out;      /* [N, ld_gout] — all nodes, also with a row-compacted graph (rows are read through row_node)        */
     int32_t ld_gout;
-    float* g_h;                 /* [N,H*D]    workspace (only read when concat != 0; unused, may be NULL, in F16X2 mode) */
+    float* g_h;                 /* [N,H*D]    workspace (written when concat != 0 or the graph is row-compacted; unused, may be NULL, in F16X2 mode) */
     float* g_V;                 /* [N,H,2F+R] workspace: d loss / d V                                 */
     float* g_sigma;             /* [E,H]      workspace: d loss / d s_e                               */
     float* Gxs;                 /* [E,F]      workspace: per-edge gradient rows bound for x[src_e]    */

@@ -26,7 +26,8 @@ class ReconGraph(C.Structure):
                 ("hub_chunk", C.c_int32), ("n_hub", C.c_int32), ("n_piece", C.c_int32),
                 ("hub_node", c_i32p), ("hub_ptr", c_i32p), ("piece", c_i32p),
                 ("n_hub_src", C.c_int32), ("n_piece_src", C.c_int32), ("hub_node_src", c_i32p), ("hub_ptr_src", c_i32p), ("piece_src", c_i32p),
-                ("hub_ws", c_f32p), ("hub_ws_floats", C.c_int64)]
+                ("hub_ws", c_f32p), ("hub_ws_floats", C.c_int64),
+                ("n_rows", C.c_int32), ("row_node", c_i32p), ("rowptr_rows", c_i32p), ("node_row", c_i32p)]
 
 
 class GatFwdArgs(C.Structure):
@@ -147,6 +148,9 @@ SYMBOLS = [
     ("recon_graph_build_counted", C.c_int, [c_i64p, c_i64p, C.POINTER(ReconGraph), C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.c_void_p]),
     ("recon_graph_hubs_read", C.c_int, [C.POINTER(ReconGraph), C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     ("recon_graph_hubs_fill", C.c_int, [C.POINTER(ReconGraph), C.c_void_p]),
+    ("recon_graph_counts_read", C.c_int, [C.POINTER(ReconGraph), C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    ("recon_graph_rows_compact", C.c_int, [C.POINTER(ReconGraph), C.c_void_p]),
+    ("recon_rows_expand", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     ("recon_graph_hub_ws_floats", C.c_size_t, [C.POINTER(ReconGraph), C.c_int32, C.c_int32, C.c_int32]),
     ("recon_spmm_rowsum_workspace_floats", C.c_size_t, [C.c_int32, C.c_int32]),
     ("recon_spmm_rowsum_fwd", C.c_int, [C.POINTER(ReconGraph), c_f32p, C.c_int32, c_f32p, c_f32p, C.c_void_p]),

@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(kThreads) k_keys_hist(const int64_t* __restric
                                                         int32_t* __restrict__ blockhist, int32_t nblocks, int32_t N, int32_t* __restrict__ bad,
                                                         int32_t* __restrict__ nexthist, const int32_t* __restrict__ lb_keys = nullptr,
                                                         int32_t* __restrict__ lb_rowptr = nullptr, int32_t* __restrict__ zero4 = nullptr) {
-    if (zero4 && blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0;      // the hub counts of recon_graph_build_counted
+    if (zero4 && blockIdx.x == 0 && threadIdx.x < 6) zero4[threadIdx.x] = 0;      // the hub counts of recon_graph_build_counted (+ flag word, + the count of rows with edges)
     if (static_cast<int>(blockIdx.x) >= nblocks) {                       // trailing blocks: the row pointers of the sort that just finished
         const int r = (blockIdx.x - nblocks) * kThreads + threadIdx.x;  // (k_rowptr_lower_bound's work: a launch less per build)
         if (r > N) return;
@@ -232,9 +232,11 @@ __global__ void __launch_bounds__(256) k_rowptr_lower_bound_count(const int32_t*
     lb[t] = mine;
     if (t == 255) lb[256] = r + 1 <= N ? search(r + 1) : E;
     if (r <= N) rowptr[r] = mine;
-    __syncthreads();
+    const int deg_o = r < N ? rowptr_other[r + 1] - rowptr_other[r] : 0;
+    const int live = __syncthreads_count(deg_o > 0);                     // (the barrier the LDS exchange needs) destination rows WITH edges: counts[5], one atomic per block
+    if (t == 0 && live) atomicAdd(&counts[5], live);
     if (r < N) {
-        const int deg = lb[t + 1] - mine, deg_o = rowptr_other[r + 1] - rowptr_other[r];
+        const int deg = lb[t + 1] - mine;
         if (deg_o > chunk) { atomicAdd(&counts[0], 1); atomicAdd(&counts[1], (deg_o + chunk - 1) / chunk); }
         if (deg > chunk) { atomicAdd(&counts[2], 1); atomicAdd(&counts[3], (deg + chunk - 1) / chunk); }
     }
@@ -287,7 +289,10 @@ template <bool FILL>
 __global__ void __launch_bounds__(1024) k_hub_scan(const int32_t* __restrict__ rowptr, int32_t N, int32_t chunk, int32_t* __restrict__ counts,
                                                    int32_t* __restrict__ hub_node, int32_t* __restrict__ hub_ptr, int4* __restrict__ piece) {
     __shared__ int32_t sh[1024], sp[1024];
+    __shared__ int32_t s_live;
     const int t = threadIdx.x;
+    if (t == 0) s_live = 0;
+    const bool count_live = !FILL && blockIdx.x == 0 && hub_ptr;          // count form behind a build, destination side: rows with edges -> counts[5]
     if (!FILL && blockIdx.x == 0 && t == 0 && hub_ptr) counts[4] = hub_node ? *hub_node : 0;   // count form behind a build: its id-range flag rides in `hub_node` (hub_ptr: non-null marks that form)
     if (!FILL && blockIdx.x == 1) {                                      // count form, second workgroup: the other row pointer rides in `piece`
         rowptr = reinterpret_cast<const int32_t*>(piece);
@@ -296,13 +301,15 @@ __global__ void __launch_bounds__(1024) k_hub_scan(const int32_t* __restrict__ r
     }
     const int per = (N + 1023) / 1024;                                   // every thread owns `per` consecutive nodes
     const int lo = min(t * per, N), hi = min(lo + per, N);
-    int h = 0, p = 0;
+    int h = 0, p = 0, live = 0;
     for (int i = lo; i < hi; ++i) {
         const int deg = rowptr[i + 1] - rowptr[i];
         if (deg > chunk) { ++h; p += (deg + chunk - 1) / chunk; }
+        live += deg > 0;
     }
     sh[t] = h; sp[t] = p;
     __syncthreads();
+    if (count_live && live) atomicAdd(&s_live, live);
     for (int off = 1; off < 1024; off <<= 1) {                           // Hillis-Steele inclusive scans
         const int vh = (t >= off) ? sh[t - off] : 0, vp = (t >= off) ? sp[t - off] : 0;
         __syncthreads();
@@ -324,7 +331,37 @@ __global__ void __launch_bounds__(1024) k_hub_scan(const int32_t* __restrict__ r
             }
         }
         if (t == 1023) hub_ptr[sh[t]] = sp[t];
-    } else if (t == 1023) { counts[0] = sh[t]; counts[1] = sp[t]; }
+    } else if (t == 1023) { counts[0] = sh[t]; counts[1] = sp[t]; if (count_live) counts[5] = s_live; }
+}
+
+// Row compaction (recon_graph.n_rows): the destination rows WITH edges, in node order — row_node[r] = node, rowptr_rows[r] = the row's
+// first slot (rowptr_rows[n_rows] = E), node_row[node] = r or -1.  ONE workgroup, the scheme of k_hub_scan: every thread counts the live
+// rows of its own run of consecutive nodes, a block-wide exclusive scan hands out the positions.  A knowledge-graph batch aggregates
+// into the batch's ~128 entities of a 14 541-entity table: every node-parallel stage of the attention layer then runs over the rows
+// that have something to aggregate instead of over the table.
+__global__ void __launch_bounds__(1024) k_rows_compact(const int32_t* __restrict__ rowptr, int32_t N, int32_t* __restrict__ row_node,
+                                                       int32_t* __restrict__ rowptr_rows, int32_t* __restrict__ node_row) {
+    __shared__ int32_t sc[1024];
+    const int t = threadIdx.x;
+    const int per = (N + 1023) / 1024;
+    const int lo = min(t * per, N), hi = min(lo + per, N);
+    int live = 0;
+    for (int i = lo; i < hi; ++i) live += rowptr[i + 1] > rowptr[i];
+    sc[t] = live;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = (t >= off) ? sc[t - off] : 0;
+        __syncthreads();
+        sc[t] += v;
+        __syncthreads();
+    }
+    int o = sc[t] - live;
+    for (int i = lo; i < hi; ++i) {
+        const int b = rowptr[i];
+        if (rowptr[i + 1] > b) { row_node[o] = i; rowptr_rows[o] = b; node_row[i] = o; ++o; }
+        else node_row[i] = -1;
+    }
+    if (t == 1023) rowptr_rows[sc[t]] = rowptr[N];
 }
 
 // ---- the whole build of a SMALL graph in ONE launch (E <= kSmallE, N <= kSmallN): the chain of 14 launches above is a chain of turn-arounds on
@@ -505,8 +542,10 @@ extern "C" int recon_graph_hubs_fill(const recon_graph* g, recon_stream_t stream
         g->n_piece_src < 0) return RECON_ERR_INVALID;
     if (g->n_hub > 0) {
         if (!g->hub_node || !g->hub_ptr || !g->piece || (reinterpret_cast<uintptr_t>(g->piece) & 15)) return RECON_ERR_INVALID;
-        hipLaunchKernelGGL((k_hub_scan<true>), dim3(1), dim3(1024), 0, as_stream(stream), g->rowptr_dst, g->N, g->hub_chunk, nullptr, g->hub_node,
-                           g->hub_ptr, reinterpret_cast<int4*>(g->piece));
+        // (rows compacted — recon_graph_rows_compact ran in front on this stream: the tables name ROWS)
+        const bool rows = g->n_rows > 0 && g->rowptr_rows;
+        hipLaunchKernelGGL((k_hub_scan<true>), dim3(1), dim3(1024), 0, as_stream(stream), rows ? g->rowptr_rows : g->rowptr_dst, rows ? g->n_rows : g->N, g->hub_chunk,
+                           nullptr, g->hub_node, g->hub_ptr, reinterpret_cast<int4*>(g->piece));
     }
     if (g->n_hub_src > 0) {
         if (!g->hub_node_src || !g->hub_ptr_src || !g->piece_src || (reinterpret_cast<uintptr_t>(g->piece_src) & 15)) return RECON_ERR_INVALID;
@@ -555,17 +594,29 @@ extern "C" int recon_graph_build_counted(const int64_t* edge_dst, const int64_t*
     return graph_build(edge_dst, edge_src, g, workspace, workspace_bytes, bad, chunk, stream);
 }
 extern "C" int recon_graph_hubs_read(const recon_graph* g, void* workspace, int32_t* counts, const int32_t* bad, int32_t* bad_host, recon_stream_t stream) {
+    return recon_graph_counts_read(g, workspace, counts, nullptr, bad, bad_host, stream);
+}
+extern "C" int recon_graph_counts_read(const recon_graph* g, void* workspace, int32_t* counts, int32_t* live_rows, const int32_t* bad, int32_t* bad_host,
+                                       recon_stream_t stream) {
     if (!g || !counts || !workspace || g->N < 0 || g->E < 0 || (bad && !bad_host)) return RECON_ERR_INVALID;
     hipStream_t st = as_stream(stream);
     counts[0] = counts[1] = counts[2] = counts[3] = 0;
     if (bad_host) *bad_host = 0;
-    if (g->E > 0) {                                                      // sizes and flag in ONE copy (the build's last launch put the flag behind the sizes)
-        int32_t five[5] = {0, 0, 0, 0, 0};
-        if (hipMemcpyAsync(five, graph_ws_counts(workspace, g->N, g->E), 5 * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return RECON_ERR_LAUNCH;
+    if (live_rows) *live_rows = 0;
+    if (g->E > 0) {                                                      // sizes, flag and the count of rows with edges in ONE copy (the build's last launch put them side by side)
+        int32_t six[6] = {0, 0, 0, 0, 0, 0};
+        if (hipMemcpyAsync(six, graph_ws_counts(workspace, g->N, g->E), 6 * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return RECON_ERR_LAUNCH;
         if (hipStreamSynchronize(st) != hipSuccess) return RECON_ERR_LAUNCH;
-        for (int i = 0; i < 4; ++i) counts[i] = five[i];
-        if (bad) *bad_host = five[4];
+        for (int i = 0; i < 4; ++i) counts[i] = six[i];
+        if (bad) *bad_host = six[4];
+        if (live_rows) *live_rows = six[5];
     } else if (hipStreamSynchronize(st) != hipSuccess) return RECON_ERR_LAUNCH;
+    return RECON_OK;
+}
+extern "C" int recon_graph_rows_compact(const recon_graph* g, recon_stream_t stream) {
+    if (!g || g->N <= 0 || !g->rowptr_dst || g->n_rows <= 0 || g->n_rows > g->N || !g->row_node || !g->rowptr_rows || !g->node_row) return RECON_ERR_INVALID;
+    hipLaunchKernelGGL(k_rows_compact, dim3(1), dim3(1024), 0, as_stream(stream), g->rowptr_dst, g->N, g->row_node, g->rowptr_rows, g->node_row);
+    RECON_CHECK_LAUNCH();
     return RECON_OK;
 }
 static int graph_build(const int64_t* edge_dst, const int64_t* edge_src, recon_graph* g, void* workspace, size_t workspace_bytes, int32_t* bad, int32_t chunk,

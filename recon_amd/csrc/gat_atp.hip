@@ -211,7 +211,10 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
                                                     int32_t ld_y, int32_t N, int32_t H, int32_t D, int32_t concat,
                                                     float* __restrict__ gh, float* __restrict__ q, uint16_t* __restrict__ ghp,
                                                     int64_t ld_p, int64_t plane_p, int32_t f16x2, const Hx2Scale gsc,
-                                                    float* __restrict__ row_inv, int64_t row_inv_ld, uint32_t* __restrict__ amax_q) {
+                                                    float* __restrict__ row_inv, int64_t row_inv_ld, uint32_t* __restrict__ amax_q,
+                                                    const int32_t* __restrict__ row_node) {
+    // row_node (row compaction, recon_graph.n_rows; NULL: rows are nodes): N counts ROWS, y and every output go by row, and row r's
+    // gradient is row row_node[r] of gy (the caller's grad_out covers all nodes).
     // ghp (optional): term planes of g_h for the split-precision GEMMs — three bfloat16 planes [3][N][ld_p], or (f16x2) the
     // half terms of s * g_h, head-major [H][N][2][D] (ld_p = 2 D, plane_p = D).  The scale s:
     //   row_inv == nullptr   one per tensor, from the published max |grad_out| (|elu'| <= 1, so it bounds |g_h|): a pass over grad_out
@@ -239,7 +242,7 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
         for (int j = 0; j < IPW; ++j) {
             const int it = min(item0 + j, total - 1);
             const int node = it / H, h = it % H;
-            g4[j] = *reinterpret_cast<const float4*>(gy + static_cast<int64_t>(node) * ld_gy + h * D + cc);
+            g4[j] = *reinterpret_cast<const float4*>(gy + static_cast<int64_t>(row_node ? row_node[node] : node) * ld_gy + h * D + cc);
             y4[j] = *reinterpret_cast<const float4*>(y + static_cast<int64_t>(node) * ld_y + h * D + cc);
         }
         const float gs_t = (f16x2 && !row_inv) ? hx2_scale_wave(gsc) : 1.f;
@@ -329,7 +332,7 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
             const int it = item0 + j;
             if (it >= total) break;
             const int node = it / H, h = it % H;
-            const float* gr = gy + static_cast<int64_t>(node) * ld_gy + h * D;
+            const float* gr = gy + static_cast<int64_t>(row_node ? row_node[node] : node) * ld_gy + h * D;
             const float* yr = y + static_cast<int64_t>(node) * ld_y + h * D;
             float part = 0.f;
             for (int c = 4 * lane; c < D; c += 256) {
@@ -377,7 +380,7 @@ __global__ void __launch_bounds__(256) k_elu_grad_q(const float* __restrict__ gy
         const int it = item0 + j;
         if (it >= total) break;
         const int node = it / H, h = it % H;
-        const float* gr = gy + static_cast<int64_t>(node) * ld_gy + h * D;
+        const float* gr = gy + static_cast<int64_t>(row_node ? row_node[node] : node) * ld_gy + h * D;
         const float* yr = y + static_cast<int64_t>(node) * ld_y + h * D;
         float* go = gh ? gh + static_cast<int64_t>(it) * D : nullptr;
         float part = 0.f;
@@ -681,6 +684,9 @@ struct AtpFwdK {
     const int4* piece;
     float* hubS; float* hubZ;
     int32_t* nan_flag;          // optional device word raised when a row sum is NaN / infinite (config.hip: recon_set_nan_flag)
+    // row compaction (recon_graph.n_rows): N above is the number of ROWS — what rowptr, the pieces, V, Z and Zk are indexed by — and row r
+    // aggregates into node row_node[r] (x and c_node are node tables); NULL: rows are nodes
+    const int32_t* row_node;
 };
 
 // two half planes of VEC consecutive ALREADY SCALED values: 2 * VEC bytes per plane.  Values are clamped to half's range: the
@@ -784,9 +790,10 @@ __global__ void __launch_bounds__(kBlock, KR >= 8 ? 2 : 1) k_gat_atp_fwd(const A
     if (is_piece) { begs[0] = pbeg; ends[0] = pend; }
     else if (p.hub_chunk && ends[0] - begs[0] > p.hub_chunk) return;    // a hub: its pieces and k_gat_atp_hub_fwd write this node
     struct NodeIn { int srcv, eidv; float cd; float xi[KR][VEC]; };
-    auto request = [&](NodeIn& q, int node, int beg, int end) {         // node < N
+    auto request = [&](NodeIn& q, int row, int beg, int end) {          // row < N
         q.srcv = 0; q.eidv = 0;
         if (beg < end) { const int kk = beg + min(lane, min(64, end - beg) - 1); q.srcv = p.src[kk]; q.eidv = p.eid[kk]; }
+        const int node = p.row_node ? p.row_node[row] : row;             // (wave-uniform) the node this row aggregates into
         q.cd = p.c_node[static_cast<int64_t>(node) * 2 * H + myhc];
 #pragma unroll
         for (int r = 0; r < KR; ++r) load_in<VEC, B16>(q.xi[r], p.x, static_cast<int64_t>(node) * F + cfF[r]);
@@ -988,7 +995,7 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_hub_fwd(const AtpFwdK p, con
     if (!(p.dst_shared && h > 0)) {
         for (int c = lane * VEC; c < F; c += 64 * VEC) {
             float xv[VEC];
-            load_in<VEC, B16>(xv, p.x, static_cast<int64_t>(node) * F + c);
+            load_in<VEC, B16>(xv, p.x, static_cast<int64_t>(p.row_node ? p.row_node[node] : node) * F + c);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) xv[v] *= zk;
             put(c, xv);
@@ -1011,6 +1018,9 @@ struct AtpBwdK {
     float* hubG;
     int32_t gee_by_slot;        // edge_embed is a table read through `eid` (recon_gat_atp_args.ee_index): g_ee rows go by CSR slot
     int32_t persist;            // k_gat_atp_bwd: 1 = persistent waves over XCD-contiguous node ranges (graphs without hub pieces), 0 = one piece / node per wave
+    // row compaction (recon_graph.n_rows): N is the number of ROWS — rowptr, the pieces, g_V, Z, Zk, q, gxd and Gs_dst go by row — and row r
+    // belongs to node row_node[r] (x is a node table); NULL: rows are nodes
+    const int32_t* row_node;
 };
 
 // ---- raw buffer access through wave-uniform ROW descriptors (round 6) -------------------------------------------------------------
@@ -1181,7 +1191,7 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
     int* const nidx = reinterpret_cast<int*>(U + H * UW) + wave * 128 + lane;
     float xi[KR][VEC], gxd[KR][VEC];
     {
-        const auto rxi = K2_RSRC(in_row(p.x, node, F), F * ES);
+        const auto rxi = K2_RSRC(in_row(p.x, p.row_node ? p.row_node[node] : node, F), F * ES);      // x is a NODE table (row compaction: AtpBwdK.row_node)
 #pragma unroll
         for (int r = 0; r < KR; ++r) {
 #pragma unroll
@@ -1626,6 +1636,7 @@ struct AtpSrcK {
     int32_t hub_chunk, n_piece;
     const int4* piece;
     float* hubP;
+    const int32_t* node_row;    // row compaction (recon_graph.node_row): gxd is indexed by ROW; a node without a row (-1) has no destination part.  NULL: gxd[node]
 };
 template <int VEC, int KR>
 __global__ void __launch_bounds__(kBlock) k_gat_atp_src(const AtpSrcK p) {
@@ -1645,13 +1656,14 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_src(const AtpSrcK p) {
         if (p.hub_chunk && end - beg > p.hub_chunk) return;
     }
     const int F = p.F, H = p.H;
+    const int drow = (p.node_row && !is_piece) ? p.node_row[node] : node;   // (wave-uniform) the node's row of gxd, -1: it has none
     float acc[KR][VEC];
 #pragma unroll
     for (int r = 0; r < KR; ++r) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[r][v] = 0.f;
         const int c = (r * 64 + lane) * VEC;
-        if (!is_piece && c < F && p.g_x) load_vec<VEC>(acc[r], p.gxd + static_cast<int64_t>(node) * F + c);
+        if (!is_piece && c < F && p.g_x && drow >= 0) load_vec<VEC>(acc[r], p.gxd + static_cast<int64_t>(drow) * F + c);
     }
     float gs = 0.f;
     // The CSC position -> slot indices of up to 64 positions come with one coalesced load and are handed out with v_readlane; four
@@ -1748,7 +1760,8 @@ __global__ void __launch_bounds__(kBlock) k_gat_atp_hub_src(const AtpSrcK p, con
     if (lane < H) sum_pieces<1>(gsl, p.hubP + F + lane, F + H, p0, p1);
     if (c < H) p.Gs_src[static_cast<int64_t>(node) * 2 * H + H + c] = gsl[0];      // stripe 0: c == lane
     if (!p.g_x) return;
-    float a[1] = {c < F ? p.gxd[static_cast<int64_t>(node) * F + c] : 0.f};
+    const int drow = p.node_row ? p.node_row[node] : node;
+    float a[1] = {(c < F && drow >= 0) ? p.gxd[static_cast<int64_t>(drow) * F + c] : 0.f};
     if (c < F) sum_pieces<1>(a, p.hubP + c, F + H, p0, p1);
     for (int h = 0; h < H; ++h) a[0] = fmaf(lane_bcast(gsl[0], h), p.u[static_cast<int64_t>(h) * p.W + F + (c < F ? c : 0)], a[0]);
     if (c < F) p.g_x[static_cast<int64_t>(node) * F + c] = a[0];
@@ -2004,6 +2017,13 @@ static int32_t atp_dst_shared(const recon_gat_atp_args* a) {
     const int64_t W = 2LL * a->F + a->R;
     return (atp_hx2(a) && !a->keep && a->H > 1 && (a->F % 8) == 0 && 2 * W * a->N * a->H < (1LL << 31)) ? a->F : 0;
 }
+// Row compaction (recon_graph.n_rows): the node-parallel stages run over the destination rows that have edges.  n = rows, rowptr = their
+// row pointers, row_node / node_row = the maps between rows and nodes (NULL: rows are nodes, n = N).
+struct AtpRows { int32_t n; const int32_t* rowptr; const int32_t* row_node; const int32_t* node_row; };
+static AtpRows atp_rows(const recon_graph* g, const recon_gat_atp_args* a) {
+    if (g->n_rows > 0 && g->n_rows < a->N && g->row_node && g->rowptr_rows && g->node_row) return AtpRows{g->n_rows, g->rowptr_rows, g->row_node, g->node_row};
+    return AtpRows{a->N, g->rowptr_dst, nullptr, nullptr};
+}
 // hub tables present and complete (recon_graph_hubs_fill)
 static bool atp_hubs(const recon_graph* g) {
     return g->hub_chunk > 0 && g->n_hub > 0 && g->n_piece > 0 && g->hub_node && g->hub_ptr && g->piece && g->hub_ws;
@@ -2110,11 +2130,12 @@ extern "C" int recon_gat_atp_aggregate(const recon_graph* g, const recon_gat_atp
     const bool train = a->Z != nullptr;
     hipStream_t st = as_stream(stream);
     AtpFwdK p;
-    p.rowptr = g->rowptr_dst; p.src = g->src; p.eid = a->ee_index ? a->ee_index : g->eid;       // the row of edge_embed a slot reads
+    const AtpRows rw = atp_rows(g, a);
+    p.rowptr = rw.rowptr; p.row_node = rw.row_node; p.src = g->src; p.eid = a->ee_index ? a->ee_index : g->eid;       // the row of edge_embed a slot reads
     p.x = a->x; p.ee = a->edge_embed; p.c_node = a->c_node; p.c_rel = a->c_rel; p.keep = a->keep;
     p.V = a->V; p.sigma = a->sigma; p.Z = a->Z; p.Zk = a->Zk;
     p.nan_flag = nan_flag();
-    p.N = a->N; p.E = a->E; p.F = a->F; p.R = a->R; p.H = a->H; p.alpha = a->alpha;
+    p.N = rw.n; p.E = a->E; p.F = a->F; p.R = a->R; p.H = a->H; p.alpha = a->alpha;
     p.crel_by_row = a->ee_index ? 1 : 0;
     p.planes = atp_hx2(a) ? ((a->F % 8 == 0 && a->R % 8 == 0) ? 2 : 1) : 0;
     p.dst_shared = atp_dst_shared(a) ? 1 : 0;
@@ -2124,7 +2145,7 @@ extern "C" int recon_gat_atp_aggregate(const recon_graph* g, const recon_gat_atp
     p.hub_chunk = hubs ? g->hub_chunk : 0; p.n_piece = hubs ? g->n_piece : 0;
     p.piece = reinterpret_cast<const int4*>(g->piece);
     p.hubS = g->hub_ws; p.hubZ = hubs ? g->hub_ws + static_cast<size_t>(g->n_piece) * a->H * (a->F + a->R) : nullptr;
-    dim3 grid(static_cast<unsigned>(ceil_div64(a->N, (kBlock / 64) * kK1NodesPerWave) + ceil_div64(p.n_piece, kBlock / 64)),
+    dim3 grid(static_cast<unsigned>(ceil_div64(rw.n, (kBlock / 64) * kK1NodesPerWave) + ceil_div64(p.n_piece, kBlock / 64)),
               static_cast<unsigned>(ceil_div64(a->H, s.ht)));
 #define CALL_FWD(V_, K_, H_)                                                                                   \
     do {                                                                                                       \
@@ -2158,6 +2179,7 @@ extern "C" int recon_gat_atp_project(const recon_graph* g, const recon_gat_atp_a
     if (rc != RECON_OK) return rc;
     if (a->N == 0) return RECON_OK;
     const int32_t W = 2 * a->F + a->R;
+    const int32_t NR = atp_rows(g, a).n;                                 // rows of V and of `out` (row compaction: the nodes with edges)
     OperandDesc A = plain_operand(a->V, static_cast<int64_t>(a->H) * W);
     OperandDesc B = plain_operand(a->a, W);
     OutputDesc C = plain_output(a->out, a->ld_out);
@@ -2165,10 +2187,42 @@ extern "C" int recon_gat_atp_project(const recon_graph* g, const recon_gat_atp_a
     bt.batch = a->H; bt.a_bs = W; bt.b_bs = static_cast<int64_t>(a->D) * W; bt.c_bs = a->D;
     bt.epilogue = a->concat ? 1 : 0;
     if (atp_hx2(a))
-        return gemm_hx2_batched(a->N, a->D, W, a->V, W, 2LL * W, 2LL * a->N * W, a->a_split, C, bt, atp_scale_v(a), atp_scale_a(a),
+        return gemm_hx2_batched(NR, a->D, W, a->V, W, 2LL * W, 2LL * NR * W, a->a_split, C, bt, atp_scale_v(a), atp_scale_a(a),
                                 as_stream(stream), atp_dst_shared(a));  // V terms [H][N][2][W]: plane stride W, row stride 2 W, head stride 2 N W
-    if (a->a_split && bx3_supported(A, W, bt)) return gemm_bx3_batched(a->N, a->D, W, A, a->a_split, C, bt, as_stream(stream));
-    return gemm_f32_batched(a->N, a->D, W, A, true, B, true, C, bt, 1, nullptr, as_stream(stream));
+    if (a->a_split && bx3_supported(A, W, bt)) return gemm_bx3_batched(NR, a->D, W, A, a->a_split, C, bt, as_stream(stream));
+    return gemm_f32_batched(NR, a->D, W, A, true, B, true, C, bt, 1, nullptr, as_stream(stream));
+}
+
+// out[n][:] = rows[node_row[n]][:], or zeros where the node has no row: the output of a row-compacted layer call back in node order
+// (GAT/layers.py:152-158: a node without in-edges gets 0 / 1e-12 = 0 and elu(0) = 0).  One wave per node.
+namespace {
+__global__ void __launch_bounds__(kBlock) k_rows_expand(const float* __restrict__ rows, int32_t ld_rows, const int32_t* __restrict__ node_row, int32_t N,
+                                                        int32_t width, float* __restrict__ out, int32_t ld_out, int32_t vec4) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (n >= N) return;
+    const int r = node_row[n];                                           // wave-uniform
+    float* o = out + static_cast<int64_t>(n) * ld_out;
+    const float* in = rows + static_cast<int64_t>(r < 0 ? 0 : r) * ld_rows;
+    if (vec4) {
+        for (int c = 4 * lane; c < width; c += 256) {
+            const float4 v = r >= 0 ? *reinterpret_cast<const float4*>(in + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(o + c) = v;
+        }
+    } else {
+        for (int c = lane; c < width; c += 64) o[c] = r >= 0 ? in[c] : 0.f;
+    }
+}
+}  // namespace
+extern "C" int recon_rows_expand(const float* rows, int32_t ld_rows, const int32_t* node_row, int32_t N, int32_t width, float* out, int32_t ld_out,
+                                 recon_stream_t stream) {
+    if (N < 0 || width < 0 || ld_rows < width || ld_out < width || (N > 0 && (!node_row || !out)) || (N > 0 && width > 0 && !rows)) return RECON_ERR_INVALID;
+    if (N == 0 || width == 0) return RECON_OK;
+    const int vec4 = ((width | ld_rows | ld_out) & 3) == 0 && !((reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(out)) & 15);
+    hipLaunchKernelGGL(k_rows_expand, dim3(static_cast<unsigned>(ceil_div64(N, kBlock / 64))), dim3(kBlock), 0, as_stream(stream), rows, ld_rows, node_row, N, width, out,
+                       ld_out, vec4);
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
 }
 
 extern "C" int recon_gat_atp_fwd(const recon_graph* g, const recon_gat_atp_args* a, recon_stream_t stream) {
@@ -2219,12 +2273,16 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
     if (!a->Z || !a->Zk || !b->grad_out || !b->g_V || !b->gxd || !b->Gs || !b->g_u || !b->partial || !b->partial2 || !b->q) return RECON_ERR_INVALID;
     if (a->E > 0 && (!a->sigma || !b->g_sigma || !b->Gxs)) return RECON_ERR_INVALID;
     const bool hx2 = atp_hx2(a);
-    if (a->concat && !b->g_h && !hx2) return RECON_ERR_INVALID;
+    if ((a->concat || atp_rows(g, a).row_node) && !b->g_h && !hx2) return RECON_ERR_INVALID;   // (compacted rows: g_h is also the row-order copy of grad_out)
     if (hx2 && (!b->gh_split || (reinterpret_cast<uintptr_t>(b->gh_split) & 15) || (b->ld_gout & 3))) return RECON_ERR_INVALID;
     if (b->ld_gout < a->H * a->D) return RECON_ERR_INVALID;
     if (a->N == 0) return RECON_OK;
     hipStream_t st = as_stream(stream);
     const int32_t N = a->N, E = a->E, F = a->F, R = a->R, D = a->D, H = a->H, W = 2 * F + R;
+    // NR rows (row compaction: the destination nodes with edges; else N): `out`, g_h, q, V, g_V, Z, Zk, gxd and the destination half of Gs
+    // go by row; x, c_node, g_x and the source half of Gs by node; grad_out is read through row_node
+    const AtpRows rw = atp_rows(g, a);
+    const int32_t NR = rw.n;
     const int64_t HD = 1LL * H * D;
     AtpShape s;
     atp_shape(F, R, H, &s);
@@ -2243,7 +2301,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
     // f16 x 2 with heads of at most 256 columns: the planes of g_h carry PER-ROW scales (k_elu_grad_q finds a row's maximum in the wave that
     // holds the row), so no pass over grad_out for a tensor-wide maximum runs in front (k_hx2_amax: 52 MB, 14 us + a launch at cfg 2).  The
     // inverse scales [H][ldi] live behind the two planes, in the room of the third plane that only the bf16 x 3 family uses.
-    const int64_t ldi = (static_cast<int64_t>(N) + 7) / 8 * 8;
+    const int64_t ldi = (static_cast<int64_t>(NR) + 7) / 8 * 8;
     const size_t inv_off = align_up(static_cast<size_t>(2) * N * bx3_kp(static_cast<int32_t>(HD)) * 2, 256);
     const bool row_scaled = hx2 && D <= 256 && ((a->ld_out | b->ld_gout) & 3) == 0 && cfg_char(CFG_ATP_ROW_SCALE) != '0' &&
                             inv_off + static_cast<size_t>(H) * ldi * sizeof(float) <= recon_gat_atp_bwd_split_bytes(N, D, H);
@@ -2255,12 +2313,12 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
             rc = hx2_amax(b->grad_out, N, static_cast<int32_t>(HD), b->ld_gout, atp_q(a, 3), st);
             if (rc != RECON_OK) return rc;
         }
-        hipLaunchKernelGGL(k_elu_grad_q, dim3(static_cast<unsigned>(ceil_div64(1LL * N * H, 16))), dim3(256), 0, st, b->grad_out, b->ld_gout, a->out,
-                           a->ld_out, N, H, D, a->concat, (a->concat && !hx2) ? b->g_h : nullptr, b->q, ghp, hx2 ? 2LL * D : ld_ghp,
-                           hx2 ? static_cast<int64_t>(D) : static_cast<int64_t>(N) * ld_ghp, hx2 ? 1 : 0,
-                           hx2 ? atp_scale_g(a) : Hx2Scale{nullptr, nullptr, 1.f}, row_inv, ldi, row_scaled ? atp_q(a, 3) : nullptr);
+        hipLaunchKernelGGL(k_elu_grad_q, dim3(static_cast<unsigned>(ceil_div64(1LL * NR * H, 16))), dim3(256), 0, st, b->grad_out, b->ld_gout, a->out,
+                           a->ld_out, NR, H, D, a->concat, ((a->concat || rw.row_node) && !hx2) ? b->g_h : nullptr, b->q, ghp, hx2 ? 2LL * D : ld_ghp,
+                           hx2 ? static_cast<int64_t>(D) : static_cast<int64_t>(NR) * ld_ghp, hx2 ? 1 : 0,
+                           hx2 ? atp_scale_g(a) : Hx2Scale{nullptr, nullptr, 1.f}, row_inv, ldi, row_scaled ? atp_q(a, 3) : nullptr, rw.row_node);
     }
-    if (a->concat) { gh = b->g_h; ld_gh = static_cast<int32_t>(HD); }
+    if (a->concat || rw.row_node) { gh = b->g_h; ld_gh = static_cast<int32_t>(HD); }
     GemmBatch bt;
     bt.batch = H; bt.epilogue = 0;
     if (phases & RECON_ATP_BWD_INPUTS) {
@@ -2271,24 +2329,24 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         OutputDesc C = plain_output(b->g_V, static_cast<int64_t>(H) * W);
         bt.a_bs = D; bt.b_bs = static_cast<int64_t>(D) * W; bt.c_bs = W;
         if (hx2)
-            rc = gemm_hx2_batched(N, W, D, b->gh_split, D, 2LL * D, 2LL * N * D,             // g_h terms [H][N][2][D]
+            rc = gemm_hx2_batched(NR, W, D, b->gh_split, D, 2LL * D, 2LL * NR * D,           // g_h terms [H][N][2][D]
                                   static_cast<const char*>(a->a_split) + split_part_bytes(D, W, H), C, bt,
                                   row_scaled ? Hx2Scale{nullptr, nullptr, 1.f} : atp_scale_g(a), atp_scale_a(a), st, 0, row_inv, ldi);
         else if (a->a_split && bx3_supported(A, D, bt))
-            rc = gemm_bx3_batched(N, W, D, A, static_cast<const char*>(a->a_split) + split_part_bytes(D, W, H), C, bt, st);
+            rc = gemm_bx3_batched(NR, W, D, A, static_cast<const char*>(a->a_split) + split_part_bytes(D, W, H), C, bt, st);
         else
-            rc = gemm_f32_batched(N, W, D, A, true, B, false, C, bt, 1, nullptr, st);
+            rc = gemm_f32_batched(NR, W, D, A, true, B, false, C, bt, 1, nullptr, st);
         if (rc != RECON_OK) return rc;
     }
     // (2) edge pass over the destination CSR
     {
         AtpBwdK p;
-        p.rowptr = g->rowptr_dst; p.src = g->src; p.eid = a->ee_index ? a->ee_index : g->eid;
+        p.rowptr = rw.rowptr; p.row_node = rw.row_node; p.src = g->src; p.eid = a->ee_index ? a->ee_index : g->eid;
         p.gee_by_slot = a->ee_index ? 1 : 0;
         p.x = a->x; p.ee = a->edge_embed; p.keep = a->keep; p.sigma = a->sigma; p.Z = a->Z; p.Zk = a->Zk;
         p.q = b->q; p.gV = b->g_V; p.u = a->u;
         p.gsigma = b->g_sigma; p.Gs_dst = b->Gs; p.Gxs = b->Gxs; p.gxd = b->gxd; p.g_ee = b->g_edge_embed;
-        p.N = N; p.E = E; p.F = F; p.R = R; p.H = H; p.alpha = a->alpha;
+        p.N = NR; p.E = E; p.F = F; p.R = R; p.H = H; p.alpha = a->alpha;
         const bool hubs = atp_hubs(g);
         if (hubs && static_cast<size_t>(g->hub_ws_floats) < recon_graph_hub_ws_floats(g, F, R, H)) return RECON_ERR_WORKSPACE;
         p.hub_chunk = hubs ? g->hub_chunk : 0; p.n_piece = hubs ? g->n_piece : 0;
@@ -2306,12 +2364,12 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
                                   else hipLaunchKernelGGL((k_gat_atp_bwd<V_, K_, H_>), grid, dim3(kBlock), lds_run, st, p); } while (0)
         p.persist = (p.n_piece == 0 && cfg_char(CFG_K2_PERSIST) != '0') ? 1 : 0;
         if (p.persist) {
-            const int64_t need = ceil_div64(N, kBlock / 64);
+            const int64_t need = ceil_div64(NR, kBlock / 64);
             int64_t nb = k2_resident_blocks(s.kr, s.ht, lds_run);
             if (nb > need) nb = (need + 7) / 8 * 8;
             grid = dim3(static_cast<unsigned>(nb));
         } else {
-            grid = dim3(static_cast<unsigned>(ceil_div64(N, kBlock / 64) + ceil_div64(p.n_piece, kBlock / 64)));
+            grid = dim3(static_cast<unsigned>(ceil_div64(NR, kBlock / 64) + ceil_div64(p.n_piece, kBlock / 64)));
         }
         ATP_DISPATCH(s, CALL_BWD);
 #undef CALL_BWD
@@ -2327,7 +2385,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         AtpSrcK p;
         p.rowptr_src = g->rowptr_src; p.slot_by_src = g->slot_by_src; p.Gxs = b->Gxs; p.gxd = b->gxd; p.gsigma = b->g_sigma;
         p.g_x = b->g_x; p.Gs_src = b->Gs; p.u = a->u; p.W = W;
-        p.N = N; p.F = F; p.H = H;
+        p.N = N; p.F = F; p.H = H; p.node_row = rw.node_row;
         const bool hubs = g->hub_chunk > 0 && g->n_hub_src > 0 && g->n_piece_src > 0 && g->hub_node_src && g->hub_ptr_src && g->piece_src && g->hub_ws;
         if (hubs && static_cast<size_t>(g->hub_ws_floats) < recon_graph_hub_ws_floats(g, F, R, H)) return RECON_ERR_WORKSPACE;
         p.hub_chunk = hubs ? g->hub_chunk : 0; p.n_piece = hubs ? g->n_piece_src : 0;
@@ -2361,19 +2419,19 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
             bw.a_bs = W; bw.b_bs = D; bw.c_bs = static_cast<int64_t>(D) * W; bw.c_transpose = 1;
             const int64_t ldv = static_cast<int64_t>(H) * W;
             if (hx2) {                                                                     // f16 x 2: both operands are half planes
-                const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));
-                rc = gemm_hx2_kmajor_batched(W, D, N, a->V, 2LL * W, W, 2LL * N * W, b->gh_split, 2LL * D, D, 2LL * N * D,
+                const int sk = bx3_kmajor_splits(NR, bx3_kmajor_split_k(W, D, NR, H));
+                rc = gemm_hx2_kmajor_batched(W, D, NR, a->V, 2LL * W, W, 2LL * NR * W, b->gh_split, 2LL * D, D, 2LL * NR * D,
                                              H, sk, b->partial, static_cast<const char*>(a->aux) + kHx2ZeroPageOffset, atp_scale_v(a), atp_scale_g(a), st,
                                              atp_dst_shared(a), row_inv, ldi);
                 // its second pass runs in FINISH, fused with the score path's terms (k_atp_weights_finish) — unless the caller wants G now
                 if (rc == RECON_OK && (phases & RECON_ATP_BWD_EARLY_SUM)) rc = splitk_reduce(b->partial, sk, W, D, C, bw.c_bs, H, 0, true, st);
             } else if (gh_planes && bx3_kmajor_supported(a->V, ldv, W, ld_ghp, D, W, D)) {    // split-precision MFMA, both operands k-major
-                const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));
-                rc = gemm_bx3_kmajor_batched(W, D, N, a->V, ldv, W, b->gh_split, ld_ghp, static_cast<int64_t>(N) * ld_ghp, D, H, sk, b->partial, st);
+                const int sk = bx3_kmajor_splits(NR, bx3_kmajor_split_k(W, D, NR, H));
+                rc = gemm_bx3_kmajor_batched(W, D, NR, a->V, ldv, W, b->gh_split, ld_ghp, static_cast<int64_t>(NR) * ld_ghp, D, H, sk, b->partial, st);
                 if (rc == RECON_OK) rc = splitk_reduce(b->partial, sk, W, D, C, bw.c_bs, H, 0, true, st);
             } else {
-                const int sk = gemm_pick_split_k(W, D, N, H);
-                rc = gemm_f32_batched(W, D, N, A, false, B, false, C, bw, sk, b->partial, st);
+                const int sk = gemm_pick_split_k(W, D, NR, H);
+                rc = gemm_f32_batched(W, D, NR, A, false, B, false, C, bw, sk, b->partial, st);
             }
             if (rc != RECON_OK) return rc;
         }
@@ -2419,13 +2477,14 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
             if (H <= 8) {
                 // the common case, all three in one <8> launch: node-side products (Gs is [N][2H], dst sums | src sums: column
                 // (s, h) lands in g_u[h][s*F ...]) as two H-column jobs, and the edge-side product g_sigma^T edge_embed[eid]
-                const Prod pr[3] = {{b->Gs, 2 * H, H, a->x, nullptr, N, F, H, W, 0, b->g_u},
+                const Prod pr[3] = {{b->Gs, 2 * H, H, a->x, rw.row_node, NR, F, H, W, 0, b->g_u},      // destination sums go by row: x through row_node
                                     {b->Gs + H, 2 * H, H, a->x, nullptr, N, F, H, W, 0, b->g_u + F},
                                     {b->g_sigma, H, H, a->edge_embed, ee_gather, E, R, H, W, 0, b->g_u + 2 * F}};
                 run_jobs(pr, 3);
             } else {
                 for (int j = 0; j < 2 * H; ++j) {                        // more than 8 heads: one column at a time keeps the map simple
-                    const Prod one = {b->Gs + j, 2 * H, 1, a->x, nullptr, N, F, 1, W, 0, b->g_u + static_cast<int64_t>(j % H) * W + (j / H) * F};
+                    const Prod one = {b->Gs + j, 2 * H, 1, a->x, j < H ? rw.row_node : nullptr, j < H ? NR : N, F, 1, W, 0,
+                                      b->g_u + static_cast<int64_t>(j % H) * W + (j / H) * F};
                     run_jobs(&one, 1);
                 }
                 for (int h0 = 0; h0 < H; h0 += 16) {
@@ -2438,7 +2497,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         }
         // (6) through u = a_2^T a
         if ((phases & RECON_ATP_BWD_FINISH) && hx2 && !(phases & RECON_ATP_BWD_EARLY_SUM)) {
-            const int sk = bx3_kmajor_splits(N, bx3_kmajor_split_k(W, D, N, H));
+            const int sk = bx3_kmajor_splits(NR, bx3_kmajor_split_k(W, D, NR, H));
             const int ntile = static_cast<int>(ceil_div64(W, 32) * ceil_div64(D, 32)) * H;
             hipLaunchKernelGGL(k_atp_weights_finish, dim3(static_cast<unsigned>(ntile + ceil_div64(1LL * H * D, 8))), dim3(256), 0, st, b->partial, sk, W,
                                D, H, a->a, a->a_2, b->g_u, b->g_a, b->g_a_2, atp_q(a, 3), kHx2QuantityWords);

@@ -467,7 +467,7 @@ def _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out,
     return _lib.GatAtpArgs(graph.N, graph.E, x.shape[1], ee.shape[1], D, H, int(bool(concat)), float(alpha),
                            x.data_ptr(), ee.data_ptr(), a.data_ptr(), a2.data_ptr(), _p(keep), _p(u),
                            _p(c_node), _p(c_rel), _p(V), _p(sigma), _p(Z), _p(Zk),
-                           out.data_ptr(), out.shape[1], _p(a_split), SPLIT_F16X2 if aux is not None else SPLIT_BF16X3,
+                           _p(out), out.shape[1] if out is not None else H * D, _p(a_split), SPLIT_F16X2 if aux is not None else SPLIT_BF16X3,
                            float(keep_max), _p(aux), _p(ee_index), ee.shape[0] if ee_index is not None else 0, int(bool(io_bf16)))
 
 
@@ -590,7 +590,6 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         dev = x.device
         need_grad = any(ctx.needs_input_grad[:4])
         train = need_grad or keep is not None
-        out = torch.empty(N, H * D, dtype=torch.float32, device=dev)
         mode = 2 if io16 else _atp_split_mode(F_, R, D, H, N)           # bfloat16 inputs: the f16 x 2 family's kernels only
         split_bytes, aux_bytes = _lib_sizes(N, E, F_, R, D, H)[:2]
         # u [H,W], c_node [N,2H], c_rel [E,H], V [N,H,W], sigma [E,H], Z [N,H], Zk [N,H], a_split, aux: one allocation
@@ -603,7 +602,8 @@ class _GATHeadsATPFunction(torch.autograd.Function):
             keep_max = 1.0
         elif keep_max is None:                                  # explicit factors without a bound: one host read (tests)
             keep_max = float(keep.max()) if aux is not None and keep.numel() else 1.0
-        args = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, alpha, concat, a_split, aux, keep_max, idx_slot, io16)
+        args = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, None, alpha, concat, a_split, aux, keep_max, idx_slot, io16)
+        args.out = V                                                     # (placeholder: the score stage writes no output; the real one follows the resolve below)
         # a graph built a moment ago has not read its hub-table sizes back yet (graph.GraphCSR.resolve: a host synchronisation).  The score
         # stage needs none of them: it goes out first, so that the device has work behind the build while the host waits and launches again
         early = graph.pending and graph.build_stream == _lib.current_stream()
@@ -611,6 +611,11 @@ class _GATHeadsATPFunction(torch.autograd.Function):
             with _on_device(dev):
                 _lib.check(L.recon_gat_atp_scores(C.byref(graph.raw_struct()), C.byref(args), _lib.current_stream()), "recon_gat_atp_scores")
         gstruct, _hub_keep = graph.call_struct(F_, R, H)
+        # few destination rows have edges (graph.ROWS_COMPACT_MAX; known once the graph is resolved): the layer runs over those rows, writes
+        # their outputs as a compact [n_rows, H D] block and the block is spread out over zeros below
+        NR = graph.n_rows or N
+        out = torch.empty(NR, H * D, dtype=torch.float32, device=dev)
+        args.out = out.data_ptr()
         with _on_device(dev):
             if early:
                 _lib.check(L.recon_gat_atp_aggregate(C.byref(gstruct), C.byref(args), _lib.current_stream()), "recon_gat_atp_aggregate")
@@ -622,6 +627,11 @@ class _GATHeadsATPFunction(torch.autograd.Function):
             ctx.ptrs = (u, c_node, c_rel, V, sigma, Z, Zk, a_split, aux)
             ctx.graph, ctx.alpha, ctx.concat, ctx.keep_max = graph, alpha, concat, keep_max
             ctx.idx_slot = idx_slot
+        if NR != N:
+            full = torch.empty(N, H * D, dtype=torch.float32, device=dev)
+            with _on_device(dev):
+                _lib.check(L.recon_rows_expand(out.data_ptr(), H * D, graph.c.node_row, N, H * D, full.data_ptr(), H * D, _lib.current_stream()), "recon_rows_expand")
+            return full
         return out
 
     @staticmethod
@@ -645,7 +655,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         # [N,H,W], g_sigma [E,H], Gxs [E,F], gxd [N,F], Gs [N,2H], g_u [H,W], q [N,H], split-K partials, skinny partials,
         # g_h term planes
         ws2, (g_h, g_V, g_sigma, Gxs, gxd, Gs, g_u, q, partial, partial2, gh_split) = _carve(dev, (
-            4 * N * H * D if (ctx.concat and aux is None) else None, 4 * N * H * W, 4 * E * H, 4 * E * F_, 4 * N * F_, 4 * N * 2 * H,
+            4 * N * H * D if ((ctx.concat or graph.n_rows) and aux is None) else None, 4 * N * H * W, 4 * E * H, 4 * E * F_, 4 * N * F_, 4 * N * 2 * H,
             4 * H * W, 4 * N * H, partial_b, partial2_b, ghs_b if use_gh_planes else None))
         g_x = torch.empty(N, F_, **f32) if nx else None
         g_ee = torch.empty(E, R, **f32) if ne else None

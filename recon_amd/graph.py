@@ -65,6 +65,10 @@ def _bad_flag(dev):
 
 DEFER_HUB_READ = True   # the host read of a fresh graph's hub-table sizes (and of its id-range flag) waits until something needs them: see GraphCSR.resolve
 HUB_CHUNK = 64          # RECON_HUB_CHUNK (include/recon_hip.h); 0 switches the splitting of long destination rows off (tests compare both)
+# Row compaction (recon_graph.n_rows): a graph whose destination rows WITH edges are at most this fraction of its nodes — a knowledge-graph
+# batch aggregates into the batch's ~128 entities of a 14 541-entity table (GAT/main.py:478-516) — gets the list of those rows, and the
+# aggregate-then-project layer runs its node-parallel stages over them.  0 switches it off (tests compare both).
+ROWS_COMPACT_MAX = float(os.environ.get("RECON_ROWS_COMPACT", "0.7"))
 
 
 class GraphCSR:
@@ -133,7 +137,7 @@ class GraphCSR:
         self._error = None
         self._pending = (ws_ptr, bad, stream) if hubs else None
         if not hubs:
-            self.n_hub = self.n_piece = self.n_hub_src = self.n_piece_src = 0
+            self.n_hub = self.n_piece = self.n_hub_src = self.n_piece_src = self.n_rows = 0
         elif not DEFER_HUB_READ:
             self.resolve()
 
@@ -152,7 +156,7 @@ class GraphCSR:
 
     def __getattr__(self, name):
         # the hub tables and their sizes exist once the counts have been read
-        if name in ("n_hub", "n_piece", "n_hub_src", "n_piece_src", "hub_node", "hub_ptr", "piece", "hub_node_src", "hub_ptr_src", "piece_src") \
+        if name in ("n_hub", "n_piece", "n_hub_src", "n_piece_src", "hub_node", "hub_ptr", "piece", "hub_node_src", "hub_ptr_src", "piece_src", "n_rows") \
                 and self.__dict__.get("_pending") is not None:
             self.resolve()
             if name in self.__dict__:
@@ -169,12 +173,12 @@ class GraphCSR:
         L, dev = _lib.lib(), self.device
         i32 = dict(dtype=torch.int32, device=dev)
         cnt = (C.c_int32 * 4)()
-        bad_host = C.c_int32(0)
+        bad_host, live = C.c_int32(0), C.c_int32(0)
         with _lib.on_device(dev):
-            _lib.check(L.recon_graph_hubs_read(C.byref(self._c), ws_ptr, cnt, _lib.ptr(bad), C.byref(bad_host) if bad is not None else None, stream),
-                       "recon_graph_hubs_read")
+            _lib.check(L.recon_graph_counts_read(C.byref(self._c), ws_ptr, cnt, C.byref(live), _lib.ptr(bad), C.byref(bad_host) if bad is not None else None, stream),
+                       "recon_graph_counts_read")
         self._pending = None
-        self.n_hub = self.n_piece = self.n_hub_src = self.n_piece_src = 0
+        self.n_hub = self.n_piece = self.n_hub_src = self.n_piece_src = self.n_rows = 0     # n_rows = 0: rows are nodes
         if bad_host.value:
             # the slot is this build's own unless a bad graph that took it a ring ago was dropped unresolved: verify, and hand it back clear
             # (on the build's stream, which hubs_read has just drained: ordered in front of whichever build takes the slot next)
@@ -184,6 +188,18 @@ class GraphCSR:
             if lo < 0 or hi >= self.N:
                 self._error = "recon_amd: edge index out of range: ids span [%d, %d] but input has %d rows" % (lo, hi, self.N)
                 raise IndexError(self._error)
+        if 0 < live.value <= ROWS_COMPACT_MAX * self.N:
+            # few rows have edges: their list, their row pointers and the node -> row map (one launch on the build's stream, in front of the
+            # hub tables, which then name rows)
+            self.n_rows = int(live.value)
+            self._rows = torch.empty(2 * self.n_rows + 1 + self.N, **i32)
+            base = self._rows.data_ptr()
+            self._c.n_rows, self._c.row_node, self._c.rowptr_rows = self.n_rows, base, base + 4 * self.n_rows
+            self._c.node_row = base + 4 * (2 * self.n_rows + 1)
+            with _lib.on_device(dev):
+                _lib.check(L.recon_graph_rows_compact(C.byref(self._c), stream), "recon_graph_rows_compact")
+                if not (cnt[0] > 0 or cnt[2] > 0) and _lib.current_stream() != stream:
+                    torch.cuda.synchronize(dev)
         if cnt[0] > 0 or cnt[2] > 0:
             self.n_hub, self.n_piece, self.n_hub_src, self.n_piece_src = (int(v) for v in cnt)
             self._c.hub_chunk = HUB_CHUNK

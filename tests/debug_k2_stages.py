@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Stage-by-stage check of the attention backward's edge pass (k_gat_atp_bwd + k_gat_atp_src) against the oracle's closed-form
 intermediates: g_sigma [E,H] (CSR-slot order), the direct part gxd, g_x, g_edge_embed.  Runs on the GPU box.
-    python3 tools/probe/k2_debug.py"""
+    python3 tests/debug_k2_stages.py   (a checker: it uses the oracle, so it lives under tests/)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from oracle import recon_oracle as O

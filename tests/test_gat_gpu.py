@@ -765,6 +765,86 @@ def test_hub_rows_split_vs_oracle_and_unsplit(N, F_, R, D, H, concat, drop, trai
         close(rest[1], g_ee, atol=1e-4, what="g_edge_embed")
 
 
+@pytest.mark.parametrize("N,F_,R,D,H,concat,drop,train,table", [
+    (900, 24, 16, 32, 4, True, False, True, False),      # f16 x 2 capable: half-term V rows, destination part shared
+    (900, 24, 16, 32, 4, True, True, True, False),       # attention dropout
+    (600, 10, 6, 50, 2, True, False, True, False),       # VEC 2, fp32 GEMMs
+    (700, 12, 8, 20, 11, True, True, True, False),       # 11 heads
+    (500, 200, 200, 40, 1, False, False, True, False),   # out_att-like single head, no ELU inside (grad_out goes into the GEMM as it is)
+    (14541, 50, 50, 100, 2, True, True, True, True),     # the stage-A first layer: 128 live rows of 14 541, relation table
+    (900, 24, 16, 32, 4, True, False, False, False),     # inference
+])
+def test_rows_with_edges_compacted_vs_oracle_and_uncompacted(N, F_, R, D, H, concat, drop, train, table, monkeypatch):
+    """Few destination rows have edges (a knowledge-graph batch: GAT/main.py:478-516): the layer runs over those rows only (recon_graph.n_rows).
+    Outputs and all gradients against the same kernels over every node (ROWS_COMPACT_MAX = 0) and against the oracle; rows without edges are
+    exactly zero (GAT/layers.py:152-158)."""
+    from recon_amd import gat_layers, graph as graph_mod
+    monkeypatch.setattr(gat_layers, "_GAT_PATH", "atp")
+    d = dev()
+    rs = np.random.RandomState(N + H)
+    live = np.sort(rs.choice(N, size=min(128, N // 6), replace=False))
+    live[-1] = N - 1; live[0] = 0                                    # the first and the last node among them
+    degs = np.zeros(N, dtype=np.int64)
+    degs[live] = rs.randint(1, 30, size=live.size)
+    degs[live[:6]] = [700, 65, 64, 128, 129, 300]                    # hub rows: the pieces name rows
+    edge = _hub_graph(N, degs, 3, src_hubs=((N - 2, 300), (7, 65)))
+    E = edge.shape[1]
+    g = torch.Generator().manual_seed(N + D)
+    x = torch.randn(N, F_, generator=g)
+    nrel = 37
+    ee = torch.randn(nrel if table else E, R, generator=g) * 0.5
+    ee_index = torch.randint(0, nrel, (E,), generator=g) if table else None
+    a = torch.stack([O.xavier_normal((D, 2 * F_ + R), 1.414, g) for _ in range(H)]) * 0.5
+    a2 = torch.cat([O.xavier_normal((1, D), 1.414, g) for _ in range(H)])
+    keep = (torch.rand(H, E, generator=g) > 0.3).float() / 0.7 if drop else None
+    G = torch.randn(N, H * D, generator=g)
+    res = {}
+    for frac in (0.7, 0.0):
+        monkeypatch.setattr(graph_mod, "ROWS_COMPACT_MAX", frac)
+        graph_mod.clear_graph_cache()
+        gr = graph_mod.prepare_graph(edge.to(d), None, N)
+        assert gr.n_rows == (live.size if frac else 0) and gr.n_hub == 5
+        if frac:
+            rows = gr._rows.cpu().numpy()
+            assert np.array_equal(rows[:live.size], live)
+            assert np.array_equal(rows[live.size:2 * live.size + 1], np.concatenate([[0], np.cumsum(degs[live])]))
+            node_row = np.full(N, -1); node_row[live] = np.arange(live.size)
+            assert np.array_equal(rows[2 * live.size + 1:], node_row)
+            assert np.array_equal(gr.hub_node.cpu().numpy(), [0, 1, 3, 4, 5])
+        xd, eed, ad, a2d = (t.to(d).requires_grad_(train) for t in (x, ee, a, a2))
+        kd = keep.to(d) if drop else None
+        idx = ee_index.to(d) if table else None
+        if train:
+            out = gat_layers.gat_heads(xd, eed, ad, a2d, gr, kd, 0.2, concat, ee_index=idx)
+            (out * G.to(d)).sum().backward()
+            res[frac] = [t.detach().cpu() for t in (out, xd.grad, eed.grad, ad.grad, a2d.grad)]
+        else:
+            with torch.no_grad():
+                res[frac] = [gat_layers.gat_heads(xd, eed, ad, a2d, gr, None, 0.2, concat, ee_index=idx).cpu()]
+    graph_mod.clear_graph_cache()
+    names = ("out", "g_x", "g_edge_embed", "g_a", "g_a_2")
+    for nm, s_, u_ in zip(names, res[0.7], res[0.0]):
+        close(s_, u_, atol=2e-5, rel_to_max=2e-5, what="compacted vs all nodes " + nm)
+    out, rest = res[0.7][0], res[0.7][1:]
+    dead = np.setdiff1d(np.arange(N), live)
+    assert not out[dead].any()
+    ee_e = ee[ee_index] if table else ee
+    g_x = torch.zeros_like(x); g_ee = torch.zeros_like(ee_e)
+    for h in range(H):
+        r = O.gat_layer_backward(x.double(), edge, ee_e.double(), None, None, a[h].double(), a2[h:h + 1].double(), 0.2, concat,
+                                 G[:, h * D:(h + 1) * D].double(), mask=keep[h].double() if drop else None)
+        close(out[:, h * D:(h + 1) * D], r["out"].float(), what="out h%d" % h)
+        if train:
+            close(rest[2][h], r["g_a"].float(), atol=1e-4, what="g_a h%d" % h)
+            close(rest[3][h:h + 1], r["g_a_2"].float(), atol=1e-4, what="g_a_2 h%d" % h)
+            g_x += r["g_x"].float(); g_ee += r["g_edge_embed"].float()
+    if train:
+        close(rest[0], g_x, atol=1e-4, what="g_x")
+        if table:
+            g_ee = torch.zeros_like(ee).index_add_(0, ee_index, g_ee)
+        close(rest[1], g_ee, atol=1e-4, what="g_edge_embed")
+
+
 @pytest.mark.parametrize("N,E,F_,R,D,H,concat,drop,nrel,extra", [
     (200, 3000, 24, 16, 32, 4, True, False, 7, 0),        # relation table only (1-hop edges), f16 x 2 capable
     (200, 3000, 24, 16, 32, 4, True, True, 7, 500),       # + 500 edges with rows of their own appended to the table (n-hop edges), dropout
