@@ -743,6 +743,17 @@ int recon_kg_adj_fill(const recon_kg* kg, const int64_t* entities, int32_t B, co
                       int64_t* edge_type, recon_stream_t stream);
 int recon_kg_nhop(const recon_kg* kg, const int64_t* sources, int32_t S, int32_t partial_2hop, int32_t write, int64_t* qcount, int64_t* quad_off,
                   int64_t* quads, int64_t* total, uint32_t* counter, recon_stream_t stream);
+/* Dead-row pruning of a batch graph for SpKBGATModified (GAT/models.py:167-178: the model keeps `mask * out_entity_1`, so an edge matters only
+ * if its destination lies in need = mask U { src(e) : mask[dst(e)] != 0 }).  edge int64 [2][E1] (row 0 destinations) with type [E1], edge_nhop
+ * [2][E2] with type_nhop [E2][2] (E2 = 0: none); mask float [N]; need: N bytes of scratch.  The surviving edges are written in their
+ * input order: out_edge (room for [2][E1]) holds the destinations at [0, counts[0]) and the sources at [E1, E1 + counts[0]) — the caller's
+ * [2, counts[0]] tensor is a view with row stride E1 —, out_type [counts[0]]; likewise out_edge_nhop (row stride E2), out_type_nhop
+ * [counts[1]][2].  pos (optional, E1 + E2): the survivors' positions in the concatenated input, the 1-hop ones at [0, counts[0]), the n-hop ones
+ * (values from E1) at [E1, E1 + counts[1]).  counts: device int64 [2], read by the caller (one synchronisation).  One launch of one workgroup:
+ * batch graphs are tens of thousands of edges. */
+int recon_edges_prune(const int64_t* edge, const int64_t* type, int64_t E1, const int64_t* edge_nhop, const int64_t* type_nhop, int64_t E2,
+                      const float* mask, int32_t N, uint8_t* need, int64_t* out_edge, int64_t* out_type, int64_t* out_edge_nhop,
+                      int64_t* out_type_nhop, int64_t* pos, int64_t* counts, recon_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * N1  the tail of SpKBGATModified (GAT/models.py:167-180) and the row normalisation of the entity table (:160):

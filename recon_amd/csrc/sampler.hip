@@ -383,6 +383,108 @@ __global__ void __launch_bounds__(64) k_kg_scan(const int64_t* __restrict__ qcou
 bool kg_ok(const recon_kg* k) {
     return k && k->num_entities > 0 && k->pair_ptr && k->pair_tgt && k->pair_first_rel && k->not_loop && k->rel_ptr && k->rel_sorted;
 }
+// ---- dead-row pruning of a batch graph (SpKBGATModified: GAT/models.py:167-178) ----------------------------------------------------
+// The reference evaluates both attention layers for every entity and then keeps, through `mask`, the rows of the batch entities only:
+//   out = entities_upgraded + mask.unsqueeze(-1) * out_entity_1.
+// A row of the second layer outside the mask is multiplied by zero, forward and backward; and a row of the first layer matters only
+// where the second layer reads it — as x_i of a kept row or as x_j of an edge into one.  So the edges both layers need are those whose
+// DESTINATION lies in   need = mask  ∪  { src(e) : mask[dst(e)] } ;  every other edge aggregates into a row nobody reads.  (In the
+// reference's batches the destinations are the batch entities' NEIGHBOURS, Corpus.get_batch_adj_data: of ~29 000 edges into ~9 000 rows
+// a few hundred edges into a few dozen rows survive.)  ONE workgroup: need <- mask; mark the sources of the edges into masked rows;
+// count the surviving edges of each list per thread (a thread owns a run of consecutive edges), scan, write them IN ORDER — the kept edges
+// of a row keep their relative order, so the row's sums are the sums the unpruned layer forms.  pos (optional): the surviving edges'
+// positions in the CONCATENATED input list, 1-hop then n-hop (the per-edge dropout factors of a recorded run are looked up through them).
+__global__ void __launch_bounds__(1024) k_edges_prune(const int64_t* __restrict__ edge, const int64_t* __restrict__ type, int64_t E1,
+                                                      const int64_t* __restrict__ edge_nhop, const int64_t* __restrict__ type_nhop, int64_t E2,
+                                                      const float* __restrict__ mask, int32_t N, uint8_t* __restrict__ need,
+                                                      int64_t* __restrict__ out_edge, int64_t* __restrict__ out_type, int64_t* __restrict__ out_edge_nhop,
+                                                      int64_t* __restrict__ out_type_nhop, int64_t* __restrict__ pos, int64_t* __restrict__ counts) {
+    // The host waits for the two counts (the output sizes): this launch is on the iteration's critical path.  Every pass asks for sixteen
+    // edges per thread at once (one edge in flight per thread: 102 us for a 30 000-edge batch; this form: 65 us).  What is left is ONE compute
+    // unit's rate of scattered accesses — ~4 per edge (the row's mask word, the source's flag, the row's flag, the survivor's words) —, not a
+    // chain of round trips: batching the survivors' loads as well (every edge's source and types, kept or not) took 117 us.  Spreading the
+    // passes over many workgroups needs a grid-wide order between marking and reading the flags (two launches, or a look-back scan).
+    // Outputs: the destination row of a list at out[0 ..), its source row at out[E ..) — the caller's [2, n] tensor is a view with row stride E.
+    __shared__ int32_t wsum[2][16];
+    constexpr int U = 16;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    for (int n0 = t; n0 < N; n0 += 1024 * U) {                        // (sixteen flags per thread in flight: one at a time was 15 round trips for 14 541 entities)
+        float m[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) m[u] = n0 + 1024 * u < N ? mask[n0 + 1024 * u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (n0 + 1024 * u < N) need[n0 + 1024 * u] = m[u] != 0.f;
+    }
+    __syncthreads();
+    auto in_range = [&](int64_t v) { return v >= 0 && v < N; };       // ids out of range: the edge is kept, and the graph build reports them as it always does
+    auto mark = [&](const int64_t* __restrict__ e, int64_t E) {
+        for (int64_t i0 = t; i0 < E; i0 += 1024 * U) {
+            int32_t d[U], s_[U];
+            float m[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + 1024 * u;
+                const int64_t dv = i < E ? e[i] : -1, sv = i < E ? e[E + i] : -1;
+                d[u] = in_range(dv) ? static_cast<int32_t>(dv) : -1; s_[u] = in_range(sv) ? static_cast<int32_t>(sv) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) m[u] = d[u] >= 0 ? mask[d[u]] : 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) if (m[u] != 0.f && s_[u] >= 0) need[s_[u]] = 1;
+        }
+    };
+    mark(edge, E1);
+    mark(edge_nhop, E2);
+    __threadfence_block();
+    __syncthreads();
+    // ordered write: a thread owns U CONSECUTIVE edges of a 16 384-edge tile; positions = kept in the tiles before + in the waves before + in the
+    // lanes before (a wave scan of the threads' counts) + among the thread's own
+    int par = 0;
+    auto write = [&](const int64_t* __restrict__ e, const int64_t* __restrict__ ty, int64_t E, int64_t* __restrict__ oe, int64_t* __restrict__ ot,
+                     bool pair, int64_t pos_off) -> int64_t {
+        int64_t run = 0;
+        for (int64_t b = 0; b < E; b += 1024 * U, par ^= 1) {
+            const int64_t i0 = b + static_cast<int64_t>(U) * t;
+            int32_t d[U];                                                // ids as 32-bit values, -1 = outside [0, N) (64-bit copies of 32 ids per thread spilled)
+            uint8_t nd[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int64_t v = i0 + u < E ? e[i0 + u] : 0; d[u] = in_range(v) ? static_cast<int32_t>(v) : -1; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) nd[u] = d[u] >= 0 ? need[d[u]] : 1;
+            int c = 0;
+            uint32_t kmask = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const bool k = i0 + u < E && nd[u] != 0; kmask |= static_cast<uint32_t>(k) << u; c += k; }
+            int x = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(x, off, 64); if (lane >= off) x += o; }
+            if (lane == 63) wsum[par][w] = x;
+            __syncthreads();                                             // (one barrier per tile: the sums alternate between two rows)
+            int wb = 0, tile = 0;
+#pragma unroll
+            for (int ww = 0; ww < 16; ++ww) { const int v = wsum[par][ww]; tile += v; wb += ww < w ? v : 0; }
+            int64_t o = run + wb + x - c;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if ((kmask >> u) & 1) {                                  // (the survivors are few: their sources and types are fetched here)
+                    const int64_t i = i0 + u;
+                    oe[o] = e[i]; oe[E + o] = e[E + i];
+                    if (pair) { ot[2 * o] = ty[2 * i]; ot[2 * o + 1] = ty[2 * i + 1]; } else ot[o] = ty[i];
+                    if (pos) pos[pos_off + o] = pos_off + i;
+                    ++o;
+                }
+            }
+            run += tile;
+        }
+        return run;
+    };
+    const int64_t n1 = write(edge, type, E1, out_edge, out_type, false, 0);
+    __syncthreads();
+    // (the n-hop positions follow the 1-hop ones at E1: the caller cuts the two runs out of pos with the counts)
+    const int64_t n2 = write(edge_nhop, type_nhop, E2, out_edge_nhop, out_type_nhop, true, E1);
+    if (t == 0) { counts[0] = n1; counts[1] = n2; }
+}
+
 KG kg_of(const recon_kg* k) {
     return KG{k->pair_ptr, k->pair_tgt, k->pair_first_rel, k->not_loop, k->rel_ptr, k->rel_sorted, k->num_entities};
 }
@@ -450,6 +552,18 @@ extern "C" int recon_kg_nhop(const recon_kg* kg, const int64_t* sources, int32_t
                            qcount, quad_off, quads);
         hipLaunchKernelGGL(recon::k_kg_scan, dim3(1), dim3(64), 0, as_stream(stream), qcount, S, quad_off, total);
     }
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+extern "C" int recon_edges_prune(const int64_t* edge, const int64_t* type, int64_t E1, const int64_t* edge_nhop, const int64_t* type_nhop, int64_t E2,
+                                 const float* mask, int32_t N, uint8_t* need, int64_t* out_edge, int64_t* out_type, int64_t* out_edge_nhop,
+                                 int64_t* out_type_nhop, int64_t* pos, int64_t* counts, recon_stream_t stream) {
+    if (E1 < 0 || E2 < 0 || N <= 0 || !mask || !need || !counts) return RECON_ERR_INVALID;
+    if (E1 > 0 && (!edge || !type || !out_edge || !out_type)) return RECON_ERR_INVALID;
+    if (E2 > 0 && (!edge_nhop || !type_nhop || !out_edge_nhop || !out_type_nhop)) return RECON_ERR_INVALID;
+    hipLaunchKernelGGL(recon::k_edges_prune, dim3(1), dim3(1024), 0, as_stream(stream), edge, type, E1, edge_nhop, type_nhop, E2, mask, N, need, out_edge, out_type,
+                       out_edge_nhop, out_type_nhop, pos, counts);
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }

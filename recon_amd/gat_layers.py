@@ -768,7 +768,7 @@ def _ones(n, device):
 
 def gat_path_for(N, E, F_, R, D, H):
     """Which formulation gat_heads uses: 'atp' (aggregate, then project) when instantiated for the shape and
-    the graph is not much sparser than its node set, else 'proj' (project, then aggregate).  RECON_GAT_PATH /
+    the graph is not much sparser than its node set (or its rows with edges get compacted), else 'proj' (project, then aggregate).  RECON_GAT_PATH /
     `gat_layers._GAT_PATH` = 'atp' | 'proj' forces one."""
     if _GAT_PATH == "proj":
         return "proj"
@@ -778,7 +778,11 @@ def gat_path_for(N, E, F_, R, D, H):
         # issues two collectives under an OverlappedWeightGradSync) and another down 'proj' (which issues none): mismatched collectives
         # hang.  With more than one rank the choice depends on the layer widths alone.
         return "atp" if ok else "proj"
-    return "atp" if (ok and 2 * E >= N) else "proj"
+    # few edges for the node set: 'proj' projects every node, 'atp' walks every node's (empty) row — unless the graph's rows get compacted
+    # (graph.ROWS_COMPACT_MAX: resolved graphs of more than HUB_CHUNK edges), when 'atp' costs what the rows WITH edges cost
+    from . import graph as _graph
+    compacts = _graph.ROWS_COMPACT_MAX >= 0.5 and _graph.HUB_CHUNK > 0 and E > _graph.HUB_CHUNK
+    return "atp" if (ok and (2 * E >= N or compacts)) else "proj"
 
 
 def _data_parallel():

@@ -2,6 +2,8 @@
 sites carry over.  `SpGAT` mirrors GAT/models.py:11-88 (same constructor, forward signature and
 state_dict keys: attention_i.a / attention_i.a_2 / W / out_att.a / out_att.a_2) but runs all heads
 in ONE fused launch instead of a Python loop over H layers."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -9,6 +11,12 @@ import torch.nn.functional as F
 from . import _lib
 from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed, gather_rows, gather_rows_pair, small_mm, IndexedRows, set_weight_grad_destination
 from .graph import prepare_graph, trust, trusted, trust_bounds
+from .sampler import prune_edges
+
+# SpKBGATModified: drop the edges into rows that its mask discards before the layers run (sampler.prune_edges); 0 = evaluate every row, as
+# the reference does (tests compare both)
+PRUNE_DEAD_ROWS = os.environ.get("RECON_KBGAT_PRUNE", "1") != "0"
+KEEP_PRUNED_POSITIONS = False   # also return the surviving edges' positions (SpKBGATModified._pruned_pos): tests replay recorded per-edge dropout factors through them
 
 
 class _AliasHeadParams(torch.autograd.Function):
@@ -218,11 +226,25 @@ class SpKBGATModified(nn.Module):
         dev = entity_embeddings.device
         edge_list, edge_type = edge_list.to(dev), edge_type.to(dev)
         edge_list_nhop, edge_type_nhop = self._nhop(train_indices_nhop, dev)
+        mask = torch.zeros(entity_embeddings.shape[0], device=dev)
+        mask[batch_entities.to(dev)] = 1.0               # the reference takes torch.unique first (:167-170): same mask, but a host round trip
+        self._pruned_pos = None
+        if PRUNE_DEAD_ROWS and mask.is_cuda and edge_list.dtype == torch.int64 and edge_list.dim() == 2 and edge_list.shape[1] > 0:
+            # :177-178 keep `mask * out_entity_1`: the edges into rows that neither the mask keeps nor a kept row reads are dropped up front
+            # (sampler.prune_edges); both layers then see the same, much smaller graph and every kept row comes out as before
+            # kept per (edge tensors, batch entities) identity + version, like the graph cache: a caller that re-uses a batch re-uses the pruned
+            # tensors (and with them the prepared graph); a fresh batch per iteration — the reference's loop — prunes once per iteration
+            ver = lambda t: (t.data_ptr(), t._version, tuple(t.shape)) if torch.is_tensor(t) else None
+            key = (ver(edge_list), ver(edge_type), ver(edge_list_nhop), ver(edge_type_nhop), ver(batch_entities), str(dev), KEEP_PRUNED_POSITIONS)
+            hit = getattr(self, "_prune_cache", None)
+            if hit is None or hit[0] != key:
+                hit = self._prune_cache = (key, prune_edges(mask, edge_list, edge_type, edge_list_nhop, edge_type_nhop, want_pos=KEEP_PRUNED_POSITIONS),
+                                           (edge_list, edge_type, edge_list_nhop, edge_type_nhop, batch_entities))      # the inputs pin their identities
+            edge_list, edge_type, edge_list_nhop, edge_type_nhop = hit[1][:4]
+            self._pruned_pos = hit[1][4] if KEEP_PRUNED_POSITIONS else None
         # :156 `edge_embed = self.relation_embeddings[edge_type]`: None lets SpGAT read the relation table in place (IndexedRows)
         out_entity, out_relation = self.sparse_gat_1(Corpus_, entity_embeddings, relation_embeddings, edge_list, edge_type,
                                                      None, edge_list_nhop, edge_type_nhop)
-        mask = torch.zeros(entity_embeddings.shape[0], device=dev)
-        mask[batch_entities.to(dev)] = 1.0               # the reference takes torch.unique first (:167-170): same mask, but a host round trip
         ew = small_mm(entity_embeddings, self.W_entities)
         if ew.dtype == torch.float32 and out_entity.dtype == torch.float32:
             return _SkipMaskNormalize.apply(ew, out_entity, mask), out_relation, mask      # :177-180 in one launch each way

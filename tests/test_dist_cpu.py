@@ -328,7 +328,11 @@ def test_formulation_choice_ignores_the_local_batch_under_data_parallelism(monke
             return 1
     monkeypatch.setattr(gat_layers._lib, "lib", lambda: _Lib)
     monkeypatch.setattr(gat_layers, "_GAT_PATH", "auto")
-    assert gat_layers.gat_path_for(1000, 100, 8, 8, 8, 2) == "proj"          # one process: sparse batches project first
+    assert gat_layers.gat_path_for(1000, 60, 8, 8, 8, 2) == "proj"           # one process: sparse batches project first ...
+    assert gat_layers.gat_path_for(1000, 100, 8, 8, 8, 2) == "atp"           # ... unless the graph's rows with edges get compacted (more than HUB_CHUNK edges)
+    from recon_amd import graph as graph_mod
+    monkeypatch.setattr(graph_mod, "ROWS_COMPACT_MAX", 0.0)
+    assert gat_layers.gat_path_for(1000, 100, 8, 8, 8, 2) == "proj"
     monkeypatch.setattr(gat_layers, "_data_parallel", lambda: True)
     assert gat_layers.gat_path_for(1000, 100, 8, 8, 8, 2) == "atp" and gat_layers.gat_path_for(10, 100, 8, 8, 8, 2) == "atp"
     monkeypatch.undo()

@@ -1054,19 +1054,23 @@ def test_spkbgat_golden(name):
     close(tr, g["test_relation"], what="batch_test relation")
 
 
+@pytest.mark.parametrize("prune", [True, False])
 @pytest.mark.parametrize("family", ["2", "1", "0"])
 @pytest.mark.parametrize("path", ["atp", "proj"])
-def test_spkbgat_train_mode_three_sgd_iterations_golden(family, path, monkeypatch):
+def test_spkbgat_train_mode_three_sgd_iterations_golden(family, path, prune, monkeypatch):
     """The regime stage A runs (GAT/main.py:478-525): SpKBGATModified with drop_GAT = 0.3 in train(), three iterations of
     forward -> batch_gat_loss -> backward -> SGD(lr = 1e-3) on three different batches, against the REFERENCE's losses and final parameters.
     The reference's dropout factors were recorded in call order — one E-vector per head (GAT/layers.py:158 inside GAT/models.py:71-72),
     dropout_layer on the concatenated heads (:73), out_att's E-vector (:86) — and are replayed here through draw_keep / dropout_layer.
-    Every GEMM family (f16 x 2, bf16 x 3, exact fp32) and both formulations."""
-    from recon_amd import gat_layers
+    Every GEMM family (f16 x 2, bf16 x 3, exact fp32) and both formulations; with and without the pruning of the edges into rows the
+    model's mask discards (models.PRUNE_DEAD_ROWS: the surviving edges take their factors from the recorded vectors by position)."""
+    from recon_amd import gat_layers, models
     from recon_amd.models import SpKBGATModified
     from recon_amd.losses import batch_gat_loss
     monkeypatch.setattr(gat_layers, "_GEMM_BX3", family)
     monkeypatch.setattr(gat_layers, "_GAT_PATH", path)
+    monkeypatch.setattr(models, "PRUNE_DEAD_ROWS", prune)
+    monkeypatch.setattr(models, "KEEP_PRUNED_POSITIONS", True)
     g = load_golden("spkbgat3_train")
     d = dev()
     H, nhid, ratio = int(g["nheads"]), int(g["nhid"]), int(g["ratio"])
@@ -1080,17 +1084,21 @@ def test_spkbgat_train_mode_three_sgd_iterations_golden(family, path, monkeypatc
     opt = torch.optim.SGD(m.parameters(), lr=float(g["lr"]))
     loss_fn = torch.nn.MarginRankingLoss(margin=float(g["margin"]))
     drawn = []
+    kept = lambda mk: mk if m._pruned_pos is None else mk.reshape(-1)[m._pruned_pos]       # the factors of the edges the model kept
+    n_kept = []
     for it in range(3):
         masks = [T(g["it%d.mask%d" % (it, k)]).to(d) for k in range(H + 2)]
         assert float(masks[0].max()) <= sg.attentions[0].keep_bound() + 1e-6
         for h, att in enumerate(sg.attentions):
-            att.draw_keep = (lambda mk, tag: (lambda E, device: (drawn.append(tag), mk.view(1, E))[1]))(masks[h], "head%d" % h)
+            att.draw_keep = (lambda mk, tag: (lambda E, device: (drawn.append(tag), kept(mk).view(1, E))[1]))(masks[h], "head%d" % h)
         sg.dropout_layer.forward = (lambda mk: (lambda x: (drawn.append("layer"), x * mk)[1]))(masks[H])
-        sg.out_att.draw_keep = (lambda mk: (lambda E, device: (drawn.append("out"), mk.view(1, E))[1]))(masks[H + 1])
+        sg.out_att.draw_keep = (lambda mk: (lambda E, device: (drawn.append("out"), kept(mk).view(1, E))[1]))(masks[H + 1])
         drawn.clear()
         out_e, out_r, _ = m(None, T(g["it%d.batch_entities" % it]).to(d), (T(g["it%d.edge" % it]).to(d), T(g["it%d.edge_type" % it]).to(d)),
                             T(g["it%d.nhop" % it]).to(d))
         assert drawn == ["head%d" % h for h in range(H)] + ["layer", "out"], drawn          # the reference's draw order
+        assert (m._pruned_pos is not None) == prune
+        n_kept.append(m._pruned_pos.numel() if prune else masks[0].numel())
         close(out_e, g["it%d.out_entity" % it], atol=2e-5, what="train-mode out_entity, iteration %d" % it)
         close(out_r, g["it%d.out_relation" % it], atol=2e-5, what="train-mode out_relation, iteration %d" % it)
         opt.zero_grad()
@@ -1098,6 +1106,8 @@ def test_spkbgat_train_mode_three_sgd_iterations_golden(family, path, monkeypatc
         loss.backward()
         opt.step()
         np.testing.assert_allclose(loss.item(), g["losses"][it], rtol=1e-4, err_msg="loss of iteration %d" % it)
+    if prune:
+        assert sum(n_kept) < sum(int(g["it%d.mask0" % it].size) for it in range(3))      # the fixture's batches do have rows the mask discards
     for k, v in m.state_dict().items():
         np.testing.assert_allclose(v.cpu().numpy(), g["p3." + k], atol=1e-5, rtol=0, err_msg=k)
         if k not in ("entity_embeddings", "final_entity_embeddings", "final_relation_embeddings"):

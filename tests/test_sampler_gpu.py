@@ -119,6 +119,83 @@ def test_sampler_feeds_spkbgat():
     assert torch.isfinite(out_e).all() and float(mask.sum()) == len(sset | tset)
 
 
+@pytest.mark.parametrize("Ne,E1,E2,B,seed", [(500, 3000, 9000, 40, 0), (14541, 2400, 27000, 128, 1), (60, 80, 0, 25, 2), (300, 1, 5, 3, 3), (100, 700, 300, 0, 4)])
+def test_prune_edges_vs_numpy(Ne, E1, E2, B, seed):
+    """sampler.prune_edges: the edges whose destination lies in mask U {src(e) : mask[dst(e)]}, in input order, with their types and
+    positions — exact integer equality with the set arithmetic done in numpy."""
+    from recon_amd.sampler import prune_edges
+    rs = np.random.RandomState(seed)
+    d = dev()
+    mask = np.zeros(Ne, dtype=np.float32)
+    mask[rs.permutation(Ne)[:B]] = 1.0
+    e1, t1 = rs.randint(0, Ne, size=(2, E1)), rs.randint(0, 7, size=E1)
+    e2, t2 = rs.randint(0, Ne, size=(2, E2)), rs.randint(0, 7, size=(E2, 2))
+    need = mask != 0
+    for e in (e1, e2):
+        need[e[1][mask[e[0]] != 0]] = True
+    k1, k2 = need[e1[0]], need[e2[0]]
+    nh = (T(e2).to(d), T(t2).to(d)) if E2 else (torch.tensor([]), torch.tensor([]))
+    oe, ot, on, ont, pos = prune_edges(T(mask).to(d), T(e1).to(d), T(t1).to(d), nh[0], nh[1], want_pos=True)
+    np.testing.assert_array_equal(oe.cpu().numpy(), e1[:, k1])
+    np.testing.assert_array_equal(ot.cpu().numpy(), t1[k1])
+    assert ot.is_contiguous()
+    if k2.any():
+        np.testing.assert_array_equal(on.cpu().numpy(), e2[:, k2])
+        np.testing.assert_array_equal(ont.cpu().numpy(), t2[k2])
+        assert ont.is_contiguous()
+    else:
+        assert on.numel() == 0 and ont.numel() == 0
+    np.testing.assert_array_equal(pos.cpu().numpy(), np.concatenate([np.nonzero(k1)[0], E1 + np.nonzero(k2)[0]]))
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.3])
+def test_spkbgat_with_and_without_dead_row_pruning(drop, monkeypatch):
+    """SpKBGATModified on a sampled batch with the edges into discarded rows dropped up front (models.PRUNE_DEAD_ROWS) against the same
+    model evaluating every row as the reference does: outputs and every parameter's gradient (train mode: the same per-edge factors,
+    handed to the pruned run by position)."""
+    from recon_amd import models
+    from recon_amd.sampler import KGNeighbourSampler
+    rs = np.random.RandomState(3)
+    Ne, Tn, n_rel, B = 2000, 30000, 11, 64
+    p = 1.0 / np.arange(1, Ne + 1) ** 0.8
+    p /= p.sum()
+    adj = T(np.stack([rs.choice(Ne, size=Tn, p=p), rs.choice(Ne, size=Tn, p=p)])).long()
+    val = T(rs.randint(0, n_rel, Tn)).long()
+    d = dev()
+    sm = KGNeighbourSampler(adj.to(d), val.to(d), Ne)
+    ents = torch.tensor(rs.permutation(Ne)[:B].tolist(), device=d)
+    (edge, et), (ss, ts) = sm.batch_adj_data(ents)
+    nhop = sm.batch_nhop_neighbors(ss)
+    E = edge.shape[1] + nhop.shape[0]
+    g = torch.Generator().manual_seed(0)
+    ent_emb, rel_emb = torch.randn(Ne, 16, generator=g), torch.randn(n_rel, 16, generator=g)
+    G = torch.randn(Ne, 16, generator=g).to(d)
+    keeps = [((torch.rand(E, generator=g) > drop).float() / (1.0 - drop)).to(d) for _ in range(3)]
+    layer_keep = ((torch.rand(Ne, 16, generator=g) > drop).float() / (1.0 - drop)).to(d)
+    res = {}
+    for prune in (True, False):
+        monkeypatch.setattr(models, "PRUNE_DEAD_ROWS", prune)
+        monkeypatch.setattr(models, "KEEP_PRUNED_POSITIONS", True)
+        torch.manual_seed(0)
+        m = models.SpKBGATModified(ent_emb.clone(), rel_emb.clone(), [8, 16], [16, 16], drop, 0.2, [2, 2], None).to(d)
+        m.train(drop > 0)
+        if drop > 0:
+            sg = m.sparse_gat_1
+            kept = lambda mk: mk if m._pruned_pos is None else mk[m._pruned_pos]
+            for h, att in enumerate(list(sg.attentions) + [sg.out_att]):
+                att.draw_keep = (lambda mk: (lambda E_, device: kept(mk).view(1, E_)))(keeps[h])
+            sg.dropout_layer.forward = lambda x: x * layer_keep
+        out_e, out_r, mask = m(None, ss, (edge, et), nhop)
+        ((out_e * G).sum() + out_r.sum()).backward()
+        res[prune] = [out_e.detach(), out_r.detach()] + [p_.grad for _, p_ in sorted(m.named_parameters()) if p_.grad is not None]
+        if prune:
+            assert m._pruned_pos.numel() < E // 4                      # the batch's neighbours are not batch entities: most edges go
+    assert len(res[True]) == len(res[False]) > 4
+    for a_, b_ in zip(res[True], res[False]):
+        tol = 1e-5 + 1e-4 * float(b_.abs().max())
+        assert float((a_ - b_).abs().max()) <= tol
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["loss1_small", "loss2_wide", "loss3_ratio1"])
 def test_batch_gat_loss_golden(name, golden):

@@ -137,7 +137,7 @@ def main(argv=None):
         for _ in range(args.iters):
             train_iter(make_batch())
         pr.disable(); torch.cuda.synchronize()
-        pstats.Stats(pr).sort_stats("tottime").print_stats(45)
+        st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(30); st.sort_stats("cumtime").print_stats(70)
         return
     t_batch = timed(make_batch, args.iters)
     t_cached = timed(lambda: train_iter(one), args.iters)
