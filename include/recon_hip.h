@@ -754,6 +754,14 @@ int recon_kg_nhop(const recon_kg* kg, const int64_t* sources, int32_t S, int32_t
 int recon_edges_prune(const int64_t* edge, const int64_t* type, int64_t E1, const int64_t* edge_nhop, const int64_t* type_nhop, int64_t E2,
                       const float* mask, int32_t N, uint8_t* need, int64_t* out_edge, int64_t* out_type, int64_t* out_edge_nhop,
                       int64_t* out_type_nhop, int64_t* pos, int64_t* counts, recon_stream_t stream);
+/* The same for a whole SpKBGATModified call (GAT/models.py:136-178), one launch: mask [N] is MADE here (zeros, 1.0 at batch_entities [B]; an id
+ * outside [0, N) sets counts[2]: the reference's indexing raises), the n-hop list arrives as the quadruples [E2][4] = (source, rel_1, rel_2,
+ * target) it is derived from (:145-148), and the survivors of both lists go into ONE buffer out_edge [2][E1 + E2] (row stride E1 + E2), the
+ * 1-hop ones at [0, counts[0]), the n-hop ones at [counts[0], counts[0] + counts[1]): the caller's 1-hop, n-hop and concatenated edge tensors are
+ * views of it.  out_type [E1], out_type_nhop [E2][2], pos as above; counts: device int64 [3]. */
+int recon_edges_prune_batch(const int64_t* batch_entities, int32_t B, const int64_t* edge, const int64_t* type, int64_t E1, const int64_t* quads,
+                            int64_t E2, int32_t N, float* mask, uint8_t* need, int64_t* out_edge, int64_t* out_type, int64_t* out_type_nhop,
+                            int64_t* pos, int64_t* counts, recon_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * N1  the tail of SpKBGATModified (GAT/models.py:167-180) and the row normalisation of the entity table (:160):

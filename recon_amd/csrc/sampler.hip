@@ -394,37 +394,59 @@ bool kg_ok(const recon_kg* k) {
 // count the surviving edges of each list per thread (a thread owns a run of consecutive edges), scan, write them IN ORDER — the kept edges
 // of a row keep their relative order, so the row's sums are the sums the unpruned layer forms.  pos (optional): the surviving edges'
 // positions in the CONCATENATED input list, 1-hop then n-hop (the per-edge dropout factors of a recorded run are looked up through them).
+// BATCH (recon_edges_prune_batch, what SpKBGATModified calls): the mask itself is made here from the batch's entity ids (GAT/models.py:167-172:
+// zeros, mask[unique(batch_entities)] = 1), the n-hop list arrives as the [E2][4] quadruples (source, rel_1, rel_2, target) it is derived from
+// (:145-148: edge = (target, source), type = (rel_1, rel_2)), and both lists' survivors go into ONE [2][E1 + E2] buffer, 1-hop first — the
+// concatenation the layers build anyway (GAT/layers.py:124-127) — so that the caller's three tensors (1-hop, n-hop, both) are views of it.
+template <bool BATCH>
 __global__ void __launch_bounds__(1024) k_edges_prune(const int64_t* __restrict__ edge, const int64_t* __restrict__ type, int64_t E1,
                                                       const int64_t* __restrict__ edge_nhop, const int64_t* __restrict__ type_nhop, int64_t E2,
-                                                      const float* __restrict__ mask, int32_t N, uint8_t* __restrict__ need,
+                                                      const float* __restrict__ mask_in, const int64_t* __restrict__ batch, int32_t B,
+                                                      float* __restrict__ mask_out, int32_t N, uint8_t* __restrict__ need,
                                                       int64_t* __restrict__ out_edge, int64_t* __restrict__ out_type, int64_t* __restrict__ out_edge_nhop,
                                                       int64_t* __restrict__ out_type_nhop, int64_t* __restrict__ pos, int64_t* __restrict__ counts) {
-    // The host waits for the two counts (the output sizes): this launch is on the iteration's critical path.  Every pass asks for sixteen
+    // The host waits for the counts (the output sizes): this launch is on the iteration's critical path.  Every pass asks for sixteen
     // edges per thread at once (one edge in flight per thread: 102 us for a 30 000-edge batch; this form: 65 us).  What is left is ONE compute
     // unit's rate of scattered accesses — ~4 per edge (the row's mask word, the source's flag, the row's flag, the survivor's words) —, not a
     // chain of round trips: batching the survivors' loads as well (every edge's source and types, kept or not) took 117 us.  Spreading the
     // passes over many workgroups needs a grid-wide order between marking and reading the flags (two launches, or a look-back scan).
-    // Outputs: the destination row of a list at out[0 ..), its source row at out[E ..) — the caller's [2, n] tensor is a view with row stride E.
+    // Outputs (!BATCH): the destination row of a list at out[0 ..), its source row at out[E ..) — the caller's [2, n] tensor is a view with row stride E.
     __shared__ int32_t wsum[2][16];
+    __shared__ int32_t s_bad;
     constexpr int U = 16;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    for (int n0 = t; n0 < N; n0 += 1024 * U) {                        // (sixteen flags per thread in flight: one at a time was 15 round trips for 14 541 entities)
-        float m[U];
+    const float* mask = BATCH ? mask_out : mask_in;
+    if constexpr (BATCH) {
+        if (t == 0) s_bad = 0;
+        for (int n = t; n < N; n += 1024) { mask_out[n] = 0.f; need[n] = 0; }
+        __syncthreads();
+        for (int b = t; b < B; b += 1024) {
+            const int64_t v = batch[b];
+            if (v >= 0 && v < N) { mask_out[v] = 1.f; need[v] = 1; } else s_bad = 1;      // the reference's `mask[mask_indices] = 1.0` raises on such an id: reported
+        }
+        __threadfence_block();
+    } else {
+        for (int n0 = t; n0 < N; n0 += 1024 * U) {                    // (sixteen flags per thread in flight: one at a time was 15 round trips for 14 541 entities)
+            float m[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) m[u] = n0 + 1024 * u < N ? mask[n0 + 1024 * u] : 0.f;
+            for (int u = 0; u < U; ++u) m[u] = n0 + 1024 * u < N ? mask[n0 + 1024 * u] : 0.f;
 #pragma unroll
-        for (int u = 0; u < U; ++u) if (n0 + 1024 * u < N) need[n0 + 1024 * u] = m[u] != 0.f;
+            for (int u = 0; u < U; ++u) if (n0 + 1024 * u < N) need[n0 + 1024 * u] = m[u] != 0.f;
+        }
     }
     __syncthreads();
     auto in_range = [&](int64_t v) { return v >= 0 && v < N; };       // ids out of range: the edge is kept, and the graph build reports them as it always does
-    auto mark = [&](const int64_t* __restrict__ e, int64_t E) {
+    // the two lists through one set of accessors: list 0 = edge [2][E1] / type [E1]; list 1 = edge_nhop [2][E2] / type_nhop [E2][2], or (BATCH) the quadruples
+    auto dst_of = [&](int list, int64_t i) { return list == 0 ? edge[i] : (BATCH ? edge_nhop[4 * i + 3] : edge_nhop[i]); };
+    auto src_of = [&](int list, int64_t i) { return list == 0 ? edge[E1 + i] : (BATCH ? edge_nhop[4 * i] : edge_nhop[E2 + i]); };
+    auto mark = [&](int list, int64_t E) {
         for (int64_t i0 = t; i0 < E; i0 += 1024 * U) {
             int32_t d[U], s_[U];
             float m[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t i = i0 + 1024 * u;
-                const int64_t dv = i < E ? e[i] : -1, sv = i < E ? e[E + i] : -1;
+                const int64_t dv = i < E ? dst_of(list, i) : -1, sv = i < E ? src_of(list, i) : -1;
                 d[u] = in_range(dv) ? static_cast<int32_t>(dv) : -1; s_[u] = in_range(sv) ? static_cast<int32_t>(sv) : -1;
             }
 #pragma unroll
@@ -433,22 +455,21 @@ __global__ void __launch_bounds__(1024) k_edges_prune(const int64_t* __restrict_
             for (int u = 0; u < U; ++u) if (m[u] != 0.f && s_[u] >= 0) need[s_[u]] = 1;
         }
     };
-    mark(edge, E1);
-    mark(edge_nhop, E2);
+    mark(0, E1);
+    mark(1, E2);
     __threadfence_block();
     __syncthreads();
     // ordered write: a thread owns U CONSECUTIVE edges of a 16 384-edge tile; positions = kept in the tiles before + in the waves before + in the
     // lanes before (a wave scan of the threads' counts) + among the thread's own
     int par = 0;
-    auto write = [&](const int64_t* __restrict__ e, const int64_t* __restrict__ ty, int64_t E, int64_t* __restrict__ oe, int64_t* __restrict__ ot,
-                     bool pair, int64_t pos_off) -> int64_t {
+    auto write = [&](int list, int64_t E, int64_t* __restrict__ oe, int64_t row_stride, int64_t* __restrict__ ot, int64_t pos_off) -> int64_t {
         int64_t run = 0;
         for (int64_t b = 0; b < E; b += 1024 * U, par ^= 1) {
             const int64_t i0 = b + static_cast<int64_t>(U) * t;
             int32_t d[U];                                                // ids as 32-bit values, -1 = outside [0, N) (64-bit copies of 32 ids per thread spilled)
             uint8_t nd[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) { const int64_t v = i0 + u < E ? e[i0 + u] : 0; d[u] = in_range(v) ? static_cast<int32_t>(v) : -1; }
+            for (int u = 0; u < U; ++u) { const int64_t v = i0 + u < E ? dst_of(list, i0 + u) : 0; d[u] = in_range(v) ? static_cast<int32_t>(v) : -1; }
 #pragma unroll
             for (int u = 0; u < U; ++u) nd[u] = d[u] >= 0 ? need[d[u]] : 1;
             int c = 0;
@@ -468,8 +489,10 @@ __global__ void __launch_bounds__(1024) k_edges_prune(const int64_t* __restrict_
             for (int u = 0; u < U; ++u) {
                 if ((kmask >> u) & 1) {                                  // (the survivors are few: their sources and types are fetched here)
                     const int64_t i = i0 + u;
-                    oe[o] = e[i]; oe[E + o] = e[E + i];
-                    if (pair) { ot[2 * o] = ty[2 * i]; ot[2 * o + 1] = ty[2 * i + 1]; } else ot[o] = ty[i];
+                    oe[o] = dst_of(list, i); oe[row_stride + o] = src_of(list, i);
+                    if (list == 0) ot[o] = type[i];
+                    else if (BATCH) { ot[2 * o] = edge_nhop[4 * i + 1]; ot[2 * o + 1] = edge_nhop[4 * i + 2]; }
+                    else { ot[2 * o] = type_nhop[2 * i]; ot[2 * o + 1] = type_nhop[2 * i + 1]; }
                     if (pos) pos[pos_off + o] = pos_off + i;
                     ++o;
                 }
@@ -478,11 +501,11 @@ __global__ void __launch_bounds__(1024) k_edges_prune(const int64_t* __restrict_
         }
         return run;
     };
-    const int64_t n1 = write(edge, type, E1, out_edge, out_type, false, 0);
+    const int64_t n1 = write(0, E1, out_edge, BATCH ? E1 + E2 : E1, out_type, 0);
     __syncthreads();
     // (the n-hop positions follow the 1-hop ones at E1: the caller cuts the two runs out of pos with the counts)
-    const int64_t n2 = write(edge_nhop, type_nhop, E2, out_edge_nhop, out_type_nhop, true, E1);
-    if (t == 0) { counts[0] = n1; counts[1] = n2; }
+    const int64_t n2 = write(1, E2, BATCH ? out_edge + n1 : out_edge_nhop, BATCH ? E1 + E2 : E2, out_type_nhop, E1);
+    if (t == 0) { counts[0] = n1; counts[1] = n2; if (BATCH) counts[2] = s_bad; }
 }
 
 KG kg_of(const recon_kg* k) {
@@ -562,8 +585,21 @@ extern "C" int recon_edges_prune(const int64_t* edge, const int64_t* type, int64
     if (E1 < 0 || E2 < 0 || N <= 0 || !mask || !need || !counts) return RECON_ERR_INVALID;
     if (E1 > 0 && (!edge || !type || !out_edge || !out_type)) return RECON_ERR_INVALID;
     if (E2 > 0 && (!edge_nhop || !type_nhop || !out_edge_nhop || !out_type_nhop)) return RECON_ERR_INVALID;
-    hipLaunchKernelGGL(recon::k_edges_prune, dim3(1), dim3(1024), 0, as_stream(stream), edge, type, E1, edge_nhop, type_nhop, E2, mask, N, need, out_edge, out_type,
-                       out_edge_nhop, out_type_nhop, pos, counts);
+    hipLaunchKernelGGL(recon::k_edges_prune<false>, dim3(1), dim3(1024), 0, as_stream(stream), edge, type, E1, edge_nhop, type_nhop, E2, mask, nullptr, 0, nullptr, N,
+                       need, out_edge, out_type, out_edge_nhop, out_type_nhop, pos, counts);
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+extern "C" int recon_edges_prune_batch(const int64_t* batch_entities, int32_t B, const int64_t* edge, const int64_t* type, int64_t E1, const int64_t* quads,
+                                       int64_t E2, int32_t N, float* mask, uint8_t* need, int64_t* out_edge, int64_t* out_type, int64_t* out_type_nhop,
+                                       int64_t* pos, int64_t* counts, recon_stream_t stream) {
+    if (B < 0 || E1 < 0 || E2 < 0 || N <= 0 || !mask || !need || !counts || (B > 0 && !batch_entities)) return RECON_ERR_INVALID;
+    if (E1 > 0 && (!edge || !type || !out_type)) return RECON_ERR_INVALID;
+    if (E2 > 0 && (!quads || !out_type_nhop)) return RECON_ERR_INVALID;
+    if (E1 + E2 > 0 && !out_edge) return RECON_ERR_INVALID;
+    hipLaunchKernelGGL(recon::k_edges_prune<true>, dim3(1), dim3(1024), 0, as_stream(stream), edge, type, E1, quads, nullptr, E2, nullptr, batch_entities, B, mask, N,
+                       need, out_edge, out_type, nullptr, out_type_nhop, pos, counts);
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }

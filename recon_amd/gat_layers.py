@@ -401,7 +401,7 @@ class _GATHeadsFunction(torch.autograd.Function):
     One C call for the forward (projection GEMMs + fused edge kernel), one for the backward."""
 
     @staticmethod
-    def forward(ctx, x, ee, a, a2, graph, keep, alpha, concat):
+    def forward(ctx, x, ee, a, a2, graph, keep, alpha, concat, keep_iid=False):
         _require_gpu_f32(x, ee, a, a2, keep)
         L = _lib.lib()
         x, ee, a, a2 = x.contiguous(), ee.contiguous(), a.contiguous(), a2.contiguous()
@@ -420,7 +420,8 @@ class _GATHeadsFunction(torch.autograd.Function):
         if keep is not None:
             if not need_grad:
                 sigma, Z = torch.empty(H, E, **f32), torch.empty(H, N, **f32)
-            keep = keep.view(H, E)[:, graph.eid_long].contiguous()       # original order -> CSR-slot order
+            # original order -> CSR-slot order; independent draws (keep_iid) are as good in any order: taken as they lie
+            keep = keep.view(H, E) if keep_iid else keep.view(H, E)[:, graph.eid_long].contiguous()
         args = _fwd_args(graph, x, ee, a, a2, keep, P, Q, sigma, Z, out, alpha, concat)
         with _lib.on_device(dev):
             _lib.check(L.recon_gat_fwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_fwd")
@@ -452,7 +453,7 @@ class _GATHeadsFunction(torch.autograd.Function):
                                partial.data_ptr(), _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2))
         with _lib.on_device(dev):
             _lib.check(L.recon_gat_bwd(C.byref(graph.c), C.byref(args), _lib.current_stream()), "recon_gat_bwd")
-        return g_x, g_ee, g_a, g_a2, None, None, None, None
+        return g_x, g_ee, g_a, g_a2, None, None, None, None, None
 
 
 def _p(t):
@@ -560,7 +561,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
     """Same contract as _GATHeadsFunction, through the aggregate-then-project kernels (csrc/gat_atp.hip)."""
 
     @staticmethod
-    def forward(ctx, x, ee, a, a2, graph, keep, alpha, concat, keep_max, ee_index=None):
+    def forward(ctx, x, ee, a, a2, graph, keep, alpha, concat, keep_max, ee_index=None, keep_iid=False):
         """ee_index (int64 [E], original edge order) makes `ee` a table: edge e uses row ee_index[e] (see gat_heads).
         x and ee may both be bfloat16 (gat_heads checks the shape: recon_gat_atp_bf16_io_supported): the forward kernels read them in
         place, as do the backward's; the result and the arithmetic stay float32 and the two input gradients are rounded to bfloat16 at the end."""
@@ -597,7 +598,8 @@ class _GATHeadsATPFunction(torch.autograd.Function):
             4 * H * W, 4 * N * 2 * H, 4 * max(E, ee.shape[0] if ee_index is not None else 0) * H, 4 * N * H * W, 4 * E * H if train else None, 4 * N * H if train else None,
             4 * N * H if train else None, split_bytes if mode else None, aux_bytes if mode == 2 else None))
         if keep is not None:
-            keep = keep.view(H, E)[:, graph.eid_long].t().contiguous()        # [H,E] original order -> [E,H] slot order
+            # [H,E] original order -> [E,H] slot order; independent draws (keep_iid: H E factors nobody has tied to edges yet) are read as [E,H]
+            keep = keep.reshape(E, H) if keep_iid else keep.view(H, E)[:, graph.eid_long].t().contiguous()
         if keep is None:
             keep_max = 1.0
         elif keep_max is None:                                  # explicit factors without a bound: one host read (tests)
@@ -703,7 +705,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
         if io16:
             g_x = g_x.to(torch.bfloat16) if g_x is not None else None
             g_ee = g_ee.to(torch.bfloat16) if g_ee is not None else None
-        return g_x, g_ee, (g_a if na else None), (g_a2 if na2 else None), None, None, None, None, None, None
+        return g_x, g_ee, (g_a if na else None), (g_a2 if na2 else None), None, None, None, None, None, None, None
 
 
 def _rowsum_by_index(rows, index, n_rows):
@@ -790,12 +792,14 @@ def _data_parallel():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=True, keep_max=None, ee_index=None):
+def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=True, keep_max=None, ee_index=None, keep_iid=False):
     """Fused forward of H `SpGraphAttentionLayer`s that share their inputs (GAT/models.py:71-72).
 
     x [N,F]; edge_embed_all [E,R] (1-hop rows then n-hop rows, original order); a [H,D,2F+R];
     a_2 [H,D]; graph = prepare_graph(edge, edge_list_nhop, N); keep [H,E] dropout factors in
-    original edge order or None; keep_max an upper bound of them (1/(1-p); read back from `keep` when omitted).
+    original edge order or None; keep_max an upper bound of them (1/(1-p); read back from `keep` when omitted); keep_iid: the H E
+    factors are independent draws that nobody has tied to particular edges (draw_keeps_iid) — the kernels take them in the order they lie
+    instead of through a gather into CSR-slot order.
     ee_index (int64 [E], original edge order) turns edge_embed_all into a TABLE [T,R]: edge e uses row ee_index[e] —
     `relation_embed[edge_type]` (GAT/models.py:79, :156) read in place by the kernels instead of materialised as E x R by the caller
     (at 272 k edges x 200 columns that tensor is 218 MB, written once and read four times per step); the table's gradient comes back
@@ -807,23 +811,23 @@ def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=Tru
         # only the fp32 ATP kernels read a table through an index: materialise the rows (gather_rows is an fp32 kernel with a fixed-order
         # backward; reduced-precision tables go through index_select, whose autograd is native)
         rows = gather_rows(edge_embed_all, ee_index) if edge_embed_all.dtype == torch.float32 else edge_embed_all.index_select(0, ee_index)
-        return gat_heads(x, rows, a, a_2, graph, keep, alpha, concat, keep_max)
+        return gat_heads(x, rows, a, a_2, graph, keep, alpha, concat, keep_max, keep_iid=keep_iid)
     if (x.dtype == torch.bfloat16 and edge_embed_all.dtype == torch.bfloat16 and ee_index is None and x.is_cuda and D % 8 == 0 and
             gat_path_for(graph.N, graph.E, x.shape[1], edge_embed_all.shape[1], D, H) == "atp" and
             _lib.lib().recon_gat_atp_bf16_io_supported(x.shape[1], edge_embed_all.shape[1], D, H) == 1 and _GEMM_BX3 in ("auto", "2")):
         # bfloat16 at the layer's boundary, read IN PLACE by the forward's kernels (csrc/gat_atp.hip, io_bf16): no up-cast copies of x and of the
         # E x R edge embeddings (174 MB of traffic at BASELINE.json configs[4]'s 145 k edges); arithmetic and parameters stay float32
-        out = _GATHeadsATPFunction.apply(x, edge_embed_all, a.float(), a_2.float(), graph, keep, alpha, concat, keep_max, None)
+        out = _GATHeadsATPFunction.apply(x, edge_embed_all, a.float(), a_2.float(), graph, keep, alpha, concat, keep_max, None, keep_iid)
         return out.to(x.dtype)
     if x.dtype in (torch.bfloat16, torch.float16):
         # Reduced-precision STORAGE at the layer boundary (BASELINE.json configs[4]: "mixed GAT+Propagation stack, bf16"): features
         # and edge embeddings arrive and leave in x.dtype; scores, softmax, aggregation and projections run the fp32 kernels (the
         # reference's own arithmetic is fp32; its exp(-leakyrelu(.)) has no max subtraction and would overflow half precision).
-        out = gat_heads(x.float(), edge_embed_all.float(), a.float(), a_2.float(), graph, keep, alpha, concat, keep_max)
+        out = gat_heads(x.float(), edge_embed_all.float(), a.float(), a_2.float(), graph, keep, alpha, concat, keep_max, keep_iid=keep_iid)
         return out.to(x.dtype)
     if gat_path_for(graph.N, graph.E, x.shape[1], edge_embed_all.shape[1], D, H) == "atp":
         Dp = (D + 7) // 8 * 8
-        if Dp != D and graph.N * H * D >= _PAD_MIN_OUT:
+        if Dp != D and (graph.n_rows or graph.N) * H * D >= _PAD_MIN_OUT:      # (rows the products run over: graph.n_rows when the rows with edges are compacted)
             # Heads whose width is not a multiple of 8 (the reference's D = 25 per head) run as Dp-wide heads with zero rows appended to
             # `a` and `a_2`: the extra output columns are act(0) = 0 and are dropped, the extra gradient rows are dropped by autograd.
             # Unpadded, the head offsets h * D are not 16-byte aligned and the three products fall back to scalar-load GEMMs (the
@@ -831,10 +835,10 @@ def gat_heads(x, edge_embed_all, a, a_2, graph, keep=None, alpha=0.2, concat=Tru
             N = x.shape[0]
             a_p = torch.nn.functional.pad(a, (0, 0, 0, Dp - D))
             a2_p = torch.nn.functional.pad(a_2, (0, Dp - D))
-            out_p = _GATHeadsATPFunction.apply(x, edge_embed_all, a_p, a2_p, graph, keep, alpha, concat, keep_max, ee_index)
+            out_p = _GATHeadsATPFunction.apply(x, edge_embed_all, a_p, a2_p, graph, keep, alpha, concat, keep_max, ee_index, keep_iid)
             return out_p.view(N, H, Dp)[:, :, :D].reshape(N, H * D)
-        return _GATHeadsATPFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat, keep_max, ee_index)
-    return _GATHeadsFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat)
+        return _GATHeadsATPFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat, keep_max, ee_index, keep_iid)
+    return _GATHeadsFunction.apply(x, edge_embed_all, a, a_2, graph, keep, alpha, concat, keep_iid)
 
 
 class IndexedRows:
@@ -909,6 +913,20 @@ class SpGraphAttentionLayer(nn.Module):
             return self.dropout(_ones(E, device)).view(1, E)
         return None
 
+    def plain_draws(self):
+        """Whether draw_keep is the method above with a stock nn.Dropout behind it (not replaced by a test that replays recorded factors, not
+        a subclass's): only then may a caller draw the factors of several heads in one call (draw_keeps_iid)."""
+        return ("draw_keep" not in self.__dict__ and type(self).draw_keep is SpGraphAttentionLayer.draw_keep and type(self.dropout) is nn.Dropout
+                and "forward" not in self.dropout.__dict__)
+
+    def draw_keeps_iid(self, H, E, device):
+        """H x E independent dropout factors in ONE nn.Dropout call, for callers whose edge list is not the reference's (the pruned batch graphs
+        of models.SpKBGATModified: the factors cannot be the reference's edge for edge anyway).  Same distribution as H calls of draw_keep; the
+        kernels read them in the order they lie (gat_heads(keep_iid=True)): no cat of the heads' vectors, no gather into slot order."""
+        if self.training and self.dropout.p > 0:
+            return self.dropout(_ones(H * E, device)).view(H, E)
+        return None
+
     def keep_bound(self):
         """Upper bound of the dropout factors draw_keep produces: 1 / (1 - p)."""
         p = float(self.dropout.p)
@@ -921,9 +939,10 @@ class SpGraphAttentionLayer(nn.Module):
         N = input.size()[0]                                  # not self.num_nodes (GAT/layers.py:112)
         graph = prepare_graph(edge, edge_list_nhop, N)
         ee, ee_index = cat_edge_embed(edge_embed, edge_list_nhop, edge_embed_nhop)     # edge_embed: [E,R] as in the reference, or IndexedRows
-        keep = self.draw_keep(graph.E, input.device)
+        iid = getattr(self, "iid_keep_draws", False) and self.plain_draws()     # set by a caller whose edge list is its own (models.SpKBGATModified, pruned graphs)
+        keep = self.draw_keeps_iid(1, graph.E, input.device) if iid else self.draw_keep(graph.E, input.device)
         out = gat_heads(input, ee, self.a.unsqueeze(0), self.a_2, graph, keep, self.alpha, self.concat if elu is None else bool(elu),
-                        keep_max=self.keep_bound() if keep is not None else None, ee_index=ee_index)
+                        keep_max=self.keep_bound() if keep is not None else None, ee_index=ee_index, keep_iid=iid and keep is not None)
         if _DEBUG_NAN:                                       # the reference's asserts (:147,:167,:172), at their price: a host round trip per call
             assert not nan_raised(input.device) and not torch.isnan(out).any()
         return out

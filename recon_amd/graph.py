@@ -81,7 +81,8 @@ class GraphCSR:
             raise RuntimeError("recon_amd: edge tensors must live on the GPU (no CPU path)")
         if edge.dtype != torch.int64 or edge.dim() != 2 or edge.shape[0] != 2:
             raise ValueError("edge must be an int64 [2,E] tensor")
-        edge = edge.contiguous()
+        if edge.stride(1) != 1 and edge.shape[1] > 1:                     # rows must be dense; the two rows may lie apart (a column range of a wider [2, .] buffer)
+            edge = edge.contiguous()
         E = edge.shape[1]
         if N >= 2 ** 31 or E >= 2 ** 31:
             raise ValueError("graph too large for int32 indices")
@@ -124,9 +125,9 @@ class GraphCSR:
         with _lib.on_device(dev):
             stream = _lib.current_stream()                                   # of `dev`, which need not be the current device
             if hubs:
-                rc = L.recon_graph_build_counted(edge.data_ptr(), edge.data_ptr() + 8 * E, C.byref(self._c), ws_ptr, ws_bytes, _lib.ptr(bad), HUB_CHUNK, stream)
+                rc = L.recon_graph_build_counted(edge.data_ptr(), edge.data_ptr() + 8 * edge.stride(0), C.byref(self._c), ws_ptr, ws_bytes, _lib.ptr(bad), HUB_CHUNK, stream)
             else:
-                rc = L.recon_graph_build_checked(edge.data_ptr(), edge.data_ptr() + 8 * E, C.byref(self._c), ws_ptr, ws_bytes, _lib.ptr(bad), stream)
+                rc = L.recon_graph_build_checked(edge.data_ptr(), edge.data_ptr() + 8 * edge.stride(0), C.byref(self._c), ws_ptr, ws_bytes, _lib.ptr(bad), stream)
         _lib.check(rc, "recon_graph_build")
         self._eid_long = None
         self._slot_idx = {}
@@ -297,7 +298,11 @@ def prepare_graph(edge, edge_list_nhop, N, rows_only=False):
     if g is not None:
         _CACHE.move_to_end(key)
         return g
-    full = torch.cat((edge, edge_list_nhop), dim=1) if nh else edge
+    joined = getattr(edge, "_recon_joined", None)                       # (sampler.prune_batch: both lists are column ranges of one buffer, side by side)
+    if nh and joined is not None and joined[1] is edge_list_nhop and joined[0].shape[1] == edge.shape[1] + edge_list_nhop.shape[1]:
+        full = joined[0]
+    else:
+        full = torch.cat((edge, edge_list_nhop), dim=1) if nh else edge
     g = GraphCSR(full, N, rows_only, validate=not (trusted(edge, N) and (not nh or trusted(edge_list_nhop, N))))
     g._keepalive = (edge, edge_list_nhop if nh else None)   # pins data_ptr identity while cached
     _CACHE[key] = g

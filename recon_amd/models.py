@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from . import _lib
 from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed, gather_rows, gather_rows_pair, small_mm, IndexedRows, set_weight_grad_destination
 from .graph import prepare_graph, trust, trusted, trust_bounds
-from .sampler import prune_edges
+from .sampler import prune_batch
 
 # SpKBGATModified: drop the edges into rows that its mask discards before the layers run (sampler.prune_edges); 0 = evaluate every row, as
 # the reference does (tests compare both)
@@ -103,10 +103,14 @@ class SpGAT(nn.Module):
         graph = prepare_graph(edge_list, edge_list_nhop, x.shape[0])
         ee, ee_index = cat_edge_embed(edge_embed, edge_list_nhop, edge_embed_nhop)
         a, a2 = self.fused_head_params()                                  # [H, D, 2F+R], [H, D]
-        keeps = [att.draw_keep(graph.E, x.device) for att in self.attentions]   # reference draw order
-        keep = torch.cat(keeps, dim=0) if keeps[0] is not None else None
+        iid = getattr(self, "iid_keep_draws", False) and all(att.plain_draws() for att in self.attentions)
+        if iid:                                                           # the edge list is the caller's own (pruned): all heads' factors in one draw
+            keep = self.attentions[0].draw_keeps_iid(len(self.attentions), graph.E, x.device)
+        else:
+            keeps = [att.draw_keep(graph.E, x.device) for att in self.attentions]   # reference draw order
+            keep = torch.cat(keeps, dim=0) if keeps[0] is not None else None
         return gat_heads(x, ee, a, a2, graph, keep, self.alpha, True,
-                         keep_max=self.attentions[0].keep_bound() if keep is not None else None, ee_index=ee_index)
+                         keep_max=self.attentions[0].keep_bound() if keep is not None else None, ee_index=ee_index, keep_iid=iid and keep is not None)
 
     def forward(self, Corpus_, entity_embeddings, relation_embed, edge_list, edge_type, edge_embed,
                 edge_list_nhop, edge_type_nhop):
@@ -225,23 +229,34 @@ class SpKBGATModified(nn.Module):
         edge_list, edge_type = adj[0], adj[1]
         dev = entity_embeddings.device
         edge_list, edge_type = edge_list.to(dev), edge_type.to(dev)
-        edge_list_nhop, edge_type_nhop = self._nhop(train_indices_nhop, dev)
-        mask = torch.zeros(entity_embeddings.shape[0], device=dev)
-        mask[batch_entities.to(dev)] = 1.0               # the reference takes torch.unique first (:167-170): same mask, but a host round trip
         self._pruned_pos = None
-        if PRUNE_DEAD_ROWS and mask.is_cuda and edge_list.dtype == torch.int64 and edge_list.dim() == 2 and edge_list.shape[1] > 0:
+        self.sparse_gat_1.iid_keep_draws = self.sparse_gat_1.out_att.iid_keep_draws = False
+        quads = train_indices_nhop
+        prune = (PRUNE_DEAD_ROWS and entity_embeddings.is_cuda and edge_list.dtype == torch.int64 and edge_list.dim() == 2 and edge_list.shape[1] > 0 and
+                 (quads.shape[0] == 0 or (quads.dtype == torch.int64 and quads.dim() == 2 and quads.shape[1] == 4)))
+        if prune:
             # :177-178 keep `mask * out_entity_1`: the edges into rows that neither the mask keeps nor a kept row reads are dropped up front
-            # (sampler.prune_edges); both layers then see the same, much smaller graph and every kept row comes out as before
-            # kept per (edge tensors, batch entities) identity + version, like the graph cache: a caller that re-uses a batch re-uses the pruned
-            # tensors (and with them the prepared graph); a fresh batch per iteration — the reference's loop — prunes once per iteration
+            # (sampler.prune_batch: one launch makes the mask, reads the n-hop edges out of the quadruples and writes both lists' survivors side by
+            # side); both layers then see the same, much smaller graph and every kept row comes out as before.
+            # Kept per (edge tensors, quadruples, batch entities) identity + version, like the graph cache: a caller that re-uses a batch re-uses
+            # the pruned tensors (and with them the prepared graph); a fresh batch per iteration — the reference's loop — prunes once per iteration
             ver = lambda t: (t.data_ptr(), t._version, tuple(t.shape)) if torch.is_tensor(t) else None
-            key = (ver(edge_list), ver(edge_type), ver(edge_list_nhop), ver(edge_type_nhop), ver(batch_entities), str(dev), KEEP_PRUNED_POSITIONS)
+            key = (ver(edge_list), ver(edge_type), ver(quads), ver(batch_entities), str(dev), KEEP_PRUNED_POSITIONS)
             hit = getattr(self, "_prune_cache", None)
             if hit is None or hit[0] != key:
-                hit = self._prune_cache = (key, prune_edges(mask, edge_list, edge_type, edge_list_nhop, edge_type_nhop, want_pos=KEEP_PRUNED_POSITIONS),
-                                           (edge_list, edge_type, edge_list_nhop, edge_type_nhop, batch_entities))      # the inputs pin their identities
-            edge_list, edge_type, edge_list_nhop, edge_type_nhop = hit[1][:4]
-            self._pruned_pos = hit[1][4] if KEEP_PRUNED_POSITIONS else None
+                q = quads.to(dev) if quads.shape[0] else quads
+                if quads.shape[0] and trusted(quads):
+                    trust(q, bound=trust_bounds(quads)[0], rel_bound=trust_bounds(quads)[1])
+                hit = self._prune_cache = (key, prune_batch(batch_entities, edge_list, edge_type, q, entity_embeddings.shape[0], want_pos=KEEP_PRUNED_POSITIONS),
+                                           (edge_list, edge_type, quads, batch_entities))      # the inputs pin their identities
+            mask, edge_list, edge_type, edge_list_nhop, edge_type_nhop = hit[1][:5]
+            self._pruned_pos = hit[1][5] if KEEP_PRUNED_POSITIONS else None
+            # the layers' per-edge dropout factors cannot be the reference's edge for edge on a pruned list: drawn in one call per layer
+            self.sparse_gat_1.iid_keep_draws = self.sparse_gat_1.out_att.iid_keep_draws = True
+        else:
+            edge_list_nhop, edge_type_nhop = self._nhop(train_indices_nhop, dev)
+            mask = torch.zeros(entity_embeddings.shape[0], device=dev)
+            mask[batch_entities.to(dev)] = 1.0           # the reference takes torch.unique first (:167-170): same mask, but a host round trip
         # :156 `edge_embed = self.relation_embeddings[edge_type]`: None lets SpGAT read the relation table in place (IndexedRows)
         out_entity, out_relation = self.sparse_gat_1(Corpus_, entity_embeddings, relation_embeddings, edge_list, edge_type,
                                                      None, edge_list_nhop, edge_type_nhop)

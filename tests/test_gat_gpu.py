@@ -845,6 +845,39 @@ def test_rows_with_edges_compacted_vs_oracle_and_uncompacted(N, F_, R, D, H, con
         close(rest[1], g_ee, atol=1e-4, what="g_edge_embed")
 
 
+@pytest.mark.parametrize("path", ["atp", "proj"])
+def test_keep_factors_taken_as_they_lie(path, monkeypatch):
+    """gat_heads(keep_iid=True): H E independent dropout factors are read by the kernels in the order they lie (CSR-slot order, [E,H] for
+    aggregate-then-project, [H,E] for project-then-aggregate) — equal to handing the same factors over edge by edge in original order."""
+    from recon_amd import gat_layers
+    from recon_amd.graph import prepare_graph
+    monkeypatch.setattr(gat_layers, "_GAT_PATH", path)
+    d = dev()
+    N, E, F_, R, D, H = 300, 4000, 24, 16, 32, 4
+    g = torch.Generator().manual_seed(5)
+    edge = torch.randint(0, N, (2, E), generator=g)
+    x, ee = torch.randn(N, F_, generator=g), torch.randn(E, R, generator=g) * 0.5
+    a = torch.stack([O.xavier_normal((D, 2 * F_ + R), 1.414, g) for _ in range(H)]) * 0.5
+    a2 = torch.cat([O.xavier_normal((1, D), 1.414, g) for _ in range(H)])
+    K = ((torch.rand(H, E, generator=g) > 0.3).float() / 0.7).to(d)
+    gr = prepare_graph(edge.to(d), None, N)
+    eid = gr.eid_long
+    by_edge = torch.empty(H, E, device=d)
+    if path == "atp":
+        by_edge[:, eid] = K.reshape(E, H).t()                            # slot k, head h reads K.reshape(E, H)[k, h]
+    else:
+        by_edge[:, eid] = K                                              # slot k, head h reads K[h, k]
+    G = torch.randn(N, H * D, generator=g).to(d)
+    res = []
+    for keep, iid in ((K, True), (by_edge, False)):
+        xd, eed, ad, a2d = (t.to(d).requires_grad_(True) for t in (x, ee, a, a2))
+        out = gat_layers.gat_heads(xd, eed, ad, a2d, gr, keep, 0.2, True, keep_max=1.0 / 0.7, keep_iid=iid)
+        (out * G).sum().backward()
+        res.append([out.detach(), xd.grad, eed.grad, ad.grad, a2d.grad])
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
+
+
 @pytest.mark.parametrize("N,E,F_,R,D,H,concat,drop,nrel,extra", [
     (200, 3000, 24, 16, 32, 4, True, False, 7, 0),        # relation table only (1-hop edges), f16 x 2 capable
     (200, 3000, 24, 16, 32, 4, True, True, 7, 500),       # + 500 edges with rows of their own appended to the table (n-hop edges), dropout

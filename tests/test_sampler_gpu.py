@@ -146,6 +146,31 @@ def test_prune_edges_vs_numpy(Ne, E1, E2, B, seed):
     else:
         assert on.numel() == 0 and ont.numel() == 0
     np.testing.assert_array_equal(pos.cpu().numpy(), np.concatenate([np.nonzero(k1)[0], E1 + np.nonzero(k2)[0]]))
+    # the whole-call form: mask made from the batch's ids, n-hop list read from quadruples, survivors of both lists side by side in one buffer
+    from recon_amd.sampler import prune_batch
+    from recon_amd.graph import prepare_graph, clear_graph_cache
+    be = np.nonzero(mask)[0][rs.permutation(int(mask.sum()))]
+    be = np.concatenate([be, be[:3]])                                    # duplicates: the reference takes torch.unique
+    quads = np.stack([e2[1], t2[:, 0], t2[:, 1], e2[0]], axis=1) if E2 else np.zeros((0, 4), dtype=np.int64)
+    m2, oe2, ot2, on2, ont2, pos2 = prune_batch(T(be).to(d), T(e1).to(d), T(t1).to(d), T(quads).to(d) if E2 else torch.tensor([], dtype=torch.long), Ne, want_pos=True)
+    np.testing.assert_array_equal(m2.cpu().numpy(), mask)
+    for a_, b_ in ((oe2, oe), (ot2, ot), (pos2, pos)):
+        assert torch.equal(a_, b_)
+    if k2.any():
+        assert torch.equal(on2, on) and torch.equal(ont2, ont)
+        clear_graph_cache()
+        g_join = prepare_graph(oe2, on2, Ne)                             # takes the joined view: no cat
+        assert g_join.edge.data_ptr() == oe2.data_ptr()
+        clear_graph_cache()
+        g_cat = prepare_graph(oe.contiguous(), on.contiguous(), Ne)
+        for nm in ("rowptr_dst", "eid", "src", "dst", "rowptr_src", "slot_by_src"):
+            assert torch.equal(getattr(g_join, nm), getattr(g_cat, nm)), nm
+        clear_graph_cache()
+    else:
+        assert on2.numel() == 0
+    if B:
+        with pytest.raises(IndexError):
+            prune_batch(torch.tensor([0, Ne], device=d), T(e1).to(d), T(t1).to(d), torch.tensor([], dtype=torch.long), Ne)
 
 
 @pytest.mark.parametrize("drop", [0.0, 0.3])

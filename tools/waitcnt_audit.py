@@ -14,7 +14,8 @@ MFMA and the back edge, is seen):
   gpr_idx n        s_set_gpr_idx_on: register sets selected by an index, moved through waits (n = 9 fp32 backward)
 
 A kernel is flagged (!!) when: a copy is awaited at vmcnt <= 1 before the next ds_read; or the head of the loop holds vmcnt(0) while the
-loop issues LDS copies; or half or more of the waits of a loop with >= 8 loads sit at vmcnt <= 1; or indexed register sets are used.
+loop issues LDS copies; or half or more of the waits of a loop with >= 8 loads sit at vmcnt <= 1; or the loop holds eight or more waits at
+vmcnt <= 1 whatever their share (round 6: k_propagate_fwd_hl<4,16,true>, 35 of 114, went unflagged); or indexed register sets are used.
 Runs here, no GPU needed.
 
   python tools/waitcnt_audit.py [-v] [file.hip ...]        # default: all of recon_amd/csrc;  -v prints each flagged loop's skeleton
@@ -103,7 +104,7 @@ def audit(body):
     if span:
         dma0 = (dma0 + 1) // 2                                          # the wrapped scan saw every copy twice
     low = sum(w <= 1 for w in waits)
-    flag = dma0 > 0 or (copies > 0 and 0 in head) or (loads >= 8 and waits and low * 2 > len(waits)) or idx > 0
+    flag = dma0 > 0 or (copies > 0 and 0 in head) or (loads >= 8 and waits and low * 2 > len(waits)) or idx > 0 or low >= 8
     return dict(mfma=len(mf), loop_mfma=sum(l.startswith("v_mfma") for l in loop), loads=loads, copies=copies, waits=dict(sorted(Counter(waits).items())),
                 head=head, dma0=dma0, branches=branches, idx=idx, flag=flag, loop=loop)
 
