@@ -845,6 +845,31 @@ def test_rows_with_edges_compacted_vs_oracle_and_uncompacted(N, F_, R, D, H, con
         close(rest[1], g_ee, atol=1e-4, what="g_edge_embed")
 
 
+@pytest.mark.parametrize("N,E,live_frac", [(5000, 40000, 0.3), (5000, 40000, 0.9), (20000, 3000, 0.05), (300, 9000, 0.6), (70000, 150000, 0.2)])
+def test_rows_with_edges_are_counted_and_listed(N, E, live_frac):
+    """recon_graph.n_rows / row_node / rowptr_rows / node_row against numpy on both builds (the single-launch build up to 8 192 edges, the sort
+    chain beyond): the rows are listed when at most ROWS_COMPACT_MAX of the nodes have in-edges, else every node stays a row."""
+    from recon_amd import graph as graph_mod
+    rs = np.random.RandomState(N + E)
+    live = np.sort(rs.choice(N, size=max(1, int(live_frac * N)), replace=False))
+    dst = live[rs.randint(0, live.size, size=E)]
+    edge = torch.from_numpy(np.stack([dst, rs.randint(0, N, size=E)])).long()
+    graph_mod.clear_graph_cache()
+    g = graph_mod.prepare_graph(edge.to(dev()), None, N)
+    have = np.unique(dst)
+    if have.size <= graph_mod.ROWS_COMPACT_MAX * N:
+        assert g.n_rows == have.size
+        rows = g._rows.cpu().numpy()
+        assert np.array_equal(rows[:have.size], have)
+        deg = np.bincount(dst, minlength=N)
+        assert np.array_equal(rows[have.size:2 * have.size + 1], np.concatenate([[0], np.cumsum(deg[have])]))
+        node_row = np.full(N, -1); node_row[have] = np.arange(have.size)
+        assert np.array_equal(rows[2 * have.size + 1:], node_row)
+    else:
+        assert g.n_rows == 0
+    graph_mod.clear_graph_cache()
+
+
 @pytest.mark.parametrize("path", ["atp", "proj"])
 def test_keep_factors_taken_as_they_lie(path, monkeypatch):
     """gat_heads(keep_iid=True): H E independent dropout factors are read by the kernels in the order they lie (CSR-slot order, [E,H] for
