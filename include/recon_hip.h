@@ -711,6 +711,12 @@ int recon_sgemm_hx2_tn_presplit(int32_t M, int32_t N, int32_t K, float* C, int32
 int recon_transe_margin_fwd(const float* entity, const float* relation, const int64_t* triples, int64_t n_pos, int32_t reps, int32_t D,
                             float margin, float* terms, float* loss, int64_t* ent_key, int64_t* rel_key, uint32_t* counter,
                             recon_stream_t stream);
+/* recon_transe_margin_fwd with ONE key tensor for both tables: keys int64 [2][6 P] (P = n_pos * reps) — the four entity ids of pair j at
+ * [q P + j], q < 4, its two relation ids PLUS n_entities at [4 P + q P + j], q < 2 (second row: a copy).  The backward's gradient rows, written
+ * as one [6 P, D] block (g_ent_rows = block, g_rel_rows = block + 4 P D), are then summed into a [n_entities + n_relations, D] table by ONE
+ * destination-only graph build and ONE recon_spmm_rowsum_fwd instead of two of each. */
+int recon_transe_margin_fwd_keys(const float* entity, const float* relation, const int64_t* triples, int64_t n_pos, int32_t reps, int32_t D,
+                                 float margin, float* terms, float* loss, int64_t* keys, int64_t n_entities, recon_stream_t stream);
 int recon_transe_margin_bwd(const float* entity, const float* relation, const int64_t* triples, int64_t n_pos, int32_t reps, int32_t D,
                             const float* terms, const float* g_loss, float* g_ent_rows, float* g_rel_rows, recon_stream_t stream);
 

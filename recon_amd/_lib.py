@@ -229,6 +229,7 @@ SYMBOLS = [
     ("recon_sgemm_bx3_tn", C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32,
                                      C.c_void_p, C.c_void_p]),
     ("recon_transe_margin_fwd", C.c_int, [c_f32p, c_f32p, c_i64p, C.c_int64, C.c_int32, C.c_int32, C.c_float, c_f32p, c_f32p, c_i64p, c_i64p, C.c_void_p, C.c_void_p]),
+    ("recon_transe_margin_fwd_keys", C.c_int, [c_f32p, c_f32p, c_i64p, C.c_int64, C.c_int32, C.c_int32, C.c_float, c_f32p, c_f32p, c_i64p, C.c_int64, C.c_void_p]),
     ("recon_transe_margin_bwd", C.c_int, [c_f32p, c_f32p, c_i64p, C.c_int64, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     ("recon_kg_nhop_lds_bytes", C.c_size_t, [C.c_int64]),
     ("recon_kg_adj_count", C.c_int, [C.POINTER(ReconKG), c_i64p, C.c_int32, c_i64p, C.c_void_p, C.c_void_p, c_i64p, c_i64p, c_i64p, c_i64p, C.c_void_p, C.c_void_p]),

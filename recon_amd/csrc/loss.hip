@@ -45,7 +45,9 @@ __device__ __forceinline__ float row_l1(const TransE& p, int64_t t, int lane, fl
 }
 
 __global__ void __launch_bounds__(256) k_transe_margin_fwd(const TransE p, float* __restrict__ terms, int64_t* __restrict__ ent_key,
-                                                            int64_t* __restrict__ rel_key, int32_t* __restrict__ nan_word) {
+                                                            int64_t* __restrict__ rel_key, int32_t* __restrict__ nan_word, int64_t key_ld, int64_t rel_off) {
+    // key_ld: row stride of the key tensors (0: each its own, 4 P / 2 P); rel_off: added to the relation keys — one [2][6 P] tensor over both
+    // tables (entity rows first, relation rows from rel_off): ONE sort and ONE segment sum for both table gradients (recon_transe_margin_fwd_keys)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t j = static_cast<int64_t>(blockIdx.x) * 4 + w;
     float sg[8];
@@ -61,12 +63,12 @@ __global__ void __launch_bounds__(256) k_transe_margin_fwd(const TransE p, float
             if (ent_key) {                                          // both rows of the [2][4 P] key tensor (row 1 is ignored by the row sum)
                 const int64_t k[4] = {p.tri[3 * tp], p.tri[3 * tp + 2], p.tri[3 * tn], p.tri[3 * tn + 2]};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { ent_key[q * P + j] = k[q]; ent_key[4 * P + q * P + j] = k[q]; }
+                for (int q = 0; q < 4; ++q) { ent_key[q * P + j] = k[q]; ent_key[(key_ld ? key_ld : 4 * P) + q * P + j] = k[q]; }
             }
             if (rel_key) {
                 const int64_t k[2] = {p.tri[3 * tp + 1], p.tri[3 * tn + 1]};
 #pragma unroll
-                for (int q = 0; q < 2; ++q) { rel_key[q * P + j] = k[q]; rel_key[2 * P + q * P + j] = k[q]; }
+                for (int q = 0; q < 2; ++q) { rel_key[q * P + j] = k[q] + rel_off; rel_key[(key_ld ? key_ld : 2 * P) + q * P + j] = k[q] + rel_off; }
             }
         }
     }
@@ -146,7 +148,20 @@ extern "C" int recon_transe_margin_fwd(const float* entity, const float* relatio
     if (p.pairs > (1LL << 31) - 4) return RECON_ERR_UNSUPPORTED;
     (void)counter;
     hipLaunchKernelGGL(recon::k_transe_margin_fwd, dim3(static_cast<unsigned>(ceil_div64(p.pairs, 4))), dim3(256), 0, as_stream(stream), p, terms, ent_key, rel_key,
-                       recon::nan_flag());
+                       recon::nan_flag(), static_cast<int64_t>(0), static_cast<int64_t>(0));
+    hipLaunchKernelGGL(recon::k_transe_mean, dim3(1), dim3(256), 0, as_stream(stream), terms, p.pairs, loss);
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+extern "C" int recon_transe_margin_fwd_keys(const float* entity, const float* relation, const int64_t* triples, int64_t n_pos, int32_t reps, int32_t D,
+                                            float margin, float* terms, float* loss, int64_t* keys, int64_t n_entities, recon_stream_t stream) {
+    recon::TransE p;
+    if (n_pos == 0 && reps > 0 && D > 0) return RECON_ERR_INVALID;
+    if (!recon::fill(&p, entity, relation, triples, n_pos, reps, D, margin) || !terms || !loss || !keys || n_entities <= 0) return RECON_ERR_INVALID;
+    if (p.pairs > ((1LL << 31) - 4) / 6) return RECON_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(recon::k_transe_margin_fwd, dim3(static_cast<unsigned>(ceil_div64(p.pairs, 4))), dim3(256), 0, as_stream(stream), p, terms, keys,
+                       keys + 4 * p.pairs, recon::nan_flag(), 6 * p.pairs, n_entities);
     hipLaunchKernelGGL(recon::k_transe_mean, dim3(1), dim3(256), 0, as_stream(stream), terms, p.pairs, loss);
     RECON_CHECK_LAUNCH();
     return RECON_OK;

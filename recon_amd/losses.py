@@ -30,33 +30,50 @@ class _TransEMarginLoss(torch.autograd.Function):
         ent, rel, tri = entity_embed.contiguous(), relation_embed.contiguous(), train_indices.contiguous()
         D, P = ent.shape[1], n_pos * reps
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        both = ctx.needs_input_grad[0] and ctx.needs_input_grad[1]      # (the usual case) one key tensor over both tables: one sort, one segment sum
         terms = torch.empty(P, dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        ek = torch.empty(2, 4 * P, dtype=torch.int64, device=dev) if need else None
-        rk = torch.empty(2, 2 * P, dtype=torch.int64, device=dev) if need else None
+        keys = torch.empty(2, 6 * P, dtype=torch.int64, device=dev) if both else None
+        ek = torch.empty(2, 4 * P, dtype=torch.int64, device=dev) if (need and not both) else None
+        rk = torch.empty(2, 2 * P, dtype=torch.int64, device=dev) if (need and not both) else None
         with _lib.on_device(dev):
-            _lib.check(_lib.lib().recon_transe_margin_fwd(ent.data_ptr(), rel.data_ptr(), tri.data_ptr(), n_pos, reps, D, float(margin), terms.data_ptr(),
-                                                          loss.data_ptr(), _lib.ptr(ek), _lib.ptr(rk), _counter(dev).data_ptr(), _lib.current_stream()),
-                       "recon_transe_margin_fwd")
+            if both:
+                _lib.check(_lib.lib().recon_transe_margin_fwd_keys(ent.data_ptr(), rel.data_ptr(), tri.data_ptr(), n_pos, reps, D, float(margin), terms.data_ptr(),
+                                                                   loss.data_ptr(), keys.data_ptr(), ent.shape[0], _lib.current_stream()),
+                           "recon_transe_margin_fwd_keys")
+            else:
+                _lib.check(_lib.lib().recon_transe_margin_fwd(ent.data_ptr(), rel.data_ptr(), tri.data_ptr(), n_pos, reps, D, float(margin), terms.data_ptr(),
+                                                              loss.data_ptr(), _lib.ptr(ek), _lib.ptr(rk), _counter(dev).data_ptr(), _lib.current_stream()),
+                           "recon_transe_margin_fwd")
         if need:
-            trust(ek, bound=ent.shape[0])                                # copies of ids that were validated (or vouched for) below
-            trust(rk, bound=rel.shape[0])
-            ctx.save_for_backward(ent, rel, tri, terms, ek, rk)
-            ctx.meta = (n_pos, reps)
+            if both:
+                trust(keys, bound=ent.shape[0] + rel.shape[0])           # copies of ids that were validated (or vouched for) below
+                ctx.save_for_backward(ent, rel, tri, terms, keys)
+            else:
+                trust(ek, bound=ent.shape[0])
+                trust(rk, bound=rel.shape[0])
+                ctx.save_for_backward(ent, rel, tri, terms, ek, rk)
+            ctx.meta = (n_pos, reps, both)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         from .gat_layers import _rowsum_keyed
-        ent, rel, tri, terms, ek, rk = ctx.saved_tensors
-        n_pos, reps = ctx.meta
+        n_pos, reps, both = ctx.meta
+        if both:
+            ent, rel, tri, terms, keys = ctx.saved_tensors
+        else:
+            ent, rel, tri, terms, ek, rk = ctx.saved_tensors
         dev, D, P = ent.device, ent.shape[1], n_pos * reps
         g = g.contiguous().to(torch.float32)
-        ge = torch.empty(4 * P, D, dtype=torch.float32, device=dev)
-        gr = torch.empty(2 * P, D, dtype=torch.float32, device=dev)
+        rows = torch.empty(6 * P, D, dtype=torch.float32, device=dev)       # the entity rows' gradients [4 P, D], then the relation rows' [2 P, D]
+        ge, gr = rows[:4 * P], rows[4 * P:]
         with _lib.on_device(dev):
             _lib.check(_lib.lib().recon_transe_margin_bwd(ent.data_ptr(), rel.data_ptr(), tri.data_ptr(), n_pos, reps, D, terms.data_ptr(), g.data_ptr(),
                                                           ge.data_ptr(), gr.data_ptr(), _lib.current_stream()), "recon_transe_margin_bwd")
+        if both:
+            g_all = _rowsum_keyed(rows, keys, ent.shape[0] + rel.shape[0])
+            return g_all[:ent.shape[0]], g_all[ent.shape[0]:], None, None, None, None
         g_ent = _rowsum_keyed(ge, ek, ent.shape[0]) if ctx.needs_input_grad[0] else None
         g_rel = _rowsum_keyed(gr, rk, rel.shape[0]) if ctx.needs_input_grad[1] else None
         return g_ent, g_rel, None, None, None, None
