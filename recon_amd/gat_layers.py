@@ -227,7 +227,7 @@ def _pair_key(idx2):
         if len(_KEY_CACHE) > 16:
             _KEY_CACHE.clear()
         flat = idx2.t().reshape(1, -1)
-        key = flat.expand(2, -1).contiguous()
+        key = flat.expand(2, -1)                                         # (both rows are the one row: a destination-only graph reads row 0 alone — no copy)
         if trusted(idx2):
             trust(key, bound=trust_bounds(idx2)[0])
         hit = _KEY_CACHE[k] = (key, idx2)
@@ -371,7 +371,7 @@ def _segment_key(index):
     if hit is None:
         if len(_KEY_CACHE) > 16:
             _KEY_CACHE.clear()
-        key = torch.stack((index, index))
+        key = index.reshape(1, -1).expand(2, -1)                       # (a destination-only graph reads row 0 alone: no copy)
         if trusted(index):
             trust(key, bound=trust_bounds(index)[0])
         hit = _KEY_CACHE[k] = (key, index)      # keeps `index` alive: its data_ptr is the key
