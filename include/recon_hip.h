@@ -767,7 +767,12 @@ int recon_edges_prune(const int64_t* edge, const int64_t* type, int64_t E1, cons
  * views of it.  out_type [E1], out_type_nhop [E2][2], pos as above; counts: device int64 [3]. */
 int recon_edges_prune_batch(const int64_t* batch_entities, int32_t B, const int64_t* edge, const int64_t* type, int64_t E1, const int64_t* quads,
                             int64_t E2, int32_t N, float* mask, uint8_t* need, int64_t* out_edge, int64_t* out_type, int64_t* out_type_nhop,
-                            int64_t* pos, int64_t* counts, recon_stream_t stream);
+                            int64_t* pos, int64_t* counts, int64_t* ext_index /* optional, E1 + E2 */, int64_t ext_base, recon_stream_t stream);
+/* ext_index: the row of the layers' edge-embedding table each surviving edge reads (GAT/layers.py:126-127 with `relation_embed[edge_type]` read in
+ * place): a 1-hop edge its relation id, the j-th surviving n-hop edge row ext_base + j (ext_base = rows of the relation table). */
+/* CSR-slot order of an index tensor in one launch: out32[k] = out64[k] = index[eid[k]] (recon_gat_atp_args.ee_index and the segment key of the
+ * table gradient). */
+int recon_slot_index(const int64_t* index, const int32_t* eid, int32_t E, int32_t* out32, int64_t* out64, recon_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * N1  the tail of SpKBGATModified (GAT/models.py:167-180) and the row normalisation of the entity table (:160):

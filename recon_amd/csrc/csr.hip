@@ -508,6 +508,15 @@ __global__ void __launch_bounds__(1024) k_graph_build_small(const int64_t* __res
     }
 }
 
+
+// out32[k] = out64[k] = index[eid[k]]: an index tensor in CSR-slot order, both widths in one launch (was an index, a cast and eid's own cast)
+__global__ void k_slot_index(const int64_t* __restrict__ index, const int32_t* __restrict__ eid, int32_t E, int32_t* __restrict__ out32, int64_t* __restrict__ out64) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= E) return;
+    const int64_t v = index[eid[k]];
+    out32[k] = static_cast<int32_t>(v);
+    out64[k] = v;
+}
 }  // namespace
 
 extern "C" int recon_graph_hubs_count(const recon_graph* g, int32_t chunk, void* workspace, int32_t* counts, recon_stream_t stream) {
@@ -679,6 +688,14 @@ static int graph_build(const int64_t* edge_dst, const int64_t* edge_src, recon_g
     if (rc != RECON_OK) return rc;
     if (chunk > 0) hipLaunchKernelGGL(k_rowptr_lower_bound_count, nb, dim3(256), 0, st, ks, E, N, g->rowptr_src, g->rowptr_dst, chunk, graph_ws_counts(workspace, N, E), bad);
     else hipLaunchKernelGGL(k_rowptr_lower_bound, nb, dim3(256), 0, st, ks, E, N, g->rowptr_src);
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+extern "C" int recon_slot_index(const int64_t* index, const int32_t* eid, int32_t E, int32_t* out32, int64_t* out64, recon_stream_t stream) {
+    if (E < 0 || (E > 0 && (!index || !eid || !out32 || !out64))) return RECON_ERR_INVALID;
+    if (E == 0) return RECON_OK;
+    hipLaunchKernelGGL(k_slot_index, dim3(static_cast<unsigned>(ceil_div64(E, 256))), dim3(256), 0, as_stream(stream), index, eid, E, out32, out64);
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }

@@ -404,7 +404,10 @@ __global__ void __launch_bounds__(1024) k_edges_prune(const int64_t* __restrict_
                                                       const float* __restrict__ mask_in, const int64_t* __restrict__ batch, int32_t B,
                                                       float* __restrict__ mask_out, int32_t N, uint8_t* __restrict__ need,
                                                       int64_t* __restrict__ out_edge, int64_t* __restrict__ out_type, int64_t* __restrict__ out_edge_nhop,
-                                                      int64_t* __restrict__ out_type_nhop, int64_t* __restrict__ pos, int64_t* __restrict__ counts) {
+                                                      int64_t* __restrict__ out_type_nhop, int64_t* __restrict__ pos, int64_t* __restrict__ counts,
+                                                      int64_t* __restrict__ ext_index, int64_t ext_base) {
+    // ext_index (BATCH, optional): the row of the layers' edge-embedding TABLE each surviving edge reads — a 1-hop edge its relation id, the j-th
+    // surviving n-hop edge row ext_base + j (the n-hop rows are appended to the relation table, gat_layers.cat_edge_embed) — as one [n1 + n2] list
     // The host waits for the counts (the output sizes): this launch is on the iteration's critical path.  Every pass asks for sixteen
     // edges per thread at once (one edge in flight per thread: 102 us for a 30 000-edge batch; this form: 65 us).  What is left is ONE compute
     // unit's rate of scattered accesses — ~4 per edge (the row's mask word, the source's flag, the row's flag, the survivor's words) —, not a
@@ -462,6 +465,7 @@ __global__ void __launch_bounds__(1024) k_edges_prune(const int64_t* __restrict_
     // ordered write: a thread owns U CONSECUTIVE edges of a 16 384-edge tile; positions = kept in the tiles before + in the waves before + in the
     // lanes before (a wave scan of the threads' counts) + among the thread's own
     int par = 0;
+    int64_t ext_off = 0;                                                 // where the n-hop survivors' entries of ext_index start: the 1-hop survivors' count
     auto write = [&](int list, int64_t E, int64_t* __restrict__ oe, int64_t row_stride, int64_t* __restrict__ ot, int64_t pos_off) -> int64_t {
         int64_t run = 0;
         for (int64_t b = 0; b < E; b += 1024 * U, par ^= 1) {
@@ -490,8 +494,8 @@ __global__ void __launch_bounds__(1024) k_edges_prune(const int64_t* __restrict_
                 if ((kmask >> u) & 1) {                                  // (the survivors are few: their sources and types are fetched here)
                     const int64_t i = i0 + u;
                     oe[o] = dst_of(list, i); oe[row_stride + o] = src_of(list, i);
-                    if (list == 0) ot[o] = type[i];
-                    else if (BATCH) { ot[2 * o] = edge_nhop[4 * i + 1]; ot[2 * o + 1] = edge_nhop[4 * i + 2]; }
+                    if (list == 0) { ot[o] = type[i]; if (BATCH && ext_index) ext_index[o] = type[i]; }
+                    else if (BATCH) { ot[2 * o] = edge_nhop[4 * i + 1]; ot[2 * o + 1] = edge_nhop[4 * i + 2]; if (ext_index) ext_index[ext_off + o] = ext_base + o; }
                     else { ot[2 * o] = type_nhop[2 * i]; ot[2 * o + 1] = type_nhop[2 * i + 1]; }
                     if (pos) pos[pos_off + o] = pos_off + i;
                     ++o;
@@ -502,6 +506,7 @@ __global__ void __launch_bounds__(1024) k_edges_prune(const int64_t* __restrict_
         return run;
     };
     const int64_t n1 = write(0, E1, out_edge, BATCH ? E1 + E2 : E1, out_type, 0);
+    ext_off = n1;
     __syncthreads();
     // (the n-hop positions follow the 1-hop ones at E1: the caller cuts the two runs out of pos with the counts)
     const int64_t n2 = write(1, E2, BATCH ? out_edge + n1 : out_edge_nhop, BATCH ? E1 + E2 : E2, out_type_nhop, E1);
@@ -586,20 +591,20 @@ extern "C" int recon_edges_prune(const int64_t* edge, const int64_t* type, int64
     if (E1 > 0 && (!edge || !type || !out_edge || !out_type)) return RECON_ERR_INVALID;
     if (E2 > 0 && (!edge_nhop || !type_nhop || !out_edge_nhop || !out_type_nhop)) return RECON_ERR_INVALID;
     hipLaunchKernelGGL(recon::k_edges_prune<false>, dim3(1), dim3(1024), 0, as_stream(stream), edge, type, E1, edge_nhop, type_nhop, E2, mask, nullptr, 0, nullptr, N,
-                       need, out_edge, out_type, out_edge_nhop, out_type_nhop, pos, counts);
+                       need, out_edge, out_type, out_edge_nhop, out_type_nhop, pos, counts, nullptr, static_cast<int64_t>(0));
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }
 
 extern "C" int recon_edges_prune_batch(const int64_t* batch_entities, int32_t B, const int64_t* edge, const int64_t* type, int64_t E1, const int64_t* quads,
                                        int64_t E2, int32_t N, float* mask, uint8_t* need, int64_t* out_edge, int64_t* out_type, int64_t* out_type_nhop,
-                                       int64_t* pos, int64_t* counts, recon_stream_t stream) {
+                                       int64_t* pos, int64_t* counts, int64_t* ext_index, int64_t ext_base, recon_stream_t stream) {
     if (B < 0 || E1 < 0 || E2 < 0 || N <= 0 || !mask || !need || !counts || (B > 0 && !batch_entities)) return RECON_ERR_INVALID;
     if (E1 > 0 && (!edge || !type || !out_type)) return RECON_ERR_INVALID;
     if (E2 > 0 && (!quads || !out_type_nhop)) return RECON_ERR_INVALID;
     if (E1 + E2 > 0 && !out_edge) return RECON_ERR_INVALID;
     hipLaunchKernelGGL(recon::k_edges_prune<true>, dim3(1), dim3(1024), 0, as_stream(stream), edge, type, E1, quads, nullptr, E2, nullptr, batch_entities, B, mask, N,
-                       need, out_edge, out_type, nullptr, out_type_nhop, pos, counts);
+                       need, out_edge, out_type, nullptr, out_type_nhop, pos, counts, ext_index, ext_base);
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }

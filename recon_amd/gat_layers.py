@@ -873,6 +873,17 @@ def _extended_index(index, n_rows, n_extra):
     return hit[0]
 
 
+def seed_extended_index(index, n_rows, n_extra, ext):
+    """Hand _extended_index the tensor it would build for (index, n_rows, n_extra) — a producer that writes the list anyway (sampler.prune_batch:
+    the prune kernel knows every surviving edge's table row) saves the arange + cat."""
+    key = (index.data_ptr(), index._version, tuple(index.shape), int(n_rows), int(n_extra))
+    if trusted(index, n_rows):
+        trust(ext, bound=int(n_rows) + int(n_extra))
+    _INDEX_CACHE[key] = (ext, index)
+    while len(_INDEX_CACHE) > 8:
+        _INDEX_CACHE.popitem(last=False)
+
+
 def cat_edge_embed(edge_embed, edge_list_nhop, edge_embed_nhop):
     """GAT/layers.py:126-127.  Returns (rows, ee_index): ee_index is None for a materialised [E,R] tensor; for IndexedRows the rows are
     the table (with the n-hop edges' rows appended) and ee_index [E] says which row each edge uses."""

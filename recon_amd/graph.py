@@ -244,10 +244,15 @@ class GraphCSR:
                 lo, hi = torch.aminmax(index)
                 if int(lo) < 0 or int(hi) >= n_rows:
                     raise IndexError("recon_amd: row index out of range: [%d, %d] into a table of %d rows" % (int(lo), int(hi), n_rows))
-            slot_long = index[self.eid_long].contiguous()
+            idx = index.contiguous()
+            slot32 = torch.empty(self.E, dtype=torch.int32, device=self.device)
+            slot_long = torch.empty(self.E, dtype=torch.int64, device=self.device)
+            with _lib.on_device(self.device):                                # index[eid] in both widths, one launch (was an index, a cast and eid's own cast)
+                _lib.check(_lib.lib().recon_slot_index(idx.data_ptr(), self.eid.data_ptr(), self.E, slot32.data_ptr(), slot_long.data_ptr(), _lib.current_stream()),
+                           "recon_slot_index")
             if trusted(index, n_rows):
                 trust(slot_long, bound=trust_bounds(index)[0])                # a permutation of trusted values
-            hit = (slot_long.to(torch.int32), slot_long, index)              # `index` pins data_ptr identity while cached
+            hit = (slot32, slot_long, index)                                 # `index` pins data_ptr identity while cached
             if len(self._slot_idx) >= 4:
                 self._slot_idx.pop(next(iter(self._slot_idx)))
             self._slot_idx[key] = hit

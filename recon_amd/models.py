@@ -247,7 +247,8 @@ class SpKBGATModified(nn.Module):
                 q = quads.to(dev) if quads.shape[0] else quads
                 if quads.shape[0] and trusted(quads):
                     trust(q, bound=trust_bounds(quads)[0], rel_bound=trust_bounds(quads)[1])
-                hit = self._prune_cache = (key, prune_batch(batch_entities, edge_list, edge_type, q, entity_embeddings.shape[0], want_pos=KEEP_PRUNED_POSITIONS),
+                hit = self._prune_cache = (key, prune_batch(batch_entities, edge_list, edge_type, q, entity_embeddings.shape[0], want_pos=KEEP_PRUNED_POSITIONS,
+                                                             table_rows=relation_embeddings.shape[0]),
                                            (edge_list, edge_type, quads, batch_entities))      # the inputs pin their identities
             mask, edge_list, edge_type, edge_list_nhop, edge_type_nhop = hit[1][:5]
             self._pruned_pos = hit[1][5] if KEEP_PRUNED_POSITIONS else None

@@ -152,7 +152,12 @@ def test_prune_edges_vs_numpy(Ne, E1, E2, B, seed):
     be = np.nonzero(mask)[0][rs.permutation(int(mask.sum()))]
     be = np.concatenate([be, be[:3]])                                    # duplicates: the reference takes torch.unique
     quads = np.stack([e2[1], t2[:, 0], t2[:, 1], e2[0]], axis=1) if E2 else np.zeros((0, 4), dtype=np.int64)
-    m2, oe2, ot2, on2, ont2, pos2 = prune_batch(T(be).to(d), T(e1).to(d), T(t1).to(d), T(quads).to(d) if E2 else torch.tensor([], dtype=torch.long), Ne, want_pos=True)
+    m2, oe2, ot2, on2, ont2, pos2 = prune_batch(T(be).to(d), T(e1).to(d), T(t1).to(d), T(quads).to(d) if E2 else torch.tensor([], dtype=torch.long), Ne, want_pos=True,
+                                                table_rows=7)
+    if k2.any():                                                         # the table row of every surviving edge, handed to the layers' extended-index cache
+        from recon_amd.gat_layers import _extended_index
+        ext = _extended_index(ot2, 7, int(k2.sum()))
+        np.testing.assert_array_equal(ext.cpu().numpy(), np.concatenate([t1[k1], 7 + np.arange(int(k2.sum()))]))
     np.testing.assert_array_equal(m2.cpu().numpy(), mask)
     for a_, b_ in ((oe2, oe), (ot2, ot), (pos2, pos)):
         assert torch.equal(a_, b_)
