@@ -673,7 +673,10 @@ __global__ void __launch_bounds__(256 * NS / GPW, 1) k_gcn_b16_stack_fwd(const G
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // copies of steps past the end target this workgroup's LDS
 #ifdef RECON_STAMPS
     stamp[ns_++] = __builtin_readcyclecounter();
-    if (blockIdx.x == 7 && t == 64) { uint64_t* o = reinterpret_cast<uint64_t*>(p.out); for (int i = 0; i < ns_; ++i) o[i] = stamp[i]; o[47] = ns_; }
+#ifndef RECON_STAMP_WAVE
+#define RECON_STAMP_WAVE 1
+#endif
+    if (blockIdx.x == 7 && t == 64 * RECON_STAMP_WAVE) { uint64_t* o = reinterpret_cast<uint64_t*>(p.out); for (int i = 0; i < ns_; ++i) o[i] = stamp[i]; o[47] = ns_; }
 #endif
 }
 
@@ -1248,7 +1251,10 @@ extern "C" int recon_gcn_b16_bwd(const recon_gcn_b16_bwd_args* b, recon_stream_t
 // four column parts per graph, one graph per wave (16 waves); RECON_GCN_STACK_GPW=2: two graphs per wave (8 waves; measured 36 us against 34 at cfg 3a)
 static void launch_stack_fwd(const GcnStackK& k, size_t lds, hipStream_t st) {
     const dim3 grid(static_cast<unsigned>(ceil_div64(k.B, 4)));
-    if (cfg_int(CFG_GCN_STACK_GPW, 1) != 2) {
+    if (cfg_int(CFG_GCN_STACK_GPW, 1) == 5) {                           // experiment: five column parts x two graph slots = ten waves, 80 KiB of fragment reads per K step
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gcn_b16_stack_fwd<5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        hipLaunchKernelGGL((k_gcn_b16_stack_fwd<5, 2>), grid, dim3(640), lds, st, k);
+    } else if (cfg_int(CFG_GCN_STACK_GPW, 1) != 2) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gcn_b16_stack_fwd<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         hipLaunchKernelGGL((k_gcn_b16_stack_fwd<4, 1>), grid, dim3(1024), lds, st, k);
     } else {
