@@ -316,7 +316,13 @@ typedef struct {
     float* g_a_2;               /* [H,D]      or NULL                                                 */
     void* gh_split;             /* recon_gat_atp_bwd_split_bytes() bytes, workspace: bfloat16 term planes of g_h for  *
                                  * the split-precision weight-gradient GEMM; NULL (or fwd.a_split NULL) = fp32 MFMA  */
+    int32_t g_ee_bf16;          /* 1: g_edge_embed points to BFLOAT16 rows [E,R] — the edge pass rounds its fp32 sums once, where it stores  *
+                                 * them (fwd.io_bf16 callers whose edge embeddings take a bfloat16 gradient: 116 MB written as fp32 and    *
+                                 * re-read by a cast at BASELINE.json configs[4]).  Only where recon_gat_atp_bwd_gee_bf16_supported() says 1  */
 } recon_gat_atp_bwd_args;
+/* whether g_ee_bf16 = 1 is available for these widths: fwd.io_bf16 shapes whose heads are walked in ONE group per wave (a second head group
+ * adds to the rows the first one stored: that sum has to stay fp32) */
+int recon_gat_atp_bwd_gee_bf16_supported(int32_t F, int32_t R, int32_t D, int32_t H);
 
 size_t recon_gat_atp_bwd_split_bytes(int32_t N, int32_t D, int32_t H);
 

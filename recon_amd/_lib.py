@@ -58,7 +58,7 @@ class GatAtpBwdArgs(C.Structure):
     _fields_ = [("fwd", GatAtpArgs), ("grad_out", c_f32p), ("ld_gout", C.c_int32), ("g_h", c_f32p), ("g_V", c_f32p),
                 ("g_sigma", c_f32p), ("Gxs", c_f32p), ("gxd", c_f32p), ("Gs", c_f32p), ("g_u", c_f32p), ("q", c_f32p),
                 ("partial", c_f32p), ("partial2", c_f32p), ("g_x", c_f32p), ("g_edge_embed", c_f32p), ("g_a", c_f32p), ("g_a_2", c_f32p),
-                ("gh_split", C.c_void_p)]
+                ("gh_split", C.c_void_p), ("g_ee_bf16", C.c_int32)]
 
 
 class PropArgs(C.Structure):
@@ -152,6 +152,7 @@ SYMBOLS = [
     ("recon_graph_rows_compact", C.c_int, [C.POINTER(ReconGraph), C.c_void_p]),
     ("recon_edges_prune_batch", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    ("recon_gat_atp_bwd_gee_bf16_supported", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     ("recon_slot_index", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("recon_edges_prune", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1017,6 +1017,7 @@ struct AtpBwdK {
     const int4* piece;
     float* hubG;
     int32_t gee_by_slot;        // edge_embed is a table read through `eid` (recon_gat_atp_args.ee_index): g_ee rows go by CSR slot
+    int32_t gee_b16;            // (B16 instances, one head group per wave, rows by edge id) g_ee points to bfloat16 rows: rounded once, at the store
     int32_t persist;            // k_gat_atp_bwd: 1 = persistent waves over XCD-contiguous node ranges (graphs without hub pieces), 0 = one piece / node per wave
     // row compaction (recon_graph.n_rows): N is the number of ROWS — rowptr, the pieces, g_V, Z, Zk, q, gxd and Gs_dst go by row — and row r
     // belongs to node row_node[r] (x is a node table); NULL: rows are nodes
@@ -1437,7 +1438,9 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                 }
                 // g_edge_embed rows go by slot (a table read through an index: the caller sums them per table row) or by edge id
                 const bool ge_edge = p.g_ee && !p.gee_by_slot;       // wave-uniform
-                const auto rGee = ge_edge ? K2_RSRC(p.g_ee + static_cast<int64_t>(e) * R, Rb) : rGe;
+                const bool ge16 = B16 && p.gee_b16 && ge_edge;       // wave-uniform: bfloat16 rows of g_edge_embed (2 R bytes each)
+                const auto rGee = ge16 ? K2_RSRC(reinterpret_cast<uint16_t*>(p.g_ee) + static_cast<int64_t>(e) * R, Rb / 2)
+                                       : (ge_edge ? K2_RSRC(p.g_ee + static_cast<int64_t>(e) * R, Rb) : rGe);
                 const uint32_t sox = static_cast<uint32_t>(j) * Fb, soe = ge_edge ? 0u : static_cast<uint32_t>(j) * Rb;
 #pragma unroll
                 for (int r = 0; r < KR; ++r) {
@@ -1452,6 +1455,20 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                         for (int v = 0; v < VEC; ++v) { ox[v] += o1[v]; orr[v] += o2[v]; }
                     }
                     buf_store_f32<VEC>(ox, rGx, voF[r], sox);       // lanes past F / R (and every lane without g_edge_embed): dropped by the range check
+                    if constexpr (B16) {
+                        if (ge16) {                                  // (one head group per wave here: nothing was added above) round to nearest even, 2 bytes per value
+                            uint32_t w2[VEC / 2];
+#pragma unroll
+                            for (int v = 0; v < VEC; v += 2) {
+                                const __bf16 b0 = static_cast<__bf16>(orr[v]), b1 = static_cast<__bf16>(orr[v + 1]);
+                                w2[v / 2] = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, b0)) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, b1)) << 16);
+                            }
+                            const uint32_t vo16 = voR[r] == kK2Oob ? kK2Oob : voR[r] / 2;
+                            if constexpr (VEC == 4) __builtin_amdgcn_raw_buffer_store_b64(k2_u32x2{w2[0], w2[1]}, rGee, vo16, 0, 0);
+                            else __builtin_amdgcn_raw_buffer_store_b32(w2[0], rGee, vo16, 0, 0);
+                            continue;
+                        }
+                    }
                     buf_store_f32<VEC>(orr, rGee, voR[r], soe);
                 }
         };
@@ -2233,6 +2250,12 @@ extern "C" int recon_gat_atp_fwd(const recon_graph* g, const recon_gat_atp_args*
     return recon_gat_atp_project(g, a, stream);
 }
 
+extern "C" int recon_gat_atp_bwd_gee_bf16_supported(int32_t F, int32_t R, int32_t D, int32_t H) {
+    recon::AtpShape s;
+    if (!recon_gat_atp_bf16_io_supported(F, R, D, H) || !recon::atp_shape(F, R, H, &s)) return 0;
+    return (s.ht >= H && s.vec == 4) ? 1 : 0;                        // one head group per wave: no read-modify-write of the stored rows
+}
+
 extern "C" size_t recon_gat_atp_bwd_split_bytes(int32_t N, int32_t D, int32_t H) {
     if (N <= 0 || D <= 0 || H <= 0) return 256;
     return align_up(static_cast<size_t>(3) * N * bx3_kp(H * D) * 2, 256);
@@ -2343,6 +2366,8 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         AtpBwdK p;
         p.rowptr = rw.rowptr; p.row_node = rw.row_node; p.src = g->src; p.eid = a->ee_index ? a->ee_index : g->eid;
         p.gee_by_slot = a->ee_index ? 1 : 0;
+        p.gee_b16 = b->g_ee_bf16 ? 1 : 0;
+        if (b->g_ee_bf16 && !(a->io_bf16 && !a->ee_index && recon_gat_atp_bwd_gee_bf16_supported(F, R, D, H))) return RECON_ERR_UNSUPPORTED;
         p.x = a->x; p.ee = a->edge_embed; p.keep = a->keep; p.sigma = a->sigma; p.Z = a->Z; p.Zk = a->Zk;
         p.q = b->q; p.gV = b->g_V; p.u = a->u;
         p.gsigma = b->g_sigma; p.Gs_dst = b->Gs; p.Gxs = b->Gxs; p.gxd = b->gxd; p.g_ee = b->g_edge_embed;

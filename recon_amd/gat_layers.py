@@ -525,6 +525,15 @@ def _view_f32(buf, ptr, n):
 
 
 _SIZE_CACHE = {}
+_GEE16 = {}
+
+
+def _gee_bf16_ok(F_, R, D, H):
+    k = (F_, R, D, H)
+    v = _GEE16.get(k)
+    if v is None:
+        v = _GEE16[k] = _lib.lib().recon_gat_atp_bwd_gee_bf16_supported(F_, R, D, H) == 1
+    return v
 
 
 def _lib_sizes(N, E, F_, R, D, H):
@@ -660,12 +669,15 @@ class _GATHeadsATPFunction(torch.autograd.Function):
             4 * N * H * D if ((ctx.concat or graph.n_rows) and aux is None) else None, 4 * N * H * W, 4 * E * H, 4 * E * F_, 4 * N * F_, 4 * N * 2 * H,
             4 * H * W, 4 * N * H, partial_b, partial2_b, ghs_b if use_gh_planes else None))
         g_x = torch.empty(N, F_, **f32) if nx else None
-        g_ee = torch.empty(E, R, **f32) if ne else None
+        # bfloat16 edge embeddings take a bfloat16 gradient: where one head group per wave walks all heads the edge pass rounds its sums as it
+        # stores them (one E x R tensor written in 2-byte values, not an fp32 one written, re-read and cast: 116 + 58 MB at configs[4])
+        gee16 = bool(ne and io16 and ctx.idx_slot is None and _gee_bf16_ok(F_, R, D, H))
+        g_ee = (torch.empty(E, R, dtype=torch.bfloat16, device=dev) if gee16 else torch.empty(E, R, **f32)) if ne else None
         g_a, g_a2 = _weight_grad_tensors(a, H, D, W, f32) if want_a else (None, None)
         fwd = _atp_args(graph, x, ee, a, a2, keep, u, c_node, c_rel, V, sigma, Z, Zk, out, ctx.alpha, ctx.concat, a_split, aux,
                         ctx.keep_max, ctx.idx_slot, io16)
         args = _lib.GatAtpBwdArgs(fwd, grad_out.data_ptr(), grad_out.shape[1], g_h, g_V, g_sigma, Gxs, gxd, Gs, g_u, q, partial, partial2,
-                                  _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2), gh_split)
+                                  _lib.ptr(g_x), _lib.ptr(g_ee), _lib.ptr(g_a), _lib.ptr(g_a2), gh_split, 1 if gee16 else 0)
         gstruct, _hub_keep = graph.call_struct(F_, R, H)
         sync = _WEIGHT_GRAD_SYNC if g_a is not None else None
         with _on_device(dev):
@@ -704,7 +716,7 @@ class _GATHeadsATPFunction(torch.autograd.Function):
             g_ee = _rowsum_by_index(g_ee, graph.slot_index_long(ctx.idx_slot), ee.shape[0])
         if io16:
             g_x = g_x.to(torch.bfloat16) if g_x is not None else None
-            g_ee = g_ee.to(torch.bfloat16) if g_ee is not None else None
+            g_ee = g_ee.to(torch.bfloat16) if (g_ee is not None and g_ee.dtype != torch.bfloat16) else g_ee
         return g_x, g_ee, (g_a if na else None), (g_a2 if na2 else None), None, None, None, None, None, None, None
 
 
