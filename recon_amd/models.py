@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from . import _lib
 from .gat_layers import SpGraphAttentionLayer, gat_heads, cat_edge_embed, gather_rows, gather_rows_pair, small_mm, IndexedRows, set_weight_grad_destination
 from .graph import prepare_graph, trust, trusted, trust_bounds
-from .sampler import prune_batch
+from .sampler import prune_batch_launch
 
 # SpKBGATModified: drop the edges into rows that its mask discards before the layers run (sampler.prune_edges); 0 = evaluate every row, as
 # the reference does (tests compare both)
@@ -243,25 +243,30 @@ class SpKBGATModified(nn.Module):
             ver = lambda t: (t.data_ptr(), t._version, tuple(t.shape)) if torch.is_tensor(t) else None
             key = (ver(edge_list), ver(edge_type), ver(quads), ver(batch_entities), str(dev), KEEP_PRUNED_POSITIONS)
             hit = getattr(self, "_prune_cache", None)
+            ew = None
             if hit is None or hit[0] != key:
                 q = quads.to(dev) if quads.shape[0] else quads
                 if quads.shape[0] and trusted(quads):
                     trust(q, bound=trust_bounds(quads)[0], rel_bound=trust_bounds(quads)[1])
-                hit = self._prune_cache = (key, prune_batch(batch_entities, edge_list, edge_type, q, entity_embeddings.shape[0], want_pos=KEEP_PRUNED_POSITIONS,
-                                                             table_rows=relation_embeddings.shape[0]),
-                                           (edge_list, edge_type, quads, batch_entities))      # the inputs pin their identities
+                finish = prune_batch_launch(batch_entities, edge_list, edge_type, q, entity_embeddings.shape[0], want_pos=KEEP_PRUNED_POSITIONS,
+                                            table_rows=relation_embeddings.shape[0])
+                # the host waits for the prune kernel's counts: the skip connection's product (:177) does not depend on them and goes out first
+                ew = small_mm(entity_embeddings, self.W_entities)
+                hit = self._prune_cache = (key, finish(), (edge_list, edge_type, quads, batch_entities))      # the inputs pin their identities
             mask, edge_list, edge_type, edge_list_nhop, edge_type_nhop = hit[1][:5]
             self._pruned_pos = hit[1][5] if KEEP_PRUNED_POSITIONS else None
             # the layers' per-edge dropout factors cannot be the reference's edge for edge on a pruned list: drawn in one call per layer
             self.sparse_gat_1.iid_keep_draws = self.sparse_gat_1.out_att.iid_keep_draws = True
         else:
+            ew = None
             edge_list_nhop, edge_type_nhop = self._nhop(train_indices_nhop, dev)
             mask = torch.zeros(entity_embeddings.shape[0], device=dev)
             mask[batch_entities.to(dev)] = 1.0           # the reference takes torch.unique first (:167-170): same mask, but a host round trip
         # :156 `edge_embed = self.relation_embeddings[edge_type]`: None lets SpGAT read the relation table in place (IndexedRows)
         out_entity, out_relation = self.sparse_gat_1(Corpus_, entity_embeddings, relation_embeddings, edge_list, edge_type,
                                                      None, edge_list_nhop, edge_type_nhop)
-        ew = small_mm(entity_embeddings, self.W_entities)
+        if ew is None:
+            ew = small_mm(entity_embeddings, self.W_entities)
         if ew.dtype == torch.float32 and out_entity.dtype == torch.float32:
             return _SkipMaskNormalize.apply(ew, out_entity, mask), out_relation, mask      # :177-180 in one launch each way
         out_entity = ew + mask.unsqueeze(-1) * out_entity
