@@ -1094,7 +1094,9 @@ constexpr int kK2Ring = 2, kK2WavesPerSimd = 3;
 // edge; missing edges copy nothing through a zero-sized descriptor), so "all but the 5 + 7 (RING - 1) youngest" is exactly "this slot's
 // copies have landed".  Eight registers less than the register ring.
 constexpr int kK2LdsRingBytes = 8192;                                  // per wave: 4 slots of 2 x 1 KiB
-template <int VEC, int KR, int HT, bool B16 = false, bool LR = false>
+// GE16 (B16 + LR instances, a separate one so that the usual instance carries none of it: with the branch inside, the cfg 5 bfloat16 walk went
+// from 138 to 150 us): g_edge_embed rows are bfloat16, rounded where they are stored
+template <int VEC, int KR, int HT, bool B16 = false, bool LR = false, bool GE16 = false>
 __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >= 4 || KR * HT >= 8 && KR >= 2) ? 2 : kK2WavesPerSimd)) k_gat_atp_bwd(const AtpBwdK p) {
     static_assert(!LR || (VEC == 4 && KR == 1), "LDS row ring: rows of at most 1 KiB");
     extern __shared__ __attribute__((aligned(16))) float U[];          // [H][F + R]: u_dst | u_rel per head (u_src is k_gat_atp_src's business now)
@@ -1438,7 +1440,7 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                 }
                 // g_edge_embed rows go by slot (a table read through an index: the caller sums them per table row) or by edge id
                 const bool ge_edge = p.g_ee && !p.gee_by_slot;       // wave-uniform
-                const bool ge16 = B16 && p.gee_b16 && ge_edge;       // wave-uniform: bfloat16 rows of g_edge_embed (2 R bytes each)
+                constexpr bool ge16 = GE16;                           // bfloat16 rows of g_edge_embed (2 R bytes each): rows by edge id, one head group per wave (host)
                 const auto rGee = ge16 ? K2_RSRC(reinterpret_cast<uint16_t*>(p.g_ee) + static_cast<int64_t>(e) * R, Rb / 2)
                                        : (ge_edge ? K2_RSRC(p.g_ee + static_cast<int64_t>(e) * R, Rb) : rGe);
                 const uint32_t sox = static_cast<uint32_t>(j) * Fb, soe = ge_edge ? 0u : static_cast<uint32_t>(j) * Rb;
@@ -1455,8 +1457,8 @@ __global__ void __launch_bounds__(kBlock, (KR * HT >= 8 && KR >= 8) ? 1 : ((KR >
                         for (int v = 0; v < VEC; ++v) { ox[v] += o1[v]; orr[v] += o2[v]; }
                     }
                     buf_store_f32<VEC>(ox, rGx, voF[r], sox);       // lanes past F / R (and every lane without g_edge_embed): dropped by the range check
-                    if constexpr (B16) {
-                        if (ge16) {                                  // (one head group per wave here: nothing was added above) round to nearest even, 2 bytes per value
+                    if constexpr (GE16) {
+                        {                                            // (one head group per wave here: nothing was added above) round to nearest even, 2 bytes per value
                             uint32_t w2[VEC / 2];
 #pragma unroll
                             for (int v = 0; v < VEC; v += 2) {
@@ -2253,7 +2255,10 @@ extern "C" int recon_gat_atp_fwd(const recon_graph* g, const recon_gat_atp_args*
 extern "C" int recon_gat_atp_bwd_gee_bf16_supported(int32_t F, int32_t R, int32_t D, int32_t H) {
     recon::AtpShape s;
     if (!recon_gat_atp_bf16_io_supported(F, R, D, H) || !recon::atp_shape(F, R, H, &s)) return 0;
-    return (s.ht >= H && s.vec == 4) ? 1 : 0;                        // one head group per wave: no read-modify-write of the stored rows
+    // one head group per wave (no read-modify-write of the stored rows), and the LDS-ring instance of the edge pass (the one built with the bfloat16 store)
+    const size_t lds_k2 = static_cast<size_t>(H) * (F + R) * sizeof(float) + (kBlock / 64) * 512;
+    const bool lring = s.vec == 4 && s.kr == 1 && lds_k2 + (kBlock / 64) * kK2LdsRingBytes <= 64 * 1024 && cfg_char(CFG_K2_LDS_RING) != '0';
+    return (s.ht >= H && lring) ? 1 : 0;
 }
 
 extern "C" size_t recon_gat_atp_bwd_split_bytes(int32_t N, int32_t D, int32_t H) {
@@ -2367,7 +2372,7 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         p.rowptr = rw.rowptr; p.row_node = rw.row_node; p.src = g->src; p.eid = a->ee_index ? a->ee_index : g->eid;
         p.gee_by_slot = a->ee_index ? 1 : 0;
         p.gee_b16 = b->g_ee_bf16 ? 1 : 0;
-        if (b->g_ee_bf16 && !(a->io_bf16 && !a->ee_index && recon_gat_atp_bwd_gee_bf16_supported(F, R, D, H))) return RECON_ERR_UNSUPPORTED;
+        if (b->g_ee_bf16 && !(a->io_bf16 && !a->ee_index && b->g_edge_embed && recon_gat_atp_bwd_gee_bf16_supported(F, R, D, H))) return RECON_ERR_UNSUPPORTED;
         p.x = a->x; p.ee = a->edge_embed; p.keep = a->keep; p.sigma = a->sigma; p.Z = a->Z; p.Zk = a->Zk;
         p.q = b->q; p.gV = b->g_V; p.u = a->u;
         p.gsigma = b->g_sigma; p.Gs_dst = b->Gs; p.Gxs = b->Gxs; p.gxd = b->gxd; p.g_ee = b->g_edge_embed;
@@ -2383,7 +2388,8 @@ extern "C" int recon_gat_atp_bwd_phase(const recon_graph* g, const recon_gat_atp
         const bool lring = s.vec == 4 && s.kr == 1 && lds_k2 + (kBlock / 64) * kK2LdsRingBytes <= 64 * 1024 && cfg_char(CFG_K2_LDS_RING) != '0';
         const size_t lds_run = lds_k2 + (lring ? (kBlock / 64) * kK2LdsRingBytes : 0);
 #define CALL_BWD(V_, K_, H_) do { constexpr bool LRC = V_ == 4 && K_ == 1;                                                                   \
-                                  if (V_ == 4 && a->io_bf16) { if (LRC && lring) hipLaunchKernelGGL((k_gat_atp_bwd<4, K_, H_, true, LRC>), grid, dim3(kBlock), lds_run, st, p); \
+                                  if (V_ == 4 && a->io_bf16) { if (LRC && lring && p.gee_b16) hipLaunchKernelGGL((k_gat_atp_bwd<4, K_, H_, true, LRC, LRC>), grid, dim3(kBlock), lds_run, st, p); \
+                                                               else if (LRC && lring) hipLaunchKernelGGL((k_gat_atp_bwd<4, K_, H_, true, LRC>), grid, dim3(kBlock), lds_run, st, p); \
                                                                else hipLaunchKernelGGL((k_gat_atp_bwd<4, K_, H_, true>), grid, dim3(kBlock), lds_run, st, p); }          \
                                   else if (LRC && lring) hipLaunchKernelGGL((k_gat_atp_bwd<V_, K_, H_, false, LRC>), grid, dim3(kBlock), lds_run, st, p);              \
                                   else hipLaunchKernelGGL((k_gat_atp_bwd<V_, K_, H_>), grid, dim3(kBlock), lds_run, st, p); } while (0)
