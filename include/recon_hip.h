@@ -755,6 +755,11 @@ int recon_kg_adj_fill(const recon_kg* kg, const int64_t* entities, int32_t B, co
                       int64_t* edge_type, recon_stream_t stream);
 int recon_kg_nhop(const recon_kg* kg, const int64_t* sources, int32_t S, int32_t partial_2hop, int32_t write, int64_t* qcount, int64_t* quad_off,
                   int64_t* quads, int64_t* total, uint32_t* counter, recon_stream_t stream);
+/* recon_kg_nhop's count pass (write = 0) over a source list whose LENGTH is still on the device: sources has room for S_max ids, *s_dev of them are
+ * valid (the unique-entity list and its count as recon_kg_adj_count leaves them).  Queued behind recon_kg_adj_count, it lets the caller read the
+ * 1-hop sizes and the 2-hop total in one host round trip; the write pass is recon_kg_nhop(write = 1) with the count the host then knows. */
+int recon_kg_nhop_count_early(const recon_kg* kg, const int64_t* sources, int32_t S_max, const int64_t* s_dev, int32_t partial_2hop, int64_t* qcount,
+                              int64_t* quad_off, int64_t* total, recon_stream_t stream);
 /* Dead-row pruning of a batch graph for SpKBGATModified (GAT/models.py:167-178: the model keeps `mask * out_entity_1`, so an edge matters only
  * if its destination lies in need = mask U { src(e) : mask[dst(e)] != 0 }).  edge int64 [2][E1] (row 0 destinations) with type [E1], edge_nhop
  * [2][E2] with type_nhop [E2][2] (E2 = 0: none); mask float [N]; need: N bytes of scratch.  The surviving edges are written in their

@@ -237,6 +237,7 @@ SYMBOLS = [
     ("recon_kg_adj_count", C.c_int, [C.POINTER(ReconKG), c_i64p, C.c_int32, c_i64p, C.c_void_p, C.c_void_p, c_i64p, c_i64p, c_i64p, c_i64p, C.c_void_p, C.c_void_p]),
     ("recon_kg_adj_fill", C.c_int, [C.POINTER(ReconKG), c_i64p, C.c_int32, c_i64p, C.c_int64, c_i64p, c_i64p, C.c_void_p]),
     ("recon_kg_nhop", C.c_int, [C.POINTER(ReconKG), c_i64p, C.c_int32, C.c_int32, C.c_int32, c_i64p, c_i64p, c_i64p, c_i64p, C.c_void_p, C.c_void_p]),
+    ("recon_kg_nhop_count_early", C.c_int, [C.POINTER(ReconKG), c_i64p, C.c_int32, c_i64p, C.c_int32, c_i64p, c_i64p, c_i64p, C.c_void_p]),
     ("recon_rows_normalize_fwd", C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_f32p, c_f32p, C.c_void_p]),
     ("recon_rows_normalize_bwd", C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_f32p, c_f32p, C.c_void_p]),
     ("recon_gat_atp_bf16_io_supported", C.c_int, [C.c_int32] * 4),

@@ -144,9 +144,12 @@ __global__ void __launch_bounds__(256) k_kg_adj_fill(const KG g, const int64_t* 
 // target) from quad_off[b] on; k_kg_scan turns the counts into offsets.
 template <bool WRITE>
 __global__ void __launch_bounds__(64) k_kg_nhop(const KG g, const int64_t* __restrict__ srcs, int32_t S, int32_t partial, int64_t* __restrict__ qcount,
-                                                 const int64_t* __restrict__ quad_off, int64_t* __restrict__ quads) {
+                                                 const int64_t* __restrict__ quad_off, int64_t* __restrict__ quads, const int64_t* __restrict__ s_dev = nullptr) {
     extern __shared__ uint32_t seen[];
     const int lane = threadIdx.x, b = blockIdx.x;
+    // s_dev (count pass launched BEFORE the host knows how many sources there are — recon_kg_nhop_count_early): the grid covers the most there
+    // can be, the sources past the count on the device have none
+    if (s_dev && b >= *s_dev) { if (lane == 0) qcount[b] = 0; return; }
     const int words = static_cast<int>((g.Ne + 63) >> 6) * 2;          // a multiple of two: the parent tables behind it stay 8-byte aligned
     const int64_t s = srcs[b], p0 = g.pair_ptr[s], p1 = g.pair_ptr[s + 1];
     for (int i = lane; i < words; i += 64) seen[i] = 0u;
@@ -266,10 +269,12 @@ __global__ void __launch_bounds__(64) k_kg_nhop(const KG g, const int64_t* __res
 constexpr int kNhopWaves = 4;
 template <bool WRITE>
 __global__ void __launch_bounds__(64 * kNhopWaves) k_kg_nhop_wg(const KG g, const int64_t* __restrict__ srcs, int32_t S, int32_t partial,
-                                                                 int64_t* __restrict__ qcount, const int64_t* __restrict__ quad_off, int64_t* __restrict__ quads) {
+                                                                 int64_t* __restrict__ qcount, const int64_t* __restrict__ quad_off, int64_t* __restrict__ quads,
+                                                                 const int64_t* __restrict__ s_dev = nullptr) {
     extern __shared__ uint32_t seen[];
     constexpr int NTH = 64 * kNhopWaves;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, b = blockIdx.x;
+    if (s_dev && b >= *s_dev) { if (t == 0) qcount[b] = 0; return; }  // (see k_kg_nhop)
     const int words = static_cast<int>((g.Ne + 63) >> 6) * 2;
     const int ne2 = static_cast<int>((g.Ne + 1) & ~1LL);               // own[] padded to an even count: the tables behind it stay 8-byte aligned
     uint32_t* own = seen + words;
@@ -580,6 +585,30 @@ extern "C" int recon_kg_nhop(const recon_kg* kg, const int64_t* sources, int32_t
                            qcount, quad_off, quads);
         hipLaunchKernelGGL(recon::k_kg_scan, dim3(1), dim3(64), 0, as_stream(stream), qcount, S, quad_off, total);
     }
+    RECON_CHECK_LAUNCH();
+    return RECON_OK;
+}
+
+// The count pass of recon_kg_nhop for sources whose NUMBER is still on the device (the unique-entity list recon_kg_adj_count has just written: up to
+// S_max entries, *s_dev of them valid): launched behind it, so that the host reads the 1-hop sizes and the 2-hop total in ONE round trip.
+extern "C" int recon_kg_nhop_count_early(const recon_kg* kg, const int64_t* sources, int32_t S_max, const int64_t* s_dev, int32_t partial_2hop, int64_t* qcount,
+                                         int64_t* quad_off, int64_t* total, recon_stream_t stream) {
+    if (!recon::kg_ok(kg) || S_max <= 0 || !sources || !s_dev || !qcount || !quad_off || !total) return RECON_ERR_INVALID;
+    const size_t lds_wg = nhop_wg_lds_bytes(kg->num_entities);
+    if (lds_wg <= 72 * 1024 && recon::cfg_char(recon::CFG_KG_NHOP) != 'w') {
+        const void* kw = reinterpret_cast<const void*>(recon::k_kg_nhop_wg<false>);
+        if (lds_wg > 48 * 1024 && hipFuncSetAttribute(kw, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_wg)) != hipSuccess) return RECON_ERR_LAUNCH;
+        hipLaunchKernelGGL(recon::k_kg_nhop_wg<false>, dim3(static_cast<unsigned>(S_max)), dim3(64 * recon::kNhopWaves), lds_wg, as_stream(stream), recon::kg_of(kg), sources,
+                           S_max, partial_2hop, qcount, quad_off, static_cast<int64_t*>(nullptr), s_dev);
+    } else {
+        const size_t lds = recon_kg_nhop_lds_bytes(kg->num_entities);
+        if (lds > 160 * 1024 - 64) return RECON_ERR_UNSUPPORTED;
+        const void* kern = reinterpret_cast<const void*>(recon::k_kg_nhop<false>);
+        if (lds > 48 * 1024 && hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return RECON_ERR_LAUNCH;
+        hipLaunchKernelGGL(recon::k_kg_nhop<false>, dim3(static_cast<unsigned>(S_max)), dim3(64), lds, as_stream(stream), recon::kg_of(kg), sources, S_max, partial_2hop,
+                           qcount, quad_off, static_cast<int64_t*>(nullptr), s_dev);
+    }
+    hipLaunchKernelGGL(recon::k_kg_scan, dim3(1), dim3(64), 0, as_stream(stream), qcount, S_max, quad_off, total);
     RECON_CHECK_LAUNCH();
     return RECON_OK;
 }
